@@ -1,0 +1,361 @@
+// oracle_align.cpp -- CPU ORACLE (test infrastructure): restatement of ygz::SparseImgAlign
+// (reference src/SparseImageAlign.cc, include/SparseImageAlign.h:90-111), of the Gauss-Newton driver it inherits
+// (include/NLSSolver_impl.hpp:17-91, reset :288-298) and of the Sophus SE3f operations it uses
+// (Thirdparty/sophus/sophus/se3.hpp:159-171,267-271,406-428, so3.hpp:234-237,268-276,425-456).
+// Eigen is not available: small fixed-size products are written out in natural (row, left-to-right) order and
+// H.ldlt().solve(b) is a pivoted LDL^T in float.  fp32 throughout; the HIP path is graded at 1e-5 on the SE3
+// output, not bit-exact.  PARITY UNPINNED (no reference test).  Built with -ffp-contract=off.
+#include <cmath>
+#include <cstring>
+
+#include "ygz_oracle.h"
+
+namespace ygzo {
+
+static const float kSophusEps = 1e-5f;  // SophusConstants<float>::epsilon()
+
+static inline void quat_mul(const float a[4], const float b[4], float o[4]) {  // Eigen quat product, (x,y,z,w)
+    float r[4];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    std::memcpy(o, r, sizeof(r));
+}
+static inline void quat_normalize(float q[4]) {  // so3.hpp:268-276
+    float n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= n;
+}
+static inline void quat_rotate(const float q[4], const float v[3], float o[3]) {  // Eigen _transformVector
+    float uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    for (int i = 0; i < 3; i++) uv[i] += uv[i];
+    float c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+    for (int i = 0; i < 3; i++) o[i] = v[i] + q[3] * uv[i] + c[i];
+}
+
+void SE3f::RotationMatrix(float R[9]) const {  // Eigen toRotationMatrix
+    const float tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const float twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const float txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const float tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+void SE3f::Act(const float p[3], float out[3]) const {
+    float r[3];
+    quat_rotate(q, p, r);
+    for (int i = 0; i < 3; i++) out[i] = r[i] + t[i];
+}
+
+SE3f SE3f::Inverse() const {  // se3.hpp:168-172
+    SE3f o;
+    o.q[0] = -q[0]; o.q[1] = -q[1]; o.q[2] = -q[2]; o.q[3] = q[3];
+    quat_normalize(o.q);  // SO3Group(Quaternion) ctor normalises
+    float nt[3] = {t[0] * -1.f, t[1] * -1.f, t[2] * -1.f};
+    quat_rotate(o.q, nt, o.t);
+    return o;
+}
+
+SE3f SE3f::Mul(const SE3f &other) const {  // operator*: fastMultiply (se3.hpp:159-163) + normalize
+    SE3f r = *this;
+    float rt[3];
+    quat_rotate(r.q, other.t, rt);
+    for (int i = 0; i < 3; i++) r.t[i] += rt[i];
+    quat_mul(r.q, other.q, r.q);
+    quat_normalize(r.q);
+    return r;
+}
+
+SE3f SE3f::Exp(const float a[6]) {  // se3.hpp:406-428
+    const float *omega = a + 3;
+    const float theta_sq = omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2];
+    const float theta = std::sqrt(theta_sq);
+    const float half_theta = 0.5f * theta;
+    float imag_factor, real_factor;
+    if (theta < kSophusEps) {  // so3.hpp:434-444
+        const float theta_po4 = theta_sq * theta_sq;
+        imag_factor = 0.5f - (float) (1.0 / 48.0) * theta_sq + (float) (1.0 / 3840.0) * theta_po4;
+        real_factor = 1.f - 0.5f * theta_sq + (float) (1.0 / 384.0) * theta_po4;
+    } else {
+        const float sin_half_theta = std::sin(half_theta);
+        imag_factor = sin_half_theta / theta;
+        real_factor = std::cos(half_theta);
+    }
+    SE3f r;
+    r.q[3] = real_factor;
+    r.q[0] = imag_factor * omega[0];
+    r.q[1] = imag_factor * omega[1];
+    r.q[2] = imag_factor * omega[2];
+    quat_normalize(r.q);
+    // Omega = hat(omega), V = I + (1-cos)/theta^2 Omega + (theta-sin)/theta^3 Omega^2
+    const float O[9] = {0, -omega[2], omega[1], omega[2], 0, -omega[0], -omega[1], omega[0], 0};
+    float O2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    float V[9];
+    if (theta < kSophusEps) {
+        r.RotationMatrix(V);
+    } else {
+        const float c1 = (1.f - std::cos(theta)) / theta_sq;
+        const float c2 = (theta - std::sin(theta)) / (theta_sq * theta);
+        for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * O[i] + c2 * O2[i];
+    }
+    for (int i = 0; i < 3; i++) r.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
+    return r;
+}
+
+SE3f SE3f::FromRt(const float R[9], const float t_[3]) {  // Eigen Quaternion(Matrix3) + normalise
+    SE3f o;
+    float tr = R[0] + R[4] + R[8];
+    if (tr > 0) {
+        float s = std::sqrt(tr + 1.f);
+        o.q[3] = 0.5f * s;
+        s = 0.5f / s;
+        o.q[0] = (R[7] - R[5]) * s;
+        o.q[1] = (R[2] - R[6]) * s;
+        o.q[2] = (R[3] - R[1]) * s;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        float s = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.f);
+        o.q[i] = 0.5f * s;
+        s = 0.5f / s;
+        o.q[3] = (R[3 * k + j] - R[3 * j + k]) * s;
+        o.q[j] = (R[3 * j + i] + R[3 * i + j]) * s;
+        o.q[k] = (R[3 * k + i] + R[3 * i + k]) * s;
+    }
+    quat_normalize(o.q);
+    for (int i = 0; i < 3; i++) o.t[i] = t_[i];
+    return o;
+}
+
+// x = H.ldlt().solve(b): LDL^T with diagonal pivoting (Eigen's LDLT picks the largest |diagonal|), float.
+static bool ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+    float A[36];
+    float b[6];
+    int perm[6];
+    std::memcpy(A, Hin, sizeof(A));
+    std::memcpy(b, bin, sizeof(b));
+    for (int i = 0; i < 6; i++) perm[i] = i;
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        float best = std::fabs(A[7 * k]);
+        for (int i = k + 1; i < 6; i++)
+            if (std::fabs(A[7 * i]) > best) { best = std::fabs(A[7 * i]); p = i; }
+        if (p != k) {
+            for (int j = 0; j < 6; j++) std::swap(A[6 * k + j], A[6 * p + j]);
+            for (int j = 0; j < 6; j++) std::swap(A[6 * j + k], A[6 * j + p]);
+            std::swap(b[k], b[p]);
+            std::swap(perm[k], perm[p]);
+        }
+        const float d = A[7 * k];
+        for (int i = k + 1; i < 6; i++) {
+            const float l = A[6 * i + k] / d;
+            for (int j = k + 1; j < 6; j++) A[6 * i + j] -= l * A[6 * k + j];
+            A[6 * i + k] = l;
+        }
+    }
+    float y[6];
+    for (int i = 0; i < 6; i++) {  // L y = b
+        float s = b[i];
+        for (int j = 0; j < i; j++) s -= A[6 * i + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < 6; i++) y[i] = y[i] / A[7 * i];  // D z = y
+    float z[6];
+    for (int i = 5; i >= 0; i--) {  // L^T w = z
+        float s = y[i];
+        for (int j = i + 1; j < 6; j++) s -= A[6 * j + i] * z[j];
+        z[i] = s;
+    }
+    for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
+    return true;
+}
+
+namespace {
+struct Aligner {
+    static const int patch_halfsize_ = 2, patch_size_ = 4, patch_area_ = 16;
+    const AlignFrame &ref, &cur;
+    int level_ = 0;
+    std::vector<float> ref_patch_cache_;  // N x 16
+    std::vector<float> jacobian_cache_;   // (N*16) x 6, column j of the reference's 6 x (N*16) matrix
+    std::vector<uint8_t> visible_fts_;
+    bool have_ref_patch_cache_ = false;
+    float H_[36], Jres_[6], x_[6];
+    float chi2_ = 1e10f;
+    size_t n_meas_ = 0;
+    int n_iter_ = 10, iter_ = 0;
+    bool stop_ = false;
+    float eps_ = 0.000001f;
+    int iters_total = 0;
+
+    Aligner(const AlignFrame &r, const AlignFrame &c) : ref(r), cur(c) {}
+
+    // SparseImageAlign.h:90-111
+    static void JacobXYZ2Cam(const float xyz[3], float J[12]) {
+        const float x = xyz[0], y = xyz[1];
+        const float z_inv = (float) (1. / xyz[2]);
+        const float z_inv_2 = z_inv * z_inv;
+        J[0] = -z_inv;
+        J[1] = 0.0f;
+        J[2] = x * z_inv_2;
+        J[3] = y * J[2];
+        J[4] = (float) -(1.0 + x * J[2]);
+        J[5] = y * z_inv;
+        J[6] = 0.0f;
+        J[7] = -z_inv;
+        J[8] = y * z_inv_2;
+        J[9] = (float) (1.0 + y * J[8]);
+        J[10] = -J[3];
+        J[11] = -x * z_inv;
+    }
+
+    // src/SparseImageAlign.cc:57-128
+    void precomputeReferencePatches() {
+        const int border = patch_halfsize_ + 1;
+        const Image &ref_img = *ref.pyramid[level_];
+        const int stride = ref_img.w;
+        const float scale = ref.invScaleFactors[level_];
+        const float focal_length = ref.fx;
+        for (int i = 0; i < ref.N; i++) {
+            if (!ref.mp_valid[i] || ref.outlier[i]) continue;
+            const KeyPoint &kp = ref.keys[i];
+            const float u_ref = kp.x * scale, v_ref = kp.y * scale;
+            const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
+            if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= ref_img.w ||
+                v_ref_i + border >= ref_img.h)
+                continue;
+            visible_fts_[i] = 1;
+            float xyz_ref[3];
+            ref.Tcw.Act(&ref.mp_world[3 * i], xyz_ref);
+            float frame_jac[12];
+            JacobXYZ2Cam(xyz_ref, frame_jac);
+            const float subpix_u_ref = u_ref - u_ref_i, subpix_v_ref = v_ref - v_ref_i;
+            const float w_ref_tl = (float) ((1.0 - subpix_u_ref) * (1.0 - subpix_v_ref));
+            const float w_ref_tr = (float) (subpix_u_ref * (1.0 - subpix_v_ref));
+            const float w_ref_bl = (float) ((1.0 - subpix_u_ref) * subpix_v_ref);
+            const float w_ref_br = subpix_u_ref * subpix_v_ref;
+            size_t pixel_counter = 0;
+            float *cache_ptr = &ref_patch_cache_[(size_t) patch_area_ * i];
+            for (int y = 0; y < patch_size_; ++y) {
+                const uint8_t *p = &ref_img.d[(size_t) (v_ref_i + y - patch_halfsize_) * stride + (u_ref_i - patch_halfsize_)];
+                for (int x = 0; x < patch_size_; ++x, ++p, ++cache_ptr, ++pixel_counter) {
+                    *cache_ptr = w_ref_tl * p[0] + w_ref_tr * p[1] + w_ref_bl * p[stride] + w_ref_br * p[stride + 1];
+                    float dx = 0.5f * ((w_ref_tl * p[1] + w_ref_tr * p[2] + w_ref_bl * p[stride + 1] + w_ref_br * p[stride + 2]) -
+                                       (w_ref_tl * p[-1] + w_ref_tr * p[0] + w_ref_bl * p[stride - 1] + w_ref_br * p[stride]));
+                    float dy = 0.5f * ((w_ref_tl * p[stride] + w_ref_tr * p[1 + stride] + w_ref_bl * p[stride * 2] +
+                                        w_ref_br * p[stride * 2 + 1]) -
+                                       (w_ref_tl * p[-stride] + w_ref_tr * p[1 - stride] + w_ref_bl * p[0] + w_ref_br * p[1]));
+                    float *J = &jacobian_cache_[((size_t) i * patch_area_ + pixel_counter) * 6];
+                    for (int k = 0; k < 6; k++) J[k] = (dx * frame_jac[k] + dy * frame_jac[6 + k]) * (focal_length * scale);
+                }
+            }
+        }
+        have_ref_patch_cache_ = true;
+    }
+
+    // :130-231 (use_weights_ == false, display_ == false in the reference's only call site)
+    float computeResiduals(const SE3f &T_cur_from_ref, bool linearize_system) {
+        const Image &cur_img = *cur.pyramid[level_];
+        if (!have_ref_patch_cache_) precomputeReferencePatches();
+        const int stride = cur_img.w;
+        const int border = patch_halfsize_ + 1;
+        const float scale = ref.invScaleFactors[level_];
+        float chi2 = 0.0;
+        for (int i = 0; i < ref.N; i++) {
+            if (!visible_fts_[i]) continue;
+            float xyz_ref[3], xyz_cur[3];
+            ref.Tcw.Act(&ref.mp_world[3 * i], xyz_ref);
+            T_cur_from_ref.Act(xyz_ref, xyz_cur);
+            const float ucx = cur.fx * xyz_cur[0] / xyz_cur[2] + cur.cx;  // Frame::Camera2Pixel (Frame.h:154-159)
+            const float ucy = cur.fy * xyz_cur[1] / xyz_cur[2] + cur.cy;
+            const float u_cur = ucx * scale, v_cur = ucy * scale;
+            const int u_cur_i = (int) floorf(u_cur), v_cur_i = (int) floorf(v_cur);
+            if (u_cur_i < 0 || v_cur_i < 0 || u_cur_i - border < 0 || v_cur_i - border < 0 ||
+                u_cur_i + border >= cur_img.w || v_cur_i + border >= cur_img.h)
+                continue;
+            const float subpix_u_cur = u_cur - u_cur_i, subpix_v_cur = v_cur - v_cur_i;
+            const float w_cur_tl = (float) ((1.0 - subpix_u_cur) * (1.0 - subpix_v_cur));
+            const float w_cur_tr = (float) (subpix_u_cur * (1.0 - subpix_v_cur));
+            const float w_cur_bl = (float) ((1.0 - subpix_u_cur) * subpix_v_cur);
+            const float w_cur_br = subpix_u_cur * subpix_v_cur;
+            const float *ref_patch_cache_ptr = &ref_patch_cache_[(size_t) patch_area_ * i];
+            size_t pixel_counter = 0;
+            for (int y = 0; y < patch_size_; ++y) {
+                const uint8_t *p = &cur_img.d[(size_t) (v_cur_i + y - patch_halfsize_) * stride + (u_cur_i - patch_halfsize_)];
+                for (int x = 0; x < patch_size_; ++x, ++pixel_counter, ++p, ++ref_patch_cache_ptr) {
+                    const float intensity_cur = w_cur_tl * p[0] + w_cur_tr * p[1] + w_cur_bl * p[stride] + w_cur_br * p[stride + 1];
+                    const float res = intensity_cur - (*ref_patch_cache_ptr);
+                    const float weight = 1.0;
+                    chi2 += res * res * weight;
+                    n_meas_++;
+                    if (linearize_system) {
+                        const float *J = &jacobian_cache_[((size_t) i * patch_area_ + pixel_counter) * 6];
+                        for (int r = 0; r < 6; r++)
+                            for (int c = 0; c < 6; c++) H_[6 * r + c] += J[r] * J[c] * weight;
+                        for (int r = 0; r < 6; r++) Jres_[r] -= J[r] * res * weight;
+                    }
+                }
+            }
+        }
+        return chi2 / n_meas_;
+    }
+
+    // NLSSolver_impl.hpp:17-91
+    void optimizeGaussNewton(SE3f &model) {
+        SE3f old_model = model;
+        for (iter_ = 0; iter_ < n_iter_; ++iter_) {
+            std::memset(H_, 0, sizeof(H_));
+            std::memset(Jres_, 0, sizeof(Jres_));
+            n_meas_ = 0;
+            float new_chi2 = computeResiduals(model, true);
+            iters_total++;
+            ldlt_solve6(H_, Jres_, x_);            // solve(): x_ = H_.ldlt().solve(Jres_)
+            if (std::isnan(x_[0])) stop_ = true;   // :235-236 -> "Matrix is close to singular"
+            if ((iter_ > 0 && new_chi2 > 1.2 * chi2_) || stop_) {
+                model = old_model;
+                break;
+            }
+            float negx[6];
+            for (int k = 0; k < 6; k++) negx[k] = -x_[k];
+            SE3f new_model = model.Mul(SE3f::Exp(negx));  // update(): T_new = T_old * exp(-x)
+            old_model = model;
+            model = new_model;
+            chi2_ = new_chi2;
+            float nm = 0;
+            for (int k = 0; k < 6; k++) nm = std::max(nm, std::fabs(x_[k]));
+            if (nm <= eps_) break;
+        }
+    }
+};
+}  // namespace
+
+AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level, int n_iter) {
+    AlignResult out;
+    std::memset(out.H, 0, sizeof(out.H));
+    if (ref.N == 0) return out;  // :24-27
+    Aligner A(ref, cur);
+    A.ref_patch_cache_.assign((size_t) ref.N * 16, 0.f);
+    A.jacobian_cache_.assign((size_t) ref.N * 16 * 6, 0.f);
+    A.visible_fts_.assign(ref.N, 0);
+    SE3f T_cur_from_ref = cur.Tcw.Mul(ref.Tcw.Inverse());
+    for (int level = max_level; level >= min_level; level -= 1) {
+        A.level_ = level;
+        std::fill(A.jacobian_cache_.begin(), A.jacobian_cache_.end(), 0.f);
+        A.have_ref_patch_cache_ = false;
+        A.n_iter_ = n_iter;  // reference indexes iterations[level_] = 10 (OOB for level >= 6; defined as n_iter)
+        A.optimizeGaussNewton(T_cur_from_ref);
+    }
+    out.TCR = T_cur_from_ref;
+    out.ret = A.n_meas_ / 16;
+    out.iters_total = A.iters_total;
+    out.chi2 = A.chi2_;
+    std::memcpy(out.H, A.H_, sizeof(out.H));
+    return out;
+}
+
+}  // namespace ygzo

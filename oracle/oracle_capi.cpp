@@ -1,0 +1,367 @@
+// oracle_capi.cpp -- CPU ORACLE (test infrastructure): flat C entry points so that tests/, bench.py's cpu_baseline
+// leg and __graft_entry__.smoke() can drive the oracle through ctypes.  Nothing in the product links this.
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#include "ygz_oracle.h"
+
+using namespace ygzo;
+
+extern "C" {
+
+void *yo_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+    return new Extractor(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+}
+void yo_extractor_destroy(void *e) { delete (Extractor *) e; }
+
+void yo_extractor_tables(void *e_, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat, int *umax16) {
+    Extractor *e = (Extractor *) e_;
+    for (int i = 0; i < e->nlevels; i++) {
+        scale[i] = e->mvScaleFactor[i];
+        inv_scale[i] = e->mvInvScaleFactor[i];
+        sigma2[i] = e->mvLevelSigma2[i];
+        inv_sigma2[i] = e->mvInvLevelSigma2[i];
+        nfeat[i] = e->mnFeaturesPerLevel[i];
+    }
+    for (int i = 0; i < 16; i++) umax16[i] = e->umax[i];
+}
+
+void yo_level_size(void *e, int w, int h, int level, int *lw, int *lh) { ((Extractor *) e)->LevelSize(w, h, level, lw, lh); }
+
+void yo_pyramid(void *e, const uint8_t *img, int w, int h, int stride) { ((Extractor *) e)->ComputePyramid(img, w, h, stride); }
+
+void yo_get_level(void *e_, int level, uint8_t *out) {
+    Extractor *e = (Extractor *) e_;
+    const Image &im = e->mvImagePyramid[level];
+    std::memcpy(out, im.d.data(), im.d.size());
+}
+
+// FAST candidates of one pyramid level (after yo_pyramid): region coordinates, cell-major order.
+int yo_cell_candidates(void *e_, int level, int *xs, int *ys, int *scores, int cap) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<KeyPoint> v;
+    e->CellCandidates(level, v);
+    int n = (int) v.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        xs[i] = (int) v[i].x;
+        ys[i] = (int) v[i].y;
+        scores[i] = (int) v[i].response;
+    }
+    return n;
+}
+
+// DistributeOctTree on an explicit candidate list; returns number kept, out_idx = index into the input list.
+int yo_octree(void *e_, const int *xs, const int *ys, const int *resp, int n, int minX, int maxX, int minY, int maxY,
+              int N, int *out_idx, int cap) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<KeyPoint> v(n);
+    for (int i = 0; i < n; i++) {
+        v[i].x = (float) xs[i];
+        v[i].y = (float) ys[i];
+        v[i].response = (float) resp[i];
+        v[i].class_id = i;
+        v[i].size = 7;
+        v[i].angle = -1;
+        v[i].octave = 0;
+    }
+    std::vector<KeyPoint> r = e->DistributeOctTree(v, minX, maxX, minY, maxY, N);
+    for (size_t i = 0; i < r.size() && (int) i < cap; i++) out_idx[i] = r[i].class_id;
+    return (int) r.size();
+}
+
+int yo_extract(void *e_, const uint8_t *img, int w, int h, int stride, KeyPoint *kps, int cap, uint8_t *desc) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<KeyPoint> k;
+    std::vector<uint8_t> d;
+    e->Extract(img, w, h, stride, k, d);
+    int n = (int) k.size();
+    if (n > cap) return -n;
+    std::memcpy(kps, k.data(), sizeof(KeyPoint) * n);
+    std::memcpy(desc, d.data(), 32 * (size_t) n);
+    return n;
+}
+
+// Keypoints of one level before scaling (level coordinates), with angle -- used to test the device stages one by one.
+int yo_level_keypoints(void *e_, int level, KeyPoint *kps, int cap) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<std::vector<KeyPoint>> all;
+    e->ComputeKeyPointsOctTree(all);
+    int n = (int) all[level].size();
+    for (int i = 0; i < n && i < cap; i++) kps[i] = all[level][i];
+    return n;
+}
+
+float yo_ic_angle(void *e_, const uint8_t *img, int w, int h, float x, float y) {
+    Extractor *e = (Extractor *) e_;
+    Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t) w * h);
+    return e->ICAngle(im, x, y);
+}
+
+void yo_descriptor(void *e_, const uint8_t *blurred, int w, int h, float x, float y, float angle, uint8_t *desc) {
+    Extractor *e = (Extractor *) e_;
+    Image im(w, h);
+    std::memcpy(im.d.data(), blurred, (size_t) w * h);
+    KeyPoint kp{x, y, 31, angle, 0, 0, -1};
+    e->ComputeDescriptor(kp, im, desc);
+}
+
+void yo_blur(const uint8_t *src, int w, int h, uint8_t *dst) {
+    Image s(w, h), d;
+    std::memcpy(s.d.data(), src, (size_t) w * h);
+    gaussian_blur7_s2_u8(s, d);
+    std::memcpy(dst, d.d.data(), (size_t) w * h);
+}
+
+void yo_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh) {
+    Image s(sw, sh), d(dw, dh);
+    std::memcpy(s.d.data(), src, (size_t) sw * sh);
+    resize_linear_u8(s, d);
+    std::memcpy(dst, d.d.data(), (size_t) dw * dh);
+}
+
+float yo_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+void yo_sincos_deg(float a, float *c, float *s) { sincos_deg(a, c, s); }
+int yo_cv_round(double v) { return cv_round(v); }
+
+int yo_fast9(const uint8_t *img, int stride, int w, int h, int threshold, int nonmax, int *xs, int *ys, int *scores, int cap) {
+    std::vector<FastPt> v;
+    fast9(img, stride, w, h, threshold, nonmax != 0, v);
+    for (size_t i = 0; i < v.size() && (int) i < cap; i++) {
+        xs[i] = v[i].x;
+        ys[i] = v[i].y;
+        scores[i] = v[i].score;
+    }
+    return (int) v.size();
+}
+
+int yo_hamming(const uint8_t *a, const uint8_t *b) { return descriptor_distance(a, b); }
+
+// ---- matcher ------------------------------------------------------------------------------------------------
+struct yo_frame {  // POD mirror of FrameView for ctypes
+    int N;
+    const KeyPoint *keys;
+    const uint8_t *desc;
+    const float *uRight;
+    float minX, minY, maxX, maxY;
+    float fx, fy, cx, cy, mb, mbf;
+    const float *scaleFactors;
+    int nlevels;
+};
+static FrameView to_view(const yo_frame *f) {
+    FrameView v;
+    v.N = f->N;
+    v.keys = f->keys;
+    v.desc = f->desc;
+    v.uRight = f->uRight;
+    v.minX = f->minX; v.minY = f->minY; v.maxX = f->maxX; v.maxY = f->maxY;
+    v.gridInvW = (float) Grid::COLS / (f->maxX - f->minX);  // src/Frame.cc:302-303
+    v.gridInvH = (float) Grid::ROWS / (f->maxY - f->minY);
+    v.fx = f->fx; v.fy = f->fy; v.cx = f->cx; v.cy = f->cy; v.mb = f->mb; v.mbf = f->mbf;
+    v.scaleFactors = f->scaleFactors;
+    v.nlevels = f->nlevels;
+    return v;
+}
+
+int yo_features_in_area(const yo_frame *f, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap) {
+    FrameView v = to_view(f);
+    Grid g;
+    g.Assign(v);
+    std::vector<int> idx;
+    g.FeaturesInArea(v, x, y, r, minLevel, maxLevel, idx);
+    for (size_t i = 0; i < idx.size() && (int) i < cap; i++) out[i] = idx[i];
+    return (int) idx.size();
+}
+
+int yo_search_by_projection_last(const yo_frame *cur, int lastN, const KeyPoint *last_keys, const uint8_t *mp_valid,
+                                 const uint8_t *outlier, const uint8_t *mp_has_obs, const float *mp_world,
+                                 const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw,
+                                 const float *tlw, float th, int bMono, int checkLevel, int checkOri, uint8_t *cur_owner,
+                                 int *cur_match) {
+    FrameView v = to_view(cur);
+    Grid g;
+    g.Assign(v);
+    ProjLastInput in;
+    in.N = lastN;
+    in.keys = last_keys;
+    in.mp_valid = mp_valid;
+    in.outlier = outlier;
+    in.mp_has_obs = mp_has_obs;
+    in.mp_world = mp_world;
+    in.mp_desc = mp_desc;
+    std::memcpy(in.Rcw, Rcw, 36);
+    std::memcpy(in.tcw, tcw, 12);
+    std::memcpy(in.Rlw, Rlw, 36);
+    std::memcpy(in.tlw, tlw, 12);
+    return search_by_projection_last(v, g, in, th, bMono != 0, checkLevel != 0, checkOri != 0, cur_owner, cur_match);
+}
+
+int yo_search_by_projection_mappoints(const yo_frame *F, int M, const uint8_t *track_in_view, const uint8_t *bad,
+                                      const uint8_t *mp_has_obs, const float *projX, const float *projY,
+                                      const float *projXR, const float *viewCos, const int *scaleLevel,
+                                      const uint8_t *mp_desc, float th, int checkLevel, float nnratio, uint8_t *owner,
+                                      int *match) {
+    FrameView v = to_view(F);
+    Grid g;
+    g.Assign(v);
+    ProjMapPointsInput in;
+    in.M = M;
+    in.track_in_view = track_in_view;
+    in.bad = bad;
+    in.mp_has_obs = mp_has_obs;
+    in.projX = projX;
+    in.projY = projY;
+    in.projXR = projXR;
+    in.viewCos = viewCos;
+    in.scaleLevel = scaleLevel;
+    in.mp_desc = mp_desc;
+    return search_by_projection_mappoints(v, g, in, th, checkLevel != 0, nnratio, owner, match);
+}
+
+int yo_search_for_initialization(const yo_frame *F1, const yo_frame *F2, float *prevMatchedXY, int windowSize,
+                                 float nnratio, int checkOri, int *matches12) {
+    FrameView v1 = to_view(F1), v2 = to_view(F2);
+    Grid g;
+    g.Assign(v2);
+    return search_for_initialization(v1, v2, g, prevMatchedXY, windowSize, nnratio, checkOri != 0, matches12);
+}
+
+// ---- SE3 / aligner ------------------------------------------------------------------------------------------
+void yo_se3_exp(const float a[6], float out7[7]) {
+    SE3f r = SE3f::Exp(a);
+    std::memcpy(out7, r.q, 16);
+    std::memcpy(out7 + 4, r.t, 12);
+}
+void yo_se3_mul(const float a7[7], const float b7[7], float out7[7]) {
+    SE3f a, b;
+    std::memcpy(a.q, a7, 16); std::memcpy(a.t, a7 + 4, 12);
+    std::memcpy(b.q, b7, 16); std::memcpy(b.t, b7 + 4, 12);
+    SE3f r = a.Mul(b);
+    std::memcpy(out7, r.q, 16);
+    std::memcpy(out7 + 4, r.t, 12);
+}
+void yo_se3_inverse(const float a7[7], float out7[7]) {
+    SE3f a;
+    std::memcpy(a.q, a7, 16); std::memcpy(a.t, a7 + 4, 12);
+    SE3f r = a.Inverse();
+    std::memcpy(out7, r.q, 16);
+    std::memcpy(out7 + 4, r.t, 12);
+}
+
+struct yo_align_frame {
+    int N;
+    const KeyPoint *keys;
+    const uint8_t *mp_valid, *outlier;
+    const float *mp_world;
+    float Tcw[7];               // qx qy qz qw tx ty tz
+    int nlevels;
+    const uint8_t *const *levels;  // tight u8 images
+    const int *level_w, *level_h;
+    const float *invScaleFactors;
+    float fx, fy, cx, cy;
+};
+
+// returns n_meas/16; out7 = TCR; info[0] = total linearisations, info[1] = chi2
+size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur, int max_level, int min_level, int n_iter,
+                           float out7[7], float info[2], float H36[36]) {
+    std::vector<Image> rimgs(ref->nlevels), cimgs(cur->nlevels);
+    AlignFrame R, C;
+    auto fill = [](const yo_align_frame *f, std::vector<Image> &imgs, AlignFrame &A) {
+        A.N = f->N;
+        A.keys = f->keys;
+        A.mp_valid = f->mp_valid;
+        A.outlier = f->outlier;
+        A.mp_world = f->mp_world;
+        std::memcpy(A.Tcw.q, f->Tcw, 16);
+        std::memcpy(A.Tcw.t, f->Tcw + 4, 12);
+        for (int l = 0; l < f->nlevels; l++) {
+            imgs[l] = Image(f->level_w[l], f->level_h[l]);
+            std::memcpy(imgs[l].d.data(), f->levels[l], imgs[l].d.size());
+            A.pyramid.push_back(&imgs[l]);
+        }
+        A.invScaleFactors = f->invScaleFactors;
+        A.fx = f->fx; A.fy = f->fy; A.cx = f->cx; A.cy = f->cy;
+    };
+    fill(ref, rimgs, R);
+    fill(cur, cimgs, C);
+    AlignResult r = sparse_img_align(R, C, max_level, min_level, n_iter);
+    std::memcpy(out7, r.TCR.q, 16);
+    std::memcpy(out7 + 4, r.TCR.t, 12);
+    if (info) { info[0] = (float) r.iters_total; info[1] = r.chi2; }
+    if (H36) std::memcpy(H36, r.H, sizeof(r.H));
+    return r.ret;
+}
+
+// ---- cpu_baseline helper: extract + frame-to-frame projection match over a list of frames, `threads` workers ----
+// Frames are u8 images of identical size laid out back to back.  Frame f (f >= 1) is matched against frame f-1
+// with an identity relative pose and unit-depth back-projected points (SURVEY §8d metric definition).
+// Returns elapsed seconds; n_kp_total / n_match_total are checksums so the work cannot be optimised away.
+double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, const uint8_t *frames,
+                              int nframes, int w, int h, int threads, float fx, float fy, float cx, float cy,
+                              long *n_kp_total, long *n_match_total) {
+    std::vector<long> kp_acc(threads, 0), m_acc(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int tid) {
+        Extractor ex(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+        std::vector<KeyPoint> kprev, kcur;
+        std::vector<uint8_t> dprev, dcur;
+        // each worker owns a contiguous chunk of frames (so that the t-1 -> t pairs stay on one worker)
+        int per = (nframes + threads - 1) / threads;
+        int f0 = tid * per, f1 = std::min(nframes, f0 + per);
+        for (int f = f0; f < f1; f++) {
+            ex.Extract(frames + (size_t) f * w * h, w, h, w, kcur, dcur);
+            kp_acc[tid] += (long) kcur.size();
+            if (f > f0 && !kprev.empty() && !kcur.empty()) {
+                FrameView cur;
+                cur.N = (int) kcur.size();
+                cur.keys = kcur.data();
+                cur.desc = dcur.data();
+                cur.uRight = nullptr;
+                cur.minX = 0; cur.minY = 0; cur.maxX = (float) w; cur.maxY = (float) h;
+                cur.gridInvW = (float) Grid::COLS / (cur.maxX - cur.minX);
+                cur.gridInvH = (float) Grid::ROWS / (cur.maxY - cur.minY);
+                cur.fx = fx; cur.fy = fy; cur.cx = cx; cur.cy = cy; cur.mb = 0; cur.mbf = 0;
+                cur.scaleFactors = ex.mvScaleFactor.data();
+                cur.nlevels = nlevels;
+                Grid g;
+                g.Assign(cur);
+                int n = (int) kprev.size();
+                std::vector<uint8_t> ones(n, 1), zeros(n, 0);
+                std::vector<float> world((size_t) 3 * n);
+                for (int i = 0; i < n; i++) {
+                    world[3 * i] = (kprev[i].x - cx) / fx;
+                    world[3 * i + 1] = (kprev[i].y - cy) / fy;
+                    world[3 * i + 2] = 1.f;
+                }
+                ProjLastInput in;
+                in.N = n;
+                in.keys = kprev.data();
+                in.mp_valid = ones.data();
+                in.outlier = zeros.data();
+                in.mp_has_obs = ones.data();
+                in.mp_world = world.data();
+                in.mp_desc = dprev.data();
+                const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+                std::memcpy(in.Rcw, I, 36); std::memcpy(in.tcw, z, 12);
+                std::memcpy(in.Rlw, I, 36); std::memcpy(in.tlw, z, 12);
+                std::vector<uint8_t> owner(cur.N, 0);
+                std::vector<int> match(cur.N, -1);
+                m_acc[tid] += search_by_projection_last(cur, g, in, 15.f, true, true, true, owner.data(), match.data());
+            }
+            kprev.swap(kcur);
+            dprev.swap(dcur);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
+    for (auto &t : th) t.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    long a = 0, b = 0;
+    for (int t = 0; t < threads; t++) { a += kp_acc[t]; b += m_acc[t]; }
+    if (n_kp_total) *n_kp_total = a;
+    if (n_match_total) *n_match_total = b;
+    return sec;
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""ctypes binding of the CPU ORACLE (oracle/libygz_oracle.so) and of the reference's libfast (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by bench.py's cpu_baseline leg and by __graft_entry__.smoke().
+The product package (orb_ygz_slam_amd) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class KeyPoint(C.Structure):  # cv::KeyPoint layout, 28 bytes
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int), ("class_id", C.c_int)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libygz_oracle.so")
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "_ref", "libfast_ref.so")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        L = _lib
+        L.yo_extractor_create.restype = C.c_void_p
+        L.yo_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.yo_extractor_destroy.argtypes = [C.c_void_p]
+        L.yo_fast_atan2.restype = C.c_float
+        L.yo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.yo_sincos_deg.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.yo_cv_round.argtypes = [C.c_double]
+        L.yo_ic_angle.restype = C.c_float
+        L.yo_ic_angle.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.yo_descriptor.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.yo_sparse_img_align.restype = C.c_size_t
+        L.yo_bench_extract_match.restype = C.c_double
+        L.yo_bench_extract_match.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    return _lib
+
+
+def ref_fast():
+    """The reference's own Thirdparty/fast, or None when oracle/_ref was never built (no reference checkout)."""
+    global _ref
+    if _ref is None:
+        build()
+        p = os.path.join(_HERE, "_ref", "libfast_ref.so")
+        if not os.path.exists(p):
+            return None
+        _ref = C.CDLL(p)
+    return _ref
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = C.c_void_p(self.L.yo_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th))
+
+    def __del__(self):
+        try:
+            self.L.yo_extractor_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.L.yo_extractor_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, nfeat=nf, umax=um)
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(), C.c_int()
+        self.L.yo_level_size(self.h, w, h, level, C.byref(lw), C.byref(lh))
+        return lw.value, lh.value
+
+    def pyramid(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        self.L.yo_pyramid(self.h, _p(img), w, h, w)
+        out = []
+        for l in range(self.nlevels):
+            lw, lh = self.level_size(w, h, l)
+            a = np.zeros((lh, lw), np.uint8)
+            self.L.yo_get_level(self.h, l, _p(a))
+            out.append(a)
+        return out
+
+    def cell_candidates(self, level, cap=400000):
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = self.L.yo_cell_candidates(self.h, level, _p(xs), _p(ys), _p(sc), cap)
+        assert n <= cap
+        return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+    def octree(self, xs, ys, resp, minX, maxX, minY, maxY, N):
+        xs, ys, resp = (np.ascontiguousarray(a, np.int32) for a in (xs, ys, resp))
+        cap = len(xs) + 8
+        out = np.zeros(cap, np.int32)
+        n = self.L.yo_octree(self.h, _p(xs), _p(ys), _p(resp), len(xs), minX, maxX, minY, maxY, N, _p(out), cap)
+        return out[:n].copy()
+
+    def level_keypoints(self, level, cap=100000):
+        k = np.zeros(cap, KP_DTYPE)
+        n = self.L.yo_level_keypoints(self.h, level, _p(k), cap)
+        return k[:n].copy()
+
+    def extract(self, img, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = cap or (self.nfeatures * 2 + 64 * self.nlevels)
+        k = np.zeros(cap, KP_DTYPE)
+        d = np.zeros((cap, 32), np.uint8)
+        n = self.L.yo_extract(self.h, _p(img), w, h, w, _p(k), cap, _p(d))
+        assert n >= 0, "oracle extract: capacity too small"
+        return k[:n].copy(), d[:n].copy()
+
+    def ic_angle(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        return float(self.L.yo_ic_angle(self.h, _p(img), img.shape[1], img.shape[0], x, y))
+
+    def descriptor(self, blurred, x, y, angle):
+        blurred = np.ascontiguousarray(blurred, np.uint8)
+        d = np.zeros(32, np.uint8)
+        self.L.yo_descriptor(self.h, _p(blurred), blurred.shape[1], blurred.shape[0], x, y, angle, _p(d))
+        return d
+
+
+def blur(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros_like(img)
+    lib().yo_blur(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def resize(img, dw, dh):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros((dh, dw), np.uint8)
+    lib().yo_resize(_p(img), img.shape[1], img.shape[0], _p(out), dw, dh)
+    return out
+
+
+def fast9(img, threshold, nonmax=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().yo_fast9(_p(img), w, w, h, threshold, int(nonmax), _p(xs), _p(ys), _p(sc), cap)
+    return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+
+def fast_atan2(y, x):
+    return float(lib().yo_fast_atan2(y, x))
+
+
+def sincos_deg(a):
+    c, s = C.c_float(), C.c_float()
+    lib().yo_sincos_deg(a, C.byref(c), C.byref(s))
+    return c.value, s.value
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().yo_hamming(_p(a), _p(b)))
+
+
+def fast10(img, barrier, stride=None):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xy = np.zeros((cap, 2), np.int16)
+    n = lib().yo_fast10_detect(_p(img), w, h, stride or w, barrier, _p(xy), cap)
+    xy = xy[:n].copy()
+    sc = np.zeros(n, np.int32)
+    lib().yo_fast10_score(_p(img), stride or w, _p(xy), n, _p(sc))
+    nm = np.zeros(max(n, 1), np.int32)
+    m = lib().yo_fast_nonmax_3x3(_p(xy), _p(sc), n, _p(nm), n)
+    return xy, sc, nm[:m].copy()
+
+
+def ref_fast10(img, barrier, which=1):
+    R = ref_fast()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h
+    xy = np.zeros((cap, 2), np.int16)
+    n = R.ref_fast10_detect(which, _p(img), w, h, w, barrier, _p(xy), cap)
+    xy = xy[:n].copy()
+    sc = np.zeros(n, np.int32)
+    R.ref_fast10_score(_p(img), w, _p(xy), n, barrier, _p(sc))
+    nm = np.zeros(max(n, 1), np.int32)
+    m = R.ref_fast_nonmax_3x3(_p(xy), _p(sc), n, _p(nm), n)
+    return xy, sc, nm[:m].copy()
+
+
+def bench_extract_match(frames, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, threads=1,
+                        fx=458.654, fy=457.296, cx=367.215, cy=248.375):
+    """CPU baseline ('port'): seconds for extract + frame-to-frame projection match over `frames` (n,h,w) u8."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w = frames.shape
+    nk, nm = C.c_long(), C.c_long()
+    sec = lib().yo_bench_extract_match(nfeatures, scale_factor, nlevels, ini_th, min_th, _p(frames), n, w, h, threads,
+                                       fx, fy, cx, cy, C.byref(nk), C.byref(nm))
+    return sec, nk.value, nm.value

@@ -1,0 +1,175 @@
+// ygz_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+//
+// A dependency-free C++17 restatement of the per-frame hot path of gaoxiang12/ORB-YGZ-SLAM:
+//   ORBextractor  (src/ORBextractor.cc)      pyramid, FAST-9 cells, octree, IC angle, 7x7 blur, rBRIEF
+//   ORBmatcher    (src/ORBmatcher.cc)        Hamming distance + SearchByProjection / SearchForInitialization
+//   Frame grid    (src/Frame.cc:314-330,424-493)
+//   SparseImgAlign(src/SparseImageAlign.cc)  + NLLSSolver Gauss-Newton + Sophus SE3f
+// plus restatements of the OpenCV 2.4.11/3.2 primitives the reference calls (resize INTER_LINEAR, FAST,
+// GaussianBlur, fastAtan2, cvRound), which are NOT under /root/reference.
+//
+// PARITY STATUS: "parity unpinned" for everything that goes through OpenCV (the reference ships no test or
+// golden vector for the extractor / matcher / aligner, and OpenCV is neither vendored nor version-pinned,
+// SURVEY.md §8c).  The only pinned vector is Thirdparty/fast's 167-corner KAT, checked in
+// tests/test_oracle_fast10.py against oracle/_ref (the reference's own libfast compiled from where it lies).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this code.
+#ifndef YGZ_ORACLE_H
+#define YGZ_ORACLE_H
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace ygzo {
+
+// Layout-compatible with cv::KeyPoint (7 x 4 bytes).
+struct KeyPoint {
+    float x, y, size, angle, response;
+    int octave, class_id;
+};
+
+struct Image {  // tight 8-bit image (step == w), like Frame::mvImagePyramid clones (src/Frame.cc:810-813)
+    int w = 0, h = 0;
+    std::vector<uint8_t> d;
+    Image() {}
+    Image(int w_, int h_) : w(w_), h(h_), d((size_t) w_ * h_) {}
+    inline uint8_t at(int y, int x) const { return d[(size_t) y * w + x]; }
+};
+
+// ---- OpenCV primitive restatements (all "recalled", defined here) ----------------------
+int cv_round(double v);                                    // B6: round half to even
+float fast_atan2_deg(float y, float x);                    // B5
+void resize_linear_u8(const Image &src, Image &dst);       // B1 (dst.w/dst.h preset)
+void gaussian_blur7_s2_u8(const Image &src, Image &dst);   // B4 legacy integer path, REFLECT_101
+// cosf/sinf of (angle_deg * (float)(pi/180)): "correctly rounded float of the double result", computed with a
+// fixed double polynomial (no FMA) so that host and device can evaluate the identical operation sequence.
+void sincos_deg(float angle_deg, float *c, float *s);
+
+// cv::FAST(img_window, kps, threshold, nonmax) TYPE_9_16 on the window [x0,x0+w)x[y0,y0+h) of `img`.
+// Output coordinates are relative to the window origin, raster order (B3).
+struct FastPt { int x, y, score; };
+void fast9(const uint8_t *img, int stride, int w, int h, int threshold, bool nonmax, std::vector<FastPt> &out);
+
+// ---- ORBextractor ------------------------------------------------------------------------------------------
+class Extractor {
+public:
+    // src/ORBextractor.cc:412-470
+    Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+
+    int nfeatures, nlevels, iniThFAST, minThFAST;
+    float scaleFactor;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    std::vector<Image> mvImagePyramid;
+
+    void LevelSize(int w, int h, int level, int *lw, int *lh) const;    // :1131-1132
+    void ComputePyramid(const uint8_t *img, int w, int h, int stride);  // :1129-1150
+    // FAST candidates of one level in region coordinates (origin = (16,16)), cell-major / raster order: the
+    // vToDistributeKeys vector of :747-781.
+    void CellCandidates(int level, std::vector<KeyPoint> &out) const;
+    void ComputeKeyPointsOctTree(std::vector<std::vector<KeyPoint>> &all) const;  // :725-804
+    // :533-723.  Tie-break of the (size, pointer) sort is DEFINED as (size, creation sequence number).
+    std::vector<KeyPoint> DistributeOctTree(const std::vector<KeyPoint> &keys, int minX, int maxX, int minY,
+                                            int maxY, int N) const;
+    float ICAngle(const Image &img, float ptx, float pty) const;  // :77-101
+    void ComputeDescriptor(const KeyPoint &kp, const Image &blurred, uint8_t *desc) const;  // :105-149
+    // operator()(InputArray, InputArray, vector<KeyPoint>&, OutputArray)  :970-1028
+    void Extract(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &kps,
+                 std::vector<uint8_t> &desc);
+};
+
+// ---- ORBmatcher / Frame grid -------------------------------------------------------------------------------
+int descriptor_distance(const uint8_t *a, const uint8_t *b);  // src/ORBmatcher.cc:1507-1523
+
+// The slice of `Frame` the matcher reads (src/Frame.h), as plain arrays.
+struct FrameView {
+    int N = 0;
+    const KeyPoint *keys = nullptr;       // mvKeys
+    const uint8_t *desc = nullptr;        // mDescriptors, N x 32
+    const float *uRight = nullptr;        // mvuRight (may be null => all -1)
+    float minX = 0, minY = 0, maxX = 0, maxY = 0;  // mnMinX ... (image bounds)
+    float gridInvW = 0, gridInvH = 0;     // mfGridElementWidthInv/HeightInv = 64/(maxX-minX), 48/(maxY-minY)
+    float fx = 0, fy = 0, cx = 0, cy = 0, mb = 0, mbf = 0;
+    const float *scaleFactors = nullptr;  // mvScaleFactors
+    int nlevels = 0;
+};
+
+struct Grid {  // Frame::mGrid[64][48]
+    static const int COLS = 64, ROWS = 48;
+    std::vector<int> cell[COLS][ROWS];
+    void Assign(const FrameView &f);  // src/Frame.cc:314-330 + PosInGrid :483-493
+    // src/Frame.cc:424-481
+    void FeaturesInArea(const FrameView &f, float x, float y, float r, int minLevel, int maxLevel,
+                        std::vector<int> &out) const;
+};
+
+// SearchByProjection(Frame &Cur, const Frame &Last, th, bMono, checkLevel)  src/ORBmatcher.cc:1218-1350
+// Last-frame side as arrays: per keypoint i: has MapPoint (mp_valid), outlier flag, world pos, MP descriptor,
+// MP->Observations()>0.  cur_owner[i2]: 0 = Cur.mvpMapPoints[i2]==NULL, 1 = non-null with Observations()==0,
+// 2 = non-null with Observations()>0.  On return cur_match[i2] = index i of the Last keypoint whose MapPoint
+// was written to Cur.mvpMapPoints[i2], or -1 (untouched) / -2 (written then nulled by the rotation check).
+struct ProjLastInput {
+    int N = 0;
+    const KeyPoint *keys = nullptr;
+    const uint8_t *mp_valid = nullptr, *outlier = nullptr, *mp_has_obs = nullptr;
+    const float *mp_world = nullptr;  // N x 3
+    const uint8_t *mp_desc = nullptr; // N x 32
+    float Rcw[9], tcw[3];             // CurrentFrame.mTcw
+    float Rlw[9], tlw[3];             // LastFrame.mTcw
+};
+int search_by_projection_last(const FrameView &cur, const Grid &grid, const ProjLastInput &last, float th,
+                              bool bMono, bool checkLevel, bool checkOrientation, uint8_t *cur_owner,
+                              int *cur_match);
+
+// SearchByProjection(Frame &F, const vector<MapPoint*>&, th, checkLevel)  src/ORBmatcher.cc:43-126
+struct ProjMapPointsInput {
+    int M = 0;
+    const uint8_t *track_in_view = nullptr, *bad = nullptr, *mp_has_obs = nullptr;
+    const float *projX = nullptr, *projY = nullptr, *projXR = nullptr, *viewCos = nullptr;
+    const int *scaleLevel = nullptr;
+    const uint8_t *mp_desc = nullptr;  // M x 32
+};
+int search_by_projection_mappoints(const FrameView &F, const Grid &grid, const ProjMapPointsInput &in, float th,
+                                   bool checkLevel, float nnratio, uint8_t *owner, int *match);
+
+// SearchForInitialization  src/ORBmatcher.cc:375-478
+int search_for_initialization(const FrameView &F1, const FrameView &F2, const Grid &grid2, float *prevMatchedXY,
+                              int windowSize, float nnratio, bool checkOrientation, int *matches12);
+
+// ---- Sophus SE3f + SparseImgAlign --------------------------------------------------------------------------
+struct SE3f {
+    float q[4] = {0, 0, 0, 1};  // x,y,z,w (Eigen coeffs order)
+    float t[3] = {0, 0, 0};
+    static SE3f FromRt(const float R[9], const float t[3]);
+    static SE3f Exp(const float a[6]);   // se3.hpp:406-428, so3.hpp:425-456
+    SE3f Inverse() const;                // se3.hpp:168-172
+    SE3f Mul(const SE3f &o) const;       // operator* = fastMultiply + normalize (se3.hpp:159-163,267-271)
+    void Act(const float p[3], float out[3]) const;  // so3*p + t (Eigen _transformVector)
+    void RotationMatrix(float R[9]) const;
+};
+
+struct AlignFrame {  // slice of Frame read by SparseImgAlign
+    int N = 0;
+    const KeyPoint *keys = nullptr;
+    const uint8_t *mp_valid = nullptr;   // mvpMapPoints[i] != nullptr && !isBad()
+    const uint8_t *outlier = nullptr;    // mvbOutlier
+    const float *mp_world = nullptr;     // N x 3
+    SE3f Tcw;
+    std::vector<const Image *> pyramid;  // mvImagePyramid (step == cols)
+    const float *invScaleFactors = nullptr;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+};
+
+struct AlignResult {
+    SE3f TCR;
+    size_t ret = 0;        // n_meas_/16
+    int iters_total = 0;   // number of computeResiduals(linearize) calls, for reporting
+    float chi2 = 0;
+    float H[36];
+};
+// SparseImgAlign(max_level, min_level, n_iter=10, GaussNewton).run(ref, cur, TCR)  src/SparseImageAlign.cc:20-49
+AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level,
+                             int n_iter);
+
+}  // namespace ygzo
+#endif
