@@ -1,0 +1,120 @@
+/* ygzf.h -- C ABI of libygzf: the MI355X (gfx950) implementation of ORB-YGZ-SLAM's per-frame hot path.
+ *
+ * This is the drop-in boundary: plain C, POD structs, raw pointers and sizes; no C++ or torch types cross it.
+ * The C++ class shells in orb_ygz_slam_amd/csrc/host/ (ygz::ORBextractor, ygz::ORBmatcher, ygz::SparseImgAlign,
+ * same public signatures as the reference) are thin wrappers over these entry points; INTEGRATION.md shows how the
+ * reference's Tracking.cc links against them.  Every function cites the reference interface it replaces
+ * (paths relative to the reference checkout gaoxiang12/ORB-YGZ-SLAM).
+ *
+ * Conventions: every function returns YGZF_OK (0) or a negative ygzf_status; no exception crosses the ABI; the
+ * caller owns all host buffers; the context owns device buffers and its HIP stream.  A context is not thread-safe:
+ * use one per thread (the reference runs one ORBextractor per eye on two std::threads, src/Frame.cc:728-731).
+ * There is no CPU fallback: without a usable HIP device ygzf_create fails with YGZF_ERR_NO_DEVICE.
+ */
+#ifndef YGZF_H
+#define YGZF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ygzf_status {
+    YGZF_OK = 0,
+    YGZF_ERR_INVALID = -1,     /* bad argument (null pointer, size out of range, capacity too small) */
+    YGZF_ERR_NO_DEVICE = -2,   /* no HIP device / device index out of range */
+    YGZF_ERR_HIP = -3,         /* a HIP runtime call failed; see ygzf_last_error */
+    YGZF_ERR_UNSUPPORTED = -4, /* configuration outside what the kernels cover (e.g. level wider than 4096 px) */
+    YGZF_ERR_STATE = -5        /* call order violated (e.g. fetch before extract) */
+} ygzf_status;
+
+typedef struct ygzf_ctx ygzf_ctx;
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  include/ORBextractor.h:58-59,
+ * src/ORBextractor.cc:412-470 */
+typedef struct ygzf_extractor_cfg {
+    int nfeatures;
+    float scale_factor;
+    int nlevels;
+    int ini_th_fast;
+    int min_th_fast;
+} ygzf_extractor_cfg;
+
+/* cv::KeyPoint, bit-compatible (7 x 4 bytes): pt.x pt.y size angle response octave class_id */
+typedef struct ygzf_kp {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} ygzf_kp;
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+/* Creates an extractor context on HIP device `device` able to process up to max_batch frames of up to
+ * max_width x max_height pixels per call. */
+int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int max_height, int max_batch, ygzf_ctx **out);
+void ygzf_destroy(ygzf_ctx *ctx);
+/* Human-readable description of the last failure on `ctx` (or of the last failed ygzf_create when ctx == NULL). */
+const char *ygzf_last_error(const ygzf_ctx *ctx);
+
+/* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:84-106); arrays of nlevels floats, any may be NULL. */
+int ygzf_get_levels(const ygzf_ctx *ctx);
+int ygzf_get_scale_tables(const ygzf_ctx *ctx, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:434-445) */
+int ygzf_get_features_per_level(const ygzf_ctx *ctx, int *nfeat);
+/* Size of pyramid level `level` for a w x h input (src/ORBextractor.cc:1131-1132). */
+int ygzf_level_size(const ygzf_ctx *ctx, int w, int h, int level, int *lw, int *lh);
+/* Upper bound on keypoints returned per frame for a w x h input (sum over levels of N_l + 3, or 4*nIni). */
+int ygzf_max_keypoints(const ygzf_ctx *ctx, int w, int h);
+
+/* ---- ORBextractor::ComputePyramid(cv::Mat)  src/ORBextractor.cc:1129-1150 ----------------------------------------
+ * Host image in; all nlevels levels are computed on the device and copied back tight (step == width) into
+ * levels_out[l] (each at least lw*lh bytes), which is what Frame clones into mvImagePyramid (src/Frame.cc:810-813).
+ * The 19-px border the reference adds is never read by the hot path and is not materialised. */
+int ygzf_compute_pyramid(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, uint8_t *const *levels_out);
+
+/* ---- ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>&, OutputArray descriptors)
+ *      src/ORBextractor.cc:970-1028 (mask ignored, as in the reference) ------------------------------------------
+ * One host frame in, keypoints (level-major order) and N x 32 descriptors out.  cap = capacity of kps/desc in
+ * keypoints (use ygzf_max_keypoints).  Empty image (img == NULL or w*h == 0) => *n_out = 0, YGZF_OK (the reference
+ * returns silently, :972-973). */
+int ygzf_extract(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
+
+/* Batched form of the same operator on DEVICE-resident frames: frame f starts at d_imgs + f*frame_stride, rows are
+ * row_pitch bytes apart.  Results stay on the device (chain into ygzf_match_*) until fetched.  Asynchronous on the
+ * context stream; ygzf_sync / ygzf_batch_counts / ygzf_batch_fetch synchronise. */
+int ygzf_extract_batch_device(ygzf_ctx *ctx, const uint8_t *d_imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
+/* Same, host frames (H2D copy of each frame included). */
+int ygzf_extract_batch_host(ygzf_ctx *ctx, const uint8_t *imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
+int ygzf_batch_counts(ygzf_ctx *ctx, int *n_kp /* n_frames ints */);
+int ygzf_batch_fetch(ygzf_ctx *ctx, int frame, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
+/* Copies pyramid level `level` of batch frame `frame` back to the host, tight. */
+int ygzf_batch_fetch_level(ygzf_ctx *ctx, int frame, int level, uint8_t *out);
+int ygzf_sync(ygzf_ctx *ctx);
+
+/* ---- stage-level accessors used by the parity tests (tests/test_gpu_extract.py) -------------------------------------
+ * FAST candidates of (frame, level) after the per-cell NMS / threshold fallback, in the reference's vToDistributeKeys
+ * order (src/ORBextractor.cc:747-781): region coordinates (origin (16,16)), cell-major, raster inside a cell. */
+int ygzf_batch_fetch_candidates(ygzf_ctx *ctx, int frame, int level, int *xs, int *ys, int *scores, int cap, int *n_out);
+/* Keypoints of (frame, level) selected by the octree, level coordinates, octree list order. */
+int ygzf_batch_fetch_level_keypoints(ygzf_ctx *ctx, int frame, int level, int *xs, int *ys, int *scores, int cap, int *n_out);
+
+/* ---- ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)  src/ORBmatcher.cc:1507-1523 ------------------
+ * Batched on the device: dist[i] = popcount(a[i] xor b[i]) over 256 bits, n pairs of 32-byte host descriptors. */
+int ygzf_descriptor_distance(ygzf_ctx *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist);
+
+/* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------
+ * HIP events recorded on the context stream (the stream every kernel of this context is launched on). */
+int ygzf_timer_start(ygzf_ctx *ctx);
+int ygzf_timer_stop(ygzf_ctx *ctx, float *elapsed_ms);
+/* Per-kernel accumulation: when enabled every kernel launch is bracketed by its own event pair. */
+int ygzf_profile_enable(ygzf_ctx *ctx, int on);
+/* Returns the number of kernel kinds; fills up to cap entries (name pointers are static strings). */
+int ygzf_profile_read(ygzf_ctx *ctx, const char **names, float *total_ms, int *launches, int cap);
+int ygzf_profile_reset(ygzf_ctx *ctx);
+/* Raw hipStream_t of the context (as void*), for callers that record their own events. */
+void *ygzf_stream(ygzf_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YGZF_H */

@@ -1,0 +1,52 @@
+"""Builds the product library orb_ygz_slam_amd/lib/libygzf.so for gfx950 with hipcc (in-tree, so that the .so travels
+to the GPU box with the repo snapshot).  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRCS = ["csrc/extract_kernels.hip", "csrc/match_kernels.hip", "csrc/align_kernels.hip", "csrc/ygzf_api.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off",                               # bit-exact float paths: no FMA contraction
+         "-fhip-fp32-correctly-rounded-divide-sqrt",        # IEEE division in fastAtan2
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def hipcc():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if p and os.path.exists(p):
+            return p
+    raise RuntimeError("hipcc not found")
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libygzf.so")
+
+
+def needs_build():
+    out = lib_path()
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
+    deps += [os.path.join(HERE, "csrc", f) for f in os.listdir(os.path.join(HERE, "csrc")) if f.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "ygzf.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return lib_path()
+    os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
+    srcs = [s for s in SRCS if os.path.exists(os.path.join(HERE, s))]
+    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include")] + srcs + ["-o", lib_path()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=HERE)
+    return lib_path()
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

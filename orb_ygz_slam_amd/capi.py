@@ -1,0 +1,216 @@
+"""ctypes binding of include/ygzf.h (libygzf.so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class YgzfError(RuntimeError):
+    pass
+
+
+class ExtractorCfg(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int), ("ini_th_fast", C.c_int),
+                ("min_th_fast", C.c_int)]
+
+
+_lib = None
+
+
+def load_library(build_if_missing=True):
+    """Loads libygzf.so (building it with hipcc first when it is missing/stale).  Fails loudly: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.lib_path()
+    if build_if_missing and _build.needs_build():
+        try:
+            _build.build()
+        except Exception as e:  # stale-but-present library is still usable on a box without hipcc sources changes
+            if not os.path.exists(path):
+                raise YgzfError("libygzf.so is missing and could not be built: %r" % (e,))
+    if not os.path.exists(path):
+        raise YgzfError("libygzf.so not found at %s (run python -m orb_ygz_slam_amd.build)" % path)
+    L = C.CDLL(path)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    L.ygzf_create.argtypes = [C.c_int, C.POINTER(ExtractorCfg), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ygzf_destroy.argtypes = [vp]
+    L.ygzf_destroy.restype = None
+    L.ygzf_last_error.argtypes = [vp]
+    L.ygzf_last_error.restype = C.c_char_p
+    L.ygzf_get_levels.argtypes = [vp]
+    L.ygzf_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.ygzf_get_features_per_level.argtypes = [vp, vp]
+    L.ygzf_level_size.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip]
+    L.ygzf_max_keypoints.argtypes = [vp, C.c_int, C.c_int]
+    L.ygzf_compute_pyramid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ygzf_extract.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, ip]
+    L.ygzf_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]
+    L.ygzf_extract_batch_host.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]
+    L.ygzf_batch_counts.argtypes = [vp, vp]
+    L.ygzf_batch_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, ip]
+    L.ygzf_batch_fetch_level.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.ygzf_sync.argtypes = [vp]
+    L.ygzf_batch_fetch_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip]
+    L.ygzf_batch_fetch_level_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip]
+    L.ygzf_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.ygzf_timer_start.argtypes = [vp]
+    L.ygzf_timer_stop.argtypes = [vp, fp]
+    L.ygzf_profile_enable.argtypes = [vp, C.c_int]
+    L.ygzf_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), fp, ip, C.c_int]
+    L.ygzf_profile_reset.argtypes = [vp]
+    L.ygzf_stream.argtypes = [vp]
+    L.ygzf_stream.restype = vp
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Extractor:
+    """Thin object wrapper over a ygzf_ctx (mirrors ygz::ORBextractor's constructor arguments)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, max_width=752, max_height=480,
+                 max_batch=1, device=0):
+        self.L = load_library()
+        self.nlevels = nlevels
+        self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.h = C.c_void_p()
+        rc = self.L.ygzf_create(device, C.byref(self.cfg), max_width, max_height, max_batch, C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise YgzfError("ygzf_create failed (%d): %s" % (rc, self.L.ygzf_last_error(None).decode()))
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.ygzf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise YgzfError("libygzf error %d: %s" % (rc, self.L.ygzf_last_error(self.h).decode()))
+        return rc
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        self._ck(self.L.ygzf_get_scale_tables(self.h, _p(sc), _p(inv), _p(s2), _p(is2)))
+        self._ck(self.L.ygzf_get_features_per_level(self.h, _p(nf)))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, nfeat=nf)
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int(), C.c_int()
+        self._ck(self.L.ygzf_level_size(self.h, w, h, level, C.byref(lw), C.byref(lh)))
+        return lw.value, lh.value
+
+    def max_keypoints(self, w, h):
+        return self._ck(self.L.ygzf_max_keypoints(self.h, w, h))
+
+    def compute_pyramid(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        outs = [np.zeros(self.level_size(w, h, l)[::-1], np.uint8) for l in range(self.nlevels)]
+        arr = (C.c_void_p * self.nlevels)(*[o.ctypes.data for o in outs])
+        self._ck(self.L.ygzf_compute_pyramid(self.h, _p(img), w, h, w, arr))
+        return outs
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        cap = self.max_keypoints(w, h)
+        k = np.zeros(max(cap, 1), KP_DTYPE)
+        d = np.zeros((max(cap, 1), 32), np.uint8)
+        n = C.c_int()
+        self._ck(self.L.ygzf_extract(self.h, _p(img), w, h, w, _p(k), _p(d), cap, C.byref(n)))
+        return k[:n.value].copy(), d[:n.value].copy()
+
+    def extract_batch_host(self, imgs):
+        imgs = np.ascontiguousarray(imgs, np.uint8)
+        n, h, w = imgs.shape
+        self._ck(self.L.ygzf_extract_batch_host(self.h, _p(imgs), n, w, h, w, w * h))
+        self._wh = (w, h, n)
+
+    def extract_batch_device(self, dptr, n, w, h, row_pitch=None, frame_stride=None):
+        row_pitch = row_pitch or w
+        frame_stride = frame_stride or row_pitch * h
+        self._ck(self.L.ygzf_extract_batch_device(self.h, C.c_void_p(dptr), n, w, h, row_pitch, frame_stride))
+        self._wh = (w, h, n)
+
+    def sync(self):
+        self._ck(self.L.ygzf_sync(self.h))
+
+    def batch_counts(self):
+        n = np.zeros(self._wh[2], np.int32)
+        self._ck(self.L.ygzf_batch_counts(self.h, _p(n)))
+        return n
+
+    def batch_fetch(self, frame):
+        w, h, _ = self._wh
+        cap = self.max_keypoints(w, h)
+        k = np.zeros(max(cap, 1), KP_DTYPE)
+        d = np.zeros((max(cap, 1), 32), np.uint8)
+        n = C.c_int()
+        self._ck(self.L.ygzf_batch_fetch(self.h, frame, _p(k), _p(d), cap, C.byref(n)))
+        return k[:n.value].copy(), d[:n.value].copy()
+
+    def batch_fetch_level(self, frame, level):
+        w, h, _ = self._wh
+        lw, lh = self.level_size(w, h, level)
+        out = np.zeros((lh, lw), np.uint8)
+        self._ck(self.L.ygzf_batch_fetch_level(self.h, frame, level, _p(out)))
+        return out
+
+    def batch_fetch_candidates(self, frame, level, cap=1 << 20):
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int()
+        self._ck(self.L.ygzf_batch_fetch_candidates(self.h, frame, level, _p(xs), _p(ys), _p(sc), cap, C.byref(n)))
+        return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
+
+    def batch_fetch_level_keypoints(self, frame, level, cap=1 << 16):
+        xs, ys, sc = (np.zeros(cap, np.int32) for _ in range(3))
+        n = C.c_int()
+        self._ck(self.L.ygzf_batch_fetch_level_keypoints(self.h, frame, level, _p(xs), _p(ys), _p(sc), cap, C.byref(n)))
+        return xs[:n.value].copy(), ys[:n.value].copy(), sc[:n.value].copy()
+
+    def descriptor_distance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(a), np.int32)
+        self._ck(self.L.ygzf_descriptor_distance(self.h, _p(a), _p(b), len(a), _p(out)))
+        return out
+
+    def timer_start(self):
+        self._ck(self.L.ygzf_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.L.ygzf_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._ck(self.L.ygzf_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self.L.ygzf_profile_reset(self.h))
+
+    def profile_read(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = (C.c_int * 16)()
+        k = self._ck(self.L.ygzf_profile_read(self.h, names, ms, n, 16))
+        return {names[i].decode(): (ms[i], n[i]) for i in range(k)}

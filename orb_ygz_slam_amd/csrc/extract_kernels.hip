@@ -1,0 +1,874 @@
+// extract_kernels.hip -- hand-written gfx950 kernels of the ORB extractor hot path (product code).
+//
+//   k_pyr_resize   K1  ORBextractor::ComputePyramid          (reference src/ORBextractor.cc:1129-1150, cv::resize)
+//   k_fast_cells   K2  ComputeKeyPointsOctTree cell loop     (:747-781, cv::FAST 9/16 + per-cell NMS + threshold fallback)
+//   k_octree       K4  DistributeOctTree                      (:533-723) as sort-by-path-key + breadth-first on ranges
+//   k_describe     K5+K6+K7  IC_Angle (:77-101), GaussianBlur 7x7 s=2 (:1010) on the 37x37 patch only,
+//                            computeOrbDescriptor (:105-149)
+//
+// Everything here is integer / compare-select work bounded by HBM traffic and launch count, not by MFMA.
+// Built with -ffp-contract=off: the few float expressions (fastAtan2, the rBRIEF rotation) must round exactly like
+// the reference's scalar C++ (no FMA), see DESIGN.md "float details inside bit-exact descriptors".
+#include "kernels.h"
+#include "orb_pattern_table.h"
+
+namespace ygzf {
+
+// ------------------------------------------------------------------------------------------------------------------
+// small wave / block primitives (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned t = (unsigned) __shfl_xor((int) v, d, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// Exclusive prefix of v over the threads of the block (thread order); *total = block sum.  tmp: >= 17 ints of LDS.
+// Contains block barriers: must be called by all threads.
+__device__ __forceinline__ int block_excl_scan(int v, int *tmp, int *total) {
+    const int incl = wave_incl_scan(v);
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();  // tmp may still be read from a previous call
+    if (lane_id() == 63) tmp[wave_id()] = incl;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int w = threadIdx.x < nw ? tmp[threadIdx.x] : 0;
+        int wi = wave_incl_scan(w);
+        if (threadIdx.x < nw) tmp[threadIdx.x] = wi - w;
+        if (threadIdx.x == nw - 1) tmp[16] = wi;
+    }
+    __syncthreads();
+    *total = tmp[16];
+    return tmp[wave_id()] + incl - v;
+}
+
+// In-place exclusive scan of an LDS array a[0..n); returns the total.  Each thread owns a contiguous chunk.
+__device__ __forceinline__ int block_scan_array(int *a, int n, int *tmp) {
+    const int per = (n + blockDim.x - 1) / blockDim.x;
+    const int b = threadIdx.x * per, e = min(n, b + per);
+    int s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    int total;
+    int off = block_excl_scan(s, tmp, &total);
+    for (int i = b; i < e; i++) {
+        int v = a[i];
+        a[i] = off;
+        off += v;
+    }
+    __syncthreads();
+    return total;
+}
+
+// Stable LSD radix sort (4-bit digits) of n (key,val) pairs on `bits` key bits by the whole block.
+// k0/v0 hold the input; result is left in *rk/*rv (one of the two buffers).  Buffers may be LDS or global.
+// histT: 256 ints of LDS, tmp: 17 ints of LDS.
+__device__ void block_radix_sort(unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, int n, int bits,
+                                 volatile int *histT, int *tmp, unsigned **rk, unsigned **rv) {
+    const int lane = lane_id(), wave = wave_id();
+    const int nw = blockDim.x >> 6;  // <= 16
+    const int seg = (((n + nw - 1) / nw) + 63) & ~63;
+    const int start = wave * seg;
+    const int end = min(n, start + seg);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int shift = 0; shift < bits; shift += 4) {
+        if (threadIdx.x < 256) histT[threadIdx.x] = 0;
+        __syncthreads();
+        for (int i = start + lane; i < end; i += 64) {
+            const int d = (k0[i] >> shift) & 15;
+            atomicAdd((int *) &histT[d * 16 + wave], 1);
+        }
+        __syncthreads();
+        {
+            int v = threadIdx.x < 256 ? histT[threadIdx.x] : 0;
+            int total;
+            int ex = block_excl_scan(v, tmp, &total);
+            if (threadIdx.x < 256) histT[threadIdx.x] = ex;
+        }
+        __syncthreads();
+        for (int base = start; base < end; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < end;
+            const unsigned key = valid ? k0[i] : 0u;
+            const unsigned val = valid ? v0[i] : 0u;
+            const int d = (key >> shift) & 15;
+            unsigned long long m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool bit = (d >> b) & 1;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            const int rank = __popcll(m & lt);
+            const int cnt = __popcll(m);
+            int pos = 0;
+            if (valid) pos = histT[d * 16 + wave] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                k1[pos] = key;
+                v1[pos] = val;
+                if (rank == cnt - 1) histT[d * 16 + wave] = pos + 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        unsigned *t = k0; k0 = k1; k1 = t;
+        t = v0; v0 = v1; v1 = t;
+    }
+    *rk = k0;
+    *rv = v0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K1  pyramid level from the previous level: cv::resize INTER_LINEAR, 8UC1, 11-bit fixed point coefficients that the
+// host precomputed exactly as OpenCV does (xofs/ialpha, yofs/ibeta).  One thread per output pixel.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_resize(FrameSet fs, const LevelGeom *__restrict__ geom, int level,
+                                                    const int *__restrict__ xofs, const short *__restrict__ xalpha,
+                                                    const int *__restrict__ yofs, const short *__restrict__ ybeta) {
+    const LevelGeom g = geom[level];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, f = blockIdx.z;
+    if (x >= g.w) return;
+    int sp;
+    const uint8_t *src = level_ptr(fs, geom[level - 1], level - 1, f, &sp);
+    const int sw = geom[level - 1].w, sh = geom[level - 1].h;
+    uint8_t *dst = fs.pyr + (long long) f * fs.pyr_stride + g.off;
+    if (g.area2x) {
+        const uint8_t *r0 = src + (long long) (2 * y) * sp + 2 * x, *r1 = r0 + sp;
+        dst[(long long) y * g.pitch + x] = (uint8_t) ((r0[0] + r0[1] + r1[0] + r1[1] + 2) >> 2);
+        return;
+    }
+    int sy = yofs[g.ytab + y];
+    const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+    const int b0 = ybeta[2 * (g.ytab + y)], b1 = ybeta[2 * (g.ytab + y) + 1];
+    const int sx = xofs[g.xtab + x];
+    const int sx1 = min(sx + 1, sw - 1);
+    const int a0 = xalpha[2 * (g.xtab + x)], a1 = xalpha[2 * (g.xtab + x) + 1];
+    const uint8_t *S0 = src + (long long) sy0 * sp, *S1 = src + (long long) sy1 * sp;
+    const int H0 = S0[sx] * a0 + S0[sx1] * a1;
+    const int H1 = S1[sx] * a0 + S1[sx1] * a1;
+    dst[(long long) y * g.pitch + x] = (uint8_t) ((((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2  FAST-9/16 per 30-px cell.  One workgroup per (cell, frame): the (wCell+6)x(hCell+6) window is staged in LDS, the
+// 16-pixel Bresenham ring is read from LDS, the score (max arc margin - 1 == cv::FAST's cornerScore) is written to an
+// LDS score map, then the cell-local 3x3 NMS is evaluated for BOTH thresholds (iniTh map and minTh map) and the minTh
+// result is used only when the iniTh result is empty -- exactly the reference's "FAST(ini); if empty FAST(min)".
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool has_arc9(unsigned m16) {
+    unsigned m = m16 | (m16 << 16);
+    unsigned r = m & (m >> 1);
+    r &= r >> 2;
+    r &= r >> 4;
+    r &= m >> 8;
+    return (r & 0xFFFFu) != 0;
+}
+
+template <int TP>
+__device__ __forceinline__ int fast9_score(const uint8_t *c, int minTh) {
+    const int v = c[0];
+    int d[16];
+    d[0] = c[3 * TP] - v;       d[1] = c[3 * TP + 1] - v;   d[2] = c[2 * TP + 2] - v;   d[3] = c[TP + 3] - v;
+    d[4] = c[3] - v;            d[5] = c[-TP + 3] - v;      d[6] = c[-2 * TP + 2] - v;  d[7] = c[-3 * TP + 1] - v;
+    d[8] = c[-3 * TP] - v;      d[9] = c[-3 * TP - 1] - v;  d[10] = c[-2 * TP - 2] - v; d[11] = c[-TP - 3] - v;
+    d[12] = c[-3] - v;          d[13] = c[TP - 3] - v;      d[14] = c[2 * TP - 2] - v;  d[15] = c[3 * TP - 1] - v;
+    unsigned B = 0, D = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        B |= (unsigned) (d[k] > minTh) << k;
+        D |= (unsigned) (d[k] < -minTh) << k;
+    }
+    const bool cb = has_arc9(B), cd = has_arc9(D);
+    if (!cb && !cd) return 0;
+    // max over the 16 arcs of 9 of the min margin (bright: d, dark: -d); only one polarity can be a corner
+    int e[16];
+    if (cb) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = d[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] = -d[k];
+    }
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) m2[k] = min(e[k], e[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+    int a = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) a = max(a, min(m8[k], e[(k + 8) & 15]));
+    return a - 1;  // >= minTh because the pixel is a corner at minTh
+}
+
+constexpr int kTP = 68;  // LDS pitch of the image window
+constexpr int kSP = 64;  // LDS pitch of the score map (<= 62 columns used)
+
+__global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
+                                                          int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
+                                                          unsigned *__restrict__ slots, int totalCells,
+                                                          long long totalSlots) {
+    __shared__ uint8_t tile[kMaxCellWin * kTP];
+    __shared__ __attribute__((aligned(16))) uint8_t smap[62 * kSP];
+    __shared__ int s_tmp[20];
+    __shared__ int s_ini;
+    const int tid = threadIdx.x;
+    const int cell = blockIdx.x, f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < nlevels && cell >= geom[l + 1].cellBase) l++;
+    const LevelGeom g = geom[l];
+    const int c = cell - g.cellBase;
+    const int ci = c / g.nCols, cj = c - ci * g.nCols;
+    const int iniX = kBorder + cj * g.wCell, iniY = kBorder + ci * g.hCell;
+    const int maxX = min(iniX + g.wCell + 6, g.maxBorderX), maxY = min(iniY + g.hCell + 6, g.maxBorderY);
+    const bool skip = (iniX >= g.maxBorderX - 6) || (iniY >= g.maxBorderY - 3);  // :751,:759 (asymmetric on purpose)
+    const int ww = maxX - iniX, hh = maxY - iniY;
+    const int dw = ww - 6, dh = hh - 6;
+    unsigned short *cnt_out = cellCnt + (long long) f * totalCells + cell;
+    if (skip || dw <= 0 || dh <= 0) {
+        if (tid == 0) *cnt_out = 0;
+        return;
+    }
+    int pitch;
+    const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
+    for (int idx = tid; idx < ww * hh; idx += kFastBlock) {
+        const int ty = idx / ww, tx = idx - ty * ww;
+        tile[ty * kTP + tx] = img[(long long) (iniY + ty) * pitch + iniX + tx];
+    }
+    for (int idx = tid; idx < (62 * kSP) / 16; idx += kFastBlock) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) s_ini = 0;
+    __syncthreads();
+    const int npix = dw * dh;
+    const int ppt = (npix + kFastBlock - 1) / kFastBlock;  // <= 15
+    const int p0 = tid * ppt;
+    for (int j = 0; j < ppt; j++) {
+        const int idx = p0 + j;
+        if (idx < npix) {
+            const int y = idx / dw, x = idx - y * dw;
+            const int s = fast9_score<kTP>(&tile[(y + 3) * kTP + x + 3], minTh);
+            smap[(y + 1) * kSP + x + 1] = (uint8_t) s;
+        }
+    }
+    __syncthreads();
+    unsigned keepIni = 0, keepMin = 0;
+    for (int j = 0; j < ppt; j++) {
+        const int idx = p0 + j;
+        if (idx < npix) {
+            const int y = idx / dw, x = idx - y * dw;
+            const uint8_t *p = &smap[(y + 1) * kSP + x + 1];
+            const int s = p[0];
+            if (s) {
+                int nmax = 0, nmaxI = 0;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        if (dx == 0 && dy == 0) continue;
+                        const int n = p[dy * kSP + dx];
+                        nmax = max(nmax, n);
+                        nmaxI = max(nmaxI, n >= iniTh ? n : 0);
+                    }
+                if (s > nmax) keepMin |= 1u << j;
+                if (s >= iniTh && s > nmaxI) keepIni |= 1u << j;
+            }
+        }
+    }
+    if (keepIni) atomicAdd(&s_ini, __popc(keepIni));
+    __syncthreads();
+    const unsigned keep = s_ini > 0 ? keepIni : keepMin;
+    int total;
+    int off = block_excl_scan(__popc(keep), s_tmp, &total);
+    unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
+    for (int j = 0; j < ppt; j++) {
+        if (keep & (1u << j)) {
+            const int idx = p0 + j;
+            const int y = idx / dw, x = idx - y * dw;
+            const unsigned s = smap[(y + 1) * kSP + x + 1];
+            out[off++] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
+        }
+    }
+    if (tid == 0) *cnt_out = (unsigned short) total;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K4  DistributeOctTree on the device.  One workgroup per (level, frame).
+//
+// The reference subdivides std::list nodes holding copies of their keypoints.  Here every candidate gets a PATH KEY:
+// its root index followed by 2 bits per subdivision (bit0: x >= midX, bit1: y >= midY, with DivideNode's ceil-halving,
+// :479-531).  After a stable radix sort by key every node of the tree at every depth is a contiguous range, so the
+// breadth-first passes (:578-700) only touch (lo, cnt, depth) triples; child ranges come from binary searches.
+// List order (push_front of n1..n4, erase of the parent), the "expand the biggest nodes first" phase with its
+// (size, creation order) sort and the early break at N nodes, and the final per-node arg-max response (first maximum in
+// original candidate order) are reproduced exactly; tools/octree_proto.py is the executable specification.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned path_key(int x, int y, const LevelGeom &g) {
+    int root = (int) ((float) x / g.hX);
+    root = min(root, g.nIni - 1);
+    int xl = (int) (g.hX * (float) root), xr = (int) (g.hX * (float) (root + 1));
+    int yl = 0, yr = g.regH;
+    unsigned k = (unsigned) root;
+    for (int d = 0; d < g.depth; d++) {
+        const int mx = xl + ((xr - xl + 1) >> 1);
+        const int my = yl + ((yr - yl + 1) >> 1);
+        const unsigned bx = x >= mx, by = y >= my;
+        if (bx) xl = mx; else xr = mx;
+        if (by) yl = my; else yr = my;
+        k = (k << 2) | (by << 1) | bx;
+    }
+    return k;
+}
+
+// first index in [lo, lo+cnt) whose 2-bit digit at `shift` is >= c (keys in the range share all higher bits)
+__device__ __forceinline__ int digit_lower_bound(const unsigned *keys, int lo, int cnt, int shift, unsigned c) {
+    int a = lo, b = lo + cnt;
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (((keys[m] >> shift) & 3u) < c) a = m + 1; else b = m;
+    }
+    return a;
+}
+
+struct OctShared {  // carved out of dynamic LDS
+    int *cellPref;            // nCells + 1
+    int *nlo[2], *ncnt[2], *ndep[2];  // node list, double buffered (cap each)
+    int *kArr, *eArr, *sArr;  // per-node scratch (cap each)
+    int *b1, *b2, *b3;        // child boundaries (cap each)
+    int *Epos, *Ecnt;         // expandable nodes in creation order (cap each)
+    unsigned *sk[2], *sv[2];  // sort buffers for E (cap each)
+    int *flag;                // processed flag per list position (cap)
+};
+
+__global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
+                                                      const unsigned short *__restrict__ cellCnt,
+                                                      const unsigned *__restrict__ slots, int totalCells,
+                                                      long long totalSlots, unsigned *__restrict__ candKey0,
+                                                      unsigned *__restrict__ candVal0, unsigned *__restrict__ candKey1,
+                                                      unsigned *__restrict__ candVal1, unsigned *__restrict__ candXY,
+                                                      long long candStride, unsigned *__restrict__ lvlKpXY,
+                                                      unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
+                                                      int *__restrict__ lvlCandCnt, int kpStride, int cap) {
+    extern __shared__ __attribute__((aligned(16))) int dyn[];
+    __shared__ int histT[256];
+    __shared__ int s_tmp[20];
+    __shared__ int s_n, s_nE, s_cut, s_flagA;
+    const int tid = threadIdx.x;
+    const int l = blockIdx.x, f = blockIdx.y;
+    const LevelGeom g = geom[l];
+    const int nCells = g.nCols * g.nRows;
+    int *lvlCnt = lvlKpCnt + f * nlevels + l;
+    if (nCells <= 0 || g.nCols <= 0) {
+        if (tid == 0) { *lvlCnt = 0; lvlCandCnt[f * nlevels + l] = 0; }
+        return;
+    }
+    OctShared S;
+    {
+        int *p = dyn;
+        S.cellPref = p; p += nCells + 1;
+        for (int b = 0; b < 2; b++) { S.nlo[b] = p; p += cap; S.ncnt[b] = p; p += cap; S.ndep[b] = p; p += cap; }
+        S.kArr = p; p += cap; S.eArr = p; p += cap; S.sArr = p; p += cap;
+        S.b1 = p; p += cap; S.b2 = p; p += cap; S.b3 = p; p += cap;
+        S.Epos = p; p += cap; S.Ecnt = p; p += cap;
+        for (int b = 0; b < 2; b++) { S.sk[b] = (unsigned *) p; p += cap; S.sv[b] = (unsigned *) p; p += cap; }
+        S.flag = p; p += cap;
+    }
+    const unsigned short *cc = cellCnt + (long long) f * totalCells + g.cellBase;
+    const unsigned *sl = slots + (long long) f * totalSlots + g.slotBase;
+    unsigned *key0 = candKey0 + (long long) f * candStride + g.candBase;
+    unsigned *val0 = candVal0 + (long long) f * candStride + g.candBase;
+    unsigned *key1 = candKey1 + (long long) f * candStride + g.candBase;
+    unsigned *val1 = candVal1 + (long long) f * candStride + g.candBase;
+    unsigned *xy = candXY + (long long) f * candStride + g.candBase;
+
+    // ---- 1. candidate offsets per cell (cell-major order == the reference's vToDistributeKeys order) ----
+    for (int i = tid; i < nCells; i += kOctBlock) S.cellPref[i] = cc[i];
+    __syncthreads();
+    const int M = block_scan_array(S.cellPref, nCells, s_tmp);
+    if (tid == 0) { S.cellPref[nCells] = M; lvlCandCnt[f * nlevels + l] = M; }
+    __syncthreads();
+    if (M == 0) {
+        if (tid == 0) *lvlCnt = 0;
+        return;
+    }
+    // ---- 2. path keys ----
+    for (int c = tid; c < nCells; c += kOctBlock) {
+        const int base = S.cellPref[c], n = S.cellPref[c + 1] - base;
+        const int ci = c / g.nCols, cj = c - ci * g.nCols;
+        for (int k = 0; k < n; k++) {
+            const unsigned e = sl[(long long) c * g.slotCap + k];
+            const int x = (int) (e & 255u) + cj * g.wCell, y = (int) ((e >> 8) & 255u) + ci * g.hCell;
+            const int i = base + k;
+            key0[i] = path_key(x, y, g);
+            val0[i] = ((e >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
+            xy[i] = (unsigned) x | ((unsigned) y << 16);
+        }
+    }
+    __syncthreads();
+    // ---- 3. sort by path key ----
+    unsigned *skeys, *svals;
+    block_radix_sort(key0, val0, key1, val1, M, g.keyBits, histT, s_tmp, &skeys, &svals);
+    // ---- 4. breadth-first subdivision on ranges ----
+    const int D = g.depth;
+    const int N = g.nFeat;
+    int cur = 0;
+    if (tid == 0) {
+        int n = 0;
+        int lo = 0;
+        for (int r = 0; r < g.nIni; r++) {  // roots in order; empty ones are erased (:566-575)
+            int a = lo, b = M;
+            while (a < b) {
+                const int m = (a + b) >> 1;
+                if ((int) (skeys[m] >> (2 * D)) <= r) a = m + 1; else b = m;
+            }
+            if (a > lo) { S.nlo[0][n] = lo; S.ncnt[0][n] = a - lo; S.ndep[0][n] = 0; n++; }
+            lo = a;
+        }
+        s_n = n;
+    }
+    __syncthreads();
+    int n = s_n;
+    bool finish = false;
+    while (!finish) {
+        const int prevSize = n;
+        // -- full pass (:588-640): every node with more than one point is divided
+        for (int i = tid; i < n; i += kOctBlock) {
+            const int cnt = S.ncnt[cur][i];
+            int k = 0, e = 0;
+            if (cnt > 1) {
+                const int lo = S.nlo[cur][i], shift = 2 * (D - (S.ndep[cur][i] + 1));
+                const int a1 = digit_lower_bound(skeys, lo, cnt, shift, 1u);
+                const int a2 = digit_lower_bound(skeys, a1, lo + cnt - a1, shift, 2u);
+                const int a3 = digit_lower_bound(skeys, a2, lo + cnt - a2, shift, 3u);
+                S.b1[i] = a1; S.b2[i] = a2; S.b3[i] = a3;
+                const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
+                k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+            }
+            S.kArr[i] = k; S.eArr[i] = e; S.sArr[i] = (cnt == 1);
+        }
+        __syncthreads();
+        const int totK = block_scan_array(S.kArr, n, s_tmp);
+        const int totE = block_scan_array(S.eArr, n, s_tmp);
+        const int totS = block_scan_array(S.sArr, n, s_tmp);
+        const int nxt = cur ^ 1;
+        for (int i = tid; i < n; i += kOctBlock) {
+            const int cnt = S.ncnt[cur][i], lo = S.nlo[cur][i], dep = S.ndep[cur][i];
+            if (cnt == 1) {
+                const int p = totK + S.sArr[i];
+                S.nlo[nxt][p] = lo; S.ncnt[nxt][p] = 1; S.ndep[nxt][p] = dep;
+            } else {
+                const int bb[5] = {lo, S.b1[i], S.b2[i], S.b3[i], lo + cnt};
+                int k = 0;
+                for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
+                int p = totK - (S.kArr[i] + k);  // children of later parents sit in front (push_front)
+                int epos[4];
+                for (int c = 3; c >= 0; c--) {   // list order n4,n3,n2,n1
+                    const int cc2 = bb[c + 1] - bb[c];
+                    epos[c] = p;
+                    if (cc2 > 0) { S.nlo[nxt][p] = bb[c]; S.ncnt[nxt][p] = cc2; S.ndep[nxt][p] = dep + 1; p++; }
+                }
+                int es = S.eArr[i];
+                for (int c = 0; c < 4; c++) {    // creation order n1..n4
+                    const int cc2 = bb[c + 1] - bb[c];
+                    if (cc2 > 1) { S.Epos[es] = epos[c]; S.Ecnt[es] = cc2; es++; }
+                }
+            }
+        }
+        __syncthreads();
+        cur = nxt;
+        n = totK + totS;
+        int nE = totE;
+        if (n >= N || n == prevSize) {
+            finish = true;
+        } else if (n + 3 * nE > N) {
+            // -- "expand the biggest first" phase (:647-700)
+            while (!finish) {
+                const int prev2 = n;
+                if (nE == 0) { finish = true; break; }  // nothing left to expand: list size cannot change (:696)
+                int seqBits = 1;
+                while ((1 << seqBits) < max(nE, 2)) seqBits++;
+                int cntBits = 1;
+                while ((1 << cntBits) <= M) cntBits++;
+                for (int j = tid; j < nE; j += kOctBlock) {
+                    S.sk[0][j] = ((unsigned) S.Ecnt[j] << seqBits) | (unsigned) j;
+                    S.sv[0][j] = (unsigned) j;
+                }
+                for (int j = tid; j < n; j += kOctBlock) S.flag[j] = 0;
+                if (tid == 0) s_cut = nE - 1;
+                __syncthreads();
+                unsigned *ek, *ev;
+                block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], nE, seqBits + cntBits, histT, s_tmp, &ek, &ev);
+                // processing order j: descending (size, creation seq)
+                for (int j = tid; j < nE; j += kOctBlock) {
+                    const int e = (int) ev[nE - 1 - j];
+                    const int pos = S.Epos[e];
+                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos], shift = 2 * (D - (S.ndep[cur][pos] + 1));
+                    const int a1 = digit_lower_bound(skeys, lo, cnt, shift, 1u);
+                    const int a2 = digit_lower_bound(skeys, a1, lo + cnt - a1, shift, 2u);
+                    const int a3 = digit_lower_bound(skeys, a2, lo + cnt - a2, shift, 3u);
+                    S.b1[j] = a1; S.b2[j] = a2; S.b3[j] = a3;
+                    const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
+                    S.kArr[j] = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) - 1;  // growth of the list
+                    S.eArr[j] = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                }
+                __syncthreads();
+                block_scan_array(S.kArr, nE, s_tmp);  // exclusive growth before j
+                for (int j = tid; j < nE; j += kOctBlock) {
+                    const int e = (int) ev[nE - 1 - j];
+                    const int pos = S.Epos[e];
+                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos];
+                    const int bb[5] = {lo, S.b1[j], S.b2[j], S.b3[j], lo + cnt};
+                    int k = 0;
+                    for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
+                    const int excl = S.kArr[j], incl = excl + k - 1;
+                    if (n + incl >= N && n + excl < N) s_cut = j;  // first expansion that reaches N nodes: break
+                }
+                __syncthreads();
+                const int nProc = s_cut + 1;
+                // nodes j >= nProc are not expanded: no children, no new expandable entries
+                for (int j = tid; j < nE; j += kOctBlock) {
+                    if (j >= nProc) S.eArr[j] = 0;
+                    else S.flag[S.Epos[(int) ev[nE - 1 - j]]] = 1;
+                }
+                __syncthreads();
+                const int totE2 = block_scan_array(S.eArr, nE, s_tmp);
+                // children of the processed nodes: total = growth + nProc
+                int totC;
+                {
+                    // growth before nProc-1 plus its own
+                    const int jl = nProc - 1;
+                    const int e = (int) ev[nE - 1 - jl];
+                    const int pos = S.Epos[e];
+                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos];
+                    const int bb[5] = {lo, S.b1[jl], S.b2[jl], S.b3[jl], lo + cnt};
+                    int k = 0;
+                    for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
+                    totC = S.kArr[jl] + jl + k;
+                }
+                // unprocessed old nodes keep their order behind the new children
+                for (int i = tid; i < n; i += kOctBlock) S.sArr[i] = 1 - S.flag[i];
+                __syncthreads();
+                block_scan_array(S.sArr, n, s_tmp);
+                const int nxt2 = cur ^ 1;
+                for (int i = tid; i < n; i += kOctBlock) {
+                    if (!S.flag[i]) {
+                        const int p = totC + S.sArr[i];
+                        S.nlo[nxt2][p] = S.nlo[cur][i]; S.ncnt[nxt2][p] = S.ncnt[cur][i]; S.ndep[nxt2][p] = S.ndep[cur][i];
+                    }
+                }
+                // new expandable list goes to the sort buffers first (Epos/Ecnt are still being read)
+                unsigned *nEpos = (ek == S.sk[0]) ? S.sk[1] : S.sk[0];
+                unsigned *nEcnt = (ev == S.sv[0]) ? S.sv[1] : S.sv[0];
+                for (int j = tid; j < nProc; j += kOctBlock) {
+                    const int e = (int) ev[nE - 1 - j];
+                    const int pos = S.Epos[e];
+                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos], dep = S.ndep[cur][pos];
+                    const int bb[5] = {lo, S.b1[j], S.b2[j], S.b3[j], lo + cnt};
+                    int k = 0;
+                    for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
+                    const int before = S.kArr[j] + j;     // children created by earlier-processed nodes
+                    int p = totC - (before + k);
+                    int epos[4];
+                    for (int c = 3; c >= 0; c--) {
+                        const int cc2 = bb[c + 1] - bb[c];
+                        epos[c] = p;
+                        if (cc2 > 0) { S.nlo[nxt2][p] = bb[c]; S.ncnt[nxt2][p] = cc2; S.ndep[nxt2][p] = dep + 1; p++; }
+                    }
+                    int es = S.eArr[j];
+                    for (int c = 0; c < 4; c++) {
+                        const int cc2 = bb[c + 1] - bb[c];
+                        if (cc2 > 1) { nEpos[es] = (unsigned) epos[c]; nEcnt[es] = (unsigned) cc2; es++; }
+                    }
+                }
+                __syncthreads();
+                for (int j = tid; j < totE2; j += kOctBlock) { S.Epos[j] = (int) nEpos[j]; S.Ecnt[j] = (int) nEcnt[j]; }
+                __syncthreads();
+                cur = nxt2;
+                n = totC + (n - nProc);
+                nE = totE2;
+                if (n >= N || n == prev2) finish = true;
+            }
+        }
+    }
+    // ---- 5. best response per node (:702-720), output in list order ----
+    unsigned *oxy = lvlKpXY + (long long) f * kpStride + g.kpBase;
+    unsigned char *osc = lvlKpScore + (long long) f * kpStride + g.kpBase;
+    const int lane = lane_id(), wave = wave_id();
+    for (int i = wave; i < n; i += kOctBlock / 64) {
+        const int lo = S.nlo[cur][i], cnt = S.ncnt[cur][i];
+        unsigned best = 0;
+        for (int k = lane; k < cnt; k += 64) best = max(best, svals[lo + k]);
+        best = wave_max_u32(best);
+        if (lane == 0) {
+            const unsigned idx = 0xFFFFFFu - (best & 0xFFFFFFu);
+            const unsigned p = xy[idx];
+            oxy[i] = ((p & 0xFFFFu) + kBorder) | (((p >> 16) + kBorder) << 16);
+            osc[i] = (unsigned char) (best >> 24);
+        }
+    }
+    if (tid == 0) *lvlCnt = n;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K5+K6+K7  orientation + local blur + rBRIEF.  One wave per keypoint: a 43x43 window of the (un-blurred) level is
+// staged in LDS (REFLECT_101 at the image border, as the blur of the border-less clone does); the intensity-centroid
+// moments use the inner 31x31 disc; the 7x7 sigma=2 fixed-point Gaussian {18,34,49,55,49,34,18}/256 is evaluated only
+// on the 37x37 pixels the rotated pattern can reach (|coord| <= 18); 4 ballots give the 4x64 descriptor bits.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, source order, no FMA
+    const float k = (float) (180.0 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k,
+                p7 = -0.04432655554792128f * k;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float) 2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float) 2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// float cos/sin of angle_deg * (float)(pi/180): double-precision quadrant reduction + fdlibm kernel polynomials,
+// rounded to float.  Operation sequence identical to the CPU definition (plain * and +, no FMA).
+__device__ __forceinline__ void sincos_deg(float angle_deg, float *c_out, float *s_out) {
+    const float factorPI = (float) (3.14159265358979323846 / 180.f);
+    const float angle = angle_deg * factorPI;
+    const double x = (double) angle;
+    const double TWO_OVER_PI = 6.36619772367581382433e-01, PIO2_1 = 1.57079632673412561417e+00,
+                 PIO2_1T = 6.07710050650619224932e-11;
+    const double kd = floor(x * TWO_OVER_PI + 0.5);
+    const int k = (int) kd;
+    const double r = (x - kd * PIO2_1) - kd * PIO2_1T;
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double sr = r + (z * r) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double cr = 1.0 - (0.5 * z - z * rc);
+    double s, c;
+    switch (k & 3) {
+        case 0: s = sr; c = cr; break;
+        case 1: s = cr; c = -sr; break;
+        case 2: s = -sr; c = -cr; break;
+        default: s = -cr; c = sr; break;
+    }
+    *c_out = (float) c;
+    *s_out = (float) s;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+// Orders this wave's LDS writes before its later LDS reads by other lanes (each wave owns a private LDS region, so
+// no block barrier is needed -- and none is allowed: waves of a block may exit early).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kWin = 43, kWinP = 44;    // raw window
+constexpr int kHb = 37, kHbP = 38;      // horizontally blurred: 43 rows x 37 cols (u16)
+constexpr int kBl = 37, kBlP = 40;      // blurred 37x37 (u8)
+constexpr int kDescWaves = 4;
+
+struct DescLds {
+    uint8_t raw[kWin * kWinP];
+    unsigned short hb[kWin * kHbP];
+    uint8_t bl[kBl * kBlP];
+};
+
+__constant__ int8_t c_pattern[1024];
+__constant__ int c_umax[16];
+
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
+                                                            const unsigned *__restrict__ lvlKpXY,
+                                                            const unsigned char *__restrict__ lvlKpScore,
+                                                            const int *__restrict__ lvlKpCnt, int kpStride,
+                                                            ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
+                                                            int *__restrict__ outCnt, int outStride) {
+    __shared__ DescLds lds[kDescWaves];
+    const int lane = lane_id(), wave = wave_id();
+    const int f = blockIdx.y;
+    const int slot = blockIdx.x * kDescWaves + wave;  // index into the frame's concatenated level lists
+    const int *cnts = lvlKpCnt + f * nlevels;
+    int l = 0, base = 0, total = 0;
+    {
+        int acc = 0;
+        bool found = false;
+        for (int i = 0; i < nlevels; i++) {
+            const int c = cnts[i];
+            if (!found && slot < acc + c) { l = i; base = acc; found = true; }
+            acc += c;
+        }
+        total = acc;
+        if (slot == 0 && lane == 0) outCnt[f] = total;
+        if (!found) return;
+    }
+    const LevelGeom g = geom[l];
+    const int li = slot - base;
+    const unsigned pxy = lvlKpXY[(long long) f * kpStride + g.kpBase + li];
+    const int kx = pxy & 0xFFFFu, ky = pxy >> 16;
+    const int score = lvlKpScore[(long long) f * kpStride + g.kpBase + li];
+    int pitch;
+    const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
+    DescLds &L = lds[wave];
+    // stage the 43x43 window (rows ky-21..ky+21), reflecting at the image border
+    for (int idx = lane; idx < kWin * kWin; idx += 64) {
+        const int r = idx / kWin, c = idx - r * kWin;
+        const int yy = reflect101(ky - 21 + r, g.h), xx = reflect101(kx - 21 + c, g.w);
+        L.raw[r * kWinP + c] = img[(long long) yy * pitch + xx];
+    }
+    wave_lds_sync();  // LDS writes of this wave are visible to all its lanes before the reads below
+    // intensity centroid on the 31x31 disc (centre = raw[21][21])
+    int m10 = 0, m01 = 0;
+    for (int idx = lane; idx < 31 * 31; idx += 64) {
+        const int v = idx / 31 - 15, u = idx - (idx / 31) * 31 - 15;
+        if (abs(u) <= c_umax[abs(v)]) {
+            const int I = L.raw[(21 + v) * kWinP + 21 + u];
+            m10 += u * I;
+            m01 += v * I;
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float) m01, (float) m10);
+    // separable blur, horizontal then vertical
+    for (int idx = lane; idx < kWin * kHb; idx += 64) {
+        const int r = idx / kHb, c = idx - r * kHb;
+        const uint8_t *p = &L.raw[r * kWinP + c];
+        L.hb[r * kHbP + c] = (unsigned short) (18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < kBl * kBl; idx += 64) {
+        const int r = idx / kBl, c = idx - r * kBl;
+        const unsigned short *p = &L.hb[r * kHbP + c];
+        const int s = 18 * (p[0] + p[6 * kHbP]) + 34 * (p[kHbP] + p[5 * kHbP]) + 49 * (p[2 * kHbP] + p[4 * kHbP]) + 55 * p[3 * kHbP];
+        const int v = (s + 32768) >> 16;
+        L.bl[r * kBlP + c] = (uint8_t) min(v, 255);
+    }
+    wave_lds_sync();
+    float a, b;
+    sincos_deg(angle, &a, &b);
+    unsigned long long bits[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int p = it * 64 + lane;
+        const float x0 = (float) c_pattern[4 * p], y0 = (float) c_pattern[4 * p + 1];
+        const float x1 = (float) c_pattern[4 * p + 2], y1 = (float) c_pattern[4 * p + 3];
+        const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = L.bl[(18 + r0) * kBlP + 18 + q0], t1 = L.bl[(18 + r1) * kBlP + 18 + q1];
+        bits[it] = __ballot(t0 < t1);
+    }
+    ygzf_kp *ok = outKp + (long long) f * outStride + slot;
+    uint8_t *od = outDesc + ((long long) f * outStride + slot) * 32;
+    if (lane < 4) ((unsigned long long *) od)[lane] = bits[lane];
+    if (lane == 0) {
+        ygzf_kp kp;
+        if (l == 0) { kp.x = (float) kx; kp.y = (float) ky; }
+        else { kp.x = (float) kx * g.scale; kp.y = (float) ky * g.scale; }  // keypoint->pt *= scale (:1016-1021)
+        kp.size = g.kpSize;
+        kp.angle = angle;
+        kp.response = (float) score;
+        kp.octave = l;
+        kp.class_id = -1;
+        *ok = kp;
+    }
+}
+
+// batched DescriptorDistance: popcount over 4 x u64
+__global__ void k_hamming_pairs(const unsigned long long *__restrict__ a, const unsigned long long *__restrict__ b, int n,
+                                int *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) d += __popcll(a[4 * i + k] ^ b[4 * i + k]);
+    out[i] = d;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------------------
+hipError_t upload_constants(const int *umax16) {
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kBriefPattern, 1024);
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
+}
+
+void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
+                       const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
+    dim3 grid((g.w + 255) / 256, g.h, nFrames);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+}
+
+void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
+                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int nFrames) {
+    if (totalCells <= 0) return;
+    hipLaunchKernelGGL(k_fast_cells, dim3(totalCells, nFrames), dim3(kFastBlock), 0, st, fs, dGeom, nlevels, iniTh, minTh,
+                       cellCnt, slots, totalCells, totalSlots);
+}
+
+size_t octree_lds_bytes(int maxCellsPerLevel, int cap) { return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 19 * (size_t) cap); }
+
+hipError_t octree_prepare(size_t ldsBytes) {
+    return hipFuncSetAttribute((const void *) k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+}
+
+void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
+                   int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
+                   long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
+                   int kpStride, int cap, size_t ldsBytes, int nFrames) {
+    hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots,
+                       totalCells, totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt,
+                       kpStride, cap);
+}
+
+void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
+                     const unsigned char *lvlKpScore, const int *lvlKpCnt, int kpStride, ygzf_kp *outKp, uint8_t *outDesc,
+                     int *outCnt, int outStride, int nFrames) {
+    dim3 grid((kpStride + kDescWaves - 1) / kDescWaves, nFrames);
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpXY, lvlKpScore, lvlKpCnt,
+                       kpStride, outKp, outDesc, outCnt, outStride);
+}
+
+void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out) {
+    hipLaunchKernelGGL(k_hamming_pairs, dim3((n + 255) / 256), dim3(256), 0, st, (const unsigned long long *) a,
+                       (const unsigned long long *) b, n, out);
+}
+
+}  // namespace ygzf

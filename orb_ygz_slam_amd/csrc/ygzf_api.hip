@@ -1,0 +1,733 @@
+// ygzf_api.hip -- the C ABI of libygzf (include/ygzf.h): context, geometry tables, buffer management and the launch
+// sequence of the extractor hot path.  Product code: no CPU fallback, nothing from oracle/ is included or linked.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "kernels.h"
+
+namespace ygzf {
+
+int cv_round_host(double v) { return (int) std::nearbyint(v); }  // cvRound: round half to even
+
+// ORBextractor::ORBextractor, reference src/ORBextractor.cc:412-470 (scale tables, per-level quota, umax)
+void Tables::init(const ygzf_extractor_cfg &c) {
+    cfg = c;
+    const int L = c.nlevels;
+    scale.assign(L, 1.f);
+    sigma2.assign(L, 1.f);
+    invScale.assign(L, 1.f);
+    invSigma2.assign(L, 1.f);
+    for (int i = 1; i < L; i++) {
+        scale[i] = scale[i - 1] * c.scale_factor;
+        sigma2[i] = scale[i] * scale[i];
+    }
+    for (int i = 0; i < L; i++) {
+        invScale[i] = 1.0f / scale[i];
+        invSigma2[i] = 1.0f / sigma2[i];
+    }
+    nFeat.assign(L, 0);
+    const float factor = 1.0f / c.scale_factor;
+    float want = c.nfeatures * (1 - factor) / (1 - (float) std::pow((double) factor, (double) L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        nFeat[l] = cv_round_host(want);
+        sum += nFeat[l];
+        want *= factor;
+    }
+    nFeat[L - 1] = std::max(c.nfeatures - sum, 0);
+    // circular patch row ends (:455-469)
+    int v, v0;
+    const int vmax = (int) std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int) std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round_host(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+void Tables::levelSize(int w, int h, int level, int *lw, int *lh) const {  // :1131-1132
+    const float s = invScale[level];
+    *lw = cv_round_host((float) w * s);
+    *lh = cv_round_host((float) h * s);
+}
+
+static inline short sat_short(float v) {
+    int i = cv_round_host((double) v);
+    return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
+}
+
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_COUNT };
+static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs"};
+
+struct Geometry {
+    int w = 0, h = 0;
+    std::vector<LevelGeom> lv;
+    std::vector<int> xofs, yofs;
+    std::vector<short> xalpha, ybeta;
+    long long pyrBytes = 0;   // per frame, levels >= 1
+    int totalCells = 0, maxCellsPerLevel = 0;
+    long long totalSlots = 0;
+    long long candStride = 0;
+    int kpStride = 0, kpCapMax = 0;
+};
+
+}  // namespace ygzf
+
+using namespace ygzf;
+
+struct ygzf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Tables tab;
+    int maxW = 0, maxH = 0, maxBatch = 0;
+    Geometry geo;
+    std::string err;
+    // device buffers (grow-only)
+    struct Buf {
+        void *p = nullptr;
+        size_t bytes = 0;
+    };
+    Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
+        dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC;
+    size_t octLds = 0;
+    // batch state
+    int lastFrames = 0;
+    FrameSet lastFs{};
+    int img0Pitch = 0;
+    // timing
+    hipEvent_t tStart = nullptr, tStop = nullptr;
+    bool profile = false;
+    struct Rec { int kind; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    float profMs[KK_COUNT] = {0};
+    int profN[KK_COUNT] = {0};
+};
+
+static std::string g_create_err;
+static std::mutex g_create_mu;
+
+static int fail(ygzf_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else {
+        std::lock_guard<std::mutex> lk(g_create_mu);
+        g_create_err = buf;
+    }
+    return code;
+}
+
+#define HIPCHECK(c, expr)                                                                                         \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) return fail(c, YGZF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                                    \
+    } while (0)
+
+static int ensure(ygzf_ctx *c, ygzf_ctx::Buf &b, size_t bytes) {
+    if (bytes <= b.bytes) return YGZF_OK;
+    if (b.p) HIPCHECK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIPCHECK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return YGZF_OK;
+}
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// Per-(w,h) geometry: level sizes, resize coefficient tables (cv::resize INTER_LINEAR fixed point, restated from the
+// OpenCV 2.4/3.2 algorithm: fx = (float)((dx+0.5)*scale - 0.5), 11-bit coefficients), FAST cell grid (:733-745),
+// octree root layout (:537-557) and buffer offsets.
+static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
+    const Tables &T = c->tab;
+    const int L = T.cfg.nlevels;
+    G = Geometry();
+    G.w = w;
+    G.h = h;
+    G.lv.assign(L, LevelGeom());
+    long long off = 0, slotBase = 0, candBase = 0;
+    int cellBase = 0, kpBase = 0;
+    for (int l = 0; l < L; l++) {
+        LevelGeom &g = G.lv[l];
+        memset(&g, 0, sizeof g);
+        T.levelSize(w, h, l, &g.w, &g.h);
+        if (g.w < 1 || g.h < 1) return fail(c, YGZF_ERR_UNSUPPORTED, "pyramid level %d of a %dx%d image is empty", l, w, h);
+        if (g.w > 4096 + 2 * kBorder || g.h > 4096 + 2 * kBorder)
+            return fail(c, YGZF_ERR_UNSUPPORTED, "level %d is %dx%d: larger than 4128 px is not supported", l, g.w, g.h);
+        g.pitch = align_up(g.w, 64);
+        g.scale = T.scale[l];
+        g.kpSize = (float) (int) (kPatchSize * T.scale[l]);  // :789 int truncation of a float product
+        g.nFeat = T.nFeat[l];
+        if (l > 0) {
+            g.off = off;
+            off += (long long) g.pitch * g.h;
+            const LevelGeom &s = G.lv[l - 1];
+            g.area2x = (s.w == 2 * g.w && s.h == 2 * g.h);
+            g.xtab = (int) G.xofs.size();
+            g.ytab = (int) G.yofs.size();
+            const double scale_x = 1. / ((double) g.w / s.w), scale_y = 1. / ((double) g.h / s.h);
+            for (int dx = 0; dx < g.w; dx++) {
+                float fx = (float) ((dx + 0.5) * scale_x - 0.5);
+                int sx = (int) std::floor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= s.w - 1) { fx = 0; sx = s.w - 1; }
+                G.xofs.push_back(sx);
+                G.xalpha.push_back(sat_short((1.f - fx) * 2048));
+                G.xalpha.push_back(sat_short(fx * 2048));
+            }
+            for (int dy = 0; dy < g.h; dy++) {
+                float fy = (float) ((dy + 0.5) * scale_y - 0.5);
+                int sy = (int) std::floor(fy);
+                fy -= sy;
+                G.yofs.push_back(sy);
+                G.ybeta.push_back(sat_short((1.f - fy) * 2048));
+                G.ybeta.push_back(sat_short(fy * 2048));
+            }
+        }
+        // FAST cells
+        g.maxBorderX = g.w - kEdgeThreshold + 3;
+        g.maxBorderY = g.h - kEdgeThreshold + 3;
+        const float width = (float) (g.maxBorderX - kBorder), height = (float) (g.maxBorderY - kBorder);
+        g.regW = g.maxBorderX - kBorder;
+        g.regH = g.maxBorderY - kBorder;
+        int nCols = width > 0 ? (int) (width / 30.f) : 0, nRows = height > 0 ? (int) (height / 30.f) : 0;
+        if (nCols < 1 || nRows < 1) nCols = nRows = 0;  // reference: division by zero (UB) -> defined as "no keypoints"
+        g.nCols = nCols;
+        g.nRows = nRows;
+        g.cellBase = cellBase;
+        g.slotBase = slotBase;
+        g.candBase = candBase;
+        g.kpBase = kpBase;
+        if (nCols) {
+            g.wCell = (int) std::ceil(width / nCols);
+            g.hCell = (int) std::ceil(height / nRows);
+            g.slotCap = ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
+            const int nc = nCols * nRows;
+            cellBase += nc;
+            slotBase += (long long) nc * g.slotCap;
+            g.candCap = nc * g.slotCap;
+            candBase += g.candCap;
+            G.maxCellsPerLevel = std::max(G.maxCellsPerLevel, nc);
+            // octree roots
+            int nIni = (int) std::round((float) g.regW / (float) g.regH);
+            if (nIni < 1) nIni = 1;  // reference: UB for tall-narrow regions; defined as one root
+            g.nIni = nIni;
+            g.hX = (float) g.regW / nIni;
+            int rootW = 1;
+            for (int i = 0; i < nIni; i++)
+                rootW = std::max(rootW, (int) (g.hX * (float) (i + 1)) - (int) (g.hX * (float) i));
+            int D = 1;
+            while ((1 << D) < std::max(std::max(rootW, g.regH), 2)) D++;
+            g.depth = D + 1;
+            int rootBits = 0;
+            while ((1 << rootBits) < nIni) rootBits++;
+            g.keyBits = rootBits + 2 * g.depth;
+            if (g.keyBits > 32) return fail(c, YGZF_ERR_UNSUPPORTED, "octree path key needs %d bits at level %d", g.keyBits, l);
+            g.kpCap = std::max(g.nFeat + 3, 4 * nIni) + 1;
+        } else {
+            g.nIni = 1;
+            g.hX = 1.f;
+            g.kpCap = 0;
+        }
+        kpBase += g.kpCap;
+        G.kpCapMax = std::max(G.kpCapMax, g.kpCap);
+    }
+    G.pyrBytes = off;
+    G.totalCells = cellBase;
+    G.totalSlots = slotBase;
+    G.candStride = candBase;
+    G.kpStride = kpBase;
+    if (G.totalCells > 0 && (size_t) G.candStride > 0xFFFFFEull)
+        return fail(c, YGZF_ERR_UNSUPPORTED, "more than 2^24 candidate slots per frame");
+    return YGZF_OK;
+}
+
+static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
+    if (w < 1 || h < 1) return fail(c, YGZF_ERR_INVALID, "image size %dx%d", w, h);
+    if (w > c->maxW || h > c->maxH) return fail(c, YGZF_ERR_INVALID, "image %dx%d exceeds the context maximum %dx%d", w, h, c->maxW, c->maxH);
+    if (nFrames < 1 || nFrames > c->maxBatch) return fail(c, YGZF_ERR_INVALID, "batch of %d frames (context maximum %d)", nFrames, c->maxBatch);
+    const int L = c->tab.cfg.nlevels;
+    if (c->geo.w != w || c->geo.h != h) {
+        Geometry G;
+        int rc = build_geometry(c, w, h, G);
+        if (rc) return rc;
+        c->geo = G;
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        rc = ensure(c, c->dGeom, sizeof(LevelGeom) * L);
+        if (rc) return rc;
+        HIPCHECK(c, hipMemcpy(c->dGeom.p, G.lv.data(), sizeof(LevelGeom) * L, hipMemcpyHostToDevice));
+        struct { ygzf_ctx::Buf *b; const void *src; size_t bytes; } up[4] = {
+            {&c->dXofs, G.xofs.data(), G.xofs.size() * sizeof(int)},
+            {&c->dXalpha, G.xalpha.data(), G.xalpha.size() * sizeof(short)},
+            {&c->dYofs, G.yofs.data(), G.yofs.size() * sizeof(int)},
+            {&c->dYbeta, G.ybeta.data(), G.ybeta.size() * sizeof(short)}};
+        for (auto &u : up) {
+            rc = ensure(c, *u.b, std::max<size_t>(u.bytes, 16));
+            if (rc) return rc;
+            if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
+        }
+        c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax);
+        if (c->octLds > 160 * 1024 - 2048)
+            return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
+                        G.maxCellsPerLevel, G.kpCapMax);
+        HIPCHECK(c, octree_prepare(c->octLds));
+    }
+    const Geometry &G = c->geo;
+    const size_t B = (size_t) nFrames;
+    int rc = 0;
+    if ((rc = ensure(c, c->dPyr, std::max<size_t>(B * G.pyrBytes, 16)))) return rc;
+    if ((rc = ensure(c, c->dCellCnt, std::max<size_t>(B * G.totalCells * sizeof(unsigned short), 16)))) return rc;
+    if ((rc = ensure(c, c->dSlots, std::max<size_t>(B * G.totalSlots * sizeof(unsigned), 16)))) return rc;
+    const size_t cb = std::max<size_t>(B * G.candStride * sizeof(unsigned), 16);
+    if ((rc = ensure(c, c->dK0, cb)) || (rc = ensure(c, c->dV0, cb)) || (rc = ensure(c, c->dK1, cb)) || (rc = ensure(c, c->dV1, cb)) ||
+        (rc = ensure(c, c->dXY, cb)))
+        return rc;
+    const size_t kp = std::max<size_t>(B * G.kpStride, 16);
+    if ((rc = ensure(c, c->dLvlXY, kp * sizeof(unsigned))) || (rc = ensure(c, c->dLvlScore, kp)) ||
+        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
+        (rc = ensure(c, c->dOutKp, kp * sizeof(ygzf_kp))) || (rc = ensure(c, c->dOutDesc, kp * 32)) ||
+        (rc = ensure(c, c->dOutCnt, B * sizeof(int))))
+        return rc;
+    return YGZF_OK;
+}
+
+// ---- per-kernel event bracketing ------------------------------------------------------------------------------------
+static hipEvent_t take_event(ygzf_ctx *c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    ygzf_ctx *c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ygzf_ctx *c_, int k) : c(c_), kind(k) {
+        if (c->profile) {
+            a = take_event(c);
+            b = take_event(c);
+            (void) hipEventRecord(a, c->stream);
+        }
+    }
+    ~ProfScope() {
+        if (c->profile) {
+            (void) hipEventRecord(b, c->stream);
+            c->recs.push_back({kind, a, b});
+        }
+    }
+};
+static void drain_profile(ygzf_ctx *c) {
+    if (c->recs.empty()) return;
+    (void) hipStreamSynchronize(c->stream);
+    for (auto &r : c->recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->profMs[r.kind] += ms;
+            c->profN[r.kind]++;
+        }
+        c->pool.push_back(r.a);
+        c->pool.push_back(r.b);
+    }
+    c->recs.clear();
+}
+
+// The launch sequence of ORBextractor::operator()(image...) for a batch resident on the device.
+static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
+    const Geometry &G = c->geo;
+    const int L = c->tab.cfg.nlevels;
+    const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
+    for (int l = 1; l < L; l++) {
+        ProfScope ps(c, KK_PYR);
+        launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
+                          (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+    }
+    if (G.totalCells > 0) {
+        {
+            ProfScope ps(c, KK_FAST);
+            launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
+                              (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, nFrames);
+        }
+        {
+            ProfScope ps(c, KK_OCTREE);
+            launch_octree(c->stream, dGeom, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                          G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
+                          (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
+                          (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p, G.kpStride,
+                          G.kpCapMax, c->octLds, nFrames);
+        }
+        {
+            ProfScope ps(c, KK_DESCRIBE);
+            launch_describe(c->stream, fs, dGeom, L, (const unsigned *) c->dLvlXY.p, (const unsigned char *) c->dLvlScore.p,
+                            (const int *) c->dLvlCnt.p, G.kpStride, (ygzf_kp *) c->dOutKp.p, (uint8_t *) c->dOutDesc.p,
+                            (int *) c->dOutCnt.p, G.kpStride, nFrames);
+        }
+    } else {
+        HIPCHECK(c, hipMemsetAsync(c->dOutCnt.p, 0, sizeof(int) * nFrames, c->stream));
+        HIPCHECK(c, hipMemsetAsync(c->dLvlCnt.p, 0, sizeof(int) * nFrames * L, c->stream));
+        HIPCHECK(c, hipMemsetAsync(c->dLvlCand.p, 0, sizeof(int) * nFrames * L, c->stream));
+    }
+    HIPCHECK(c, hipGetLastError());
+    c->lastFrames = nFrames;
+    c->lastFs = fs;
+    return YGZF_OK;
+}
+
+static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, int row_pitch, size_t frame_stride,
+                         FrameSet *fs) {
+    const int pitch = align_up(w, 64);
+    int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
+    if (rc) return rc;
+    for (int f = 0; f < nFrames; f++)
+        HIPCHECK(c, hipMemcpy2DAsync((uint8_t *) c->dImg0.p + (size_t) f * pitch * h, pitch, imgs + f * frame_stride, row_pitch, w, h,
+                                     hipMemcpyHostToDevice, c->stream));
+    fs->img0 = (const uint8_t *) c->dImg0.p;
+    fs->img0_stride = (long long) pitch * h;
+    fs->img0_pitch = pitch;
+    fs->pyr = (uint8_t *) c->dPyr.p;
+    fs->pyr_stride = c->geo.pyrBytes;
+    return YGZF_OK;
+}
+
+extern "C" {
+
+int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int max_height, int max_batch, ygzf_ctx **out) {
+    if (!cfg || !out) return fail(nullptr, YGZF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 0 || !(cfg->scale_factor > 1.0f) || cfg->ini_th_fast < 0 ||
+        cfg->min_th_fast < 0 || cfg->ini_th_fast > 255 || cfg->min_th_fast > 255 || cfg->min_th_fast > cfg->ini_th_fast)
+        return fail(nullptr, YGZF_ERR_INVALID, "bad extractor configuration (nlevels 1..%d, scale_factor > 1, 0 <= minTh <= iniTh <= 255)",
+                    kMaxLevels);
+    if (max_width < 1 || max_height < 1 || max_batch < 1) return fail(nullptr, YGZF_ERR_INVALID, "bad maximum sizes");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, YGZF_ERR_NO_DEVICE, "no HIP device available (%s): libygzf has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, YGZF_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+    ygzf_ctx *c = new ygzf_ctx();
+    c->device = device;
+    c->maxW = max_width;
+    c->maxH = max_height;
+    c->maxBatch = max_batch;
+    c->tab.init(*cfg);
+    auto bail = [&](int rc) {
+        g_create_err = c->err;
+        ygzf_destroy(c);
+        return rc;
+    };
+#define CK(expr)                                                                                                   \
+    do {                                                                                                           \
+        hipError_t _e = (expr);                                                                                    \
+        if (_e != hipSuccess) {                                                                                    \
+            fail(c, YGZF_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e));                                  \
+            return bail(YGZF_ERR_HIP);                                                                             \
+        }                                                                                                          \
+    } while (0)
+    CK(hipSetDevice(device));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipEventCreate(&c->tStart));
+    CK(hipEventCreate(&c->tStop));
+    CK(upload_constants(c->tab.umax));
+#undef CK
+    // validate the largest configuration up front (and size the buffers once)
+    int rc = apply_geometry(c, max_width, max_height, max_batch);
+    if (rc) return bail(rc);
+    *out = c;
+    return YGZF_OK;
+}
+
+void ygzf_destroy(ygzf_ctx *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
+                             &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
+                             &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC};
+    for (auto *b : bufs)
+        if (b->p) (void) hipFree(b->p);
+    for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
+    for (auto e : c->pool) (void) hipEventDestroy(e);
+    if (c->tStart) (void) hipEventDestroy(c->tStart);
+    if (c->tStop) (void) hipEventDestroy(c->tStop);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *ygzf_last_error(const ygzf_ctx *c) {
+    if (c) return c->err.c_str();
+    return g_create_err.c_str();
+}
+
+int ygzf_get_levels(const ygzf_ctx *c) { return c ? c->tab.cfg.nlevels : YGZF_ERR_INVALID; }
+
+int ygzf_get_scale_tables(const ygzf_ctx *c, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2) {
+    if (!c) return YGZF_ERR_INVALID;
+    const size_t n = sizeof(float) * c->tab.cfg.nlevels;
+    if (scale) memcpy(scale, c->tab.scale.data(), n);
+    if (inv_scale) memcpy(inv_scale, c->tab.invScale.data(), n);
+    if (sigma2) memcpy(sigma2, c->tab.sigma2.data(), n);
+    if (inv_sigma2) memcpy(inv_sigma2, c->tab.invSigma2.data(), n);
+    return YGZF_OK;
+}
+
+int ygzf_get_features_per_level(const ygzf_ctx *c, int *nfeat) {
+    if (!c || !nfeat) return YGZF_ERR_INVALID;
+    memcpy(nfeat, c->tab.nFeat.data(), sizeof(int) * c->tab.cfg.nlevels);
+    return YGZF_OK;
+}
+
+int ygzf_level_size(const ygzf_ctx *c, int w, int h, int level, int *lw, int *lh) {
+    if (!c || !lw || !lh || level < 0 || level >= c->tab.cfg.nlevels) return YGZF_ERR_INVALID;
+    c->tab.levelSize(w, h, level, lw, lh);
+    return YGZF_OK;
+}
+
+int ygzf_max_keypoints(const ygzf_ctx *c_, int w, int h) {
+    ygzf_ctx *c = const_cast<ygzf_ctx *>(c_);
+    if (!c) return YGZF_ERR_INVALID;
+    if (c->geo.w == w && c->geo.h == h) return c->geo.kpStride;
+    Geometry G;
+    int rc = build_geometry(c, w, h, G);
+    return rc ? rc : G.kpStride;
+}
+
+int ygzf_sync(ygzf_ctx *c) {
+    if (!c) return YGZF_ERR_INVALID;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, uint8_t *const *levels_out) {
+    if (!c || !img || !levels_out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, 1);
+    if (rc) return rc;
+    FrameSet fs;
+    if ((rc = upload_frames(c, img, 1, w, h, stride, 0, &fs))) return rc;
+    const Geometry &G = c->geo;
+    const int L = c->tab.cfg.nlevels;
+    for (int l = 1; l < L; l++) {
+        ProfScope ps(c, KK_PYR);
+        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, G.lv[l], l, 1, (const int *) c->dXofs.p,
+                          (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    for (int l = 0; l < L; l++) {
+        int pitch;
+        const uint8_t *p = level_ptr(fs, G.lv[l], l, 0, &pitch);
+        HIPCHECK(c, hipMemcpy2DAsync(levels_out[l], G.lv[l].w, p, pitch, G.lv[l].w, G.lv[l].h, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->lastFrames = 0;
+    return YGZF_OK;
+}
+
+int ygzf_extract_batch_device(ygzf_ctx *c, const uint8_t *d_imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride) {
+    if (!c || !d_imgs) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (row_pitch < w) return fail(c, YGZF_ERR_INVALID, "row_pitch %d < width %d", row_pitch, w);
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, n_frames);
+    if (rc) return rc;
+    FrameSet fs;
+    fs.img0 = d_imgs;
+    fs.img0_stride = (long long) frame_stride;
+    fs.img0_pitch = row_pitch;
+    fs.pyr = (uint8_t *) c->dPyr.p;
+    fs.pyr_stride = c->geo.pyrBytes;
+    return run_extract(c, fs, n_frames);
+}
+
+int ygzf_extract_batch_host(ygzf_ctx *c, const uint8_t *imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride) {
+    if (!c || !imgs) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (row_pitch < w) return fail(c, YGZF_ERR_INVALID, "row_pitch %d < width %d", row_pitch, w);
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, n_frames);
+    if (rc) return rc;
+    FrameSet fs;
+    if ((rc = upload_frames(c, imgs, n_frames, w, h, row_pitch, frame_stride, &fs))) return rc;
+    return run_extract(c, fs, n_frames);
+}
+
+int ygzf_batch_counts(ygzf_ctx *c, int *n_kp) {
+    if (!c || !n_kp) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    HIPCHECK(c, hipMemcpyAsync(n_kp, c->dOutCnt.p, sizeof(int) * c->lastFrames, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_batch_fetch(ygzf_ctx *c, int frame, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
+    if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (frame < 0 || frame >= c->lastFrames) return fail(c, YGZF_ERR_INVALID, "frame %d out of range", frame);
+    int n = 0;
+    HIPCHECK(c, hipMemcpyAsync(&n, (int *) c->dOutCnt.p + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    if (n == 0) return YGZF_OK;
+    if (n > cap || !kps || !desc) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d keypoints", cap, n);
+    const size_t base = (size_t) frame * c->geo.kpStride;
+    HIPCHECK(c, hipMemcpyAsync(kps, (ygzf_kp *) c->dOutKp.p + base, sizeof(ygzf_kp) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(desc, (uint8_t *) c->dOutDesc.p + base * 32, (size_t) 32 * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_extract(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
+    if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *n_out = 0;
+    if (!img || w <= 0 || h <= 0) return YGZF_OK;  // reference: `if (_image.empty()) return;`
+    int rc = ygzf_extract_batch_host(c, img, 1, w, h, stride, 0);
+    if (rc) return rc;
+    return ygzf_batch_fetch(c, 0, kps, desc, cap, n_out);
+}
+
+int ygzf_batch_fetch_level(ygzf_ctx *c, int frame, int level, uint8_t *out) {
+    if (!c || !out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (frame < 0 || frame >= c->lastFrames || level < 0 || level >= c->tab.cfg.nlevels) return fail(c, YGZF_ERR_INVALID, "bad frame/level");
+    int pitch;
+    const LevelGeom &g = c->geo.lv[level];
+    const uint8_t *p = level_ptr(c->lastFs, g, level, frame, &pitch);
+    HIPCHECK(c, hipMemcpy2DAsync(out, g.w, p, pitch, g.w, g.h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_batch_fetch_candidates(ygzf_ctx *c, int frame, int level, int *xs, int *ys, int *scores, int cap, int *n_out) {
+    if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (frame < 0 || frame >= c->lastFrames || level < 0 || level >= c->tab.cfg.nlevels) return fail(c, YGZF_ERR_INVALID, "bad frame/level");
+    const Geometry &G = c->geo;
+    const LevelGeom &g = G.lv[level];
+    const int nc = g.nCols * g.nRows;
+    *n_out = 0;
+    if (nc == 0) return YGZF_OK;
+    std::vector<unsigned short> cnt(nc);
+    std::vector<unsigned> sl((size_t) nc * g.slotCap);
+    HIPCHECK(c, hipMemcpyAsync(cnt.data(), (unsigned short *) c->dCellCnt.p + (size_t) frame * G.totalCells + g.cellBase,
+                               sizeof(unsigned short) * nc, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(sl.data(), (unsigned *) c->dSlots.p + (size_t) frame * G.totalSlots + g.slotBase,
+                               sizeof(unsigned) * sl.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    int n = 0;
+    for (int ci = 0; ci < nc; ci++) {
+        const int i = ci / g.nCols, j = ci % g.nCols;
+        for (int k = 0; k < cnt[ci]; k++, n++) {
+            if (n < cap && xs && ys && scores) {
+                const unsigned e = sl[(size_t) ci * g.slotCap + k];
+                xs[n] = (int) (e & 255u) + j * g.wCell;
+                ys[n] = (int) ((e >> 8) & 255u) + i * g.hCell;
+                scores[n] = (int) (e >> 16);
+            }
+        }
+    }
+    *n_out = n;
+    return n > cap ? fail(c, YGZF_ERR_INVALID, "capacity %d < %d candidates", cap, n) : YGZF_OK;
+}
+
+int ygzf_batch_fetch_level_keypoints(ygzf_ctx *c, int frame, int level, int *xs, int *ys, int *scores, int cap, int *n_out) {
+    if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    const int L = c->tab.cfg.nlevels;
+    if (frame < 0 || frame >= c->lastFrames || level < 0 || level >= L) return fail(c, YGZF_ERR_INVALID, "bad frame/level");
+    const Geometry &G = c->geo;
+    const LevelGeom &g = G.lv[level];
+    int n = 0;
+    HIPCHECK(c, hipMemcpyAsync(&n, (int *) c->dLvlCnt.p + frame * L + level, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    if (n == 0) return YGZF_OK;
+    if (n > cap) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d keypoints", cap, n);
+    std::vector<unsigned> xy(n);
+    std::vector<unsigned char> sc(n);
+    const size_t base = (size_t) frame * G.kpStride + g.kpBase;
+    HIPCHECK(c, hipMemcpyAsync(xy.data(), (unsigned *) c->dLvlXY.p + base, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(sc.data(), (unsigned char *) c->dLvlScore.p + base, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) {
+        xs[i] = (int) (xy[i] & 0xFFFFu);
+        ys[i] = (int) (xy[i] >> 16);
+        scores[i] = sc[i];
+    }
+    return YGZF_OK;
+}
+
+int ygzf_descriptor_distance(ygzf_ctx *c, const uint8_t *a, const uint8_t *b, int n, int *dist) {
+    if (!c || !a || !b || !dist || n < 0) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n == 0) return YGZF_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->dTmpA, (size_t) n * 32)) || (rc = ensure(c, c->dTmpB, (size_t) n * 32)) ||
+        (rc = ensure(c, c->dTmpC, (size_t) n * sizeof(int))))
+        return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->dTmpA.p, a, (size_t) n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->dTmpB.p, b, (size_t) n * 32, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KK_HAMMING);
+        launch_hamming_pairs(c->stream, c->dTmpA.p, c->dTmpB.p, n, (int *) c->dTmpC.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(dist, c->dTmpC.p, (size_t) n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_timer_start(ygzf_ctx *c) {
+    if (!c) return YGZF_ERR_INVALID;
+    HIPCHECK(c, hipEventRecord(c->tStart, c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_timer_stop(ygzf_ctx *c, float *elapsed_ms) {
+    if (!c || !elapsed_ms) return YGZF_ERR_INVALID;
+    HIPCHECK(c, hipEventRecord(c->tStop, c->stream));
+    HIPCHECK(c, hipEventSynchronize(c->tStop));
+    HIPCHECK(c, hipEventElapsedTime(elapsed_ms, c->tStart, c->tStop));
+    return YGZF_OK;
+}
+
+int ygzf_profile_enable(ygzf_ctx *c, int on) {
+    if (!c) return YGZF_ERR_INVALID;
+    drain_profile(c);
+    c->profile = on != 0;
+    return YGZF_OK;
+}
+
+int ygzf_profile_read(ygzf_ctx *c, const char **names, float *total_ms, int *launches, int cap) {
+    if (!c) return YGZF_ERR_INVALID;
+    drain_profile(c);
+    for (int k = 0; k < KK_COUNT && k < cap; k++) {
+        if (names) names[k] = kKernelNames[k];
+        if (total_ms) total_ms[k] = c->profMs[k];
+        if (launches) launches[k] = c->profN[k];
+    }
+    return KK_COUNT;
+}
+
+int ygzf_profile_reset(ygzf_ctx *c) {
+    if (!c) return YGZF_ERR_INVALID;
+    drain_profile(c);
+    for (int k = 0; k < KK_COUNT; k++) { c->profMs[k] = 0; c->profN[k] = 0; }
+    return YGZF_OK;
+}
+
+void *ygzf_stream(ygzf_ctx *c) { return c ? (void *) c->stream : nullptr; }
+
+}  // extern "C"

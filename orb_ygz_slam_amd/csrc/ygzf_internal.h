@@ -1,0 +1,79 @@
+// ygzf_internal.h -- shared host/device definitions of libygzf (product code; never includes oracle/).
+#ifndef YGZF_INTERNAL_H
+#define YGZF_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ygzf.h"
+
+namespace ygzf {
+
+constexpr int kPatchSize = 31;        // reference src/ORBextractor.cc:73
+constexpr int kHalfPatch = 15;        // :74
+constexpr int kEdgeThreshold = 19;    // :75
+constexpr int kBorder = kEdgeThreshold - 3;  // minBorderX of ComputeKeyPointsOctTree (:733)
+constexpr int kMaxLevels = 16;
+constexpr int kMaxCellWin = 66;       // window side of one FAST cell: wCell(<60)+6
+constexpr int kFastBlock = 256;
+constexpr int kOctBlock = 1024;
+
+// Geometry of one pyramid level; one table per (w,h) configuration, uploaded to the device.
+struct LevelGeom {
+    int w, h, pitch;          // level image; pitch in bytes (64-aligned) for levels >= 1
+    long long off;            // byte offset of the level inside one frame's pyramid slab (levels >= 1)
+    int area2x;               // 1: previous level is exactly 2x in both axes -> 2x2 area average (cv::resize quirk)
+    int xtab, ytab;           // offsets into the resize coefficient tables
+    // FAST cell grid, src/ORBextractor.cc:733-745
+    int nCols, nRows, wCell, hCell;
+    int maxBorderX, maxBorderY;
+    int cellBase;             // first cell of this level inside a frame's cell arrays
+    int slotCap;              // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2)
+    long long slotBase;       // first slot of this level inside a frame's slot array
+    // octree, :533-563
+    int regW, regH;           // maxBorderX-minBorderX, maxBorderY-minBorderY
+    int nIni;
+    float hX;
+    int depth;                // D: subdivisions encoded in the path key
+    int keyBits;              // root bits + 2*D
+    int nFeat;                // mnFeaturesPerLevel[level]
+    int kpCap, kpBase;        // capacity / base of this level inside a frame's level-keypoint arrays
+    long long candBase;       // base inside a frame's candidate scratch arrays
+    int candCap;              // nCells*slotCap
+    float scale;              // mvScaleFactor[level]
+    float kpSize;             // (float)(int)(PATCH_SIZE*scale)
+};
+
+struct FrameSet {
+    const uint8_t *img0;      // level 0 of frame 0
+    long long img0_stride;    // bytes between frames
+    int img0_pitch;
+    uint8_t *pyr;             // pyramid slab (levels >= 1) of frame 0
+    long long pyr_stride;
+};
+
+__host__ __device__ inline const uint8_t *level_ptr(const FrameSet &fs, const LevelGeom &g, int level, int frame, int *pitch) {
+    if (level == 0) {
+        *pitch = fs.img0_pitch;
+        return fs.img0 + (long long) frame * fs.img0_stride;
+    }
+    *pitch = g.pitch;
+    return fs.pyr + (long long) frame * fs.pyr_stride + g.off;
+}
+
+// Host-side tables of one extractor configuration (product restatement of ORBextractor's ctor).
+struct Tables {
+    ygzf_extractor_cfg cfg;
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> nFeat;
+    int umax[16];
+    void init(const ygzf_extractor_cfg &c);
+    void levelSize(int w, int h, int level, int *lw, int *lh) const;
+};
+
+int cv_round_host(double v);
+
+}  // namespace ygzf
+#endif
