@@ -102,6 +102,45 @@ int ygzf_batch_fetch_level_keypoints(ygzf_ctx *ctx, int frame, int level, int *x
  * Batched on the device: dist[i] = popcount(a[i] xor b[i]) over 256 bits, n pairs of 32-byte host descriptors. */
 int ygzf_descriptor_distance(ygzf_ctx *ctx, const uint8_t *a, const uint8_t *b, int n, int *dist);
 
+/* ---- ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono,
+ *      bool checkLevel)  src/ORBmatcher.cc:1218-1350, together with the Frame grid it searches
+ *      (Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea, src/Frame.cc:314-330, 483-493, 424-481) ------------
+ * Frame / MapPoint objects are passed as the plain arrays the function reads. */
+typedef struct ygzf_camera {         /* Frame statics: fx fy cx cy mb mbf (src/Frame.cc:27-33) and the image bounds mnMinX.. */
+    float fx, fy, cx, cy, mb, mbf;
+    float min_x, min_y, max_x, max_y;
+} ygzf_camera;
+
+typedef struct ygzf_frame_view {     /* the slice of `Frame` the matcher reads */
+    int n;                           /* Frame::N */
+    const ygzf_kp *keys;             /* mvKeys */
+    const uint8_t *desc;             /* mDescriptors, n x 32 */
+    const float *u_right;            /* mvuRight, or NULL for monocular (all -1) */
+    const float *scale_factors;      /* mvScaleFactors, or NULL to use the context's extractor tables */
+    int nlevels;
+} ygzf_frame_view;
+
+/* One (Last, Cur) pair from host arrays.
+ *   per Last keypoint i: mp_valid[i] (mvpMapPoints[i] != NULL; NULL array = all valid), outlier[i] (mvbOutlier; NULL = none),
+ *   mp_has_obs[i] (pMP->Observations() > 0; NULL = all), mp_world (GetWorldPos, n x 3), mp_desc (GetDescriptor, n x 32);
+ *   Rcw/tcw = CurrentFrame.mTcw, Rlw/tlw = LastFrame.mTcw (row-major 3x3 + 3).
+ *   cur_owner (in/out, cur->n bytes): state of CurrentFrame.mvpMapPoints: 0 NULL, 1 set by a point with no observations,
+ *   2 set by a point with Observations() > 0.  cur_match (out): index of the Last keypoint whose MapPoint was written to
+ *   CurrentFrame.mvpMapPoints[i2]; -1 untouched; -2 written, then reset to NULL by the rotation-consistency check.
+ *   *nmatches = the function's return value. */
+int ygzf_search_by_projection_last(ygzf_ctx *ctx, const ygzf_frame_view *cur, const ygzf_camera *cam, int last_n, const ygzf_kp *last_keys,
+                                   const uint8_t *mp_valid, const uint8_t *outlier, const uint8_t *mp_has_obs, const float *mp_world,
+                                   const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw, const float *tlw, float th,
+                                   int b_mono, int check_level, int check_orientation, uint8_t *cur_owner, int *cur_match, int *nmatches);
+
+/* Batched, device-resident form chained behind ygzf_extract_batch_*: frame f of the batch is CurrentFrame, frame f-1 is
+ * LastFrame (for f == 0: the last frame of the previous batch of this context, or an empty frame).  Identity relative
+ * pose; every Last keypoint carries a MapPoint at its unit-depth back-projection ((x-cx)/fx, (y-cy)/fy, 1) whose
+ * descriptor is the keypoint's own -- the synthetic scenario of the extract+match metric. */
+int ygzf_match_batch_prev(ygzf_ctx *ctx, const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation);
+int ygzf_match_counts(ygzf_ctx *ctx, int *nmatches /* n_frames ints */);
+int ygzf_match_fetch(ygzf_ctx *ctx, int frame, int *cur_match, uint8_t *cur_owner, int cap);
+
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------
  * HIP events recorded on the context stream (the stream every kernel of this context is launched on). */
 int ygzf_timer_start(ygzf_ctx *ctx);

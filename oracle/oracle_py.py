@@ -224,3 +224,50 @@ def bench_extract_match(frames, nfeatures=1000, scale_factor=1.2, nlevels=8, ini
     sec = lib().yo_bench_extract_match(nfeatures, scale_factor, nlevels, ini_th, min_th, _p(frames), n, w, h, threads,
                                        fx, fy, cx, cy, C.byref(nk), C.byref(nm))
     return sec, nk.value, nm.value
+
+
+class _YoFrame(C.Structure):
+    _fields_ = [("N", C.c_int), ("keys", C.c_void_p), ("desc", C.c_void_p), ("uRight", C.c_void_p), ("minX", C.c_float),
+                ("minY", C.c_float), ("maxX", C.c_float), ("maxY", C.c_float), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("mb", C.c_float), ("mbf", C.c_float), ("scaleFactors", C.c_void_p),
+                ("nlevels", C.c_int)]
+
+
+def _yo_frame(keys, desc, scale_factors, w, h, fx, fy, cx, cy, mb=0.0, mbf=0.0, u_right=None, keep=None):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    keep.extend([keys, desc, sf])
+    ur = None
+    if u_right is not None:
+        ur = np.ascontiguousarray(u_right, np.float32)
+        keep.append(ur)
+    return _YoFrame(len(keys), keys.ctypes.data, desc.ctypes.data, ur.ctypes.data if ur is not None else None, 0.0, 0.0, float(w),
+                    float(h), fx, fy, cx, cy, mb, mbf, sf.ctypes.data, len(sf))
+
+
+def search_by_projection_last(cur_keys, cur_desc, scale_factors, w, h, cam, last_keys, mp_world, mp_desc, Rcw, tcw, Rlw, tlw, th,
+                              mono=True, check_level=True, check_ori=True, mp_valid=None, outlier=None, mp_has_obs=None,
+                              u_right=None, cur_owner=None):
+    """Oracle ORBmatcher::SearchByProjection(Cur, Last, ...) -> (nmatches, cur_match, cur_owner).  cam = dict(fx,fy,cx,cy[,mb,mbf])."""
+    keep = []
+    fr = _yo_frame(cur_keys, cur_desc, scale_factors, w, h, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam.get("mb", 0.0),
+                   cam.get("mbf", 0.0), u_right, keep)
+    lk = np.ascontiguousarray(last_keys, KP_DTYPE)
+    n = len(lk)
+    valid = np.ones(n, np.uint8) if mp_valid is None else np.ascontiguousarray(mp_valid, np.uint8)
+    outl = np.zeros(n, np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8)
+    obs = np.ones(n, np.uint8) if mp_has_obs is None else np.ascontiguousarray(mp_has_obs, np.uint8)
+    mw = np.ascontiguousarray(mp_world, np.float32)
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    mats = [np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, Rlw, tlw)]
+    nt = fr.N
+    owner = np.zeros(max(nt, 1), np.uint8) if cur_owner is None else np.array(cur_owner, np.uint8)
+    match = np.full(max(nt, 1), -1, np.int32)
+    L = lib()
+    L.yo_search_by_projection_last.argtypes = [C.POINTER(_YoFrame), C.c_int] + [C.c_void_p] * 10 + [C.c_float, C.c_int, C.c_int,
+                                                                                                   C.c_int, C.c_void_p, C.c_void_p]
+    r = L.yo_search_by_projection_last(C.byref(fr), n, _p(lk), _p(valid), _p(outl), _p(obs), _p(mw), _p(md), _p(mats[0]),
+                                       _p(mats[1]), _p(mats[2]), _p(mats[3]), th, int(mono), int(check_level), int(check_ori),
+                                       _p(owner), _p(match))
+    return r, match[:nt], owner[:nt]

@@ -20,6 +20,24 @@ class ExtractorCfg(C.Structure):
                 ("min_th_fast", C.c_int)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("mb", C.c_float),
+                ("mbf", C.c_float), ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+class FrameView(C.Structure):
+    _fields_ = [("n", C.c_int), ("keys", C.c_void_p), ("desc", C.c_void_p), ("u_right", C.c_void_p),
+                ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
+
+
+# EuRoC cam0 intrinsics (reference Examples/Monocular/EuRoC.yaml:8-11), used by bench.py / tests
+EUROC = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375)
+
+
+def make_camera(w, h, fx=EUROC["fx"], fy=EUROC["fy"], cx=EUROC["cx"], cy=EUROC["cy"], mb=0.0, mbf=0.0):
+    return Camera(fx, fy, cx, cy, mb, mbf, 0.0, 0.0, float(w), float(h))
+
+
 _lib = None
 
 
@@ -60,6 +78,11 @@ def load_library(build_if_missing=True):
     L.ygzf_batch_fetch_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip]
     L.ygzf_batch_fetch_level_keypoints.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip]
     L.ygzf_descriptor_distance.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.ygzf_match_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_float, C.c_int, C.c_int, C.c_int]
+    L.ygzf_match_counts.argtypes = [vp, vp]
+    L.ygzf_match_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.ygzf_search_by_projection_last.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                                 vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, ip]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
     L.ygzf_profile_enable.argtypes = [vp, C.c_int]
@@ -193,6 +216,56 @@ class Extractor:
         out = np.zeros(len(a), np.int32)
         self._ck(self.L.ygzf_descriptor_distance(self.h, _p(a), _p(b), len(a), _p(out)))
         return out
+
+    def match_batch_prev(self, cam, th=15.0, mono=True, check_level=True, check_ori=True):
+        self._ck(self.L.ygzf_match_batch_prev(self.h, C.byref(cam), th, int(mono), int(check_level), int(check_ori)))
+
+    def match_counts(self):
+        n = np.zeros(self._wh[2], np.int32)
+        self._ck(self.L.ygzf_match_counts(self.h, _p(n)))
+        return n
+
+    def match_fetch(self, frame):
+        w, h, _ = self._wh
+        cap = self.max_keypoints(w, h)
+        m = np.zeros(max(cap, 1), np.int32)
+        o = np.zeros(max(cap, 1), np.uint8)
+        self._ck(self.L.ygzf_match_fetch(self.h, frame, _p(m), _p(o), cap))
+        return m, o
+
+    def search_by_projection_last(self, cam, cur_keys, cur_desc, last_keys, mp_world, mp_desc, Rcw, tcw, Rlw, tlw, th, mono=True,
+                                  check_level=True, check_ori=True, mp_valid=None, outlier=None, mp_has_obs=None, u_right=None,
+                                  cur_owner=None, scale_factors=None):
+        """ORBmatcher::SearchByProjection(Cur, Last, th, bMono, checkLevel) on host arrays -> (nmatches, cur_match, cur_owner)."""
+        ck = np.ascontiguousarray(cur_keys, KP_DTYPE)
+        cd = np.ascontiguousarray(cur_desc, np.uint8)
+        lk = np.ascontiguousarray(last_keys, KP_DTYPE)
+        mw = np.ascontiguousarray(mp_world, np.float32)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        keep = [ck, cd, lk, mw, md]
+
+        def opt(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return _p(a)
+        fv = FrameView(len(ck), ck.ctypes.data, cd.ctypes.data, None, None, self.nlevels)
+        ur = opt(u_right, np.float32)
+        if ur is not None:
+            fv.u_right = ur
+        sf = opt(scale_factors, np.float32)
+        if sf is not None:
+            fv.scale_factors = sf
+        owner = np.zeros(max(len(ck), 1), np.uint8) if cur_owner is None else np.array(cur_owner, np.uint8)
+        match = np.full(max(len(ck), 1), -1, np.int32)
+        mats = [np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, Rlw, tlw)]
+        n = C.c_int()
+        self._ck(self.L.ygzf_search_by_projection_last(self.h, C.byref(fv), C.byref(cam), len(lk), _p(lk), opt(mp_valid, np.uint8),
+                                                       opt(outlier, np.uint8), opt(mp_has_obs, np.uint8), _p(mw), _p(md), _p(mats[0]),
+                                                       _p(mats[1]), _p(mats[2]), _p(mats[3]), th, int(mono), int(check_level),
+                                                       int(check_ori), _p(owner), _p(match), C.byref(n)))
+        return n.value, match[:len(ck)], owner[:len(ck)]
 
     def timer_start(self):
         self._ck(self.L.ygzf_timer_start(self.h))

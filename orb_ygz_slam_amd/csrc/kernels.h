@@ -22,5 +22,44 @@ void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom,
                      int *outCnt, int outStride, int nFrames);
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out);
 
+// ---- matcher (match_kernels.hip) -----------------------------------------------------------------------------------
+struct MatchQueryScratch;  // opaque: per-query parameters when they do not fit in LDS
+struct MatchArgs {
+    // Cur side, pair p uses base + p*kpStrideCur
+    const ygzf_kp *curKeys;
+    const uint8_t *curDesc;
+    const float *curURight;        // nullable (mono): all "-1"
+    const int *curCnt;             // count of pair p at curCnt[p*cntStrideCur + cntOffCur]
+    long long kpStrideCur;
+    int cntStrideCur, cntOffCur;
+    const uint8_t *ownerIn;        // nullable: initial Cur.mvpMapPoints state (0 free / 1 owned, 0 obs / 2 owned, obs > 0)
+    // Last side
+    const ygzf_kp *lastKeys;
+    const uint8_t *mpDesc;
+    const float *world;
+    const uint8_t *mpValid, *outlier, *hasObs;  // nullable: all valid / none outlier / all observed
+    const int *lastCnt;
+    long long kpStrideLast;
+    int cntStrideLast, cntOffLast;
+    const float *poses;            // per pair: Rcw[9] tcw[3] Rlw[9] tlw[3]
+    // camera / frame statics
+    float fx, fy, cx, cy, mb, mbf, minX, minY, maxX, maxY, gridInvW, gridInvH;
+    float scaleFactors[kMaxLevels];
+    float th;
+    int bMono, checkLevel, checkOri;
+    // outputs
+    uint8_t *owner;                // per pair kpStrideCur
+    int *match;                    // per pair kpStrideCur
+    int *nmatches;                 // per pair
+    // LDS plan
+    int capCur, capLast, descInLds, qpInLds;
+    void *qpScratch;               // capLast * 32 bytes per pair when !qpInLds
+};
+size_t match_lds_bytes(int capCur, int capLast, bool descInLds, bool qpInLds);
+hipError_t match_prepare(size_t ldsBytes);
+void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt, long long kpStride, int maxKp, int nFrames, float fx,
+                             float fy, float cx, float cy, float *world);
+void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ldsBytes);
+
 }  // namespace ygzf
 #endif

@@ -62,8 +62,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_COUNT };
-static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs"};
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_COUNT };
+static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
+                                             "k_backproject_unit", "k_match_last"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -94,7 +95,10 @@ struct ygzf_ctx {
         size_t bytes = 0;
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
-        dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC;
+        dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
+        dGen[12];
+    bool carryValid = false;
+    int lastMatchPairs = 0;
     size_t octLds = 0;
     // batch state
     int lastFrames = 0;
@@ -278,6 +282,8 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             if (rc) return rc;
             if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
         }
+        c->carryValid = false;
+        c->lastFrames = 0;
         c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax);
         if (c->octLds > 160 * 1024 - 2048)
             return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
@@ -295,11 +301,14 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         (rc = ensure(c, c->dXY, cb)))
         return rc;
     const size_t kp = std::max<size_t>(B * G.kpStride, 16);
+    const size_t kp1 = std::max<size_t>((B + 1) * G.kpStride, 16);  // + carry slot
+    void *oldCnt = c->dOutCnt.p, *oldKp = c->dOutKp.p;
     if ((rc = ensure(c, c->dLvlXY, kp * sizeof(unsigned))) || (rc = ensure(c, c->dLvlScore, kp)) ||
         (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
-        (rc = ensure(c, c->dOutKp, kp * sizeof(ygzf_kp))) || (rc = ensure(c, c->dOutDesc, kp * 32)) ||
-        (rc = ensure(c, c->dOutCnt, B * sizeof(int))))
+        (rc = ensure(c, c->dOutKp, kp1 * sizeof(ygzf_kp))) || (rc = ensure(c, c->dOutDesc, kp1 * 32)) ||
+        (rc = ensure(c, c->dOutCnt, (B + 1) * sizeof(int))))
         return rc;
+    if (oldCnt != c->dOutCnt.p || oldKp != c->dOutKp.p) c->carryValid = false;
     return YGZF_OK;
 }
 
@@ -352,6 +361,21 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     const Geometry &G = c->geo;
     const int L = c->tab.cfg.nlevels;
     const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
+    // slot 0 of the output arrays carries the last frame of the previous batch (Last frame of pair 0 in ygzf_match_batch_prev)
+    ygzf_kp *outKp = (ygzf_kp *) c->dOutKp.p;
+    uint8_t *outDesc = (uint8_t *) c->dOutDesc.p;
+    int *outCnt = (int *) c->dOutCnt.p;
+    if (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) {
+        const size_t s = (size_t) c->lastFrames * G.kpStride;
+        HIPCHECK(c, hipMemcpyAsync(outKp, outKp + s, sizeof(ygzf_kp) * G.kpStride, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(outDesc, outDesc + s * 32, (size_t) 32 * G.kpStride, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(outCnt, outCnt + c->lastFrames, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int), c->stream));
+    }
+    outKp += G.kpStride;
+    outDesc += (size_t) G.kpStride * 32;
+    outCnt += 1;
     for (int l = 1; l < L; l++) {
         ProfScope ps(c, KK_PYR);
         launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
@@ -374,17 +398,18 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
         {
             ProfScope ps(c, KK_DESCRIBE);
             launch_describe(c->stream, fs, dGeom, L, (const unsigned *) c->dLvlXY.p, (const unsigned char *) c->dLvlScore.p,
-                            (const int *) c->dLvlCnt.p, G.kpStride, (ygzf_kp *) c->dOutKp.p, (uint8_t *) c->dOutDesc.p,
-                            (int *) c->dOutCnt.p, G.kpStride, nFrames);
+                            (const int *) c->dLvlCnt.p, G.kpStride, outKp, outDesc, outCnt, G.kpStride, nFrames);
         }
     } else {
-        HIPCHECK(c, hipMemsetAsync(c->dOutCnt.p, 0, sizeof(int) * nFrames, c->stream));
+        HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int) * nFrames, c->stream));
         HIPCHECK(c, hipMemsetAsync(c->dLvlCnt.p, 0, sizeof(int) * nFrames * L, c->stream));
         HIPCHECK(c, hipMemsetAsync(c->dLvlCand.p, 0, sizeof(int) * nFrames * L, c->stream));
     }
     HIPCHECK(c, hipGetLastError());
     c->lastFrames = nFrames;
     c->lastFs = fs;
+    c->carryValid = true;
+    c->lastMatchPairs = 0;
     return YGZF_OK;
 }
 
@@ -458,9 +483,12 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
-                             &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC};
+                             &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
+                             &c->dNMatch, &c->dPoses, &c->dQp};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
+    for (auto &b : c->dGen)
+        if (b.p) (void) hipFree(b.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
@@ -567,7 +595,7 @@ int ygzf_extract_batch_host(ygzf_ctx *c, const uint8_t *imgs, int n_frames, int 
 int ygzf_batch_counts(ygzf_ctx *c, int *n_kp) {
     if (!c || !n_kp) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
-    HIPCHECK(c, hipMemcpyAsync(n_kp, c->dOutCnt.p, sizeof(int) * c->lastFrames, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(n_kp, (int *) c->dOutCnt.p + 1, sizeof(int) * c->lastFrames, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }
@@ -577,12 +605,12 @@ int ygzf_batch_fetch(ygzf_ctx *c, int frame, ygzf_kp *kps, uint8_t *desc, int ca
     if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
     if (frame < 0 || frame >= c->lastFrames) return fail(c, YGZF_ERR_INVALID, "frame %d out of range", frame);
     int n = 0;
-    HIPCHECK(c, hipMemcpyAsync(&n, (int *) c->dOutCnt.p + frame, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(&n, (int *) c->dOutCnt.p + frame + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     *n_out = n;
     if (n == 0) return YGZF_OK;
     if (n > cap || !kps || !desc) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d keypoints", cap, n);
-    const size_t base = (size_t) frame * c->geo.kpStride;
+    const size_t base = (size_t) (frame + 1) * c->geo.kpStride;
     HIPCHECK(c, hipMemcpyAsync(kps, (ygzf_kp *) c->dOutKp.p + base, sizeof(ygzf_kp) * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipMemcpyAsync(desc, (uint8_t *) c->dOutDesc.p + base * 32, (size_t) 32 * n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -729,5 +757,203 @@ int ygzf_profile_reset(ygzf_ctx *c) {
 }
 
 void *ygzf_stream(ygzf_ctx *c) { return c ? (void *) c->stream : nullptr; }
+
+// ---- matcher ----------------------------------------------------------------------------------------------------------
+static void fill_camera(MatchArgs &A, const ygzf_camera *cam, const ygzf_ctx *c) {
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy; A.mb = cam->mb; A.mbf = cam->mbf;
+    A.minX = cam->min_x; A.minY = cam->min_y; A.maxX = cam->max_x; A.maxY = cam->max_y;
+    A.gridInvW = (float) 64 / (cam->max_x - cam->min_x);  // mfGridElementWidthInv, src/Frame.cc:302-303
+    A.gridInvH = (float) 48 / (cam->max_y - cam->min_y);
+    for (int l = 0; l < kMaxLevels; l++) A.scaleFactors[l] = l < c->tab.cfg.nlevels ? c->tab.scale[l] : 1.f;
+}
+
+static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsBytes) {
+    const size_t budget = 150 * 1024;
+    A.descInLds = 1;
+    A.qpInLds = 1;
+    size_t b = match_lds_bytes(A.capCur, A.capLast, true, true);
+    if (b > budget) { A.descInLds = 0; b = match_lds_bytes(A.capCur, A.capLast, false, true); }
+    if (b > budget) { A.qpInLds = 0; b = match_lds_bytes(A.capCur, A.capLast, false, false); }
+    if (b > budget) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher needs %zu bytes of LDS for %d/%d keypoints", b, A.capCur, A.capLast);
+    if (!A.qpInLds) {
+        int rc = ensure(c, c->dQp, (size_t) nPairs * A.capLast * 32);
+        if (rc) return rc;
+        A.qpScratch = c->dQp.p;
+    } else
+        A.qpScratch = nullptr;
+    HIPCHECK(c, match_prepare(b));
+    *ldsBytes = b;
+    return YGZF_OK;
+}
+
+int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation) {
+    if (!c || !cam) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const Geometry &G = c->geo;
+    const int B = c->lastFrames;
+    if (G.kpStride == 0) return fail(c, YGZF_ERR_STATE, "configuration yields no keypoints");
+    int rc;
+    if ((rc = ensure(c, c->dWorld, (size_t) (B + 1) * G.kpStride * 3 * sizeof(float))) ||
+        (rc = ensure(c, c->dOwner, (size_t) B * G.kpStride)) || (rc = ensure(c, c->dMatch, (size_t) B * G.kpStride * sizeof(int))) ||
+        (rc = ensure(c, c->dNMatch, (size_t) B * sizeof(int))) || (rc = ensure(c, c->dPoses, (size_t) B * 24 * sizeof(float))))
+        return rc;
+    // identity poses for every pair
+    {
+        std::vector<float> poses((size_t) B * 24, 0.f);
+        for (int p = 0; p < B; p++) {
+            float *q = &poses[(size_t) p * 24];
+            q[0] = q[4] = q[8] = 1.f;
+            q[12] = q[16] = q[20] = 1.f;
+        }
+        HIPCHECK(c, hipMemcpyAsync(c->dPoses.p, poses.data(), poses.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));  // `poses` goes out of scope
+    }
+    const ygzf_kp *kp = (const ygzf_kp *) c->dOutKp.p;
+    const uint8_t *desc = (const uint8_t *) c->dOutDesc.p;
+    const int *cnt = (const int *) c->dOutCnt.p;
+    {
+        ProfScope ps(c, KK_BACKPROJ);
+        launch_backproject_unit(c->stream, kp, cnt, G.kpStride, G.kpStride, B, cam->fx, cam->fy, cam->cx, cam->cy, (float *) c->dWorld.p);
+    }
+    MatchArgs A;
+    memset(&A, 0, sizeof A);
+    A.curKeys = kp + G.kpStride;            // pair p: Cur = slot p+1, Last = slot p
+    A.curDesc = desc + (size_t) G.kpStride * 32;
+    A.curURight = nullptr;
+    A.curCnt = cnt;
+    A.kpStrideCur = G.kpStride;
+    A.cntStrideCur = 1;
+    A.cntOffCur = 1;
+    A.ownerIn = nullptr;
+    A.lastKeys = kp;
+    A.mpDesc = desc;
+    A.world = (const float *) c->dWorld.p;
+    A.lastCnt = cnt;
+    A.kpStrideLast = G.kpStride;
+    A.cntStrideLast = 1;
+    A.cntOffLast = 0;
+    A.poses = (const float *) c->dPoses.p;
+    fill_camera(A, cam, c);
+    A.th = th;
+    A.bMono = b_mono != 0;
+    A.checkLevel = check_level != 0;
+    A.checkOri = check_orientation != 0;
+    A.owner = (uint8_t *) c->dOwner.p;
+    A.match = (int *) c->dMatch.p;
+    A.nmatches = (int *) c->dNMatch.p;
+    A.capCur = G.kpStride;
+    A.capLast = G.kpStride;
+    size_t lds;
+    if ((rc = plan_match_lds(c, A, B, &lds))) return rc;
+    {
+        ProfScope ps(c, KK_MATCH);
+        launch_match_last(c->stream, A, B, lds);
+    }
+    HIPCHECK(c, hipGetLastError());
+    c->lastMatchPairs = B;
+    return YGZF_OK;
+}
+
+int ygzf_match_counts(ygzf_ctx *c, int *nmatches) {
+    if (!c || !nmatches) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastMatchPairs < 1) return fail(c, YGZF_ERR_STATE, "no matched batch");
+    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int) * c->lastMatchPairs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_match_fetch(ygzf_ctx *c, int frame, int *cur_match, uint8_t *cur_owner, int cap) {
+    if (!c) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastMatchPairs < 1) return fail(c, YGZF_ERR_STATE, "no matched batch");
+    if (frame < 0 || frame >= c->lastMatchPairs) return fail(c, YGZF_ERR_INVALID, "frame %d out of range", frame);
+    int n = 0;
+    HIPCHECK(c, hipMemcpyAsync(&n, (int *) c->dOutCnt.p + frame + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (n > cap) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d keypoints", cap, n);
+    const size_t base = (size_t) frame * c->geo.kpStride;
+    if (cur_match && n) HIPCHECK(c, hipMemcpyAsync(cur_match, (int *) c->dMatch.p + base, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (cur_owner && n) HIPCHECK(c, hipMemcpyAsync(cur_owner, (uint8_t *) c->dOwner.p + base, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, const ygzf_camera *cam, int last_n, const ygzf_kp *last_keys,
+                                   const uint8_t *mp_valid, const uint8_t *outlier, const uint8_t *mp_has_obs, const float *mp_world,
+                                   const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw, const float *tlw, float th,
+                                   int b_mono, int check_level, int check_orientation, uint8_t *cur_owner, int *cur_match, int *nmatches) {
+    if (!c || !cur || !cam || !nmatches || !Rcw || !tcw || !Rlw || !tlw) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *nmatches = 0;
+    if (cur->n < 0 || last_n < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    if (cur->n == 0 || last_n == 0) {
+        for (int i = 0; i < cur->n; i++) if (cur_match) cur_match[i] = -1;
+        return YGZF_OK;
+    }
+    if (!cur->keys || !cur->desc || !last_keys || !mp_world || !mp_desc || !cur_match || !cur_owner)
+        return fail(c, YGZF_ERR_INVALID, "null array");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t nt = cur->n, nq = last_n;
+    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
+    ygzf_ctx::Buf *G = c->dGen;
+    int counts[2] = {cur->n, last_n};
+    float pose[24];
+    memcpy(pose, Rcw, 36); memcpy(pose + 9, tcw, 12); memcpy(pose + 12, Rlw, 36); memcpy(pose + 21, tlw, 12);
+    Up ups[] = {{&G[0], cur->keys, nt * sizeof(ygzf_kp)}, {&G[1], cur->desc, nt * 32}, {&G[2], cur->u_right, cur->u_right ? nt * 4 : 0},
+                {&G[3], cur_owner, nt}, {&G[4], last_keys, nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32}, {&G[6], mp_world, nq * 12},
+                {&G[7], mp_valid, mp_valid ? nq : 0}, {&G[8], outlier, outlier ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
+                {&G[10], counts, sizeof counts}, {&G[11], pose, sizeof pose}};
+    int rc;
+    for (auto &u : ups) {
+        if (!u.bytes) continue;
+        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
+        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
+    MatchArgs A;
+    memset(&A, 0, sizeof A);
+    A.curKeys = (const ygzf_kp *) G[0].p;
+    A.curDesc = (const uint8_t *) G[1].p;
+    A.curURight = cur->u_right ? (const float *) G[2].p : nullptr;
+    A.ownerIn = (const uint8_t *) G[3].p;
+    A.curCnt = (const int *) G[10].p;
+    A.kpStrideCur = (long long) nt;
+    A.cntStrideCur = 0;
+    A.cntOffCur = 0;
+    A.lastKeys = (const ygzf_kp *) G[4].p;
+    A.mpDesc = (const uint8_t *) G[5].p;
+    A.world = (const float *) G[6].p;
+    A.mpValid = mp_valid ? (const uint8_t *) G[7].p : nullptr;
+    A.outlier = outlier ? (const uint8_t *) G[8].p : nullptr;
+    A.hasObs = mp_has_obs ? (const uint8_t *) G[9].p : nullptr;
+    A.lastCnt = (const int *) G[10].p;
+    A.kpStrideLast = (long long) nq;
+    A.cntStrideLast = 0;
+    A.cntOffLast = 1;
+    A.poses = (const float *) G[11].p;
+    fill_camera(A, cam, c);
+    if (cur->scale_factors) for (int l = 0; l < kMaxLevels && l < cur->nlevels; l++) A.scaleFactors[l] = cur->scale_factors[l];
+    A.th = th;
+    A.bMono = b_mono != 0;
+    A.checkLevel = check_level != 0;
+    A.checkOri = check_orientation != 0;
+    A.owner = (uint8_t *) c->dOwner.p;
+    A.match = (int *) c->dMatch.p;
+    A.nmatches = (int *) c->dNMatch.p;
+    A.capCur = (int) nt;
+    A.capLast = (int) nq;
+    size_t lds;
+    if ((rc = plan_match_lds(c, A, 1, &lds))) return rc;
+    {
+        ProfScope ps(c, KK_MATCH);
+        launch_match_last(c->stream, A, 1, lds);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(cur_owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(cur_match, c->dMatch.p, nt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
 
 }  // extern "C"

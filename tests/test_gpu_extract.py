@@ -33,7 +33,7 @@ def _cmp_frame(oracle, ex, oex, img, frame=0):
     assert len(k) == len(ok)
     for fld in ("x", "y", "size", "response", "octave", "class_id"):
         assert (k[fld] == ok[fld]).all(), fld
-    assert np.abs(k["angle"] - ok["angle"]).max() <= 1e-5
+    assert len(k) == 0 or np.abs(k["angle"] - ok["angle"]).max() <= 1e-5
     assert (k["angle"] == ok["angle"]).all()
     assert (d == od).all(), "descriptors differ in %d rows" % int((d != od).any(axis=1).sum())
     return len(k)

@@ -1,0 +1,95 @@
+"""GPU parity tests of the matcher hot path (ORBmatcher::SearchByProjection(Cur, Last) + Frame grid) vs the oracle:
+result-identical match assignment (which Last keypoint's MapPoint lands in which Cur slot), ownership state and count."""
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit_world(keys, cam):
+    w = np.zeros((len(keys), 3), np.float32)
+    w[:, 0] = (keys["x"] - np.float32(cam["cx"])) / np.float32(cam["fx"])
+    w[:, 1] = (keys["y"] - np.float32(cam["cy"])) / np.float32(cam["fy"])
+    w[:, 2] = 1.0
+    return w
+
+
+def test_match_batch_prev_equals_oracle(oracle):
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    base = synth_frame(40, w + 16, h + 16)
+    # consecutive frames = shifted crops of one scene (+ a different scene) so that matches exist
+    imgs = np.stack([base[8:8 + h, 8:8 + w], base[9:9 + h, 10:10 + w], base[6:6 + h, 11:11 + w], synth_frame(41, w, h),
+                     base[7:7 + h, 9:9 + w]])
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=len(imgs))
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    cam = make_camera(w, h)
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    prev = None
+    for rnd in range(2):   # second round exercises the carry of the previous batch's last frame
+        ex.extract_batch_host(imgs)
+        ex.match_batch_prev(cam, 15.0, True, True, True)
+        counts = ex.match_counts()
+        for f in range(len(imgs)):
+            k, d = ex.batch_fetch(f)
+            m, o = ex.match_fetch(f)
+            m, o = m[:len(k)], o[:len(k)]
+            if prev is None:
+                assert counts[f] == 0 and (m == -1).all()
+            else:
+                pk, pd = prev
+                exp_n, exp_m, exp_o = oracle.search_by_projection_last(k, d, oex.tables()["scale"], w, h, EUROC, pk,
+                                                                       _unit_world(pk, EUROC), pd, I, z, I, z, 15.0)
+                assert counts[f] == exp_n, (rnd, f, counts[f], exp_n)
+                assert (m == exp_m).all() and (o == exp_o).all()
+                if f in (1, 2):
+                    assert exp_n > 100
+            prev = (k, d)
+
+
+def test_search_by_projection_last_variants(oracle):
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    base = synth_frame(50, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[10:10 + h, 5:5 + w]
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    rng = np.random.default_rng(3)
+    n = len(ka)
+    depth = rng.uniform(2.0, 8.0, n).astype(np.float32)
+    world = _unit_world(ka, EUROC) * depth[:, None]
+    # small relative motion: rotation about y by 0.5 deg + translation
+    ang = np.float32(np.deg2rad(0.5))
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.02, -0.01, 0.03], np.float32)
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    valid = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    outl = (rng.uniform(size=n) > 0.9).astype(np.uint8)
+    obs = (rng.uniform(size=n) > 0.3).astype(np.uint8)
+    uright = np.where(rng.uniform(size=len(kb)) > 0.5, kb["x"] - 5.0, -1.0).astype(np.float32)
+    owner0 = (rng.uniform(size=len(kb)) > 0.95).astype(np.uint8) * 2
+    cases = [dict(th=15.0, mono=True, check_level=True, check_ori=True),
+             dict(th=7.0, mono=False, check_level=True, check_ori=True, u_right=uright, mb=0.11, mbf=50.0),
+             dict(th=30.0, mono=True, check_level=False, check_ori=False),
+             dict(th=15.0, mono=False, check_level=True, check_ori=True, tz=0.5, mb=0.11, mbf=50.0),    # bForward
+             dict(th=15.0, mono=False, check_level=True, check_ori=True, tz=-0.5, mb=0.11, mbf=50.0)]   # bBackward
+    for cs in cases:
+        cam_d = dict(EUROC, mb=cs.get("mb", 0.0), mbf=cs.get("mbf", 0.0))
+        cam = make_camera(w, h, mb=cam_d["mb"], mbf=cam_d["mbf"])
+        t = tcw.copy()
+        t[2] += cs.get("tz", 0.0)
+        kw = dict(mp_valid=valid, outlier=outl, mp_has_obs=obs, u_right=cs.get("u_right"), cur_owner=owner0)
+        e_n, e_m, e_o = oracle.search_by_projection_last(kb, db, sf, w, h, cam_d, ka, world, da, Rcw, t, I, z, cs["th"], cs["mono"],
+                                                         cs["check_level"], cs["check_ori"], **kw)
+        g_n, g_m, g_o = ex.search_by_projection_last(cam, kb, db, ka, world, da, Rcw, t, I, z, cs["th"], cs["mono"], cs["check_level"],
+                                                     cs["check_ori"], scale_factors=sf, **kw)
+        assert g_n == e_n, (cs, g_n, e_n)
+        assert (g_m == e_m).all() and (g_o == e_o).all(), cs
+    # empty sides
+    g_n, g_m, g_o = ex.search_by_projection_last(make_camera(w, h), kb, db, ka[:0], world[:0], da[:0], I, z, I, z, 15.0)
+    assert g_n == 0 and (g_m == -1).all()
