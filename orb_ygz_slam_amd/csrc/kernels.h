@@ -54,6 +54,7 @@ struct MatchArgs {
     // LDS plan
     int capCur, capLast, descInLds, qpInLds;
     void *qpScratch;               // capLast * 32 bytes per pair when !qpInLds
+    long long *dbg;                // nullable: 8 wall_clock64 stamps per pair (phase timing, debug)
 };
 size_t match_lds_bytes(int capCur, int capLast, bool descInLds, bool qpInLds);
 hipError_t match_prepare(size_t ldsBytes);

@@ -53,14 +53,126 @@ __global__ void k_backproject_unit(const ygzf_kp *__restrict__ keys, const int *
     w[2] = 1.f;
 }
 
-struct QueryParam {  // per Last keypoint, precomputed by all waves
-    float u, v, radius, invzc;
-    short minCx, maxCx, minCy, maxCy;
-    short minLevel, maxLevel;   // GetFeaturesInArea arguments
-    int valid;
+struct QueryParam {  // per Last keypoint, precomputed by all waves (32 bytes)
+    float u, v, radius, invzc, angle;
+    unsigned char minCx, maxCx, minCy, maxCy;
+    signed char minLevel, maxLevel;   // GetFeaturesInArea arguments (-1 = unbounded)
+    unsigned char valid, hasObs;
+    unsigned pad;
 };
 
-__global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
+constexpr int kMatchBlock = 1024;
+constexpr unsigned kNoKey = (256u << 16);
+
+struct MatchLds {
+    int *cellStart, *cellFill, *list, *events;
+    QueryParam *qp;
+    unsigned long long *desc;   // Cur descriptors (optional)
+    float *cx, *cy, *cang;      // Cur keypoint x, y, angle
+    uint4 *specKey;             // per query: the 4 best acceptable candidates against the INITIAL ownership,
+    ushort4 *specI2;            //   keys (dist << 16 | visiting order) ascending; key >= kNoKey: none
+    float *qang;                // Last keypoint angle
+    unsigned char *qobs;        // MapPoint has observations
+    unsigned char *owner, *octave;
+    int *match;                 // per Cur keypoint: accepted Last index (flushed to global at the end)
+};
+
+// GetFeaturesInArea + best-candidate scan of one query by one wave.
+// The reference visits cells `for ix: for iy:` (src/Frame.cc:451-452); cells of one grid column are adjacent in the
+// counting-sorted list (cell id = ix*48 + iy), so the candidates of a query are (maxCx-minCx+1) <= 64 contiguous list
+// ranges, already in the reference's visiting order.  The ranges are flattened: lane j takes the j-th candidate, so the
+// dependent LDS chain (index -> attributes -> descriptor) is walked once per 64 candidates instead of once per cell.
+// Returns the wave-uniform best key ((dist << 16) | order; dist 256 = none) and the Cur index that holds it.
+// Wave-wide unsigned min without LDS traffic: DPP inside each row of 16 lanes (quad_perm swaps, row_ror 4/8), then the
+// four row results are combined through SGPRs (v_readlane).  ds_bpermute-based shuffles cost an LDS round trip per step,
+// which dominated the scan when it was written with __shfl_xor.
+__device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
+    unsigned t;
+    t = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) v, 0xb1, 0xf, 0xf, false); v = t < v ? t : v;   // quad_perm [1,0,3,2]
+    t = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) v, 0x4e, 0xf, 0xf, false); v = t < v ? t : v;   // quad_perm [2,3,0,1]
+    t = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) v, 0x124, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:4
+    t = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) v, 0x128, 0xf, 0xf, false); v = t < v ? t : v;  // row_ror:8
+    const unsigned a = (unsigned) __builtin_amdgcn_readlane((int) v, 0), b = (unsigned) __builtin_amdgcn_readlane((int) v, 16);
+    const unsigned c = (unsigned) __builtin_amdgcn_readlane((int) v, 32), d = (unsigned) __builtin_amdgcn_readlane((int) v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+
+__device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
+                                               unsigned long long q1, unsigned long long q2, unsigned long long q3,
+                                               const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2) {
+    const int nCx = q.maxCx - q.minCx + 1;   // <= 64 (one lane per grid column)
+    const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+    int rs = 0, rlen = 0;
+    if (lane < nCx) {
+        const int c0 = (q.minCx + lane) * GRID_ROWS;
+        rs = L.cellStart[c0 + q.minCy];
+        rlen = L.cellStart[c0 + q.maxCy + 1] - rs;
+    }
+    // lane j -> list index of the j-th candidate; the (<= 64) ranges are walked with wave-uniform scalars
+    int li0 = -1, li1 = -1, li2 = -1, li3 = -1;   // candidates lane, lane+64, lane+128, lane+192
+    int total = 0;
+    for (int r = 0; r < nCx; r++) {
+        const int st = __builtin_amdgcn_readlane(rs, r), ln = __builtin_amdgcn_readlane(rlen, r);
+        const int a0 = lane - total, a1 = a0 + 64, a2 = a0 + 128, a3 = a0 + 192;
+        if (a0 >= 0 && a0 < ln) li0 = st + a0;
+        if (a1 >= 0 && a1 < ln) li1 = st + a1;
+        if (a2 >= 0 && a2 < ln) li2 = st + a2;
+        if (a3 >= 0 && a3 < ln) li3 = st + a3;
+        total += ln;
+    }
+    unsigned best = (256u << 16) | 0xFFFFu;
+    int bestI2 = -1;
+    for (int jb = 0; jb < total; jb += 64) {
+        const int j = jb + lane;
+        int li;
+        if (jb == 0) li = li0;
+        else if (jb == 64) li = li1;
+        else if (jb == 128) li = li2;
+        else if (jb == 192) li = li3;
+        else {   // more than 256 candidates in one window: rare, resolve by walking the ranges again
+            li = -1;
+            int acc = 0;
+            for (int r = 0; r < nCx; r++) {
+                const int st = __builtin_amdgcn_readlane(rs, r), ln = __builtin_amdgcn_readlane(rlen, r);
+                if (j >= acc && j < acc + ln) li = st + (j - acc);
+                acc += ln;
+            }
+        }
+        if (li < 0) continue;
+        const int i2 = L.list[li];
+        if (bCheckLevels) {
+            const int o = L.octave[i2];
+            if (o < q.minLevel) continue;
+            if (q.maxLevel >= 0 && o > q.maxLevel) continue;
+        }
+        const float distx = L.cx[i2] - q.u, disty = L.cy[i2] - q.v;
+        if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
+        if (L.owner[i2] == 2) continue;  // mvpMapPoints[i2] && Observations() > 0
+        if (uRight && uRight[i2] > 0) {
+            const float ur = q.u - A.mbf * q.invzc;
+            const float er = fabsf(ur - uRight[i2]);
+            if (er > q.radius) continue;
+        }
+        unsigned long long d0, d1, d2, d3;
+        if (A.descInLds) {
+            d0 = L.desc[4 * i2]; d1 = L.desc[4 * i2 + 1]; d2 = L.desc[4 * i2 + 2]; d3 = L.desc[4 * i2 + 3];
+        } else {
+            const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
+            d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
+        }
+        const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
+        const unsigned key = (dist << 16) | (unsigned) j;
+        if (key < best) { best = key; bestI2 = i2; }
+    }
+    const unsigned wbest = wave_min_dpp(best);
+    const unsigned long long who = __ballot(best == wbest);
+    const int src = __ffsll((long long) who) - 1;
+    *bestIdx2 = __builtin_amdgcn_readlane(bestI2, src);
+    return wbest;
+}
+
+__global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ int s_tmp[20];
     __shared__ int s_hist[HISTO_LENGTH];
@@ -81,41 +193,53 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
     int *matchOut = A.match + (long long) pair * A.kpStrideCur;
     const float *pose = A.poses + (long long) pair * 24;  // Rcw[9] tcw[3] Rlw[9] tlw[3]
 
+    long long *dbg = A.dbg ? A.dbg + (long long) pair * 8 : nullptr;
+#define STAMP(k) do { if (dbg && tid == 0) dbg[k] = wall_clock64(); } while (0)
+    STAMP(0);
     // ---- LDS carve-up ----
+    MatchLds L;
     unsigned char *p = dyn;
-    int *cellStart = (int *) p; p += sizeof(int) * (GRID_CELLS + 1);
-    int *cellFill = (int *) p; p += sizeof(int) * GRID_CELLS;
-    int *list = (int *) p; p += sizeof(int) * A.capCur;
-    int *events = (int *) p; p += sizeof(int) * A.capLast;
-    QueryParam *qp;
-    if (A.qpInLds) { qp = (QueryParam *) p; p += sizeof(QueryParam) * A.capLast; }
-    else qp = (QueryParam *) A.qpScratch + (long long) pair * A.capLast;
-    unsigned long long *ldsDesc = (unsigned long long *) p; p += A.descInLds ? (size_t) 32 * A.capCur : 0;
-    unsigned char *owner = p; p += A.capCur;
-    unsigned char *octave = p; p += A.capCur;
+    L.cellStart = (int *) p; p += sizeof(int) * (GRID_CELLS + 1);
+    p = (unsigned char *) (((size_t) p + 15) & ~(size_t) 15);
+    L.specKey = (uint4 *) p; p += sizeof(uint4) * A.capLast;
+    L.specI2 = (ushort4 *) p; p += sizeof(ushort4) * A.capLast;
+    L.desc = (unsigned long long *) p; p += A.descInLds ? (size_t) 32 * A.capCur : 0;
+    L.cellFill = (int *) p; p += sizeof(int) * GRID_CELLS;
+    L.list = (int *) p; p += sizeof(int) * A.capCur;
+    L.events = (int *) p; p += sizeof(int) * A.capLast;
+    L.qang = (float *) p; p += sizeof(float) * A.capLast;
+    L.cx = (float *) p; p += sizeof(float) * A.capCur;
+    L.cy = (float *) p; p += sizeof(float) * A.capCur;
+    L.cang = (float *) p; p += sizeof(float) * A.capCur;
+    L.match = (int *) p; p += sizeof(int) * A.capCur;
+    L.owner = p; p += A.capCur;
+    L.octave = p; p += A.capCur;
+    L.qobs = p; p += A.capLast;
+    L.qp = (QueryParam *) A.qpScratch + (long long) pair * A.capLast;   // global: only the rare full rescans read it back
 
     // ---- Frame::AssignFeaturesToGrid ----
-    for (int i = tid; i < GRID_CELLS; i += 256) cellFill[i] = 0;
+    for (int i = tid; i < GRID_CELLS; i += kMatchBlock) L.cellFill[i] = 0;
     if (tid < HISTO_LENGTH) s_hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < nt; i += 256) {
+    for (int i = tid; i < nt; i += kMatchBlock) {
         const ygzf_kp k = curKeys[i];
         const int px = (int) roundf((k.x - A.minX) * A.gridInvW);
         const int py = (int) roundf((k.y - A.minY) * A.gridInvH);
-        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&cellFill[px * GRID_ROWS + py], 1);
-        owner[i] = A.ownerIn ? A.ownerIn[(long long) pair * A.kpStrideCur + i] : 0;
-        octave[i] = (unsigned char) k.octave;
-        matchOut[i] = -1;
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&L.cellFill[px * GRID_ROWS + py], 1);
+        L.owner[i] = A.ownerIn ? A.ownerIn[(long long) pair * A.kpStrideCur + i] : 0;
+        L.octave[i] = (unsigned char) k.octave;
+        L.cx[i] = k.x; L.cy[i] = k.y; L.cang[i] = k.angle;
+        L.match[i] = -1;
         if (A.descInLds) {
             const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i * 32);
-            ldsDesc[4 * i] = d[0]; ldsDesc[4 * i + 1] = d[1]; ldsDesc[4 * i + 2] = d[2]; ldsDesc[4 * i + 3] = d[3];
+            L.desc[4 * i] = d[0]; L.desc[4 * i + 1] = d[1]; L.desc[4 * i + 2] = d[2]; L.desc[4 * i + 3] = d[3];
         }
     }
     __syncthreads();
-    {   // exclusive scan of 3072 counts: 12 per thread
-        const int per = GRID_CELLS / 256;
+    {   // exclusive scan of 3072 counts: 3 per thread
+        const int per = GRID_CELLS / kMatchBlock;
         int s = 0;
-        for (int k = 0; k < per; k++) s += cellFill[tid * per + k];
+        for (int k = 0; k < per; k++) s += L.cellFill[tid * per + k];
         int incl = m_wave_incl_scan(s);
         if (lane == 63) s_tmp[wave] = incl;
         __syncthreads();
@@ -123,31 +247,31 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
         for (int w2 = 0; w2 < wave; w2++) woff += s_tmp[w2];
         int off = woff + incl - s;
         for (int k = 0; k < per; k++) {
-            const int c = cellFill[tid * per + k];
-            cellStart[tid * per + k] = off;
+            const int c = L.cellFill[tid * per + k];
+            L.cellStart[tid * per + k] = off;
             off += c;
         }
-        if (tid == 255) cellStart[GRID_CELLS] = off;
+        if (tid == kMatchBlock - 1) L.cellStart[GRID_CELLS] = off;
     }
     __syncthreads();
-    for (int i = tid; i < GRID_CELLS; i += 256) cellFill[i] = cellStart[i];
+    for (int i = tid; i < GRID_CELLS; i += kMatchBlock) L.cellFill[i] = L.cellStart[i];
     __syncthreads();
-    for (int i = tid; i < nt; i += 256) {
-        const ygzf_kp k = curKeys[i];
-        const int px = (int) roundf((k.x - A.minX) * A.gridInvW);
-        const int py = (int) roundf((k.y - A.minY) * A.gridInvH);
-        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) list[atomicAdd(&cellFill[px * GRID_ROWS + py], 1)] = i;
+    for (int i = tid; i < nt; i += kMatchBlock) {
+        const int px = (int) roundf((L.cx[i] - A.minX) * A.gridInvW);
+        const int py = (int) roundf((L.cy[i] - A.minY) * A.gridInvH);
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) L.list[atomicAdd(&L.cellFill[px * GRID_ROWS + py], 1)] = i;
     }
     __syncthreads();
-    for (int c = tid; c < GRID_CELLS; c += 256) {  // cells keep ascending keypoint index (push_back order)
-        const int s = cellStart[c], e = cellStart[c + 1];
+    for (int c = tid; c < GRID_CELLS; c += kMatchBlock) {  // cells keep ascending keypoint index (push_back order)
+        const int s = L.cellStart[c], e = L.cellStart[c + 1];
         for (int a = s + 1; a < e; a++) {
-            const int v = list[a];
+            const int v = L.list[a];
             int b = a - 1;
-            while (b >= s && list[b] > v) { list[b + 1] = list[b]; b--; }
-            list[b + 1] = v;
+            while (b >= s && L.list[b] > v) { L.list[b + 1] = L.list[b]; b--; }
+            L.list[b + 1] = v;
         }
     }
+    STAMP(1);
     // ---- per-query projection (:1243-1272) ----
     const float *Rcw = pose, *tcw = pose + 9, *Rlw = pose + 12, *tlw = pose + 21;
     float twc[3], tlc2;
@@ -155,12 +279,14 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
     tlc2 = (Rlw[6] * twc[0] + Rlw[7] * twc[1] + Rlw[8] * twc[2]) + tlw[2];
     const bool bForward = tlc2 > A.mb && !A.bMono;
     const bool bBackward = -tlc2 > A.mb && !A.bMono;
-    for (int i = tid; i < nq; i += 256) {
+    for (int i = tid; i < nq; i += kMatchBlock) {
         QueryParam q;
         q.valid = 0;
-        q.u = q.v = q.radius = q.invzc = 0;
+        q.u = q.v = q.radius = q.invzc = q.angle = 0;
         q.minCx = q.maxCx = q.minCy = q.maxCy = 0;
         q.minLevel = q.maxLevel = -1;
+        q.hasObs = hasObs ? (hasObs[i] != 0) : 1;
+        q.pad = 0;
         const bool has = (mpValid ? mpValid[i] != 0 : true) && !(outlier ? outlier[i] != 0 : false);
         if (has) {
             const float *X = world + 3 * (size_t) i;
@@ -172,7 +298,8 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
                 const float u = A.fx * xc * invzc + A.cx;
                 const float v = A.fy * yc * invzc + A.cy;
                 if (!(u < A.minX || u > A.maxX) && !(v < A.minY || v > A.maxY)) {
-                    const int oct = lastKeys[i].octave;
+                    const ygzf_kp lk = lastKeys[i];
+                    const int oct = lk.octave;
                     const float r = A.th * A.scaleFactors[oct];
                     int minL, maxL;
                     if (!A.checkLevel) { minL = -1; maxL = -1; }
@@ -187,108 +314,127 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
                     if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) &&
                         nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY) {
                         q.valid = 1;
-                        q.u = u; q.v = v; q.radius = r; q.invzc = invzc;
-                        q.minCx = (short) nMinCellX; q.maxCx = (short) nMaxCellX;
-                        q.minCy = (short) nMinCellY; q.maxCy = (short) nMaxCellY;
-                        q.minLevel = (short) minL; q.maxLevel = (short) maxL;
+                        q.u = u; q.v = v; q.radius = r; q.invzc = invzc; q.angle = lk.angle;
+                        q.minCx = (unsigned char) nMinCellX; q.maxCx = (unsigned char) nMaxCellX;
+                        q.minCy = (unsigned char) nMinCellY; q.maxCy = (unsigned char) nMaxCellY;
+                        q.minLevel = (signed char) minL; q.maxLevel = (signed char) maxL;
                     }
                 }
             }
         }
-        qp[i] = q;
+        L.qp[i] = q;
+        L.qang[i] = q.angle;
+        L.qobs[i] = q.hasObs;
+        // ---- speculative candidates: the 4 best acceptable (dist <= TH_HIGH) candidates against the INITIAL ownership,
+        // one thread per query, no cross-lane traffic.  The in-order pass takes the first of them that is still free: the
+        // current candidate set is a subset of the initial one, so that IS the current minimum.  Only when all four have
+        // been taken does it fall back to a full cooperative rescan.
+        unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu;
+        unsigned short j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+        if (q.valid) {
+            const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
+            const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+            const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+            unsigned ord = 0;
+            for (int ix = q.minCx; ix <= q.maxCx; ix++) {
+                const int c0 = ix * GRID_ROWS;
+                const int s = L.cellStart[c0 + q.minCy], e = L.cellStart[c0 + q.maxCy + 1];
+                for (int li = s; li < e; li++, ord++) {
+                    const int i2 = L.list[li];
+                    if (bCheckLevels) {
+                        const int o = L.octave[i2];
+                        if (o < q.minLevel) continue;
+                        if (q.maxLevel >= 0 && o > q.maxLevel) continue;
+                    }
+                    const float distx = L.cx[i2] - q.u, disty = L.cy[i2] - q.v;
+                    if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
+                    if (L.owner[i2] == 2) continue;
+                    if (uRight && uRight[i2] > 0) {
+                        const float ur = q.u - A.mbf * q.invzc;
+                        const float er = fabsf(ur - uRight[i2]);
+                        if (er > q.radius) continue;
+                    }
+                    unsigned long long d0, d1, d2, d3;
+                    if (A.descInLds) {
+                        d0 = L.desc[4 * i2]; d1 = L.desc[4 * i2 + 1]; d2 = L.desc[4 * i2 + 2]; d3 = L.desc[4 * i2 + 3];
+                    } else {
+                        const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
+                        d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
+                    }
+                    const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
+                    if (dist > (unsigned) TH_HIGH) continue;
+                    const unsigned key = (dist << 16) | (ord & 0xFFFFu);
+                    const unsigned short jj = (unsigned short) i2;
+                    if (key < k3) {   // insert into the sorted quadruple
+                        if (key < k2) {
+                            k3 = k2; j3 = j2;
+                            if (key < k1) {
+                                k2 = k1; j2 = j1;
+                                if (key < k0) { k1 = k0; j1 = j0; k0 = key; j0 = jj; }
+                                else { k1 = key; j1 = jj; }
+                            } else { k2 = key; j2 = jj; }
+                        } else { k3 = key; j3 = jj; }
+                    }
+                }
+            }
+        }
+        L.specKey[i] = make_uint4(k0, k1, k2, k3);
+        L.specI2[i] = make_ushort4(j0, j1, j2, j3);
     }
     __syncthreads();
+    STAMP(2);
+    STAMP(3);
     if (wave != 0) return;
 
-    // ---- in-order resolution by one wave ----
-    int nmatches = 0, nEvents = 0;
+    // ---- in-order resolution by one wave.  Only LDS is touched inside the loop (a global store followed by the
+    // ordering the next iteration needs would cost a full memory round trip per query).
+    int nmatches = 0, nEvents = 0, nRescan = 0;
     const float factor = 1.0f / HISTO_LENGTH;
-    QueryParam qn = nq > 0 ? qp[0] : QueryParam();
-    unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-    if (nq > 0) { const unsigned long long *qd = (const unsigned long long *) mpDesc; n0 = qd[0]; n1 = qd[1]; n2 = qd[2]; n3 = qd[3]; }
+    volatile unsigned char *vowner = L.owner;
     for (int i = 0; i < nq; i++) {
-        const QueryParam q = qn;
-        const unsigned long long q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-        if (i + 1 < nq) {  // prefetch the next query while this one is resolved
-            qn = qp[i + 1];
-            const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) (i + 1) * 32);
-            n0 = qd[0]; n1 = qd[1]; n2 = qd[2]; n3 = qd[3];
+        const uint4 keys = L.specKey[i];
+        if (keys.x >= kNoKey) continue;               // no acceptable candidate even before anything was taken
+        const ushort4 idx = L.specI2[i];
+        int bestIdx2 = -1;
+        if (vowner[idx.x] != 2) bestIdx2 = idx.x;
+        else if (keys.y >= kNoKey) continue;
+        else if (vowner[idx.y] != 2) bestIdx2 = idx.y;
+        else if (keys.z >= kNoKey) continue;
+        else if (vowner[idx.z] != 2) bestIdx2 = idx.z;
+        else if (keys.w >= kNoKey) continue;
+        else if (vowner[idx.w] != 2) bestIdx2 = idx.w;
+        else {                                        // all four taken meanwhile: full rescan against the current ownership
+            const QueryParam q = L.qp[i];
+            const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
+            const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &bestIdx2);
+            nRescan++;
+            if ((int) (key >> 16) > TH_HIGH) continue;
         }
-        if (!q.valid) continue;
-        const int nCy = q.maxCy - q.minCy + 1;
-        const int nc = (q.maxCx - q.minCx + 1) * nCy;
-        const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
-        unsigned best = (256u << 16) | 0xFFFFu;
-        int bestI2 = -1;
-        int orderBase = 0;
-        for (int cbase = 0; cbase < nc; cbase += 64) {
-            const int ci = cbase + lane;
-            int s = 0, cnt = 0;
-            if (ci < nc) {
-                const int ix = q.minCx + ci / nCy, iy = q.minCy + ci % nCy;  // for ix: for iy: (src/Frame.cc:451-452)
-                s = cellStart[ix * GRID_ROWS + iy];
-                cnt = cellStart[ix * GRID_ROWS + iy + 1] - s;
-            }
-            const int incl = m_wave_incl_scan(cnt);
-            const int ord0 = orderBase + incl - cnt;
-            for (int k = 0; k < cnt; k++) {
-                const int i2 = list[s + k];
-                if (bCheckLevels) {
-                    const int o = octave[i2];
-                    if (o < q.minLevel) continue;
-                    if (q.maxLevel >= 0 && o > q.maxLevel) continue;
-                }
-                const ygzf_kp kc = curKeys[i2];
-                const float distx = kc.x - q.u, disty = kc.y - q.v;
-                if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
-                if (owner[i2] == 2) continue;  // mvpMapPoints[i2] && Observations() > 0
-                if (uRight && uRight[i2] > 0) {
-                    const float ur = q.u - A.mbf * q.invzc;
-                    const float er = fabsf(ur - uRight[i2]);
-                    if (er > q.radius) continue;
-                }
-                unsigned long long d0, d1, d2, d3;
-                if (A.descInLds) {
-                    d0 = ldsDesc[4 * i2]; d1 = ldsDesc[4 * i2 + 1]; d2 = ldsDesc[4 * i2 + 2]; d3 = ldsDesc[4 * i2 + 3];
-                } else {
-                    const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
-                    d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
-                }
-                const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
-                const unsigned key = (dist << 16) | (unsigned) (ord0 + k);
-                if (key < best) { best = key; bestI2 = i2; }
-            }
-            orderBase += __shfl(incl, 63, 64);
+        if (lane == 0) {
+            vowner[bestIdx2] = L.qobs[i] ? 2 : 1;
+            L.match[bestIdx2] = i;
         }
-        const unsigned wbest = m_wave_min(best);
-        const int bestDist = (int) (wbest >> 16);
-        if (bestDist <= TH_HIGH) {
-            const unsigned long long who = __ballot(best == wbest);
-            const int src = __ffsll((long long) who) - 1;
-            const int bestIdx2 = __shfl(bestI2, src, 64);
-            if (lane == 0) {
-                owner[bestIdx2] = (hasObs ? hasObs[i] != 0 : true) ? 2 : 1;
-                matchOut[bestIdx2] = i;
-            }
-            nmatches++;
-            if (A.checkOri) {
-                float rot = lastKeys[i].angle - curKeys[bestIdx2].angle;
-                if (rot < 0.0) rot += 360.0f;
-                int bin = (int) roundf(rot * factor);
-                if (bin == HISTO_LENGTH) bin = 0;
-                if (lane == 0) {
-                    events[nEvents] = (bin << 24) | bestIdx2;
-                    s_hist[bin]++;
-                }
-                nEvents++;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nmatches++;
+        if (A.checkOri) {
+            float rot = L.qang[i] - L.cang[bestIdx2];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int) roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (lane == 0) L.events[nEvents] = (bin << 24) | bestIdx2;
+            nEvents++;
         }
+        __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    STAMP(4);
     // ---- rotation consistency (:1327-1345) + ComputeThreeMaxima (:1471-1502) ----
     if (A.checkOri) {
+        for (int e = lane; e < nEvents; e += 64) atomicAdd(&s_hist[L.events[e] >> 24], 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int ind1 = -1, ind2 = -1, ind3 = -1;
         int max1 = 0, max2 = 0, max3 = 0;
         for (int b = 0; b < HISTO_LENGTH; b++) {
@@ -301,11 +447,11 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
         else if (max3 < 0.1f * (float) max1) { ind3 = -1; }
         int removed = 0;
         for (int e = lane; e < nEvents; e += 64) {
-            const int ev = events[e];
+            const int ev = L.events[e];
             const int bin = ev >> 24, idx = ev & 0xFFFFFF;
             if (bin != ind1 && bin != ind2 && bin != ind3) {
-                owner[idx] = 0;
-                matchOut[idx] = -2;
+                L.owner[idx] = 0;
+                L.match[idx] = -2;
                 removed++;
             }
         }
@@ -316,15 +462,19 @@ __global__ __launch_bounds__(256) void k_match_last(MatchArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int i = lane; i < nt; i += 64) ownerOut[i] = owner[i];
+    for (int i = lane; i < nt; i += 64) { ownerOut[i] = L.owner[i]; matchOut[i] = L.match[i]; }
     if (lane == 0) A.nmatches[pair] = nmatches;
+    STAMP(5);
+    if (dbg && tid == 0) { dbg[6] = nRescan; dbg[7] = nq; }
+#undef STAMP
 }
 
-static_assert(sizeof(QueryParam) == 32, "QueryParam is 32 bytes (qpScratch sizing)");
-
 size_t match_lds_bytes(int capCur, int capLast, bool descInLds, bool qpInLds) {
-    size_t b = sizeof(int) * (GRID_CELLS + 1) + sizeof(int) * GRID_CELLS + sizeof(int) * (size_t) capCur + sizeof(int) * (size_t) capLast +
-               (qpInLds ? sizeof(QueryParam) * (size_t) capLast : 0) + (descInLds ? (size_t) 32 * capCur : 0) + 2 * (size_t) capCur + 64;
+    (void) qpInLds;  // per-query parameters always live in global scratch now
+    size_t b = sizeof(int) * (GRID_CELLS + 1) + 16 + (sizeof(uint4) + sizeof(ushort4)) * (size_t) capLast +
+               (descInLds ? (size_t) 32 * capCur : 0) + sizeof(int) * GRID_CELLS + sizeof(int) * (size_t) capCur +
+               sizeof(int) * (size_t) capLast + sizeof(float) * (size_t) capLast + 3 * sizeof(float) * (size_t) capCur +
+               sizeof(int) * (size_t) capCur + 2 * (size_t) capCur + (size_t) capLast + 64;
     return (b + 15) & ~(size_t) 15;
 }
 
@@ -339,7 +489,7 @@ void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt
 }
 
 void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ldsBytes) {
-    hipLaunchKernelGGL(k_match_last, dim3(nPairs), dim3(256), ldsBytes, st, A);
+    hipLaunchKernelGGL(k_match_last, dim3(nPairs), dim3(kMatchBlock), ldsBytes, st, A);
 }
 
 }  // namespace ygzf

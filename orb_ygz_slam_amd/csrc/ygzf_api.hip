@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -99,6 +100,8 @@ struct ygzf_ctx {
         dGen[12];
     bool carryValid = false;
     int lastMatchPairs = 0;
+    int identityPoses = 0;
+    void *identityPosesPtr = nullptr;
     size_t octLds = 0;
     // batch state
     int lastFrames = 0;
@@ -768,19 +771,16 @@ static void fill_camera(MatchArgs &A, const ygzf_camera *cam, const ygzf_ctx *c)
 }
 
 static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsBytes) {
-    const size_t budget = 150 * 1024;
+    const size_t budget = 156 * 1024;
+    if (A.capCur > 65535) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher supports at most 65535 keypoints per frame");
     A.descInLds = 1;
-    A.qpInLds = 1;
-    size_t b = match_lds_bytes(A.capCur, A.capLast, true, true);
-    if (b > budget) { A.descInLds = 0; b = match_lds_bytes(A.capCur, A.capLast, false, true); }
-    if (b > budget) { A.qpInLds = 0; b = match_lds_bytes(A.capCur, A.capLast, false, false); }
+    A.qpInLds = 0;
+    size_t b = match_lds_bytes(A.capCur, A.capLast, true, false);
+    if (b > budget) { A.descInLds = 0; b = match_lds_bytes(A.capCur, A.capLast, false, false); }
     if (b > budget) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher needs %zu bytes of LDS for %d/%d keypoints", b, A.capCur, A.capLast);
-    if (!A.qpInLds) {
-        int rc = ensure(c, c->dQp, (size_t) nPairs * A.capLast * 32);
-        if (rc) return rc;
-        A.qpScratch = c->dQp.p;
-    } else
-        A.qpScratch = nullptr;
+    int rc = ensure(c, c->dQp, (size_t) nPairs * A.capLast * 32);
+    if (rc) return rc;
+    A.qpScratch = c->dQp.p;
     HIPCHECK(c, match_prepare(b));
     *ldsBytes = b;
     return YGZF_OK;
@@ -798,8 +798,8 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
         (rc = ensure(c, c->dOwner, (size_t) B * G.kpStride)) || (rc = ensure(c, c->dMatch, (size_t) B * G.kpStride * sizeof(int))) ||
         (rc = ensure(c, c->dNMatch, (size_t) B * sizeof(int))) || (rc = ensure(c, c->dPoses, (size_t) B * 24 * sizeof(float))))
         return rc;
-    // identity poses for every pair
-    {
+    // identity poses for every pair (uploaded once per buffer / batch size, so the steady state has no host sync)
+    if (c->identityPoses < B || c->identityPosesPtr != c->dPoses.p) {
         std::vector<float> poses((size_t) B * 24, 0.f);
         for (int p = 0; p < B; p++) {
             float *q = &poses[(size_t) p * 24];
@@ -808,6 +808,8 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
         }
         HIPCHECK(c, hipMemcpyAsync(c->dPoses.p, poses.data(), poses.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));  // `poses` goes out of scope
+        c->identityPoses = B;
+        c->identityPosesPtr = c->dPoses.p;
     }
     const ygzf_kp *kp = (const ygzf_kp *) c->dOutKp.p;
     const uint8_t *desc = (const uint8_t *) c->dOutDesc.p;
@@ -844,6 +846,10 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
     A.nmatches = (int *) c->dNMatch.p;
     A.capCur = G.kpStride;
     A.capLast = G.kpStride;
+    if (getenv("YGZF_MATCH_DEBUG")) {
+        if ((rc = ensure(c, c->dTmpC, (size_t) B * 8 * sizeof(long long)))) return rc;
+        A.dbg = (long long *) c->dTmpC.p;
+    }
     size_t lds;
     if ((rc = plan_match_lds(c, A, B, &lds))) return rc;
     {
@@ -851,6 +857,13 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
         launch_match_last(c->stream, A, B, lds);
     }
     HIPCHECK(c, hipGetLastError());
+    if (A.dbg) {
+        long long st[8];
+        const int pp = B > 1 ? 1 : 0;
+        HIPCHECK(c, hipMemcpy(st, A.dbg + 8 * pp, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ygzf match pair %d, 100MHz ticks] grid %lld  proj %lld  spec %lld  seq %lld  tail %lld  rescans %lld of %lld queries\n", pp,
+                st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6], st[7]);
+    }
     c->lastMatchPairs = B;
     return YGZF_OK;
 }
