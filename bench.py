@@ -101,7 +101,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent extractor contexts (own HIP stream + buffers) the batch is split over, so that the "
+                         "latency-bound kernels of one sub-batch overlap the throughput-bound kernels of another")
     ap.add_argument("--workload", default="euroc752x480_8lvl_1000feat", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -152,26 +155,36 @@ def main():
 
     frames = make_frames(B, w, h, seed0=1000 + 97 * rank)   # every rank owns its own clip (one-frame-per-GPU sharding at scale)
     d_frames = torch.from_numpy(frames).to("cuda:%d" % local_rank)
-    ex = Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=local_rank)
+    S = max(1, args.streams)
+    if B % S:
+        raise SystemExit("--batch must be a multiple of --streams")
+    Bs = B // S
+    exs = [Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=Bs, device=local_rank) for _ in range(S)]
+    ex = exs[0]
     cam = make_camera(w, h)
+    ptrs = [d_frames.data_ptr() + i * Bs * w * h for i in range(S)]
 
     def step():
-        ex.extract_batch_device(d_frames.data_ptr(), B, w, h)
-        ex.match_batch_prev(cam, 15.0, True, True, True)
+        for e, ptr in zip(exs, ptrs):
+            e.extract_batch_device(ptr, Bs, w, h)
+            e.match_batch_prev(cam, 15.0, True, True, True)
 
     for _ in range(args.warmup):
         step()
-    ex.sync()
+    for e in exs:
+        e.sync()
     if not args.no_profile:
-        ex.profile_enable(True)
-        ex.profile_reset()
+        for e in exs:
+            e.profile_enable(True)
+            e.profile_reset()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ex.sync()
+    for e in exs:
+        e.sync()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -181,10 +194,15 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el[0])
 
-    prof = {} if args.no_profile else ex.profile_read()
-    ex.profile_enable(False)
-    kp_counts = ex.batch_counts()
-    m_counts = ex.match_counts()
+    prof = {}
+    if not args.no_profile:
+        for e in exs:
+            for name, (ms, n) in e.profile_read().items():
+                a = prof.get(name, (0.0, 0))
+                prof[name] = (a[0] + ms, a[1] + n)
+            e.profile_enable(False)
+    kp_counts = np.concatenate([e.batch_counts() for e in exs])
+    m_counts = np.concatenate([e.match_counts() for e in exs])
 
     if rank == 0:
         total_frames = world * B * args.steps
@@ -200,7 +218,7 @@ def main():
             cand = [k for k in kernels if per_kernel.get(k, 0) > 0]
             dom = max(cand, key=lambda k: kernels[k]["total_ms"])
             launches_per_step = kernels[dom]["launches"] / args.steps
-            bytes_per_launch = per_kernel[dom] * B / launches_per_step   # pyramid: 7 launches share its bytes
+            bytes_per_launch = per_kernel[dom] * B / launches_per_step   # pyramid: 7 launches share its bytes; S sub-batches
             avg_s = kernels[dom]["total_ms"] / kernels[dom]["launches"] * 1e-3
             achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
@@ -221,7 +239,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h, "levels": nl, "scale_factor": sf, "features": nf,
-                       "frames_per_gpu_per_step": B, "match": "SearchByProjection(cur,last) th=15, identity pose",
+                       "frames_per_gpu_per_step": B, "streams": S, "match": "SearchByProjection(cur,last) th=15, identity pose",
                        "sharding": "one clip per GPU, no collective"},
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "roofline": roofline, "kernels": kernels,

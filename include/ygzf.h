@@ -141,6 +141,30 @@ int ygzf_match_batch_prev(ygzf_ctx *ctx, const ygzf_camera *cam, float th, int b
 int ygzf_match_counts(ygzf_ctx *ctx, int *nmatches /* n_frames ints */);
 int ygzf_match_fetch(ygzf_ctx *ctx, int frame, int *cur_match, uint8_t *cur_owner, int cap);
 
+/* ---- ygz::SparseImgAlign(max_level, min_level, n_iter = 10, GaussNewton).run(Frame *ref, Frame *cur, SE3f &TCR)
+ *      include/SparseImageAlign.h:14-51, src/SparseImageAlign.cc:7-49 (+ NLLSSolver<6,SE3f>::optimizeGaussNewton,
+ *      include/NLSSolver_impl.hpp:17-91) -------------------------------------------------------------------------------
+ * Frames as plain arrays.  Tcw = Frame::mTcw as (qx qy qz qw tx ty tz) (Sophus SE3f storage order); levels[l] = tight
+ * 8-bit image of pyramid level l (Frame::mvImagePyramid[l], step == cols); only levels min_level..max_level are read.
+ * ref needs keys / mp_valid / outlier / mp_world; cur only Tcw and its pyramid.  inv_scale_factors = mvInvScaleFactors.
+ * The reference indexes `iterations[level]` out of bounds for level > 5: n_iter applies to every level.
+ * Outputs: TCR_out = T_cur_from_ref (same 7-float layout; untouched when ref->n == 0), *ret = n_meas_/16 (0 = failure,
+ * src/Tracking.cc:2089), info[0] = Gauss-Newton linearisations run, info[1] = final chi2, H36 = the Hessian H_ of the
+ * last iteration (getFisherInformation() = H36 / (5e-4*255*255)).  info and H36 may be NULL. */
+typedef struct ygzf_sia_frame {
+    int n;
+    const ygzf_kp *keys;
+    const uint8_t *mp_valid;       /* mvpMapPoints[i] != NULL && !isBad(); NULL = all valid */
+    const uint8_t *outlier;        /* mvbOutlier; NULL = none */
+    const float *mp_world;         /* n x 3 */
+    float Tcw[7];
+    int nlevels;
+    const uint8_t *const *levels;
+    const int *level_w, *level_h;
+} ygzf_sia_frame;
+int ygzf_sia_run(ygzf_ctx *ctx, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, const ygzf_camera *cam, const float *inv_scale_factors,
+                 int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36);
+
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------
  * HIP events recorded on the context stream (the stream every kernel of this context is launched on). */
 int ygzf_timer_start(ygzf_ctx *ctx);

@@ -271,3 +271,81 @@ def search_by_projection_last(cur_keys, cur_desc, scale_factors, w, h, cam, last
                                        _p(mats[1]), _p(mats[2]), _p(mats[3]), th, int(mono), int(check_level), int(check_ori),
                                        _p(owner), _p(match))
     return r, match[:nt], owner[:nt]
+
+
+class _YoAlignFrame(C.Structure):
+    _fields_ = [("N", C.c_int), ("keys", C.c_void_p), ("mp_valid", C.c_void_p), ("outlier", C.c_void_p), ("mp_world", C.c_void_p),
+                ("Tcw", C.c_float * 7), ("nlevels", C.c_int), ("levels", C.POINTER(C.c_void_p)), ("level_w", C.c_void_p),
+                ("level_h", C.c_void_p), ("invScaleFactors", C.c_void_p), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float)]
+
+
+def _align_frame(keys, mp_valid, outlier, mp_world, Tcw7, pyramid, inv_scale, cam, keep):
+    keys = np.ascontiguousarray(keys, KP_DTYPE)
+    n = len(keys)
+    mv = np.ones(n, np.uint8) if mp_valid is None else np.ascontiguousarray(mp_valid, np.uint8)
+    ol = np.zeros(n, np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8)
+    mw = np.zeros((max(n, 1), 3), np.float32) if mp_world is None else np.ascontiguousarray(mp_world, np.float32)
+    pyr = [np.ascontiguousarray(p, np.uint8) for p in pyramid]
+    lw = np.array([p.shape[1] for p in pyr], np.int32)
+    lh = np.array([p.shape[0] for p in pyr], np.int32)
+    isf = np.ascontiguousarray(inv_scale, np.float32)
+    arr = (C.c_void_p * len(pyr))(*[p.ctypes.data for p in pyr])
+    keep.extend([keys, mv, ol, mw, pyr, lw, lh, isf, arr])
+    f = _YoAlignFrame()
+    f.N = n
+    f.keys, f.mp_valid, f.outlier, f.mp_world = keys.ctypes.data, mv.ctypes.data, ol.ctypes.data, mw.ctypes.data
+    for i in range(7):
+        f.Tcw[i] = float(Tcw7[i])
+    f.nlevels = len(pyr)
+    f.levels = arr
+    f.level_w, f.level_h, f.invScaleFactors = lw.ctypes.data, lh.ctypes.data, isf.ctypes.data
+    f.fx, f.fy, f.cx, f.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    return f
+
+
+def sparse_img_align(ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, cam, max_level, min_level, n_iter=10,
+                     mp_valid=None, outlier=None):
+    """Oracle SparseImgAlign(max_level, min_level, n_iter).run(ref, cur, TCR) -> (ret, TCR7 (qx qy qz qw tx ty tz), info, H)."""
+    keep = []
+    R = _align_frame(ref_keys, mp_valid, outlier, ref_world, ref_Tcw7, ref_pyr, inv_scale, cam, keep)
+    Cf = _align_frame(np.zeros(0, KP_DTYPE), None, None, None, cur_Tcw7, cur_pyr, inv_scale, cam, keep)
+    out7 = np.zeros(7, np.float32)
+    info = np.zeros(2, np.float32)
+    H = np.zeros(36, np.float32)
+    L = lib()
+    L.yo_sparse_img_align.argtypes = [C.POINTER(_YoAlignFrame), C.POINTER(_YoAlignFrame), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+    ret = L.yo_sparse_img_align(C.byref(R), C.byref(Cf), max_level, min_level, n_iter, _p(out7), _p(info), _p(H))
+    return int(ret), out7, info, H.reshape(6, 6)
+
+
+def se3_exp(a6):
+    a = np.ascontiguousarray(a6, np.float32)
+    out = np.zeros(7, np.float32)
+    lib().yo_se3_exp(_p(a), _p(out))
+    return out
+
+
+def se3_mul(a7, b7):
+    a, b = np.ascontiguousarray(a7, np.float32), np.ascontiguousarray(b7, np.float32)
+    out = np.zeros(7, np.float32)
+    lib().yo_se3_mul(_p(a), _p(b), _p(out))
+    return out
+
+
+def se3_inverse(a7):
+    a = np.ascontiguousarray(a7, np.float32)
+    out = np.zeros(7, np.float32)
+    lib().yo_se3_inverse(_p(a), _p(out))
+    return out
+
+
+def features_in_area(keys, scale_factors, w, h, x, y, r, min_level=-1, max_level=-1):
+    keep = []
+    fr = _yo_frame(keys, np.zeros((len(keys), 32), np.uint8), scale_factors, w, h, 1.0, 1.0, 0.0, 0.0, keep=keep)
+    out = np.zeros(max(len(keys), 1), np.int32)
+    L = lib()
+    L.yo_features_in_area.argtypes = [C.POINTER(_YoFrame), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = L.yo_features_in_area(C.byref(fr), x, y, r, min_level, max_level, _p(out), len(out))
+    return out[:n].copy()

@@ -30,6 +30,12 @@ class FrameView(C.Structure):
                 ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
 
 
+class SiaFrame(C.Structure):
+    _fields_ = [("n", C.c_int), ("keys", C.c_void_p), ("mp_valid", C.c_void_p), ("outlier", C.c_void_p), ("mp_world", C.c_void_p),
+                ("Tcw", C.c_float * 7), ("nlevels", C.c_int), ("levels", C.POINTER(C.c_void_p)), ("level_w", C.c_void_p),
+                ("level_h", C.c_void_p)]
+
+
 # EuRoC cam0 intrinsics (reference Examples/Monocular/EuRoC.yaml:8-11), used by bench.py / tests
 EUROC = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375)
 
@@ -83,6 +89,8 @@ def load_library(build_if_missing=True):
     L.ygzf_match_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.ygzf_search_by_projection_last.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                                  vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, ip]
+    L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
+                               C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
     L.ygzf_profile_enable.argtypes = [vp, C.c_int]
@@ -266,6 +274,48 @@ class Extractor:
                                                        _p(mats[1]), _p(mats[2]), _p(mats[3]), th, int(mono), int(check_level),
                                                        int(check_ori), _p(owner), _p(match), C.byref(n)))
         return n.value, match[:len(ck)], owner[:len(ck)]
+
+    def sia_run(self, cam, ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, max_level, min_level, n_iter=10,
+                mp_valid=None, outlier=None):
+        """SparseImgAlign(max_level, min_level, n_iter).run(ref, cur, TCR) -> (ret, TCR7, info[2], H 6x6)."""
+        keep = []
+
+        def frame(keys, world, Tcw7, pyr, valid, outl):
+            f = SiaFrame()
+            keys = np.ascontiguousarray(keys, KP_DTYPE)
+            f.n = len(keys)
+            keep.append(keys)
+            f.keys = keys.ctypes.data
+            if world is not None:
+                world = np.ascontiguousarray(world, np.float32)
+                keep.append(world)
+                f.mp_world = world.ctypes.data
+            for name, a in (("mp_valid", valid), ("outlier", outl)):
+                if a is not None:
+                    a = np.ascontiguousarray(a, np.uint8)
+                    keep.append(a)
+                    setattr(f, name, a.ctypes.data)
+            for i in range(7):
+                f.Tcw[i] = float(Tcw7[i])
+            pyr = [np.ascontiguousarray(p, np.uint8) for p in pyr]
+            lw = np.array([p.shape[1] for p in pyr], np.int32)
+            lh = np.array([p.shape[0] for p in pyr], np.int32)
+            arr = (C.c_void_p * len(pyr))(*[p.ctypes.data for p in pyr])
+            keep.extend([pyr, lw, lh, arr])
+            f.nlevels = len(pyr)
+            f.levels = arr
+            f.level_w, f.level_h = lw.ctypes.data, lh.ctypes.data
+            return f
+        R = frame(ref_keys, ref_world, ref_Tcw7, ref_pyr, mp_valid, outlier)
+        Cf = frame(np.zeros(0, KP_DTYPE), None, cur_Tcw7, cur_pyr, None, None)
+        isf = np.ascontiguousarray(inv_scale, np.float32)
+        out7 = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+        info = np.zeros(2, np.float32)
+        H = np.zeros(36, np.float32)
+        ret = C.c_size_t()
+        self._ck(self.L.ygzf_sia_run(self.h, C.byref(R), C.byref(Cf), C.byref(cam), _p(isf), max_level, min_level, n_iter, _p(out7),
+                                     C.byref(ret), _p(info), _p(H)))
+        return int(ret.value), out7, info, H.reshape(6, 6)
 
     def timer_start(self):
         self._ck(self.L.ygzf_timer_start(self.h))

@@ -185,30 +185,39 @@ __device__ __forceinline__ bool has_arc9(unsigned m16) {
     return (r & 0xFFFFu) != 0;
 }
 
+// Ring differences d[k] = ring_k - centre for the 16-pixel Bresenham circle (offsets as cv::FAST / libfast).
 template <int TP>
-__device__ __forceinline__ int fast9_score(const uint8_t *c, int minTh) {
+__device__ __forceinline__ void ring_diffs(const uint8_t *c, int d[16]) {
     const int v = c[0];
-    int d[16];
     d[0] = c[3 * TP] - v;       d[1] = c[3 * TP + 1] - v;   d[2] = c[2 * TP + 2] - v;   d[3] = c[TP + 3] - v;
     d[4] = c[3] - v;            d[5] = c[-TP + 3] - v;      d[6] = c[-2 * TP + 2] - v;  d[7] = c[-3 * TP + 1] - v;
     d[8] = c[-3 * TP] - v;      d[9] = c[-3 * TP - 1] - v;  d[10] = c[-2 * TP - 2] - v; d[11] = c[-TP - 3] - v;
     d[12] = c[-3] - v;          d[13] = c[TP - 3] - v;      d[14] = c[2 * TP - 2] - v;  d[15] = c[3 * TP - 1] - v;
+}
+
+// 1 = bright corner, 2 = dark corner, 0 = none, at threshold t (9 contiguous ring pixels > v+t or < v-t).
+template <int TP>
+__device__ __forceinline__ int fast9_test(const uint8_t *c, int t) {
+    int d[16];
+    ring_diffs<TP>(c, d);
     unsigned B = 0, D = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        B |= (unsigned) (d[k] > minTh) << k;
-        D |= (unsigned) (d[k] < -minTh) << k;
+        B |= (unsigned) (d[k] > t) << k;
+        D |= (unsigned) (d[k] < -t) << k;
     }
-    const bool cb = has_arc9(B), cd = has_arc9(D);
-    if (!cb && !cd) return 0;
-    // max over the 16 arcs of 9 of the min margin (bright: d, dark: -d); only one polarity can be a corner
+    return has_arc9(B) ? 1 : (has_arc9(D) ? 2 : 0);
+}
+
+// cv::FAST cornerScore<16> for a pixel known to be a corner of polarity `pol`: max over the 16 arcs of 9 of the minimum
+// margin, minus 1 (== the largest threshold for which the pixel is still a corner).
+template <int TP>
+__device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int pol) {
     int e[16];
-    if (cb) {
+    ring_diffs<TP>(c, e);
+    if (pol == 2) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) e[k] = d[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) e[k] = -d[k];
+        for (int k = 0; k < 16; k++) e[k] = -e[k];
     }
     int m2[16], m4[16], m8[16];
 #pragma unroll
@@ -220,7 +229,7 @@ __device__ __forceinline__ int fast9_score(const uint8_t *c, int minTh) {
     int a = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) a = max(a, min(m8[k], e[(k + 8) & 15]));
-    return a - 1;  // >= minTh because the pixel is a corner at minTh
+    return a - 1;
 }
 
 constexpr int kTP = 68;  // LDS pitch of the image window
@@ -229,13 +238,18 @@ constexpr int kSP = 64;  // LDS pitch of the score map (<= 62 columns used)
 __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                           int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
                                                           unsigned *__restrict__ slots, int totalCells,
-                                                          long long totalSlots) {
+                                                          long long totalSlots, int cellsPerXcd) {
     __shared__ uint8_t tile[kMaxCellWin * kTP];
     __shared__ __attribute__((aligned(16))) uint8_t smap[62 * kSP];
+    __shared__ unsigned short queue[60 * 60];   // corner pixels (tile offset << 2 | polarity) awaiting their score
     __shared__ int s_tmp[20];
-    __shared__ int s_ini;
+    __shared__ int s_ini, s_q;
     const int tid = threadIdx.x;
-    const int cell = blockIdx.x, f = blockIdx.y;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; performance only).  Give every XCD a
+    // contiguous run of cells so that neighbouring windows, which share cache lines, meet in the same L2.
+    const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);
+    const int f = blockIdx.y;
+    if (cell >= totalCells || (int) (blockIdx.x >> 3) >= cellsPerXcd) return;
     int l = 0;
     while (l + 1 < nlevels && cell >= geom[l + 1].cellBase) l++;
     const LevelGeom g = geom[l];
@@ -253,30 +267,46 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     }
     int pitch;
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
-    for (int idx = tid; idx < ww * hh; idx += kFastBlock) {
-        const int ty = idx / ww, tx = idx - ty * ww;
-        tile[ty * kTP + tx] = img[(long long) (iniY + ty) * pitch + iniX + tx];
+    {   // stage the window; (ty, tx) advance incrementally (no per-element division)
+        int ty = tid / ww, tx = tid - ty * ww;
+        const int sy = kFastBlock / ww, sx = kFastBlock - sy * ww;
+        for (int idx = tid; idx < ww * hh; idx += kFastBlock) {
+            tile[ty * kTP + tx] = img[(long long) (iniY + ty) * pitch + iniX + tx];
+            ty += sy; tx += sx;
+            if (tx >= ww) { tx -= ww; ty++; }
+        }
     }
     for (int idx = tid; idx < (62 * kSP) / 16; idx += kFastBlock) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) s_ini = 0;
+    if (tid == 0) { s_ini = 0; s_q = 0; }
     __syncthreads();
     const int npix = dw * dh;
-    const int ppt = (npix + kFastBlock - 1) / kFastBlock;  // <= 15
+    const int ppt = (npix + kFastBlock - 1) / kFastBlock;  // <= 15 consecutive pixels per thread (raster order)
     const int p0 = tid * ppt;
-    for (int j = 0; j < ppt; j++) {
-        const int idx = p0 + j;
-        if (idx < npix) {
-            const int y = idx / dw, x = idx - y * dw;
-            const int s = fast9_score<kTP>(&tile[(y + 3) * kTP + x + 3], minTh);
-            smap[(y + 1) * kSP + x + 1] = (uint8_t) s;
+    const int y0 = p0 / dw, x0 = p0 - y0 * dw;
+    // pass 1: corner test at minTh for every pixel; corners are queued so that the (much costlier) score runs densely
+    {
+        int y = y0, x = x0;
+        for (int j = 0; j < ppt && p0 + j < npix; j++) {
+            const int off = (y + 3) * kTP + x + 3;
+            const int pol = fast9_test<kTP>(&tile[off], minTh);
+            if (pol) queue[atomicAdd(&s_q, 1)] = (unsigned short) ((off << 2) | pol);
+            if (++x == dw) { x = 0; y++; }
         }
     }
     __syncthreads();
+    const int nq = s_q;
+    for (int qi = tid; qi < nq; qi += kFastBlock) {
+        const int e = queue[qi];
+        const int off = e >> 2;
+        const int s = fast9_arc_score<kTP>(&tile[off], e & 3);
+        const int ty = off / kTP, tx = off - ty * kTP;
+        smap[(ty - 2) * kSP + tx - 2] = (uint8_t) s;   // score-map coords = domain coords + 1
+    }
+    __syncthreads();
     unsigned keepIni = 0, keepMin = 0;
-    for (int j = 0; j < ppt; j++) {
-        const int idx = p0 + j;
-        if (idx < npix) {
-            const int y = idx / dw, x = idx - y * dw;
+    {
+        int y = y0, x = x0;
+        for (int j = 0; j < ppt && p0 + j < npix; j++) {
             const uint8_t *p = &smap[(y + 1) * kSP + x + 1];
             const int s = p[0];
             if (s) {
@@ -293,6 +323,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
                 if (s > nmax) keepMin |= 1u << j;
                 if (s >= iniTh && s > nmaxI) keepIni |= 1u << j;
             }
+            if (++x == dw) { x = 0; y++; }
         }
     }
     if (keepIni) atomicAdd(&s_ini, __popc(keepIni));
@@ -301,12 +332,14 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     int total;
     int off = block_excl_scan(__popc(keep), s_tmp, &total);
     unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
-    for (int j = 0; j < ppt; j++) {
-        if (keep & (1u << j)) {
-            const int idx = p0 + j;
-            const int y = idx / dw, x = idx - y * dw;
-            const unsigned s = smap[(y + 1) * kSP + x + 1];
-            out[off++] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
+    if (keep) {
+        int y = y0, x = x0;
+        for (int j = 0; j < ppt; j++) {
+            if (keep & (1u << j)) {
+                const unsigned s = smap[(y + 1) * kSP + x + 1];
+                out[off++] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
+            }
+            if (++x == dw) { x = 0; y++; }
         }
     }
     if (tid == 0) *cnt_out = (unsigned short) total;
@@ -839,8 +872,9 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int nFrames) {
     if (totalCells <= 0) return;
-    hipLaunchKernelGGL(k_fast_cells, dim3(totalCells, nFrames), dim3(kFastBlock), 0, st, fs, dGeom, nlevels, iniTh, minTh,
-                       cellCnt, slots, totalCells, totalSlots);
+    const int cellsPerXcd = (totalCells + 7) / 8;
+    hipLaunchKernelGGL(k_fast_cells, dim3(8 * cellsPerXcd, nFrames), dim3(kFastBlock), 0, st, fs, dGeom, nlevels, iniTh, minTh,
+                       cellCnt, slots, totalCells, totalSlots, cellsPerXcd);
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap) { return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 19 * (size_t) cap); }

@@ -62,5 +62,32 @@ void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt
                              float fy, float cx, float cy, float *world);
 void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ldsBytes);
 
+
+// ---- sparse image alignment (align_kernels.hip) ----------------------------------------------------------------------
+struct SiaLevel {
+    const uint8_t *img;
+    int w, h, pitch;
+};
+struct SiaArgs {
+    const ygzf_kp *keys;            // ref keypoints, pair p at keys + p*kpStride
+    const float *world;             // MapPoint world positions, 3 per keypoint
+    const uint8_t *mpValid, *outlier;  // nullable
+    long long kpStride;
+    const int *nRef;                // per-pair count, or null -> n
+    int n;
+    const float *poses;             // per pair 14 floats: ref Tcw (qx qy qz qw tx ty tz), cur Tcw
+    const SiaLevel *refLv, *curLv;  // per pair lvStride entries, indexed by pyramid level
+    int lvStride;
+    float invScale[kMaxLevels];
+    float fx, fy, cx, cy;
+    int maxLevel, minLevel, nIter;
+    float eps;
+    float *patchCache;              // kpStride*16 floats per pair
+    float *jacCache;                // kpStride*96 floats per pair
+    uint8_t *visible;               // kpStride per pair
+    float *out;                     // 48 floats per pair: TCR[7], ret, iters, chi2, pad[2], H[36]
+};
+void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs);
+
 }  // namespace ygzf
 #endif

@@ -63,9 +63,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -97,7 +97,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12];
+        dGen[12], dSia[8];
     bool carryValid = false;
     int lastMatchPairs = 0;
     int identityPoses = 0;
@@ -491,6 +491,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dSia)
         if (b.p) (void) hipFree(b.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
@@ -966,6 +968,98 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
     HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
+
+// ---- SparseImgAlign::run ------------------------------------------------------------------------------------------------
+int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, const ygzf_camera *cam, const float *inv_scale_factors,
+                 int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36) {
+    if (!c || !ref || !cur || !cam || !inv_scale_factors || !TCR_out || !ret) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *ret = 0;
+    if (max_level < min_level || min_level < 0 || max_level >= kMaxLevels || max_level >= ref->nlevels || max_level >= cur->nlevels)
+        return fail(c, YGZF_ERR_INVALID, "bad level range [%d,%d]", min_level, max_level);
+    if (ref->n < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    // T_cur_from_ref for the empty case is still cur*ref^-1 in the reference only after the early return; :24-27 returns 0 at once
+    if (ref->n == 0) {   // "SparseImgAlign: no features to track!" -> return 0, TCR untouched
+        if (info) { info[0] = 0; info[1] = 0; }
+        return YGZF_OK;
+    }
+    if (!ref->keys || !ref->mp_world || !ref->levels || !cur->levels || !ref->level_w || !ref->level_h || !cur->level_w || !cur->level_h)
+        return fail(c, YGZF_ERR_INVALID, "null array");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t N = ref->n;
+    int rc;
+    ygzf_ctx::Buf *S = c->dSia;
+    // 0 keys, 1 world, 2 valid, 3 outlier, 4 images, 5 tables (poses + levels), 6 caches, 7 out
+    if ((rc = ensure(c, S[0], N * sizeof(ygzf_kp))) || (rc = ensure(c, S[1], N * 12)) || (rc = ensure(c, S[2], N)) || (rc = ensure(c, S[3], N)))
+        return rc;
+    HIPCHECK(c, hipMemcpyAsync(S[0].p, ref->keys, N * sizeof(ygzf_kp), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(S[1].p, ref->mp_world, N * 12, hipMemcpyHostToDevice, c->stream));
+    if (ref->mp_valid) HIPCHECK(c, hipMemcpyAsync(S[2].p, ref->mp_valid, N, hipMemcpyHostToDevice, c->stream));
+    if (ref->outlier) HIPCHECK(c, hipMemcpyAsync(S[3].p, ref->outlier, N, hipMemcpyHostToDevice, c->stream));
+    size_t imgBytes = 0;
+    for (int l = min_level; l <= max_level; l++) {
+        if (ref->level_w[l] < 1 || ref->level_h[l] < 1 || cur->level_w[l] < 1 || cur->level_h[l] < 1 || !ref->levels[l] || !cur->levels[l])
+            return fail(c, YGZF_ERR_INVALID, "bad pyramid level %d", l);
+        imgBytes += (size_t) ref->level_w[l] * ref->level_h[l] + (size_t) cur->level_w[l] * cur->level_h[l] + 128;
+    }
+    if ((rc = ensure(c, S[4], imgBytes))) return rc;
+    std::vector<SiaLevel> lv(2 * kMaxLevels);
+    memset(lv.data(), 0, lv.size() * sizeof(SiaLevel));
+    size_t off = 0;
+    for (int l = min_level; l <= max_level; l++) {
+        for (int side = 0; side < 2; side++) {
+            const ygzf_sia_frame *f = side ? cur : ref;
+            const size_t b = (size_t) f->level_w[l] * f->level_h[l];
+            uint8_t *d = (uint8_t *) S[4].p + off;
+            HIPCHECK(c, hipMemcpyAsync(d, f->levels[l], b, hipMemcpyHostToDevice, c->stream));   // Frame clones are tight (step == cols)
+            SiaLevel &L = lv[side * kMaxLevels + l];
+            L.img = d; L.w = f->level_w[l]; L.h = f->level_h[l]; L.pitch = f->level_w[l];
+            off += (b + 63) & ~(size_t) 63;
+        }
+    }
+    const size_t tabBytes = 14 * sizeof(float) + lv.size() * sizeof(SiaLevel);
+    if ((rc = ensure(c, S[5], tabBytes + 64))) return rc;
+    float poses[14];
+    memcpy(poses, ref->Tcw, 28);
+    memcpy(poses + 7, cur->Tcw, 28);
+    HIPCHECK(c, hipMemcpyAsync(S[5].p, poses, sizeof poses, hipMemcpyHostToDevice, c->stream));
+    SiaLevel *dLv = (SiaLevel *) ((uint8_t *) S[5].p + 64);
+    HIPCHECK(c, hipMemcpyAsync(dLv, lv.data(), lv.size() * sizeof(SiaLevel), hipMemcpyHostToDevice, c->stream));
+    if ((rc = ensure(c, S[6], N * (16 + 96) * sizeof(float) + N + 64)) || (rc = ensure(c, S[7], 48 * sizeof(float)))) return rc;
+    SiaArgs A;
+    memset(&A, 0, sizeof A);
+    A.keys = (const ygzf_kp *) S[0].p;
+    A.world = (const float *) S[1].p;
+    A.mpValid = ref->mp_valid ? (const uint8_t *) S[2].p : nullptr;
+    A.outlier = ref->outlier ? (const uint8_t *) S[3].p : nullptr;
+    A.kpStride = (long long) N;
+    A.nRef = nullptr;
+    A.n = (int) N;
+    A.poses = (const float *) S[5].p;
+    A.refLv = dLv;
+    A.curLv = dLv + kMaxLevels;
+    A.lvStride = 0;
+    for (int l = 0; l < kMaxLevels; l++) A.invScale[l] = l <= max_level ? inv_scale_factors[l] : 1.f;
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy;
+    A.maxLevel = max_level; A.minLevel = min_level; A.nIter = n_iter;
+    A.eps = 0.000001f;   // src/SparseImageAlign.cc:17
+    A.patchCache = (float *) S[6].p;
+    A.jacCache = A.patchCache + N * 16;
+    A.visible = (uint8_t *) (A.jacCache + N * 96);
+    A.out = (float *) S[7].p;
+    {
+        ProfScope ps(c, KK_SIA);
+        launch_sia(c->stream, A, 1);
+    }
+    HIPCHECK(c, hipGetLastError());
+    float out[48];
+    HIPCHECK(c, hipMemcpyAsync(out, S[7].p, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    memcpy(TCR_out, out, 28);
+    *ret = (size_t) out[7];
+    if (info) { info[0] = out[8]; info[1] = out[9]; }
+    if (H36) memcpy(H36, out + 12, 36 * sizeof(float));
     return YGZF_OK;
 }
 
