@@ -55,6 +55,6 @@ def test_product_does_not_reference_the_oracle():
         for f in files:
             if f.endswith((".hip", ".h", ".cpp", ".cc", ".py")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
-                if re.search(r'#include\s*[<"].*oracle|from\s+oracle|import\s+oracle|libygz_oracle', txt):
+                if re.search(r'^\s*#include\s*[<"][^>"\n]*oracle|^\s*from\s+oracle\b|^\s*import\s+oracle\b|libygz_oracle', txt, flags=re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
