@@ -1,0 +1,105 @@
+// ORBmatcher.cc -- shell of ygz::ORBmatcher over libygzf's C ABI (product code, host side): packs the Frame / MapPoint
+// fields SearchByProjection reads into the plain arrays of ygzf_search_by_projection_last and scatters the result back
+// into CurrentFrame.mvpMapPoints.
+#include "ORBmatcher.h"
+
+#include <cstdio>
+#include <mutex>
+
+#include "../../../include/ygzf.h"
+
+namespace ygz {
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+int ORBmatcher::sDevice = 0;
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+// One pair of 32-byte rows: a popcount over 4 x u64 on the host (a device launch for 64 bytes would be absurd); the batched
+// device form is ygzf_descriptor_distance / the matcher kernels.
+int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b) {
+    const uint64_t *pa = a.ptr<uint64_t>(), *pb = b.ptr<uint64_t>();
+    int dist = 0;
+    for (int i = 0; i < 4; i++) dist += __builtin_popcountll(pa[i] ^ pb[i]);
+    return dist;
+}
+
+namespace {
+struct CtxPool {
+    std::mutex mu;
+    std::vector<ygzf_ctx *> free_;
+    ygzf_ctx *take(int device) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!free_.empty()) { ygzf_ctx *c = free_.back(); free_.pop_back(); return c; }
+        }
+        ygzf_extractor_cfg cfg = {1000, 1.2f, 8, 20, 7};   // the matcher only uses the context's stream and scratch buffers
+        ygzf_ctx *c = nullptr;
+        if (ygzf_create(device, &cfg, 64, 64, 1, &c) != YGZF_OK) { fprintf(stderr, "ygz::ORBmatcher: %s\n", ygzf_last_error(nullptr)); return nullptr; }
+        return c;
+    }
+    void give(ygzf_ctx *c) { std::lock_guard<std::mutex> lk(mu); free_.push_back(c); }
+    ~CtxPool() { for (ygzf_ctx *c : free_) ygzf_destroy(c); }
+};
+CtxPool &pool() { static CtxPool p; return p; }
+}  // namespace
+
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, bool checkLevel) {
+    const int nt = CurrentFrame.N, nq = LastFrame.N;
+    if (nt <= 0 || nq <= 0) return 0;
+    ygzf_ctx *c = pool().take(sDevice);
+    if (!c) return 0;
+    // ---- pack LastFrame ----
+    std::vector<uint8_t> valid(nq), outl(nq), obs(nq), mpdesc((size_t) nq * 32);
+    std::vector<float> world((size_t) nq * 3);
+    for (int i = 0; i < nq; i++) {
+        MapPoint *mp = LastFrame.mvpMapPoints[i];
+        valid[i] = mp != nullptr;
+        outl[i] = LastFrame.mvbOutlier[i];
+        if (mp) {
+            obs[i] = mp->Observations() > 0;
+            ygz_compat::world_pos(mp, &world[3 * (size_t) i]);
+            const cv::Mat d = mp->GetDescriptor();
+            std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
+        }
+    }
+    // ---- pack CurrentFrame ----
+    std::vector<uint8_t> owner(nt), cdesc((size_t) nt * 32);
+    for (int i = 0; i < nt; i++) {
+        MapPoint *mp = CurrentFrame.mvpMapPoints[i];
+        owner[i] = mp ? (mp->Observations() > 0 ? 2 : 1) : 0;
+        std::memcpy(&cdesc[(size_t) i * 32], CurrentFrame.mDescriptors.ptr<uint8_t>(i), 32);
+    }
+    ygzf_frame_view cur;
+    cur.n = nt;
+    cur.keys = (const ygzf_kp *) CurrentFrame.mvKeys.data();
+    cur.desc = cdesc.data();
+    cur.u_right = CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data();
+    cur.scale_factors = CurrentFrame.mvScaleFactors.data();
+    cur.nlevels = (int) CurrentFrame.mvScaleFactors.size();
+    ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, CurrentFrame.mb, CurrentFrame.mbf,
+                       Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    float Rcw[9], tcw[3], Rlw[9], tlw[3];
+    ygz_compat::se3_to_Rt(CurrentFrame.mTcw, Rcw, tcw);
+    ygz_compat::se3_to_Rt(LastFrame.mTcw, Rlw, tlw);
+    std::vector<int> match(nt, -1);
+    int nmatches = 0;
+    const int rc = ygzf_search_by_projection_last(c, &cur, &cam, nq, (const ygzf_kp *) LastFrame.mvKeys.data(), valid.data(), outl.data(),
+                                                  obs.data(), world.data(), mpdesc.data(), Rcw, tcw, Rlw, tlw, th, bMono, checkLevel,
+                                                  mbCheckOrientation, owner.data(), match.data(), &nmatches);
+    if (rc != YGZF_OK) {
+        fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
+        pool().give(c);
+        return 0;
+    }
+    pool().give(c);
+    for (int i2 = 0; i2 < nt; i2++) {
+        if (match[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[match[i2]];
+        else if (match[i2] == -2) CurrentFrame.mvpMapPoints[i2] = static_cast<MapPoint *>(nullptr);   // culled by the rotation check
+    }
+    return nmatches;
+}
+
+}  // namespace ygz

@@ -1,0 +1,34 @@
+// ORBmatcher.h -- the Tracking-called part of ygz::ORBmatcher (reference include/ORBmatcher.h:38-149) over libygzf.
+#ifndef YGZF_HOST_ORBMATCHER_H
+#define YGZF_HOST_ORBMATCHER_H
+#include <vector>
+
+#include "ygz_compat.h"
+
+struct ygzf_ctx;
+
+namespace ygz {
+class ORBmatcher {
+public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true);
+
+    // Hamming distance between two 256-bit ORB descriptors (static, called all over the reference).
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+
+    // Project MapPoints tracked in the last frame into the current frame and search matches (TrackWithMotionModel).
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, bool checkLevel = true);
+
+    static const int TH_LOW;
+    static const int TH_HIGH;
+    static const int HISTO_LENGTH;
+
+    // Matcher objects are created on the stack per call from several threads: contexts come from a small
+    // thread-safe pool and are handed back by the destructor of the lease.
+    static int sDevice;
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+}  // namespace ygz
+#endif

@@ -1,0 +1,94 @@
+// test_shells.cc -- drives the three class shells (reference signatures) the way Tracking.cc does and dumps their
+// outputs as raw binaries for tests/test_gpu_shells.py to compare with the oracle.
+// usage: test_shells <dir>   reads <dir>/a.u8, <dir>/b.u8 (752x480 u8) and <dir>/depth.f32 (plane depth).
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+#include "SparseImageAlign.h"
+
+namespace ygz {
+float Frame::fx, Frame::fy, Frame::cx, Frame::cy, Frame::invfx, Frame::invfy, Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+}
+
+static std::vector<unsigned char> slurp(const std::string &p) {
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) { perror(p.c_str()); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> b(n);
+    if (fread(b.data(), 1, n, f) != (size_t) n) exit(2);
+    fclose(f);
+    return b;
+}
+static void dump(const std::string &p, const void *d, size_t n) {
+    FILE *f = fopen(p.c_str(), "wb");
+    if (n) fwrite(d, 1, n, f);
+    fclose(f);
+}
+
+int main(int argc, char **argv) {
+    using namespace ygz;
+    if (argc < 2) return 2;
+    const std::string dir = argv[1];
+    const int W = 752, H = 480, L = 8;
+    Frame::fx = 458.654f; Frame::fy = 457.296f; Frame::cx = 367.215f; Frame::cy = 248.375f;
+    Frame::mnMinX = 0; Frame::mnMinY = 0; Frame::mnMaxX = (float) W; Frame::mnMaxY = (float) H;
+    std::vector<unsigned char> ia = slurp(dir + "/a.u8"), ib = slurp(dir + "/b.u8"), wd = slurp(dir + "/depth.f32");
+    const float depth = *(const float *) wd.data();
+    ORBextractor ex(600, 1.2f, L, 20, 7);
+    Frame A, B;
+    Frame *fr[2] = {&A, &B};
+    std::vector<unsigned char> *im[2] = {&ia, &ib};
+    for (int k = 0; k < 2; k++) {
+        Frame &F = *fr[k];
+        F.mImGray = cv::Mat(H, W, CV_8UC1, im[k]->data());
+        ex.ComputePyramid(F.mImGray);                                  // Frame ctor -> ComputeImagePyramid (src/Frame.cc:807-813)
+        F.mvImagePyramid.clear();
+        for (int l = 0; l < L; l++) F.mvImagePyramid.push_back(ex.mvImagePyramid[l].clone());
+        F.mvScaleFactors = ex.GetScaleFactors();
+        F.mvInvScaleFactors = ex.GetInverseScaleFactors();
+        ex(&F, F.mvKeys, cv::_OutputArray(F.mDescriptors), ORBextractor::ORBSLAM_KEYPOINT, true);   // Frame::ExtractORB
+        F.N = (int) F.mvKeys.size();
+        F.mvpMapPoints.assign(F.N, nullptr);
+        F.mvbOutlier.assign(F.N, false);
+        F.mvuRight.assign(F.N, -1.f);
+    }
+    dump(dir + "/a_kps.bin", A.mvKeys.data(), A.mvKeys.size() * sizeof(cv::KeyPoint));
+    dump(dir + "/a_desc.bin", A.mDescriptors.ptr(0), (size_t) A.N * 32);
+    dump(dir + "/b_kps.bin", B.mvKeys.data(), B.mvKeys.size() * sizeof(cv::KeyPoint));
+    dump(dir + "/b_desc.bin", B.mDescriptors.ptr(0), (size_t) B.N * 32);
+    // MapPoints of A: plane at `depth`, descriptor = the keypoint's own
+    std::vector<MapPoint> mps(A.N);
+    for (int i = 0; i < A.N; i++) {
+        mps[i].mWorldPos[0] = (A.mvKeys[i].pt.x - Frame::cx) / Frame::fx * depth;
+        mps[i].mWorldPos[1] = (A.mvKeys[i].pt.y - Frame::cy) / Frame::fy * depth;
+        mps[i].mWorldPos[2] = depth;
+        mps[i].mDescriptor = A.mDescriptors.row(i).clone();
+        A.mvpMapPoints[i] = &mps[i];
+    }
+    // TrackWithSparseAlignment: SparseImgAlign(nLevels-1, 1).run(&last, &cur, TCR)   (src/Tracking.cc:207, :2087)
+    SparseImgAlign align(L - 1, 1);
+    SE3f TCR;
+    const size_t ret = align.run(&A, &B, TCR);
+    float t7[8];
+    ygz_compat::se3_to7(TCR, t7);
+    t7[7] = (float) ret;
+    dump(dir + "/tcr.bin", t7, sizeof t7);
+    // TrackWithMotionModel: cur pose = TCR * last pose, then SearchByProjection(cur, last, 15, mono)  (:1072-1093)
+    B.mTcw = TCR;
+    ORBmatcher matcher(0.9f, true);
+    const int nm = matcher.SearchByProjection(B, A, 15.f, true);
+    std::vector<int> assigned(B.N, -1);
+    for (int i = 0; i < B.N; i++)
+        if (B.mvpMapPoints[i]) assigned[i] = (int) (B.mvpMapPoints[i] - mps.data());
+    dump(dir + "/match.bin", assigned.data(), assigned.size() * sizeof(int));
+    dump(dir + "/nmatch.bin", &nm, sizeof nm);
+    cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
+    printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));
+    return 0;
+}

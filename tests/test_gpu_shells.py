@@ -1,0 +1,77 @@
+"""GPU test of the host-side mirror of the reference interface: the C++ class shells ygz::ORBextractor / ygz::ORBmatcher /
+ygz::SparseImgAlign (orb_ygz_slam_amd/csrc/host, reference signatures) are driven the way Tracking.cc drives them
+(tests/cpp/test_shells.cc) and their outputs compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.capi import EUROC, KP_DTYPE
+from orb_ygz_slam_amd.scene import two_view_scene
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(tmp):
+    host = os.path.join(ROOT, "orb_ygz_slam_amd", "csrc", "host")
+    lib = os.path.join(ROOT, "orb_ygz_slam_amd", "lib")
+    exe = os.path.join(tmp, "test_shells")
+    srcs = [os.path.join(ROOT, "tests", "cpp", "test_shells.cc")] + [os.path.join(host, f) for f in
+                                                                     ("ORBextractor.cc", "ORBmatcher.cc", "SparseImageAlign.cc")]
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", host] + srcs + ["-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
+    return exe
+
+
+def _R_from_q(q):  # Eigen toRotationMatrix, float32, same operation order as ygz_compat::se3_to_Rt
+    f = np.float32
+    tx, ty, tz = f(2) * q[0], f(2) * q[1], f(2) * q[2]
+    twx, twy, twz = tx * q[3], ty * q[3], tz * q[3]
+    txx, txy, txz = tx * q[0], ty * q[0], tz * q[0]
+    tyy, tyz, tzz = ty * q[1], tz * q[1], tz * q[2]
+    return np.array([[f(1) - (tyy + tzz), txy - twz, txz + twy], [txy + twz, f(1) - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, f(1) - (txx + tyy)]], np.float32)
+
+
+def test_class_shells_end_to_end(oracle, tmp_path):
+    from orb_ygz_slam_amd import load_library
+    load_library()
+    exe = _build(str(tmp_path))
+    w, h, depth = 752, 480, np.float32(4.0)
+    imgA, imgB, (R, t), _ = two_view_scene(9, w, h, EUROC, Z=float(depth))
+    imgA.tofile(tmp_path / "a.u8")
+    imgB.tofile(tmp_path / "b.u8")
+    np.array([depth], np.float32).tofile(tmp_path / "depth.f32")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "shells ok" in out.stdout
+    oex = oracle.Extractor(600, 1.2, 8, 20, 7)
+    res = {}
+    for name, img in (("a", imgA), ("b", imgB)):
+        k = np.fromfile(tmp_path / (name + "_kps.bin"), KP_DTYPE)
+        d = np.fromfile(tmp_path / (name + "_desc.bin"), np.uint8).reshape(-1, 32)
+        ok, od = oex.extract(img)
+        assert len(k) == len(ok) and (k == ok).all() and (d == od).all()
+        res[name] = (k, d)
+    ka, da = res["a"]
+    kb, db = res["b"]
+    f = np.float32
+    world = np.stack([(ka["x"] - f(EUROC["cx"])) / f(EUROC["fx"]) * depth, (ka["y"] - f(EUROC["cy"])) / f(EUROC["fy"]) * depth,
+                      np.full(len(ka), depth, np.float32)], -1).astype(np.float32)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    pyrA, pyrB = oex.pyramid(imgA), oex.pyramid(imgB)
+    o_ret, o_T, _, _ = oracle.sparse_img_align(ka, world, ident, pyrA, ident, pyrB, oex.tables()["inv_scale"], EUROC, 7, 1)
+    t7 = np.fromfile(tmp_path / "tcr.bin", np.float32)
+    assert int(t7[7]) == o_ret and o_ret > 100
+    assert np.abs(t7[:7] - o_T).max() <= 1e-5
+    assert np.abs(t7[4:7] - t).max() < 5e-3
+    # matcher: CurrentFrame.mTcw = TCR (as computed on the device), LastFrame.mTcw = identity
+    Rcw, tcw = _R_from_q(t7[:4]), t7[4:7]
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    e_n, e_m, _ = oracle.search_by_projection_last(kb, db, oex.tables()["scale"], w, h, EUROC, ka, world, da, Rcw, tcw, I, z, 15.0)
+    nm = int(np.fromfile(tmp_path / "nmatch.bin", np.int32)[0])
+    assigned = np.fromfile(tmp_path / "match.bin", np.int32)
+    assert nm == e_n and nm > 100
+    exp = np.where(e_m >= 0, e_m, -1)
+    assert (assigned == exp).all()
