@@ -80,7 +80,8 @@ int ygzf_compute_pyramid(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int st
 int ygzf_extract(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
 
 /* Batched form of the same operator on DEVICE-resident frames: frame f starts at d_imgs + f*frame_stride, rows are
- * row_pitch bytes apart.  Results stay on the device (chain into ygzf_match_*) until fetched.  Asynchronous on the
+ * row_pitch bytes apart (base pointer, row_pitch and frame_stride must be multiples of 4: the kernels use aligned 32-bit loads).
+ * Results stay on the device (chain into ygzf_match_*) until fetched.  Asynchronous on the
  * context stream; ygzf_sync / ygzf_batch_counts / ygzf_batch_fetch synchronise. */
 int ygzf_extract_batch_device(ygzf_ctx *ctx, const uint8_t *d_imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
 /* Same, host frames (H2D copy of each frame included). */

@@ -298,7 +298,7 @@ size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur,
 // with an identity relative pose and unit-depth back-projected points (SURVEY §8d metric definition).
 // Returns elapsed seconds; n_kp_total / n_match_total are checksums so the work cannot be optimised away.
 double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, const uint8_t *frames,
-                              int nframes, int w, int h, int threads, float fx, float fy, float cx, float cy,
+                              int nframes, int w, int h, int threads, int frames_per_thread, float fx, float fy, float cx, float cy,
                               long *n_kp_total, long *n_match_total) {
     std::vector<long> kp_acc(threads, 0), m_acc(threads, 0);
     auto t0 = std::chrono::steady_clock::now();
@@ -306,13 +306,14 @@ double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int
         Extractor ex(nfeatures, scaleFactor, nlevels, iniTh, minTh);
         std::vector<KeyPoint> kprev, kcur;
         std::vector<uint8_t> dprev, dcur;
-        // each worker owns a contiguous chunk of frames (so that the t-1 -> t pairs stay on one worker)
-        int per = (nframes + threads - 1) / threads;
-        int f0 = tid * per, f1 = std::min(nframes, f0 + per);
-        for (int f = f0; f < f1; f++) {
+        // each worker walks `frames_per_thread` consecutive frames of the clip (wrapping around), starting at its own offset,
+        // so that the t-1 -> t pairs stay on one worker and every worker does the same amount of work
+        const int start = (int) (((long) tid * 8) % nframes);
+        for (int j = 0; j < frames_per_thread; j++) {
+            const int f = (start + j) % nframes;
             ex.Extract(frames + (size_t) f * w * h, w, h, w, kcur, dcur);
             kp_acc[tid] += (long) kcur.size();
-            if (f > f0 && !kprev.empty() && !kcur.empty()) {
+            if (j > 0 && !kprev.empty() && !kcur.empty()) {
                 FrameView cur;
                 cur.N = (int) kcur.size();
                 cur.keys = kcur.data();

@@ -9,6 +9,8 @@
 // Everything here is integer / compare-select work bounded by HBM traffic and launch count, not by MFMA.
 // Built with -ffp-contract=off: the few float expressions (fastAtan2, the rBRIEF rotation) must round exactly like
 // the reference's scalar C++ (no FMA), see DESIGN.md "float details inside bit-exact descriptors".
+#include <cstdlib>
+
 #include "kernels.h"
 #include "orb_pattern_table.h"
 
@@ -196,6 +198,8 @@ __device__ __forceinline__ void ring_diffs(const uint8_t *c, int d[16]) {
 }
 
 // 1 = bright corner, 2 = dark corner, 0 = none, at threshold t (9 contiguous ring pixels > v+t or < v-t).
+// The 16-bit ring masks are built arithmetically (sign bit of t - d / d + t moved to bit k): three VALU ops per ring
+// pixel and polarity and no compare -> SGPR -> select round trip (which also costs hazard nops on gfx9).
 template <int TP>
 __device__ __forceinline__ int fast9_test(const uint8_t *c, int t) {
     int d[16];
@@ -203,8 +207,8 @@ __device__ __forceinline__ int fast9_test(const uint8_t *c, int t) {
     unsigned B = 0, D = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        B |= (unsigned) (d[k] > t) << k;
-        D |= (unsigned) (d[k] < -t) << k;
+        B |= ((unsigned) (t - d[k]) >> 31) << k;      // d > t
+        D |= ((unsigned) (d[k] + t) >> 31) << k;      // d < -t
     }
     return has_arc9(B) ? 1 : (has_arc9(D) ? 2 : 0);
 }
@@ -232,14 +236,14 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int pol) {
     return a - 1;
 }
 
-constexpr int kTP = 68;  // LDS pitch of the image window
+constexpr int kTP = 72;  // LDS pitch of the image window (66 + up to 3 bytes of alignment slack, multiple of 4)
 constexpr int kSP = 64;  // LDS pitch of the score map (<= 62 columns used)
 
 __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                           int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
                                                           unsigned *__restrict__ slots, int totalCells,
-                                                          long long totalSlots, int cellsPerXcd) {
-    __shared__ uint8_t tile[kMaxCellWin * kTP];
+                                                          long long totalSlots, int cellsPerXcd, int dbgStage) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kMaxCellWin * kTP];
     __shared__ __attribute__((aligned(16))) uint8_t smap[62 * kSP];
     __shared__ unsigned short queue[60 * 60];   // corner pixels (tile offset << 2 | polarity) awaiting their score
     __shared__ int s_tmp[20];
@@ -267,18 +271,25 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     }
     int pitch;
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
-    {   // stage the window; (ty, tx) advance incrementally (no per-element division)
-        int ty = tid / ww, tx = tid - ty * ww;
-        const int sy = kFastBlock / ww, sx = kFastBlock - sy * ww;
-        for (int idx = tid; idx < ww * hh; idx += kFastBlock) {
-            tile[ty * kTP + tx] = img[(long long) (iniY + ty) * pitch + iniX + tx];
+    // stage the window with aligned 32-bit loads: the LDS tile keeps the global misalignment (xoff = iniX & 3), so tile
+    // column tx of the window lives at byte xoff + tx of the row; 32-bit offsets only (a frame is < 2 GiB).
+    const int xoff = iniX & 3;
+    {
+        const int wd = (xoff + ww + 3) >> 2;                       // dwords per row (<= 18)
+        const unsigned *src = (const unsigned *) (img + (unsigned) iniY * (unsigned) pitch + (unsigned) (iniX - xoff));
+        const unsigned pitch4 = (unsigned) pitch >> 2;             // pitch is a multiple of 4 (checked by the host)
+        int ty = tid / wd, tx = tid - ty * wd;
+        const int sy = kFastBlock / wd, sx = kFastBlock - sy * wd;
+        for (int idx = tid; idx < wd * hh; idx += kFastBlock) {
+            ((unsigned *) tile)[ty * (kTP / 4) + tx] = src[(unsigned) ty * pitch4 + (unsigned) tx];
             ty += sy; tx += sx;
-            if (tx >= ww) { tx -= ww; ty++; }
+            if (tx >= wd) { tx -= wd; ty++; }
         }
     }
     for (int idx = tid; idx < (62 * kSP) / 16; idx += kFastBlock) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
     if (tid == 0) { s_ini = 0; s_q = 0; }
     __syncthreads();
+    if (dbgStage == 1) { if (tid == 0) *cnt_out = tile[tid]; return; }
     const int npix = dw * dh;
     const int ppt = (npix + kFastBlock - 1) / kFastBlock;  // <= 15 consecutive pixels per thread (raster order)
     const int p0 = tid * ppt;
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     {
         int y = y0, x = x0;
         for (int j = 0; j < ppt && p0 + j < npix; j++) {
-            const int off = (y + 3) * kTP + x + 3;
+            const int off = (y + 3) * kTP + x + 3 + xoff;
             const int pol = fast9_test<kTP>(&tile[off], minTh);
             if (pol) queue[atomicAdd(&s_q, 1)] = (unsigned short) ((off << 2) | pol);
             if (++x == dw) { x = 0; y++; }
@@ -295,14 +306,16 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     }
     __syncthreads();
     const int nq = s_q;
+    if (dbgStage == 2) { if (tid == 0) *cnt_out = nq; return; }
     for (int qi = tid; qi < nq; qi += kFastBlock) {
         const int e = queue[qi];
         const int off = e >> 2;
         const int s = fast9_arc_score<kTP>(&tile[off], e & 3);
-        const int ty = off / kTP, tx = off - ty * kTP;
+        const int ty = off / kTP, tx = off - ty * kTP - xoff;
         smap[(ty - 2) * kSP + tx - 2] = (uint8_t) s;   // score-map coords = domain coords + 1
     }
     __syncthreads();
+    if (dbgStage == 3) { if (tid == 0) *cnt_out = smap[70]; return; }
     unsigned keepIni = 0, keepMin = 0;
     {
         int y = y0, x = x0;
@@ -328,6 +341,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     }
     if (keepIni) atomicAdd(&s_ini, __popc(keepIni));
     __syncthreads();
+    if (dbgStage == 4) { if (tid == 0) *cnt_out = s_ini; return; }
     const unsigned keep = s_ini > 0 ? keepIni : keepMin;
     int total;
     int off = block_excl_scan(__popc(keep), s_tmp, &total);
@@ -401,7 +415,8 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
                                                       unsigned *__restrict__ candVal1, unsigned *__restrict__ candXY,
                                                       long long candStride, unsigned *__restrict__ lvlKpXY,
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
-                                                      int *__restrict__ lvlCandCnt, int kpStride, int cap) {
+                                                      int *__restrict__ lvlCandCnt, unsigned short *__restrict__ procOrder,
+                                                      int kpStride, int cap) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[256];
     __shared__ int s_tmp[20];
@@ -656,9 +671,21 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
         if (lane == 0) {
             const unsigned idx = 0xFFFFFFu - (best & 0xFFFFFFu);
             const unsigned p = xy[idx];
-            oxy[i] = ((p & 0xFFFFu) + kBorder) | (((p >> 16) + kBorder) << 16);
+            const unsigned kx = (p & 0xFFFFu) + kBorder, ky = (p >> 16) + kBorder;
+            oxy[i] = kx | (ky << 16);
             osc[i] = (unsigned char) (best >> 24);
+            // spatial key for the PROCESSING order of k_describe: 64x64-px tiles, row-major inside (locality of the 43x43
+            // window gathers; the output order is untouched)
+            S.sk[0][i] = ((((ky >> 6) << 6) | (kx >> 6)) << 12) | ((ky & 63) << 6) | (kx & 63);
+            S.sv[0][i] = (unsigned) i;
         }
+    }
+    __syncthreads();
+    {
+        unsigned *ok, *ov;
+        block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 24, histT, s_tmp, &ok, &ov);
+        unsigned short *po = procOrder + (long long) f * kpStride + g.kpBase;
+        for (int i = tid; i < n; i += kOctBlock) po[i] = (unsigned short) ov[i];
     }
     if (tid == 0) *lvlCnt = n;
 }
@@ -733,15 +760,15 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kWin = 43, kWinP = 44;    // raw window
-constexpr int kHb = 37, kHbP = 38;      // horizontally blurred: 43 rows x 37 cols (u16)
+constexpr int kWin = 43, kWinP = 64;    // raw window: one 16-byte aligned 64-byte span per row (+ alignment slack)
+constexpr int kHb = 37, kHbP = 40;      // horizontally blurred: 43 rows x 37 cols (u16), pitch even for 32-bit stores
 constexpr int kBl = 37, kBlP = 40;      // blurred 37x37 (u8)
 constexpr int kDescWaves = 4;
 
 struct DescLds {
-    uint8_t raw[kWin * kWinP];
-    unsigned short hb[kWin * kHbP];
-    uint8_t bl[kBl * kBlP];
+    __attribute__((aligned(16))) uint8_t raw[kWin * kWinP + 16];
+    __attribute__((aligned(16))) unsigned short hb[kWin * kHbP + 8];
+    __attribute__((aligned(16))) uint8_t bl[kBl * kBlP + 8];
 };
 
 __constant__ int8_t c_pattern[1024];
@@ -750,13 +777,18 @@ __constant__ int c_umax[16];
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                             const unsigned *__restrict__ lvlKpXY,
                                                             const unsigned char *__restrict__ lvlKpScore,
-                                                            const int *__restrict__ lvlKpCnt, int kpStride,
+                                                            const int *__restrict__ lvlKpCnt,
+                                                            const unsigned short *__restrict__ procOrder, int kpStride,
                                                             ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                            int *__restrict__ outCnt, int outStride) {
+                                                            int *__restrict__ outCnt, int outStride, int blocksPerXcd,
+                                                            int dbgStage) {
     __shared__ DescLds lds[kDescWaves];
     const int lane = lane_id(), wave = wave_id();
     const int f = blockIdx.y;
-    const int slot = blockIdx.x * kDescWaves + wave;  // index into the frame's concatenated level lists
+    // XCD-aware: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (spatially ordered) keypoint slots so
+    // that overlapping 43x43 windows meet in the same L2.  pslot = position in the frame's concatenated PROCESSING order.
+    if ((int) (blockIdx.x >> 3) >= blocksPerXcd) return;
+    const int pslot = ((blockIdx.x & 7) * blocksPerXcd + (blockIdx.x >> 3)) * kDescWaves + wave;
     const int *cnts = lvlKpCnt + f * nlevels;
     int l = 0, base = 0, total = 0;
     {
@@ -764,56 +796,99 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const
         bool found = false;
         for (int i = 0; i < nlevels; i++) {
             const int c = cnts[i];
-            if (!found && slot < acc + c) { l = i; base = acc; found = true; }
+            if (!found && pslot < acc + c) { l = i; base = acc; found = true; }
             acc += c;
         }
         total = acc;
-        if (slot == 0 && lane == 0) outCnt[f] = total;
+        if (pslot == 0 && lane == 0) outCnt[f] = total;
         if (!found) return;
     }
     const LevelGeom g = geom[l];
-    const int li = slot - base;
+    const int li = procOrder[(long long) f * kpStride + g.kpBase + (pslot - base)];  // list position handled by this wave
+    const int slot = base + li;                                                     // output index: level-major, list order
     const unsigned pxy = lvlKpXY[(long long) f * kpStride + g.kpBase + li];
     const int kx = pxy & 0xFFFFu, ky = pxy >> 16;
     const int score = lvlKpScore[(long long) f * kpStride + g.kpBase + li];
     int pitch;
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
     DescLds &L = lds[wave];
-    // stage the 43x43 window (rows ky-21..ky+21), reflecting at the image border
-    for (int idx = lane; idx < kWin * kWin; idx += 64) {
-        const int r = idx / kWin, c = idx - r * kWin;
-        const int yy = reflect101(ky - 21 + r, g.h), xx = reflect101(kx - 21 + c, g.w);
-        L.raw[r * kWinP + c] = img[(long long) yy * pitch + xx];
+    if (dbgStage == 6) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = (uint8_t) kx; return; }
+    // ---- stage the 43x43 window (rows ky-21..ky+21).  Interior keypoints: the 43 bytes of a row lie inside one 16-byte
+    // aligned 64-byte span -> 4 lanes x dwordx4 per row, 3 wave-level loads for the whole window, all in flight at once.
+    // Keypoints within 21 px of the image border need BORDER_REFLECT_101 (what the blur of the border-less level clone
+    // sees) and take the byte path.  Window column c of row r lives at raw[r*64 + ((rowOff0 + r*rowOffStep) & 15) + c].
+    const bool interior = kx >= 21 && kx + 21 < g.w && ky >= 21 && ky + 22 < g.h && ((pitch & 3) == 0);
+    int rowOff0 = 0, rowOffStep = 0;
+    if (interior) {
+        const unsigned long long a00 = (unsigned long long) img + (unsigned) (ky - 21) * (unsigned) pitch + (unsigned) (kx - 21);
+        rowOff0 = (int) (a00 & 15);
+        rowOffStep = pitch & 15;
+        for (int idx = lane; idx < kWin * 4; idx += 64) {
+            const int r = idx >> 2, q = idx & 3;
+            const unsigned long long a = a00 + (unsigned) r * (unsigned) pitch;
+            *(uint4 *) &L.raw[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
+        }
+    } else {
+        for (int idx = lane; idx < kWin * kWin; idx += 64) {
+            const int r = idx / kWin, c = idx - r * kWin;
+            const int yy = reflect101(ky - 21 + r, g.h), xx = reflect101(kx - 21 + c, g.w);
+            L.raw[r * kWinP + c] = img[(long long) yy * pitch + xx];
+        }
     }
-    wave_lds_sync();  // LDS writes of this wave are visible to all its lanes before the reads below
-    // intensity centroid on the 31x31 disc (centre = raw[21][21])
+#define RAWP(r) (&L.raw[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
+    wave_lds_sync();
+    if (dbgStage == 1) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = L.raw[100]; return; }
+    // ---- intensity centroid on the 31x31 disc (centre = window (21,21)): two rows per step, no divisions
     int m10 = 0, m01 = 0;
-    for (int idx = lane; idx < 31 * 31; idx += 64) {
-        const int v = idx / 31 - 15, u = idx - (idx / 31) * 31 - 15;
-        if (abs(u) <= c_umax[abs(v)]) {
-            const int I = L.raw[(21 + v) * kWinP + 21 + u];
-            m10 += u * I;
-            m01 += v * I;
+    {
+        const int u = (lane & 31) - 15;
+        for (int it = 0; it < 16; it++) {
+            const int v = 2 * it + (lane >> 5) - 15;
+            if ((lane & 31) < 31 && v <= 15 && abs(u) <= c_umax[abs(v)]) {
+                const int I = RAWP(21 + v)[21 + u];
+                m10 += u * I;
+                m01 += v * I;
+            }
         }
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float) m01, (float) m10);
-    // separable blur, horizontal then vertical
-    for (int idx = lane; idx < kWin * kHb; idx += 64) {
-        const int r = idx / kHb, c = idx - r * kHb;
-        const uint8_t *p = &L.raw[r * kWinP + c];
-        L.hb[r * kHbP + c] = (unsigned short) (18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    if (dbgStage == 2) { if (lane == 0) outKp[(long long) f * outStride + slot].angle = angle; return; }
+    // ---- separable 7-tap blur {18,34,49,55,49,34,18}: each lane produces runs of 8 outputs from a sliding window
+    // horizontal: 43 rows x 5 segments (8+8+8+8+5 columns)
+    for (int t = lane; t < kWin * 5; t += 64) {
+        const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
+        const uint8_t *p = RAWP(r) + 8 * sg;
+        int q[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = p[k];           // columns 8*sg .. 8*sg+13 (<= 45 + slack: inside the LDS row)
+        unsigned o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
+        unsigned *dst = (unsigned *) &L.hb[r * kHbP + 8 * sg];
+        dst[0] = o[0] | (o[1] << 16); dst[1] = o[2] | (o[3] << 16);
+        if (sg < 4) { dst[2] = o[4] | (o[5] << 16); dst[3] = o[6] | (o[7] << 16); }
+        else { dst[2] = o[4]; }                              // columns 32..36: 5 outputs (column 37.. unused)
     }
     wave_lds_sync();
-    for (int idx = lane; idx < kBl * kBl; idx += 64) {
-        const int r = idx / kBl, c = idx - r * kBl;
-        const unsigned short *p = &L.hb[r * kHbP + c];
-        const int s = 18 * (p[0] + p[6 * kHbP]) + 34 * (p[kHbP] + p[5 * kHbP]) + 49 * (p[2 * kHbP] + p[4 * kHbP]) + 55 * p[3 * kHbP];
-        const int v = (s + 32768) >> 16;
-        L.bl[r * kBlP + c] = (uint8_t) min(v, 255);
+    if (dbgStage == 5) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = (uint8_t) L.hb[100]; return; }
+    // vertical: 37 columns x 5 row segments
+    for (int t = lane; t < kBl * 5; t += 64) {
+        const int sg = (t * 1772) >> 16, c = t - 37 * sg;   // t / 37, t % 37 for t < 185
+        const unsigned short *p = &L.hb[(8 * sg) * kHbP + c];
+        const int nr = sg < 4 ? 8 : 5;
+        int q[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = (8 * sg + k < kWin) ? p[k * kHbP] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int s2 = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
+            if (k < nr) L.bl[(8 * sg + k) * kBlP + c] = (uint8_t) min((s2 + 32768) >> 16, 255);
+        }
     }
     wave_lds_sync();
+    if (dbgStage == 3) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = L.bl[100]; return; }
     float a, b;
     sincos_deg(angle, &a, &b);
     unsigned long long bits[4];
@@ -841,6 +916,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const
         kp.class_id = -1;
         *ok = kp;
     }
+#undef RAWP
 }
 
 // batched DescriptorDistance: popcount over 4 x u64
@@ -874,7 +950,7 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
     if (totalCells <= 0) return;
     const int cellsPerXcd = (totalCells + 7) / 8;
     hipLaunchKernelGGL(k_fast_cells, dim3(8 * cellsPerXcd, nFrames), dim3(kFastBlock), 0, st, fs, dGeom, nlevels, iniTh, minTh,
-                       cellCnt, slots, totalCells, totalSlots, cellsPerXcd);
+                       cellCnt, slots, totalCells, totalSlots, cellsPerXcd, getenv("YGZF_FAST_STAGE") ? atoi(getenv("YGZF_FAST_STAGE")) : 0);
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap) { return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 19 * (size_t) cap); }
@@ -886,18 +962,20 @@ hipError_t octree_prepare(size_t ldsBytes) {
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   int kpStride, int cap, size_t ldsBytes, int nFrames) {
+                   unsigned short *procOrder, int kpStride, int cap, size_t ldsBytes, int nFrames) {
     hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots,
                        totalCells, totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt,
-                       kpStride, cap);
+                       procOrder, kpStride, cap);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
-                     const unsigned char *lvlKpScore, const int *lvlKpCnt, int kpStride, ygzf_kp *outKp, uint8_t *outDesc,
-                     int *outCnt, int outStride, int nFrames) {
-    dim3 grid((kpStride + kDescWaves - 1) / kDescWaves, nFrames);
+                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
+                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames) {
+    const int nblk = (kpStride + kDescWaves - 1) / kDescWaves;
+    const int blocksPerXcd = (nblk + 7) / 8;
+    dim3 grid(8 * blocksPerXcd, nFrames);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpXY, lvlKpScore, lvlKpCnt,
-                       kpStride, outKp, outDesc, outCnt, outStride);
+                       procOrder, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd, getenv("YGZF_DESC_STAGE") ? atoi(getenv("YGZF_DESC_STAGE")) : 0);
 }
 
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out) {

@@ -97,7 +97,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8];
+        dGen[12], dSia[8], dProcOrder;
     bool carryValid = false;
     int lastMatchPairs = 0;
     int identityPoses = 0;
@@ -296,7 +296,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
     const Geometry &G = c->geo;
     const size_t B = (size_t) nFrames;
     int rc = 0;
-    if ((rc = ensure(c, c->dPyr, std::max<size_t>(B * G.pyrBytes, 16)))) return rc;
+    if ((rc = ensure(c, c->dPyr, std::max<size_t>(B * G.pyrBytes, 16) + 256))) return rc;
     if ((rc = ensure(c, c->dCellCnt, std::max<size_t>(B * G.totalCells * sizeof(unsigned short), 16)))) return rc;
     if ((rc = ensure(c, c->dSlots, std::max<size_t>(B * G.totalSlots * sizeof(unsigned), 16)))) return rc;
     const size_t cb = std::max<size_t>(B * G.candStride * sizeof(unsigned), 16);
@@ -307,7 +307,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
     const size_t kp1 = std::max<size_t>((B + 1) * G.kpStride, 16);  // + carry slot
     void *oldCnt = c->dOutCnt.p, *oldKp = c->dOutKp.p;
     if ((rc = ensure(c, c->dLvlXY, kp * sizeof(unsigned))) || (rc = ensure(c, c->dLvlScore, kp)) ||
-        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
+        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dProcOrder, kp * sizeof(unsigned short))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
         (rc = ensure(c, c->dOutKp, kp1 * sizeof(ygzf_kp))) || (rc = ensure(c, c->dOutDesc, kp1 * 32)) ||
         (rc = ensure(c, c->dOutCnt, (B + 1) * sizeof(int))))
         return rc;
@@ -395,13 +395,14 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             launch_octree(c->stream, dGeom, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                           G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                           (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
-                          (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p, G.kpStride,
-                          G.kpCapMax, c->octLds, nFrames);
+                          (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
+                          (unsigned short *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLds, nFrames);
         }
         {
             ProfScope ps(c, KK_DESCRIBE);
             launch_describe(c->stream, fs, dGeom, L, (const unsigned *) c->dLvlXY.p, (const unsigned char *) c->dLvlScore.p,
-                            (const int *) c->dLvlCnt.p, G.kpStride, outKp, outDesc, outCnt, G.kpStride, nFrames);
+                            (const int *) c->dLvlCnt.p, (const unsigned short *) c->dProcOrder.p, G.kpStride, outKp, outDesc, outCnt,
+                            G.kpStride, nFrames);
         }
     } else {
         HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int) * nFrames, c->stream));
@@ -487,7 +488,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)
@@ -574,6 +575,8 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
 int ygzf_extract_batch_device(ygzf_ctx *c, const uint8_t *d_imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride) {
     if (!c || !d_imgs) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (row_pitch < w) return fail(c, YGZF_ERR_INVALID, "row_pitch %d < width %d", row_pitch, w);
+    if (((uintptr_t) d_imgs & 3) || (row_pitch & 3) || (frame_stride & 3))
+        return fail(c, YGZF_ERR_UNSUPPORTED, "device frames must be 4-byte aligned (base pointer, row_pitch and frame_stride multiples of 4)");
     HIPCHECK(c, hipSetDevice(c->device));
     int rc = apply_geometry(c, w, h, n_frames);
     if (rc) return rc;
