@@ -405,6 +405,7 @@ struct OctShared {  // carved out of dynamic LDS
     int *Epos, *Ecnt;         // expandable nodes in creation order (cap each)
     unsigned *sk[2], *sv[2];  // sort buffers for E (cap each)
     int *flag;                // processed flag per list position (cap)
+    unsigned *cand;           // LDS-resident candidate sort buffers (4 x ldsCand), optional
 };
 
 __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
@@ -416,13 +417,15 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
                                                       long long candStride, unsigned *__restrict__ lvlKpXY,
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
                                                       int *__restrict__ lvlCandCnt, unsigned short *__restrict__ procOrder,
-                                                      int kpStride, int cap) {
+                                                      int kpStride, int cap, int ldsCand, long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[256];
     __shared__ int s_tmp[20];
     __shared__ int s_n, s_nE, s_cut, s_flagA;
     const int tid = threadIdx.x;
     const int l = blockIdx.x, f = blockIdx.y;
+#define OSTAMP(k) do { if (dbg && tid == 0 && f == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
+    OSTAMP(0);
     const LevelGeom g = geom[l];
     const int nCells = g.nCols * g.nRows;
     int *lvlCnt = lvlKpCnt + f * nlevels + l;
@@ -440,10 +443,11 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
         S.Epos = p; p += cap; S.Ecnt = p; p += cap;
         for (int b = 0; b < 2; b++) { S.sk[b] = (unsigned *) p; p += cap; S.sv[b] = (unsigned *) p; p += cap; }
         S.flag = p; p += cap;
+        S.cand = (unsigned *) p;   // 4 * ldsCand words: key/val double buffers when the level's candidates fit
     }
     const unsigned short *cc = cellCnt + (long long) f * totalCells + g.cellBase;
     const unsigned *sl = slots + (long long) f * totalSlots + g.slotBase;
-    unsigned *key0 = candKey0 + (long long) f * candStride + g.candBase;
+    unsigned *key0 = candKey0 + (long long) f * candStride + g.candBase;   // global scratch (used when M > ldsCand)
     unsigned *val0 = candVal0 + (long long) f * candStride + g.candBase;
     unsigned *key1 = candKey1 + (long long) f * candStride + g.candBase;
     unsigned *val1 = candVal1 + (long long) f * candStride + g.candBase;
@@ -459,23 +463,30 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
         if (tid == 0) *lvlCnt = 0;
         return;
     }
-    // ---- 2. path keys ----
-    for (int c = tid; c < nCells; c += kOctBlock) {
-        const int base = S.cellPref[c], n = S.cellPref[c + 1] - base;
-        const int ci = c / g.nCols, cj = c - ci * g.nCols;
-        for (int k = 0; k < n; k++) {
-            const unsigned e = sl[(long long) c * g.slotCap + k];
-            const int x = (int) (e & 255u) + cj * g.wCell, y = (int) ((e >> 8) & 255u) + ci * g.hCell;
-            const int i = base + k;
-            key0[i] = path_key(x, y, g);
-            val0[i] = ((e >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
-            xy[i] = (unsigned) x | ((unsigned) y << 16);
+    OSTAMP(1);
+    // ---- 2. path keys: one thread per candidate (its cell by binary search in the prefix table) ----
+    const bool inLds = M <= ldsCand;
+    if (inLds) { key0 = S.cand; val0 = S.cand + ldsCand; key1 = S.cand + 2 * ldsCand; val1 = S.cand + 3 * ldsCand; }
+    for (int i = tid; i < M; i += kOctBlock) {
+        int a = 0, b = nCells;                       // last cell c with cellPref[c] <= i
+        while (b - a > 1) {
+            const int m = (a + b) >> 1;
+            if (S.cellPref[m] <= i) a = m; else b = m;
         }
+        const int c = a, k = i - S.cellPref[c];
+        const int ci = c / g.nCols, cj = c - ci * g.nCols;
+        const unsigned e = sl[(long long) c * g.slotCap + k];
+        const int x = (int) (e & 255u) + cj * g.wCell, y = (int) ((e >> 8) & 255u) + ci * g.hCell;
+        key0[i] = path_key(x, y, g);
+        val0[i] = ((e >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
+        xy[i] = (unsigned) x | ((unsigned) y << 16);
     }
     __syncthreads();
+    OSTAMP(2);
     // ---- 3. sort by path key ----
     unsigned *skeys, *svals;
     block_radix_sort(key0, val0, key1, val1, M, g.keyBits, histT, s_tmp, &skeys, &svals);
+    OSTAMP(3);
     // ---- 4. breadth-first subdivision on ranges ----
     const int D = g.depth;
     const int N = g.nFeat;
@@ -659,6 +670,7 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
             }
         }
     }
+    OSTAMP(4);
     // ---- 5. best response per node (:702-720), output in list order ----
     unsigned *oxy = lvlKpXY + (long long) f * kpStride + g.kpBase;
     unsigned char *osc = lvlKpScore + (long long) f * kpStride + g.kpBase;
@@ -674,20 +686,23 @@ __global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restric
             const unsigned kx = (p & 0xFFFFu) + kBorder, ky = (p >> 16) + kBorder;
             oxy[i] = kx | (ky << 16);
             osc[i] = (unsigned char) (best >> 24);
-            // spatial key for the PROCESSING order of k_describe: 64x64-px tiles, row-major inside (locality of the 43x43
-            // window gathers; the output order is untouched)
-            S.sk[0][i] = ((((ky >> 6) << 6) | (kx >> 6)) << 12) | ((ky & 63) << 6) | (kx & 63);
+            // spatial key for the PROCESSING order of k_describe: 64x64-px tile id, stable within a tile (locality of the
+            // 43x43 window gathers; the output order is untouched)
+            S.sk[0][i] = ((ky >> 6) << 6) | (kx >> 6);
             S.sv[0][i] = (unsigned) i;
         }
     }
     __syncthreads();
     {
         unsigned *ok, *ov;
-        block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 24, histT, s_tmp, &ok, &ov);
+        block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 12, histT, s_tmp, &ok, &ov);
         unsigned short *po = procOrder + (long long) f * kpStride + g.kpBase;
         for (int i = tid; i < n; i += kOctBlock) po[i] = (unsigned short) ov[i];
     }
     if (tid == 0) *lvlCnt = n;
+    OSTAMP(5);
+    if (dbg && tid == 0 && f == 0) { dbg[l * 8 + 6] = M; dbg[l * 8 + 7] = n; }
+#undef OSTAMP
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -953,7 +968,9 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
                        cellCnt, slots, totalCells, totalSlots, cellsPerXcd, getenv("YGZF_FAST_STAGE") ? atoi(getenv("YGZF_FAST_STAGE")) : 0);
 }
 
-size_t octree_lds_bytes(int maxCellsPerLevel, int cap) { return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 19 * (size_t) cap); }
+size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand) {
+    return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 19 * (size_t) cap + 4 * (size_t) ldsCand);
+}
 
 hipError_t octree_prepare(size_t ldsBytes) {
     return hipFuncSetAttribute((const void *) k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
@@ -962,10 +979,10 @@ hipError_t octree_prepare(size_t ldsBytes) {
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   unsigned short *procOrder, int kpStride, int cap, size_t ldsBytes, int nFrames) {
+                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg) {
     hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots,
                        totalCells, totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt,
-                       procOrder, kpStride, cap);
+                       procOrder, kpStride, cap, ldsCand, dbg);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,

@@ -11,12 +11,12 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int nFrames);
-size_t octree_lds_bytes(int maxCellsPerLevel, int cap);
+size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand);
 hipError_t octree_prepare(size_t ldsBytes);
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   unsigned short *procOrder, int kpStride, int cap, size_t ldsBytes, int nFrames);
+                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg = nullptr);
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
                      const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
                      ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames);

@@ -103,6 +103,7 @@ struct ygzf_ctx {
     int identityPoses = 0;
     void *identityPosesPtr = nullptr;
     size_t octLds = 0;
+    int octLdsCand = 0;
     // batch state
     int lastFrames = 0;
     FrameSet lastFs{};
@@ -287,7 +288,14 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         }
         c->carryValid = false;
         c->lastFrames = 0;
-        c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax);
+        // LDS-resident candidate sort buffers: as many as keep two workgroups per CU (<= ~78 KB each)
+        {
+            const size_t fixed = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0);
+            const size_t budget = 78 * 1024;
+            c->octLdsCand = fixed + 16 * 256 < budget ? (int) ((budget - fixed) / 16) : 0;
+            if (c->octLdsCand > 8192) c->octLdsCand = 8192;
+        }
+        c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, c->octLdsCand);
         if (c->octLds > 160 * 1024 - 2048)
             return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
                         G.maxCellsPerLevel, G.kpCapMax);
@@ -390,13 +398,27 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                               (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, nFrames);
         }
+        long long *odbg = nullptr;
+        if (getenv("YGZF_OCT_DEBUG")) {
+            int rc2 = ensure(c, c->dTmpA, 16 * 8 * sizeof(long long));
+            if (rc2) return rc2;
+            odbg = (long long *) c->dTmpA.p;
+        }
         {
             ProfScope ps(c, KK_OCTREE);
             launch_octree(c->stream, dGeom, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                           G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                           (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                           (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
-                          (unsigned short *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLds, nFrames);
+                          (unsigned short *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg);
+        }
+        if (odbg) {
+            long long st[16 * 8];
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            HIPCHECK(c, hipMemcpy(st, odbg, sizeof st, hipMemcpyDeviceToHost));
+            for (int l = 0; l < L; l++)
+                fprintf(stderr, "[ygzf octree lvl %d, 10ns ticks] prefix %lld keys %lld sort %lld bfs %lld final %lld  M=%lld n=%lld\n", l, st[l * 8 + 1] - st[l * 8],
+                        st[l * 8 + 2] - st[l * 8 + 1], st[l * 8 + 3] - st[l * 8 + 2], st[l * 8 + 4] - st[l * 8 + 3], st[l * 8 + 5] - st[l * 8 + 4], st[l * 8 + 6], st[l * 8 + 7]);
         }
         {
             ProfScope ps(c, KK_DESCRIBE);
