@@ -140,6 +140,8 @@ __device__ void block_radix_sort(unsigned *k0, unsigned *v0, unsigned *k1, unsig
     *rv = v0;
 }
 
+__device__ __forceinline__ void wave_lds_sync();
+
 // ------------------------------------------------------------------------------------------------------------------
 // K1  pyramid level from the previous level: cv::resize INTER_LINEAR, 8UC1, 11-bit fixed point coefficients that the
 // host precomputed exactly as OpenCV does (xofs/ialpha, yofs/ibeta).  One thread per output pixel.
@@ -187,23 +189,23 @@ __device__ __forceinline__ bool has_arc9(unsigned m16) {
     return (r & 0xFFFFu) != 0;
 }
 
-// Ring differences d[k] = ring_k - centre for the 16-pixel Bresenham circle (offsets as cv::FAST / libfast).
-template <int TP>
-__device__ __forceinline__ void ring_diffs(const uint8_t *c, int d[16]) {
+// Ring differences d[k] = ring_k - centre for the 16-pixel Bresenham circle (offsets as cv::FAST / libfast);
+// tp = LDS pitch of the staged window.
+__device__ __forceinline__ void ring_diffs(const uint8_t *c, int tp, int d[16]) {
     const int v = c[0];
-    d[0] = c[3 * TP] - v;       d[1] = c[3 * TP + 1] - v;   d[2] = c[2 * TP + 2] - v;   d[3] = c[TP + 3] - v;
-    d[4] = c[3] - v;            d[5] = c[-TP + 3] - v;      d[6] = c[-2 * TP + 2] - v;  d[7] = c[-3 * TP + 1] - v;
-    d[8] = c[-3 * TP] - v;      d[9] = c[-3 * TP - 1] - v;  d[10] = c[-2 * TP - 2] - v; d[11] = c[-TP - 3] - v;
-    d[12] = c[-3] - v;          d[13] = c[TP - 3] - v;      d[14] = c[2 * TP - 2] - v;  d[15] = c[3 * TP - 1] - v;
+    const int t2 = 2 * tp, t3 = 3 * tp;
+    d[0] = c[t3] - v;        d[1] = c[t3 + 1] - v;    d[2] = c[t2 + 2] - v;    d[3] = c[tp + 3] - v;
+    d[4] = c[3] - v;         d[5] = c[-tp + 3] - v;   d[6] = c[-t2 + 2] - v;   d[7] = c[-t3 + 1] - v;
+    d[8] = c[-t3] - v;       d[9] = c[-t3 - 1] - v;   d[10] = c[-t2 - 2] - v;  d[11] = c[-tp - 3] - v;
+    d[12] = c[-3] - v;       d[13] = c[tp - 3] - v;   d[14] = c[t2 - 2] - v;   d[15] = c[t3 - 1] - v;
 }
 
 // 1 = bright corner, 2 = dark corner, 0 = none, at threshold t (9 contiguous ring pixels > v+t or < v-t).
-// The 16-bit ring masks are built arithmetically (sign bit of t - d / d + t moved to bit k): three VALU ops per ring
-// pixel and polarity and no compare -> SGPR -> select round trip (which also costs hazard nops on gfx9).
-template <int TP>
-__device__ __forceinline__ int fast9_test(const uint8_t *c, int t) {
+// The 16-bit ring masks are built arithmetically (sign bit of t - d / d + t moved to bit k): no compare -> SGPR -> select
+// round trip (which also costs hazard nops on gfx9).
+__device__ __forceinline__ int fast9_test(const uint8_t *c, int tp, int t) {
     int d[16];
-    ring_diffs<TP>(c, d);
+    ring_diffs(c, tp, d);
     unsigned B = 0, D = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -215,10 +217,9 @@ __device__ __forceinline__ int fast9_test(const uint8_t *c, int t) {
 
 // cv::FAST cornerScore<16> for a pixel known to be a corner of polarity `pol`: max over the 16 arcs of 9 of the minimum
 // margin, minus 1 (== the largest threshold for which the pixel is still a corner).
-template <int TP>
-__device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int pol) {
+__device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol) {
     int e[16];
-    ring_diffs<TP>(c, e);
+    ring_diffs(c, tp, e);
     if (pol == 2) {
 #pragma unroll
         for (int k = 0; k < 16; k++) e[k] = -e[k];
@@ -236,127 +237,198 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int pol) {
     return a - 1;
 }
 
-constexpr int kTP = 72;  // LDS pitch of the image window (66 + up to 3 bytes of alignment slack, multiple of 4)
-constexpr int kSP = 64;  // LDS pitch of the score map (<= 62 columns used)
+constexpr int kSP = 64;          // LDS pitch of a cell's score map (<= 62 columns used)
+constexpr int kCornerCap = 512;  // corners listed per cell before the dense fallback takes over
 
+// One workgroup = a 2x2 group of cells of one level, one WAVE per cell.  The union window of the group is staged once
+// (aligned dwords); after that single block barrier every wave works alone on its cell: corner test over the cell's
+// pixels in raster order with ballot-compacted corner list, score per corner, 3x3 NMS for both thresholds on the wave's
+// private score map, cell-empty fallback, and ordered output -- all synchronisation is wave-local.
 __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                           int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
-                                                          unsigned *__restrict__ slots, int totalCells,
-                                                          long long totalSlots, int cellsPerXcd, int dbgStage) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kMaxCellWin * kTP];
-    __shared__ __attribute__((aligned(16))) uint8_t smap[62 * kSP];
-    __shared__ unsigned short queue[60 * 60];   // corner pixels (tile offset << 2 | polarity) awaiting their score
-    __shared__ int s_tmp[20];
-    __shared__ int s_ini, s_q;
-    const int tid = threadIdx.x;
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 (observed dispatch order; performance only).  Give every XCD a
-    // contiguous run of cells so that neighbouring windows, which share cache lines, meet in the same L2.
-    const int cell = (blockIdx.x & 7) * cellsPerXcd + (blockIdx.x >> 3);
+                                                          unsigned *__restrict__ slots, int totalCells, long long totalSlots,
+                                                          int totalGroups, int groupsPerXcd, int tilePitch, int tileRows,
+                                                          int smapRows) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
+    // that neighbouring windows, which share cache lines, meet in the same L2.
+    if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
+    const int grp = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);
     const int f = blockIdx.y;
-    if (cell >= totalCells || (int) (blockIdx.x >> 3) >= cellsPerXcd) return;
+    if (grp >= totalGroups) return;
     int l = 0;
-    while (l + 1 < nlevels && cell >= geom[l + 1].cellBase) l++;
+    while (l + 1 < nlevels && grp >= geom[l + 1].groupBase) l++;
     const LevelGeom g = geom[l];
-    const int c = cell - g.cellBase;
-    const int ci = c / g.nCols, cj = c - ci * g.nCols;
-    const int iniX = kBorder + cj * g.wCell, iniY = kBorder + ci * g.hCell;
-    const int maxX = min(iniX + g.wCell + 6, g.maxBorderX), maxY = min(iniY + g.hCell + 6, g.maxBorderY);
-    const bool skip = (iniX >= g.maxBorderX - 6) || (iniY >= g.maxBorderY - 3);  // :751,:759 (asymmetric on purpose)
-    const int ww = maxX - iniX, hh = maxY - iniY;
-    const int dw = ww - 6, dh = hh - 6;
-    unsigned short *cnt_out = cellCnt + (long long) f * totalCells + cell;
-    if (skip || dw <= 0 || dh <= 0) {
-        if (tid == 0) *cnt_out = 0;
-        return;
-    }
+    const int gl = grp - g.groupBase;
+    const int gCols = (g.nCols + 1) >> 1;
+    const int gi = gl / gCols, gj = gl - gi * gCols;
+    // union window of the group, clipped like the cells are
+    const int gx0 = kBorder + (2 * gj) * g.wCell, gy0 = kBorder + (2 * gi) * g.hCell;
+    const int gx1 = min(gx0 + 2 * g.wCell + 6, g.maxBorderX), gy1 = min(gy0 + 2 * g.hCell + 6, g.maxBorderY);
+    uint8_t *tile = fdyn;
+    const int tp = tilePitch;
+    const int xoff = gx0 & 3;
     int pitch;
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
-    // stage the window with aligned 32-bit loads: the LDS tile keeps the global misalignment (xoff = iniX & 3), so tile
-    // column tx of the window lives at byte xoff + tx of the row; 32-bit offsets only (a frame is < 2 GiB).
-    const int xoff = iniX & 3;
-    {
-        const int wd = (xoff + ww + 3) >> 2;                       // dwords per row (<= 18)
-        const unsigned *src = (const unsigned *) (img + (unsigned) iniY * (unsigned) pitch + (unsigned) (iniX - xoff));
-        const unsigned pitch4 = (unsigned) pitch >> 2;             // pitch is a multiple of 4 (checked by the host)
+    if (gx1 > gx0 && gy1 > gy0) {
+        const int wd = (xoff + (gx1 - gx0) + 3) >> 2, hh = gy1 - gy0;
+        const unsigned *src = (const unsigned *) (img + (unsigned) gy0 * (unsigned) pitch + (unsigned) (gx0 - xoff));
+        const unsigned pitch4 = (unsigned) pitch >> 2;
         int ty = tid / wd, tx = tid - ty * wd;
         const int sy = kFastBlock / wd, sx = kFastBlock - sy * wd;
         for (int idx = tid; idx < wd * hh; idx += kFastBlock) {
-            ((unsigned *) tile)[ty * (kTP / 4) + tx] = src[(unsigned) ty * pitch4 + (unsigned) tx];
+            ((unsigned *) tile)[ty * (tp >> 2) + tx] = src[(unsigned) ty * pitch4 + (unsigned) tx];
             ty += sy; tx += sx;
             if (tx >= wd) { tx -= wd; ty++; }
         }
     }
-    for (int idx = tid; idx < (62 * kSP) / 16; idx += kFastBlock) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) { s_ini = 0; s_q = 0; }
-    __syncthreads();
-    if (dbgStage == 1) { if (tid == 0) *cnt_out = tile[tid]; return; }
+    __syncthreads();   // the only block-level synchronisation
+    // ---- per-wave: one cell ----
+    const int ci = 2 * gi + (wave >> 1), cj = 2 * gj + (wave & 1);
+    if (ci >= g.nRows || cj >= g.nCols) return;
+    const int c = ci * g.nCols + cj;
+    unsigned short *cnt_out = cellCnt + (long long) f * totalCells + g.cellBase + c;
+    const int iniX = kBorder + cj * g.wCell, iniY = kBorder + ci * g.hCell;
+    const int maxX = min(iniX + g.wCell + 6, g.maxBorderX), maxY = min(iniY + g.hCell + 6, g.maxBorderY);
+    const bool skip = (iniX >= g.maxBorderX - 6) || (iniY >= g.maxBorderY - 3);  // :751,:759 (asymmetric on purpose)
+    const int dw = maxX - iniX - 6, dh = maxY - iniY - 6;
+    if (skip || dw <= 0 || dh <= 0) {
+        if (lane == 0) *cnt_out = 0;
+        return;
+    }
+    uint8_t *smap = fdyn + ((tileRows * tp + 15) & ~15) + wave * (smapRows * kSP);
+    unsigned short *clist = (unsigned short *) (fdyn + ((tileRows * tp + 15) & ~15) + kFastBlock / 64 * (smapRows * kSP)) + wave * kCornerCap;
+    for (int idx = lane; idx < ((dh + 2) * kSP) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
+    // origin of the cell window inside the staged tile
+    const int obase = (iniY - gy0) * tp + (iniX - gx0) + xoff;
     const int npix = dw * dh;
-    const int ppt = (npix + kFastBlock - 1) / kFastBlock;  // <= 15 consecutive pixels per thread (raster order)
-    const int p0 = tid * ppt;
-    const int y0 = p0 / dw, x0 = p0 - y0 * dw;
-    // pass 1: corner test at minTh for every pixel; corners are queued so that the (much costlier) score runs densely
+    const int qy = 64 / dw, qx = 64 - qy * dw;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    // pass 1: corner test at minTh for every pixel in raster order; corners are appended to the wave's list (tile offset,
+    // polarity) by ballot rank, so the list IS in raster order.  When the list is full the rest is handled by the dense
+    // fallback below (never on natural images: > 512 corners in a 30x30 cell).
+    int ncorn = 0;
+    bool overflow = false;
     {
-        int y = y0, x = x0;
-        for (int j = 0; j < ppt && p0 + j < npix; j++) {
-            const int off = (y + 3) * kTP + x + 3 + xoff;
-            const int pol = fast9_test<kTP>(&tile[off], minTh);
-            if (pol) queue[atomicAdd(&s_q, 1)] = (unsigned short) ((off << 2) | pol);
-            if (++x == dw) { x = 0; y++; }
+        int y = lane / dw, x = lane - y * dw;
+        for (int base = 0; base < npix; base += 64) {
+            const bool valid = base + lane < npix;
+            const int off = obase + (y + 3) * tp + x + 3;
+            const int pol = valid ? fast9_test(&tile[off], tp, minTh) : 0;
+            const unsigned long long m = __ballot(pol != 0);
+            const int add = __popcll(m);
+            if (ncorn + add > kCornerCap) { overflow = true; break; }
+            if (pol) clist[ncorn + __popcll(m & lane_lt)] = (unsigned short) (((y * dw + x) << 2) | pol);
+            ncorn += add;
+            y += qy; x += qx;
+            if (x >= dw) { x -= dw; y++; }
         }
     }
-    __syncthreads();
-    const int nq = s_q;
-    if (dbgStage == 2) { if (tid == 0) *cnt_out = nq; return; }
-    for (int qi = tid; qi < nq; qi += kFastBlock) {
-        const int e = queue[qi];
-        const int off = e >> 2;
-        const int s = fast9_arc_score<kTP>(&tile[off], e & 3);
-        const int ty = off / kTP, tx = off - ty * kTP - xoff;
-        smap[(ty - 2) * kSP + tx - 2] = (uint8_t) s;   // score-map coords = domain coords + 1
-    }
-    __syncthreads();
-    if (dbgStage == 3) { if (tid == 0) *cnt_out = smap[70]; return; }
-    unsigned keepIni = 0, keepMin = 0;
-    {
-        int y = y0, x = x0;
-        for (int j = 0; j < ppt && p0 + j < npix; j++) {
-            const uint8_t *p = &smap[(y + 1) * kSP + x + 1];
-            const int s = p[0];
-            if (s) {
+    wave_lds_sync();
+    unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
+    if (!overflow) {
+        // pass 2: score of every listed corner -> private score map
+        for (int qb = 0; qb < ncorn; qb += 64) {
+            const int qi = qb + lane;
+            if (qi < ncorn) {
+                const int e = clist[qi];
+                const int p = e >> 2, y = p / dw, x = p - y * dw;
+                smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&tile[obase + (y + 3) * tp + x + 3], tp, e & 3);
+            }
+        }
+        wave_lds_sync();
+        // pass 3: 3x3 NMS at both thresholds over the corner list
+        int nIni = 0;
+        for (int qb = 0; qb < ncorn; qb += 64) {
+            const int qi = qb + lane;
+            int kIni = 0, kMin = 0, e = 0;
+            if (qi < ncorn) {
+                e = clist[qi];
+                const int p = e >> 2, y = p / dw, x = p - y * dw;
+                const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
+                const int s = sp[0];
                 int nmax = 0, nmaxI = 0;
 #pragma unroll
                 for (int dy = -1; dy <= 1; dy++)
 #pragma unroll
                     for (int dx = -1; dx <= 1; dx++) {
                         if (dx == 0 && dy == 0) continue;
-                        const int n = p[dy * kSP + dx];
+                        const int n = sp[dy * kSP + dx];
                         nmax = max(nmax, n);
                         nmaxI = max(nmaxI, n >= iniTh ? n : 0);
                     }
-                if (s > nmax) keepMin |= 1u << j;
-                if (s >= iniTh && s > nmaxI) keepIni |= 1u << j;
+                kMin = s > nmax;
+                kIni = (s >= iniTh) && (s > nmaxI);
+                clist[qi] = (unsigned short) ((e & ~3) | kIni | (kMin << 1));   // polarity no longer needed: keep flags
             }
-            if (++x == dw) { x = 0; y++; }
+            nIni += __popcll(__ballot(kIni != 0));
         }
-    }
-    if (keepIni) atomicAdd(&s_ini, __popc(keepIni));
-    __syncthreads();
-    if (dbgStage == 4) { if (tid == 0) *cnt_out = s_ini; return; }
-    const unsigned keep = s_ini > 0 ? keepIni : keepMin;
-    int total;
-    int off = block_excl_scan(__popc(keep), s_tmp, &total);
-    unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
-    if (keep) {
-        int y = y0, x = x0;
-        for (int j = 0; j < ppt; j++) {
-            if (keep & (1u << j)) {
+        wave_lds_sync();
+        // output: the list is in raster order; keep the iniTh survivors, or the minTh survivors when the cell is empty at iniTh
+        const int want = nIni > 0 ? 1 : 2;
+        int total = 0;
+        for (int qb = 0; qb < ncorn; qb += 64) {
+            const int qi = qb + lane;
+            const int e = qi < ncorn ? clist[qi] : 0;
+            const bool keep = (e & want) != 0;
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int p = e >> 2, y = p / dw, x = p - y * dw;
                 const unsigned s = smap[(y + 1) * kSP + x + 1];
-                out[off++] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
+                out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
             }
-            if (++x == dw) { x = 0; y++; }
+            total += __popcll(m);
+        }
+        if (lane == 0) *cnt_out = (unsigned short) total;
+        return;
+    }
+    // ---- dense fallback (corner list overflow): score every pixel, NMS every pixel ----
+    {
+        int y = lane / dw, x = lane - y * dw;
+        for (int base = 0; base < npix; base += 64) {
+            if (base + lane < npix) {
+                const uint8_t *cp = &tile[obase + (y + 3) * tp + x + 3];
+                const int pol = fast9_test(cp, tp, minTh);
+                if (pol) smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(cp, tp, pol);
+            }
+            y += qy; x += qx;
+            if (x >= dw) { x -= dw; y++; }
         }
     }
-    if (tid == 0) *cnt_out = (unsigned short) total;
+    wave_lds_sync();
+    for (int pass = 0; pass < 2; pass++) {       // pass 0: iniTh map; pass 1 (only if empty): minTh map
+        int total = 0;
+        int y = lane / dw, x = lane - y * dw;
+        for (int base = 0; base < npix; base += 64) {
+            bool keep = false;
+            unsigned s = 0;
+            if (base + lane < npix) {
+                const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
+                s = sp[0];
+                const int th = pass == 0 ? iniTh : 0;
+                if (s > 0 && (int) s >= th) {
+                    int nmax = 0;
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int n = sp[dy * kSP + dx];
+                            nmax = max(nmax, n >= th ? n : 0);
+                        }
+                    keep = (int) s > nmax;
+                }
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
+            total += __popcll(m);
+            y += qy; x += qx;
+            if (x >= dw) { x -= dw; y++; }
+        }
+        if (total > 0 || pass == 1) {
+            if (lane == 0) *cnt_out = (unsigned short) total;
+            break;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -960,12 +1032,19 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
 }
 
+size_t fast_lds_bytes(int tilePitch, int tileRows, int smapRows) {
+    return (((size_t) tileRows * tilePitch + 15) & ~(size_t) 15) + (size_t) (kFastBlock / 64) * smapRows * kSP +
+           (size_t) (kFastBlock / 64) * kCornerCap * sizeof(unsigned short) + 64;
+}
+
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
-                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int nFrames) {
-    if (totalCells <= 0) return;
-    const int cellsPerXcd = (totalCells + 7) / 8;
-    hipLaunchKernelGGL(k_fast_cells, dim3(8 * cellsPerXcd, nFrames), dim3(kFastBlock), 0, st, fs, dGeom, nlevels, iniTh, minTh,
-                       cellCnt, slots, totalCells, totalSlots, cellsPerXcd, getenv("YGZF_FAST_STAGE") ? atoi(getenv("YGZF_FAST_STAGE")) : 0);
+                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int tilePitch,
+                       int tileRows, int smapRows, int nFrames) {
+    if (totalGroups <= 0) return;
+    const int groupsPerXcd = (totalGroups + 7) / 8;
+    hipLaunchKernelGGL(k_fast_cells, dim3(8 * groupsPerXcd, nFrames), dim3(kFastBlock), fast_lds_bytes(tilePitch, tileRows, smapRows), st, fs,
+                       dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalGroups, groupsPerXcd, tilePitch, tileRows,
+                       smapRows);
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand) {

@@ -9,8 +9,10 @@ hipError_t upload_constants(const int *umax16);
 
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
+size_t fast_lds_bytes(int tilePitch, int tileRows, int smapRows);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
-                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int nFrames);
+                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int tilePitch,
+                       int tileRows, int smapRows, int nFrames);
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand);
 hipError_t octree_prepare(size_t ldsBytes);
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,

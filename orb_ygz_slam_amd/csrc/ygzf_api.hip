@@ -74,6 +74,7 @@ struct Geometry {
     std::vector<short> xalpha, ybeta;
     long long pyrBytes = 0;   // per frame, levels >= 1
     int totalCells = 0, maxCellsPerLevel = 0;
+    int totalGroups = 0, fastTilePitch = 16, fastTileRows = 1, fastSmapRows = 3;   // 2x2 cell groups of k_fast_cells
     long long totalSlots = 0;
     long long candStride = 0;
     int kpStride = 0, kpCapMax = 0;
@@ -165,7 +166,7 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
     G.h = h;
     G.lv.assign(L, LevelGeom());
     long long off = 0, slotBase = 0, candBase = 0;
-    int cellBase = 0, kpBase = 0;
+    int cellBase = 0, kpBase = 0, groupBase = 0;
     for (int l = 0; l < L; l++) {
         LevelGeom &g = G.lv[l];
         memset(&g, 0, sizeof g);
@@ -215,6 +216,7 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
         g.nCols = nCols;
         g.nRows = nRows;
         g.cellBase = cellBase;
+        g.groupBase = groupBase;
         g.slotBase = slotBase;
         g.candBase = candBase;
         g.kpBase = kpBase;
@@ -224,6 +226,10 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
             g.slotCap = ((g.wCell + 1) / 2) * ((g.hCell + 1) / 2);
             const int nc = nCols * nRows;
             cellBase += nc;
+            groupBase += ((nCols + 1) / 2) * ((nRows + 1) / 2);
+            G.fastTilePitch = std::max(G.fastTilePitch, (2 * g.wCell + 6 + 3 + 3) / 4 * 4);
+            G.fastTileRows = std::max(G.fastTileRows, 2 * g.hCell + 6);
+            G.fastSmapRows = std::max(G.fastSmapRows, g.hCell + 2);
             slotBase += (long long) nc * g.slotCap;
             g.candCap = nc * g.slotCap;
             candBase += g.candCap;
@@ -254,6 +260,7 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
     }
     G.pyrBytes = off;
     G.totalCells = cellBase;
+    G.totalGroups = groupBase;
     G.totalSlots = slotBase;
     G.candStride = candBase;
     G.kpStride = kpBase;
@@ -396,7 +403,8 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
         {
             ProfScope ps(c, KK_FAST);
             launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
-                              (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, nFrames);
+                              (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
+                              G.fastTilePitch, G.fastTileRows, G.fastSmapRows, nFrames);
         }
         long long *odbg = nullptr;
         if (getenv("YGZF_OCT_DEBUG")) {

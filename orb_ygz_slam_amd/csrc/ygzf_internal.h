@@ -30,6 +30,7 @@ struct LevelGeom {
     int nCols, nRows, wCell, hCell;
     int maxBorderX, maxBorderY;
     int cellBase;             // first cell of this level inside a frame's cell arrays
+    int groupBase;            // first 2x2 cell group (one FAST workgroup) of this level inside a frame
     int slotCap;              // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2)
     long long slotBase;       // first slot of this level inside a frame's slot array
     // octree, :533-563
