@@ -166,6 +166,17 @@ typedef struct ygzf_sia_frame {
 int ygzf_sia_run(ygzf_ctx *ctx, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, const ygzf_camera *cam, const float *inv_scale_factors,
                  int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36);
 
+/* ---- Thirdparty/fast (Rosten FAST-10/16), replaced outright: fast::fast_corner_detect_10_sse2 + fast::fast_corner_score_10
+ *      + fast::fast_nonmax_3x3  (Thirdparty/fast/include/fast/fast.h:19-29; called at src/ORBextractor.cc:1220-1235,
+ *      :1330-1340, :1440-1450) on the window [x0,x0+w) x [y0,y0+h) of a host image -----------------------------------------
+ * xy: corners in raster order as (x, y) int16 pairs relative to the window origin (fast::fast_xy); scores[i] = largest
+ * barrier for which corner i is still a corner; nonmax_idx = indices into the corner list that survive the 3x3 non-maximum
+ * suppression (suppressed if any 8-neighbour corner scores >= own).  scores / nonmax_idx / n_nonmax may be NULL.
+ * Domain as libfast: x,y in [3,w-3) x [3,h-3); for w < 22 the reference falls back to its plain detector, which scans the
+ * WHOLE window and reads 3 px around it, so such windows must lie 3 px inside the image (error otherwise); h < 7: nothing. */
+int ygzf_fast10(ygzf_ctx *ctx, const uint8_t *img, int img_w, int img_h, int stride, int x0, int y0, int w, int h, int barrier, int16_t *xy,
+                int *scores, int *nonmax_idx, int cap, int *n_corners, int *n_nonmax);
+
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------
  * HIP events recorded on the context stream (the stream every kernel of this context is launched on). */
 int ygzf_timer_start(ygzf_ctx *ctx);

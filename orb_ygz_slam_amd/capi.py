@@ -91,6 +91,7 @@ def load_library(build_if_missing=True):
                                                  vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, ip]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
+    L.ygzf_fast10.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip, ip]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
     L.ygzf_profile_enable.argtypes = [vp, C.c_int]
@@ -316,6 +317,19 @@ class Extractor:
         self._ck(self.L.ygzf_sia_run(self.h, C.byref(R), C.byref(Cf), C.byref(cam), _p(isf), max_level, min_level, n_iter, _p(out7),
                                      C.byref(ret), _p(info), _p(H)))
         return int(ret.value), out7, info, H.reshape(6, 6)
+
+    def fast10(self, img, barrier, window=None, cap=None):
+        """libfast replacement: (xy int16 (n,2), scores, nonmax indices) of fast_corner_detect_10_sse2 / score / nonmax_3x3."""
+        img = np.ascontiguousarray(img, np.uint8)
+        ih, iw = img.shape
+        x0, y0, w, h = window if window is not None else (0, 0, iw, ih)
+        cap = cap or w * h
+        xy = np.zeros((max(cap, 1), 2), np.int16)
+        sc = np.zeros(max(cap, 1), np.int32)
+        nm = np.zeros(max(cap, 1), np.int32)
+        n, k = C.c_int(), C.c_int()
+        self._ck(self.L.ygzf_fast10(self.h, _p(img), iw, ih, iw, x0, y0, w, h, barrier, _p(xy), _p(sc), _p(nm), cap, C.byref(n), C.byref(k)))
+        return xy[:n.value].copy(), sc[:n.value].copy(), nm[:k.value].copy()
 
     def timer_start(self):
         self._ck(self.L.ygzf_timer_start(self.h))

@@ -65,6 +65,10 @@ void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt
 void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ldsBytes);
 
 
+// ---- FAST-10 (fast10_kernels.hip): Thirdparty/fast replacement -------------------------------------------------------
+void launch_fast10(hipStream_t st, const uint8_t *img, int pitch, int x0, int y0, int w, int h, int dx0, int dx1, int dy0, int dy1, int barrier,
+                   short *S, int *rowCnt, int *rowKept, int *totals, short *xy, int *scores, int *nonmax, int cap);
+
 // ---- sparse image alignment (align_kernels.hip) ----------------------------------------------------------------------
 struct SiaLevel {
     const uint8_t *img;

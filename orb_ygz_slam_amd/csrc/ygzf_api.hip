@@ -63,9 +63,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -98,7 +98,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder;
+        dGen[12], dSia[8], dProcOrder, dF10[6];
     bool carryValid = false;
     int lastMatchPairs = 0;
     int identityPoses = 0;
@@ -524,6 +524,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &b : c->dGen)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dSia)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dF10)
         if (b.p) (void) hipFree(b.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
@@ -1093,6 +1095,51 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     *ret = (size_t) out[7];
     if (info) { info[0] = out[8]; info[1] = out[9]; }
     if (H36) memcpy(H36, out + 12, 36 * sizeof(float));
+    return YGZF_OK;
+}
+
+// ---- Thirdparty/fast replacement ------------------------------------------------------------------------------------------
+int ygzf_fast10(ygzf_ctx *c, const uint8_t *img, int img_w, int img_h, int stride, int x0, int y0, int w, int h, int barrier, int16_t *xy,
+                int *scores, int *nonmax_idx, int cap, int *n_corners, int *n_nonmax) {
+    if (!c || !img || !n_corners) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *n_corners = 0;
+    if (n_nonmax) *n_nonmax = 0;
+    if (img_w < 1 || img_h < 1 || stride < img_w || w < 1 || h < 1 || x0 < 0 || y0 < 0 || x0 + w > img_w || y0 + h > img_h || cap < 0)
+        return fail(c, YGZF_ERR_INVALID, "bad image / window geometry");
+    // detection domain of fast_corner_detect_10_sse2 (faster_corner_10_sse.cpp:188-198)
+    int dx0 = 3, dx1 = w - 3, dy0 = 3, dy1 = h - 3;
+    if (w < 22) {          // falls back to the plain detector, which scans the whole window and reads 3 px around it
+        dx0 = 0; dx1 = w; dy0 = 0; dy1 = h;
+        if (x0 < 3 || y0 < 3 || x0 + w + 3 > img_w || y0 + h + 3 > img_h)
+            return fail(c, YGZF_ERR_INVALID, "a window narrower than 22 px needs a 3-px margin inside the image (the reference reads it)");
+    } else if (h < 7)
+        return YGZF_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    ygzf_ctx::Buf *B = c->dF10;
+    const int pitch = align_up(img_w, 64);
+    int rc;
+    if ((rc = ensure(c, B[0], (size_t) pitch * img_h)) || (rc = ensure(c, B[1], (size_t) w * h * sizeof(short))) ||
+        (rc = ensure(c, B[2], (size_t) (2 * h + 2) * sizeof(int))) || (rc = ensure(c, B[3], (size_t) std::max(cap, 1) * 2 * sizeof(short))) ||
+        (rc = ensure(c, B[4], (size_t) std::max(cap, 1) * sizeof(int))) || (rc = ensure(c, B[5], (size_t) std::max(cap, 1) * sizeof(int))))
+        return rc;
+    HIPCHECK(c, hipMemcpy2DAsync(B[0].p, pitch, img, stride, img_w, img_h, hipMemcpyHostToDevice, c->stream));
+    int *rowCnt = (int *) B[2].p, *rowKept = rowCnt + h, *totals = rowKept + h;
+    {
+        ProfScope ps(c, KK_FAST10);
+        launch_fast10(c->stream, (const uint8_t *) B[0].p, pitch, x0, y0, w, h, dx0, dx1, dy0, dy1, barrier, (short *) B[1].p, rowCnt, rowKept,
+                      totals, (short *) B[3].p, (int *) B[4].p, (int *) B[5].p, cap);
+    }
+    HIPCHECK(c, hipGetLastError());
+    int tot[2];
+    HIPCHECK(c, hipMemcpyAsync(tot, totals, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *n_corners = tot[0];
+    if (n_nonmax) *n_nonmax = tot[1];
+    if (tot[0] > cap) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d corners", cap, tot[0]);
+    if (tot[0] && xy) HIPCHECK(c, hipMemcpyAsync(xy, B[3].p, (size_t) tot[0] * 2 * sizeof(short), hipMemcpyDeviceToHost, c->stream));
+    if (tot[0] && scores) HIPCHECK(c, hipMemcpyAsync(scores, B[4].p, (size_t) tot[0] * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (tot[1] && nonmax_idx) HIPCHECK(c, hipMemcpyAsync(nonmax_idx, B[5].p, (size_t) tot[1] * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }
 
