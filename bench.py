@@ -77,20 +77,33 @@ def make_frames(n, w, h, seed0=1000):
     return frames
 
 
+def effective_cores():
+    """Cores this process may actually use: affinity mask, further limited by a cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(frames, cfg, seconds_budget=12.0):
     """The CPU oracle ('port' of the reference path; the reference itself cannot be built here) on this host's cores:
-    every worker thread runs extract + projection match over its own run of consecutive frames of the same clip."""
+    every worker thread runs extract + projection match over its own run of consecutive frames of the same clip for a
+    bounded time (about `seconds_budget` s), so the default bench run stays within minutes on any host."""
     from oracle import oracle_py as O
     w, h, nl, sf, nf, ini, mn = cfg
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    sec1, _, _ = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=1, frames_per_thread=8)   # calibrate: 1 thread
-    fps1 = 8.0 / max(sec1, 1e-6)
-    per_thread = int(min(2000, max(8, seconds_budget * fps1 * 0.6)))   # all cores busy -> lower clocks / shared bandwidth
-    sec, nk, nm = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=cores, frames_per_thread=per_thread)
-    n = cores * per_thread
+    cores = effective_cores()
+    sec1, _, _, n1 = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=1, frames_per_thread=1000, max_seconds=2.0)
+    fps1 = n1 / max(sec1, 1e-6)
+    sec, nk, nm, n = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=cores, frames_per_thread=100000,
+                                           max_seconds=seconds_budget)
+    n = max(n, 1)
     return {"value": round(n / sec, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x %d consecutive frames of the bench clip (%d frames total) in %.1f s; 1 thread: %.2f frames/s"
-                      % (cores, per_thread, n, sec, fps1),
+            "sample": "%d threads, each on its own run of consecutive frames of the bench clip, time-bounded: %d frames in %.1f s; "
+                      "1 thread: %.2f frames/s" % (cores, n, sec, fps1),
             "keypoints_per_frame": round(nk / n, 1), "matches_per_frame": round(nm / n, 1)}
 
 

@@ -298,9 +298,9 @@ size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur,
 // with an identity relative pose and unit-depth back-projected points (SURVEY §8d metric definition).
 // Returns elapsed seconds; n_kp_total / n_match_total are checksums so the work cannot be optimised away.
 double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, const uint8_t *frames,
-                              int nframes, int w, int h, int threads, int frames_per_thread, float fx, float fy, float cx, float cy,
-                              long *n_kp_total, long *n_match_total) {
-    std::vector<long> kp_acc(threads, 0), m_acc(threads, 0);
+                              int nframes, int w, int h, int threads, int frames_per_thread, double max_seconds, float fx, float fy,
+                              float cx, float cy, long *n_kp_total, long *n_match_total, long *n_frames_done) {
+    std::vector<long> kp_acc(threads, 0), m_acc(threads, 0), f_acc(threads, 0);
     auto t0 = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
         Extractor ex(nfeatures, scaleFactor, nlevels, iniTh, minTh);
@@ -310,6 +310,8 @@ double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int
         // so that the t-1 -> t pairs stay on one worker and every worker does the same amount of work
         const int start = (int) (((long) tid * 8) % nframes);
         for (int j = 0; j < frames_per_thread; j++) {
+            // time-bounded sample: stop at the deadline (the host may give this process far fewer cores than it shows)
+            if (max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds) break;
             const int f = (start + j) % nframes;
             ex.Extract(frames + (size_t) f * w * h, w, h, w, kcur, dcur);
             kp_acc[tid] += (long) kcur.size();
@@ -352,14 +354,16 @@ double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int
             }
             kprev.swap(kcur);
             dprev.swap(dcur);
+            f_acc[tid]++;
         }
     };
     std::vector<std::thread> th;
     for (int t = 0; t < threads; t++) th.emplace_back(worker, t);
     for (auto &t : th) t.join();
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    long a = 0, b = 0;
-    for (int t = 0; t < threads; t++) { a += kp_acc[t]; b += m_acc[t]; }
+    long a = 0, b = 0, fd = 0;
+    for (int t = 0; t < threads; t++) { a += kp_acc[t]; b += m_acc[t]; fd += f_acc[t]; }
+    if (n_frames_done) *n_frames_done = fd;
     if (n_kp_total) *n_kp_total = a;
     if (n_match_total) *n_match_total = b;
     return sec;

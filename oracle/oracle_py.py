@@ -49,8 +49,8 @@ def lib():
         L.yo_sparse_img_align.restype = C.c_size_t
         L.yo_bench_extract_match.restype = C.c_double
         L.yo_bench_extract_match.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                             C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
-                                             C.POINTER(C.c_long), C.POINTER(C.c_long)]
+                                             C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float,
+                                             C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     return _lib
 
 
@@ -216,17 +216,17 @@ def ref_fast10(img, barrier, which=1):
 
 
 def bench_extract_match(frames, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, threads=1,
-                        frames_per_thread=None, fx=458.654, fy=457.296, cx=367.215, cy=248.375):
+                        frames_per_thread=None, max_seconds=0.0, fx=458.654, fy=457.296, cx=367.215, cy=248.375):
     """CPU baseline ('port'): seconds for `threads` workers each doing extract + frame-to-frame projection match on
-    `frames_per_thread` consecutive frames of the clip `frames` (n,h,w) u8.  Returns (seconds, keypoints, matches)."""
+    `frames_per_thread` consecutive frames of the clip `frames` (n,h,w) u8.  Stops early at `max_seconds` (0 = no limit).  Returns (seconds, keypoints, matches, frames_done)."""
     frames = np.ascontiguousarray(frames, np.uint8)
     n, h, w = frames.shape
     if frames_per_thread is None:
         frames_per_thread = max(1, n // threads)
-    nk, nm = C.c_long(), C.c_long()
+    nk, nm, nf = C.c_long(), C.c_long(), C.c_long()
     sec = lib().yo_bench_extract_match(nfeatures, scale_factor, nlevels, ini_th, min_th, _p(frames), n, w, h, threads,
-                                       frames_per_thread, fx, fy, cx, cy, C.byref(nk), C.byref(nm))
-    return sec, nk.value, nm.value
+                                       frames_per_thread, max_seconds, fx, fy, cx, cy, C.byref(nk), C.byref(nm), C.byref(nf))
+    return sec, nk.value, nm.value, nf.value
 
 
 class _YoFrame(C.Structure):
