@@ -134,6 +134,17 @@ int ygzf_search_by_projection_last(ygzf_ctx *ctx, const ygzf_frame_view *cur, co
                                    const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw, const float *tlw, float th,
                                    int b_mono, int check_level, int check_orientation, uint8_t *cur_owner, int *cur_match, int *nmatches);
 
+/* ---- ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, bool checkLevel)
+ *      src/ORBmatcher.cc:43-126 (Tracking::SearchLocalPoints, nnratio 0.8) ---------------------------------------------------
+ * Per MapPoint i (fields set by Frame::isInFrustum, src/Frame.cc:413-419): track_in_view = mbTrackInView, is_bad = isBad()
+ * (NULL = none), mp_has_obs = Observations() > 0 (NULL = all), proj_x/proj_y/proj_xr = mTrackProjX/Y/XR (proj_xr may be
+ * NULL for monocular), view_cos = mTrackViewCos, scale_level = mnTrackScaleLevel, mp_desc = GetDescriptor().
+ * owner (in/out) / match (out: index of the MapPoint written to F.mvpMapPoints[idx], -1 untouched) / *nmatches as above. */
+int ygzf_search_by_projection_mappoints(ygzf_ctx *ctx, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
+                                        const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y,
+                                        const float *proj_xr, const float *view_cos, const int *scale_level, const uint8_t *mp_desc, float th,
+                                        int check_level, float nnratio, uint8_t *owner, int *match, int *nmatches);
+
 /* Batched, device-resident form chained behind ygzf_extract_batch_*: frame f of the batch is CurrentFrame, frame f-1 is
  * LastFrame (for f == 0: the last frame of the previous batch of this context, or an empty frame).  Identity relative
  * pose; every Last keypoint carries a MapPoint at its unit-depth back-projection ((x-cx)/fx, (y-cy)/fy, 1) whose

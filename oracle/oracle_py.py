@@ -352,3 +352,29 @@ def features_in_area(keys, scale_factors, w, h, x, y, r, min_level=-1, max_level
     L.yo_features_in_area.argtypes = [C.POINTER(_YoFrame), C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
     n = L.yo_features_in_area(C.byref(fr), x, y, r, min_level, max_level, _p(out), len(out))
     return out[:n].copy()
+
+
+def search_by_projection_mappoints(keys, desc, scale_factors, w, h, cam, track_in_view, proj_x, proj_y, view_cos, scale_level, mp_desc,
+                                   th, check_level=True, nnratio=0.8, is_bad=None, mp_has_obs=None, proj_xr=None, u_right=None,
+                                   owner=None):
+    """Oracle ORBmatcher::SearchByProjection(F, MapPoints, th, checkLevel) -> (nmatches, match, owner)."""
+    keep = []
+    fr = _yo_frame(keys, desc, scale_factors, w, h, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam.get("mb", 0.0), cam.get("mbf", 0.0),
+                   u_right, keep)
+    M = len(proj_x)
+    tiv = np.ascontiguousarray(track_in_view, np.uint8)
+    bad = np.zeros(M, np.uint8) if is_bad is None else np.ascontiguousarray(is_bad, np.uint8)
+    obs = np.ones(M, np.uint8) if mp_has_obs is None else np.ascontiguousarray(mp_has_obs, np.uint8)
+    px, py, vc = (np.ascontiguousarray(a, np.float32) for a in (proj_x, proj_y, view_cos))
+    pxr = np.zeros(M, np.float32) if proj_xr is None else np.ascontiguousarray(proj_xr, np.float32)
+    lv = np.ascontiguousarray(scale_level, np.int32)
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    nt = fr.N
+    own = np.zeros(max(nt, 1), np.uint8) if owner is None else np.array(owner, np.uint8)
+    match = np.full(max(nt, 1), -1, np.int32)
+    L = lib()
+    L.yo_search_by_projection_mappoints.argtypes = [C.POINTER(_YoFrame), C.c_int] + [C.c_void_p] * 9 + [C.c_float, C.c_int, C.c_float,
+                                                                                                        C.c_void_p, C.c_void_p]
+    r = L.yo_search_by_projection_mappoints(C.byref(fr), M, _p(tiv), _p(bad), _p(obs), _p(px), _p(py), _p(pxr), _p(vc), _p(lv), _p(md), th,
+                                            int(check_level), nnratio, _p(own), _p(match))
+    return r, match[:nt], own[:nt]

@@ -89,6 +89,8 @@ def load_library(build_if_missing=True):
     L.ygzf_match_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.ygzf_search_by_projection_last.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                                  vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, ip]
+    L.ygzf_search_by_projection_mappoints.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int] + [vp] * 9 + [
+        C.c_float, C.c_int, C.c_float, vp, vp, ip]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_fast10.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip, ip]
@@ -275,6 +277,36 @@ class Extractor:
                                                        _p(mats[1]), _p(mats[2]), _p(mats[3]), th, int(mono), int(check_level),
                                                        int(check_ori), _p(owner), _p(match), C.byref(n)))
         return n.value, match[:len(ck)], owner[:len(ck)]
+
+    def search_by_projection_mappoints(self, cam, keys, desc, track_in_view, proj_x, proj_y, view_cos, scale_level, mp_desc, th,
+                                       check_level=True, nnratio=0.8, is_bad=None, mp_has_obs=None, proj_xr=None, u_right=None,
+                                       owner=None, scale_factors=None):
+        """ORBmatcher::SearchByProjection(F, MapPoints, th, checkLevel) on host arrays -> (nmatches, match, owner)."""
+        ck = np.ascontiguousarray(keys, KP_DTYPE)
+        cd = np.ascontiguousarray(desc, np.uint8)
+        keep = [ck, cd]
+
+        def arr(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return _p(a)
+        fv = FrameView(len(ck), ck.ctypes.data, cd.ctypes.data, None, None, self.nlevels)
+        ur = arr(u_right, np.float32)
+        if ur is not None:
+            fv.u_right = ur
+        sf = arr(scale_factors, np.float32)
+        if sf is not None:
+            fv.scale_factors = sf
+        own = np.zeros(max(len(ck), 1), np.uint8) if owner is None else np.array(owner, np.uint8)
+        match = np.full(max(len(ck), 1), -1, np.int32)
+        n = C.c_int()
+        self._ck(self.L.ygzf_search_by_projection_mappoints(
+            self.h, C.byref(fv), C.byref(cam), len(proj_x), arr(track_in_view, np.uint8), arr(is_bad, np.uint8), arr(mp_has_obs, np.uint8),
+            arr(proj_x, np.float32), arr(proj_y, np.float32), arr(proj_xr, np.float32), arr(view_cos, np.float32),
+            arr(scale_level, np.int32), arr(mp_desc, np.uint8), th, int(check_level), nnratio, _p(own), _p(match), C.byref(n)))
+        return n.value, match[:len(ck)], own[:len(ck)]
 
     def sia_run(self, cam, ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, max_level, min_level, n_iter=10,
                 mp_valid=None, outlier=None):

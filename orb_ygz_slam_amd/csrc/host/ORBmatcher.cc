@@ -102,4 +102,51 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
     return nmatches;
 }
 
+// src/ORBmatcher.cc:43-126
+int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, bool checkLevel) {
+    const int nt = F.N, M = (int) vpMapPoints.size();
+    if (nt <= 0 || M <= 0) return 0;
+    ygzf_ctx *c = pool().take(sDevice);
+    if (!c) return 0;
+    std::vector<uint8_t> tiv(M), bad(M), obs(M), mpdesc((size_t) M * 32);
+    std::vector<float> px(M), py(M), pxr(M), vc(M);
+    std::vector<int> lvl(M);
+    for (int i = 0; i < M; i++) {
+        MapPoint *mp = vpMapPoints[i];
+        tiv[i] = mp->mbTrackInView;
+        if (!tiv[i]) continue;
+        bad[i] = mp->isBad();
+        obs[i] = mp->Observations() > 0;
+        px[i] = mp->mTrackProjX; py[i] = mp->mTrackProjY; pxr[i] = mp->mTrackProjXR; vc[i] = mp->mTrackViewCos;
+        lvl[i] = mp->mnTrackScaleLevel;
+        const cv::Mat d = mp->GetDescriptor();
+        std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
+    }
+    std::vector<uint8_t> owner(nt), cdesc((size_t) nt * 32);
+    for (int i = 0; i < nt; i++) {
+        MapPoint *mp = F.mvpMapPoints[i];
+        owner[i] = mp ? (mp->Observations() > 0 ? 2 : 1) : 0;
+        std::memcpy(&cdesc[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
+    }
+    ygzf_frame_view fv;
+    fv.n = nt;
+    fv.keys = (const ygzf_kp *) F.mvKeys.data();
+    fv.desc = cdesc.data();
+    fv.u_right = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
+    fv.scale_factors = F.mvScaleFactors.data();
+    fv.nlevels = (int) F.mvScaleFactors.size();
+    ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F.mb, F.mbf, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    std::vector<int> match(nt, -1);
+    int nmatches = 0;
+    const int rc = ygzf_search_by_projection_mappoints(c, &fv, &cam, M, tiv.data(), bad.data(), obs.data(), px.data(), py.data(), pxr.data(),
+                                                       vc.data(), lvl.data(), mpdesc.data(), th, checkLevel, mfNNratio, owner.data(),
+                                                       match.data(), &nmatches);
+    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
+    pool().give(c);
+    if (rc != YGZF_OK) return 0;
+    for (int i = 0; i < nt; i++)
+        if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
+    return nmatches;
+}
+
 }  // namespace ygz

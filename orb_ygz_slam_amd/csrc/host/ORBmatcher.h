@@ -18,6 +18,9 @@ public:
     // Project MapPoints tracked in the last frame into the current frame and search matches (TrackWithMotionModel).
     int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, bool checkLevel = true);
 
+    // Search matches between Frame keypoints and projected MapPoints (Tracking::SearchLocalPoints).
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3, bool checkLevel = true);
+
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;

@@ -44,6 +44,11 @@ struct MatchArgs {
     long long kpStrideLast;
     int cntStrideLast, cntOffLast;
     const float *poses;            // per pair: Rcw[9] tcw[3] Rlw[9] tlw[3]
+    // mode 1 = SearchByProjection(F, MapPoints): queries come projected (Frame::isInFrustum); mpValid = mbTrackInView, outlier = isBad()
+    int mode;
+    const float *mpProjX, *mpProjY, *mpProjXR, *mpViewCos;
+    const int *mpLevel;
+    float nnratio;
     // camera / frame statics
     float fx, fy, cx, cy, mb, mbf, minX, minY, maxX, maxY, gridInvW, gridInvH;
     float scaleFactors[kMaxLevels];

@@ -54,7 +54,7 @@ __global__ void k_backproject_unit(const ygzf_kp *__restrict__ keys, const int *
 }
 
 struct QueryParam {  // per Last keypoint, precomputed by all waves (32 bytes)
-    float u, v, radius, invzc, angle;
+    float u, v, radius, ur, angle;    // ur: expected right-image column (u - mbf/z, or MapPoint::mTrackProjXR)
     unsigned char minCx, maxCx, minCy, maxCy;
     signed char minLevel, maxLevel;   // GetFeaturesInArea arguments (-1 = unbounded)
     unsigned char valid, hasObs;
@@ -100,7 +100,8 @@ __device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
 
 __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
                                                unsigned long long q1, unsigned long long q2, unsigned long long q3,
-                                               const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2) {
+                                               const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2,
+                                               unsigned *secondKey = nullptr, int *secondIdx2 = nullptr) {
     const int nCx = q.maxCx - q.minCx + 1;   // <= 64 (one lane per grid column)
     const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
     int rs = 0, rlen = 0;
@@ -121,8 +122,8 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         if (a3 >= 0 && a3 < ln) li3 = st + a3;
         total += ln;
     }
-    unsigned best = (256u << 16) | 0xFFFFu;
-    int bestI2 = -1;
+    unsigned best = (256u << 16) | 0xFFFFu, best2 = (256u << 16) | 0xFFFFu;   // per-lane best and runner-up
+    int bestI2 = -1, best2I2 = -1;
     for (int jb = 0; jb < total; jb += 64) {
         const int j = jb + lane;
         int li;
@@ -150,8 +151,7 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
         if (L.owner[i2] == 2) continue;  // mvpMapPoints[i2] && Observations() > 0
         if (uRight && uRight[i2] > 0) {
-            const float ur = q.u - A.mbf * q.invzc;
-            const float er = fabsf(ur - uRight[i2]);
+            const float er = fabsf(q.ur - uRight[i2]);
             if (er > q.radius) continue;
         }
         unsigned long long d0, d1, d2, d3;
@@ -163,12 +163,21 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         }
         const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
         const unsigned key = (dist << 16) | (unsigned) j;
-        if (key < best) { best = key; bestI2 = i2; }
+        if (key < best) { best2 = best; best2I2 = bestI2; best = key; bestI2 = i2; }
+        else if (key < best2) { best2 = key; best2I2 = i2; }
     }
     const unsigned wbest = wave_min_dpp(best);
     const unsigned long long who = __ballot(best == wbest);
     const int src = __ffsll((long long) who) - 1;
     *bestIdx2 = __builtin_amdgcn_readlane(bestI2, src);
+    if (secondKey) {   // second smallest (dist, order) key over the same candidates (SearchByProjection(F, MapPoints) ratio test)
+        const unsigned second = wave_min_dpp(lane == src ? best2 : min(best, best2));
+        const unsigned long long who2 = __ballot(lane == src ? best2 == second : (best == second || best2 == second));
+        const int src2 = __ffsll((long long) who2) - 1;
+        const int cand2 = (lane == src) ? best2I2 : (best == second ? bestI2 : best2I2);
+        *secondKey = second;
+        *secondIdx2 = __builtin_amdgcn_readlane(cand2, src2);
+    }
     return wbest;
 }
 
@@ -282,13 +291,37 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     for (int i = tid; i < nq; i += kMatchBlock) {
         QueryParam q;
         q.valid = 0;
-        q.u = q.v = q.radius = q.invzc = q.angle = 0;
+        q.u = q.v = q.radius = q.ur = q.angle = 0;
         q.minCx = q.maxCx = q.minCy = q.maxCy = 0;
         q.minLevel = q.maxLevel = -1;
         q.hasObs = hasObs ? (hasObs[i] != 0) : 1;
         q.pad = 0;
         const bool has = (mpValid ? mpValid[i] != 0 : true) && !(outlier ? outlier[i] != 0 : false);
-        if (has) {
+        if (A.mode == 1) {
+            // SearchByProjection(Frame &F, const vector<MapPoint*> &, th, checkLevel)  src/ORBmatcher.cc:43-126: the projection was
+            // done by Frame::isInFrustum; mpValid = mbTrackInView, outlier = isBad()
+            if (has) {
+                const int lvl = A.mpLevel[(long long) pair * A.kpStrideLast + i];
+                float r = A.mpViewCos[(long long) pair * A.kpStrideLast + i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos
+                if (A.th != 1.0) r *= A.th;
+                const float u = A.mpProjX[(long long) pair * A.kpStrideLast + i], v = A.mpProjY[(long long) pair * A.kpStrideLast + i];
+                const float rad = r * A.scaleFactors[lvl];
+                const int nMinCellX = max(0, (int) floorf((u - A.minX - rad) * A.gridInvW));
+                const int nMaxCellX = min(GRID_COLS - 1, (int) ceilf((u - A.minX + rad) * A.gridInvW));
+                const int nMinCellY = max(0, (int) floorf((v - A.minY - rad) * A.gridInvH));
+                const int nMaxCellY = min(GRID_ROWS - 1, (int) ceilf((v - A.minY + rad) * A.gridInvH));
+                if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) && nMaxCellX >= nMinCellX &&
+                    nMaxCellY >= nMinCellY) {
+                    q.valid = 1;
+                    q.u = u; q.v = v; q.radius = rad;
+                    q.ur = A.mpProjXR ? A.mpProjXR[(long long) pair * A.kpStrideLast + i] : 0.f;
+                    q.minCx = (unsigned char) nMinCellX; q.maxCx = (unsigned char) nMaxCellX;
+                    q.minCy = (unsigned char) nMinCellY; q.maxCy = (unsigned char) nMaxCellY;
+                    q.minLevel = (signed char) (A.checkLevel ? lvl - 1 : -1);
+                    q.maxLevel = (signed char) (A.checkLevel ? lvl : -1);
+                }
+            }
+        } else if (has) {
             const float *X = world + 3 * (size_t) i;
             const float xc = (Rcw[0] * X[0] + Rcw[1] * X[1] + Rcw[2] * X[2]) + tcw[0];
             const float yc = (Rcw[3] * X[0] + Rcw[4] * X[1] + Rcw[5] * X[2]) + tcw[1];
@@ -314,7 +347,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) &&
                         nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY) {
                         q.valid = 1;
-                        q.u = u; q.v = v; q.radius = r; q.invzc = invzc; q.angle = lk.angle;
+                        q.u = u; q.v = v; q.radius = r; q.ur = u - A.mbf * invzc; q.angle = lk.angle;
                         q.minCx = (unsigned char) nMinCellX; q.maxCx = (unsigned char) nMaxCellX;
                         q.minCy = (unsigned char) nMinCellY; q.maxCy = (unsigned char) nMaxCellY;
                         q.minLevel = (signed char) minL; q.maxLevel = (signed char) maxL;
@@ -350,8 +383,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
                     if (L.owner[i2] == 2) continue;
                     if (uRight && uRight[i2] > 0) {
-                        const float ur = q.u - A.mbf * q.invzc;
-                        const float er = fabsf(ur - uRight[i2]);
+                        const float er = fabsf(q.ur - uRight[i2]);
                         if (er > q.radius) continue;
                     }
                     unsigned long long d0, d1, d2, d3;
@@ -362,7 +394,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                         d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
                     }
                     const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
-                    if (dist > (unsigned) TH_HIGH) continue;
+                    if (A.mode == 0 && dist > (unsigned) TH_HIGH) continue;   // mode 1 needs the runner-up even when it is far
                     const unsigned key = (dist << 16) | (ord & 0xFFFFu);
                     const unsigned short jj = (unsigned short) i2;
                     if (key < k3) {   // insert into the sorted quadruple
@@ -391,6 +423,44 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     int nmatches = 0, nEvents = 0, nRescan = 0;
     const float factor = 1.0f / HISTO_LENGTH;
     volatile unsigned char *vowner = L.owner;
+    const bool doOri = A.checkOri && A.mode == 0;
+    if (A.mode == 1) {
+        // best and second-best among the candidates that are free NOW = the first two free entries of the (dist, order)-sorted
+        // speculative list; a full list that runs out before both are found is rescanned.  Accept rule :112-121.
+        for (int i = 0; i < nq; i++) {
+            const uint4 keys = L.specKey[i];
+            if (keys.x >= kNoKey) continue;
+            const ushort4 idx = L.specI2[i];
+            const unsigned kk[4] = {keys.x, keys.y, keys.z, keys.w};
+            const int ii[4] = {idx.x, idx.y, idx.z, idx.w};
+            unsigned k1 = kNoKey, k2 = kNoKey;
+            int b1 = -1, b2 = -1;
+            bool exhausted = true;     // walked all 4 entries and every one was a real candidate
+            for (int e = 0; e < 4; e++) {
+                if (kk[e] >= kNoKey) { exhausted = false; break; }
+                if (vowner[ii[e]] == 2) continue;
+                if (b1 < 0) { b1 = ii[e]; k1 = kk[e]; }
+                else { b2 = ii[e]; k2 = kk[e]; exhausted = false; break; }
+            }
+            if (exhausted) {
+                const QueryParam q = L.qp[i];
+                const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
+                k1 = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &b1, &k2, &b2);
+                nRescan++;
+            }
+            const int bestDist = (int) (k1 >> 16);
+            if (b1 < 0 || bestDist > TH_HIGH) continue;
+            const int bestDist2 = (int) (k2 >> 16);      // 256 when there is no runner-up
+            const int bestLevel = L.octave[b1], bestLevel2 = (b2 >= 0 && bestDist2 < 256) ? L.octave[b2] : -1;
+            if (bestLevel == bestLevel2 && (float) bestDist > A.nnratio * (float) bestDist2) continue;
+            if (lane == 0) {
+                vowner[b1] = L.qobs[i] ? 2 : 1;
+                L.match[b1] = i;
+            }
+            nmatches++;
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else
     for (int i = 0; i < nq; i++) {
         const uint4 keys = L.specKey[i];
         if (keys.x >= kNoKey) continue;               // no acceptable candidate even before anything was taken
@@ -415,7 +485,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             L.match[bestIdx2] = i;
         }
         nmatches++;
-        if (A.checkOri) {
+        if (doOri) {
             float rot = L.qang[i] - L.cang[bestIdx2];
             if (rot < 0.0) rot += 360.0f;
             int bin = (int) roundf(rot * factor);
@@ -430,7 +500,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     STAMP(4);
     // ---- rotation consistency (:1327-1345) + ComputeThreeMaxima (:1471-1502) ----
-    if (A.checkOri) {
+    if (doOri) {
         for (int e = lane; e < nEvents; e += 64) atomicAdd(&s_hist[L.events[e] >> 24], 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -1143,4 +1143,97 @@ int ygzf_fast10(ygzf_ctx *c, const uint8_t *img, int img_w, int img_h, int strid
     return YGZF_OK;
 }
 
+int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
+                                        const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y,
+                                        const float *proj_xr, const float *view_cos, const int *scale_level, const uint8_t *mp_desc, float th,
+                                        int check_level, float nnratio, uint8_t *owner, int *match, int *nmatches) {
+    if (!c || !F || !cam || !nmatches) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *nmatches = 0;
+    if (F->n < 0 || n_mp < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    if (F->n == 0 || n_mp == 0) {
+        for (int i = 0; i < F->n; i++) if (match) match[i] = -1;
+        return YGZF_OK;
+    }
+    if (!F->keys || !F->desc || !track_in_view || !proj_x || !proj_y || !view_cos || !scale_level || !mp_desc || !owner || !match)
+        return fail(c, YGZF_ERR_INVALID, "null array");
+    for (int i = 0; i < n_mp; i++)
+        if (track_in_view[i] && (scale_level[i] < 0 || scale_level[i] >= kMaxLevels)) return fail(c, YGZF_ERR_INVALID, "mnTrackScaleLevel out of range");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t nt = F->n, nq = n_mp;
+    ygzf_ctx::Buf *G = c->dGen;
+    int counts[2] = {F->n, n_mp};
+    float pose[24] = {0};
+    std::vector<ygzf_kp> dummyKeys(nq);   // the Last-keypoint array is not read in this mode; keep the pointer valid
+    memset(dummyKeys.data(), 0, nq * sizeof(ygzf_kp));
+    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
+    Up ups[] = {{&G[0], F->keys, nt * sizeof(ygzf_kp)}, {&G[1], F->desc, nt * 32}, {&G[2], F->u_right, F->u_right ? nt * 4 : 0},
+                {&G[3], owner, nt}, {&G[4], dummyKeys.data(), nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32}, {&G[6], proj_x, nq * 4},
+                {&G[7], track_in_view, nq}, {&G[8], is_bad, is_bad ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
+                {&G[10], counts, sizeof counts}, {&G[11], pose, sizeof pose}};
+    int rc;
+    for (auto &u : ups) {
+        if (!u.bytes) continue;
+        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
+        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    // remaining per-MapPoint arrays share one scratch buffer: projY | projXR | viewCos | level
+    if ((rc = ensure(c, c->dTmpA, nq * 16))) return rc;
+    float *dY = (float *) c->dTmpA.p, *dXR = dY + nq, *dVC = dXR + nq;
+    int *dLv = (int *) (dVC + nq);
+    HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
+    if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dVC, view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dLv, scale_level, nq * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
+    MatchArgs A;
+    memset(&A, 0, sizeof A);
+    A.mode = 1;
+    A.curKeys = (const ygzf_kp *) G[0].p;
+    A.curDesc = (const uint8_t *) G[1].p;
+    A.curURight = F->u_right ? (const float *) G[2].p : nullptr;
+    A.ownerIn = (const uint8_t *) G[3].p;
+    A.curCnt = (const int *) G[10].p;
+    A.kpStrideCur = (long long) nt;
+    A.lastKeys = (const ygzf_kp *) G[4].p;
+    A.mpDesc = (const uint8_t *) G[5].p;
+    A.world = (const float *) G[6].p;     // unused in this mode
+    A.mpValid = (const uint8_t *) G[7].p;
+    A.outlier = is_bad ? (const uint8_t *) G[8].p : nullptr;
+    A.hasObs = mp_has_obs ? (const uint8_t *) G[9].p : nullptr;
+    A.lastCnt = (const int *) G[10].p;
+    A.kpStrideLast = (long long) nq;
+    A.cntOffLast = 1;
+    A.poses = (const float *) G[11].p;
+    A.mpProjX = (const float *) G[6].p;
+    A.mpProjY = dY;
+    A.mpProjXR = proj_xr ? dXR : nullptr;
+    A.mpViewCos = dVC;
+    A.mpLevel = dLv;
+    A.nnratio = nnratio;
+    fill_camera(A, cam, c);
+    if (F->scale_factors) for (int l = 0; l < kMaxLevels && l < F->nlevels; l++) A.scaleFactors[l] = F->scale_factors[l];
+    A.th = th;
+    A.bMono = 1;
+    A.checkLevel = check_level != 0;
+    A.checkOri = 0;
+    A.owner = (uint8_t *) c->dOwner.p;
+    A.match = (int *) c->dMatch.p;
+    A.nmatches = (int *) c->dNMatch.p;
+    A.capCur = (int) nt;
+    A.capLast = (int) nq;
+    size_t lds;
+    if ((rc = plan_match_lds(c, A, 1, &lds))) return rc;
+    {
+        ProfScope ps(c, KK_MATCH);
+        launch_match_last(c->stream, A, 1, lds);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(match, c->dMatch.p, nt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
+
 }  // extern "C"

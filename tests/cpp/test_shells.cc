@@ -88,6 +88,24 @@ int main(int argc, char **argv) {
         if (B.mvpMapPoints[i]) assigned[i] = (int) (B.mvpMapPoints[i] - mps.data());
     dump(dir + "/match.bin", assigned.data(), assigned.size() * sizeof(int));
     dump(dir + "/nmatch.bin", &nm, sizeof nm);
+    // Tracking::SearchLocalPoints: SearchByProjection(frame, localMapPoints, th) with the fields Frame::isInFrustum sets
+    std::vector<MapPoint *> local;
+    for (int i = 0; i < A.N; i++) {
+        mps[i].mbTrackInView = (i % 7) != 0;
+        mps[i].mTrackProjX = A.mvKeys[i].pt.x + 0.5f; mps[i].mTrackProjY = A.mvKeys[i].pt.y - 0.25f;
+        mps[i].mTrackViewCos = (i % 3) ? 0.9995f : 0.99f;
+        mps[i].mnTrackScaleLevel = A.mvKeys[i].octave;
+        local.push_back(&mps[i]);
+    }
+    Frame A2 = A;                       // match the points back into a copy of their own frame
+    A2.mvpMapPoints.assign(A2.N, nullptr);
+    ORBmatcher matcher2(0.8f, true);
+    const int nm2 = matcher2.SearchByProjection(A2, local, 3.f, true);
+    std::vector<int> assigned2(A2.N, -1);
+    for (int i = 0; i < A2.N; i++)
+        if (A2.mvpMapPoints[i]) assigned2[i] = (int) (A2.mvpMapPoints[i] - mps.data());
+    dump(dir + "/match2.bin", assigned2.data(), assigned2.size() * sizeof(int));
+    dump(dir + "/nmatch2.bin", &nm2, sizeof nm2);
     cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
     printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));
     return 0;

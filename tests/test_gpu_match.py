@@ -93,3 +93,40 @@ def test_search_by_projection_last_variants(oracle):
     # empty sides
     g_n, g_m, g_o = ex.search_by_projection_last(make_camera(w, h), kb, db, ka[:0], world[:0], da[:0], I, z, I, z, 15.0)
     assert g_n == 0 and (g_m == -1).all()
+
+
+def test_search_by_projection_mappoints(oracle):
+    """ORBmatcher::SearchByProjection(F, MapPoints, th, checkLevel) (Tracking::SearchLocalPoints) vs the oracle."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    base = synth_frame(60, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[9:9 + h, 11:11 + w]
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = ex.extract(a)     # "local map points": keypoints of frame A, projected where they land in B (+ jitter)
+    kb, db = ex.extract(b)
+    rng = np.random.default_rng(7)
+    M = len(ka)
+    px = (ka["x"] - 3.0 + rng.normal(0, 1.0, M)).astype(np.float32)
+    py = (ka["y"] - 1.0 + rng.normal(0, 1.0, M)).astype(np.float32)
+    vc = rng.uniform(0.99, 1.0, M).astype(np.float32)
+    lvl = np.clip(ka["octave"] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    tiv = (rng.uniform(size=M) > 0.15).astype(np.uint8)
+    bad = (rng.uniform(size=M) > 0.95).astype(np.uint8)
+    obs = (rng.uniform(size=M) > 0.2).astype(np.uint8)
+    pxr = (px - 4.0).astype(np.float32)
+    uright = np.where(rng.uniform(size=len(kb)) > 0.5, kb["x"] - 4.0, -1.0).astype(np.float32)
+    owner0 = (rng.uniform(size=len(kb)) > 0.93).astype(np.uint8) * 2
+    for cs in (dict(th=1.0, check_level=False, nnratio=0.8), dict(th=3.0, check_level=True, nnratio=0.8),
+               dict(th=5.0, check_level=False, nnratio=0.6, stereo=True), dict(th=8.0, check_level=True, nnratio=0.9, stereo=True)):
+        kw = dict(is_bad=bad, mp_has_obs=obs, owner=owner0)
+        if cs.get("stereo"):
+            kw.update(proj_xr=pxr, u_right=uright)
+        e_n, e_m, e_o = oracle.search_by_projection_mappoints(kb, db, sf, w, h, EUROC, tiv, px, py, vc, lvl, da, cs["th"], cs["check_level"],
+                                                              cs["nnratio"], **kw)
+        g_n, g_m, g_o = ex.search_by_projection_mappoints(make_camera(w, h), kb, db, tiv, px, py, vc, lvl, da, cs["th"], cs["check_level"],
+                                                          cs["nnratio"], scale_factors=sf, **kw)
+        assert g_n == e_n, (cs, g_n, e_n)
+        assert (g_m == e_m).all() and (g_o == e_o).all(), cs
+        assert e_n > 50

@@ -75,3 +75,16 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     assert nm == e_n and nm > 100
     exp = np.where(e_m >= 0, e_m, -1)
     assert (assigned == exp).all()
+    # SearchByProjection(F, MapPoints): the local points of A matched back into A
+    M = len(ka)
+    idx = np.arange(M)
+    tiv = (idx % 7 != 0).astype(np.uint8)
+    px = (ka["x"] + f(0.5)).astype(np.float32)
+    py = (ka["y"] - f(0.25)).astype(np.float32)
+    vc = np.where(idx % 3 != 0, f(0.9995), f(0.99)).astype(np.float32)
+    e_n2, e_m2, _ = oracle.search_by_projection_mappoints(ka, da, oex.tables()["scale"], w, h, EUROC, tiv, px, py, vc, ka["octave"], da, 3.0,
+                                                          True, 0.8)
+    nm2 = int(np.fromfile(tmp_path / "nmatch2.bin", np.int32)[0])
+    assigned2 = np.fromfile(tmp_path / "match2.bin", np.int32)
+    assert nm2 == e_n2 and nm2 > 100
+    assert (assigned2 == np.where(e_m2 >= 0, e_m2, -1)).all()
