@@ -207,23 +207,32 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     STAMP(0);
     // ---- LDS carve-up ----
     MatchLds L;
+    // Arrays that do not fit the LDS budget (large keypoint counts: 4000 / 8000 features) live in a per-pair global
+    // scratch arena instead; `spill` is the host's plan, bit per array group.
     unsigned char *p = dyn;
-    L.cellStart = (int *) p; p += sizeof(int) * (GRID_CELLS + 1);
-    p = (unsigned char *) (((size_t) p + 15) & ~(size_t) 15);
-    L.specKey = (uint4 *) p; p += sizeof(uint4) * A.capLast;
-    L.specI2 = (ushort4 *) p; p += sizeof(ushort4) * A.capLast;
-    L.desc = (unsigned long long *) p; p += A.descInLds ? (size_t) 32 * A.capCur : 0;
-    L.cellFill = (int *) p; p += sizeof(int) * GRID_CELLS;
-    L.list = (int *) p; p += sizeof(int) * A.capCur;
-    L.events = (int *) p; p += sizeof(int) * A.capLast;
-    L.qang = (float *) p; p += sizeof(float) * A.capLast;
-    L.cx = (float *) p; p += sizeof(float) * A.capCur;
-    L.cy = (float *) p; p += sizeof(float) * A.capCur;
-    L.cang = (float *) p; p += sizeof(float) * A.capCur;
-    L.match = (int *) p; p += sizeof(int) * A.capCur;
-    L.owner = p; p += A.capCur;
-    L.octave = p; p += A.capCur;
-    L.qobs = p; p += A.capLast;
+    unsigned char *gp = (unsigned char *) A.spillScratch + (long long) pair * A.spillStride;
+#define CARVE(ptr, type, count, bit)                                                        \
+    do {                                                                                    \
+        if (A.spill & (bit)) { ptr = (type *) gp; gp += (((size_t) sizeof(type) * (count)) + 15) & ~(size_t) 15; } \
+        else { ptr = (type *) p; p += (((size_t) sizeof(type) * (count)) + 15) & ~(size_t) 15; }                   \
+    } while (0)
+    CARVE(L.cellStart, int, GRID_CELLS + 1, 0);
+    CARVE(L.cellFill, int, GRID_CELLS, 0);
+    CARVE(L.list, int, A.capCur, 0);
+    CARVE(L.cx, float, A.capCur, 0);
+    CARVE(L.cy, float, A.capCur, 0);
+    CARVE(L.owner, unsigned char, A.capCur, 0);
+    CARVE(L.octave, unsigned char, A.capCur, 0);
+    CARVE(L.qobs, unsigned char, A.capLast, 0);
+    CARVE(L.specKey, uint4, A.capLast, kSpillSpec);
+    CARVE(L.specI2, ushort4, A.capLast, kSpillSpec);
+    CARVE(L.events, int, A.capLast, kSpillMisc);
+    CARVE(L.qang, float, A.capLast, kSpillMisc);
+    CARVE(L.cang, float, A.capCur, kSpillMisc);
+    CARVE(L.match, int, A.capCur, kSpillMisc);
+    L.desc = nullptr;
+    if (A.descInLds) CARVE(L.desc, unsigned long long, 4 * (size_t) A.capCur, 0);
+#undef CARVE
     L.qp = (QueryParam *) A.qpScratch + (long long) pair * A.capLast;   // global: only the rare full rescans read it back
 
     // ---- Frame::AssignFeaturesToGrid ----
@@ -539,13 +548,21 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
 #undef STAMP
 }
 
-size_t match_lds_bytes(int capCur, int capLast, bool descInLds, bool qpInLds) {
-    (void) qpInLds;  // per-query parameters always live in global scratch now
-    size_t b = sizeof(int) * (GRID_CELLS + 1) + 16 + (sizeof(uint4) + sizeof(ushort4)) * (size_t) capLast +
-               (descInLds ? (size_t) 32 * capCur : 0) + sizeof(int) * GRID_CELLS + sizeof(int) * (size_t) capCur +
-               sizeof(int) * (size_t) capLast + sizeof(float) * (size_t) capLast + 3 * sizeof(float) * (size_t) capCur +
-               sizeof(int) * (size_t) capCur + 2 * (size_t) capCur + (size_t) capLast + 64;
-    return (b + 15) & ~(size_t) 15;
+static inline size_t al16(size_t b) { return (b + 15) & ~(size_t) 15; }
+
+// LDS bytes / per-pair global spill bytes of the carve-up in k_match_last for a given plan
+size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes) {
+    size_t lds = al16(sizeof(int) * (GRID_CELLS + 1)) + al16(sizeof(int) * GRID_CELLS) + al16(sizeof(int) * (size_t) capCur) +
+                 2 * al16(sizeof(float) * (size_t) capCur) + 2 * al16((size_t) capCur) + al16((size_t) capLast);
+    size_t gl = 0;
+    const size_t spec = al16(sizeof(uint4) * (size_t) capLast) + al16(sizeof(ushort4) * (size_t) capLast);
+    const size_t misc = al16(sizeof(int) * (size_t) capLast) + al16(sizeof(float) * (size_t) capLast) + al16(sizeof(float) * (size_t) capCur) +
+                        al16(sizeof(int) * (size_t) capCur);
+    if (spill & kSpillSpec) gl += spec; else lds += spec;
+    if (spill & kSpillMisc) gl += misc; else lds += misc;
+    if (descInLds) lds += al16((size_t) 32 * capCur);
+    if (spillBytes) *spillBytes = gl;
+    return lds + 64;
 }
 
 hipError_t match_prepare(size_t ldsBytes) {

@@ -98,7 +98,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6];
+        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill;
     bool carryValid = false;
     int lastMatchPairs = 0;
     int identityPoses = 0;
@@ -518,7 +518,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)
@@ -810,14 +810,25 @@ static void fill_camera(MatchArgs &A, const ygzf_camera *cam, const ygzf_ctx *c)
 static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsBytes) {
     const size_t budget = 156 * 1024;
     if (A.capCur > 65535) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher supports at most 65535 keypoints per frame");
-    A.descInLds = 1;
     A.qpInLds = 0;
-    size_t b = match_lds_bytes(A.capCur, A.capLast, true, false);
-    if (b > budget) { A.descInLds = 0; b = match_lds_bytes(A.capCur, A.capLast, false, false); }
-    if (b > budget) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher needs %zu bytes of LDS for %d/%d keypoints", b, A.capCur, A.capLast);
+    // plans in order of preference: everything in LDS; descriptors in global; + speculative lists in global; + misc arrays
+    const struct { int desc, spill; } plans[] = {{1, 0}, {0, 0}, {0, kSpillSpec}, {0, kSpillSpec | kSpillMisc}};
+    size_t b = 0, sp = 0;
+    bool ok = false;
+    for (const auto &pl : plans) {
+        b = match_lds_bytes(A.capCur, A.capLast, pl.desc != 0, pl.spill, &sp);
+        if (b <= budget) { A.descInLds = pl.desc; A.spill = pl.spill; ok = true; break; }
+    }
+    if (!ok) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher needs %zu bytes of LDS for %d/%d keypoints", b, A.capCur, A.capLast);
     int rc = ensure(c, c->dQp, (size_t) nPairs * A.capLast * 32);
     if (rc) return rc;
     A.qpScratch = c->dQp.p;
+    A.spillStride = (long long) sp;
+    A.spillScratch = nullptr;
+    if (sp) {
+        if ((rc = ensure(c, c->dSpill, (size_t) nPairs * sp))) return rc;
+        A.spillScratch = c->dSpill.p;
+    }
     HIPCHECK(c, match_prepare(b));
     *ldsBytes = b;
     return YGZF_OK;

@@ -94,3 +94,30 @@ def test_descriptor_distance(oracle):
     got = ex.descriptor_distance(a, b)
     exp = np.array([oracle.hamming(a[i], b[i]) for i in range(len(a))])
     assert (got == exp).all() and (got[:10] == 0).all() and (got[10:20] == 256).all()
+
+
+@pytest.mark.parametrize("w,h,nl,nf", [(1920, 1080, 8, 4000), (3840, 2160, 12, 8000)])
+def test_baseline_large_configs(oracle, w, h, nl, nf):
+    """BASELINE.json configs[3] / configs[4] shapes (one frame, one eye): full-size parity vs the oracle + matcher chain."""
+    from orb_ygz_slam_amd import Extractor, make_camera
+    img = synth_frame(70 + nl, w, h)
+    ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=2)
+    oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
+    imgs = np.stack([img, np.roll(img, 2, axis=1)])
+    ex.extract_batch_host(imgs)
+    n = _cmp_frame(oracle, ex, oex, imgs[0], frame=0)
+    assert n > 0.9 * nf
+    ok, od = oex.extract(imgs[1])
+    k, d = ex.batch_fetch(1)
+    assert (k == ok).all() and (d == od).all()
+    # the matcher chain works at this keypoint count (descriptors no longer fit in LDS) and agrees with the oracle
+    from orb_ygz_slam_amd import EUROC
+    cam = make_camera(w, h)
+    ex.match_batch_prev(cam, 15.0, True, True, True)
+    k0, d0 = ex.batch_fetch(0)
+    world = np.stack([(k0["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]), (k0["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]),
+                      np.ones(len(k0), np.float32)], -1)
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    e_n, e_m, e_o = oracle.search_by_projection_last(k, d, oex.tables()["scale"], w, h, EUROC, k0, world, d0, I, z, I, z, 15.0)
+    m, o = ex.match_fetch(1)
+    assert ex.match_counts()[1] == e_n and (m[:len(k)] == e_m).all() and e_n > 0.3 * nf
