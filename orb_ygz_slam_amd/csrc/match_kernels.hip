@@ -75,6 +75,7 @@ struct MatchLds {
     unsigned char *qobs;        // MapPoint has observations
     unsigned char *owner, *octave;
     int *match;                 // per Cur keypoint: accepted Last index (flushed to global at the end)
+    int *claim;                 // per Cur keypoint: lowest pending lane that wants it this round (64 = none)
 };
 
 // GetFeaturesInArea + best-candidate scan of one query by one wave.
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     CARVE(L.qang, float, A.capLast, kSpillMisc);
     CARVE(L.cang, float, A.capCur, kSpillMisc);
     CARVE(L.match, int, A.capCur, kSpillMisc);
+    CARVE(L.claim, int, A.capCur, kSpillMisc);
     L.desc = nullptr;
     if (A.descInLds) CARVE(L.desc, unsigned long long, 4 * (size_t) A.capCur, 0);
 #undef CARVE
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         L.octave[i] = (unsigned char) k.octave;
         L.cx[i] = k.x; L.cy[i] = k.y; L.cang[i] = k.angle;
         L.match[i] = -1;
+        L.claim[i] = 64;
         if (A.descInLds) {
             const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i * 32);
             L.desc[4 * i] = d[0]; L.desc[4 * i + 1] = d[1]; L.desc[4 * i + 2] = d[2]; L.desc[4 * i + 3] = d[3];
@@ -433,6 +436,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     const float factor = 1.0f / HISTO_LENGTH;
     volatile unsigned char *vowner = L.owner;
     const bool doOri = A.checkOri && A.mode == 0;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
     if (A.mode == 1) {
         // best and second-best among the candidates that are free NOW = the first two free entries of the (dist, order)-sorted
         // speculative list; a full list that runs out before both are found is rescanned.  Accept rule :112-121.
@@ -469,40 +473,104 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             nmatches++;
             __builtin_amdgcn_wave_barrier();
         }
-    } else
-    for (int i = 0; i < nq; i++) {
-        const uint4 keys = L.specKey[i];
-        if (keys.x >= kNoKey) continue;               // no acceptable candidate even before anything was taken
-        const ushort4 idx = L.specI2[i];
-        int bestIdx2 = -1;
-        if (vowner[idx.x] != 2) bestIdx2 = idx.x;
-        else if (keys.y >= kNoKey) continue;
-        else if (vowner[idx.y] != 2) bestIdx2 = idx.y;
-        else if (keys.z >= kNoKey) continue;
-        else if (vowner[idx.z] != 2) bestIdx2 = idx.z;
-        else if (keys.w >= kNoKey) continue;
-        else if (vowner[idx.w] != 2) bestIdx2 = idx.w;
-        else {                                        // all four taken meanwhile: full rescan against the current ownership
-            const QueryParam q = L.qp[i];
-            const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
-            const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &bestIdx2);
-            nRescan++;
-            if ((int) (key >> 16) > TH_HIGH) continue;
+    } else {
+        // In-order semantics, 64 queries at a time.  Lane = query.  Every pending lane picks the first entry of its
+        // speculative list that is free NOW; a lane is "in conflict" if an EARLIER pending lane (whose MapPoint has
+        // observations, i.e. blocks) picked the same keypoint, or if its list is exhausted.  All lanes before the first
+        // conflict are final -- no earlier query can still change what they see -- and commit together; the first
+        // conflicting lane then re-picks against the updated ownership (or takes the cooperative rescan).  Each round
+        // retires at least one query; rounds per tile = 1 + number of real conflicts.
+        volatile int *vclaim = L.claim;
+        for (int tile = 0; tile < nq; tile += 64) {
+            const int i = tile + lane;
+            const bool active = i < nq;
+            uint4 keys = make_uint4(kNoKey, kNoKey, kNoKey, kNoKey);
+            ushort4 idx = make_ushort4(0, 0, 0, 0);
+            bool obs = false;
+            if (active) { keys = L.specKey[i]; idx = L.specI2[i]; obs = L.qobs[i] != 0; }
+            bool pending = active && keys.x < kNoKey;
+            while (__ballot(pending)) {
+                int choice = -1;
+                bool rescan = false;
+                if (pending) {
+                    if (vowner[idx.x] != 2) choice = idx.x;
+                    else if (keys.y >= kNoKey) pending = false;
+                    else if (vowner[idx.y] != 2) choice = idx.y;
+                    else if (keys.z >= kNoKey) pending = false;
+                    else if (vowner[idx.z] != 2) choice = idx.z;
+                    else if (keys.w >= kNoKey) pending = false;
+                    else if (vowner[idx.w] != 2) choice = idx.w;
+                    else rescan = true;
+                }
+                if (pending && choice >= 0 && obs) atomicMin((int *) &vclaim[choice], lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bool conflict = pending && (rescan || (choice >= 0 && vclaim[choice] < lane));
+                __builtin_amdgcn_wave_barrier();
+                if (pending && choice >= 0 && obs) vclaim[choice] = 64;
+                const unsigned long long cm = __ballot(conflict);
+                const int first = cm ? (int) __ffsll((long long) cm) - 1 : 64;
+                const bool commit = pending && lane < first;
+                const unsigned long long mcommit = __ballot(commit);
+                if (mcommit) {
+                    const unsigned long long noobs = __ballot(commit && !obs);
+                    if (noobs == 0) {
+                        if (commit) { vowner[choice] = 2; L.match[choice] = i; }
+                    } else {
+                        // a MapPoint without observations does not block its keypoint: later queries may overwrite it, so
+                        // these commits must land in query order
+                        unsigned long long mm = mcommit;
+                        while (mm) {
+                            const int k = (int) __ffsll((long long) mm) - 1;
+                            mm &= mm - 1;
+                            if (lane == k) { vowner[choice] = obs ? 2 : 1; L.match[choice] = i; }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    if (doOri && commit) {
+                        float rot = L.qang[i] - L.cang[choice];
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int) roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        L.events[nEvents + __popcll(mcommit & lane_lt)] = (bin << 24) | choice;
+                    }
+                    const int nc = __popcll(mcommit);
+                    nmatches += nc;
+                    if (doOri) nEvents += nc;
+                    if (commit) pending = false;
+                }
+                // the first conflicting lane with an exhausted list: cooperative rescan against the current ownership
+                const bool firstRescan = first < 64 && __builtin_amdgcn_readlane((int) rescan, first) != 0;
+                if (firstRescan) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int qi = tile + first;
+                    const QueryParam q = L.qp[qi];
+                    const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) qi * 32);
+                    int b = -1;
+                    const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &b);
+                    nRescan++;
+                    if ((int) (key >> 16) <= TH_HIGH) {
+                        if (lane == first) { vowner[b] = obs ? 2 : 1; L.match[b] = qi; }
+                        if (doOri) {
+                            float rot = L.qang[qi] - L.cang[b];
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int) roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            if (lane == 0) L.events[nEvents] = (bin << 24) | b;
+                            nEvents++;
+                        }
+                        nmatches++;
+                    }
+                    if (lane == first) pending = false;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
-        if (lane == 0) {
-            vowner[bestIdx2] = L.qobs[i] ? 2 : 1;
-            L.match[bestIdx2] = i;
-        }
-        nmatches++;
-        if (doOri) {
-            float rot = L.qang[i] - L.cang[bestIdx2];
-            if (rot < 0.0) rot += 360.0f;
-            int bin = (int) roundf(rot * factor);
-            if (bin == HISTO_LENGTH) bin = 0;
-            if (lane == 0) L.events[nEvents] = (bin << 24) | bestIdx2;
-            nEvents++;
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -557,7 +625,7 @@ size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_
     size_t gl = 0;
     const size_t spec = al16(sizeof(uint4) * (size_t) capLast) + al16(sizeof(ushort4) * (size_t) capLast);
     const size_t misc = al16(sizeof(int) * (size_t) capLast) + al16(sizeof(float) * (size_t) capLast) + al16(sizeof(float) * (size_t) capCur) +
-                        al16(sizeof(int) * (size_t) capCur);
+                        2 * al16(sizeof(int) * (size_t) capCur);
     if (spill & kSpillSpec) gl += spec; else lds += spec;
     if (spill & kSpillMisc) gl += misc; else lds += misc;
     if (descInLds) lds += al16((size_t) 32 * capCur);
