@@ -174,6 +174,75 @@ __global__ __launch_bounds__(256) void k_pyr_resize(FrameSet fs, const LevelGeom
     dst[(long long) y * g.pitch + x] = (uint8_t) ((((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// Tiled variant (the one normally launched): a workgroup produces a 256 x 32 output tile.  The <= 41 x 312 byte source
+// region is staged in LDS with coalesced aligned dword loads; every thread owns 4 adjacent columns (their xofs / alpha
+// stay in registers) over 8 rows, so the per-pixel memory instruction count drops from 8 (gathers + table loads) to ~0.2.
+constexpr int kPyrTW = 256, kPyrTH = 32, kPyrSrcRows = 44, kPyrSrcPitch = 328;
+
+__global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const LevelGeom *__restrict__ geom, int level,
+                                                          const int *__restrict__ xofs, const short *__restrict__ xalpha,
+                                                          const int *__restrict__ yofs, const short *__restrict__ ybeta) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kPyrSrcRows * kPyrSrcPitch];
+    const LevelGeom g = geom[level];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kPyrTW, y0 = blockIdx.y * kPyrTH, f = blockIdx.z;
+    int sp;
+    const uint8_t *src = level_ptr(fs, geom[level - 1], level - 1, f, &sp);
+    const int sw = geom[level - 1].w, sh = geom[level - 1].h;
+    const int xl = min(x0 + kPyrTW, g.w) - 1, yl = min(y0 + kPyrTH, g.h) - 1;
+    const int sxa = xofs[g.xtab + x0] & ~3, sxb = min(xofs[g.xtab + xl] + 1, sw - 1);
+    const int sya = min(max(yofs[g.ytab + y0], 0), sh - 1), syb = min(max(yofs[g.ytab + yl] + 1, 0), sh - 1);
+    const int nd = (sxb - sxa) / 4 + 1, nr = syb - sya + 1;          // dwords per row (<= 82), rows (<= 42)
+    {
+        const unsigned total = (unsigned) sh * (unsigned) sp;          // bytes of the source level that may be touched
+        int r = tid / nd, c = tid - r * nd;
+        const int sr = 256 / nd, sc = 256 - sr * nd;
+        for (int idx = tid; idx < nd * nr; idx += 256) {
+            const unsigned off = (unsigned) (sya + r) * (unsigned) sp + (unsigned) (sxa + 4 * c);
+            unsigned v;
+            if (off + 4 <= total) v = *(const unsigned *) (src + off);
+            else {   // last dword of the last row of a caller-owned level-0 buffer: never read past its end
+                v = 0;
+                for (int b = 0; b < 4; b++) if (off + b < total) v |= (unsigned) src[off + b] << (8 * b);
+            }
+            ((unsigned *) tile)[r * (kPyrSrcPitch / 4) + c] = v;
+            r += sr; c += sc;
+            if (c >= nd) { c -= nd; r++; }
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, rg = tid >> 6;
+    const int xb = x0 + 4 * lane;
+    if (xb >= g.w) return;
+    int lx[4], lx1[4], a0[4], a1[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = min(xb + k, g.w - 1);
+        const int sx = xofs[g.xtab + x];
+        lx[k] = sx - sxa;
+        lx1[k] = min(sx + 1, sw - 1) - sxa;
+        a0[k] = xalpha[2 * (g.xtab + x)];
+        a1[k] = xalpha[2 * (g.xtab + x) + 1];
+    }
+    uint8_t *dstf = fs.pyr + (long long) f * fs.pyr_stride + g.off;
+    for (int ry = 0; ry < 8; ry++) {
+        const int y = y0 + rg * 8 + ry;
+        if (y >= g.h) break;
+        const int sy = yofs[g.ytab + y];
+        const int r0 = min(max(sy, 0), sh - 1) - sya, r1 = min(max(sy + 1, 0), sh - 1) - sya;
+        const int b0 = ybeta[2 * (g.ytab + y)], b1 = ybeta[2 * (g.ytab + y) + 1];
+        const uint8_t *S0 = tile + r0 * kPyrSrcPitch, *S1 = tile + r1 * kPyrSrcPitch;
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int H0 = S0[lx[k]] * a0[k] + S0[lx1[k]] * a1[k];
+            const int H1 = S1[lx[k]] * a0[k] + S1[lx1[k]] * a1[k];
+            out |= (unsigned) ((((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2) << (8 * k);
+        }
+        *(unsigned *) (dstf + (unsigned) y * (unsigned) g.pitch + xb) = out;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // K2  FAST-9/16 per 30-px cell.  One workgroup per (cell, frame): the (wCell+6)x(hCell+6) window is staged in LDS, the
 // 16-pixel Bresenham ring is read from LDS, the score (max arc margin - 1 == cv::FAST's cornerScore) is written to an
@@ -1028,8 +1097,13 @@ hipError_t upload_constants(const int *umax16) {
 
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
-    dim3 grid((g.w + 255) / 256, g.h, nFrames);
-    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+    if (g.area2x) {   // exact 2x levels (scaleFactor 2.0 configs) keep the simple per-pixel kernel
+        dim3 grid((g.w + 255) / 256, g.h, nFrames);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+        return;
+    }
+    dim3 grid((g.w + kPyrTW - 1) / kPyrTW, (g.h + kPyrTH - 1) / kPyrTH, nFrames);
+    hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
 }
 
 size_t fast_lds_bytes(int tilePitch, int tileRows, int smapRows) {
