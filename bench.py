@@ -117,6 +117,9 @@ def main():
                     help="independent extractor contexts (own HIP stream + buffers) the batch is split over, so that the "
                          "latency-bound kernels of one sub-batch overlap the throughput-bound kernels of another")
     ap.add_argument("--workload", default="euroc752x480_8lvl_1000feat", choices=sorted(WORKLOADS))
+    ap.add_argument("--align", action="store_true",
+                    help="BASELINE config 3: also run SparseImgAlign (levels L-1..1, 10 iterations) of every frame against its "
+                         "predecessor; `metric` stays extract+match, the step simply carries the extra work (see config.align)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -179,6 +182,8 @@ def main():
         for e, ptr in zip(exs, ptrs):
             e.extract_batch_device(ptr, Bs, w, h)
             e.match_batch_prev(cam, 15.0, True, True, True)
+            if args.align:
+                e.align_batch_prev(cam, nl - 1, 1, 10)
 
     for _ in range(args.warmup):
         step()
@@ -250,7 +255,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h, "levels": nl, "scale_factor": sf, "features": nf,
-                       "frames_per_gpu_per_step": B, "streams": S, "match": "SearchByProjection(cur,last) th=15, identity pose",
+                       "frames_per_gpu_per_step": B, "streams": S, "align": bool(args.align), "match": "SearchByProjection(cur,last) th=15, identity pose",
                        "sharding": "one clip per GPU, no collective"},
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "roofline": roofline, "kernels": kernels,

@@ -177,6 +177,14 @@ typedef struct ygzf_sia_frame {
 int ygzf_sia_run(ygzf_ctx *ctx, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, const ygzf_camera *cam, const float *inv_scale_factors,
                  int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36);
 
+/* Batched, device-resident form chained behind ygzf_extract_batch_* (BASELINE config 3: extract + match + align):
+ * for batch frame f, ref = frame f-1 (f == 0: the last frame of the previous batch of this context; without one the entry
+ * reports ret = 0), cur = frame f; features = the keypoints of ref with MapPoints at their unit-depth back-projection;
+ * both poses identity.  Uses the pyramids already in HBM (levels >= 1: min_level >= 1, as Tracking's
+ * SparseImgAlign(nLevels-1, 1)).  The first call makes the context keep the last pyramid across batches. */
+int ygzf_align_batch_prev(ygzf_ctx *ctx, const ygzf_camera *cam, int max_level, int min_level, int n_iter);
+int ygzf_align_fetch(ygzf_ctx *ctx, int frame, float *TCR_out, size_t *ret, float *info);
+
 /* ---- Thirdparty/fast (Rosten FAST-10/16), replaced outright: fast::fast_corner_detect_10_sse2 + fast::fast_corner_score_10
  *      + fast::fast_nonmax_3x3  (Thirdparty/fast/include/fast/fast.h:19-29; called at src/ORBextractor.cc:1220-1235,
  *      :1330-1340, :1440-1450) on the window [x0,x0+w) x [y0,y0+h) of a host image -----------------------------------------

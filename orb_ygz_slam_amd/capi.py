@@ -93,6 +93,8 @@ def load_library(build_if_missing=True):
         C.c_float, C.c_int, C.c_float, vp, vp, ip]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
+    L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
+    L.ygzf_align_fetch.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_size_t), vp]
     L.ygzf_fast10.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip, ip]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
@@ -349,6 +351,16 @@ class Extractor:
         self._ck(self.L.ygzf_sia_run(self.h, C.byref(R), C.byref(Cf), C.byref(cam), _p(isf), max_level, min_level, n_iter, _p(out7),
                                      C.byref(ret), _p(info), _p(H)))
         return int(ret.value), out7, info, H.reshape(6, 6)
+
+    def align_batch_prev(self, cam, max_level=None, min_level=1, n_iter=10):
+        self._ck(self.L.ygzf_align_batch_prev(self.h, C.byref(cam), self.nlevels - 1 if max_level is None else max_level, min_level, n_iter))
+
+    def align_fetch(self, frame):
+        T = np.zeros(7, np.float32)
+        info = np.zeros(2, np.float32)
+        ret = C.c_size_t()
+        self._ck(self.L.ygzf_align_fetch(self.h, frame, _p(T), C.byref(ret), _p(info)))
+        return int(ret.value), T, info
 
     def fast10(self, img, barrier, window=None, cap=None):
         """libfast replacement: (xy int16 (n,2), scores, nonmax indices) of fast_corner_detect_10_sse2 / score / nonmax_3x3."""

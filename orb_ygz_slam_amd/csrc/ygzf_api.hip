@@ -98,7 +98,11 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill;
+        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5];
+    bool alignCarry = false;      // keep the last frame's pyramid across batches (enabled by the first ygzf_align_batch_prev)
+    bool carryPyrValid = false;
+    int lastAlignPairs = 0;
+    std::vector<unsigned char> alKey;   // cache key of the uploaded SiaLevel tables
     bool carryValid = false;
     int lastMatchPairs = 0;
     int identityPoses = 0;
@@ -394,6 +398,14 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     outKp += G.kpStride;
     outDesc += (size_t) G.kpStride * 32;
     outCnt += 1;
+    if (c->alignCarry && G.pyrBytes > 0) {   // the previous batch's last pyramid is the reference of pair 0 in ygzf_align_batch_prev
+        int rc2 = ensure(c, c->dCarryPyr, (size_t) G.pyrBytes + 256);
+        if (rc2) return rc2;
+        c->carryPyrValid = c->carryValid && c->lastFrames > 0;
+        if (c->carryPyrValid)
+            HIPCHECK(c, hipMemcpyAsync(c->dCarryPyr.p, (uint8_t *) c->dPyr.p + (size_t) (c->lastFrames - 1) * G.pyrBytes, (size_t) G.pyrBytes,
+                                       hipMemcpyDeviceToDevice, c->stream));
+    }
     for (int l = 1; l < L; l++) {
         ProfScope ps(c, KK_PYR);
         launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
@@ -444,6 +456,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     c->lastFs = fs;
     c->carryValid = true;
     c->lastMatchPairs = 0;
+    c->lastAlignPairs = 0;
     return YGZF_OK;
 }
 
@@ -518,7 +531,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)
@@ -526,6 +539,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &b : c->dSia)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dF10)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dAl)
         if (b.p) (void) hipFree(b.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
@@ -1244,6 +1259,110 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
     HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
+
+// ---- SparseImgAlign over a resident batch ---------------------------------------------------------------------------------
+int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, int min_level, int n_iter) {
+    if (!c || !cam) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    const int L = c->tab.cfg.nlevels;
+    if (min_level < 1 || max_level < min_level || max_level >= L)
+        return fail(c, YGZF_ERR_INVALID, "level range [%d,%d] (the resident form aligns on pyramid levels >= 1, as Tracking does)", min_level, max_level);
+    HIPCHECK(c, hipSetDevice(c->device));
+    const Geometry &G = c->geo;
+    const int B = c->lastFrames;
+    if (G.kpStride == 0) return fail(c, YGZF_ERR_STATE, "configuration yields no keypoints");
+    c->alignCarry = true;
+    int rc;
+    ygzf_ctx::Buf *S = c->dAl;   // 0 level tables, 1 poses, 2 caches, 3 out, (world = dWorld)
+    if ((rc = ensure(c, c->dWorld, (size_t) (B + 1) * G.kpStride * 3 * sizeof(float))) ||
+        (rc = ensure(c, S[0], (size_t) B * 2 * kMaxLevels * sizeof(SiaLevel))) || (rc = ensure(c, S[1], (size_t) B * 14 * sizeof(float))) ||
+        (rc = ensure(c, S[2], (size_t) B * G.kpStride * ((16 + 96) * sizeof(float) + 1) + 64)) ||
+        (rc = ensure(c, S[3], (size_t) B * 48 * sizeof(float))) || (rc = ensure(c, c->dCarryPyr, (size_t) G.pyrBytes + 256)))
+        return rc;
+    // level tables + identity poses: uploaded when anything they depend on changed
+    std::vector<unsigned char> key;
+    {
+        const void *parts[] = {c->dPyr.p, c->dCarryPyr.p, S[0].p, S[1].p};
+        key.insert(key.end(), (const unsigned char *) parts, (const unsigned char *) parts + sizeof parts);
+        const int ints[] = {B, G.w, G.h, c->carryPyrValid ? 1 : 0};
+        key.insert(key.end(), (const unsigned char *) ints, (const unsigned char *) ints + sizeof ints);
+    }
+    if (key != c->alKey) {
+        std::vector<SiaLevel> lv((size_t) B * 2 * kMaxLevels);
+        memset(lv.data(), 0, lv.size() * sizeof(SiaLevel));
+        for (int p = 0; p < B; p++)
+            for (int l = 1; l < L; l++) {
+                const LevelGeom &g = G.lv[l];
+                SiaLevel &r = lv[((size_t) p * 2 + 0) * kMaxLevels + l], &cu = lv[((size_t) p * 2 + 1) * kMaxLevels + l];
+                r.w = cu.w = g.w; r.h = cu.h = g.h; r.pitch = cu.pitch = g.pitch;
+                cu.img = (const uint8_t *) c->dPyr.p + (size_t) p * G.pyrBytes + g.off;
+                r.img = p > 0 ? (const uint8_t *) c->dPyr.p + (size_t) (p - 1) * G.pyrBytes + g.off : (const uint8_t *) c->dCarryPyr.p + g.off;
+            }
+        std::vector<float> poses((size_t) B * 14, 0.f);
+        for (int p = 0; p < B; p++) poses[(size_t) p * 14 + 3] = poses[(size_t) p * 14 + 10] = 1.f;   // identity quaternions
+        HIPCHECK(c, hipMemcpyAsync(S[0].p, lv.data(), lv.size() * sizeof(SiaLevel), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(S[1].p, poses.data(), poses.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->alKey = key;
+    }
+    const ygzf_kp *kp = (const ygzf_kp *) c->dOutKp.p;
+    const int *cnt = (const int *) c->dOutCnt.p;
+    {
+        ProfScope ps(c, KK_BACKPROJ);
+        launch_backproject_unit(c->stream, kp, cnt, G.kpStride, G.kpStride, B, cam->fx, cam->fy, cam->cx, cam->cy, (float *) c->dWorld.p);
+    }
+    SiaArgs A;
+    memset(&A, 0, sizeof A);
+    A.keys = kp;                 // pair p: reference = output slot p (slot 0 = carry), current = slot p + 1
+    A.world = (const float *) c->dWorld.p;
+    A.kpStride = G.kpStride;
+    A.nRef = cnt;
+    A.poses = (const float *) S[1].p;
+    A.refLv = (const SiaLevel *) S[0].p;
+    A.curLv = A.refLv + kMaxLevels;
+    A.lvStride = 2 * kMaxLevels;
+    for (int l = 0; l < kMaxLevels; l++) A.invScale[l] = l < L ? c->tab.invScale[l] : 1.f;
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy;
+    A.maxLevel = max_level; A.minLevel = min_level; A.nIter = n_iter;
+    A.eps = 0.000001f;
+    A.patchCache = (float *) S[2].p;
+    A.jacCache = A.patchCache + (size_t) B * G.kpStride * 16;
+    A.visible = (uint8_t *) (A.jacCache + (size_t) B * G.kpStride * 96);
+    A.out = (float *) S[3].p;
+    const int first = c->carryPyrValid ? 0 : 1;   // without a carried pyramid frame 0 has no reference image
+    if (!c->carryPyrValid) HIPCHECK(c, hipMemsetAsync(S[3].p, 0, 48 * sizeof(float), c->stream));
+    if (B - first > 0) {
+        SiaArgs A2 = A;
+        A2.keys += (size_t) first * G.kpStride;
+        A2.world += (size_t) first * G.kpStride * 3;
+        A2.nRef += first;
+        A2.poses += (size_t) first * 14;
+        A2.refLv += (size_t) first * A.lvStride;
+        A2.curLv += (size_t) first * A.lvStride;
+        A2.patchCache += (size_t) first * G.kpStride * 16;
+        A2.jacCache += (size_t) first * G.kpStride * 96;
+        A2.visible += (size_t) first * G.kpStride;
+        A2.out += (size_t) first * 48;
+        ProfScope ps(c, KK_SIA);
+        launch_sia(c->stream, A2, B - first);
+    }
+    HIPCHECK(c, hipGetLastError());
+    c->lastAlignPairs = B;
+    return YGZF_OK;
+}
+
+int ygzf_align_fetch(ygzf_ctx *c, int frame, float *TCR_out, size_t *ret, float *info) {
+    if (!c || !TCR_out || !ret) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastAlignPairs < 1) return fail(c, YGZF_ERR_STATE, "no aligned batch");
+    if (frame < 0 || frame >= c->lastAlignPairs) return fail(c, YGZF_ERR_INVALID, "frame %d out of range", frame);
+    float out[48];
+    HIPCHECK(c, hipMemcpyAsync(out, (float *) c->dAl[3].p + (size_t) frame * 48, sizeof out, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    memcpy(TCR_out, out, 28);
+    *ret = (size_t) out[7];
+    if (info) { info[0] = out[8]; info[1] = out[9]; }
     return YGZF_OK;
 }
 

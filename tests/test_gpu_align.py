@@ -58,3 +58,45 @@ def test_sia_edge_cases(oracle):
     o = oracle.sparse_img_align(k, world, ident, pyrA, ident, pyrB, inv, EUROC, 7, 1, outlier=np.ones(len(k), np.uint8))
     assert ret == 0 and o[0] == 0                      # nothing visible -> singular system -> stop, 0 measurements
     assert np.abs(T - o[1]).max() <= TOL
+
+
+def test_align_batch_prev_matches_host_api(oracle):
+    """Device-resident batch form (ref = previous frame of the batch, unit-depth points) == ygzf_sia_run on the same data,
+    including the pyramid carried over from the previous batch."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    imgA, imgB, _, _ = two_view_scene(11, w, h, EUROC, Z=1.0, rotvec=(0.002, -0.003, 0.001), trans=(0.004, -0.003, 0.002))
+    imgC, _, _, _ = two_view_scene(12, w, h, EUROC)
+    imgs = np.stack([imgA, imgB, imgC])
+    ex = Extractor(600, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=3)
+    cam = make_camera(w, h)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    inv = ex.tables()["inv_scale"]
+    for rnd in range(2):
+        ex.extract_batch_host(imgs)
+        ex.align_batch_prev(cam, 7, 1, 10)
+        res = [ex.align_fetch(f) for f in range(3)]
+        kps = [ex.batch_fetch(f)[0] for f in range(3)]
+        pyr = [[ex.batch_fetch_level(f, l) for l in range(8)] for f in range(3)]
+        for f in range(3):
+            if f == 0 and rnd == 0:
+                assert res[0][0] == 0          # no predecessor yet
+                continue
+            rf = (f - 1) % 3                   # f == 0 in round 1: the carried last frame of the previous batch
+            k = kps[rf]
+            world = np.stack([(k["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]),
+                              (k["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]), np.ones(len(k), np.float32)], -1)
+            ret, T, info, _ = ex2_run(ex, cam, k, world, ident, pyr[rf], pyr[f], inv)
+            assert res[f][0] == ret, (rnd, f, res[f][0], ret)
+            assert np.abs(res[f][1] - T).max() <= 1e-6
+    assert res[1][0] > 100 and np.abs(res[1][1][4:]).max() > 1e-3   # A -> B really moved
+
+
+def ex2_run(ex, cam, k, world, ident, pyr_ref, pyr_cur, inv):
+    from orb_ygz_slam_amd import Extractor
+    global _EX2
+    try:
+        _EX2
+    except NameError:
+        _EX2 = Extractor(600, 1.2, 8, 20, 7, max_width=64, max_height=64, max_batch=1)
+    return _EX2.sia_run(cam, k, world, ident, pyr_ref, ident, pyr_cur, inv, 7, 1)
