@@ -15,7 +15,7 @@
 
 namespace ygzf {
 
-constexpr int kSiaBlock = 256;
+constexpr int kSiaBlock = 512;
 constexpr float kSophusEps = 1e-5f;
 
 struct Se3 { float q[4]; float t[3]; };  // quaternion x,y,z,w + translation
@@ -105,49 +105,88 @@ __device__ Se3 se3_exp(const float a[6]) {  // se3.hpp:406-428
     return r;
 }
 
-// x = H.ldlt().solve(b): LDL^T with diagonal pivoting, 6x6 float (single lane).
-__device__ void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+// x = H.ldlt().solve(b): LDL^T with diagonal pivoting, 6x6 float (single lane).  Every array index is a compile-time
+// constant after unrolling (the pivot swap is a chain of predicated exchanges), so A/b/perm stay in registers; with
+// run-time indices they land in scratch memory and each access costs a memory round trip.
+__device__ __forceinline__ void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
     float A[36], b[6];
     int perm[6];
+#pragma unroll
     for (int i = 0; i < 36; i++) A[i] = Hin[i];
+#pragma unroll
     for (int i = 0; i < 6; i++) { b[i] = bin[i]; perm[i] = i; }
+#pragma unroll
     for (int k = 0; k < 6; k++) {
         int p = k;
         float best = fabsf(A[7 * k]);
+#pragma unroll
         for (int i = k + 1; i < 6; i++)
             if (fabsf(A[7 * i]) > best) { best = fabsf(A[7 * i]); p = i; }
-        if (p != k) {
-            for (int j = 0; j < 6; j++) { float t = A[6 * k + j]; A[6 * k + j] = A[6 * p + j]; A[6 * p + j] = t; }
-            for (int j = 0; j < 6; j++) { float t = A[6 * j + k]; A[6 * j + k] = A[6 * j + p]; A[6 * j + p] = t; }
-            float t = b[k]; b[k] = b[p]; b[p] = t;
-            int ti = perm[k]; perm[k] = perm[p]; perm[p] = ti;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            if (p == i) {   // exchange rows / columns k and i
+#pragma unroll
+                for (int j = 0; j < 6; j++) { const float t = A[6 * k + j]; A[6 * k + j] = A[6 * i + j]; A[6 * i + j] = t; }
+#pragma unroll
+                for (int j = 0; j < 6; j++) { const float t = A[6 * j + k]; A[6 * j + k] = A[6 * j + i]; A[6 * j + i] = t; }
+                const float t = b[k]; b[k] = b[i]; b[i] = t;
+                const int ti = perm[k]; perm[k] = perm[i]; perm[i] = ti;
+            }
         }
         const float d = A[7 * k];
+#pragma unroll
         for (int i = k + 1; i < 6; i++) {
             const float l = A[6 * i + k] / d;
+#pragma unroll
             for (int j = k + 1; j < 6; j++) A[6 * i + j] -= l * A[6 * k + j];
             A[6 * i + k] = l;
         }
     }
     float y[6], z[6];
+#pragma unroll
     for (int i = 0; i < 6; i++) {
         float s = b[i];
+#pragma unroll
         for (int j = 0; j < i; j++) s -= A[6 * i + j] * y[j];
         y[i] = s;
     }
+#pragma unroll
     for (int i = 0; i < 6; i++) y[i] = y[i] / A[7 * i];
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
         float s = y[i];
+#pragma unroll
         for (int j = i + 1; j < 6; j++) s -= A[6 * j + i] * z[j];
         z[i] = s;
     }
-    for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (perm[i] == q) x[q] = z[i];
+    }
+}
+
+// Wave-wide float sum without LDS traffic (DPP inside rows of 16 lanes, rows combined through SGPRs); the result is the same
+// in every lane and bit-reproducible run to run (fixed tree).
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (a + b) + (c + d);
 }
 
 constexpr int kAcc = 30;  // 21 upper-triangular H entries + 6 b + chi2 + n_meas + n_visible_features
 
 __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
+    extern __shared__ float4 s_feat[];   // per feature: xyz in the reference camera (Tref * Xw, constant over the run), w = visible flag
     __shared__ float s_red[(kSiaBlock / 64) * kAcc];
+    __shared__ float s_tot[kAcc];
     __shared__ Se3 s_T, s_Told, s_Tref;
     __shared__ float s_H[36], s_b[6], s_x[6];
     __shared__ float s_chi2, s_newchi2;
@@ -159,8 +198,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     const float *world = A.world + (long long) pair * A.kpStride * 3;
     const uint8_t *mpValid = A.mpValid ? A.mpValid + (long long) pair * A.kpStride : nullptr;
     const uint8_t *outlier = A.outlier ? A.outlier + (long long) pair * A.kpStride : nullptr;
-    float *patchCache = A.patchCache + (long long) pair * A.kpStride * 16;
-    float *jacCache = A.jacCache + (long long) pair * A.kpStride * 96;
+    float *rowCache = A.patchCache + (long long) pair * A.kpStride * 48;   // per (feature, row): patch[4] dx[4] dy[4]
     uint8_t *visible = A.visible + (long long) pair * A.kpStride;
     float *out = A.out + (long long) pair * 48;   // TCR[7], ret, iters, chi2, pad[2], H[36]
 
@@ -176,8 +214,11 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         s_iters = 0;
         for (int i = 0; i < 36; i++) s_H[i] = 0;
     }
-    for (int i = tid; i < N; i += kSiaBlock) visible[i] = 0;   // allocated once in run(), never cleared between levels
-    for (int i = tid; i < N * 16; i += kSiaBlock) patchCache[i] = 0.f;
+    for (int i = tid; i < N; i += kSiaBlock) {                  // visible_fts_: allocated once in run(), never cleared between levels
+        visible[i] = 0;
+        s_feat[i] = make_float4(0.f, 0.f, 1.f, 0.f);
+    }
+    for (int i = tid; i < N * 48; i += kSiaBlock) rowCache[i] = 0.f;
     __syncthreads();
     if (N == 0) {                               // :24-27 "no features to track"
         if (tid == 0) { for (int i = 0; i < 48; i++) out[i] = 0; out[3] = 1.f; }
@@ -187,111 +228,133 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     for (int level = A.maxLevel; level >= A.minLevel; level--) {
         const SiaLevel Lr = A.refLv[(long long) pair * A.lvStride + level], Lc = A.curLv[(long long) pair * A.lvStride + level];
         const float scale = A.invScale[level];
-        // ---- precomputeReferencePatches (jacobian cache zeroed per level, :41) ----
-        for (int i = tid; i < N * 96; i += kSiaBlock) jacCache[i] = 0.f;
-        __syncthreads();
+        // ---- precomputeReferencePatches.  The reference zeroes the whole jacobian cache per level (:41); only features that
+        // stay "visible" from a coarser level but fail this level's border test can still read it, so only their rows are zeroed.
+        const long long p0c = wall_clock64();
         {
+            // work item = (feature, patch row): 4 pixels; the per-feature terms are recomputed by the 4 rows (cheap ALU)
             const Se3 Tref = s_Tref;
-            for (int i = tid; i < N; i += kSiaBlock) {
-                if ((mpValid && !mpValid[i]) || (outlier && outlier[i])) continue;
+            for (int it = tid; it < 4 * N; it += kSiaBlock) {
+                const int i = it >> 2, y = it & 3;
+                bool ok = !((mpValid && !mpValid[i]) || (outlier && outlier[i]));
                 const ygzf_kp kp = keys[i];
                 const float u_ref = kp.x * scale, v_ref = kp.y * scale;
                 const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
-                if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) continue;
-                visible[i] = 1;
+                if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) ok = false;
+                float *rc = rowCache + ((size_t) i * 4 + y) * 12;   // per (feature, row): patch[4] | dx[4] | dy[4]
+                if (!ok) {
+                    if (s_feat[i].w != 0.f) {   // visible from an earlier level: its Jacobian counts as zero at this level
+#pragma unroll
+                        for (int k = 4; k < 12; k++) rc[k] = 0.f;
+                    }
+                    continue;
+                }
                 float xyz[3];
                 se3_act(Tref, world + 3 * (size_t) i, xyz);
-                // JacobXYZ2Cam (include/SparseImageAlign.h:90-111)
-                float J[12];
-                {
-                    const float x = xyz[0], y = xyz[1];
-                    const float z_inv = (float) (1. / (double) xyz[2]);
-                    const float z_inv_2 = z_inv * z_inv;
-                    J[0] = -z_inv; J[1] = 0.f; J[2] = x * z_inv_2; J[3] = y * J[2];
-                    J[4] = (float) -(1.0 + (double) (x * J[2])); J[5] = y * z_inv;
-                    J[6] = 0.f; J[7] = -z_inv; J[8] = y * z_inv_2; J[9] = (float) (1.0 + (double) (y * J[8]));
-                    J[10] = -J[3]; J[11] = -x * z_inv;
-                }
+                if (y == 0) { visible[i] = 1; s_feat[i] = make_float4(xyz[0], xyz[1], xyz[2], 1.f); }
                 const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
                 const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
                 const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
                 const int st = Lr.pitch;
-                const float fs = A.fx * scale;
-                for (int y = 0; y < 4; y++) {
-                    const uint8_t *p = Lr.img + (long long) (v_ref_i + y - 2) * st + (u_ref_i - 2);
-                    for (int x = 0; x < 4; x++, p++) {
-                        const int px = y * 4 + x;
-                        patchCache[(size_t) i * 16 + px] = w_tl * p[0] + w_tr * p[1] + w_bl * p[st] + w_br * p[st + 1];
-                        const float dx = 0.5f * ((w_tl * p[1] + w_tr * p[2] + w_bl * p[st + 1] + w_br * p[st + 2]) -
-                                                 (w_tl * p[-1] + w_tr * p[0] + w_bl * p[st - 1] + w_br * p[st]));
-                        const float dy = 0.5f * ((w_tl * p[st] + w_tr * p[1 + st] + w_bl * p[st * 2] + w_br * p[st * 2 + 1]) -
-                                                 (w_tl * p[-st] + w_tr * p[1 - st] + w_bl * p[0] + w_br * p[1]));
-                        float *Jc = jacCache + ((size_t) i * 16 + px) * 6;
-                        for (int k = 0; k < 6; k++) Jc[k] = (dx * J[k] + dy * J[6 + k]) * fs;
-                    }
+                const uint8_t *p = Lr.img + (long long) (v_ref_i + y - 2) * st + (u_ref_i - 2);
+#pragma unroll
+                for (int x = 0; x < 4; x++, p++) {
+                    rc[x] = w_tl * p[0] + w_tr * p[1] + w_bl * p[st] + w_br * p[st + 1];
+                    rc[4 + x] = 0.5f * ((w_tl * p[1] + w_tr * p[2] + w_bl * p[st + 1] + w_br * p[st + 2]) -
+                                        (w_tl * p[-1] + w_tr * p[0] + w_bl * p[st - 1] + w_br * p[st]));
+                    rc[8 + x] = 0.5f * ((w_tl * p[st] + w_tr * p[1 + st] + w_bl * p[st * 2] + w_br * p[st * 2 + 1]) -
+                                        (w_tl * p[-st] + w_tr * p[1 - st] + w_bl * p[0] + w_br * p[1]));
                 }
             }
         }
         __syncthreads();
+        if (tid == 0 && A.dbg) A.dbg[4] += wall_clock64() - p0c;
         // ---- optimizeGaussNewton ----
         if (tid == 0) { s_Told = s_T; s_break = 0; }
         __syncthreads();
         for (int iter = 0; iter < A.nIter; iter++) {
+            const long long c0 = wall_clock64();
             const Se3 T = s_T, Tref = s_Tref;
             float acc[kAcc];
 #pragma unroll
             for (int k = 0; k < kAcc; k++) acc[k] = 0.f;
-            for (int i = tid; i < N; i += kSiaBlock) {
-                if (!visible[i]) continue;
-                float xr[3], xc[3];
-                se3_act(Tref, world + 3 * (size_t) i, xr);
+            for (int it = tid; it < 4 * N; it += kSiaBlock) {
+                const int i = it >> 2, y = it & 3;            // work item = (feature, patch row)
+                const float4 ft = s_feat[i];
+                if (ft.w == 0.f) continue;
+                const float xr[3] = {ft.x, ft.y, ft.z};
+                float xc[3];
                 se3_act(T, xr, xc);
                 const float ucx = A.fx * xc[0] / xc[2] + A.cx, ucy = A.fy * xc[1] / xc[2] + A.cy;   // Frame::Camera2Pixel
                 const float u_cur = ucx * scale, v_cur = ucy * scale;
                 const int ui = (int) floorf(u_cur), vi = (int) floorf(v_cur);
                 if (ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 || ui + border >= Lc.w || vi + border >= Lc.h) continue;
-                acc[29] += 1.f;
+                if (y == 0) acc[29] += 1.f;
                 const float su = u_cur - ui, sv = v_cur - vi;
                 const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
                 const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
                 const int st = Lc.pitch;
-                for (int y = 0; y < 4; y++) {
-                    const uint8_t *p = Lc.img + (long long) (vi + y - 2) * st + (ui - 2);
-                    for (int x = 0; x < 4; x++, p++) {
-                        const int px = y * 4 + x;
-                        const float I = w_tl * p[0] + w_tr * p[1] + w_bl * p[st] + w_br * p[st + 1];
-                        const float res = I - patchCache[(size_t) i * 16 + px];
-                        acc[27] += res * res;
-                        acc[28] += 1.f;
-                        const float *Jc = jacCache + ((size_t) i * 16 + px) * 6;
-                        const float j0 = Jc[0], j1 = Jc[1], j2 = Jc[2], j3 = Jc[3], j4 = Jc[4], j5 = Jc[5];
-                        acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j0 * j3; acc[4] += j0 * j4; acc[5] += j0 * j5;
-                        acc[6] += j1 * j1; acc[7] += j1 * j2; acc[8] += j1 * j3; acc[9] += j1 * j4; acc[10] += j1 * j5;
-                        acc[11] += j2 * j2; acc[12] += j2 * j3; acc[13] += j2 * j4; acc[14] += j2 * j5;
-                        acc[15] += j3 * j3; acc[16] += j3 * j4; acc[17] += j3 * j5;
-                        acc[18] += j4 * j4; acc[19] += j4 * j5;
-                        acc[20] += j5 * j5;
-                        acc[21] -= j0 * res; acc[22] -= j1 * res; acc[23] -= j2 * res; acc[24] -= j3 * res; acc[25] -= j4 * res;
-                        acc[26] -= j5 * res;
-                    }
+                const uint8_t *p = Lc.img + (long long) (vi + y - 2) * st + (ui - 2);
+                int t0[5], t1[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) { t0[k] = p[k]; t1[k] = p[st + k]; }
+                const float4 *rcp = (const float4 *) (rowCache + ((size_t) i * 4 + y) * 12);
+                const float4 pc = rcp[0], dxv = rcp[1], dyv = rcp[2];
+                // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point, rebuilt from the LDS copy: the
+                // cached quantity of the reference, (dx*J.row0 + dy*J.row1) * (fx*scale), is re-evaluated with the same
+                // operations, so only patch/dx/dy (12 B per pixel instead of 28 B) stream from memory every iteration
+                float J[12];
+                {
+                    const float x = xr[0], yy = xr[1];
+                    const float z_inv = (float) (1. / (double) xr[2]);
+                    const float z_inv_2 = z_inv * z_inv;
+                    J[0] = -z_inv; J[1] = 0.f; J[2] = x * z_inv_2; J[3] = yy * J[2];
+                    J[4] = (float) -(1.0 + (double) (x * J[2])); J[5] = yy * z_inv;
+                    J[6] = 0.f; J[7] = -z_inv; J[8] = yy * z_inv_2; J[9] = (float) (1.0 + (double) (yy * J[8]));
+                    J[10] = -J[3]; J[11] = -x * z_inv;
+                }
+                const float fs = A.fx * scale;
+                const float pcv[4] = {pc.x, pc.y, pc.z, pc.w}, dxa[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, dya[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
+                float jj[24];
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) jj[6 * x + k] = (dxa[x] * J[k] + dya[x] * J[6 + k]) * fs;
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const float I = w_tl * t0[x] + w_tr * t0[x + 1] + w_bl * t1[x] + w_br * t1[x + 1];
+                    const float res = I - pcv[x];
+                    acc[27] += res * res;
+                    acc[28] += 1.f;
+                    const float j0 = jj[6 * x], j1 = jj[6 * x + 1], j2 = jj[6 * x + 2], j3 = jj[6 * x + 3], j4 = jj[6 * x + 4], j5 = jj[6 * x + 5];
+                    acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j0 * j3; acc[4] += j0 * j4; acc[5] += j0 * j5;
+                    acc[6] += j1 * j1; acc[7] += j1 * j2; acc[8] += j1 * j3; acc[9] += j1 * j4; acc[10] += j1 * j5;
+                    acc[11] += j2 * j2; acc[12] += j2 * j3; acc[13] += j2 * j4; acc[14] += j2 * j5;
+                    acc[15] += j3 * j3; acc[16] += j3 * j4; acc[17] += j3 * j5;
+                    acc[18] += j4 * j4; acc[19] += j4 * j5;
+                    acc[20] += j5 * j5;
+                    acc[21] -= j0 * res; acc[22] -= j1 * res; acc[23] -= j2 * res; acc[24] -= j3 * res; acc[25] -= j4 * res;
+                    acc[26] -= j5 * res;
                 }
             }
-            // fixed-shape reduction: butterfly inside each wave, then lane 0 of the block sums the 4 wave partials in order
+            const long long c1 = wall_clock64();
+            // fixed-shape reduction: DPP tree inside each wave, then 30 threads add the 16 wave partials in order
 #pragma unroll
             for (int k = 0; k < kAcc; k++) {
-                float v = acc[k];
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                const float v = wave_sum_dpp(acc[k]);
                 if (lane == 0) s_red[wave * kAcc + k] = v;
             }
             __syncthreads();
+            if (tid < kAcc) {
+                float v = 0.f;
+                for (int w2 = 0; w2 < kSiaBlock / 64; w2++) v += s_red[w2 * kAcc + tid];
+                s_tot[tid] = v;
+            }
+            __syncthreads();
+            const long long c2 = wall_clock64();
             if (tid == 0) {
                 float r[kAcc];
-                for (int k = 0; k < kAcc; k++) {
-                    float v = 0.f;
-                    for (int w2 = 0; w2 < kSiaBlock / 64; w2++) v += s_red[w2 * kAcc + k];
-                    r[k] = v;
-                }
+                for (int k = 0; k < kAcc; k++) r[k] = s_tot[k];
                 int t = 0;
                 for (int a = 0; a < 6; a++)
                     for (int b2 = a; b2 < 6; b2++, t++) { s_H[6 * a + b2] = r[t]; s_H[6 * b2 + a] = r[t]; }
@@ -318,6 +381,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                     if (nm <= A.eps) s_break = 1;                // converged
                 }
             }
+            if (tid == 0 && A.dbg) { const long long c3 = wall_clock64(); A.dbg[0] += c1 - c0; A.dbg[1] += c2 - c1; A.dbg[2] += c3 - c2; A.dbg[3] += 1; }
             __syncthreads();
             if (s_break) break;
         }
@@ -334,8 +398,14 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     }
 }
 
-void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs) {
-    hipLaunchKernelGGL(k_sia_run, dim3(nPairs), dim3(kSiaBlock), 0, st, A);
+size_t sia_lds_bytes(int maxFeatures) { return (size_t) maxFeatures * sizeof(float4) + 16; }
+
+hipError_t sia_prepare(size_t ldsBytes) {
+    return hipFuncSetAttribute((const void *) k_sia_run, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+}
+
+void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes) {
+    hipLaunchKernelGGL(k_sia_run, dim3(nPairs), dim3(kSiaBlock), ldsBytes, st, A);
 }
 
 }  // namespace ygzf

@@ -97,12 +97,15 @@ struct SiaArgs {
     float fx, fy, cx, cy;
     int maxLevel, minLevel, nIter;
     float eps;
-    float *patchCache;              // kpStride*16 floats per pair
-    float *jacCache;                // kpStride*96 floats per pair
+    float *patchCache;              // kpStride*48 floats per pair: per (feature, patch row) patch[4] | dx[4] | dy[4]
+    float *jacCache;                // unused (Jacobians are rebuilt from dx, dy each iteration)
     uint8_t *visible;               // kpStride per pair
     float *out;                     // 48 floats per pair: TCR[7], ret, iters, chi2, pad[2], H[36]
+    long long *dbg;                 // nullable: phase clocks of pair 0 (debug)
 };
-void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs);
+size_t sia_lds_bytes(int maxFeatures);
+hipError_t sia_prepare(size_t ldsBytes);
+void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes);
 
 }  // namespace ygzf
 #endif

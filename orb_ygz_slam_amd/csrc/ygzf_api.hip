@@ -1106,17 +1106,30 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     A.maxLevel = max_level; A.minLevel = min_level; A.nIter = n_iter;
     A.eps = 0.000001f;   // src/SparseImageAlign.cc:17
     A.patchCache = (float *) S[6].p;
-    A.jacCache = A.patchCache + N * 16;
-    A.visible = (uint8_t *) (A.jacCache + N * 96);
+    A.jacCache = nullptr;
+    A.visible = (uint8_t *) (A.patchCache + N * 48);
     A.out = (float *) S[7].p;
     {
+        if (getenv("YGZF_SIA_DEBUG")) {
+            if ((rc = ensure(c, c->dTmpB, 64))) return rc;
+            HIPCHECK(c, hipMemsetAsync(c->dTmpB.p, 0, 64, c->stream));
+            A.dbg = (long long *) c->dTmpB.p;
+        }
+        const size_t sl = sia_lds_bytes((int) N);
+        if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 16));
+        HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
-        launch_sia(c->stream, A, 1);
+        launch_sia(c->stream, A, 1, sl);
     }
     HIPCHECK(c, hipGetLastError());
     float out[48];
     HIPCHECK(c, hipMemcpyAsync(out, S[7].p, sizeof out, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (A.dbg) {
+        long long st[5];
+        HIPCHECK(c, hipMemcpy(st, A.dbg, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ygzf sia, 10ns ticks over %lld iterations] accumulate %lld  reduce %lld  solve %lld  precompute(all levels) %lld\n", st[3], st[0], st[1], st[2], st[4]);
+    }
     memcpy(TCR_out, out, 28);
     *ret = (size_t) out[7];
     if (info) { info[0] = out[8]; info[1] = out[9]; }
@@ -1328,8 +1341,8 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
     A.maxLevel = max_level; A.minLevel = min_level; A.nIter = n_iter;
     A.eps = 0.000001f;
     A.patchCache = (float *) S[2].p;
-    A.jacCache = A.patchCache + (size_t) B * G.kpStride * 16;
-    A.visible = (uint8_t *) (A.jacCache + (size_t) B * G.kpStride * 96);
+    A.jacCache = nullptr;
+    A.visible = (uint8_t *) (A.patchCache + (size_t) B * G.kpStride * 48);
     A.out = (float *) S[3].p;
     const int first = c->carryPyrValid ? 0 : 1;   // without a carried pyramid frame 0 has no reference image
     if (!c->carryPyrValid) HIPCHECK(c, hipMemsetAsync(S[3].p, 0, 48 * sizeof(float), c->stream));
@@ -1341,12 +1354,14 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
         A2.poses += (size_t) first * 14;
         A2.refLv += (size_t) first * A.lvStride;
         A2.curLv += (size_t) first * A.lvStride;
-        A2.patchCache += (size_t) first * G.kpStride * 16;
-        A2.jacCache += (size_t) first * G.kpStride * 96;
+        A2.patchCache += (size_t) first * G.kpStride * 48;
         A2.visible += (size_t) first * G.kpStride;
         A2.out += (size_t) first * 48;
+        const size_t sl = sia_lds_bytes(G.kpStride);
+        if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 16));
+        HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
-        launch_sia(c->stream, A2, B - first);
+        launch_sia(c->stream, A2, B - first, sl);
     }
     HIPCHECK(c, hipGetLastError());
     c->lastAlignPairs = B;
