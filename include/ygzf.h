@@ -185,6 +185,27 @@ int ygzf_sia_run(ygzf_ctx *ctx, const ygzf_sia_frame *ref, const ygzf_sia_frame 
 int ygzf_align_batch_prev(ygzf_ctx *ctx, const ygzf_camera *cam, int max_level, int min_level, int n_iter);
 int ygzf_align_fetch(ygzf_ctx *ctx, int frame, float *TCR_out, size_t *ret, float *info);
 
+/* ---- ORBextractor::operator()(Frame*, vector<KeyPoint>&, OutputArray, DSO_KEYPOINT, leftEye)   src/ORBextractor.cc:1031-1127 -----
+ * with ComputeKeyPointsDSOSingleLevel (:1275-1386: FAST-10 per grid cell at barrier 20 then 5, 20-px edge filter, occupancy of the
+ * frame's existing keys, Shi-Tomasi score :1152-1187, 3 best per cell, grid-size retry loop) and the descriptors of existing + new keys.
+ * The pyramid is computed from `img` (what the Frame constructor does before, src/Frame.cc:807-813).
+ * keys: in  = the frame's n_existing keys (mvKeys: level-0 coordinates, octave = level they were found at),
+ *       out = the same keys with IC_Angle recomputed (:1380-1383) followed by the new level-0 keys (size 7, response 0, octave 0).
+ * desc: n_total x 32 bytes, row i belongs to keys[i] (:1101-1126).
+ * grid_size: ORBextractor::mnGridSize, persistent across frames; pass a negative value for "not yet set" (:1298-1299).
+ * Defined where the reference is not: score ties keep raster order; a NaN score ranks lowest; a frame without a single FAST corner
+ * returns no new keys (the reference never leaves its loop); existing keys closer than 15 px to their level's border are rejected
+ * (out-of-bounds reads in the reference). */
+int ygzf_extract_dso(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, ygzf_kp *keys, int n_existing, int cap, uint8_t *desc,
+                     int *grid_size, int *n_total);
+
+/* Descriptors (and optionally IC_Angle) of keys that already exist in a frame -- the "existing ones" loop of the Frame overload,
+ * src/ORBextractor.cc:1093-1106 -- on the pyramid of frame `frame` of the last extracted batch.  keys hold level-0 coordinates and the
+ * octave they live on; the descriptor is taken at cvRound(pt * mvInvScaleFactor[octave]) on the blurred level.
+ * recompute_angle = 0: the stored angle is used (ORBSLAM_KEYPOINT / FAST_KEYPOINT branches, :1096);
+ * recompute_angle = 1: IC_Angle first (what ComputeKeyPointsDSOSingleLevel does to them, :1380-1383), returned in angles_out. */
+int ygzf_describe_keys(ygzf_ctx *ctx, int frame, const ygzf_kp *keys, int n, int recompute_angle, float *angles_out, uint8_t *desc);
+
 /* ---- Thirdparty/fast (Rosten FAST-10/16), replaced outright: fast::fast_corner_detect_10_sse2 + fast::fast_corner_score_10
  *      + fast::fast_nonmax_3x3  (Thirdparty/fast/include/fast/fast.h:19-29; called at src/ORBextractor.cc:1220-1235,
  *      :1330-1340, :1440-1450) on the window [x0,x0+w) x [y0,y0+h) of a host image -----------------------------------------

@@ -121,6 +121,44 @@ void yo_resize(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
     std::memcpy(dst, d.d.data(), (size_t) dw * dh);
 }
 
+// operator()(Frame*, ..., DSO_KEYPOINT): keys holds n_existing keys on entry; returns the total count (existing + new)
+int yo_extract_dso(void *e_, const uint8_t *img, int w, int h, int stride, KeyPoint *keys, int n_existing, int cap, uint8_t *desc, int *grid_size) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<KeyPoint> k(keys, keys + n_existing);
+    std::vector<uint8_t> d;
+    e->mnGridSize = *grid_size;
+    e->ExtractDSO(img, w, h, stride, k, d);
+    *grid_size = e->mnGridSize;
+    const int n = (int) k.size();
+    if (n > cap) return -n;
+    std::memcpy(keys, k.data(), sizeof(KeyPoint) * n);
+    std::memcpy(desc, d.data(), 32 * (size_t) n);
+    return n;
+}
+
+// the "existing ones" loop of the Frame overload (src/ORBextractor.cc:1093-1106) on the pyramid of `img`;
+// recompute != 0: IC_Angle first, as ComputeKeyPointsDSOSingleLevel :1380-1383 (angles are written back into keys)
+void yo_describe_keys(void *e_, const uint8_t *img, int w, int h, int stride, KeyPoint *keys, int n, int recompute, uint8_t *desc) {
+    Extractor *e = (Extractor *) e_;
+    e->ComputePyramid(img, w, h, stride);
+    std::vector<Image> blurred(e->nlevels);
+    for (int i = 0; i < e->nlevels; i++) gaussian_blur7_s2_u8(e->mvImagePyramid[i], blurred[i]);
+    for (int i = 0; i < n; i++) {
+        KeyPoint tmp = keys[i];
+        tmp.x *= e->mvInvScaleFactor[tmp.octave];
+        tmp.y *= e->mvInvScaleFactor[tmp.octave];
+        if (recompute) keys[i].angle = tmp.angle = e->ICAngle(e->mvImagePyramid[tmp.octave], tmp.x, tmp.y);
+        e->ComputeDescriptor(tmp, blurred[tmp.octave], desc + (size_t) i * 32);
+    }
+}
+
+float yo_shi_tomasi(void *e_, const uint8_t *img, int w, int h, int u, int v) {
+    Extractor *e = (Extractor *) e_;
+    Image im(w, h);
+    std::memcpy(im.d.data(), img, (size_t) w * h);
+    return e->ShiTomasiScore(im, u, v);
+}
+
 float yo_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 void yo_sincos_deg(float a, float *c, float *s) { sincos_deg(a, c, s); }
 int yo_cv_round(double v) { return cv_round(v); }

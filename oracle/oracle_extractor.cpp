@@ -387,4 +387,116 @@ void Extractor::Extract(const uint8_t *img, int w, int h, int stride, std::vecto
     }
 }
 
+
+// ---- FAST-10 grid path (DSO_KEYPOINT) ---------------------------------------------------------------------------------
+extern "C" int yo_fast10_detect(const uint8_t *img, int w, int h, int stride, int barrier, short *xy, int cap);  // oracle_fast10.cpp
+
+// :1152-1187
+float Extractor::ShiTomasiScore(const Image &img, int u, int v) const {
+    float dXX = 0.0, dYY = 0.0, dXY = 0.0;
+    const int halfbox_size = 4;
+    const int box_size = 2 * halfbox_size;
+    const int box_area = box_size * box_size;
+    const int x_min = u - halfbox_size, x_max = u + halfbox_size, y_min = v - halfbox_size, y_max = v + halfbox_size;
+    if (x_min < 1 || x_max >= img.w - 1 || y_min < 1 || y_max >= img.h - 1) return 0.0;
+    const int stride = img.w;
+    for (int y = y_min; y < y_max; ++y) {
+        const uint8_t *ptr_left = &img.d[(size_t) stride * y + x_min - 1];
+        const uint8_t *ptr_right = &img.d[(size_t) stride * y + x_min + 1];
+        const uint8_t *ptr_top = &img.d[(size_t) stride * (y - 1) + x_min];
+        const uint8_t *ptr_bottom = &img.d[(size_t) stride * (y + 1) + x_min];
+        for (int x = 0; x < box_size; ++x, ++ptr_left, ++ptr_right, ++ptr_top, ++ptr_bottom) {
+            float dx = (float) (*ptr_right - *ptr_left);
+            float dy = (float) (*ptr_bottom - *ptr_top);
+            dXX += dx * dx;
+            dYY += dy * dy;
+            dXY += dx * dy;
+        }
+    }
+    dXX = (float) (dXX / (2.0 * box_area));
+    dYY = (float) (dYY / (2.0 * box_area));
+    dXY = (float) (dXY / (2.0 * box_area));
+    return (float) (0.5 * (dXX + dYY - std::sqrt((dXX + dYY) * (dXX + dYY) - 4 * (dXX * dYY - dXY * dXY))));
+}
+
+// :1275-1386
+void Extractor::ComputeKeyPointsDSOSingleLevel(std::vector<KeyPoint> &allKeypoints, std::vector<KeyPoint> &exist_kps) {
+    const Image &img = mvImagePyramid[0];
+    std::vector<uint8_t> occ((size_t) img.w * img.h, 0);
+    for (KeyPoint &kp : exist_kps) occ[(size_t) cv_round(kp.y) * img.w + cv_round(kp.x)] = 255;
+    const int h = img.h, w = img.w, n = nfeatures;
+    if (mnGridSize < 0) mnGridSize = static_cast<int>(std::sqrt(1.0 * h * w / n));
+    int cnt = 0;
+    std::vector<short> xy((size_t) 2 * 64 * 64 + 16);
+    while (cnt < n) {
+        if (cnt > 0) {
+            mnGridSize -= 5;
+            if (mnGridSize < 7) {
+                mnGridSize = 7;
+                break;
+            }
+        }
+        allKeypoints.clear();
+        const int grid_n_rows = h / mnGridSize, grid_n_cols = w / mnGridSize;
+        if ((size_t) mnGridSize * mnGridSize * 2 > xy.size()) xy.resize((size_t) mnGridSize * mnGridSize * 2);
+        cnt = 0;
+        for (int k = 0; k < grid_n_rows * grid_n_cols; k++) {
+            const int nn = k / grid_n_cols;
+            if (nn == 0 || nn == grid_n_rows - 1 || (k % grid_n_cols) == 0 || (k + 1) % grid_n_cols == 0) continue;
+            const int x_start = (k - nn * grid_n_cols) * mnGridSize, y_start = nn * mnGridSize;
+            const uint8_t *data = &img.d[(size_t) y_start * w + x_start];
+            int nc = yo_fast10_detect(data, mnGridSize, mnGridSize, w, 20, xy.data(), mnGridSize * mnGridSize);
+            if (nc == 0) nc = yo_fast10_detect(data, mnGridSize, mnGridSize, w, 5, xy.data(), mnGridSize * mnGridSize);  // :1337 hard-coded 5
+            if (nc == 0) continue;
+            std::vector<std::pair<std::pair<int, int>, float>> corner_score;
+            for (int c = 0; c < nc; c++) {
+                const int x = xy[2 * c] + x_start, y = xy[2 * c + 1] + y_start;
+                if (x < 20 || y < 20 || x >= img.w - 20 || y >= img.h - 20) continue;
+                if (occ[(size_t) y * w + x] == 255) continue;
+                corner_score.push_back(std::make_pair(std::make_pair(x, y), ShiTomasiScore(img, x, y)));
+            }
+            std::stable_sort(corner_score.begin(), corner_score.end(),
+                             [](const std::pair<std::pair<int, int>, float> &a, const std::pair<std::pair<int, int>, float> &b) {
+                                 return a.second > b.second;
+                             });
+            const int take = corner_score.size() > 3 ? 3 : (int) corner_score.size();
+            for (int i = 0; i < take; i++) {
+                KeyPoint kp;
+                kp.x = (float) corner_score[i].first.first;
+                kp.y = (float) corner_score[i].first.second;
+                kp.size = 7;
+                kp.response = 0;
+                kp.octave = 0;
+                kp.class_id = -1;
+                kp.angle = ICAngle(img, kp.x, kp.y);
+                allKeypoints.push_back(kp);
+                cnt++;
+            }
+        }
+        if (cnt == 0) break;  // the reference never leaves this loop on a frame without a single corner; defined: no new keys
+    }
+    if (cnt > n) mnGridSize += 5;
+    for (KeyPoint &kp : exist_kps) kp.angle = ICAngle(mvImagePyramid[kp.octave], kp.x * mvInvScaleFactor[kp.octave], kp.y * mvInvScaleFactor[kp.octave]);
+}
+
+// :1031-1127 with method == DSO_KEYPOINT, leftEye == true
+void Extractor::ExtractDSO(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc) {
+    ComputePyramid(img, w, h, stride);   // Frame ctor: ComputeImagePyramid; the overload then uses frame->mvImagePyramid
+    const int N = (int) keys.size();
+    std::vector<KeyPoint> kps;
+    ComputeKeyPointsDSOSingleLevel(kps, keys);
+    const int nkeypoints = (int) kps.size() + N;
+    desc.assign((size_t) nkeypoints * 32, 0);
+    std::vector<Image> blurred(nlevels);
+    for (int i = 0; i < nlevels; i++) gaussian_blur7_s2_u8(mvImagePyramid[i], blurred[i]);
+    for (int i = 0; i < N; i++) {
+        KeyPoint tmp = keys[i];
+        tmp.x *= mvInvScaleFactor[tmp.octave];
+        tmp.y *= mvInvScaleFactor[tmp.octave];
+        ComputeDescriptor(tmp, blurred[tmp.octave], &desc[(size_t) i * 32]);
+    }
+    for (size_t i = 0; i < kps.size(); i++) ComputeDescriptor(kps[i], blurred[0], &desc[(size_t) (N + i) * 32]);
+    keys.insert(keys.end(), kps.begin(), kps.end());
+}
+
 }  // namespace ygzo

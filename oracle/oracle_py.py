@@ -136,6 +136,39 @@ class Extractor:
         assert n >= 0, "oracle extract: capacity too small"
         return k[:n].copy(), d[:n].copy()
 
+    def extract_dso(self, img, existing=None, grid_size=-1, cap=None):
+        """operator()(Frame*, ..., DSO_KEYPOINT) -> (keys (existing with updated angles + new), desc, new mnGridSize)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        existing = np.zeros(0, KP_DTYPE) if existing is None else np.ascontiguousarray(existing, KP_DTYPE)
+        cap = cap or (len(existing) + 3 * (w // 7) * (h // 7) + 16)
+        k = np.zeros(cap, KP_DTYPE)
+        k[:len(existing)] = existing
+        d = np.zeros((cap, 32), np.uint8)
+        g = C.c_int(grid_size)
+        self.L.yo_extract_dso.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                          C.POINTER(C.c_int)]
+        n = self.L.yo_extract_dso(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g))
+        assert n >= 0
+        return k[:n].copy(), d[:n].copy(), g.value
+
+    def describe_keys(self, img, keys, recompute_angle=False):
+        """Descriptors (and optionally fresh IC_Angle) of existing keys -> (keys, desc)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        k = np.ascontiguousarray(keys, KP_DTYPE).copy()
+        d = np.zeros((len(k), 32), np.uint8)
+        self.L.yo_describe_keys.restype = None
+        self.L.yo_describe_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.L.yo_describe_keys(self.h, _p(img), w, h, w, _p(k), len(k), int(recompute_angle), _p(d))
+        return k, d
+
+    def shi_tomasi(self, img, u, v):
+        img = np.ascontiguousarray(img, np.uint8)
+        self.L.yo_shi_tomasi.restype = C.c_float
+        self.L.yo_shi_tomasi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        return float(self.L.yo_shi_tomasi(self.h, _p(img), img.shape[1], img.shape[0], u, v))
+
     def ic_angle(self, img, x, y):
         img = np.ascontiguousarray(img, np.uint8)
         return float(self.L.yo_ic_angle(self.h, _p(img), img.shape[1], img.shape[0], x, y))

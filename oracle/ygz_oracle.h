@@ -73,6 +73,15 @@ public:
                                             int maxY, int N) const;
     float ICAngle(const Image &img, float ptx, float pty) const;  // :77-101
     void ComputeDescriptor(const KeyPoint &kp, const Image &blurred, uint8_t *desc) const;  // :105-149
+    // ShiTomasiScore :1152-1187 (8x8 box; all sums are exact integers in float)
+    float ShiTomasiScore(const Image &img, int u, int v) const;
+    // ComputeKeyPointsDSOSingleLevel :1275-1386.  mnGridSize persists across frames (-1 = not yet set).  Ties of the
+    // per-cell score sort (std::sort, unspecified order) are DEFINED as raster order.  exist_kps: angles are recomputed.
+    int mnGridSize = -1;
+    void ComputeKeyPointsDSOSingleLevel(std::vector<KeyPoint> &allKeypoints, std::vector<KeyPoint> &exist_kps);
+    // operator()(Frame*, vector<KeyPoint>&, OutputArray, DSO_KEYPOINT, leftEye = true) :1031-1127 on a frame whose pyramid is
+    // computed from `img`: keys = frame->mvKeys (in: the N existing keys, out: + the new ones), desc = N_total x 32.
+    void ExtractDSO(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc);
     // operator()(InputArray, InputArray, vector<KeyPoint>&, OutputArray)  :970-1028
     void Extract(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &kps,
                  std::vector<uint8_t> &desc);

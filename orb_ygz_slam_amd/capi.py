@@ -96,6 +96,8 @@ def load_library(build_if_missing=True):
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
     L.ygzf_align_fetch.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_size_t), vp]
     L.ygzf_fast10.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip, ip]
+    L.ygzf_describe_keys.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    L.ygzf_extract_dso.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, ip, ip]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
     L.ygzf_profile_enable.argtypes = [vp, C.c_int]
@@ -374,6 +376,27 @@ class Extractor:
         n, k = C.c_int(), C.c_int()
         self._ck(self.L.ygzf_fast10(self.h, _p(img), iw, ih, iw, x0, y0, w, h, barrier, _p(xy), _p(sc), _p(nm), cap, C.byref(n), C.byref(k)))
         return xy[:n.value].copy(), sc[:n.value].copy(), nm[:k.value].copy()
+
+    def extract_dso(self, img, existing=None, grid_size=-1, cap=None):
+        """operator()(Frame*, ..., DSO_KEYPOINT): (keys = existing (angles recomputed) + new level-0 keys, desc, new mnGridSize)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        existing = np.zeros(0, KP_DTYPE) if existing is None else np.ascontiguousarray(existing, KP_DTYPE)
+        cap = cap or (len(existing) + 3 * (w // 7) * (h // 7) + 16)
+        k = np.zeros(cap, KP_DTYPE)
+        k[:len(existing)] = existing
+        d = np.zeros((cap, 32), np.uint8)
+        g, n = C.c_int(grid_size), C.c_int()
+        self._ck(self.L.ygzf_extract_dso(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g), C.byref(n)))
+        return k[:n.value].copy(), d[:n.value].copy(), g.value
+
+    def describe_keys(self, keys, frame=0, recompute_angle=False):
+        """Descriptors (+ optionally IC_Angle) of existing keys on the pyramid of `frame` of the last batch -> (angles, desc)."""
+        k = np.ascontiguousarray(keys, KP_DTYPE)
+        ang = np.zeros(len(k), np.float32)
+        d = np.zeros((len(k), 32), np.uint8)
+        self._ck(self.L.ygzf_describe_keys(self.h, frame, _p(k), len(k), int(recompute_angle), _p(ang), _p(d)))
+        return ang, d
 
     def timer_start(self):
         self._ck(self.L.ygzf_timer_start(self.h))

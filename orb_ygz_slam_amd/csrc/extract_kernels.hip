@@ -930,14 +930,105 @@ struct DescLds {
 __constant__ int8_t c_pattern[1024];
 __constant__ int c_umax[16];
 
+// One wave: orientation + blurred patch + 256 rBRIEF bits of the keypoint at integer (kx,ky) of a gw x gh level image.
+__device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img, int pitch, int gw, int gh, int kx, int ky, DescLds &L,
+                                                int lane, float *angleOut, unsigned long long bits[4], bool presetAngle = false,
+                                                float preset = 0.f) {
+    // ---- stage the 43x43 window (rows ky-21..ky+21).  Interior keypoints: the 43 bytes of a row lie inside one 16-byte
+    // aligned 64-byte span -> 4 lanes x dwordx4 per row, 3 wave-level loads for the whole window, all in flight at once.
+    // Keypoints within 21 px of the image border need BORDER_REFLECT_101 (what the blur of the border-less level clone
+    // sees) and take the byte path.  Window column c of row r lives at raw[r*64 + ((rowOff0 + r*rowOffStep) & 15) + c].
+    const bool interior = kx >= 21 && kx + 21 < gw && ky >= 21 && ky + 22 < gh && ((pitch & 3) == 0);
+    int rowOff0 = 0, rowOffStep = 0;
+    if (interior) {
+        const unsigned long long a00 = (unsigned long long) img + (unsigned) (ky - 21) * (unsigned) pitch + (unsigned) (kx - 21);
+        rowOff0 = (int) (a00 & 15);
+        rowOffStep = pitch & 15;
+        for (int idx = lane; idx < kWin * 4; idx += 64) {
+            const int r = idx >> 2, q = idx & 3;
+            const unsigned long long a = a00 + (unsigned) r * (unsigned) pitch;
+            *(uint4 *) &L.raw[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
+        }
+    } else {
+        for (int idx = lane; idx < kWin * kWin; idx += 64) {
+            const int r = idx / kWin, c = idx - r * kWin;
+            const int yy = reflect101(ky - 21 + r, gh), xx = reflect101(kx - 21 + c, gw);
+            L.raw[r * kWinP + c] = img[(long long) yy * pitch + xx];
+        }
+    }
+#define RAWP(r) (&L.raw[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
+    wave_lds_sync();
+    // ---- intensity centroid on the 31x31 disc (centre = window (21,21)): two rows per step, no divisions
+    int m10 = 0, m01 = 0;
+    {
+        const int u = (lane & 31) - 15;
+        for (int it = 0; it < 16; it++) {
+            const int v = 2 * it + (lane >> 5) - 15;
+            if ((lane & 31) < 31 && v <= 15 && abs(u) <= c_umax[abs(v)]) {
+                const int I = RAWP(21 + v)[21 + u];
+                m10 += u * I;
+                m01 += v * I;
+            }
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = presetAngle ? preset : fast_atan2_deg((float) m01, (float) m10);
+    // ---- separable 7-tap blur {18,34,49,55,49,34,18}: each lane produces runs of 8 outputs from a sliding window
+    // horizontal: 43 rows x 5 segments (8+8+8+8+5 columns)
+    for (int t = lane; t < kWin * 5; t += 64) {
+        const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
+        const uint8_t *p = RAWP(r) + 8 * sg;
+        int q[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = p[k];           // columns 8*sg .. 8*sg+13 (<= 45 + slack: inside the LDS row)
+        unsigned o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
+        unsigned *dst = (unsigned *) &L.hb[r * kHbP + 8 * sg];
+        dst[0] = o[0] | (o[1] << 16); dst[1] = o[2] | (o[3] << 16);
+        if (sg < 4) { dst[2] = o[4] | (o[5] << 16); dst[3] = o[6] | (o[7] << 16); }
+        else { dst[2] = o[4]; }                              // columns 32..36: 5 outputs (column 37.. unused)
+    }
+    wave_lds_sync();
+    // vertical: 37 columns x 5 row segments
+    for (int t = lane; t < kBl * 5; t += 64) {
+        const int sg = (t * 1772) >> 16, c = t - 37 * sg;   // t / 37, t % 37 for t < 185
+        const unsigned short *p = &L.hb[(8 * sg) * kHbP + c];
+        const int nr = sg < 4 ? 8 : 5;
+        int q[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) q[k] = (8 * sg + k < kWin) ? p[k * kHbP] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int s2 = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
+            if (k < nr) L.bl[(8 * sg + k) * kBlP + c] = (uint8_t) min((s2 + 32768) >> 16, 255);
+        }
+    }
+    wave_lds_sync();
+    float a, b;
+    sincos_deg(angle, &a, &b);
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int p = it * 64 + lane;
+        const float x0 = (float) c_pattern[4 * p], y0 = (float) c_pattern[4 * p + 1];
+        const float x1 = (float) c_pattern[4 * p + 2], y1 = (float) c_pattern[4 * p + 3];
+        const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = L.bl[(18 + r0) * kBlP + 18 + q0], t1 = L.bl[(18 + r1) * kBlP + 18 + q1];
+        bits[it] = __ballot(t0 < t1);
+    }
+    *angleOut = angle;
+#undef RAWP
+}
+
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                             const unsigned *__restrict__ lvlKpXY,
                                                             const unsigned char *__restrict__ lvlKpScore,
                                                             const int *__restrict__ lvlKpCnt,
                                                             const unsigned short *__restrict__ procOrder, int kpStride,
                                                             ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                            int *__restrict__ outCnt, int outStride, int blocksPerXcd,
-                                                            int dbgStage) {
+                                                            int *__restrict__ outCnt, int outStride, int blocksPerXcd) {
     __shared__ DescLds lds[kDescWaves];
     const int lane = lane_id(), wave = wave_id();
     const int f = blockIdx.y;
@@ -967,97 +1058,9 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const
     const int score = lvlKpScore[(long long) f * kpStride + g.kpBase + li];
     int pitch;
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
-    DescLds &L = lds[wave];
-    if (dbgStage == 6) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = (uint8_t) kx; return; }
-    // ---- stage the 43x43 window (rows ky-21..ky+21).  Interior keypoints: the 43 bytes of a row lie inside one 16-byte
-    // aligned 64-byte span -> 4 lanes x dwordx4 per row, 3 wave-level loads for the whole window, all in flight at once.
-    // Keypoints within 21 px of the image border need BORDER_REFLECT_101 (what the blur of the border-less level clone
-    // sees) and take the byte path.  Window column c of row r lives at raw[r*64 + ((rowOff0 + r*rowOffStep) & 15) + c].
-    const bool interior = kx >= 21 && kx + 21 < g.w && ky >= 21 && ky + 22 < g.h && ((pitch & 3) == 0);
-    int rowOff0 = 0, rowOffStep = 0;
-    if (interior) {
-        const unsigned long long a00 = (unsigned long long) img + (unsigned) (ky - 21) * (unsigned) pitch + (unsigned) (kx - 21);
-        rowOff0 = (int) (a00 & 15);
-        rowOffStep = pitch & 15;
-        for (int idx = lane; idx < kWin * 4; idx += 64) {
-            const int r = idx >> 2, q = idx & 3;
-            const unsigned long long a = a00 + (unsigned) r * (unsigned) pitch;
-            *(uint4 *) &L.raw[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
-        }
-    } else {
-        for (int idx = lane; idx < kWin * kWin; idx += 64) {
-            const int r = idx / kWin, c = idx - r * kWin;
-            const int yy = reflect101(ky - 21 + r, g.h), xx = reflect101(kx - 21 + c, g.w);
-            L.raw[r * kWinP + c] = img[(long long) yy * pitch + xx];
-        }
-    }
-#define RAWP(r) (&L.raw[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
-    wave_lds_sync();
-    if (dbgStage == 1) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = L.raw[100]; return; }
-    // ---- intensity centroid on the 31x31 disc (centre = window (21,21)): two rows per step, no divisions
-    int m10 = 0, m01 = 0;
-    {
-        const int u = (lane & 31) - 15;
-        for (int it = 0; it < 16; it++) {
-            const int v = 2 * it + (lane >> 5) - 15;
-            if ((lane & 31) < 31 && v <= 15 && abs(u) <= c_umax[abs(v)]) {
-                const int I = RAWP(21 + v)[21 + u];
-                m10 += u * I;
-                m01 += v * I;
-            }
-        }
-    }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
-    const float angle = fast_atan2_deg((float) m01, (float) m10);
-    if (dbgStage == 2) { if (lane == 0) outKp[(long long) f * outStride + slot].angle = angle; return; }
-    // ---- separable 7-tap blur {18,34,49,55,49,34,18}: each lane produces runs of 8 outputs from a sliding window
-    // horizontal: 43 rows x 5 segments (8+8+8+8+5 columns)
-    for (int t = lane; t < kWin * 5; t += 64) {
-        const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
-        const uint8_t *p = RAWP(r) + 8 * sg;
-        int q[14];
-#pragma unroll
-        for (int k = 0; k < 14; k++) q[k] = p[k];           // columns 8*sg .. 8*sg+13 (<= 45 + slack: inside the LDS row)
-        unsigned o[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) o[k] = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
-        unsigned *dst = (unsigned *) &L.hb[r * kHbP + 8 * sg];
-        dst[0] = o[0] | (o[1] << 16); dst[1] = o[2] | (o[3] << 16);
-        if (sg < 4) { dst[2] = o[4] | (o[5] << 16); dst[3] = o[6] | (o[7] << 16); }
-        else { dst[2] = o[4]; }                              // columns 32..36: 5 outputs (column 37.. unused)
-    }
-    wave_lds_sync();
-    if (dbgStage == 5) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = (uint8_t) L.hb[100]; return; }
-    // vertical: 37 columns x 5 row segments
-    for (int t = lane; t < kBl * 5; t += 64) {
-        const int sg = (t * 1772) >> 16, c = t - 37 * sg;   // t / 37, t % 37 for t < 185
-        const unsigned short *p = &L.hb[(8 * sg) * kHbP + c];
-        const int nr = sg < 4 ? 8 : 5;
-        int q[14];
-#pragma unroll
-        for (int k = 0; k < 14; k++) q[k] = (8 * sg + k < kWin) ? p[k * kHbP] : 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int s2 = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
-            if (k < nr) L.bl[(8 * sg + k) * kBlP + c] = (uint8_t) min((s2 + 32768) >> 16, 255);
-        }
-    }
-    wave_lds_sync();
-    if (dbgStage == 3) { if (lane == 0) outDesc[((long long) f * outStride + slot) * 32] = L.bl[100]; return; }
-    float a, b;
-    sincos_deg(angle, &a, &b);
+    float angle;
     unsigned long long bits[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int p = it * 64 + lane;
-        const float x0 = (float) c_pattern[4 * p], y0 = (float) c_pattern[4 * p + 1];
-        const float x1 = (float) c_pattern[4 * p + 2], y1 = (float) c_pattern[4 * p + 3];
-        const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
-        const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = L.bl[(18 + r0) * kBlP + 18 + q0], t1 = L.bl[(18 + r1) * kBlP + 18 + q1];
-        bits[it] = __ballot(t0 < t1);
-    }
+    describe_window(img, pitch, g.w, g.h, kx, ky, lds[wave], lane, &angle, bits);
     ygzf_kp *ok = outKp + (long long) f * outStride + slot;
     uint8_t *od = outDesc + ((long long) f * outStride + slot) * 32;
     if (lane < 4) ((unsigned long long *) od)[lane] = bits[lane];
@@ -1072,7 +1075,28 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const
         kp.class_id = -1;
         *ok = kp;
     }
-#undef RAWP
+}
+
+// Orientation + descriptor of an explicit keypoint list (the Frame* overload, src/ORBextractor.cc:1031-1127: keys that already
+// exist in the frame get IC_Angle (:1380-1383) and a descriptor at pt*invScale[octave] (:1104-1116), new level-0 keys follow).
+// list[i] = {x, y, level | flag, angle bits} in LEVEL coordinates (already rounded as cvRound does); flag 0x100: keep the given angle
+// (the ORBSLAM_KEYPOINT / FAST_KEYPOINT branches leave the angle of existing keys alone, :1096-1099).
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe_list(FrameSet fs, const LevelGeom *__restrict__ geom, const int4 *__restrict__ list,
+                                                                 int n, int frame, float *__restrict__ outAngle, uint8_t *__restrict__ outDesc) {
+    __shared__ DescLds lds[kDescWaves];
+    const int lane = lane_id(), wave = wave_id();
+    const int i = blockIdx.x * kDescWaves + wave;
+    if (i >= n) return;
+    const int4 e = list[i];
+    const int level = e.z & 0xFF;
+    const LevelGeom g = geom[level];
+    int pitch;
+    const uint8_t *img = level_ptr(fs, g, level, frame, &pitch);
+    float angle;
+    unsigned long long bits[4];
+    describe_window(img, pitch, g.w, g.h, e.x, e.y, lds[wave], lane, &angle, bits, (e.z & 0x100) != 0, __int_as_float(e.w));
+    if (lane < 4) ((unsigned long long *) (outDesc + (long long) i * 32))[lane] = bits[lane];
+    if (lane == 0) outAngle[i] = angle;
 }
 
 // batched DescriptorDistance: popcount over 4 x u64
@@ -1145,7 +1169,14 @@ void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom,
     const int blocksPerXcd = (nblk + 7) / 8;
     dim3 grid(8 * blocksPerXcd, nFrames);
     hipLaunchKernelGGL(k_describe, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpXY, lvlKpScore, lvlKpCnt,
-                       procOrder, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd, getenv("YGZF_DESC_STAGE") ? atoi(getenv("YGZF_DESC_STAGE")) : 0);
+                       procOrder, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd);
+}
+
+void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,
+                          float *outAngle, uint8_t *outDesc) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_describe_list, dim3((n + kDescWaves - 1) / kDescWaves), dim3(64 * kDescWaves), 0, st, fs, dGeom, (const int4 *) list, n,
+                       frame, outAngle, outDesc);
 }
 
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out) {

@@ -9,34 +9,10 @@
 // The generated decision trees of libfast are replaced by their definition: a pixel is a corner at barrier b iff 10
 // contiguous ring pixels are all > p+b or all < p-b; its score is (max over the 16 arcs of 10 of the min margin) - 1.
 // Pinned against the reference's own library (oracle/_ref) incl. the 167-corner known answer on its test image.
+#include "fast10_device.h"
 #include "kernels.h"
 
 namespace ygzf {
-
-__device__ __forceinline__ int arc10_margin(const uint8_t *p, int pitch) {
-    const int v = p[0];
-    int d[16];
-    d[0] = p[3 * pitch] - v;      d[1] = p[3 * pitch + 1] - v;  d[2] = p[2 * pitch + 2] - v;  d[3] = p[pitch + 3] - v;
-    d[4] = p[3] - v;              d[5] = p[-pitch + 3] - v;     d[6] = p[-2 * pitch + 2] - v; d[7] = p[-3 * pitch + 1] - v;
-    d[8] = p[-3 * pitch] - v;     d[9] = p[-3 * pitch - 1] - v; d[10] = p[-2 * pitch - 2] - v; d[11] = p[-pitch - 3] - v;
-    d[12] = p[-3] - v;            d[13] = p[pitch - 3] - v;     d[14] = p[2 * pitch - 2] - v; d[15] = p[3 * pitch - 1] - v;
-    int best = -256;
-#pragma unroll
-    for (int pol = 0; pol < 2; pol++) {
-        int m2[16], m4[16], m8[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
-#pragma unroll
-        for (int k = 0; k < 16; k++) best = max(best, min(m8[k], m2[(k + 8) & 15]));   // 10 contiguous: 8 + 2
-#pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = -d[k];
-    }
-    return best;   // corner at barrier b  <=>  best > b
-}
 
 // score map over the window: -1 = not a corner (or outside the detection domain), else the libfast score
 __global__ void k_f10_score(const uint8_t *__restrict__ img, int pitch, int x0, int y0, int w, int h, int dx0, int dx1, int dy0, int dy1,

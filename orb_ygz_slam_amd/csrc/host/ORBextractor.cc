@@ -78,24 +78,68 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     for (int i = 0; i < n; i++) std::memcpy(d.ptr<uint8_t>(i), &desc[(size_t) i * 32], 32);
 }
 
-// src/ORBextractor.cc:1031-1127.  ORBSLAM_KEYPOINT on a frame without pre-existing keys (the path taken for initial
-// frames, relocalisation, re-extraction after a direct-tracking failure and every right-eye image) runs on the device.
-// FAST_KEYPOINT / DSO_KEYPOINT (libfast FAST-10 grid paths) and descriptors of pre-existing direct-tracked keys are the
-// next rows of the scope table; they are reported, not silently emulated on the CPU.
+// src/ORBextractor.cc:1031-1127, the overload Frame::ExtractORB calls (src/Frame.cc:332-348):
+//   ORBSLAM_KEYPOINT  octree keypoints on all levels; keys the frame already holds (direct-tracked) keep their angle and get
+//                     descriptors first (:1093-1106)
+//   DSO_KEYPOINT      FAST-10 grid keypoints on level 0 beside the frame's existing keys (ComputeKeyPointsDSOSingleLevel)
+//   FAST_KEYPOINT     never requested by the reference and marked "has a bug ... don't call" by its author (:1191): reported, not run.
+// There is no CPU fallback: on a device error the outputs stay untouched and the error is printed.
 void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors, KeyPointMethod method,
                               bool leftEye) {
-    if (method != ORBSLAM_KEYPOINT || (leftEye && frame->N > 0)) {
-        fprintf(stderr, "ygz::ORBextractor: KeyPointMethod %d with %d pre-existing keys is not implemented on the device yet\n", (int) method,
-                frame->N);
+    if (method == FAST_KEYPOINT) {
+        fprintf(stderr, "ygz::ORBextractor: FAST_KEYPOINT (ComputeKeyPointsFast) is not provided -- the reference never calls it\n");
         return;
     }
+    static_assert(sizeof(cv::KeyPoint) == sizeof(ygzf_kp), "cv::KeyPoint layout");
     const cv::Mat &img = leftEye ? (frame->mvImagePyramid.empty() ? frame->mImGray : frame->mvImagePyramid[0]) : frame->mImRight;
     if (!leftEye) ComputePyramid(img);          // right eye: the extractor's own pyramid is read by ComputeStereoMatches
     else mvImagePyramid = frame->mvImagePyramid;
-    cv::Mat mask;
-    std::vector<cv::KeyPoint> kps;
-    (*this)(cv::_InputArray(img), cv::_InputArray(mask), kps, _descriptors);
-    _keypoints.insert(_keypoints.end(), kps.begin(), kps.end());
+    const int N = leftEye ? frame->N : 0;       // existing keys of the frame (:1090-1092)
+    if (img.empty()) return;
+    ygzf_ctx *c = ensureContext(img.cols, img.rows);
+    if (!c) return;
+    std::vector<cv::KeyPoint> fresh;            // the new keypoints
+    std::vector<uint8_t> descExisting((size_t) N * 32), descNew;
+    if (method == DSO_KEYPOINT) {
+        const int cap = N + 3 * (img.cols / 7) * (img.rows / 7) + 16;
+        std::vector<cv::KeyPoint> all(cap);
+        std::vector<uint8_t> d((size_t) cap * 32);
+        for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];
+        int total = 0;
+        if (ygzf_extract_dso(c, img.ptr<uint8_t>(0), img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &mnGridSize, &total) !=
+            YGZF_OK) {
+            fprintf(stderr, "ygz::ORBextractor (DSO_KEYPOINT): %s\n", ygzf_last_error(c));
+            return;
+        }
+        for (int i = 0; i < N; i++) frame->mvKeys[i].angle = all[i].angle;   // ComputeKeyPointsDSOSingleLevel re-orients them (:1380-1383)
+        fresh.assign(all.begin() + N, all.begin() + total);
+        std::memcpy(descExisting.data(), d.data(), (size_t) N * 32);
+        descNew.assign(d.begin() + (size_t) N * 32, d.begin() + (size_t) total * 32);
+    } else {
+        const int cap = ygzf_max_keypoints(c, img.cols, img.rows);
+        fresh.resize(cap > 0 ? cap : 0);
+        descNew.resize((size_t) (cap > 0 ? cap : 0) * 32);
+        int n = 0;
+        if (ygzf_extract(c, img.ptr<uint8_t>(0), img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n) != YGZF_OK) {
+            fprintf(stderr, "ygz::ORBextractor (ORBSLAM_KEYPOINT): %s\n", ygzf_last_error(c));
+            return;
+        }
+        fresh.resize(n);
+        if (N > 0 && ygzf_describe_keys(c, 0, (const ygzf_kp *) frame->mvKeys.data(), N, 0, nullptr, descExisting.data()) != YGZF_OK) {
+            fprintf(stderr, "ygz::ORBextractor (existing keys): %s\n", ygzf_last_error(c));
+            return;
+        }
+    }
+    const int nkeypoints = (int) fresh.size() + (int) _keypoints.size();   // :1065-1068
+    if (nkeypoints == 0) {
+        _descriptors.release();
+        return;
+    }
+    _descriptors.create(nkeypoints, 32, CV_8U);
+    cv::Mat d = _descriptors.getMat();
+    for (int i = 0; i < N && i < nkeypoints; i++) std::memcpy(d.ptr<uint8_t>(i), &descExisting[(size_t) i * 32], 32);
+    for (int i = 0; i < (int) fresh.size() && N + i < nkeypoints; i++) std::memcpy(d.ptr<uint8_t>(N + i), &descNew[(size_t) i * 32], 32);   // offset = frame->N
+    _keypoints.insert(_keypoints.end(), fresh.begin(), fresh.end());
 }
 
 }  // namespace ygz

@@ -49,6 +49,7 @@ protected:
     int iniThFAST, minThFAST;
     std::vector<int> mnFeaturesPerLevel;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    int mnGridSize = -1;   // dynamic grid size of the DSO_KEYPOINT path (include/ORBextractor.h:171), persists across frames
 
 private:
     ygzf_ctx *ensureContext(int w, int h);

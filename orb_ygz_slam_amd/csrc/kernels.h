@@ -78,6 +78,15 @@ void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ld
 void launch_fast10(hipStream_t st, const uint8_t *img, int pitch, int x0, int y0, int w, int h, int dx0, int dx1, int dy0, int dy1, int barrier,
                    short *S, int *rowCnt, int *rowKept, int *totals, short *xy, int *scores, int *nonmax, int cap);
 
+// ---- FAST-10 grid detector of the DSO_KEYPOINT path (dso_kernels.hip) + list describe (extract_kernels.hip) -----------------
+constexpr int kDsoMaxGrid = 64;   // largest supported mnGridSize (cell side in px)
+void launch_dso_occ(hipStream_t st, const unsigned *xy, int n, int w, int h, unsigned *occ);
+void launch_dso_cells(hipStream_t st, const uint8_t *img, int pitch, int w, int h, int grid, int nCols, int nRows, const unsigned *occ, int *cellCnt,
+                      unsigned *cellXY, int *total);
+void launch_dso_compact(hipStream_t st, const int *cellCnt, const unsigned *cellXY, int nInner, int nExisting, void *list, unsigned *newXY);
+void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,
+                          float *outAngle, uint8_t *outDesc);
+
 // ---- sparse image alignment (align_kernels.hip) ----------------------------------------------------------------------
 struct SiaLevel {
     const uint8_t *img;

@@ -63,9 +63,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -98,7 +98,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5];
+        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8];
     bool alignCarry = false;      // keep the last frame's pyramid across batches (enabled by the first ygzf_align_batch_prev)
     bool carryPyrValid = false;
     int lastAlignPairs = 0;
@@ -541,6 +541,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &b : c->dF10)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dAl)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dDso)
         if (b.p) (void) hipFree(b.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
@@ -1179,6 +1181,164 @@ int ygzf_fast10(ygzf_ctx *c, const uint8_t *img, int img_w, int img_h, int strid
     if (tot[0] && scores) HIPCHECK(c, hipMemcpyAsync(scores, B[4].p, (size_t) tot[0] * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (tot[1] && nonmax_idx) HIPCHECK(c, hipMemcpyAsync(nonmax_idx, B[5].p, (size_t) tot[1] * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+// Level position of an existing key as the reference rounds it: tmp.pt *= mvInvScaleFactor[octave] (float), then cvRound
+static int key_level_position(ygzf_ctx *c, const ygzf_kp &k, int i, int *px, int *py) {
+    const int L = c->tab.cfg.nlevels;
+    if (k.octave < 0 || k.octave >= L) return fail(c, YGZF_ERR_INVALID, "key %d: octave %d out of range", i, k.octave);
+    const float inv = c->tab.invScale[k.octave];
+    const float lx = k.x * inv, ly = k.y * inv;
+    *px = cv_round_host((double) lx);
+    *py = cv_round_host((double) ly);
+    const LevelGeom &g = c->geo.lv[k.octave];
+    // IC_Angle and the rotated pattern read the 31x31 patch around the rounded position: outside the level that is an out-of-bounds
+    // read in the reference (its levels have no border here)
+    if (*px < kHalfPatch || *py < kHalfPatch || *px >= g.w - kHalfPatch || *py >= g.h - kHalfPatch)
+        return fail(c, YGZF_ERR_INVALID, "key %d is closer than %d px to the border of level %d", i, kHalfPatch, k.octave);
+    return YGZF_OK;
+}
+
+int ygzf_describe_keys(ygzf_ctx *c, int frame, const ygzf_kp *keys, int n, int recompute_angle, float *angles_out, uint8_t *desc) {
+    if (!c || (n > 0 && (!keys || !desc))) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (frame < 0 || frame >= c->lastFrames) return fail(c, YGZF_ERR_INVALID, "frame %d out of range", frame);
+    if (n <= 0) return YGZF_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    std::vector<int> list4((size_t) 4 * n);
+    for (int i = 0; i < n; i++) {
+        int px, py;
+        int rc = key_level_position(c, keys[i], i, &px, &py);
+        if (rc) return rc;
+        list4[4 * i] = px;
+        list4[4 * i + 1] = py;
+        list4[4 * i + 2] = keys[i].octave | (recompute_angle ? 0 : 0x100);
+        memcpy(&list4[4 * i + 3], &keys[i].angle, 4);
+    }
+    int rc;
+    if ((rc = ensure(c, c->dDso[5], 16 * (size_t) n)) || (rc = ensure(c, c->dDso[7], 4 * (size_t) n)) || (rc = ensure(c, c->dTmpC, 32 * (size_t) n))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->dDso[5].p, list4.data(), 16 * (size_t) n, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KK_DESCRIBE);
+        launch_describe_list(c->stream, c->lastFs, (const LevelGeom *) c->dGeom.p, c->dDso[5].p, n, frame, (float *) c->dDso[7].p, (uint8_t *) c->dTmpC.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    if (angles_out) HIPCHECK(c, hipMemcpyAsync(angles_out, c->dDso[7].p, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(desc, c->dTmpC.p, 32 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, ygzf_kp *keys, int n_existing, int cap, uint8_t *desc,
+                     int *grid_size, int *n_total) {
+    if (!c || !img || !grid_size || !n_total || (n_existing > 0 && !keys)) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n_existing < 0 || n_existing > cap) return fail(c, YGZF_ERR_INVALID, "n_existing %d outside 0..cap", n_existing);
+    if (w > 65535 || h > 65535) return fail(c, YGZF_ERR_UNSUPPORTED, "image larger than 65535 px");
+    *n_total = n_existing;
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, 1);
+    if (rc) return rc;
+    FrameSet fs;
+    if ((rc = upload_frames(c, img, 1, w, h, stride, 0, &fs))) return rc;
+    const Geometry &G = c->geo;
+    const int L = c->tab.cfg.nlevels, n = c->tab.cfg.nfeatures;
+    const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
+    for (int l = 1; l < L; l++) {   // Frame ctor: ComputeImagePyramid (src/Frame.cc:807-813)
+        ProfScope ps(c, KK_PYR);
+        launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, 1, (const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p,
+                          (const short *) c->dYbeta.p);
+    }
+    c->lastFrames = 0;
+    c->carryValid = false;
+    // existing keys: occupancy at cvRound(pt) on level 0 (:1286-1291), describe position cvRound(pt * invScale[octave]) (:1104-1112, :1380-1383)
+    std::vector<unsigned> occXY(n_existing);
+    std::vector<int> list4((size_t) 4 * n_existing);
+    for (int i = 0; i < n_existing; i++) {
+        const ygzf_kp &k = keys[i];
+        int px, py;
+        if ((rc = key_level_position(c, k, i, &px, &py))) return rc;
+        const int ox = cv_round_host((double) k.x), oy = cv_round_host((double) k.y);
+        if (ox < 0 || oy < 0 || ox >= w || oy >= h) return fail(c, YGZF_ERR_INVALID, "existing key %d lies outside the image", i);
+        occXY[i] = (unsigned) ox | ((unsigned) oy << 16);
+        list4[4 * i] = px; list4[4 * i + 1] = py; list4[4 * i + 2] = k.octave; list4[4 * i + 3] = 0;
+    }
+    int grid = *grid_size;
+    if (grid < 0) grid = (int) std::sqrt(1.0 * h * w / (n > 0 ? n : 1));
+    const int minGrid = 7;
+    const int maxCells = (w / minGrid) * (h / minGrid) + 1;
+    const size_t occWords = ((size_t) w * h + 31) / 32;
+    ygzf_ctx::Buf &dOcc = c->dDso[0], &dOccXY = c->dDso[1], &dCellCnt = c->dDso[2], &dCellXY = c->dDso[3], &dTotal = c->dDso[4], &dList = c->dDso[5],
+                  &dNewXY = c->dDso[6], &dAng = c->dDso[7];
+    const size_t maxEntries = (size_t) n_existing + 3 * (size_t) maxCells;
+    if ((rc = ensure(c, dOcc, occWords * 4)) || (rc = ensure(c, dOccXY, 4 * (size_t) (n_existing + 1))) || (rc = ensure(c, dCellCnt, 4 * (size_t) maxCells)) ||
+        (rc = ensure(c, dCellXY, 12 * (size_t) maxCells)) || (rc = ensure(c, dTotal, 64)) || (rc = ensure(c, dList, 16 * maxEntries)) ||
+        (rc = ensure(c, dNewXY, 4 * 3 * (size_t) maxCells)) || (rc = ensure(c, dAng, 4 * maxEntries)) || (rc = ensure(c, c->dTmpC, 32 * maxEntries)))
+        return rc;
+    HIPCHECK(c, hipMemsetAsync(dOcc.p, 0, occWords * 4, c->stream));
+    if (n_existing > 0) {
+        HIPCHECK(c, hipMemcpyAsync(dOccXY.p, occXY.data(), 4 * (size_t) n_existing, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(dList.p, list4.data(), 16 * (size_t) n_existing, hipMemcpyHostToDevice, c->stream));
+        launch_dso_occ(c->stream, (const unsigned *) dOccXY.p, n_existing, w, h, (unsigned *) dOcc.p);
+    }
+    // the grid-size retry loop of :1301-1377; mnGridSize persists across frames through *grid_size
+    int cnt = 0, nInner = 0;
+    while (cnt < n) {
+        if (cnt > 0) {
+            grid -= 5;
+            if (grid < minGrid) {
+                grid = minGrid;
+                break;   // the keypoints of the previous pass stand
+            }
+        }
+        if (grid > kDsoMaxGrid) return fail(c, YGZF_ERR_UNSUPPORTED, "mnGridSize %d > %d (nfeatures too small for this image size)", grid, kDsoMaxGrid);
+        if (grid < 1) return fail(c, YGZF_ERR_INVALID, "grid size %d", grid);
+        const int nRows = h / grid, nCols = w / grid;
+        nInner = (nRows > 2 && nCols > 2) ? (nRows - 2) * (nCols - 2) : 0;
+        if (nInner > maxCells) return fail(c, YGZF_ERR_INVALID, "grid size %d below the minimum %d", grid, minGrid);
+        HIPCHECK(c, hipMemsetAsync(dTotal.p, 0, 4, c->stream));
+        {
+            ProfScope ps(c, KK_DSO);
+            launch_dso_cells(c->stream, fs.img0, fs.img0_pitch, w, h, grid, nCols, nRows, (const unsigned *) dOcc.p, (int *) dCellCnt.p, (unsigned *) dCellXY.p,
+                             (int *) dTotal.p);
+        }
+        cnt = 0;
+        if (nInner > 0) {
+            HIPCHECK(c, hipMemcpyAsync(&cnt, dTotal.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+        }
+        if (cnt == 0) break;   // the reference loops forever on a frame without a single corner; defined: no new keypoints
+    }
+    if (cnt > n) grid += 5;
+    *grid_size = grid;
+    const int total = n_existing + cnt;
+    *n_total = total;
+    if (total > cap) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d keypoints", cap, total);
+    if (total == 0) return YGZF_OK;
+    if (!desc || !keys) return fail(c, YGZF_ERR_INVALID, "null output");
+    if (cnt > 0) launch_dso_compact(c->stream, (const int *) dCellCnt.p, (const unsigned *) dCellXY.p, nInner, n_existing, dList.p, (unsigned *) dNewXY.p);
+    {
+        ProfScope ps(c, KK_DESCRIBE);
+        launch_describe_list(c->stream, fs, dGeom, dList.p, total, 0, (float *) dAng.p, (uint8_t *) c->dTmpC.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    std::vector<float> ang(total);
+    std::vector<unsigned> nxy(cnt);
+    HIPCHECK(c, hipMemcpyAsync(ang.data(), dAng.p, 4 * (size_t) total, hipMemcpyDeviceToHost, c->stream));
+    if (cnt > 0) HIPCHECK(c, hipMemcpyAsync(nxy.data(), dNewXY.p, 4 * (size_t) cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(desc, c->dTmpC.p, 32 * (size_t) total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n_existing; i++) keys[i].angle = ang[i];
+    for (int i = 0; i < cnt; i++) {   // :1356-1366
+        ygzf_kp &k = keys[n_existing + i];
+        k.x = (float) (nxy[i] & 0xFFFFu);
+        k.y = (float) (nxy[i] >> 16);
+        k.size = 7.f;
+        k.angle = ang[n_existing + i];
+        k.response = 0.f;
+        k.octave = 0;
+        k.class_id = -1;
+    }
     return YGZF_OK;
 }
 

@@ -106,6 +106,33 @@ int main(int argc, char **argv) {
         if (A2.mvpMapPoints[i]) assigned2[i] = (int) (A2.mvpMapPoints[i] - mps.data());
     dump(dir + "/match2.bin", assigned2.data(), assigned2.size() * sizeof(int));
     dump(dir + "/nmatch2.bin", &nm2, sizeof nm2);
+    // Frame::ExtractORB on a direct-tracked frame (src/Frame.cc:335-337): N existing keys, DSO_KEYPOINT adds FAST-10 grid keys
+    {
+        Frame C = B;
+        C.mvKeys.assign(B.mvKeys.begin(), B.mvKeys.begin() + 150);
+        for (auto &k : C.mvKeys) k.angle = 0.f;                      // stale angles: the DSO path recomputes them
+        C.N = 150;
+        C.mDescriptors = cv::Mat();
+        ex(&C, C.mvKeys, cv::_OutputArray(C.mDescriptors), ORBextractor::DSO_KEYPOINT, true);
+        dump(dir + "/c_kps.bin", C.mvKeys.data(), C.mvKeys.size() * sizeof(cv::KeyPoint));
+        dump(dir + "/c_desc.bin", C.mDescriptors.ptr(0), C.mvKeys.size() * 32);
+        // a second direct-tracked frame: the grid size persists inside the extractor
+        Frame C2 = A;
+        C2.mvKeys.assign(A.mvKeys.begin(), A.mvKeys.begin() + 80);
+        C2.N = 80;
+        C2.mDescriptors = cv::Mat();
+        ex(&C2, C2.mvKeys, cv::_OutputArray(C2.mDescriptors), ORBextractor::DSO_KEYPOINT, true);
+        dump(dir + "/c2_kps.bin", C2.mvKeys.data(), C2.mvKeys.size() * sizeof(cv::KeyPoint));
+        dump(dir + "/c2_desc.bin", C2.mDescriptors.ptr(0), C2.mvKeys.size() * 32);
+        // ORBSLAM_KEYPOINT on a frame that already holds keys: their angle is kept, descriptors first, new keys appended
+        Frame D = B;
+        D.mvKeys.assign(B.mvKeys.begin() + 10, B.mvKeys.begin() + 70);
+        D.N = 60;
+        D.mDescriptors = cv::Mat();
+        ex(&D, D.mvKeys, cv::_OutputArray(D.mDescriptors), ORBextractor::ORBSLAM_KEYPOINT, true);
+        dump(dir + "/d_kps.bin", D.mvKeys.data(), D.mvKeys.size() * sizeof(cv::KeyPoint));
+        dump(dir + "/d_desc.bin", D.mDescriptors.ptr(0), D.mvKeys.size() * 32);
+    }
     cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
     printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));
     return 0;

@@ -88,3 +88,20 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     assigned2 = np.fromfile(tmp_path / "match2.bin", np.int32)
     assert nm2 == e_n2 and nm2 > 100
     assert (assigned2 == np.where(e_m2 >= 0, e_m2, -1)).all()
+    # Frame overload with existing keys: DSO_KEYPOINT twice (grid size persists in the extractor), then ORBSLAM_KEYPOINT
+    oex2 = oracle.Extractor(600, 1.2, 8, 20, 7)
+    stale = kb[:150].copy()
+    stale["angle"] = 0
+    ko, do, g = oex2.extract_dso(imgB, existing=stale)
+    kc = np.fromfile(tmp_path / "c_kps.bin", KP_DTYPE)
+    dc = np.fromfile(tmp_path / "c_desc.bin", np.uint8).reshape(-1, 32)
+    assert len(kc) == len(ko) > 150 and (kc == ko).all() and (dc == do).all()
+    ko2, do2, _ = oex2.extract_dso(imgA, existing=ka[:80], grid_size=g)
+    kc2 = np.fromfile(tmp_path / "c2_kps.bin", KP_DTYPE)
+    dc2 = np.fromfile(tmp_path / "c2_desc.bin", np.uint8).reshape(-1, 32)
+    assert len(kc2) == len(ko2) > 80 and (kc2 == ko2).all() and (dc2 == do2).all()
+    kd = np.fromfile(tmp_path / "d_kps.bin", KP_DTYPE)
+    dd = np.fromfile(tmp_path / "d_desc.bin", np.uint8).reshape(-1, 32)
+    _, dex = oex2.describe_keys(imgB, kb[10:70])
+    assert len(kd) == 60 + len(kb) and (kd[:60] == kb[10:70]).all() and (kd[60:] == kb).all()
+    assert (dd[:60] == dex).all() and (dd[:60] == db[10:70]).all() and (dd[60:] == db).all()
