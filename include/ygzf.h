@@ -134,6 +134,18 @@ int ygzf_search_by_projection_last(ygzf_ctx *ctx, const ygzf_frame_view *cur, co
                                    const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw, const float *tlw, float th,
                                    int b_mono, int check_level, int check_orientation, uint8_t *cur_owner, int *cur_match, int *nmatches);
 
+/* ---- ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
+ *      src/ORBmatcher.cc:1352-1469 (Tracking::Relocalization: th 10 / ORBdist 100, then th 3 / ORBdist 64) -----------------------
+ * The O(N) scalar prologue stays on the host (:1371-1400: projection with CurrentFrame.mTcw, image-bounds and distance gates,
+ * MapPoint::PredictScale with its logf) -- the class shell does it with the reference's own expressions.  Per KeyFrame MapPoint i:
+ * valid[i] = passed every gate, proj_x/proj_y = (u, v), pred_level = nPredictedLevel, kf_angle = pKF->mvKeys[i].angle,
+ * mp_desc = GetDescriptor().  The device does the window search (radius th*scale[level], levels level-1..level+1), the in-order
+ * "slot already taken" resolution (:1419), the accept rule bestDist <= ORBdist and the rotation histogram (:1433-1464).
+ * owner (in/out, cur->n bytes): nonzero <=> CurrentFrame.mvpMapPoints[i] != NULL (any MapPoint blocks); match / nmatches as above. */
+int ygzf_search_by_projection_kf(ygzf_ctx *ctx, const ygzf_frame_view *cur, const ygzf_camera *cam, int n_mp, const uint8_t *valid,
+                                 const float *proj_x, const float *proj_y, const int *pred_level, const float *kf_angle, const uint8_t *mp_desc,
+                                 float th, int orb_dist, int check_orientation, uint8_t *owner, int *match, int *nmatches);
+
 /* ---- ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, bool checkLevel)
  *      src/ORBmatcher.cc:43-126 (Tracking::SearchLocalPoints, nnratio 0.8) ---------------------------------------------------
  * Per MapPoint i (fields set by Frame::isInFrustum, src/Frame.cc:413-419): track_in_view = mbTrackInView, is_bad = isBad()

@@ -257,6 +257,30 @@ int yo_search_by_projection_mappoints(const yo_frame *F, int M, const uint8_t *t
     return search_by_projection_mappoints(v, g, in, th, checkLevel != 0, nnratio, owner, match);
 }
 
+int yo_search_by_projection_kf(const yo_frame *cur, int M, const uint8_t *usable, const float *world, const float *maxDistInv,
+                               const float *minDistInv, const float *mfMaxDistance, const float *kf_angle, const uint8_t *mp_desc,
+                               const float *Rcw, const float *tcw, float logScaleFactor, int nScaleLevels, float th, int ORBdist,
+                               int checkOri, uint8_t *cur_owner, int *cur_match, uint8_t *out_valid, float *out_u, float *out_v,
+                               int *out_level) {
+    FrameView v = to_view(cur);
+    Grid g;
+    g.Assign(v);
+    ProjKFInput in;
+    in.M = M;
+    in.usable = usable;
+    in.world = world;
+    in.maxDistInv = maxDistInv;
+    in.minDistInv = minDistInv;
+    in.mfMaxDistance = mfMaxDistance;
+    in.kf_angle = kf_angle;
+    in.mp_desc = mp_desc;
+    std::memcpy(in.Rcw, Rcw, 36);
+    std::memcpy(in.tcw, tcw, 12);
+    in.logScaleFactor = logScaleFactor;
+    in.nScaleLevels = nScaleLevels;
+    return search_by_projection_kf(v, g, in, th, ORBdist, checkOri != 0, cur_owner, cur_match, out_valid, out_u, out_v, out_level);
+}
+
 int yo_search_for_initialization(const yo_frame *F1, const yo_frame *F2, float *prevMatchedXY, int windowSize,
                                  float nnratio, int checkOri, int *matches12) {
     FrameView v1 = to_view(F1), v2 = to_view(F2);

@@ -230,6 +230,87 @@ int search_by_projection_mappoints(const FrameView &F, const Grid &grid, const P
     return nmatches;
 }
 
+// :1352-1469
+int search_by_projection_kf(const FrameView &cur, const Grid &grid, const ProjKFInput &in, float th, int ORBdist,
+                            bool checkOrientation, uint8_t *cur_owner, int *cur_match, uint8_t *out_valid, float *out_u,
+                            float *out_v, int *out_level) {
+    int nmatches = 0;
+    const float *Rcw = in.Rcw, *tcw = in.tcw;
+    float Ow[3];  // -1 * Rcw^T * tcw
+    for (int i = 0; i < 3; i++) Ow[i] = -1 * (Rcw[i] * tcw[0] + Rcw[3 + i] * tcw[1] + Rcw[6 + i] * tcw[2]);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vIndices2;
+    for (int i = 0; i < in.M; i++) {
+        if (out_valid) out_valid[i] = 0;
+        if (!in.usable[i]) continue;
+        const float *x3Dw = &in.world[3 * i];
+        float x3Dc[3];
+        mat3_mul_vec(Rcw, x3Dw, x3Dc);
+        for (int k = 0; k < 3; k++) x3Dc[k] = x3Dc[k] + tcw[k];
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float) (1.0 / x3Dc[2]);
+        const float u = cur.fx * xc * invzc + cur.cx;
+        const float v = cur.fy * yc * invzc + cur.cy;
+        if (u < cur.minX || u > cur.maxX) continue;
+        if (v < cur.minY || v > cur.maxY) continue;
+        const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+        const float dist3D = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);  // Eigen norm(): sqrt of the in-order sum
+        if (dist3D < in.minDistInv[i] || dist3D > in.maxDistInv[i]) continue;
+        // MapPoint::PredictScale(dist3D, &CurrentFrame)  src/MapPoint.cc:359-373 (std::log / std::ceil float overloads)
+        const float ratio = in.mfMaxDistance[i] / dist3D;
+        int nPredictedLevel = (int) std::ceil(std::log(ratio) / in.logScaleFactor);
+        if (nPredictedLevel < 0) nPredictedLevel = 0;
+        else if (nPredictedLevel >= in.nScaleLevels) nPredictedLevel = in.nScaleLevels - 1;
+        if (out_valid) {
+            out_valid[i] = 1;
+            out_u[i] = u;
+            out_v[i] = v;
+            out_level[i] = nPredictedLevel;
+        }
+        const float radius = th * cur.scaleFactors[nPredictedLevel];
+        grid.FeaturesInArea(cur, u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1, vIndices2);
+        if (vIndices2.empty()) continue;
+        const uint8_t *dMP = &in.mp_desc[32 * (size_t) i];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int i2 : vIndices2) {
+            if (cur_owner[i2]) continue;
+            const int dist = descriptor_distance(dMP, &cur.desc[32 * (size_t) i2]);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx2 = i2;
+            }
+        }
+        // (:1431 dereferences bestIdx2 == -1 when every candidate is occupied and ORBdist >= 256; callers pass 100 / 64)
+        if (bestDist <= ORBdist && bestIdx2 >= 0) {
+            cur_owner[bestIdx2] = 2;
+            cur_match[bestIdx2] = i;
+            nmatches++;
+            if (checkOrientation) {
+                float rot = in.kf_angle[i] - cur.keys[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int) std::round(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i != ind1 && i != ind2 && i != ind3) {
+                for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                    cur_owner[rotHist[i][j]] = 0;
+                    cur_match[rotHist[i][j]] = -2;
+                    nmatches--;
+                }
+            }
+        }
+    }
+    return nmatches;
+}
+
 // :375-478
 int search_for_initialization(const FrameView &F1, const FrameView &F2, const Grid &grid2, float *prevMatchedXY,
                               int windowSize, float nnratio, bool checkOrientation, int *vnMatches12) {

@@ -387,6 +387,33 @@ def features_in_area(keys, scale_factors, w, h, x, y, r, min_level=-1, max_level
     return out[:n].copy()
 
 
+def search_by_projection_kf(keys, desc, scale_factors, w, h, cam, usable, world, max_dist_inv, min_dist_inv, mf_max_distance, kf_angle,
+                            mp_desc, Rcw, tcw, log_scale_factor, th, orb_dist, check_ori=True, owner=None):
+    """Oracle ORBmatcher::SearchByProjection(Cur, KF, found, th, ORBdist) -> (nmatches, match, owner, (valid, u, v, level))."""
+    keep = []
+    fr = _yo_frame(keys, desc, scale_factors, w, h, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam.get("mb", 0.0), cam.get("mbf", 0.0),
+                   None, keep)
+    M = len(usable)
+    us = np.ascontiguousarray(usable, np.uint8)
+    wd, mx, mn, mf, ka = (np.ascontiguousarray(a, np.float32) for a in (world, max_dist_inv, min_dist_inv, mf_max_distance, kf_angle))
+    md = np.ascontiguousarray(mp_desc, np.uint8)
+    R = np.ascontiguousarray(Rcw, np.float32)
+    t = np.ascontiguousarray(tcw, np.float32)
+    nt = fr.N
+    own = np.zeros(max(nt, 1), np.uint8) if owner is None else np.array(owner, np.uint8)
+    match = np.full(max(nt, 1), -1, np.int32)
+    ov = np.zeros(max(M, 1), np.uint8)
+    ou, ovv = np.zeros(max(M, 1), np.float32), np.zeros(max(M, 1), np.float32)
+    ol = np.zeros(max(M, 1), np.int32)
+    L = lib()
+    L.yo_search_by_projection_kf.argtypes = [C.POINTER(_YoFrame), C.c_int] + [C.c_void_p] * 9 + [C.c_float, C.c_int, C.c_float, C.c_int, C.c_int] + \
+        [C.c_void_p] * 6
+    r = L.yo_search_by_projection_kf(C.byref(fr), M, _p(us), _p(wd), _p(mx), _p(mn), _p(mf), _p(ka), _p(md), _p(R), _p(t),
+                                     float(log_scale_factor), len(scale_factors), th, orb_dist, int(check_ori), _p(own), _p(match), _p(ov), _p(ou),
+                                     _p(ovv), _p(ol))
+    return r, match[:nt], own[:nt], (ov[:M], ou[:M], ovv[:M], ol[:M])
+
+
 def search_by_projection_mappoints(keys, desc, scale_factors, w, h, cam, track_in_view, proj_x, proj_y, view_cos, scale_level, mp_desc,
                                    th, check_level=True, nnratio=0.8, is_bad=None, mp_has_obs=None, proj_xr=None, u_right=None,
                                    owner=None):

@@ -141,6 +141,26 @@ struct ProjMapPointsInput {
 int search_by_projection_mappoints(const FrameView &F, const Grid &grid, const ProjMapPointsInput &in, float th,
                                    bool checkLevel, float nnratio, uint8_t *owner, int *match);
 
+// SearchByProjection(Frame &Cur, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)  src/ORBmatcher.cc:1352-1469
+// KeyFrame side as arrays over pKF->GetMapPointMatches(): usable[i] = pMP && !pMP->isBad() && !sAlreadyFound.count(pMP);
+// maxDist/minDist = GetMax/MinDistanceInvariance(); mfMaxDistance feeds MapPoint::PredictScale (src/MapPoint.cc:359-373).
+// cur_owner[i2] != 0 <=> Cur.mvpMapPoints[i2] != NULL (any MapPoint blocks, :1419).  The scalar prologue (:1371-1400) is exposed
+// through out_* (may be null): validity after all gates, projection, predicted level.
+struct ProjKFInput {
+    int M = 0;
+    const uint8_t *usable = nullptr;
+    const float *world = nullptr;      // M x 3
+    const float *maxDistInv = nullptr, *minDistInv = nullptr, *mfMaxDistance = nullptr;
+    const float *kf_angle = nullptr;   // pKF->mvKeys[i].angle
+    const uint8_t *mp_desc = nullptr;  // M x 32
+    float Rcw[9], tcw[3];
+    float logScaleFactor = 0;          // Frame::mfLogScaleFactor
+    int nScaleLevels = 0;              // Frame::mnScaleLevels
+};
+int search_by_projection_kf(const FrameView &cur, const Grid &grid, const ProjKFInput &in, float th, int ORBdist,
+                            bool checkOrientation, uint8_t *cur_owner, int *cur_match, uint8_t *out_valid, float *out_u,
+                            float *out_v, int *out_level);
+
 // SearchForInitialization  src/ORBmatcher.cc:375-478
 int search_for_initialization(const FrameView &F1, const FrameView &F2, const Grid &grid2, float *prevMatchedXY,
                               int windowSize, float nnratio, bool checkOrientation, int *matches12);

@@ -91,6 +91,8 @@ def load_library(build_if_missing=True):
                                                  vp, vp, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, ip]
     L.ygzf_search_by_projection_mappoints.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int] + [vp] * 9 + [
         C.c_float, C.c_int, C.c_float, vp, vp, ip]
+    L.ygzf_search_by_projection_kf.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int] + [vp] * 6 + [
+        C.c_float, C.c_int, C.c_int, vp, vp, ip]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
@@ -310,6 +312,29 @@ class Extractor:
             self.h, C.byref(fv), C.byref(cam), len(proj_x), arr(track_in_view, np.uint8), arr(is_bad, np.uint8), arr(mp_has_obs, np.uint8),
             arr(proj_x, np.float32), arr(proj_y, np.float32), arr(proj_xr, np.float32), arr(view_cos, np.float32),
             arr(scale_level, np.int32), arr(mp_desc, np.uint8), th, int(check_level), nnratio, _p(own), _p(match), C.byref(n)))
+        return n.value, match[:len(ck)], own[:len(ck)]
+
+    def search_by_projection_kf(self, cam, keys, desc, valid, proj_x, proj_y, pred_level, kf_angle, mp_desc, th, orb_dist, check_ori=True,
+                                owner=None, scale_factors=None):
+        """ORBmatcher::SearchByProjection(Cur, KF, found, th, ORBdist), device part, on host arrays -> (nmatches, match, owner)."""
+        ck = np.ascontiguousarray(keys, KP_DTYPE)
+        cd = np.ascontiguousarray(desc, np.uint8)
+        keep = [ck, cd]
+
+        def arr(a, dt):
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return _p(a)
+        fv = FrameView(len(ck), ck.ctypes.data, cd.ctypes.data, None, None, self.nlevels)
+        if scale_factors is not None:
+            fv.scale_factors = arr(scale_factors, np.float32)
+        own = np.zeros(max(len(ck), 1), np.uint8) if owner is None else np.array(owner, np.uint8)
+        match = np.full(max(len(ck), 1), -1, np.int32)
+        n = C.c_int()
+        self._ck(self.L.ygzf_search_by_projection_kf(
+            self.h, C.byref(fv), C.byref(cam), len(proj_x), arr(valid, np.uint8), arr(proj_x, np.float32), arr(proj_y, np.float32),
+            arr(pred_level, np.int32), arr(kf_angle, np.float32), arr(mp_desc, np.uint8), th, orb_dist, int(check_ori), _p(own), _p(match),
+            C.byref(n)))
         return n.value, match[:len(ck)], own[:len(ck)]
 
     def sia_run(self, cam, ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, max_level, min_level, n_iter=10,

@@ -3,6 +3,7 @@
 // into CurrentFrame.mvpMapPoints.
 #include "ORBmatcher.h"
 
+#include <cmath>
 #include <cstdio>
 #include <mutex>
 
@@ -146,6 +147,75 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     if (rc != YGZF_OK) return 0;
     for (int i = 0; i < nt; i++)
         if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:1352-1469.  The scalar prologue (:1371-1400) runs here with the reference's expressions -- MapPoint::PredictScale
+// keeps its own logf -- and the window search / in-order slot resolution / rotation histogram run on the device.
+int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist) {
+    const int nt = CurrentFrame.N;
+    const std::vector<MapPoint *> vpMPs = pKF->GetMapPointMatches();
+    const int M = (int) vpMPs.size();
+    if (nt <= 0 || M <= 0) return 0;
+    float Rcw[9], tcw[3], Ow[3];
+    ygz_compat::se3_to_Rt(CurrentFrame.mTcw, Rcw, tcw);
+    for (int i = 0; i < 3; i++) Ow[i] = -1 * (Rcw[i] * tcw[0] + Rcw[3 + i] * tcw[1] + Rcw[6 + i] * tcw[2]);
+    std::vector<uint8_t> valid(M, 0), mpdesc((size_t) M * 32);
+    std::vector<float> pu(M), pv(M), ang(M);
+    std::vector<int> lvl(M);
+    for (int i = 0; i < M; i++) {
+        MapPoint *pMP = vpMPs[i];
+        if (!pMP || pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+        float x3Dw[3];
+        ygz_compat::world_pos(pMP, x3Dw);
+        const float xc = (Rcw[0] * x3Dw[0] + Rcw[1] * x3Dw[1] + Rcw[2] * x3Dw[2]) + tcw[0];
+        const float yc = (Rcw[3] * x3Dw[0] + Rcw[4] * x3Dw[1] + Rcw[5] * x3Dw[2]) + tcw[1];
+        const float zc = (Rcw[6] * x3Dw[0] + Rcw[7] * x3Dw[1] + Rcw[8] * x3Dw[2]) + tcw[2];
+        const float invzc = 1.0 / zc;
+        const float u = Frame::fx * xc * invzc + Frame::cx;
+        const float v = Frame::fy * yc * invzc + Frame::cy;
+        if (u < Frame::mnMinX || u > Frame::mnMaxX) continue;
+        if (v < Frame::mnMinY || v > Frame::mnMaxY) continue;
+        const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+        float dist3D = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+        const float maxDistance = pMP->GetMaxDistanceInvariance();
+        const float minDistance = pMP->GetMinDistanceInvariance();
+        if (dist3D < minDistance || dist3D > maxDistance) continue;
+        valid[i] = 1;
+        pu[i] = u;
+        pv[i] = v;
+        lvl[i] = pMP->PredictScale(dist3D, &CurrentFrame);
+        ang[i] = pKF->mvKeys[i].angle;
+        const cv::Mat d = pMP->GetDescriptor();
+        std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
+    }
+    std::vector<uint8_t> owner(nt), cdesc((size_t) nt * 32);
+    for (int i = 0; i < nt; i++) {
+        owner[i] = CurrentFrame.mvpMapPoints[i] != nullptr;
+        std::memcpy(&cdesc[(size_t) i * 32], CurrentFrame.mDescriptors.ptr<uint8_t>(i), 32);
+    }
+    ygzf_frame_view cur;
+    cur.n = nt;
+    cur.keys = (const ygzf_kp *) CurrentFrame.mvKeys.data();
+    cur.desc = cdesc.data();
+    cur.u_right = nullptr;
+    cur.scale_factors = CurrentFrame.mvScaleFactors.data();
+    cur.nlevels = (int) CurrentFrame.mvScaleFactors.size();
+    ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, CurrentFrame.mb, CurrentFrame.mbf,
+                       Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    ygzf_ctx *c = pool().take(sDevice);
+    if (!c) return 0;
+    std::vector<int> match(nt, -1);
+    int nmatches = 0;
+    const int rc = ygzf_search_by_projection_kf(c, &cur, &cam, M, valid.data(), pu.data(), pv.data(), lvl.data(), ang.data(), mpdesc.data(), th, ORBdist,
+                                                mbCheckOrientation, owner.data(), match.data(), &nmatches);
+    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
+    pool().give(c);
+    if (rc != YGZF_OK) return 0;
+    for (int i2 = 0; i2 < nt; i2++) {
+        if (match[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = vpMPs[match[i2]];
+        else if (match[i2] == -2) CurrentFrame.mvpMapPoints[i2] = static_cast<MapPoint *>(nullptr);
+    }
     return nmatches;
 }
 

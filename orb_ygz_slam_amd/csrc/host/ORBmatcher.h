@@ -1,6 +1,7 @@
 // ORBmatcher.h -- the Tracking-called part of ygz::ORBmatcher (reference include/ORBmatcher.h:38-149) over libygzf.
 #ifndef YGZF_HOST_ORBMATCHER_H
 #define YGZF_HOST_ORBMATCHER_H
+#include <set>
 #include <vector>
 
 #include "ygz_compat.h"
@@ -20,6 +21,9 @@ public:
 
     // Search matches between Frame keypoints and projected MapPoints (Tracking::SearchLocalPoints).
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3, bool checkLevel = true);
+
+    // Project MapPoints seen in a KeyFrame into the current frame and search matches (Tracking::Relocalization).
+    int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
 
     static const int TH_LOW;
     static const int TH_HIGH;

@@ -30,6 +30,7 @@ inline void world_pos(ygz::MapPoint *mp, float o[3]) { const ygz::Vector3f p = m
 }  // namespace ygz_compat
 #else  // ---------------------------------------------------------------------------------------------- stand-alone shim
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <vector>
@@ -105,6 +106,7 @@ struct SE3f {  // Sophus::SE3f storage: unit quaternion (x,y,z,w) + translation
     float q[4] = {0, 0, 0, 1};
     float t[3] = {0, 0, 0};
 };
+class Frame;
 class MapPoint {  // the accessors the hot path calls (reference include/MapPoint.h)
 public:
     Vector3f mWorldPos{};
@@ -119,6 +121,11 @@ public:
     cv::Mat GetDescriptor() const { return mDescriptor.clone(); }
     int Observations() const { return nObs; }
     bool isBad() const { return mbBad; }
+    // scale-invariance range (src/MapPoint.cc:325-373)
+    float mfMinDistance = 0, mfMaxDistance = 0;
+    float GetMinDistanceInvariance() const { return 0.8f * mfMinDistance; }
+    float GetMaxDistanceInvariance() const { return 1.2f * mfMaxDistance; }
+    inline int PredictScale(const float &currentDist, Frame *pF);
 };
 class Frame {  // the members the hot path reads/writes (reference include/Frame.h)
 public:
@@ -134,6 +141,21 @@ public:
     std::vector<bool> mvbOutlier;
     std::vector<float> mvScaleFactors, mvInvScaleFactors;
     SE3f mTcw;
+    float mfLogScaleFactor = 0;
+    int mnScaleLevels = 0;
+};
+inline int MapPoint::PredictScale(const float &currentDist, Frame *pF) {  // src/MapPoint.cc:359-373
+    float ratio = mfMaxDistance / currentDist;
+    int nScale = (int) std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+    return nScale;
+}
+class KeyFrame {  // the members SearchByProjection(Cur, KF, ...) reads (reference include/KeyFrame.h)
+public:
+    std::vector<cv::KeyPoint> mvKeys;
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<MapPoint *> GetMapPointMatches() const { return mvpMapPoints; }
 };
 }  // namespace ygz
 

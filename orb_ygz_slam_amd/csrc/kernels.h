@@ -45,10 +45,13 @@ struct MatchArgs {
     int cntStrideLast, cntOffLast;
     const float *poses;            // per pair: Rcw[9] tcw[3] Rlw[9] tlw[3]
     // mode 1 = SearchByProjection(F, MapPoints): queries come projected (Frame::isInFrustum); mpValid = mbTrackInView, outlier = isBad()
+    // mode 2 = SearchByProjection(Cur, KeyFrame, found, th, ORBdist): queries come projected with their predicted level (the host keeps
+    //          the scalar prologue incl. MapPoint::PredictScale's logf); window th*scale[lvl], levels lvl-1..lvl+1, accept <= maxDist
     int mode;
-    const float *mpProjX, *mpProjY, *mpProjXR, *mpViewCos;
+    const float *mpProjX, *mpProjY, *mpProjXR, *mpViewCos, *mpAngle;
     const int *mpLevel;
     float nnratio;
+    int maxDist;                   // accept threshold of the in-order pass (TH_HIGH, or ORBdist in mode 2)
     // camera / frame statics
     float fx, fy, cx, cy, mb, mbf, minX, minY, maxX, maxY, gridInvW, gridInvH;
     float scaleFactors[kMaxLevels];

@@ -309,13 +309,18 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         q.hasObs = hasObs ? (hasObs[i] != 0) : 1;
         q.pad = 0;
         const bool has = (mpValid ? mpValid[i] != 0 : true) && !(outlier ? outlier[i] != 0 : false);
-        if (A.mode == 1) {
-            // SearchByProjection(Frame &F, const vector<MapPoint*> &, th, checkLevel)  src/ORBmatcher.cc:43-126: the projection was
+        if (A.mode != 0) {
+            // mode 1: SearchByProjection(Frame &F, const vector<MapPoint*> &, th, checkLevel)  src/ORBmatcher.cc:43-126: the projection was
             // done by Frame::isInFrustum; mpValid = mbTrackInView, outlier = isBad()
+            // mode 2: SearchByProjection(Cur, KeyFrame, found, th, ORBdist)  :1352-1469: projection / distance gate / PredictScale on the host
             if (has) {
                 const int lvl = A.mpLevel[(long long) pair * A.kpStrideLast + i];
-                float r = A.mpViewCos[(long long) pair * A.kpStrideLast + i] > 0.998 ? 2.5f : 4.0f;   // RadiusByViewingCos
-                if (A.th != 1.0) r *= A.th;
+                float r;
+                if (A.mode == 2) r = A.th;                                                             // radius = th * scale[nPredictedLevel]
+                else {
+                    r = A.mpViewCos[(long long) pair * A.kpStrideLast + i] > 0.998 ? 2.5f : 4.0f;      // RadiusByViewingCos
+                    if (A.th != 1.0) r *= A.th;
+                }
                 const float u = A.mpProjX[(long long) pair * A.kpStrideLast + i], v = A.mpProjY[(long long) pair * A.kpStrideLast + i];
                 const float rad = r * A.scaleFactors[lvl];
                 const int nMinCellX = max(0, (int) floorf((u - A.minX - rad) * A.gridInvW));
@@ -329,8 +334,13 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     q.ur = A.mpProjXR ? A.mpProjXR[(long long) pair * A.kpStrideLast + i] : 0.f;
                     q.minCx = (unsigned char) nMinCellX; q.maxCx = (unsigned char) nMaxCellX;
                     q.minCy = (unsigned char) nMinCellY; q.maxCy = (unsigned char) nMaxCellY;
-                    q.minLevel = (signed char) (A.checkLevel ? lvl - 1 : -1);
-                    q.maxLevel = (signed char) (A.checkLevel ? lvl : -1);
+                    if (A.mode == 2) {
+                        q.minLevel = (signed char) (lvl - 1); q.maxLevel = (signed char) (lvl + 1);
+                        q.angle = A.mpAngle[(long long) pair * A.kpStrideLast + i];
+                    } else {
+                        q.minLevel = (signed char) (A.checkLevel ? lvl - 1 : -1);
+                        q.maxLevel = (signed char) (A.checkLevel ? lvl : -1);
+                    }
                 }
             }
         } else if (has) {
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                         d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
                     }
                     const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
-                    if (A.mode == 0 && dist > (unsigned) TH_HIGH) continue;   // mode 1 needs the runner-up even when it is far
+                    if (A.mode != 1 && dist > (unsigned) A.maxDist) continue;   // mode 1 needs the runner-up even when it is far
                     const unsigned key = (dist << 16) | (ord & 0xFFFFu);
                     const unsigned short jj = (unsigned short) i2;
                     if (key < k3) {   // insert into the sorted quadruple
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     int nmatches = 0, nEvents = 0, nRescan = 0;
     const float factor = 1.0f / HISTO_LENGTH;
     volatile unsigned char *vowner = L.owner;
-    const bool doOri = A.checkOri && A.mode == 0;
+    const bool doOri = A.checkOri && A.mode != 1;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     if (A.mode == 1) {
         // best and second-best among the candidates that are free NOW = the first two free entries of the (dist, order)-sorted
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     int b = -1;
                     const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &b);
                     nRescan++;
-                    if ((int) (key >> 16) <= TH_HIGH) {
+                    if ((int) (key >> 16) <= A.maxDist) {
                         if (lane == first) { vowner[b] = obs ? 2 : 1; L.match[b] = qi; }
                         if (doOri) {
                             float rot = L.qang[qi] - L.cang[b];

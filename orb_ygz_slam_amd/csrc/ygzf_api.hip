@@ -885,6 +885,7 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
     }
     MatchArgs A;
     memset(&A, 0, sizeof A);
+    A.maxDist = 100;   // TH_HIGH
     A.curKeys = kp + G.kpStride;            // pair p: Cur = slot p+1, Last = slot p
     A.curDesc = desc + (size_t) G.kpStride * 32;
     A.curURight = nullptr;
@@ -989,6 +990,7 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
     if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
     MatchArgs A;
     memset(&A, 0, sizeof A);
+    A.maxDist = 100;   // TH_HIGH
     A.curKeys = (const ygzf_kp *) G[0].p;
     A.curDesc = (const uint8_t *) G[1].p;
     A.curURight = cur->u_right ? (const float *) G[2].p : nullptr;
@@ -1342,10 +1344,11 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
     return YGZF_OK;
 }
 
-int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
-                                        const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y,
-                                        const float *proj_xr, const float *view_cos, const int *scale_level, const uint8_t *mp_desc, float th,
-                                        int check_level, float nnratio, uint8_t *owner, int *match, int *nmatches) {
+// shared body of the two searches whose queries arrive already projected (mode 1: F x local MapPoints, mode 2: Cur x KeyFrame points)
+static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
+                           const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y, const float *proj_xr,
+                           const float *view_cos, const int *scale_level, const float *mp_angle, const uint8_t *mp_desc, float th,
+                           int check_level, float nnratio, int max_dist, int check_ori, uint8_t *owner, int *match, int *nmatches) {
     if (!c || !F || !cam || !nmatches) return fail(c, YGZF_ERR_INVALID, "null argument");
     *nmatches = 0;
     if (F->n < 0 || n_mp < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
@@ -1353,10 +1356,11 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
         for (int i = 0; i < F->n; i++) if (match) match[i] = -1;
         return YGZF_OK;
     }
-    if (!F->keys || !F->desc || !track_in_view || !proj_x || !proj_y || !view_cos || !scale_level || !mp_desc || !owner || !match)
+    if (!F->keys || !F->desc || !track_in_view || !proj_x || !proj_y || (mode == 1 && !view_cos) || (mode == 2 && !mp_angle) || !scale_level || !mp_desc ||
+        !owner || !match)
         return fail(c, YGZF_ERR_INVALID, "null array");
     for (int i = 0; i < n_mp; i++)
-        if (track_in_view[i] && (scale_level[i] < 0 || scale_level[i] >= kMaxLevels)) return fail(c, YGZF_ERR_INVALID, "mnTrackScaleLevel out of range");
+        if (track_in_view[i] && (scale_level[i] < 0 || scale_level[i] >= kMaxLevels)) return fail(c, YGZF_ERR_INVALID, "scale level out of range");
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t nt = F->n, nq = n_mp;
     ygzf_ctx::Buf *G = c->dGen;
@@ -1381,12 +1385,14 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
     int *dLv = (int *) (dVC + nq);
     HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
     if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(dVC, view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dVC, mode == 2 ? mp_angle : view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipMemcpyAsync(dLv, scale_level, nq * 4, hipMemcpyHostToDevice, c->stream));
     if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
     MatchArgs A;
     memset(&A, 0, sizeof A);
-    A.mode = 1;
+    A.maxDist = 100;   // TH_HIGH
+    A.mode = mode;
+    A.maxDist = max_dist;
     A.curKeys = (const ygzf_kp *) G[0].p;
     A.curDesc = (const uint8_t *) G[1].p;
     A.curURight = F->u_right ? (const float *) G[2].p : nullptr;
@@ -1407,6 +1413,7 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
     A.mpProjY = dY;
     A.mpProjXR = proj_xr ? dXR : nullptr;
     A.mpViewCos = dVC;
+    A.mpAngle = dVC;
     A.mpLevel = dLv;
     A.nnratio = nnratio;
     fill_camera(A, cam, c);
@@ -1414,7 +1421,7 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
     A.th = th;
     A.bMono = 1;
     A.checkLevel = check_level != 0;
-    A.checkOri = 0;
+    A.checkOri = check_ori != 0;
     A.owner = (uint8_t *) c->dOwner.p;
     A.match = (int *) c->dMatch.p;
     A.nmatches = (int *) c->dNMatch.p;
@@ -1433,6 +1440,24 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     c->lastMatchPairs = 0;
     return YGZF_OK;
+}
+
+int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
+                                        const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y,
+                                        const float *proj_xr, const float *view_cos, const int *scale_level, const uint8_t *mp_desc, float th,
+                                        int check_level, float nnratio, uint8_t *owner, int *match, int *nmatches) {
+    return projected_match(c, 1, F, cam, n_mp, track_in_view, is_bad, mp_has_obs, proj_x, proj_y, proj_xr, view_cos, scale_level, nullptr, mp_desc,
+                           th, check_level, nnratio, 100, 0, owner, match, nmatches);
+}
+
+int ygzf_search_by_projection_kf(ygzf_ctx *c, const ygzf_frame_view *cur, const ygzf_camera *cam, int n_mp, const uint8_t *valid,
+                                 const float *proj_x, const float *proj_y, const int *pred_level, const float *kf_angle, const uint8_t *mp_desc,
+                                 float th, int orb_dist, int check_orientation, uint8_t *owner, int *match, int *nmatches) {
+    if (!c || !cur || !owner) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (orb_dist < 0 || orb_dist > 256) return fail(c, YGZF_ERR_INVALID, "ORBdist %d outside 0..256", orb_dist);
+    for (int i = 0; i < cur->n; i++) owner[i] = owner[i] ? 2 : 0;   // `if (CurrentFrame.mvpMapPoints[i2]) continue;` (:1419): any MapPoint blocks
+    return projected_match(c, 2, cur, cam, n_mp, valid, nullptr, nullptr, proj_x, proj_y, nullptr, nullptr, pred_level, kf_angle, mp_desc, th, 0,
+                           0.f, orb_dist, check_orientation, owner, match, nmatches);
 }
 
 // ---- SparseImgAlign over a resident batch ---------------------------------------------------------------------------------

@@ -1,7 +1,9 @@
 // test_shells.cc -- drives the three class shells (reference signatures) the way Tracking.cc does and dumps their
 // outputs as raw binaries for tests/test_gpu_shells.py to compare with the oracle.
 // usage: test_shells <dir>   reads <dir>/a.u8, <dir>/b.u8 (752x480 u8) and <dir>/depth.f32 (plane depth).
+#include <cmath>
 #include <cstdio>
+#include <set>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -132,6 +134,30 @@ int main(int argc, char **argv) {
         ex(&D, D.mvKeys, cv::_OutputArray(D.mDescriptors), ORBextractor::ORBSLAM_KEYPOINT, true);
         dump(dir + "/d_kps.bin", D.mvKeys.data(), D.mvKeys.size() * sizeof(cv::KeyPoint));
         dump(dir + "/d_desc.bin", D.mDescriptors.ptr(0), D.mvKeys.size() * 32);
+    }
+    // Tracking::Relocalization refinement: SearchByProjection(cur, KF, found, 10, 100)  (src/Tracking.cc:1830-1860)
+    {
+        KeyFrame KF;
+        KF.mvKeys = A.mvKeys;
+        for (int i = 0; i < A.N; i++) {
+            mps[i].mfMaxDistance = depth * A.mvScaleFactors[A.mvKeys[i].octave];   // MapPoint::UpdateNormalAndDepth
+            mps[i].mfMinDistance = mps[i].mfMaxDistance / A.mvScaleFactors[L - 1];
+            KF.mvpMapPoints.push_back((i % 11 == 0) ? nullptr : &mps[i]);
+        }
+        std::set<MapPoint *> found;
+        for (int i = 0; i < A.N; i += 5) found.insert(&mps[i]);
+        Frame B2 = B;
+        B2.mvpMapPoints.assign(B2.N, nullptr);
+        for (int i = 0; i < B2.N; i += 13) B2.mvpMapPoints[i] = &mps[0];          // slots filled by the first pass
+        B2.mfLogScaleFactor = std::log(1.2f);
+        B2.mnScaleLevels = L;
+        ORBmatcher matcher3(0.9f, true);
+        const int nm3 = matcher3.SearchByProjection(B2, &KF, found, 10.f, 100);
+        std::vector<int> assigned3(B2.N, -1);
+        for (int i = 0; i < B2.N; i++)
+            if (B2.mvpMapPoints[i] && !(i % 13 == 0 && B2.mvpMapPoints[i] == &mps[0])) assigned3[i] = (int) (B2.mvpMapPoints[i] - mps.data());
+        dump(dir + "/match3.bin", assigned3.data(), assigned3.size() * sizeof(int));
+        dump(dir + "/nmatch3.bin", &nm3, sizeof nm3);
     }
     cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
     printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));

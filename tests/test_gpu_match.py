@@ -130,3 +130,43 @@ def test_search_by_projection_mappoints(oracle):
         assert g_n == e_n, (cs, g_n, e_n)
         assert (g_m == e_m).all() and (g_o == e_o).all(), cs
         assert e_n > 50
+
+
+def test_search_by_projection_keyframe(oracle):
+    """SearchByProjection(Cur, KF, found, th, ORBdist) (relocalisation refinement, src/ORBmatcher.cc:1352-1469): the oracle runs the whole
+    function; the device gets the host prologue's (valid, u, v, level) and must reproduce assignment, ownership and count."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    base = synth_frame(60, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[11:11 + h, 4:4 + w]
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = ex.extract(a)      # the KeyFrame
+    kb, db = ex.extract(b)      # the current frame
+    cam = make_camera(w, h)
+    rng = np.random.default_rng(11)
+    n = len(ka)
+    depth = rng.uniform(2.0, 8.0, n).astype(np.float32)
+    world = _unit_world(ka, EUROC) * depth[:, None]
+    ang = np.float32(np.deg2rad(0.4))
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.03, 0.01, -0.02], np.float32)
+    # scale-invariance range of each point as MapPoint::UpdateNormalAndDepth sets it from its reference observation
+    dist = np.linalg.norm(world, axis=1).astype(np.float32)
+    mf_max = (dist * sf[ka["octave"]]).astype(np.float32)
+    mf_min = (mf_max / sf[7]).astype(np.float32)
+    max_inv, min_inv = (np.float32(1.2) * mf_max).astype(np.float32), (np.float32(0.8) * mf_min).astype(np.float32)
+    usable = (rng.uniform(size=n) > 0.15).astype(np.uint8)          # NULL / bad / already found
+    owner0 = (rng.uniform(size=len(kb)) > 0.9).astype(np.uint8)       # slots the first relocalisation pass filled
+    log_sf = np.log(np.float32(1.2))
+    for th, orb_dist, ori in ((10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (25.0, 256, True)):
+        e_n, e_m, e_o, (valid, u, v, lvl) = oracle.search_by_projection_kf(kb, db, sf, w, h, EUROC, usable, world, max_inv, min_inv, mf_max,
+                                                                          ka["angle"], da, Rcw, tcw, log_sf, th, orb_dist, ori, owner=owner0)
+        g_n, g_m, g_o = ex.search_by_projection_kf(cam, kb, db, valid, u, v, lvl, ka["angle"], da, th, orb_dist, ori, owner=owner0,
+                                                   scale_factors=sf)
+        assert valid.sum() > 300
+        assert g_n == e_n and (g_m == e_m).all()
+        assert ((g_o != 0) == (e_o != 0)).all()
+        if th >= 10:
+            assert e_n > 50

@@ -105,3 +105,17 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     _, dex = oex2.describe_keys(imgB, kb[10:70])
     assert len(kd) == 60 + len(kb) and (kd[:60] == kb[10:70]).all() and (kd[60:] == kb).all()
     assert (dd[:60] == dex).all() and (dd[:60] == db[10:70]).all() and (dd[60:] == db).all()
+    # SearchByProjection(cur, KF, found, 10, 100): host prologue in the shell (projection, distance gate, PredictScale) + device search
+    sf = oex.tables()["scale"]
+    idx = np.arange(M)
+    usable = ((idx % 11 != 0) & (idx % 5 != 0)).astype(np.uint8)
+    mf_max = (depth * sf[ka["octave"]]).astype(np.float32)
+    mf_min = (mf_max / sf[7]).astype(np.float32)
+    owner0 = (np.arange(len(kb)) % 13 == 0).astype(np.uint8)
+    e_n3, e_m3, _, _ = oracle.search_by_projection_kf(kb, db, sf, w, h, EUROC, usable, world, (f(1.2) * mf_max).astype(np.float32),
+                                                      (f(0.8) * mf_min).astype(np.float32), mf_max, ka["angle"], da, Rcw, tcw,
+                                                      np.log(f(1.2)), 10.0, 100, True, owner=owner0)
+    nm3 = int(np.fromfile(tmp_path / "nmatch3.bin", np.int32)[0])
+    assigned3 = np.fromfile(tmp_path / "match3.bin", np.int32)
+    assert nm3 == e_n3 and nm3 > 50
+    assert (assigned3 == np.where(e_m3 >= 0, e_m3, -1)).all()
