@@ -146,6 +146,25 @@ int ygzf_search_by_projection_kf(ygzf_ctx *ctx, const ygzf_frame_view *cur, cons
                                  const float *proj_x, const float *proj_y, const int *pred_level, const float *kf_angle, const uint8_t *mp_desc,
                                  float th, int orb_dist, int check_orientation, uint8_t *owner, int *match, int *nmatches);
 
+/* ---- ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)
+ *      src/ORBmatcher.cc:375-478 (Tracking::MonocularInitialization, nnratio 0.9, windowSize 100) ------------------------------------
+ * Level-0 keys of F1 against the windowSize window around prev_matched_xy[i] in F2 (level 0), recorded-distance candidate gate
+ * (:414-415), accept bestDist <= TH_LOW && bestDist < nnratio * bestDist2, take-over of an already matched F2 key (:427-430), rotation
+ * histogram.  matches12 (F1->n ints) = vnMatches12; prev_matched_xy (F1->n x 2, in/out) is updated like vbPrevMatched (:470-474). */
+int ygzf_search_for_initialization(ygzf_ctx *ctx, const ygzf_frame_view *F1, const ygzf_frame_view *F2, const ygzf_camera *cam,
+                                   float *prev_matched_xy, int window_size, float nnratio, int check_orientation, int *matches12, int *nmatches);
+
+/* ---- ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)   src/ORBmatcher.cc:155-263 ---------------
+ * The DBoW2 FeatureVector merge-join (:169-247, equal node ids) stays with the caller -- the vocabulary and Frame::ComputeBoW are outside
+ * this path -- and arrives as a joined node list: node k pairs the KeyFrame feature indices kf_idx[kf_off[k] .. kf_off[k+1]) with the
+ * Frame feature indices f_idx[f_off[k] .. f_off[k+1]) (each offset array has n_nodes + 1 entries).  kf_valid[i] = the KeyFrame's MapPoint
+ * i exists and is not bad.  The device runs the per-node brute force (best / second best, "slot already matched" chain, TH_LOW + ratio)
+ * and the rotation histogram.  match (n_f ints): KeyFrame feature index whose MapPoint lands in vpMapPointMatches[i]; -1 none;
+ * -2 culled by the rotation check.  At most 4096 Frame features per node. */
+int ygzf_search_by_bow(ygzf_ctx *ctx, int n_nodes, const int *kf_off, const int *kf_idx, const int *f_off, const int *f_idx, int n_kf,
+                       const uint8_t *kf_valid, const ygzf_kp *kf_keys, const uint8_t *kf_desc, int n_f, const ygzf_kp *f_keys, const uint8_t *f_desc,
+                       float nnratio, int check_orientation, int *match, int *nmatches);
+
 /* ---- ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, bool checkLevel)
  *      src/ORBmatcher.cc:43-126 (Tracking::SearchLocalPoints, nnratio 0.8) ---------------------------------------------------
  * Per MapPoint i (fields set by Frame::isInFrustum, src/Frame.cc:413-419): track_in_view = mbTrackInView, is_bad = isBad()

@@ -281,6 +281,12 @@ int yo_search_by_projection_kf(const yo_frame *cur, int M, const uint8_t *usable
     return search_by_projection_kf(v, g, in, th, ORBdist, checkOri != 0, cur_owner, cur_match, out_valid, out_u, out_v, out_level);
 }
 
+int yo_search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int *f_off, const int *f_idx, const uint8_t *kf_valid,
+                     const KeyPoint *kf_keys, const uint8_t *kf_desc, int nF, const KeyPoint *f_keys, const uint8_t *f_desc, float nnratio,
+                     int checkOri, int *match) {
+    return search_by_bow(nNodes, kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, nF, f_keys, f_desc, nnratio, checkOri != 0, match);
+}
+
 int yo_search_for_initialization(const yo_frame *F1, const yo_frame *F2, float *prevMatchedXY, int windowSize,
                                  float nnratio, int checkOri, int *matches12) {
     FrameView v1 = to_view(F1), v2 = to_view(F2);

@@ -311,6 +311,61 @@ int search_by_projection_kf(const FrameView &cur, const Grid &grid, const ProjKF
     return nmatches;
 }
 
+// :155-263
+int search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int *f_off, const int *f_idx, const uint8_t *kf_valid,
+                  const KeyPoint *kf_keys, const uint8_t *kf_desc, int nF, const KeyPoint *f_keys, const uint8_t *f_desc, float nnratio,
+                  bool checkOrientation, int *match) {
+    for (int i = 0; i < nF; i++) match[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int k = 0; k < nNodes; k++) {
+        for (int a = kf_off[k]; a < kf_off[k + 1]; a++) {
+            const int realIdxKF = kf_idx[a];
+            if (!kf_valid[realIdxKF]) continue;
+            const uint8_t *dKF = &kf_desc[32 * (size_t) realIdxKF];
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+            for (int b = f_off[k]; b < f_off[k + 1]; b++) {
+                const int realIdxF = f_idx[b];
+                if (match[realIdxF] >= 0) continue;  // vpMapPointMatches[realIdxF] already set
+                const int dist = descriptor_distance(dKF, &f_desc[32 * (size_t) realIdxF]);
+                if (dist < bestDist1) {
+                    bestDist2 = bestDist1;
+                    bestDist1 = dist;
+                    bestIdxF = realIdxF;
+                } else if (dist < bestDist2) {
+                    bestDist2 = dist;
+                }
+            }
+            if (bestDist1 <= TH_LOW) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    match[bestIdxF] = realIdxKF;
+                    if (checkOrientation) {
+                        float rot = kf_keys[realIdxKF].angle - f_keys[bestIdxF].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int) std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(bestIdxF);
+                    }
+                    nmatches++;
+                }
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                match[rotHist[i][j]] = -2;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 // :375-478
 int search_for_initialization(const FrameView &F1, const FrameView &F2, const Grid &grid2, float *prevMatchedXY,
                               int windowSize, float nnratio, bool checkOrientation, int *vnMatches12) {

@@ -414,6 +414,33 @@ def search_by_projection_kf(keys, desc, scale_factors, w, h, cam, usable, world,
     return r, match[:nt], own[:nt], (ov[:M], ou[:M], ovv[:M], ol[:M])
 
 
+def search_for_initialization(keys1, desc1, keys2, desc2, scale_factors, w, h, cam, prev_matched_xy, window=100, nnratio=0.9, check_ori=True):
+    """Oracle ORBmatcher::SearchForInitialization -> (nmatches, matches12, updated prev_matched_xy)."""
+    keep = []
+    f1 = _yo_frame(keys1, desc1, scale_factors, w, h, cam["fx"], cam["fy"], cam["cx"], cam["cy"], 0.0, 0.0, None, keep)
+    f2 = _yo_frame(keys2, desc2, scale_factors, w, h, cam["fx"], cam["fy"], cam["cx"], cam["cy"], 0.0, 0.0, None, keep)
+    pm = np.array(prev_matched_xy, np.float32).reshape(-1, 2).copy()
+    m12 = np.full(max(f1.N, 1), -1, np.int32)
+    L = lib()
+    L.yo_search_for_initialization.argtypes = [C.POINTER(_YoFrame), C.POINTER(_YoFrame), C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    r = L.yo_search_for_initialization(C.byref(f1), C.byref(f2), _p(pm), int(window), nnratio, int(check_ori), _p(m12))
+    return r, m12[:f1.N], pm
+
+
+def search_by_bow(kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, f_keys, f_desc, nnratio=0.7, check_ori=True):
+    """Oracle ORBmatcher::SearchByBoW(KF, F) on a joined node list -> (nmatches, match per Frame feature)."""
+    ko, ki, fo, fi = (np.ascontiguousarray(a, np.int32) for a in (kf_off, kf_idx, f_off, f_idx))
+    kv = np.ascontiguousarray(kf_valid, np.uint8)
+    kk, fk = np.ascontiguousarray(kf_keys, KP_DTYPE), np.ascontiguousarray(f_keys, KP_DTYPE)
+    kd, fd = np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(f_desc, np.uint8)
+    match = np.full(max(len(fk), 1), -1, np.int32)
+    L = lib()
+    L.yo_search_by_bow.argtypes = [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    r = L.yo_search_by_bow(len(ko) - 1, _p(ko), _p(ki), _p(fo), _p(fi), _p(kv), _p(kk), _p(kd), len(fk), _p(fk), _p(fd), nnratio, int(check_ori),
+                           _p(match))
+    return r, match[:len(fk)]
+
+
 def search_by_projection_mappoints(keys, desc, scale_factors, w, h, cam, track_in_view, proj_x, proj_y, view_cos, scale_level, mp_desc,
                                    th, check_level=True, nnratio=0.8, is_bad=None, mp_has_obs=None, proj_xr=None, u_right=None,
                                    owner=None):

@@ -165,6 +165,15 @@ int search_by_projection_kf(const FrameView &cur, const Grid &grid, const ProjKF
 int search_for_initialization(const FrameView &F1, const FrameView &F2, const Grid &grid2, float *prevMatchedXY,
                               int windowSize, float nnratio, bool checkOrientation, int *matches12);
 
+// SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)  src/ORBmatcher.cc:155-263.
+// The FeatureVector merge-join (:169-247: equal node ids, lower_bound skips) is the caller's; the oracle gets the joined node list:
+// node k pairs KeyFrame feature indices kf_idx[kf_off[k]..kf_off[k+1]) with Frame feature indices f_idx[f_off[k]..f_off[k+1]).
+// kf_valid[i] = vpMapPointsKF[i] && !isBad().  match[iF] = KeyFrame feature index whose MapPoint lands in vpMapPointMatches[iF],
+// -1 none, -2 culled by the rotation check.
+int search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int *f_off, const int *f_idx, const uint8_t *kf_valid,
+                  const KeyPoint *kf_keys, const uint8_t *kf_desc, int nF, const KeyPoint *f_keys, const uint8_t *f_desc, float nnratio,
+                  bool checkOrientation, int *match);
+
 // ---- Sophus SE3f + SparseImgAlign --------------------------------------------------------------------------
 struct SE3f {
     float q[4] = {0, 0, 0, 1};  // x,y,z,w (Eigen coeffs order)

@@ -93,6 +93,9 @@ def load_library(build_if_missing=True):
         C.c_float, C.c_int, C.c_float, vp, vp, ip]
     L.ygzf_search_by_projection_kf.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int] + [vp] * 6 + [
         C.c_float, C.c_int, C.c_int, vp, vp, ip]
+    L.ygzf_search_for_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int,
+                                                 vp, ip]
+    L.ygzf_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_float, C.c_int, vp, ip]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
@@ -336,6 +339,36 @@ class Extractor:
             arr(pred_level, np.int32), arr(kf_angle, np.float32), arr(mp_desc, np.uint8), th, orb_dist, int(check_ori), _p(own), _p(match),
             C.byref(n)))
         return n.value, match[:len(ck)], own[:len(ck)]
+
+    def search_for_initialization(self, cam, keys1, desc1, keys2, desc2, prev_matched_xy, window=100, nnratio=0.9, check_ori=True,
+                                  scale_factors=None):
+        """ORBmatcher::SearchForInitialization -> (nmatches, matches12, updated prev_matched_xy)."""
+        k1, k2 = np.ascontiguousarray(keys1, KP_DTYPE), np.ascontiguousarray(keys2, KP_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        f1 = FrameView(len(k1), k1.ctypes.data, d1.ctypes.data, None, None, self.nlevels)
+        f2 = FrameView(len(k2), k2.ctypes.data, d2.ctypes.data, None, None, self.nlevels)
+        sf = None
+        if scale_factors is not None:
+            sf = np.ascontiguousarray(scale_factors, np.float32)
+            f1.scale_factors = f2.scale_factors = _p(sf)
+        pm = np.array(prev_matched_xy, np.float32).reshape(-1, 2).copy()
+        m12 = np.full(max(len(k1), 1), -1, np.int32)
+        n = C.c_int()
+        self._ck(self.L.ygzf_search_for_initialization(self.h, C.byref(f1), C.byref(f2), C.byref(cam), _p(pm), int(window), nnratio, int(check_ori),
+                                                       _p(m12), C.byref(n)))
+        return n.value, m12[:len(k1)], pm
+
+    def search_by_bow(self, kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, f_keys, f_desc, nnratio=0.7, check_ori=True):
+        """ORBmatcher::SearchByBoW(KF, F) on a joined node list -> (nmatches, match per Frame feature)."""
+        ko, ki, fo, fi = (np.ascontiguousarray(a, np.int32) for a in (kf_off, kf_idx, f_off, f_idx))
+        kv = np.ascontiguousarray(kf_valid, np.uint8)
+        kk, fk = np.ascontiguousarray(kf_keys, KP_DTYPE), np.ascontiguousarray(f_keys, KP_DTYPE)
+        kd, fd = np.ascontiguousarray(kf_desc, np.uint8), np.ascontiguousarray(f_desc, np.uint8)
+        match = np.full(max(len(fk), 1), -1, np.int32)
+        n = C.c_int()
+        self._ck(self.L.ygzf_search_by_bow(self.h, len(ko) - 1, _p(ko), _p(ki), _p(fo), _p(fi), len(kk), _p(kv), _p(kk), _p(kd), len(fk), _p(fk),
+                                           _p(fd), nnratio, int(check_ori), _p(match), C.byref(n)))
+        return n.value, match[:len(fk)]
 
     def sia_run(self, cam, ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, max_level, min_level, n_iter=10,
                 mp_valid=None, outlier=None):

@@ -219,4 +219,74 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     return nmatches;
 }
 
+// src/ORBmatcher.cc:155-263.  The FeatureVector merge-join runs here exactly as in the reference (:169-247); the per-node brute force,
+// the slot chain and the rotation histogram run on the device.
+int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches) {
+    const std::vector<MapPoint *> vpMapPointsKF = pKF->GetMapPointMatches();
+    vpMapPointMatches = std::vector<MapPoint *>(F.N, static_cast<MapPoint *>(nullptr));
+    const DBoW2::FeatureVector &vFeatVecKF = pKF->mFeatVec;
+    std::vector<int> kfOff{0}, fOff{0}, kfIdx, fIdx;
+    DBoW2::FeatureVector::const_iterator KFit = vFeatVecKF.begin(), Fit = F.mFeatVec.begin();
+    const DBoW2::FeatureVector::const_iterator KFend = vFeatVecKF.end(), Fend = F.mFeatVec.end();
+    while (KFit != KFend && Fit != Fend) {
+        if (KFit->first == Fit->first) {
+            kfIdx.insert(kfIdx.end(), KFit->second.begin(), KFit->second.end());
+            fIdx.insert(fIdx.end(), Fit->second.begin(), Fit->second.end());
+            kfOff.push_back((int) kfIdx.size());
+            fOff.push_back((int) fIdx.size());
+            KFit++;
+            Fit++;
+        } else if (KFit->first < Fit->first) {
+            KFit = vFeatVecKF.lower_bound(Fit->first);
+        } else {
+            Fit = F.mFeatVec.lower_bound(KFit->first);
+        }
+    }
+    const int nNodes = (int) kfOff.size() - 1, nKF = (int) vpMapPointsKF.size();
+    if (nNodes <= 0 || F.N <= 0 || nKF <= 0) return 0;
+    std::vector<uint8_t> valid(nKF), kfDesc((size_t) nKF * 32), fDesc((size_t) F.N * 32);
+    for (int i = 0; i < nKF; i++) {
+        valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+        std::memcpy(&kfDesc[(size_t) i * 32], pKF->mDescriptors.ptr<uint8_t>(i), 32);
+    }
+    for (int i = 0; i < F.N; i++) std::memcpy(&fDesc[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
+    ygzf_ctx *c = pool().take(sDevice);
+    if (!c) return 0;
+    std::vector<int> match(F.N, -1);
+    int nmatches = 0;
+    const int rc = ygzf_search_by_bow(c, nNodes, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF, valid.data(), (const ygzf_kp *) pKF->mvKeys.data(),
+                                      kfDesc.data(), F.N, (const ygzf_kp *) F.mvKeys.data(), fDesc.data(), mfNNratio, mbCheckOrientation, match.data(),
+                                      &nmatches);
+    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByBoW: %s\n", ygzf_last_error(c));
+    pool().give(c);
+    if (rc != YGZF_OK) return 0;
+    for (int i = 0; i < F.N; i++)
+        if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:375-478
+int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize) {
+    vnMatches12 = std::vector<int>(F1.N, -1);
+    if (F1.N <= 0 || F2.N <= 0) return 0;
+    std::vector<uint8_t> d1((size_t) F1.N * 32), d2((size_t) F2.N * 32);
+    for (int i = 0; i < F1.N; i++) std::memcpy(&d1[(size_t) i * 32], F1.mDescriptors.ptr<uint8_t>(i), 32);
+    for (int i = 0; i < F2.N; i++) std::memcpy(&d2[(size_t) i * 32], F2.mDescriptors.ptr<uint8_t>(i), 32);
+    ygzf_frame_view v1, v2;
+    v1.n = F1.N; v1.keys = (const ygzf_kp *) F1.mvKeys.data(); v1.desc = d1.data(); v1.u_right = nullptr;
+    v1.scale_factors = F1.mvScaleFactors.data(); v1.nlevels = (int) F1.mvScaleFactors.size();
+    v2.n = F2.N; v2.keys = (const ygzf_kp *) F2.mvKeys.data(); v2.desc = d2.data(); v2.u_right = nullptr;
+    v2.scale_factors = F2.mvScaleFactors.data(); v2.nlevels = (int) F2.mvScaleFactors.size();
+    ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F2.mb, F2.mbf, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f layout");
+    ygzf_ctx *c = pool().take(sDevice);
+    if (!c) return 0;
+    int nmatches = 0;
+    const int rc = ygzf_search_for_initialization(c, &v1, &v2, &cam, (float *) vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation,
+                                                  vnMatches12.data(), &nmatches);
+    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchForInitialization: %s\n", ygzf_last_error(c));
+    pool().give(c);
+    return rc == YGZF_OK ? nmatches : 0;
+}
+
 }  // namespace ygz

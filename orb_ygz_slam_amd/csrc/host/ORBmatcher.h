@@ -25,6 +25,12 @@ public:
     // Project MapPoints seen in a KeyFrame into the current frame and search matches (Tracking::Relocalization).
     int SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std::set<MapPoint *> &sAlreadyFound, const float th, const int ORBdist);
 
+    // Brute force inside equal vocabulary nodes between KeyFrame MapPoints and Frame keypoints (TrackReferenceKeyFrame, Relocalization).
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
+
+    // Matching for the map initialisation (monocular only).
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10);
+
     static const int TH_LOW;
     static const int TH_HIGH;
     static const int HISTO_LENGTH;

@@ -32,6 +32,7 @@ inline void world_pos(ygz::MapPoint *mp, float o[3]) { const ygz::Vector3f p = m
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <vector>
 
@@ -100,6 +101,10 @@ typedef const _InputArray &InputArray;
 typedef const _OutputArray &OutputArray;
 }  // namespace cv
 
+namespace DBoW2 {
+typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;   // node id -> feature indices (DBoW2/FeatureVector.h)
+}
+
 namespace ygz {
 struct Vector3f { float v[3]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
 struct SE3f {  // Sophus::SE3f storage: unit quaternion (x,y,z,w) + translation
@@ -143,6 +148,7 @@ public:
     SE3f mTcw;
     float mfLogScaleFactor = 0;
     int mnScaleLevels = 0;
+    DBoW2::FeatureVector mFeatVec;
 };
 inline int MapPoint::PredictScale(const float &currentDist, Frame *pF) {  // src/MapPoint.cc:359-373
     float ratio = mfMaxDistance / currentDist;
@@ -156,6 +162,8 @@ public:
     std::vector<cv::KeyPoint> mvKeys;
     std::vector<MapPoint *> mvpMapPoints;
     std::vector<MapPoint *> GetMapPointMatches() const { return mvpMapPoints; }
+    cv::Mat mDescriptors;
+    DBoW2::FeatureVector mFeatVec;
 };
 }  // namespace ygz
 

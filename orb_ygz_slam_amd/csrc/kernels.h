@@ -47,6 +47,8 @@ struct MatchArgs {
     // mode 1 = SearchByProjection(F, MapPoints): queries come projected (Frame::isInFrustum); mpValid = mbTrackInView, outlier = isBad()
     // mode 2 = SearchByProjection(Cur, KeyFrame, found, th, ORBdist): queries come projected with their predicted level (the host keeps
     //          the scalar prologue incl. MapPoint::PredictScale's logf); window th*scale[lvl], levels lvl-1..lvl+1, accept <= maxDist
+    // mode 3 = SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize): Last = F1 (keys, descriptors in mpDesc),
+    //          Cur = F2, mpProjX/Y = vbPrevMatched, th = windowSize; TH_LOW + ratio accept, take-over bookkeeping, result in match12
     int mode;
     const float *mpProjX, *mpProjY, *mpProjXR, *mpViewCos, *mpAngle;
     const int *mpLevel;
@@ -61,6 +63,7 @@ struct MatchArgs {
     uint8_t *owner;                // per pair kpStrideCur
     int *match;                    // per pair kpStrideCur
     int *nmatches;                 // per pair
+    int *match12;                  // mode 3 (SearchForInitialization): vnMatches12, per pair kpStrideLast
     // LDS plan
     int capCur, capLast, descInLds, qpInLds;
     int spill;                     // kSpill* bits: array groups that live in spillScratch instead of LDS
@@ -76,6 +79,11 @@ void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt
                              float fy, float cx, float cy, float *world);
 void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ldsBytes);
 
+
+// SearchByBoW per-node brute force (match_kernels.hip); match (nF ints) must be pre-set to -1, hist (30 ints) and nmatches to 0
+void launch_bow(hipStream_t st, int nNodes, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx, const uint8_t *kfValid,
+                const ygzf_kp *kfKeys, const uint8_t *kfDesc, int nF, const ygzf_kp *fKeys, const uint8_t *fDesc, float nnratio, int checkOri, int *match,
+                unsigned char *binOf, int *hist, int *nmatches);
 
 // ---- FAST-10 (fast10_kernels.hip): Thirdparty/fast replacement -------------------------------------------------------
 void launch_fast10(hipStream_t st, const uint8_t *img, int pitch, int x0, int y0, int w, int h, int dx0, int dx1, int dy0, int dy1, int barrier,

@@ -102,7 +102,8 @@ __device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
 __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
                                                unsigned long long q1, unsigned long long q2, unsigned long long q3,
                                                const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2,
-                                               unsigned *secondKey = nullptr, int *secondIdx2 = nullptr) {
+                                               unsigned *secondKey = nullptr, int *secondIdx2 = nullptr,
+                                               const volatile int *matchedDist = nullptr) {
     const int nCx = q.maxCx - q.minCx + 1;   // <= 64 (one lane per grid column)
     const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
     int rs = 0, rlen = 0;
@@ -163,6 +164,7 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
             d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
         }
         const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
+        if (matchedDist && matchedDist[i2] <= (int) dist) continue;   // SearchForInitialization :414-415
         const unsigned key = (dist << 16) | (unsigned) j;
         if (key < best) { best2 = best; best2I2 = bestI2; best = key; bestI2 = i2; }
         else if (key < best2) { best2 = key; best2I2 = i2; }
@@ -309,7 +311,27 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         q.hasObs = hasObs ? (hasObs[i] != 0) : 1;
         q.pad = 0;
         const bool has = (mpValid ? mpValid[i] != 0 : true) && !(outlier ? outlier[i] != 0 : false);
-        if (A.mode != 0) {
+        if (A.mode == 3) {
+            // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  src/ORBmatcher.cc:375-478: queries = the level-0
+            // keys of F1 (:390-392), window windowSize around the previously matched position, level 0 only
+            const ygzf_kp lk = lastKeys[i];
+            if (lk.octave <= 0) {
+                const float u = A.mpProjX[(long long) pair * A.kpStrideLast + i], v = A.mpProjY[(long long) pair * A.kpStrideLast + i];
+                const float rad = A.th;
+                const int nMinCellX = max(0, (int) floorf((u - A.minX - rad) * A.gridInvW));
+                const int nMaxCellX = min(GRID_COLS - 1, (int) ceilf((u - A.minX + rad) * A.gridInvW));
+                const int nMinCellY = max(0, (int) floorf((v - A.minY - rad) * A.gridInvH));
+                const int nMaxCellY = min(GRID_ROWS - 1, (int) ceilf((v - A.minY + rad) * A.gridInvH));
+                if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0) && nMaxCellX >= nMinCellX &&
+                    nMaxCellY >= nMinCellY) {
+                    q.valid = 1;
+                    q.u = u; q.v = v; q.radius = rad; q.angle = lk.angle;
+                    q.minCx = (unsigned char) nMinCellX; q.maxCx = (unsigned char) nMaxCellX;
+                    q.minCy = (unsigned char) nMinCellY; q.maxCy = (unsigned char) nMaxCellY;
+                    q.minLevel = (signed char) lk.octave; q.maxLevel = (signed char) lk.octave;
+                }
+            }
+        } else if (A.mode != 0) {
             // mode 1: SearchByProjection(Frame &F, const vector<MapPoint*> &, th, checkLevel)  src/ORBmatcher.cc:43-126: the projection was
             // done by Frame::isInFrustum; mpValid = mbTrackInView, outlier = isBad()
             // mode 2: SearchByProjection(Cur, KeyFrame, found, th, ORBdist)  :1352-1469: projection / distance gate / PredictScale on the host
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                         d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
                     }
                     const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
-                    if (A.mode != 1 && dist > (unsigned) A.maxDist) continue;   // mode 1 needs the runner-up even when it is far
+                    if ((A.mode == 0 || A.mode == 2) && dist > (unsigned) A.maxDist) continue;   // modes 1, 3 need the runner-up even when it is far
                     const unsigned key = (dist << 16) | (ord & 0xFFFFu);
                     const unsigned short jj = (unsigned short) i2;
                     if (key < k3) {   // insert into the sorted quadruple
@@ -445,8 +467,97 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     int nmatches = 0, nEvents = 0, nRescan = 0;
     const float factor = 1.0f / HISTO_LENGTH;
     volatile unsigned char *vowner = L.owner;
-    const bool doOri = A.checkOri && A.mode != 1;
+    const bool doOri = A.checkOri && (A.mode == 0 || A.mode == 2);
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    if (A.mode == 3) {
+        // SearchForInitialization :394-447.  State: L.claim[i2] = vMatchedDistance, L.match[i2] = vnMatches21, L.events[i1] = vnMatches12
+        // (| bin << 24).  A candidate counts only while its recorded distance is larger than this query's (:414-415); recorded
+        // distances only ever shrink, so the candidates valid NOW are a subset of the speculative (dist, order)-sorted list: best
+        // and runner-up are its first two valid entries, a full list that runs out first is rescanned.  A later query may take a
+        // keypoint over from an earlier one (:427-430); the histogram keeps the earlier vote (:441), as the reference does.
+        volatile int *vdist = L.claim;
+        volatile int *v21 = L.match;
+        volatile int *v12 = L.events;
+        for (int i = lane; i < nt; i += 64) vdist[i] = 0x7FFFFFFF;
+        for (int i = lane; i < nq; i += 64) v12[i] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int TH_LOW = 50;
+        for (int i = 0; i < nq; i++) {
+            const uint4 keys = L.specKey[i];
+            if (keys.x >= kNoKey) continue;
+            const ushort4 idx = L.specI2[i];
+            const unsigned kk[4] = {keys.x, keys.y, keys.z, keys.w};
+            const int ii[4] = {idx.x, idx.y, idx.z, idx.w};
+            unsigned k1 = kNoKey, k2 = kNoKey;
+            int b1 = -1, b2 = -1;
+            bool exhausted = true;
+            for (int e = 0; e < 4; e++) {
+                if (kk[e] >= kNoKey) { exhausted = false; break; }
+                if (vdist[ii[e]] <= (int) (kk[e] >> 16)) continue;
+                if (b1 < 0) { b1 = ii[e]; k1 = kk[e]; }
+                else { b2 = ii[e]; k2 = kk[e]; exhausted = false; break; }
+            }
+            if (exhausted) {
+                const QueryParam q = L.qp[i];
+                const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
+                k1 = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, nullptr, lane, &b1, &k2, &b2, vdist);
+                nRescan++;
+            }
+            const int bestDist = (int) (k1 >> 16);
+            if (b1 < 0 || bestDist > TH_LOW) continue;
+            const int bestDist2 = (int) (k2 >> 16);
+            const bool noSecond = b2 < 0 || bestDist2 >= 256;        // bestDist2 stays INT_MAX in the reference
+            if (!noSecond && !((float) bestDist < (float) bestDist2 * A.nnratio)) continue;
+            const int old = v21[b1];
+            if (old >= 0) nmatches--;
+            nmatches++;
+            float rot = L.qang[i] - L.cang[b1];
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int) roundf(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            if (lane == 0) {
+                if (old >= 0) v12[old] = -1;
+                v12[i] = (bin << 24) | b1;
+                v21[b1] = i;
+                vdist[b1] = bestDist;
+                if (A.checkOri) s_hist[bin]++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        if (A.checkOri) {
+            int max1 = 0, max2 = 0, max3 = 0;
+            for (int b = 0; b < HISTO_LENGTH; b++) {
+                const int s = s_hist[b];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+                else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+                else if (s > max3) { max3 = s; ind3 = b; }
+            }
+            if (max2 < 0.1f * (float) max1) { ind2 = -1; ind3 = -1; }
+            else if (max3 < 0.1f * (float) max1) { ind3 = -1; }
+        }
+        int removed = 0;
+        int *m12 = A.match12 + (long long) pair * A.kpStrideLast;
+        for (int i = lane; i < nq; i += 64) {
+            int ev = v12[i];
+            int m = -1;
+            if (ev >= 0) {
+                const int bin = ev >> 24;
+                m = ev & 0xFFFFFF;
+                if (A.checkOri && bin != ind1 && bin != ind2 && bin != ind3) { m = -1; removed++; }
+            }
+            m12[i] = m;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        nmatches -= removed;
+        if (lane == 0) A.nmatches[pair] = nmatches;
+        return;
+    }
     if (A.mode == 1) {
         // best and second-best among the candidates that are free NOW = the first two free entries of the (dist, order)-sorted
         // speculative list; a full list that runs out before both are found is rescanned.  Accept rule :112-121.
@@ -624,6 +735,107 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     STAMP(5);
     if (dbg && tid == 0) { dbg[6] = nRescan; dbg[7] = nq; }
 #undef STAMP
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  src/ORBmatcher.cc:155-263, the per-node brute force.
+// A feature belongs to exactly one vocabulary node, so the nodes common to both FeatureVectors are independent problems: one wave
+// per node walks that node's KeyFrame features in order (the "slot already matched" test :198-199 chains them), its lanes spread
+// over the node's Frame features.  The rotation histogram (:215-246) spans all nodes: votes are counted with atomics and the
+// culling runs in a second, tiny kernel.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bow_nodes(int nNodes, const int *__restrict__ kfOff, const int *__restrict__ kfIdx,
+                                                   const int *__restrict__ fOff, const int *__restrict__ fIdx,
+                                                   const uint8_t *__restrict__ kfValid, const ygzf_kp *__restrict__ kfKeys,
+                                                   const uint8_t *__restrict__ kfDesc, const ygzf_kp *__restrict__ fKeys,
+                                                   const uint8_t *__restrict__ fDesc, float nnratio, int checkOri, int *__restrict__ match,
+                                                   unsigned char *__restrict__ binOf, int *__restrict__ hist, int *__restrict__ nmatches) {
+    const int lane = m_lane(), wave = threadIdx.x >> 6;
+    const int node = blockIdx.x * 4 + wave;
+    if (node >= nNodes) return;
+    const int f0 = fOff[node], nF = fOff[node + 1] - f0;
+    const int rounds = (nF + 63) >> 6;
+    const float factor = 1.0f / HISTO_LENGTH;
+    const int TH_LOW = 50;
+    unsigned long long taken = 0;   // bit r: this lane's candidate of round r (position r*64 + lane) already carries a match
+    int count = 0;
+    for (int a = kfOff[node]; a < kfOff[node + 1]; a++) {
+        const int iKF = kfIdx[a];
+        if (!kfValid[iKF]) continue;
+        const unsigned long long *qd = (const unsigned long long *) (kfDesc + (size_t) iKF * 32);
+        const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+        unsigned best = (256u << 16) | 0xFFFFu, best2 = (256u << 16) | 0xFFFFu;
+        if (rounds <= 64) {
+            for (int r = 0; r < rounds; r++) {
+                const int b = r * 64 + lane;
+                if (b >= nF || ((taken >> r) & 1ull)) continue;
+                const unsigned long long *d = (const unsigned long long *) (fDesc + (size_t) fIdx[f0 + b] * 32);
+                const unsigned dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+                const unsigned key = (dist << 16) | (unsigned) b;
+                if (key < best) { best2 = best; best = key; }
+                else if (key < best2) best2 = key;
+            }
+        }
+        const unsigned wbest = wave_min_dpp(best);
+        const unsigned long long who = __ballot(best == wbest);
+        const int src = __ffsll((long long) who) - 1;
+        const unsigned second = wave_min_dpp(lane == src ? best2 : min(best, best2));
+        const int bestDist1 = (int) (wbest >> 16), bestDist2 = (int) (second >> 16);
+        if (bestDist1 > TH_LOW) continue;
+        if (!((float) bestDist1 < nnratio * (float) bestDist2)) continue;
+        const int b = (int) (wbest & 0xFFFFu);
+        if (lane == (b & 63)) taken |= 1ull << (b >> 6);
+        if (lane == 0) {
+            const int iF = fIdx[f0 + b];
+            match[iF] = iKF;
+            if (checkOri) {
+                float rot = kfKeys[iKF].angle - fKeys[iF].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int) roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                binOf[iF] = (unsigned char) bin;
+                atomicAdd(&hist[bin], 1);
+            }
+        }
+        count++;
+    }
+    if (lane == 0 && count) atomicAdd(nmatches, count);
+}
+
+__global__ __launch_bounds__(256) void k_bow_finish(int nF, int checkOri, int *__restrict__ match, const unsigned char *__restrict__ binOf,
+                                                    const int *__restrict__ hist, int *__restrict__ nmatches) {
+    if (!checkOri) return;
+    __shared__ int s_removed;
+    if (threadIdx.x == 0) s_removed = 0;
+    __syncthreads();
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int b = 0; b < HISTO_LENGTH; b++) {   // ComputeThreeMaxima :1471-1502
+        const int s = hist[b];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+        else if (s > max3) { max3 = s; ind3 = b; }
+    }
+    if (max2 < 0.1f * (float) max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float) max1) { ind3 = -1; }
+    int removed = 0;
+    for (int i = threadIdx.x; i < nF; i += blockDim.x) {
+        if (match[i] < 0) continue;
+        const int bin = binOf[i];
+        if (bin != ind1 && bin != ind2 && bin != ind3) { match[i] = -2; removed++; }
+    }
+    if (removed) atomicAdd(&s_removed, removed);
+    __syncthreads();
+    if (threadIdx.x == 0) *nmatches -= s_removed;
+}
+
+void launch_bow(hipStream_t st, int nNodes, const int *kfOff, const int *kfIdx, const int *fOff, const int *fIdx, const uint8_t *kfValid,
+                const ygzf_kp *kfKeys, const uint8_t *kfDesc, int nF, const ygzf_kp *fKeys, const uint8_t *fDesc, float nnratio, int checkOri, int *match,
+                unsigned char *binOf, int *hist, int *nmatches) {
+    if (nNodes > 0)
+        hipLaunchKernelGGL(k_bow_nodes, dim3((nNodes + 3) / 4), dim3(256), 0, st, nNodes, kfOff, kfIdx, fOff, fIdx, kfValid, kfKeys, kfDesc, fKeys, fDesc,
+                           nnratio, checkOri, match, binOf, hist, nmatches);
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, nF, checkOri, match, binOf, hist, nmatches);
 }
 
 static inline size_t al16(size_t b) { return (b + 15) & ~(size_t) 15; }

@@ -1348,7 +1348,8 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
 static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
                            const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y, const float *proj_xr,
                            const float *view_cos, const int *scale_level, const float *mp_angle, const uint8_t *mp_desc, float th,
-                           int check_level, float nnratio, int max_dist, int check_ori, uint8_t *owner, int *match, int *nmatches) {
+                           int check_level, float nnratio, int max_dist, int check_ori, uint8_t *owner, int *match, int *nmatches,
+                           const ygzf_kp *last_keys = nullptr, int *match12 = nullptr) {
     if (!c || !F || !cam || !nmatches) return fail(c, YGZF_ERR_INVALID, "null argument");
     *nmatches = 0;
     if (F->n < 0 || n_mp < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
@@ -1356,22 +1357,23 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         for (int i = 0; i < F->n; i++) if (match) match[i] = -1;
         return YGZF_OK;
     }
-    if (!F->keys || !F->desc || !track_in_view || !proj_x || !proj_y || (mode == 1 && !view_cos) || (mode == 2 && !mp_angle) || !scale_level || !mp_desc ||
-        !owner || !match)
-        return fail(c, YGZF_ERR_INVALID, "null array");
-    for (int i = 0; i < n_mp; i++)
-        if (track_in_view[i] && (scale_level[i] < 0 || scale_level[i] >= kMaxLevels)) return fail(c, YGZF_ERR_INVALID, "scale level out of range");
+    if (!F->keys || !F->desc || !proj_x || !proj_y || !mp_desc || !owner || !match) return fail(c, YGZF_ERR_INVALID, "null array");
+    if (mode != 3) {
+        if (!track_in_view || (mode == 1 && !view_cos) || (mode == 2 && !mp_angle) || !scale_level) return fail(c, YGZF_ERR_INVALID, "null array");
+        for (int i = 0; i < n_mp; i++)
+            if (track_in_view[i] && (scale_level[i] < 0 || scale_level[i] >= kMaxLevels)) return fail(c, YGZF_ERR_INVALID, "scale level out of range");
+    } else if (!last_keys || !match12) return fail(c, YGZF_ERR_INVALID, "null array");
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t nt = F->n, nq = n_mp;
     ygzf_ctx::Buf *G = c->dGen;
     int counts[2] = {F->n, n_mp};
     float pose[24] = {0};
-    std::vector<ygzf_kp> dummyKeys(nq);   // the Last-keypoint array is not read in this mode; keep the pointer valid
-    memset(dummyKeys.data(), 0, nq * sizeof(ygzf_kp));
+    std::vector<ygzf_kp> dummyKeys(last_keys ? 0 : nq);   // the Last-keypoint array is not read in modes 1, 2; keep the pointer valid
+    if (!last_keys) memset(dummyKeys.data(), 0, nq * sizeof(ygzf_kp));
     struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
     Up ups[] = {{&G[0], F->keys, nt * sizeof(ygzf_kp)}, {&G[1], F->desc, nt * 32}, {&G[2], F->u_right, F->u_right ? nt * 4 : 0},
-                {&G[3], owner, nt}, {&G[4], dummyKeys.data(), nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32}, {&G[6], proj_x, nq * 4},
-                {&G[7], track_in_view, nq}, {&G[8], is_bad, is_bad ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
+                {&G[3], owner, nt}, {&G[4], last_keys ? last_keys : dummyKeys.data(), nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32},
+                {&G[6], proj_x, nq * 4}, {&G[7], track_in_view, track_in_view ? nq : 0}, {&G[8], is_bad, is_bad ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
                 {&G[10], counts, sizeof counts}, {&G[11], pose, sizeof pose}};
     int rc;
     for (auto &u : ups) {
@@ -1385,8 +1387,10 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     int *dLv = (int *) (dVC + nq);
     HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
     if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(dVC, mode == 2 ? mp_angle : view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(dLv, scale_level, nq * 4, hipMemcpyHostToDevice, c->stream));
+    if (mode != 3) {
+        HIPCHECK(c, hipMemcpyAsync(dVC, mode == 2 ? mp_angle : view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(dLv, scale_level, nq * 4, hipMemcpyHostToDevice, c->stream));
+    } else if ((rc = ensure(c, c->dTmpB, nq * sizeof(int)))) return rc;
     if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
     MatchArgs A;
     memset(&A, 0, sizeof A);
@@ -1402,7 +1406,8 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     A.lastKeys = (const ygzf_kp *) G[4].p;
     A.mpDesc = (const uint8_t *) G[5].p;
     A.world = (const float *) G[6].p;     // unused in this mode
-    A.mpValid = (const uint8_t *) G[7].p;
+    A.mpValid = track_in_view ? (const uint8_t *) G[7].p : nullptr;
+    A.match12 = (int *) c->dTmpB.p;
     A.outlier = is_bad ? (const uint8_t *) G[8].p : nullptr;
     A.hasObs = mp_has_obs ? (const uint8_t *) G[9].p : nullptr;
     A.lastCnt = (const int *) G[10].p;
@@ -1434,11 +1439,81 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         launch_match_last(c->stream, A, 1, lds);
     }
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(match, c->dMatch.p, nt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (mode == 3) HIPCHECK(c, hipMemcpyAsync(match12, c->dTmpB.p, nq * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    else {
+        HIPCHECK(c, hipMemcpyAsync(owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(match, c->dMatch.p, nt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
+
+int ygzf_search_by_bow(ygzf_ctx *c, int n_nodes, const int *kf_off, const int *kf_idx, const int *f_off, const int *f_idx, int n_kf,
+                       const uint8_t *kf_valid, const ygzf_kp *kf_keys, const uint8_t *kf_desc, int n_f, const ygzf_kp *f_keys, const uint8_t *f_desc,
+                       float nnratio, int check_orientation, int *match, int *nmatches) {
+    if (!c || !nmatches || (n_f > 0 && !match)) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *nmatches = 0;
+    for (int i = 0; i < n_f; i++) match[i] = -1;   // vpMapPointMatches = vector<MapPoint*>(F.N, NULL)  (:158)
+    if (n_nodes <= 0 || n_kf <= 0 || n_f <= 0) return YGZF_OK;
+    if (!kf_off || !kf_idx || !f_off || !f_idx || !kf_valid || !kf_keys || !kf_desc || !f_keys || !f_desc) return fail(c, YGZF_ERR_INVALID, "null array");
+    const int nk = kf_off[n_nodes], nfi = f_off[n_nodes];
+    for (int k = 0; k < n_nodes; k++) {
+        if (kf_off[k] > kf_off[k + 1] || f_off[k] > f_off[k + 1] || kf_off[k] < 0 || f_off[k] < 0) return fail(c, YGZF_ERR_INVALID, "node offsets not ascending");
+        if (f_off[k + 1] - f_off[k] > 4096) return fail(c, YGZF_ERR_UNSUPPORTED, "more than 4096 frame features in one vocabulary node");
+    }
+    for (int i = 0; i < nk; i++) if (kf_idx[i] < 0 || kf_idx[i] >= n_kf) return fail(c, YGZF_ERR_INVALID, "KeyFrame feature index out of range");
+    for (int i = 0; i < nfi; i++) if (f_idx[i] < 0 || f_idx[i] >= n_f) return fail(c, YGZF_ERR_INVALID, "Frame feature index out of range");
+    HIPCHECK(c, hipSetDevice(c->device));
+    ygzf_ctx::Buf *G = c->dGen;
+    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
+    Up ups[] = {{&G[0], kf_off, 4 * (size_t) (n_nodes + 1)}, {&G[1], kf_idx, 4 * (size_t) nk}, {&G[2], f_off, 4 * (size_t) (n_nodes + 1)},
+                {&G[3], f_idx, 4 * (size_t) nfi}, {&G[4], kf_valid, (size_t) n_kf}, {&G[5], kf_keys, sizeof(ygzf_kp) * (size_t) n_kf},
+                {&G[6], kf_desc, 32 * (size_t) n_kf}, {&G[7], f_keys, sizeof(ygzf_kp) * (size_t) n_f}, {&G[8], f_desc, 32 * (size_t) n_f}};
+    int rc;
+    for (auto &u : ups) {
+        if ((rc = ensure(c, *u.b, u.bytes + 16))) return rc;
+        if (u.bytes) HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ensure(c, c->dMatch, 4 * (size_t) n_f)) || (rc = ensure(c, c->dOwner, (size_t) n_f)) || (rc = ensure(c, c->dNMatch, 4)) ||
+        (rc = ensure(c, G[9], 4 * 32)))
+        return rc;
+    HIPCHECK(c, hipMemsetAsync(c->dMatch.p, 0xFF, 4 * (size_t) n_f, c->stream));
+    HIPCHECK(c, hipMemsetAsync(c->dNMatch.p, 0, 4, c->stream));
+    HIPCHECK(c, hipMemsetAsync(G[9].p, 0, 4 * 32, c->stream));
+    {
+        ProfScope ps(c, KK_MATCH);
+        launch_bow(c->stream, n_nodes, (const int *) G[0].p, (const int *) G[1].p, (const int *) G[2].p, (const int *) G[3].p, (const uint8_t *) G[4].p,
+                   (const ygzf_kp *) G[5].p, (const uint8_t *) G[6].p, n_f, (const ygzf_kp *) G[7].p, (const uint8_t *) G[8].p, nnratio, check_orientation != 0,
+                   (int *) c->dMatch.p, (unsigned char *) c->dOwner.p, (int *) G[9].p, (int *) c->dNMatch.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(match, c->dMatch.p, 4 * (size_t) n_f, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
+
+int ygzf_search_for_initialization(ygzf_ctx *c, const ygzf_frame_view *F1, const ygzf_frame_view *F2, const ygzf_camera *cam, float *prev_matched_xy,
+                                   int window_size, float nnratio, int check_orientation, int *matches12, int *nmatches) {
+    if (!c || !F1 || !F2 || !cam || !nmatches || !matches12 || !prev_matched_xy) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *nmatches = 0;
+    for (int i = 0; i < F1->n; i++) matches12[i] = -1;   // vnMatches12 = vector<int>(F1.N, -1)  (:379)
+    if (F1->n <= 0 || F2->n <= 0) return YGZF_OK;
+    std::vector<float> px(F1->n), py(F1->n);
+    for (int i = 0; i < F1->n; i++) { px[i] = prev_matched_xy[2 * i]; py[i] = prev_matched_xy[2 * i + 1]; }
+    std::vector<uint8_t> owner(F2->n, 0);
+    std::vector<int> match21(F2->n, -1);
+    int rc = projected_match(c, 3, F2, cam, F1->n, nullptr, nullptr, nullptr, px.data(), py.data(), nullptr, nullptr, nullptr, nullptr, F1->desc,
+                             (float) window_size, 0, nnratio, 50, check_orientation, owner.data(), match21.data(), nmatches, F1->keys, matches12);
+    if (rc) return rc;
+    for (int i = 0; i < F1->n; i++)      // :470-474 update prev matched
+        if (matches12[i] >= 0) {
+            prev_matched_xy[2 * i] = F2->keys[matches12[i]].x;
+            prev_matched_xy[2 * i + 1] = F2->keys[matches12[i]].y;
+        }
     return YGZF_OK;
 }
 

@@ -159,6 +159,40 @@ int main(int argc, char **argv) {
         dump(dir + "/match3.bin", assigned3.data(), assigned3.size() * sizeof(int));
         dump(dir + "/nmatch3.bin", &nm3, sizeof nm3);
     }
+    // MonocularInitialization: SearchForInitialization(ini, cur, prevMatched, matches, 100)  (src/Tracking.cc:741-743)
+    {
+        std::vector<cv::Point2f> prev(A.N);
+        for (int i = 0; i < A.N; i++) prev[i] = A.mvKeys[i].pt;
+        std::vector<int> m12;
+        ORBmatcher matcher4(0.9f, true);
+        const int nm4 = matcher4.SearchForInitialization(A, B, prev, m12, 100);
+        dump(dir + "/match4.bin", m12.data(), m12.size() * sizeof(int));
+        dump(dir + "/prev4.bin", prev.data(), prev.size() * sizeof(cv::Point2f));
+        dump(dir + "/nmatch4.bin", &nm4, sizeof nm4);
+    }
+    // TrackReferenceKeyFrame: SearchByBoW(refKF, cur, out)  (src/Tracking.cc:934-936); FeatureVector stand-in: node = leading descriptor bits
+    {
+        KeyFrame KF;
+        KF.mvKeys = A.mvKeys;
+        KF.mDescriptors = A.mDescriptors;
+        for (int i = 0; i < A.N; i++) {
+            KF.mvpMapPoints.push_back((i % 9 == 0) ? nullptr : &mps[i]);
+            KF.mFeatVec[A.mDescriptors.ptr<unsigned char>(i)[0] >> 3].push_back(i);
+        }
+        Frame B3 = B;
+        for (int i = 0; i < B3.N; i++) {
+            const unsigned node = B3.mDescriptors.ptr<unsigned char>(i)[0] >> 3;
+            if (node != 7) B3.mFeatVec[node].push_back(i);                     // a node missing on one side exercises lower_bound
+        }
+        std::vector<MapPoint *> out;
+        ORBmatcher matcher5(0.7f, true);
+        const int nm5 = matcher5.SearchByBoW(&KF, B3, out);
+        std::vector<int> assigned5(B3.N, -1);
+        for (int i = 0; i < B3.N; i++)
+            if (out[i]) assigned5[i] = (int) (out[i] - mps.data());
+        dump(dir + "/match5.bin", assigned5.data(), assigned5.size() * sizeof(int));
+        dump(dir + "/nmatch5.bin", &nm5, sizeof nm5);
+    }
     cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
     printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));
     return 0;

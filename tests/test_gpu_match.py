@@ -170,3 +170,64 @@ def test_search_by_projection_keyframe(oracle):
         assert ((g_o != 0) == (e_o != 0)).all()
         if th >= 10:
             assert e_n > 50
+
+
+def test_search_for_initialization(oracle):
+    """SearchForInitialization (monocular initialisation, src/ORBmatcher.cc:375-478): matches12, count and the updated vbPrevMatched."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    base = synth_frame(70, w + 32, h + 32)
+    a, b = base[16:16 + h, 16:16 + w], base[20:20 + h, 9:9 + w]
+    ex = Extractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)     # the Ini extractor: 2 x nFeatures
+    oex = oracle.Extractor(2000, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    cam = make_camera(w, h)
+    prev = np.stack([ka["x"], ka["y"]], -1).astype(np.float32)                      # vbPrevMatched starts as F1's own positions
+    for window, ratio, ori in ((100, 0.9, True), (30, 0.9, True), (100, 0.6, False), (100, 0.05, True)):
+        e_n, e_m, e_p = oracle.search_for_initialization(ka, da, kb, db, sf, w, h, EUROC, prev, window, ratio, ori)
+        g_n, g_m, g_p = ex.search_for_initialization(cam, ka, da, kb, db, prev, window, ratio, ori, scale_factors=sf)
+        assert g_n == e_n and (g_m == e_m).all() and (g_p == e_p).all()
+        if ratio >= 0.6:
+            assert e_n > 50
+    # a second round starts from the updated positions (the reference calls it once per frame until initialisation succeeds)
+    e_n, e_m, e_p = oracle.search_for_initialization(ka, da, kb, db, sf, w, h, EUROC, prev, 100, 0.9, True)
+    e_n2, e_m2, e_p2 = oracle.search_for_initialization(ka, da, kb, db, sf, w, h, EUROC, e_p, 100, 0.9, True)
+    g_n2, g_m2, g_p2 = ex.search_for_initialization(cam, ka, da, kb, db, e_p, 100, 0.9, True, scale_factors=sf)
+    assert g_n2 == e_n2 and (g_m2 == e_m2).all() and (g_p2 == e_p2).all()
+
+
+def _fake_feature_vector(desc, bits):
+    """Stand-in for DBoW2's FeatureVector (the vocabulary blob is not shipped): node id = leading descriptor bits."""
+    node = (desc[:, 0].astype(np.int32) >> (8 - bits)) if bits <= 8 else ((desc[:, 0].astype(np.int32) << (bits - 8)) | (desc[:, 1] >> (16 - bits)))
+    return {int(n): np.nonzero(node == n)[0].astype(np.int32) for n in np.unique(node)}
+
+
+def _join(fv_kf, fv_f):
+    nodes = sorted(set(fv_kf) & set(fv_f))               # the merge-join of :169-247
+    ko, fo, ki, fi = [0], [0], [], []
+    for n in nodes:
+        ki.extend(fv_kf[n]); fi.extend(fv_f[n])
+        ko.append(len(ki)); fo.append(len(fi))
+    return np.array(ko, np.int32), np.array(ki, np.int32), np.array(fo, np.int32), np.array(fi, np.int32)
+
+
+def test_search_by_bow(oracle):
+    """SearchByBoW(KF, F) per-node brute force (src/ORBmatcher.cc:155-263) on a joined node list."""
+    from orb_ygz_slam_amd import Extractor
+    w, h = 752, 480
+    base = synth_frame(80, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[9:9 + h, 10:10 + w]
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    rng = np.random.default_rng(5)
+    valid = (rng.uniform(size=len(ka)) > 0.1).astype(np.uint8)
+    for bits, ratio, ori in ((4, 0.7, False), (6, 0.75, True), (1, 0.9, True), (10, 0.7, True)):
+        ko, ki, fo, fi = _join(_fake_feature_vector(da, bits), _fake_feature_vector(db, bits))
+        e_n, e_m = oracle.search_by_bow(ko, ki, fo, fi, valid, ka, da, kb, db, ratio, ori)
+        g_n, g_m = ex.search_by_bow(ko, ki, fo, fi, valid, ka, da, kb, db, ratio, ori)
+        assert g_n == e_n and (g_m == e_m).all()
+        if bits <= 6:
+            assert e_n > 20

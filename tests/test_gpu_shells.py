@@ -119,3 +119,19 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     assigned3 = np.fromfile(tmp_path / "match3.bin", np.int32)
     assert nm3 == e_n3 and nm3 > 50
     assert (assigned3 == np.where(e_m3 >= 0, e_m3, -1)).all()
+    # SearchForInitialization(A, B, prevMatched = A's positions, 100)
+    prev = np.stack([ka["x"], ka["y"]], -1).astype(np.float32)
+    e_n4, e_m4, e_p4 = oracle.search_for_initialization(ka, da, kb, db, sf, w, h, EUROC, prev, 100, 0.9, True)
+    assert int(np.fromfile(tmp_path / "nmatch4.bin", np.int32)[0]) == e_n4 and e_n4 > 50
+    assert (np.fromfile(tmp_path / "match4.bin", np.int32) == e_m4).all()
+    assert (np.fromfile(tmp_path / "prev4.bin", np.float32).reshape(-1, 2) == e_p4).all()
+    # SearchByBoW(KF = A, F = B) with the stand-in FeatureVectors (node = first descriptor byte >> 3; node 7 absent in F)
+    na, nb = da[:, 0].astype(np.int32) >> 3, db[:, 0].astype(np.int32) >> 3
+    nodes = sorted((set(na.tolist()) & set(nb.tolist())) - {7})
+    ko, fo, ki, fi = [0], [0], [], []
+    for n in nodes:
+        ki.extend(np.nonzero(na == n)[0]); fi.extend(np.nonzero(nb == n)[0])
+        ko.append(len(ki)); fo.append(len(fi))
+    e_n5, e_m5 = oracle.search_by_bow(ko, ki, fo, fi, (idx % 9 != 0).astype(np.uint8), ka, da, kb, db, 0.7, True)
+    assert int(np.fromfile(tmp_path / "nmatch5.bin", np.int32)[0]) == e_n5 and e_n5 > 20
+    assert (np.fromfile(tmp_path / "match5.bin", np.int32) == np.where(e_m5 >= 0, e_m5, -1)).all()
