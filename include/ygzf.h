@@ -237,6 +237,21 @@ int ygzf_extract_dso(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride
  * recompute_angle = 1: IC_Angle first (what ComputeKeyPointsDSOSingleLevel does to them, :1380-1383), returned in angles_out. */
 int ygzf_describe_keys(ygzf_ctx *ctx, int frame, const ygzf_kp *keys, int n, int recompute_angle, float *angles_out, uint8_t *desc);
 
+/* ---- Frame::ComputeStereoMatches()   src/Frame.cc:509-682 (the step right after stereo extraction) ------------------------
+ * Per left keypoint: best Hamming match among the right keypoints whose row band covers its row (octave +-1, disparity range
+ * [0, mbf/mb]), accepted below (TH_HIGH+TH_LOW)/2; 11x11 SAD of the centre-subtracted patches over +-5 px on the keypoint's pyramid
+ * level of both eyes; parabola sub-pixel fit; mvuRight / mvDepth; finally matches with SAD >= 1.5*1.4*median are dropped.
+ * u_right / depth: n_left floats each, -1 = no match.  Defined where the reference is not: an empty match list skips the median cut.
+ * Host-array form (what the Frame member is bound to): both level-0 images, the pyramids are recomputed on the
+ * device -- the extractors' host pyramids come from the same ComputePyramid.  The context must be created with max_batch >= 2. */
+int ygzf_compute_stereo_matches(ygzf_ctx *ctx, const uint8_t *img_left, const uint8_t *img_right, int w, int h, int stride, int n_left,
+                                const ygzf_kp *keys_left, const uint8_t *desc_left, int n_right, const ygzf_kp *keys_right, const uint8_t *desc_right,
+                                float mb, float mbf, float *u_right, float *depth);
+/* Batch-resident form: the last extracted batch holds (left, right) image pairs, frames 2p / 2p+1; keys, descriptors and pyramids stay
+ * on the device.  ygzf_stereo_fetch copies pair p's mvuRight / mvDepth (as many as the left frame has keypoints). */
+int ygzf_stereo_batch(ygzf_ctx *ctx, float mb, float mbf);
+int ygzf_stereo_fetch(ygzf_ctx *ctx, int pair, float *u_right, float *depth, int cap);
+
 /* ---- Thirdparty/fast (Rosten FAST-10/16), replaced outright: fast::fast_corner_detect_10_sse2 + fast::fast_corner_score_10
  *      + fast::fast_nonmax_3x3  (Thirdparty/fast/include/fast/fast.h:19-29; called at src/ORBextractor.cc:1220-1235,
  *      :1330-1340, :1440-1450) on the window [x0,x0+w) x [y0,y0+h) of a host image -----------------------------------------

@@ -361,6 +361,20 @@ size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur,
     return r.ret;
 }
 
+// Frame::ComputeStereoMatches on two images: both pyramids are computed with extractor e (as the two ORBextractor instances do)
+void yo_compute_stereo_matches(void *e_, const uint8_t *imgL, const uint8_t *imgR, int w, int h, int N, const KeyPoint *keysL,
+                               const uint8_t *descL, int Nr, const KeyPoint *keysR, const uint8_t *descR, float mb, float mbf, float *uRight,
+                               float *depth) {
+    Extractor *e = (Extractor *) e_;
+    e->ComputePyramid(imgL, w, h, w);
+    std::vector<Image> L = e->mvImagePyramid;
+    e->ComputePyramid(imgR, w, h, w);
+    std::vector<Image> R = e->mvImagePyramid;
+    std::vector<const Image *> pl, pr;
+    for (int l = 0; l < e->nlevels; l++) { pl.push_back(&L[l]); pr.push_back(&R[l]); }
+    compute_stereo_matches(N, keysL, descL, Nr, keysR, descR, pl, pr, e->mvScaleFactor.data(), e->mvInvScaleFactor.data(), mb, mbf, uRight, depth);
+}
+
 // ---- cpu_baseline helper: extract + frame-to-frame projection match over a list of frames, `threads` workers ----
 // Frames are u8 images of identical size laid out back to back.  Frame f (f >= 1) is matched against frame f-1
 // with an identity relative pose and unit-depth back-projected points (SURVEY §8d metric definition).

@@ -163,6 +163,19 @@ class Extractor:
         self.L.yo_describe_keys(self.h, _p(img), w, h, w, _p(k), len(k), int(recompute_angle), _p(d))
         return k, d
 
+    def compute_stereo_matches(self, img_l, img_r, keys_l, desc_l, keys_r, desc_r, mb, mbf):
+        """Frame::ComputeStereoMatches -> (mvuRight, mvDepth)."""
+        il, ir = np.ascontiguousarray(img_l, np.uint8), np.ascontiguousarray(img_r, np.uint8)
+        h, w = il.shape
+        kl, kr = np.ascontiguousarray(keys_l, KP_DTYPE), np.ascontiguousarray(keys_r, KP_DTYPE)
+        dl, dr = np.ascontiguousarray(desc_l, np.uint8), np.ascontiguousarray(desc_r, np.uint8)
+        ur, dp = np.zeros(max(len(kl), 1), np.float32), np.zeros(max(len(kl), 1), np.float32)
+        self.L.yo_compute_stereo_matches.restype = None
+        self.L.yo_compute_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        self.L.yo_compute_stereo_matches(self.h, _p(il), _p(ir), w, h, len(kl), _p(kl), _p(dl), len(kr), _p(kr), _p(dr), mb, mbf, _p(ur), _p(dp))
+        return ur[:len(kl)], dp[:len(kl)]
+
     def shi_tomasi(self, img, u, v):
         img = np.ascontiguousarray(img, np.uint8)
         self.L.yo_shi_tomasi.restype = C.c_float

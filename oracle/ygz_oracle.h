@@ -209,5 +209,13 @@ struct AlignResult {
 AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level,
                              int n_iter);
 
+// ---- Frame::ComputeStereoMatches  src/Frame.cc:509-682 -------------------------------------------------------------------------
+// Left/right keys + descriptors, both extractors' pyramids (tight levels), mvScaleFactors / mvInvScaleFactors, mb, mbf.
+// Out: mvuRight / mvDepth (N floats each, -1 = no match).  Defined where the reference is not: an empty match list skips the median
+// cut (the reference reads vDistIdx[0] of an empty vector); right keys whose row band leaves the image are clipped to it.
+void compute_stereo_matches(int N, const KeyPoint *keysL, const uint8_t *descL, int Nr, const KeyPoint *keysR, const uint8_t *descR,
+                            const std::vector<const Image *> &pyrL, const std::vector<const Image *> &pyrR, const float *scaleFactors,
+                            const float *invScaleFactors, float mb, float mbf, float *uRight, float *depth);
+
 }  // namespace ygzo
 #endif

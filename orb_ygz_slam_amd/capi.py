@@ -96,6 +96,9 @@ def load_library(build_if_missing=True):
     L.ygzf_search_for_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int,
                                                  vp, ip]
     L.ygzf_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_float, C.c_int, vp, ip]
+    L.ygzf_compute_stereo_matches.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp]
+    L.ygzf_stereo_batch.argtypes = [vp, C.c_float, C.c_float]
+    L.ygzf_stereo_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
@@ -455,6 +458,27 @@ class Extractor:
         d = np.zeros((len(k), 32), np.uint8)
         self._ck(self.L.ygzf_describe_keys(self.h, frame, _p(k), len(k), int(recompute_angle), _p(ang), _p(d)))
         return ang, d
+
+    def compute_stereo_matches(self, img_l, img_r, keys_l, desc_l, keys_r, desc_r, mb, mbf):
+        """Frame::ComputeStereoMatches on host arrays -> (mvuRight, mvDepth)."""
+        il, ir = np.ascontiguousarray(img_l, np.uint8), np.ascontiguousarray(img_r, np.uint8)
+        h, w = il.shape
+        kl, kr = np.ascontiguousarray(keys_l, KP_DTYPE), np.ascontiguousarray(keys_r, KP_DTYPE)
+        dl, dr = np.ascontiguousarray(desc_l, np.uint8), np.ascontiguousarray(desc_r, np.uint8)
+        ur, dp = np.zeros(max(len(kl), 1), np.float32), np.zeros(max(len(kl), 1), np.float32)
+        self._ck(self.L.ygzf_compute_stereo_matches(self.h, _p(il), _p(ir), w, h, w, len(kl), _p(kl), _p(dl), len(kr), _p(kr), _p(dr), mb, mbf,
+                                                    _p(ur), _p(dp)))
+        return ur[:len(kl)], dp[:len(kl)]
+
+    def stereo_batch(self, mb, mbf):
+        self._ck(self.L.ygzf_stereo_batch(self.h, mb, mbf))
+
+    def stereo_fetch(self, pair):
+        w, h, _ = self._wh
+        cap = max(self.max_keypoints(w, h), 1)
+        ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+        self._ck(self.L.ygzf_stereo_fetch(self.h, pair, _p(ur), _p(dp), cap))
+        return ur, dp
 
     def timer_start(self):
         self._ck(self.L.ygzf_timer_start(self.h))

@@ -24,7 +24,7 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
     ygzf_destroy(mCtx);
     mCtx = nullptr;
     ygzf_extractor_cfg cfg = {nfeatures, (float) scaleFactor, nlevels, iniThFAST, minThFAST};
-    if (ygzf_create(sDevice, &cfg, w, h, 1, &mCtx) != YGZF_OK) {
+    if (ygzf_create(sDevice, &cfg, w, h, 2, &mCtx) != YGZF_OK) {   // 2 frames: the stereo matcher stages both eyes
         fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(nullptr));
         mCtx = nullptr;
         return nullptr;
@@ -140,6 +140,26 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
     for (int i = 0; i < N && i < nkeypoints; i++) std::memcpy(d.ptr<uint8_t>(i), &descExisting[(size_t) i * 32], 32);
     for (int i = 0; i < (int) fresh.size() && N + i < nkeypoints; i++) std::memcpy(d.ptr<uint8_t>(N + i), &descNew[(size_t) i * 32], 32);   // offset = frame->N
     _keypoints.insert(_keypoints.end(), fresh.begin(), fresh.end());
+}
+
+// Body for ygz::Frame::ComputeStereoMatches (src/Frame.cc:509-682), see INTEGRATION.md: the left extractor's context stages both
+// eyes' level-0 images, rebuilds their pyramids on the device and runs the row-band Hamming search + SAD refinement + median cut.
+void ORBextractor::ComputeStereoMatches(Frame &F) {
+    F.mvuRight = std::vector<float>(F.N, -1.0f);
+    F.mvDepth = std::vector<float>(F.N, -1.0f);
+    if (F.N <= 0) return;
+    const cv::Mat &imL = F.mvImagePyramid.empty() ? F.mImGray : F.mvImagePyramid[0];
+    ygzf_ctx *c = ensureContext(imL.cols, imL.rows);
+    if (!c) return;
+    const int Nr = (int) F.mvKeysRight.size();
+    std::vector<uint8_t> dl((size_t) F.N * 32), dr((size_t) Nr * 32);
+    for (int i = 0; i < F.N; i++) std::memcpy(&dl[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
+    for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t) i * 32], F.mDescriptorsRight.ptr<uint8_t>(i), 32);
+    if (imL.step != F.mImRight.step) { fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: left/right row steps differ\n"); return; }
+    if (ygzf_compute_stereo_matches(c, imL.ptr<uint8_t>(0), F.mImRight.ptr<uint8_t>(0), imL.cols, imL.rows, (int) imL.step, F.N,
+                                    (const ygzf_kp *) F.mvKeys.data(), dl.data(), Nr, (const ygzf_kp *) F.mvKeysRight.data(), dr.data(), F.mb, F.mbf,
+                                    F.mvuRight.data(), F.mvDepth.data()) != YGZF_OK)
+        fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: %s\n", ygzf_last_error(c));
 }
 
 }  // namespace ygz

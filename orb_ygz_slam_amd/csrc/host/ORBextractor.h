@@ -39,6 +39,9 @@ public:
     std::vector<cv::Mat> mvImagePyramid;
     void ComputePyramid(cv::Mat image);
 
+    // Not in the reference class: the body Frame::ComputeStereoMatches (src/Frame.cc:509-682) is bound to.
+    void ComputeStereoMatches(Frame &F);
+
     // Device on which new extractors create their context (default 0); set before constructing.
     static int sDevice;
 

@@ -139,9 +139,9 @@ public:
     int N = 0;
     cv::Mat mImGray, mImRight;
     std::vector<cv::Mat> mvImagePyramid;
-    std::vector<cv::KeyPoint> mvKeys;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
     std::vector<float> mvuRight, mvDepth;
-    cv::Mat mDescriptors;
+    cv::Mat mDescriptors, mDescriptorsRight;
     std::vector<MapPoint *> mvpMapPoints;
     std::vector<bool> mvbOutlier;
     std::vector<float> mvScaleFactors, mvInvScaleFactors;

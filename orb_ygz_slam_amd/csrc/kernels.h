@@ -98,6 +98,35 @@ void launch_dso_compact(hipStream_t st, const int *cellCnt, const unsigned *cell
 void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,
                           float *outAngle, uint8_t *outDesc);
 
+// ---- Frame::ComputeStereoMatches (stereo_kernels.hip) ---------------------------------------------------------------------
+struct StereoRec {   // per right keypoint: x, row band (min | max << 16), octave
+    float x;
+    unsigned band;
+    int octave;
+};
+struct StereoArgs {
+    // keys / descriptors of pair p: left at keys[p*keyStride + keyOffL + i], right at keys[p*keyStride + keyOffR + i] (desc alike, x32)
+    const ygzf_kp *keys;
+    const uint8_t *desc;
+    long long keyStride;
+    int keyOffL, keyOffR;
+    const int *cnt;                // counts of pair p at cnt[p*cntStride + cntOffL / cntOffR]
+    int cntStride, cntOffL, cntOffR;
+    // pyramids: left image of pair p = frame frame0 + p*frameStep of fs, right = the next frame
+    FrameSet fs;
+    const LevelGeom *geom;
+    int frame0, frameStep;
+    float scale[kMaxLevels], invScale[kMaxLevels];
+    float mb, mbf;
+    int nRows;                     // rows of level 0
+    StereoRec *rec;                // scratch, pair p at rec + p*recStride
+    long long recStride;
+    float *uRight, *depth;         // outputs, pair p at + p*outStride, one per left keypoint
+    int *sad;                      // accepted SAD per left keypoint (-1: no match), same stride
+    long long outStride;
+};
+void launch_stereo(hipStream_t st, const StereoArgs &A, int nPairs, int maxLeft, int maxRight);
+
 // ---- sparse image alignment (align_kernels.hip) ----------------------------------------------------------------------
 struct SiaLevel {
     const uint8_t *img;

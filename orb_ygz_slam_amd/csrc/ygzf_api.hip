@@ -63,9 +63,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -98,7 +98,8 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8];
+        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6];
+    int lastStereoPairs = 0;
     bool alignCarry = false;      // keep the last frame's pyramid across batches (enabled by the first ygzf_align_batch_prev)
     bool carryPyrValid = false;
     int lastAlignPairs = 0;
@@ -457,6 +458,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     c->carryValid = true;
     c->lastMatchPairs = 0;
     c->lastAlignPairs = 0;
+    c->lastStereoPairs = 0;
     return YGZF_OK;
 }
 
@@ -543,6 +545,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &b : c->dAl)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dDso)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dSt)
         if (b.p) (void) hipFree(b.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
@@ -1533,6 +1537,156 @@ int ygzf_search_by_projection_kf(ygzf_ctx *c, const ygzf_frame_view *cur, const 
     for (int i = 0; i < cur->n; i++) owner[i] = owner[i] ? 2 : 0;   // `if (CurrentFrame.mvpMapPoints[i2]) continue;` (:1419): any MapPoint blocks
     return projected_match(c, 2, cur, cam, n_mp, valid, nullptr, nullptr, proj_x, proj_y, nullptr, nullptr, pred_level, kf_angle, mp_desc, th, 0,
                            0.f, orb_dist, check_orientation, owner, match, nmatches);
+}
+
+// ---- Frame::ComputeStereoMatches ----------------------------------------------------------------------------------------------
+static void fill_stereo_common(ygzf_ctx *c, StereoArgs &A, float mb, float mbf, int h) {
+    const int L = c->tab.cfg.nlevels;
+    for (int l = 0; l < kMaxLevels; l++) {
+        A.scale[l] = l < L ? c->tab.scale[l] : 1.f;
+        A.invScale[l] = l < L ? c->tab.invScale[l] : 1.f;
+    }
+    A.mb = mb;
+    A.mbf = mbf;
+    A.nRows = h;
+    A.geom = (const LevelGeom *) c->dGeom.p;
+}
+
+int ygzf_stereo_batch(ygzf_ctx *c, float mb, float mbf) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (c->lastFrames < 2 || (c->lastFrames & 1)) return fail(c, YGZF_ERR_STATE, "stereo needs an extracted batch of (left, right) frame pairs");
+    if (!(mb > 0)) return fail(c, YGZF_ERR_INVALID, "baseline mb must be positive");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const Geometry &G = c->geo;
+    const int P = c->lastFrames / 2;
+    if (G.kpStride > 65535) return fail(c, YGZF_ERR_UNSUPPORTED, "more than 65535 keypoints per frame");
+    int rc;
+    const size_t per = (size_t) G.kpStride;
+    if ((rc = ensure(c, c->dSt[0], sizeof(StereoRec) * per * P + 64)) || (rc = ensure(c, c->dSt[1], 4 * per * P + 64)) ||
+        (rc = ensure(c, c->dSt[2], 4 * per * P + 64)) || (rc = ensure(c, c->dSt[3], 4 * per * P + 64)))
+        return rc;
+    StereoArgs A;
+    memset(&A, 0, sizeof A);
+    A.keys = (const ygzf_kp *) c->dOutKp.p;       // slot 0 = carry; frame f lives in slot f + 1
+    A.desc = (const uint8_t *) c->dOutDesc.p;
+    A.keyStride = 2 * (long long) G.kpStride;
+    A.keyOffL = G.kpStride;
+    A.keyOffR = 2 * G.kpStride;
+    A.cnt = (const int *) c->dOutCnt.p;
+    A.cntStride = 2;
+    A.cntOffL = 1;
+    A.cntOffR = 2;
+    A.fs = c->lastFs;
+    A.frame0 = 0;
+    A.frameStep = 2;
+    fill_stereo_common(c, A, mb, mbf, G.h);
+    A.rec = (StereoRec *) c->dSt[0].p;
+    A.recStride = (long long) per;
+    A.uRight = (float *) c->dSt[1].p;
+    A.depth = (float *) c->dSt[2].p;
+    A.sad = (int *) c->dSt[3].p;
+    A.outStride = (long long) per;
+    {
+        ProfScope ps(c, KK_STEREO);
+        launch_stereo(c->stream, A, P, G.kpStride, G.kpStride);
+    }
+    HIPCHECK(c, hipGetLastError());
+    c->lastStereoPairs = P;
+    return YGZF_OK;
+}
+
+int ygzf_stereo_fetch(ygzf_ctx *c, int pair, float *u_right, float *depth, int cap) {
+    if (!c || !u_right || !depth) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (pair < 0 || pair >= c->lastStereoPairs) return fail(c, YGZF_ERR_STATE, "pair %d: no stereo result", pair);
+    int n = 0;
+    HIPCHECK(c, hipMemcpyAsync(&n, (int *) c->dOutCnt.p + 1 + 2 * pair, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (n > cap) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d left keypoints", cap, n);
+    if (n == 0) return YGZF_OK;
+    const size_t off = (size_t) pair * c->geo.kpStride;
+    HIPCHECK(c, hipMemcpyAsync(u_right, (float *) c->dSt[1].p + off, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(depth, (float *) c->dSt[2].p + off, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_compute_stereo_matches(ygzf_ctx *c, const uint8_t *img_left, const uint8_t *img_right, int w, int h, int stride, int n_left,
+                                const ygzf_kp *keys_left, const uint8_t *desc_left, int n_right, const ygzf_kp *keys_right, const uint8_t *desc_right,
+                                float mb, float mbf, float *u_right, float *depth) {
+    if (!c || !img_left || !img_right) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n_left < 0 || n_right < 0 || n_right > 65535) return fail(c, YGZF_ERR_INVALID, "bad keypoint counts");
+    if (n_left == 0) return YGZF_OK;
+    if (!keys_left || !desc_left || !u_right || !depth || (n_right > 0 && (!keys_right || !desc_right))) return fail(c, YGZF_ERR_INVALID, "null array");
+    if (!(mb > 0)) return fail(c, YGZF_ERR_INVALID, "baseline mb must be positive");
+    const int L = c->tab.cfg.nlevels;
+    for (int i = 0; i < n_left; i++) if (keys_left[i].octave < 0 || keys_left[i].octave >= L) return fail(c, YGZF_ERR_INVALID, "left key %d: octave out of range", i);
+    for (int i = 0; i < n_right; i++) if (keys_right[i].octave < 0 || keys_right[i].octave >= L) return fail(c, YGZF_ERR_INVALID, "right key %d: octave out of range", i);
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (c->maxBatch < 2) return fail(c, YGZF_ERR_INVALID, "context created with max_batch < 2");
+    int rc = apply_geometry(c, w, h, 2);
+    if (rc) return rc;
+    // both eyes' pyramids: the two extractor instances computed exactly these levels (ComputePyramid), recomputed here on the device
+    std::vector<uint8_t> both((size_t) 2 * w * h);
+    for (int y = 0; y < h; y++) {
+        memcpy(&both[(size_t) y * w], img_left + (size_t) y * stride, w);
+        memcpy(&both[(size_t) (h + y) * w], img_right + (size_t) y * stride, w);
+    }
+    FrameSet fs;
+    if ((rc = upload_frames(c, both.data(), 2, w, h, w, (size_t) w * h, &fs))) return rc;
+    const Geometry &G = c->geo;
+    for (int l = 1; l < L; l++) {
+        ProfScope ps(c, KK_PYR);
+        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, G.lv[l], l, 2, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
+                          (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+    }
+    c->lastFrames = 0;
+    c->carryValid = false;
+    const size_t nk = (size_t) n_left + n_right;
+    int counts[2] = {n_left, n_right};
+    if ((rc = ensure(c, c->dSt[0], sizeof(StereoRec) * (size_t) (n_right + 1))) || (rc = ensure(c, c->dSt[1], 4 * (size_t) n_left)) ||
+        (rc = ensure(c, c->dSt[2], 4 * (size_t) n_left)) || (rc = ensure(c, c->dSt[3], 4 * (size_t) n_left)) ||
+        (rc = ensure(c, c->dSt[4], sizeof(ygzf_kp) * nk + 64)) || (rc = ensure(c, c->dSt[5], 32 * nk + 64)))
+        return rc;
+    uint8_t *dk = (uint8_t *) c->dSt[4].p, *dd = (uint8_t *) c->dSt[5].p;
+    HIPCHECK(c, hipMemcpyAsync(dk, keys_left, sizeof(ygzf_kp) * (size_t) n_left, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(dd, desc_left, 32 * (size_t) n_left, hipMemcpyHostToDevice, c->stream));
+    if (n_right > 0) {
+        HIPCHECK(c, hipMemcpyAsync(dk + sizeof(ygzf_kp) * (size_t) n_left, keys_right, sizeof(ygzf_kp) * (size_t) n_right, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(dd + 32 * (size_t) n_left, desc_right, 32 * (size_t) n_right, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ensure(c, c->dNMatch, 8))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->dNMatch.p, counts, sizeof counts, hipMemcpyHostToDevice, c->stream));
+    StereoArgs A;
+    memset(&A, 0, sizeof A);
+    A.keys = (const ygzf_kp *) dk;
+    A.desc = dd;
+    A.keyStride = (long long) nk;
+    A.keyOffL = 0;
+    A.keyOffR = n_left;
+    A.cnt = (const int *) c->dNMatch.p;
+    A.cntStride = 2;
+    A.cntOffL = 0;
+    A.cntOffR = 1;
+    A.fs = fs;
+    A.frame0 = 0;
+    A.frameStep = 2;
+    fill_stereo_common(c, A, mb, mbf, h);
+    A.rec = (StereoRec *) c->dSt[0].p;
+    A.recStride = n_right + 1;
+    A.uRight = (float *) c->dSt[1].p;
+    A.depth = (float *) c->dSt[2].p;
+    A.sad = (int *) c->dSt[3].p;
+    A.outStride = n_left;
+    {
+        ProfScope ps(c, KK_STEREO);
+        launch_stereo(c->stream, A, 1, n_left, n_right);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(u_right, c->dSt[1].p, 4 * (size_t) n_left, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(depth, c->dSt[2].p, 4 * (size_t) n_left, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->lastStereoPairs = 0;
+    return YGZF_OK;
 }
 
 // ---- SparseImgAlign over a resident batch ---------------------------------------------------------------------------------

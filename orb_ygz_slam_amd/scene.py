@@ -66,3 +66,20 @@ def two_view_scene(seed, w, h, cam, Z=4.0, rotvec=(0.004, -0.006, 0.003), trans=
         return np.stack([X, Y, np.full_like(X, Z)], -1).astype(np.float32)
 
     return imgA, imgB, (R, t), backproject
+
+
+def stereo_scene(seed, w=752, h=480, disparities=(3, 7, 12, 20, 33, 48, 5, 9), noise=3):
+    """A rectified stereo pair: horizontal bands of the left image re-appear in the right image shifted by a known disparity
+    (+ small independent noise).  Returns (left, right, band height, disparities)."""
+    from .synth import synth_frame
+    pad = 64 + max(disparities)
+    base = synth_frame(seed, w + 2 * pad, h)
+    left = np.ascontiguousarray(base[:, pad:pad + w])
+    right = np.zeros_like(left)
+    bh = (h + len(disparities) - 1) // len(disparities)
+    for b, d in enumerate(disparities):
+        right[b * bh:(b + 1) * bh] = base[b * bh:(b + 1) * bh, pad + d:pad + d + w]
+    rng = np.random.default_rng(seed + 1000)
+    if noise:
+        right = np.clip(right.astype(np.int32) + rng.integers(-noise, noise + 1, right.shape), 0, 255).astype(np.uint8)
+    return left, right, bh, tuple(disparities)

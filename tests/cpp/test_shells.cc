@@ -193,6 +193,19 @@ int main(int argc, char **argv) {
         dump(dir + "/match5.bin", assigned5.data(), assigned5.size() * sizeof(int));
         dump(dir + "/nmatch5.bin", &nm5, sizeof nm5);
     }
+    // stereo: left = A, right eye image r.u8 -> ExtractORB(1, imRight) then ComputeStereoMatches  (src/Frame.cc:728-738)
+    {
+        std::vector<unsigned char> irr = slurp(dir + "/r.u8");
+        Frame S = A;
+        S.mImRight = cv::Mat(H, W, CV_8UC1, irr.data());
+        S.mb = 0.11f; S.mbf = 47.9f;
+        ORBextractor exR(600, 1.2f, L, 20, 7);
+        exR(&S, S.mvKeysRight, cv::_OutputArray(S.mDescriptorsRight), ORBextractor::ORBSLAM_KEYPOINT, false);
+        ex.ComputeStereoMatches(S);
+        dump(dir + "/s_kpsr.bin", S.mvKeysRight.data(), S.mvKeysRight.size() * sizeof(cv::KeyPoint));
+        dump(dir + "/s_uright.bin", S.mvuRight.data(), S.mvuRight.size() * sizeof(float));
+        dump(dir + "/s_depth.bin", S.mvDepth.data(), S.mvDepth.size() * sizeof(float));
+    }
     cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
     printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));
     return 0;

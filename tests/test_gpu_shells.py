@@ -43,6 +43,10 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     imgA.tofile(tmp_path / "a.u8")
     imgB.tofile(tmp_path / "b.u8")
     np.array([depth], np.float32).tofile(tmp_path / "depth.f32")
+    imgR = np.zeros_like(imgA)                      # right eye of A: bands of A shifted by known disparities
+    for bnd, dsp in enumerate((4, 9, 15, 22, 30, 6)):
+        imgR[bnd * 80:(bnd + 1) * 80, :w - dsp] = imgA[bnd * 80:(bnd + 1) * 80, dsp:]
+    imgR.tofile(tmp_path / "r.u8")
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shells ok" in out.stdout
@@ -135,3 +139,10 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     e_n5, e_m5 = oracle.search_by_bow(ko, ki, fo, fi, (idx % 9 != 0).astype(np.uint8), ka, da, kb, db, 0.7, True)
     assert int(np.fromfile(tmp_path / "nmatch5.bin", np.int32)[0]) == e_n5 and e_n5 > 20
     assert (np.fromfile(tmp_path / "match5.bin", np.int32) == np.where(e_m5 >= 0, e_m5, -1)).all()
+    # stereo: right-eye extraction through the shell (leftEye = false) + ComputeStereoMatches
+    kr, dr = oex.extract(imgR)
+    assert (np.fromfile(tmp_path / "s_kpsr.bin", KP_DTYPE) == kr).all()
+    our, odp = oex.compute_stereo_matches(imgA, imgR, ka, da, kr, dr, 0.11, 47.9)
+    sur, sdp = np.fromfile(tmp_path / "s_uright.bin", np.float32), np.fromfile(tmp_path / "s_depth.bin", np.float32)
+    assert (sur.view(np.uint32) == our.view(np.uint32)).all() and (sdp.view(np.uint32) == odp.view(np.uint32)).all()
+    assert (our >= 0).sum() > 100
