@@ -252,6 +252,25 @@ int ygzf_compute_stereo_matches(ygzf_ctx *ctx, const uint8_t *img_left, const ui
 int ygzf_stereo_batch(ygzf_ctx *ctx, float mb, float mbf);
 int ygzf_stereo_fetch(ygzf_ctx *ctx, int pair, float *u_right, float *depth, int cap);
 
+/* ---- ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level)
+ *      src/ORBmatcher.cc:1574-1602 with GetWarpAffineMatrix :1525-1548, GetBestSearchLevel / GetBilateralInterpUchar
+ *      include/ORBmatcher.h:185-211, WarpAffine :1550-1572 and ygz::Align2D src/Align.cc:8-104    ----------------------------
+ * Tracking::SearchLocalPointsDirect (src/Tracking.cc:2174-2326) calls it once per (MapPoint, observing KeyFrame) candidate; the device
+ * form takes the independent candidates as one batch.  The images live in an HBM-resident cache: every KeyFrame (and the current frame)
+ * is put once -- its pyramid is built on the device -- and referenced by slot afterwards.
+ *   ygzf_image_cache_reserve : n_slots images of w x h (the extractor configuration of the context defines the pyramid)
+ *   ygzf_image_cache_put     : upload a level-0 image into a slot and build its pyramid
+ *   ygzf_find_direct_projection_batch : candidate i = (ref_slot[i], ref_Tcw7[i] = ref->GetPose() as quaternion x,y,z,w + translation,
+ *       ref_kp[i] = ref->mvKeys[mp->GetObservations()[ref]], mp_world[i] = mp->GetWorldPos()); cur_Tcw7 = curr->mTcw;
+ *       px_curr (n x 2, in/out): initial guess (mTrackProjX/Y) -> refined pixel; search_level / success (the bool result) out;
+ *       patches_with_border (nullable, n x 100): the warped 10x10 reference patches, for tests.
+ * Results equal the CPU definition bit for bit (one thread per candidate keeps the reference's sequential accumulation order). */
+int ygzf_image_cache_reserve(ygzf_ctx *ctx, int n_slots, int w, int h);
+int ygzf_image_cache_put(ygzf_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride);
+int ygzf_find_direct_projection_batch(ygzf_ctx *ctx, const ygzf_camera *cam, int cur_slot, const float *cur_Tcw7, int n, const int *ref_slot,
+                                      const float *ref_Tcw7, const ygzf_kp *ref_kp, const float *mp_world, float *px_curr, int *search_level,
+                                      uint8_t *success, uint8_t *patches_with_border);
+
 /* ---- Thirdparty/fast (Rosten FAST-10/16), replaced outright: fast::fast_corner_detect_10_sse2 + fast::fast_corner_score_10
  *      + fast::fast_nonmax_3x3  (Thirdparty/fast/include/fast/fast.h:19-29; called at src/ORBextractor.cc:1220-1235,
  *      :1330-1340, :1440-1450) on the window [x0,x0+w) x [y0,y0+h) of a host image -----------------------------------------

@@ -375,6 +375,41 @@ void yo_compute_stereo_matches(void *e_, const uint8_t *imgL, const uint8_t *img
     compute_stereo_matches(N, keysL, descL, Nr, keysR, descR, pl, pr, e->mvScaleFactor.data(), e->mvInvScaleFactor.data(), mb, mbf, uRight, depth);
 }
 
+// FindDirectProjection for n candidates: reference KeyFrame images ref_imgs[ref_slot[i]] (all w x h), one current image; every pyramid is
+// computed with extractor e.  px_curr (n x 2) in/out, search_level / success out, patches (n x 100, may be null) = _patch_with_border.
+void yo_find_direct_projection_batch(void *e_, int n_refs, const uint8_t *const *ref_imgs, const uint8_t *cur_img, int w, int h,
+                                     const float *cur_Tcw7, float fx, float fy, float cx, float cy, int n, const int *ref_slot,
+                                     const float *ref_Tcw7, const KeyPoint *ref_kp, const float *mp_world, float *px_curr, int *search_level,
+                                     uint8_t *success, uint8_t *patches) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<std::vector<Image>> refs(n_refs);
+    for (int r = 0; r < n_refs; r++) {
+        e->ComputePyramid(ref_imgs[r], w, h, w);
+        refs[r] = e->mvImagePyramid;
+    }
+    e->ComputePyramid(cur_img, w, h, w);
+    std::vector<Image> cur = e->mvImagePyramid;
+    DirectCur C;
+    std::memcpy(C.Tcw.q, cur_Tcw7, 16);
+    std::memcpy(C.Tcw.t, cur_Tcw7 + 4, 12);
+    for (int l = 0; l < e->nlevels; l++) C.pyramid.push_back(&cur[l]);
+    C.scaleFactors = e->mvScaleFactor.data();
+    C.invScaleFactors = e->mvInvScaleFactor.data();
+    C.fx = fx; C.fy = fy; C.cx = cx; C.cy = cy;
+    for (int i = 0; i < n; i++) {
+        DirectRef R;
+        R.kp = ref_kp[i];
+        std::memcpy(R.Tcw.q, ref_Tcw7 + 7 * i, 16);
+        std::memcpy(R.Tcw.t, ref_Tcw7 + 7 * i + 4, 12);
+        R.level_img = &refs[ref_slot[i]][R.kp.octave];
+        R.scaleFactors = e->mvScaleFactor.data();
+        R.invLevelSigma2_1 = e->mvInvLevelSigma2[e->nlevels > 1 ? 1 : 0];
+        R.nlevels = e->nlevels;
+        R.fx = fx; R.fy = fy; R.cx = cx; R.cy = cy;
+        success[i] = find_direct_projection(R, C, mp_world + 3 * i, px_curr + 2 * i, &search_level[i], patches ? patches + 100 * (size_t) i : nullptr);
+    }
+}
+
 // ---- cpu_baseline helper: extract + frame-to-frame projection match over a list of frames, `threads` workers ----
 // Frames are u8 images of identical size laid out back to back.  Frame f (f >= 1) is matched against frame f-1
 // with an identity relative pose and unit-depth back-projected points (SURVEY §8d metric definition).

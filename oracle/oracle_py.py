@@ -176,6 +176,29 @@ class Extractor:
         self.L.yo_compute_stereo_matches(self.h, _p(il), _p(ir), w, h, len(kl), _p(kl), _p(dl), len(kr), _p(kr), _p(dr), mb, mbf, _p(ur), _p(dp))
         return ur[:len(kl)], dp[:len(kl)]
 
+    def find_direct_projection_batch(self, ref_imgs, cur_img, cur_Tcw7, cam, ref_slot, ref_Tcw7, ref_kp, mp_world, px_curr):
+        """ORBmatcher::FindDirectProjection for n candidates -> (px_curr n x 2, search_level, success, patch_with_border n x 100)."""
+        refs = [np.ascontiguousarray(r, np.uint8) for r in ref_imgs]
+        cur = np.ascontiguousarray(cur_img, np.uint8)
+        h, w = cur.shape
+        ptrs = (C.c_void_p * len(refs))(*[r.ctypes.data for r in refs])
+        ct = np.ascontiguousarray(cur_Tcw7, np.float32)
+        rs = np.ascontiguousarray(ref_slot, np.int32)
+        rt = np.ascontiguousarray(ref_Tcw7, np.float32)
+        rk = np.ascontiguousarray(ref_kp, KP_DTYPE)
+        mw = np.ascontiguousarray(mp_world, np.float32)
+        px = np.array(px_curr, np.float32).reshape(-1, 2).copy()
+        n = len(rs)
+        sl = np.zeros(max(n, 1), np.int32)
+        ok = np.zeros(max(n, 1), np.uint8)
+        pt = np.zeros((max(n, 1), 100), np.uint8)
+        self.L.yo_find_direct_projection_batch.restype = None
+        self.L.yo_find_direct_projection_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float,
+                                                           C.c_float, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 8
+        self.L.yo_find_direct_projection_batch(self.h, len(refs), ptrs, _p(cur), w, h, _p(ct), cam["fx"], cam["fy"], cam["cx"], cam["cy"], n,
+                                               _p(rs), _p(rt), _p(rk), _p(mw), _p(px), _p(sl), _p(ok), _p(pt))
+        return px, sl[:n], ok[:n], pt[:n]
+
     def shi_tomasi(self, img, u, v):
         img = np.ascontiguousarray(img, np.uint8)
         self.L.yo_shi_tomasi.restype = C.c_float

@@ -209,6 +209,26 @@ struct AlignResult {
 AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level,
                              int n_iter);
 
+// ---- ORBmatcher::FindDirectProjection + Align2D  src/ORBmatcher.cc:1525-1602, src/Align.cc:8-104 -------------------------------------
+struct DirectRef {   // the reference KeyFrame's slice
+    KeyPoint kp;                    // ref->mvKeys[mp->GetObservations()[ref]]
+    SE3f Tcw;                       // ref->GetPose()
+    const Image *level_img = nullptr;   // ref->mvImagePyramid[kp.octave]
+    const float *scaleFactors = nullptr;
+    float invLevelSigma2_1 = 0;     // ref->mvInvLevelSigma2[1]
+    int nlevels = 0;                // ref->mvImagePyramid.size()
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+};
+struct DirectCur {
+    SE3f Tcw;
+    std::vector<const Image *> pyramid;
+    const float *scaleFactors = nullptr, *invScaleFactors = nullptr;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+};
+bool align2d(const Image &cur_img, const uint8_t *ref_patch_with_border, const uint8_t *ref_patch, int n_iter, float cur_px_estimate[2]);
+bool find_direct_projection(const DirectRef &ref, const DirectCur &cur, const float mp_world[3], float px_curr[2], int *search_level,
+                            uint8_t *patch_with_border_out);
+
 // ---- Frame::ComputeStereoMatches  src/Frame.cc:509-682 -------------------------------------------------------------------------
 // Left/right keys + descriptors, both extractors' pyramids (tight levels), mvScaleFactors / mvInvScaleFactors, mb, mbf.
 // Out: mvuRight / mvDepth (N floats each, -1 = no match).  Defined where the reference is not: an empty match list skips the median

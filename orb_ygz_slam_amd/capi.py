@@ -99,6 +99,9 @@ def load_library(build_if_missing=True):
     L.ygzf_compute_stereo_matches.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp]
     L.ygzf_stereo_batch.argtypes = [vp, C.c_float, C.c_float]
     L.ygzf_stereo_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    L.ygzf_image_cache_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.ygzf_image_cache_put.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    L.ygzf_find_direct_projection_batch.argtypes = [vp, C.POINTER(Camera), C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
@@ -479,6 +482,29 @@ class Extractor:
         ur, dp = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
         self._ck(self.L.ygzf_stereo_fetch(self.h, pair, _p(ur), _p(dp), cap))
         return ur, dp
+
+    def image_cache_reserve(self, n_slots, w, h):
+        self._ck(self.L.ygzf_image_cache_reserve(self.h, n_slots, w, h))
+
+    def image_cache_put(self, slot, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        self._ck(self.L.ygzf_image_cache_put(self.h, slot, _p(img), img.shape[1], img.shape[0], img.shape[1]))
+
+    def find_direct_projection_batch(self, cam, cur_slot, cur_Tcw7, ref_slot, ref_Tcw7, ref_kp, mp_world, px_curr, want_patches=False):
+        """ORBmatcher::FindDirectProjection over a candidate batch -> (px_curr n x 2, search_level, success[, patches n x 100])."""
+        ct = np.ascontiguousarray(cur_Tcw7, np.float32)
+        rs = np.ascontiguousarray(ref_slot, np.int32)
+        rt = np.ascontiguousarray(ref_Tcw7, np.float32)
+        rk = np.ascontiguousarray(ref_kp, KP_DTYPE)
+        mw = np.ascontiguousarray(mp_world, np.float32)
+        px = np.array(px_curr, np.float32).reshape(-1, 2).copy()
+        n = len(rs)
+        sl = np.zeros(max(n, 1), np.int32)
+        ok = np.zeros(max(n, 1), np.uint8)
+        pt = np.zeros((max(n, 1), 100), np.uint8) if want_patches else None
+        self._ck(self.L.ygzf_find_direct_projection_batch(self.h, C.byref(cam), cur_slot, _p(ct), n, _p(rs), _p(rt), _p(rk), _p(mw), _p(px), _p(sl),
+                                                          _p(ok), _p(pt) if want_patches else None))
+        return (px, sl[:n], ok[:n], pt[:n]) if want_patches else (px, sl[:n], ok[:n])
 
     def timer_start(self):
         self._ck(self.L.ygzf_timer_start(self.h))

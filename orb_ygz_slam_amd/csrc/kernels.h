@@ -127,6 +127,28 @@ struct StereoArgs {
 };
 void launch_stereo(hipStream_t st, const StereoArgs &A, int nPairs, int maxLeft, int maxRight);
 
+// ---- ORBmatcher::FindDirectProjection + Align2D over a candidate batch (direct_kernels.hip) ---------------------------------
+struct DirectArgs {
+    FrameSet cache;                // the image cache: slot s = frame s of this FrameSet
+    const LevelGeom *geom;
+    int nlevels;
+    int curSlot;
+    float curTcw[7];
+    float fx, fy, cx, cy;
+    float scale[kMaxLevels], invScale[kMaxLevels];
+    float invLevelSigma2_1;        // mvInvLevelSigma2[1]
+    int n;
+    const int *refSlot;
+    const float *refTcw7;          // n x 7 (quaternion x,y,z,w + translation)
+    const ygzf_kp *refKp;
+    const float *mpWorld;          // n x 3
+    float *pxCurr;                 // n x 2, in/out
+    int *searchLevel;
+    uint8_t *success;
+    uint8_t *patches;              // nullable: n x 100 (_patch_with_border, tests)
+};
+void launch_direct_projection(hipStream_t st, const DirectArgs &A);
+
 // ---- sparse image alignment (align_kernels.hip) ----------------------------------------------------------------------
 struct SiaLevel {
     const uint8_t *img;

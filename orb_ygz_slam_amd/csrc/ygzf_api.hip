@@ -63,9 +63,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -98,7 +98,10 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6];
+        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8];
+    int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
+    long long cachePyrBytes = 0;
+    std::vector<unsigned char> cacheFilled;
     int lastStereoPairs = 0;
     bool alignCarry = false;      // keep the last frame's pyramid across batches (enabled by the first ygzf_align_batch_prev)
     bool carryPyrValid = false;
@@ -548,6 +551,10 @@ void ygzf_destroy(ygzf_ctx *c) {
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dSt)
         if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dDir)
+        if (b.p) (void) hipFree(b.p);
+    if (c->dCacheImg.p) (void) hipFree(c->dCacheImg.p);
+    if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
@@ -1686,6 +1693,121 @@ int ygzf_compute_stereo_matches(ygzf_ctx *c, const uint8_t *img_left, const uint
     HIPCHECK(c, hipMemcpyAsync(depth, c->dSt[2].p, 4 * (size_t) n_left, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     c->lastStereoPairs = 0;
+    return YGZF_OK;
+}
+
+// ---- image cache (KeyFrame / current-frame pyramids resident in HBM) + FindDirectProjection batch -------------------------------------
+static FrameSet cache_frameset(const ygzf_ctx *c) {
+    FrameSet fs;
+    fs.img0 = (const uint8_t *) c->dCacheImg.p;
+    fs.img0_stride = (long long) c->cachePitch * c->cacheH;
+    fs.img0_pitch = c->cachePitch;
+    fs.pyr = (uint8_t *) c->dCachePyr.p;
+    fs.pyr_stride = c->cachePyrBytes;
+    return fs;
+}
+
+int ygzf_image_cache_reserve(ygzf_ctx *c, int n_slots, int w, int h) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (n_slots < 1 || w < 1 || h < 1) return fail(c, YGZF_ERR_INVALID, "bad cache size");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, 1);
+    if (rc) return rc;
+    const int pitch = align_up(w, 64);
+    if ((rc = ensure(c, c->dCacheImg, (size_t) n_slots * pitch * h + 256)) || (rc = ensure(c, c->dCachePyr, (size_t) n_slots * c->geo.pyrBytes + 256))) return rc;
+    c->cacheSlots = n_slots;
+    c->cacheW = w;
+    c->cacheH = h;
+    c->cachePitch = pitch;
+    c->cachePyrBytes = c->geo.pyrBytes;
+    c->cacheFilled.assign(n_slots, 0);
+    return YGZF_OK;
+}
+
+int ygzf_image_cache_put(ygzf_ctx *c, int slot, const uint8_t *img, int w, int h, int stride) {
+    if (!c || !img) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->cacheSlots <= 0) return fail(c, YGZF_ERR_STATE, "image cache not reserved");
+    if (slot < 0 || slot >= c->cacheSlots) return fail(c, YGZF_ERR_INVALID, "slot %d outside 0..%d", slot, c->cacheSlots - 1);
+    if (w != c->cacheW || h != c->cacheH || stride < w) return fail(c, YGZF_ERR_INVALID, "image %dx%d does not match the cache (%dx%d)", w, h, c->cacheW, c->cacheH);
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, 1);
+    if (rc) return rc;
+    FrameSet fs = cache_frameset(c);
+    fs.img0 += (long long) slot * fs.img0_stride;      // the launchers address "frame 0" of the set they are given
+    fs.pyr += (long long) slot * fs.pyr_stride;
+    HIPCHECK(c, hipMemcpy2DAsync((void *) fs.img0, c->cachePitch, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    const int L = c->tab.cfg.nlevels;
+    for (int l = 1; l < L; l++) {
+        ProfScope ps(c, KK_PYR);
+        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, c->geo.lv[l], l, 1, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
+                          (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    c->cacheFilled[slot] = 1;
+    return YGZF_OK;
+}
+
+int ygzf_find_direct_projection_batch(ygzf_ctx *c, const ygzf_camera *cam, int cur_slot, const float *cur_Tcw7, int n, const int *ref_slot,
+                                      const float *ref_Tcw7, const ygzf_kp *ref_kp, const float *mp_world, float *px_curr, int *search_level,
+                                      uint8_t *success, uint8_t *patches_with_border) {
+    if (!c || !cam || !cur_Tcw7) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    if (n == 0) return YGZF_OK;
+    if (!ref_slot || !ref_Tcw7 || !ref_kp || !mp_world || !px_curr || !search_level || !success) return fail(c, YGZF_ERR_INVALID, "null array");
+    if (c->cacheSlots <= 0) return fail(c, YGZF_ERR_STATE, "image cache not reserved");
+    if (c->geo.w != c->cacheW || c->geo.h != c->cacheH) {
+        int rc0 = apply_geometry(c, c->cacheW, c->cacheH, 1);
+        if (rc0) return rc0;
+    }
+    const int L = c->tab.cfg.nlevels;
+    if (cur_slot < 0 || cur_slot >= c->cacheSlots || !c->cacheFilled[cur_slot]) return fail(c, YGZF_ERR_INVALID, "current-frame slot %d is empty", cur_slot);
+    for (int i = 0; i < n; i++) {
+        if (ref_slot[i] < 0 || ref_slot[i] >= c->cacheSlots || !c->cacheFilled[ref_slot[i]]) return fail(c, YGZF_ERR_INVALID, "candidate %d: slot %d is empty", i, ref_slot[i]);
+        if (ref_kp[i].octave < 0 || ref_kp[i].octave >= L) return fail(c, YGZF_ERR_INVALID, "candidate %d: octave out of range", i);
+    }
+    HIPCHECK(c, hipSetDevice(c->device));
+    ygzf_ctx::Buf *D = c->dDir;
+    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
+    Up ups[] = {{&D[0], ref_slot, 4 * (size_t) n}, {&D[1], ref_Tcw7, 28 * (size_t) n}, {&D[2], ref_kp, sizeof(ygzf_kp) * (size_t) n},
+                {&D[3], mp_world, 12 * (size_t) n}, {&D[4], px_curr, 8 * (size_t) n}};
+    int rc;
+    for (auto &u : ups) {
+        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
+        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    if ((rc = ensure(c, D[5], 4 * (size_t) n)) || (rc = ensure(c, D[6], (size_t) n)) || (patches_with_border && (rc = ensure(c, D[7], 100 * (size_t) n)))) return rc;
+    DirectArgs A;
+    memset(&A, 0, sizeof A);
+    A.cache = cache_frameset(c);
+    A.geom = (const LevelGeom *) c->dGeom.p;
+    A.nlevels = L;
+    A.curSlot = cur_slot;
+    memcpy(A.curTcw, cur_Tcw7, 28);
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy;
+    for (int l = 0; l < kMaxLevels; l++) {
+        A.scale[l] = l < L ? c->tab.scale[l] : 1.f;
+        A.invScale[l] = l < L ? c->tab.invScale[l] : 1.f;
+    }
+    A.invLevelSigma2_1 = c->tab.invSigma2[L > 1 ? 1 : 0];
+    A.n = n;
+    A.refSlot = (const int *) D[0].p;
+    A.refTcw7 = (const float *) D[1].p;
+    A.refKp = (const ygzf_kp *) D[2].p;
+    A.mpWorld = (const float *) D[3].p;
+    A.pxCurr = (float *) D[4].p;
+    A.searchLevel = (int *) D[5].p;
+    A.success = (uint8_t *) D[6].p;
+    A.patches = patches_with_border ? (uint8_t *) D[7].p : nullptr;
+    {
+        ProfScope ps(c, KK_DIRECT);
+        launch_direct_projection(c->stream, A);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(px_curr, D[4].p, 8 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(search_level, D[5].p, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(success, D[6].p, (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    if (patches_with_border) HIPCHECK(c, hipMemcpyAsync(patches_with_border, D[7].p, 100 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }
 
