@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--align", action="store_true",
                     help="BASELINE config 3: also run SparseImgAlign (levels L-1..1, 10 iterations) of every frame against its "
                          "predecessor; `metric` stays extract+match, the step simply carries the extra work (see config.align)")
+    ap.add_argument("--stereo", action="store_true",
+                    help="BASELINE config 5 shape: the batch holds (left, right) pairs; Frame::ComputeStereoMatches runs on every pair "
+                         "after extraction (extra work inside the step, see config.stereo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -138,14 +141,20 @@ def main():
 
     import torch
     dist = None
+    use_gpu = not args.plumbing_selftest
+    if use_gpu and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo" if args.plumbing_selftest else "nccl")
+        dist.init_process_group(backend="nccl" if use_gpu else "gloo")
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            if use_gpu:
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
 
     if args.plumbing_selftest:
         # exercises sharding, barrier and max-over-ranks reduction without a GPU; never a valid measurement
@@ -170,8 +179,8 @@ def main():
     frames = make_frames(B, w, h, seed0=1000 + 97 * rank)   # every rank owns its own clip (one-frame-per-GPU sharding at scale)
     d_frames = torch.from_numpy(frames).to("cuda:%d" % local_rank)
     S = max(1, args.streams)
-    if B % S:
-        raise SystemExit("--batch must be a multiple of --streams")
+    if B % S or (args.stereo and (B // S) % 2):
+        raise SystemExit("--batch must be a multiple of --streams (and of 2 x --streams with --stereo)")
     Bs = B // S
     exs = [Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=Bs, device=local_rank) for _ in range(S)]
     ex = exs[0]
@@ -184,6 +193,8 @@ def main():
             e.match_batch_prev(cam, 15.0, True, True, True)
             if args.align:
                 e.align_batch_prev(cam, nl - 1, 1, 10)
+            if args.stereo:
+                e.stereo_batch(0.11, 47.9)
 
     for _ in range(args.warmup):
         step()
@@ -255,7 +266,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h, "levels": nl, "scale_factor": sf, "features": nf,
-                       "frames_per_gpu_per_step": B, "streams": S, "align": bool(args.align), "match": "SearchByProjection(cur,last) th=15, identity pose",
+                       "frames_per_gpu_per_step": B, "streams": S, "align": bool(args.align), "stereo": bool(args.stereo), "match": "SearchByProjection(cur,last) th=15, identity pose",
                        "sharding": "one clip per GPU, no collective"},
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "roofline": roofline, "kernels": kernels,

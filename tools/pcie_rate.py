@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""tools/pcie_rate.py -- the PCIe-inclusive rate of the hot path (host frames in, keypoints + descriptors + matches out), which is
+NOT bench.py's `value` (that one starts with the frames resident in HBM): ygzf_extract_batch_host + ygzf_match_batch_prev + fetch of
+every frame's results, pageable host memory, one stream."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from bench import WORKLOADS, make_frames  # noqa: E402
+from orb_ygz_slam_amd import Extractor, make_camera  # noqa: E402
+
+
+def main():
+    w, h, nl, sf, nf, ini, mn = WORKLOADS["euroc752x480_8lvl_1000feat"]
+    B, steps = 256, 5
+    frames = make_frames(B, w, h)
+    ex = Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B)
+    cam = make_camera(w, h)
+
+    def step(fetch):
+        ex.extract_batch_host(frames)
+        ex.match_batch_prev(cam, 15.0, True, True, True)
+        if fetch:
+            for f in range(B):
+                ex.batch_fetch(f)
+                ex.match_fetch(f)
+        ex.sync()
+    step(True)
+    res = {}
+    for name, fetch in (("h2d_only", False), ("h2d_and_d2h_per_frame_fetch", True)):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(fetch)
+        res[name] = round(B * steps / (time.perf_counter() - t0), 1)
+    print(json.dumps({"pcie_inclusive_frames_per_s": res, "batch": B, "note": "pageable host memory, single stream, python fetch loop"}))
+
+
+if __name__ == "__main__":
+    main()
