@@ -270,18 +270,49 @@ __device__ __forceinline__ void ring_diffs(const uint8_t *c, int tp, int d[16]) 
 }
 
 // 1 = bright corner, 2 = dark corner, 0 = none, at threshold t (9 contiguous ring pixels > v+t or < v-t).
-// The 16-bit ring masks are built arithmetically (sign bit of t - d / d + t moved to bit k): no compare -> SGPR -> select
-// round trip (which also costs hazard nops on gfx9).
+// Ring pixels k and k+8 share one register as two 16-bit lanes, so one packed subtract (v_pk_sub_i16) tests two ring positions
+// per polarity; the sign bits (bit 15 / 31) are shifted into place as they arrive: after 8 steps ring k sits at bit 8+k of the low
+// half and ring 8+k at bit 24+k.  No compare -> SGPR -> select round trip (which also costs hazard nops on gfx9).
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) {
+    const v2s r = __builtin_bit_cast(v2s, a) - __builtin_bit_cast(v2s, b);
+    return __builtin_bit_cast(unsigned, r);
+}
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rot16pk(unsigned a, int sh) {   // rotate both 16-bit halves right by sh
+    const v2u x = __builtin_bit_cast(v2u, a);
+    const v2u r = (x >> (v2u) (unsigned short) sh) | (x << (v2u) (unsigned short) (16 - sh));
+    return __builtin_bit_cast(unsigned, r);
+}
 __device__ __forceinline__ int fast9_test(const uint8_t *c, int tp, int t) {
-    int d[16];
-    ring_diffs(c, tp, d);
-    unsigned B = 0, D = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        B |= ((unsigned) (t - d[k]) >> 31) << k;      // d > t
-        D |= ((unsigned) (d[k] + t) >> 31) << k;      // d < -t
+    const int v = c[0];
+    const int t2 = 2 * tp, t3 = 3 * tp;
+    const unsigned hi = (unsigned) (v + t) * 0x10001u;                 // (v+t, v+t)
+    const unsigned lo = ((unsigned) (v - t) & 0xFFFFu) * 0x10001u;     // (v-t, v-t) as two's-complement halves
+    unsigned accB = 0, accD = 0;
+#define RING_PAIR(a, b)                                                                \
+    {                                                                                  \
+        const unsigned pk = (unsigned) c[a] | ((unsigned) c[b] << 16);                 \
+        accB = (accB >> 1) | (pk_sub16(hi, pk) & 0x80008000u);   /* ring > v + t */    \
+        accD = (accD >> 1) | (pk_sub16(pk, lo) & 0x80008000u);   /* ring < v - t */    \
     }
-    return has_arc9(B) ? 1 : (has_arc9(D) ? 2 : 0);
+    RING_PAIR(t3, -t3)            // 0, 8
+    RING_PAIR(t3 + 1, -t3 - 1)    // 1, 9
+    RING_PAIR(t2 + 2, -t2 - 2)    // 2, 10
+    RING_PAIR(tp + 3, -tp - 3)    // 3, 11
+    RING_PAIR(3, -3)              // 4, 12
+    RING_PAIR(-tp + 3, tp - 3)    // 5, 13
+    RING_PAIR(-t2 + 2, t2 - 2)    // 6, 14
+    RING_PAIR(-t3 + 1, t3 - 1)    // 7, 15
+#undef RING_PAIR
+    // both 16-bit ring masks in one register (bright | dark << 16): one v_perm_b32 gathers the four mask bytes, and the
+    // "9 contiguous of the circular 16" test runs on both halves at once with packed 16-bit rotates (runs >= 2, 4, 8, then 9)
+    const unsigned m = __builtin_amdgcn_perm(accD, accB, 0x07050301u);
+    unsigned r = m & rot16pk(m, 1);
+    r &= rot16pk(r, 2);
+    r &= rot16pk(r, 4);
+    r &= rot16pk(m, 8);
+    return (r & 0xFFFFu) ? 1 : (r ? 2 : 0);
 }
 
 // cv::FAST cornerScore<16> for a pixel known to be a corner of polarity `pol`: max over the 16 arcs of 9 of the minimum
