@@ -134,6 +134,37 @@ int ygzf_search_by_projection_last(ygzf_ctx *ctx, const ygzf_frame_view *cur, co
                                    const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw, const float *tlw, float th,
                                    int b_mono, int check_level, int check_orientation, uint8_t *cur_owner, int *cur_match, int *nmatches);
 
+/* ---- Frame::isInFrustum(MapPoint *pMP, float viewingCosLimit)   src/Frame.cc:363-422 over a MapPoint batch, and its
+ *      fusion with SearchByProjection(F, MapPoints) = the body of Tracking::SearchLocalPoints (src/Tracking.cc:1544-1593) ---------------
+ * Per MapPoint i: world = GetWorldPos(), normal = GetNormal(), max_dist_inv / min_dist_inv = GetMax/MinDistanceInvariance(),
+ * mf_max_distance = mfMaxDistance (numerator of MapPoint::PredictScale, src/MapPoint.cc:359-373), candidate[i] (NULL = all) = the point
+ * is evaluated at all (not bad, not already matched in this frame).  Rcw / tcw / Ow = Frame::mRcw / mtcw / mOw.
+ * Outputs = the fields isInFrustum writes: in_view = mbTrackInView, proj_x / proj_y / proj_xr = mTrackProjX/Y/XR, level =
+ * mnTrackScaleLevel, view_cos = mTrackViewCos (defined where in_view).  PredictScale's ceil(logf(ratio) / log_scale_factor) is a step
+ * function of ratio: the library tabulates its steps with the host's libm (ygzf_predict_scale_steps) and the device compares.
+ * ygzf_search_local_points runs isInFrustum and then SearchByProjection(F, MapPoints, th, check_level) (nnratio as the matcher's) on
+ * the device without a host round trip; the frustum outputs are optional (NULL = not copied back). */
+typedef struct ygzf_frustum_in {
+    const float *world, *normal;                 /* n x 3 each */
+    const float *max_dist_inv, *min_dist_inv, *mf_max_distance;
+    const uint8_t *candidate;                    /* nullable */
+    float Rcw[9], tcw[3], Ow[3];
+    float log_scale_factor;                      /* Frame::mfLogScaleFactor */
+    float viewing_cos_limit;
+} ygzf_frustum_in;
+int ygzf_predict_scale_steps(float log_scale_factor, int nlevels, float *steps);   /* host only: steps[k] = smallest ratio with level >= k */
+int ygzf_is_in_frustum_batch(ygzf_ctx *ctx, const ygzf_camera *cam, int nlevels, int n, const ygzf_frustum_in *in, uint8_t *in_view, float *proj_x,
+                             float *proj_y, float *proj_xr, int *level, float *view_cos);
+int ygzf_search_local_points(ygzf_ctx *ctx, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const ygzf_frustum_in *in,
+                             const uint8_t *mp_has_obs, const uint8_t *mp_desc, float th, int check_level, float nnratio, uint8_t *owner, int *match,
+                             int *nmatches, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, int *level, float *view_cos);
+
+/* ---- MapPoint::ComputeDistinctiveDescriptors()   src/MapPoint.cc:211-271 over a MapPoint batch -----------------------------
+ * Point p owns the observation descriptors desc[obs_off[p] .. obs_off[p+1]) (32 bytes each, those of its non-bad KeyFrames in map order);
+ * best_idx[p] = index within the point's observations of the descriptor with the least median Hamming distance to the others (first
+ * minimum, median = sorted row element (size_t)(0.5*(N-1))), -1 for a point without observations.  At most 256 observations per point. */
+int ygzf_distinctive_descriptors_batch(ygzf_ctx *ctx, int n_points, const int *obs_off, const uint8_t *desc, int *best_idx);
+
 /* ---- ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)
  *      src/ORBmatcher.cc:1352-1469 (Tracking::Relocalization: th 10 / ORBdist 100, then th 3 / ORBdist 64) -----------------------
  * The O(N) scalar prologue stays on the host (:1371-1400: projection with CurrentFrame.mTcw, image-bounds and distance gates,

@@ -1,6 +1,7 @@
 // oracle_capi.cpp -- CPU ORACLE (test infrastructure): flat C entry points so that tests/, bench.py's cpu_baseline
 // leg and __graft_entry__.smoke() can drive the oracle through ctypes.  Nothing in the product links this.
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <thread>
 
@@ -285,6 +286,42 @@ int yo_search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int
                      const KeyPoint *kf_keys, const uint8_t *kf_desc, int nF, const KeyPoint *f_keys, const uint8_t *f_desc, float nnratio,
                      int checkOri, int *match) {
     return search_by_bow(nNodes, kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, nF, f_keys, f_desc, nnratio, checkOri != 0, match);
+}
+
+void yo_is_in_frustum(const yo_frame *F, int M, const float *world, const float *normal, const float *maxDistInv, const float *minDistInv,
+                      const float *mfMaxDistance, const float *Rcw, const float *tcw, const float *Ow, float logScaleFactor, int nScaleLevels,
+                      float viewingCosLimit, uint8_t *in_view, float *projX, float *projY, float *projXR, int *level, float *viewCos) {
+    FrameView v = to_view(F);
+    FrustumInput in;
+    in.M = M;
+    in.world = world;
+    in.normal = normal;
+    in.maxDistInv = maxDistInv;
+    in.minDistInv = minDistInv;
+    in.mfMaxDistance = mfMaxDistance;
+    std::memcpy(in.Rcw, Rcw, 36);
+    std::memcpy(in.tcw, tcw, 12);
+    std::memcpy(in.Ow, Ow, 12);
+    in.logScaleFactor = logScaleFactor;
+    in.nScaleLevels = nScaleLevels;
+    is_in_frustum(v, in, viewingCosLimit, in_view, projX, projY, projXR, level, viewCos);
+}
+
+// MapPoint::PredictScale (src/MapPoint.cc:359-373) for an array of ratios = mfMaxDistance / dist
+void yo_predict_scale(const float *ratio, int n, float logScaleFactor, int nScaleLevels, int *level) {
+    for (int i = 0; i < n; i++) {
+        int nScale = (int) std::ceil(std::log(ratio[i]) / logScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= nScaleLevels) nScale = nScaleLevels - 1;
+        level[i] = nScale;
+    }
+}
+
+void yo_distinctive_descriptors(int nPoints, const int *obs_off, const uint8_t *desc, int *best) {
+    for (int p = 0; p < nPoints; p++) {
+        const int n = obs_off[p + 1] - obs_off[p];
+        best[p] = n > 0 ? distinctive_descriptor(desc + 32 * (size_t) obs_off[p], n) : -1;
+    }
 }
 
 int yo_search_for_initialization(const yo_frame *F1, const yo_frame *F2, float *prevMatchedXY, int windowSize,

@@ -4,6 +4,7 @@
 // Built with -ffp-contract=off: float expressions are evaluated in source order without FMA.
 // PARITY UNPINNED: the reference ships no test for this path.
 #include <climits>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -364,6 +365,65 @@ int search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int *f
         }
     }
     return nmatches;
+}
+
+// src/Frame.cc:363-422
+void is_in_frustum(const FrameView &F, const FrustumInput &in, float viewingCosLimit, uint8_t *in_view, float *projX, float *projY,
+                   float *projXR, int *level, float *viewCos) {
+    for (int i = 0; i < in.M; i++) {
+        in_view[i] = 0;
+        const float *P = &in.world[3 * i];
+        float Pc[3];
+        mat3_mul_vec(in.Rcw, P, Pc);
+        for (int k = 0; k < 3; k++) Pc[k] = Pc[k] + in.tcw[k];
+        const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+        if (PcZ < 0.0f) continue;
+        const float invz = 1.0f / PcZ;
+        const float u = F.fx * PcX * invz + F.cx;
+        const float v = F.fy * PcY * invz + F.cy;
+        if (u < F.minX || u > F.maxX) continue;
+        if (v < F.minY || v > F.maxY) continue;
+        const float PO[3] = {P[0] - in.Ow[0], P[1] - in.Ow[1], P[2] - in.Ow[2]};
+        const float dist = std::sqrt(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+        if (dist < in.minDistInv[i] || dist > in.maxDistInv[i]) continue;
+        const float *Pn = &in.normal[3 * i];
+        const float vc = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+        if (vc < viewingCosLimit) continue;
+        const float ratio = in.mfMaxDistance[i] / dist;   // MapPoint::PredictScale
+        int nScale = (int) std::ceil(std::log(ratio) / in.logScaleFactor);
+        if (nScale < 0) nScale = 0;
+        else if (nScale >= in.nScaleLevels) nScale = in.nScaleLevels - 1;
+        in_view[i] = 1;
+        projX[i] = u;
+        projXR[i] = u - F.mbf * invz;
+        projY[i] = v;
+        level[i] = nScale;
+        viewCos[i] = vc;
+    }
+}
+
+// src/MapPoint.cc:211-271
+int distinctive_descriptor(const uint8_t *desc, int N) {
+    std::vector<float> D((size_t) N * N);
+    for (int i = 0; i < N; i++) {
+        D[(size_t) i * N + i] = 0;
+        for (int j = i + 1; j < N; j++) {
+            const int distij = descriptor_distance(&desc[32 * (size_t) i], &desc[32 * (size_t) j]);
+            D[(size_t) i * N + j] = (float) distij;
+            D[(size_t) j * N + i] = (float) distij;
+        }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (int i = 0; i < N; i++) {
+        std::vector<int> vDists(D.begin() + (size_t) i * N, D.begin() + (size_t) (i + 1) * N);
+        std::sort(vDists.begin(), vDists.end());
+        const int median = vDists[(size_t) (0.5 * (N - 1))];
+        if (median < BestMedian) {
+            BestMedian = median;
+            BestIdx = i;
+        }
+    }
+    return BestIdx;
 }
 
 // :375-478

@@ -477,6 +477,48 @@ def search_by_bow(kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, f_ke
     return r, match[:len(fk)]
 
 
+def is_in_frustum(keys, desc, scale_factors, w, h, cam, world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow,
+                  log_scale_factor, viewing_cos_limit=0.5):
+    """Oracle Frame::isInFrustum for M points -> (in_view, projX, projY, projXR, level, viewCos)."""
+    keep = []
+    fr = _yo_frame(keys, desc, scale_factors, w, h, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam.get("mb", 0.0), cam.get("mbf", 0.0),
+                   None, keep)
+    wd, nm, mx, mn, mf = (np.ascontiguousarray(a, np.float32) for a in (world, normal, max_dist_inv, min_dist_inv, mf_max_distance))
+    R, t, O = (np.ascontiguousarray(a, np.float32) for a in (Rcw, tcw, Ow))
+    M = len(mx)
+    iv = np.zeros(max(M, 1), np.uint8)
+    px, py, pxr, vc = (np.zeros(max(M, 1), np.float32) for _ in range(4))
+    lv = np.zeros(max(M, 1), np.int32)
+    L = lib()
+    L.yo_is_in_frustum.restype = None
+    L.yo_is_in_frustum.argtypes = [C.POINTER(_YoFrame), C.c_int] + [C.c_void_p] * 8 + [C.c_float, C.c_int, C.c_float] + [C.c_void_p] * 6
+    L.yo_is_in_frustum(C.byref(fr), M, _p(wd), _p(nm), _p(mx), _p(mn), _p(mf), _p(R), _p(t), _p(O), float(log_scale_factor), len(scale_factors),
+                       viewing_cos_limit, _p(iv), _p(px), _p(py), _p(pxr), _p(lv), _p(vc))
+    return iv[:M], px[:M], py[:M], pxr[:M], lv[:M], vc[:M]
+
+
+def predict_scale(ratio, log_scale_factor, nlevels):
+    r = np.ascontiguousarray(ratio, np.float32)
+    out = np.zeros(max(len(r), 1), np.int32)
+    L = lib()
+    L.yo_predict_scale.restype = None
+    L.yo_predict_scale.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    L.yo_predict_scale(_p(r), len(r), float(log_scale_factor), nlevels, _p(out))
+    return out[:len(r)]
+
+
+def distinctive_descriptors(obs_off, desc):
+    """Oracle MapPoint::ComputeDistinctiveDescriptors for a batch of points -> index (within the point's observations) of the winner."""
+    oo = np.ascontiguousarray(obs_off, np.int32)
+    d = np.ascontiguousarray(desc, np.uint8)
+    best = np.zeros(max(len(oo) - 1, 1), np.int32)
+    L = lib()
+    L.yo_distinctive_descriptors.restype = None
+    L.yo_distinctive_descriptors.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.yo_distinctive_descriptors(len(oo) - 1, _p(oo), _p(d), _p(best))
+    return best[:len(oo) - 1]
+
+
 def search_by_projection_mappoints(keys, desc, scale_factors, w, h, cam, track_in_view, proj_x, proj_y, view_cos, scale_level, mp_desc,
                                    th, check_level=True, nnratio=0.8, is_bad=None, mp_has_obs=None, proj_xr=None, u_right=None,
                                    owner=None):

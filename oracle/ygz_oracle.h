@@ -161,6 +161,24 @@ int search_by_projection_kf(const FrameView &cur, const Grid &grid, const ProjKF
                             bool checkOrientation, uint8_t *cur_owner, int *cur_match, uint8_t *out_valid, float *out_u,
                             float *out_v, int *out_level);
 
+// Frame::isInFrustum(MapPoint*, viewingCosLimit)  src/Frame.cc:363-422 with MapPoint::PredictScale src/MapPoint.cc:359-373, for M points.
+// Rcw/tcw = mRcw/mtcw, Ow = mOw (camera centre); out_* = the fields the function writes into the MapPoint (valid where in_view).
+struct FrustumInput {
+    int M = 0;
+    const float *world = nullptr, *normal = nullptr;            // M x 3: GetWorldPos(), GetNormal()
+    const float *maxDistInv = nullptr, *minDistInv = nullptr;   // GetMax/MinDistanceInvariance()
+    const float *mfMaxDistance = nullptr;                       // PredictScale's numerator
+    float Rcw[9], tcw[3], Ow[3];
+    float logScaleFactor = 0;
+    int nScaleLevels = 0;
+};
+void is_in_frustum(const FrameView &F, const FrustumInput &in, float viewingCosLimit, uint8_t *in_view, float *projX, float *projY,
+                   float *projXR, int *level, float *viewCos);
+
+// MapPoint::ComputeDistinctiveDescriptors  src/MapPoint.cc:211-271: index of the observation descriptor with the least median
+// Hamming distance to the others (desc: N x 32); N >= 1.
+int distinctive_descriptor(const uint8_t *desc, int N);
+
 // SearchForInitialization  src/ORBmatcher.cc:375-478
 int search_for_initialization(const FrameView &F1, const FrameView &F2, const Grid &grid2, float *prevMatchedXY,
                               int windowSize, float nnratio, bool checkOrientation, int *matches12);

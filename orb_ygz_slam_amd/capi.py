@@ -30,6 +30,12 @@ class FrameView(C.Structure):
                 ("scale_factors", C.c_void_p), ("nlevels", C.c_int)]
 
 
+class FrustumIn(C.Structure):
+    _fields_ = [("world", C.c_void_p), ("normal", C.c_void_p), ("max_dist_inv", C.c_void_p), ("min_dist_inv", C.c_void_p),
+                ("mf_max_distance", C.c_void_p), ("candidate", C.c_void_p), ("Rcw", C.c_float * 9), ("tcw", C.c_float * 3), ("Ow", C.c_float * 3),
+                ("log_scale_factor", C.c_float), ("viewing_cos_limit", C.c_float)]
+
+
 class SiaFrame(C.Structure):
     _fields_ = [("n", C.c_int), ("keys", C.c_void_p), ("mp_valid", C.c_void_p), ("outlier", C.c_void_p), ("mp_world", C.c_void_p),
                 ("Tcw", C.c_float * 7), ("nlevels", C.c_int), ("levels", C.POINTER(C.c_void_p)), ("level_w", C.c_void_p),
@@ -102,6 +108,11 @@ def load_library(build_if_missing=True):
     L.ygzf_image_cache_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ygzf_image_cache_put.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.ygzf_find_direct_projection_batch.argtypes = [vp, C.POINTER(Camera), C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ygzf_predict_scale_steps.argtypes = [C.c_float, C.c_int, vp]
+    L.ygzf_is_in_frustum_batch.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(FrustumIn), vp, vp, vp, vp, vp, vp]
+    L.ygzf_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, C.POINTER(FrustumIn), vp, vp, C.c_float, C.c_int,
+                                           C.c_float, vp, vp, ip, vp, vp, vp, vp, vp, vp]
+    L.ygzf_distinctive_descriptors_batch.argtypes = [vp, C.c_int, vp, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
@@ -375,6 +386,70 @@ class Extractor:
         self._ck(self.L.ygzf_search_by_bow(self.h, len(ko) - 1, _p(ko), _p(ki), _p(fo), _p(fi), len(kk), _p(kv), _p(kk), _p(kd), len(fk), _p(fk),
                                            _p(fd), nnratio, int(check_ori), _p(match), C.byref(n)))
         return n.value, match[:len(fk)]
+
+    @staticmethod
+    def _frustum_in(world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow, log_scale_factor, viewing_cos_limit, candidate, keep):
+        fi = FrustumIn()
+        for name, arr, dt in (("world", world, np.float32), ("normal", normal, np.float32), ("max_dist_inv", max_dist_inv, np.float32),
+                              ("min_dist_inv", min_dist_inv, np.float32), ("mf_max_distance", mf_max_distance, np.float32),
+                              ("candidate", candidate, np.uint8)):
+            if arr is None:
+                continue
+            a = np.ascontiguousarray(arr, dt)
+            keep.append(a)
+            setattr(fi, name, a.ctypes.data)
+        fi.Rcw = (C.c_float * 9)(*np.asarray(Rcw, np.float32).ravel())
+        fi.tcw = (C.c_float * 3)(*np.asarray(tcw, np.float32).ravel())
+        fi.Ow = (C.c_float * 3)(*np.asarray(Ow, np.float32).ravel())
+        fi.log_scale_factor = float(log_scale_factor)
+        fi.viewing_cos_limit = float(viewing_cos_limit)
+        return fi
+
+    def is_in_frustum_batch(self, cam, world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow, log_scale_factor,
+                            viewing_cos_limit=0.5, candidate=None):
+        """Frame::isInFrustum over a MapPoint batch -> (in_view, projX, projY, projXR, level, viewCos)."""
+        keep = []
+        fi = self._frustum_in(world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow, log_scale_factor, viewing_cos_limit,
+                              candidate, keep)
+        n = len(keep[2])
+        iv = np.zeros(max(n, 1), np.uint8)
+        px, py, pxr, vc = (np.zeros(max(n, 1), np.float32) for _ in range(4))
+        lv = np.zeros(max(n, 1), np.int32)
+        self._ck(self.L.ygzf_is_in_frustum_batch(self.h, C.byref(cam), self.nlevels, n, C.byref(fi), _p(iv), _p(px), _p(py), _p(pxr), _p(lv), _p(vc)))
+        return iv[:n], px[:n], py[:n], pxr[:n], lv[:n], vc[:n]
+
+    def search_local_points(self, cam, keys, desc, world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow, log_scale_factor,
+                            mp_desc, th, check_level=False, nnratio=0.8, viewing_cos_limit=0.5, candidate=None, mp_has_obs=None, owner=None,
+                            scale_factors=None):
+        """isInFrustum + SearchByProjection(F, MapPoints) fused on the device -> (nmatches, match, owner, in_view)."""
+        ck = np.ascontiguousarray(keys, KP_DTYPE)
+        cd = np.ascontiguousarray(desc, np.uint8)
+        keep = [ck, cd]
+        fi = self._frustum_in(world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow, log_scale_factor, viewing_cos_limit,
+                              candidate, keep)
+        fv = FrameView(len(ck), ck.ctypes.data, cd.ctypes.data, None, None, self.nlevels)
+        if scale_factors is not None:
+            sf = np.ascontiguousarray(scale_factors, np.float32)
+            keep.append(sf)
+            fv.scale_factors = _p(sf)
+        md = np.ascontiguousarray(mp_desc, np.uint8)
+        n = len(md)
+        obs = None if mp_has_obs is None else np.ascontiguousarray(mp_has_obs, np.uint8)
+        own = np.zeros(max(len(ck), 1), np.uint8) if owner is None else np.array(owner, np.uint8)
+        match = np.full(max(len(ck), 1), -1, np.int32)
+        iv = np.zeros(max(n, 1), np.uint8)
+        nm = C.c_int()
+        self._ck(self.L.ygzf_search_local_points(self.h, C.byref(fv), C.byref(cam), n, C.byref(fi), _p(obs) if obs is not None else None, _p(md), th,
+                                                 int(check_level), nnratio, _p(own), _p(match), C.byref(nm), _p(iv), None, None, None, None, None))
+        return nm.value, match[:len(ck)], own[:len(ck)], iv[:n]
+
+    def distinctive_descriptors_batch(self, obs_off, desc):
+        """MapPoint::ComputeDistinctiveDescriptors over a MapPoint batch -> winning observation index per point."""
+        oo = np.ascontiguousarray(obs_off, np.int32)
+        d = np.ascontiguousarray(desc, np.uint8)
+        best = np.zeros(max(len(oo) - 1, 1), np.int32)
+        self._ck(self.L.ygzf_distinctive_descriptors_batch(self.h, len(oo) - 1, _p(oo), _p(d), _p(best)))
+        return best[:len(oo) - 1]
 
     def sia_run(self, cam, ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, max_level, min_level, n_iter=10,
                 mp_valid=None, outlier=None):

@@ -85,6 +85,24 @@ void launch_bow(hipStream_t st, int nNodes, const int *kfOff, const int *kfIdx, 
                 const ygzf_kp *kfKeys, const uint8_t *kfDesc, int nF, const ygzf_kp *fKeys, const uint8_t *fDesc, float nnratio, int checkOri, int *match,
                 unsigned char *binOf, int *hist, int *nmatches);
 
+// Frame::isInFrustum over a MapPoint batch (match_kernels.hip); outputs are the mode-1 inputs of k_match_last
+struct FrustumArgs {
+    int n;
+    const uint8_t *candidate;      // nullable: evaluate only where nonzero
+    const float *world, *normal, *maxDistInv, *minDistInv, *mfMaxDistance;
+    float Rcw[9], tcw[3], Ow[3];
+    float fx, fy, cx, cy, mbf, minX, minY, maxX, maxY;
+    float viewingCosLimit;
+    float levelStep[kMaxLevels];   // levelStep[k] = smallest ratio with PredictScale >= k (k = 1 .. nLevels-1), tabulated on the host
+    int nLevels;
+    uint8_t *inView;
+    float *projX, *projY, *projXR, *viewCos;
+    int *level;
+};
+void launch_frustum(hipStream_t st, const FrustumArgs &A);
+// MapPoint::ComputeDistinctiveDescriptors over a MapPoint batch (<= 256 observations per point)
+void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best);
+
 // ---- FAST-10 (fast10_kernels.hip): Thirdparty/fast replacement -------------------------------------------------------
 void launch_fast10(hipStream_t st, const uint8_t *img, int pitch, int x0, int y0, int w, int h, int dx0, int dx1, int dy0, int dy1, int barrier,
                    short *S, int *rowCnt, int *rowKept, int *totals, short *xy, int *scores, int *nonmax, int cap);

@@ -838,6 +838,101 @@ void launch_bow(hipStream_t st, int nNodes, const int *kfOff, const int *kfIdx, 
     hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, nF, checkOri, match, binOf, hist, nmatches);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::isInFrustum for a batch of MapPoints  (src/Frame.cc:363-422; Tracking::SearchLocalPoints src/Tracking.cc:1544-1593 calls it
+// for every local MapPoint before SearchByProjection).  One thread per point; its outputs are exactly the MapPoint fields mode 1 of
+// k_match_last reads, so the two chain on the device without a host round trip.  MapPoint::PredictScale's
+// ceil(logf(ratio) / logScaleFactor) is a step function of `ratio`; the host tabulates its steps with its own libm (levelStep[k] =
+// smallest ratio that yields level >= k), so the level is found by comparisons and matches the CPU bit for bit.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_frustum(FrustumArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    A.inView[i] = 0;
+    if (A.candidate && !A.candidate[i]) return;
+    const float *P = A.world + 3 * (size_t) i;
+    const float PcX = (A.Rcw[0] * P[0] + A.Rcw[1] * P[1] + A.Rcw[2] * P[2]) + A.tcw[0];
+    const float PcY = (A.Rcw[3] * P[0] + A.Rcw[4] * P[1] + A.Rcw[5] * P[2]) + A.tcw[1];
+    const float PcZ = (A.Rcw[6] * P[0] + A.Rcw[7] * P[1] + A.Rcw[8] * P[2]) + A.tcw[2];
+    if (PcZ < 0.0f) return;
+    const float invz = 1.0f / PcZ;
+    const float u = A.fx * PcX * invz + A.cx;
+    const float v = A.fy * PcY * invz + A.cy;
+    if (u < A.minX || u > A.maxX) return;
+    if (v < A.minY || v > A.maxY) return;
+    const float PO[3] = {P[0] - A.Ow[0], P[1] - A.Ow[1], P[2] - A.Ow[2]};
+    const float dist = sqrtf(PO[0] * PO[0] + PO[1] * PO[1] + PO[2] * PO[2]);
+    if (dist < A.minDistInv[i] || dist > A.maxDistInv[i]) return;
+    const float *Pn = A.normal + 3 * (size_t) i;
+    const float viewCos = (PO[0] * Pn[0] + PO[1] * Pn[1] + PO[2] * Pn[2]) / dist;
+    if (viewCos < A.viewingCosLimit) return;
+    const float ratio = A.mfMaxDistance[i] / dist;
+    int level = 0;
+    for (int k = 1; k < A.nLevels; k++) level += (ratio >= A.levelStep[k]) ? 1 : 0;
+    A.inView[i] = 1;
+    A.projX[i] = u;
+    A.projXR[i] = u - A.mbf * invz;
+    A.projY[i] = v;
+    A.level[i] = level;
+    A.viewCos[i] = viewCos;
+}
+
+void launch_frustum(hipStream_t st, const FrustumArgs &A) {
+    if (A.n > 0) hipLaunchKernelGGL(k_frustum, dim3((A.n + 255) / 256), dim3(256), 0, st, A);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// MapPoint::ComputeDistinctiveDescriptors for a batch of MapPoints  (src/MapPoint.cc:211-271): per point, the observation whose
+// descriptor has the least median Hamming distance to the others.  One wave per point, lane j owns observation j (+64, ...); the
+// median of row i (the reference sorts the row and reads element (size_t)(0.5*(N-1))) is the k-th smallest, found by a 9-step
+// bisection on the value with ballot counts instead of a sort.  First minimum wins (strict `<`).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kDistinctMaxObs = 256;
+__global__ __launch_bounds__(256) void k_distinctive(int nPoints, const int *__restrict__ obsOff, const uint8_t *__restrict__ desc,
+                                                     int *__restrict__ best) {
+    const int lane = m_lane(), p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= nPoints) return;
+    const int o0 = obsOff[p], N = obsOff[p + 1] - o0;
+    if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    const int k = (int) (0.5 * (N - 1));
+    const int per = (N + 63) >> 6;   // <= 4
+    unsigned long long d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int j = r * 64 + lane;
+        if (r < per && j < N) {
+            const unsigned long long *q = (const unsigned long long *) (desc + (size_t) (o0 + j) * 32);
+            d[r][0] = q[0]; d[r][1] = q[1]; d[r][2] = q[2]; d[r][3] = q[3];
+        } else d[r][0] = d[r][1] = d[r][2] = d[r][3] = 0;
+    }
+    int bestMedian = 0x7FFFFFFF, bestIdx = 0;
+    for (int i = 0; i < N; i++) {
+        const unsigned long long *q = (const unsigned long long *) (desc + (size_t) (o0 + i) * 32);
+        const unsigned long long q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        int dist[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = r * 64 + lane;
+            dist[r] = (r < per && j < N) ? (int) (__popcll(q0 ^ d[r][0]) + __popcll(q1 ^ d[r][1]) + __popcll(q2 ^ d[r][2]) + __popcll(q3 ^ d[r][3])) : 1 << 20;
+        }
+        // smallest value m with #{dist <= m} > k
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) cnt += __popcll(__ballot(dist[r] <= mid));
+            if (cnt > k) hi = mid; else lo = mid + 1;
+        }
+        if (lo < bestMedian) { bestMedian = lo; bestIdx = i; }
+    }
+    if (lane == 0) best[p] = bestIdx;
+}
+
+void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best) {
+    if (nPoints > 0) hipLaunchKernelGGL(k_distinctive, dim3((nPoints + 3) / 4), dim3(256), 0, st, nPoints, obsOff, desc, best);
+}
+
 static inline size_t al16(size_t b) { return (b + 15) & ~(size_t) 15; }
 
 // LDS bytes / per-pair global spill bytes of the carve-up in k_match_last for a given plan

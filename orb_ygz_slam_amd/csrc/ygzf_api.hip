@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 
 #include "kernels.h"
@@ -98,7 +99,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8];
+        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6];
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
     std::vector<unsigned char> cacheFilled;
@@ -552,6 +553,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &b : c->dSt)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dDir)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dFr)
         if (b.p) (void) hipFree(b.p);
     if (c->dCacheImg.p) (void) hipFree(c->dCacheImg.p);
     if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
@@ -1355,12 +1358,74 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
     return YGZF_OK;
 }
 
+// MapPoint::PredictScale (src/MapPoint.cc:359-373) is a non-decreasing step function of ratio = mfMaxDistance / dist; its steps are
+// tabulated here with the host's own libm so that the device reproduces it by comparisons: step[k] = smallest float ratio whose level
+// is >= k (k = 1 .. nlevels-1).
+static int predict_scale_host(float ratio, float logScaleFactor, int nScaleLevels) {
+    int nScale = (int) std::ceil(std::log(ratio) / logScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= nScaleLevels) nScale = nScaleLevels - 1;
+    return nScale;
+}
+static void predict_scale_steps(float logScaleFactor, int nScaleLevels, float *step) {
+    for (int k = 0; k < kMaxLevels; k++) step[k] = std::numeric_limits<float>::infinity();
+    for (int k = 1; k < nScaleLevels && k < kMaxLevels; k++) {
+        uint32_t lo = 0x00800000u, hi = 0x7F7FFFFFu;   // positive normal floats, ordered like their bit patterns
+        auto lvl = [&](uint32_t b) { float r; memcpy(&r, &b, 4); return predict_scale_host(r, logScaleFactor, nScaleLevels); };
+        if (lvl(hi) < k) continue;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (lvl(mid) >= k) hi = mid; else lo = mid + 1;
+        }
+        memcpy(&step[k], &lo, 4);
+    }
+}
+
+struct FrustumHost {   // host-side inputs of the fused isInFrustum stage (ygzf_frustum_in without the ABI wrapper)
+    const ygzf_frustum_in *in;
+    uint8_t *in_view;
+    float *proj_x, *proj_y, *proj_xr, *view_cos;
+    int *level;
+};
+
+static int fill_frustum_args(ygzf_ctx *c, FrustumArgs &A, const ygzf_frustum_in *in, const ygzf_camera *cam, int n, int nlevels) {
+    if (!in->world || !in->normal || !in->max_dist_inv || !in->min_dist_inv || !in->mf_max_distance) return fail(c, YGZF_ERR_INVALID, "null frustum array");
+    if (nlevels < 1 || nlevels > kMaxLevels) return fail(c, YGZF_ERR_INVALID, "nlevels out of range");
+    ygzf_ctx::Buf *B = c->dFr;
+    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
+    Up ups[] = {{&B[0], in->world, 12 * (size_t) n}, {&B[1], in->normal, 12 * (size_t) n}, {&B[2], in->max_dist_inv, 4 * (size_t) n},
+                {&B[3], in->min_dist_inv, 4 * (size_t) n}, {&B[4], in->mf_max_distance, 4 * (size_t) n}, {&B[5], in->candidate, in->candidate ? (size_t) n : 0}};
+    int rc;
+    for (auto &u : ups) {
+        if (!u.bytes) continue;
+        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
+        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    memset(&A, 0, sizeof A);
+    A.n = n;
+    A.candidate = in->candidate ? (const uint8_t *) B[5].p : nullptr;
+    A.world = (const float *) B[0].p;
+    A.normal = (const float *) B[1].p;
+    A.maxDistInv = (const float *) B[2].p;
+    A.minDistInv = (const float *) B[3].p;
+    A.mfMaxDistance = (const float *) B[4].p;
+    memcpy(A.Rcw, in->Rcw, 36);
+    memcpy(A.tcw, in->tcw, 12);
+    memcpy(A.Ow, in->Ow, 12);
+    A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy; A.mbf = cam->mbf;
+    A.minX = cam->min_x; A.minY = cam->min_y; A.maxX = cam->max_x; A.maxY = cam->max_y;
+    A.viewingCosLimit = in->viewing_cos_limit;
+    predict_scale_steps(in->log_scale_factor, nlevels, A.levelStep);
+    A.nLevels = nlevels;
+    return YGZF_OK;
+}
+
 // shared body of the two searches whose queries arrive already projected (mode 1: F x local MapPoints, mode 2: Cur x KeyFrame points)
 static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const uint8_t *track_in_view,
                            const uint8_t *is_bad, const uint8_t *mp_has_obs, const float *proj_x, const float *proj_y, const float *proj_xr,
                            const float *view_cos, const int *scale_level, const float *mp_angle, const uint8_t *mp_desc, float th,
                            int check_level, float nnratio, int max_dist, int check_ori, uint8_t *owner, int *match, int *nmatches,
-                           const ygzf_kp *last_keys = nullptr, int *match12 = nullptr) {
+                           const ygzf_kp *last_keys = nullptr, int *match12 = nullptr, const FrustumHost *fr = nullptr) {
     if (!c || !F || !cam || !nmatches) return fail(c, YGZF_ERR_INVALID, "null argument");
     *nmatches = 0;
     if (F->n < 0 || n_mp < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
@@ -1368,8 +1433,10 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         for (int i = 0; i < F->n; i++) if (match) match[i] = -1;
         return YGZF_OK;
     }
-    if (!F->keys || !F->desc || !proj_x || !proj_y || !mp_desc || !owner || !match) return fail(c, YGZF_ERR_INVALID, "null array");
-    if (mode != 3) {
+    if (!F->keys || !F->desc || ((!proj_x || !proj_y) && !fr) || !mp_desc || !owner || !match) return fail(c, YGZF_ERR_INVALID, "null array");
+    if (fr) {
+        if (mode != 1) return fail(c, YGZF_ERR_INVALID, "fused frustum stage only feeds SearchByProjection(F, MapPoints)");
+    } else if (mode != 3) {
         if (!track_in_view || (mode == 1 && !view_cos) || (mode == 2 && !mp_angle) || !scale_level) return fail(c, YGZF_ERR_INVALID, "null array");
         for (int i = 0; i < n_mp; i++)
             if (track_in_view[i] && (scale_level[i] < 0 || scale_level[i] >= kMaxLevels)) return fail(c, YGZF_ERR_INVALID, "scale level out of range");
@@ -1384,7 +1451,7 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
     Up ups[] = {{&G[0], F->keys, nt * sizeof(ygzf_kp)}, {&G[1], F->desc, nt * 32}, {&G[2], F->u_right, F->u_right ? nt * 4 : 0},
                 {&G[3], owner, nt}, {&G[4], last_keys ? last_keys : dummyKeys.data(), nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32},
-                {&G[6], proj_x, nq * 4}, {&G[7], track_in_view, track_in_view ? nq : 0}, {&G[8], is_bad, is_bad ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
+                {&G[6], proj_x, fr ? 0 : nq * 4}, {&G[7], track_in_view, track_in_view && !fr ? nq : 0}, {&G[8], is_bad, is_bad ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
                 {&G[10], counts, sizeof counts}, {&G[11], pose, sizeof pose}};
     int rc;
     for (auto &u : ups) {
@@ -1396,9 +1463,24 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     if ((rc = ensure(c, c->dTmpA, nq * 16))) return rc;
     float *dY = (float *) c->dTmpA.p, *dXR = dY + nq, *dVC = dXR + nq;
     int *dLv = (int *) (dVC + nq);
-    HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
-    if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
-    if (mode != 3) {
+    if (fr) {   // Frame::isInFrustum on the device: its outputs land where the matcher reads them
+        if ((rc = ensure(c, G[6], nq * 4)) || (rc = ensure(c, G[7], nq))) return rc;
+        FrustumArgs FA;
+        if ((rc = fill_frustum_args(c, FA, fr->in, cam, n_mp, F->nlevels > 0 ? F->nlevels : c->tab.cfg.nlevels))) return rc;
+        FA.inView = (uint8_t *) G[7].p;
+        FA.projX = (float *) G[6].p;
+        FA.projY = dY;
+        FA.projXR = dXR;
+        FA.viewCos = dVC;
+        FA.level = dLv;
+        HIPCHECK(c, hipMemsetAsync(dLv, 0, nq * 4, c->stream));   // the matcher indexes scaleFactors[level] only for in-view points
+        launch_frustum(c->stream, FA);
+    } else {
+        HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
+        if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    if (fr) {
+    } else if (mode != 3) {
         HIPCHECK(c, hipMemcpyAsync(dVC, mode == 2 ? mp_angle : view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
         HIPCHECK(c, hipMemcpyAsync(dLv, scale_level, nq * 4, hipMemcpyHostToDevice, c->stream));
     } else if ((rc = ensure(c, c->dTmpB, nq * sizeof(int)))) return rc;
@@ -1417,7 +1499,7 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     A.lastKeys = (const ygzf_kp *) G[4].p;
     A.mpDesc = (const uint8_t *) G[5].p;
     A.world = (const float *) G[6].p;     // unused in this mode
-    A.mpValid = track_in_view ? (const uint8_t *) G[7].p : nullptr;
+    A.mpValid = (track_in_view || fr) ? (const uint8_t *) G[7].p : nullptr;
     A.match12 = (int *) c->dTmpB.p;
     A.outlier = is_bad ? (const uint8_t *) G[8].p : nullptr;
     A.hasObs = mp_has_obs ? (const uint8_t *) G[9].p : nullptr;
@@ -1427,7 +1509,7 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     A.poses = (const float *) G[11].p;
     A.mpProjX = (const float *) G[6].p;
     A.mpProjY = dY;
-    A.mpProjXR = proj_xr ? dXR : nullptr;
+    A.mpProjXR = (proj_xr || fr) ? dXR : nullptr;
     A.mpViewCos = dVC;
     A.mpAngle = dVC;
     A.mpLevel = dLv;
@@ -1450,6 +1532,14 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         launch_match_last(c->stream, A, 1, lds);
     }
     HIPCHECK(c, hipGetLastError());
+    if (fr) {
+        if (fr->in_view) HIPCHECK(c, hipMemcpyAsync(fr->in_view, G[7].p, nq, hipMemcpyDeviceToHost, c->stream));
+        if (fr->proj_x) HIPCHECK(c, hipMemcpyAsync(fr->proj_x, G[6].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        if (fr->proj_y) HIPCHECK(c, hipMemcpyAsync(fr->proj_y, dY, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        if (fr->proj_xr) HIPCHECK(c, hipMemcpyAsync(fr->proj_xr, dXR, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        if (fr->view_cos) HIPCHECK(c, hipMemcpyAsync(fr->view_cos, dVC, nq * 4, hipMemcpyDeviceToHost, c->stream));
+        if (fr->level) HIPCHECK(c, hipMemcpyAsync(fr->level, dLv, nq * 4, hipMemcpyDeviceToHost, c->stream));
+    }
     if (mode == 3) HIPCHECK(c, hipMemcpyAsync(match12, c->dTmpB.p, nq * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     else {
         HIPCHECK(c, hipMemcpyAsync(owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
@@ -1534,6 +1624,77 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *c, const ygzf_frame_view *F, c
                                         int check_level, float nnratio, uint8_t *owner, int *match, int *nmatches) {
     return projected_match(c, 1, F, cam, n_mp, track_in_view, is_bad, mp_has_obs, proj_x, proj_y, proj_xr, view_cos, scale_level, nullptr, mp_desc,
                            th, check_level, nnratio, 100, 0, owner, match, nmatches);
+}
+
+int ygzf_predict_scale_steps(float log_scale_factor, int nlevels, float *steps) {
+    if (!steps || nlevels < 1 || nlevels > kMaxLevels) return YGZF_ERR_INVALID;
+    float st[kMaxLevels];
+    predict_scale_steps(log_scale_factor, nlevels, st);
+    for (int k = 0; k < nlevels; k++) steps[k] = k == 0 ? 0.f : st[k];
+    return YGZF_OK;
+}
+
+int ygzf_is_in_frustum_batch(ygzf_ctx *c, const ygzf_camera *cam, int nlevels, int n, const ygzf_frustum_in *in, uint8_t *in_view, float *proj_x,
+                             float *proj_y, float *proj_xr, int *level, float *view_cos) {
+    if (!c || !cam || !in || !in_view || !proj_x || !proj_y || !proj_xr || !level || !view_cos) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    if (n == 0) return YGZF_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->dTmpA, (size_t) n * 20 + 64)) || (rc = ensure(c, c->dOwner, (size_t) n))) return rc;
+    FrustumArgs A;
+    if ((rc = fill_frustum_args(c, A, in, cam, n, nlevels))) return rc;
+    float *base = (float *) c->dTmpA.p;
+    A.inView = (uint8_t *) c->dOwner.p;
+    A.projX = base; A.projY = base + n; A.projXR = base + 2 * (size_t) n; A.viewCos = base + 3 * (size_t) n;
+    A.level = (int *) (base + 4 * (size_t) n);
+    HIPCHECK(c, hipMemsetAsync(base, 0, (size_t) n * 20, c->stream));
+    launch_frustum(c->stream, A);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(in_view, A.inView, (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(proj_x, A.projX, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(proj_y, A.projY, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(proj_xr, A.projXR, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(view_cos, A.viewCos, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(level, A.level, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_search_local_points(ygzf_ctx *c, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const ygzf_frustum_in *in,
+                             const uint8_t *mp_has_obs, const uint8_t *mp_desc, float th, int check_level, float nnratio, uint8_t *owner, int *match,
+                             int *nmatches, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, int *level, float *view_cos) {
+    if (!in) return fail(c, YGZF_ERR_INVALID, "null argument");
+    FrustumHost fr = {in, in_view, proj_x, proj_y, proj_xr, view_cos, level};
+    return projected_match(c, 1, F, cam, n_mp, nullptr, nullptr, mp_has_obs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mp_desc, th, check_level,
+                           nnratio, 100, 0, owner, match, nmatches, nullptr, nullptr, &fr);
+}
+
+int ygzf_distinctive_descriptors_batch(ygzf_ctx *c, int n_points, const int *obs_off, const uint8_t *desc, int *best_idx) {
+    if (!c || (n_points > 0 && (!obs_off || !best_idx))) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n_points <= 0) return YGZF_OK;
+    const int total = obs_off[n_points];
+    for (int p = 0; p < n_points; p++) {
+        const int n = obs_off[p + 1] - obs_off[p];
+        if (n < 0 || obs_off[p] < 0) return fail(c, YGZF_ERR_INVALID, "observation offsets not ascending");
+        if (n > 256) return fail(c, YGZF_ERR_UNSUPPORTED, "more than 256 observations of one MapPoint");
+    }
+    if (total > 0 && !desc) return fail(c, YGZF_ERR_INVALID, "null descriptors");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->dTmpA, 4 * (size_t) (n_points + 1))) || (rc = ensure(c, c->dTmpB, 4 * (size_t) n_points)) ||
+        (rc = ensure(c, c->dTmpC, 32 * (size_t) (total + 1))))
+        return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->dTmpA.p, obs_off, 4 * (size_t) (n_points + 1), hipMemcpyHostToDevice, c->stream));
+    if (total > 0) HIPCHECK(c, hipMemcpyAsync(c->dTmpC.p, desc, 32 * (size_t) total, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KK_HAMMING);
+        launch_distinctive(c->stream, n_points, (const int *) c->dTmpA.p, (const uint8_t *) c->dTmpC.p, (int *) c->dTmpB.p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(best_idx, c->dTmpB.p, 4 * (size_t) n_points, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
 }
 
 int ygzf_search_by_projection_kf(ygzf_ctx *c, const ygzf_frame_view *cur, const ygzf_camera *cam, int n_mp, const uint8_t *valid,
