@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
             const unsigned long long m = __ballot(pol != 0);
             const int add = __popcll(m);
             if (ncorn + add > kCornerCap) { overflow = true; break; }
-            if (pol) clist[ncorn + __popcll(m & lane_lt)] = (unsigned short) (((y * dw + x) << 2) | pol);
+            if (pol) clist[ncorn + __popcll(m & lane_lt)] = (unsigned short) ((y << 8) | (x << 2) | pol);   // x, y < 64
             ncorn += add;
             y += qy; x += qx;
             if (x >= dw) { x -= dw; y++; }
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
             const int qi = qb + lane;
             if (qi < ncorn) {
                 const int e = clist[qi];
-                const int p = e >> 2, y = p / dw, x = p - y * dw;
+                const int y = e >> 8, x = (e >> 2) & 63;
                 smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&tile[obase + (y + 3) * tp + x + 3], tp, e & 3);
             }
         }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
             int kIni = 0, kMin = 0, e = 0;
             if (qi < ncorn) {
                 e = clist[qi];
-                const int p = e >> 2, y = p / dw, x = p - y * dw;
+                const int y = e >> 8, x = (e >> 2) & 63;
                 const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
                 const int s = sp[0];
                 int nmax = 0, nmaxI = 0;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
             const bool keep = (e & want) != 0;
             const unsigned long long m = __ballot(keep);
             if (keep) {
-                const int p = e >> 2, y = p / dw, x = p - y * dw;
+                const int y = e >> 8, x = (e >> 2) & 63;
                 const unsigned s = smap[(y + 1) * kSP + x + 1];
                 out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
             }
