@@ -580,7 +580,7 @@ struct OctShared {  // carved out of dynamic LDS
     unsigned *cand;           // LDS-resident candidate sort buffers (4 x ldsCand), optional
 };
 
-__global__ __launch_bounds__(kOctBlock) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
+__global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
                                                       const unsigned short *__restrict__ cellCnt,
                                                       const unsigned *__restrict__ slots, int totalCells,
                                                       long long totalSlots, unsigned *__restrict__ candKey0,
@@ -952,10 +952,12 @@ constexpr int kHb = 37, kHbP = 40;      // horizontally blurred: 43 rows x 37 co
 constexpr int kBl = 37, kBlP = 40;      // blurred 37x37 (u8)
 constexpr int kDescWaves = 4;
 
-struct DescLds {
-    __attribute__((aligned(16))) uint8_t raw[kWin * kWinP + 16];
+struct DescLds {   // 6.2 KB per wave -> 6 workgroups (24 waves) per CU
+    union {           // the blurred patch replaces the raw window, which is dead once the horizontal pass has run
+        __attribute__((aligned(16))) uint8_t raw[kWin * kWinP + 16];
+        __attribute__((aligned(16))) uint8_t bl[kBl * kBlP + 8];
+    };
     __attribute__((aligned(16))) unsigned short hb[kWin * kHbP + 8];
-    __attribute__((aligned(16))) uint8_t bl[kBl * kBlP + 8];
 };
 
 __constant__ int8_t c_pattern[1024];
