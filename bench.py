@@ -112,8 +112,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="frames per GPU per step")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--batch", type=int, default=768, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=3,
                     help="independent extractor contexts (own HIP stream + buffers) the batch is split over, so that the "
                          "latency-bound kernels of one sub-batch overlap the throughput-bound kernels of another")
     ap.add_argument("--workload", default="euroc752x480_8lvl_1000feat", choices=sorted(WORKLOADS))

@@ -684,10 +684,10 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         const int prevSize = n;
         // -- full pass (:588-640): every node with more than one point is divided
         for (int i = tid; i < n; i += kOctBlock) {
-            const int cnt = S.ncnt[cur][i];
+            const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
             int k = 0, e = 0;
             if (cnt > 1) {
-                const int lo = S.nlo[cur][i], shift = 2 * (D - (S.ndep[cur][i] + 1));
+                const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[i] + 1));
                 const int a1 = digit_lower_bound(skeys, lo, cnt, shift, 1u);
                 const int a2 = digit_lower_bound(skeys, a1, lo + cnt - a1, shift, 2u);
                 const int a3 = digit_lower_bound(skeys, a2, lo + cnt - a2, shift, 3u);
@@ -704,10 +704,10 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         const int totS = block_scan_array(S.sArr, n, s_tmp);
         const int nxt = cur ^ 1;
         for (int i = tid; i < n; i += kOctBlock) {
-            const int cnt = S.ncnt[cur][i], lo = S.nlo[cur][i], dep = S.ndep[cur][i];
+            const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i], lo = (cur ? S.nlo[1] : S.nlo[0])[i], dep = (cur ? S.ndep[1] : S.ndep[0])[i];
             if (cnt == 1) {
                 const int p = totK + S.sArr[i];
-                S.nlo[nxt][p] = lo; S.ncnt[nxt][p] = 1; S.ndep[nxt][p] = dep;
+                (nxt ? S.nlo[1] : S.nlo[0])[p] = lo; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = 1; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep;
             } else {
                 const int bb[5] = {lo, S.b1[i], S.b2[i], S.b3[i], lo + cnt};
                 int k = 0;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 for (int c = 3; c >= 0; c--) {   // list order n4,n3,n2,n1
                     const int cc2 = bb[c + 1] - bb[c];
                     epos[c] = p;
-                    if (cc2 > 0) { S.nlo[nxt][p] = bb[c]; S.ncnt[nxt][p] = cc2; S.ndep[nxt][p] = dep + 1; p++; }
+                    if (cc2 > 0) { (nxt ? S.nlo[1] : S.nlo[0])[p] = bb[c]; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = cc2; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep + 1; p++; }
                 }
                 int es = S.eArr[i];
                 for (int c = 0; c < 4; c++) {    // creation order n1..n4
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 for (int j = tid; j < nE; j += kOctBlock) {
                     const int e = (int) ev[nE - 1 - j];
                     const int pos = S.Epos[e];
-                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos], shift = 2 * (D - (S.ndep[cur][pos] + 1));
+                    const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[pos] + 1));
                     const int a1 = digit_lower_bound(skeys, lo, cnt, shift, 1u);
                     const int a2 = digit_lower_bound(skeys, a1, lo + cnt - a1, shift, 2u);
                     const int a3 = digit_lower_bound(skeys, a2, lo + cnt - a2, shift, 3u);
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 for (int j = tid; j < nE; j += kOctBlock) {
                     const int e = (int) ev[nE - 1 - j];
                     const int pos = S.Epos[e];
-                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos];
+                    const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos];
                     const int bb[5] = {lo, S.b1[j], S.b2[j], S.b3[j], lo + cnt};
                     int k = 0;
                     for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                     const int jl = nProc - 1;
                     const int e = (int) ev[nE - 1 - jl];
                     const int pos = S.Epos[e];
-                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos];
+                    const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos];
                     const int bb[5] = {lo, S.b1[jl], S.b2[jl], S.b3[jl], lo + cnt};
                     int k = 0;
                     for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 for (int i = tid; i < n; i += kOctBlock) {
                     if (!S.flag[i]) {
                         const int p = totC + S.sArr[i];
-                        S.nlo[nxt2][p] = S.nlo[cur][i]; S.ncnt[nxt2][p] = S.ncnt[cur][i]; S.ndep[nxt2][p] = S.ndep[cur][i];
+                        (nxt2 ? S.nlo[1] : S.nlo[0])[p] = (cur ? S.nlo[1] : S.nlo[0])[i]; (nxt2 ? S.ncnt[1] : S.ncnt[0])[p] = (cur ? S.ncnt[1] : S.ncnt[0])[i]; (nxt2 ? S.ndep[1] : S.ndep[0])[p] = (cur ? S.ndep[1] : S.ndep[0])[i];
                     }
                 }
                 // new expandable list goes to the sort buffers first (Epos/Ecnt are still being read)
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 for (int j = tid; j < nProc; j += kOctBlock) {
                     const int e = (int) ev[nE - 1 - j];
                     const int pos = S.Epos[e];
-                    const int cnt = S.ncnt[cur][pos], lo = S.nlo[cur][pos], dep = S.ndep[cur][pos];
+                    const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos], dep = (cur ? S.ndep[1] : S.ndep[0])[pos];
                     const int bb[5] = {lo, S.b1[j], S.b2[j], S.b3[j], lo + cnt};
                     int k = 0;
                     for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                     for (int c = 3; c >= 0; c--) {
                         const int cc2 = bb[c + 1] - bb[c];
                         epos[c] = p;
-                        if (cc2 > 0) { S.nlo[nxt2][p] = bb[c]; S.ncnt[nxt2][p] = cc2; S.ndep[nxt2][p] = dep + 1; p++; }
+                        if (cc2 > 0) { (nxt2 ? S.nlo[1] : S.nlo[0])[p] = bb[c]; (nxt2 ? S.ncnt[1] : S.ncnt[0])[p] = cc2; (nxt2 ? S.ndep[1] : S.ndep[0])[p] = dep + 1; p++; }
                     }
                     int es = S.eArr[j];
                     for (int c = 0; c < 4; c++) {
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     unsigned char *osc = lvlKpScore + (long long) f * kpStride + g.kpBase;
     const int lane = lane_id(), wave = wave_id();
     for (int i = wave; i < n; i += kOctBlock / 64) {
-        const int lo = S.nlo[cur][i], cnt = S.ncnt[cur][i];
+        const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
         unsigned best = 0;
         for (int k = lane; k < cnt; k += 64) best = max(best, svals[lo + k]);
         best = wave_max_u32(best);
