@@ -88,6 +88,9 @@ int ygzf_extract_batch_device(ygzf_ctx *ctx, const uint8_t *d_imgs, int n_frames
 int ygzf_extract_batch_host(ygzf_ctx *ctx, const uint8_t *imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
 int ygzf_batch_counts(ygzf_ctx *ctx, int *n_kp /* n_frames ints */);
 int ygzf_batch_fetch(ygzf_ctx *ctx, int frame, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
+/* All frames of the batch with one synchronisation: kps / desc hold n_frames rows of `stride` (>= ygzf_max_keypoints) entries, frame f's
+ * first n_kp[f] entries are valid.  Pass page-locked host memory (hipHostMalloc / hipHostRegister) for full PCIe rate. */
+int ygzf_batch_fetch_all(ygzf_ctx *ctx, ygzf_kp *kps, uint8_t *desc, int *n_kp, int stride);
 /* Copies pyramid level `level` of batch frame `frame` back to the host, tight. */
 int ygzf_batch_fetch_level(ygzf_ctx *ctx, int frame, int level, uint8_t *out);
 int ygzf_sync(ygzf_ctx *ctx);

@@ -85,6 +85,7 @@ def load_library(build_if_missing=True):
     L.ygzf_extract_batch_host.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t]
     L.ygzf_batch_counts.argtypes = [vp, vp]
     L.ygzf_batch_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int, ip]
+    L.ygzf_batch_fetch_all.argtypes = [vp, vp, vp, vp, C.c_int]
     L.ygzf_batch_fetch_level.argtypes = [vp, C.c_int, C.c_int, vp]
     L.ygzf_sync.argtypes = [vp]
     L.ygzf_batch_fetch_candidates.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip]
@@ -227,6 +228,16 @@ class Extractor:
         n = C.c_int()
         self._ck(self.L.ygzf_batch_fetch(self.h, frame, _p(k), _p(d), cap, C.byref(n)))
         return k[:n.value].copy(), d[:n.value].copy()
+
+    def batch_fetch_all(self, n_frames, out=None):
+        """All frames' keypoints / descriptors with one synchronisation -> (kps (B, stride), desc (B, stride, 32), counts)."""
+        w, h, _ = self._wh
+        stride = max(self.max_keypoints(w, h), 1)
+        if out is None:
+            out = (np.zeros((n_frames, stride), KP_DTYPE), np.zeros((n_frames, stride, 32), np.uint8), np.zeros(n_frames, np.int32))
+        k, d, n = out
+        self._ck(self.L.ygzf_batch_fetch_all(self.h, _p(k), _p(d), _p(n), stride))
+        return k, d, n
 
     def batch_fetch_level(self, frame, level):
         w, h, _ = self._wh

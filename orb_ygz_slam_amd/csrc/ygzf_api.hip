@@ -688,6 +688,21 @@ int ygzf_batch_fetch(ygzf_ctx *c, int frame, ygzf_kp *kps, uint8_t *desc, int ca
     return YGZF_OK;
 }
 
+int ygzf_batch_fetch_all(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int *n_kp, int stride) {
+    if (!c || !kps || !desc || !n_kp) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (stride < c->geo.kpStride) return fail(c, YGZF_ERR_INVALID, "stride %d < %d (ygzf_max_keypoints)", stride, c->geo.kpStride);
+    const int B = c->lastFrames, ks = c->geo.kpStride;
+    HIPCHECK(c, hipMemcpyAsync(n_kp, (int *) c->dOutCnt.p + 1, sizeof(int) * B, hipMemcpyDeviceToHost, c->stream));
+    // slot f + 1 holds frame f; rows of `stride` keypoints on the host side, kpStride on the device side
+    HIPCHECK(c, hipMemcpy2DAsync(kps, sizeof(ygzf_kp) * (size_t) stride, (ygzf_kp *) c->dOutKp.p + ks, sizeof(ygzf_kp) * (size_t) ks,
+                                 sizeof(ygzf_kp) * (size_t) ks, B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpy2DAsync(desc, 32 * (size_t) stride, (uint8_t *) c->dOutDesc.p + 32 * (size_t) ks, 32 * (size_t) ks, 32 * (size_t) ks, B,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
 int ygzf_extract(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
     if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
     *n_out = 0;
