@@ -580,6 +580,9 @@ struct OctShared {  // carved out of dynamic LDS
     unsigned *cand;           // LDS-resident candidate sort buffers (4 x ldsCand), optional
 };
 
+// kGlobalNodes: the 19 per-list-position arrays live in a global arena (nodeArena, 19 * cap ints per (frame, level)) instead of LDS --
+// configurations whose per-level feature budget is too large for the LDS plan (e.g. one level with > 2000 features).
+template <bool kGlobalNodes>
 __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
                                                       const unsigned short *__restrict__ cellCnt,
                                                       const unsigned *__restrict__ slots, int totalCells,
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                                                       long long candStride, unsigned *__restrict__ lvlKpXY,
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
                                                       int *__restrict__ lvlCandCnt, unsigned short *__restrict__ procOrder,
-                                                      int kpStride, int cap, int ldsCand, long long *dbg) {
+                                                      int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[256];
     __shared__ int s_tmp[20];
@@ -609,13 +612,15 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     {
         int *p = dyn;
         S.cellPref = p; p += nCells + 1;
+        int *candLds = p;
+        if (kGlobalNodes) p = nodeArena + ((long long) blockIdx.y * nlevels + blockIdx.x) * (19LL * cap);
         for (int b = 0; b < 2; b++) { S.nlo[b] = p; p += cap; S.ncnt[b] = p; p += cap; S.ndep[b] = p; p += cap; }
         S.kArr = p; p += cap; S.eArr = p; p += cap; S.sArr = p; p += cap;
         S.b1 = p; p += cap; S.b2 = p; p += cap; S.b3 = p; p += cap;
         S.Epos = p; p += cap; S.Ecnt = p; p += cap;
         for (int b = 0; b < 2; b++) { S.sk[b] = (unsigned *) p; p += cap; S.sv[b] = (unsigned *) p; p += cap; }
         S.flag = p; p += cap;
-        S.cand = (unsigned *) p;   // 4 * ldsCand words: key/val double buffers when the level's candidates fit
+        S.cand = (unsigned *) (kGlobalNodes ? candLds : p);   // 4 * ldsCand words: key/val double buffers when the level's candidates fit
     }
     const unsigned short *cc = cellCnt + (long long) f * totalCells + g.cellBase;
     const unsigned *sl = slots + (long long) f * totalSlots + g.slotBase;
@@ -1154,7 +1159,7 @@ hipError_t upload_constants(const int *umax16) {
 
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
-    if (g.area2x) {   // exact 2x levels (scaleFactor 2.0 configs) keep the simple per-pixel kernel
+    if (g.area2x || !g.tiledOk) {   // exact 2x levels (area mean) and steep pyramids (tile would not fit LDS): per-pixel kernel
         dim3 grid((g.w + 255) / 256, g.h, nFrames);
         hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
         return;
@@ -1178,21 +1183,27 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
                        smapRows);
 }
 
-size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand) {
-    return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 19 * (size_t) cap + 4 * (size_t) ldsCand);
+size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes) {
+    return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + (globalNodes ? 0 : 19 * (size_t) cap) + 4 * (size_t) ldsCand);
 }
 
-hipError_t octree_prepare(size_t ldsBytes) {
-    return hipFuncSetAttribute((const void *) k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+hipError_t octree_prepare(size_t ldsBytes, bool globalNodes) {
+    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes)
+                       : hipFuncSetAttribute((const void *) k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
 }
 
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg) {
-    hipLaunchKernelGGL(k_octree, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots,
-                       totalCells, totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt,
-                       procOrder, kpStride, cap, ldsCand, dbg);
+                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena) {
+    if (nodeArena)
+        hipLaunchKernelGGL(k_octree<true>, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots, totalCells,
+                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procOrder, kpStride, cap, ldsCand,
+                           dbg, nodeArena);
+    else
+        hipLaunchKernelGGL(k_octree<false>, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots, totalCells,
+                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procOrder, kpStride, cap, ldsCand,
+                           dbg, nodeArena);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,

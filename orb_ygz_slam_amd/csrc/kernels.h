@@ -13,12 +13,12 @@ size_t fast_lds_bytes(int tilePitch, int tileRows, int smapRows);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int tilePitch,
                        int tileRows, int smapRows, int nFrames);
-size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand);
-hipError_t octree_prepare(size_t ldsBytes);
+size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes);
+hipError_t octree_prepare(size_t ldsBytes, bool globalNodes);
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg = nullptr);
+                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena);
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
                      const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
                      ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames);

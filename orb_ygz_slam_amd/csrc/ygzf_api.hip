@@ -114,6 +114,8 @@ struct ygzf_ctx {
     void *identityPosesPtr = nullptr;
     size_t octLds = 0;
     int octLdsCand = 0;
+    bool octGlobalNodes = false;
+    Buf dOctNodes;
     // batch state
     int lastFrames = 0;
     FrameSet lastFs{};
@@ -213,6 +215,19 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
                 G.ybeta.push_back(sat_short((1.f - fy) * 2048));
                 G.ybeta.push_back(sat_short(fy * 2048));
             }
+            // the LDS-tiled resize kernel stages <= 44 rows x 328 bytes of source per 256 x 32 output tile: true for the usual scale
+            // factors (<= ~1.27); steeper pyramids take the per-pixel kernel
+            g.tiledOk = 1;
+            for (int x0 = 0; x0 < g.w && g.tiledOk; x0 += 256) {
+                const int xl = std::min(x0 + 256, g.w) - 1;
+                const int sxa = G.xofs[g.xtab + x0] & ~3, sxb = std::min(G.xofs[g.xtab + xl] + 1, s.w - 1);
+                if ((sxb - sxa) / 4 + 1 > 328 / 4) g.tiledOk = 0;
+            }
+            for (int y0 = 0; y0 < g.h && g.tiledOk; y0 += 32) {
+                const int yl = std::min(y0 + 32, g.h) - 1;
+                const int sya = std::min(std::max(G.yofs[g.ytab + y0], 0), s.h - 1), syb = std::min(std::max(G.yofs[g.ytab + yl] + 1, 0), s.h - 1);
+                if (syb - sya + 1 > 44) g.tiledOk = 0;
+            }
         }
         // FAST cells
         g.maxBorderX = g.w - kEdgeThreshold + 3;
@@ -306,16 +321,19 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         c->lastFrames = 0;
         // LDS-resident candidate sort buffers: as many as keep two workgroups per CU (<= ~78 KB each)
         {
-            const size_t fixed = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0);
+            // per-list-position arrays (19 x cap ints) stay in LDS while one workgroup fits the CU; very large per-level feature budgets
+            // move them to a global arena
+            c->octGlobalNodes = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, false) > 150 * 1024;
+            const size_t fixed = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, c->octGlobalNodes);
             const size_t budget = 78 * 1024;
             c->octLdsCand = fixed + 16 * 256 < budget ? (int) ((budget - fixed) / 16) : 0;
             if (c->octLdsCand > 8192) c->octLdsCand = 8192;
         }
-        c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, c->octLdsCand);
+        c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, c->octLdsCand, c->octGlobalNodes);
         if (c->octLds > 160 * 1024 - 2048)
             return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
                         G.maxCellsPerLevel, G.kpCapMax);
-        HIPCHECK(c, octree_prepare(c->octLds));
+        HIPCHECK(c, octree_prepare(c->octLds, c->octGlobalNodes));
     }
     const Geometry &G = c->geo;
     const size_t B = (size_t) nFrames;
@@ -327,6 +345,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
     if ((rc = ensure(c, c->dK0, cb)) || (rc = ensure(c, c->dV0, cb)) || (rc = ensure(c, c->dK1, cb)) || (rc = ensure(c, c->dV1, cb)) ||
         (rc = ensure(c, c->dXY, cb)))
         return rc;
+    if (c->octGlobalNodes && (rc = ensure(c, c->dOctNodes, B * L * 19 * (size_t) G.kpCapMax * sizeof(int) + 64))) return rc;
     const size_t kp = std::max<size_t>(B * G.kpStride, 16);
     const size_t kp1 = std::max<size_t>((B + 1) * G.kpStride, 16);  // + carry slot
     void *oldCnt = c->dOutCnt.p, *oldKp = c->dOutKp.p;
@@ -435,7 +454,8 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                           G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                           (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                           (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
-                          (unsigned short *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg);
+                          (unsigned short *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg,
+                          c->octGlobalNodes ? (int *) c->dOctNodes.p : nullptr);
         }
         if (odbg) {
             long long st[16 * 8];
@@ -537,7 +557,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)

@@ -25,6 +25,7 @@ struct LevelGeom {
     int w, h, pitch;          // level image; pitch in bytes (64-aligned) for levels >= 1
     long long off;            // byte offset of the level inside one frame's pyramid slab (levels >= 1)
     int area2x;               // 1: previous level is exactly 2x in both axes -> 2x2 area average (cv::resize quirk)
+    int tiledOk;              // 1: every 256x32 output tile's source region fits the LDS staging area of k_pyr_resize_tiled
     int xtab, ytab;           // offsets into the resize coefficient tables
     // FAST cell grid, src/ORBextractor.cc:733-745
     int nCols, nRows, wCell, hCell;

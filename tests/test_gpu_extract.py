@@ -121,3 +121,54 @@ def test_baseline_large_configs(oracle, w, h, nl, nf):
     e_n, e_m, e_o = oracle.search_by_projection_last(k, d, oex.tables()["scale"], w, h, EUROC, k0, world, d0, I, z, I, z, 15.0)
     m, o = ex.match_fetch(1)
     assert ex.match_counts()[1] == e_n and (m[:len(k)] == e_m).all() and e_n > 0.3 * nf
+
+
+def test_bench_clip_parity(oracle):
+    """The exact clip bench.py times: every frame of a 64-frame run (extract + match against the predecessor, carried across two
+    batches) equals the oracle -- the number `value` is quoted on is a number about correct results."""
+    from bench import make_frames
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    frames = make_frames(64, w, h)
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=32)
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    cam = make_camera(w, h)
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    prev = None
+    for half in range(2):
+        ex.extract_batch_host(frames[32 * half:32 * half + 32])
+        ex.match_batch_prev(cam, 15.0, True, True, True)
+        counts = ex.match_counts()
+        for f in range(32):
+            k, d = ex.batch_fetch(f)
+            ok, od = oex.extract(frames[32 * half + f])
+            assert len(k) == len(ok) and (k == ok).all() and (d == od).all()
+            m, o = ex.match_fetch(f)
+            if prev is not None:
+                pk, pd = prev
+                world = np.stack([(pk["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]),
+                                  (pk["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]), np.ones(len(pk), np.float32)], -1).astype(np.float32)
+                e_n, e_m, e_o = oracle.search_by_projection_last(k, d, oex.tables()["scale"], w, h, EUROC, pk, world, pd, I, z, I, z, 15.0)
+                assert counts[f] == e_n and (m[:len(k)] == e_m).all() and (o[:len(k)] == e_o).all()
+            prev = (k, d)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("YGZF_FUZZ_SEEDS", "10"))))
+def test_extract_fuzz_sizes_and_configs(oracle, seed):
+    """Random image sizes / pyramid depths / scale factors / feature budgets / thresholds."""
+    from orb_ygz_slam_amd import Extractor
+    rng = np.random.default_rng(100 + seed)
+    w, h = int(rng.integers(120, 900)), int(rng.integers(100, 700))
+    nl = int(rng.integers(1, 10))
+    sf = float(rng.choice([1.1, 1.2, 1.25, 1.5, 2.0]))
+    nf = int(rng.integers(50, 3000))
+    ini = int(rng.integers(8, 40))
+    mn = int(rng.integers(2, ini + 1))
+    ex = Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=2)
+    oex = oracle.Extractor(nf, sf, nl, ini, mn)
+    imgs = np.stack([synth_frame(200 + seed, w, h), rng.integers(0, 256, (h, w), dtype=np.uint8)])
+    ex.extract_batch_host(imgs)
+    for f in range(2):
+        k, d = ex.batch_fetch(f)
+        ok, od = oex.extract(imgs[f])
+        assert len(k) == len(ok) and (k == ok).all() and (d == od).all(), (w, h, nl, sf, nf, ini, mn, f)
