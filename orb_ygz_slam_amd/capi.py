@@ -532,7 +532,9 @@ class Extractor:
         img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape
         existing = np.zeros(0, KP_DTYPE) if existing is None else np.ascontiguousarray(existing, KP_DTYPE)
-        cap = cap or (len(existing) + 3 * (w // 7) * (h // 7) + 16)
+        g0 = grid_size if grid_size > 0 else max(1, int(np.sqrt(h * w / max(self.cfg.nfeatures if hasattr(self, 'cfg') else self.nfeatures, 1))))
+        gm = max(1, min(7, g0))
+        cap = cap or (len(existing) + 3 * (w // gm) * (h // gm) + 16)
         k = np.zeros(cap, KP_DTYPE)
         k[:len(existing)] = existing
         d = np.zeros((cap, 32), np.uint8)

@@ -3,6 +3,8 @@
 // silent return (src/ORBextractor.cc:972-973), zero keypoints => descriptors.release() (:990-991).
 #include "ORBextractor.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 
 #include "../../../include/ygzf.h"
@@ -101,7 +103,9 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
     std::vector<cv::KeyPoint> fresh;            // the new keypoints
     std::vector<uint8_t> descExisting((size_t) N * 32), descNew;
     if (method == DSO_KEYPOINT) {
-        const int cap = N + 3 * (img.cols / 7) * (img.rows / 7) + 16;
+        const int g0 = mnGridSize > 0 ? mnGridSize : std::max(1, (int) std::sqrt(1.0 * img.rows * img.cols / std::max(nfeatures, 1)));
+        const int gm = std::max(1, std::min(7, g0));   // smallest grid the retry loop can reach
+        const int cap = N + 3 * (img.cols / gm) * (img.rows / gm) + 16;
         std::vector<cv::KeyPoint> all(cap);
         std::vector<uint8_t> d((size_t) cap * 32);
         for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];

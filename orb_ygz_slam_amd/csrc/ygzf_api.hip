@@ -1317,7 +1317,9 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
     int grid = *grid_size;
     if (grid < 0) grid = (int) std::sqrt(1.0 * h * w / (n > 0 ? n : 1));
     const int minGrid = 7;
-    const int maxCells = (w / minGrid) * (h / minGrid) + 1;
+    if (grid < 1) return fail(c, YGZF_ERR_INVALID, "grid size %d", grid);
+    const int gmin = std::min(grid, minGrid);   // a start below 7 (many features on a small image) is used as it is; it only never shrinks further
+    const int maxCells = (w / gmin) * (h / gmin) + 1;
     const size_t occWords = ((size_t) w * h + 31) / 32;
     ygzf_ctx::Buf &dOcc = c->dDso[0], &dOccXY = c->dDso[1], &dCellCnt = c->dDso[2], &dCellXY = c->dDso[3], &dTotal = c->dDso[4], &dList = c->dDso[5],
                   &dNewXY = c->dDso[6], &dAng = c->dDso[7];
@@ -1346,7 +1348,7 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
         if (grid < 1) return fail(c, YGZF_ERR_INVALID, "grid size %d", grid);
         const int nRows = h / grid, nCols = w / grid;
         nInner = (nRows > 2 && nCols > 2) ? (nRows - 2) * (nCols - 2) : 0;
-        if (nInner > maxCells) return fail(c, YGZF_ERR_INVALID, "grid size %d below the minimum %d", grid, minGrid);
+        if (nInner > maxCells) return fail(c, YGZF_ERR_INVALID, "grid size %d: more cells than planned", grid);
         HIPCHECK(c, hipMemsetAsync(dTotal.p, 0, 4, c->stream));
         {
             ProfScope ps(c, KK_DSO);
