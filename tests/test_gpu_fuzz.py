@@ -122,3 +122,113 @@ def test_fuzz_dso(oracle, seed):
         ko, do, g_cpu = oex.extract_dso(img, existing=existing if it else None, grid_size=g_cpu)
         assert g_gpu == g_cpu and len(kg) == len(ko), (w, h, nl, sf, nf, it, g_gpu, g_cpu, len(kg), len(ko))
         assert (kg == ko).all() and (dg == do).all(), (w, h, nl, sf, nf, it)
+
+
+def _frame_pair(ex, rng, w, h, seed):
+    base = synth_frame(seed, w + 16, h + 16)
+    dx, dy = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+    a, b = base[8:8 + h, 8:8 + w], base[dy:dy + h, dx:dx + w]
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    return a, b, ka, da, kb, db
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_projected_searches(oracle, seed):
+    """SearchByProjection(F, MapPoints) / (Cur, KF, found) / SearchForInitialization / SearchByBoW with random sizes and parameters,
+    incl. large keypoint counts (the matcher's LDS spill plans) and tiny ones."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(200, 1100)), int(rng.integers(160, 800))
+    nf = int(rng.choice([30, 300, 1000, 2500, 5000]))
+    ex = Extractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    a, b, ka, da, kb, db = _frame_pair(ex, rng, w, h, 1100 + seed)
+    if len(ka) < 2 or len(kb) < 2:
+        pytest.skip("no keypoints")
+    cam = make_camera(w, h)
+    M, N = len(ka), len(kb)
+    # (F, MapPoints)
+    tiv = (rng.uniform(size=M) > 0.15).astype(np.uint8)
+    px = (ka["x"] + rng.uniform(-3, 3, M)).astype(np.float32)
+    py = (ka["y"] + rng.uniform(-3, 3, M)).astype(np.float32)
+    vc = rng.uniform(0.99, 1.0, M).astype(np.float32)
+    lvl = np.clip(ka["octave"] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    bad = (rng.uniform(size=M) > 0.95).astype(np.uint8)
+    obs = (rng.uniform(size=M) > 0.2).astype(np.uint8)
+    own = ((rng.uniform(size=N) > 0.9) * rng.integers(1, 3, N)).astype(np.uint8)
+    th, chk, ratio = float(rng.choice([1.0, 3.0, 5.0])), bool(rng.integers(0, 2)), float(rng.choice([0.6, 0.8, 0.9]))
+    e = oracle.search_by_projection_mappoints(kb, db, sf, w, h, EUROC, tiv, px, py, vc, lvl, da, th, chk, ratio, is_bad=bad, mp_has_obs=obs, owner=own)
+    g = ex.search_by_projection_mappoints(cam, kb, db, tiv, px, py, vc, lvl, da, th, chk, ratio, is_bad=bad, mp_has_obs=obs, owner=own,
+                                          scale_factors=sf)
+    assert g[0] == e[0] and (g[1] == e[1]).all() and (g[2] == e[2]).all(), ("mappoints", w, h, nf, th, chk, ratio)
+    # (Cur, KF, found): device part
+    valid = tiv
+    own2 = (rng.uniform(size=N) > 0.85).astype(np.uint8)
+    thk, od, ori = float(rng.choice([3.0, 10.0])), int(rng.choice([64, 100])), bool(rng.integers(0, 2))
+    g = ex.search_by_projection_kf(cam, kb, db, valid, px, py, lvl, ka["angle"], da, thk, od, ori, owner=own2, scale_factors=sf)
+    # oracle of the device part = mode-2 rules expressed through the mappoints oracle is not available: use the full KF oracle with a
+    # world/pose that reproduces (px, py, lvl) is overkill here; the dedicated test covers it.  Check invariants instead.
+    gm = g[1]
+    assert g[0] == (gm >= 0).sum() and not (gm[own2 != 0] >= 0).any()
+    # SearchForInitialization
+    prev = np.stack([ka["x"], ka["y"]], -1).astype(np.float32) + rng.uniform(-2, 2, (M, 2)).astype(np.float32)
+    win, r2, ori2 = int(rng.choice([10, 50, 100])), float(rng.choice([0.6, 0.9])), bool(rng.integers(0, 2))
+    e = oracle.search_for_initialization(ka, da, kb, db, sf, w, h, EUROC, prev, win, r2, ori2)
+    g = ex.search_for_initialization(cam, ka, da, kb, db, prev, win, r2, ori2, scale_factors=sf)
+    assert g[0] == e[0] and (g[1] == e[1]).all() and (g[2] == e[2]).all(), ("init", w, h, nf, win, r2, ori2)
+    # SearchByBoW on stand-in FeatureVectors (node = leading descriptor bits)
+    bits = int(rng.integers(1, 9))
+    na, nb = da[:, 0].astype(np.int32) >> (8 - bits), db[:, 0].astype(np.int32) >> (8 - bits)
+    nodes = sorted(set(na.tolist()) & set(nb.tolist()))
+    ko, fo, ki, fi = [0], [0], [], []
+    for n_ in nodes:
+        ki.extend(np.nonzero(na == n_)[0]); fi.extend(np.nonzero(nb == n_)[0])
+        ko.append(len(ki)); fo.append(len(fi))
+    if max(np.diff(fo), default=0) <= 4096:
+        e = oracle.search_by_bow(ko, ki, fo, fi, tiv, ka, da, kb, db, ratio, ori2)
+        g = ex.search_by_bow(ko, ki, fo, fi, tiv, ka, da, kb, db, ratio, ori2)
+        assert g[0] == e[0] and (g[1] == e[1]).all(), ("bow", w, h, nf, bits)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_frustum_and_distinctive(oracle, seed):
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    rng = np.random.default_rng(1200 + seed)
+    w, h = 752, 480
+    nl = int(rng.integers(1, 13))
+    sfv = float(rng.choice([1.1, 1.2, 1.5, 2.0]))
+    if sfv == 2.0:
+        nl = min(nl, 8)          # deeper 2.0-pyramids of a 752x480 image have empty levels (rejected at create time)
+    ex = Extractor(500, sfv, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(500, sfv, nl, 20, 7)
+    sf = oex.tables()["scale"]
+    cam = make_camera(w, h, mbf=47.9)
+    cam_d = dict(EUROC, mbf=47.9)
+    n = int(rng.choice([1, 7, 500, 5000]))
+    world = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    world[:, 2] = rng.uniform(-1, 12, n)
+    normal = rng.normal(size=(n, 3)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    mf = rng.uniform(0.5, 30, n).astype(np.float32)
+    mx, mn = (np.float32(1.2) * mf).astype(np.float32), (np.float32(0.8) * mf / sf[-1]).astype(np.float32)
+    ang = np.float32(rng.uniform(-0.3, 0.3))
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = rng.uniform(-0.5, 0.5, 3).astype(np.float32)
+    Ow = (-Rcw.T @ tcw).astype(np.float32)
+    lsf = np.log(np.float32(sfv), dtype=np.float32)
+    lim = float(rng.choice([0.5, 0.0, 0.9]))
+    dummy_k = np.zeros(1, oex.extract(np.zeros((64, 64), np.uint8))[0].dtype)
+    o = oracle.is_in_frustum(dummy_k, np.zeros((1, 32), np.uint8), sf, w, h, cam_d, world, normal, mx, mn, mf, Rcw, tcw, Ow, lsf, lim)
+    g = ex.is_in_frustum_batch(cam, world, normal, mx, mn, mf, Rcw, tcw, Ow, lsf, lim)
+    iv = o[0].astype(bool)
+    assert (g[0] == o[0]).all(), (nl, sfv, n, lim)
+    for a_, b_ in zip(g[1:], o[1:]):
+        assert np.array_equal(a_[iv].view(np.uint32), b_[iv].view(np.uint32)), (nl, sfv, n, lim)
+    counts = rng.integers(0, int(rng.choice([4, 30, 257])), int(rng.integers(1, 200)))
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    desc = rng.integers(0, 256, (max(off[-1], 1), 32), dtype=np.uint8)
+    if off[-1] > 0 and seed % 2:
+        desc[:] = desc[0] ^ np.packbits((rng.uniform(size=(len(desc), 256)) < 0.1).astype(np.uint8), axis=1)
+    assert (ex.distinctive_descriptors_batch(off, desc) == oracle.distinctive_descriptors(off, desc)).all()
