@@ -40,11 +40,18 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return lib_path()
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
-    srcs = [s for s in SRCS if os.path.exists(os.path.join(HERE, s))]
-    cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include")] + srcs + ["-o", lib_path()]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=HERE)
+    import fcntl
+    with open(os.path.join(HERE, "lib", ".build.lock"), "w") as lock:   # several ranks of one node may get here at once
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return lib_path()
+        srcs = [s for s in SRCS if os.path.exists(os.path.join(HERE, s))]
+        tmp = lib_path() + ".tmp.%d" % os.getpid()
+        cmd = [hipcc()] + FLAGS + ["-I" + os.path.join(ROOT, "include")] + srcs + ["-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=HERE)
+        os.replace(tmp, lib_path())                                      # a loaded library is never rewritten in place
     return lib_path()
 
 
