@@ -491,9 +491,13 @@ static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, i
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
-    for (int f = 0; f < nFrames; f++)
-        HIPCHECK(c, hipMemcpy2DAsync((uint8_t *) c->dImg0.p + (size_t) f * pitch * h, pitch, imgs + f * frame_stride, row_pitch, w, h,
-                                     hipMemcpyHostToDevice, c->stream));
+    if (nFrames > 1 && frame_stride == (size_t) row_pitch * h) {   // frames back to back: one 2-D copy of nFrames * h rows
+        HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, pitch, imgs, row_pitch, w, (size_t) nFrames * h, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (int f = 0; f < nFrames; f++)
+            HIPCHECK(c, hipMemcpy2DAsync((uint8_t *) c->dImg0.p + (size_t) f * pitch * h, pitch, imgs + f * frame_stride, row_pitch, w, h,
+                                         hipMemcpyHostToDevice, c->stream));
+    }
     fs->img0 = (const uint8_t *) c->dImg0.p;
     fs->img0_stride = (long long) pitch * h;
     fs->img0_pitch = pitch;
