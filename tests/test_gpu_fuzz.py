@@ -232,3 +232,71 @@ def test_fuzz_frustum_and_distinctive(oracle, seed):
     if off[-1] > 0 and seed % 2:
         desc[:] = desc[0] ^ np.packbits((rng.uniform(size=(len(desc), 256)) < 0.1).astype(np.uint8), axis=1)
     assert (ex.distinctive_descriptors_batch(off, desc) == oracle.distinctive_descriptors(off, desc)).all()
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_sparse_img_align(oracle, seed):
+    """SparseImgAlign::run with random motions, level ranges, iteration counts, feature budgets and invalid / outlier MapPoints
+    (SE3 within 1e-5 of the oracle, same measurement count)."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    from orb_ygz_slam_amd.scene import two_view_scene
+    rng = np.random.default_rng(1400 + seed)
+    w, h = 752, 480
+    nl = int(rng.integers(3, 9))
+    nf = int(rng.choice([60, 300, 1000, 2000]))
+    rv = tuple(rng.uniform(-0.01, 0.01, 3))
+    tr = tuple(rng.uniform(-0.05, 0.05, 3))
+    imgA, imgB, _, backproject = two_view_scene(1500 + seed, w, h, EUROC, Z=float(rng.uniform(2, 8)), rotvec=rv, trans=tr)
+    ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
+    k, _ = ex.extract(imgA)
+    pyrA, pyrB = ex.compute_pyramid(imgA), ex.compute_pyramid(imgB)
+    world = backproject(k["x"], k["y"])
+    inv = oex.tables()["inv_scale"]
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    max_level = int(rng.integers(1, nl))
+    min_level = int(rng.integers(0, max_level + 1))
+    n_iter = int(rng.choice([1, 3, 10]))
+    valid = (rng.uniform(size=len(k)) > 0.2).astype(np.uint8)
+    outl = (rng.uniform(size=len(k)) > 0.9).astype(np.uint8)
+    o = oracle.sparse_img_align(k, world, ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter, mp_valid=valid, outlier=outl)
+    g = ex.sia_run(make_camera(w, h), k, world, ident, pyrA, ident, pyrB, inv, max_level, min_level, n_iter, mp_valid=valid, outlier=outl)
+    assert g[0] == o[0], (nl, nf, max_level, min_level, n_iter, g[0], o[0])
+    # 1e-5 on well-posed problems; where the normal equations are ill-conditioned (few features, one coarse level, no convergence) the
+    # reference's own result moves by more than that when its features are merely summed in another order -- measured by running the
+    # oracle on the reversed feature list -- and the device is held to that band instead
+    orev = oracle.sparse_img_align(k[::-1], world[::-1], ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter,
+                                   mp_valid=valid[::-1], outlier=outl[::-1])
+    tol = max(1e-5, 4.0 * float(np.abs(orev[1] - o[1]).max()))
+    assert np.abs(g[1] - o[1]).max() <= tol, (nl, nf, max_level, min_level, n_iter, tol, g[1], o[1])
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_direct_projection(oracle, seed):
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    from orb_ygz_slam_amd.scene import rotvec_to_quat, two_view_scene
+    rng = np.random.default_rng(1600 + seed)
+    w, h = 752, 480
+    nl = int(rng.integers(2, 9))
+    sfv = float(rng.choice([1.2, 1.2, 1.5]))
+    rv = tuple(rng.uniform(-0.03, 0.03, 3))
+    tr = tuple(rng.uniform(-0.2, 0.2, 3))
+    A, B, (R, t), bp = two_view_scene(1700 + seed, w, h, EUROC, Z=float(rng.uniform(2, 6)), rotvec=rv, trans=tr)
+    ex = Extractor(800, sfv, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(800, sfv, nl, 20, 7)
+    k, _ = ex.extract(A)
+    if len(k) == 0:
+        pytest.skip("no keypoints")
+    world = bp(k["x"], k["y"]) * rng.uniform(0.7, 1.4, (len(k), 1)).astype(np.float32)
+    q = rotvec_to_quat(rv)
+    T7 = np.array([q[0], q[1], q[2], q[3], *tr], np.float32)
+    ident = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], np.float32), (len(k), 1))
+    px0 = (np.stack([k["x"], k["y"]], -1) + rng.uniform(-30, 30, (len(k), 2))).astype(np.float32)
+    ex.image_cache_reserve(2, w, h)
+    ex.image_cache_put(0, A)
+    ex.image_cache_put(1, B)
+    slot = np.zeros(len(k), np.int32)
+    g = ex.find_direct_projection_batch(make_camera(w, h), 1, T7, slot, ident, k, world, px0, want_patches=True)
+    o = oex.find_direct_projection_batch([A], B, T7, EUROC, slot, ident, k, world, px0)
+    assert (g[3] == o[3]).all() and (g[1] == o[1]).all() and (g[2] == o[2]).all(), (nl, sfv)
+    assert np.array_equal(np.nan_to_num(g[0], nan=-1e9).view(np.uint32), np.nan_to_num(o[0], nan=-1e9).view(np.uint32)), (nl, sfv)
