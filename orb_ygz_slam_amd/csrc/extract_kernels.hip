@@ -958,10 +958,7 @@ constexpr int kBl = 37, kBlP = 40;      // blurred 37x37 (u8)
 constexpr int kDescWaves = 4;
 
 struct DescLds {   // 6.2 KB per wave -> 6 workgroups (24 waves) per CU
-    union {           // the blurred patch replaces the raw window, which is dead once the horizontal pass has run
-        __attribute__((aligned(16))) uint8_t raw[kWin * kWinP + 16];
-        __attribute__((aligned(16))) uint8_t bl[kBl * kBlP + 8];
-    };
+    __attribute__((aligned(16))) uint8_t raw[kWin * kWinP + 16];
     __attribute__((aligned(16))) unsigned short hb[kWin * kHbP + 8];
 };
 
@@ -1029,21 +1026,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         else { dst[2] = o[4]; }                              // columns 32..36: 5 outputs (column 37.. unused)
     }
     wave_lds_sync();
-    // vertical: 37 columns x 5 row segments
-    for (int t = lane; t < kBl * 5; t += 64) {
-        const int sg = (t * 1772) >> 16, c = t - 37 * sg;   // t / 37, t % 37 for t < 185
-        const unsigned short *p = &L.hb[(8 * sg) * kHbP + c];
-        const int nr = sg < 4 ? 8 : 5;
-        int q[14];
-#pragma unroll
-        for (int k = 0; k < 14; k++) q[k] = (8 * sg + k < kWin) ? p[k * kHbP] : 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int s2 = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
-            if (k < nr) L.bl[(8 * sg + k) * kBlP + c] = (uint8_t) min((s2 + 32768) >> 16, 255);
-        }
-    }
-    wave_lds_sync();
+    // vertical pass only where the rotated pattern samples (512 points instead of the 37 x 37 patch): 7 taps straight from hb
     float a, b;
     sincos_deg(angle, &a, &b);
 #pragma unroll
@@ -1053,7 +1036,10 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         const float x1 = (float) c_pattern[4 * p + 2], y1 = (float) c_pattern[4 * p + 3];
         const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-        const int t0 = L.bl[(18 + r0) * kBlP + 18 + q0], t1 = L.bl[(18 + r1) * kBlP + 18 + q1];
+        const unsigned short *p0 = &L.hb[(18 + r0) * kHbP + 18 + q0], *p1 = &L.hb[(18 + r1) * kHbP + 18 + q1];
+        const int s0 = 18 * (p0[0] + p0[6 * kHbP]) + 34 * (p0[kHbP] + p0[5 * kHbP]) + 49 * (p0[2 * kHbP] + p0[4 * kHbP]) + 55 * p0[3 * kHbP];
+        const int s1 = 18 * (p1[0] + p1[6 * kHbP]) + 34 * (p1[kHbP] + p1[5 * kHbP]) + 49 * (p1[2 * kHbP] + p1[4 * kHbP]) + 55 * p1[3 * kHbP];
+        const int t0 = min((s0 + 32768) >> 16, 255), t1 = min((s1 + 32768) >> 16, 255);
         bits[it] = __ballot(t0 < t1);
     }
     *angleOut = angle;
