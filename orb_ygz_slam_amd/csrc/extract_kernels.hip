@@ -962,6 +962,24 @@ struct DescLds {   // 6.2 KB per wave -> 6 workgroups (24 waves) per CU
     __attribute__((aligned(16))) unsigned short hb[kWin * kHbP + 8];
 };
 
+// umax of the 31-px circular patch (src/ORBextractor.cc:455-469 for HALF_PATCH_SIZE = 15); ygzf_create checks the context's table against it
+constexpr int kUmax15[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+struct DiscMasks { unsigned long long m[16]; };
+constexpr DiscMasks make_disc_masks() {
+    DiscMasks d{};
+    for (int it = 0; it < 16; it++) {
+        unsigned long long m = 0;
+        for (int lane = 0; lane < 64; lane++) {
+            const int u = (lane & 31) - 15, v = 2 * it + (lane >> 5) - 15;
+            const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+            if ((lane & 31) < 31 && v <= 15 && au <= kUmax15[av]) m |= 1ull << lane;
+        }
+        d.m[it] = m;
+    }
+    return d;
+}
+constexpr DiscMasks kDiscMask = make_disc_masks();
+
 __constant__ int8_t c_pattern[1024];
 __constant__ int c_umax[16];
 
@@ -994,17 +1012,23 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
 #define RAWP(r) (&L.raw[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
     wave_lds_sync();
     // ---- intensity centroid on the 31x31 disc (centre = window (21,21)): two rows per step, no divisions
-    int m10 = 0, m01 = 0;
+    int m10, m01;
     {
+        // lane = (row parity, column): u = (lane & 31) - 15, v = 2 * it + (lane >> 5) - 15.  Which lanes lie inside the disc in step `it`
+        // is a compile-time lane mask (kDiscMask, from the fixed umax table of HALF_PATCH_SIZE = 15); m10 = u * (sum of the column).
         const int u = (lane & 31) - 15;
+        int colSum = 0, vSum = 0;
+#pragma unroll
         for (int it = 0; it < 16; it++) {
             const int v = 2 * it + (lane >> 5) - 15;
-            if ((lane & 31) < 31 && v <= 15 && abs(u) <= c_umax[abs(v)]) {
+            if ((kDiscMask.m[it] >> lane) & 1ull) {
                 const int I = RAWP(21 + v)[21 + u];
-                m10 += u * I;
-                m01 += v * I;
+                colSum += I;
+                vSum += v * I;
             }
         }
+        m10 = u * colSum;
+        m01 = vSum;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -1138,6 +1162,8 @@ __global__ void k_hamming_pairs(const unsigned long long *__restrict__ a, const 
 // launchers
 // ------------------------------------------------------------------------------------------------------------------
 hipError_t upload_constants(const int *umax16) {
+    for (int i = 0; i < 16; i++)
+        if (umax16[i] != kUmax15[i]) return hipErrorInvalidValue;   // the orientation kernel's disc masks are built for this table
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kBriefPattern, 1024);
     if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
