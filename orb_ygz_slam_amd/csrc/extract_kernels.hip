@@ -980,7 +980,7 @@ constexpr DiscMasks make_disc_masks() {
 }
 constexpr DiscMasks kDiscMask = make_disc_masks();
 
-__constant__ int8_t c_pattern[1024];
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024];
 __constant__ int c_umax[16];
 
 // One wave: orientation + blurred patch + 256 rBRIEF bits of the keypoint at integer (kx,ky) of a gw x gh level image.
@@ -1056,8 +1056,9 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int p = it * 64 + lane;
-        const float x0 = (float) c_pattern[4 * p], y0 = (float) c_pattern[4 * p + 1];
-        const float x1 = (float) c_pattern[4 * p + 2], y1 = (float) c_pattern[4 * p + 3];
+        const int pk = ((const int *) c_pattern)[p];   // (x0, y0, x1, y1) as 4 signed bytes: one load
+        const float x0 = (float) (signed char) (pk & 0xFF), y0 = (float) (signed char) ((pk >> 8) & 0xFF);
+        const float x1 = (float) (signed char) ((pk >> 16) & 0xFF), y1 = (float) (signed char) ((pk >> 24) & 0xFF);
         const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
         const unsigned short *p0 = &L.hb[(18 + r0) * kHbP + 18 + q0], *p1 = &L.hb[(18 + r1) * kHbP + 18 + q1];
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const
                                                             ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
                                                             int *__restrict__ outCnt, int outStride, int blocksPerXcd) {
     __shared__ DescLds lds[kDescWaves];
-    const int lane = lane_id(), wave = wave_id();
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform: the keypoint record loads go scalar
     const int f = blockIdx.y;
     // XCD-aware: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (spatially ordered) keypoint slots so
     // that overlapping 43x43 windows meet in the same L2.  pslot = position in the frame's concatenated PROCESSING order.
