@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const Lev
         }
     }
     __syncthreads();
-    const int lane = tid & 63, rg = tid >> 6;
+    const int lane = tid & 63, rg = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xb = x0 + 4 * lane;
     if (xb >= g.w) return;
     int lx[4], lx1[4], a0[4], a1[4];
@@ -225,13 +225,23 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const Lev
         a1[k] = xalpha[2 * (g.xtab + x) + 1];
     }
     uint8_t *dstf = fs.pyr + (long long) f * fs.pyr_stride + g.off;
+    // the 8 rows of this wave: their y coefficients are wave-uniform -> scalar loads, all issued before the arithmetic
+    int r0s[8], r1s[8], b0s[8], b1s[8];
+#pragma unroll
+    for (int ry = 0; ry < 8; ry++) {
+        const int y = min(y0 + rg * 8 + ry, g.h - 1);
+        const int sy = yofs[g.ytab + y];
+        r0s[ry] = min(max(sy, 0), sh - 1) - sya;
+        r1s[ry] = min(max(sy + 1, 0), sh - 1) - sya;
+        b0s[ry] = ybeta[2 * (g.ytab + y)];
+        b1s[ry] = ybeta[2 * (g.ytab + y) + 1];
+    }
+#pragma unroll
     for (int ry = 0; ry < 8; ry++) {
         const int y = y0 + rg * 8 + ry;
         if (y >= g.h) break;
-        const int sy = yofs[g.ytab + y];
-        const int r0 = min(max(sy, 0), sh - 1) - sya, r1 = min(max(sy + 1, 0), sh - 1) - sya;
-        const int b0 = ybeta[2 * (g.ytab + y)], b1 = ybeta[2 * (g.ytab + y) + 1];
-        const uint8_t *S0 = tile + r0 * kPyrSrcPitch, *S1 = tile + r1 * kPyrSrcPitch;
+        const int b0 = b0s[ry], b1 = b1s[ry];
+        const uint8_t *S0 = tile + r0s[ry] * kPyrSrcPitch, *S1 = tile + r1s[ry] * kPyrSrcPitch;
         unsigned out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
