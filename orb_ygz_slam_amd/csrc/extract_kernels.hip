@@ -394,8 +394,9 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
         }
     }
     __syncthreads();   // the only block-level synchronisation
-    // ---- per-wave: one cell ----
-    const int ci = 2 * gi + (wave >> 1), cj = 2 * gj + (wave & 1);
+    // ---- per-wave: one cell (everything derived from the wave index is wave-uniform: keep it on the scalar unit) ----
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int ci = 2 * gi + (wv >> 1), cj = 2 * gj + (wv & 1);
     if (ci >= g.nRows || cj >= g.nCols) return;
     const int c = ci * g.nCols + cj;
     unsigned short *cnt_out = cellCnt + (long long) f * totalCells + g.cellBase + c;
@@ -407,8 +408,8 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
         if (lane == 0) *cnt_out = 0;
         return;
     }
-    uint8_t *smap = fdyn + ((tileRows * tp + 15) & ~15) + wave * (smapRows * kSP);
-    unsigned short *clist = (unsigned short *) (fdyn + ((tileRows * tp + 15) & ~15) + kFastBlock / 64 * (smapRows * kSP)) + wave * kCornerCap;
+    uint8_t *smap = fdyn + ((tileRows * tp + 15) & ~15) + wv * (smapRows * kSP);
+    unsigned short *clist = (unsigned short *) (fdyn + ((tileRows * tp + 15) & ~15) + kFastBlock / 64 * (smapRows * kSP)) + wv * kCornerCap;
     for (int idx = lane; idx < ((dh + 2) * kSP) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
     // origin of the cell window inside the staged tile
     const int obase = (iniY - gy0) * tp + (iniX - gx0) + xoff;
