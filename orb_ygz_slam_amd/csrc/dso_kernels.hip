@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * kDsoWaves) void k_dso_cells(const uint8_t *__r
                                                             const unsigned *__restrict__ occ, int *__restrict__ cellCnt,
                                                             unsigned *__restrict__ cellXY, int *__restrict__ total) {
     __shared__ uint8_t tiles[kDsoWaves][(kDsoMaxGrid + 10) * kDsoTileP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int innerCols = nCols - 2, nInner = innerCols * (nRows - 2);
     const int cell = blockIdx.x * kDsoWaves + wave;
     if (cell >= nInner) return;   // waves are independent: no block barrier below

@@ -20,7 +20,7 @@ namespace ygzf {
 // small wave / block primitives (wave = 64 lanes)
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform by construction
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
     const int lane = lane_id();

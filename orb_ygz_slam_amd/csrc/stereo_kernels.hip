@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned s_wave_min(unsigned v) {
 
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nl = A.cnt[(long long) pair * A.cntStride + A.cntOffL], nr = A.cnt[(long long) pair * A.cntStride + A.cntOffR];
     if (iL >= nl) return;
     float *outU = A.uRight + (long long) pair * A.outStride, *outD = A.depth + (long long) pair * A.outStride;
