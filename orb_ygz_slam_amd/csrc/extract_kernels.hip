@@ -968,9 +968,15 @@ constexpr int kHb = 37, kHbP = 40;      // horizontally blurred: 43 rows x 37 co
 constexpr int kBl = 37, kBlP = 40;      // blurred 37x37 (u8)
 constexpr int kDescWaves = 4;
 
-struct DescLds {   // 6.2 KB per wave -> 6 workgroups (24 waves) per CU
-    __attribute__((aligned(16))) uint8_t raw[kWin * kWinP + 16];
-    __attribute__((aligned(16))) unsigned short hb[kWin * kHbP + 8];
+// Per-wave LDS: the row-blurred window hb (43 rows x 40 u16 = 3440 B) and the raw window (43 rows x 64 B) share memory: hb rows 0..25
+// sit in front of raw, hb rows 26..42 overlay raw rows 0..21, which are dead by the time they are written (the orientation moments
+// are taken first, the horizontal pass consumes raw rows in ascending order and a wave's LDS operations execute in order).
+// 4.9 KB per wave -> 8 workgroups of 4 waves fit a CU.
+constexpr int kHbFront = 26 * kHbP * 2;   // bytes of hb in front of raw (rows 0..25)
+struct DescLds {
+    __attribute__((aligned(16))) uint8_t mem[kHbFront + kWin * kWinP + 16];
+    __device__ __forceinline__ uint8_t *rawp() { return mem + kHbFront; }
+    __device__ __forceinline__ unsigned short *hbp() { return (unsigned short *) mem; }
 };
 
 // umax of the 31-px circular patch (src/ORBextractor.cc:455-469 for HALF_PATCH_SIZE = 15); ygzf_create checks the context's table against it
@@ -1011,16 +1017,16 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         for (int idx = lane; idx < kWin * 4; idx += 64) {
             const int r = idx >> 2, q = idx & 3;
             const unsigned long long a = a00 + (unsigned) r * (unsigned) pitch;
-            *(uint4 *) &L.raw[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
+            *(uint4 *) &L.rawp()[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
         }
     } else {
         for (int idx = lane; idx < kWin * kWin; idx += 64) {
             const int r = idx / kWin, c = idx - r * kWin;
             const int yy = reflect101(ky - 21 + r, gh), xx = reflect101(kx - 21 + c, gw);
-            L.raw[r * kWinP + c] = img[(long long) yy * pitch + xx];
+            L.rawp()[r * kWinP + c] = img[(long long) yy * pitch + xx];
         }
     }
-#define RAWP(r) (&L.raw[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
+#define RAWP(r) (&L.rawp()[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
     wave_lds_sync();
     // ---- intensity centroid on the 31x31 disc (centre = window (21,21)): two rows per step, no divisions
     int m10, m01;
@@ -1055,7 +1061,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         unsigned o[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) o[k] = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
-        unsigned *dst = (unsigned *) &L.hb[r * kHbP + 8 * sg];
+        unsigned *dst = (unsigned *) &L.hbp()[r * kHbP + 8 * sg];
         dst[0] = o[0] | (o[1] << 16); dst[1] = o[2] | (o[3] << 16);
         if (sg < 4) { dst[2] = o[4] | (o[5] << 16); dst[3] = o[6] | (o[7] << 16); }
         else { dst[2] = o[4]; }                              // columns 32..36: 5 outputs (column 37.. unused)
@@ -1072,7 +1078,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         const float x1 = (float) (signed char) ((pk >> 16) & 0xFF), y1 = (float) (signed char) ((pk >> 24) & 0xFF);
         const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
-        const unsigned short *p0 = &L.hb[(18 + r0) * kHbP + 18 + q0], *p1 = &L.hb[(18 + r1) * kHbP + 18 + q1];
+        const unsigned short *p0 = &L.hbp()[(18 + r0) * kHbP + 18 + q0], *p1 = &L.hbp()[(18 + r1) * kHbP + 18 + q1];
         const int s0 = 18 * (p0[0] + p0[6 * kHbP]) + 34 * (p0[kHbP] + p0[5 * kHbP]) + 49 * (p0[2 * kHbP] + p0[4 * kHbP]) + 55 * p0[3 * kHbP];
         const int s1 = 18 * (p1[0] + p1[6 * kHbP]) + 34 * (p1[kHbP] + p1[5 * kHbP]) + 49 * (p1[2 * kHbP] + p1[4 * kHbP]) + 55 * p1[3 * kHbP];
         const int t0 = min((s0 + 32768) >> 16, 255), t1 = min((s1 + 32768) >> 16, 255);
