@@ -1088,7 +1088,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
 #undef RAWP
 }
 
-__global__ __launch_bounds__(64 * kDescWaves) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                             const unsigned *__restrict__ lvlKpXY,
                                                             const unsigned char *__restrict__ lvlKpScore,
                                                             const int *__restrict__ lvlKpCnt,
