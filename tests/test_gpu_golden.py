@@ -67,3 +67,17 @@ def test_gpu_reproduces_committed_goldens():
     from make_golden_paths import cases
     from tests.test_oracle_paths_golden import check_against_golden
     check_against_golden(cases(_GpuAsOracle()), float_tol={("align", "T"): 1e-5})
+
+
+def test_gpu_reproduces_extract_goldens():
+    """HIP extractor against the committed extract_golden.npz (the FAST-10 fixture with the reference library's own 167-corner known
+    answer is replayed by tests/test_gpu_fast10.py)."""
+    import hashlib
+    from orb_ygz_slam_amd import Extractor
+    from orb_ygz_slam_amd.synth import synth_frame
+    from tests.test_oracle_golden import CASES, GOLD as EG
+    for name, w, h, seed, cfg in CASES:
+        img = synth_frame(seed, w, h)
+        k, d = Extractor(*cfg, max_width=w, max_height=h, max_batch=1).extract(img)
+        assert len(k) == int(EG[name + "_n"][0])
+        assert hashlib.sha256(k.tobytes() + d.tobytes()).digest() == EG[name + "_sha"].tobytes(), name
