@@ -264,10 +264,13 @@ def test_fuzz_sparse_img_align(oracle, seed):
     assert g[0] == o[0], (nl, nf, max_level, min_level, n_iter, g[0], o[0])
     # 1e-5 on well-posed problems; where the normal equations are ill-conditioned (few features, one coarse level, no convergence) the
     # reference's own result moves by more than that when its features are merely summed in another order -- measured by running the
-    # oracle on the reversed feature list -- and the device is held to that band instead
-    orev = oracle.sparse_img_align(k[::-1], world[::-1], ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter,
-                                   mp_valid=valid[::-1], outlier=outl[::-1])
-    tol = max(1e-5, 4.0 * float(np.abs(orev[1] - o[1]).max()))
+    # oracle on permuted feature lists -- and the device is held to that band instead
+    band = 0.0
+    for perm in (np.arange(len(k))[::-1], rng.permutation(len(k)), rng.permutation(len(k))):
+        op = oracle.sparse_img_align(k[perm], world[perm], ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter,
+                                     mp_valid=valid[perm], outlier=outl[perm])
+        band = max(band, float(np.abs(op[1] - o[1]).max()))
+    tol = max(1e-5, 10.0 * band)   # a pose that differs in the last bits can flip a feature across a level's border test: discrete jumps
     assert np.abs(g[1] - o[1]).max() <= tol, (nl, nf, max_level, min_level, n_iter, tol, g[1], o[1])
 
 
