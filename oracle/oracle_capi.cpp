@@ -78,8 +78,10 @@ int yo_extract(void *e_, const uint8_t *img, int w, int h, int stride, KeyPoint 
     e->Extract(img, w, h, stride, k, d);
     int n = (int) k.size();
     if (n > cap) return -n;
-    std::memcpy(kps, k.data(), sizeof(KeyPoint) * n);
-    std::memcpy(desc, d.data(), 32 * (size_t) n);
+    if (n > 0) {   // empty vectors have a null data(): memcpy(…, nullptr, 0) is undefined
+        std::memcpy(kps, k.data(), sizeof(KeyPoint) * n);
+        std::memcpy(desc, d.data(), 32 * (size_t) n);
+    }
     return n;
 }
 
@@ -132,8 +134,10 @@ int yo_extract_dso(void *e_, const uint8_t *img, int w, int h, int stride, KeyPo
     *grid_size = e->mnGridSize;
     const int n = (int) k.size();
     if (n > cap) return -n;
-    std::memcpy(keys, k.data(), sizeof(KeyPoint) * n);
-    std::memcpy(desc, d.data(), 32 * (size_t) n);
+    if (n > 0) {
+        std::memcpy(keys, k.data(), sizeof(KeyPoint) * n);
+        std::memcpy(desc, d.data(), 32 * (size_t) n);
+    }
     return n;
 }
 

@@ -34,7 +34,7 @@ _ref = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(os.environ.get("YGZ_ORACLE_LIB") or build())   # YGZ_ORACLE_LIB: the sanitizer build (tests/test_oracle_sanitizers.py)
         L = _lib
         L.yo_extractor_create.restype = C.c_void_p
         L.yo_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
