@@ -144,6 +144,7 @@ class Extractor:
         self.L = load_library()
         self.nlevels = nlevels
         self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self._wh = (max_width, max_height, 0)   # (w, h, frames) of the last extracted batch
         self.h = C.c_void_p()
         rc = self.L.ygzf_create(device, C.byref(self.cfg), max_width, max_height, max_batch, C.byref(self.h))
         if rc != 0:

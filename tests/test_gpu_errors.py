@@ -1,0 +1,75 @@
+"""Error conventions of the C ABI on a live device: every misuse returns a negative status with an explanation (no exception crosses
+the ABI, nothing is silently clamped), and the context stays usable afterwards."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def test_misuse_is_reported_not_absorbed(oracle):
+    from orb_ygz_slam_amd import Extractor, make_camera
+    from orb_ygz_slam_amd.capi import KP_DTYPE, ExtractorCfg, YgzfError, load_library
+    L = load_library()
+    # bad configurations are rejected at create time
+    for cfg in ((1000, 1.0, 8, 20, 7), (1000, 1.2, 0, 20, 7), (1000, 1.2, 17, 20, 7), (-1, 1.2, 8, 20, 7), (1000, 1.2, 8, 7, 20), (1000, 1.2, 8, 300, 7)):
+        h = C.c_void_p()
+        c = ExtractorCfg(*cfg)
+        assert L.ygzf_create(0, C.byref(c), 640, 480, 1, C.byref(h)) < 0 and not h.value
+        assert len(L.ygzf_last_error(None)) > 0
+    h = C.c_void_p()
+    assert L.ygzf_create(99, C.byref(ExtractorCfg(1000, 1.2, 8, 20, 7)), 640, 480, 1, C.byref(h)) < 0      # no such device
+    w, hh = 640, 480
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=hh, max_batch=2)
+    img = synth_frame(0, w, hh)
+    # state errors: nothing extracted yet
+    with pytest.raises(YgzfError):
+        ex.batch_fetch(0)
+    with pytest.raises(YgzfError):
+        ex.match_counts()
+    with pytest.raises(YgzfError):
+        ex.stereo_fetch(0)
+    # a batch larger than the context was created for, an image larger than planned
+    with pytest.raises(YgzfError):
+        ex.extract_batch_host(np.stack([img] * 3))
+    with pytest.raises(YgzfError):
+        ex.extract(synth_frame(1, 800, 600))
+    # capacity too small: the count is reported, nothing is written past the buffer
+    k = np.zeros(10, KP_DTYPE)
+    d = np.zeros((10, 32), np.uint8)
+    n = C.c_int()
+    rc = L.ygzf_extract(ex.h, img.ctypes.data_as(C.c_void_p), w, hh, w, k.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert rc < 0 and n.value > 10 and (k["x"] == 0).all()
+    # stereo needs (left, right) pairs; frame index out of range
+    ex.extract_batch_host(img[None])
+    with pytest.raises(YgzfError):
+        ex.stereo_batch(0.11, 47.9)
+    with pytest.raises(YgzfError):
+        ex.batch_fetch(1)
+    # unaligned device frames are refused (4-byte alignment contract of the resident-batch entry)
+    with pytest.raises(YgzfError):
+        ex.extract_batch_device(0x7F0000001001, 1, w, hh)      # rejected on the address alone, never dereferenced
+    # existing keys outside their level / bad octave in the DSO path
+    bad = np.zeros(1, KP_DTYPE)
+    bad["x"], bad["y"], bad["octave"] = 3.0, 3.0, 0
+    with pytest.raises(YgzfError):
+        ex.extract_dso(img, existing=bad)
+    bad["x"], bad["y"], bad["octave"] = 100.0, 100.0, 9
+    with pytest.raises(YgzfError):
+        ex.extract_dso(img, existing=bad)
+    # direct projection without a cache / with an empty slot
+    cam = make_camera(w, hh)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    with pytest.raises(YgzfError):
+        ex.find_direct_projection_batch(cam, 0, ident, [0], ident[None], bad, np.zeros((1, 3), np.float32), np.zeros((1, 2), np.float32))
+    ex.image_cache_reserve(2, w, hh)
+    ex.image_cache_put(0, img)
+    with pytest.raises(YgzfError):
+        ex.find_direct_projection_batch(cam, 1, ident, [0], ident[None], bad, np.zeros((1, 3), np.float32), np.zeros((1, 2), np.float32))
+    # after all that the context still produces correct results
+    kk, dd = ex.extract(img)
+    ok, od = oracle.Extractor(1000, 1.2, 8, 20, 7).extract(img)
+    assert (kk == ok).all() and (dd == od).all()
