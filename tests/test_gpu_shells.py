@@ -146,3 +146,16 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     sur, sdp = np.fromfile(tmp_path / "s_uright.bin", np.float32), np.fromfile(tmp_path / "s_depth.bin", np.float32)
     assert (sur.view(np.uint32) == our.view(np.uint32)).all() and (sdp.view(np.uint32) == odp.view(np.uint32)).all()
     assert (our >= 0).sum() > 100
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/extract_match.c: the boundary is usable from C99 without any C++ or Python in between."""
+    from orb_ygz_slam_amd import load_library
+    load_library()
+    lib = os.path.join(ROOT, "orb_ygz_slam_amd", "lib")
+    exe = str(tmp_path / "extract_match")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "extract_match.c"),
+                           "-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "keypoints:" in out.stdout
