@@ -172,3 +172,33 @@ def test_extract_fuzz_sizes_and_configs(oracle, seed):
         k, d = ex.batch_fetch(f)
         ok, od = oex.extract(imgs[f])
         assert len(k) == len(ok) and (k == ok).all() and (d == od).all(), (w, h, nl, sf, nf, ini, mn, f)
+
+
+def test_two_host_threads_two_contexts(oracle):
+    """The reference extracts the two eyes on two std::threads with one extractor each (src/Frame.cc:728-731): contexts are
+    independent (own stream, own buffers, no shared mutable globals), so concurrent use from two host threads gives the same bytes."""
+    import threading
+    from orb_ygz_slam_amd import Extractor
+    w, h = 752, 480
+    imgs = [synth_frame(300, w, h), synth_frame(301, w, h)]
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    want = [oex.extract(im) for im in imgs]
+    errors = []
+
+    def worker(i):
+        try:
+            ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)     # created inside the thread, like the eyes' extractors
+            for _ in range(25):
+                k, d = ex.extract(imgs[i])
+                if not ((k == want[i][0]).all() and (d == want[i][1]).all()):
+                    errors.append("thread %d: mismatch" % i)
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
