@@ -6,6 +6,7 @@
 #include <set>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ORBextractor.h"
@@ -205,6 +206,23 @@ int main(int argc, char **argv) {
         dump(dir + "/s_kpsr.bin", S.mvKeysRight.data(), S.mvKeysRight.size() * sizeof(cv::KeyPoint));
         dump(dir + "/s_uright.bin", S.mvuRight.data(), S.mvuRight.size() * sizeof(float));
         dump(dir + "/s_depth.bin", S.mvDepth.data(), S.mvDepth.size() * sizeof(float));
+    }
+    // ORBmatcher objects live on the stacks of several threads at once (Tracking / LocalMapping / LoopClosing): the context pool
+    {
+        std::vector<int> results(3 * 4, -1);
+        std::vector<std::thread> th;
+        for (int t = 0; t < 3; t++)
+            th.emplace_back([&, t]() {
+                for (int it = 0; it < 4; it++) {
+                    Frame Bt = B;                                   // private copy: the search writes mvpMapPoints
+                    Bt.mvpMapPoints.assign(Bt.N, nullptr);
+                    ORBmatcher m(0.9f, true);
+                    results[t * 4 + it] = m.SearchByProjection(Bt, A, 15.f, true);
+                }
+            });
+        for (auto &t : th) t.join();
+        for (int r : results)
+            if (r != nm) { fprintf(stderr, "threaded SearchByProjection: %d != %d\n", r, nm); return 3; }
     }
     cv::Mat d0 = A.mDescriptors.row(0), d1 = A.mDescriptors.row(1);
     printf("shells ok: %d / %d keypoints, align ret %zu, %d matches, dist(0,1)=%d\n", A.N, B.N, ret, nm, ORBmatcher::DescriptorDistance(d0, d1));

@@ -20,7 +20,7 @@ def _build(tmp):
     exe = os.path.join(tmp, "test_shells")
     srcs = [os.path.join(ROOT, "tests", "cpp", "test_shells.cc")] + [os.path.join(host, f) for f in
                                                                      ("ORBextractor.cc", "ORBmatcher.cc", "SparseImageAlign.cc")]
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", host] + srcs + ["-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", host] + srcs + ["-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
     return exe
 
 
