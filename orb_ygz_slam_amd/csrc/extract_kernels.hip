@@ -268,17 +268,6 @@ __device__ __forceinline__ bool has_arc9(unsigned m16) {
     return (r & 0xFFFFu) != 0;
 }
 
-// Ring differences d[k] = ring_k - centre for the 16-pixel Bresenham circle (offsets as cv::FAST / libfast);
-// tp = LDS pitch of the staged window.
-__device__ __forceinline__ void ring_diffs(const uint8_t *c, int tp, int d[16]) {
-    const int v = c[0];
-    const int t2 = 2 * tp, t3 = 3 * tp;
-    d[0] = c[t3] - v;        d[1] = c[t3 + 1] - v;    d[2] = c[t2 + 2] - v;    d[3] = c[tp + 3] - v;
-    d[4] = c[3] - v;         d[5] = c[-tp + 3] - v;   d[6] = c[-t2 + 2] - v;   d[7] = c[-t3 + 1] - v;
-    d[8] = c[-t3] - v;       d[9] = c[-t3 - 1] - v;   d[10] = c[-t2 - 2] - v;  d[11] = c[-tp - 3] - v;
-    d[12] = c[-3] - v;       d[13] = c[tp - 3] - v;   d[14] = c[t2 - 2] - v;   d[15] = c[t3 - 1] - v;
-}
-
 // 1 = bright corner, 2 = dark corner, 0 = none, at threshold t (9 contiguous ring pixels > v+t or < v-t).
 // Ring pixels k and k+8 share one register as two 16-bit lanes, so one packed subtract (v_pk_sub_i16) tests two ring positions
 // per polarity; the sign bits (bit 15 / 31) are shifted into place as they arrive: after 8 steps ring k sits at bit 8+k of the low
@@ -326,25 +315,44 @@ __device__ __forceinline__ int fast9_test(const uint8_t *c, int tp, int t) {
 }
 
 // cv::FAST cornerScore<16> for a pixel known to be a corner of polarity `pol`: max over the 16 arcs of 9 of the minimum
-// margin, minus 1 (== the largest threshold for which the pixel is still a corner).
+// margin, minus 1 (== the largest threshold for which the pixel is still a corner).  Signed margins e[k] = +-(ring_k - centre)
+// live as 16-bit pairs (e[k] | e[k+8] << 16), so every packed min serves two arcs; "k+8" neighbours are the swapped halves.
+__device__ __forceinline__ unsigned pk_min16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ unsigned pk_max16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+}
+__device__ __forceinline__ unsigned pk_mul16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_bit_cast(v2s, a) * __builtin_bit_cast(v2s, b));
+}
+__device__ __forceinline__ unsigned swap16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
 __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol) {
-    int e[16];
-    ring_diffs(c, tp, e);
-    if (pol == 2) {
+    const int t2 = 2 * tp, t3 = 3 * tp;
+    const unsigned vv = (unsigned) c[0] * 0x10001u;
+    const unsigned sg = pol == 2 ? 0xFFFFFFFFu : 0x00010001u;   // -1 / +1 in both halves
+    unsigned P[8];
+#define MARGIN_PAIR(k, a, b) P[k] = pk_mul16(pk_sub16((unsigned) c[a] | ((unsigned) c[b] << 16), vv), sg);
+    MARGIN_PAIR(0, t3, -t3) MARGIN_PAIR(1, t3 + 1, -t3 - 1) MARGIN_PAIR(2, t2 + 2, -t2 - 2) MARGIN_PAIR(3, tp + 3, -tp - 3)
+    MARGIN_PAIR(4, 3, -3) MARGIN_PAIR(5, -tp + 3, tp - 3) MARGIN_PAIR(6, -t2 + 2, t2 - 2) MARGIN_PAIR(7, -t3 + 1, t3 - 1)
+#undef MARGIN_PAIR
+    unsigned M2[8], M4[8], M8[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) e[k] = -e[k];
-    }
-    int m2[16], m4[16], m8[16];
+    for (int k = 0; k < 7; k++) M2[k] = pk_min16(P[k], P[k + 1]);                 // (m2[k], m2[k+8])
+    M2[7] = pk_min16(P[7], swap16(P[0]));
 #pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = min(e[k], e[(k + 1) & 15]);
+    for (int k = 0; k < 6; k++) M4[k] = pk_min16(M2[k], M2[k + 2]);
+    M4[6] = pk_min16(M2[6], swap16(M2[0]));
+    M4[7] = pk_min16(M2[7], swap16(M2[1]));
 #pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+    for (int k = 0; k < 4; k++) M8[k] = pk_min16(M4[k], M4[k + 4]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
-    int a = 0;
+    for (int k = 4; k < 8; k++) M8[k] = pk_min16(M4[k], swap16(M4[k - 4]));
+    unsigned best = 0;   // margins of a corner's winning arc are positive; max(0, ...) as the scalar form's `a = 0` start
 #pragma unroll
-    for (int k = 0; k < 16; k++) a = max(a, min(m8[k], e[(k + 8) & 15]));
-    return a - 1;
+    for (int k = 0; k < 8; k++) best = pk_max16(best, pk_min16(M8[k], swap16(P[k])));   // min(m8[k], e[k+8]) | min(m8[k+8], e[k])
+    const int lo = (short) (best & 0xFFFFu), hi = (short) (best >> 16);
+    return max(lo, hi) - 1;
 }
 
 constexpr int kSP = 64;          // LDS pitch of a cell's score map (<= 62 columns used)
