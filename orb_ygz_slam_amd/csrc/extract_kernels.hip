@@ -1063,16 +1063,32 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     for (int t = lane; t < kWin * 5; t += 64) {
         const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
         const uint8_t *p = RAWP(r) + 8 * sg;
-        int q[14];
+        // two adjacent outputs per packed 16-bit operation: PP[j] = (q[j], q[j+1]); every partial sum fits 16 bits
+        // (18*510 + 34*510 + 49*510 + 55*255 = 65535), so the packed arithmetic is exact
+        unsigned PP[13];
+        {
+            unsigned prev = p[0];
 #pragma unroll
-        for (int k = 0; k < 14; k++) q[k] = p[k];           // columns 8*sg .. 8*sg+13 (<= 45 + slack: inside the LDS row)
-        unsigned o[8];
+            for (int j = 0; j < 13; j++) {
+                const unsigned nxt = p[j + 1];
+                PP[j] = prev | (nxt << 16);
+                prev = nxt;
+            }
+        }
+        unsigned O[4];
 #pragma unroll
-        for (int k = 0; k < 8; k++) o[k] = 18 * (q[k] + q[k + 6]) + 34 * (q[k + 1] + q[k + 5]) + 49 * (q[k + 2] + q[k + 4]) + 55 * q[k + 3];
+        for (int k = 0; k < 4; k++) {
+            const v2u s06 = __builtin_bit_cast(v2u, PP[2 * k]) + __builtin_bit_cast(v2u, PP[2 * k + 6]);
+            const v2u s15 = __builtin_bit_cast(v2u, PP[2 * k + 1]) + __builtin_bit_cast(v2u, PP[2 * k + 5]);
+            const v2u s24 = __builtin_bit_cast(v2u, PP[2 * k + 2]) + __builtin_bit_cast(v2u, PP[2 * k + 4]);
+            const v2u c3 = __builtin_bit_cast(v2u, PP[2 * k + 3]);
+            const v2u acc = s06 * (v2u) (unsigned short) 18 + s15 * (v2u) (unsigned short) 34 + s24 * (v2u) (unsigned short) 49 + c3 * (v2u) (unsigned short) 55;
+            O[k] = __builtin_bit_cast(unsigned, acc);
+        }
         unsigned *dst = (unsigned *) &L.hbp()[r * kHbP + 8 * sg];
-        dst[0] = o[0] | (o[1] << 16); dst[1] = o[2] | (o[3] << 16);
-        if (sg < 4) { dst[2] = o[4] | (o[5] << 16); dst[3] = o[6] | (o[7] << 16); }
-        else { dst[2] = o[4]; }                              // columns 32..36: 5 outputs (column 37.. unused)
+        dst[0] = O[0]; dst[1] = O[1];
+        if (sg < 4) { dst[2] = O[2]; dst[3] = O[3]; }
+        else { dst[2] = O[2] & 0xFFFFu; }                    // columns 32..36: 5 outputs (column 37.. unused)
     }
     wave_lds_sync();
     // vertical pass only where the rotated pattern samples (512 points instead of the 37 x 37 patch): 7 taps straight from hb
