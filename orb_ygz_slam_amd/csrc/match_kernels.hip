@@ -294,6 +294,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             L.list[b + 1] = v;
         }
     }
+    __syncthreads();   // the candidate scans below read the cells other threads have just sorted
     STAMP(1);
     // ---- per-query projection (:1243-1272) ----
     const float *Rcw = pose, *tcw = pose + 9, *Rlw = pose + 12, *tlw = pose + 21;
