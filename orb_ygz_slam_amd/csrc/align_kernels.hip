@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
 size_t sia_lds_bytes(int maxFeatures) { return (size_t) maxFeatures * sizeof(float4) + 16; }
 
 hipError_t sia_prepare(size_t ldsBytes) {
-    return hipFuncSetAttribute((const void *) k_sia_run, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+    return hipFuncSetAttribute((const void *) k_sia_run, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
 }
 
 void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes) {

@@ -1242,8 +1242,8 @@ size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalN
 }
 
 hipError_t octree_prepare(size_t ldsBytes, bool globalNodes) {
-    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes)
-                       : hipFuncSetAttribute((const void *) k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds)
+                       : hipFuncSetAttribute((const void *) k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
 }
 
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,

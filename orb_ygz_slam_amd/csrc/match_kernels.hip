@@ -952,7 +952,7 @@ size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_
 }
 
 hipError_t match_prepare(size_t ldsBytes) {
-    return hipFuncSetAttribute((const void *) k_match_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+    return hipFuncSetAttribute((const void *) k_match_last, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
 }
 
 void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt, long long kpStride, int maxKp, int nFrames, float fx,

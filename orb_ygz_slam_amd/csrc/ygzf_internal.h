@@ -19,6 +19,9 @@ constexpr int kMaxLevels = 16;
 constexpr int kMaxCellWin = 66;       // window side of one FAST cell: wCell(<60)+6
 constexpr int kFastBlock = 256;
 constexpr int kOctBlock = 1024;
+// The dynamic-LDS ceiling of a kernel is a per-process attribute of the function: it is always set to the same value (the CU's 160 KB
+// minus room for static LDS), never to a per-call size, so that contexts used from different threads cannot lower it under each other.
+constexpr int kMaxDynLds = 160 * 1024 - 2048;
 
 // Geometry of one pyramid level; one table per (w,h) configuration, uploaded to the device.
 struct LevelGeom {
