@@ -175,28 +175,40 @@ def test_extract_fuzz_sizes_and_configs(oracle, seed):
 
 
 def test_two_host_threads_two_contexts(oracle):
-    """The reference extracts the two eyes on two std::threads with one extractor each (src/Frame.cc:728-731): contexts are
-    independent (own stream, own buffers, no shared mutable globals), so concurrent use from two host threads gives the same bytes."""
+    """The reference extracts the two eyes on two std::threads with one extractor each (src/Frame.cc:728-731) and keeps a third, larger
+    extractor for initialisation: contexts are independent (own stream, own buffers, no shared mutable state), also when their
+    configurations -- and therefore their kernels' LDS plans -- differ.  Concurrent use from host threads gives the same bytes."""
     import threading
-    from orb_ygz_slam_amd import Extractor
-    w, h = 752, 480
-    imgs = [synth_frame(300, w, h), synth_frame(301, w, h)]
-    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
-    want = [oex.extract(im) for im in imgs]
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    cfgs = [(752, 480, 1000, 8), (752, 480, 2500, 8), (640, 360, 400, 5)]
+    imgs = [synth_frame(300 + i, c[0], c[1]) for i, c in enumerate(cfgs)]
+    want = [oracle.Extractor(c[2], 1.2, c[3], 20, 7).extract(im) for c, im in zip(cfgs, imgs)]
     errors = []
 
     def worker(i):
         try:
-            ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)     # created inside the thread, like the eyes' extractors
+            w, h, nf, nl = cfgs[i]
+            ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1)     # created inside the thread, like the eyes' extractors
+            cam = make_camera(w, h)
+            k0, d0 = want[i]
+            world = np.stack([(k0["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]), (k0["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]),
+                              np.ones(len(k0), np.float32)], -1).astype(np.float32)
+            I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+            first = None
             for _ in range(25):
                 k, d = ex.extract(imgs[i])
-                if not ((k == want[i][0]).all() and (d == want[i][1]).all()):
-                    errors.append("thread %d: mismatch" % i)
+                if not ((k == k0).all() and (d == d0).all()):
+                    errors.append("thread %d: extraction mismatch" % i)
+                    return
+                m = ex.search_by_projection_last(cam, k, d, k, world, d, I, z, I, z, 15.0)     # a frame against itself: every key finds itself
+                first = first if first is not None else m
+                if m[0] != first[0] or (m[1] != first[1]).any() or m[0] < 0.9 * len(k):
+                    errors.append("thread %d: matcher mismatch" % i)
                     return
         except Exception as e:  # noqa: BLE001
             errors.append("thread %d: %r" % (i, e))
 
-    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(len(cfgs))]
     for t in ts:
         t.start()
     for t in ts:
