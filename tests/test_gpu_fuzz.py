@@ -303,3 +303,46 @@ def test_fuzz_direct_projection(oracle, seed):
     o = oex.find_direct_projection_batch([A], B, T7, EUROC, slot, ident, k, world, px0)
     assert (g[3] == o[3]).all() and (g[1] == o[1]).all() and (g[2] == o[2]).all(), (nl, sfv)
     assert np.array_equal(np.nan_to_num(g[0], nan=-1e9).view(np.uint32), np.nan_to_num(o[0], nan=-1e9).view(np.uint32)), (nl, sfv)
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_batch_pipeline_carry(oracle, seed):
+    """A clip cut into batches of random sizes: extraction, match against the predecessor (also across batch boundaries, through the
+    carry slot) and the stereo pairing must not depend on how the clip was cut."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    rng = np.random.default_rng(1800 + seed)
+    w, h = int(rng.integers(300, 800)), int(rng.integers(240, 520))
+    nf = int(rng.choice([200, 700, 1500]))
+    base = synth_frame(1900 + seed, w + 40, h + 40)
+    n = 14
+    clip = np.stack([base[(3 * i) % 30:(3 * i) % 30 + h, (5 * i) % 35:(5 * i) % 35 + w] for i in range(n)])
+    th = float(rng.choice([7.0, 15.0, 30.0]))
+    mono, chk, ori = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    ex = Extractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=8)
+    oex = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    cam_d = dict(EUROC, mb=0.11, mbf=40.0)
+    cam = make_camera(w, h, mb=0.11, mbf=40.0)
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    sf = oex.tables()["scale"]
+    prev = None
+    pos = 0
+    while pos < n:
+        bs = int(min(n - pos, rng.integers(1, 7)))
+        ex.extract_batch_host(clip[pos:pos + bs])
+        ex.match_batch_prev(cam, th, mono, chk, ori)
+        counts = ex.match_counts()
+        for f in range(bs):
+            k, d = ex.batch_fetch(f)
+            ok, od = oex.extract(clip[pos + f])
+            assert len(k) == len(ok) and (k == ok).all() and (d == od).all(), (w, h, nf, pos, f)
+            m, o = ex.match_fetch(f)
+            if prev is None:
+                assert counts[f] == 0
+            elif len(k) and len(prev[0]):
+                pk, pd = prev
+                world = np.stack([(pk["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]), (pk["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]),
+                                  np.ones(len(pk), np.float32)], -1).astype(np.float32)
+                e = oracle.search_by_projection_last(k, d, sf, w, h, cam_d, pk, world, pd, I, z, I, z, th, mono, chk, ori)
+                assert counts[f] == e[0] and (m[:len(k)] == e[1]).all() and (o[:len(k)] == e[2]).all(), (w, h, nf, pos, f, th, mono, chk, ori)
+            prev = (k, d)
+        pos += bs
