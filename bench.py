@@ -53,12 +53,12 @@ def algorithmic_bytes(w, h, nlevels, sf, nfeat):
     K = nfeat
     per = {
         "k_pyr_resize": (P - Pl) + (P - P0),              # read levels 0..L-2, write levels 1..L-1
-        "k_fast_cells": P,                                 # FAST read of every level
+        "k_fast_quads": P,                                 # FAST read of every level
         "k_describe": 2 * P + K * (749 + 512 + 32 + 28),   # blur read+write, orientation disc, samples, descriptor, KeyPoint
         "k_match_last": (K + K) * 32 + K * 8,              # B_match
         "k_octree": 0,                                     # candidate lists only (not part of SURVEY's formula)
     }
-    total = per["k_pyr_resize"] + per["k_fast_cells"] + per["k_describe"] + per["k_match_last"]
+    total = per["k_pyr_resize"] + per["k_fast_quads"] + per["k_describe"] + per["k_match_last"]
     return total, per
 
 

@@ -1,7 +1,7 @@
 // extract_kernels.hip -- hand-written gfx950 kernels of the ORB extractor hot path (product code).
 //
 //   k_pyr_resize   K1  ORBextractor::ComputePyramid          (reference src/ORBextractor.cc:1129-1150, cv::resize)
-//   k_fast_cells   K2  ComputeKeyPointsOctTree cell loop     (:747-781, cv::FAST 9/16 + per-cell NMS + threshold fallback)
+//   k_fast_quads   K2  ComputeKeyPointsOctTree cell loop     (:747-781, cv::FAST 9/16 + per-cell NMS + threshold fallback)
 //   k_octree       K4  DistributeOctTree                      (:533-723) as sort-by-path-key + breadth-first on ranges
 //   k_describe     K5+K6+K7  IC_Angle (:77-101), GaussianBlur 7x7 s=2 (:1010) on the 37x37 patch only,
 //                            computeOrbDescriptor (:105-149)
@@ -254,10 +254,11 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const Lev
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K2  FAST-9/16 per 30-px cell.  One workgroup per (cell, frame): the (wCell+6)x(hCell+6) window is staged in LDS, the
-// 16-pixel Bresenham ring is read from LDS, the score (max arc margin - 1 == cv::FAST's cornerScore) is written to an
-// LDS score map, then the cell-local 3x3 NMS is evaluated for BOTH thresholds (iniTh map and minTh map) and the minTh
-// result is used only when the iniTh result is empty -- exactly the reference's "FAST(ini); if empty FAST(min)".
+// K2  FAST-9/16 per 30-px cell.  One wave per (cell, frame): the (wCell+6)x(hCell+6) window is staged in LDS, corners are
+// found at minTh (byte-sliced test, four pixels per lane), their score (max arc margin - 1 == cv::FAST's cornerScore) is
+// written to an LDS score map, then the cell-local 3x3 NMS is evaluated for BOTH thresholds and the minTh result is used
+// only when the iniTh result is empty -- exactly the reference's "FAST(ini); if empty FAST(min)".
+// The per-pixel helpers below (fast9_test / fast9_arc_score) serve the listed corners and the dense fallback.
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool has_arc9(unsigned m16) {
     unsigned m = m16 | (m16 << 16);
@@ -358,17 +359,91 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol
 constexpr int kSP = 64;          // LDS pitch of a cell's score map (<= 62 columns used)
 constexpr int kCornerCap = 512;  // corners listed per cell before the dense fallback takes over
 
-// One workgroup = a 2x2 group of cells of one level, one WAVE per cell.  The union window of the group is staged once
-// (aligned dwords); after that single block barrier every wave works alone on its cell: corner test over the cell's
-// pixels in raster order with ballot-compacted corner list, score per corner, 3x3 NMS for both thresholds on the wave's
-// private score map, cell-empty fallback, and ordered output -- all synchronisation is wave-local.
-__global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
+// ------------------------------------------------------------------------------------------------------------------
+// K2q  The same cell loop with FOUR pixels per lane in pass 1 (byte-sliced FAST-9 test).
+// Every wave stages its own cell window into LDS, shifted so that tested pixel x of the cell sits at column x + 4: the four centres of
+// quad q are then exactly dword q + 1 of their row, and the ring pixel (dx, dy) of all four is one v_alignbyte_b32 of two neighbouring
+// dwords with a compile-time shift.  One v_lerp_u8 compares four bytes at once (bit 7 of (a + b + r) >> 1 is the carry of the 9-bit sum):
+//   bright_k  = bit7 lerp(ring_k, 255 - min(c + t, 255), 0)   <=> ring_k >  c + t
+//   !dark_k   = bit7 lerp(ring_k, 255 - max(c - t, 0),   1)   <=> ring_k >= c - t
+// and "9 contiguous of the circular 16" is evaluated bit-sliced over the 16 ring registers (3-input AND / OR trees: an arc of 9 is three
+// arcs of 3), so no per-pixel mask is ever assembled.  The low 7 bits of every byte are don't-care throughout.  Results (polarity per
+// pixel) are identical to fast9_test; the score / NMS passes work per listed corner.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fast9_quad(const unsigned *w, int pd, int t) {
+#define QROW(r) const unsigned a##r = w[(r) * pd], b##r = w[(r) * pd + 1], c##r = w[(r) * pd + 2];
+    QROW(0) QROW(1) QROW(2) QROW(3) QROW(4) QROW(5) QROW(6)
+#undef QROW
+#define AB(hi, lo, sh) __builtin_amdgcn_alignbyte(hi, lo, sh)
+    unsigned R[16];
+    R[8] = b0;            R[9] = AB(b0, a0, 3);   R[7] = AB(c0, b0, 1);   // dy = -3: dx 0, -1, +1
+    R[10] = AB(b1, a1, 2); R[6] = AB(c1, b1, 2);                          // dy = -2: dx -2, +2
+    R[11] = AB(b2, a2, 1); R[5] = AB(c2, b2, 3);                          // dy = -1: dx -3, +3
+    R[12] = AB(b3, a3, 1); R[4] = AB(c3, b3, 3);                          // dy =  0
+    R[13] = AB(b4, a4, 1); R[3] = AB(c4, b4, 3);                          // dy = +1
+    R[14] = AB(b5, a5, 2); R[2] = AB(c5, b5, 2);                          // dy = +2
+    R[0] = b6;            R[15] = AB(b6, a6, 3);  R[1] = AB(c6, b6, 1);   // dy = +3
+#undef AB
+    // per-byte saturated thresholds on the complemented centre: 255 - min(c + t, 255) = max(nc - t, 0); 255 - max(c - t, 0) = min(nc + t, 255)
+    const unsigned nc = ~b3;
+    const unsigned ev = nc & 0x00FF00FFu, od = (nc >> 8) & 0x00FF00FFu;
+    const unsigned tt = (unsigned) t * 0x10001u;
+    const v2u tv = __builtin_bit_cast(v2u, tt), cap = __builtin_bit_cast(v2u, 0x00FF00FFu);
+    const unsigned nhiE = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, ev), tv));
+    const unsigned nhiO = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, od), tv));
+    const unsigned nloE = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(v2u, ev) + tv, cap));
+    const unsigned nloO = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(v2u, od) + tv, cap));
+    const unsigned nhi = nhiE | (nhiO << 8), nlo = nloE | (nloO << 8);
+    unsigned B[16], N[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        B[k] = __builtin_amdgcn_lerp(R[k], nhi, 0u);
+        N[k] = __builtin_amdgcn_lerp(R[k], nlo, 0x01010101u);
+    }
+    unsigned A3[16], O3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A3[k] = B[k] & B[(k + 1) & 15] & B[(k + 2) & 15];
+        O3[k] = N[k] | N[(k + 1) & 15] | N[(k + 2) & 15];
+    }
+    unsigned bright = 0, ndark = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        bright |= A3[k] & A3[(k + 3) & 15] & A3[(k + 6) & 15];
+        ndark &= O3[k] | O3[(k + 3) & 15] | O3[(k + 6) & 15];
+    }
+    const unsigned fb = bright & 0x80808080u, fd = ~(ndark | bright) & 0x80808080u;
+    return (fb >> 7) | (fd >> 6);   // per byte: 1 bright corner, 2 dark corner, 0 none
+}
+
+// a / x for 0 <= a <= 64, 1 <= x <= 64 as (a * kRcp16[x]) >> 16 (exact in that range): lane -> (row, column) splits without the
+// 30-instruction integer division sequence; x is wave-uniform, so the table read is one scalar load.
+__constant__ unsigned kRcp16[65] = {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097, 3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1025};
+__device__ __forceinline__ int div_small(int a, unsigned m) { return (int) (((unsigned) a * m) >> 16); }
+
+// 3x3 NMS of a listed corner on the score map: survivor at minTh (strictly above all 8 neighbours) and at iniTh.  A corner of
+// FAST(iniTh) has score >= iniTh and competes with the neighbours of score >= iniTh only -- but a neighbour below iniTh <= s cannot
+// beat s, so the iniTh survivor test is "minTh survivor and s >= iniTh".
+__device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh) {
+    const int s = sp[0];
+    int nmax = max(max((int) sp[-kSP - 1], (int) sp[-kSP]), max((int) sp[-kSP + 1], (int) sp[-1]));
+    nmax = max(nmax, max(max((int) sp[1], (int) sp[kSP - 1]), max((int) sp[kSP], (int) sp[kSP + 1])));
+    const int kMin = s > nmax;
+    return (kMin && s >= iniTh ? 1 : 0) | (kMin << 1);
+}
+
+// One workgroup = a 2x2 group of cells of one level, one WAVE per cell, no block-level synchronisation: every wave stages its own
+// window.  Pass 1 lists the quads that hold a corner (raster order); the quad list is expanded into the corner list (raster order);
+// then score per corner -> private score map, 3x3 NMS for both thresholds, cell-empty fallback and ordered output.  The common case
+// (<= 64 corners in the cell) keeps everything after the expansion in registers.  kP = compile-time window pitch (0: run-time).
+template <int kP>
+__global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                           int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
                                                           unsigned *__restrict__ slots, int totalCells, long long totalSlots,
-                                                          int totalGroups, int groupsPerXcd, int tilePitch, int tileRows,
-                                                          int smapRows) {
+                                                          int totalGroups, int groupsPerXcd, int winPitch, int winRows,
+                                                          int smapRows, int quadCap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
     // that neighbouring windows, which share cache lines, meet in the same L2.
     if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
@@ -381,29 +456,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
     const int gl = grp - g.groupBase;
     const int gCols = (g.nCols + 1) >> 1;
     const int gi = gl / gCols, gj = gl - gi * gCols;
-    // union window of the group, clipped like the cells are
-    const int gx0 = kBorder + (2 * gj) * g.wCell, gy0 = kBorder + (2 * gi) * g.hCell;
-    const int gx1 = min(gx0 + 2 * g.wCell + 6, g.maxBorderX), gy1 = min(gy0 + 2 * g.hCell + 6, g.maxBorderY);
-    uint8_t *tile = fdyn;
-    const int tp = tilePitch;
-    const int xoff = gx0 & 3;
-    int pitch;
-    const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
-    if (gx1 > gx0 && gy1 > gy0) {
-        const int wd = (xoff + (gx1 - gx0) + 3) >> 2, hh = gy1 - gy0;
-        const unsigned *src = (const unsigned *) (img + (unsigned) gy0 * (unsigned) pitch + (unsigned) (gx0 - xoff));
-        const unsigned pitch4 = (unsigned) pitch >> 2;
-        int ty = tid / wd, tx = tid - ty * wd;
-        const int sy = kFastBlock / wd, sx = kFastBlock - sy * wd;
-        for (int idx = tid; idx < wd * hh; idx += kFastBlock) {
-            ((unsigned *) tile)[ty * (tp >> 2) + tx] = src[(unsigned) ty * pitch4 + (unsigned) tx];
-            ty += sy; tx += sx;
-            if (tx >= wd) { tx -= wd; ty++; }
-        }
-    }
-    __syncthreads();   // the only block-level synchronisation
-    // ---- per-wave: one cell (everything derived from the wave index is wave-uniform: keep it on the scalar unit) ----
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // everything derived from the wave index stays on the scalar unit
     const int ci = 2 * gi + (wv >> 1), cj = 2 * gj + (wv & 1);
     if (ci >= g.nRows || cj >= g.nCols) return;
     const int c = ci * g.nCols + cj;
@@ -416,75 +469,145 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
         if (lane == 0) *cnt_out = 0;
         return;
     }
-    uint8_t *smap = fdyn + ((tileRows * tp + 15) & ~15) + wv * (smapRows * kSP);
-    unsigned short *clist = (unsigned short *) (fdyn + ((tileRows * tp + 15) & ~15) + kFastBlock / 64 * (smapRows * kSP)) + wv * kCornerCap;
-    for (int idx = lane; idx < ((dh + 2) * kSP) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
-    // origin of the cell window inside the staged tile
-    const int obase = (iniY - gy0) * tp + (iniX - gx0) + xoff;
-    const int npix = dw * dh;
-    const int qy = 64 / dw, qx = 64 - qy * dw;
-    const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    // pass 1: corner test at minTh for every pixel in raster order; corners are appended to the wave's list (tile offset,
-    // polarity) by ballot rank, so the list IS in raster order.  When the list is full the rest is handled by the dense
-    // fallback below (never on natural images: > 512 corners in a 30x30 cell).
-    int ncorn = 0;
-    bool overflow = false;
-    {
-        int y = lane / dw, x = lane - y * dw;
-        for (int base = 0; base < npix; base += 64) {
-            const bool valid = base + lane < npix;
-            const int off = obase + (y + 3) * tp + x + 3;
-            const int pol = valid ? fast9_test(&tile[off], tp, minTh) : 0;
-            const unsigned long long m = __ballot(pol != 0);
-            const int add = __popcll(m);
-            if (ncorn + add > kCornerCap) { overflow = true; break; }
-            if (pol) clist[ncorn + __popcll(m & lane_lt)] = (unsigned short) ((y << 8) | (x << 2) | pol);   // x, y < 64
-            ncorn += add;
-            y += qy; x += qx;
-            if (x >= dw) { x -= dw; y++; }
+    const int P = kP ? kP : winPitch;
+    const int winBytes = (winRows * P + 16 + 15) & ~15;   // 16 bytes of slack: the last quad of the last row reads past its row
+    const int perWave = winBytes + smapRows * kSP + quadCap * 4 + kCornerCap * 2;    // all multiples of 16
+    uint8_t *win = fdyn + wv * perWave;
+    uint8_t *smap = win + winBytes;
+    unsigned *qlist = (unsigned *) (smap + smapRows * kSP);
+    unsigned short *clist = (unsigned short *) (qlist + quadCap);
+    {   // stage the window: LDS column 1 + b of row r = image pixel (iniX + b, iniY + r), i.e. tested pixel x of the cell at column x + 4.
+        // All global loads of a chunk are issued before the first use; lanes past the end repeat the last dword.
+        int pitch;
+        const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
+        const int ww = maxX - iniX, wh = maxY - iniY;
+        const int nd = (ww + 1 + 3) >> 2, total = nd * wh;
+        const unsigned g0 = (unsigned) (iniX - 1);
+        const unsigned sh = g0 & 3u;
+        const unsigned *src = (const unsigned *) (img + (unsigned) iniY * (unsigned) pitch + (g0 & ~3u));
+        const unsigned pitch4 = (unsigned) pitch >> 2;
+        const unsigned mnd = kRcp16[nd];
+        int r = div_small(lane, mnd), d = lane - r * nd;
+        const int sr = div_small(64, mnd), sd = 64 - sr * nd;
+        constexpr int kU = 6;
+        for (int i0 = 0; i0 < total; i0 += 64 * kU) {
+            unsigned lo[kU], hi[kU];
+            int dst[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const bool in = r < wh;
+                const int rr = in ? r : wh - 1, dd = in ? d : nd - 1;
+                const unsigned *sp = src + (unsigned) rr * pitch4 + (unsigned) dd;
+                lo[u] = sp[0];
+                hi[u] = sp[1];
+                dst[u] = rr * (P >> 2) + dd;
+                r += sr; d += sd;
+                if (d >= nd) { d -= nd; r++; }
+            }
+            if (i0 == 0)
+                for (int idx = lane; idx < ((dh + 2) * kSP) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < kU; u++) ((unsigned *) win)[dst[u]] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
         }
     }
     wave_lds_sync();
+    // ---- pass 1: four pixels per lane, quads in raster order; quads that hold a corner are listed as  pol bytes | y << 2 | q << 10 ----
+    int nQ = 0;
+    {
+        const int nq = (dw + 3) >> 2, nquads = nq * dh;
+        const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
+        const unsigned mnq = kRcp16[nq];
+        int y = div_small(lane, mnq), q = lane - y * nq;
+        const int qy = div_small(64, mnq), qx = 64 - qy * nq;
+        for (int base = 0; base < nquads; base += 64) {
+            unsigned pb = 0;
+            if (base + lane < nquads) {
+                pb = fast9_quad((const unsigned *) (win + y * P) + q, P >> 2, minTh);
+                pb &= (q == nq - 1) ? lastMask : 0x03030303u;
+            }
+            const unsigned long long m = __ballot(pb != 0);
+            if (m) {
+                if (pb) qlist[nQ + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] =
+                            pb | ((unsigned) y << 2) | ((unsigned) q << 10);
+                nQ += __popcll(m);
+            }
+            y += qy; q += qx;
+            if (q >= nq) { q -= nq; y++; }
+        }
+    }
+    wave_lds_sync();
+    // ---- expansion: quad list -> corner list (y << 8 | x << 2 | polarity), still raster order ----
+    int ncorn = 0;
+    bool overflow = false;
+    for (int qb = 0; qb < nQ; qb += 64) {
+        const unsigned rec = qb + lane < nQ ? qlist[qb + lane] : 0u;
+        unsigned rank = 0;
+        int add = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long m = __ballot(((rec >> (8 * j)) & 3u) != 0);
+            rank = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, rank));
+            add += __popcll(m);
+        }
+        if (ncorn + add > kCornerCap) { overflow = true; break; }
+        int pos = ncorn + (int) rank;
+        const unsigned yx = ((rec & 0xFCu) << 6) | ((rec & 0x3C00u) >> 6);   // y << 8 | 4q << 2
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned pj = (rec >> (8 * j)) & 3u;
+            if (pj) clist[pos++] = (unsigned short) (yx | (j << 2) | pj);
+        }
+        ncorn += add;
+    }
+    wave_lds_sync();
     unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
+    const unsigned long long lane_lt = (1ull << lane) - 1ull;
+    if (!overflow && ncorn <= 64) {
+        // ---- common case: one corner per lane, in registers ----
+        const bool have = lane < ncorn;
+        const int e = have ? clist[lane] : 0;
+        const int y = e >> 8, x = (e >> 2) & 63;
+        uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
+        int s = 0;
+        if (have) {
+            s = fast9_arc_score(&win[(y + 3) * P + x + 4], P, e & 3);
+            sp[0] = (uint8_t) s;
+        }
+        wave_lds_sync();
+        const int fl = have ? nms_flags(sp, iniTh) : 0;
+        const bool anyIni = __ballot(fl & 1) != 0;
+        const bool keep = (fl & (anyIni ? 1 : 2)) != 0;   // the iniTh survivors, or the minTh survivors when the cell is empty at iniTh
+        const unsigned long long m = __ballot(keep);
+        if (keep) out[__popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | ((unsigned) s << 16);
+        if (lane == 0) *cnt_out = (unsigned short) __popcll(m);
+        return;
+    }
     if (!overflow) {
-        // pass 2: score of every listed corner -> private score map
+        // score of every listed corner -> private score map
         for (int qb = 0; qb < ncorn; qb += 64) {
             const int qi = qb + lane;
             if (qi < ncorn) {
                 const int e = clist[qi];
                 const int y = e >> 8, x = (e >> 2) & 63;
-                smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&tile[obase + (y + 3) * tp + x + 3], tp, e & 3);
+                smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&win[(y + 3) * P + x + 4], P, e & 3);
             }
         }
         wave_lds_sync();
-        // pass 3: 3x3 NMS at both thresholds over the corner list
+        // 3x3 NMS at both thresholds over the corner list
         int nIni = 0;
         for (int qb = 0; qb < ncorn; qb += 64) {
             const int qi = qb + lane;
-            int kIni = 0, kMin = 0, e = 0;
+            int fl = 0;
             if (qi < ncorn) {
-                e = clist[qi];
+                const int e = clist[qi];
                 const int y = e >> 8, x = (e >> 2) & 63;
-                const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
-                const int s = sp[0];
-                int nmax = 0, nmaxI = 0;
-#pragma unroll
-                for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; dx++) {
-                        if (dx == 0 && dy == 0) continue;
-                        const int n = sp[dy * kSP + dx];
-                        nmax = max(nmax, n);
-                        nmaxI = max(nmaxI, n >= iniTh ? n : 0);
-                    }
-                kMin = s > nmax;
-                kIni = (s >= iniTh) && (s > nmaxI);
-                clist[qi] = (unsigned short) ((e & ~3) | kIni | (kMin << 1));   // polarity no longer needed: keep flags
+                fl = nms_flags(&smap[(y + 1) * kSP + x + 1], iniTh);
+                clist[qi] = (unsigned short) ((e & ~3) | fl);   // polarity no longer needed: keep the flags
             }
-            nIni += __popcll(__ballot(kIni != 0));
+            nIni += __popcll(__ballot(fl & 1));
         }
         wave_lds_sync();
-        // output: the list is in raster order; keep the iniTh survivors, or the minTh survivors when the cell is empty at iniTh
+        // output: the list is in raster order
         const int want = nIni > 0 ? 1 : 2;
         int total = 0;
         for (int qb = 0; qb < ncorn; qb += 64) {
@@ -502,45 +625,38 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_cells(FrameSet fs, const Le
         if (lane == 0) *cnt_out = (unsigned short) total;
         return;
     }
-    // ---- dense fallback (corner list overflow): score every pixel, NMS every pixel ----
+    // ---- dense fallback (corner list overflow, never on natural images: > 512 corners in one cell): score and NMS every pixel ----
+    const int npix = dw * dh;
+    const unsigned mdw = kRcp16[dw];
+    const int py = div_small(64, mdw), px = 64 - py * dw;
     {
-        int y = lane / dw, x = lane - y * dw;
+        int y = div_small(lane, mdw), x = lane - y * dw;
         for (int base = 0; base < npix; base += 64) {
             if (base + lane < npix) {
-                const uint8_t *cp = &tile[obase + (y + 3) * tp + x + 3];
-                const int pol = fast9_test(cp, tp, minTh);
-                if (pol) smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(cp, tp, pol);
+                const uint8_t *cp = &win[(y + 3) * P + x + 4];
+                const int pol = fast9_test(cp, P, minTh);
+                if (pol) smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(cp, P, pol);
             }
-            y += qy; x += qx;
+            y += py; x += px;
             if (x >= dw) { x -= dw; y++; }
         }
     }
     wave_lds_sync();
     for (int pass = 0; pass < 2; pass++) {       // pass 0: iniTh map; pass 1 (only if empty): minTh map
         int total = 0;
-        int y = lane / dw, x = lane - y * dw;
+        int y = div_small(lane, mdw), x = lane - y * dw;
         for (int base = 0; base < npix; base += 64) {
             bool keep = false;
             unsigned s = 0;
             if (base + lane < npix) {
                 const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
                 s = sp[0];
-                const int th = pass == 0 ? iniTh : 0;
-                if (s > 0 && (int) s >= th) {
-                    int nmax = 0;
-                    for (int dy = -1; dy <= 1; dy++)
-                        for (int dx = -1; dx <= 1; dx++) {
-                            if (dx == 0 && dy == 0) continue;
-                            const int n = sp[dy * kSP + dx];
-                            nmax = max(nmax, n >= th ? n : 0);
-                        }
-                    keep = (int) s > nmax;
-                }
+                if (s > 0) keep = (nms_flags(sp, iniTh) & (pass == 0 ? 1 : 2)) != 0;
             }
             const unsigned long long m = __ballot(keep);
             if (keep) out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
             total += __popcll(m);
-            y += qy; x += qx;
+            y += py; x += px;
             if (x >= dw) { x -= dw; y++; }
         }
         if (total > 0 || pass == 1) {
@@ -1222,19 +1338,27 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
     hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
 }
 
-size_t fast_lds_bytes(int tilePitch, int tileRows, int smapRows) {
-    return (((size_t) tileRows * tilePitch + 15) & ~(size_t) 15) + (size_t) (kFastBlock / 64) * smapRows * kSP +
-           (size_t) (kFastBlock / 64) * kCornerCap * sizeof(unsigned short) + 64;
+size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap) {
+    return (size_t) (kFastBlock / 64) * ((((size_t) winRows * winPitch + 16 + 15) & ~(size_t) 15) + (size_t) smapRows * kSP + (size_t) quadCap * 4 + kCornerCap * sizeof(unsigned short)) + 64;
 }
 
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
-                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int tilePitch,
-                       int tileRows, int smapRows, int nFrames) {
+                       unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
+                       int nFrames, int winPitch, int winRows, int quadCap) {
     if (totalGroups <= 0) return;
     const int groupsPerXcd = (totalGroups + 7) / 8;
-    hipLaunchKernelGGL(k_fast_cells, dim3(8 * groupsPerXcd, nFrames), dim3(kFastBlock), fast_lds_bytes(tilePitch, tileRows, smapRows), st, fs,
-                       dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalGroups, groupsPerXcd, tilePitch, tileRows,
-                       smapRows);
+    const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
+    const size_t lds = fast_quads_lds_bytes(winPitch, winRows, smapRows, quadCap);
+#define YGZF_FAST_LAUNCH(KP)                                                                                                            \
+    hipLaunchKernelGGL(k_fast_quads<KP>, grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, \
+                       totalGroups, groupsPerXcd, winPitch, winRows, smapRows, quadCap)
+    switch (winPitch) {   // the usual pitches (cells of 30..41 pixels) get immediate LDS offsets; anything else the run-time pitch
+        case 40: YGZF_FAST_LAUNCH(40); break;
+        case 44: YGZF_FAST_LAUNCH(44); break;
+        case 48: YGZF_FAST_LAUNCH(48); break;
+        default: YGZF_FAST_LAUNCH(0); break;
+    }
+#undef YGZF_FAST_LAUNCH
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes) {

@@ -65,7 +65,7 @@ static inline short sat_short(float v) {
 }
 
 enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_COUNT };
-static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_cells", "k_octree", "k_describe", "k_hamming_pairs",
+static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_quads", "k_octree", "k_describe", "k_hamming_pairs",
                                              "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection"};
 
 struct Geometry {
@@ -75,7 +75,7 @@ struct Geometry {
     std::vector<short> xalpha, ybeta;
     long long pyrBytes = 0;   // per frame, levels >= 1
     int totalCells = 0, maxCellsPerLevel = 0;
-    int totalGroups = 0, fastTilePitch = 16, fastTileRows = 1, fastSmapRows = 3;   // 2x2 cell groups of k_fast_cells
+    int totalGroups = 0, fastSmapRows = 3, fastWinPitch = 16, fastWinRows = 7, fastQuadCap = 4;   // 2x2 cell groups of k_fast_quads   // 2x2 cell groups of k_fast_cells
     long long totalSlots = 0;
     long long candStride = 0;
     int kpStride = 0, kpCapMax = 0;
@@ -251,9 +251,10 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
             const int nc = nCols * nRows;
             cellBase += nc;
             groupBase += ((nCols + 1) / 2) * ((nRows + 1) / 2);
-            G.fastTilePitch = std::max(G.fastTilePitch, (2 * g.wCell + 6 + 3 + 3) / 4 * 4);
-            G.fastTileRows = std::max(G.fastTileRows, 2 * g.hCell + 6);
             G.fastSmapRows = std::max(G.fastSmapRows, g.hCell + 2);
+            G.fastWinPitch = std::max(G.fastWinPitch, (g.wCell + 6 + 1 + 3) / 4 * 4);   // per-wave window of k_fast_quads: column 0 unused
+            G.fastWinRows = std::max(G.fastWinRows, g.hCell + 6);
+            G.fastQuadCap = std::max(G.fastQuadCap, ((g.wCell + 3) / 4 * g.hCell + 3) / 4 * 4);
             slotBase += (long long) nc * g.slotCap;
             g.candCap = nc * g.slotCap;
             candBase += g.candCap;
@@ -440,7 +441,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             ProfScope ps(c, KK_FAST);
             launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                               (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
-                              G.fastTilePitch, G.fastTileRows, G.fastSmapRows, nFrames);
+                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap);
         }
         long long *odbg = nullptr;
         if (getenv("YGZF_OCT_DEBUG")) {
