@@ -287,6 +287,7 @@ def main():
                        "sharding": "one clip per GPU, no collective"},
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "roofline": roofline, "kernels": kernels,
+            "kernels_isolated_avg_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in iso.items() if v[1]},   # one stream at a time (untimed pass)
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, cfg, args.cpu_seconds)

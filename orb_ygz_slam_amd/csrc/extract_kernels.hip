@@ -1174,32 +1174,34 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = presetAngle ? preset : fast_atan2_deg((float) m01, (float) m10);
-    // ---- separable 7-tap blur {18,34,49,55,49,34,18}: each lane produces runs of 8 outputs from a sliding window
+    // ---- separable 7-tap blur {18,34,49,55,49,34,18}: each lane produces runs of 8 outputs
     // horizontal: 43 rows x 5 segments (8+8+8+8+5 columns)
     for (int t = lane; t < kWin * 5; t += 64) {
         const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
-        const uint8_t *p = RAWP(r) + 8 * sg;
-        // two adjacent outputs per packed 16-bit operation: PP[j] = (q[j], q[j+1]); every partial sum fits 16 bits
-        // (18*510 + 34*510 + 49*510 + 55*255 = 65535), so the packed arithmetic is exact
-        unsigned PP[13];
-        {
-            unsigned prev = p[0];
+        // 15 source bytes from an arbitrary byte address: five aligned dwords, shifted into place once (e[k] = bytes 4k..4k+3 of the
+        // run); output j = <bytes j..j+3, (18,34,49,55)> + <bytes j+4..j+7, (49,34,18,0)> -- two v_dot4_u32_u8 per output, exact
+        // (the sum is at most 65535).
+        const unsigned A = (unsigned) (RAWP(r) - L.rawp()) + 8u * (unsigned) sg;
+        const unsigned *dw = (const unsigned *) L.rawp() + (A >> 2);
+        const unsigned sh = A & 3u;
+        const unsigned d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3], d4 = dw[4];
+        unsigned X[12];
+        X[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        X[4] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        X[8] = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        const unsigned e3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
 #pragma unroll
-            for (int j = 0; j < 13; j++) {
-                const unsigned nxt = p[j + 1];
-                PP[j] = prev | (nxt << 16);
-                prev = nxt;
-            }
+        for (int j = 1; j < 4; j++) {
+            X[j] = __builtin_amdgcn_alignbyte(X[4], X[0], j);
+            X[4 + j] = __builtin_amdgcn_alignbyte(X[8], X[4], j);
+            X[8 + j] = __builtin_amdgcn_alignbyte(e3, X[8], j);
         }
         unsigned O[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const v2u s06 = __builtin_bit_cast(v2u, PP[2 * k]) + __builtin_bit_cast(v2u, PP[2 * k + 6]);
-            const v2u s15 = __builtin_bit_cast(v2u, PP[2 * k + 1]) + __builtin_bit_cast(v2u, PP[2 * k + 5]);
-            const v2u s24 = __builtin_bit_cast(v2u, PP[2 * k + 2]) + __builtin_bit_cast(v2u, PP[2 * k + 4]);
-            const v2u c3 = __builtin_bit_cast(v2u, PP[2 * k + 3]);
-            const v2u acc = s06 * (v2u) (unsigned short) 18 + s15 * (v2u) (unsigned short) 34 + s24 * (v2u) (unsigned short) 49 + c3 * (v2u) (unsigned short) 55;
-            O[k] = __builtin_bit_cast(unsigned, acc);
+            const unsigned lo = __builtin_amdgcn_udot4(X[2 * k], 0x37312212u, __builtin_amdgcn_udot4(X[2 * k + 4], 0x00122231u, 0u, false), false);
+            const unsigned hi = __builtin_amdgcn_udot4(X[2 * k + 1], 0x37312212u, __builtin_amdgcn_udot4(X[2 * k + 5], 0x00122231u, 0u, false), false);
+            O[k] = lo | (hi << 16);
         }
         unsigned *dst = (unsigned *) &L.hbp()[r * kHbP + 8 * sg];
         dst[0] = O[0]; dst[1] = O[1];
