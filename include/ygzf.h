@@ -84,7 +84,8 @@ int ygzf_extract(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, yg
  * Results stay on the device (chain into ygzf_match_*) until fetched.  Asynchronous on the
  * context stream; ygzf_sync / ygzf_batch_counts / ygzf_batch_fetch synchronise. */
 int ygzf_extract_batch_device(ygzf_ctx *ctx, const uint8_t *d_imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
-/* Same, host frames (H2D copy of each frame included). */
+/* Same, host frames (H2D copy of each frame included).  The copy is asynchronous too: `imgs` must stay valid and unchanged until the next
+ * synchronising call on this context (ygzf_sync, ygzf_batch_counts, ygzf_batch_fetch*, ...); page-locked memory gives the full PCIe rate. */
 int ygzf_extract_batch_host(ygzf_ctx *ctx, const uint8_t *imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
 int ygzf_batch_counts(ygzf_ctx *ctx, int *n_kp /* n_frames ints */);
 int ygzf_batch_fetch(ygzf_ctx *ctx, int frame, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
@@ -293,7 +294,8 @@ int ygzf_stereo_fetch(ygzf_ctx *ctx, int pair, float *u_right, float *depth, int
  * form takes the independent candidates as one batch.  The images live in an HBM-resident cache: every KeyFrame (and the current frame)
  * is put once -- its pyramid is built on the device -- and referenced by slot afterwards.
  *   ygzf_image_cache_reserve : n_slots images of w x h (the extractor configuration of the context defines the pyramid)
- *   ygzf_image_cache_put     : upload a level-0 image into a slot and build its pyramid
+ *   ygzf_image_cache_put     : upload a level-0 image into a slot and build its pyramid (asynchronous: `img` must stay valid until the
+ *       next synchronising call on this context, e.g. ygzf_find_direct_projection_batch or ygzf_sync)
  *   ygzf_find_direct_projection_batch : candidate i = (ref_slot[i], ref_Tcw7[i] = ref->GetPose() as quaternion x,y,z,w + translation,
  *       ref_kp[i] = ref->mvKeys[mp->GetObservations()[ref]], mp_world[i] = mp->GetWorldPos()); cur_Tcw7 = curr->mTcw;
  *       px_curr (n x 2, in/out): initial guess (mTrackProjX/Y) -> refined pixel; search_level / success (the bool result) out;

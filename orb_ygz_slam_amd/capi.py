@@ -145,6 +145,7 @@ class Extractor:
         self.nlevels = nlevels
         self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th)
         self._wh = (max_width, max_height, 0)   # (w, h, frames) of the last extracted batch
+        self._inflight = []                     # host arrays handed to asynchronous uploads, kept alive until the next synchronisation
         self.h = C.c_void_p()
         rc = self.L.ygzf_create(device, C.byref(self.cfg), max_width, max_height, max_batch, C.byref(self.h))
         if rc != 0:
@@ -205,6 +206,7 @@ class Extractor:
         imgs = np.ascontiguousarray(imgs, np.uint8)
         n, h, w = imgs.shape
         self._ck(self.L.ygzf_extract_batch_host(self.h, _p(imgs), n, w, h, w, w * h))
+        self._inflight.append(imgs)   # the H2D copy is asynchronous: the frames must stay alive until the next synchronising call
         self._wh = (w, h, n)
 
     def extract_batch_device(self, dptr, n, w, h, row_pitch=None, frame_stride=None):
@@ -215,10 +217,12 @@ class Extractor:
 
     def sync(self):
         self._ck(self.L.ygzf_sync(self.h))
+        self._inflight.clear()
 
     def batch_counts(self):
         n = np.zeros(self._wh[2], np.int32)
         self._ck(self.L.ygzf_batch_counts(self.h, _p(n)))
+        self._inflight.clear()
         return n
 
     def batch_fetch(self, frame):
@@ -228,6 +232,7 @@ class Extractor:
         d = np.zeros((max(cap, 1), 32), np.uint8)
         n = C.c_int()
         self._ck(self.L.ygzf_batch_fetch(self.h, frame, _p(k), _p(d), cap, C.byref(n)))
+        self._inflight.clear()
         return k[:n.value].copy(), d[:n.value].copy()
 
     def batch_fetch_all(self, n_frames, out=None):
@@ -238,6 +243,7 @@ class Extractor:
             out = (np.zeros((n_frames, stride), KP_DTYPE), np.zeros((n_frames, stride, 32), np.uint8), np.zeros(n_frames, np.int32))
         k, d, n = out
         self._ck(self.L.ygzf_batch_fetch_all(self.h, _p(k), _p(d), _p(n), stride))
+        self._inflight.clear()
         return k, d, n
 
     def batch_fetch_level(self, frame, level):
@@ -272,6 +278,7 @@ class Extractor:
     def match_counts(self):
         n = np.zeros(self._wh[2], np.int32)
         self._ck(self.L.ygzf_match_counts(self.h, _p(n)))
+        self._inflight.clear()
         return n
 
     def match_fetch(self, frame):
@@ -280,6 +287,7 @@ class Extractor:
         m = np.zeros(max(cap, 1), np.int32)
         o = np.zeros(max(cap, 1), np.uint8)
         self._ck(self.L.ygzf_match_fetch(self.h, frame, _p(m), _p(o), cap))
+        self._inflight.clear()
         return m, o
 
     def search_by_projection_last(self, cam, cur_keys, cur_desc, last_keys, mp_world, mp_desc, Rcw, tcw, Rlw, tlw, th, mono=True,
@@ -578,6 +586,9 @@ class Extractor:
     def image_cache_put(self, slot, img):
         img = np.ascontiguousarray(img, np.uint8)
         self._ck(self.L.ygzf_image_cache_put(self.h, slot, _p(img), img.shape[1], img.shape[0], img.shape[1]))
+        self._inflight.append(img)
+        if len(self._inflight) > 64:
+            self.sync()
 
     def find_direct_projection_batch(self, cam, cur_slot, cur_Tcw7, ref_slot, ref_Tcw7, ref_kp, mp_world, px_curr, want_patches=False):
         """ORBmatcher::FindDirectProjection over a candidate batch -> (px_curr n x 2, search_level, success[, patches n x 100])."""
@@ -593,6 +604,7 @@ class Extractor:
         pt = np.zeros((max(n, 1), 100), np.uint8) if want_patches else None
         self._ck(self.L.ygzf_find_direct_projection_batch(self.h, C.byref(cam), cur_slot, _p(ct), n, _p(rs), _p(rt), _p(rk), _p(mw), _p(px), _p(sl),
                                                           _p(ok), _p(pt) if want_patches else None))
+        self._inflight.clear()
         return (px, sl[:n], ok[:n], pt[:n]) if want_patches else (px, sl[:n], ok[:n])
 
     def timer_start(self):

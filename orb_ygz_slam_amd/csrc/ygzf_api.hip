@@ -123,6 +123,7 @@ struct ygzf_ctx {
     // timing
     hipEvent_t tStart = nullptr, tStop = nullptr;
     bool profile = false;
+    bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;   // debugging aid: synchronise after every kernel and name it on stderr
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -382,6 +383,11 @@ struct ProfScope {
         }
     }
     ~ProfScope() {
+        if (c->debugSync) {
+            fprintf(stderr, "[ygzf] %s ...", kKernelNames[kind]);
+            const hipError_t e = hipStreamSynchronize(c->stream);
+            fprintf(stderr, " %s\n", hipGetErrorString(e));
+        }
         if (c->profile) {
             (void) hipEventRecord(b, c->stream);
             c->recs.push_back({kind, a, b});

@@ -21,7 +21,7 @@ def _cfg(rng, max_w=800, max_h=620, max_feat=2500):
 
 @pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_special_images(oracle, seed):
-    """Degenerate image content: flat, saturated, 1-px checkerboard, ramps, sparse impulses, hard binary edges."""
+    """Degenerate image content: flat, saturated, 1-px checkerboard, ramps, sparse impulses, hard binary edges, corner-dense bowls."""
     from orb_ygz_slam_amd import Extractor
     rng = np.random.default_rng(300 + seed)
     w, h, nl, sf, nf = _cfg(rng)
@@ -29,7 +29,10 @@ def test_fuzz_special_images(oracle, seed):
     imgs = [np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8), (((xx + yy) & 1) * 255).astype(np.uint8),
             ((xx * 255) // max(w - 1, 1)).astype(np.uint8), ((xx // 7 + yy // 5) % 2 * 200 + 20).astype(np.uint8),
             (rng.uniform(size=(h, w)) > 0.995).astype(np.uint8) * 255, (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8),
-            np.clip(synth_frame(seed, w, h).astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8)]
+            np.clip(synth_frame(seed, w, h).astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8),
+            # 16-px paraboloid bowls: ~68 % of the pixels are FAST corners, > 512 per cell -> the corner list overflows (dense fallback)
+            np.clip((((xx % 16) - 8) ** 2 + ((yy % 16) - 8) ** 2) * (250.0 / 128.0), 0, 255).astype(np.uint8),
+            np.clip((((xx % 20) - 10) ** 2 + ((yy % 20) - 10) ** 2) * (250.0 / 200.0), 0, 255).astype(np.uint8)]   # ~460 per cell: long lists
     ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=len(imgs))
     oex = oracle.Extractor(nf, sf, nl, 20, 7)
     ex.extract_batch_host(np.stack(imgs))
