@@ -19,6 +19,9 @@ namespace ygzf {
 // ------------------------------------------------------------------------------------------------------------------
 // small wave / block primitives (wave = 64 lanes)
 // ------------------------------------------------------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform by construction
 
@@ -197,32 +200,52 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const Lev
         const unsigned total = (unsigned) sh * (unsigned) sp;          // bytes of the source level that may be touched
         int r = tid / nd, c = tid - r * nd;
         const int sr = 256 / nd, sc = 256 - sr * nd;
-        for (int idx = tid; idx < nd * nr; idx += 256) {
-            const unsigned off = (unsigned) (sya + r) * (unsigned) sp + (unsigned) (sxa + 4 * c);
-            unsigned v;
-            if (off + 4 <= total) v = *(const unsigned *) (src + off);
-            else {   // last dword of the last row of a caller-owned level-0 buffer: never read past its end
-                v = 0;
-                for (int b = 0; b < 4; b++) if (off + b < total) v |= (unsigned) src[off + b] << (8 * b);
+        constexpr int kU = 4;   // loads of a chunk are all in flight before the first LDS store; threads past the end repeat the last dword
+        for (int i0 = 0; i0 < nd * nr; i0 += 256 * kU) {
+            unsigned v[kU];
+            int dst[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const bool in = r < nr;
+                const int rr = in ? r : nr - 1, cc = in ? c : nd - 1;
+                const unsigned off = (unsigned) (sya + rr) * (unsigned) sp + (unsigned) (sxa + 4 * cc);
+                if (off + 4 <= total) v[u] = *(const unsigned *) (src + off);
+                else {   // last dword of the last row of a caller-owned level-0 buffer: never read past its end
+                    v[u] = 0;
+                    for (int b = 0; b < 4; b++) if (off + b < total) v[u] |= (unsigned) src[off + b] << (8 * b);
+                }
+                dst[u] = rr * (kPyrSrcPitch / 4) + cc;
+                r += sr; c += sc;
+                if (c >= nd) { c -= nd; r++; }
             }
-            ((unsigned *) tile)[r * (kPyrSrcPitch / 4) + c] = v;
-            r += sr; c += sc;
-            if (c >= nd) { c -= nd; r++; }
+#pragma unroll
+            for (int u = 0; u < kU; u++) ((unsigned *) tile)[dst[u]] = v[u];
         }
     }
     __syncthreads();
     const int lane = tid & 63, rg = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xb = x0 + 4 * lane;
     if (xb >= g.w) return;
-    int lx[4], lx1[4], a0[4], a1[4];
+    // The four columns of a lane read source bytes lx[0] .. lx[0] + 5 (scale < 1.28, see tiledOk): per visited source row three aligned
+    // dwords are shifted to start at lx[0] (v_alignbyte), one v_perm_b32 per column picks its (left, right) pixel pair into 16-bit halves
+    // and one v_dot2_u32_u16 applies (alpha0, alpha1).  The row sums H of a source row are kept for the next output row, which reuses
+    // the lower row of this one five times out of six at scale 1.2.
+    unsigned sel[4], ap[4];
+    int bd4;
+    unsigned osh;
+    {
+        int lx0 = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int x = min(xb + k, g.w - 1);
-        const int sx = xofs[g.xtab + x];
-        lx[k] = sx - sxa;
-        lx1[k] = min(sx + 1, sw - 1) - sxa;
-        a0[k] = xalpha[2 * (g.xtab + x)];
-        a1[k] = xalpha[2 * (g.xtab + x) + 1];
+        for (int k = 0; k < 4; k++) {
+            const int x = min(xb + k, g.w - 1);
+            const int sx = xofs[g.xtab + x];
+            const int lx = sx - sxa, lx1 = min(sx + 1, sw - 1) - sxa;
+            if (k == 0) lx0 = lx;
+            sel[k] = (unsigned) (lx - lx0) | 0x0C00u | ((unsigned) (lx1 - lx0) << 16) | 0x0C000000u;
+            ap[k] = (unsigned) (unsigned short) xalpha[2 * (g.xtab + x)] | ((unsigned) (unsigned short) xalpha[2 * (g.xtab + x) + 1] << 16);
+        }
+        bd4 = lx0 & ~3;
+        osh = (unsigned) lx0 & 3u;
     }
     uint8_t *dstf = fs.pyr + (long long) f * fs.pyr_stride + g.off;
     // the 8 rows of this wave: their y coefficients are wave-uniform -> scalar loads, all issued before the arithmetic
@@ -236,18 +259,41 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const Lev
         b0s[ry] = ybeta[2 * (g.ytab + y)];
         b1s[ry] = ybeta[2 * (g.ytab + y) + 1];
     }
+    auto hrow = [&](int r, unsigned (&H)[4]) {
+        const unsigned *p = (const unsigned *) (tile + r * kPyrSrcPitch + bd4);
+        const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
+        const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, osh), e1 = __builtin_amdgcn_alignbyte(d2, d1, osh);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, __builtin_amdgcn_perm(e1, e0, sel[k])), __builtin_bit_cast(v2u, ap[k]), 0u, false);
+    };
+    int have = -1;
+    unsigned Hc[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int ry = 0; ry < 8; ry++) {
         const int y = y0 + rg * 8 + ry;
         if (y >= g.h) break;
         const int b0 = b0s[ry], b1 = b1s[ry];
-        const uint8_t *S0 = tile + r0s[ry] * kPyrSrcPitch, *S1 = tile + r1s[ry] * kPyrSrcPitch;
+        unsigned H0[4], H1[4];
+        if (r0s[ry] == have) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) H0[k] = Hc[k];
+        } else {
+            hrow(r0s[ry], H0);
+        }
+        if (r1s[ry] == r0s[ry]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) H1[k] = H0[k];
+        } else {
+            hrow(r1s[ry], H1);
+        }
+        have = r1s[ry];
         unsigned out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int H0 = S0[lx[k]] * a0[k] + S0[lx1[k]] * a1[k];
-            const int H1 = S1[lx[k]] * a0[k] + S1[lx1[k]] * a1[k];
-            out |= (unsigned) ((((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2) << (8 * k);
+            Hc[k] = H1[k];
+            // operands fit 24 bits (beta <= 2048, H >> 4 <= 32640): full-rate 24-bit multiplies, same integers as the 32-bit form
+            out |= (unsigned) (((__mul24(b0, (int) (H0[k] >> 4)) >> 16) + (__mul24(b1, (int) (H1[k] >> 4)) >> 16) + 2) >> 2) << (8 * k);
         }
         *(unsigned *) (dstf + (unsigned) y * (unsigned) g.pitch + xb) = out;
     }
