@@ -465,7 +465,7 @@ __device__ __forceinline__ unsigned fast9_quad(const unsigned *w, int pd, int t)
 // a / x for 0 <= a <= 64, 1 <= x <= 64 as (a * kRcp16[x]) >> 16 (exact in that range): lane -> (row, column) splits without the
 // 30-instruction integer division sequence; x is wave-uniform, so the table read is one scalar load.
 __constant__ unsigned kRcp16[65] = {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097, 3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1025};
-__device__ __forceinline__ int div_small(int a, unsigned m) { return (int) (((unsigned) a * m) >> 16); }
+__device__ __forceinline__ int div_small(int a, unsigned m) { return (int) (__umul24((unsigned) a, m) >> 16); }   // both < 2^24: full-rate multiply
 
 // 3x3 NMS of a listed corner on the score map: survivor at minTh (strictly above all 8 neighbours) and at iniTh.  A corner of
 // FAST(iniTh) has score >= iniTh and competes with the neighbours of score >= iniTh only -- but a neighbour below iniTh <= s cannot
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
         const unsigned *src = (const unsigned *) (img + (unsigned) iniY * (unsigned) pitch + (g0 & ~3u));
         const unsigned pitch4 = (unsigned) pitch >> 2;
         const unsigned mnd = kRcp16[nd];
-        int r = div_small(lane, mnd), d = lane - r * nd;
+        int r = div_small(lane, mnd), d = lane - __mul24(r, nd);
         const int sr = div_small(64, mnd), sd = 64 - sr * nd;
         constexpr int kU = 6;
         for (int i0 = 0; i0 < total; i0 += 64 * kU) {
@@ -543,10 +543,10 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
             for (int u = 0; u < kU; u++) {
                 const bool in = r < wh;
                 const int rr = in ? r : wh - 1, dd = in ? d : nd - 1;
-                const unsigned *sp = src + (unsigned) rr * pitch4 + (unsigned) dd;
+                const unsigned *sp = src + __umul24((unsigned) rr, pitch4) + (unsigned) dd;   // rows, pitch < 2^24
                 lo[u] = sp[0];
                 hi[u] = sp[1];
-                dst[u] = rr * (P >> 2) + dd;
+                dst[u] = __mul24(rr, P >> 2) + dd;
                 r += sr; d += sd;
                 if (d >= nd) { d -= nd; r++; }
             }
@@ -563,12 +563,12 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
         const int nq = (dw + 3) >> 2, nquads = nq * dh;
         const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
         const unsigned mnq = kRcp16[nq];
-        int y = div_small(lane, mnq), q = lane - y * nq;
+        int y = div_small(lane, mnq), q = lane - __mul24(y, nq);
         const int qy = div_small(64, mnq), qx = 64 - qy * nq;
         for (int base = 0; base < nquads; base += 64) {
             unsigned pb = 0;
             if (base + lane < nquads) {
-                pb = fast9_quad((const unsigned *) (win + y * P) + q, P >> 2, minTh);
+                pb = fast9_quad((const unsigned *) (win + __mul24(y, P)) + q, P >> 2, minTh);
                 pb &= (q == nq - 1) ? lastMask : 0x03030303u;
             }
             const unsigned long long m = __ballot(pb != 0);
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
         uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
         int s = 0;
         if (have) {
-            s = fast9_arc_score(&win[(y + 3) * P + x + 4], P, e & 3);
+            s = fast9_arc_score(&win[__mul24(y + 3, P) + x + 4], P, e & 3);
             sp[0] = (uint8_t) s;
         }
         wave_lds_sync();
@@ -1186,7 +1186,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         rowOffStep = pitch & 15;
         for (int idx = lane; idx < kWin * 4; idx += 64) {
             const int r = idx >> 2, q = idx & 3;
-            const unsigned long long a = a00 + (unsigned) r * (unsigned) pitch;
+            const unsigned long long a = a00 + __umul24((unsigned) r, (unsigned) pitch);
             *(uint4 *) &L.rawp()[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
         }
     } else {
