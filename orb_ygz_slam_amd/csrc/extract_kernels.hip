@@ -1151,21 +1151,25 @@ struct DescLds {
 
 // umax of the 31-px circular patch (src/ORBextractor.cc:455-469 for HALF_PATCH_SIZE = 15); ygzf_create checks the context's table against it
 constexpr int kUmax15[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-struct DiscMasks { unsigned long long m[16]; };
-constexpr DiscMasks make_disc_masks() {
-    DiscMasks d{};
-    for (int it = 0; it < 16; it++) {
-        unsigned long long m = 0;
-        for (int lane = 0; lane < 64; lane++) {
-            const int u = (lane & 31) - 15, v = 2 * it + (lane >> 5) - 15;
-            const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
-            if ((lane & 31) < 31 && v <= 15 && au <= kUmax15[av]) m |= 1ull << lane;
+// Disc membership as byte masks: item = (row v + 15) * 8 + j covers columns u + 15 = 4j .. 4j + 3 of row v; byte k of m[item] is 0xFF
+// when (u, v) lies inside the patch (|u| <= umax[|v|]).  Items 248..255 (past the last row) are empty.
+struct DiscBytes { unsigned m[256]; };
+constexpr DiscBytes make_disc_bytes() {
+    DiscBytes d{};
+    for (int item = 0; item < 248; item++) {
+        const int v = (item >> 3) - 15, j = item & 7;
+        const int av = v < 0 ? -v : v;
+        unsigned m = 0;
+        for (int k = 0; k < 4; k++) {
+            const int u = 4 * j + k - 15;
+            const int au = u < 0 ? -u : u;
+            if (u <= 15 && au <= kUmax15[av]) m |= 0xFFu << (8 * k);
         }
-        d.m[it] = m;
+        d.m[item] = m;
     }
     return d;
 }
-constexpr DiscMasks kDiscMask = make_disc_masks();
+__constant__ DiscBytes c_disc = make_disc_bytes();
 
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024];
 __constant__ int c_umax[16];
@@ -1178,6 +1182,9 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     // aligned 64-byte span -> 4 lanes x dwordx4 per row, 3 wave-level loads for the whole window, all in flight at once.
     // Keypoints within 21 px of the image border need BORDER_REFLECT_101 (what the blur of the border-less level clone
     // sees) and take the byte path.  Window column c of row r lives at raw[r*64 + ((rowOff0 + r*rowOffStep) & 15) + c].
+    unsigned discM[4];   // disc membership bytes of this lane's four centroid work items: loaded first, used after the window is staged
+#pragma unroll
+    for (int it = 0; it < 4; it++) discM[it] = c_disc.m[it * 64 + lane];
     const bool interior = kx >= 21 && kx + 21 < gw && ky >= 21 && ky + 22 < gh && ((pitch & 3) == 0);
     int rowOff0 = 0, rowOffStep = 0;
     if (interior) {
@@ -1198,24 +1205,27 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     }
 #define RAWP(r) (&L.rawp()[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
     wave_lds_sync();
-    // ---- intensity centroid on the 31x31 disc (centre = window (21,21)): two rows per step, no divisions
+    // ---- intensity centroid on the 31x31 disc (centre = window (21,21)).  Work item = four pixels (row v, columns u = 4j-15 .. 4j-12):
+    // two aligned dwords shifted into place, masked with the disc membership bytes, then m01 += v * (sum of the bytes) [v_sad_u8] and
+    // m10 += <bytes, (4j .. 4j+3)> - 15 * sum [v_dot4_u32_u8].  248 items = 4 steps of the wave; integer sums, any order is exact.
     int m10, m01;
     {
-        // lane = (row parity, column): u = (lane & 31) - 15, v = 2 * it + (lane >> 5) - 15.  Which lanes lie inside the disc in step `it`
-        // is a compile-time lane mask (kDiscMask, from the fixed umax table of HALF_PATCH_SIZE = 15); m10 = u * (sum of the column).
-        const int u = (lane & 31) - 15;
-        int colSum = 0, vSum = 0;
+        unsigned wsum = 0, ssum = 0;
+        int vsum = 0;
+        const unsigned ucol = 0x03020100u + 0x04040404u * (unsigned) (lane & 7);
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            const int v = 2 * it + (lane >> 5) - 15;
-            if ((kDiscMask.m[it] >> lane) & 1ull) {
-                const int I = RAWP(21 + v)[21 + u];
-                colSum += I;
-                vSum += v * I;
-            }
+        for (int it = 0; it < 4; it++) {
+            const int r = 6 + it * 8 + (lane >> 3);                      // window row 21 + v
+            const unsigned A = (unsigned) (RAWP(r) - L.rawp()) + 6u + 4u * (unsigned) (lane & 7);
+            const unsigned *dw = (const unsigned *) L.rawp() + (A >> 2);
+            const unsigned px = __builtin_amdgcn_alignbyte(dw[1], dw[0], A & 3u) & discM[it];
+            const unsigned sm = __builtin_amdgcn_sad_u8(px, 0u, 0u);
+            wsum = __builtin_amdgcn_udot4(px, ucol, wsum, false);
+            ssum += sm;
+            vsum += __mul24(r - 21, (int) sm);
         }
-        m10 = u * colSum;
-        m01 = vSum;
+        m10 = (int) wsum - __mul24(15, (int) ssum);
+        m01 = vsum;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
