@@ -373,7 +373,10 @@ __device__ __forceinline__ unsigned pk_max16(unsigned a, unsigned b) {
 __device__ __forceinline__ unsigned pk_mul16(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_bit_cast(v2s, a) * __builtin_bit_cast(v2s, b));
 }
-__device__ __forceinline__ unsigned swap16(unsigned a) { return __builtin_amdgcn_alignbit(a, a, 16); }
+__device__ __forceinline__ unsigned swap16(unsigned a) {   // a half swap feeding a packed min/max folds into its op_sel bits
+    const v2s x = __builtin_bit_cast(v2s, a);
+    return __builtin_bit_cast(unsigned, __builtin_shufflevector(x, x, 1, 0));
+}
 __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol) {
     const int t2 = 2 * tp, t3 = 3 * tp;
     const unsigned vv = (unsigned) c[0] * 0x10001u;
@@ -1171,7 +1174,7 @@ constexpr DiscBytes make_disc_bytes() {
 }
 __constant__ DiscBytes c_disc = make_disc_bytes();
 
-__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024];
+__constant__ __attribute__((aligned(16))) float4 c_pattern[256];   // (x0, y0, x1, y1) of test pair p, already as floats
 __constant__ int c_umax[16];
 
 // One wave: orientation + blurred patch + 256 rBRIEF bits of the keypoint at integer (kx,ky) of a gw x gh level image.
@@ -1271,9 +1274,8 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int p = it * 64 + lane;
-        const int pk = ((const int *) c_pattern)[p];   // (x0, y0, x1, y1) as 4 signed bytes: one load
-        const float x0 = (float) (signed char) (pk & 0xFF), y0 = (float) (signed char) ((pk >> 8) & 0xFF);
-        const float x1 = (float) (signed char) ((pk >> 16) & 0xFF), y1 = (float) (signed char) ((pk >> 24) & 0xFF);
+        const float4 pk = c_pattern[p];
+        const float x0 = pk.x, y0 = pk.y, x1 = pk.z, y1 = pk.w;
         const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
         const unsigned short *p0 = &L.hbp()[(18 + r0) * kHbP + 18 + q0], *p1 = &L.hbp()[(18 + r1) * kHbP + 18 + q1];
@@ -1380,7 +1382,9 @@ __global__ void k_hamming_pairs(const unsigned long long *__restrict__ a, const 
 hipError_t upload_constants(const int *umax16) {
     for (int i = 0; i < 16; i++)
         if (umax16[i] != kUmax15[i]) return hipErrorInvalidValue;   // the orientation kernel's disc masks are built for this table
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), kBriefPattern, 1024);
+    float pf[1024];
+    for (int i = 0; i < 1024; i++) pf[i] = (float) kBriefPattern[i];
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_pattern), pf, sizeof pf);
     if (e != hipSuccess) return e;
     return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
 }
