@@ -10,6 +10,7 @@
 // (float round-off can make the discriminant negative) ranks lowest.
 #include "fast10_device.h"
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ygzf {
 
@@ -31,16 +32,6 @@ __device__ __forceinline__ unsigned score_rank(float s) {   // monotone u32 imag
     if (s == 0.f) s = 0.f;
     const unsigned b = __float_as_uint(s);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned lo = (unsigned) __shfl_xor((int) (unsigned) v, d, 64), hi = (unsigned) __shfl_xor((int) (unsigned) (v >> 32), d, 64);
-        const unsigned long long t = ((unsigned long long) hi << 32) | lo;
-        v = t > v ? t : v;
-    }
-    return v;
 }
 
 __global__ __launch_bounds__(64 * kDsoWaves) void k_dso_cells(const uint8_t *__restrict__ img, int pitch, int w, int h, int grid, int nCols, int nRows,

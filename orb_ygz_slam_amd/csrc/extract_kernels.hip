@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "wave_ops.h"
 #include "orb_pattern_table.h"
 
 namespace ygzf {
@@ -24,33 +25,6 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform by construction
-
-// Wave-level scan / reductions on DPP (no LDS permute round trips: a ds_bpermute step costs an LDS latency, a DPP step one VALU slot).
-// Lanes a DPP step cannot source (row start, masked rows) add the identity through `old`.
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8  -> inclusive inside every row of 16
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);   // row_ror:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);   // row_ror:8  -> every lane holds its row's sum
-    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-    v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0xb1, 0xf, 0xf, false));
-    v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x4e, 0xf, 0xf, false));
-    v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x124, 0xf, 0xf, false));
-    v = max(v, (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, 0x128, 0xf, 0xf, false));
-    return max(max((unsigned) __builtin_amdgcn_readlane((int) v, 0), (unsigned) __builtin_amdgcn_readlane((int) v, 16)),
-               max((unsigned) __builtin_amdgcn_readlane((int) v, 32), (unsigned) __builtin_amdgcn_readlane((int) v, 48)));
-}
 
 // Exclusive prefix of v over the threads of the block (thread order); *total = block sum.  tmp: >= 17 ints of LDS.
 // Contains block barriers: must be called by all threads.

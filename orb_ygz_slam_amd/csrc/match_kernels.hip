@@ -14,6 +14,7 @@
 // reference's strict `dist < bestDist` scan.  Rotation-histogram voting (:1315-1345, including the factor = 1/30 quirk)
 // is applied at the end.  Float expressions are evaluated in source order (library built with -ffp-contract=off).
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ygzf {
 
@@ -23,23 +24,7 @@ constexpr int HISTO_LENGTH = 30;
 
 __device__ __forceinline__ int m_lane() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ int m_wave_incl_scan(int v) {
-    const int lane = m_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned m_wave_min(unsigned v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        unsigned t = (unsigned) __shfl_xor((int) v, d, 64);
-        v = t < v ? t : v;
-    }
-    return v;
-}
+__device__ __forceinline__ int m_wave_incl_scan(int v) { return wave_incl_scan(v); }
 
 __global__ void k_backproject_unit(const ygzf_kp *__restrict__ keys, const int *__restrict__ cnt, long long kpStride, float fx,
                                    float fy, float cx, float cy, float *__restrict__ world) {
@@ -553,8 +538,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             }
             m12[i] = m;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        removed = wave_sum(removed);
         nmatches -= removed;
         if (lane == 0) A.nmatches[pair] = nmatches;
         return;
@@ -724,8 +708,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 removed++;
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) removed += __shfl_xor(removed, d, 64);
+        removed = wave_sum(removed);
         nmatches -= removed;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -12,6 +12,7 @@
 // strict `dist < bestDist` scan.  convertTo(CV_32F) / "minus centre" / cv::norm(NORM_L1) are integer arithmetic that float holds
 // exactly (|sum| <= 121 * 510), evaluated here in int32.  Float expressions keep source order (library built -ffp-contract=off).
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ygzf {
 
@@ -31,19 +32,8 @@ __global__ void k_stereo_prep(StereoArgs A) {
     A.rec[(long long) pair * A.recStride + i] = rec;
 }
 
-__device__ __forceinline__ int s_wave_sum(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ unsigned s_wave_min(unsigned v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned t = (unsigned) __shfl_xor((int) v, d, 64);
-        v = t < v ? t : v;
-    }
-    return v;
-}
+__device__ __forceinline__ int s_wave_sum(int v) { return wave_sum(v); }
+__device__ __forceinline__ unsigned s_wave_min(unsigned v) { return wave_min_u32(v); }
 
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
