@@ -62,6 +62,37 @@ __device__ __forceinline__ int block_scan_array(int *a, int n, int *tmp) {
     return total;
 }
 
+// In-place exclusive scans of three LDS arrays a, b, c [0..n) at once: the three running sums travel as 21-bit fields of one 64-bit word
+// (every sum < 2^21: callers scan child / node counts bounded by the candidate count), so the block pays one set of barriers instead of
+// three.  tmp64: >= 17 u64 of LDS.  Returns the totals.
+__device__ __forceinline__ void block_scan_array3(int *a, int *b, int *c, int n, unsigned long long *tmp64, int *totA, int *totB, int *totC) {
+    const int per = (n + blockDim.x - 1) / blockDim.x;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    unsigned long long s = 0;
+    for (int i = lo; i < hi; i++) s += (unsigned long long) (unsigned) a[i] | ((unsigned long long) (unsigned) b[i] << 21) | ((unsigned long long) (unsigned) c[i] << 42);
+    const unsigned long long incl = wave_incl_scan_u64(s);
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();  // tmp64 may still be read from a previous call
+    if (lane_id() == 63) tmp64[wave_id()] = incl;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const unsigned long long w = threadIdx.x < nw ? tmp64[threadIdx.x] : 0ull;
+        const unsigned long long wi = wave_incl_scan_u64(w);
+        if (threadIdx.x < nw) tmp64[threadIdx.x] = wi - w;
+        if (threadIdx.x == nw - 1) tmp64[16] = wi;
+    }
+    __syncthreads();
+    const unsigned long long total = tmp64[16];
+    unsigned long long off = tmp64[wave_id()] + incl - s;
+    for (int i = lo; i < hi; i++) {
+        const unsigned long long v = (unsigned long long) (unsigned) a[i] | ((unsigned long long) (unsigned) b[i] << 21) | ((unsigned long long) (unsigned) c[i] << 42);
+        a[i] = (int) (off & 0x1FFFFFu); b[i] = (int) ((off >> 21) & 0x1FFFFFu); c[i] = (int) (off >> 42);
+        off += v;
+    }
+    __syncthreads();
+    *totA = (int) (total & 0x1FFFFFu); *totB = (int) ((total >> 21) & 0x1FFFFFu); *totC = (int) (total >> 42);
+}
+
 // Stable LSD radix sort (4-bit digits) of n (key,val) pairs on `bits` key bits by the whole block.
 // k0/v0 hold the input; result is left in *rk/*rv (one of the two buffers).  Buffers may be LDS or global.
 // histT: 256 ints of LDS, tmp: 17 ints of LDS.
@@ -758,6 +789,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[256];
     __shared__ int s_tmp[20];
+    __shared__ unsigned long long s_tmp64[17];
     __shared__ int s_n, s_nE, s_cut, s_flagA;
     const int tid = threadIdx.x;
     const int l = blockIdx.x, f = blockIdx.y;
@@ -866,9 +898,8 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
             S.kArr[i] = k; S.eArr[i] = e; S.sArr[i] = (cnt == 1);
         }
         __syncthreads();
-        const int totK = block_scan_array(S.kArr, n, s_tmp);
-        const int totE = block_scan_array(S.eArr, n, s_tmp);
-        const int totS = block_scan_array(S.sArr, n, s_tmp);
+        int totK, totE, totS;
+        block_scan_array3(S.kArr, S.eArr, S.sArr, n, s_tmp64, &totK, &totE, &totS);
         const int nxt = cur ^ 1;
         for (int i = tid; i < n; i += kOctBlock) {
             const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i], lo = (cur ? S.nlo[1] : S.nlo[0])[i], dep = (cur ? S.ndep[1] : S.ndep[0])[i];
