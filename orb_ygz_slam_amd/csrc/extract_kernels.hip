@@ -1045,22 +1045,25 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     unsigned *oxy = lvlKpXY + (long long) f * kpStride + g.kpBase;
     unsigned char *osc = lvlKpScore + (long long) f * kpStride + g.kpBase;
     const int lane = lane_id(), wave = wave_id();
-    for (int i = wave; i < n; i += kOctBlock / 64) {
+    for (int i = wave; i < n; i += kOctBlock / 64) {   // a wave per node: arg-max over its range (LDS / DPP only)
         const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
         unsigned best = 0;
         for (int k = lane; k < cnt; k += 64) best = max(best, svals[lo + k]);
         best = wave_max_u32(best);
-        if (lane == 0) {
-            const unsigned idx = 0xFFFFFFu - (best & 0xFFFFFFu);
-            const unsigned p = xy[idx];
-            const unsigned kx = (p & 0xFFFFu) + kBorder, ky = (p >> 16) + kBorder;
-            oxy[i] = kx | (ky << 16);
-            osc[i] = (unsigned char) (best >> 24);
-            // spatial key for the PROCESSING order of k_describe: 64x64-px tile id, stable within a tile (locality of the
-            // 43x43 window gathers; the output order is untouched)
-            S.sk[0][i] = ((ky >> 6) << 6) | (kx >> 6);
-            S.sv[0][i] = (unsigned) i;
-        }
+        if (lane == 0) S.kArr[i] = (int) best;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kOctBlock) {         // a thread per node: the dependent global read of the winner's position, all in flight at once
+        const unsigned best = (unsigned) S.kArr[i];
+        const unsigned idx = 0xFFFFFFu - (best & 0xFFFFFFu);
+        const unsigned p = xy[idx];
+        const unsigned kx = (p & 0xFFFFu) + kBorder, ky = (p >> 16) + kBorder;
+        oxy[i] = kx | (ky << 16);
+        osc[i] = (unsigned char) (best >> 24);
+        // spatial key for the PROCESSING order of k_describe: 64x64-px tile id, stable within a tile (locality of the
+        // 43x43 window gathers; the output order is untouched)
+        S.sk[0][i] = ((ky >> 6) << 6) | (kx >> 6);
+        S.sv[0][i] = (unsigned) i;
     }
     __syncthreads();
     {
