@@ -93,11 +93,37 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return (a + b) + (c + d);
 }
 
+// Eight image bytes starting at column c0 of a row as one (unaligned) 8-byte load: scattered single-byte loads were the limit of the patch
+// loops (every lane of a load instruction touches its own cache line; the texture path serialises them).  The load never leaves the row:
+// it starts at min(c0, w - 8) and the result is shifted so that byte 0 is column c0 (callers need at most 8 - shift bytes).
+__device__ __forceinline__ unsigned long long row_bytes8(const uint8_t *row, int c0, int w) {
+    if (w < 8) {
+        unsigned long long v = 0;
+        for (int k = 0; k < 8 && c0 + k < w; k++) v |= (unsigned long long) row[c0 + k] << (8 * k);
+        return v;
+    }
+    const int s0 = min(c0, w - 8);
+    unsigned long long v;
+    __builtin_memcpy(&v, row + s0, 8);
+    return v >> (8 * (c0 - s0));
+}
+__device__ __forceinline__ float byte_f(unsigned long long v, int k) { return (float) (unsigned) ((v >> (8 * k)) & 0xFFull); }
+
+// the row part of wave_sum_dpp: every lane ends with the sum of its row of 16
+__device__ __forceinline__ float row_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    return v;
+}
+
 constexpr int kAcc = 30;  // 21 upper-triangular H entries + 6 b + chi2 + n_meas + n_visible_features
 
 __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
-    extern __shared__ float4 s_feat[];   // per feature: xyz in the reference camera (Tref * Xw, constant over the run), w = visible flag
-    __shared__ float s_red[(kSiaBlock / 64) * kAcc];
+    extern __shared__ float4 s_feat[];   // per feature: xyz in the reference camera (Tref * Xw, constant over the run), w = visible flag;
+                                         // behind it float2 s_uv[]: the reference keypoint (level 0), x = -100 for excluded features
+    __shared__ float s_red[(kSiaBlock / 16) * kAcc];   // one partial per row of 16 lanes
     __shared__ float s_tot[kAcc];
     __shared__ Se3 s_T, s_Told, s_Tref;
     __shared__ float s_H[36], s_b[6], s_x[6];
@@ -126,11 +152,22 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         s_iters = 0;
         for (int i = 0; i < 36; i++) s_H[i] = 0;
     }
-    for (int i = tid; i < N; i += kSiaBlock) {                  // visible_fts_: allocated once in run(), never cleared between levels
-        visible[i] = 0;
-        s_feat[i] = make_float4(0.f, 0.f, 1.f, 0.f);
-    }
+    float2 *s_uv = (float2 *) (s_feat + A.ldsFeat);
     for (int i = tid; i < N * 48; i += kSiaBlock) rowCache[i] = 0.f;
+    __syncthreads();                                            // s_Tref is set
+    {   // per-feature terms that do not depend on the level, once per run: the keypoint, the exclusion flags and Tref * Xw go to LDS
+        // (the level loop below used to re-read keys / world / flags for every (feature, row) item: two dependent global latencies each)
+        const Se3 Tref = s_Tref;
+        for (int i = tid; i < N; i += kSiaBlock) {              // visible_fts_: allocated once in run(), never cleared between levels
+            visible[i] = 0;
+            const bool excluded = (mpValid && !mpValid[i]) || (outlier && outlier[i]);
+            const ygzf_kp kp = keys[i];
+            s_uv[i] = excluded ? make_float2(-100.f, -100.f) : make_float2(kp.x, kp.y);   // fails every level's border test
+            float xyz[3];
+            se3_act(Tref, world + 3 * (size_t) i, xyz);
+            s_feat[i] = make_float4(xyz[0], xyz[1], xyz[2], 0.f);
+        }
+    }
     __syncthreads();
     if (N == 0) {                               // :24-27 "no features to track"
         if (tid == 0) { for (int i = 0; i < 48; i++) out[i] = 0; out[3] = 1.f; }
@@ -144,12 +181,11 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         // stay "visible" from a coarser level but fail this level's border test can still read it, so only their rows are zeroed.
         const long long p0c = wall_clock64();
         {
-            // work item = (feature, patch row): 4 pixels; the per-feature terms are recomputed by the 4 rows (cheap ALU)
-            const Se3 Tref = s_Tref;
+            // work item = (feature, patch row): 4 pixels
             for (int it = tid; it < 4 * N; it += kSiaBlock) {
                 const int i = it >> 2, y = it & 3;
-                bool ok = !((mpValid && !mpValid[i]) || (outlier && outlier[i]));
-                const ygzf_kp kp = keys[i];
+                bool ok = true;
+                const float2 kp = s_uv[i];
                 const float u_ref = kp.x * scale, v_ref = kp.y * scale;
                 const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
                 if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) ok = false;
@@ -161,21 +197,22 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                     }
                     continue;
                 }
-                float xyz[3];
-                se3_act(Tref, world + 3 * (size_t) i, xyz);
-                if (y == 0) { visible[i] = 1; s_feat[i] = make_float4(xyz[0], xyz[1], xyz[2], 1.f); }
+                if (y == 0) { visible[i] = 1; s_feat[i].w = 1.f; }
                 const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
                 const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
                 const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
                 const int st = Lr.pitch;
-                const uint8_t *p = Lr.img + (long long) (v_ref_i + y - 2) * st + (u_ref_i - 2);
+                // columns u-3 .. u+3 of rows v+y-3 .. v+y: p[k] of the scalar form (p = row + u - 2) is byte k + 1
+                const uint8_t *r0 = Lr.img + (long long) (v_ref_i + y - 2) * st;
+                const unsigned long long bm = row_bytes8(r0 - st, u_ref_i - 3, Lr.w), b0 = row_bytes8(r0, u_ref_i - 3, Lr.w);
+                const unsigned long long b1 = row_bytes8(r0 + st, u_ref_i - 3, Lr.w), b2 = row_bytes8(r0 + 2 * st, u_ref_i - 3, Lr.w);
 #pragma unroll
-                for (int x = 0; x < 4; x++, p++) {
-                    rc[x] = w_tl * p[0] + w_tr * p[1] + w_bl * p[st] + w_br * p[st + 1];
-                    rc[4 + x] = 0.5f * ((w_tl * p[1] + w_tr * p[2] + w_bl * p[st + 1] + w_br * p[st + 2]) -
-                                        (w_tl * p[-1] + w_tr * p[0] + w_bl * p[st - 1] + w_br * p[st]));
-                    rc[8 + x] = 0.5f * ((w_tl * p[st] + w_tr * p[1 + st] + w_bl * p[st * 2] + w_br * p[st * 2 + 1]) -
-                                        (w_tl * p[-st] + w_tr * p[1 - st] + w_bl * p[0] + w_br * p[1]));
+                for (int x = 0; x < 4; x++) {
+                    rc[x] = w_tl * byte_f(b0, x + 1) + w_tr * byte_f(b0, x + 2) + w_bl * byte_f(b1, x + 1) + w_br * byte_f(b1, x + 2);
+                    rc[4 + x] = 0.5f * ((w_tl * byte_f(b0, x + 2) + w_tr * byte_f(b0, x + 3) + w_bl * byte_f(b1, x + 2) + w_br * byte_f(b1, x + 3)) -
+                                        (w_tl * byte_f(b0, x) + w_tr * byte_f(b0, x + 1) + w_bl * byte_f(b1, x) + w_br * byte_f(b1, x + 1)));
+                    rc[8 + x] = 0.5f * ((w_tl * byte_f(b1, x + 1) + w_tr * byte_f(b1, x + 2) + w_bl * byte_f(b2, x + 1) + w_br * byte_f(b2, x + 2)) -
+                                        (w_tl * byte_f(bm, x + 1) + w_tr * byte_f(bm, x + 2) + w_bl * byte_f(b0, x + 1) + w_br * byte_f(b0, x + 2)));
                 }
             }
         }
@@ -206,10 +243,11 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
                 const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
                 const int st = Lc.pitch;
-                const uint8_t *p = Lc.img + (long long) (vi + y - 2) * st + (ui - 2);
+                const uint8_t *prow = Lc.img + (long long) (vi + y - 2) * st;
+                const unsigned long long q0 = row_bytes8(prow, ui - 2, Lc.w), q1 = row_bytes8(prow + st, ui - 2, Lc.w);
                 int t0[5], t1[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) { t0[k] = p[k]; t1[k] = p[st + k]; }
+                for (int k = 0; k < 5; k++) { t0[k] = (int) ((q0 >> (8 * k)) & 0xFFull); t1[k] = (int) ((q1 >> (8 * k)) & 0xFFull); }
                 const float4 *rcp = (const float4 *) (rowCache + ((size_t) i * 4 + y) * 12);
                 const float4 pc = rcp[0], dxv = rcp[1], dyv = rcp[2];
                 // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point, rebuilt from the LDS copy: the
@@ -250,16 +288,21 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 }
             }
             const long long c1 = wall_clock64();
-            // fixed-shape reduction: DPP tree inside each wave, then 30 threads add the 16 wave partials in order
+            // fixed-shape reduction: DPP tree inside each row of 16 lanes -> one LDS partial per row; then 30 threads combine the four rows of
+            // a wave as (r0 + r1) + (r2 + r3) and add the waves in order (the same tree as a full wave reduction, without the 4 v_readlane + 3 adds
+            // per accumulator and wave)
 #pragma unroll
             for (int k = 0; k < kAcc; k++) {
-                const float v = wave_sum_dpp(acc[k]);
-                if (lane == 0) s_red[wave * kAcc + k] = v;
+                const float v = row_sum_dpp(acc[k]);
+                if ((lane & 15) == 0) s_red[(tid >> 4) * kAcc + k] = v;
             }
             __syncthreads();
             if (tid < kAcc) {
                 float v = 0.f;
-                for (int w2 = 0; w2 < kSiaBlock / 64; w2++) v += s_red[w2 * kAcc + tid];
+                for (int w2 = 0; w2 < kSiaBlock / 64; w2++) {
+                    const float *r = s_red + (4 * w2) * kAcc + tid;
+                    v += (r[0] + r[kAcc]) + (r[2 * kAcc] + r[3 * kAcc]);
+                }
                 s_tot[tid] = v;
             }
             __syncthreads();
@@ -310,10 +353,16 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     }
 }
 
-size_t sia_lds_bytes(int maxFeatures) { return (size_t) maxFeatures * sizeof(float4) + 16; }
+size_t sia_lds_bytes(int maxFeatures) { return (size_t) maxFeatures * (sizeof(float4) + sizeof(float2)) + 16; }
 
 hipError_t sia_prepare(size_t ldsBytes) {
-    return hipFuncSetAttribute((const void *) k_sia_run, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    // the kernel's static LDS (reduction partials, solver state) comes out of the same 160 KB: the ceiling is a constant of the kernel,
+    // so every context sets the same value
+    hipFuncAttributes fa;
+    const hipError_t e = hipFuncGetAttributes(&fa, (const void *) k_sia_run);
+    if (e != hipSuccess) return e;
+    const int ceiling = (int) std::min<size_t>(kMaxDynLds, 160 * 1024 - ((fa.sharedSizeBytes + 255) & ~(size_t) 255));
+    return hipFuncSetAttribute((const void *) k_sia_run, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
 }
 
 void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes) {

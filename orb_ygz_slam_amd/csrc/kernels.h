@@ -173,6 +173,7 @@ struct SiaLevel {
     int w, h, pitch;
 };
 struct SiaArgs {
+    int ldsFeat;                    // feature slots of the dynamic LDS carve-up (float4 s_feat[ldsFeat] | float2 s_uv[ldsFeat])
     const ygzf_kp *keys;            // ref keypoints, pair p at keys + p*kpStride
     const float *world;             // MapPoint world positions, 3 per keypoint
     const uint8_t *mpValid, *outlier;  // nullable

@@ -1180,7 +1180,8 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
             A.dbg = (long long *) c->dTmpB.p;
         }
         const size_t sl = sia_lds_bytes((int) N);
-        if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 16));
+        A.ldsFeat = (int) N;
+        if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 24));
         HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
         launch_sia(c->stream, A, 1, sl);
@@ -2103,7 +2104,8 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
         A2.visible += (size_t) first * G.kpStride;
         A2.out += (size_t) first * 48;
         const size_t sl = sia_lds_bytes(G.kpStride);
-        if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 16));
+        A2.ldsFeat = G.kpStride;
+        if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 24));
         HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
         launch_sia(c->stream, A2, B - first, sl);
