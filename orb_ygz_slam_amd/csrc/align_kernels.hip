@@ -105,9 +105,14 @@ __device__ __forceinline__ unsigned long long row_bytes8(const uint8_t *row, int
     const int s0 = min(c0, w - 8);
     unsigned long long v;
     __builtin_memcpy(&v, row + s0, 8);
-    return v >> (8 * (c0 - s0));
+    // shift <= 3 bytes for every caller (patches stay 3 pixels inside the image): 32-bit byte alignment instead of a 64-bit shift
+    const unsigned sh = (unsigned) (c0 - s0), lo = (unsigned) v, hi = (unsigned) (v >> 32);
+    return ((unsigned long long) (hi >> (8 * sh)) << 32) | __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
-__device__ __forceinline__ float byte_f(unsigned long long v, int k) { return (float) (unsigned) ((v >> (8 * k)) & 0xFFull); }
+__device__ __forceinline__ float byte_f(unsigned long long v, int k) {   // k is a compile-time constant at every call site
+    const unsigned w = k < 4 ? (unsigned) v : (unsigned) (v >> 32);
+    return (float) ((w >> (8 * (k & 3))) & 0xFFu);
+}
 
 // the row part of wave_sum_dpp: every lane ends with the sum of its row of 16
 __device__ __forceinline__ float row_sum_dpp(float v) {
@@ -247,7 +252,10 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 const unsigned long long q0 = row_bytes8(prow, ui - 2, Lc.w), q1 = row_bytes8(prow + st, ui - 2, Lc.w);
                 int t0[5], t1[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) { t0[k] = (int) ((q0 >> (8 * k)) & 0xFFull); t1[k] = (int) ((q1 >> (8 * k)) & 0xFFull); }
+                for (int k = 0; k < 5; k++) {
+                    t0[k] = (int) (((k < 4 ? (unsigned) q0 : (unsigned) (q0 >> 32)) >> (8 * (k & 3))) & 0xFFu);
+                    t1[k] = (int) (((k < 4 ? (unsigned) q1 : (unsigned) (q1 >> 32)) >> (8 * (k & 3))) & 0xFFu);
+                }
                 const float4 *rcp = (const float4 *) (rowCache + ((size_t) i * 4 + y) * 12);
                 const float4 pc = rcp[0], dxv = rcp[1], dyv = rcp[2];
                 // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point, rebuilt from the LDS copy: the
