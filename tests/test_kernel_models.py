@@ -1,0 +1,117 @@
+"""CPU models of the arithmetic tricks the HIP kernels rely on, checked exhaustively / on large random samples against the plain
+definitions.  They guard the algebra (saturation corners, rounding, exactness ranges) independently of a GPU:
+
+* k_fast_quads' byte-sliced FAST-9 test: v_lerp_u8 as a four-byte comparator + bit-sliced 3-input arc trees
+  (orb_ygz_slam_amd/csrc/extract_kernels.hip: fast9_quad) against the scalar "9 contiguous of 16" definition (cv::FAST 9/16);
+* the (a * m) >> 16 small division (div_small / kRcp16);
+* the horizontal blur as two v_dot4_u32_u8 and the pyramid row sum as v_dot2_u32_u16 (plain integer identities);
+* the NMS shortcut "iniTh survivor == minTh survivor with score >= iniTh".
+"""
+import numpy as np
+
+
+def lerp_u8(a, b, c):
+    """V_LERP_U8 per byte: (a + b + (c & 1)) >> 1 on uint8 arrays."""
+    return ((a.astype(np.uint16) + b.astype(np.uint16) + (c.astype(np.uint16) & 1)) >> 1).astype(np.uint8)
+
+
+def fast9_quad_model(center, ring, t):
+    """center: (n,) uint8, ring: (n, 16) uint8, t: int -> polarity per pixel (0 none, 1 bright, 2 dark), using only bit 7 of byte results."""
+    c = center.astype(np.int32)
+    nc = 255 - c                                           # ~b3
+    nhi = np.maximum(nc - t, 0).astype(np.uint8)           # v_pk_sub_u16 clamp
+    nlo = np.minimum(nc + t, 255).astype(np.uint8)         # v_pk_add_u16 + v_pk_min_u16
+    zero, one = np.zeros_like(center), np.ones_like(center)
+    B = [lerp_u8(ring[:, k], nhi, zero) for k in range(16)]
+    N = [lerp_u8(ring[:, k], nlo, one) for k in range(16)]
+    A3 = [B[k] & B[(k + 1) & 15] & B[(k + 2) & 15] for k in range(16)]
+    O3 = [N[k] | N[(k + 1) & 15] | N[(k + 2) & 15] for k in range(16)]
+    bright = np.zeros_like(center)
+    ndark = np.full_like(center, 255)
+    for k in range(16):
+        bright |= A3[k] & A3[(k + 3) & 15] & A3[(k + 6) & 15]
+        ndark &= O3[k] | O3[(k + 3) & 15] | O3[(k + 6) & 15]
+    fb = (bright & 0x80) != 0
+    fd = ((~(ndark | bright)) & 0x80) != 0
+    return np.where(fb, 1, np.where(fd, 2, 0))
+
+
+def fast9_scalar(center, ring, t):
+    c = center.astype(np.int32)[:, None]
+    r = ring.astype(np.int32)
+    br, dk = r > c + t, r < c - t
+
+    def arc(m):
+        m2 = np.concatenate([m, m[:, :8]], axis=1)
+        out = np.zeros(len(m), bool)
+        for k in range(16):
+            out |= m2[:, k:k + 9].all(axis=1)
+        return out
+    b, d = arc(br), arc(dk)
+    return np.where(b, 1, np.where(d, 2, 0))
+
+
+def test_fast9_byte_sliced_model_matches_definition():
+    rng = np.random.default_rng(7)
+    n = 400_000
+    for t in (1, 7, 20, 100, 254):
+        center = rng.integers(0, 256, n).astype(np.uint8)
+        # rings biased towards the centre +- t so that arcs of 8 / 9 / 10 and the saturation corners are all frequent
+        delta = rng.integers(-t - 3, t + 4, (n, 16))
+        ring = np.clip(center[:, None].astype(np.int32) + delta * rng.integers(0, 3, (n, 16)), 0, 255).astype(np.uint8)
+        edge = rng.integers(0, 4, n)
+        center = np.where(edge == 0, rng.choice([0, 1, 254, 255], n), center).astype(np.uint8)
+        assert (fast9_quad_model(center, ring, t) == fast9_scalar(center, ring, t)).all(), t
+
+
+def test_fast9_model_structured_arcs():
+    """Every arc start x every arc length 7..11 x both polarities, at the saturation corners of centre +- t."""
+    rows_c, rows_r = [], []
+    for c in (0, 5, 7, 8, 128, 247, 248, 250, 255):
+        for pol in (+1, -1):
+            for start in range(16):
+                for length in (7, 8, 9, 10, 11, 16):
+                    for margin in (7, 8):     # exactly t (not a corner pixel) and t + 1
+                        ring = np.full(16, c, np.int32)
+                        for i in range(length):
+                            ring[(start + i) & 15] = c + pol * margin
+                        rows_c.append(c)
+                        rows_r.append(np.clip(ring, 0, 255))
+    center = np.array(rows_c, np.uint8)
+    ring = np.array(rows_r, np.uint8)
+    assert (fast9_quad_model(center, ring, 7) == fast9_scalar(center, ring, 7)).all()
+    assert fast9_scalar(center, ring, 7).max() == 2          # the set does contain bright and dark corners
+
+
+def test_small_division_table_is_exact():
+    for x in range(1, 65):
+        m = 65536 // x + 1
+        assert m < (1 << 24)                                 # __umul24 operand range
+        for a in range(0, 65):
+            assert (a * m) >> 16 == a // x, (a, x)
+
+
+def test_dot_product_forms_of_blur_and_resize():
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (100_000, 8)).astype(np.int64)
+    ref = 18 * (q[:, 0] + q[:, 6]) + 34 * (q[:, 1] + q[:, 5]) + 49 * (q[:, 2] + q[:, 4]) + 55 * q[:, 3]
+    w0, w1 = np.array([18, 34, 49, 55]), np.array([49, 34, 18, 0])     # 0x37312212, 0x00122231 (byte 0 first)
+    assert (ref == (q[:, :4] * w0).sum(1) + (q[:, 4:] * w1).sum(1)).all()
+    assert ref.max() <= 65535
+    a1 = rng.integers(0, 2049, 100_000)
+    a0 = 2048 - a1
+    p = rng.integers(0, 256, (100_000, 2))
+    H = p[:, 0] * a0 + p[:, 1] * a1
+    assert H.max() < (1 << 24) and (H >> 4).max() <= 32640   # 24-bit multiply operands of the vertical step
+
+
+def test_nms_threshold_shortcut():
+    """survivor at iniTh: s >= iniTh and s > every neighbour with score >= iniTh  <=>  s >= iniTh and s > every neighbour."""
+    rng = np.random.default_rng(11)
+    s = rng.integers(0, 256, 200_000)
+    nb = rng.integers(0, 256, (200_000, 8))
+    nb[rng.integers(0, 2, nb.shape) == 0] = 0                # many empty neighbours, as in a real score map
+    for ini in (1, 7, 20, 200):
+        long_form = (s >= ini) & (s > np.where(nb >= ini, nb, 0).max(1))
+        short_form = (s >= ini) & (s > nb.max(1))
+        assert (long_form == short_form).all()
