@@ -115,3 +115,81 @@ def test_nms_threshold_shortcut():
         long_form = (s >= ini) & (s > np.where(nb >= ini, nb, 0).max(1))
         short_form = (s >= ini) & (s > nb.max(1))
         assert (long_form == short_form).all()
+
+
+UMAX15 = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]   # src/ORBextractor.cc:455-469 for HALF_PATCH_SIZE = 15
+
+
+def test_centroid_on_masked_dwords_equals_ic_angle_sums():
+    """describe_window's moments: 248 (row, dword) items, byte masks from umax, m10 = <bytes, column index> - 15 * sum, m01 = v * sum."""
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        patch = rng.integers(0, 256, (31, 32)).astype(np.int64)      # rows v = -15..15, columns u + 15 = 0..31 (column 31 is outside)
+        m10 = m01 = 0
+        for v in range(-15, 16):                                     # IC_Angle (:83-110): all (u, v) with |u| <= umax[|v|]
+            for u in range(-UMAX15[abs(v)], UMAX15[abs(v)] + 1):
+                m10 += u * patch[v + 15, u + 15]
+                m01 += v * patch[v + 15, u + 15]
+        wsum = ssum = vsum = 0
+        for item in range(256):
+            row, j = item >> 3, item & 7
+            if row >= 31:
+                continue                                             # the kernel's table holds zero masks there
+            v = row - 15
+            px = [patch[row, 4 * j + k] if (4 * j + k - 15 <= 15 and abs(4 * j + k - 15) <= UMAX15[abs(v)]) else 0 for k in range(4)]
+            sm = sum(px)
+            wsum += sum((4 * j + k) * px[k] for k in range(4))
+            ssum += sm
+            vsum += v * sm
+        assert (wsum - 15 * ssum, vsum) == (m10, m01)
+
+
+def test_quad_record_round_trip():
+    """k_fast_quads: record = pol bytes | y << 2 | q << 10; the expansion rebuilds (y << 8 | 4q << 2) with two mask-shifts."""
+    for y in range(0, 59):
+        for q in range(0, 15):
+            for pb in (0x00000001, 0x02000000, 0x01020102, 0x00020000):
+                rec = pb | (y << 2) | (q << 10)
+                assert rec & 0x03030303 == pb
+                yx = ((rec & 0xFC) << 6) | ((rec & 0x3C00) >> 6)
+                assert yx == (y << 8) | ((4 * q) << 2)
+
+
+def _dpp(v, ctrl, row_mask, old=0):
+    """update_dpp(old, v, ctrl, row_mask, 0xf, bound_ctrl=false) on a 64-lane array for the controls wave_ops.h uses."""
+    out = np.full(64, old, dtype=np.int64)
+    for lane in range(64):
+        row, i = lane >> 4, lane & 15
+        if not (row_mask >> row) & 1:
+            out[lane] = old
+            continue
+        if 0x111 <= ctrl <= 0x11F:                                   # row_shr:n
+            n = ctrl - 0x110
+            out[lane] = v[lane - n] if i >= n else old
+        elif ctrl == 0x142:                                          # row_bcast:15 -> lane 15 of the previous row
+            out[lane] = v[(row - 1) * 16 + 15] if row >= 1 else old
+        elif ctrl == 0x143:                                          # row_bcast:31 -> lane 31 into rows 2 and 3
+            out[lane] = v[31] if row >= 2 else old
+        else:
+            raise ValueError(ctrl)
+    return out
+
+
+def test_dpp_inclusive_scan_sequence():
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        x = rng.integers(0, 1000, 64).astype(np.int64)
+        v = x.copy()
+        for ctrl, mask in ((0x111, 0xF), (0x112, 0xF), (0x114, 0xF), (0x118, 0xF), (0x142, 0xA), (0x143, 0xC)):
+            v = v + _dpp(v, ctrl, mask)
+        assert (v == np.cumsum(x)).all()
+
+
+def test_row_bytes8_window_never_leaves_the_row():
+    """SparseImgAlign's 8-byte row load: start min(c0, w - 8), shift c0 - start <= 3, the needed bytes are inside the loaded eight."""
+    for w in range(8, 80):
+        for u in range(3, w - 3):                                    # border = 3: u - 3 >= 0, u + 3 < w
+            for c0, need in ((u - 3, 7), (u - 2, 5)):                # precompute (7 bytes), residual loop (5 bytes)
+                s0 = min(c0, w - 8)
+                sh = c0 - s0
+                assert 0 <= s0 and s0 + 8 <= w and 0 <= sh <= 3 and sh + need <= 8
