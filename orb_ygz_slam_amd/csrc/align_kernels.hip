@@ -248,14 +248,10 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
                 const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
                 const int st = Lc.pitch;
-                const uint8_t *prow = Lc.img + (long long) (vi + y - 2) * st;
-                const unsigned long long q0 = row_bytes8(prow, ui - 2, Lc.w), q1 = row_bytes8(prow + st, ui - 2, Lc.w);
+                const uint8_t *p = Lc.img + (long long) (vi + y - 2) * st + (ui - 2);
                 int t0[5], t1[5];
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    t0[k] = (int) (((k < 4 ? (unsigned) q0 : (unsigned) (q0 >> 32)) >> (8 * (k & 3))) & 0xFFu);
-                    t1[k] = (int) (((k < 4 ? (unsigned) q1 : (unsigned) (q1 >> 32)) >> (8 * (k & 3))) & 0xFFu);
-                }
+                for (int k = 0; k < 5; k++) { t0[k] = p[k]; t1[k] = p[st + k]; }
                 const float4 *rcp = (const float4 *) (rowCache + ((size_t) i * 4 + y) * 12);
                 const float4 pc = rcp[0], dxv = rcp[1], dyv = rcp[2];
                 // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point, rebuilt from the LDS copy: the
