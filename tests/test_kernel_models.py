@@ -189,7 +189,7 @@ def test_row_bytes8_window_never_leaves_the_row():
     """SparseImgAlign's 8-byte row load: start min(c0, w - 8), shift c0 - start <= 3, the needed bytes are inside the loaded eight."""
     for w in range(8, 80):
         for u in range(3, w - 3):                                    # border = 3: u - 3 >= 0, u + 3 < w
-            for c0, need in ((u - 3, 7), (u - 2, 5)):                # precompute (7 bytes), residual loop (5 bytes)
+            for c0, need in ((u - 3, 7), (u - 2, 5)):                # precompute (7 bytes); a 5-byte window one column further in
                 s0 = min(c0, w - 8)
                 sh = c0 - s0
                 assert 0 <= s0 and s0 + 8 <= w and 0 <= sh <= 3 and sh + need <= 8
