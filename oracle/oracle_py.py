@@ -70,6 +70,99 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+_ref_ex = None
+
+
+def ref_extractor_lib():
+    """The reference's own src/ORBextractor.cc (oracle/_ref/libref_orbextractor.so, built by oracle/Makefile from the reference checkout
+    against the OpenCV stand-in of oracle/ref_shim/), or None when it was never built."""
+    global _ref_ex
+    if _ref_ex is None:
+        build()
+        p = os.path.join(_HERE, "_ref", "libref_orbextractor.so")
+        if not os.path.exists(p):
+            return None
+        _ref_ex = C.CDLL(p)
+        _ref_ex.yr_extract.restype = C.c_int
+        _ref_ex.yr_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        _ref_ex.yr_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _ref_ex.yr_frame_extractor_create.restype = C.c_void_p
+        _ref_ex.yr_frame_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        _ref_ex.yr_frame_extractor_destroy.argtypes = [C.c_void_p]
+        _ref_ex.yr_frame_extract.restype = C.c_int
+        _ref_ex.yr_frame_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    return _ref_ex
+
+
+def _kp7_to_struct(a):
+    k = np.zeros(len(a), KP_DTYPE)
+    for i, f in enumerate(("x", "y", "size", "angle", "response")):
+        k[f] = a[:, i]
+    k["octave"] = a[:, 5].astype(np.int32)
+    k["class_id"] = a[:, 6].astype(np.int32)
+    return k
+
+
+def _struct_to_kp7(k):
+    a = np.zeros((len(k), 7), np.float32)
+    for i, f in enumerate(("x", "y", "size", "angle", "response", "octave", "class_id")):
+        a[:, i] = k[f]
+    return a
+
+
+def ref_extract(img, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, cap=60000):
+    """ygz::ORBextractor(...)(image, mask, keypoints, descriptors) run by the REFERENCE's own code -> (keys, desc)."""
+    L = ref_extractor_lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    kp = np.zeros((cap, 7), np.float32)
+    d = np.zeros((cap, 32), np.uint8)
+    n = L.yr_extract(_p(img), w, h, w, nfeatures, scale_factor, nlevels, ini_th, min_th, _p(kp), _p(d), cap)
+    assert n >= 0
+    return _kp7_to_struct(kp[:n]), d[:n].copy()
+
+
+def ref_pyramid(img, scale_factor=1.2, nlevels=8):
+    L = ref_extractor_lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = []
+    for lvl in range(nlevels):
+        lw, lh = C.c_int(), C.c_int()
+        L.yr_pyramid_level(_p(img), w, h, w, scale_factor, nlevels, lvl, None, C.byref(lw), C.byref(lh))
+        o = np.zeros((lh.value, lw.value), np.uint8)
+        L.yr_pyramid_level(_p(img), w, h, w, scale_factor, nlevels, lvl, _p(o), C.byref(lw), C.byref(lh))
+        out.append(o)
+    return out
+
+
+class RefFrameExtractor:
+    """The reference's ORBextractor object kept across frames (mnGridSize of the DSO detector is state), driven through
+    operator()(Frame*, keypoints, descriptors, method, leftEye = true).  method: 0 ORBSLAM_KEYPOINT, 2 DSO_KEYPOINT."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = ref_extractor_lib()
+        self.h = self.L.yr_frame_extractor_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+
+    def close(self):
+        if self.h:
+            self.L.yr_frame_extractor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def extract(self, img, method, existing=None, cap=60000):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        ex = _struct_to_kp7(existing) if existing is not None and len(existing) else np.zeros((0, 7), np.float32)
+        kp = np.zeros((cap, 7), np.float32)
+        d = np.zeros((cap, 32), np.uint8)
+        n = self.L.yr_frame_extract(self.h, _p(img), w, h, w, method, _p(ex) if len(ex) else None, len(ex), _p(kp), _p(d), cap)
+        assert n >= 0
+        return _kp7_to_struct(kp[:n]), d[:n].copy()
+
+
 class Extractor:
     def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
         self.L = lib()

@@ -1,0 +1,15 @@
+// oracle/ref_shim/Frame.h -- TEST INFRASTRUCTURE: the four members of ygz::Frame that src/ORBextractor.cc reads (include/Frame.h
+// itself needs Eigen / Sophus / DBoW2).  Found before the reference's own header through the include path of oracle/Makefile.
+#ifndef YGZ_ORACLE_REF_SHIM_FRAME_H
+#define YGZ_ORACLE_REF_SHIM_FRAME_H
+#include "mini_cv.h"
+namespace ygz {
+class Frame {
+public:
+    cv::Mat mImRight;                        // include/Frame.h: right image of a stereo frame
+    std::vector<cv::Mat> mvImagePyramid;     // pyramid of the left image (built by Frame::ComputeImagePyramid)
+    std::vector<cv::KeyPoint> mvKeys;        // keypoints the frame already holds
+    int N = 0;                               // their number
+};
+}  // namespace ygz
+#endif
