@@ -1,7 +1,8 @@
 // oracle_extractor.cpp -- CPU ORACLE (test infrastructure): restatement of ygz::ORBextractor,
 // reference src/ORBextractor.cc (line numbers cited per function).  Built with -ffp-contract=off.
-// PARITY UNPINNED (see ygz_oracle.h): the reference has no test for this path; this file defines the semantics
-// the HIP implementation is graded against.
+// PARITY: PINNED to the reference's own src/ORBextractor.cc for everything in this file (tests/test_ref_extractor.py runs that file,
+// compiled where it lies against oracle/ref_shim/, next to this one and demands identical keypoints and descriptors); the OpenCV
+// primitives it calls (oracle_cvprims.cpp) remain unpinned, and the octree's heap-pointer tie-break is defined as creation order.
 #include <algorithm>
 #include <cmath>
 #include <cstring>

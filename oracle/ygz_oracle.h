@@ -8,10 +8,11 @@
 // plus restatements of the OpenCV 2.4.11/3.2 primitives the reference calls (resize INTER_LINEAR, FAST,
 // GaussianBlur, fastAtan2, cvRound), which are NOT under /root/reference.
 //
-// PARITY STATUS: "parity unpinned" for everything that goes through OpenCV (the reference ships no test or
-// golden vector for the extractor / matcher / aligner, and OpenCV is neither vendored nor version-pinned,
-// SURVEY.md §8c).  The only pinned vector is Thirdparty/fast's 167-corner KAT, checked in
-// tests/test_oracle_fast10.py against oracle/_ref (the reference's own libfast compiled from where it lies).
+// PARITY STATUS: "parity unpinned" for the OpenCV primitives (oracle_cvprims.cpp) and for the matcher / aligner / stereo / direct
+// restatements (the reference ships no test or golden vector for them, OpenCV is neither vendored nor version-pinned, and those sources
+// need Eigen / Sophus / the whole Frame-MapPoint graph).  PINNED: the extractor (oracle_extractor.cpp) against the
+// reference's own src/ORBextractor.cc compiled where it lies over oracle/ref_shim/ (tests/test_ref_extractor.py), and FAST-10 against
+// the reference's own libfast incl. Thirdparty/fast's 167-corner KAT (tests/test_oracle_fast10.py); both live in oracle/_ref.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this code.
 #ifndef YGZ_ORACLE_H
