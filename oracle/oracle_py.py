@@ -31,8 +31,36 @@ _lib = None
 _ref = None
 
 
+_lib_override = None
+
+
+def ref_matcher_lib():
+    """The reference's own src/ORBmatcher.cc behind the oracle's flat matcher API (oracle/_ref/libref_orbmatcher.so), or None."""
+    build()
+    p = os.path.join(_HERE, "_ref", "libref_orbmatcher.so")
+    return C.CDLL(p) if os.path.exists(p) else None
+
+
+class reference_matcher:
+    """with reference_matcher(): the matcher wrappers of this module (search_by_projection_*, search_for_initialization, search_by_bow)
+    run the REFERENCE's code instead of the oracle's restatement -- same flat inputs, same outputs (a slot that was matched and then
+    culled by the rotation check reads -1 there, -2 from the oracle: the reference leaves no trace of it)."""
+
+    def __enter__(self):
+        global _lib_override
+        _lib_override = ref_matcher_lib()
+        assert _lib_override is not None, "oracle/_ref/libref_orbmatcher.so not built"
+        return self
+
+    def __exit__(self, *a):
+        global _lib_override
+        _lib_override = None
+
+
 def lib():
     global _lib
+    if _lib_override is not None:
+        return _lib_override
     if _lib is None:
         _lib = C.CDLL(os.environ.get("YGZ_ORACLE_LIB") or build())   # YGZ_ORACLE_LIB: the sanitizer build (tests/test_oracle_sanitizers.py)
         L = _lib

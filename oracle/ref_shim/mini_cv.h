@@ -20,6 +20,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <list>
@@ -95,6 +96,11 @@ struct MatStep {   // Mat::step: converts to size_t and offers .p[0]
 // matrix, src/ORBextractor.cc:964, must clear the view, not rebind the header)
 struct MatZerosExpr { int rows, cols; };
 
+[[noreturn]] inline void mini_cv_unsupported(const char *what) {
+    std::fprintf(stderr, "oracle/ref_shim/mini_cv: %s is not provided (outside the pinned path)\n", what);
+    std::abort();
+}
+
 // 8-bit single-channel matrix header over a shared buffer (views: rowRange / colRange / operator()(Rect) keep the parent's step)
 class Mat {
 public:
@@ -128,6 +134,13 @@ public:
     Mat rowRange(int a, int b) const { Mat m = *this; m.data = data + (size_t) a * step.p[0]; m.rows = b - a; return m; }
     Mat colRange(int a, int b) const { Mat m = *this; m.data = data + a; m.cols = b - a; return m; }
     Mat operator()(const Rect &r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
+    Mat row(int y) const { return rowRange(y, y + 1); }
+    // float-matrix algebra (Sim3 / fuse functions of the matcher): declared so that those functions compile, never executed
+    Mat col(int) const { mini_cv_unsupported("Mat::col"); }
+    Mat t() const { mini_cv_unsupported("Mat::t"); }
+    double dot(const Mat &) const { mini_cv_unsupported("Mat::dot"); }
+    template <class T> T &at(int) { mini_cv_unsupported("Mat::at(int)"); }
+    template <class T> const T &at(int) const { mini_cv_unsupported("Mat::at(int)"); }
     template <class T> T &at(int y, int x) { return *(T *) (data + (size_t) y * step.p[0] + x); }
     template <class T> const T &at(int y, int x) const { return *(const T *) (data + (size_t) y * step.p[0] + x); }
     template <class T> T *ptr(int y = 0) { return (T *) (data + (size_t) y * step.p[0]); }
@@ -156,6 +169,14 @@ public:
 typedef const _InputArray &InputArray;
 typedef const _OutputArray &OutputArray;
 
+inline Mat operator/(const Mat &, double) { mini_cv_unsupported("Mat / s"); }
+inline Mat operator*(const Mat &, const Mat &) { mini_cv_unsupported("Mat * Mat"); }
+inline Mat operator*(double, const Mat &) { mini_cv_unsupported("s * Mat"); }
+inline Mat operator+(const Mat &, const Mat &) { mini_cv_unsupported("Mat + Mat"); }
+inline Mat operator-(const Mat &, const Mat &) { mini_cv_unsupported("Mat - Mat"); }
+inline Mat operator-(const Mat &) { mini_cv_unsupported("-Mat"); }
+inline double norm(const Mat &) { mini_cv_unsupported("cv::norm"); }
+
 enum { BORDER_REFLECT_101 = 4, BORDER_ISOLATED = 16, INTER_LINEAR = 1 };
 
 // the primitives: bodies in mini_cv.cpp on top of the oracle's restatements (oracle_cvprims.cpp)
@@ -170,4 +191,10 @@ struct KeyPointsFilter {
 };
 
 }  // namespace cv
+
+#ifdef YGZ_REF_MATCHER
+using cv::Mat;   // include/Common.h:64
+#include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
+#include "matcher_stubs.h"
+#endif
 #endif

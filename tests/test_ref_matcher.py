@@ -1,0 +1,190 @@
+"""The oracle's matcher against THE REFERENCE'S OWN src/ORBmatcher.cc (compiled where it lies into oracle/_ref/libref_orbmatcher.so by
+oracle/Makefile, against oracle/ref_shim/: OpenCV stand-in + plain-data Frame / KeyFrame / MapPoint + 3x3 arithmetic stand-ins for
+Eigen / Sophus -- see oracle/ref_orbmatcher_capi.cpp).  Both sides get identical flat inputs through the same Python wrappers.
+
+Pinned by this: SearchByProjection(F, MapPoints), SearchByProjection(Cur, Last), SearchByProjection(Cur, KF, found), SearchForInitialization,
+SearchByBoW(KF, F), DescriptorDistance, ComputeThreeMaxima, RadiusByViewingCos -- rows a-10 ... a-14 of SURVEY 8a.  Not pinned: the Frame
+grid (GetFeaturesInArea), MapPoint::PredictScale and the 3x3 float products, which are the oracle's restatements on both sides.
+
+CPU tier; skipped where the library was never built."""
+import numpy as np
+import pytest
+
+from oracle import oracle_py as O
+from orb_ygz_slam_amd.scene import synth_frame
+
+pytestmark = pytest.mark.skipif(O.ref_matcher_lib() is None, reason="oracle/_ref/libref_orbmatcher.so not built (reference checkout absent)")
+
+CAM = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375)
+W, H = 752, 480
+
+
+def canon(m):
+    return np.where(m == -2, -1, m)      # matched-then-culled slots: NULL either way
+
+
+def unit_world(keys):
+    return np.stack([(keys["x"] - np.float32(CAM["cx"])) / np.float32(CAM["fx"]), (keys["y"] - np.float32(CAM["cy"])) / np.float32(CAM["fy"]),
+                     np.ones(len(keys), np.float32)], -1).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def pair():
+    base = synth_frame(50, W + 16, H + 16)
+    a, b = base[8:8 + H, 8:8 + W], base[10:10 + H, 5:5 + W]
+    oex = O.Extractor(1000, 1.2, 8, 20, 7)
+    ka, da = oex.extract(a)
+    kb, db = oex.extract(b)
+    return ka, da, kb, db, oex.tables()["scale"]
+
+
+def test_descriptor_distance(pair):
+    ka, da, kb, db, sf = pair
+    import ctypes
+    L = O.ref_matcher_lib()
+    L.yo_descriptor_distance.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    for i in range(0, min(len(da), len(db)), 7):
+        assert L.yo_descriptor_distance(da[i].ctypes.data, db[i].ctypes.data) == int(np.unpackbits(da[i] ^ db[i]).sum())
+
+
+def test_search_by_projection_last_equals_reference(pair):
+    ka, da, kb, db, sf = pair
+    rng = np.random.default_rng(3)
+    n = len(ka)
+    depth = rng.uniform(2.0, 8.0, n).astype(np.float32)
+    world = unit_world(ka) * depth[:, None]
+    ang = np.float32(np.deg2rad(0.5))
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.02, -0.01, 0.03], np.float32)
+    angl = np.float32(np.deg2rad(-0.3))
+    Rlw = np.array([[1, 0, 0], [0, np.cos(angl), -np.sin(angl)], [0, np.sin(angl), np.cos(angl)]], np.float32)
+    tlw = np.array([-0.01, 0.02, 0.0], np.float32)
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    valid = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    outl = (rng.uniform(size=n) > 0.9).astype(np.uint8)
+    obs = (rng.uniform(size=n) > 0.3).astype(np.uint8)
+    uright = np.where(rng.uniform(size=len(kb)) > 0.5, kb["x"] - 5.0, -1.0).astype(np.float32)
+    owner0 = ((rng.uniform(size=len(kb)) > 0.9) * rng.integers(1, 3, len(kb))).astype(np.uint8)
+    cases = [dict(th=15.0, mono=True, check_level=True, check_ori=True), dict(th=7.0, mono=False, check_level=True, check_ori=True, u_right=uright, mb=0.11, mbf=50.0),
+             dict(th=30.0, mono=True, check_level=False, check_ori=False), dict(th=15.0, mono=False, check_level=True, check_ori=True, tz=0.5, mb=0.11, mbf=50.0),
+             dict(th=15.0, mono=False, check_level=True, check_ori=True, tz=-0.5, mb=0.11, mbf=50.0),
+             dict(th=15.0, mono=True, check_level=True, check_ori=True, last=(Rlw, tlw))]
+    total = 0
+    for cs in cases:
+        cam = dict(CAM, mb=cs.get("mb", 0.0), mbf=cs.get("mbf", 0.0))
+        t = tcw.copy()
+        t[2] += cs.get("tz", 0.0)
+        Rl, tl = cs.get("last", (I, z))
+        kw = dict(mp_valid=valid, outlier=outl, mp_has_obs=obs, u_right=cs.get("u_right"), cur_owner=owner0)
+        args = (kb, db, sf, W, H, cam, ka, world, da, Rcw, t, Rl, tl, cs["th"], cs["mono"], cs["check_level"], cs["check_ori"])
+        e_n, e_m, e_o = O.search_by_projection_last(*args, **kw)
+        with O.reference_matcher():
+            r_n, r_m, r_o = O.search_by_projection_last(*args, **kw)
+        assert r_n == e_n, (cs, r_n, e_n)
+        assert (r_m == canon(e_m)).all() and (r_o == e_o).all(), cs
+        total += e_n
+    assert total > 300
+
+
+def test_search_by_projection_mappoints_equals_reference(pair):
+    ka, da, kb, db, sf = pair
+    rng = np.random.default_rng(7)
+    M = len(ka)
+    px = (ka["x"] - 3.0 + rng.normal(0, 1.0, M)).astype(np.float32)
+    py = (ka["y"] + 2.0 + rng.normal(0, 1.0, M)).astype(np.float32)
+    vc = rng.uniform(0.99, 1.0, M).astype(np.float32)
+    vc[::5] = rng.uniform(0.9, 0.998, len(vc[::5]))           # both branches of RadiusByViewingCos
+    lvl = np.clip(ka["octave"] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    tiv = (rng.uniform(size=M) > 0.15).astype(np.uint8)
+    bad = (rng.uniform(size=M) > 0.95).astype(np.uint8)
+    obs = (rng.uniform(size=M) > 0.2).astype(np.uint8)
+    pxr = (px - 4.0).astype(np.float32)
+    uright = np.where(rng.uniform(size=len(kb)) > 0.5, kb["x"] - 4.0, -1.0).astype(np.float32)
+    owner0 = ((rng.uniform(size=len(kb)) > 0.9) * rng.integers(1, 3, len(kb))).astype(np.uint8)
+    for cs in (dict(th=1.0, check_level=False, nnratio=0.8), dict(th=3.0, check_level=True, nnratio=0.8),
+               dict(th=5.0, check_level=False, nnratio=0.6, stereo=True), dict(th=8.0, check_level=True, nnratio=0.9, stereo=True)):
+        kw = dict(is_bad=bad, mp_has_obs=obs, owner=owner0)
+        if cs.get("stereo"):
+            kw.update(proj_xr=pxr, u_right=uright)
+        args = (kb, db, sf, W, H, CAM, tiv, px, py, vc, lvl, da, cs["th"], cs["check_level"], cs["nnratio"])
+        e_n, e_m, e_o = O.search_by_projection_mappoints(*args, **kw)
+        with O.reference_matcher():
+            r_n, r_m, r_o = O.search_by_projection_mappoints(*args, **kw)
+        assert r_n == e_n and (r_m == canon(e_m)).all() and (r_o == e_o).all(), cs
+        assert e_n > 50
+
+
+def test_search_by_projection_keyframe_equals_reference(pair):
+    ka, da, kb, db, sf = pair
+    rng = np.random.default_rng(11)
+    n = len(ka)
+    depth = rng.uniform(2.0, 8.0, n).astype(np.float32)
+    world = unit_world(ka) * depth[:, None]
+    ang = np.float32(np.deg2rad(0.4))
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = np.array([0.03, 0.01, -0.02], np.float32)
+    dist = np.linalg.norm(world, axis=1).astype(np.float32)
+    mf_max = (dist * sf[ka["octave"]]).astype(np.float32)
+    mf_min = (mf_max / sf[7]).astype(np.float32)
+    max_inv, min_inv = (np.float32(1.2) * mf_max).astype(np.float32), (np.float32(0.8) * mf_min).astype(np.float32)
+    usable = (rng.uniform(size=n) > 0.15).astype(np.uint8)
+    owner0 = (rng.uniform(size=len(kb)) > 0.9).astype(np.uint8)
+    log_sf = np.log(np.float32(1.2))
+    # (ORBdist >= 256 is left out: with every candidate slot taken the reference writes mvpMapPoints[-1], src/ORBmatcher.cc:1430-1432)
+    for th, orb_dist, ori in ((10.0, 100, True), (3.0, 64, True), (10.0, 100, False), (25.0, 200, True)):
+        args = (kb, db, sf, W, H, CAM, usable, world, max_inv, min_inv, mf_max, ka["angle"], da, Rcw, tcw, log_sf, th, orb_dist, ori)
+        e_n, e_m, e_o, _ = O.search_by_projection_kf(*args, owner=owner0)
+        with O.reference_matcher():
+            r_n, r_m, r_o, _ = O.search_by_projection_kf(*args, owner=owner0)
+        assert r_n == e_n and (r_m == canon(e_m)).all(), (th, orb_dist, ori, r_n, e_n)
+        assert ((r_o != 0) == (e_o != 0)).all()
+        if th >= 10:
+            assert e_n > 50
+
+
+def test_search_for_initialization_equals_reference():
+    base = synth_frame(70, W + 32, H + 32)
+    a, b = base[16:16 + H, 16:16 + W], base[20:20 + H, 9:9 + W]
+    oex = O.Extractor(2000, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = oex.extract(a)
+    kb, db = oex.extract(b)
+    prev = np.stack([ka["x"], ka["y"]], -1).astype(np.float32)
+    state = prev
+    for window, ratio, ori in ((100, 0.9, True), (30, 0.9, True), (100, 0.6, False), (100, 0.05, True), (100, 0.9, True)):
+        args = (ka, da, kb, db, sf, W, H, CAM, state, window, ratio, ori)
+        e_n, e_m, e_p = O.search_for_initialization(*args)
+        with O.reference_matcher():
+            r_n, r_m, r_p = O.search_for_initialization(*args)
+        assert r_n == e_n and (r_m == e_m).all() and (r_p == e_p).all(), (window, ratio, ori)
+        state = e_p                                    # the next call starts from the updated vbPrevMatched
+    assert e_n > 50
+
+
+def _fake_feature_vector(desc, bits):
+    node = (desc[:, 0].astype(np.int32) >> (8 - bits)) if bits <= 8 else ((desc[:, 0].astype(np.int32) << (bits - 8)) | (desc[:, 1] >> (16 - bits)))
+    return {int(n): np.nonzero(node == n)[0].astype(np.int32) for n in np.unique(node)}
+
+
+def _join(fv_kf, fv_f):
+    nodes = sorted(set(fv_kf) & set(fv_f))
+    ko, fo, ki, fi = [0], [0], [], []
+    for n in nodes:
+        ki.extend(fv_kf[n]); fi.extend(fv_f[n])
+        ko.append(len(ki)); fo.append(len(fi))
+    return np.array(ko, np.int32), np.array(ki, np.int32), np.array(fo, np.int32), np.array(fi, np.int32)
+
+
+def test_search_by_bow_equals_reference(pair):
+    ka, da, kb, db, sf = pair
+    rng = np.random.default_rng(5)
+    valid = (rng.uniform(size=len(ka)) > 0.1).astype(np.uint8)
+    for bits, ratio, ori in ((4, 0.7, False), (6, 0.75, True), (1, 0.9, True), (10, 0.7, True)):
+        ko, ki, fo, fi = _join(_fake_feature_vector(da, bits), _fake_feature_vector(db, bits))
+        args = (ko, ki, fo, fi, valid, ka, da, kb, db, ratio, ori)
+        e_n, e_m = O.search_by_bow(*args)
+        with O.reference_matcher():
+            r_n, r_m = O.search_by_bow(*args)
+        assert r_n == e_n and (r_m == canon(e_m)).all(), (bits, ratio, ori, r_n, e_n)
+        if bits <= 6:
+            assert e_n > 20
