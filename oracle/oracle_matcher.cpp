@@ -2,7 +2,9 @@
 // ygz::ORBmatcher (reference src/ORBmatcher.cc) and of the Frame feature grid (src/Frame.cc).
 // MapPoint / Frame objects are replaced by the plain arrays the functions actually read (see ygz_oracle.h).
 // Built with -ffp-contract=off: float expressions are evaluated in source order without FMA.
-// PARITY UNPINNED: the reference ships no test for this path.
+// PARITY: the five search functions, DescriptorDistance and ComputeThreeMaxima are PINNED to the reference's own src/ORBmatcher.cc
+// (tests/test_ref_matcher.py runs that file, compiled where it lies over oracle/ref_shim/, on identical inputs); the Frame grid,
+// isInFrustum, PredictScale and ComputeDistinctiveDescriptors restatements remain unpinned (the reference ships no test for them).
 #include <climits>
 #include <algorithm>
 #include <cmath>

@@ -11,7 +11,8 @@
 // PARITY STATUS: "parity unpinned" for the OpenCV primitives (oracle_cvprims.cpp) and for the matcher / aligner / stereo / direct
 // restatements (the reference ships no test or golden vector for them, OpenCV is neither vendored nor version-pinned, and those sources
 // need Eigen / Sophus / the whole Frame-MapPoint graph).  PINNED: the extractor (oracle_extractor.cpp) against the
-// reference's own src/ORBextractor.cc compiled where it lies over oracle/ref_shim/ (tests/test_ref_extractor.py), and FAST-10 against
+// reference's own src/ORBextractor.cc and the matcher's search functions against its src/ORBmatcher.cc, both compiled where they lie
+// over oracle/ref_shim/ (tests/test_ref_extractor.py, tests/test_ref_matcher.py), and FAST-10 against
 // the reference's own libfast incl. Thirdparty/fast's 167-corner KAT (tests/test_oracle_fast10.py); both live in oracle/_ref.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this code.
