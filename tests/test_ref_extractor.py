@@ -108,3 +108,25 @@ def test_frame_overload_dso_sequence_with_state():
         assert_same(rk, rd, ok, od, ("dso frame", i))
         existing = ok[::5].copy()                      # a subset survives as the next frame's tracked keys
     ref.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_sizes_and_configs_equal_reference(seed):
+    rng = np.random.default_rng(900 + seed)
+    while True:   # the reference has undefined behaviour on degenerate levels (no 30-px cell fits: division by zero, :739-742; taller than
+        # 1.5 x wide: nIni = 0, :541-544) where the oracle defines a result -- keep every level a landscape of at least 90 x 70 pixels
+        w, h = int(rng.integers(120, 900)), int(rng.integers(100, 640))
+        nl = int(rng.integers(1, 10))
+        sf = float(rng.choice([1.1, 1.2, 1.2, 1.25, 1.5, 2.0]))
+        top = sf ** (nl - 1)
+        if w >= h and w / top >= 90 and h / top >= 70:
+            break
+    nf = int(rng.integers(50, 3000))
+    ini = int(rng.choice([20, 20, 12, 30]))
+    mn = int(rng.choice([7, 7, 5, 10]))
+    img = synth_frame(1000 + seed, w, h)
+    if seed % 4 == 3:
+        img = np.clip(img.astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8)     # hard contrast: dense corners, many octree ties
+    rk, rd = O.ref_extract(img, nf, sf, nl, ini, mn)
+    ok, od = O.Extractor(nf, sf, nl, ini, mn).extract(img)
+    assert_same(rk, rd, ok, od, (w, h, nf, sf, nl, ini, mn))

@@ -188,3 +188,70 @@ def test_search_by_bow_equals_reference(pair):
         assert r_n == e_n and (r_m == canon(e_m)).all(), (bits, ratio, ori, r_n, e_n)
         if bits <= 6:
             assert e_n > 20
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_projection_searches_equal_reference(seed):
+    """Random image pairs, poses, thresholds and flag combinations through the three projection searches."""
+    rng = np.random.default_rng(1200 + seed)
+    w, h = int(rng.integers(320, 800)), int(rng.integers(240, 520))
+    nf = int(rng.choice([300, 800, 1500]))
+    base = synth_frame(1300 + seed, w + 16, h + 16)
+    dx, dy = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+    a, b = base[8:8 + h, 8:8 + w], base[dy:dy + h, dx:dx + w]
+    oex = O.Extractor(nf, 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = oex.extract(a)
+    kb, db = oex.extract(b)
+    if len(ka) < 20 or len(kb) < 20:
+        pytest.skip("too few keypoints")
+    cam = dict(CAM, mb=0.11, mbf=40.0)
+    n = len(ka)
+    depth = rng.uniform(1.0, 9.0, n).astype(np.float32)
+    world = np.stack([(ka["x"] - np.float32(CAM["cx"])) / np.float32(CAM["fx"]) * depth, (ka["y"] - np.float32(CAM["cy"])) / np.float32(CAM["fy"]) * depth,
+                      depth], -1).astype(np.float32)
+    ang = np.float32(np.deg2rad(rng.uniform(-1, 1)))
+    Rcw = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tcw = rng.uniform(-0.05, 0.05, 3).astype(np.float32)
+    tcw[2] = np.float32(rng.choice([0.0, 0.4, -0.4]))
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    valid = (rng.uniform(size=n) > 0.1).astype(np.uint8)
+    outl = (rng.uniform(size=n) > 0.9).astype(np.uint8)
+    obs = (rng.uniform(size=n) > 0.3).astype(np.uint8)
+    mono = bool(rng.integers(0, 2))
+    uright = None if mono else np.where(rng.uniform(size=len(kb)) > 0.4, kb["x"] - rng.uniform(0, 30, len(kb)), -1.0).astype(np.float32)
+    owner0 = ((rng.uniform(size=len(kb)) > 0.9) * rng.integers(1, 3, len(kb))).astype(np.uint8)
+    th = float(rng.choice([3.0, 7.0, 15.0, 30.0]))
+    chk, ori = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    args = (kb, db, sf, w, h, cam, ka, world, da, Rcw, tcw, I, z, th, mono, chk, ori)
+    kw = dict(mp_valid=valid, outlier=outl, mp_has_obs=obs, u_right=uright, cur_owner=owner0)
+    e = O.search_by_projection_last(*args, **kw)
+    with O.reference_matcher():
+        r = O.search_by_projection_last(*args, **kw)
+    assert r[0] == e[0] and (r[1] == canon(e[1])).all() and (r[2] == e[2]).all(), ("last", w, h, nf, th, mono, chk, ori)
+    # F vs MapPoints
+    M = n
+    px = (ka["x"] + (8 - dx) + rng.normal(0, 1.5, M)).astype(np.float32)
+    py = (ka["y"] + (8 - dy) + rng.normal(0, 1.5, M)).astype(np.float32)
+    vc = rng.uniform(0.9, 1.0, M).astype(np.float32)
+    lvl = np.clip(ka["octave"] + rng.integers(-1, 2, M), 0, 7).astype(np.int32)
+    tiv = (rng.uniform(size=M) > 0.15).astype(np.uint8)
+    bad = (rng.uniform(size=M) > 0.95).astype(np.uint8)
+    nn = float(rng.choice([0.6, 0.8, 0.9]))
+    args = (kb, db, sf, w, h, cam, tiv, px, py, vc, lvl, da, float(rng.choice([1.0, 3.0, 5.0])), chk, nn)
+    kw = dict(is_bad=bad, mp_has_obs=obs, owner=owner0, proj_xr=(px - 6.0).astype(np.float32), u_right=uright)
+    e = O.search_by_projection_mappoints(*args, **kw)
+    with O.reference_matcher():
+        r = O.search_by_projection_mappoints(*args, **kw)
+    assert r[0] == e[0] and (r[1] == canon(e[1])).all() and (r[2] == e[2]).all(), ("mappoints", w, h, nf)
+    # Cur vs KeyFrame
+    dist = np.linalg.norm(world, axis=1).astype(np.float32)
+    mf_max = (dist * sf[ka["octave"]]).astype(np.float32)
+    mf_min = (mf_max / sf[7]).astype(np.float32)
+    args = (kb, db, sf, w, h, cam, valid, world, (np.float32(1.2) * mf_max).astype(np.float32), (np.float32(0.8) * mf_min).astype(np.float32), mf_max,
+            ka["angle"], da, Rcw, tcw, np.log(np.float32(1.2)), th, int(rng.choice([64, 100, 150])), ori)
+    own1 = (owner0 != 0).astype(np.uint8)
+    e = O.search_by_projection_kf(*args, owner=own1)
+    with O.reference_matcher():
+        r = O.search_by_projection_kf(*args, owner=own1)
+    assert r[0] == e[0] and (r[1] == canon(e[1])).all() and ((r[2] != 0) == (e[2] != 0)).all(), ("kf", w, h, nf)
