@@ -4,8 +4,11 @@
 //   ygz::Align2D                                                           src/Align.cc:8-104
 //   KeyFrame::Pixel2Camera / World2Pixel                                   include/KeyFrame.h:173-194, include/Frame.h:154-175
 // Eigen is not available: Matrix2f / Matrix3f determinant, inverse (cofactor form) and products are written out in natural order; this
-// file DEFINES that order (PARITY UNPINNED, no reference test) and the HIP path repeats it operation for operation, so the two agree
-// bit for bit.  Built with -ffp-contract=off.
+// file DEFINES that order (unpinned) and the HIP path repeats it operation for operation, so the two agree bit for bit.
+// PARITY: the control flow and every other operation are PINNED to the reference's own src/ORBmatcher.cc + src/Align.cc
+// (tests/test_ref_matcher.py::test_find_direct_projection_equals_reference: those files, compiled where they lie over oracle/ref_shim/
+// with this file's conventions for the small-matrix / pose algebra, return identical pixels, levels, flags and patches).
+// Built with -ffp-contract=off.
 #include <cmath>
 #include <cstring>
 
@@ -16,7 +19,7 @@ namespace ygzo {
 static const int WarpHalfPatchSize = 4, WarpPatchSize = 8;  // include/ORBmatcher.h:35-36
 
 // Matrix3f::inverse() (Eigen compute_inverse_size3: cofactors, det from the first column)
-static void inverse3(const float m[9], float r[9]) {
+void inverse3(const float m[9], float r[9]) {
 #define M(i, j) m[3 * (i) + (j)]
 #define COF(i, j) (M(((i) + 1) % 3, ((j) + 1) % 3) * M(((i) + 2) % 3, ((j) + 2) % 3) - M(((i) + 1) % 3, ((j) + 2) % 3) * M(((i) + 2) % 3, ((j) + 1) % 3))
     const float c00 = COF(0, 0), c10 = COF(1, 0), c20 = COF(2, 0);

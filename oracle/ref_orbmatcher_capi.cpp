@@ -12,7 +12,9 @@
 // (src/MapPoint.cc:359-373), the 3x3 float arithmetic behind Eigen / Sophus.
 #include <opencv2/core/core.hpp>   // oracle/ref_shim: mini_cv.h + matcher_stubs.h (YGZ_REF_MATCHER)
 
+#define private public             // the warped patch (_patch_with_border) is a private member of the reference class; the test reads it
 #include "ORBmatcher.h"            // the reference's own header
+#undef private
 #include "ygz_oracle.h"            // grid restatement (ygzo::Grid), struct layouts of the flat API
 
 namespace {
@@ -273,6 +275,59 @@ int yo_search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int
     const int n = matcher.SearchByBoW(&KF, F, out);
     for (int i = 0; i < nF; i++) match[i] = out[i] ? (int) (out[i] - mps.data()) : -1;
     return n;
+}
+
+// ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level)   :1573-1602, with
+// GetWarpAffineMatrix :1525-1548, WarpAffine :1550-1572, GetBestSearchLevel / GetBilateralInterpUchar (include/ORBmatcher.h:185-211) and
+// the reference's own ygz::Align2D (src/Align.cc, compiled into this library).  Pyramids come in level by level (tight 8-bit images).
+void yr_find_direct_projection_batch(int nlevels, const float *scaleFactors, const float *invLevelSigma2, const int *lw, const int *lh, int n_refs,
+                                     const uint8_t *const *ref_levels /* n_refs x nlevels */, const uint8_t *const *cur_levels /* nlevels */,
+                                     const float *cur_Tcw7, float fx, float fy, float cx, float cy, int n, const int *ref_slot, const float *ref_Tcw7,
+                                     const ygzo::KeyPoint *ref_kp, const float *mp_world, float *px_curr, int *search_level, uint8_t *success,
+                                     uint8_t *patches) {
+    auto level_mat = [&](const uint8_t *p, int l) {
+        cv::Mat m(lh[l], lw[l], CV_8U);
+        std::memcpy(m.data, p, (size_t) lw[l] * lh[l]);
+        return m;
+    };
+    auto se3 = [](const float *T7) {
+        ygzo::SE3f q;
+        std::memcpy(q.q, T7, 16);
+        std::memcpy(q.t, T7 + 4, 12);
+        return SE3f(q);
+    };
+    std::vector<ygz::KeyFrame> kfs((size_t) std::max(n_refs, 1));
+    for (int r = 0; r < n_refs; r++) {
+        ygz::KeyFrame &K = kfs[r];
+        K.fx = fx; K.fy = fy; K.cx = cx; K.cy = cy;
+        K.mvScaleFactors.assign(scaleFactors, scaleFactors + nlevels);
+        K.mvInvLevelSigma2.assign(invLevelSigma2, invLevelSigma2 + nlevels);
+        for (int l = 0; l < nlevels; l++) K.mvImagePyramid.push_back(level_mat(ref_levels[r * nlevels + l], l));
+    }
+    ygz::Frame cur;
+    cur.fx = fx; cur.fy = fy; cur.cx = cx; cur.cy = cy;
+    cur.mTcw = se3(cur_Tcw7);
+    cur.mvScaleFactors.assign(scaleFactors, scaleFactors + nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        cur.mvInvScaleFactors.push_back(1.0f / scaleFactors[l]);
+        cur.mvImagePyramid.push_back(level_mat(cur_levels[l], l));
+    }
+    ygz::ORBmatcher matcher;
+    for (int i = 0; i < n; i++) {
+        ygz::KeyFrame &K = kfs[ref_slot[i]];
+        K.mPose = se3(ref_Tcw7 + 7 * i);                       // candidates of one KeyFrame share its pose in the caller's data
+        K.mvKeys.assign(1, cv::KeyPoint(ref_kp[i].x, ref_kp[i].y, ref_kp[i].size, ref_kp[i].angle, ref_kp[i].response, ref_kp[i].octave, ref_kp[i].class_id));
+        ygz::MapPoint mp;
+        mp.mWorldPos = Vector3f(mp_world[3 * i], mp_world[3 * i + 1], mp_world[3 * i + 2]);
+        mp.mObservations[&K] = 0;
+        Vector2f px(px_curr[2 * i], px_curr[2 * i + 1]);
+        int sl = 0;
+        success[i] = matcher.FindDirectProjection(&K, &cur, &mp, px, sl) ? 1 : 0;
+        px_curr[2 * i] = px[0];
+        px_curr[2 * i + 1] = px[1];
+        search_level[i] = sl;
+        if (patches) std::memcpy(patches + 100 * (size_t) i, matcher._patch_with_border, 100);
+    }
 }
 
 }  // extern "C"

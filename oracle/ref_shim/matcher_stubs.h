@@ -13,6 +13,8 @@
 #define YGZ_CONVERTER_H_
 
 #include <cstdlib>
+
+#include "ygz_oracle.h"   // ygzo::SE3f (quaternion form, Sophus semantics), ygzo::inverse3: the oracle's conventions behind the stand-ins
 #include <nmmintrin.h>   // _mm_popcnt_u64 (ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:1515)
 
 using namespace std;   // include/Common.h:19
@@ -32,6 +34,10 @@ struct Vector2f {
     float &operator()(int i) { return v[i]; }
     float operator()(int i) const { return v[i]; }
     Vector2f &operator*=(float s) { v[0] *= s; v[1] *= s; return *this; }
+    float x() const { return v[0]; }
+    float y() const { return v[1]; }
+    struct CommaInit { Vector2f *p; CommaInit operator,(float b) { p->v[1] = b; return *this; } };
+    CommaInit operator<<(float a) { v[0] = a; return CommaInit{this}; }   // `vec << u, v;`
 };
 inline Vector2f operator+(const Vector2f &a, const Vector2f &b) { return Vector2f(a[0] + b[0], a[1] + b[1]); }
 inline Vector2f operator-(const Vector2f &a, const Vector2f &b) { return Vector2f(a[0] - b[0], a[1] - b[1]); }
@@ -48,6 +54,9 @@ struct Vector3f {
     float operator()(int i) const { return v[i]; }
     float dot(const Vector3f &o) const { return v[0] * o[0] + v[1] * o[1] + v[2] * o[2]; }
     float norm() const { return std::sqrt(dot(*this)); }
+    void setZero() { v[0] = v[1] = v[2] = 0; }
+    struct Row { const Vector3f *p; };
+    Row transpose() const { return Row{this}; }
 };
 inline Vector3f operator+(const Vector3f &a, const Vector3f &b) { return Vector3f(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
 inline Vector3f operator-(const Vector3f &a, const Vector3f &b) { return Vector3f(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
@@ -57,24 +66,38 @@ struct Matrix3f {
     Matrix3f() { for (float &x : m) x = 0; }
     float &operator()(int r, int c) { return m[3 * r + c]; }
     float operator()(int r, int c) const { return m[3 * r + c]; }
+    void setZero() { for (float &x : m) x = 0; }
+    Matrix3f &operator+=(const Matrix3f &o) { for (int i = 0; i < 9; i++) m[i] += o.m[i]; return *this; }
+    Matrix3f inverse() const { Matrix3f r; ygzo::inverse3(m, r.m); return r; }
     Matrix3f transpose() const { Matrix3f t; for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) t(r, c) = (*this)(c, r); return t; }
 };
 inline Vector3f operator*(const Matrix3f &A, const Vector3f &x) {
     return Vector3f(A(0, 0) * x[0] + A(0, 1) * x[1] + A(0, 2) * x[2], A(1, 0) * x[0] + A(1, 1) * x[1] + A(1, 2) * x[2],
                     A(2, 0) * x[0] + A(2, 1) * x[1] + A(2, 2) * x[2]);
 }
+inline Matrix3f operator*(const Vector3f &a, const Vector3f::Row &b) {   // outer product J * J^T
+    Matrix3f r;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = a[i] * (*b.p)[j];
+    return r;
+}
 inline Matrix3f operator*(float s, const Matrix3f &A) { Matrix3f r; for (int i = 0; i < 9; i++) r.m[i] = s * A.m[i]; return r; }
 inline Matrix3f operator*(int s, const Matrix3f &A) { return (float) s * A; }
 
-struct Matrix2f {   // only FindDirectProjection's warp uses it (not pinned)
-    float m[4];
+struct Matrix2f {   // FindDirectProjection's warp; determinant / inverse written as in oracle_direct.cpp (adjugate * (1 / det))
+    float m[4];   // row major
     Matrix2f() { for (float &x : m) x = 0; }
     struct ColRef { Matrix2f *M; int c; void operator=(const Vector2f &v) { M->m[c] = v[0]; M->m[2 + c] = v[1]; } };
     ColRef col(int c) { return ColRef{this, c}; }
-    Matrix2f inverse() const { yr_unsupported("Matrix2f::inverse"); }
-    float determinant() const { yr_unsupported("Matrix2f::determinant"); }
+    float determinant() const { return m[0] * m[3] - m[2] * m[1]; }
+    Matrix2f inverse() const {
+        const float det = m[0] * m[3] - m[2] * m[1];
+        const float invdet = 1.f / det;
+        Matrix2f r;
+        r.m[0] = m[3] * invdet; r.m[1] = -m[1] * invdet; r.m[2] = -m[2] * invdet; r.m[3] = m[0] * invdet;
+        return r;
+    }
 };
-inline Vector2f operator*(const Matrix2f &, const Vector2f &) { yr_unsupported("Matrix2f * Vector2f"); }
+inline Vector2f operator*(const Matrix2f &A, const Vector2f &x) { return Vector2f(A.m[0] * x[0] + A.m[1] * x[1], A.m[2] * x[0] + A.m[3] * x[1]); }
 }  // namespace Eigen
 using Eigen::Matrix2f;
 using Eigen::Matrix3f;
@@ -82,16 +105,20 @@ using Eigen::Vector2f;
 using Eigen::Vector3f;
 
 namespace Sophus {
-struct SE3f {   // rotation matrix + translation, as the matcher reads them
+// The projection searches only read rotationMatrix() / translation() (R, t are what the harness puts there); the direct projection
+// composes, inverts and applies poses: that goes through the oracle's quaternion-form SE3f (Sophus semantics, ygz_oracle.h).
+struct SE3f {
     Matrix3f R;
     Vector3f t;
+    ygzo::SE3f q;
     SE3f() { R(0, 0) = R(1, 1) = R(2, 2) = 1.f; }
+    explicit SE3f(const ygzo::SE3f &q_) : q(q_) { q.RotationMatrix(R.m); t = Vector3f(q.t[0], q.t[1], q.t[2]); }
     Matrix3f rotationMatrix() const { return R; }
     Vector3f translation() const { return t; }
-    SE3f inverse() const { yr_unsupported("SE3f::inverse"); }
+    SE3f inverse() const { return SE3f(q.Inverse()); }
 };
-inline SE3f operator*(const SE3f &, const SE3f &) { yr_unsupported("SE3f * SE3f"); }
-inline Vector3f operator*(const SE3f &T, const Vector3f &x) { return T.R * x + T.t; }
+inline SE3f operator*(const SE3f &a, const SE3f &b) { return SE3f(a.q.Mul(b.q)); }
+inline Vector3f operator*(const SE3f &T, const Vector3f &x) { Vector3f o; T.q.Act(x.v, o.v); return o; }
 }  // namespace Sophus
 using Sophus::SE3f;
 
@@ -121,7 +148,8 @@ public:
     cv::Mat GetDescriptor() { return mDescriptor; }
     bool isBad() { return mbBad; }
     int Observations() { return nObs; }
-    std::map<KeyFrame *, size_t> GetObservations() { yr_unsupported("MapPoint::GetObservations"); }
+    std::map<KeyFrame *, size_t> mObservations;
+    std::map<KeyFrame *, size_t> GetObservations() { return mObservations; }
     float GetMinDistanceInvariance() { return minDistInv; }               // src/MapPoint.cc:347-350
     float GetMaxDistanceInvariance() { return maxDistInv; }               // :352-355
     int PredictScale(const float &currentDist, KeyFrame *pKF);           // :359-373 (body in ref_orbmatcher_capi.cpp)
@@ -152,7 +180,10 @@ public:
     void *grid = nullptr;                      // ygzo::Grid + FrameView of this frame (ref_orbmatcher_capi.cpp)
 
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1, const int maxLevel = -1) const;
-    Vector2f World2Pixel(const Vector3f &, const SE3f &) { yr_unsupported("Frame::World2Pixel"); }
+    Vector2f World2Pixel(const Vector3f &p_w, const SE3f &T_c_w) const {   // include/Frame.h:146-175: Camera2Pixel(T_c_w * p_w)
+        const Vector3f p_c = T_c_w * p_w;
+        return Vector2f(fx * p_c(0) / p_c(2) + cx, fy * p_c(1) / p_c(2) + cy);
+    }
 };
 
 // include/KeyFrame.h
@@ -178,10 +209,13 @@ public:
     Matrix3f GetRotation() { yr_unsupported("KeyFrame::GetRotation"); }
     Vector3f GetTranslation() { yr_unsupported("KeyFrame::GetTranslation"); }
     Vector3f GetCameraCenter() { yr_unsupported("KeyFrame::GetCameraCenter"); }
-    SE3f GetPose() const { yr_unsupported("KeyFrame::GetPose"); }
+    SE3f mPose;
+    SE3f GetPose() const { return mPose; }
     bool IsInImage(const float &, const float &) const { yr_unsupported("KeyFrame::IsInImage"); }
     std::vector<size_t> GetFeaturesInArea(const float &, const float &, const float &) const { yr_unsupported("KeyFrame::GetFeaturesInArea"); }
-    Vector3f Pixel2Camera(const Vector2f &, float) const { yr_unsupported("KeyFrame::Pixel2Camera"); }
+    Vector3f Pixel2Camera(const Vector2f &p_p, float depth = 1) const {   // include/KeyFrame.h:181-187
+        return Vector3f((p_p(0) - cx) * depth / fx, (p_p(1) - cy) * depth / fy, depth);
+    }
 };
 
 // include/Converter.h: only the Sim3 / fuse functions use it
@@ -192,7 +226,8 @@ public:
 };
 
 // include/Align.h
-inline bool Align2D(const cv::Mat &, uint8_t *, uint8_t *, const int, Vector2f &, bool = false) { yr_unsupported("Align2D"); }
+bool Align2D(const cv::Mat &cur_img, uint8_t *ref_patch_with_border, uint8_t *ref_patch, const int n_iter, Vector2f &cur_px_estimate,
+             bool no_simd = false);   // body: the reference's own src/Align.cc
 
 }  // namespace ygz
 #endif

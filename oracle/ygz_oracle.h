@@ -245,6 +245,7 @@ struct DirectCur {
     const float *scaleFactors = nullptr, *invScaleFactors = nullptr;
     float fx = 0, fy = 0, cx = 0, cy = 0;
 };
+void inverse3(const float m[9], float r[9]);   // Matrix3f::inverse() as Eigen's compute_inverse_size3 (cofactors; oracle_direct.cpp)
 bool align2d(const Image &cur_img, const uint8_t *ref_patch_with_border, const uint8_t *ref_patch, int n_iter, float cur_px_estimate[2]);
 bool find_direct_projection(const DirectRef &ref, const DirectCur &cur, const float mp_world[3], float px_curr[2], int *search_level,
                             uint8_t *patch_with_border_out);

@@ -255,3 +255,65 @@ def test_fuzz_projection_searches_equal_reference(seed):
     with O.reference_matcher():
         r = O.search_by_projection_kf(*args, owner=own1)
     assert r[0] == e[0] and (r[1] == canon(e[1])).all() and ((r[2] != 0) == (e[2] != 0)).all(), ("kf", w, h, nf)
+
+
+def _ref_find_direct_projection_batch(oex, ref_imgs, cur_img, cur_Tcw7, cam, ref_slot, ref_Tcw7, ref_kp, mp_world, px_curr):
+    """ORBmatcher::FindDirectProjection run by the reference's own code (yr_find_direct_projection_batch); pyramids from the oracle."""
+    import ctypes as C
+    L = O.ref_matcher_lib()
+    tb = oex.tables()
+    nl = len(tb["scale"])
+    pyr_refs = [oex.pyramid(np.ascontiguousarray(r, np.uint8)) for r in ref_imgs]
+    pyr_cur = oex.pyramid(np.ascontiguousarray(cur_img, np.uint8))
+    lw = np.array([p.shape[1] for p in pyr_cur], np.int32)
+    lh = np.array([p.shape[0] for p in pyr_cur], np.int32)
+    keep = [np.ascontiguousarray(l) for p in pyr_refs for l in p] + [np.ascontiguousarray(l) for l in pyr_cur]
+    rp = (C.c_void_p * (len(pyr_refs) * nl))(*[a.ctypes.data for a in keep[:len(pyr_refs) * nl]])
+    cp = (C.c_void_p * nl)(*[a.ctypes.data for a in keep[len(pyr_refs) * nl:]])
+    sf = np.ascontiguousarray(tb["scale"], np.float32)
+    ils = np.ascontiguousarray(tb["inv_sigma2"] if "inv_sigma2" in tb else 1.0 / (tb["scale"] * tb["scale"]), np.float32)
+    ct = np.ascontiguousarray(cur_Tcw7, np.float32)
+    rs = np.ascontiguousarray(ref_slot, np.int32)
+    rt = np.ascontiguousarray(ref_Tcw7, np.float32)
+    rk = np.ascontiguousarray(ref_kp, O.KP_DTYPE)
+    mw = np.ascontiguousarray(mp_world, np.float32)
+    px = np.array(px_curr, np.float32).reshape(-1, 2).copy()
+    n = len(rs)
+    sl = np.zeros(max(n, 1), np.int32)
+    ok = np.zeros(max(n, 1), np.uint8)
+    pt = np.zeros((max(n, 1), 100), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.yr_find_direct_projection_batch.restype = None
+    L.yr_find_direct_projection_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_int] + [C.c_void_p] * 8
+    L.yr_find_direct_projection_batch(nl, p(sf), p(ils), p(lw), p(lh), len(pyr_refs), rp, cp, p(ct), cam["fx"], cam["fy"], cam["cx"], cam["cy"], n,
+                                      p(rs), p(rt), p(rk), p(mw), p(px), p(sl), p(ok), p(pt))
+    return px, sl[:n], ok[:n], pt[:n]
+
+
+def test_find_direct_projection_equals_reference():
+    """FindDirectProjection + GetWarpAffineMatrix + WarpAffine + GetBestSearchLevel + the reference's own Align2D (src/Align.cc) on a rendered
+    two-view scene: refined pixel, search level, success flag and the warped 10x10 patch, bit for bit.  (Pose algebra and the 2x2 / 3x3
+    inverses are the oracle's conventions on both sides.)"""
+    from orb_ygz_slam_amd.scene import rotvec_to_quat, two_view_scene
+    w, h = 752, 480
+    for seed, rv, tr in ((9, (0.01, -0.02, 0.03), (0.1, -0.05, 0.2)), (4, (-0.03, 0.01, -0.02), (-0.2, 0.1, -0.3))):
+        A, B, (R, t), bp = two_view_scene(seed, w, h, CAM, Z=4.0, rotvec=rv, trans=tr)
+        oex = O.Extractor(1000, 1.2, 8, 20, 7)
+        ka, _ = oex.extract(A)
+        world = bp(ka["x"], ka["y"])
+        q = rotvec_to_quat(rv)
+        cur7 = np.array([q[0], q[1], q[2], q[3], *tr], np.float32)
+        ref7 = np.tile(np.array([0, 0, 0, 1, 0, 0, 0], np.float32), (len(ka), 1))
+        Xc = (R @ world.T.astype(np.float64)).T + t
+        u = CAM["fx"] * Xc[:, 0] / Xc[:, 2] + CAM["cx"]
+        v = CAM["fy"] * Xc[:, 1] / Xc[:, 2] + CAM["cy"]
+        rng = np.random.default_rng(seed)
+        px0 = np.stack([u, v], -1) + rng.uniform(-2.5, 2.5, (len(ka), 2))
+        px0[::17] += 400.0                                  # candidates that leave the image: Align2D breaks out, success = false
+        slot = np.zeros(len(ka), np.int32)
+        e_px, e_sl, e_ok, e_pt = oex.find_direct_projection_batch([A], B, cur7, CAM, slot, ref7, ka, world, px0)
+        r_px, r_sl, r_ok, r_pt = _ref_find_direct_projection_batch(oex, [A], B, cur7, CAM, slot, ref7, ka, world, px0)
+        assert (r_sl == e_sl).all() and (r_ok == e_ok).all() and (r_pt == e_pt).all()
+        assert (r_px.view(np.uint32) == e_px.view(np.uint32)).all()
+        assert e_ok.sum() > 0.5 * len(ka) and (e_ok == 0).sum() > 10
