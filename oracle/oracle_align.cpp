@@ -4,7 +4,11 @@
 // (Thirdparty/sophus/sophus/se3.hpp:159-171,267-271,406-428, so3.hpp:234-237,268-276,425-456).
 // Eigen is not available: small fixed-size products are written out in natural (row, left-to-right) order and
 // H.ldlt().solve(b) is a pivoted LDL^T in float.  fp32 throughout; the HIP path is graded at 1e-5 on the SE3
-// output, not bit-exact.  PARITY UNPINNED (no reference test).  Built with -ffp-contract=off.
+// output, not bit-exact.  Built with -ffp-contract=off.
+// PARITY: the aligner's own logic (driver, level loop, caches, residual loop, stop / rollback rules) is PINNED to the reference's
+// src/SparseImageAlign.cc + NLSSolver (tests/test_ref_matcher.py::test_sparse_img_align_equals_reference: compiled where they lie over
+// oracle/ref_shim/, they return the same SE3 bit pattern, count, chi2 and Hessian); the Sophus / Eigen restatements in this file
+// (quaternion algebra, exp, LDL^T, product order) are what that build uses too, and stay unpinned.
 #include <cmath>
 #include <cstring>
 
@@ -134,7 +138,7 @@ SE3f SE3f::FromRt(const float R[9], const float t_[3]) {  // Eigen Quaternion(Ma
 }
 
 // x = H.ldlt().solve(b): LDL^T with diagonal pivoting (Eigen's LDLT picks the largest |diagonal|), float.
-static bool ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+bool ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
     float A[36];
     float b[6];
     int perm[6];

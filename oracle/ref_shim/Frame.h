@@ -3,6 +3,7 @@
 #ifndef YGZ_ORACLE_REF_SHIM_FRAME_H
 #define YGZ_ORACLE_REF_SHIM_FRAME_H
 #include "mini_cv.h"
+#ifndef YGZ_REF_MATCHER   // the matcher / aligner builds get their Frame from matcher_stubs.h
 namespace ygz {
 class Frame {
 public:
@@ -12,4 +13,5 @@ public:
     int N = 0;                               // their number
 };
 }  // namespace ygz
+#endif
 #endif

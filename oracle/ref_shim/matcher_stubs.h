@@ -116,6 +116,7 @@ struct SE3f {
     Matrix3f rotationMatrix() const { return R; }
     Vector3f translation() const { return t; }
     SE3f inverse() const { return SE3f(q.Inverse()); }
+    template <class V> static SE3f exp(const V &a) { float v[6]; for (int i = 0; i < 6; i++) v[i] = a[i]; return SE3f(ygzo::SE3f::Exp(v)); }
 };
 inline SE3f operator*(const SE3f &a, const SE3f &b) { return SE3f(a.q.Mul(b.q)); }
 inline Vector3f operator*(const SE3f &T, const Vector3f &x) { Vector3f o; T.q.Act(x.v, o.v); return o; }
@@ -180,6 +181,7 @@ public:
     void *grid = nullptr;                      // ygzo::Grid + FrameView of this frame (ref_orbmatcher_capi.cpp)
 
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1, const int maxLevel = -1) const;
+    Vector2f Camera2Pixel(const Vector3f &p_c) const { return Vector2f(fx * p_c(0) / p_c(2) + cx, fy * p_c(1) / p_c(2) + cy); }   // include/Frame.h:154-159
     Vector2f World2Pixel(const Vector3f &p_w, const SE3f &T_c_w) const {   // include/Frame.h:146-175: Camera2Pixel(T_c_w * p_w)
         const Vector3f p_c = T_c_w * p_w;
         return Vector2f(fx * p_c(0) / p_c(2) + cx, fy * p_c(1) / p_c(2) + cy);

@@ -37,6 +37,7 @@ typedef unsigned char uchar;
 
 #define CV_8U 0
 #define CV_8UC1 0
+#define CV_32F 5
 #define CV_PI 3.1415926535897932384626433832795
 #define CV_Assert(x) assert(x)
 
@@ -110,11 +111,15 @@ public:
     Mat() : rows(0), cols(0), data(nullptr) {}
     Mat(int r, int c, int type) : rows(0), cols(0), data(nullptr) { create(r, c, type); }
     Mat(Size s, int type) : rows(0), cols(0), data(nullptr) { create(s.height, s.width, type); }
-    void create(int r, int c, int /*type*/) {
-        if (data && rows == r && cols == c) return;   // as cv::Mat::create: same size and type -> nothing happens
-        buf = std::make_shared<std::vector<uchar>>((size_t) r * c + 64);
-        rows = r; cols = c; data = buf->data(); step.p[0] = (size_t) c; step.p[1] = 1;
+    template <class S> Mat(Size s, int type, const S &) : rows(0), cols(0), data(nullptr) { create(s.height, s.width, type); }   // (size, type, Scalar(0)): residual display image
+    void create(int r, int c, int type) {
+        const size_t es = type == CV_32F ? 4 : 1;     // 8-bit everywhere except the aligner's float patch cache
+        if (data && rows == r && cols == c && elem == es) return;   // as cv::Mat::create: same size and type -> nothing happens
+        buf = std::make_shared<std::vector<uchar>>((size_t) r * c * es + 64);
+        rows = r; cols = c; elem = es; data = buf->data(); step.p[0] = (size_t) c * es; step.p[1] = es;
     }
+    size_t elem = 1;
+    Size size() const { return Size(cols, rows); }
     static MatZerosExpr zeros(int r, int c, int /*type*/) { return MatZerosExpr{r, c}; }
     Mat(const MatZerosExpr &e) : rows(0), cols(0), data(nullptr) { *this = e; }
     Mat &operator=(const MatZerosExpr &e) {
@@ -196,5 +201,6 @@ struct KeyPointsFilter {
 using cv::Mat;   // include/Common.h:64
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 #include "matcher_stubs.h"
+#include "sia_stubs.h"
 #endif
 #endif

@@ -8,10 +8,11 @@
 // plus restatements of the OpenCV 2.4.11/3.2 primitives the reference calls (resize INTER_LINEAR, FAST,
 // GaussianBlur, fastAtan2, cvRound), which are NOT under /root/reference.
 //
-// PARITY STATUS: "parity unpinned" for the OpenCV primitives (oracle_cvprims.cpp) and for the matcher / aligner / stereo / direct
-// restatements (the reference ships no test or golden vector for them, OpenCV is neither vendored nor version-pinned, and those sources
+// PARITY STATUS: "parity unpinned" for the OpenCV primitives (oracle_cvprims.cpp), the Eigen / Sophus algebra and the Frame-grid /
+// stereo / frustum / distinctive-descriptor restatements (the reference ships no test or golden vector for them, OpenCV is neither vendored nor version-pinned, and those sources
 // need Eigen / Sophus / the whole Frame-MapPoint graph).  PINNED: the extractor (oracle_extractor.cpp) against the
-// reference's own src/ORBextractor.cc and the matcher's search functions against its src/ORBmatcher.cc, both compiled where they lie
+// reference's own src/ORBextractor.cc, the matcher's search functions and the direct projection against its src/ORBmatcher.cc +
+// src/Align.cc, the sparse image aligner against its src/SparseImageAlign.cc + NLSSolver, all compiled where they lie
 // over oracle/ref_shim/ (tests/test_ref_extractor.py, tests/test_ref_matcher.py), and FAST-10 against
 // the reference's own libfast incl. Thirdparty/fast's 167-corner KAT (tests/test_oracle_fast10.py); both live in oracle/_ref.
 //
@@ -225,6 +226,7 @@ struct AlignResult {
     float chi2 = 0;
     float H[36];
 };
+bool ldlt_solve6(const float H[36], const float b[6], float x[6]);   // x = H.ldlt().solve(b): pivoted LDL^T in float (oracle_align.cpp)
 // SparseImgAlign(max_level, min_level, n_iter=10, GaussNewton).run(ref, cur, TCR)  src/SparseImageAlign.cc:20-49
 AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level,
                              int n_iter);

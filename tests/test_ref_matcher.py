@@ -317,3 +317,37 @@ def test_find_direct_projection_equals_reference():
         assert (r_sl == e_sl).all() and (r_ok == e_ok).all() and (r_pt == e_pt).all()
         assert (r_px.view(np.uint32) == e_px.view(np.uint32)).all()
         assert e_ok.sum() > 0.5 * len(ka) and (e_ok == 0).sum() > 10
+
+
+def test_sparse_img_align_equals_reference():
+    """SparseImgAlign(max_level, min_level, n_iter).run(ref, cur, TCR): the reference's own src/SparseImageAlign.cc + NLSSolver (Gauss-Newton
+    driver, level loop, caches, visibility, stop / rollback rules) against the oracle -- resulting SE3 (bit pattern), return value,
+    number of linearisations, final chi2 and Hessian.  max_level <= 5: the reference indexes `int iterations[6]` with the level; n_iter = 10:
+    run() overwrites the constructor's n_iter with iterations[level] = 10 on every level (src/SparseImageAlign.cc:39-44), the oracle's n_iter
+    parameter generalises that."""
+    from orb_ygz_slam_amd.scene import two_view_scene
+    w, h = 752, 480
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    cases = [(21, (0.004, -0.006, 0.003), (0.02, -0.01, 0.03), 5, 1, 10), (22, (-0.01, 0.004, 0.0), (-0.03, 0.02, 0.01), 4, 0, 10),
+             (23, (0.002, 0.002, -0.008), (0.0, 0.0, 0.05), 5, 2, 10), (24, (0.03, -0.02, 0.01), (0.3, -0.2, 0.4), 5, 1, 10)]   # last: too far -> rollbacks
+    for seed, rv, tr, max_level, min_level, n_iter in cases:
+        A, B, _, bp = two_view_scene(seed, w, h, CAM, Z=3.0, rotvec=rv, trans=tr)
+        oex = O.Extractor(600, 1.2, 8, 20, 7)
+        k, _ = oex.extract(A)
+        world = bp(k["x"], k["y"])
+        pa, pb = oex.pyramid(A), oex.pyramid(B)
+        inv = oex.tables()["inv_scale"]
+        rng = np.random.default_rng(seed)
+        valid = (rng.uniform(size=len(k)) > 0.1).astype(np.uint8)
+        outl = (rng.uniform(size=len(k)) > 0.95).astype(np.uint8)
+        args = (k, world, ident, pa, ident, pb, inv, CAM, max_level, min_level, n_iter)
+        e_ret, e_T, e_info, e_H = O.sparse_img_align(*args, mp_valid=valid, outlier=outl)
+        with O.reference_matcher():
+            r_ret, r_T, r_info, r_H = O.sparse_img_align(*args, mp_valid=valid, outlier=outl)
+        assert r_ret == e_ret and r_info[0] == e_info[0], (seed, r_ret, e_ret, r_info, e_info)
+        assert (r_T.view(np.uint32) == e_T.view(np.uint32)).all(), (seed, r_T, e_T)
+        assert r_info[1] == e_info[1] and (r_H == e_H).all()
+        assert e_ret > 100
+    # no features: "SparseImgAlign: no features to track!" -> 0
+    with O.reference_matcher():
+        assert O.sparse_img_align(k[:0], world[:0], ident, pa, ident, pb, inv, CAM, 5, 1)[0] == 0
