@@ -3,8 +3,9 @@
 // MapPoint / Frame objects are replaced by the plain arrays the functions actually read (see ygz_oracle.h).
 // Built with -ffp-contract=off: float expressions are evaluated in source order without FMA.
 // PARITY: the five search functions, DescriptorDistance and ComputeThreeMaxima are PINNED to the reference's own src/ORBmatcher.cc
-// (tests/test_ref_matcher.py runs that file, compiled where it lies over oracle/ref_shim/, on identical inputs); the Frame grid,
-// isInFrustum, PredictScale and ComputeDistinctiveDescriptors restatements remain unpinned (the reference ships no test for them).
+// (tests/test_ref_matcher.py runs that file, compiled where it lies over oracle/ref_shim/, on identical inputs); PredictScale and
+// ComputeDistinctiveDescriptors to its src/MapPoint.cc (tests/test_ref_mappoint.py); the Frame grid and isInFrustum (src/Frame.cc)
+// remain unpinned.
 #include <climits>
 #include <algorithm>
 #include <cmath>

@@ -41,6 +41,27 @@ def ref_matcher_lib():
     return C.CDLL(p) if os.path.exists(p) else None
 
 
+def ref_mappoint_lib():
+    """The reference's own src/MapPoint.cc (oracle/_ref/libref_mappoint.so) behind yo_distinctive_descriptors / yo_predict_scale, or None."""
+    build()
+    p = os.path.join(_HERE, "_ref", "libref_mappoint.so")
+    return C.CDLL(p) if os.path.exists(p) else None
+
+
+class reference_mappoint:
+    """with reference_mappoint(): distinctive_descriptors() and predict_scale() run the reference's MapPoint code."""
+
+    def __enter__(self):
+        global _lib_override
+        _lib_override = ref_mappoint_lib()
+        assert _lib_override is not None, "oracle/_ref/libref_mappoint.so not built"
+        return self
+
+    def __exit__(self, *a):
+        global _lib_override
+        _lib_override = None
+
+
 class reference_matcher:
     """with reference_matcher(): the matcher wrappers of this module (search_by_projection_*, search_for_initialization, search_by_bow)
     run the REFERENCE's code instead of the oracle's restatement -- same flat inputs, same outputs (a slot that was matched and then

@@ -8,7 +8,10 @@
 
 #define YGZ_FRAME_H_
 #define YGZ_KEYFRAME_H_
+#ifndef YGZ_REF_MAPPOINT   // the MapPoint build (tests the reference's own src/MapPoint.cc) keeps the real include/MapPoint.h
 #define YGZ_MAPPOINT_H
+#endif
+#define YGZ_MAP_H_
 #define YGZ_ALIGN_H_
 #define YGZ_CONVERTER_H_
 
@@ -55,11 +58,14 @@ struct Vector3f {
     float dot(const Vector3f &o) const { return v[0] * o[0] + v[1] * o[1] + v[2] * o[2]; }
     float norm() const { return std::sqrt(dot(*this)); }
     void setZero() { v[0] = v[1] = v[2] = 0; }
+    void normalize() { const float n = norm(); v[0] /= n; v[1] /= n; v[2] /= n; }   // Eigen: *this /= norm()
     struct Row { const Vector3f *p; };
     Row transpose() const { return Row{this}; }
 };
 inline Vector3f operator+(const Vector3f &a, const Vector3f &b) { return Vector3f(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
 inline Vector3f operator-(const Vector3f &a, const Vector3f &b) { return Vector3f(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline Vector3f operator*(const Vector3f &a, float s) { return Vector3f(a[0] * s, a[1] * s, a[2] * s); }
+inline Vector3f operator/(const Vector3f &a, float s) { return Vector3f(a[0] / s, a[1] / s, a[2] / s); }
 
 struct Matrix3f {
     float m[9];   // row major
@@ -128,6 +134,7 @@ namespace ygz {
 class Frame;
 class KeyFrame;
 
+#ifndef YGZ_REF_MAPPOINT
 // include/MapPoint.h, src/MapPoint.cc: the fields / accessors the matcher touches
 class MapPoint {
 public:
@@ -161,6 +168,10 @@ public:
     void AddObservation(KeyFrame *, size_t) { yr_unsupported("MapPoint::AddObservation"); }
 };
 
+#else
+class MapPoint;
+#endif
+
 // include/Frame.h: data members the matcher reads + GetFeaturesInArea (src/Frame.cc:424-481, body = the oracle's restatement)
 class Frame {
 public:
@@ -179,6 +190,9 @@ public:
     std::vector<cv::Mat> mvImagePyramid;
     DBoW2::FeatureVector mFeatVec;
     void *grid = nullptr;                      // ygzo::Grid + FrameView of this frame (ref_orbmatcher_capi.cpp)
+    long unsigned int mnId = 0;
+    Vector3f mOw;
+    Vector3f GetCameraCenter() { return mOw; }
 
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1, const int maxLevel = -1) const;
     Vector2f Camera2Pixel(const Vector3f &p_c) const { return Vector2f(fx * p_c(0) / p_c(2) + cx, fy * p_c(1) / p_c(2) + cy); }   // include/Frame.h:154-159
@@ -210,7 +224,14 @@ public:
     void AddMapPoint(MapPoint *, const size_t &) { yr_unsupported("KeyFrame::AddMapPoint"); }
     Matrix3f GetRotation() { yr_unsupported("KeyFrame::GetRotation"); }
     Vector3f GetTranslation() { yr_unsupported("KeyFrame::GetTranslation"); }
-    Vector3f GetCameraCenter() { yr_unsupported("KeyFrame::GetCameraCenter"); }
+    Vector3f mOw;
+    Vector3f GetCameraCenter() { return mOw; }
+    long unsigned int mnFrameId = 0;
+    bool mbBad = false;
+    bool isBad() { return mbBad; }
+    void EraseMapPointMatch(MapPoint *) {}
+    void EraseMapPointMatch(const size_t &) {}
+    void ReplaceMapPointMatch(const size_t &, MapPoint *) {}
     SE3f mPose;
     SE3f GetPose() const { return mPose; }
     bool IsInImage(const float &, const float &) const { yr_unsupported("KeyFrame::IsInImage"); }
@@ -218,6 +239,13 @@ public:
     Vector3f Pixel2Camera(const Vector2f &p_p, float depth = 1) const {   // include/KeyFrame.h:181-187
         return Vector3f((p_p(0) - cx) * depth / fx, (p_p(1) - cy) * depth / fy, depth);
     }
+};
+
+// include/Map.h: what src/MapPoint.cc touches
+class Map {
+public:
+    std::mutex mMutexPointCreation;
+    void EraseMapPoint(MapPoint *) {}
 };
 
 // include/Converter.h: only the Sim3 / fuse functions use it

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -140,6 +141,7 @@ public:
     Mat colRange(int a, int b) const { Mat m = *this; m.data = data + a; m.cols = b - a; return m; }
     Mat operator()(const Rect &r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
     Mat row(int y) const { return rowRange(y, y + 1); }
+    void copyTo(Mat &dst) const { dst = clone(); }
     // float-matrix algebra (Sim3 / fuse functions of the matcher): declared so that those functions compile, never executed
     Mat col(int) const { mini_cv_unsupported("Mat::col"); }
     Mat t() const { mini_cv_unsupported("Mat::t"); }
