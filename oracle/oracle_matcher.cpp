@@ -4,8 +4,8 @@
 // Built with -ffp-contract=off: float expressions are evaluated in source order without FMA.
 // PARITY: the five search functions, DescriptorDistance and ComputeThreeMaxima are PINNED to the reference's own src/ORBmatcher.cc
 // (tests/test_ref_matcher.py runs that file, compiled where it lies over oracle/ref_shim/, on identical inputs); PredictScale and
-// ComputeDistinctiveDescriptors to its src/MapPoint.cc (tests/test_ref_mappoint.py); the Frame grid and isInFrustum (src/Frame.cc)
-// remain unpinned.
+// ComputeDistinctiveDescriptors to its src/MapPoint.cc (tests/test_ref_mappoint.py); the Frame grid and isInFrustum to its src/Frame.cc
+// (tests/test_ref_frame.py).
 #include <climits>
 #include <algorithm>
 #include <cmath>

@@ -62,6 +62,27 @@ class reference_mappoint:
         _lib_override = None
 
 
+def ref_frame_lib():
+    """The reference's own src/Frame.cc (oracle/_ref/libref_frame.so) behind yo_features_in_area / yo_is_in_frustum / yo_compute_stereo_matches."""
+    build()
+    p = os.path.join(_HERE, "_ref", "libref_frame.so")
+    return C.CDLL(p) if os.path.exists(p) else None
+
+
+class reference_frame:
+    """with reference_frame(): features_in_area() and is_in_frustum() run the reference's Frame code."""
+
+    def __enter__(self):
+        global _lib_override
+        _lib_override = ref_frame_lib()
+        assert _lib_override is not None, "oracle/_ref/libref_frame.so not built"
+        return self
+
+    def __exit__(self, *a):
+        global _lib_override
+        _lib_override = None
+
+
 class reference_matcher:
     """with reference_matcher(): the matcher wrappers of this module (search_by_projection_*, search_for_initialization, search_by_bow)
     run the REFERENCE's code instead of the oracle's restatement -- same flat inputs, same outputs (a slot that was matched and then

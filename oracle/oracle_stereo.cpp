@@ -1,5 +1,5 @@
 // oracle_stereo.cpp -- CPU ORACLE (test infrastructure): restatement of ygz::Frame::ComputeStereoMatches,
-// reference src/Frame.cc:509-682.  PARITY UNPINNED (see ygz_oracle.h): the reference has no test for this path; cv::Mat::convertTo /
+// reference src/Frame.cc:509-682.  PARITY: PINNED to the reference's own src/Frame.cc (tests/test_ref_frame.py: real Frame.h, compiled where it lies); cv::Mat::convertTo /
 // cv::norm(NORM_L1) on the 11x11 patches are exact integer arithmetic in float, restated as such.
 #include <algorithm>
 #include <climits>

@@ -14,4 +14,7 @@ public:
 };
 }  // namespace ygz
 #endif
+#ifdef YGZ_REF_FRAME     // src/ORBextractor.cc says #include "Frame.h" and finds this file first: hand over to the real header
+#include_next "Frame.h"
+#endif
 #endif

@@ -1,0 +1,10 @@
+// oracle/ref_shim/.../BowVector.h -- TEST INFRASTRUCTURE: DBoW2::BowVector is a std::map<WordId, WordValue> (Thirdparty/DBoW2/DBoW2/BowVector.h)
+#ifndef YGZ_ORACLE_REF_SHIM_BOWVECTOR_H
+#define YGZ_ORACLE_REF_SHIM_BOWVECTOR_H
+#include <map>
+namespace DBoW2 {
+typedef unsigned int WordId;
+typedef double WordValue;
+class BowVector : public std::map<WordId, WordValue> {};
+}  // namespace DBoW2
+#endif

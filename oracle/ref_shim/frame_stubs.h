@@ -1,0 +1,70 @@
+// oracle/ref_shim/frame_stubs.h -- TEST INFRASTRUCTURE (YGZ_REF_FRAME build): what the REAL include/Frame.h and src/Frame.cc need beyond
+// matcher_stubs.h -- IMU types, double-precision pose types, the vocabulary -- as declarations with aborting bodies: those code paths
+// (IMU integration, constructors, BoW, undistortion) are compiled, never executed; the pinned functions are AssignFeaturesToGrid / PosInGrid /
+// GetFeaturesInArea, isInFrustum and ComputeStereoMatches.
+#ifndef YGZ_ORACLE_REF_SHIM_FRAME_STUBS_H
+#define YGZ_ORACLE_REF_SHIM_FRAME_STUBS_H
+#include "mini_cv.h"
+
+namespace Eigen {
+struct Vector3d {
+    double v[3];
+    Vector3d() { v[0] = v[1] = v[2] = 0; }
+    static Vector3d Zero() { return Vector3d(); }
+};
+inline Vector3d operator+(const Vector3d &, const Vector3d &) { yr_unsupported("Vector3d +"); }
+inline Vector3d operator-(const Vector3d &, const Vector3d &) { yr_unsupported("Vector3d -"); }
+inline Vector3d operator-(const Vector3d &) { yr_unsupported("-Vector3d"); }
+}  // namespace Eigen
+using Eigen::Vector3d;
+using namespace Eigen;   // the IMU headers do that for the real include/Frame.h (Matrix<double, 15, 15> mMargCovInv)
+
+namespace Sophus {
+struct SO3d {
+    SO3d inverse() const { yr_unsupported("SO3d::inverse"); }
+};
+inline SO3d operator*(const SO3d &, const SO3d &) { yr_unsupported("SO3d * SO3d"); }
+inline Vector3d operator*(const SO3d &, const Vector3d &) { yr_unsupported("SO3d * v"); }
+struct SE3d {
+    SO3d r; Vector3d p;
+    SE3d() {}
+    SE3d(const SO3d &, const Vector3d &) {}
+    const SO3d &so3() const { return r; }
+    const Vector3d &translation() const { return p; }
+    template <class T> SE3f cast() const { yr_unsupported("SE3d::cast"); }
+};
+}  // namespace Sophus
+using Sophus::SE3d;
+using Sophus::SO3d;
+
+namespace ygz {
+struct IMUData { double _t = 0; Vector3d _g, _a; };
+class NavState {
+public:
+    Vector3d Get_BiasGyr() const { yr_unsupported("NavState"); }
+    Vector3d Get_BiasAcc() const { yr_unsupported("NavState"); }
+    Vector3d Get_dBias_Gyr() const { yr_unsupported("NavState"); }
+    Vector3d Get_dBias_Acc() const { yr_unsupported("NavState"); }
+    void Set_BiasGyr(const Vector3d &) {}
+    void Set_BiasAcc(const Vector3d &) {}
+    void Set_DeltaBiasGyr(const Vector3d &) {}
+    void Set_DeltaBiasAcc(const Vector3d &) {}
+    SO3d Get_R() const { yr_unsupported("NavState"); }
+    Vector3d Get_P() const { yr_unsupported("NavState"); }
+    Vector3d Get_V() const { yr_unsupported("NavState"); }
+    void Set_Pos(const Vector3d &) {}
+    void Set_Vel(const Vector3d &) {}
+    void Set_Rot(const SO3d &) {}
+};
+class IMUPreintegrator {
+public:
+    void reset() {}
+    void update(const Vector3d &, const Vector3d &, double) {}
+};
+// include/ORBVocabulary.h: DBoW2::TemplatedVocabulary<...>; Frame::ComputeBoW calls transform()
+class ORBVocabulary {
+public:
+    template <class D> void transform(const D &, DBoW2::BowVector &, DBoW2::FeatureVector &, int) const { yr_unsupported("ORBVocabulary::transform"); }
+};
+}  // namespace ygz
+#endif

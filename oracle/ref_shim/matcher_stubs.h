@@ -6,7 +6,10 @@
 #ifndef YGZ_ORACLE_REF_SHIM_MATCHER_STUBS_H
 #define YGZ_ORACLE_REF_SHIM_MATCHER_STUBS_H
 
+#ifndef YGZ_REF_FRAME      // the Frame build (tests the reference's own src/Frame.cc) keeps the real include/Frame.h
 #define YGZ_FRAME_H_
+#endif
+#define YGZ_ORBVOCABULARY_H_
 #define YGZ_KEYFRAME_H_
 #ifndef YGZ_REF_MAPPOINT   // the MapPoint build (tests the reference's own src/MapPoint.cc) keeps the real include/MapPoint.h
 #define YGZ_MAPPOINT_H
@@ -39,6 +42,7 @@ struct Vector2f {
     Vector2f &operator*=(float s) { v[0] *= s; v[1] *= s; return *this; }
     float x() const { return v[0]; }
     float y() const { return v[1]; }
+    float operator()(int i, int) const { return v[i]; }
     struct CommaInit { Vector2f *p; CommaInit operator,(float b) { p->v[1] = b; return *this; } };
     CommaInit operator<<(float a) { v[0] = a; return CommaInit{this}; }   // `vec << u, v;`
 };
@@ -57,6 +61,7 @@ struct Vector3f {
     float operator()(int i) const { return v[i]; }
     float dot(const Vector3f &o) const { return v[0] * o[0] + v[1] * o[1] + v[2] * o[2]; }
     float norm() const { return std::sqrt(dot(*this)); }
+    float operator()(int i, int) const { return v[i]; }
     void setZero() { v[0] = v[1] = v[2] = 0; }
     void normalize() { const float n = norm(); v[0] /= n; v[1] /= n; v[2] /= n; }   // Eigen: *this /= norm()
     struct Row { const Vector3f *p; };
@@ -64,6 +69,7 @@ struct Vector3f {
 };
 inline Vector3f operator+(const Vector3f &a, const Vector3f &b) { return Vector3f(a[0] + b[0], a[1] + b[1], a[2] + b[2]); }
 inline Vector3f operator-(const Vector3f &a, const Vector3f &b) { return Vector3f(a[0] - b[0], a[1] - b[1], a[2] - b[2]); }
+inline Vector3f operator-(const Vector3f &a) { return Vector3f(-a[0], -a[1], -a[2]); }
 inline Vector3f operator*(const Vector3f &a, float s) { return Vector3f(a[0] * s, a[1] * s, a[2] * s); }
 inline Vector3f operator/(const Vector3f &a, float s) { return Vector3f(a[0] / s, a[1] / s, a[2] / s); }
 
@@ -72,6 +78,7 @@ struct Matrix3f {
     Matrix3f() { for (float &x : m) x = 0; }
     float &operator()(int r, int c) { return m[3 * r + c]; }
     float operator()(int r, int c) const { return m[3 * r + c]; }
+    static Matrix3f Zero() { return Matrix3f(); }
     void setZero() { for (float &x : m) x = 0; }
     Matrix3f &operator+=(const Matrix3f &o) { for (int i = 0; i < 9; i++) m[i] += o.m[i]; return *this; }
     Matrix3f inverse() const { Matrix3f r; ygzo::inverse3(m, r.m); return r; }
@@ -172,6 +179,7 @@ public:
 class MapPoint;
 #endif
 
+#ifndef YGZ_REF_FRAME
 // include/Frame.h: data members the matcher reads + GetFeaturesInArea (src/Frame.cc:424-481, body = the oracle's restatement)
 class Frame {
 public:
@@ -201,6 +209,8 @@ public:
         return Vector2f(fx * p_c(0) / p_c(2) + cx, fy * p_c(1) / p_c(2) + cy);
     }
 };
+
+#endif
 
 // include/KeyFrame.h
 class KeyFrame {
@@ -253,6 +263,8 @@ class Converter {
 public:
     static cv::Mat toCvMat(const Vector3f &) { yr_unsupported("Converter::toCvMat"); }
     static cv::Mat toCvMat(const Matrix3f &) { yr_unsupported("Converter::toCvMat"); }
+    template <class A, class B, class C> static void updateNS(A &, const B &, const C &) { yr_unsupported("Converter::updateNS"); }
+    static std::vector<cv::Mat> toDescriptorVector(const cv::Mat &) { yr_unsupported("Converter::toDescriptorVector"); }
 };
 
 // include/Align.h

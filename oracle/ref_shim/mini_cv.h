@@ -133,8 +133,8 @@ public:
     int type() const { return CV_8UC1; }
     size_t step1() const { return step.p[0]; }
     Mat clone() const {
-        Mat m(rows, cols, CV_8UC1);
-        for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t) y * m.cols, data + (size_t) y * step.p[0], (size_t) cols);
+        Mat m(rows, cols, elem == 4 ? CV_32F : CV_8UC1);
+        for (int y = 0; y < rows; y++) std::memcpy(m.data + (size_t) y * m.step.p[0], data + (size_t) y * step.p[0], (size_t) cols * elem);
         return m;
     }
     Mat rowRange(int a, int b) const { Mat m = *this; m.data = data + (size_t) a * step.p[0]; m.rows = b - a; return m; }
@@ -142,14 +142,22 @@ public:
     Mat operator()(const Rect &r) const { return rowRange(r.y, r.y + r.height).colRange(r.x, r.x + r.width); }
     Mat row(int y) const { return rowRange(y, y + 1); }
     void copyTo(Mat &dst) const { dst = clone(); }
+    // 8-bit -> float conversion (Frame::ComputeStereoMatches converts its 11 x 11 windows); a new buffer, as OpenCV allocates for a new type
+    void convertTo(Mat &dst, int type) const {
+        assert(type == CV_32F && elem == 1);
+        Mat o(rows, cols, CV_32F);
+        for (int y = 0; y < rows; y++) for (int x = 0; x < cols; x++) o.at<float>(y, x) = (float) at<uchar>(y, x);
+        dst = o;
+    }
+    static Mat ones(int r, int c, int type) { assert(type == CV_32F); Mat o(r, c, CV_32F); for (int y = 0; y < r; y++) for (int x = 0; x < c; x++) o.at<float>(y, x) = 1.f; return o; }
     // float-matrix algebra (Sim3 / fuse functions of the matcher): declared so that those functions compile, never executed
     Mat col(int) const { mini_cv_unsupported("Mat::col"); }
     Mat t() const { mini_cv_unsupported("Mat::t"); }
     double dot(const Mat &) const { mini_cv_unsupported("Mat::dot"); }
     template <class T> T &at(int) { mini_cv_unsupported("Mat::at(int)"); }
     template <class T> const T &at(int) const { mini_cv_unsupported("Mat::at(int)"); }
-    template <class T> T &at(int y, int x) { return *(T *) (data + (size_t) y * step.p[0] + x); }
-    template <class T> const T &at(int y, int x) const { return *(const T *) (data + (size_t) y * step.p[0] + x); }
+    template <class T> T &at(int y, int x) { return *(T *) (data + (size_t) y * step.p[0] + (size_t) x * sizeof(T)); }
+    template <class T> const T &at(int y, int x) const { return *(const T *) (data + (size_t) y * step.p[0] + (size_t) x * sizeof(T)); }
     template <class T> T *ptr(int y = 0) { return (T *) (data + (size_t) y * step.p[0]); }
     template <class T> const T *ptr(int y = 0) const { return (const T *) (data + (size_t) y * step.p[0]); }
     uchar *ptr(int y = 0) { return data + (size_t) y * step.p[0]; }
@@ -178,11 +186,32 @@ typedef const _OutputArray &OutputArray;
 
 inline Mat operator/(const Mat &, double) { mini_cv_unsupported("Mat / s"); }
 inline Mat operator*(const Mat &, const Mat &) { mini_cv_unsupported("Mat * Mat"); }
-inline Mat operator*(double, const Mat &) { mini_cv_unsupported("s * Mat"); }
+inline Mat operator*(double s, const Mat &a) {   // float matrices only (the stereo windows)
+    assert(a.elem == 4);
+    Mat o(a.rows, a.cols, CV_32F);
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) o.at<float>(y, x) = (float) (s * a.at<float>(y, x));
+    return o;
+}
 inline Mat operator+(const Mat &, const Mat &) { mini_cv_unsupported("Mat + Mat"); }
-inline Mat operator-(const Mat &, const Mat &) { mini_cv_unsupported("Mat - Mat"); }
+inline Mat operator-(const Mat &a, const Mat &b) {
+    assert(a.elem == 4 && b.elem == 4 && a.rows == b.rows && a.cols == b.cols);
+    Mat o(a.rows, a.cols, CV_32F);
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) o.at<float>(y, x) = a.at<float>(y, x) - b.at<float>(y, x);
+    return o;
+}
 inline Mat operator-(const Mat &) { mini_cv_unsupported("-Mat"); }
 inline double norm(const Mat &) { mini_cv_unsupported("cv::norm"); }
+enum { NORM_L1 = 2 };
+inline double norm(const Mat &a, const Mat &b, int type) {   // NORM_L1 of float matrices, accumulated in double as OpenCV does
+    assert(type == NORM_L1 && a.elem == 4 && b.elem == 4);
+    double acc = 0;
+    for (int y = 0; y < a.rows; y++) for (int x = 0; x < a.cols; x++) acc += std::fabs((double) a.at<float>(y, x) - (double) b.at<float>(y, x));
+    return acc;
+}
+#define CV_16SC2 11
+inline void initUndistortRectifyMap(const Mat &, const Mat &, const Mat &, const Mat &, Size, int, Mat &, Mat &) { mini_cv_unsupported("initUndistortRectifyMap"); }
+inline void remap(const Mat &, Mat &, const Mat &, const Mat &, int) { mini_cv_unsupported("remap"); }
+inline void undistortPoints(const Mat &, Mat &, const Mat &, const Mat &, const Mat &, const Mat &) { mini_cv_unsupported("undistortPoints"); }
 
 enum { BORDER_REFLECT_101 = 4, BORDER_ISOLATED = 16, INTER_LINEAR = 1 };
 
@@ -204,5 +233,9 @@ using cv::Mat;   // include/Common.h:64
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 #include "matcher_stubs.h"
 #include "sia_stubs.h"
+#ifdef YGZ_REF_FRAME
+#include "Thirdparty/DBoW2/DBoW2/BowVector.h"
+#include "frame_stubs.h"
+#endif
 #endif
 #endif

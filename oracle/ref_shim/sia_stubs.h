@@ -19,6 +19,7 @@ template <class T, int R, int C, int Opt = 0> struct Matrix {   // column-major,
     std::vector<T> d;
     int cols_;
     Matrix() : d((size_t) R * (C == Dynamic ? 0 : C), T(0)), cols_(C == Dynamic ? 0 : C) {}
+    static Matrix Zero() { return Matrix(); }
     int rows() const { return R; }
     int cols() const { return cols_; }
     int size() const { return R * cols_; }

@@ -8,12 +8,12 @@
 // plus restatements of the OpenCV 2.4.11/3.2 primitives the reference calls (resize INTER_LINEAR, FAST,
 // GaussianBlur, fastAtan2, cvRound), which are NOT under /root/reference.
 //
-// PARITY STATUS: "parity unpinned" for the OpenCV primitives (oracle_cvprims.cpp), the Eigen / Sophus algebra and the Frame-grid /
-// stereo / frustum / distinctive-descriptor restatements (the reference ships no test or golden vector for them, OpenCV is neither vendored nor version-pinned, and those sources
+// PARITY STATUS: "parity unpinned" for the OpenCV primitives (oracle_cvprims.cpp) and the Eigen / Sophus algebra (the reference ships no test or golden vector for them, OpenCV is neither vendored nor version-pinned, and those sources
 // need Eigen / Sophus / the whole Frame-MapPoint graph).  PINNED: the extractor (oracle_extractor.cpp) against the
 // reference's own src/ORBextractor.cc, the matcher's search functions and the direct projection against its src/ORBmatcher.cc +
-// src/Align.cc, the sparse image aligner against its src/SparseImageAlign.cc + NLSSolver, all compiled where they lie
-// over oracle/ref_shim/ (tests/test_ref_extractor.py, tests/test_ref_matcher.py), and FAST-10 against
+// src/Align.cc, the sparse image aligner against its src/SparseImageAlign.cc + NLSSolver, the Frame grid / isInFrustum /
+// ComputeStereoMatches against its src/Frame.cc, ComputeDistinctiveDescriptors / PredictScale against its src/MapPoint.cc, all compiled where they lie
+// over oracle/ref_shim/ (tests/test_ref_*.py), and FAST-10 against
 // the reference's own libfast incl. Thirdparty/fast's 167-corner KAT (tests/test_oracle_fast10.py); both live in oracle/_ref.
 //
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this code.
