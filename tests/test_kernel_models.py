@@ -193,3 +193,41 @@ def test_row_bytes8_window_never_leaves_the_row():
                 s0 = min(c0, w - 8)
                 sh = c0 - s0
                 assert 0 <= s0 and s0 + 8 <= w and 0 <= sh <= 3 and sh + need <= 8
+
+
+def test_packed_triple_scan_fields():
+    """k_octree's block_scan_array3: three exclusive scans as 21-bit fields of one 64-bit running sum (no carries between fields while every
+    total stays below 2^21)."""
+    rng = np.random.default_rng(21)
+    for n in (1, 7, 218, 1023, 2500):
+        a, b, c = (rng.integers(0, 5, n).astype(np.uint64), rng.integers(0, 5, n).astype(np.uint64), rng.integers(0, 2, n).astype(np.uint64))
+        packed = a | (b << np.uint64(21)) | (c << np.uint64(42))
+        excl = np.concatenate([[np.uint64(0)], np.cumsum(packed)[:-1]]).astype(np.uint64)
+        m = np.uint64(0x1FFFFF)
+        assert ((excl & m) == np.concatenate([[0], np.cumsum(a)[:-1]])).all()
+        assert (((excl >> np.uint64(21)) & m) == np.concatenate([[0], np.cumsum(b)[:-1]])).all()
+        assert ((excl >> np.uint64(42)) == np.concatenate([[0], np.cumsum(c)[:-1]])).all()
+    assert 4 * 400_000 < (1 << 21)          # children per pass <= candidates per level; 4K frames stay far below the field width
+
+
+def test_pyramid_perm_selectors_and_dot2():
+    """k_pyr_resize_tiled: per column the (left, right) source pixels are picked out of eight shifted bytes by one v_perm_b32 selector
+    (byte index | 0x0c = zero), then one 16-bit dot product with (alpha0, alpha1)."""
+    rng = np.random.default_rng(13)
+    for _ in range(2000):
+        row = rng.integers(0, 256, 64).astype(np.int64)
+        scale = rng.uniform(1.0, 1.27)
+        x0 = int(rng.integers(0, 40))
+        sx = [int(np.floor((x0 + k + 0.5) * scale - 0.5)) for k in range(4)]
+        lx0 = sx[0]
+        e = row[lx0:lx0 + 8]                                # the two dwords after v_alignbyte_b32: bytes lx0 .. lx0 + 7
+        for k in range(4):
+            d, d1 = sx[k] - lx0, sx[k] + 1 - lx0
+            assert 0 <= d <= 4 and d1 <= 5                  # scale < 1.28: everything inside the eight bytes
+            sel = d | 0x0C00 | (d1 << 16) | 0x0C000000
+            picked = [e[(sel >> (8 * b)) & 0xFF] if ((sel >> (8 * b)) & 0xFF) < 8 else 0 for b in range(4)]
+            pair = picked[0] | (picked[1] << 8) | (picked[2] << 16) | (picked[3] << 24)
+            a1 = int(rng.integers(0, 2049))
+            a0 = 2048 - a1
+            H = (pair & 0xFFFF) * a0 + (pair >> 16) * a1    # v_dot2_u32_u16
+            assert H == row[sx[k]] * a0 + row[sx[k] + 1] * a1
