@@ -39,7 +39,18 @@ typedef struct ygzf_extractor_cfg {
     int nlevels;
     int ini_th_fast;
     int min_th_fast;
+    int cv_mode;               /* ygzf_cv_mode; 0 (what a zero-initialised tail gives) = the reference's own build */
 } ygzf_extractor_cfg;
+
+/* Which OpenCV generation's 8-bit cv::GaussianBlur(7x7, sigma 2) the descriptors are sampled from (src/ORBextractor.cc:1010, :1083).
+ * The reference does not pin OpenCV (CMakeLists.txt:40-46) and this is the one primitive of the path whose arithmetic differs between
+ * the versions it can be built against; keypoints, angles and pyramids are the same in all modes.
+ *   YGZF_CV_LEGACY_SSE2  OpenCV 2.4.x / 3.0-3.3 on x86 (the reference's tested versions, built -march=native): fixed-point kernel
+ *                        {18,34,49,55,49,34,18}/256 per axis, column pass in SSE2 floats -> exact quotient rounded half to EVEN on the
+ *                        columns of the vector body [0, width & ~3), (sum + 2^15) >> 16 on the last width % 4 columns
+ *   YGZF_CV_LEGACY_INT   the same kernel without the SSE2 column body: (sum + 2^15) >> 16 everywhere
+ *   YGZF_CV_4            OpenCV >= 3.4.11 / 4.x bit-exact path: Q8.8 kernel {18,34,48,56,48,34,18}, (sum + 2^15) >> 16 */
+typedef enum ygzf_cv_mode { YGZF_CV_LEGACY_SSE2 = 0, YGZF_CV_LEGACY_INT = 1, YGZF_CV_4 = 2 } ygzf_cv_mode;
 
 /* cv::KeyPoint, bit-compatible (7 x 4 bytes): pt.x pt.y size angle response octave class_id */
 typedef struct ygzf_kp {
@@ -54,6 +65,11 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
 void ygzf_destroy(ygzf_ctx *ctx);
 /* Human-readable description of the last failure on `ctx` (or of the last failed ygzf_create when ctx == NULL). */
 const char *ygzf_last_error(const ygzf_ctx *ctx);
+
+/* The constructor's tables without a context or a device (host arithmetic only): what ORBextractor::ORBextractor fills before any image
+ * arrives (src/ORBextractor.cc:419-445) -- Frame's constructors read them first thing (src/Frame.cc:119-125).  Arrays of cfg->nlevels
+ * entries, any may be NULL. */
+int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat);
 
 /* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:84-106); arrays of nlevels floats, any may be NULL. */

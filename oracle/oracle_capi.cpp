@@ -110,6 +110,8 @@ void yo_descriptor(void *e_, const uint8_t *blurred, int w, int h, float x, floa
     e->ComputeDescriptor(kp, im, desc);
 }
 
+void yo_blur_kernel(int mode, int *k7) { gaussian_kernel7_s2(mode, k7); }
+
 void yo_blur(const uint8_t *src, int w, int h, uint8_t *dst) {
     Image s(w, h), d;
     std::memcpy(s.d.data(), src, (size_t) w * h);

@@ -146,25 +146,70 @@ static inline int reflect101(int i, int n) {
     return i;
 }
 
-// B4: cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101), CV_8UC1, legacy (2.4.x / 3.2) integer path:
-// float kernel exp(-x^2/8) normalised, converted to int32 with cvRound(k*256) = {18,34,49,55,49,34,18};
-// row pass u8 -> int32, column pass (sum + 2^15) >> 16, saturate.
-void gaussian_blur7_s2_u8(const Image &src, Image &dst) {
-    int kq[7];
-    {
-        float cf[7];
-        double sum = 0;
-        for (int i = 0; i < 7; i++) {
-            double x = i - 3.0;
-            cf[i] = (float) std::exp(-0.5 / (2.0 * 2.0) * x * x);
-            sum += cf[i];
+// B4: cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101), CV_8UC1 (call sites src/ORBextractor.cc:1010, :1083).
+// OpenCV is neither vendored nor version-pinned by the reference (find_package(OpenCV 3.0) else 2.4.3, CMakeLists.txt:40-46), and the
+// 8-bit Gaussian is the one primitive of this path whose arithmetic changed between the versions a user can build against.  Three
+// recalled definitions, selected process-wide with set_cv_mode():
+//   CV_MODE_LEGACY_SSE2 (0, default) OpenCV 2.4.x / 3.0 - 3.3 on x86 -- what the reference's own build produces (-march=native,
+//       CMakeLists.txt:13-14; tested versions 2.4.11 / 3.2, README-ORB-SLAM2.md:64).  Separable fixed-point filter: the float kernel
+//       exp(-x^2/8) normalised, both 1-D kernels converted to int32 with cvRound(k*256) = {18,34,49,55,49,34,18} (sum 257); row pass
+//       u8 -> int32; column pass through SymmColumnVec_32s8u: the int kernel is turned back into floats k/65536, the row sums are
+//       converted to float, s = c*f0, then s += (row[+k] + row[-k]) * fk for k = 1..3 (mulps / addps, no FMA), _mm_cvtps_epi32
+//       (ROUND HALF TO EVEN) and unsigned saturation.  The vector body covers columns [0, width & ~3); the last width % 4 columns go
+//       through the scalar FixedPtCastEx tail, (sum + 2^15) >> 16.  Every float operation is exact here (numerators stay below
+//       2^24 until the result is >= 256, which saturates either way), so the two roundings differ only on exact ties,
+//       sum mod 65536 == 32768.
+//   CV_MODE_LEGACY_INT (1) the same kernel without the SSE2 column body (non-x86 / SIMD-less builds): (sum + 2^15) >> 16 everywhere.
+//   CV_MODE_CV4 (2) OpenCV >= 3.4.11 / 4.x "bit-exact" 8-bit path: Q8.8 kernel from getGaussianKernelFixedPoint_ED (error diffusion,
+//       centre = 256 - rest) = {18,34,48,56,48,34,18} (sum 256); horizontal pass into ufixedpoint16 (exact, <= 255*256), vertical pass
+//       in Q16.16 with (sum + 2^15) >> 16.  SIMD and scalar forms agree by design.
+// IPP / OpenCL dispatch of a particular OpenCV binary is outside all three.
+static int g_cv_mode = CV_MODE_LEGACY_SSE2;
+void set_cv_mode(int mode) { g_cv_mode = mode; }
+int get_cv_mode() { return g_cv_mode; }
+
+}  // namespace ygzo
+// exported by every library that links this file (the oracle and the oracle/_ref builds of the reference's own sources)
+extern "C" void yo_set_cv_mode(int mode) { ygzo::set_cv_mode(mode); }
+extern "C" int yo_get_cv_mode() { return ygzo::get_cv_mode(); }
+namespace ygzo {
+
+void gaussian_kernel7_s2(int mode, int kq[7]) {
+    if (mode == CV_MODE_CV4) {
+        // getGaussianKernelFixedPoint_ED: normalised double kernel, v_i = round(k_i * 256 + err), err carried, centre takes the remainder
+        double k[7], sum = 0;
+        for (int i = 0; i < 7; i++) { const double x = i - 3.0; k[i] = std::exp(-0.5 / (2.0 * 2.0) * x * x); sum += k[i]; }
+        double err = 0;
+        int acc = 0;
+        for (int i = 0; i < 3; i++) {
+            const double adj = k[i] / sum * 256.0 + err;
+            const int v = cv_round(adj);
+            err = adj - v;
+            kq[i] = kq[6 - i] = v;
+            acc += 2 * v;
         }
-        sum = 1. / sum;
-        for (int i = 0; i < 7; i++) {
-            cf[i] = (float) (cf[i] * sum);
-            kq[i] = cv_round((double) cf[i] * 256.0);
-        }
+        kq[3] = 256 - acc;
+        return;
     }
+    float cf[7];
+    double sum = 0;
+    for (int i = 0; i < 7; i++) {
+        double x = i - 3.0;
+        cf[i] = (float) std::exp(-0.5 / (2.0 * 2.0) * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) {
+        cf[i] = (float) (cf[i] * sum);
+        kq[i] = cv_round((double) cf[i] * 256.0);
+    }
+}
+
+void gaussian_blur7_s2_u8(const Image &src, Image &dst) { gaussian_blur7_s2_u8(src, dst, g_cv_mode); }
+
+void gaussian_blur7_s2_u8(const Image &src, Image &dst, int mode) {
+    int kq[7];
+    gaussian_kernel7_s2(mode, kq);
     const int w = src.w, h = src.h;
     dst.w = w;
     dst.h = h;
@@ -176,13 +221,26 @@ void gaussian_blur7_s2_u8(const Image &src, Image &dst) {
             for (int k = -3; k <= 3; k++) s += kq[k + 3] * src.at(y, reflect101(x + k, w));
             rows[(size_t) y * w + x] = s;
         }
-    for (int y = 0; y < h; y++)
+    const int wvec = mode == CV_MODE_LEGACY_SSE2 ? (w & ~3) : 0;   // columns of the SSE2 body (16- and 4-wide loops)
+    float fk[4];
+    for (int k = 0; k < 4; k++) fk[k] = (float) kq[3 + k] * (1.f / 65536.f);   // kernel.convertTo(CV_32F, 1. / (1 << 16)): exact
+    for (int y = 0; y < h; y++) {
+        const int *R[7];
+        for (int k = -3; k <= 3; k++) R[k + 3] = &rows[(size_t) reflect101(y + k, h) * w];
         for (int x = 0; x < w; x++) {
-            int s = 0;
-            for (int k = -3; k <= 3; k++) s += kq[k + 3] * rows[(size_t) reflect101(y + k, h) * w + x];
-            int v = (s + 32768) >> 16;
+            int v;
+            if (x < wvec) {
+                float s = (float) R[3][x] * fk[0];                               // mulps (+ delta 0)
+                for (int k = 1; k <= 3; k++) s = s + (float) (R[3 + k][x] + R[3 - k][x]) * fk[k];   // paddd, cvtdq2ps, mulps, addps
+                v = (int) std::nearbyintf(s);                                    // cvtps2dq: round half to even
+            } else {
+                int s = 0;
+                for (int k = -3; k <= 3; k++) s += kq[k + 3] * R[k + 3][x];
+                v = (s + 32768) >> 16;
+            }
             dst.d[(size_t) y * w + x] = (uint8_t) (v < 0 ? 0 : v > 255 ? 255 : v);
         }
+    }
 }
 
 // B3: cv::FAST TYPE_9_16.  Ring offsets as in Thirdparty/fast/src/fast_10.cpp:16-33 (same Bresenham circle).

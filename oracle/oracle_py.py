@@ -30,6 +30,42 @@ def build(force=False):
 _lib = None
 _ref = None
 
+# OpenCV arithmetic mode of the 8-bit GaussianBlur (oracle_cvprims.cpp): process-wide, applied to the oracle and to every oracle/_ref
+# build of the reference's own sources (their cv::GaussianBlur is the same restatement)
+CV_MODE_LEGACY_SSE2, CV_MODE_LEGACY_INT, CV_MODE_CV4 = 0, 1, 2
+_cv_mode = CV_MODE_LEGACY_SSE2
+_cv_libs = []
+
+
+def _track_cv(L):
+    if L is not None and hasattr(L, "yo_set_cv_mode") and all(L is not x for x in _cv_libs):
+        _cv_libs.append(L)
+        L.yo_set_cv_mode(_cv_mode)
+    return L
+
+
+def set_cv_mode(mode):
+    global _cv_mode
+    _cv_mode = int(mode)
+    for L in _cv_libs:
+        L.yo_set_cv_mode(_cv_mode)
+
+
+class cv_mode:
+    """with cv_mode(CV_MODE_CV4): ... -- the oracle (and the reference builds) blur like that OpenCV generation inside the block."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _cv_mode
+        set_cv_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        set_cv_mode(self.prev)
+
+
 
 _lib_override = None
 
@@ -38,7 +74,7 @@ def ref_matcher_lib():
     """The reference's own src/ORBmatcher.cc behind the oracle's flat matcher API (oracle/_ref/libref_orbmatcher.so), or None."""
     build()
     p = os.path.join(_HERE, "_ref", "libref_orbmatcher.so")
-    return C.CDLL(p) if os.path.exists(p) else None
+    return _track_cv(C.CDLL(p)) if os.path.exists(p) else None
 
 
 def ref_mappoint_lib():
@@ -66,7 +102,7 @@ def ref_frame_lib():
     """The reference's own src/Frame.cc (oracle/_ref/libref_frame.so) behind yo_features_in_area / yo_is_in_frustum / yo_compute_stereo_matches."""
     build()
     p = os.path.join(_HERE, "_ref", "libref_frame.so")
-    return C.CDLL(p) if os.path.exists(p) else None
+    return _track_cv(C.CDLL(p)) if os.path.exists(p) else None
 
 
 class reference_frame:
@@ -106,6 +142,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(os.environ.get("YGZ_ORACLE_LIB") or build())   # YGZ_ORACLE_LIB: the sanitizer build (tests/test_oracle_sanitizers.py)
         L = _lib
+        _track_cv(L)
         L.yo_extractor_create.restype = C.c_void_p
         L.yo_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
         L.yo_extractor_destroy.argtypes = [C.c_void_p]
@@ -152,7 +189,7 @@ def ref_extractor_lib():
         p = os.path.join(_HERE, "_ref", "libref_orbextractor.so")
         if not os.path.exists(p):
             return None
-        _ref_ex = C.CDLL(p)
+        _ref_ex = _track_cv(C.CDLL(p))
         _ref_ex.yr_extract.restype = C.c_int
         _ref_ex.yr_extract.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _ref_ex.yr_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -382,10 +419,17 @@ class Extractor:
 
 
 def blur(img):
+    """cv::GaussianBlur 7x7 sigma 2 REFLECT_101 in the current cv mode."""
     img = np.ascontiguousarray(img, np.uint8)
     out = np.zeros_like(img)
     lib().yo_blur(_p(img), img.shape[1], img.shape[0], _p(out))
     return out
+
+
+def blur_kernel(mode):
+    k = np.zeros(7, np.int32)
+    lib().yo_blur_kernel(mode, _p(k))
+    return k
 
 
 def resize(img, dw, dh):

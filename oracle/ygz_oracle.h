@@ -43,7 +43,13 @@ struct Image {  // tight 8-bit image (step == w), like Frame::mvImagePyramid clo
 int cv_round(double v);                                    // B6: round half to even
 float fast_atan2_deg(float y, float x);                    // B5
 void resize_linear_u8(const Image &src, Image &dst);       // B1 (dst.w/dst.h preset)
-void gaussian_blur7_s2_u8(const Image &src, Image &dst);   // B4 legacy integer path, REFLECT_101
+// B4, REFLECT_101.  Three recalled OpenCV definitions (see oracle_cvprims.cpp): the process-wide mode is what the extractor uses.
+enum { CV_MODE_LEGACY_SSE2 = 0, CV_MODE_LEGACY_INT = 1, CV_MODE_CV4 = 2 };
+void set_cv_mode(int mode);
+int get_cv_mode();
+void gaussian_kernel7_s2(int mode, int kq[7]);
+void gaussian_blur7_s2_u8(const Image &src, Image &dst);             // current mode
+void gaussian_blur7_s2_u8(const Image &src, Image &dst, int mode);
 // cosf/sinf of (angle_deg * (float)(pi/180)): "correctly rounded float of the double result", computed with a
 // fixed double polynomial (no FMA) so that host and device can evaluate the identical operation sequence.
 void sincos_deg(float angle_deg, float *c, float *s);

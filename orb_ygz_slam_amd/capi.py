@@ -17,7 +17,10 @@ class YgzfError(RuntimeError):
 
 class ExtractorCfg(C.Structure):
     _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int), ("ini_th_fast", C.c_int),
-                ("min_th_fast", C.c_int)]
+                ("min_th_fast", C.c_int), ("cv_mode", C.c_int)]
+
+
+CV_LEGACY_SSE2, CV_LEGACY_INT, CV_4 = 0, 1, 2   # ygzf_cv_mode
 
 
 class Camera(C.Structure):
@@ -74,6 +77,7 @@ def load_library(build_if_missing=True):
     L.ygzf_destroy.restype = None
     L.ygzf_last_error.argtypes = [vp]
     L.ygzf_last_error.restype = C.c_char_p
+    L.ygzf_scale_tables_host.argtypes = [C.POINTER(ExtractorCfg), vp, vp, vp, vp, vp]
     L.ygzf_get_levels.argtypes = [vp]
     L.ygzf_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
     L.ygzf_get_features_per_level.argtypes = [vp, vp]
@@ -140,10 +144,10 @@ class Extractor:
     """Thin object wrapper over a ygzf_ctx (mirrors ygz::ORBextractor's constructor arguments)."""
 
     def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, max_width=752, max_height=480,
-                 max_batch=1, device=0):
+                 max_batch=1, device=0, cv_mode=CV_LEGACY_SSE2):
         self.L = load_library()
         self.nlevels = nlevels
-        self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th, cv_mode)
         self._wh = (max_width, max_height, 0)   # (w, h, frames) of the last extracted batch
         self._inflight = []                     # host arrays handed to asynchronous uploads, kept alive until the next synchronisation
         self.h = C.c_void_p()

@@ -125,6 +125,8 @@ __device__ __forceinline__ float row_sum_dpp(float v) {
 
 constexpr int kAcc = 30;  // 21 upper-triangular H entries + 6 b + chi2 + n_meas + n_visible_features
 
+// DBG: phase clocks (YGZF_SIA_DEBUG) are compiled in only in the instrumented instantiation; the production kernel reads no clock
+template <bool DBG>
 __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     extern __shared__ float4 s_feat[];   // per feature: xyz in the reference camera (Tref * Xw, constant over the run), w = visible flag;
                                          // behind it float2 s_uv[]: the reference keypoint (level 0), x = -100 for excluded features
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         const float scale = A.invScale[level];
         // ---- precomputeReferencePatches.  The reference zeroes the whole jacobian cache per level (:41); only features that
         // stay "visible" from a coarser level but fail this level's border test can still read it, so only their rows are zeroed.
-        const long long p0c = wall_clock64();
+        const long long p0c = DBG ? wall_clock64() : 0;
         {
             // work item = (feature, patch row): 4 pixels
             for (int it = tid; it < 4 * N; it += kSiaBlock) {
@@ -222,12 +224,12 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
             }
         }
         __syncthreads();
-        if (tid == 0 && A.dbg) A.dbg[4] += wall_clock64() - p0c;
+        if (DBG && tid == 0 && A.dbg) A.dbg[4] += wall_clock64() - p0c;
         // ---- optimizeGaussNewton ----
         if (tid == 0) { s_Told = s_T; s_break = 0; }
         __syncthreads();
         for (int iter = 0; iter < A.nIter; iter++) {
-            const long long c0 = wall_clock64();
+            const long long c0 = DBG ? wall_clock64() : 0;
             const Se3 T = s_T, Tref = s_Tref;
             float acc[kAcc];
 #pragma unroll
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                     acc[26] -= j5 * res;
                 }
             }
-            const long long c1 = wall_clock64();
+            const long long c1 = DBG ? wall_clock64() : 0;
             // fixed-shape reduction: DPP tree inside each row of 16 lanes -> one LDS partial per row; then 30 threads combine the four rows of
             // a wave as (r0 + r1) + (r2 + r3) and add the waves in order (the same tree as a full wave reduction, without the 4 v_readlane + 3 adds
             // per accumulator and wave)
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 s_tot[tid] = v;
             }
             __syncthreads();
-            const long long c2 = wall_clock64();
+            const long long c2 = DBG ? wall_clock64() : 0;
             if (tid == 0) {
                 float r[kAcc];
                 for (int k = 0; k < kAcc; k++) r[k] = s_tot[k];
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                     if (nm <= A.eps) s_break = 1;                // converged
                 }
             }
-            if (tid == 0 && A.dbg) { const long long c3 = wall_clock64(); A.dbg[0] += c1 - c0; A.dbg[1] += c2 - c1; A.dbg[2] += c3 - c2; A.dbg[3] += 1; }
+            if (DBG && tid == 0 && A.dbg) { const long long c3 = wall_clock64(); A.dbg[0] += c1 - c0; A.dbg[1] += c2 - c1; A.dbg[2] += c3 - c2; A.dbg[3] += 1; }
             __syncthreads();
             if (s_break) break;
         }
@@ -363,14 +365,17 @@ hipError_t sia_prepare(size_t ldsBytes) {
     // the kernel's static LDS (reduction partials, solver state) comes out of the same 160 KB: the ceiling is a constant of the kernel,
     // so every context sets the same value
     hipFuncAttributes fa;
-    const hipError_t e = hipFuncGetAttributes(&fa, (const void *) k_sia_run);
+    hipError_t e = hipFuncGetAttributes(&fa, (const void *) k_sia_run<false>);
     if (e != hipSuccess) return e;
     const int ceiling = (int) std::min<size_t>(kMaxDynLds, 160 * 1024 - ((fa.sharedSizeBytes + 255) & ~(size_t) 255));
-    return hipFuncSetAttribute((const void *) k_sia_run, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
+    e = hipFuncSetAttribute((const void *) k_sia_run<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void *) k_sia_run<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
 }
 
 void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes) {
-    hipLaunchKernelGGL(k_sia_run, dim3(nPairs), dim3(kSiaBlock), ldsBytes, st, A);
+    if (A.dbg) hipLaunchKernelGGL(k_sia_run<true>, dim3(nPairs), dim3(kSiaBlock), ldsBytes, st, A);
+    else hipLaunchKernelGGL(k_sia_run<false>, dim3(nPairs), dim3(kSiaBlock), ldsBytes, st, A);
 }
 
 }  // namespace ygzf

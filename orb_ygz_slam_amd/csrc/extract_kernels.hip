@@ -1190,6 +1190,12 @@ __constant__ __attribute__((aligned(16))) float4 c_pattern[256];   // (x0, y0, x
 __constant__ int c_umax[16];
 
 // One wave: orientation + blurred patch + 256 rBRIEF bits of the keypoint at integer (kx,ky) of a gw x gh level image.
+// CVM = ygzf_cv_mode: which OpenCV generation's 8-bit GaussianBlur the descriptor samples (include/ygzf.h):
+//   YGZF_CV_LEGACY_SSE2  kernel {18,34,49,55,49,34,18}; the x86 column pass rounds the exact quotient sum/65536 half to EVEN on the
+//                        columns of its SSE2 body ([0, width & ~3)) and half UP ((sum + 2^15) >> 16) on the scalar tail
+//   YGZF_CV_LEGACY_INT   same kernel, (sum + 2^15) >> 16 everywhere
+//   YGZF_CV_4            Q8.8 kernel {18,34,48,56,48,34,18}, (sum + 2^15) >> 16
+template <int CVM>
 __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img, int pitch, int gw, int gh, int kx, int ky, DescLds &L,
                                                 int lane, float *angleOut, unsigned long long bits[4], bool presetAngle = false,
                                                 float preset = 0.f) {
@@ -1245,7 +1251,10 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = presetAngle ? preset : fast_atan2_deg((float) m01, (float) m10);
-    // ---- separable 7-tap blur {18,34,49,55,49,34,18}: each lane produces runs of 8 outputs
+    // ---- separable 7-tap blur {18,34,k2,k3,k2,34,18}: each lane produces runs of 8 outputs
+    constexpr int k2 = CVM == YGZF_CV_4 ? 48 : 49, k3 = CVM == YGZF_CV_4 ? 56 : 55;
+    constexpr unsigned kTapLo = 0x00002212u | ((unsigned) k2 << 16) | ((unsigned) k3 << 24);   // bytes (18, 34, k2, k3)
+    constexpr unsigned kTapHi = 0x00122200u | (unsigned) k2;                                  // bytes (k2, 34, 18, 0)
     // horizontal: 43 rows x 5 segments (8+8+8+8+5 columns)
     for (int t = lane; t < kWin * 5; t += 64) {
         const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
@@ -1270,8 +1279,8 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         unsigned O[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned lo = __builtin_amdgcn_udot4(X[2 * k], 0x37312212u, __builtin_amdgcn_udot4(X[2 * k + 4], 0x00122231u, 0u, false), false);
-            const unsigned hi = __builtin_amdgcn_udot4(X[2 * k + 1], 0x37312212u, __builtin_amdgcn_udot4(X[2 * k + 5], 0x00122231u, 0u, false), false);
+            const unsigned lo = __builtin_amdgcn_udot4(X[2 * k], kTapLo, __builtin_amdgcn_udot4(X[2 * k + 4], kTapHi, 0u, false), false);
+            const unsigned hi = __builtin_amdgcn_udot4(X[2 * k + 1], kTapLo, __builtin_amdgcn_udot4(X[2 * k + 5], kTapHi, 0u, false), false);
             O[k] = lo | (hi << 16);
         }
         unsigned *dst = (unsigned *) &L.hbp()[r * kHbP + 8 * sg];
@@ -1291,15 +1300,25 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         const int r0 = __float2int_rn(x0 * b + y0 * a), q0 = __float2int_rn(x0 * a - y0 * b);
         const int r1 = __float2int_rn(x1 * b + y1 * a), q1 = __float2int_rn(x1 * a - y1 * b);
         const unsigned short *p0 = &L.hbp()[(18 + r0) * kHbP + 18 + q0], *p1 = &L.hbp()[(18 + r1) * kHbP + 18 + q1];
-        const int s0 = 18 * (p0[0] + p0[6 * kHbP]) + 34 * (p0[kHbP] + p0[5 * kHbP]) + 49 * (p0[2 * kHbP] + p0[4 * kHbP]) + 55 * p0[3 * kHbP];
-        const int s1 = 18 * (p1[0] + p1[6 * kHbP]) + 34 * (p1[kHbP] + p1[5 * kHbP]) + 49 * (p1[2 * kHbP] + p1[4 * kHbP]) + 55 * p1[3 * kHbP];
-        const int t0 = min((s0 + 32768) >> 16, 255), t1 = min((s1 + 32768) >> 16, 255);
+        const int s0 = 18 * (p0[0] + p0[6 * kHbP]) + 34 * (p0[kHbP] + p0[5 * kHbP]) + k2 * (p0[2 * kHbP] + p0[4 * kHbP]) + k3 * p0[3 * kHbP];
+        const int s1 = 18 * (p1[0] + p1[6 * kHbP]) + 34 * (p1[kHbP] + p1[5 * kHbP]) + k2 * (p1[2 * kHbP] + p1[4 * kHbP]) + k3 * p1[3 * kHbP];
+        int t0 = (s0 + 32768) >> 16, t1 = (s1 + 32768) >> 16;
+        if (CVM == YGZF_CV_LEGACY_SSE2) {
+            // exact tie (sum = q*65536 + 32768) inside the SSE2 body: cvtps2dq rounds to even, i.e. the half-up result loses its low bit
+            const int wv = gw & ~3;
+            const int c0 = reflect101(kx + q0, gw), c1 = reflect101(kx + q1, gw);
+            if ((s0 & 0xFFFF) == 0x8000 && c0 < wv) t0 &= ~1;
+            if ((s1 & 0xFFFF) == 0x8000 && c1 < wv) t1 &= ~1;
+        }
+        t0 = min(t0, 255);
+        t1 = min(t1, 255);
         bits[it] = __ballot(t0 < t1);
     }
     *angleOut = angle;
 #undef RAWP
 }
 
+template <int CVM>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                             const unsigned *__restrict__ lvlKpXY,
                                                             const unsigned char *__restrict__ lvlKpScore,
@@ -1338,7 +1357,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
     float angle;
     unsigned long long bits[4];
-    describe_window(img, pitch, g.w, g.h, kx, ky, lds[wave], lane, &angle, bits);
+    describe_window<CVM>(img, pitch, g.w, g.h, kx, ky, lds[wave], lane, &angle, bits);
     ygzf_kp *ok = outKp + (long long) f * outStride + slot;
     uint8_t *od = outDesc + ((long long) f * outStride + slot) * 32;
     if (lane < 4) ((unsigned long long *) od)[lane] = bits[lane];
@@ -1359,6 +1378,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
 // exist in the frame get IC_Angle (:1380-1383) and a descriptor at pt*invScale[octave] (:1104-1116), new level-0 keys follow).
 // list[i] = {x, y, level | flag, angle bits} in LEVEL coordinates (already rounded as cvRound does); flag 0x100: keep the given angle
 // (the ORBSLAM_KEYPOINT / FAST_KEYPOINT branches leave the angle of existing keys alone, :1096-1099).
+template <int CVM>
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe_list(FrameSet fs, const LevelGeom *__restrict__ geom, const int4 *__restrict__ list,
                                                                  int n, int frame, float *__restrict__ outAngle, uint8_t *__restrict__ outDesc) {
     __shared__ DescLds lds[kDescWaves];
@@ -1372,7 +1392,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe_list(FrameSet fs, 
     const uint8_t *img = level_ptr(fs, g, level, frame, &pitch);
     float angle;
     unsigned long long bits[4];
-    describe_window(img, pitch, g.w, g.h, e.x, e.y, lds[wave], lane, &angle, bits, (e.z & 0x100) != 0, __int_as_float(e.w));
+    describe_window<CVM>(img, pitch, g.w, g.h, e.x, e.y, lds[wave], lane, &angle, bits, (e.z & 0x100) != 0, __int_as_float(e.w));
     if (lane < 4) ((unsigned long long *) (outDesc + (long long) i * 32))[lane] = bits[lane];
     if (lane == 0) outAngle[i] = angle;
 }
@@ -1460,19 +1480,30 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const un
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
                      const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
-                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames) {
+                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode) {
     const int nblk = (kpStride + kDescWaves - 1) / kDescWaves;
     const int blocksPerXcd = (nblk + 7) / 8;
     dim3 grid(8 * blocksPerXcd, nFrames);
-    hipLaunchKernelGGL(k_describe, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpXY, lvlKpScore, lvlKpCnt,
-                       procOrder, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd);
+#define YGZF_DESC_LAUNCH(M)                                                                                                      \
+    hipLaunchKernelGGL(k_describe<M>, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpXY, lvlKpScore, lvlKpCnt, \
+                       procOrder, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd)
+    switch (cvMode) {
+        case YGZF_CV_LEGACY_INT: YGZF_DESC_LAUNCH(YGZF_CV_LEGACY_INT); break;
+        case YGZF_CV_4: YGZF_DESC_LAUNCH(YGZF_CV_4); break;
+        default: YGZF_DESC_LAUNCH(YGZF_CV_LEGACY_SSE2); break;
+    }
+#undef YGZF_DESC_LAUNCH
 }
 
 void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,
-                          float *outAngle, uint8_t *outDesc) {
+                          float *outAngle, uint8_t *outDesc, int cvMode) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_describe_list, dim3((n + kDescWaves - 1) / kDescWaves), dim3(64 * kDescWaves), 0, st, fs, dGeom, (const int4 *) list, n,
-                       frame, outAngle, outDesc);
+    const dim3 grid((n + kDescWaves - 1) / kDescWaves), block(64 * kDescWaves);
+    switch (cvMode) {
+        case YGZF_CV_LEGACY_INT: hipLaunchKernelGGL(k_describe_list<YGZF_CV_LEGACY_INT>, grid, block, 0, st, fs, dGeom, (const int4 *) list, n, frame, outAngle, outDesc); break;
+        case YGZF_CV_4: hipLaunchKernelGGL(k_describe_list<YGZF_CV_4>, grid, block, 0, st, fs, dGeom, (const int4 *) list, n, frame, outAngle, outDesc); break;
+        default: hipLaunchKernelGGL(k_describe_list<YGZF_CV_LEGACY_SSE2>, grid, block, 0, st, fs, dGeom, (const int4 *) list, n, frame, outAngle, outDesc); break;
+    }
 }
 
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out) {

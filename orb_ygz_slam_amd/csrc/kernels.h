@@ -21,7 +21,7 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const un
                    unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena);
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
                      const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
-                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames);
+                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode);
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out);
 
 // ---- matcher (match_kernels.hip) -----------------------------------------------------------------------------------
@@ -114,7 +114,7 @@ void launch_dso_cells(hipStream_t st, const uint8_t *img, int pitch, int w, int 
                       unsigned *cellXY, int *total);
 void launch_dso_compact(hipStream_t st, const int *cellCnt, const unsigned *cellXY, int nInner, int nExisting, void *list, unsigned *newXY);
 void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,
-                          float *outAngle, uint8_t *outDesc);
+                          float *outAngle, uint8_t *outDesc, int cvMode);
 
 // ---- Frame::ComputeStereoMatches (stereo_kernels.hip) ---------------------------------------------------------------------
 struct StereoRec {   // per right keypoint: x, row band (min | max << 16), octave

@@ -123,7 +123,10 @@ struct ygzf_ctx {
     // timing
     hipEvent_t tStart = nullptr, tStop = nullptr;
     bool profile = false;
-    bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;   // debugging aid: synchronise after every kernel and name it on stderr
+    // debugging aids, read once per context (never on the launch path): synchronise after every kernel and name it on stderr /
+    // phase clocks of the octree, matcher and aligner kernels printed to stderr
+    bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
+    bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -131,18 +134,22 @@ struct ygzf_ctx {
     int profN[KK_COUNT] = {0};
 };
 
-static std::string g_create_err;
-static std::mutex g_create_mu;
+// last failed ygzf_create of THIS thread (the reference constructs its left / right extractors from different threads)
+static thread_local std::string g_create_err;
 
+// Every error return goes through here.  Entry points queue asynchronous uploads from caller-owned or local host arrays and synchronise
+// at their end: an early error return must not leave such a copy in flight behind a source that is about to disappear, so the stream is
+// drained first (errors are not a fast path).
 static int fail(ygzf_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
-    else {
-        std::lock_guard<std::mutex> lk(g_create_mu);
+    if (c) {
+        if (c->stream) (void) hipStreamSynchronize(c->stream);
+        c->err = buf;
+    } else {
         g_create_err = buf;
     }
     return code;
@@ -304,7 +311,11 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         Geometry G;
         int rc = build_geometry(c, w, h, G);
         if (rc) return rc;
-        c->geo = G;
+        // c->geo is committed only after every fallible step below has succeeded: a failed attempt leaves (w, h) unset, so that a retry
+        // runs the whole setup again instead of continuing on partial device tables
+        c->geo.w = c->geo.h = 0;
+        c->carryValid = false;
+        c->lastFrames = 0;
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         rc = ensure(c, c->dGeom, sizeof(LevelGeom) * L);
         if (rc) return rc;
@@ -319,8 +330,6 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             if (rc) return rc;
             if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
         }
-        c->carryValid = false;
-        c->lastFrames = 0;
         // LDS-resident candidate sort buffers: as many as keep two workgroups per CU (<= ~78 KB each)
         {
             // per-list-position arrays (19 x cap ints) stay in LDS while one workgroup fits the CU; very large per-level feature budgets
@@ -336,6 +345,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
                         G.maxCellsPerLevel, G.kpCapMax);
         HIPCHECK(c, octree_prepare(c->octLds, c->octGlobalNodes));
+        c->geo = G;
     }
     const Geometry &G = c->geo;
     const size_t B = (size_t) nFrames;
@@ -450,7 +460,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                               G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap);
         }
         long long *odbg = nullptr;
-        if (getenv("YGZF_OCT_DEBUG")) {
+        if (c->octDebug) {
             int rc2 = ensure(c, c->dTmpA, 16 * 8 * sizeof(long long));
             if (rc2) return rc2;
             odbg = (long long *) c->dTmpA.p;
@@ -476,7 +486,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             ProfScope ps(c, KK_DESCRIBE);
             launch_describe(c->stream, fs, dGeom, L, (const unsigned *) c->dLvlXY.p, (const unsigned char *) c->dLvlScore.p,
                             (const int *) c->dLvlCnt.p, (const unsigned short *) c->dProcOrder.p, G.kpStride, outKp, outDesc, outCnt,
-                            G.kpStride, nFrames);
+                            G.kpStride, nFrames, c->tab.cfg.cv_mode);
         }
     } else {
         HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int) * nFrames, c->stream));
@@ -522,6 +532,7 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
         cfg->min_th_fast < 0 || cfg->ini_th_fast > 255 || cfg->min_th_fast > 255 || cfg->min_th_fast > cfg->ini_th_fast)
         return fail(nullptr, YGZF_ERR_INVALID, "bad extractor configuration (nlevels 1..%d, scale_factor > 1, 0 <= minTh <= iniTh <= 255)",
                     kMaxLevels);
+    if (cfg->cv_mode < YGZF_CV_LEGACY_SSE2 || cfg->cv_mode > YGZF_CV_4) return fail(nullptr, YGZF_ERR_INVALID, "cv_mode %d (0 legacy SSE2, 1 legacy integer, 2 OpenCV >= 3.4.11 / 4.x)", cfg->cv_mode);
     if (max_width < 1 || max_height < 1 || max_batch < 1) return fail(nullptr, YGZF_ERR_INVALID, "bad maximum sizes");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -536,7 +547,7 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     c->maxBatch = max_batch;
     c->tab.init(*cfg);
     auto bail = [&](int rc) {
-        g_create_err = c->err;
+        g_create_err = c->err;   // thread-local
         ygzf_destroy(c);
         return rc;
     };
@@ -600,6 +611,19 @@ void ygzf_destroy(ygzf_ctx *c) {
 const char *ygzf_last_error(const ygzf_ctx *c) {
     if (c) return c->err.c_str();
     return g_create_err.c_str();
+}
+
+int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat) {
+    if (!cfg || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 0 || !(cfg->scale_factor > 1.0f)) return YGZF_ERR_INVALID;
+    Tables T;
+    T.init(*cfg);
+    const size_t n = sizeof(float) * cfg->nlevels;
+    if (scale) memcpy(scale, T.scale.data(), n);
+    if (inv_scale) memcpy(inv_scale, T.invScale.data(), n);
+    if (sigma2) memcpy(sigma2, T.sigma2.data(), n);
+    if (inv_sigma2) memcpy(inv_sigma2, T.invSigma2.data(), n);
+    if (nfeat) memcpy(nfeat, T.nFeat.data(), sizeof(int) * cfg->nlevels);
+    return YGZF_OK;
 }
 
 int ygzf_get_levels(const ygzf_ctx *c) { return c ? c->tab.cfg.nlevels : YGZF_ERR_INVALID; }
@@ -972,7 +996,7 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
     A.nmatches = (int *) c->dNMatch.p;
     A.capCur = G.kpStride;
     A.capLast = G.kpStride;
-    if (getenv("YGZF_MATCH_DEBUG")) {
+    if (c->matchDebug) {
         if ((rc = ensure(c, c->dTmpC, (size_t) B * 8 * sizeof(long long)))) return rc;
         A.dbg = (long long *) c->dTmpC.p;
     }
@@ -1030,6 +1054,13 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
     }
     if (!cur->keys || !cur->desc || !last_keys || !mp_world || !mp_desc || !cur_match || !cur_owner)
         return fail(c, YGZF_ERR_INVALID, "null array");
+    {   // the kernel indexes its scale-factor table with these octaves and stores Cur's as bytes
+        const int nl = cur->scale_factors ? std::min(cur->nlevels, (int) kMaxLevels) : c->tab.cfg.nlevels;
+        for (int i = 0; i < last_n; i++)
+            if (last_keys[i].octave < 0 || last_keys[i].octave >= nl) return fail(c, YGZF_ERR_INVALID, "last_keys[%d].octave %d outside 0..%d", i, last_keys[i].octave, nl - 1);
+        for (int i = 0; i < cur->n; i++)
+            if (cur->keys[i].octave < 0 || cur->keys[i].octave >= nl) return fail(c, YGZF_ERR_INVALID, "cur keys[%d].octave %d outside 0..%d", i, cur->keys[i].octave, nl - 1);
+    }
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t nt = cur->n, nq = last_n;
     struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
@@ -1174,7 +1205,7 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     A.visible = (uint8_t *) (A.patchCache + N * 48);
     A.out = (float *) S[7].p;
     {
-        if (getenv("YGZF_SIA_DEBUG")) {
+        if (c->siaDebug) {
             if ((rc = ensure(c, c->dTmpB, 64))) return rc;
             HIPCHECK(c, hipMemsetAsync(c->dTmpB.p, 0, 64, c->stream));
             A.dbg = (long long *) c->dTmpB.p;
@@ -1284,7 +1315,7 @@ int ygzf_describe_keys(ygzf_ctx *c, int frame, const ygzf_kp *keys, int n, int r
     HIPCHECK(c, hipMemcpyAsync(c->dDso[5].p, list4.data(), 16 * (size_t) n, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, KK_DESCRIBE);
-        launch_describe_list(c->stream, c->lastFs, (const LevelGeom *) c->dGeom.p, c->dDso[5].p, n, frame, (float *) c->dDso[7].p, (uint8_t *) c->dTmpC.p);
+        launch_describe_list(c->stream, c->lastFs, (const LevelGeom *) c->dGeom.p, c->dDso[5].p, n, frame, (float *) c->dDso[7].p, (uint8_t *) c->dTmpC.p, c->tab.cfg.cv_mode);
     }
     HIPCHECK(c, hipGetLastError());
     if (angles_out) HIPCHECK(c, hipMemcpyAsync(angles_out, c->dDso[7].p, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
@@ -1384,7 +1415,7 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
     if (cnt > 0) launch_dso_compact(c->stream, (const int *) dCellCnt.p, (const unsigned *) dCellXY.p, nInner, n_existing, dList.p, (unsigned *) dNewXY.p);
     {
         ProfScope ps(c, KK_DESCRIBE);
-        launch_describe_list(c->stream, fs, dGeom, dList.p, total, 0, (float *) dAng.p, (uint8_t *) c->dTmpC.p);
+        launch_describe_list(c->stream, fs, dGeom, dList.p, total, 0, (float *) dAng.p, (uint8_t *) c->dTmpC.p, c->tab.cfg.cv_mode);
     }
     HIPCHECK(c, hipGetLastError());
     std::vector<float> ang(total);

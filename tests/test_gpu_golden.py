@@ -78,6 +78,7 @@ def test_gpu_reproduces_extract_goldens():
     from tests.test_oracle_golden import CASES, GOLD as EG
     for name, w, h, seed, cfg in CASES:
         img = synth_frame(seed, w, h)
-        k, d = Extractor(*cfg, max_width=w, max_height=h, max_batch=1).extract(img)
-        assert len(k) == int(EG[name + "_n"][0])
-        assert hashlib.sha256(k.tobytes() + d.tobytes()).digest() == EG[name + "_sha"].tobytes(), name
+        for mode in (0, 1, 2):   # ygzf_cv_mode: the three GaussianBlur generations
+            k, d = Extractor(*cfg, max_width=w, max_height=h, max_batch=1, cv_mode=mode).extract(img)
+            assert len(k) == int(EG[name + "_n"][0])
+            assert hashlib.sha256(k.tobytes() + d.tobytes()).digest() == EG["%s_m%d_sha" % (name, mode)].tobytes(), (name, mode)

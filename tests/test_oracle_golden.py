@@ -15,14 +15,16 @@ CASES = [("vga_s0", 640, 480, 0, (1000, 1.2, 8, 20, 7)), ("vga_s1", 640, 480, 1,
          ("small_s4", 320, 240, 4, (500, 1.2, 8, 20, 7))]
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("name,w,h,seed,cfg", CASES)
-def test_oracle_matches_golden(oracle, name, w, h, seed, cfg):
+def test_oracle_matches_golden(oracle, name, w, h, seed, cfg, mode):
     img = synth_frame(seed, w, h)
     assert hashlib.sha256(img.tobytes()).digest() == GOLD[name + "_img_sha"].tobytes(), "synthetic generator drifted"
-    k, d = oracle.Extractor(*cfg).extract(img)
+    with oracle.cv_mode(mode):
+        k, d = oracle.Extractor(*cfg).extract(img)
     assert len(k) == int(GOLD[name + "_n"][0])
-    assert hashlib.sha256(k.tobytes() + d.tobytes()).digest() == GOLD[name + "_sha"].tobytes()
-    if name + "_kps" in GOLD:
+    assert hashlib.sha256(k.tobytes() + d.tobytes()).digest() == GOLD["%s_m%d_sha" % (name, mode)].tobytes()
+    if mode == 0 and name + "_kps" in GOLD:
         assert (k == GOLD[name + "_kps"]).all() and (d == GOLD[name + "_desc"]).all()
 
 
