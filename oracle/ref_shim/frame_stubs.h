@@ -62,9 +62,18 @@ public:
     void update(const Vector3d &, const Vector3d &, double) {}
 };
 // include/ORBVocabulary.h: DBoW2::TemplatedVocabulary<...>; Frame::ComputeBoW calls transform()
+#ifdef YGZ_BOUNDARY_BUILD
+// boundary build (tests/cpp/build_boundary.sh: the reference's own Frame.cc over the PRODUCT's class shells): ExtractFeatures() ends in
+// ComputeBoW(), so the vocabulary must be callable; the test driver supplies the body
+class ORBVocabulary {
+public:
+    void transform(const std::vector<cv::Mat> &features, DBoW2::BowVector &v, DBoW2::FeatureVector &fv, int levelsup) const;
+};
+#else
 class ORBVocabulary {
 public:
     template <class D> void transform(const D &, DBoW2::BowVector &, DBoW2::FeatureVector &, int) const { yr_unsupported("ORBVocabulary::transform"); }
 };
+#endif
 }  // namespace ygz
 #endif

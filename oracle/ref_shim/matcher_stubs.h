@@ -117,6 +117,18 @@ using Eigen::Matrix3f;
 using Eigen::Vector2f;
 using Eigen::Vector3f;
 
+namespace Eigen {
+struct Quaternionf {   // Eigen::Quaternionf(w, x, y, z) with coefficient accessors: what the product's class shells use to cross their C ABI
+    float c[4];       // x, y, z, w (Eigen's storage order)
+    Quaternionf() { c[0] = c[1] = c[2] = 0; c[3] = 1; }
+    Quaternionf(float w, float x, float y, float z) { c[0] = x; c[1] = y; c[2] = z; c[3] = w; }
+    float x() const { return c[0]; }
+    float y() const { return c[1]; }
+    float z() const { return c[2]; }
+    float w() const { return c[3]; }
+};
+}  // namespace Eigen
+
 namespace Sophus {
 // The projection searches only read rotationMatrix() / translation() (R, t are what the harness puts there); the direct projection
 // composes, inverts and applies poses: that goes through the oracle's quaternion-form SE3f (Sophus semantics, ygz_oracle.h).
@@ -126,6 +138,13 @@ struct SE3f {
     ygzo::SE3f q;
     SE3f() { R(0, 0) = R(1, 1) = R(2, 2) = 1.f; }
     explicit SE3f(const ygzo::SE3f &q_) : q(q_) { q.RotationMatrix(R.m); t = Vector3f(q.t[0], q.t[1], q.t[2]); }
+    SE3f(const Eigen::Quaternionf &qq, const Vector3f &tt) {   // Sophus::SE3f(unit quaternion, translation)
+        for (int i = 0; i < 4; i++) q.q[i] = qq.c[i];
+        for (int i = 0; i < 3; i++) q.t[i] = tt[i];
+        q.RotationMatrix(R.m);
+        t = tt;
+    }
+    Eigen::Quaternionf unit_quaternion() const { return Eigen::Quaternionf(q.q[3], q.q[0], q.q[1], q.q[2]); }
     Matrix3f rotationMatrix() const { return R; }
     Vector3f translation() const { return t; }
     SE3f inverse() const { return SE3f(q.Inverse()); }
@@ -264,7 +283,15 @@ public:
     static cv::Mat toCvMat(const Vector3f &) { yr_unsupported("Converter::toCvMat"); }
     static cv::Mat toCvMat(const Matrix3f &) { yr_unsupported("Converter::toCvMat"); }
     template <class A, class B, class C> static void updateNS(A &, const B &, const C &) { yr_unsupported("Converter::updateNS"); }
+#ifdef YGZ_BOUNDARY_BUILD
+    static std::vector<cv::Mat> toDescriptorVector(const cv::Mat &D) {   // src/Converter.cc:52-59
+        std::vector<cv::Mat> v;
+        for (int j = 0; j < D.rows; j++) v.push_back(D.row(j));
+        return v;
+    }
+#else
     static std::vector<cv::Mat> toDescriptorVector(const cv::Mat &) { yr_unsupported("Converter::toDescriptorVector"); }
+#endif
 };
 
 // include/Align.h

@@ -3,19 +3,44 @@
 // silent return (src/ORBextractor.cc:972-973), zero keypoints => descriptors.release() (:990-991).
 #include "ORBextractor.h"
 
+#include "ygz_compat.h"   // reference tree: Frame.h / MapPoint.h / KeyFrame.h; stand-alone: the minimal types
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 
 #include "../../../include/ygzf.h"
 
 namespace ygz {
 
 int ORBextractor::sDevice = 0;
+int ORBextractor::sCvMode = 0;
 
+// src/ORBextractor.cc:412-470: the scale / sigma / per-level quota tables exist as soon as the object does -- Frame's constructors read
+// them before the first image is processed (src/Frame.cc:119-125 vs :148) -- so they are computed here on the host (ygzf_scale_tables_host:
+// the same arithmetic the device context uses), no device needed.
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
-    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
-    mvImagePyramid.resize(nlevels);
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
+      mDevice(sDevice), mCvMode(sCvMode) {
+    const int L = std::max(nlevels, 0);
+    mvScaleFactor.resize(L); mvInvScaleFactor.resize(L); mvLevelSigma2.resize(L); mvInvLevelSigma2.resize(L);
+    mnFeaturesPerLevel.resize(L);
+    mvImagePyramid.resize(L);
+    ygzf_extractor_cfg cfg = {nfeatures, (float) scaleFactor, nlevels, iniThFAST, minThFAST, mCvMode};
+    if (L > 0 && ygzf_scale_tables_host(&cfg, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
+                                        mnFeaturesPerLevel.data()) != YGZF_OK)
+        fprintf(stderr, "ygz::ORBextractor: bad configuration (nfeatures %d, scaleFactor %g, nlevels %d)\n", nfeatures, (double) scaleFactor, nlevels);
+    // row ends of the 31-px circular patch (:455-469), kept for parity with the reference's member; the device holds its own copy
+    const int HALF_PATCH_SIZE = 15;
+    umax.assign(HALF_PATCH_SIZE + 1, 0);
+    const int vmax = (int) std::floor(HALF_PATCH_SIZE * std::sqrt(2.f) / 2 + 1), vmin = (int) std::ceil(HALF_PATCH_SIZE * std::sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) umax[v] = (int) std::nearbyint(std::sqrt((double) HALF_PATCH_SIZE * HALF_PATCH_SIZE - v * v));
+    for (int v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
 }
 
 ORBextractor::~ORBextractor() { ygzf_destroy(mCtx); }
@@ -25,18 +50,14 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
     if (mCtx && w <= mCtxW && h <= mCtxH) return mCtx;
     ygzf_destroy(mCtx);
     mCtx = nullptr;
-    ygzf_extractor_cfg cfg = {nfeatures, (float) scaleFactor, nlevels, iniThFAST, minThFAST};
-    if (ygzf_create(sDevice, &cfg, w, h, 2, &mCtx) != YGZF_OK) {   // 2 frames: the stereo matcher stages both eyes
+    ygzf_extractor_cfg cfg = {nfeatures, (float) scaleFactor, nlevels, iniThFAST, minThFAST, mCvMode};
+    if (ygzf_create(mDevice, &cfg, w, h, 2, &mCtx) != YGZF_OK) {   // 2 frames: the stereo matcher stages both eyes
         fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(nullptr));
         mCtx = nullptr;
         return nullptr;
     }
     mCtxW = w;
     mCtxH = h;
-    mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels);
-    mnFeaturesPerLevel.resize(nlevels);
-    ygzf_get_scale_tables(mCtx, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data());
-    ygzf_get_features_per_level(mCtx, mnFeaturesPerLevel.data());
     return mCtx;
 }
 
@@ -49,9 +70,9 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
         int lw, lh;
         ygzf_level_size(c, image.cols, image.rows, l, &lw, &lh);
         mvImagePyramid[l] = cv::Mat(lh, lw, CV_8UC1);   // fresh buffer: Frames keep (shared) references to earlier levels
-        out[l] = mvImagePyramid[l].ptr<uint8_t>(0);
+        out[l] = mvImagePyramid[l].data;
     }
-    if (ygzf_compute_pyramid(c, image.ptr<uint8_t>(0), image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK)
+    if (ygzf_compute_pyramid(c, image.data, image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK)
         fprintf(stderr, "ygz::ORBextractor::ComputePyramid: %s\n", ygzf_last_error(c));
 }
 
@@ -65,7 +86,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     _keypoints.resize(cap > 0 ? cap : 0);
     std::vector<uint8_t> desc((size_t) (cap > 0 ? cap : 0) * 32);
     int n = 0;
-    if (ygzf_extract(c, image.ptr<uint8_t>(0), image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
+    if (ygzf_extract(c, image.data, image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
         YGZF_OK) {
         fprintf(stderr, "ygz::ORBextractor::operator(): %s\n", ygzf_last_error(c));
         n = 0;
@@ -77,7 +98,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     }
     _descriptors.create(n, 32, CV_8U);
     cv::Mat d = _descriptors.getMat();
-    for (int i = 0; i < n; i++) std::memcpy(d.ptr<uint8_t>(i), &desc[(size_t) i * 32], 32);
+    for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc[(size_t) i * 32], 32);
 }
 
 // src/ORBextractor.cc:1031-1127, the overload Frame::ExtractORB calls (src/Frame.cc:332-348):
@@ -110,7 +131,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         std::vector<uint8_t> d((size_t) cap * 32);
         for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];
         int total = 0;
-        if (ygzf_extract_dso(c, img.ptr<uint8_t>(0), img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &mnGridSize, &total) !=
+        if (ygzf_extract_dso(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &mnGridSize, &total) !=
             YGZF_OK) {
             fprintf(stderr, "ygz::ORBextractor (DSO_KEYPOINT): %s\n", ygzf_last_error(c));
             return;
@@ -124,7 +145,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         fresh.resize(cap > 0 ? cap : 0);
         descNew.resize((size_t) (cap > 0 ? cap : 0) * 32);
         int n = 0;
-        if (ygzf_extract(c, img.ptr<uint8_t>(0), img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n) != YGZF_OK) {
+        if (ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n) != YGZF_OK) {
             fprintf(stderr, "ygz::ORBextractor (ORBSLAM_KEYPOINT): %s\n", ygzf_last_error(c));
             return;
         }
@@ -141,7 +162,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
     }
     _descriptors.create(nkeypoints, 32, CV_8U);
     cv::Mat d = _descriptors.getMat();
-    for (int i = 0; i < N && i < nkeypoints; i++) std::memcpy(d.ptr<uint8_t>(i), &descExisting[(size_t) i * 32], 32);
+    for (int i = 0; i < N && i < nkeypoints; i++) std::memcpy(d.ptr(i), &descExisting[(size_t) i * 32], 32);
     for (int i = 0; i < (int) fresh.size() && N + i < nkeypoints; i++) std::memcpy(d.ptr<uint8_t>(N + i), &descNew[(size_t) i * 32], 32);   // offset = frame->N
     _keypoints.insert(_keypoints.end(), fresh.begin(), fresh.end());
 }
@@ -157,10 +178,10 @@ void ORBextractor::ComputeStereoMatches(Frame &F) {
     if (!c) return;
     const int Nr = (int) F.mvKeysRight.size();
     std::vector<uint8_t> dl((size_t) F.N * 32), dr((size_t) Nr * 32);
-    for (int i = 0; i < F.N; i++) std::memcpy(&dl[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
-    for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t) i * 32], F.mDescriptorsRight.ptr<uint8_t>(i), 32);
+    for (int i = 0; i < F.N; i++) std::memcpy(&dl[(size_t) i * 32], F.mDescriptors.ptr(i), 32);
+    for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t) i * 32], F.mDescriptorsRight.ptr(i), 32);
     if (imL.step != F.mImRight.step) { fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: left/right row steps differ\n"); return; }
-    if (ygzf_compute_stereo_matches(c, imL.ptr<uint8_t>(0), F.mImRight.ptr<uint8_t>(0), imL.cols, imL.rows, (int) imL.step, F.N,
+    if (ygzf_compute_stereo_matches(c, imL.data, F.mImRight.data, imL.cols, imL.rows, (int) imL.step, F.N,
                                     (const ygzf_kp *) F.mvKeys.data(), dl.data(), Nr, (const ygzf_kp *) F.mvKeysRight.data(), dr.data(), F.mb, F.mbf,
                                     F.mvuRight.data(), F.mvDepth.data()) != YGZF_OK)
         fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: %s\n", ygzf_last_error(c));

@@ -1,63 +1,103 @@
-// ORBextractor.h -- ygz::ORBextractor with the reference's public interface (include/ORBextractor.h:45-109), implemented
-// as a thin shell over the C ABI of libygzf (include/ygzf.h).  Tracking.cc / Frame.cc of the reference compile and link
-// against this class unchanged; see INTEGRATION.md.
-#ifndef YGZF_HOST_ORBEXTRACTOR_H
-#define YGZF_HOST_ORBEXTRACTOR_H
-#include <vector>
+// ORBextractor.h -- ygz::ORBextractor over libygzf: the drop-in replacement of the reference's include/ORBextractor.h.
+//
+// It IS that header for the reference tree: same include guard (YGZ_ORBEXTRACTOR_H_), same public interface
+// (include/ORBextractor.h:45-109: constructor, both operator() overloads, the six getters, the public mvImagePyramid, ComputePyramid,
+// the two enums) and the reference's protected data members, so that Frame.h / Frame.cc / Tracking.cc compile against it unchanged.
+// In the reference tree this file replaces include/ORBextractor.h and ORBextractor.cc replaces src/ORBextractor.cc (the
+// boundary test builds exactly that: tests/cpp/build_boundary.sh compiles the reference's own src/Frame.cc against this header).
+// What is not carried over are the protected CPU helpers (ComputeKeyPointsOctTree, DistributeOctTree, ... and class ExtractorNode): they
+// are implementation details of the file this one replaces, nothing outside src/ORBextractor.cc refers to them.
+//
+// Stand-alone (this repository, no OpenCV / Eigen installed) the same class compiles over the minimal types of ygz_compat.h.
+#ifndef YGZ_ORBEXTRACTOR_H_
+#define YGZ_ORBEXTRACTOR_H_
 
+#ifdef YGZF_WITH_REFERENCE_HEADERS
+#include "Common.h"   // the reference's include/Common.h (OpenCV, Eigen, Sophus, glog), as its own ORBextractor.h does
+#else
 #include "ygz_compat.h"
+#endif
+
+#include <vector>
 
 struct ygzf_ctx;
 
 namespace ygz {
+
 class Frame;
 
 class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    // which detector operator()(Frame*, ...) runs: the ORB-SLAM octree detector, SVO's grid FAST (never requested by the reference and
+    // marked "has a bug ... don't call" by its author, src/ORBextractor.cc:1191) or the DSO-like dynamic grid FAST
     typedef enum { ORBSLAM_KEYPOINT, FAST_KEYPOINT, DSO_KEYPOINT } KeyPointMethod;
 
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+
     ~ORBextractor();
-    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor(const ORBextractor &) = delete;              // owns a device context
     ORBextractor &operator=(const ORBextractor &) = delete;
 
     // Compute the ORB features and descriptors on an image (mask ignored, as in the reference).
     void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors);
-    // The overload Frame::ExtractORB uses.
+
+    // detect features for a frame: the overload Frame::ExtractORB uses
     void operator()(Frame *frame, std::vector<cv::KeyPoint> &keypoints, cv::OutputArray descriptors, KeyPointMethod method,
                     bool leftEye = true);
 
     int inline GetLevels() { return nlevels; }
+
     float inline GetScaleFactor() { return scaleFactor; }
+
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+
     std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Host-readable 8-bit levels (Frame clones them; ComputeStereoMatches reads them directly).
+    // Host-readable 8-bit levels (Frame clones them, src/Frame.cc:810-813; ComputeStereoMatches reads them directly, :515-623).
     std::vector<cv::Mat> mvImagePyramid;
+
     void ComputePyramid(cv::Mat image);
 
-    // Not in the reference class: the body Frame::ComputeStereoMatches (src/Frame.cc:509-682) is bound to.
+    // ---- additions (not in the reference class) -------------------------------------------------------------------------------------
+    // Device form of Frame::ComputeStereoMatches (src/Frame.cc:509-682): same outputs (mvuRight, mvDepth); a one-line binding in
+    // Frame.cc makes the reference use it, the reference's own CPU body keeps working on the pyramids above otherwise.
     void ComputeStereoMatches(Frame &F);
-
-    // Device on which new extractors create their context (default 0); set before constructing.
+    // HIP device on which extractors constructed from now on create their context (default 0).
     static int sDevice;
+    // ygzf_cv_mode of extractors constructed from now on: which OpenCV generation's 8-bit GaussianBlur the descriptors follow
+    // (include/ygzf.h; default 0 = OpenCV 2.4 / 3.2 on x86, the versions the reference names).
+    static int sCvMode;
 
 protected:
-    int nfeatures;
-    double scaleFactor;
-    int nlevels;
-    int iniThFAST, minThFAST;
+    int nfeatures = 0;
+    double scaleFactor = 0;
+    int nlevels = 0;
+    int iniThFAST = 0;
+    int minThFAST = 0;
+
     std::vector<int> mnFeaturesPerLevel;
-    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
-    int mnGridSize = -1;   // dynamic grid size of the DSO_KEYPOINT path (include/ORBextractor.h:171), persists across frames
+
+    std::vector<int> umax;
+    std::vector<float> mvScaleFactor;
+    std::vector<float> mvInvScaleFactor;
+    std::vector<float> mvLevelSigma2;
+    std::vector<float> mvInvLevelSigma2;
+
+    int mnGridSize = -1;   // dynamic grid size of the DSO_KEYPOINT detector (include/ORBextractor.h:171); -1: not yet set (:1298-1299)
 
 private:
     ygzf_ctx *ensureContext(int w, int h);
     ygzf_ctx *mCtx = nullptr;
     int mCtxW = 0, mCtxH = 0;
+    int mDevice = 0, mCvMode = 0;
 };
+
 }  // namespace ygz
+
 #endif

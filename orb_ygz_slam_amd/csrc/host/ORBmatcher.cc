@@ -1,57 +1,54 @@
-// ORBmatcher.cc -- shell of ygz::ORBmatcher over libygzf's C ABI (product code, host side): packs the Frame / MapPoint
-// fields SearchByProjection reads into the plain arrays of ygzf_search_by_projection_last and scatters the result back
-// into CurrentFrame.mvpMapPoints.
-#include "ORBmatcher.h"
+// ORBmatcher.cc -- the hot-path members of ygz::ORBmatcher over libygzf's C ABI (product code, host side): each packs the Frame / MapPoint /
+// KeyFrame fields the reference function reads into the plain arrays of its ygzf_* entry point and scatters the result back.
+// Inside the reference tree this file is compiled against the reference's own, unchanged include/ORBmatcher.h and replaces the bodies of
+//   ORBmatcher(float, bool), DescriptorDistance, the three Tracking-side SearchByProjection overloads, SearchByBoW(KeyFrame*, Frame&, ...),
+//   SearchForInitialization, FindDirectProjection                                (src/ORBmatcher.cc:36-133, 155-263, 375-478, 1218-1602);
+// the LocalMapping / LoopClosing members (Fuse x2, SearchBySim3, SearchForTriangulation, SearchByProjection(KF, Scw, ...),
+// SearchByBoW(KF, KF, ...)) are outside the hot path and keep their reference bodies (link recipe).
+#include "ORBextractor.h"   // first: inside the reference tree this is the replacement header (same include guard)
+#include "ORBmatcher.h"     // the reference's own header (reference tree) or standalone/ORBmatcher.h, by include path
+#include "ygz_compat.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <map>
 #include <mutex>
 
 #include "../../../include/ygzf.h"
+#include "ygzf_pool.h"
 
 namespace ygz {
 
 const int ORBmatcher::TH_HIGH = 100;
 const int ORBmatcher::TH_LOW = 50;
 const int ORBmatcher::HISTO_LENGTH = 30;
-int ORBmatcher::sDevice = 0;
 
 ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
 
 // One pair of 32-byte rows: a popcount over 4 x u64 on the host (a device launch for 64 bytes would be absurd); the batched
 // device form is ygzf_descriptor_distance / the matcher kernels.
 int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b) {
-    const uint64_t *pa = a.ptr<uint64_t>(), *pb = b.ptr<uint64_t>();
+    uint64_t pa[4], pb[4];
+    std::memcpy(pa, a.data, 32);
+    std::memcpy(pb, b.data, 32);
     int dist = 0;
     for (int i = 0; i < 4; i++) dist += __builtin_popcountll(pa[i] ^ pb[i]);
     return dist;
 }
 
 namespace {
-struct CtxPool {
-    std::mutex mu;
-    std::vector<ygzf_ctx *> free_;
-    ygzf_ctx *take(int device) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!free_.empty()) { ygzf_ctx *c = free_.back(); free_.pop_back(); return c; }
-        }
-        ygzf_extractor_cfg cfg = {1000, 1.2f, 8, 20, 7};   // the matcher only uses the context's stream and scratch buffers
-        ygzf_ctx *c = nullptr;
-        if (ygzf_create(device, &cfg, 64, 64, 1, &c) != YGZF_OK) { fprintf(stderr, "ygz::ORBmatcher: %s\n", ygzf_last_error(nullptr)); return nullptr; }
-        return c;
-    }
-    void give(ygzf_ctx *c) { std::lock_guard<std::mutex> lk(mu); free_.push_back(c); }
-    ~CtxPool() { for (ygzf_ctx *c : free_) ygzf_destroy(c); }
-};
-CtxPool &pool() { static CtxPool p; return p; }
+// ORBmatcher objects are created on the stack per call from several threads: every call leases a context of the device
+// extractors are created on (ORBextractor::sDevice) from the per-device pool.
+inline int device() { return ORBextractor::sDevice; }
 }  // namespace
 
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, bool checkLevel) {
     const int nt = CurrentFrame.N, nq = LastFrame.N;
     if (nt <= 0 || nq <= 0) return 0;
-    ygzf_ctx *c = pool().take(sDevice);
-    if (!c) return 0;
+    ygzf_host::Lease lease(device());
+    if (!lease) return 0;
+    ygzf_ctx *c = lease.get();
     // ---- pack LastFrame ----
     std::vector<uint8_t> valid(nq), outl(nq), obs(nq), mpdesc((size_t) nq * 32);
     std::vector<float> world((size_t) nq * 3);
@@ -92,10 +89,8 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
                                                   mbCheckOrientation, owner.data(), match.data(), &nmatches);
     if (rc != YGZF_OK) {
         fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
-        pool().give(c);
         return 0;
     }
-    pool().give(c);
     for (int i2 = 0; i2 < nt; i2++) {
         if (match[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[match[i2]];
         else if (match[i2] == -2) CurrentFrame.mvpMapPoints[i2] = static_cast<MapPoint *>(nullptr);   // culled by the rotation check
@@ -107,8 +102,9 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
 int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th, bool checkLevel) {
     const int nt = F.N, M = (int) vpMapPoints.size();
     if (nt <= 0 || M <= 0) return 0;
-    ygzf_ctx *c = pool().take(sDevice);
-    if (!c) return 0;
+    ygzf_host::Lease lease(device());
+    if (!lease) return 0;
+    ygzf_ctx *c = lease.get();
     std::vector<uint8_t> tiv(M), bad(M), obs(M), mpdesc((size_t) M * 32);
     std::vector<float> px(M), py(M), pxr(M), vc(M);
     std::vector<int> lvl(M);
@@ -143,7 +139,6 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
                                                        vc.data(), lvl.data(), mpdesc.data(), th, checkLevel, mfNNratio, owner.data(),
                                                        match.data(), &nmatches);
     if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
-    pool().give(c);
     if (rc != YGZF_OK) return 0;
     for (int i = 0; i < nt; i++)
         if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
@@ -203,14 +198,14 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     cur.nlevels = (int) CurrentFrame.mvScaleFactors.size();
     ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, CurrentFrame.mb, CurrentFrame.mbf,
                        Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    ygzf_ctx *c = pool().take(sDevice);
-    if (!c) return 0;
+    ygzf_host::Lease lease(device());
+    if (!lease) return 0;
+    ygzf_ctx *c = lease.get();
     std::vector<int> match(nt, -1);
     int nmatches = 0;
     const int rc = ygzf_search_by_projection_kf(c, &cur, &cam, M, valid.data(), pu.data(), pv.data(), lvl.data(), ang.data(), mpdesc.data(), th, ORBdist,
                                                 mbCheckOrientation, owner.data(), match.data(), &nmatches);
     if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
-    pool().give(c);
     if (rc != YGZF_OK) return 0;
     for (int i2 = 0; i2 < nt; i2++) {
         if (match[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = vpMPs[match[i2]];
@@ -250,15 +245,15 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
         std::memcpy(&kfDesc[(size_t) i * 32], pKF->mDescriptors.ptr<uint8_t>(i), 32);
     }
     for (int i = 0; i < F.N; i++) std::memcpy(&fDesc[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
-    ygzf_ctx *c = pool().take(sDevice);
-    if (!c) return 0;
+    ygzf_host::Lease lease(device());
+    if (!lease) return 0;
+    ygzf_ctx *c = lease.get();
     std::vector<int> match(F.N, -1);
     int nmatches = 0;
     const int rc = ygzf_search_by_bow(c, nNodes, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF, valid.data(), (const ygzf_kp *) pKF->mvKeys.data(),
                                       kfDesc.data(), F.N, (const ygzf_kp *) F.mvKeys.data(), fDesc.data(), mfNNratio, mbCheckOrientation, match.data(),
                                       &nmatches);
     if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByBoW: %s\n", ygzf_last_error(c));
-    pool().give(c);
     if (rc != YGZF_OK) return 0;
     for (int i = 0; i < F.N; i++)
         if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
@@ -279,14 +274,107 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     v2.scale_factors = F2.mvScaleFactors.data(); v2.nlevels = (int) F2.mvScaleFactors.size();
     ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F2.mb, F2.mbf, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
     static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f layout");
-    ygzf_ctx *c = pool().take(sDevice);
-    if (!c) return 0;
+    ygzf_host::Lease lease(device());
+    if (!lease) return 0;
+    ygzf_ctx *c = lease.get();
     int nmatches = 0;
     const int rc = ygzf_search_for_initialization(c, &v1, &v2, &cam, (float *) vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation,
                                                   vnMatches12.data(), &nmatches);
     if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchForInitialization: %s\n", ygzf_last_error(c));
-    pool().give(c);
     return rc == YGZF_OK ? nmatches : 0;
+}
+
+// src/ORBmatcher.cc:1574-1602 (+ GetWarpAffineMatrix :1525-1548, GetBestSearchLevel / GetBilateralInterpUchar include/ORBmatcher.h:185-211,
+// WarpAffine :1550-1572, ygz::Align2D src/Align.cc:8-104) for ONE (MapPoint, KeyFrame) candidate -- the signature Tracking::
+// SearchLocalPointsDirect calls (src/Tracking.cc:2210, :2289).  The KeyFrames' and the current frame's level-0 images live in an
+// HBM-resident cache on the device (their pyramids are rebuilt there by the same resize kernel the extractor used, so they equal the host
+// copies): a KeyFrame is uploaded the first time it is referenced, the current frame whenever its id changes; slots are recycled least
+// recently used.  A launch per candidate is latency-bound: callers that own the candidate loop should hand the whole list to
+// ygzf_find_direct_projection_batch instead (INTEGRATION.md shows that binding for SearchLocalPointsDirect); this member exists so that the
+// unmodified caller keeps working.
+namespace {
+struct DirectCache {
+    std::mutex mu;
+    ygzf_ctx *ctx = nullptr;
+    int w = 0, h = 0, nlevels = 0, device = -1;
+    float scaleFactor = 0;
+    static const int kSlots = 96;                    // 95 KeyFrames + the current frame
+    std::map<unsigned long, int> kfSlot;             // KeyFrame::mnId -> slot
+    std::vector<unsigned long> slotKf, slotUse;      // owner / last use per slot
+    unsigned long tick = 0, curId = ~0ul;
+    bool curValid = false;
+
+    bool prepare(int dev, int W, int H, int L, float sf) {
+        if (ctx && dev == device && W == w && H == h && L == nlevels && sf == scaleFactor) return true;
+        if (ctx) ygzf_destroy(ctx);
+        ctx = nullptr;
+        ygzf_extractor_cfg cfg = {1000, sf, L, 20, 7, 0};   // the pyramid geometry is all that matters here
+        if (ygzf_create(dev, &cfg, W, H, 1, &ctx) != YGZF_OK) { fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(nullptr)); ctx = nullptr; return false; }
+        if (ygzf_image_cache_reserve(ctx, kSlots, W, H) != YGZF_OK) { fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(ctx)); return false; }
+        device = dev; w = W; h = H; nlevels = L; scaleFactor = sf;
+        kfSlot.clear();
+        slotKf.assign(kSlots, ~0ul);
+        slotUse.assign(kSlots, 0);
+        curValid = false;
+        return true;
+    }
+    int keyframe_slot(unsigned long id, const cv::Mat &img0) {
+        auto it = kfSlot.find(id);
+        if (it != kfSlot.end()) { slotUse[it->second] = ++tick; return it->second; }
+        int victim = 1;                                // slot 0 is the current frame's
+        for (int s = 1; s < kSlots; s++)
+            if (slotUse[s] < slotUse[victim]) victim = s;
+        if (slotKf[victim] != ~0ul) kfSlot.erase(slotKf[victim]);
+        if (ygzf_image_cache_put(ctx, victim, img0.data, img0.cols, img0.rows, (int) img0.step) != YGZF_OK) {
+            fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(ctx));
+            slotKf[victim] = ~0ul;
+            return -1;
+        }
+        slotKf[victim] = id;
+        kfSlot[id] = victim;
+        slotUse[victim] = ++tick;
+        return victim;
+    }
+};
+DirectCache &direct_cache() { static DirectCache *c = new DirectCache(); return *c; }   // never destroyed (HIP may be gone at exit)
+}  // namespace
+
+bool ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level) {
+    const int L = (int) ref->mvImagePyramid.size();
+    if (L < 1 || (int) curr->mvImagePyramid.size() != L || (int) curr->mvScaleFactors.size() < L) return false;
+    const cv::Mat &cur0 = curr->mvImagePyramid[0], &ref0 = ref->mvImagePyramid[0];
+    if (cur0.cols != ref0.cols || cur0.rows != ref0.rows) return false;
+    DirectCache &dc = direct_cache();
+    std::lock_guard<std::mutex> lk(dc.mu);
+    if (!dc.prepare(device(), cur0.cols, cur0.rows, L, L > 1 ? curr->mvScaleFactors[1] : 1.2f)) return false;
+    if (!dc.curValid || dc.curId != curr->mnId) {
+        if (ygzf_image_cache_put(dc.ctx, 0, cur0.data, cur0.cols, cur0.rows, (int) cur0.step) != YGZF_OK) {
+            fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(dc.ctx));
+            return false;
+        }
+        dc.curId = curr->mnId;
+        dc.curValid = true;
+    }
+    const int slot = dc.keyframe_slot(ref->mnId, ref0);
+    if (slot < 0) return false;
+    const int index = (int) mp->GetObservations()[ref];
+    const cv::KeyPoint kp = ref->mvKeys[index];
+    float refT[7], curT[7], world[3], px[2] = {px_curr[0], px_curr[1]};
+    ygz_compat::se3_to7(ref->GetPose(), refT);
+    ygz_compat::se3_to7(curr->mTcw, curT);
+    ygz_compat::world_pos(mp, world);
+    ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, 0, 0, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
+    int level = 0;
+    uint8_t ok = 0;
+    static_assert(sizeof(cv::KeyPoint) == sizeof(ygzf_kp), "cv::KeyPoint layout");
+    if (ygzf_find_direct_projection_batch(dc.ctx, &cam, 0, curT, 1, &slot, refT, (const ygzf_kp *) &kp, world, px, &level, &ok, nullptr) != YGZF_OK) {
+        fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(dc.ctx));
+        return false;
+    }
+    px_curr[0] = px[0];
+    px_curr[1] = px[1];
+    search_level = level;
+    return ok != 0;
 }
 
 }  // namespace ygz

@@ -1,36 +1,39 @@
-// SparseImageAlign.cc -- shell of ygz::SparseImgAlign::run over libygzf's C ABI (product code, host side).
-#include "SparseImageAlign.h"
+// SparseImageAlign.cc -- ygz::SparseImgAlign over libygzf's C ABI (product code, host side): the replacement of the reference's
+// src/SparseImageAlign.cc.  Inside the reference tree it defines the members of the reference's OWN class (include/SparseImageAlign.h,
+// derived from NLLSSolver<6, SE3f>, unchanged): constructor, run, getFisherInformation, and the solver's virtual hooks, which are never
+// entered because the whole Gauss-Newton loop (all levels x iterations, include/NLSSolver_impl.hpp:17-91) runs inside one kernel.
+// Stand-alone it defines the same members of standalone/SparseImageAlign.h.
+#include "ORBextractor.h"        // first: inside the reference tree this is the replacement header (same include guard)
+#include "SparseImageAlign.h"    // the reference's own header (reference tree) or standalone/SparseImageAlign.h, by include path
+#include "ygz_compat.h"
 
 #include <cstdio>
 #include <vector>
 
 #include "../../../include/ygzf.h"
+#include "ygzf_pool.h"
 
 namespace ygz {
 
-int SparseImgAlign::sDevice = 0;
-
-SparseImgAlign::SparseImgAlign(int max_level, int min_level, int n_iter, Method method, bool, bool)
-    : n_iter_(n_iter), max_level_(max_level), min_level_(min_level) {
-    for (float &v : H_) v = 0.f;
-    if (method != GaussNewton) fprintf(stderr, "ygz::SparseImgAlign: only GaussNewton (the reference's only use) is implemented\n");
+SparseImgAlign::SparseImgAlign(int max_level, int min_level, int n_iter, Method method, bool display, bool verbose)
+    : display_(display), max_level_(max_level), min_level_(min_level) {   // src/SparseImageAlign.cc:7-18
+    n_iter_ = n_iter;
+    n_iter_init_ = n_iter_;
+    method_ = method;
+    verbose_ = verbose;
+    eps_ = 0.000001;
+    if (method != GaussNewton) fprintf(stderr, "ygz::SparseImgAlign: only GaussNewton (the reference's only use, src/Tracking.cc:207) runs on the device\n");
 }
 
-SparseImgAlign::~SparseImgAlign() { ygzf_destroy(ctx_); }
-
 size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
+    n_meas_ = 0;
     if (ref->mvKeys.empty()) {
-        fprintf(stderr, "SparseImgAlign: no features to track!\n");
+        fprintf(stderr, "SparseImgAlign: no features to track!\n");   // the reference logs the same and returns 0 (:24-27)
         return 0;
     }
-    if (!ctx_) {
-        ygzf_extractor_cfg cfg = {1000, 1.2f, 8, 20, 7};   // only the stream and scratch buffers of the context are used
-        if (ygzf_create(sDevice, &cfg, 64, 64, 1, &ctx_) != YGZF_OK) {
-            fprintf(stderr, "ygz::SparseImgAlign: %s\n", ygzf_last_error(nullptr));
-            ctx_ = nullptr;
-            return 0;
-        }
-    }
+    ygzf_host::Lease lease(ORBextractor::sDevice);
+    if (!lease) return 0;
+    ygzf_ctx *ctx = lease.get();
     const int N = ref->N;
     std::vector<uint8_t> valid(N), outl(N);
     std::vector<float> world((size_t) N * 3);
@@ -43,7 +46,7 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
     auto fill = [](Frame *f, ygzf_sia_frame &o, std::vector<const uint8_t *> &lv, std::vector<int> &w, std::vector<int> &h) {
         const int L = (int) f->mvImagePyramid.size();
         lv.resize(L); w.resize(L); h.resize(L);
-        for (int l = 0; l < L; l++) { lv[l] = f->mvImagePyramid[l].ptr<uint8_t>(0); w[l] = f->mvImagePyramid[l].cols; h[l] = f->mvImagePyramid[l].rows; }
+        for (int l = 0; l < L; l++) { lv[l] = f->mvImagePyramid[l].data; w[l] = f->mvImagePyramid[l].cols; h[l] = f->mvImagePyramid[l].rows; }
         o.nlevels = L; o.levels = lv.data(); o.level_w = w.data(); o.level_h = h.data();
         ygz_compat::se3_to7(f->mTcw, o.Tcw);
     };
@@ -58,19 +61,44 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
     R.outlier = outl.data();
     R.mp_world = world.data();
     ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, 0, 0, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    float T7[7];
+    float T7[7], H36[36];
     size_t ret = 0;
-    if (ygzf_sia_run(ctx_, &R, &C, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, n_iter_, T7, &ret, nullptr, H_) != YGZF_OK) {
-        fprintf(stderr, "ygz::SparseImgAlign::run: %s\n", ygzf_last_error(ctx_));
+    const int kIterations = 10;   // run() overrides the constructor's n_iter with iterations[level] = 10 on every level (:38-43)
+    if (ygzf_sia_run(ctx, &R, &C, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret, nullptr, H36) != YGZF_OK) {
+        fprintf(stderr, "ygz::SparseImgAlign::run: %s\n", ygzf_last_error(ctx));
         return 0;
     }
-    TCR = ygz_compat::se3_from7(T7);
+    n_iter_ = kIterations;
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) H_(r, c) = H36[6 * r + c];
+    n_meas_ = ret * 16;   // patch_area_
+    TCR = ygz_compat::se3_from7(T7);   // the reference assigns T_cur_from_ref whenever it got past the feature check (:46)
     return ret;
 }
 
-void SparseImgAlign::getFisherInformation(float out36[36]) const {
-    const float sigma_i_sq = 5e-4f * 255 * 255;   // image noise, src/SparseImageAlign.cc:52
-    for (int i = 0; i < 36; i++) out36[i] = H_[i] / sigma_i_sq;
+#ifdef YGZF_WITH_REFERENCE_HEADERS
+typedef Matrix<float, 6, 6> FisherMatrix;
+#else
+typedef Matrix6f FisherMatrix;
+#endif
+
+FisherMatrix SparseImgAlign::getFisherInformation() {   // :51-55
+    const float sigma_i_sq = 5e-4 * 255 * 255;   // image noise
+    FisherMatrix I;
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) I(r, c) = H_(r, c) / sigma_i_sq;
+    return I;
 }
+
+#ifdef YGZF_WITH_REFERENCE_HEADERS
+// The solver hooks NLLSSolver<6, SE3f> declares pure virtual (include/NLSSolver.h:60-84): required by the class's vtable, not entered --
+// run() above does not go through optimize().
+void SparseImgAlign::precomputeReferencePatches() {}
+float SparseImgAlign::computeResiduals(const SE3f &, bool, bool) { return 0.f; }
+int SparseImgAlign::solve() { return 0; }
+void SparseImgAlign::update(const ModelType &old_model, ModelType &new_model) { new_model = old_model; }
+void SparseImgAlign::startIteration() {}
+void SparseImgAlign::finishIteration() {}
+#endif
 
 }  // namespace ygz

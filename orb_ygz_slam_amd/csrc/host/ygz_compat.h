@@ -1,8 +1,9 @@
 // ygz_compat.h -- the types the three class shells are written against (product code, host side).
 //
 // Built inside the reference tree (-DYGZF_WITH_REFERENCE_HEADERS) this header simply pulls the
-// reference's own Common.h / Frame.h / MapPoint.h (OpenCV cv::Mat / cv::KeyPoint, Sophus SE3f, Eigen) and defines the few
-// adapters below on top of them.  Built stand-alone (this repository: no OpenCV / Eigen / Sophus installed) it provides a
+// reference's own Common.h / Frame.h / MapPoint.h / KeyFrame.h (OpenCV cv::Mat / cv::KeyPoint, Sophus SE3f, Eigen) and defines the
+// few adapters below on top of them; it is included by the shells' .cc files only (Frame.h itself includes ORBextractor.h).
+// Built stand-alone (this repository: no OpenCV / Eigen / Sophus installed) it provides a
 // minimal stand-in for exactly the slice of those types the hot-path signatures touch, layout-compatible where layout
 // matters (cv::KeyPoint = 7 x 4 bytes, continuous 8-bit Mats), so that the shells compile and are testable here.
 #ifndef YGZF_COMPAT_H
@@ -12,21 +13,22 @@
 #include "Common.h"     // reference include/Common.h: OpenCV, Eigen, Sophus, glog, typedefs (SE3f, Vector3f, ...)
 #include "Frame.h"
 #include "MapPoint.h"
-namespace ygz_compat {
-inline void se3_to7(const ygz::SE3f &T, float o[7]) {
-    const auto &q = T.unit_quaternion();
+#include "KeyFrame.h"
+namespace ygz_compat {   // SE3f / Vector3f / Matrix3f are the global names include/Common.h brings in (using Sophus::SE3f, Eigen::...)
+inline void se3_to7(const SE3f &T, float o[7]) {
+    const Eigen::Quaternionf q = T.unit_quaternion();
     o[0] = q.x(); o[1] = q.y(); o[2] = q.z(); o[3] = q.w();
     o[4] = T.translation()[0]; o[5] = T.translation()[1]; o[6] = T.translation()[2];
 }
-inline ygz::SE3f se3_from7(const float i[7]) {
-    return ygz::SE3f(Eigen::Quaternionf(i[3], i[0], i[1], i[2]), ygz::Vector3f(i[4], i[5], i[6]));
+inline SE3f se3_from7(const float i[7]) {
+    return SE3f(Eigen::Quaternionf(i[3], i[0], i[1], i[2]), Vector3f(i[4], i[5], i[6]));
 }
-inline void se3_to_Rt(const ygz::SE3f &T, float R[9], float t[3]) {
-    const Eigen::Matrix3f M = T.rotationMatrix();
+inline void se3_to_Rt(const SE3f &T, float R[9], float t[3]) {
+    const Matrix3f M = T.rotationMatrix();
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = M(r, c);
     for (int r = 0; r < 3; r++) t[r] = T.translation()[r];
 }
-inline void world_pos(ygz::MapPoint *mp, float o[3]) { const ygz::Vector3f p = mp->GetWorldPos(); o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+inline void world_pos(ygz::MapPoint *mp, float o[3]) { const Vector3f p = mp->GetWorldPos(); o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
 }  // namespace ygz_compat
 #else  // ---------------------------------------------------------------------------------------------- stand-alone shim
 #include <cstdint>
@@ -40,6 +42,7 @@ inline void world_pos(ygz::MapPoint *mp, float o[3]) { const ygz::Vector3f p = m
 #define CV_8UC1 0
 #define CV_32F 5
 
+#include <set>
 namespace cv {
 struct Point2f { float x, y; };
 struct KeyPoint {  // bit-compatible with cv::KeyPoint
@@ -107,6 +110,9 @@ typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;   // no
 
 namespace ygz {
 struct Vector3f { float v[3]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
+struct Matrix3f { float m[9]; };
+struct Vector2f { float v[2]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
+class KeyFrame;
 struct SE3f {  // Sophus::SE3f storage: unit quaternion (x,y,z,w) + translation
     float q[4] = {0, 0, 0, 1};
     float t[3] = {0, 0, 0};
@@ -131,6 +137,8 @@ public:
     float GetMinDistanceInvariance() const { return 0.8f * mfMinDistance; }
     float GetMaxDistanceInvariance() const { return 1.2f * mfMaxDistance; }
     inline int PredictScale(const float &currentDist, Frame *pF);
+    std::map<KeyFrame *, size_t> mObservations;
+    std::map<KeyFrame *, size_t> GetObservations() const { return mObservations; }
 };
 class Frame {  // the members the hot path reads/writes (reference include/Frame.h)
 public:
@@ -149,6 +157,7 @@ public:
     float mfLogScaleFactor = 0;
     int mnScaleLevels = 0;
     DBoW2::FeatureVector mFeatVec;
+    long unsigned int mnId = 0;
 };
 inline int MapPoint::PredictScale(const float &currentDist, Frame *pF) {  // src/MapPoint.cc:359-373
     float ratio = mfMaxDistance / currentDist;
@@ -164,6 +173,11 @@ public:
     std::vector<MapPoint *> GetMapPointMatches() const { return mvpMapPoints; }
     cv::Mat mDescriptors;
     DBoW2::FeatureVector mFeatVec;
+    // read by FindDirectProjection (src/ORBmatcher.cc:1574-1602)
+    long unsigned int mnId = 0;
+    std::vector<cv::Mat> mvImagePyramid;
+    SE3f mPose;
+    SE3f GetPose() const { return mPose; }
 };
 }  // namespace ygz
 

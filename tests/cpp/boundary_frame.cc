@@ -1,0 +1,210 @@
+// tests/cpp/boundary_frame.cc -- TEST DRIVER of the drop-in boundary: the REFERENCE's own src/Frame.cc (compiled where it lies, real
+// include/Frame.h) runs on top of the PRODUCT's class shells (orb_ygz_slam_amd/csrc/host: ygz::ORBextractor replaces include/ORBextractor.h +
+// src/ORBextractor.cc, ygz::ORBmatcher's hot-path members replace those of src/ORBmatcher.cc) and libygzf.  Built by
+// tests/cpp/build_boundary.sh; OpenCV / Eigen / Sophus are the stand-ins of oracle/ref_shim (not installed here), whose compute primitives
+// abort in this build (tests/cpp/mini_cv_nocompute.cpp).  tests/test_gpu_boundary.py compares everything dumped here with the oracle.
+//
+// What runs, in the reference's own code:
+//   ygz::Frame::Frame(imLeft, imRight, t, &exL, &exR, voc, K, dist, bf, thDepth)   src/Frame.cc:190-230  -> GetLevels / GetScaleFactor(s) ... of
+//        the shell BEFORE any image, then Frame::ComputeImagePyramid -> shell ComputePyramid (HIP) + clones of mvImagePyramid
+//   Frame::ExtractFeatures()                                                   :716-795  -> two std::threads, Frame::ExtractORB(0 / 1) -> shell
+//        operator()(Frame*, keys, desc, ORBSLAM_KEYPOINT, leftEye) on two contexts concurrently (HIP); then the reference's CPU
+//        Frame::ComputeStereoMatches (:509-682) reading mpORBextractor{Left,Right}->mvImagePyramid (host copies of the device pyramids) and
+//        calling ORBmatcher::DescriptorDistance (shell); AssignFeaturesToGrid; ComputeBoW
+//   ygz::Frame::Frame(imGray, t, &ex, voc, K, dist, bf, thDepth) + ExtractFeatures()   monocular, on a second image
+//   a direct-tracked frame: N > 0 existing keys && !mbFeatureExtracted -> ExtractORB takes the DSO_KEYPOINT branch (:335-337)
+//   ORBmatcher(0.9, true).SearchByProjection(cur, last, 15, mono) on those reference-built Frames (Tracking::TrackWithMotionModel's call),
+//   Frame::isInFrustum (reference, CPU) feeding ORBmatcher(0.8).SearchByProjection(F, mappoints, th) (Tracking::SearchLocalPoints),
+//   SparseImgAlign(nLevels-1, 1).run(&last, &cur, TCR) (Tracking.cc:207, :2087) through the reference's own class declaration,
+//   and the shell's device ComputeStereoMatches(F) beside the reference's CPU one.
+// usage: boundary_frame <dir>   reads <dir>/left.u8 right.u8 next.u8 (W x H u8, sizes in <dir>/size.i32), writes *.bin
+#include <opencv2/core/core.hpp>
+
+#define private public
+#define protected public
+#include "ORBmatcher.h"          // the reference's: pulls the real Frame.h (whose ORBextractor.h is the product's, same guard)
+#include "SparseImageAlign.h"    // the reference's
+#undef private
+#undef protected
+
+#include <cstdio>
+#include <string>
+
+static std::vector<unsigned char> slurp(const std::string &p) {
+    FILE *f = fopen(p.c_str(), "rb");
+    if (!f) { perror(p.c_str()); exit(2); }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> b(n);
+    if (n && fread(b.data(), 1, n, f) != (size_t) n) exit(2);
+    fclose(f);
+    return b;
+}
+static void dump(const std::string &p, const void *d, size_t n) {
+    FILE *f = fopen(p.c_str(), "wb");
+    if (n) fwrite(d, 1, n, f);
+    fclose(f);
+}
+static void dump_desc(const std::string &p, const cv::Mat &D, int n) {
+    std::vector<unsigned char> b((size_t) n * 32);
+    for (int i = 0; i < n; i++) std::memcpy(&b[(size_t) i * 32], D.ptr(i), 32);
+    dump(p, b.data(), b.size());
+}
+
+namespace ygz {
+// src/MapPoint.cc:359-373 for the plain-data MapPoint of oracle/ref_shim (the reference's MapPoint.cc needs Map / KeyFrame machinery)
+int MapPoint::PredictScale(const float &currentDist, Frame *pF) {
+    const float ratio = mfMaxDistance / currentDist;
+    int nScale = (int) std::ceil(std::log(ratio) / pF->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= pF->mnScaleLevels) nScale = pF->mnScaleLevels - 1;
+    return nScale;
+}
+int MapPoint::PredictScale(const float &, KeyFrame *) { yr_unsupported("MapPoint::PredictScale(KeyFrame*)"); }
+// the vocabulary is outside this test (Frame::ComputeBoW has its own device path and test): leave the vectors empty
+void ORBVocabulary::transform(const std::vector<cv::Mat> &, DBoW2::BowVector &, DBoW2::FeatureVector &, int) const {}
+}  // namespace ygz
+
+int main(int argc, char **argv) {
+    using namespace ygz;
+    if (argc < 2) return 2;
+    const std::string dir = argv[1];
+    std::vector<unsigned char> sz = slurp(dir + "/size.i32");
+    const int W = ((const int *) sz.data())[0], H = ((const int *) sz.data())[1], NF = ((const int *) sz.data())[2], L = ((const int *) sz.data())[3];
+    std::vector<unsigned char> il = slurp(dir + "/left.u8"), ir = slurp(dir + "/right.u8"), in = slurp(dir + "/next.u8");
+    auto wrap = [&](std::vector<unsigned char> &b) { cv::Mat m(H, W, CV_8UC1); std::memcpy(m.data, b.data(), (size_t) W * H); return m; };
+    const cv::Mat imL = wrap(il), imR = wrap(ir), imN = wrap(in);
+    Matrix3f K;
+    K(0, 0) = 458.654f; K(1, 1) = 457.296f; K(0, 2) = 367.215f; K(1, 2) = 248.375f; K(2, 2) = 1.f;
+    cv::Mat dist(4, 1, CV_32F);
+    std::memset(dist.data, 0, 4 * sizeof(float));
+    const float bf = 47.9f, thDepth = 35.f;
+    ORBVocabulary voc;
+
+    // Tracking::Tracking (src/Tracking.cc:179-185): the extractors exist before the first frame arrives
+    ORBextractor exL(NF, 1.2f, L, 20, 7), exR(NF, 1.2f, L, 20, 7);
+
+    // ---- stereo frame through the reference's constructor + ExtractFeatures ------------------------------------------------------------
+    Frame S(imL, imR, 0.0, &exL, &exR, &voc, K, dist, bf, thDepth);
+    if ((int) S.mvScaleFactors.size() != L || (int) S.mvInvLevelSigma2.size() != L || (int) S.mvImagePyramid.size() != L) {
+        fprintf(stderr, "scale tables / pyramid missing after the Frame constructor\n");
+        return 3;
+    }
+    dump(dir + "/s_scale.bin", S.mvScaleFactors.data(), L * sizeof(float));
+    for (int l = 0; l < L; l++) {
+        const cv::Mat &m = S.mvImagePyramid[l];
+        std::vector<unsigned char> b((size_t) m.rows * m.cols);
+        for (int y = 0; y < m.rows; y++) std::memcpy(&b[(size_t) y * m.cols], m.ptr(y), (size_t) m.cols);
+        dump(dir + "/s_pyr" + std::to_string(l) + ".bin", b.data(), b.size());
+    }
+    S.ExtractFeatures();
+    dump(dir + "/s_keys.bin", S.mvKeys.data(), S.mvKeys.size() * sizeof(cv::KeyPoint));
+    dump_desc(dir + "/s_desc.bin", S.mDescriptors, S.N);
+    dump(dir + "/s_keysr.bin", S.mvKeysRight.data(), S.mvKeysRight.size() * sizeof(cv::KeyPoint));
+    dump_desc(dir + "/s_descr.bin", S.mDescriptorsRight, (int) S.mvKeysRight.size());
+    dump(dir + "/s_uright.bin", S.mvuRight.data(), S.mvuRight.size() * sizeof(float));     // the REFERENCE's CPU ComputeStereoMatches on the HIP pyramids
+    dump(dir + "/s_depth.bin", S.mvDepth.data(), S.mvDepth.size() * sizeof(float));
+    {   // grid built by the reference's AssignFeaturesToGrid: a few GetFeaturesInArea queries as a fingerprint
+        std::vector<int> q;
+        for (int k = 0; k < 12; k++) {
+            const std::vector<size_t> v = S.GetFeaturesInArea(60.f + 55.f * k, 40.f + 33.f * k, 25.f, k % 3 ? -1 : 0, k % 3 ? -1 : 2);
+            q.push_back((int) v.size());
+            for (size_t i : v) q.push_back((int) i);
+        }
+        dump(dir + "/s_grid.bin", q.data(), q.size() * sizeof(int));
+    }
+    {   // the shell's device ComputeStereoMatches on the same frame: must equal the reference's CPU result
+        Frame S2(S);
+        S2.mpORBextractorLeft = &exL;
+        exL.ComputeStereoMatches(S2);
+        dump(dir + "/s_uright_dev.bin", S2.mvuRight.data(), S2.mvuRight.size() * sizeof(float));
+        dump(dir + "/s_depth_dev.bin", S2.mvDepth.data(), S2.mvDepth.size() * sizeof(float));
+    }
+
+    // ---- monocular frames: last = left image, cur = next image ---------------------------------------------------------------------------
+    ORBextractor ex(NF, 1.2f, L, 20, 7);
+    Frame last(imL, 0.0, &ex, &voc, K, dist, bf, thDepth), cur(imN, 0.1, &ex, &voc, K, dist, bf, thDepth);
+    last.ExtractFeatures();
+    cur.ExtractFeatures();
+    dump(dir + "/m_keys_last.bin", last.mvKeys.data(), last.mvKeys.size() * sizeof(cv::KeyPoint));
+    dump(dir + "/m_keys_cur.bin", cur.mvKeys.data(), cur.mvKeys.size() * sizeof(cv::KeyPoint));
+    dump_desc(dir + "/m_desc_cur.bin", cur.mDescriptors, cur.N);
+    // MapPoints of `last` on the plane z = depth
+    const float depth = 4.0f;
+    std::vector<MapPoint> mps(last.N);
+    for (int i = 0; i < last.N; i++) {
+        mps[i].mWorldPos = Vector3f((last.mvKeys[i].pt.x - Frame::cx) / Frame::fx * depth, (last.mvKeys[i].pt.y - Frame::cy) / Frame::fy * depth, depth);
+        mps[i].mNormal = Vector3f(0, 0, 1);
+        mps[i].mDescriptor = last.mDescriptors.row(i).clone();
+        mps[i].nObs = 1;
+        mps[i].mfMaxDistance = depth * last.mvScaleFactors[last.mvKeys[i].octave];
+        mps[i].maxDistInv = 1.2f * mps[i].mfMaxDistance;
+        mps[i].minDistInv = 0.8f * mps[i].mfMaxDistance / last.mvScaleFactors[L - 1];
+        last.mvpMapPoints[i] = &mps[i];
+    }
+    last.SetPose(SE3f());
+    // TrackWithSparseAlignment (src/Tracking.cc:2061-2105)
+    SparseImgAlign align(L - 1, 1);
+    SE3f TCR;
+    cur.SetPose(SE3f());
+    const size_t ret = align.run(&last, &cur, TCR);
+    float t7[8];
+    { const Eigen::Quaternionf q = TCR.unit_quaternion(); t7[0] = q.x(); t7[1] = q.y(); t7[2] = q.z(); t7[3] = q.w(); }
+    for (int i = 0; i < 3; i++) t7[4 + i] = TCR.translation()[i];
+    t7[7] = (float) ret;
+    dump(dir + "/m_tcr.bin", t7, sizeof t7);
+    { const Matrix<float, 6, 6> I = align.getFisherInformation(); float f36[36]; for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) f36[6 * r + c] = I(r, c); dump(dir + "/m_fisher.bin", f36, sizeof f36); }
+    cur.SetPose(TCR * last.mTcw);                                        // :2095
+    {
+        float Rt[12];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rt[3 * r + c] = cur.mRcw(r, c);
+        for (int r = 0; r < 3; r++) Rt[9 + r] = cur.mtcw[r];
+        dump(dir + "/m_pose.bin", Rt, sizeof Rt);
+    }
+    // TrackWithMotionModel (:1072-1093)
+    ORBmatcher matcher(0.9, true);
+    const int nm = matcher.SearchByProjection(cur, last, 15, true);
+    std::vector<int> assigned(cur.N, -1);
+    for (int i = 0; i < cur.N; i++)
+        if (cur.mvpMapPoints[i]) assigned[i] = (int) (cur.mvpMapPoints[i] - mps.data());
+    dump(dir + "/m_match.bin", assigned.data(), assigned.size() * sizeof(int));
+    dump(dir + "/m_nmatch.bin", &nm, sizeof nm);
+    // SearchLocalPoints (:1544-1593): the reference's isInFrustum marks the points, the shell searches
+    {
+        Frame cur2(cur);
+        cur2.mvpMapPoints.assign(cur2.N, (MapPoint *) nullptr);
+        cur2.SetPose(cur.mTcw);
+        std::vector<MapPoint *> local;
+        std::vector<float> frustum;
+        for (int i = 0; i < last.N; i++) {
+            const bool in = cur2.isInFrustum(&mps[i], 0.5f);
+            frustum.push_back(in ? 1.f : 0.f);
+            frustum.push_back(mps[i].mTrackProjX); frustum.push_back(mps[i].mTrackProjY); frustum.push_back((float) mps[i].mnTrackScaleLevel);
+            frustum.push_back(mps[i].mTrackViewCos);
+            local.push_back(&mps[i]);
+        }
+        dump(dir + "/m_frustum.bin", frustum.data(), frustum.size() * sizeof(float));
+        ORBmatcher m2(0.8, true);
+        const int nm2 = m2.SearchByProjection(cur2, local, 3, false);
+        std::vector<int> a2(cur2.N, -1);
+        for (int i = 0; i < cur2.N; i++)
+            if (cur2.mvpMapPoints[i]) a2[i] = (int) (cur2.mvpMapPoints[i] - mps.data());
+        dump(dir + "/m_match2.bin", a2.data(), a2.size() * sizeof(int));
+        dump(dir + "/m_nmatch2.bin", &nm2, sizeof nm2);
+    }
+    // ---- direct-tracked frame: keys carried over from the last frame, no extraction yet -> ExtractORB takes DSO_KEYPOINT (src/Frame.cc:335-337)
+    {
+        Frame D(imN, 0.2, &ex, &voc, K, dist, bf, thDepth);
+        const int keep = std::min(cur.N, 120);
+        D.mvKeys.assign(cur.mvKeys.begin(), cur.mvKeys.begin() + keep);
+        D.N = keep;
+        D.mvpMapPoints.assign(keep, (MapPoint *) nullptr);
+        D.mvbOutlier.assign(keep, false);
+        D.ExtractFeatures();
+        dump(dir + "/d_keys.bin", D.mvKeys.data(), D.mvKeys.size() * sizeof(cv::KeyPoint));
+        dump_desc(dir + "/d_desc.bin", D.mDescriptors, D.N);
+    }
+    printf("boundary ok: stereo %d / %d keys, mono %d -> %d keys, align ret %zu, %d matches\n", S.N, (int) S.mvKeysRight.size(), last.N, cur.N, ret, nm);
+    return 0;
+}

@@ -44,6 +44,16 @@ int main(int argc, char **argv) {
     std::vector<unsigned char> ia = slurp(dir + "/a.u8"), ib = slurp(dir + "/b.u8"), wd = slurp(dir + "/depth.f32");
     const float depth = *(const float *) wd.data();
     ORBextractor ex(600, 1.2f, L, 20, 7);
+    {   // Frame's constructors read the tables before any image has been processed (src/Frame.cc:119-125): they must exist right after
+        // construction, with no device work behind them
+        std::vector<float> t;
+        for (const std::vector<float> &v : {ex.GetScaleFactors(), ex.GetInverseScaleFactors(), ex.GetScaleSigmaSquares(), ex.GetInverseScaleSigmaSquares()}) {
+            if ((int) v.size() != L) { fprintf(stderr, "scale table of %zu entries right after construction\n", v.size()); return 4; }
+            t.insert(t.end(), v.begin(), v.end());
+        }
+        if (ex.GetLevels() != L || ex.GetScaleFactor() != 1.2f) return 4;
+        dump(dir + "/tables.bin", t.data(), t.size() * sizeof(float));
+    }
     Frame A, B;
     Frame *fr[2] = {&A, &B};
     std::vector<unsigned char> *im[2] = {&ia, &ib};
@@ -91,6 +101,28 @@ int main(int argc, char **argv) {
         if (B.mvpMapPoints[i]) assigned[i] = (int) (B.mvpMapPoints[i] - mps.data());
     dump(dir + "/match.bin", assigned.data(), assigned.size() * sizeof(int));
     dump(dir + "/nmatch.bin", &nm, sizeof nm);
+    // Tracking::SearchLocalPointsDirect: matcher.FindDirectProjection(KF, &cur, mp, px, level) once per candidate (src/Tracking.cc:2210, :2289)
+    {
+        KeyFrame KF;
+        KF.mnId = 7;
+        KF.mvKeys = A.mvKeys;
+        KF.mvImagePyramid = A.mvImagePyramid;
+        KF.mPose = A.mTcw;
+        B.mnId = 41;
+        const int nd = std::min(A.N, 160);
+        std::vector<float> out((size_t) nd * 4);
+        ORBmatcher dm;
+        for (int i = 0; i < nd; i++) {
+            mps[i].mObservations[&KF] = (size_t) i;
+            Vector2f px;
+            px[0] = A.mvKeys[i].pt.x + ((i % 5) - 2) * 0.75f;      // initial guess: the KeyFrame position, up to 1.5 px off
+            px[1] = A.mvKeys[i].pt.y + ((i % 3) - 1) * 0.5f;
+            int level = -1;
+            const bool ok = dm.FindDirectProjection(&KF, &B, &mps[i], px, level);
+            out[4 * i] = px[0]; out[4 * i + 1] = px[1]; out[4 * i + 2] = (float) level; out[4 * i + 3] = ok ? 1.f : 0.f;
+        }
+        dump(dir + "/direct.bin", out.data(), out.size() * sizeof(float));
+    }
     // Tracking::SearchLocalPoints: SearchByProjection(frame, localMapPoints, th) with the fields Frame::isInFrustum sets
     std::vector<MapPoint *> local;
     for (int i = 0; i < A.N; i++) {

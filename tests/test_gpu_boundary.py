@@ -1,0 +1,103 @@
+"""GPU test of the drop-in boundary: tests/cpp/bin/boundary_frame is the REFERENCE's own src/Frame.cc (real include/Frame.h, its
+constructors, ExtractFeatures with its two extraction threads, ComputeStereoMatches, AssignFeaturesToGrid, isInFrustum) linked against the
+PRODUCT's class shells (orb_ygz_slam_amd/csrc/host: ORBextractor.h in place of the reference's header, ORBmatcher.cc / SparseImageAlign.cc
+defining the members of the reference's own, unchanged class declarations) and libygzf.so -- built by tests/cpp/build_boundary.sh where the
+reference checkout exists.  The OpenCV stand-in's compute primitives abort in that binary, so every pyramid, keypoint and descriptor below
+came out of the HIP library.  Everything the reference code produced through that path must equal the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.capi import EUROC, KP_DTYPE
+from orb_ygz_slam_amd.scene import two_view_scene
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "tests", "cpp", "bin", "boundary_frame")
+
+
+def test_reference_frame_over_product_shells(oracle, tmp_path):
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call([os.path.join(ROOT, "tests", "cpp", "build_boundary.sh")])
+    assert os.path.exists(EXE), "tests/cpp/bin/boundary_frame missing: run tests/cpp/build_boundary.sh where /root/reference exists"
+    from orb_ygz_slam_amd import load_library
+    load_library()
+    w, h, NF, L, depth = 752, 480, 1000, 8, np.float32(4.0)
+    imgL, imgN, (R, t), _ = two_view_scene(17, w, h, EUROC, Z=float(depth))
+    imgR = np.zeros_like(imgL)                      # right eye: bands of the left image shifted by known disparities
+    for bnd, dsp in enumerate((5, 11, 17, 24, 31, 8)):
+        imgR[bnd * 80:(bnd + 1) * 80, :w - dsp] = imgL[bnd * 80:(bnd + 1) * 80, dsp:]
+    np.array([w, h, NF, L], np.int32).tofile(tmp_path / "size.i32")
+    imgL.tofile(tmp_path / "left.u8"); imgR.tofile(tmp_path / "right.u8"); imgN.tofile(tmp_path / "next.u8")
+    out = subprocess.run([EXE, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "boundary ok" in out.stdout
+    rd = lambda name, dt: np.fromfile(tmp_path / name, dt)
+    f = np.float32
+    oex = oracle.Extractor(NF, 1.2, L, 20, 7)
+    tab = oex.tables()
+    # ---- stereo frame: reference constructor + ExtractFeatures over the shells ----
+    assert (rd("s_scale.bin", np.float32) == tab["scale"]).all()
+    for l, lvl in enumerate(oex.pyramid(imgL)):
+        assert (rd("s_pyr%d.bin" % l, np.uint8).reshape(lvl.shape) == lvl).all(), "Frame::mvImagePyramid[%d]" % l
+    kl, dl = oex.extract(imgL)
+    kr, dr = oex.extract(imgR)
+    assert (rd("s_keys.bin", KP_DTYPE) == kl).all() and (rd("s_desc.bin", np.uint8).reshape(-1, 32) == dl).all()
+    assert (rd("s_keysr.bin", KP_DTYPE) == kr).all() and (rd("s_descr.bin", np.uint8).reshape(-1, 32) == dr).all()
+    mbf = f(47.9)
+    mb = mbf / f(EUROC["fx"])
+    our, odp = oex.compute_stereo_matches(imgL, imgR, kl, dl, kr, dr, float(mb), float(mbf))
+    sur, sdp = rd("s_uright.bin", np.float32), rd("s_depth.bin", np.float32)
+    assert (sur.view(np.uint32) == our.view(np.uint32)).all() and (sdp.view(np.uint32) == odp.view(np.uint32)).all()     # reference CPU code on HIP pyramids
+    assert (rd("s_uright_dev.bin", np.float32).view(np.uint32) == our.view(np.uint32)).all()                               # device ComputeStereoMatches
+    assert (rd("s_depth_dev.bin", np.float32).view(np.uint32) == odp.view(np.uint32)).all()
+    assert (our >= 0).sum() > 100
+    g = rd("s_grid.bin", np.int32)
+    pos = 0
+    for k in range(12):
+        exp = oracle.features_in_area(kl, tab["scale"], w, h, 60.0 + 55.0 * k, 40.0 + 33.0 * k, 25.0, -1 if k % 3 else 0, -1 if k % 3 else 2)
+        n = int(g[pos]); pos += 1
+        assert n == len(exp) and (g[pos:pos + n] == exp).all()
+        pos += n
+    # ---- monocular pair ----
+    kn, dn = oex.extract(imgN)
+    assert (rd("m_keys_last.bin", KP_DTYPE) == kl).all() and (rd("m_keys_cur.bin", KP_DTYPE) == kn).all()
+    assert (rd("m_desc_cur.bin", np.uint8).reshape(-1, 32) == dn).all()
+    world = np.stack([(kl["x"] - f(EUROC["cx"])) / f(EUROC["fx"]) * depth, (kl["y"] - f(EUROC["cy"])) / f(EUROC["fy"]) * depth,
+                      np.full(len(kl), depth, np.float32)], -1).astype(np.float32)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    o_ret, o_T, _, o_H = oracle.sparse_img_align(kl, world, ident, oex.pyramid(imgL), ident, oex.pyramid(imgN), tab["inv_scale"], EUROC, L - 1, 1)
+    t7 = rd("m_tcr.bin", np.float32)
+    assert int(t7[7]) == o_ret and o_ret > 100
+    assert np.abs(t7[:7] - o_T).max() <= 1e-5                      # north_star tolerance on the SE3
+    assert np.abs(t7[4:7] - t).max() < 5e-3
+    fisher = rd("m_fisher.bin", np.float32)
+    o_H = np.asarray(o_H, np.float32).reshape(-1)
+    assert np.allclose(fisher, o_H / f(5e-4 * 255 * 255), rtol=2e-3, atol=1e-3 * np.abs(o_H).max() / (5e-4 * 255 * 255))
+    pose = rd("m_pose.bin", np.float32)
+    Rcw, tcw = pose[:9].reshape(3, 3), pose[9:]
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    e_n, e_m, _ = oracle.search_by_projection_last(kn, dn, tab["scale"], w, h, EUROC, kl, world, dl, Rcw, tcw, I, z, 15.0)
+    assert int(rd("m_nmatch.bin", np.int32)[0]) == e_n and e_n > 100
+    assert (rd("m_match.bin", np.int32) == np.where(e_m >= 0, e_m, -1)).all()
+    # SearchLocalPoints: the reference's isInFrustum (CPU) marks, the shell searches
+    fr = rd("m_frustum.bin", np.float32).reshape(-1, 5)
+    Ow = -(Rcw.T @ tcw)
+    mf_max = (depth * tab["scale"][kl["octave"]]).astype(np.float32)
+    iv, px, py, _, lv, vc = oracle.is_in_frustum(kn, dn, tab["scale"], w, h, EUROC, world, np.tile(np.array([0, 0, 1], np.float32), (len(kl), 1)),
+                                                 (f(1.2) * mf_max).astype(np.float32), (f(0.8) * mf_max / tab["scale"][L - 1]).astype(np.float32), mf_max,
+                                                 Rcw, tcw, Ow.astype(np.float32), np.log(f(1.2)), 0.5)
+    assert (fr[:, 0].astype(np.uint8) == iv).all() and iv.sum() > 100
+    sel = iv.astype(bool)
+    assert (fr[sel, 1] == px[sel]).all() and (fr[sel, 2] == py[sel]).all() and (fr[sel, 3].astype(np.int32) == lv[sel]).all()
+    e_n2, e_m2, _ = oracle.search_by_projection_mappoints(kn, dn, tab["scale"], w, h, EUROC, iv, fr[:, 1].copy(), fr[:, 2].copy(), fr[:, 4].copy(),
+                                                          fr[:, 3].astype(np.int32), dl, 3.0, False, 0.8)
+    assert int(rd("m_nmatch2.bin", np.int32)[0]) == e_n2 and e_n2 > 50
+    assert (rd("m_match2.bin", np.int32) == np.where(e_m2 >= 0, e_m2, -1)).all()
+    # direct-tracked frame: Frame::ExtractORB took the DSO_KEYPOINT branch
+    ko, do, _ = oracle.Extractor(NF, 1.2, L, 20, 7).extract_dso(imgN, existing=kn[:120])
+    kd = rd("d_keys.bin", KP_DTYPE)
+    assert len(kd) == len(ko) > 120 and (kd == ko).all()
+    assert (rd("d_desc.bin", np.uint8).reshape(-1, 32) == do).all()

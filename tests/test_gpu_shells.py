@@ -19,8 +19,10 @@ def _build(tmp):
     lib = os.path.join(ROOT, "orb_ygz_slam_amd", "lib")
     exe = os.path.join(tmp, "test_shells")
     srcs = [os.path.join(ROOT, "tests", "cpp", "test_shells.cc")] + [os.path.join(host, f) for f in
-                                                                     ("ORBextractor.cc", "ORBmatcher.cc", "SparseImageAlign.cc")]
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", host] + srcs + ["-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
+                                                                     ("ORBextractor.cc", "ORBmatcher.cc", "SparseImageAlign.cc", "ygzf_pool.cc")]
+    # stand-alone build of the shells: host/ (ORBextractor.h, ygz_compat.h) + host/standalone/ (ORBmatcher.h, SparseImageAlign.h)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", host, "-I", os.path.join(host, "standalone")] + srcs +
+                          ["-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
     return exe
 
 
@@ -51,6 +53,10 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shells ok" in out.stdout
     oex = oracle.Extractor(600, 1.2, 8, 20, 7)
+    tb = np.fromfile(tmp_path / "tables.bin", np.float32).reshape(4, 8)      # getters read right after construction, before any image
+    ot = oex.tables()
+    for row, key in enumerate(("scale", "inv_scale", "sigma2", "inv_sigma2")):
+        assert (tb[row] == ot[key]).all(), key
     res = {}
     for name, img in (("a", imgA), ("b", imgB)):
         k = np.fromfile(tmp_path / (name + "_kps.bin"), KP_DTYPE)
@@ -70,6 +76,15 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     assert int(t7[7]) == o_ret and o_ret > 100
     assert np.abs(t7[:7] - o_T).max() <= 1e-5
     assert np.abs(t7[4:7] - t).max() < 5e-3
+    # FindDirectProjection as a member, one candidate per call (KeyFrame = A at identity, current frame = B at TCR)
+    dr = np.fromfile(tmp_path / "direct.bin", np.float32).reshape(-1, 4)
+    nd = len(dr)
+    i5, i3 = np.arange(nd) % 5, np.arange(nd) % 3
+    px0 = np.stack([ka["x"][:nd] + (i5 - 2).astype(np.float32) * f(0.75), ka["y"][:nd] + (i3 - 1).astype(np.float32) * f(0.5)], -1).astype(np.float32)
+    opx, osl, ook, _ = oex.find_direct_projection_batch([imgA], imgB, t7[:7], EUROC, np.zeros(nd, np.int32), np.tile(ident, (nd, 1)), ka[:nd], world[:nd], px0)
+    assert nd == 160 and (dr[:, 2].astype(np.int32) == osl).all() and (dr[:, 3].astype(np.uint8) == ook).all()
+    assert np.array_equal(dr[:, :2].copy().view(np.uint32), opx.view(np.uint32))
+    assert ook.sum() > 100
     # matcher: CurrentFrame.mTcw = TCR (as computed on the device), LastFrame.mTcw = identity
     Rcw, tcw = _R_from_q(t7[:4]), t7[4:7]
     I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)

@@ -1,0 +1,123 @@
+// tools/micro/valu_peak.hip -- calibrates the vector-ALU issue ceiling of gfx950 for the byte-parallel integer instructions the FAST /
+// describe / pyramid kernels are built from (is a wave64 VALU instruction 4 cycles -- SIMD16 -- or 2 -- SIMD32?).
+// Every kernel runs kIter x 64 dependent-free instructions of one kind per wave (8 independent accumulator chains per lane, so the
+// 4-8 cycle result latency never stalls issue) at 1, 2, 4 and 8 waves per SIMD on all 256 CUs and reports
+//     cycles per wave-instruction per SIMD = (SIMDs x shader-clock cycles of the launch) / (waves x instructions per wave)
+// with the shader clock taken from s_memtime deltas inside the kernel (clock64) and from wall time x 2.4 GHz beside it.
+// Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/micro/valu_peak.hip -o /tmp/valu_peak && /tmp/valu_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+constexpr int kIter = 2000, kUnroll = 8, kChains = 8;   // 2000 x 8 x 8 = 128000 instructions per wave
+
+#define CHAIN8(OP)                                                                       \
+    for (int it = 0; it < kIter; it++) {                                                 \
+        _Pragma("unroll") for (int u = 0; u < kUnroll; u++) {                            \
+            OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)                      \
+        }                                                                                \
+    }
+
+#define OP_LERP(x) asm volatile("v_lerp_u8 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_BITOP3(x) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x) : "v"(b), "v"(c));
+#define OP_ADD(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_ALIGN(x) asm volatile("v_alignbyte_b32 %0, %0, %1, 1" : "+v"(x) : "v"(b));
+#define OP_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_DOT4(x) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(x) : "v"(b), "v"(c));
+#define OP_SAD(x) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(x) : "v"(b), "v"(c));
+#define OP_PKMIN(x) asm volatile("v_pk_min_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_PKADD(x) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_MUL24(x) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_OR3(x) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_PKFMA(x) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x##w) : "v"(bw), "v"(cw));
+#define OP_CMP(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc");
+#define OP_CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
+#define OP_DPP(x) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b));
+#define OP_MBCNT(x) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(x) : "v"(b));
+
+#define KERNEL(NAME, OP)                                                                                         \
+    __global__ __launch_bounds__(256) void NAME(unsigned *out, long long *clk, unsigned seed) {                  \
+        unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        unsigned b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x5bd1e995u;                                   \
+        const long long t0 = clock64();                                                                          \
+        CHAIN8(OP)                                                                                               \
+        const long long t1 = clock64();                                                                          \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                      \
+        if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;                                               \
+    }
+
+KERNEL(k_lerp, OP_LERP)
+KERNEL(k_bitop3, OP_BITOP3)
+KERNEL(k_add, OP_ADD)
+KERNEL(k_align, OP_ALIGN)
+KERNEL(k_perm, OP_PERM)
+KERNEL(k_dot4, OP_DOT4)
+KERNEL(k_sad, OP_SAD)
+KERNEL(k_pkmin, OP_PKMIN)
+KERNEL(k_pkadd, OP_PKADD)
+KERNEL(k_mul24, OP_MUL24)
+KERNEL(k_mullo, OP_MULLO)
+KERNEL(k_or3, OP_OR3)
+KERNEL(k_fma, OP_FMA)
+KERNEL(k_cmp, OP_CMP)
+KERNEL(k_cndmask, OP_CNDMASK)
+KERNEL(k_dpp, OP_DPP)
+KERNEL(k_mbcnt, OP_MBCNT)
+
+__global__ __launch_bounds__(256) void k_pkfma(unsigned *out, long long *clk, unsigned seed) {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 a0w = {1.f + threadIdx.x, 2.f}, a1w = a0w * 3.f, a2w = a0w * 5.f, a3w = a0w * 7.f, a4w = a0w * 0.5f, a5w = a0w * 0.25f, a6w = a0w * 9.f, a7w = a0w * 1.5f;
+    v2 bw = {0.999f, 1.001f}, cw = {1e-3f * seed, 2e-3f};
+    const long long t0 = clock64();
+    CHAIN8(OP_PKFMA)
+    const long long t1 = clock64();
+    const v2 s = a0w + a1w + a2w + a3w + a4w + a5w + a6w + a7w;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = __float_as_uint(s.x + s.y);
+    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+}
+
+typedef void (*kern_t)(unsigned *, long long *, unsigned);
+
+int main() {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount, simds = cus * 4;
+    printf("device %s: %d CUs, clockRate %d kHz\n", p.gcnArchName, cus, p.clockRate);
+    unsigned *out;
+    long long *clk;
+    hipMalloc(&out, (size_t) cus * 8 * 256 * 4 + 1024);
+    hipMalloc(&clk, 64);
+    struct { const char *name; kern_t k; } ks[] = {{"v_lerp_u8", k_lerp}, {"v_bitop3_b32", k_bitop3}, {"v_or3_b32", k_or3}, {"v_add_u32", k_add}, {"v_alignbyte_b32", k_align},
+                                                   {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4}, {"v_sad_u8", k_sad}, {"v_pk_min_u16", k_pkmin}, {"v_pk_add_u16", k_pkadd},
+                                                   {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo}, {"v_cmp_lt_u32", k_cmp}, {"v_cndmask_b32", k_cndmask},
+                                                   {"v_add_u32_dpp", k_dpp}, {"v_mbcnt_lo", k_mbcnt}, {"v_fma_f32", k_fma}, {"v_pk_fma_f32", k_pkfma}};
+    const double instr = (double) kIter * kUnroll * kChains;
+    printf("%-18s %s\n", "instruction", "waves/SIMD: cycles per wave-instruction per SIMD  [by s_memtime | by wall time at 2.4 GHz]");
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (auto &k : ks) {
+        printf("%-18s", k.name);
+        for (int wps : {1, 2, 4, 8}) {
+            const int blocks = cus * wps;   // 256-thread blocks: one wave per SIMD each
+            hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, out, clk, 1u);
+            hipDeviceSynchronize();
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k.k, dim3(blocks), dim3(256), 0, 0, out, clk, 2u);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            long long c;
+            hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
+            // one wave's own s_memtime span covers wps waves sharing its SIMD
+            const double cyc_mem = (double) c / (instr * wps);
+            const double cyc_wall = ms * 1e-3 * 2.4e9 / (instr * wps);
+            printf("  %d: %5.2f | %5.2f", wps, cyc_mem, cyc_wall);
+        }
+        printf("\n");
+    }
+    return 0;
+}
