@@ -414,7 +414,7 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol
     return max(lo, hi) - 1;
 }
 
-constexpr int kSP = 64;          // LDS pitch of a cell's score map (<= 62 columns used)
+// LDS pitch of a cell's score map = the window pitch (wCell + 2 columns used, the window pitch is >= wCell + 7)
 constexpr int kCornerCap = 512;  // corners listed per cell before the dense fallback takes over
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -458,18 +458,33 @@ __device__ __forceinline__ unsigned fast9_quad(const unsigned *w, int pd, int t)
         B[k] = __builtin_amdgcn_lerp(R[k], nhi, 0u);
         N[k] = __builtin_amdgcn_lerp(R[k], nlo, 0x01010101u);
     }
-    unsigned A3[16], O3[16];
+    // "9 contiguous of the circular 16", bit-sliced: arcs of 3, then arcs of 9 = three arcs of 3, then the reduction over the 16 start
+    // positions -- 80 three-input operations.  Every one is written as v_bitop3_b32: on gfx950 that instruction issues at the full rate
+    // (2 cycles per wave64) while v_or3_b32 / v_and_or_b32, which the compiler would pick for `a | b | c`, issue at half rate like most
+    // three-operand integer instructions (profiles/micro/r02_valu_issue_rates.txt).
+#define AND3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x80)
+#define OR3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE)
+    unsigned A3[16], O3[16], A9[16], O9[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        A3[k] = B[k] & B[(k + 1) & 15] & B[(k + 2) & 15];
-        O3[k] = N[k] | N[(k + 1) & 15] | N[(k + 2) & 15];
+        A3[k] = AND3(B[k], B[(k + 1) & 15], B[(k + 2) & 15]);
+        O3[k] = OR3(N[k], N[(k + 1) & 15], N[(k + 2) & 15]);
     }
-    unsigned bright = 0, ndark = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        bright |= A3[k] & A3[(k + 3) & 15] & A3[(k + 6) & 15];
-        ndark &= O3[k] | O3[(k + 3) & 15] | O3[(k + 6) & 15];
+        A9[k] = AND3(A3[k], A3[(k + 3) & 15], A3[(k + 6) & 15]);
+        O9[k] = OR3(O3[k], O3[(k + 3) & 15], O3[(k + 6) & 15]);
     }
+    unsigned bright = OR3(A9[0], A9[1], A9[2]), ndark = AND3(O9[0], O9[1], O9[2]);
+#pragma unroll
+    for (int k = 3; k < 15; k += 2) {
+        bright = OR3(bright, A9[k], A9[k + 1]);
+        ndark = AND3(ndark, O9[k], O9[k + 1]);
+    }
+    bright |= A9[15];
+    ndark &= O9[15];
+#undef AND3
+#undef OR3
     const unsigned fb = bright & 0x80808080u, fd = ~(ndark | bright) & 0x80808080u;
     return (fb >> 7) | (fd >> 6);   // per byte: 1 bright corner, 2 dark corner, 0 none
 }
@@ -482,7 +497,7 @@ __device__ __forceinline__ int div_small(int a, unsigned m) { return (int) (__um
 // 3x3 NMS of a listed corner on the score map: survivor at minTh (strictly above all 8 neighbours) and at iniTh.  A corner of
 // FAST(iniTh) has score >= iniTh and competes with the neighbours of score >= iniTh only -- but a neighbour below iniTh <= s cannot
 // beat s, so the iniTh survivor test is "minTh survivor and s >= iniTh".
-__device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh) {
+__device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh, int kSP) {
     const int s = sp[0];
     int nmax = max(max((int) sp[-kSP - 1], (int) sp[-kSP]), max((int) sp[-kSP + 1], (int) sp[-1]));
     nmax = max(nmax, max(max((int) sp[1], (int) sp[kSP - 1]), max((int) sp[kSP], (int) sp[kSP + 1])));
@@ -528,12 +543,16 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
         return;
     }
     const int P = kP ? kP : winPitch;
+    const int kSP = P;   // score-map pitch
     const int winBytes = (winRows * P + 16 + 15) & ~15;   // 16 bytes of slack: the last quad of the last row reads past its row
-    const int perWave = winBytes + smapRows * kSP + quadCap * 4 + kCornerCap * 2;    // all multiples of 16
+    // the quad list lives only between pass 1 and the expansion, the score map only after the expansion: they share their bytes (one
+    // more workgroup fits a CU: 8 x 4 waves instead of 6 x 4 at the usual 30-px cells)
+    const int smapBytes = (max(smapRows * kSP, quadCap * 4) + 15) & ~15;
+    const int perWave = winBytes + smapBytes + kCornerCap * 2;    // all multiples of 16
     uint8_t *win = fdyn + wv * perWave;
     uint8_t *smap = win + winBytes;
-    unsigned *qlist = (unsigned *) (smap + smapRows * kSP);
-    unsigned short *clist = (unsigned short *) (qlist + quadCap);
+    unsigned *qlist = (unsigned *) smap;
+    unsigned short *clist = (unsigned short *) (smap + smapBytes);
     {   // stage the window: LDS column 1 + b of row r = image pixel (iniX + b, iniY + r), i.e. tested pixel x of the cell at column x + 4.
         // All global loads of a chunk are issued before the first use; lanes past the end repeat the last dword.
         int pitch;
@@ -562,8 +581,6 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
                 r += sr; d += sd;
                 if (d >= nd) { d -= nd; r++; }
             }
-            if (i0 == 0)
-                for (int idx = lane; idx < ((dh + 2) * kSP) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < kU; u++) ((unsigned *) win)[dst[u]] = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh);
         }
@@ -618,6 +635,9 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
         ncorn += add;
     }
     wave_lds_sync();
+    // the quad list is consumed: its bytes become the (zeroed) score map
+    for (int idx = lane; idx < ((dh + 2) * kSP + 15) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
     unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
     if (!overflow && ncorn <= 64) {
@@ -632,7 +652,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
             sp[0] = (uint8_t) s;
         }
         wave_lds_sync();
-        const int fl = have ? nms_flags(sp, iniTh) : 0;
+        const int fl = have ? nms_flags(sp, iniTh, kSP) : 0;
         const bool anyIni = __ballot(fl & 1) != 0;
         const bool keep = (fl & (anyIni ? 1 : 2)) != 0;   // the iniTh survivors, or the minTh survivors when the cell is empty at iniTh
         const unsigned long long m = __ballot(keep);
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
             if (qi < ncorn) {
                 const int e = clist[qi];
                 const int y = e >> 8, x = (e >> 2) & 63;
-                fl = nms_flags(&smap[(y + 1) * kSP + x + 1], iniTh);
+                fl = nms_flags(&smap[(y + 1) * kSP + x + 1], iniTh, kSP);
                 clist[qi] = (unsigned short) ((e & ~3) | fl);   // polarity no longer needed: keep the flags
             }
             nIni += __popcll(__ballot(fl & 1));
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
             if (base + lane < npix) {
                 const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
                 s = sp[0];
-                if (s > 0) keep = (nms_flags(sp, iniTh) & (pass == 0 ? 1 : 2)) != 0;
+                if (s > 0) keep = (nms_flags(sp, iniTh, kSP) & (pass == 0 ? 1 : 2)) != 0;
             }
             const unsigned long long m = __ballot(keep);
             if (keep) out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
@@ -1433,7 +1453,8 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 }
 
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap) {
-    return (size_t) (kFastBlock / 64) * ((((size_t) winRows * winPitch + 16 + 15) & ~(size_t) 15) + (size_t) smapRows * kSP + (size_t) quadCap * 4 + kCornerCap * sizeof(unsigned short)) + 64;
+    const size_t smapBytes = (std::max((size_t) smapRows * winPitch, (size_t) quadCap * 4) + 15) & ~(size_t) 15;   // score map and quad list share their bytes
+    return (size_t) (kFastBlock / 64) * ((((size_t) winRows * winPitch + 16 + 15) & ~(size_t) 15) + smapBytes + kCornerCap * sizeof(unsigned short)) + 64;
 }
 
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,

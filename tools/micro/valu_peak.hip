@@ -36,16 +36,54 @@ constexpr int kIter = 2000, kUnroll = 8, kChains = 8;   // 2000 x 8 x 8 = 128000
 #define OP_CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : "vcc");
 #define OP_DPP(x) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b));
 #define OP_MBCNT(x) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(x) : "v"(b));
+#define OP2(NAME, INS) 
+#define OP_AND(x) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_OR(x) asm volatile("v_or_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_LSHL(x) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(x));
+#define OP_LSHR(x) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(x));
+#define OP_MINU(x) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_SUB(x) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_ANDOR(x) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_LSHLOR(x) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(x) : "v"(b));
+#define OP_LSHLADD(x) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x) : "v"(b));
+#define OP_ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, 1, 31" : "+v"(x));
+#define OP_BFI(x) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(b));
+#define OP_CNDS(x) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "s"(msk));
+#define OP_CMPS(x) asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(sm) : "v"(x), "v"(b));
+#define OP_MAD24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_MIN3(x) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_MED3(x) asm volatile("v_med3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_PKMAX(x) asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_PKSUB(x) asm volatile("v_pk_sub_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_PKLSHL(x) asm volatile("v_pk_lshlrev_b16 %0, 1, %0" : "+v"(x));
+#define OP_PKMUL(x) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_MULF(x) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_ADDF(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_CVTF(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
+#define OP_CVTUB(x) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(x));
+#define OP_MULHI(x) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_XAD(x) asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+#define OP_SAD16(x) asm volatile("v_sad_u16 %0, %1, %2, %0" : "+v"(x) : "v"(b), "v"(c));
+#define OP_ADDLSHL(x) asm volatile("v_add_lshl_u32 %0, %0, %1, 1" : "+v"(x) : "v"(b));
+#define OP_NOT(x) asm volatile("v_not_b32 %0, %0" : "+v"(x));
+#define OP_BCNT(x) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(x) : "v"(b));
+#define OP_SDWA(x) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(x) : "v"(b));
+#define OP_DPPROR(x) asm volatile("v_mov_b32_dpp %0, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b));
+#define OP_BITOP2(x) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xfe" : "+v"(x) : "v"(b), "v"(c));
 
 #define KERNEL(NAME, OP)                                                                                         \
     __global__ __launch_bounds__(256) void NAME(unsigned *out, long long *clk, unsigned seed) {                  \
         unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
         unsigned b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x5bd1e995u;                                   \
-        const long long t0 = clock64();                                                                          \
+        unsigned long long msk = 0x5555aaaa3333ccccull * seed, sm = 0;                                           \
+        const long long t0 = clock64(), w0 = wall_clock64();                                                     \
         CHAIN8(OP)                                                                                               \
-        const long long t1 = clock64();                                                                          \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                      \
-        if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;                                               \
+        const long long t1 = clock64(), w1 = wall_clock64();                                                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (unsigned) sm;      \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { clk[0] = t1 - t0; clk[1] = w1 - w0; }             \
     }
 
 KERNEL(k_lerp, OP_LERP)
@@ -65,17 +103,24 @@ KERNEL(k_cmp, OP_CMP)
 KERNEL(k_cndmask, OP_CNDMASK)
 KERNEL(k_dpp, OP_DPP)
 KERNEL(k_mbcnt, OP_MBCNT)
+KERNEL(k_and, OP_AND) KERNEL(k_or, OP_OR) KERNEL(k_xor, OP_XOR) KERNEL(k_lshl, OP_LSHL) KERNEL(k_lshr, OP_LSHR) KERNEL(k_minu, OP_MINU)
+KERNEL(k_sub, OP_SUB) KERNEL(k_andor, OP_ANDOR) KERNEL(k_lshlor, OP_LSHLOR) KERNEL(k_lshladd, OP_LSHLADD) KERNEL(k_add3, OP_ADD3)
+KERNEL(k_bfe, OP_BFE) KERNEL(k_bfi, OP_BFI) KERNEL(k_mov, OP_MOV) KERNEL(k_cnds, OP_CNDS) KERNEL(k_cmps, OP_CMPS) KERNEL(k_mad24, OP_MAD24)
+KERNEL(k_min3, OP_MIN3) KERNEL(k_med3, OP_MED3) KERNEL(k_pkmax, OP_PKMAX) KERNEL(k_pksub, OP_PKSUB) KERNEL(k_pklshl, OP_PKLSHL)
+KERNEL(k_pkmul, OP_PKMUL) KERNEL(k_mulf, OP_MULF) KERNEL(k_addf, OP_ADDF) KERNEL(k_cvtf, OP_CVTF) KERNEL(k_cvtub, OP_CVTUB)
+KERNEL(k_mulhi, OP_MULHI) KERNEL(k_xad, OP_XAD) KERNEL(k_sad16, OP_SAD16) KERNEL(k_addlshl, OP_ADDLSHL) KERNEL(k_not, OP_NOT)
+KERNEL(k_bcnt, OP_BCNT) KERNEL(k_sdwa, OP_SDWA) KERNEL(k_dppror, OP_DPPROR) KERNEL(k_bitop2, OP_BITOP2)
 
 __global__ __launch_bounds__(256) void k_pkfma(unsigned *out, long long *clk, unsigned seed) {
     typedef float v2 __attribute__((ext_vector_type(2)));
     v2 a0w = {1.f + threadIdx.x, 2.f}, a1w = a0w * 3.f, a2w = a0w * 5.f, a3w = a0w * 7.f, a4w = a0w * 0.5f, a5w = a0w * 0.25f, a6w = a0w * 9.f, a7w = a0w * 1.5f;
     v2 bw = {0.999f, 1.001f}, cw = {1e-3f * seed, 2e-3f};
-    const long long t0 = clock64();
+    const long long t0 = clock64(), w0 = wall_clock64();
     CHAIN8(OP_PKFMA)
-    const long long t1 = clock64();
+    const long long t1 = clock64(), w1 = wall_clock64();
     const v2 s = a0w + a1w + a2w + a3w + a4w + a5w + a6w + a7w;
     out[blockIdx.x * blockDim.x + threadIdx.x] = __float_as_uint(s.x + s.y);
-    if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
 typedef void (*kern_t)(unsigned *, long long *, unsigned);
@@ -92,9 +137,18 @@ int main() {
     struct { const char *name; kern_t k; } ks[] = {{"v_lerp_u8", k_lerp}, {"v_bitop3_b32", k_bitop3}, {"v_or3_b32", k_or3}, {"v_add_u32", k_add}, {"v_alignbyte_b32", k_align},
                                                    {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4}, {"v_sad_u8", k_sad}, {"v_pk_min_u16", k_pkmin}, {"v_pk_add_u16", k_pkadd},
                                                    {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo}, {"v_cmp_lt_u32", k_cmp}, {"v_cndmask_b32", k_cndmask},
-                                                   {"v_add_u32_dpp", k_dpp}, {"v_mbcnt_lo", k_mbcnt}, {"v_fma_f32", k_fma}, {"v_pk_fma_f32", k_pkfma}};
+                                                   {"v_add_u32_dpp", k_dpp}, {"v_mbcnt_lo", k_mbcnt}, {"v_fma_f32", k_fma}, {"v_pk_fma_f32", k_pkfma},
+                                                   {"v_and_b32", k_and}, {"v_or_b32", k_or}, {"v_xor_b32", k_xor}, {"v_lshlrev_b32", k_lshl}, {"v_lshrrev_b32", k_lshr},
+                                                   {"v_min_u32", k_minu}, {"v_sub_u32", k_sub}, {"v_and_or_b32", k_andor}, {"v_lshl_or_b32", k_lshlor},
+                                                   {"v_lshl_add_u32", k_lshladd}, {"v_add3_u32", k_add3}, {"v_bfe_u32", k_bfe}, {"v_bfi_b32", k_bfi}, {"v_mov_b32", k_mov},
+                                                   {"v_cndmask (sgpr)", k_cnds}, {"v_cmp -> sgpr", k_cmps}, {"v_mad_u32_u24", k_mad24}, {"v_min3_u32", k_min3},
+                                                   {"v_med3_u32", k_med3}, {"v_pk_max_u16", k_pkmax}, {"v_pk_sub_u16", k_pksub}, {"v_pk_lshlrev_b16", k_pklshl},
+                                                   {"v_pk_mul_lo_u16", k_pkmul}, {"v_mul_f32", k_mulf}, {"v_add_f32", k_addf}, {"v_cvt_f32_u32", k_cvtf},
+                                                   {"v_cvt_f32_ubyte0", k_cvtub}, {"v_mul_hi_u32", k_mulhi}, {"v_xad_u32", k_xad}, {"v_sad_u16", k_sad16},
+                                                   {"v_add_lshl_u32", k_addlshl}, {"v_not_b32", k_not}, {"v_bcnt_u32_b32", k_bcnt}, {"v_add_u32_sdwa", k_sdwa},
+                                                   {"v_mov_b32_dpp ror", k_dppror}, {"v_bitop3 (or3)", k_bitop2}};
     const double instr = (double) kIter * kUnroll * kChains;
-    printf("%-18s %s\n", "instruction", "waves/SIMD: cycles per wave-instruction per SIMD  [by s_memtime | by wall time at 2.4 GHz]");
+    printf("%-18s %s\n", "instruction", "waves/SIMD: shader-clock cycles per wave-instruction per SIMD @ measured GHz (s_memtime / s_memrealtime)");
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -110,12 +164,12 @@ int main() {
             hipEventSynchronize(e1);
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
-            long long c;
-            hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost);
-            // one wave's own s_memtime span covers wps waves sharing its SIMD
-            const double cyc_mem = (double) c / (instr * wps);
-            const double cyc_wall = ms * 1e-3 * 2.4e9 / (instr * wps);
-            printf("  %d: %5.2f | %5.2f", wps, cyc_mem, cyc_wall);
+            long long c[2];
+            hipMemcpy(c, clk, 16, hipMemcpyDeviceToHost);
+            // shader clock while this kernel ran: s_memtime ticks per s_memrealtime tick (100 MHz) over one wave's run
+            const double ghz = c[1] > 0 ? (double) c[0] / (double) c[1] * 0.1 : 0;
+            const double cyc = ms * 1e-3 * ghz * 1e9 / (instr * wps);
+            printf("  %d: %5.2f @%4.2f", wps, cyc, ghz);
         }
         printf("\n");
     }
