@@ -3,19 +3,32 @@
 
 One "step" = one pass of the hot path (ORBextractor::operator() on every frame of a batch + ORBmatcher::SearchByProjection
 of every frame against its predecessor) over one batch of synthetic frames that is already resident in HBM when the
-timed region starts.  One process per GPU; frames are independent so each rank owns its own batch (weak scaling) and
-there is no collective in the data path -- torch.distributed is used only for the barrier and the max-over-ranks time.
+timed region starts.  The batch (default 9216 frames of 752x480 = 3.3 GB) is walked in sub-batches of 256 frames that
+rotate over 3 independent extractor contexts (own HIP stream and buffers each), so a step is 36 sub-batch launches and
+20 steps give a timed region of about one second.  One process per GPU; frames are independent, so each rank owns its own
+clip (weak scaling) and there is no collective in the data path -- torch.distributed is used only for the barrier and
+the max-over-ranks time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         bench.py --gpus 8 --steps 20 --warmup 3
+    python bench.py --devices-in-process 8        # the same sharding inside ONE process: one host thread + contexts per device
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field).
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definition of every field):
+  value              resident-frames rate of the timed region (the contract's number)
+  value_end_to_end   host frames in (pinned, H2D) -> kernels -> every keypoint + descriptor out (D2H), two contexts software-pipelined
+  roofline           HBM roofline of the dominant kernel (algorithmic bytes / measured launch time / 8 TB/s)
+  roofline_valu      the ceiling that actually binds it: vector-ALU issue cycles (instruction counts from the PMC profile x the
+                     issue costs calibrated by tools/micro/valu_peak.hip) / SIMD cycles available
+  cpu_baseline       the oracle ("port") on this host's cores; cpu_baseline_reference: the reference's own ORBextractor.cc +
+                     ORBmatcher.cc (oracle/_ref, over the OpenCV stand-in), one thread
+  other_workloads    short runs of BASELINE configs 4 / 5 (1920x1080/4000, 3840x2160 stereo/12 levels/8000) with their own rooflines
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -30,7 +43,11 @@ WORKLOADS = {
     "fhd1920x1080_8lvl_4000feat": (1920, 1080, 8, 1.2, 4000, 20, 7),    # configs[3]
     "uhd3840x2160_12lvl_8000feat": (3840, 2160, 12, 1.2, 8000, 20, 7),  # configs[4] (one eye)
 }
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+# (frames per sub-batch launch, sub-batch rounds per step) chosen so that 20 steps take about a second
+SHAPES = {"euroc752x480_8lvl_1000feat": (256, 12), "vga640x480_8lvl_1000feat": (256, 12), "fhd1920x1080_8lvl_4000feat": (32, 16),
+          "uhd3840x2160_12lvl_8000feat": (8, 13)}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, peak shader clock
 
 
 def level_sizes(w, h, nlevels, sf):
@@ -62,6 +79,11 @@ def algorithmic_bytes(w, h, nlevels, sf, nfeat):
     return total, per
 
 
+def align_bytes(nlevels, n_features):
+    """SURVEY 8(d) B_align, caches on chip: (L-1) * 10 iterations * N features * 25 B; upper bound with caches in HBM beside it."""
+    return (nlevels - 1) * 10 * n_features * 25, (nlevels - 1) * n_features * (448 + 10 * 473)
+
+
 def make_frames(n, w, h, seed0=1000):
     """Synthetic clip: groups of 8 consecutive frames are shifted crops of one scene so that frame-to-frame matching
     has something to find; every 8th frame is a scene cut."""
@@ -90,9 +112,8 @@ def effective_cores():
 
 
 def cpu_baseline(frames, cfg, seconds_budget=12.0):
-    """The CPU oracle ('port' of the reference path; the reference itself cannot be built here) on this host's cores:
-    every worker thread runs extract + projection match over its own run of consecutive frames of the same clip for a
-    bounded time (about `seconds_budget` s), so the default bench run stays within minutes on any host."""
+    """The CPU oracle ('port' of the reference path) on this host's cores: every worker thread runs extract + projection match over its own
+    run of consecutive frames of the same clip for a bounded time (about `seconds_budget` s)."""
     from oracle import oracle_py as O
     w, h, nl, sf, nf, ini, mn = cfg
     cores = effective_cores()
@@ -107,14 +128,232 @@ def cpu_baseline(frames, cfg, seconds_budget=12.0):
             "keypoints_per_frame": round(nk / n, 1), "matches_per_frame": round(nm / n, 1)}
 
 
+def cpu_baseline_reference(frames, cfg, seconds_budget=6.0):
+    """The reference's OWN src/ORBextractor.cc and src/ORBmatcher.cc (compiled where they lie into oracle/_ref over the OpenCV stand-in of
+    oracle/ref_shim: cv::resize / cv::FAST / cv::GaussianBlur underneath are the oracle's plain restatements, not an optimised OpenCV),
+    one thread, on consecutive frames of the same clip for a bounded time.  None when oracle/_ref was never built."""
+    from oracle import oracle_py as O
+    if O.ref_extractor_lib() is None or O.ref_matcher_lib() is None:
+        return None
+    w, h, nl, sf, nf, ini, mn = cfg
+    from orb_ygz_slam_amd.capi import EUROC
+    scale = O.Extractor(nf, sf, nl, ini, mn).tables()["scale"]
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    t0 = time.perf_counter()
+    prev, n, nk, nm = None, 0, 0, 0
+    while time.perf_counter() - t0 < seconds_budget and n < len(frames):
+        k, d = O.ref_extract(frames[n], nf, sf, nl, ini, mn)
+        if prev is not None and len(k) and len(prev[0]):
+            pk, pd = prev
+            world = np.stack([(pk["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]), (pk["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]),
+                              np.ones(len(pk), np.float32)], -1).astype(np.float32)
+            with O.reference_matcher():
+                m, _, _ = O.search_by_projection_last(k, d, scale, w, h, EUROC, pk, world, pd, I, z, I, z, 15.0)
+            nm += m
+        prev = (k, d)
+        nk += len(k)
+        n += 1
+    sec = time.perf_counter() - t0
+    return {"value": round(n / sec, 2), "unit": "frames/s", "cores": 1, "kind": "reference-over-shim",
+            "sample": "the reference's own ORBextractor.cc + ORBmatcher.cc (oracle/_ref) on %d consecutive frames of the bench clip in %.1f s, one thread; "
+                      "OpenCV primitives = the oracle's restatements" % (n, sec),
+            "keypoints_per_frame": round(nk / max(n, 1), 1), "matches_per_frame": round(nm / max(n - 1, 1), 1)}
+
+
+class Pipeline:
+    """One device's share of the work: `streams` extractor contexts, a resident clip of rounds x streams x sub frames."""
+
+    def __init__(self, device, workload, sub, rounds, streams, seed0, align=False, stereo=False, distinct=None):
+        import torch
+        from orb_ygz_slam_amd import Extractor, make_camera
+        self.cfg = WORKLOADS[workload]
+        w, h, nl, sf, nf, ini, mn = self.cfg
+        self.device, self.sub, self.rounds, self.S, self.align, self.stereo = device, sub, rounds, streams, align, stereo
+        D = streams * sub if distinct is None else distinct          # distinct synthetic frames; the resident batch tiles them
+        self.frames = make_frames(D, w, h, seed0=seed0)
+        base = torch.from_numpy(self.frames).to("cuda:%d" % device)
+        total = rounds * streams * sub
+        reps = (total + D - 1) // D
+        self.d_frames = base.repeat(reps, 1, 1)[:total].contiguous() if reps > 1 else base
+        self.batch = total
+        self.exs = [Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=sub, device=device) for _ in range(streams)]
+        self.cam = make_camera(w, h)
+        self.w, self.h, self.nl = w, h, nl
+        p0 = self.d_frames.data_ptr()
+        self.ptrs = [[p0 + ((r * streams + s) * sub) * w * h for s in range(streams)] for r in range(rounds)]
+
+    def launch(self, e, ptr):
+        e.extract_batch_device(ptr, self.sub, self.w, self.h)
+        e.match_batch_prev(self.cam, 15.0, True, True, True)
+        if self.align:
+            e.align_batch_prev(self.cam, self.nl - 1, 1, 10)
+        if self.stereo:
+            e.stereo_batch(0.11, 47.9)
+
+    def step(self):
+        for r in range(self.rounds):
+            for s, e in enumerate(self.exs):
+                self.launch(e, self.ptrs[r][s])
+
+    def sync(self):
+        for e in self.exs:
+            e.sync()
+
+    def profile(self, on):
+        for e in self.exs:
+            e.profile_enable(on)
+            if on:
+                e.profile_reset()
+
+    def profile_read(self):
+        prof = {}
+        for e in self.exs:
+            for name, (ms, n) in e.profile_read().items():
+                a = prof.get(name, (0.0, 0))
+                prof[name] = (a[0] + ms, a[1] + n)
+        return prof
+
+
+def run_timed(pipes, steps, warmup, barrier, sync_all):
+    """W untimed steps, then exactly `steps` steps between barrier + synchronise brackets on every device of this process (one host thread
+    per device when there are several).  Returns this process's elapsed seconds."""
+    def loop(p, n):
+        for _ in range(n):
+            p.step()
+        p.sync()
+    if len(pipes) == 1:
+        loop(pipes[0], warmup)
+        sync_all(); barrier(); sync_all()
+        t0 = time.perf_counter()
+        loop(pipes[0], steps)
+        sync_all(); barrier(); sync_all()
+        return time.perf_counter() - t0
+    gate = threading.Barrier(len(pipes) + 1)
+    def worker(p):
+        loop(p, warmup)
+        gate.wait()            # warm-up done everywhere
+        gate.wait()            # go
+        loop(p, steps)
+        gate.wait()            # done
+    th = [threading.Thread(target=worker, args=(p,)) for p in pipes]
+    for t in th:
+        t.start()
+    gate.wait()
+    sync_all(); barrier(); sync_all()
+    t0 = time.perf_counter()
+    gate.wait()
+    gate.wait()
+    sync_all(); barrier(); sync_all()
+    el = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    return el
+
+
+def end_to_end(pipe, batches=40):
+    """SURVEY 8(d) 'end-to-end': page-locked host frames in (H2D), kernels, every keypoint + descriptor + count out (D2H) -- two contexts
+    software-pipelined: while one sub-batch is in its kernels the other one's frames go up and results come down."""
+    import torch
+    from orb_ygz_slam_amd.capi import KP_DTYPE
+    from orb_ygz_slam_amd import Extractor
+    w, h, nl, sf, nf, ini, mn = pipe.cfg
+    B = pipe.sub
+    exs = list(pipe.exs[:2])
+    while len(exs) < 2:
+        exs.append(Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=pipe.device))
+    stride = exs[0].max_keypoints(w, h)
+    pins, outs, keep = [], [], []
+    for i in range(2):
+        src = pipe.frames[(i * B) % len(pipe.frames):][:B]
+        if len(src) < B:
+            src = np.concatenate([src, pipe.frames[:B - len(src)]])
+        pf = torch.from_numpy(np.ascontiguousarray(src)).pin_memory()
+        ok = torch.empty((B, stride, KP_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+        od = torch.empty((B, stride, 32), dtype=torch.uint8).pin_memory()
+        on = torch.empty(B, dtype=torch.int32).pin_memory()
+        keep += [pf, ok, od, on]
+        pins.append(pf.numpy())
+        outs.append((ok.numpy().view(KP_DTYPE).reshape(B, stride), od.numpy(), on.numpy()))
+
+    def submit(i):
+        exs[i].extract_batch_host(pins[i])
+        exs[i].match_batch_prev(pipe.cam, 15.0, True, True, True)
+    submit(0); submit(1); exs[0].batch_fetch_all(B, outs[0]); exs[1].batch_fetch_all(B, outs[1])     # warm-up
+    t0 = time.perf_counter()
+    submit(0)
+    for it in range(1, batches):
+        submit(it & 1)                                                  # enqueue the next sub-batch on the other stream ...
+        exs[(it - 1) & 1].batch_fetch_all(B, outs[(it - 1) & 1])        # ... then wait for / download the previous one
+    exs[(batches - 1) & 1].batch_fetch_all(B, outs[(batches - 1) & 1])
+    return B * batches, time.perf_counter() - t0
+
+
+def kernel_table(prof):
+    return {name: {"launches": n, "avg_us": round(1e3 * ms / n, 2), "total_ms": round(ms, 3)} for name, (ms, n) in prof.items() if n}
+
+
+def hbm_roofline(workload, kernels, iso, per_kernel, frames_per_launch, total_bytes, fps_per_gpu, only=None):
+    cand = [k for k in kernels if per_kernel.get(k, 0) > 0 and (only is None or k == only)]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda k: kernels[k]["total_ms"])
+    div = WORKLOADS[workload][2] - 1 if dom == "k_pyr_resize" else 1      # the L-1 resize launches share the pyramid's bytes
+    bytes_per_launch = per_kernel[dom] * frames_per_launch / div
+    avg_s = kernels[dom]["avg_us"] * 1e-6
+    achieved = bytes_per_launch / avg_s / 1e9
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(workload, {}).get(dom)
+        except Exception:
+            traffic = None
+    iso_us = iso.get(dom)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(bytes_per_launch),
+            "isolated_avg_us": iso_us,
+            "isolated_frac": round(bytes_per_launch / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5) if iso_us else None,
+            "pipeline_achieved": round(total_bytes * fps_per_gpu / 1e9, 2),
+            "pipeline_frac": round(total_bytes * fps_per_gpu / 1e9 / HBM_PEAK_GBS, 5)}
+
+
+def valu_roofline(workload, kernels, iso, frames_per_launch):
+    """Vector-ALU issue roofline of the dominant kernel.  profiles/valu_mix.json (tools/valu_mix.py) holds, per kernel, the VALU
+    instructions per frame (SQ_INSTS_VALU of the PMC profile) and the mean issue cost of one instruction in SIMD cycles (instruction mix of
+    the kernel's ISA weighted with the per-opcode costs calibrated by tools/micro/valu_peak.hip: 2 cycles for the full-rate 32-bit ops, 4 for
+    the byte / packed / three-operand ones).  achieved = issue cycles per launch / launch time; peak = 1024 SIMDs x 2.4 GHz."""
+    f = os.path.join(ROOT, "profiles", "valu_mix.json")
+    if not os.path.exists(f):
+        return None
+    try:
+        mix = json.load(open(f)).get(workload, {})
+    except Exception:
+        return None
+    cand = [k for k in kernels if k in mix]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda k: kernels[k]["total_ms"])
+    m = mix[dom]
+    cycles = m["valu_insts_per_frame"] * frames_per_launch * m["cycles_per_inst"]
+    peak = SIMDS * CLOCK_GHZ                                      # G SIMD-cycles / s
+    ach = cycles / (kernels[dom]["avg_us"] * 1e-6) / 1e9
+    iso_us = iso.get(dom)
+    return {"bound": "valu", "kernel": dom, "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G SIMD-issue-cycles/s",
+            "frac": round(ach / peak, 4), "valu_insts_per_frame": m["valu_insts_per_frame"], "cycles_per_inst": m["cycles_per_inst"],
+            "isolated_frac": round(cycles / (iso_us * 1e-6) / 1e9 / peak, 4) if iso_us else None,
+            "source": "profiles/valu_mix.json"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=768, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (default: sub-batch x streams x rounds of the workload, "
+                                                          "9216 for the 752x480 metric)")
+    ap.add_argument("--sub-batch", type=int, default=0, help="frames per extractor launch (default per workload: 256 / 32 / 8)")
     ap.add_argument("--streams", type=int, default=3,
-                    help="independent extractor contexts (own HIP stream + buffers) the batch is split over, so that the "
+                    help="independent extractor contexts (own HIP stream + buffers) the sub-batches rotate over, so that the "
                          "latency-bound kernels of one sub-batch overlap the throughput-bound kernels of another")
     ap.add_argument("--workload", default="euroc752x480_8lvl_1000feat", choices=sorted(WORKLOADS))
     ap.add_argument("--align", action="store_true",
@@ -123,9 +362,13 @@ def main():
     ap.add_argument("--stereo", action="store_true",
                     help="BASELINE config 5 shape: the batch holds (left, right) pairs; Frame::ComputeStereoMatches runs on every pair "
                          "after extraction (extra work inside the step, see config.stereo)")
+    ap.add_argument("--devices-in-process", type=int, default=1,
+                    help="shard over this many devices inside ONE process (one host thread + contexts per device, SURVEY 8e) instead of / "
+                         "in addition to one process per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_end_to_end and other_workloads")
     ap.add_argument("--plumbing-selftest", action="store_true",
                     help="CPU-only check of the multi-process plumbing (gloo): no GPU work, output is NOT a measurement")
     args = ap.parse_args()
@@ -137,13 +380,24 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     cfg = WORKLOADS[args.workload]
     w, h, nl, sf, nf, ini, mn = cfg
-    B = args.batch
+    S = max(1, args.streams)
+    sub, rounds = SHAPES[args.workload]
+    if args.sub_batch:
+        sub = args.sub_batch
+    if args.batch:
+        if args.batch % (S * sub):
+            raise SystemExit("--batch must be a multiple of --streams x --sub-batch (%d)" % (S * sub))
+        rounds = args.batch // (S * sub)
+    if args.stereo and sub % 2:
+        raise SystemExit("--stereo needs an even --sub-batch")
+    B = S * sub * rounds
+    ndev = max(1, args.devices_in_process)
 
     import torch
     dist = None
     use_gpu = not args.plumbing_selftest
     if use_gpu and torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)          # before the process group: RCCL binds its communicator to the current device
+        torch.cuda.set_device(local_rank * ndev)   # before the process group: RCCL binds its communicator to the current device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -152,20 +406,25 @@ def main():
     def barrier():
         if dist is not None:
             if use_gpu:
-                dist.barrier(device_ids=[local_rank])
+                dist.barrier(device_ids=[local_rank * ndev])
             else:
                 dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=("cuda:%d" % (local_rank * ndev)) if use_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
     if args.plumbing_selftest:
         # exercises sharding, barrier and max-over-ranks reduction without a GPU; never a valid measurement
         barrier()
         t0 = time.perf_counter()
         time.sleep(0.01 * (rank + 1))
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        el = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
-            print(json.dumps({"plumbing_selftest": True, "n_gpus": world, "frames_per_rank": B, "max_elapsed_s": float(el[0]),
+            print(json.dumps({"plumbing_selftest": True, "n_gpus": world, "frames_per_rank": B, "max_elapsed_s": el,
                               "valid_measurement": False}))
         if dist is not None:
             dist.destroy_process_group()
@@ -173,124 +432,127 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    from orb_ygz_slam_amd import Extractor, make_camera
+    have = torch.cuda.device_count()
+    devices = [local_rank * ndev + i for i in range(ndev)]
+    if devices[-1] >= have:
+        raise SystemExit("device %d requested but only %d visible (no extrapolation: SURVEY 8e)" % (devices[-1], have))
 
-    frames = make_frames(B, w, h, seed0=1000 + 97 * rank)   # every rank owns its own clip (one-frame-per-GPU sharding at scale)
-    d_frames = torch.from_numpy(frames).to("cuda:%d" % local_rank)
-    S = max(1, args.streams)
-    if B % S or (args.stereo and (B // S) % 2):
-        raise SystemExit("--batch must be a multiple of --streams (and of 2 x --streams with --stereo)")
-    Bs = B // S
-    exs = [Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=Bs, device=local_rank) for _ in range(S)]
-    ex = exs[0]
-    cam = make_camera(w, h)
-    ptrs = [d_frames.data_ptr() + i * Bs * w * h for i in range(S)]
+    def sync_all():
+        for d in devices:
+            torch.cuda.synchronize(d)
 
-    def step():
-        for e, ptr in zip(exs, ptrs):
-            e.extract_batch_device(ptr, Bs, w, h)
-            e.match_batch_prev(cam, 15.0, True, True, True)
-            if args.align:
-                e.align_batch_prev(cam, nl - 1, 1, 10)
-            if args.stereo:
-                e.stereo_batch(0.11, 47.9)
-
-    for _ in range(args.warmup):
-        step()
-    for e in exs:
-        e.sync()
+    pipes = [Pipeline(d, args.workload, sub, rounds, S, 1000 + 97 * (rank * ndev + i), args.align, args.stereo) for i, d in enumerate(devices)]
     if not args.no_profile:
-        for e in exs:
-            e.profile_enable(True)
-            e.profile_reset()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    for e in exs:
-        e.sync()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el[0])
+        pipes[0].step(); pipes[0].sync()           # first-touch allocations out of the way before events are recorded
+        pipes[0].profile(True)
+    elapsed = max_over_ranks(run_timed(pipes, args.steps, args.warmup, barrier, sync_all))
+    n_gpus = world * ndev
+    total_frames = n_gpus * B * args.steps
+    fps = total_frames / elapsed
 
-    prof = {}
+    pipe = pipes[0]
+    kernels, iso = {}, {}
     if not args.no_profile:
-        for e in exs:
-            for name, (ms, n) in e.profile_read().items():
-                a = prof.get(name, (0.0, 0))
-                prof[name] = (a[0] + ms, a[1] + n)
-            e.profile_enable(False)
-    # untimed extra pass: the same sub-batches one context at a time, so that per-kernel durations are not stretched by the other streams
-    iso = {}
-    if not args.no_profile:
-        for e, ptr in zip(exs, ptrs):
+        prof = pipe.profile_read()
+        pipe.profile(False)
+        # the profile covers warm-up + timed steps of device 0 (same launches; events are only read here, after the region)
+        kernels = kernel_table(prof)
+        # untimed extra pass: one context at a time, so that per-kernel durations are not stretched by the other streams
+        acc = {}
+        for s, e in enumerate(pipe.exs):
             e.profile_enable(True)
             e.profile_reset()
             for _ in range(2):
-                e.extract_batch_device(ptr, Bs, w, h)
-                e.match_batch_prev(cam, 15.0, True, True, True)
+                pipe.launch(e, pipe.ptrs[0][s])
                 e.sync()
             for name, (ms, n) in e.profile_read().items():
-                a = iso.get(name, (0.0, 0))
-                iso[name] = (a[0] + ms, a[1] + n)
+                a = acc.get(name, (0.0, 0))
+                acc[name] = (a[0] + ms, a[1] + n)
             e.profile_enable(False)
-    kp_counts = np.concatenate([e.batch_counts() for e in exs])
-    m_counts = np.concatenate([e.match_counts() for e in exs])
+        iso = {k: round(1e3 * v[0] / v[1], 2) for k, v in acc.items() if v[1]}
+    kp_counts = np.concatenate([e.batch_counts() for e in pipe.exs])
+    m_counts = np.concatenate([e.match_counts() for e in pipe.exs])
+
+    # ---- end-to-end (PCIe inclusive) on every rank at once ----
+    e2e = None
+    if not args.no_extras:
+        barrier()
+        nfr, sec = end_to_end(pipe)
+        sec = max_over_ranks(sec)
+        e2e = {"value": round(world * nfr / sec, 1), "unit": "frames/s", "frames": world * nfr,
+               "what": "pinned host frames -> H2D -> extract + match -> D2H of all keypoints, descriptors and counts; two contexts "
+                       "software-pipelined per GPU (device 0 of each process)"}
+
+    # ---- short runs of the other BASELINE configurations (their own contexts; each rank its own clip) ----
+    others = {}
+    if not args.no_extras and args.workload == "euroc752x480_8lvl_1000feat" and not args.align and not args.stereo:
+        for p in pipes:
+            for e in p.exs:
+                e.close()
+        pipes_keep_frames = pipes[0].frames
+        del pipes
+        torch.cuda.empty_cache()
+        for name, wl, o_align, o_stereo, o_steps in (("fhd1920x1080_8lvl_4000feat", "fhd1920x1080_8lvl_4000feat", False, False, 3),
+                                                     ("uhd3840x2160_12lvl_8000feat_stereo", "uhd3840x2160_12lvl_8000feat", False, True, 3),
+                                                     ("euroc752x480_8lvl_1000feat_align", "euroc752x480_8lvl_1000feat", True, False, 3)):
+            osub, orounds = SHAPES[wl]
+            orounds = max(1, orounds // 4)
+            ps = [Pipeline(d, wl, osub, orounds, S, 5000 + 31 * (rank * ndev + i), o_align, o_stereo, distinct=min(S * osub, 8 if "uhd" in wl else 24 if "fhd" in wl else 96))
+                  for i, d in enumerate(devices)]
+            ps[0].step(); ps[0].sync()
+            ps[0].profile(True)
+            el = max_over_ranks(run_timed(ps, o_steps, 1, barrier, sync_all))
+            oprof = kernel_table(ps[0].profile_read())
+            ps[0].profile(False)
+            ofps = n_gpus * ps[0].batch * o_steps / el
+            ow, oh, onl, osf, onf = WORKLOADS[wl][:5]
+            tb, per = algorithmic_bytes(ow, oh, onl, osf, onf)
+            entry = {"value": round(ofps, 1), "unit": "frames/s" if not o_stereo else "frames/s (2 frames = 1 stereo pair)", "ms_per_step": round(1e3 * el / o_steps, 3),
+                     "frames_per_gpu_per_step": ps[0].batch, "steps": o_steps,
+                     "roofline": hbm_roofline(wl, oprof, {}, per, osub, tb, ofps / n_gpus),
+                     "kernels": {k: v["avg_us"] for k, v in oprof.items()}}
+            if o_align and "k_sia_run" in oprof:
+                nfeat = float(np.concatenate([e.batch_counts() for e in ps[0].exs]).mean())
+                on_chip, in_hbm = align_bytes(onl, nfeat)
+                avg = oprof["k_sia_run"]["avg_us"] * 1e-6
+                entry["roofline_align"] = {"bound": "hbm", "kernel": "k_sia_run", "achieved": round(in_hbm * osub / avg / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": round(in_hbm * osub / avg / 1e9 / HBM_PEAK_GBS, 5),
+                                           "algorithmic_bytes_per_launch": int(in_hbm * osub), "on_chip_bytes_per_launch": int(on_chip * osub),
+                                           "note": "B_align upper bound of SURVEY 8(d) (caches in HBM); the kernel is latency-bound (one workgroup per pair)"}
+            others[name] = entry
+            for p in ps:
+                for e in p.exs:
+                    e.close()
+            del ps
+            torch.cuda.empty_cache()
+        frames_for_cpu = pipes_keep_frames
+    else:
+        frames_for_cpu = pipes[0].frames
 
     if rank == 0:
-        total_frames = world * B * args.steps
-        fps = total_frames / elapsed
         total_bytes, per_kernel = algorithmic_bytes(w, h, nl, sf, nf)
-        roofline = None
-        kernels = {}
-        if prof:
-            for name, (ms, n) in prof.items():
-                if n:
-                    kernels[name] = {"launches": n, "avg_us": round(1e3 * ms / n, 2), "total_ms": round(ms, 3)}
-            # dominant = largest total time among the kernels SURVEY's byte formula covers
-            cand = [k for k in kernels if per_kernel.get(k, 0) > 0]
-            dom = max(cand, key=lambda k: kernels[k]["total_ms"])
-            launches_per_step = kernels[dom]["launches"] / args.steps
-            bytes_per_launch = per_kernel[dom] * B / launches_per_step   # pyramid: 7 launches share its bytes; S sub-batches
-            avg_s = kernels[dom]["total_ms"] / kernels[dom]["launches"] * 1e-3
-            achieved = bytes_per_launch / avg_s / 1e9
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tfile):
-                try:
-                    traffic = json.load(open(tfile)).get(args.workload, {}).get(dom)
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                        "isolated_avg_us": round(1e3 * iso[dom][0] / iso[dom][1], 2) if iso.get(dom, (0, 0))[1] else None,
-                        "isolated_frac": round(bytes_per_launch / (iso[dom][0] / iso[dom][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                        if iso.get(dom, (0, 0))[1] else None,
-                        "pipeline_achieved": round(total_bytes * fps / world / 1e9, 2),
-                        "pipeline_frac": round(total_bytes * fps / world / 1e9 / HBM_PEAK_GBS, 5)}
         out = {
             "metric": "frames/s ORB extract+match, 752x480 8-lvl 1000-feat; 1->8 GPU scaling",
-            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "width": w, "height": h, "levels": nl, "scale_factor": sf, "features": nf,
-                       "frames_per_gpu_per_step": B, "streams": S, "align": bool(args.align), "stereo": bool(args.stereo), "match": "SearchByProjection(cur,last) th=15, identity pose",
+                       "frames_per_gpu_per_step": B, "sub_batch": sub, "rounds_per_step": rounds, "streams": S, "distinct_frames": min(B, S * sub),
+                       "align": bool(args.align), "stereo": bool(args.stereo),
+                       "match": "SearchByProjection(cur,last) th=15, identity pose", "processes": world, "devices_per_process": ndev,
                        "sharding": "one clip per GPU, no collective"},
+            "timed_region_s": round(elapsed, 4),
+            "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e,
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
-            "roofline": roofline, "kernels": kernels,
-            "kernels_isolated_avg_us": {k: round(1e3 * v[0] / v[1], 2) for k, v in iso.items() if v[1]},   # one stream at a time (untimed pass)
+            "roofline": hbm_roofline(args.workload, kernels, iso, per_kernel, sub, total_bytes, fps / n_gpus) if kernels else None,
+            "roofline_valu": valu_roofline(args.workload, kernels, iso, sub) if kernels else None,
+            "kernels": kernels,
+            "kernels_isolated_avg_us": iso,   # one stream at a time (untimed pass)
+            "other_workloads": others or None,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, cfg, args.cpu_seconds)
+        if not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(frames_for_cpu, cfg, args.cpu_seconds)
+            out["cpu_baseline_reference"] = cpu_baseline_reference(frames_for_cpu, cfg, min(6.0, args.cpu_seconds))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

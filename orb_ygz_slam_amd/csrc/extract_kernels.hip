@@ -519,8 +519,11 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
     const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
     // that neighbouring windows, which share cache lines, meet in the same L2.
-    if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
-    const int grp = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);
+    // kFastBlock == 64: one wave per workgroup (a finished cell frees its LDS at once instead of waiting for the slowest of four); the four
+    // cells of a group sit 8 block ids apart, i.e. on the same XCD
+    const unsigned gb = kFastBlock == 64 ? ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u) : blockIdx.x;
+    if ((int) (gb >> 3) >= groupsPerXcd) return;
+    const int grp = (gb & 7) * groupsPerXcd + (gb >> 3);
     const int f = blockIdx.y;
     if (grp >= totalGroups) return;
     int l = 0;
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
     const int gl = grp - g.groupBase;
     const int gCols = (g.nCols + 1) >> 1;
     const int gi = gl / gCols, gj = gl - gi * gCols;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // everything derived from the wave index stays on the scalar unit
+    const int wv = kFastBlock == 64 ? (int) ((blockIdx.x >> 3) & 3u) : __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: stays on the scalar unit
     const int ci = 2 * gi + (wv >> 1), cj = 2 * gj + (wv & 1);
     if (ci >= g.nRows || cj >= g.nCols) return;
     const int c = ci * g.nCols + cj;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
     // more workgroup fits a CU: 8 x 4 waves instead of 6 x 4 at the usual 30-px cells)
     const int smapBytes = (max(smapRows * kSP, quadCap * 4) + 15) & ~15;
     const int perWave = winBytes + smapBytes + kCornerCap * 2;    // all multiples of 16
-    uint8_t *win = fdyn + wv * perWave;
+    uint8_t *win = fdyn + (kFastBlock == 64 ? 0 : wv * perWave);
     uint8_t *smap = win + winBytes;
     unsigned *qlist = (unsigned *) smap;
     unsigned short *clist = (unsigned short *) (smap + smapBytes);
@@ -1462,7 +1465,7 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
                        int nFrames, int winPitch, int winRows, int quadCap) {
     if (totalGroups <= 0) return;
     const int groupsPerXcd = (totalGroups + 7) / 8;
-    const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
+    const dim3 grid(8 * groupsPerXcd * (kFastBlock == 64 ? 4 : 1), nFrames), block(kFastBlock);
     const size_t lds = fast_quads_lds_bytes(winPitch, winRows, smapRows, quadCap);
 #define YGZF_FAST_LAUNCH(KP)                                                                                                            \
     hipLaunchKernelGGL(k_fast_quads<KP>, grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, \
