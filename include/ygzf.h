@@ -216,6 +216,19 @@ int ygzf_search_by_bow(ygzf_ctx *ctx, int n_nodes, const int *kf_off, const int 
                        const uint8_t *kf_valid, const ygzf_kp *kf_keys, const uint8_t *kf_desc, int n_f, const ygzf_kp *f_keys, const uint8_t *f_desc,
                        float nnratio, int check_orientation, int *match, int *nmatches);
 
+/* ---- Frame::ComputeBoW()   src/Frame.cc:495-500 -> ORBVocabulary::transform(features, BowVector, FeatureVector, levelsup = 4), i.e.
+ *      DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1151-1283 ---
+ * The vocabulary tree lives on the device.  ygzf_vocabulary_set uploads it as the reference's loaders build it (loadFromTextFile
+ * :1362-1447, load :1672-1715): node 0 is the root, parent[i] the parent of node i (parent[0] ignored), desc the n_nodes x 32 centroids;
+ * the children of a node are its child nodes in ascending node id (the order m_nodes[pid].children.push_back(nid) produces), a node
+ * without children is a word; depth_levels = m_L.  ygzf_bow_transform propagates n descriptors down the tree (nearest child in Hamming
+ * distance at every level, first minimum wins, :1262-1273) and returns per descriptor the LEAF NODE id it lands in (the caller's
+ * vocabulary object maps it to WordId and idf weight: m_nodes[leaf].word_id / .weight) and the node id at level m_L - levelsup (the
+ * FeatureVector key; 0 = root when m_L - levelsup <= 0).  The BowVector / FeatureVector maps are assembled by the caller in feature order
+ * (std::map containers of the reference; the class shell does it, host/ORBVocabularyDevice.h). */
+int ygzf_vocabulary_set(ygzf_ctx *ctx, int n_nodes, int depth_levels, const int *parent, const uint8_t *desc);
+int ygzf_bow_transform(ygzf_ctx *ctx, int n, const uint8_t *desc, int levelsup, int *leaf_node, int *level_node);
+
 /* ---- ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th, bool checkLevel)
  *      src/ORBmatcher.cc:43-126 (Tracking::SearchLocalPoints, nnratio 0.8) ---------------------------------------------------
  * Per MapPoint i (fields set by Frame::isInFrustum, src/Frame.cc:413-419): track_in_view = mbTrackInView, is_bad = isBad()

@@ -752,3 +752,148 @@ def search_by_projection_mappoints(keys, desc, scale_factors, w, h, cam, track_i
     r = L.yo_search_by_projection_mappoints(C.byref(fr), M, _p(tiv), _p(bad), _p(obs), _p(px), _p(py), _p(pxr), _p(vc), _p(lv), _p(md), th,
                                             int(check_level), nnratio, _p(own), _p(match))
     return r, match[:nt], own[:nt]
+
+
+# ---- Frame::ComputeBoW / DBoW2 vocabulary -------------------------------------------------------------------------------------
+# The oracle of the tree descent is this numpy restatement of TemplatedVocabulary::transform (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+# 1151-1283) + BowVector::addWeight / normalize (BowVector.cpp:34-84) + FeatureVector::addFeature; tests/test_ref_dbow2.py pins it to the
+# reference's own DBoW2 compiled into oracle/_ref/libref_dbow2.so.  ORBvoc.bin itself is a blob the reference does not ship
+# (.MISSING_LARGE_BLOBS): vocabularies here are generated (same k-ary layout, random centroids and idf weights).
+
+def make_vocabulary(seed, k=10, L=3, stop_fraction=0.02):
+    """A full k-ary tree of depth L as the loaders build it: (parent, is_leaf, desc n x 32, weight) in node-id order, node 0 = root;
+    the children of a node are consecutive ids (HKmeans creation order).  A few words get weight 0 (stopped words)."""
+    rng = np.random.default_rng(seed)
+    parent, level = [-1], [0]
+    frontier = [0]
+    for lv in range(1, L + 1):
+        nxt = []
+        for p in frontier:
+            for _ in range(k):
+                parent.append(p); level.append(lv); nxt.append(len(parent) - 1)
+        frontier = nxt
+    n = len(parent)
+    parent = np.array(parent, np.int32)
+    level = np.array(level)
+    is_leaf = (level == L).astype(np.uint8)
+    desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    # children resemble their parent (a few flipped bits per level), so that descents are decided by small margins and ties occur
+    for i in range(1, n):
+        flip = np.zeros(32, np.uint8)
+        for b in rng.integers(0, 256, 24 - 3 * min(level[i], 6)):
+            flip[b >> 3] ^= np.uint8(1 << (b & 7))
+        desc[i] = desc[parent[i]] ^ flip
+    weight = np.where(is_leaf > 0, np.round(rng.uniform(0.5, 9.0, n), 6), 0.0)
+    weight[(is_leaf > 0) & (rng.random(n) < stop_fraction)] = 0.0
+    return dict(k=k, L=L, parent=parent, is_leaf=is_leaf, desc=desc, weight=weight)
+
+
+def write_vocabulary_text(voc, path, scoring=0, weighting=0):
+    """The text format of TemplatedVocabulary::saveToTextFile / loadFromTextFile (:1362-1470): "k L scoring weighting", then one line per
+    node 1..n-1: parent isLeaf 32 descriptor bytes weight."""
+    lines = ["%d %d %d %d" % (voc["k"], voc["L"], scoring, weighting)]
+    for i in range(1, len(voc["parent"])):
+        lines.append("%d %d %s %.6f" % (voc["parent"][i], voc["is_leaf"][i], " ".join(str(int(b)) for b in voc["desc"][i]), voc["weight"][i]))
+    with open(path, "w") as f:
+        f.write("\n".join(lines))     # no trailing newline: the loader's `while(!f.eof())` loop would turn it into one more (bogus) node
+
+
+_POP8 = np.array([bin(i).count("1") for i in range(256)], np.int32)
+
+
+def bow_descend(voc, desc, levelsup=4):
+    """Per descriptor: (leaf node id, node id at level L - levelsup) -- the descent of :1240-1283, first nearest child wins."""
+    parent = voc["parent"]
+    n_nodes = len(parent)
+    order = np.argsort(parent[1:], kind="stable") + 1            # children in ascending node id, grouped by parent
+    counts = np.bincount(parent[1:], minlength=n_nodes)
+    off = np.concatenate([[0], np.cumsum(counts)])
+    d = np.ascontiguousarray(desc, np.uint8)
+    n = len(d)
+    node = np.zeros(n, np.int64)
+    nid = np.zeros(n, np.int64)
+    nid_level = voc["L"] - levelsup
+    active = np.ones(n, bool)
+    level = 0
+    while active.any():
+        level += 1
+        for i in np.nonzero(active)[0]:
+            c0, c1 = off[node[i]], off[node[i] + 1]
+            if c1 == c0:
+                active[i] = False
+                if nid_level > 0 and level - 1 < nid_level:
+                    nid[i] = node[i]
+                continue
+            ch = order[c0:c1]
+            dist = _POP8[voc["desc"][ch] ^ d[i]].sum(1)
+            node[i] = ch[int(np.argmin(dist))]                      # argmin returns the first minimum
+            if level == nid_level:
+                nid[i] = node[i]
+    return node.astype(np.int32), nid.astype(np.int32)
+
+
+def bow_vectors(voc, leaf, nid, scoring_l1=True):
+    """BowVector (ascending word id, tf-idf summed in feature order, L1-normalised) and FeatureVector (node -> feature indices) from the
+    descent -- what transform(features, v, fv, levelsup) assembles (:1151-1238)."""
+    word_of = np.cumsum(voc["is_leaf"]) - 1                         # WordId = rank among the leaves in node order (loadFromTextFile :1433-1440)
+    bow, fv = {}, {}
+    for i, (lf, nd) in enumerate(zip(leaf, nid)):
+        w = float(voc["weight"][lf])
+        if w > 0:
+            wid = int(word_of[lf])
+            bow[wid] = bow.get(wid, 0.0) + w
+            fv.setdefault(int(nd), []).append(i)
+    ids = sorted(bow)
+    vals = [bow[i] for i in ids]
+    if scoring_l1:
+        norm = 0.0
+        for v in vals:
+            norm += abs(v)
+        if norm > 0:
+            vals = [v / norm for v in vals]
+    return np.array(ids, np.int32), np.array(vals, np.float64), {k: np.array(v, np.int32) for k, v in sorted(fv.items())}
+
+
+def ref_dbow2_lib():
+    build()
+    p = os.path.join(_HERE, "_ref", "libref_dbow2.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    L.yr_voc_load_text.restype = C.c_void_p
+    L.yr_voc_load_text.argtypes = [C.c_char_p]
+    L.yr_voc_free.argtypes = [C.c_void_p]
+    L.yr_voc_size.argtypes = [C.c_void_p]
+    L.yr_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    return L
+
+
+class RefVocabulary:
+    """The reference's ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) loaded from a text file by its own loader."""
+
+    def __init__(self, path):
+        self.L = ref_dbow2_lib()
+        assert self.L is not None, "oracle/_ref/libref_dbow2.so not built"
+        self.h = self.L.yr_voc_load_text(path.encode())
+        assert self.h, "loadFromTextFile failed"
+
+    def size(self):
+        return self.L.yr_voc_size(self.h)
+
+    def transform(self, desc, levelsup=4):
+        d = np.ascontiguousarray(desc, np.uint8)
+        n = len(d)
+        ids, vals = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float64)
+        nodes, off, idx = np.zeros(max(n, 1), np.int32), np.zeros(n + 2, np.int32), np.zeros(max(n, 1), np.int32)
+        nb, nf = C.c_int(), C.c_int()
+        rc = self.L.yr_voc_transform(self.h, _p(d), n, levelsup, _p(ids), _p(vals), len(ids), C.byref(nb), _p(nodes), _p(off), _p(idx), len(nodes), C.byref(nf))
+        assert rc == 0
+        fv = {int(nodes[k]): idx[off[k]:off[k + 1]].copy() for k in range(nf.value)}
+        return ids[:nb.value].copy(), vals[:nb.value].copy(), fv
+
+    def __del__(self):
+        try:
+            self.L.yr_voc_free(self.h)
+        except Exception:
+            pass

@@ -62,7 +62,9 @@ public:
     void update(const Vector3d &, const Vector3d &, double) {}
 };
 // include/ORBVocabulary.h: DBoW2::TemplatedVocabulary<...>; Frame::ComputeBoW calls transform()
-#ifdef YGZ_BOUNDARY_BUILD
+#if defined(YGZ_REAL_DBOW2)
+// the reference's real include/ORBVocabulary.h (DBoW2::TemplatedVocabulary) is used: nothing to stand in for
+#elif defined(YGZ_BOUNDARY_BUILD)
 // boundary build (tests/cpp/build_boundary.sh: the reference's own Frame.cc over the PRODUCT's class shells): ExtractFeatures() ends in
 // ComputeBoW(), so the vocabulary must be callable; the test driver supplies the body
 class ORBVocabulary {

@@ -9,7 +9,9 @@
 #ifndef YGZ_REF_FRAME      // the Frame build (tests the reference's own src/Frame.cc) keeps the real include/Frame.h
 #define YGZ_FRAME_H_
 #endif
+#ifndef YGZ_REAL_DBOW2
 #define YGZ_ORBVOCABULARY_H_
+#endif
 #define YGZ_KEYFRAME_H_
 #ifndef YGZ_REF_MAPPOINT   // the MapPoint build (tests the reference's own src/MapPoint.cc) keeps the real include/MapPoint.h
 #define YGZ_MAPPOINT_H

@@ -113,6 +113,8 @@ def load_library(build_if_missing=True):
     L.ygzf_image_cache_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ygzf_image_cache_put.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
     L.ygzf_find_direct_projection_batch.argtypes = [vp, C.POINTER(Camera), C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.ygzf_vocabulary_set.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.ygzf_bow_transform.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
     L.ygzf_predict_scale_steps.argtypes = [C.c_float, C.c_int, vp]
     L.ygzf_is_in_frustum_batch.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.POINTER(FrustumIn), vp, vp, vp, vp, vp, vp]
     L.ygzf_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, C.POINTER(FrustumIn), vp, vp, C.c_float, C.c_int,
@@ -555,6 +557,20 @@ class Extractor:
         self._ck(self.L.ygzf_extract_dso(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g), C.byref(n)))
         return k[:n.value].copy(), d[:n.value].copy(), g.value
 
+    def vocabulary_set(self, parent, desc, depth_levels):
+        """DBoW2 vocabulary tree onto the device: parent[i] of every node (node 0 = root), n_nodes x 32 centroids, m_L."""
+        p = np.ascontiguousarray(parent, np.int32)
+        d = np.ascontiguousarray(desc, np.uint8)
+        self._ck(self.L.ygzf_vocabulary_set(self.h, len(p), depth_levels, _p(p), _p(d)))
+
+    def bow_transform(self, desc, levelsup=4):
+        """Tree descent of n descriptors -> (leaf node id, node id at level L - levelsup) per descriptor."""
+        d = np.ascontiguousarray(desc, np.uint8)
+        n = len(d)
+        leaf, lvl = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        self._ck(self.L.ygzf_bow_transform(self.h, n, _p(d), levelsup, _p(leaf), _p(lvl)))
+        return leaf[:n], lvl[:n]
+
     def describe_keys(self, keys, frame=0, recompute_angle=False):
         """Descriptors (+ optionally IC_Angle) of existing keys on the pyramid of `frame` of the last batch -> (angles, desc)."""
         k = np.ascontiguousarray(keys, KP_DTYPE)
@@ -626,8 +642,8 @@ class Extractor:
         self._ck(self.L.ygzf_profile_reset(self.h))
 
     def profile_read(self):
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        n = (C.c_int * 16)()
-        k = self._ck(self.L.ygzf_profile_read(self.h, names, ms, n, 16))
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = (C.c_int * 32)()
+        k = self._ck(self.L.ygzf_profile_read(self.h, names, ms, n, 32))
         return {names[i].decode(): (ms[i], n[i]) for i in range(k)}

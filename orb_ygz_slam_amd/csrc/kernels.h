@@ -103,6 +103,10 @@ void launch_frustum(hipStream_t st, const FrustumArgs &A);
 // MapPoint::ComputeDistinctiveDescriptors over a MapPoint batch (<= 256 observations per point)
 void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best);
 
+// Frame::ComputeBoW: descriptor -> vocabulary tree descent (match_kernels.hip)
+void launch_bow_descend(hipStream_t st, int n, const uint8_t *desc, const int *childOff, const int *childIdx, const uint8_t *nodeDesc, int nidLevel,
+                        int *leafNode, int *levelNode);
+
 // ---- FAST-10 (fast10_kernels.hip): Thirdparty/fast replacement -------------------------------------------------------
 void launch_fast10(hipStream_t st, const uint8_t *img, int pitch, int x0, int y0, int w, int h, int dx0, int dx1, int dy0, int dy1, int barrier,
                    short *S, int *rowCnt, int *rowKept, int *totals, short *xy, int *scores, int *nonmax, int cap);

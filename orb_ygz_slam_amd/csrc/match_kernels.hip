@@ -917,6 +917,51 @@ void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const ui
     if (nPoints > 0) hipLaunchKernelGGL(k_distinctive, dim3((nPoints + 3) / 4), dim3(256), 0, st, nPoints, obsOff, desc, best);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::ComputeBoW (src/Frame.cc:495-500) -> DBoW2::TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1240-1283): the descriptor is propagated down the k-ary vocabulary tree, at every node to
+// the child whose centroid is nearest in Hamming distance (FORB::distance, FORB.cpp:82-101; first minimum wins: `d < best_d`).
+// One wave per descriptor; the children of the current node go over the lanes (k = 10 for ORBvoc: one step per level), a 64-bit
+// (distance << 32 | child position) minimum picks the first nearest child.  Outputs: the leaf NODE id (the host maps it to WordId /
+// weight: those tables stay with the vocabulary object) and the node id at level L - levelsup (the FeatureVector key).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bow_descend(int n, const uint8_t *__restrict__ desc, const int *__restrict__ childOff,
+                                                     const int *__restrict__ childIdx, const uint8_t *__restrict__ nodeDesc, int nidLevel,
+                                                     int *__restrict__ leafNode, int *__restrict__ levelNode) {
+    const int lane = m_lane(), i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const unsigned long long *q = (const unsigned long long *) (desc + (size_t) i * 32);
+    const unsigned long long q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    int node = 0, level = 0, nid = 0;
+    for (;;) {
+        const int c0 = childOff[node], nc = childOff[node + 1] - c0;
+        if (nc <= 0) break;                       // leaf
+        level++;
+        unsigned long long best = ~0ull;
+        for (int base = 0; base < nc; base += 64) {
+            unsigned long long key = ~0ull;
+            if (base + lane < nc) {
+                const int id = childIdx[c0 + base + lane];
+                const unsigned long long *d = (const unsigned long long *) (nodeDesc + (size_t) id * 32);
+                const unsigned dist = (unsigned) (__popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]));
+                key = ((unsigned long long) dist << 32) | (unsigned) (base + lane);
+            }
+            const unsigned long long m = ~wave_max_u64(~key);   // minimum
+            best = m < best ? m : best;
+        }
+        node = childIdx[c0 + (int) (best & 0xFFFFFFFFu)];
+        if (level == nidLevel) nid = node;
+    }
+    // a leaf above level L - levelsup (ragged tree) leaves *nid unassigned in the reference: defined here as that leaf
+    if (nidLevel > 0 && level < nidLevel) nid = node;
+    if (lane == 0) { leafNode[i] = node; levelNode[i] = nid; }
+}
+
+void launch_bow_descend(hipStream_t st, int n, const uint8_t *desc, const int *childOff, const int *childIdx, const uint8_t *nodeDesc, int nidLevel,
+                        int *leafNode, int *levelNode) {
+    if (n > 0) hipLaunchKernelGGL(k_bow_descend, dim3((n + 3) / 4), dim3(256), 0, st, n, desc, childOff, childIdx, nodeDesc, nidLevel, leafNode, levelNode);
+}
+
 static inline size_t al16(size_t b) { return (b + 15) & ~(size_t) 15; }
 
 // LDS bytes / per-pair global spill bytes of the carve-up in k_match_last for a given plan

@@ -64,9 +64,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_quads", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -99,7 +99,8 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6];
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6];
+    int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
     std::vector<unsigned char> cacheFilled;
@@ -585,6 +586,10 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &b : c->dGen)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dSia)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dVoc)
+        if (b.p) (void) hipFree(b.p);
+    for (auto &b : c->dBow)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dF10)
         if (b.p) (void) hipFree(b.p);
@@ -1554,7 +1559,10 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         FA.viewCos = dVC;
         FA.level = dLv;
         HIPCHECK(c, hipMemsetAsync(dLv, 0, nq * 4, c->stream));   // the matcher indexes scaleFactors[level] only for in-view points
-        launch_frustum(c->stream, FA);
+        {
+            ProfScope ps(c, KK_FRUSTUM);
+            launch_frustum(c->stream, FA);
+        }
     } else {
         HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
         if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
@@ -1664,7 +1672,7 @@ int ygzf_search_by_bow(ygzf_ctx *c, int n_nodes, const int *kf_off, const int *k
     HIPCHECK(c, hipMemsetAsync(c->dNMatch.p, 0, 4, c->stream));
     HIPCHECK(c, hipMemsetAsync(G[9].p, 0, 4 * 32, c->stream));
     {
-        ProfScope ps(c, KK_MATCH);
+        ProfScope ps(c, KK_BOWNODES);
         launch_bow(c->stream, n_nodes, (const int *) G[0].p, (const int *) G[1].p, (const int *) G[2].p, (const int *) G[3].p, (const uint8_t *) G[4].p,
                    (const ygzf_kp *) G[5].p, (const uint8_t *) G[6].p, n_f, (const ygzf_kp *) G[7].p, (const uint8_t *) G[8].p, nnratio, check_orientation != 0,
                    (int *) c->dMatch.p, (unsigned char *) c->dOwner.p, (int *) G[9].p, (int *) c->dNMatch.p);
@@ -1729,7 +1737,10 @@ int ygzf_is_in_frustum_batch(ygzf_ctx *c, const ygzf_camera *cam, int nlevels, i
     A.projX = base; A.projY = base + n; A.projXR = base + 2 * (size_t) n; A.viewCos = base + 3 * (size_t) n;
     A.level = (int *) (base + 4 * (size_t) n);
     HIPCHECK(c, hipMemsetAsync(base, 0, (size_t) n * 20, c->stream));
-    launch_frustum(c->stream, A);
+    {
+        ProfScope ps(c, KK_FRUSTUM);
+        launch_frustum(c->stream, A);
+    }
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipMemcpyAsync(in_view, A.inView, (size_t) n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipMemcpyAsync(proj_x, A.projX, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
@@ -1768,11 +1779,63 @@ int ygzf_distinctive_descriptors_batch(ygzf_ctx *c, int n_points, const int *obs
     HIPCHECK(c, hipMemcpyAsync(c->dTmpA.p, obs_off, 4 * (size_t) (n_points + 1), hipMemcpyHostToDevice, c->stream));
     if (total > 0) HIPCHECK(c, hipMemcpyAsync(c->dTmpC.p, desc, 32 * (size_t) total, hipMemcpyHostToDevice, c->stream));
     {
-        ProfScope ps(c, KK_HAMMING);
+        ProfScope ps(c, KK_DISTINCTIVE);
         launch_distinctive(c->stream, n_points, (const int *) c->dTmpA.p, (const uint8_t *) c->dTmpC.p, (int *) c->dTmpB.p);
     }
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipMemcpyAsync(best_idx, c->dTmpB.p, 4 * (size_t) n_points, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+// ---- Frame::ComputeBoW: vocabulary on the device + tree descent ------------------------------------------------------------------------
+int ygzf_vocabulary_set(ygzf_ctx *c, int n_nodes, int depth_levels, const int *parent, const uint8_t *desc) {
+    if (!c || !parent || !desc) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n_nodes < 1 || depth_levels < 0) return fail(c, YGZF_ERR_INVALID, "bad vocabulary size");
+    HIPCHECK(c, hipSetDevice(c->device));
+    // children lists in ascending node id (= the loaders' push_back order), as CSR
+    std::vector<int> off((size_t) n_nodes + 1, 0), idx((size_t) std::max(n_nodes - 1, 1));
+    for (int i = 1; i < n_nodes; i++) {
+        if (parent[i] < 0 || parent[i] >= n_nodes || parent[i] == i) return fail(c, YGZF_ERR_INVALID, "node %d: parent %d out of range", i, parent[i]);
+        off[(size_t) parent[i] + 1]++;
+    }
+    for (int i = 0; i < n_nodes; i++) off[(size_t) i + 1] += off[i];
+    {
+        std::vector<int> fill(off.begin(), off.end() - 1);
+        for (int i = 1; i < n_nodes; i++) idx[(size_t) fill[parent[i]]++] = i;
+    }
+    int rc;
+    if ((rc = ensure(c, c->dVoc[0], off.size() * sizeof(int))) || (rc = ensure(c, c->dVoc[1], idx.size() * sizeof(int))) ||
+        (rc = ensure(c, c->dVoc[2], (size_t) n_nodes * 32)))
+        return rc;
+    c->vocNodes = 0;
+    HIPCHECK(c, hipMemcpyAsync(c->dVoc[0].p, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->dVoc[1].p, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->dVoc[2].p, desc, (size_t) n_nodes * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->vocNodes = n_nodes;
+    c->vocLevels = depth_levels;
+    return YGZF_OK;
+}
+
+int ygzf_bow_transform(ygzf_ctx *c, int n, const uint8_t *desc, int levelsup, int *leaf_node, int *level_node) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (c->vocNodes < 1) return fail(c, YGZF_ERR_STATE, "no vocabulary on the device (ygzf_vocabulary_set)");
+    if (n < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    if (n == 0) return YGZF_OK;
+    if (!desc || !leaf_node || !level_node) return fail(c, YGZF_ERR_INVALID, "null argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->dBow[0], (size_t) n * 32)) || (rc = ensure(c, c->dBow[1], (size_t) n * 4)) || (rc = ensure(c, c->dBow[2], (size_t) n * 4))) return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->dBow[0].p, desc, (size_t) n * 32, hipMemcpyHostToDevice, c->stream));
+    {
+        ProfScope ps(c, KK_BOW);
+        launch_bow_descend(c->stream, n, (const uint8_t *) c->dBow[0].p, (const int *) c->dVoc[0].p, (const int *) c->dVoc[1].p, (const uint8_t *) c->dVoc[2].p,
+                           c->vocLevels - levelsup, (int *) c->dBow[1].p, (int *) c->dBow[2].p);
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(leaf_node, c->dBow[1].p, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(level_node, c->dBow[2].p, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }

@@ -62,9 +62,8 @@ int MapPoint::PredictScale(const float &currentDist, Frame *pF) {
     return nScale;
 }
 int MapPoint::PredictScale(const float &, KeyFrame *) { yr_unsupported("MapPoint::PredictScale(KeyFrame*)"); }
-// the vocabulary is outside this test (Frame::ComputeBoW has its own device path and test): leave the vectors empty
-void ORBVocabulary::transform(const std::vector<cv::Mat> &, DBoW2::BowVector &, DBoW2::FeatureVector &, int) const {}
 }  // namespace ygz
+#include "ORBVocabularyDevice.h"   // ygz::DeviceORBVocabulary over the reference's real DBoW2 (this build: -DYGZ_REAL_DBOW2)
 
 int main(int argc, char **argv) {
     using namespace ygz;
@@ -80,7 +79,10 @@ int main(int argc, char **argv) {
     cv::Mat dist(4, 1, CV_32F);
     std::memset(dist.data, 0, 4 * sizeof(float));
     const float bf = 47.9f, thDepth = 35.f;
-    ORBVocabulary voc;
+    // src/System.cc builds the vocabulary object and loads it with the reference's own loader; as DeviceORBVocabulary its (virtual)
+    // transform runs on the GPU when Frame::ComputeBoW calls it
+    DeviceORBVocabulary voc;
+    if (!voc.loadFromTextFile(dir + "/voc.txt")) { fprintf(stderr, "vocabulary %s/voc.txt did not load\n", dir.c_str()); return 2; }
 
     // Tracking::Tracking (src/Tracking.cc:179-185): the extractors exist before the first frame arrives
     ORBextractor exL(NF, 1.2f, L, 20, 7), exR(NF, 1.2f, L, 20, 7);
@@ -113,6 +115,26 @@ int main(int argc, char **argv) {
             for (size_t i : v) q.push_back((int) i);
         }
         dump(dir + "/s_grid.bin", q.data(), q.size() * sizeof(int));
+    }
+    {   // Frame::ComputeBoW ran at the end of ExtractFeatures through the device vocabulary; beside it the CPU base class on the same descriptors
+        std::vector<double> bow;
+        for (auto &e : S.mBowVec) { bow.push_back((double) e.first); bow.push_back(e.second); }
+        dump(dir + "/s_bow.bin", bow.data(), bow.size() * sizeof(double));
+        std::vector<int> fvv;
+        for (auto &e : S.mFeatVec) { fvv.push_back((int) e.first); fvv.push_back((int) e.second.size()); for (unsigned f : e.second) fvv.push_back((int) f); }
+        dump(dir + "/s_featvec.bin", fvv.data(), fvv.size() * sizeof(int));
+        DBoW2::BowVector cb;
+        DBoW2::FeatureVector cf;
+        std::vector<cv::Mat> vd = Converter::toDescriptorVector(S.mDescriptors);
+        voc.ORBVocabulary::transform(vd, cb, cf, 4);          // the reference's CPU transform
+        if (cb.size() != S.mBowVec.size() || cf.size() != S.mFeatVec.size()) { fprintf(stderr, "BoW sizes differ from the CPU class\n"); return 5; }
+        auto a = cb.begin();
+        for (auto b = S.mBowVec.begin(); b != S.mBowVec.end(); ++a, ++b)
+            if (a->first != b->first || std::memcmp(&a->second, &b->second, sizeof(double))) { fprintf(stderr, "BowVector differs from the CPU class at word %u\n", a->first); return 5; }
+        auto c = cf.begin();
+        for (auto d = S.mFeatVec.begin(); d != S.mFeatVec.end(); ++c, ++d)
+            if (c->first != d->first || c->second != d->second) { fprintf(stderr, "FeatureVector differs from the CPU class at node %u\n", c->first); return 5; }
+        if (S.mBowVec.empty()) { fprintf(stderr, "empty BowVector\n"); return 5; }
     }
     {   // the shell's device ComputeStereoMatches on the same frame: must equal the reference's CPU result
         Frame S2(S);

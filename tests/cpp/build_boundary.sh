@@ -6,6 +6,8 @@
 #     is force-included ahead of everything, in a checkout one copies it over the file), ORBextractor.cc that of src/ORBextractor.cc;
 #   * ORBmatcher.cc / SparseImageAlign.cc are compiled against the reference's OWN, unchanged include/ORBmatcher.h, SparseImageAlign.h,
 #     NLSSolver.h and define those classes' hot-path members;
+#   * the vocabulary is the reference's REAL DBoW2 (Thirdparty/DBoW2, compiled in), wrapped by ygz::DeviceORBVocabulary, whose virtual
+#     transform() Frame::ComputeBoW reaches unchanged;
 #   * OpenCV, Eigen and Sophus are not installed in this environment: oracle/ref_shim stands in for their headers (test infrastructure);
 #     its compute primitives are replaced by aborting bodies (tests/cpp/mini_cv_nocompute.cpp), the pose algebra behind the Sophus stand-in
 #     is oracle_align.cpp's.
@@ -19,11 +21,13 @@ OUT=$ROOT/tests/cpp/bin
 if [ ! -f "$REF/src/Frame.cc" ]; then echo "reference checkout absent: keeping prebuilt $OUT/boundary_frame (if any)"; exit 0; fi
 mkdir -p "$OUT"
 g++ -O2 -std=c++14 -msse4.2 -pthread -w -ffp-contract=off \
-    -DYGZ_REF_MATCHER -DYGZ_REF_FRAME -DYGZ_BOUNDARY_BUILD -DYGZF_WITH_REFERENCE_HEADERS \
+    -DYGZ_REF_MATCHER -DYGZ_REF_FRAME -DYGZ_BOUNDARY_BUILD -DYGZ_REAL_DBOW2 -DYGZF_WITH_REFERENCE_HEADERS \
     -I"$S" -I"$ROOT/oracle" -I"$REF/include" -I"$REF" -I"$H" \
-    -include "$S/mini_cv.h" -include "$H/ORBextractor.h" \
+    -include "$S/dbow2_stubs.h" -include "$H/ORBextractor.h" \
     "$REF/src/Frame.cc" \
-    "$H/ORBextractor.cc" "$H/ORBmatcher.cc" "$H/SparseImageAlign.cc" "$H/ygzf_pool.cc" \
+    "$H/ORBextractor.cc" "$H/ORBmatcher.cc" "$H/SparseImageAlign.cc" "$H/ORBVocabularyDevice.cc" "$H/ygzf_pool.cc" \
+    "$REF/Thirdparty/DBoW2/DBoW2/FORB.cpp" "$REF/Thirdparty/DBoW2/DBoW2/BowVector.cpp" "$REF/Thirdparty/DBoW2/DBoW2/FeatureVector.cpp" \
+    "$REF/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp" "$REF/Thirdparty/DBoW2/DUtils/Random.cpp" "$REF/Thirdparty/DBoW2/DUtils/Timestamp.cpp" \
     "$ROOT/tests/cpp/boundary_frame.cc" "$ROOT/tests/cpp/mini_cv_nocompute.cpp" \
     "$ROOT/oracle/oracle_align.cpp" "$ROOT/oracle/oracle_direct.cpp" \
     -L"$ROOT/orb_ygz_slam_amd/lib" -lygzf -Wl,-rpath,'$ORIGIN/../../../orb_ygz_slam_amd/lib' \

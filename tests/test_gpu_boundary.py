@@ -31,6 +31,8 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
         imgR[bnd * 80:(bnd + 1) * 80, :w - dsp] = imgL[bnd * 80:(bnd + 1) * 80, dsp:]
     np.array([w, h, NF, L], np.int32).tofile(tmp_path / "size.i32")
     imgL.tofile(tmp_path / "left.u8"); imgR.tofile(tmp_path / "right.u8"); imgN.tofile(tmp_path / "next.u8")
+    voc = oracle.make_vocabulary(23, 10, 5)          # ORBvoc's shape (k = 10) one level shallower: 111 111 nodes, levelsup = 4 -> FeatureVector keys at level 1
+    oracle.write_vocabulary_text(voc, str(tmp_path / "voc.txt"))
     out = subprocess.run([EXE, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "boundary ok" in out.stdout
@@ -54,6 +56,16 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     assert (rd("s_uright_dev.bin", np.float32).view(np.uint32) == our.view(np.uint32)).all()                               # device ComputeStereoMatches
     assert (rd("s_depth_dev.bin", np.float32).view(np.uint32) == odp.view(np.uint32)).all()
     assert (our >= 0).sum() > 100
+    # Frame::ComputeBoW -> DeviceORBVocabulary::transform (the binary has already compared it with the reference's CPU DBoW2 class)
+    leaf, nid = oracle.bow_descend(voc, dl, 4)
+    o_ids, o_vals, o_fv = oracle.bow_vectors(voc, leaf, nid)
+    bow = rd("s_bow.bin", np.float64).reshape(-1, 2)
+    assert (bow[:, 0].astype(np.int32) == o_ids).all() and (bow[:, 1].view(np.uint64) == o_vals.view(np.uint64)).all() and len(o_ids) > 100
+    fvv, pos = rd("s_featvec.bin", np.int32), 0
+    for key in sorted(o_fv):
+        assert fvv[pos] == key and fvv[pos + 1] == len(o_fv[key]) and (fvv[pos + 2:pos + 2 + fvv[pos + 1]] == o_fv[key]).all()
+        pos += 2 + fvv[pos + 1]
+    assert pos == len(fvv)
     g = rd("s_grid.bin", np.int32)
     pos = 0
     for k in range(12):
