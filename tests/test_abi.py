@@ -58,3 +58,30 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r'^\s*#include\s*[<"][^>"\n]*oracle|^\s*from\s+oracle\b|^\s*import\s+oracle\b|libygz_oracle', txt, flags=re.M):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_device_index_is_never_silently_remapped():
+    """ygzf_create(device = k) on a host without that device: YGZF_ERR_NO_DEVICE for every index, no fall-back to another device or to the CPU."""
+    if have_gpu():
+        pytest.skip("GPU present (the live-device form of this check is tests/test_gpu_errors.py)")
+    from orb_ygz_slam_amd.capi import ExtractorCfg, load_library
+    L = load_library()
+    for dev in (0, 1, 7, -1):
+        h = C.c_void_p()
+        assert L.ygzf_create(dev, C.byref(ExtractorCfg(1000, 1.2, 8, 20, 7, 0)), 640, 480, 1, C.byref(h)) == -2 and not h.value
+
+
+def test_scale_tables_without_a_device(oracle):
+    """ORBextractor's constructor tables come from host arithmetic alone (ygzf_scale_tables_host): Frame's constructors read them before any
+    image -- and any device -- is involved.  Equal to the oracle's (= the reference constructor's, tests/test_ref_extractor.py)."""
+    import numpy as np
+    from orb_ygz_slam_amd.capi import ExtractorCfg, load_library
+    L = load_library()
+    for nf, sf, nl in ((1000, 1.2, 8), (2000, 1.2, 8), (8000, 1.2, 12), (500, 2.0, 4), (1234, 1.1, 16)):
+        sc, inv, s2, is2 = (np.zeros(nl, np.float32) for _ in range(4))
+        nfeat = np.zeros(nl, np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        assert L.ygzf_scale_tables_host(C.byref(ExtractorCfg(nf, sf, nl, 20, 7, 0)), vp(sc), vp(inv), vp(s2), vp(is2), vp(nfeat)) == 0
+        t = oracle.Extractor(nf, sf, nl, 20, 7).tables()
+        assert (sc == t["scale"]).all() and (inv == t["inv_scale"]).all() and (s2 == t["sigma2"]).all() and (is2 == t["inv_sigma2"]).all()
+        assert (nfeat == t["nfeat"]).all()

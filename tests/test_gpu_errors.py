@@ -22,6 +22,17 @@ def test_misuse_is_reported_not_absorbed(oracle):
         assert len(L.ygzf_last_error(None)) > 0
     h = C.c_void_p()
     assert L.ygzf_create(99, C.byref(ExtractorCfg(1000, 1.2, 8, 20, 7)), 640, 480, 1, C.byref(h)) < 0      # no such device
+    # one past the last visible device: YGZF_ERR_NO_DEVICE (-2), never a silent fall-back to device 0; the last device itself works
+    import torch
+    nd = torch.cuda.device_count()
+    assert L.ygzf_create(nd, C.byref(ExtractorCfg(1000, 1.2, 8, 20, 7)), 640, 480, 1, C.byref(h)) == -2 and not h.value
+    assert L.ygzf_create(-1, C.byref(ExtractorCfg(1000, 1.2, 8, 20, 7)), 640, 480, 1, C.byref(h)) == -2 and not h.value
+    assert b"out of range" in L.ygzf_last_error(None)
+    last = Extractor(300, 1.2, 4, 20, 7, max_width=320, max_height=240, device=nd - 1)
+    k_last, _ = last.extract(synth_frame(2, 320, 240))
+    assert len(k_last) > 0
+    last.close()
+    assert L.ygzf_create(0, C.byref(ExtractorCfg(1000, 1.2, 8, 20, 7, 3)), 640, 480, 1, C.byref(h)) == -1   # cv_mode out of range
     w, hh = 640, 480
     ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=hh, max_batch=2)
     img = synth_frame(0, w, hh)

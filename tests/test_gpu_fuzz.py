@@ -1,5 +1,6 @@
 """GPU fuzz parity: random configurations of the matcher, stereo, DSO and extractor paths against the oracle.  The number of seeds per
-test is YGZF_FUZZ_SEEDS (default 6) so that the suite stays short; run with a larger value when hunting."""
+test is YGZF_FUZZ_SEEDS (default 32 for the cheap fuzzers, a quarter of that for the two that run whole image batches / permuted oracle
+re-runs per seed); run with a larger value when hunting."""
 import os
 
 import numpy as np
@@ -8,7 +9,10 @@ import pytest
 from orb_ygz_slam_amd.synth import synth_frame
 
 pytestmark = pytest.mark.gpu
-SEEDS = range(int(os.environ.get("YGZF_FUZZ_SEEDS", "6")))
+NSEEDS = int(os.environ.get("YGZF_FUZZ_SEEDS", "32"))
+SEEDS = range(NSEEDS)
+SEEDS_HEAVY = range(max(NSEEDS // 4, 4))
+ALIGN_STATS = {"well": 0, "ill": 0, "worst_well": 0.0}
 
 
 def _cfg(rng, max_w=800, max_h=620, max_feat=2500):
@@ -19,7 +23,7 @@ def _cfg(rng, max_w=800, max_h=620, max_feat=2500):
     return w, h, nl, sf, nf
 
 
-@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("seed", SEEDS_HEAVY)
 def test_fuzz_special_images(oracle, seed):
     """Degenerate image content: flat, saturated, 1-px checkerboard, ramps, sparse impulses, hard binary edges, corner-dense bowls."""
     from orb_ygz_slam_amd import Extractor
@@ -237,7 +241,7 @@ def test_fuzz_frustum_and_distinctive(oracle, seed):
     assert (ex.distinctive_descriptors_batch(off, desc) == oracle.distinctive_descriptors(off, desc)).all()
 
 
-@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("seed", SEEDS_HEAVY)
 def test_fuzz_sparse_img_align(oracle, seed):
     """SparseImgAlign::run with random motions, level ranges, iteration counts, feature budgets and invalid / outlier MapPoints
     (SE3 within 1e-5 of the oracle, same measurement count)."""
@@ -273,8 +277,27 @@ def test_fuzz_sparse_img_align(oracle, seed):
         op = oracle.sparse_img_align(k[perm], world[perm], ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter,
                                      mp_valid=valid[perm], outlier=outl[perm])
         band = max(band, float(np.abs(op[1] - o[1]).max()))
-    tol = max(1e-5, 10.0 * band)   # a pose that differs in the last bits can flip a feature across a level's border test: discrete jumps
-    assert np.abs(g[1] - o[1]).max() <= tol, (nl, nf, max_level, min_level, n_iter, tol, g[1], o[1])
+    err = float(np.abs(g[1] - o[1]).max())
+    if band < 1e-6:
+        # well-conditioned (the reference's own result is stable under re-ordering to below 1e-6): the north_star tolerance, no allowance
+        ALIGN_STATS["well"] += 1
+        ALIGN_STATS["worst_well"] = max(ALIGN_STATS["worst_well"], err)
+        assert err <= 1e-5, (nl, nf, max_level, min_level, n_iter, band, g[1], o[1])
+    else:
+        # ill-conditioned: a pose that differs in the last bits can flip a feature across a level's border test (discrete jumps); the device
+        # is held to ten times the oracle's own re-ordering band and the case is counted
+        ALIGN_STATS["ill"] += 1
+        assert err <= max(1e-5, 10.0 * band), (nl, nf, max_level, min_level, n_iter, band, g[1], o[1])
+
+
+def test_fuzz_sparse_img_align_report():
+    """Runs after the seeds above: most cases must be well-conditioned ones held to 1e-5 (printed with -s / in the failure message)."""
+    n = ALIGN_STATS["well"] + ALIGN_STATS["ill"]
+    if n == 0:
+        pytest.skip("aligner fuzz did not run")
+    print("aligner fuzz: %d well-conditioned cases within 1e-5 (worst %.2e), %d ill-conditioned held to 10 x band" %
+          (ALIGN_STATS["well"], ALIGN_STATS["worst_well"], ALIGN_STATS["ill"]))
+    assert ALIGN_STATS["well"] >= max(1, 0.25 * n), ALIGN_STATS     # random level ranges / 1-iteration runs / 60-feature budgets make about half the cases ill-posed
 
 
 @pytest.mark.parametrize("seed", SEEDS)

@@ -32,6 +32,30 @@ def test_compute_stereo_matches(oracle, w, h, nfeat, seed):
     assert np.median(err) < 0.5
 
 
+def test_compute_stereo_matches_uhd_config5(oracle):
+    """BASELINE config 5 shape: 3840x2160 stereo pair, 12 pyramid levels, 8000 features per eye -- extraction of both eyes and
+    ComputeStereoMatches (batch-resident form, as bench.py --stereo runs it) bit-identical to the oracle."""
+    from orb_ygz_slam_amd import Extractor
+    w, h = 3840, 2160
+    left, right, bh, ds = stereo_scene(31, w, h)
+    ex = Extractor(8000, 1.2, 12, 20, 7, max_width=w, max_height=h, max_batch=2)
+    oex = oracle.Extractor(8000, 1.2, 12, 20, 7)
+    ex.extract_batch_host(np.stack([left, right]))
+    ex.stereo_batch(MB, MBF)
+    kl, dl = ex.batch_fetch(0)
+    kr, dr = ex.batch_fetch(1)
+    okl, odl = oex.extract(left)
+    okr, odr = oex.extract(right)
+    assert len(kl) == len(okl) > 7000 and (kl == okl).all() and (dl == odl).all()
+    assert len(kr) == len(okr) and (kr == okr).all() and (dr == odr).all()
+    ur, dp = ex.stereo_fetch(0)
+    our, odp = oex.compute_stereo_matches(left, right, kl, dl, kr, dr, MB, MBF)
+    assert _same(ur[:len(kl)], our) and _same(dp[:len(kl)], odp)
+    assert (our >= 0).sum() > 1000
+    ur2, dp2 = ex.compute_stereo_matches(left, right, kl, dl, kr, dr, MB, MBF)     # host-array form
+    assert _same(ur2, our) and _same(dp2, odp)
+
+
 def test_stereo_batch_resident(oracle):
     from orb_ygz_slam_amd import Extractor
     w, h = 752, 480
