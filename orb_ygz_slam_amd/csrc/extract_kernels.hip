@@ -509,30 +509,17 @@ __device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh, int kSP) 
 // window.  Pass 1 lists the quads that hold a corner (raster order); the quad list is expanded into the corner list (raster order);
 // then score per corner -> private score map, 3x3 NMS for both thresholds, cell-empty fallback and ordered output.  The common case
 // (<= 64 corners in the cell) keeps everything after the expansion in registers.  kP = compile-time window pitch (0: run-time).
+// one cell = one wave's unit of work; returns when the cell is done (all paths), so that a wave can take several cells in a row
 template <int kP>
-__global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
-                                                          int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
-                                                          unsigned *__restrict__ slots, int totalCells, long long totalSlots,
-                                                          int totalGroups, int groupsPerXcd, int winPitch, int winRows,
-                                                          int smapRows, int quadCap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
-    // that neighbouring windows, which share cache lines, meet in the same L2.
-    // kFastBlock == 64: one wave per workgroup (a finished cell frees its LDS at once instead of waiting for the slowest of four); the four
-    // cells of a group sit 8 block ids apart, i.e. on the same XCD
-    const unsigned gb = kFastBlock == 64 ? ((blockIdx.x >> 5) << 3) | (blockIdx.x & 7u) : blockIdx.x;
-    if ((int) (gb >> 3) >= groupsPerXcd) return;
-    const int grp = (gb & 7) * groupsPerXcd + (gb >> 3);
-    const int f = blockIdx.y;
-    if (grp >= totalGroups) return;
+__device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *__restrict__ geom, int nlevels, int iniTh, int minTh,
+                                          unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells, long long totalSlots,
+                                          int winPitch, int winRows, int smapRows, int quadCap, uint8_t *fdyn, int grp, int f, int wv, int lane) {
     int l = 0;
     while (l + 1 < nlevels && grp >= geom[l + 1].groupBase) l++;
     const LevelGeom g = geom[l];
     const int gl = grp - g.groupBase;
     const int gCols = (g.nCols + 1) >> 1;
     const int gi = gl / gCols, gj = gl - gi * gCols;
-    const int wv = kFastBlock == 64 ? (int) ((blockIdx.x >> 3) & 3u) : __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: stays on the scalar unit
     const int ci = 2 * gi + (wv >> 1), cj = 2 * gj + (wv & 1);
     if (ci >= g.nRows || cj >= g.nCols) return;
     const int c = ci * g.nCols + cj;
@@ -552,7 +539,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
     // more workgroup fits a CU: 8 x 4 waves instead of 6 x 4 at the usual 30-px cells)
     const int smapBytes = (max(smapRows * kSP, quadCap * 4) + 15) & ~15;
     const int perWave = winBytes + smapBytes + kCornerCap * 2;    // all multiples of 16
-    uint8_t *win = fdyn + (kFastBlock == 64 ? 0 : wv * perWave);
+    uint8_t *win = fdyn + wv * perWave;
     uint8_t *smap = win + winBytes;
     unsigned *qlist = (unsigned *) smap;
     unsigned short *clist = (unsigned short *) (smap + smapBytes);
@@ -744,6 +731,35 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
             if (lane == 0) *cnt_out = (unsigned short) total;
             break;
         }
+    }
+}
+
+
+// One workgroup = kFastRep consecutive 2x2 groups of cells of one frame, one WAVE per cell position, no block-level synchronisation: a wave
+// works through its kFastRep cells one after the other.  Measured (isolated, 256 frames): 1 cell per wave 625-645 us, 2 cells 644 us,
+// 4 cells 742 us -- longer-lived waves lose more to imbalance inside a workgroup (its LDS is held until the slowest wave ends) and to
+// the grid's tail than they gain from fewer workgroup launches, so one cell per wave stays.
+constexpr int kFastRep = 1;
+template <int kP>
+__global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
+                                                          int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
+                                                          unsigned *__restrict__ slots, int totalCells, long long totalSlots,
+                                                          int totalGroups, int groupsPerXcd, int winPitch, int winRows,
+                                                          int smapRows, int quadCap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
+    // that neighbouring windows, which share cache lines, meet in the same L2.  groupsPerXcd counts workgroups (kFastRep groups each).
+    if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
+    const int sg = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);
+    const int f = blockIdx.y;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // everything derived from the wave index stays on the scalar unit
+#pragma unroll 1
+    for (int r = 0; r < kFastRep; r++) {
+        const int grp = sg * kFastRep + r;
+        if (grp >= totalGroups) return;
+        fast_cell<kP>(fs, geom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, winPitch, winRows, smapRows, quadCap, fdyn, grp, f, wv, lane);
+        wave_lds_sync();   // the next cell reuses this wave's LDS region
     }
 }
 
@@ -1464,8 +1480,8 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
                        int nFrames, int winPitch, int winRows, int quadCap) {
     if (totalGroups <= 0) return;
-    const int groupsPerXcd = (totalGroups + 7) / 8;
-    const dim3 grid(8 * groupsPerXcd * (kFastBlock == 64 ? 4 : 1), nFrames), block(kFastBlock);
+    const int groupsPerXcd = ((totalGroups + kFastRep - 1) / kFastRep + 7) / 8;    // workgroups (of kFastRep groups) per XCD
+    const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
     const size_t lds = fast_quads_lds_bytes(winPitch, winRows, smapRows, quadCap);
 #define YGZF_FAST_LAUNCH(KP)                                                                                                            \
     hipLaunchKernelGGL(k_fast_quads<KP>, grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, \

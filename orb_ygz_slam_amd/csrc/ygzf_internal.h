@@ -17,7 +17,7 @@ constexpr int kEdgeThreshold = 19;    // :75
 constexpr int kBorder = kEdgeThreshold - 3;  // minBorderX of ComputeKeyPointsOctTree (:733)
 constexpr int kMaxLevels = 16;
 constexpr int kMaxCellWin = 66;       // window side of one FAST cell: wCell(<60)+6
-constexpr int kFastBlock = 256;   // 4 cells per workgroup; single-wave workgroups (64) measured slower: 739 vs 625 us per 256 frames
+constexpr int kFastBlock = 256;   // 4 waves (cell positions) per workgroup; single-wave workgroups measured slower: 739 vs 625 us per 256 frames
 constexpr int kOctBlock = 1024;
 // The dynamic-LDS ceiling of a kernel is a per-process attribute of the function: it is always set to the same value (the CU's 160 KB
 // minus room for static LDS), never to a per-call size, so that contexts used from different threads cannot lower it under each other.
