@@ -192,6 +192,27 @@ int main(int argc, char **argv) {
         if (cur.mvpMapPoints[i]) assigned[i] = (int) (cur.mvpMapPoints[i] - mps.data());
     dump(dir + "/m_match.bin", assigned.data(), assigned.size() * sizeof(int));
     dump(dir + "/m_nmatch.bin", &nm, sizeof nm);
+    // SearchLocalPointsDirect (:2174-2326): FindDirectProjection(KF, &cur, mp, px, level) once per candidate, through the reference's class
+    {
+        KeyFrame KF;
+        KF.mnId = 3;
+        KF.mvKeys = last.mvKeys;
+        KF.mvImagePyramid = last.mvImagePyramid;
+        KF.mPose = last.mTcw;
+        const int nd = std::min(last.N, 120);
+        std::vector<float> out((size_t) nd * 4);
+        for (int i = 0; i < nd; i++) {
+            mps[i].mObservations[&KF] = (size_t) i;
+            Vector2f px(last.mvKeys[i].pt.x + ((i % 5) - 2) * 0.75f, last.mvKeys[i].pt.y + ((i % 3) - 1) * 0.5f);
+            int level = -1;
+            const bool ok = matcher.FindDirectProjection(&KF, &cur, &mps[i], px, level);
+            out[4 * i] = px[0]; out[4 * i + 1] = px[1]; out[4 * i + 2] = (float) level; out[4 * i + 3] = ok ? 1.f : 0.f;
+        }
+        dump(dir + "/m_direct.bin", out.data(), out.size() * sizeof(float));
+        const Eigen::Quaternionf q = cur.mTcw.unit_quaternion();
+        const float c7[7] = {q.x(), q.y(), q.z(), q.w(), cur.mTcw.translation()[0], cur.mTcw.translation()[1], cur.mTcw.translation()[2]};
+        dump(dir + "/m_pose7.bin", c7, sizeof c7);
+    }
     // SearchLocalPoints (:1544-1593): the reference's isInFrustum marks the points, the shell searches
     {
         Frame cur2(cur);

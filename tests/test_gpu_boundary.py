@@ -94,6 +94,21 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     e_n, e_m, _ = oracle.search_by_projection_last(kn, dn, tab["scale"], w, h, EUROC, kl, world, dl, Rcw, tcw, I, z, 15.0)
     assert int(rd("m_nmatch.bin", np.int32)[0]) == e_n and e_n > 100
     assert (rd("m_match.bin", np.int32) == np.where(e_m >= 0, e_m, -1)).all()
+    # FindDirectProjection through the reference's class declaration, one candidate per call
+    dr = rd("m_direct.bin", np.float32).reshape(-1, 4)
+    nd = len(dr)
+    i5, i3 = np.arange(nd) % 5, np.arange(nd) % 3
+    px0 = np.stack([kl["x"][:nd] + (i5 - 2).astype(np.float32) * f(0.75), kl["y"][:nd] + (i3 - 1).astype(np.float32) * f(0.5)], -1).astype(np.float32)
+    opx, osl, ook, _ = oex.find_direct_projection_batch([imgL], imgN, rd("m_pose7.bin", np.float32), EUROC, np.zeros(nd, np.int32), np.tile(ident, (nd, 1)),
+                                                        kl[:nd], world[:nd], px0)
+    assert nd == 120 and (dr[:, 2].astype(np.int32) == osl).all() and (dr[:, 3].astype(np.uint8) == ook).all() and ook.sum() > 60
+    assert np.array_equal(dr[:, :2].copy().view(np.uint32), opx.view(np.uint32))
+    # the link: hot-path members are the product's (strong), the LocalMapping / LoopClosing members still the reference's own (weak)
+    sym = open(EXE + ".symbols").read().splitlines()
+    strong = [l for l in sym if l.startswith("T ")]
+    weak = [l for l in sym if l.startswith("W ")]
+    assert len(strong) == 7 and all(any(n in l for l in strong) for n in ("FindDirectProjection", "SearchForInitialization", "DescriptorDistance", "SearchByBoW(ygz::KeyFrame*, ygz::Frame&"))
+    assert len(weak) == 6 and all(any(n in l for l in weak) for n in ("Fuse", "SearchBySim3", "SearchForTriangulation"))
     # SearchLocalPoints: the reference's isInFrustum (CPU) marks, the shell searches
     fr = rd("m_frustum.bin", np.float32).reshape(-1, 5)
     Ow = -(Rcw.T @ tcw)
