@@ -98,7 +98,10 @@ int ygzf_extract(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, yg
 /* Batched form of the same operator on DEVICE-resident frames: frame f starts at d_imgs + f*frame_stride, rows are
  * row_pitch bytes apart (base pointer, row_pitch and frame_stride must be multiples of 4: the kernels use aligned 32-bit loads).
  * Results stay on the device (chain into ygzf_match_*) until fetched.  Asynchronous on the
- * context stream; ygzf_sync / ygzf_batch_counts / ygzf_batch_fetch synchronise. */
+ * context stream; ygzf_sync / ygzf_batch_counts / ygzf_batch_fetch synchronise.
+ * Lifetime: the context keeps d_imgs as level 0 of the batch -- ygzf_describe_keys, ygzf_stereo_batch, ygzf_align_batch_prev and
+ * ygzf_batch_fetch_level(…, 0, …) read it later -- so the frames must stay valid and unchanged until the next ygzf_extract* call on this
+ * context (or its destruction). */
 int ygzf_extract_batch_device(ygzf_ctx *ctx, const uint8_t *d_imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
 /* Same, host frames (H2D copy of each frame included).  The copy is asynchronous too: `imgs` must stay valid and unchanged until the next
  * synchronising call on this context (ygzf_sync, ygzf_batch_counts, ygzf_batch_fetch*, ...); page-locked memory gives the full PCIe rate. */
