@@ -367,6 +367,9 @@ def main():
     ap.add_argument("--devices-in-process", type=int, default=1,
                     help="shard over this many devices inside ONE process (one host thread + contexts per device, SURVEY 8e) instead of / "
                          "in addition to one process per GPU")
+    ap.add_argument("--reuse-devices", action="store_true",
+                    help="testing aid for --devices-in-process on a box with fewer GPUs: logical device i runs on physical device i %% count "
+                         "(exercises the threaded path; the line is then NOT a scaling measurement and says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -436,6 +439,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     have = torch.cuda.device_count()
     devices = [local_rank * ndev + i for i in range(ndev)]
+    if args.reuse_devices:
+        devices = [d % have for d in devices]
     if devices[-1] >= have:
         raise SystemExit("device %d requested but only %d visible (no extrapolation: SURVEY 8e)" % (devices[-1], have))
 
@@ -541,7 +546,7 @@ def main():
             "config": {"workload": args.workload, "width": w, "height": h, "levels": nl, "scale_factor": sf, "features": nf,
                        "frames_per_gpu_per_step": B, "sub_batch": sub, "rounds_per_step": rounds, "streams": S, "distinct_frames": min(B, S * sub),
                        "align": bool(args.align), "stereo": bool(args.stereo),
-                       "match": "SearchByProjection(cur,last) th=15, identity pose", "processes": world, "devices_per_process": ndev,
+                       "match": "SearchByProjection(cur,last) th=15, identity pose", "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
                        "sharding": "one clip per GPU, no collective"},
             "timed_region_s": round(elapsed, 4),
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e,
