@@ -37,13 +37,15 @@ def test_fuzz_special_images(oracle, seed):
             # 16-px paraboloid bowls: ~68 % of the pixels are FAST corners, > 512 per cell -> the corner list overflows (dense fallback)
             np.clip((((xx % 16) - 8) ** 2 + ((yy % 16) - 8) ** 2) * (250.0 / 128.0), 0, 255).astype(np.uint8),
             np.clip((((xx % 20) - 10) ** 2 + ((yy % 20) - 10) ** 2) * (250.0 / 200.0), 0, 255).astype(np.uint8)]   # ~460 per cell: long lists
-    ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=len(imgs))
+    mode = seed % 3                                   # the three GaussianBlur generations take turns
+    ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=len(imgs), cv_mode=mode)
     oex = oracle.Extractor(nf, sf, nl, 20, 7)
     ex.extract_batch_host(np.stack(imgs))
     for f, img in enumerate(imgs):
         k, d = ex.batch_fetch(f)
-        ok, od = oex.extract(img)
-        assert len(k) == len(ok) and (k == ok).all() and (d == od).all(), (w, h, nl, sf, nf, f)
+        with oracle.cv_mode(mode):
+            ok, od = oex.extract(img)
+        assert len(k) == len(ok) and (k == ok).all() and (d == od).all(), (w, h, nl, sf, nf, f, mode)
 
 
 @pytest.mark.parametrize("seed", SEEDS)
@@ -114,7 +116,8 @@ def test_fuzz_dso(oracle, seed):
     w, h, nl, sf, nf = _cfg(rng, max_feat=3000)
     nf = max(nf, int(w * h / 3600) + 1)              # initial grid <= 60 px
     img = synth_frame(900 + seed, w, h) if seed % 3 else (rng.integers(0, 256, (h, w), dtype=np.uint8) // 2 + 60).astype(np.uint8)
-    ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+    mode = (seed // 2) % 3
+    ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=1, cv_mode=mode)
     oex = oracle.Extractor(nf, sf, nl, 20, 7)
     k0, _ = ex.extract(img)
     inv = oex.tables()["inv_scale"]
@@ -126,7 +129,8 @@ def test_fuzz_dso(oracle, seed):
     g_gpu = g_cpu = int(rng.choice([-1, 12, 25, 40]))
     for it in range(2):
         kg, dg, g_gpu = ex.extract_dso(img, existing=existing if it else None, grid_size=g_gpu)
-        ko, do, g_cpu = oex.extract_dso(img, existing=existing if it else None, grid_size=g_cpu)
+        with oracle.cv_mode(mode):
+            ko, do, g_cpu = oex.extract_dso(img, existing=existing if it else None, grid_size=g_cpu)
         assert g_gpu == g_cpu and len(kg) == len(ko), (w, h, nl, sf, nf, it, g_gpu, g_cpu, len(kg), len(ko))
         assert (kg == ko).all() and (dg == do).all(), (w, h, nl, sf, nf, it)
 
