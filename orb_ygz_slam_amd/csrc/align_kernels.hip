@@ -79,20 +79,6 @@ __device__ __forceinline__ void ldlt_solve6(const float Hin[36], const float bin
     }
 }
 
-// Wave-wide float sum without LDS traffic (DPP inside rows of 16 lanes, rows combined through SGPRs); the result is the same
-// in every lane and bit-reproducible run to run (fixed tree).
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
-    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-    const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-    return (a + b) + (c + d);
-}
-
 // Eight image bytes starting at column c0 of a row as one (unaligned) 8-byte load: scattered single-byte loads were the limit of the patch
 // loops (every lane of a load instruction touches its own cache line; the texture path serialises them).  The load never leaves the row:
 // it starts at min(c0, w - 8) and the result is shifted so that byte 0 is column c0 (callers need at most 8 - shift bytes).
@@ -114,16 +100,50 @@ __device__ __forceinline__ float byte_f(unsigned long long v, int k) {   // k is
     return (float) ((w >> (8 * (k & 3))) & 0xFFu);
 }
 
-// the row part of wave_sum_dpp: every lane ends with the sum of its row of 16
-__device__ __forceinline__ float row_sum_dpp(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
-    return v;
+// The terms of JacobXYZ2Cam (include/SparseImageAlign.h:90-111) that depend on the reference-frame point only, with the reference's
+// operations: ja = (1/z, x/z^2, x*y/z^2, -(1 + x^2/z^2)), jb = (y/z, y/z^2, 1 + y^2/z^2, -x/z)
+__device__ __forceinline__ void jac_terms(const float xr[3], float4 &ja, float4 &jb) {
+    const float x = xr[0], yy = xr[1];
+    const float z_inv = (float) (1. / (double) xr[2]);
+    const float z_inv_2 = z_inv * z_inv;
+    const float J2 = x * z_inv_2, J8 = yy * z_inv_2;
+    ja = make_float4(z_inv, J2, yy * J2, (float) -(1.0 + (double) (x * J2)));
+    jb = make_float4(yy * z_inv, J8, (float) (1.0 + (double) (yy * J8)), -x * z_inv);
 }
 
 constexpr int kAcc = 30;  // 21 upper-triangular H entries + 6 b + chi2 + n_meas + n_visible_features
+
+// The wave totals of the 30 accumulators, written to out[0..29].  Halving tree instead of 30 full butterflies: v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, so ONE add folds lanes l and l + 32 of TWO accumulators (lanes < 32 keep the
+// first, lanes >= 32 the second); v_permlane16_swap does the same with rows of 16 -- after the two stages 8 registers hold, per row of 16
+// lanes, the column sums of a different accumulator (rows 0..3 of register n: accumulators 4n, 4n+2, 4n+1, 4n+3), and four DPP steps
+// inside the rows finish: 86 instructions instead of 210.  Fixed tree -> bit-reproducible run to run.
+__device__ __forceinline__ void wave_sums_30(const float (&acc)[kAcc], float *out, int lane) {
+    float A[16];
+#pragma unroll
+    for (int m = 0; m < 15; m++) {
+        float a = acc[2 * m], b = acc[2 * m + 1];
+        // (inline asm: with this compiler the two results of __builtin_amdgcn_permlane32_swap collapse into one when both feed an add;
+        // the s_nop covers the VALU-write -> permlane-swap-read wait states the compiler would insert for the builtin)
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        A[m] = a + b;
+    }
+    A[15] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        float a = A[2 * n], b = A[2 * n + 1];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        float v = a + b;
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));  // row_ror:4
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+        const int row = lane >> 4;
+        const int k = 4 * n + ((row & 1) << 1) + (row >> 1);
+        if ((lane & 15) == 0 && k < kAcc) out[k] = v;
+    }
+}
+  // 21 upper-triangular H entries + 6 b + chi2 + n_meas + n_visible_features
 
 // DBG: phase clocks (YGZF_SIA_DEBUG) are compiled in only in the instrumented instantiation; the production kernel reads no clock
 template <bool DBG>
@@ -143,7 +163,10 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     const float *world = A.world + (long long) pair * A.kpStride * 3;
     const uint8_t *mpValid = A.mpValid ? A.mpValid + (long long) pair * A.kpStride : nullptr;
     const uint8_t *outlier = A.outlier ? A.outlier + (long long) pair * A.kpStride : nullptr;
-    float *rowCache = A.patchCache + (long long) pair * A.kpStride * 48;   // per (feature, row): patch[4] dx[4] dy[4]
+    // reference patch cache of this pair: 12 planes of float4, plane 3 * row + {0 patch, 1 dx, 2 dy}, feature i at [plane * kpStride + i]
+    // (a lane works on one feature: consecutive lanes read consecutive float4s of a plane)
+    float4 *rowCache = (float4 *) (A.patchCache + (long long) pair * A.kpStride * 48);
+    const size_t plane = (size_t) A.kpStride;
     uint8_t *visible = A.visible + (long long) pair * A.kpStride;
     float *out = A.out + (long long) pair * 48;   // TCR[7], ret, iters, chi2, pad[2], H[36]
 
@@ -160,7 +183,10 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         for (int i = 0; i < 36; i++) s_H[i] = 0;
     }
     float2 *s_uv = (float2 *) (s_feat + A.ldsFeat);
-    for (int i = tid; i < N * 48; i += kSiaBlock) rowCache[i] = 0.f;
+    float4 *s_jac = (float4 *) (s_uv + A.ldsFeat);   // two per feature when A.jacLds
+    uint8_t *s_img = (uint8_t *) s_feat + A.stageOff;   // A.stageBytes: the current image of a level that fits (coarse levels)
+    for (int j = 0; j < 12; j++)
+        for (int i = tid; i < N; i += kSiaBlock) rowCache[j * plane + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();                                            // s_Tref is set
     {   // per-feature terms that do not depend on the level, once per run: the keypoint, the exclusion flags and Tref * Xw go to LDS
         // (the level loop below used to re-read keys / world / flags for every (feature, row) item: two dependent global latencies each)
@@ -173,6 +199,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
             float xyz[3];
             se3_act(Tref, world + 3 * (size_t) i, xyz);
             s_feat[i] = make_float4(xyz[0], xyz[1], xyz[2], 0.f);
+            if (A.jacLds) jac_terms(xyz, s_jac[2 * i], s_jac[2 * i + 1]);
         }
     }
     __syncthreads();
@@ -186,40 +213,68 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         const float scale = A.invScale[level];
         // ---- precomputeReferencePatches.  The reference zeroes the whole jacobian cache per level (:41); only features that
         // stay "visible" from a coarser level but fail this level's border test can still read it, so only their rows are zeroed.
+        // The current image of a coarse level fits the LDS left beside the feature tables: staged once per level with coalesced loads, its
+        // 5 x 5-byte patch gathers then cost LDS bank cycles instead of 64 scattered cache lines per load instruction (the texture path
+        // works such a gather off one line at a time, and the eight waves of the workgroup queue behind each other).
+        const unsigned imgBytes = (unsigned) Lc.h * (unsigned) Lc.pitch;
+        const bool staged = imgBytes + 8 <= (unsigned) A.stageBytes;
+        if (staged) {
+            // every level image the library hands to this kernel starts dword-aligned and is followed by >= 3 bytes of its own allocation
+            // (64-byte pitches in the pyramid buffers, 64-byte rounded slots for uploaded frames): whole dwords, the last one may over-read
+            if (((unsigned long long) Lc.img & 3u) == 0) {
+                const unsigned nd = (imgBytes + 3) >> 2;
+                for (unsigned d = tid; d < nd; d += kSiaBlock) ((unsigned *) s_img)[d] = ((const unsigned *) Lc.img)[d];
+            } else {
+                for (unsigned b = tid; b < imgBytes; b += kSiaBlock) s_img[b] = Lc.img[b];
+            }
+        }
+        const uint8_t *s_cur = s_img;
         const long long p0c = DBG ? wall_clock64() : 0;
         {
-            // work item = (feature, patch row): 4 pixels
-            for (int it = tid; it < 4 * N; it += kSiaBlock) {
-                const int i = it >> 2, y = it & 3;
-                bool ok = true;
+            // work item = feature: the 7 x 8 image bytes under its 4 x 4 patch and the one-pixel gradient ring are loaded once (seven
+            // 8-byte row loads, all in flight together) instead of four rows per (feature, row) item
+            for (int i = tid; i < N; i += kSiaBlock) {
                 const float2 kp = s_uv[i];
                 const float u_ref = kp.x * scale, v_ref = kp.y * scale;
                 const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
-                if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) ok = false;
-                float *rc = rowCache + ((size_t) i * 4 + y) * 12;   // per (feature, row): patch[4] | dx[4] | dy[4]
-                if (!ok) {
+                float4 *rc = rowCache + i;
+                if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) {
                     if (s_feat[i].w != 0.f) {   // visible from an earlier level: its Jacobian counts as zero at this level
+                        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int k = 4; k < 12; k++) rc[k] = 0.f;
+                        for (int y = 0; y < 4; y++) { rc[(3 * y + 1) * plane] = z4; rc[(3 * y + 2) * plane] = z4; }
                     }
                     continue;
                 }
-                if (y == 0) { visible[i] = 1; s_feat[i].w = 1.f; }
+                visible[i] = 1;
+                s_feat[i].w = 1.f;
                 const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
-                const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
-                const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
+                // the reference forms these in double and rounds to float: with u, v >= 3 the fractions are multiples of 2^-22, so 1 - su and
+                // 1 - sv are exact in fp32 and the fp32 product is the same single rounding of the same exact product
+                // (tests/test_kernel_models.py::test_bilinear_weights_fp32)
+                const float usu = 1.f - su, usv = 1.f - sv;
+                const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
                 const int st = Lr.pitch;
-                // columns u-3 .. u+3 of rows v+y-3 .. v+y: p[k] of the scalar form (p = row + u - 2) is byte k + 1
-                const uint8_t *r0 = Lr.img + (long long) (v_ref_i + y - 2) * st;
-                const unsigned long long bm = row_bytes8(r0 - st, u_ref_i - 3, Lr.w), b0 = row_bytes8(r0, u_ref_i - 3, Lr.w);
-                const unsigned long long b1 = row_bytes8(r0 + st, u_ref_i - 3, Lr.w), b2 = row_bytes8(r0 + 2 * st, u_ref_i - 3, Lr.w);
+                // columns u-3 .. u+4 of rows v-3 .. v+3: p[k] of the scalar form (p = row + u - 2) is byte k + 1
+                const uint8_t *rt = Lr.img + (long long) (v_ref_i - 3) * st;
+                unsigned long long R[7];
 #pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    rc[x] = w_tl * byte_f(b0, x + 1) + w_tr * byte_f(b0, x + 2) + w_bl * byte_f(b1, x + 1) + w_br * byte_f(b1, x + 2);
-                    rc[4 + x] = 0.5f * ((w_tl * byte_f(b0, x + 2) + w_tr * byte_f(b0, x + 3) + w_bl * byte_f(b1, x + 2) + w_br * byte_f(b1, x + 3)) -
-                                        (w_tl * byte_f(b0, x) + w_tr * byte_f(b0, x + 1) + w_bl * byte_f(b1, x) + w_br * byte_f(b1, x + 1)));
-                    rc[8 + x] = 0.5f * ((w_tl * byte_f(b1, x + 1) + w_tr * byte_f(b1, x + 2) + w_bl * byte_f(b2, x + 1) + w_br * byte_f(b2, x + 2)) -
-                                        (w_tl * byte_f(bm, x + 1) + w_tr * byte_f(bm, x + 2) + w_bl * byte_f(b0, x + 1) + w_br * byte_f(b0, x + 2)));
+                for (int r = 0; r < 7; r++) R[r] = row_bytes8(rt + (long long) r * st, u_ref_i - 3, Lr.w);
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    const unsigned long long bm = R[y], b0 = R[y + 1], b1 = R[y + 2], b2 = R[y + 3];
+                    float o[12];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        o[x] = w_tl * byte_f(b0, x + 1) + w_tr * byte_f(b0, x + 2) + w_bl * byte_f(b1, x + 1) + w_br * byte_f(b1, x + 2);
+                        o[4 + x] = 0.5f * ((w_tl * byte_f(b0, x + 2) + w_tr * byte_f(b0, x + 3) + w_bl * byte_f(b1, x + 2) + w_br * byte_f(b1, x + 3)) -
+                                           (w_tl * byte_f(b0, x) + w_tr * byte_f(b0, x + 1) + w_bl * byte_f(b1, x) + w_br * byte_f(b1, x + 1)));
+                        o[8 + x] = 0.5f * ((w_tl * byte_f(b1, x + 1) + w_tr * byte_f(b1, x + 2) + w_bl * byte_f(b2, x + 1) + w_br * byte_f(b2, x + 2)) -
+                                           (w_tl * byte_f(bm, x + 1) + w_tr * byte_f(bm, x + 2) + w_bl * byte_f(b0, x + 1) + w_br * byte_f(b0, x + 2)));
+                    }
+                    rc[(3 * y) * plane] = make_float4(o[0], o[1], o[2], o[3]);
+                    rc[(3 * y + 1) * plane] = make_float4(o[4], o[5], o[6], o[7]);
+                    rc[(3 * y + 2) * plane] = make_float4(o[8], o[9], o[10], o[11]);
                 }
             }
         }
@@ -234,8 +289,9 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
             float acc[kAcc];
 #pragma unroll
             for (int k = 0; k < kAcc; k++) acc[k] = 0.f;
-            for (int it = tid; it < 4 * N; it += kSiaBlock) {
-                const int i = it >> 2, y = it & 3;            // work item = (feature, patch row)
+            // work item = feature: projection, interpolation weights and the point's Jacobian terms once per feature (they were rebuilt for
+            // each of its four patch rows), five dword-aligned 8-byte row loads for the 5 x 5 bytes under the patch
+            for (int i = tid; i < N; i += kSiaBlock) {
                 const float4 ft = s_feat[i];
                 if (ft.w == 0.f) continue;
                 const float xr[3] = {ft.x, ft.y, ft.z};
@@ -245,69 +301,106 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 const float u_cur = ucx * scale, v_cur = ucy * scale;
                 const int ui = (int) floorf(u_cur), vi = (int) floorf(v_cur);
                 if (ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 || ui + border >= Lc.w || vi + border >= Lc.h) continue;
-                if (y == 0) acc[29] += 1.f;
+                acc[29] += 1.f;
                 const float su = u_cur - ui, sv = v_cur - vi;
-                const float w_tl = (float) ((1.0 - su) * (1.0 - sv)), w_tr = (float) (su * (1.0 - sv));
-                const float w_bl = (float) ((1.0 - su) * sv), w_br = su * sv;
+                // the reference forms these in double and rounds to float: with u, v >= 3 the fractions are multiples of 2^-22, so 1 - su and
+                // 1 - sv are exact in fp32 and the fp32 product is the same single rounding of the same exact product
+                // (tests/test_kernel_models.py::test_bilinear_weights_fp32)
+                const float usu = 1.f - su, usv = 1.f - sv;
+                const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
                 const int st = Lc.pitch;
-                const uint8_t *p = Lc.img + (long long) (vi + y - 2) * st + (ui - 2);
-                int t0[5], t1[5];
+                const uint8_t *p = Lc.img + (long long) (vi - 2) * st + (ui - 2);
+                // rows vi-2 .. vi+2, columns ui-2 .. ui+2.  Each row is fetched as the two aligned dwords around its first byte (the patch
+                // stays 3 pixels inside the image, so both dwords lie inside the level) and byte-aligned in registers.
+                unsigned rlo[5], rhi[5];
+                if (staged) {
+                    const unsigned o0 = (unsigned) (vi - 2) * (unsigned) st + (unsigned) (ui - 2);
 #pragma unroll
-                for (int k = 0; k < 5; k++) { t0[k] = p[k]; t1[k] = p[st + k]; }
-                const float4 *rcp = (const float4 *) (rowCache + ((size_t) i * 4 + y) * 12);
-                const float4 pc = rcp[0], dxv = rcp[1], dyv = rcp[2];
-                // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point, rebuilt from the LDS copy: the
-                // cached quantity of the reference, (dx*J.row0 + dy*J.row1) * (fx*scale), is re-evaluated with the same
-                // operations, so only patch/dx/dy (12 B per pixel instead of 28 B) stream from memory every iteration
+                    for (int r = 0; r < 5; r++) {
+                        const uint8_t *q = s_cur + o0 + (unsigned) r * (unsigned) st;
+                        const unsigned sh = (unsigned) (unsigned long long) q & 3u;   // LDS addresses: the low bits of the generic pointer are the LDS offset's
+                        const unsigned *qa = (const unsigned *) (q - sh);
+                        const unsigned v0 = qa[0], v1 = qa[1];
+                        rlo[r] = __builtin_amdgcn_alignbyte(v1, v0, sh);
+                        rhi[r] = v1 >> (8 * sh);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 5; r++) {
+                        const uint8_t *q = p + (long long) r * st;
+                        const unsigned sh = (unsigned) (unsigned long long) q & 3u;
+                        const uint2 v = *(const uint2 *) __builtin_assume_aligned(q - sh, 4);
+                        rlo[r] = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+                        rhi[r] = v.y >> (8 * sh);
+                    }
+                }
+                float tf[5][5];
+#pragma unroll
+                for (int r = 0; r < 5; r++) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) tf[r][k] = (float) ((rlo[r] >> (8 * k)) & 0xFFu);
+                    tf[r][4] = (float) (rhi[r] & 0xFFu);
+                }
+                // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point: the cached quantity of the reference,
+                // (dx*J.row0 + dy*J.row1) * (fx*scale), is re-evaluated with the same operations, so only patch/dx/dy (12 B per pixel
+                // instead of 28 B) stream from memory every iteration.  The point-only terms come from LDS when they fit (staged once per run).
                 float J[12];
                 {
-                    const float x = xr[0], yy = xr[1];
-                    const float z_inv = (float) (1. / (double) xr[2]);
-                    const float z_inv_2 = z_inv * z_inv;
-                    J[0] = -z_inv; J[1] = 0.f; J[2] = x * z_inv_2; J[3] = yy * J[2];
-                    J[4] = (float) -(1.0 + (double) (x * J[2])); J[5] = yy * z_inv;
-                    J[6] = 0.f; J[7] = -z_inv; J[8] = yy * z_inv_2; J[9] = (float) (1.0 + (double) (yy * J[8]));
-                    J[10] = -J[3]; J[11] = -x * z_inv;
+                    float4 ja, jb;
+                    if (A.jacLds) { ja = s_jac[2 * i]; jb = s_jac[2 * i + 1]; }
+                    else jac_terms(xr, ja, jb);
+                    J[0] = -ja.x; J[1] = 0.f; J[2] = ja.y; J[3] = ja.z; J[4] = ja.w; J[5] = jb.x;
+                    J[6] = 0.f; J[7] = -ja.x; J[8] = jb.y; J[9] = jb.z; J[10] = -ja.z; J[11] = jb.w;
                 }
                 const float fs = A.fx * scale;
-                const float pcv[4] = {pc.x, pc.y, pc.z, pc.w}, dxa[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, dya[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
-                // The normal equations are sums of thousands of products: their rounding is not part of the reference's definition (its own
-                // result moves in the 7th digit when features are summed in another order, tests/test_gpu_fuzz.py) and the SE3 is graded at
-                // 1e-5, so this block -- and only this block -- lets the compiler contract a*b + c into v_fma_f32 (one full-rate instruction
-                // instead of two, one rounding instead of two): the accumulate phase is issue-bound at two waves per SIMD.
-                {
+                float Jf[12];   // J * (fx * scale): folded once per feature (the reference scales every (dx*J0 + dy*J1) row; see the note below)
+#pragma unroll
+                for (int k = 0; k < 12; k++) Jf[k] = J[k] * fs;
+                acc[28] += 16.f;   // n_meas: one per patch pixel (exact in fp32)
+                const float4 *rcp = rowCache + i;
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    const float4 pc = rcp[(3 * y) * plane], dxv = rcp[(3 * y + 1) * plane], dyv = rcp[(3 * y + 2) * plane];
+                    const float pcv[4] = {pc.x, pc.y, pc.z, pc.w}, dxa[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, dya[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
+                    // The normal equations are sums of thousands of products: their rounding is not part of the reference's definition (its
+                    // own result moves in the 7th digit when features are summed in another order, tests/test_gpu_fuzz.py) and the SE3 is
+                    // graded at 1e-5, so this block -- and only this block -- lets the compiler contract a*b + c into v_fma_f32 (one
+                    // full-rate instruction instead of two, one rounding instead of two) and takes the factor fx*scale into the Jacobian
+                    // terms before instead of after the dx / dy combination: the accumulate phase is issue-bound at two waves per SIMD.
+                    {
 #pragma clang fp contract(fast)
-                    float jj[24];
+                        float jj[24];
 #pragma unroll
-                    for (int x = 0; x < 4; x++)
+                        for (int x = 0; x < 4; x++)
 #pragma unroll
-                        for (int k = 0; k < 6; k++) jj[6 * x + k] = (dxa[x] * J[k] + dya[x] * J[6 + k]) * fs;
+                            for (int k = 0; k < 6; k++) jj[6 * x + k] = dxa[x] * Jf[k] + dya[x] * Jf[6 + k];
 #pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        const float I = w_tl * t0[x] + w_tr * t0[x + 1] + w_bl * t1[x] + w_br * t1[x + 1];
-                        const float res = I - pcv[x];
-                        acc[27] += res * res;
-                        acc[28] += 1.f;
-                        const float j0 = jj[6 * x], j1 = jj[6 * x + 1], j2 = jj[6 * x + 2], j3 = jj[6 * x + 3], j4 = jj[6 * x + 4], j5 = jj[6 * x + 5];
-                        acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j0 * j3; acc[4] += j0 * j4; acc[5] += j0 * j5;
-                        acc[6] += j1 * j1; acc[7] += j1 * j2; acc[8] += j1 * j3; acc[9] += j1 * j4; acc[10] += j1 * j5;
-                        acc[11] += j2 * j2; acc[12] += j2 * j3; acc[13] += j2 * j4; acc[14] += j2 * j5;
-                        acc[15] += j3 * j3; acc[16] += j3 * j4; acc[17] += j3 * j5;
-                        acc[18] += j4 * j4; acc[19] += j4 * j5;
-                        acc[20] += j5 * j5;
-                        acc[21] -= j0 * res; acc[22] -= j1 * res; acc[23] -= j2 * res; acc[24] -= j3 * res; acc[25] -= j4 * res;
-                        acc[26] -= j5 * res;
+                        for (int x = 0; x < 4; x++) {
+                            const float I = w_tl * tf[y][x] + w_tr * tf[y][x + 1] + w_bl * tf[y + 1][x] + w_br * tf[y + 1][x + 1];
+                            const float res = I - pcv[x];
+                            acc[27] += res * res;
+                            const float j0 = jj[6 * x], j1 = jj[6 * x + 1], j2 = jj[6 * x + 2], j3 = jj[6 * x + 3], j4 = jj[6 * x + 4], j5 = jj[6 * x + 5];
+                            acc[0] += j0 * j0; acc[1] += j0 * j1; acc[2] += j0 * j2; acc[3] += j0 * j3; acc[4] += j0 * j4; acc[5] += j0 * j5;
+                            acc[6] += j1 * j1; acc[7] += j1 * j2; acc[8] += j1 * j3; acc[9] += j1 * j4; acc[10] += j1 * j5;
+                            acc[11] += j2 * j2; acc[12] += j2 * j3; acc[13] += j2 * j4; acc[14] += j2 * j5;
+                            acc[15] += j3 * j3; acc[16] += j3 * j4; acc[17] += j3 * j5;
+                            acc[18] += j4 * j4; acc[19] += j4 * j5;
+                            acc[20] += j5 * j5;
+                            acc[21] -= j0 * res; acc[22] -= j1 * res; acc[23] -= j2 * res; acc[24] -= j3 * res; acc[25] -= j4 * res;
+                            acc[26] -= j5 * res;
+                        }
                     }
                 }
             }
             const long long c1 = DBG ? wall_clock64() : 0;
-            // fixed-shape reduction: full-wave DPP sum per accumulator -> one LDS partial per wave (8 x 30 floats); after ONE block barrier
+            // fixed-shape reduction: wave totals of the 30 accumulators (wave_sums_30) -> one LDS partial per wave (8 x 30 floats); after ONE block barrier
             // wave 0 adds the eight waves in order (lanes 0..29), publishes the totals to its own lane 0 through LDS (wave-level
             // synchronisation only) and goes straight on to the solve -- one barrier less per iteration than the row-partial form
-#pragma unroll
-            for (int k = 0; k < kAcc; k++) {
-                const float v = wave_sum_dpp(acc[k]);
-                if (lane == 0) s_red[wave * kAcc + k] = v;
+            wave_sums_30(acc, s_red + wave * kAcc, lane);
+            if (DBG && A.dbg) {
+                if (tid == 0) A.dbg[5] += wall_clock64() - c1;
+                if (tid == kSiaBlock - 64) A.dbg[6] += c1 - c0;
+                if (lane == 0) A.dbg[8 + wave] += c1 - c0;
             }
             __syncthreads();
             if (wave == 0) {
@@ -333,7 +426,9 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 s_iters++;
                 const float new_chi2 = r[27] / r[28];           // chi2 / n_meas_ (NaN when nothing is visible, as the reference)
                 float x[6];
+                const long long q0 = DBG ? wall_clock64() : 0;
                 ldlt_solve6(s_H, s_b, x);
+                if (DBG && A.dbg) A.dbg[7] += wall_clock64() - q0;
                 for (int a = 0; a < 6; a++) s_x[a] = x[a];
                 if (isnan(x[0])) s_stop = 1;                     // solve() failed -> stop_ (:235-236)
                 if ((iter > 0 && (double) new_chi2 > 1.2 * (double) s_chi2) || s_stop) {
@@ -368,7 +463,28 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     }
 }
 
-size_t sia_lds_bytes(int maxFeatures) { return (size_t) maxFeatures * (sizeof(float4) + sizeof(float2)) + 16; }
+// per feature: float4 s_feat + float2 s_uv, plus two float4 of Jacobian terms while that keeps the workgroup under 96 KB (4000 features)
+bool sia_jac_in_lds(int maxFeatures) { return (size_t) maxFeatures * 56 + 16 <= 96 * 1024; }
+size_t sia_lds_bytes(int maxFeatures) {
+    return (size_t) maxFeatures * (sizeof(float4) + sizeof(float2) + (sia_jac_in_lds(maxFeatures) ? 2 * sizeof(float4) : 0)) + 16;
+}
+
+// dynamic LDS the kernel may use (160 KB minus its static part)
+static int sia_dyn_ceiling(hipError_t *err) {
+    hipFuncAttributes fa;
+    *err = hipFuncGetAttributes(&fa, (const void *) k_sia_run<false>);
+    if (*err != hipSuccess) return 0;
+    return (int) std::min<size_t>(kMaxDynLds, 160 * 1024 - ((fa.sharedSizeBytes + 255) & ~(size_t) 255));
+}
+
+// bytes of LDS left for the staged current image behind a feature table of featBytes (0 when nothing useful fits)
+size_t sia_stage_bytes(size_t featBytes, size_t largestLevelBytes) {
+    hipError_t e;
+    const int ceiling = sia_dyn_ceiling(&e);
+    if (e != hipSuccess || (size_t) ceiling < featBytes + 4096) return 0;
+    const size_t avail = ((size_t) ceiling - featBytes) & ~(size_t) 15;
+    return std::min(avail, (largestLevelBytes + 8 + 15) & ~(size_t) 15);
+}
 
 hipError_t sia_prepare(size_t ldsBytes) {
     // the kernel's static LDS (reduction partials, solver state) comes out of the same 160 KB: the ceiling is a constant of the kernel,

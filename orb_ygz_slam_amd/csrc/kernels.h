@@ -177,7 +177,9 @@ struct SiaLevel {
     int w, h, pitch;
 };
 struct SiaArgs {
-    int ldsFeat;                    // feature slots of the dynamic LDS carve-up (float4 s_feat[ldsFeat] | float2 s_uv[ldsFeat])
+    int ldsFeat;                    // feature slots of the dynamic LDS carve-up (float4 s_feat[ldsFeat] | float2 s_uv[ldsFeat] | float4 s_jac[2*ldsFeat])
+    int stageOff, stageBytes;       // byte offset (from the start of dynamic LDS) and size of the staged current-image region
+    int jacLds;                     // the point-only Jacobian terms are staged in LDS (sia_jac_in_lds(ldsFeat))
     const ygzf_kp *keys;            // ref keypoints, pair p at keys + p*kpStride
     const float *world;             // MapPoint world positions, 3 per keypoint
     const uint8_t *mpValid, *outlier;  // nullable
@@ -191,13 +193,15 @@ struct SiaArgs {
     float fx, fy, cx, cy;
     int maxLevel, minLevel, nIter;
     float eps;
-    float *patchCache;              // kpStride*48 floats per pair: per (feature, patch row) patch[4] | dx[4] | dy[4]
+    float *patchCache;              // kpStride*48 floats per pair (16-byte aligned): 12 planes of kpStride float4, plane 3*row + {patch, dx, dy}
     float *jacCache;                // unused (Jacobians are rebuilt from dx, dy each iteration)
     uint8_t *visible;               // kpStride per pair
     float *out;                     // 48 floats per pair: TCR[7], ret, iters, chi2, pad[2], H[36]
     long long *dbg;                 // nullable: phase clocks of pair 0 (debug)
 };
 size_t sia_lds_bytes(int maxFeatures);
+bool sia_jac_in_lds(int maxFeatures);
+size_t sia_stage_bytes(size_t featBytes, size_t largestLevelBytes);
 hipError_t sia_prepare(size_t ldsBytes);
 void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes);
 

@@ -1211,13 +1211,21 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     A.out = (float *) S[7].p;
     {
         if (c->siaDebug) {
-            if ((rc = ensure(c, c->dTmpB, 64))) return rc;
-            HIPCHECK(c, hipMemsetAsync(c->dTmpB.p, 0, 64, c->stream));
+            if ((rc = ensure(c, c->dTmpB, 256))) return rc;
+            HIPCHECK(c, hipMemsetAsync(c->dTmpB.p, 0, 256, c->stream));
             A.dbg = (long long *) c->dTmpB.p;
         }
-        const size_t sl = sia_lds_bytes((int) N);
+        size_t sl = sia_lds_bytes((int) N);
         A.ldsFeat = (int) N;
+        A.jacLds = sia_jac_in_lds((int) N) ? 1 : 0;
         if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 24));
+        {
+            size_t largest = 0;   // the largest current-frame level that may be staged in LDS beside the feature tables
+            for (int l = min_level; l <= max_level; l++) largest = std::max(largest, (size_t) cur->level_w[l] * cur->level_h[l]);
+            A.stageOff = (int) ((sl + 15) & ~(size_t) 15);
+            A.stageBytes = (int) sia_stage_bytes((size_t) A.stageOff, largest);
+            sl = (size_t) A.stageOff + (size_t) A.stageBytes;
+        }
         HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
         launch_sia(c->stream, A, 1, sl);
@@ -1227,9 +1235,10 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     HIPCHECK(c, hipMemcpyAsync(out, S[7].p, sizeof out, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     if (A.dbg) {
-        long long st[5];
+        long long st[16];
         HIPCHECK(c, hipMemcpy(st, A.dbg, sizeof st, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[ygzf sia, 10ns ticks over %lld iterations] accumulate %lld  reduce %lld  solve %lld  precompute(all levels) %lld\n", st[3], st[0], st[1], st[2], st[4]);
+        fprintf(stderr, "[ygzf sia, 10ns ticks over %lld iterations] accumulate %lld (last wave %lld)  reduce %lld (wave sums %lld)  solve %lld  precompute(all levels) %lld\n", st[3], st[0], st[6], st[1], st[5], st[2], st[4]);
+        fprintf(stderr, "[ygzf sia] ldlt %lld; accumulate per wave:", st[7]); for (int w = 0; w < 8; w++) fprintf(stderr, " %lld", st[8 + w]); fprintf(stderr, "\n");
     }
     memcpy(TCR_out, out, 28);
     *ret = (size_t) out[7];
@@ -2197,9 +2206,17 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
         A2.patchCache += (size_t) first * G.kpStride * 48;
         A2.visible += (size_t) first * G.kpStride;
         A2.out += (size_t) first * 48;
-        const size_t sl = sia_lds_bytes(G.kpStride);
+        size_t sl = sia_lds_bytes(G.kpStride);
         A2.ldsFeat = G.kpStride;
+        A2.jacLds = sia_jac_in_lds(G.kpStride) ? 1 : 0;
         if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 24));
+        {
+            size_t largest = 0;
+            for (int l = min_level; l <= max_level; l++) largest = std::max(largest, (size_t) G.lv[l].pitch * G.lv[l].h);
+            A2.stageOff = (int) ((sl + 15) & ~(size_t) 15);
+            A2.stageBytes = (int) sia_stage_bytes((size_t) A2.stageOff, largest);
+            sl = (size_t) A2.stageOff + (size_t) A2.stageBytes;
+        }
         HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
         launch_sia(c->stream, A2, B - first, sl);

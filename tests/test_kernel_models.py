@@ -231,3 +231,22 @@ def test_pyramid_perm_selectors_and_dot2():
             a0 = 2048 - a1
             H = (pair & 0xFFFF) * a0 + (pair >> 16) * a1    # v_dot2_u32_u16
             assert H == row[sx[k]] * a0 + row[sx[k] + 1] * a1
+
+
+def test_bilinear_weights_fp32():
+    """align_kernels.hip forms the bilinear weights of SparseImgAlign in fp32 where the reference (src/SparseImageAlign.cc:93-96,182-185)
+    multiplies in double and rounds to float: for pixel coordinates >= 3 (the patch border) the fractions are multiples of 2^-22, so
+    1 - s is exact in fp32 and both forms round the same exact product once."""
+    rng = np.random.default_rng(5)
+    one = np.float32(1)
+    for lo, hi in ((3, 8), (3, 64), (3, 4096)):
+        u = rng.uniform(lo, hi, 400_000).astype(np.float32)
+        v = rng.uniform(lo, hi, 400_000).astype(np.float32)
+        u[:64] = np.nextafter(np.floor(u[:64]) + one, np.float32(0))   # fractions next to 1
+        v[:64] = np.floor(v[:64])                                       # and exactly 0
+        su, sv = (u - np.floor(u)).astype(np.float32), (v - np.floor(v)).astype(np.float32)
+        sud, svd = su.astype(np.float64), sv.astype(np.float64)
+        ref = [((1.0 - sud) * (1.0 - svd)).astype(np.float32), (sud * (1.0 - svd)).astype(np.float32), ((1.0 - sud) * svd).astype(np.float32)]
+        got = [(one - su) * (one - sv), su * (one - sv), (one - su) * sv]
+        for r, g in zip(ref, got):
+            assert g.dtype == np.float32 and np.array_equal(r, g)
