@@ -415,6 +415,7 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol
 }
 
 // LDS pitch of a cell's score map = the window pitch (wCell + 2 columns used, the window pitch is >= wCell + 7)
+struct FastGroupBases { int v[kMaxLevels]; };   // first 2x2 cell group of every level inside a frame (LevelGeom::groupBase), by value
 constexpr int kCornerCap = 512;  // corners listed per cell before the dense fallback takes over
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -513,9 +514,14 @@ __device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh, int kSP) 
 template <int kP>
 __device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *__restrict__ geom, int nlevels, int iniTh, int minTh,
                                           unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells, long long totalSlots,
-                                          int winPitch, int winRows, int smapRows, int quadCap, uint8_t *fdyn, int grp, int f, int wv, int lane) {
+                                          int winPitch, int winRows, int smapRows, int quadCap, uint8_t *fdyn, int grp, int f, int wv, int lane,
+                                          const FastGroupBases &gb) {
+    // level of this group: the per-level first-group table rides in the kernel arguments (SGPRs after the initial argument load), so the
+    // search is scalar compares instead of a chain of dependent scalar loads from geom[] (up to one memory round trip per level)
     int l = 0;
-    while (l + 1 < nlevels && grp >= geom[l + 1].groupBase) l++;
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; k++)
+        if (k < nlevels && grp >= gb.v[k]) l = k;
     const LevelGeom g = geom[l];
     const int gl = grp - g.groupBase;
     const int gCols = (g.nCols + 1) >> 1;
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
                                                           int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
                                                           unsigned *__restrict__ slots, int totalCells, long long totalSlots,
                                                           int totalGroups, int groupsPerXcd, int winPitch, int winRows,
-                                                          int smapRows, int quadCap) {
+                                                          int smapRows, int quadCap, FastGroupBases gb) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
     const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
@@ -758,7 +764,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
     for (int r = 0; r < kFastRep; r++) {
         const int grp = sg * kFastRep + r;
         if (grp >= totalGroups) return;
-        fast_cell<kP>(fs, geom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, winPitch, winRows, smapRows, quadCap, fdyn, grp, f, wv, lane);
+        fast_cell<kP>(fs, geom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, winPitch, winRows, smapRows, quadCap, fdyn, grp, f, wv, lane, gb);
         wave_lds_sync();   // the next cell reuses this wave's LDS region
     }
 }
@@ -1478,14 +1484,16 @@ size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap
 
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
-                       int nFrames, int winPitch, int winRows, int quadCap) {
+                       int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost) {
     if (totalGroups <= 0) return;
+    FastGroupBases gb;
+    for (int k = 0; k < kMaxLevels; k++) gb.v[k] = k < nlevels ? groupBaseHost[k] : 0x7fffffff;
     const int groupsPerXcd = ((totalGroups + kFastRep - 1) / kFastRep + 7) / 8;    // workgroups (of kFastRep groups) per XCD
     const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
     const size_t lds = fast_quads_lds_bytes(winPitch, winRows, smapRows, quadCap);
 #define YGZF_FAST_LAUNCH(KP)                                                                                                            \
     hipLaunchKernelGGL(k_fast_quads<KP>, grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, \
-                       totalGroups, groupsPerXcd, winPitch, winRows, smapRows, quadCap)
+                       totalGroups, groupsPerXcd, winPitch, winRows, smapRows, quadCap, gb)
     switch (winPitch) {   // the usual pitches (cells of 30..41 pixels) get immediate LDS offsets; anything else the run-time pitch
         case 40: YGZF_FAST_LAUNCH(40); break;
         case 44: YGZF_FAST_LAUNCH(44); break;

@@ -456,9 +456,11 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     if (G.totalCells > 0) {
         {
             ProfScope ps(c, KK_FAST);
+            int groupBase[kMaxLevels];
+            for (int l = 0; l < L; l++) groupBase[l] = G.lv[l].groupBase;
             launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                               (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
-                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap);
+                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase);
         }
         long long *odbg = nullptr;
         if (c->octDebug) {
