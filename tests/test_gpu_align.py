@@ -100,3 +100,31 @@ def ex2_run(ex, cam, k, world, ident, pyr_ref, pyr_cur, inv):
     except NameError:
         _EX2 = Extractor(600, 1.2, 8, 20, 7, max_width=64, max_height=64, max_batch=1)
     return _EX2.sia_run(cam, k, world, ident, pyr_ref, ident, pyr_cur, inv, 7, 1)
+
+
+@pytest.mark.parametrize("nfeat", [2400, 6200])
+def test_sia_large_feature_counts(oracle, nfeat):
+    """The kernel's LDS plan changes with the feature count: above ~1750 features the point-only Jacobian terms are rebuilt per iteration
+    instead of read from LDS, and near the 6400-feature ceiling no pyramid level of the current frame is staged in LDS any more.  Same
+    1e-5 bar against the oracle on both plans (features beyond what the extractor finds are jittered copies: the aligner only needs
+    pixel positions and 3D points)."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    imgA, imgB, (R, t), backproject = two_view_scene(21, w, h, EUROC, rotvec=(0.003, -0.004, 0.002), trans=(0.02, -0.015, 0.01))
+    ex = Extractor(3000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(3000, 1.2, 8, 20, 7)
+    k0, _ = ex.extract(imgA)
+    rng = np.random.default_rng(nfeat)
+    reps = -(-nfeat // len(k0))
+    k = np.concatenate([k0] * reps)[:nfeat].copy()
+    k["x"] = np.clip(k["x"] + rng.uniform(-2, 2, nfeat).astype(np.float32) * (np.arange(nfeat) >= len(k0)), 20, w - 21)
+    k["y"] = np.clip(k["y"] + rng.uniform(-2, 2, nfeat).astype(np.float32) * (np.arange(nfeat) >= len(k0)), 20, h - 21)
+    world = backproject(k["x"], k["y"])
+    pyrA, pyrB = ex.compute_pyramid(imgA), ex.compute_pyramid(imgB)
+    inv = oex.tables()["inv_scale"]
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    o_ret, o_T, o_info, o_H = oracle.sparse_img_align(k, world, ident, pyrA, ident, pyrB, inv, EUROC, 7, 1)
+    g_ret, g_T, g_info, g_H = ex.sia_run(make_camera(w, h), k, world, ident, pyrA, ident, pyrB, inv, 7, 1)
+    assert g_ret == o_ret and g_ret > nfeat // 2, (g_ret, o_ret)
+    assert float(np.abs(g_T - o_T).max()) <= TOL, (g_T, o_T, g_info, o_info)
+    assert np.abs(g_T[4:] - t).max() < 5e-3
