@@ -182,6 +182,14 @@ int ygzf_search_local_points(ygzf_ctx *ctx, const ygzf_frame_view *F, const ygzf
                              const uint8_t *mp_has_obs, const uint8_t *mp_desc, float th, int check_level, float nnratio, uint8_t *owner, int *match,
                              int *nmatches, uint8_t *in_view, float *proj_x, float *proj_y, float *proj_xr, int *level, float *view_cos);
 
+/* ---- Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel)   src/Frame.cc:424-481 over the grid of Frame::AssignFeaturesToGrid
+ *      (:314-330, PosInGrid :483-493) as a direct query --------------------------------------------------------------------
+ * keys = the frame's mvKeys, cam->min_x .. max_y = mnMinX .. mnMaxY.  Query q = xyr[3q .. 3q+2] with levels[2q], levels[2q+1] (levels NULL:
+ * -1, -1 = no level test).  out_idx[q * cap ..] receives the indices the reference's vector holds, in its order (grid column, grid row,
+ * keypoint index); out_n[q] = that vector's size -- when it exceeds cap only the first cap indices are stored. */
+int ygzf_features_in_area(ygzf_ctx *ctx, const ygzf_camera *cam, int n_keys, const ygzf_kp *keys, int n_queries, const float *xyr,
+                          const int *levels, int cap, int *out_idx, int *out_n);
+
 /* ---- MapPoint::ComputeDistinctiveDescriptors()   src/MapPoint.cc:211-271 over a MapPoint batch -----------------------------
  * Point p owns the observation descriptors desc[obs_off[p] .. obs_off[p+1]) (32 bytes each, those of its non-bad KeyFrames in map order);
  * best_idx[p] = index within the point's observations of the descriptor with the least median Hamming distance to the others (first

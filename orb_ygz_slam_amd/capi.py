@@ -120,6 +120,7 @@ def load_library(build_if_missing=True):
     L.ygzf_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, C.POINTER(FrustumIn), vp, vp, C.c_float, C.c_int,
                                            C.c_float, vp, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ygzf_distinctive_descriptors_batch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
@@ -468,6 +469,18 @@ class Extractor:
         self._ck(self.L.ygzf_search_local_points(self.h, C.byref(fv), C.byref(cam), n, C.byref(fi), _p(obs) if obs is not None else None, _p(md), th,
                                                  int(check_level), nnratio, _p(own), _p(match), C.byref(nm), _p(iv), None, None, None, None, None))
         return nm.value, match[:len(ck)], own[:len(ck)], iv[:n]
+
+    def features_in_area(self, cam, keys, xyr, levels=None, cap=None):
+        """Frame::GetFeaturesInArea for a batch of (x, y, r[, minLevel, maxLevel]) queries -> list of index arrays in the reference's order."""
+        ck = np.ascontiguousarray(keys, KP_DTYPE)
+        q = np.ascontiguousarray(xyr, np.float32).reshape(-1, 3)
+        lv = None if levels is None else np.ascontiguousarray(levels, np.int32).reshape(-1, 2)
+        cap = max(len(ck), 1) if cap is None else int(cap)
+        out = np.full((max(len(q), 1), max(cap, 1)), -1, np.int32)
+        cnt = np.zeros(max(len(q), 1), np.int32)
+        self._ck(self.L.ygzf_features_in_area(self.h, C.byref(cam), len(ck), _p(ck), len(q), _p(q), None if lv is None else _p(lv), cap,
+                                              _p(out), _p(cnt)))
+        return [out[i, :min(int(cnt[i]), cap)].copy() for i in range(len(q))], cnt[:len(q)].copy()
 
     def distinctive_descriptors_batch(self, obs_off, desc):
         """MapPoint::ComputeDistinctiveDescriptors over a MapPoint batch -> winning observation index per point."""

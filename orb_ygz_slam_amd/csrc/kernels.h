@@ -176,6 +176,19 @@ struct SiaLevel {
     const uint8_t *img;
     int w, h, pitch;
 };
+struct FiaArgs {                    // Frame::GetFeaturesInArea queries against one frame's keypoints
+    const ygzf_kp *keys;
+    int n;
+    float minX, minY, gridInvW, gridInvH;
+    int nq;
+    const float *xyr;               // 3 per query
+    const int *levels;              // 2 per query (minLevel, maxLevel) or null (-1, -1)
+    int cap;
+    int *outIdx, *outN;             // nq x cap indices (reference order), nq counts (uncapped)
+};
+size_t fia_lds_bytes(int n);
+hipError_t launch_features_in_area(hipStream_t st, const FiaArgs &A);
+
 struct SiaArgs {
     int ldsFeat;                    // feature slots of the dynamic LDS carve-up (float4 s_feat[ldsFeat] | float2 s_uv[ldsFeat] | float4 s_jac[2*ldsFeat])
     int stageOff, stageBytes;       // byte offset (from the start of dynamic LDS) and size of the staged current-image region

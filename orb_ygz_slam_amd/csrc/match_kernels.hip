@@ -964,6 +964,123 @@ void launch_bow_descend(hipStream_t st, int n, const uint8_t *desc, const int *c
 
 static inline size_t al16(size_t b) { return (b + 15) & ~(size_t) 15; }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea as a direct query (src/Frame.cc:314-330, 483-493, 424-481): the index list the
+// reference returns for (x, y, r, minLevel, maxLevel), in its order -- grid columns ix ascending, cells iy ascending inside a column,
+// keypoint indices ascending inside a cell (push_back order).  Every workgroup rebuilds the 64x48 grid of the frame in LDS (counting
+// sort; the cells of one grid column are adjacent, so the cells [minCy, maxCy] of column ix are ONE contiguous run of the list) and
+// serves a slice of the queries, one wave per query: 64 list entries per step, ordered append by ballot rank.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kMatchBlock) void k_features_in_area(FiaArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    __shared__ int s_tmp[kMatchBlock / 64];
+    int *cellStart = (int *) dyn;                    // GRID_CELLS + 1 (+ 3 pad)
+    int *cellFill = cellStart + GRID_CELLS + 4;      // GRID_CELLS
+    int *list = cellFill + GRID_CELLS;               // n
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = A.n;
+    for (int i = tid; i < GRID_CELLS; i += kMatchBlock) cellFill[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kMatchBlock) {
+        const ygzf_kp k = A.keys[i];
+        const int px = (int) roundf((k.x - A.minX) * A.gridInvW);     // Frame::PosInGrid (round, as the reference)
+        const int py = (int) roundf((k.y - A.minY) * A.gridInvH);
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) atomicAdd(&cellFill[px * GRID_ROWS + py], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan of 3072 counts: 3 per thread
+        const int per = GRID_CELLS / kMatchBlock;
+        int sum = 0;
+        for (int k = 0; k < per; k++) sum += cellFill[tid * per + k];
+        const int incl = m_wave_incl_scan(sum);
+        if (lane == 63) s_tmp[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w2 = 0; w2 < wave; w2++) woff += s_tmp[w2];
+        int off = woff + incl - sum;
+        for (int k = 0; k < per; k++) {
+            const int c = cellFill[tid * per + k];
+            cellStart[tid * per + k] = off;
+            off += c;
+        }
+        if (tid == kMatchBlock - 1) cellStart[GRID_CELLS] = off;
+    }
+    __syncthreads();
+    for (int i = tid; i < GRID_CELLS; i += kMatchBlock) cellFill[i] = cellStart[i];
+    __syncthreads();
+    for (int i = tid; i < n; i += kMatchBlock) {
+        const ygzf_kp k = A.keys[i];
+        const int px = (int) roundf((k.x - A.minX) * A.gridInvW);
+        const int py = (int) roundf((k.y - A.minY) * A.gridInvH);
+        if (!(px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS)) list[atomicAdd(&cellFill[px * GRID_ROWS + py], 1)] = i;
+    }
+    __syncthreads();
+    for (int c = tid; c < GRID_CELLS; c += kMatchBlock) {  // cells keep ascending keypoint index (push_back order)
+        const int s = cellStart[c], e = cellStart[c + 1];
+        for (int a = s + 1; a < e; a++) {
+            const int v = list[a];
+            int b = a - 1;
+            while (b >= s && list[b] > v) { list[b + 1] = list[b]; b--; }
+            list[b + 1] = v;
+        }
+    }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int wavesTotal = gridDim.x * (kMatchBlock / 64);
+    for (int q = blockIdx.x * (kMatchBlock / 64) + wave; q < A.nq; q += wavesTotal) {
+        const float x = A.xyr[3 * q], y = A.xyr[3 * q + 1], r = A.xyr[3 * q + 2];
+        const int minLevel = A.levels ? A.levels[2 * q] : -1, maxLevel = A.levels ? A.levels[2 * q + 1] : -1;
+        int *out = A.outIdx + (long long) q * A.cap;
+        int total = 0;
+        const int nMinCellX = max(0, (int) floorf((x - A.minX - r) * A.gridInvW));
+        const int nMaxCellX = min(GRID_COLS - 1, (int) ceilf((x - A.minX + r) * A.gridInvW));
+        const int nMinCellY = max(0, (int) floorf((y - A.minY - r) * A.gridInvH));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int) ceilf((y - A.minY + r) * A.gridInvH));
+        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+            const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+                if (nMinCellY > nMaxCellY) break;
+                const int s = cellStart[ix * GRID_ROWS + nMinCellY], e = cellStart[ix * GRID_ROWS + nMaxCellY + 1];
+                for (int base = s; base < e; base += 64) {
+                    const int j = base + lane;
+                    bool ok = false;
+                    int idx = -1;
+                    if (j < e) {
+                        idx = list[j];
+                        const ygzf_kp kp = A.keys[idx];
+                        ok = true;
+                        if (bCheckLevels) {
+                            if (kp.octave < minLevel) ok = false;
+                            if (maxLevel >= 0 && kp.octave > maxLevel) ok = false;
+                        }
+                        const float distx = kp.x - x, disty = kp.y - y;
+                        if (!(fabsf(distx) < r && fabsf(disty) < r)) ok = false;
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) {
+                        const int pos = total + __popcll(m & lt);
+                        if (pos < A.cap) out[pos] = idx;
+                    }
+                    total += __popcll(m);
+                }
+            }
+        }
+        if (lane == 0) A.outN[q] = total;
+    }
+}
+
+size_t fia_lds_bytes(int n) { return sizeof(int) * ((size_t) GRID_CELLS + 4 + GRID_CELLS + (size_t) n) + 16; }
+
+hipError_t launch_features_in_area(hipStream_t st, const FiaArgs &A) {
+    const size_t lds = fia_lds_bytes(A.n);
+    hipError_t e = hipFuncSetAttribute((const void *) k_features_in_area, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    if (e != hipSuccess) return e;
+    const int perWg = kMatchBlock / 64;
+    const int wgs = std::max(1, std::min(64, (A.nq + 4 * perWg - 1) / (4 * perWg)));   // >= 4 queries per wave before another workgroup rebuilds the grid
+    hipLaunchKernelGGL(k_features_in_area, dim3(wgs), dim3(kMatchBlock), lds, st, A);
+    return hipSuccess;
+}
+
 // LDS bytes / per-pair global spill bytes of the carve-up in k_match_last for a given plan
 size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes) {
     size_t lds = al16(sizeof(int) * (GRID_CELLS + 1)) + al16(sizeof(int) * GRID_CELLS) + al16(sizeof(int) * (size_t) capCur) +

@@ -64,9 +64,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_GRID, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_quads", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes", "k_features_in_area"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -1770,6 +1770,48 @@ int ygzf_search_local_points(ygzf_ctx *c, const ygzf_frame_view *F, const ygzf_c
     FrustumHost fr = {in, in_view, proj_x, proj_y, proj_xr, view_cos, level};
     return projected_match(c, 1, F, cam, n_mp, nullptr, nullptr, mp_has_obs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mp_desc, th, check_level,
                            nnratio, 100, 0, owner, match, nmatches, nullptr, nullptr, &fr);
+}
+
+int ygzf_features_in_area(ygzf_ctx *c, const ygzf_camera *cam, int n_keys, const ygzf_kp *keys, int n_queries, const float *xyr, const int *levels,
+                          int cap, int *out_idx, int *out_n) {
+    if (!c || !cam || (n_keys > 0 && !keys) || (n_queries > 0 && (!xyr || !out_n)) || (n_queries > 0 && cap > 0 && !out_idx))
+        return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n_keys < 0 || n_queries < 0 || cap < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
+    if (!(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) return fail(c, YGZF_ERR_INVALID, "empty image bounds");
+    if (n_queries == 0) return YGZF_OK;
+    if (fia_lds_bytes(n_keys) > (size_t) kMaxDynLds) return fail(c, YGZF_ERR_UNSUPPORTED, "more than %d keypoints in one grid", (int) ((kMaxDynLds - 25000) / 4));
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc;
+    const size_t qBytes = (size_t) n_queries * 12, lBytes = levels ? (size_t) n_queries * 8 : 0;
+    const size_t oBytes = (size_t) n_queries * (size_t) cap * 4, nBytes = (size_t) n_queries * 4;
+    const size_t nPad = (nBytes + 15) & ~(size_t) 15;
+    if ((rc = ensure(c, c->dTmpA, (size_t) n_keys * sizeof(ygzf_kp) + 64)) || (rc = ensure(c, c->dTmpB, qBytes + lBytes + 64)) ||
+        (rc = ensure(c, c->dTmpC, nPad + oBytes + 64)))
+        return rc;
+    if (n_keys > 0) HIPCHECK(c, hipMemcpyAsync(c->dTmpA.p, keys, (size_t) n_keys * sizeof(ygzf_kp), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->dTmpB.p, xyr, qBytes, hipMemcpyHostToDevice, c->stream));
+    if (levels) HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dTmpB.p + qBytes, levels, lBytes, hipMemcpyHostToDevice, c->stream));
+    FiaArgs A;
+    A.keys = (const ygzf_kp *) c->dTmpA.p;
+    A.n = n_keys;
+    A.minX = cam->min_x; A.minY = cam->min_y;
+    A.gridInvW = (float) 64 / (cam->max_x - cam->min_x);   // mfGridElementWidthInv / HeightInv, src/Frame.cc:302-303
+    A.gridInvH = (float) 48 / (cam->max_y - cam->min_y);
+    A.nq = n_queries;
+    A.xyr = (const float *) c->dTmpB.p;
+    A.levels = levels ? (const int *) ((uint8_t *) c->dTmpB.p + qBytes) : nullptr;
+    A.cap = cap;
+    A.outN = (int *) c->dTmpC.p;
+    A.outIdx = (int *) ((uint8_t *) c->dTmpC.p + nPad);
+    {
+        ProfScope ps(c, KK_GRID);
+        HIPCHECK(c, launch_features_in_area(c->stream, A));
+    }
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(out_n, A.outN, nBytes, hipMemcpyDeviceToHost, c->stream));
+    if (oBytes) HIPCHECK(c, hipMemcpyAsync(out_idx, A.outIdx, oBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
 }
 
 int ygzf_distinctive_descriptors_batch(ygzf_ctx *c, int n_points, const int *obs_off, const uint8_t *desc, int *best_idx) {
