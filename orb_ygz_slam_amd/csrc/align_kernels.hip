@@ -471,10 +471,16 @@ size_t sia_lds_bytes(int maxFeatures) {
 
 // dynamic LDS the kernel may use (160 KB minus its static part)
 static int sia_dyn_ceiling(hipError_t *err) {
-    hipFuncAttributes fa;
-    *err = hipFuncGetAttributes(&fa, (const void *) k_sia_run<false>);
-    if (*err != hipSuccess) return 0;
-    return (int) std::min<size_t>(kMaxDynLds, 160 * 1024 - ((fa.sharedSizeBytes + 255) & ~(size_t) 255));
+    // a constant of the compiled kernel: asked once per process (thread-safe static initialisation), not on every call
+    struct Q { hipError_t e; int v; };
+    static const Q q = [] {
+        hipFuncAttributes fa;
+        Q r{hipFuncGetAttributes(&fa, (const void *) k_sia_run<false>), 0};
+        if (r.e == hipSuccess) r.v = (int) std::min<size_t>(kMaxDynLds, 160 * 1024 - ((fa.sharedSizeBytes + 255) & ~(size_t) 255));
+        return r;
+    }();
+    *err = q.e;
+    return q.v;
 }
 
 // bytes of LDS left for the staged current image behind a feature table of featBytes (0 when nothing useful fits)
@@ -489,10 +495,9 @@ size_t sia_stage_bytes(size_t featBytes, size_t largestLevelBytes) {
 hipError_t sia_prepare(size_t ldsBytes) {
     // the kernel's static LDS (reduction partials, solver state) comes out of the same 160 KB: the ceiling is a constant of the kernel,
     // so every context sets the same value
-    hipFuncAttributes fa;
-    hipError_t e = hipFuncGetAttributes(&fa, (const void *) k_sia_run<false>);
+    hipError_t e;
+    const int ceiling = sia_dyn_ceiling(&e);
     if (e != hipSuccess) return e;
-    const int ceiling = (int) std::min<size_t>(kMaxDynLds, 160 * 1024 - ((fa.sharedSizeBytes + 255) & ~(size_t) 255));
     e = hipFuncSetAttribute((const void *) k_sia_run<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *) k_sia_run<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
