@@ -538,6 +538,7 @@ def main():
 
     if rank == 0:
         total_bytes, per_kernel = algorithmic_bytes(w, h, nl, sf, nf)
+        fast_plan = {1: "one pass at minTh", 2: "iniTh first"}.get(pipe.exs[0].fast_plan(), "?") + " (chosen by the library from the clip's statistics)"
         out = {
             "metric": "frames/s ORB extract+match, 752x480 8-lvl 1000-feat; 1->8 GPU scaling",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -546,7 +547,7 @@ def main():
             "config": {"workload": args.workload, "width": w, "height": h, "levels": nl, "scale_factor": sf, "features": nf,
                        "frames_per_gpu_per_step": B, "sub_batch": sub, "rounds_per_step": rounds, "streams": S, "distinct_frames": min(B, S * sub),
                        "align": bool(args.align), "stereo": bool(args.stereo),
-                       "match": "SearchByProjection(cur,last) th=15, identity pose", "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
+                       "match": "SearchByProjection(cur,last) th=15, identity pose", "fast_plan": fast_plan, "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
                        "sharding": "one clip per GPU, no collective"},
             "timed_region_s": round(elapsed, 4),
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e,

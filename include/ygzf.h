@@ -71,6 +71,16 @@ const char *ygzf_last_error(const ygzf_ctx *ctx);
  * entries, any may be NULL. */
 int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat);
 
+/* Tuning knob of the cell loop of ComputeKeyPointsOctTree (src/ORBextractor.cc:747-781: FAST(iniThFAST), and FAST(minThFAST) where that
+ * finds nothing).  The keypoints are the same under every plan; only the cost differs with the image content:
+ *   YGZF_FAST_PLAN_AUTO       (default) chosen before every launch from statistics of the context's earlier launches
+ *   YGZF_FAST_PLAN_ONE_PASS   one corner test at minThFAST per cell, every corner scored, both thresholds' 3x3 NMS from the same score map
+ *   YGZF_FAST_PLAN_INI_FIRST  the reference's order: test and score at iniThFAST, a second test at minThFAST only in cells left empty
+ * ygzf_get_fast_plan reports the plan the next launch will use (1 or 2). */
+enum ygzf_fast_plan { YGZF_FAST_PLAN_AUTO = 0, YGZF_FAST_PLAN_ONE_PASS = 1, YGZF_FAST_PLAN_INI_FIRST = 2 };
+int ygzf_set_fast_plan(ygzf_ctx *ctx, int plan);
+int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
+
 /* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:84-106); arrays of nlevels floats, any may be NULL. */
 int ygzf_get_levels(const ygzf_ctx *ctx);

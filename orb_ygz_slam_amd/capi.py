@@ -120,6 +120,8 @@ def load_library(build_if_missing=True):
     L.ygzf_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, C.POINTER(FrustumIn), vp, vp, C.c_float, C.c_int,
                                            C.c_float, vp, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ygzf_distinctive_descriptors_batch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
+    L.ygzf_get_fast_plan.argtypes = [vp, vp]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
@@ -469,6 +471,15 @@ class Extractor:
         self._ck(self.L.ygzf_search_local_points(self.h, C.byref(fv), C.byref(cam), n, C.byref(fi), _p(obs) if obs is not None else None, _p(md), th,
                                                  int(check_level), nnratio, _p(own), _p(match), C.byref(nm), _p(iv), None, None, None, None, None))
         return nm.value, match[:len(ck)], own[:len(ck)], iv[:n]
+
+    def set_fast_plan(self, plan):
+        """0 auto (default), 1 one pass at minTh, 2 iniTh first -- same keypoints, different cost (include/ygzf.h)."""
+        self._ck(self.L.ygzf_set_fast_plan(self.h, int(plan)))
+
+    def fast_plan(self):
+        p = C.c_int(0)
+        self._ck(self.L.ygzf_get_fast_plan(self.h, C.byref(p)))
+        return p.value
 
     def features_in_area(self, cam, keys, xyr, levels=None, cap=None):
         """Frame::GetFeaturesInArea for a batch of (x, y, r[, minLevel, maxLevel]) queries -> list of index arrays in the reference's order."""

@@ -511,11 +511,11 @@ __device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh, int kSP) 
 // then score per corner -> private score map, 3x3 NMS for both thresholds, cell-empty fallback and ordered output.  The common case
 // (<= 64 corners in the cell) keeps everything after the expansion in registers.  kP = compile-time window pitch (0: run-time).
 // one cell = one wave's unit of work; returns when the cell is done (all paths), so that a wave can take several cells in a row
-template <int kP>
+template <int kP, bool kIniFirst>
 __device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *__restrict__ geom, int nlevels, int iniTh, int minTh,
                                           unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells, long long totalSlots,
                                           int winPitch, int winRows, int smapRows, int quadCap, uint8_t *fdyn, int grp, int f, int wv, int lane,
-                                          const FastGroupBases &gb) {
+                                          const FastGroupBases &gb, unsigned *__restrict__ stats) {
     // level of this group: the per-level first-group table rides in the kernel arguments (SGPRs after the initial argument load), so the
     // search is scalar compares instead of a chain of dependent scalar loads from geom[] (up to one memory round trip per level)
     int l = 0;
@@ -582,161 +582,194 @@ __device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *_
         }
     }
     wave_lds_sync();
-    // ---- pass 1: four pixels per lane, quads in raster order; quads that hold a corner are listed as  pol bytes | y << 2 | q << 10 ----
-    int nQ = 0;
-    {
-        const int nq = (dw + 3) >> 2, nquads = nq * dh;
-        const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
-        const unsigned mnq = kRcp16[nq];
-        int y = div_small(lane, mnq), q = lane - __mul24(y, nq);
-        const int qy = div_small(64, mnq), qx = 64 - qy * nq;
-        for (int base = 0; base < nquads; base += 64) {
-            unsigned pb = 0;
-            if (base + lane < nquads) {
-                pb = fast9_quad((const unsigned *) (win + __mul24(y, P)) + q, P >> 2, minTh);
-                pb &= (q == nq - 1) ? lastMask : 0x03030303u;
-            }
-            const unsigned long long m = __ballot(pb != 0);
-            if (m) {
-                if (pb) qlist[nQ + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] =
-                            pb | ((unsigned) y << 2) | ((unsigned) q << 10);
-                nQ += __popcll(m);
-            }
-            y += qy; q += qx;
-            if (q >= nq) { q -= nq; y++; }
-        }
-    }
-    wave_lds_sync();
-    // ---- expansion: quad list -> corner list (y << 8 | x << 2 | polarity), still raster order ----
-    int ncorn = 0;
-    bool overflow = false;
-    for (int qb = 0; qb < nQ; qb += 64) {
-        const unsigned rec = qb + lane < nQ ? qlist[qb + lane] : 0u;
-        unsigned rank = 0;
-        int add = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned long long m = __ballot(((rec >> (8 * j)) & 3u) != 0);
-            rank = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, rank));
-            add += __popcll(m);
-        }
-        if (ncorn + add > kCornerCap) { overflow = true; break; }
-        int pos = ncorn + (int) rank;
-        const unsigned yx = ((rec & 0xFCu) << 6) | ((rec & 0x3C00u) >> 6);   // y << 8 | 4q << 2
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned pj = (rec >> (8 * j)) & 3u;
-            if (pj) clist[pos++] = (unsigned short) (yx | (j << 2) | pj);
-        }
-        ncorn += add;
-    }
-    wave_lds_sync();
-    // the quad list is consumed: its bytes become the (zeroed) score map
-    for (int idx = lane; idx < ((dh + 2) * kSP + 15) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
-    wave_lds_sync();
     unsigned *out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
-    if (!overflow && ncorn <= 64) {
-        // ---- common case: one corner per lane, in registers ----
-        const bool have = lane < ncorn;
-        const int e = have ? clist[lane] : 0;
-        const int y = e >> 8, x = (e >> 2) & 63;
-        uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
-        int s = 0;
-        if (have) {
-            s = fast9_arc_score(&win[__mul24(y + 3, P) + x + 4], P, e & 3);
-            sp[0] = (uint8_t) s;
-        }
-        wave_lds_sync();
-        const int fl = have ? nms_flags(sp, iniTh, kSP) : 0;
-        const bool anyIni = __ballot(fl & 1) != 0;
-        const bool keep = (fl & (anyIni ? 1 : 2)) != 0;   // the iniTh survivors, or the minTh survivors when the cell is empty at iniTh
-        const unsigned long long m = __ballot(keep);
-        if (keep) out[__popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | ((unsigned) s << 16);
-        if (lane == 0) *cnt_out = (unsigned short) __popcll(m);
-        return;
-    }
-    if (!overflow) {
-        // score of every listed corner -> private score map
-        for (int qb = 0; qb < ncorn; qb += 64) {
-            const int qi = qb + lane;
-            if (qi < ncorn) {
-                const int e = clist[qi];
-                const int y = e >> 8, x = (e >> 2) & 63;
-                smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&win[(y + 3) * P + x + 4], P, e & 3);
+    // Threshold plan of the cell (identical results, different cost):
+    //   kIniFirst = false  ONE pass at minTh; the 3x3 NMS is evaluated for both thresholds at once (a corner of FAST(iniTh) has score
+    //                      >= iniTh and only neighbours of score >= iniTh compete in FAST(iniTh) -- but a weaker neighbour cannot beat it, so
+    //                      "survives at minTh and score >= iniTh" is the FAST(iniTh) survivor test).  Every corner of FAST(minTh) is scored.
+    //   kIniFirst = true   the reference's own order: a pass at iniTh, and only a cell that keeps nothing runs the pass at minTh.  Corner-
+    //                      dense content (hundreds of FAST(minTh) corners per cell, of which a handful reach iniTh) scores a fraction of the
+    //                      corners; the price is a second pass 1 in the cells that are empty at iniTh.  The host picks the plan per batch
+    //                      from the statistics the kernel leaves in `stats` (sampled workgroups).
+    const int nPass = (kIniFirst && iniTh != minTh) ? 2 : 1;
+    // every 16th cell group of the frame reports (the group index runs over all levels, rows and columns, so the sample is spread over the pyramid)
+    const bool sampled = stats != nullptr && (grp & 15) == 0;
+    unsigned *st = sampled ? stats + 4 * ((grp >> 4) & 63) : nullptr;
+#pragma unroll 1
+    for (int pass = 0; pass < nPass; pass++) {
+        const int th = nPass == 2 && pass == 0 ? iniTh : minTh;   // threshold of this pass' corner test
+        const bool lastPass = pass == nPass - 1;
+        // ---- pass 1: four pixels per lane, quads in raster order; quads that hold a corner are listed as  pol bytes | y << 2 | q << 10 ----
+        int nQ = 0;
+        {
+            const int nq = (dw + 3) >> 2, nquads = nq * dh;
+            const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
+            const unsigned mnq = kRcp16[nq];
+            int y = div_small(lane, mnq), q = lane - __mul24(y, nq);
+            const int qy = div_small(64, mnq), qx = 64 - qy * nq;
+            for (int base = 0; base < nquads; base += 64) {
+                unsigned pb = 0;
+                if (base + lane < nquads) {
+                    pb = fast9_quad((const unsigned *) (win + __mul24(y, P)) + q, P >> 2, th);
+                    pb &= (q == nq - 1) ? lastMask : 0x03030303u;
+                }
+                const unsigned long long m = __ballot(pb != 0);
+                if (m) {
+                    if (pb) qlist[nQ + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] =
+                                pb | ((unsigned) y << 2) | ((unsigned) q << 10);
+                    nQ += __popcll(m);
+                }
+                y += qy; q += qx;
+                if (q >= nq) { q -= nq; y++; }
             }
         }
         wave_lds_sync();
-        // 3x3 NMS at both thresholds over the corner list
-        int nIni = 0;
-        for (int qb = 0; qb < ncorn; qb += 64) {
-            const int qi = qb + lane;
-            int fl = 0;
-            if (qi < ncorn) {
-                const int e = clist[qi];
-                const int y = e >> 8, x = (e >> 2) & 63;
-                fl = nms_flags(&smap[(y + 1) * kSP + x + 1], iniTh, kSP);
-                clist[qi] = (unsigned short) ((e & ~3) | fl);   // polarity no longer needed: keep the flags
+        // ---- expansion: quad list -> corner list (y << 8 | x << 2 | polarity), still raster order ----
+        int ncorn = 0;
+        bool overflow = false;
+        for (int qb = 0; qb < nQ; qb += 64) {
+            const unsigned rec = qb + lane < nQ ? qlist[qb + lane] : 0u;
+            unsigned rank = 0;
+            int add = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned long long m = __ballot(((rec >> (8 * j)) & 3u) != 0);
+                rank = __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, rank));
+                add += __popcll(m);
             }
-            nIni += __popcll(__ballot(fl & 1));
+            if (ncorn + add > kCornerCap) { overflow = true; break; }
+            int pos = ncorn + (int) rank;
+            const unsigned yx = ((rec & 0xFCu) << 6) | ((rec & 0x3C00u) >> 6);   // y << 8 | 4q << 2
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned pj = (rec >> (8 * j)) & 3u;
+                if (pj) clist[pos++] = (unsigned short) (yx | (j << 2) | pj);
+            }
+            ncorn += add;
         }
         wave_lds_sync();
-        // output: the list is in raster order
-        const int want = nIni > 0 ? 1 : 2;
-        int total = 0;
-        for (int qb = 0; qb < ncorn; qb += 64) {
-            const int qi = qb + lane;
-            const int e = qi < ncorn ? clist[qi] : 0;
-            const bool keep = (e & want) != 0;
+        // the quad list is consumed: its bytes become the (zeroed) score map
+        for (int idx = lane; idx < ((dh + 2) * kSP + 15) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        if (sampled && lane == 0 && !kIniFirst && ncorn > 64) atomicAdd(&st[2], (unsigned) ((min(ncorn, kCornerCap) - 1) >> 6));   // score rounds beyond the first
+        int total = 0;          // keypoints this pass keeps
+        bool usedMin = false;   // the single-pass plan fell back to the minTh survivors
+        if (!overflow && ncorn <= 64) {
+            // ---- common case: one corner per lane, in registers ----
+            const bool have = lane < ncorn;
+            const int e = have ? clist[lane] : 0;
+            const int y = e >> 8, x = (e >> 2) & 63;
+            uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
+            int sc = 0;
+            if (have) {
+                sc = fast9_arc_score(&win[__mul24(y + 3, P) + x + 4], P, e & 3);
+                sp[0] = (uint8_t) sc;
+            }
+            wave_lds_sync();
+            const int fl = have ? nms_flags(sp, iniTh, kSP) : 0;
+            bool keep;
+            if (kIniFirst) keep = (fl & 2) != 0;                      // survivors of FAST(th)
+            else {
+                const bool anyIni = __ballot(fl & 1) != 0;
+                keep = (fl & (anyIni ? 1 : 2)) != 0;                  // the iniTh survivors, or the minTh survivors when the cell is empty at iniTh
+                usedMin = !anyIni;
+            }
             const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int y = e >> 8, x = (e >> 2) & 63;
-                const unsigned s = smap[(y + 1) * kSP + x + 1];
-                out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
+            total = __popcll(m);
+            if (total > 0 || lastPass) {
+                if (keep) out[__popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | ((unsigned) sc << 16);
             }
-            total += __popcll(m);
-        }
-        if (lane == 0) *cnt_out = (unsigned short) total;
-        return;
-    }
-    // ---- dense fallback (corner list overflow, never on natural images: > 512 corners in one cell): score and NMS every pixel ----
-    const int npix = dw * dh;
-    const unsigned mdw = kRcp16[dw];
-    const int py = div_small(64, mdw), px = 64 - py * dw;
-    {
-        int y = div_small(lane, mdw), x = lane - y * dw;
-        for (int base = 0; base < npix; base += 64) {
-            if (base + lane < npix) {
-                const uint8_t *cp = &win[(y + 3) * P + x + 4];
-                const int pol = fast9_test(cp, P, minTh);
-                if (pol) smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(cp, P, pol);
+        } else if (!overflow) {
+            // score of every listed corner -> private score map
+            for (int qb = 0; qb < ncorn; qb += 64) {
+                const int qi = qb + lane;
+                if (qi < ncorn) {
+                    const int e = clist[qi];
+                    const int y = e >> 8, x = (e >> 2) & 63;
+                    smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&win[(y + 3) * P + x + 4], P, e & 3);
+                }
             }
-            y += py; x += px;
-            if (x >= dw) { x -= dw; y++; }
-        }
-    }
-    wave_lds_sync();
-    for (int pass = 0; pass < 2; pass++) {       // pass 0: iniTh map; pass 1 (only if empty): minTh map
-        int total = 0;
-        int y = div_small(lane, mdw), x = lane - y * dw;
-        for (int base = 0; base < npix; base += 64) {
-            bool keep = false;
-            unsigned s = 0;
-            if (base + lane < npix) {
-                const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
-                s = sp[0];
-                if (s > 0) keep = (nms_flags(sp, iniTh, kSP) & (pass == 0 ? 1 : 2)) != 0;
+            wave_lds_sync();
+            // 3x3 NMS at both thresholds over the corner list
+            int nIni = 0;
+            for (int qb = 0; qb < ncorn; qb += 64) {
+                const int qi = qb + lane;
+                int fl = 0;
+                if (qi < ncorn) {
+                    const int e = clist[qi];
+                    const int y = e >> 8, x = (e >> 2) & 63;
+                    fl = nms_flags(&smap[(y + 1) * kSP + x + 1], iniTh, kSP);
+                    clist[qi] = (unsigned short) ((e & ~3) | fl);   // polarity no longer needed: keep the flags
+                }
+                nIni += __popcll(__ballot(fl & 1));
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (s << 16);
-            total += __popcll(m);
-            y += py; x += px;
-            if (x >= dw) { x -= dw; y++; }
+            wave_lds_sync();
+            // output: the list is in raster order
+            const int want = kIniFirst ? 2 : (nIni > 0 ? 1 : 2);
+            usedMin = !kIniFirst && nIni == 0;
+            for (int qb = 0; qb < ncorn; qb += 64) {
+                const int qi = qb + lane;
+                const int e = qi < ncorn ? clist[qi] : 0;
+                const bool keep = (e & want) != 0;
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int y = e >> 8, x = (e >> 2) & 63;
+                    const unsigned sv = smap[(y + 1) * kSP + x + 1];
+                    out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (sv << 16);   // (a pass that keeps nothing writes nothing)
+                }
+                total += __popcll(m);
+            }
+        } else {
+            // ---- dense fallback (corner list overflow, never on natural images: > 512 corners in one cell): score and NMS every pixel ----
+            const int npix = dw * dh;
+            const unsigned mdw = kRcp16[dw];
+            const int py = div_small(64, mdw), px = 64 - py * dw;
+            {
+                int y = div_small(lane, mdw), x = lane - y * dw;
+                for (int base = 0; base < npix; base += 64) {
+                    if (base + lane < npix) {
+                        const uint8_t *cp = &win[(y + 3) * P + x + 4];
+                        const int pol = fast9_test(cp, P, th);
+                        if (pol) smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(cp, P, pol);
+                    }
+                    y += py; x += px;
+                    if (x >= dw) { x -= dw; y++; }
+                }
+            }
+            wave_lds_sync();
+            // single-pass plan: sub-pass 0 keeps the iniTh survivors, sub-pass 1 (only if that is empty) the minTh survivors
+            for (int sub = kIniFirst ? 1 : 0; sub < 2; sub++) {
+                total = 0;
+                int y = div_small(lane, mdw), x = lane - y * dw;
+                for (int base = 0; base < npix; base += 64) {
+                    bool keep = false;
+                    unsigned sv = 0;
+                    if (base + lane < npix) {
+                        const uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
+                        sv = sp[0];
+                        if (sv > 0) keep = (nms_flags(sp, iniTh, kSP) & (sub == 0 ? 1 : 2)) != 0;
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    if (keep) out[total + __popcll(m & lane_lt)] = (unsigned) (x + 3) | ((unsigned) (y + 3) << 8) | (sv << 16);
+                    total += __popcll(m);
+                    y += py; x += px;
+                    if (x >= dw) { x -= dw; y++; }
+                }
+                if (total > 0) break;
+                usedMin = !kIniFirst;
+            }
         }
-        if (total > 0 || pass == 1) {
+        if (total > 0 || lastPass) {
             if (lane == 0) *cnt_out = (unsigned short) total;
-            break;
+            if (sampled && lane == 0) {
+                atomicAdd(&st[0], 1u);
+                st[3] = kIniFirst ? 2u : 1u;   // which plan these numbers come from
+                if (usedMin || (nPass == 2 && pass == 1)) atomicAdd(&st[1], 1u);   // the cell's keypoints are FAST(minTh)'s
+            }
+            return;
         }
+        wave_lds_sync();   // the next pass reuses the quad list / score map / corner list bytes
     }
 }
 
@@ -746,12 +779,12 @@ __device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *_
 // 4 cells 742 us -- longer-lived waves lose more to imbalance inside a workgroup (its LDS is held until the slowest wave ends) and to
 // the grid's tail than they gain from fewer workgroup launches, so one cell per wave stays.
 constexpr int kFastRep = 1;
-template <int kP>
+template <int kP, bool kIniFirst>
 __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
                                                           int iniTh, int minTh, unsigned short *__restrict__ cellCnt,
                                                           unsigned *__restrict__ slots, int totalCells, long long totalSlots,
                                                           int totalGroups, int groupsPerXcd, int winPitch, int winRows,
-                                                          int smapRows, int quadCap, FastGroupBases gb) {
+                                                          int smapRows, int quadCap, FastGroupBases gb, unsigned *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
     const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware mapping (performance only): workgroup b runs on XCD b % 8; give every XCD a contiguous run of groups so
@@ -764,7 +797,7 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
     for (int r = 0; r < kFastRep; r++) {
         const int grp = sg * kFastRep + r;
         if (grp >= totalGroups) return;
-        fast_cell<kP>(fs, geom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, winPitch, winRows, smapRows, quadCap, fdyn, grp, f, wv, lane, gb);
+        fast_cell<kP, kIniFirst>(fs, geom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, winPitch, winRows, smapRows, quadCap, fdyn, grp, f, wv, lane, gb, stats);
         wave_lds_sync();   // the next cell reuses this wave's LDS region
     }
 }
@@ -1484,16 +1517,22 @@ size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap
 
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
-                       int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost) {
+                       int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost, bool iniFirst, unsigned *stats) {
     if (totalGroups <= 0) return;
     FastGroupBases gb;
     for (int k = 0; k < kMaxLevels; k++) gb.v[k] = k < nlevels ? groupBaseHost[k] : 0x7fffffff;
     const int groupsPerXcd = ((totalGroups + kFastRep - 1) / kFastRep + 7) / 8;    // workgroups (of kFastRep groups) per XCD
     const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
     const size_t lds = fast_quads_lds_bytes(winPitch, winRows, smapRows, quadCap);
-#define YGZF_FAST_LAUNCH(KP)                                                                                                            \
-    hipLaunchKernelGGL(k_fast_quads<KP>, grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, \
-                       totalGroups, groupsPerXcd, winPitch, winRows, smapRows, quadCap, gb)
+#define YGZF_FAST_LAUNCH(KP)                                                                                                                       \
+    do {                                                                                                                                           \
+        if (iniFirst)                                                                                                                              \
+            hipLaunchKernelGGL((k_fast_quads<KP, true>), grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells,       \
+                               totalSlots, totalGroups, groupsPerXcd, winPitch, winRows, smapRows, quadCap, gb, stats);                            \
+        else                                                                                                                                       \
+            hipLaunchKernelGGL((k_fast_quads<KP, false>), grid, block, lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt, slots, totalCells,      \
+                               totalSlots, totalGroups, groupsPerXcd, winPitch, winRows, smapRows, quadCap, gb, stats);                            \
+    } while (0)
     switch (winPitch) {   // the usual pitches (cells of 30..41 pixels) get immediate LDS offsets; anything else the run-time pitch
         case 40: YGZF_FAST_LAUNCH(40); break;
         case 44: YGZF_FAST_LAUNCH(44); break;

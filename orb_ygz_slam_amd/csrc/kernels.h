@@ -12,7 +12,8 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
-                       int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost);
+                       int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost, bool iniFirst, unsigned *stats);
+constexpr int kFastStatWords = 4 * 64;   // `stats`: 64 x {cells sampled, cells whose keypoints are FAST(minTh)'s, score rounds beyond the first, plan: 1 one pass / 2 iniTh first}
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes);
 hipError_t octree_prepare(size_t ldsBytes, bool globalNodes);
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,

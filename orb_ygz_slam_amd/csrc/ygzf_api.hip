@@ -117,6 +117,13 @@ struct ygzf_ctx {
     int octLdsCand = 0;
     bool octGlobalNodes = false;
     Buf dOctNodes;
+    // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at
+    // minTh, 2 = iniTh first.  Identical results either way.
+    int fastPlan = 0;
+    bool fastIniFirst = false;
+    double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
+    Buf dFastStats;
+    unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
     // batch state
     int lastFrames = 0;
     FrameSet lastFs{};
@@ -454,14 +461,35 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                           (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
     }
     if (G.totalCells > 0) {
+        int groupBase[kMaxLevels];
+        for (int l = 0; l < L; l++) groupBase[l] = G.lv[l].groupBase;
+        // threshold plan of this launch: from the statistics of an earlier launch of this context (whatever the asynchronous copy has
+        // delivered by now; a stale or half-written snapshot only affects speed -- both plans return the same keypoints)
+        {
+            unsigned cells = 0, usedMin = 0, extra = 0, plan = 0;
+            for (int k = 0; k < 64; k++) {
+                cells += c->hFastStats[4 * k]; usedMin += c->hFastStats[4 * k + 1]; extra += c->hFastStats[4 * k + 2]; plan |= c->hFastStats[4 * k + 3];
+            }
+            if (cells >= 32 && (plan == 1 || plan == 2)) {
+                if (plan == 1) c->fastExtraRounds = (double) extra / cells;   // only the one-pass plan sees every FAST(minTh) corner
+                // a score round costs ~180 vector instructions per wave, a second pass 1 ~700: iniTh first pays when the rounds it saves
+                // outweigh the second passes of the cells that are empty at iniTh
+                c->fastIniFirst = c->fastExtraRounds * 180.0 > ((double) usedMin / cells) * 700.0;
+            }
+        }
+        const bool iniFirst = c->fastPlan == 2 || (c->fastPlan == 0 && c->fastIniFirst);
+        {
+            int rcS = ensure(c, c->dFastStats, kFastStatWords * sizeof(unsigned));
+            if (rcS) return rcS;
+            HIPCHECK(c, hipMemsetAsync(c->dFastStats.p, 0, kFastStatWords * sizeof(unsigned), c->stream));
+        }
         {
             ProfScope ps(c, KK_FAST);
-            int groupBase[kMaxLevels];
-            for (int l = 0; l < L; l++) groupBase[l] = G.lv[l].groupBase;
             launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                               (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
-                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase);
+                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase, iniFirst, (unsigned *) c->dFastStats.p);
         }
+        HIPCHECK(c, hipMemcpyAsync(c->hFastStats, c->dFastStats.p, kFastStatWords * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         long long *odbg = nullptr;
         if (c->octDebug) {
             int rc2 = ensure(c, c->dTmpA, 16 * 8 * sizeof(long long));
@@ -567,6 +595,8 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     CK(hipEventCreate(&c->tStart));
     CK(hipEventCreate(&c->tStop));
     CK(upload_constants(c->tab.umax));
+    CK(hipHostMalloc((void **) &c->hFastStats, kFastStatWords * sizeof(unsigned)));
+    memset(c->hFastStats, 0, kFastStatWords * sizeof(unsigned));
 #undef CK
     // validate the largest configuration up front (and size the buffers once)
     int rc = apply_geometry(c, max_width, max_height, max_batch);
@@ -607,6 +637,8 @@ void ygzf_destroy(ygzf_ctx *c) {
         if (b.p) (void) hipFree(b.p);
     if (c->dCacheImg.p) (void) hipFree(c->dCacheImg.p);
     if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
+    if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
+    if (c->hFastStats) (void) hipHostFree(c->hFastStats);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
@@ -618,6 +650,19 @@ void ygzf_destroy(ygzf_ctx *c) {
 const char *ygzf_last_error(const ygzf_ctx *c) {
     if (c) return c->err.c_str();
     return g_create_err.c_str();
+}
+
+int ygzf_set_fast_plan(ygzf_ctx *c, int plan) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (plan < YGZF_FAST_PLAN_AUTO || plan > YGZF_FAST_PLAN_INI_FIRST) return fail(c, YGZF_ERR_INVALID, "FAST plan %d (0 auto, 1 one pass, 2 iniTh first)", plan);
+    c->fastPlan = plan;
+    return YGZF_OK;
+}
+
+int ygzf_get_fast_plan(const ygzf_ctx *c, int *plan) {
+    if (!c || !plan) return YGZF_ERR_INVALID;
+    *plan = c->fastPlan == YGZF_FAST_PLAN_AUTO ? (c->fastIniFirst ? YGZF_FAST_PLAN_INI_FIRST : YGZF_FAST_PLAN_ONE_PASS) : c->fastPlan;
+    return YGZF_OK;
 }
 
 int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat) {

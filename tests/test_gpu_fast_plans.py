@@ -1,0 +1,68 @@
+"""The two threshold plans of the FAST cell kernel (one pass at minTh with a dual-threshold NMS / iniTh first, minTh only in cells left empty)
+must return the same keypoints as the oracle's literal `FAST(ini); if empty FAST(min)` on every kind of content; the automatic choice
+only changes the cost."""
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(w, h):
+    rng = np.random.default_rng(77)
+    flat = np.full((h, w), 120, np.uint8)
+    sparse = flat.copy()
+    for k in range(12):                                   # a dozen faint blobs: most cells are empty at iniTh, some even at minTh
+        x, y = int(rng.integers(40, w - 40)), int(rng.integers(40, h - 40))
+        sparse[y:y + 5, x:x + 5] = 120 + int(rng.integers(9, 40))
+    weak = (120 + 6 * rng.standard_normal((h, w))).clip(0, 255).astype(np.uint8)   # many corners at 7, almost none at 20
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)                            # > 512 corners per cell: dense fallback
+    ties = np.zeros((h, w), np.uint8)
+    ties[::2, ::2] = 200                                                             # equal scores everywhere: NMS keeps nothing at iniTh
+    return {"synthetic": synth_frame(3, w, h), "flat": flat, "sparse": sparse, "weak": weak, "noise": noise, "ties": ties}
+
+
+@pytest.mark.parametrize("plan", [1, 2])
+@pytest.mark.parametrize("ini,mn", [(20, 7), (12, 12), (40, 5)])
+def test_both_plans_equal_the_oracle(oracle, plan, ini, mn):
+    from orb_ygz_slam_amd import Extractor
+    w, h = 640, 480
+    ex = Extractor(1000, 1.2, 8, ini, mn, max_width=w, max_height=h, max_batch=1)
+    ex.set_fast_plan(plan)
+    assert ex.fast_plan() == plan
+    oex = oracle.Extractor(1000, 1.2, 8, ini, mn)
+    for name, img in _images(w, h).items():
+        k, d = ex.extract(img)
+        ok, od = oex.extract(img)
+        assert len(k) == len(ok), (name, plan, len(k), len(ok))
+        for f in ("x", "y", "octave", "response", "angle", "size"):
+            assert np.array_equal(k[f], ok[f]), (name, plan, f)
+        assert np.array_equal(d, od), (name, plan)
+
+
+def test_automatic_plan_follows_the_content(oracle):
+    from orb_ygz_slam_amd import Extractor
+    w, h = 752, 480
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=4)
+    assert ex.fast_plan() == 1                                     # nothing measured yet: one pass
+    dense = np.stack([synth_frame(40 + i, w, h) for i in range(4)])
+    ref = None
+    for _ in range(4):                                             # the statistics of a launch steer the next ones
+        ex.extract_batch_host(dense)
+        got = [ex.batch_fetch(f) for f in range(4)]
+        if ref is None:
+            ref = got
+        for (k, d), (k0, d0) in zip(got, ref):
+            assert np.array_equal(k, k0) and np.array_equal(d, d0)
+    assert ex.fast_plan() == 2                                     # hundreds of minTh corners per cell, few cells empty at iniTh
+    rng = np.random.default_rng(1)
+    weak = np.stack([(120 + 5 * rng.standard_normal((h, w))).clip(0, 255).astype(np.uint8) for _ in range(4)])
+    for _ in range(4):
+        ex.extract_batch_host(weak)
+        ex.batch_fetch(0)
+    assert ex.fast_plan() == 1                                     # nearly every cell is empty at iniTh: a second pass everywhere would not pay
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    k, d = ex.batch_fetch(3)
+    ok, od = oex.extract(weak[3])
+    assert np.array_equal(k["x"], ok["x"]) and np.array_equal(k["y"], ok["y"]) and np.array_equal(d, od)

@@ -39,6 +39,7 @@ def test_fuzz_special_images(oracle, seed):
             np.clip((((xx % 20) - 10) ** 2 + ((yy % 20) - 10) ** 2) * (250.0 / 200.0), 0, 255).astype(np.uint8)]   # ~460 per cell: long lists
     mode = seed % 3                                   # the three GaussianBlur generations take turns
     ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=len(imgs), cv_mode=mode)
+    ex.set_fast_plan(seed % 3)   # 0 automatic, 1 one pass at minTh, 2 iniTh first: the same keypoints under each
     oex = oracle.Extractor(nf, sf, nl, 20, 7)
     ex.extract_batch_host(np.stack(imgs))
     for f, img in enumerate(imgs):
@@ -118,6 +119,7 @@ def test_fuzz_dso(oracle, seed):
     img = synth_frame(900 + seed, w, h) if seed % 3 else (rng.integers(0, 256, (h, w), dtype=np.uint8) // 2 + 60).astype(np.uint8)
     mode = (seed // 2) % 3
     ex = Extractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=1, cv_mode=mode)
+    ex.set_fast_plan(seed % 3)   # 0 automatic, 1 one pass at minTh, 2 iniTh first: the same keypoints under each
     oex = oracle.Extractor(nf, sf, nl, 20, 7)
     k0, _ = ex.extract(img)
     inv = oex.tables()["inv_scale"]
