@@ -458,6 +458,7 @@ def main():
     fps = total_frames / elapsed
 
     pipe = pipes[0]
+    fast_plan_id = pipe.exs[0].fast_plan()   # before the contexts are released further down
     kernels, iso = {}, {}
     if not args.no_profile:
         prof = pipe.profile_read()
@@ -538,7 +539,7 @@ def main():
 
     if rank == 0:
         total_bytes, per_kernel = algorithmic_bytes(w, h, nl, sf, nf)
-        fast_plan = {1: "one pass at minTh", 2: "iniTh first"}.get(pipe.exs[0].fast_plan(), "?") + " (chosen by the library from the clip's statistics)"
+        fast_plan = {1: "one pass at minTh", 2: "iniTh first"}.get(fast_plan_id, "?") + " (chosen by the library from the clip's statistics)"
         out = {
             "metric": "frames/s ORB extract+match, 752x480 8-lvl 1000-feat; 1->8 GPU scaling",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
