@@ -252,20 +252,22 @@ def run_timed(pipes, steps, warmup, barrier, sync_all):
     return el
 
 
-def end_to_end(pipe, batches=40):
-    """SURVEY 8(d) 'end-to-end': page-locked host frames in (H2D), kernels, every keypoint + descriptor + count out (D2H) -- two contexts
-    software-pipelined: while one sub-batch is in its kernels the other one's frames go up and results come down."""
+def end_to_end(pipe, batches=42, depth=2):
+    """SURVEY 8(d) 'end-to-end': page-locked host frames in (H2D), kernels, every keypoint + descriptor + count out (D2H) -- `depth` contexts
+    software-pipelined: while one sub-batch is in its kernels the next ones' frames go up and the previous one's results come down (the
+    upload alone is 1.7 ms per 256 frames, the kernels 1.3 ms; measured: depth 2 134 k, depth 3 133 k, depth 4 113 k frames/s -- the link
+    is the limit at ~48 GB/s up + 9 GB/s down)."""
     import torch
     from orb_ygz_slam_amd.capi import KP_DTYPE
     from orb_ygz_slam_amd import Extractor
     w, h, nl, sf, nf, ini, mn = pipe.cfg
     B = pipe.sub
-    exs = list(pipe.exs[:2])
-    while len(exs) < 2:
+    exs = list(pipe.exs[:depth])
+    while len(exs) < depth:
         exs.append(Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=pipe.device))
     stride = exs[0].max_keypoints(w, h)
     pins, outs, keep = [], [], []
-    for i in range(2):
+    for i in range(depth):
         src = pipe.frames[(i * B) % len(pipe.frames):][:B]
         if len(src) < B:
             src = np.concatenate([src, pipe.frames[:B - len(src)]])
@@ -280,13 +282,17 @@ def end_to_end(pipe, batches=40):
     def submit(i):
         exs[i].extract_batch_host(pins[i])
         exs[i].match_batch_prev(pipe.cam, 15.0, True, True, True)
-    submit(0); submit(1); exs[0].batch_fetch_all(B, outs[0]); exs[1].batch_fetch_all(B, outs[1])     # warm-up
+    for i in range(depth):                                                 # warm-up
+        submit(i)
+    for i in range(depth):
+        exs[i].batch_fetch_all(B, outs[i])
     t0 = time.perf_counter()
-    submit(0)
-    for it in range(1, batches):
-        submit(it & 1)                                                  # enqueue the next sub-batch on the other stream ...
-        exs[(it - 1) & 1].batch_fetch_all(B, outs[(it - 1) & 1])        # ... then wait for / download the previous one
-    exs[(batches - 1) & 1].batch_fetch_all(B, outs[(batches - 1) & 1])
+    for it in range(batches):
+        if it >= depth:                                                    # the context is reused: its previous sub-batch comes down first
+            exs[it % depth].batch_fetch_all(B, outs[it % depth])
+        submit(it % depth)
+    for it in range(batches, batches + depth):                             # drain
+        exs[it % depth].batch_fetch_all(B, outs[it % depth])
     return B * batches, time.perf_counter() - t0
 
 
