@@ -467,8 +467,9 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
         // delivered by now; a stale or half-written snapshot only affects speed -- both plans return the same keypoints)
         {
             unsigned cells = 0, usedMin = 0, extra = 0, plan = 0;
+            const volatile unsigned *hs = c->hFastStats;   // written by the copy engine, possibly right now
             for (int k = 0; k < 64; k++) {
-                cells += c->hFastStats[4 * k]; usedMin += c->hFastStats[4 * k + 1]; extra += c->hFastStats[4 * k + 2]; plan |= c->hFastStats[4 * k + 3];
+                cells += hs[4 * k]; usedMin += hs[4 * k + 1]; extra += hs[4 * k + 2]; plan |= hs[4 * k + 3];
             }
             if (cells >= 32 && (plan == 1 || plan == 2)) {
                 if (plan == 1) c->fastExtraRounds = (double) extra / cells;   // only the one-pass plan sees every FAST(minTh) corner
