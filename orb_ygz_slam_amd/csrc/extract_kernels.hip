@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                                                       unsigned *__restrict__ candVal1, unsigned *__restrict__ candXY,
                                                       long long candStride, unsigned *__restrict__ lvlKpXY,
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
-                                                      int *__restrict__ lvlCandCnt, unsigned short *__restrict__ procOrder,
+                                                      int *__restrict__ lvlCandCnt, uint2 *__restrict__ procRec,
                                                       int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[256];
@@ -1138,6 +1138,8 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         const unsigned kx = (p & 0xFFFFu) + kBorder, ky = (p >> 16) + kBorder;
         oxy[i] = kx | (ky << 16);
         osc[i] = (unsigned char) (best >> 24);
+        S.b1[i] = (int) (kx | (ky << 16));      // (the child-boundary arrays are free after the tree passes)
+        S.b2[i] = (int) (best >> 24);
         // spatial key for the PROCESSING order of k_describe: 64x64-px tile id, stable within a tile (locality of the
         // 43x43 window gathers; the output order is untouched)
         S.sk[0][i] = ((ky >> 6) << 6) | (kx >> 6);
@@ -1147,8 +1149,13 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     {
         unsigned *ok, *ov;
         block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 12, histT, s_tmp, &ok, &ov);
-        unsigned short *po = procOrder + (long long) f * kpStride + g.kpBase;
-        for (int i = tid; i < n; i += kOctBlock) po[i] = (unsigned short) ov[i];
+        // k_describe's work list: processing position i -> (x | y << 16, score | list position << 8) in ONE record, so that a describe wave
+        // knows its keypoint after a single memory round trip (it used to follow procOrder -> position / score: two dependent ones)
+        uint2 *pr = procRec + (long long) f * kpStride + g.kpBase;
+        for (int i = tid; i < n; i += kOctBlock) {
+            const unsigned li = ov[i];
+            pr[i] = make_uint2((unsigned) S.b1[li], (unsigned) S.b2[li] | (li << 8));
+        }
     }
     if (tid == 0) *lvlCnt = n;
     OSTAMP(5);
@@ -1396,41 +1403,46 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
 #undef RAWP
 }
 
+struct DescLevelBases { int v[kMaxLevels]; };   // LevelGeom::kpBase of every level (first keypoint slot of the level inside a frame), by value
 template <int CVM>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
-                                                            const unsigned *__restrict__ lvlKpXY,
-                                                            const unsigned char *__restrict__ lvlKpScore,
                                                             const int *__restrict__ lvlKpCnt,
-                                                            const unsigned short *__restrict__ procOrder, int kpStride,
+                                                            const uint2 *__restrict__ procRec, int kpStride,
                                                             ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                            int *__restrict__ outCnt, int outStride, int blocksPerXcd) {
+                                                            int *__restrict__ outCnt, int outStride, int blocksPerXcd, DescLevelBases kb) {
     __shared__ DescLds lds[kDescWaves];
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform: the keypoint record loads go scalar
     const int f = blockIdx.y;
     // XCD-aware: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (spatially ordered) keypoint slots so
-    // that overlapping 43x43 windows meet in the same L2.  pslot = position in the frame's concatenated PROCESSING order.
+    // that overlapping 43x43 windows meet in the same L2.  s = slot of the frame's level-major capacity layout: the wave handles
+    // position s - kpBase[l] of level l's PROCESSING order, if the level has that many keypoints.
     if ((int) (blockIdx.x >> 3) >= blocksPerXcd) return;
-    const int pslot = ((blockIdx.x & 7) * blocksPerXcd + (blockIdx.x >> 3)) * kDescWaves + wave;
+    const int s = ((blockIdx.x & 7) * blocksPerXcd + (blockIdx.x >> 3)) * kDescWaves + wave;
+    if (s >= kpStride) return;
+    // The level comes from the kernel arguments (scalar compares), so the three things the wave needs from memory -- the level counts, its
+    // work record and the level geometry -- are requested together: ONE round trip before the window loads instead of four dependent ones
+    // (counts -> geometry -> processing order -> position / score), which were a quarter of the kernel's time.
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxLevels; k++)
+        if (k < nlevels && s >= kb.v[k]) l = k;
+    const int p = s - kb.v[l];
     const int *cnts = lvlKpCnt + f * nlevels;
-    int l = 0, base = 0, total = 0;
-    {
-        int acc = 0;
-        bool found = false;
-        for (int i = 0; i < nlevels; i++) {
-            const int c = cnts[i];
-            if (!found && pslot < acc + c) { l = i; base = acc; found = true; }
-            acc += c;
-        }
-        total = acc;
-        if (pslot == 0 && lane == 0) outCnt[f] = total;
-        if (!found) return;
-    }
+    const uint2 rec = procRec[(long long) f * kpStride + s];
     const LevelGeom g = geom[l];
-    const int li = procOrder[(long long) f * kpStride + g.kpBase + (pslot - base)];  // list position handled by this wave
+    int base = 0, total = 0, mine = 0;
+    for (int i = 0; i < nlevels; i++) {
+        const int c = cnts[i];
+        if (i < l) base += c;
+        if (i == l) mine = c;
+        total += c;
+    }
+    if (s == 0 && lane == 0) outCnt[f] = total;
+    if (p >= mine) return;
+    const int li = (int) (rec.y >> 8);                                               // list position handled by this wave
     const int slot = base + li;                                                     // output index: level-major, list order
-    const unsigned pxy = lvlKpXY[(long long) f * kpStride + g.kpBase + li];
-    const int kx = pxy & 0xFFFFu, ky = pxy >> 16;
-    const int score = lvlKpScore[(long long) f * kpStride + g.kpBase + li];
+    const int kx = rec.x & 0xFFFFu, ky = rec.x >> 16;
+    const int score = rec.y & 0xFFu;
     int pitch;
     const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
     float angle;
@@ -1554,26 +1566,28 @@ hipError_t octree_prepare(size_t ldsBytes, bool globalNodes) {
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena) {
+                   uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena) {
     if (nodeArena)
         hipLaunchKernelGGL(k_octree<true>, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots, totalCells,
-                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procOrder, kpStride, cap, ldsCand,
+                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
                            dbg, nodeArena);
     else
         hipLaunchKernelGGL(k_octree<false>, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots, totalCells,
-                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procOrder, kpStride, cap, ldsCand,
+                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
                            dbg, nodeArena);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
-                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
-                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode) {
+                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const uint2 *procRec, int kpStride,
+                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode, const int *kpBaseHost) {
+    DescLevelBases kb;
+    for (int k = 0; k < kMaxLevels; k++) kb.v[k] = k < nlevels ? kpBaseHost[k] : 0x7fffffff;
     const int nblk = (kpStride + kDescWaves - 1) / kDescWaves;
     const int blocksPerXcd = (nblk + 7) / 8;
     dim3 grid(8 * blocksPerXcd, nFrames);
 #define YGZF_DESC_LAUNCH(M)                                                                                                      \
-    hipLaunchKernelGGL(k_describe<M>, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpXY, lvlKpScore, lvlKpCnt, \
-                       procOrder, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd)
+    hipLaunchKernelGGL(k_describe<M>, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpCnt,                       \
+                       procRec, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd, kb)
     switch (cvMode) {
         case YGZF_CV_LEGACY_INT: YGZF_DESC_LAUNCH(YGZF_CV_LEGACY_INT); break;
         case YGZF_CV_4: YGZF_DESC_LAUNCH(YGZF_CV_4); break;

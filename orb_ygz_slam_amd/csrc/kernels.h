@@ -19,10 +19,10 @@ hipError_t octree_prepare(size_t ldsBytes, bool globalNodes);
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   unsigned short *procOrder, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena);
+                   uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena);
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
-                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const unsigned short *procOrder, int kpStride,
-                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode);
+                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const uint2 *procRec, int kpStride,
+                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode, const int *kpBaseHost);
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out);
 
 // ---- matcher (match_kernels.hip) -----------------------------------------------------------------------------------

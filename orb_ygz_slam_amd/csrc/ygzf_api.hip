@@ -370,7 +370,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
     const size_t kp1 = std::max<size_t>((B + 1) * G.kpStride, 16);  // + carry slot
     void *oldCnt = c->dOutCnt.p, *oldKp = c->dOutKp.p;
     if ((rc = ensure(c, c->dLvlXY, kp * sizeof(unsigned))) || (rc = ensure(c, c->dLvlScore, kp)) ||
-        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dProcOrder, kp * sizeof(unsigned short))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
+        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dProcOrder, kp * sizeof(uint2))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
         (rc = ensure(c, c->dOutKp, kp1 * sizeof(ygzf_kp))) || (rc = ensure(c, c->dOutDesc, kp1 * 32)) ||
         (rc = ensure(c, c->dOutCnt, (B + 1) * sizeof(int))))
         return rc;
@@ -503,7 +503,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                           G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                           (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                           (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
-                          (unsigned short *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg,
+                          (uint2 *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg,
                           c->octGlobalNodes ? (int *) c->dOctNodes.p : nullptr);
         }
         if (odbg) {
@@ -515,10 +515,12 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                         st[l * 8 + 2] - st[l * 8 + 1], st[l * 8 + 3] - st[l * 8 + 2], st[l * 8 + 4] - st[l * 8 + 3], st[l * 8 + 5] - st[l * 8 + 4], st[l * 8 + 6], st[l * 8 + 7]);
         }
         {
+            int kpBase[kMaxLevels];
+            for (int l = 0; l < L; l++) kpBase[l] = G.lv[l].kpBase;
             ProfScope ps(c, KK_DESCRIBE);
             launch_describe(c->stream, fs, dGeom, L, (const unsigned *) c->dLvlXY.p, (const unsigned char *) c->dLvlScore.p,
-                            (const int *) c->dLvlCnt.p, (const unsigned short *) c->dProcOrder.p, G.kpStride, outKp, outDesc, outCnt,
-                            G.kpStride, nFrames, c->tab.cfg.cv_mode);
+                            (const int *) c->dLvlCnt.p, (const uint2 *) c->dProcOrder.p, G.kpStride, outKp, outDesc, outCnt,
+                            G.kpStride, nFrames, c->tab.cfg.cv_mode, kpBase);
         }
     } else {
         HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int) * nFrames, c->stream));
