@@ -1,0 +1,65 @@
+"""Long-run hygiene of the library: device memory must not grow while the same calls repeat (contexts grow their scratch buffers once and
+keep them), and creating / destroying contexts returns everything."""
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+from orb_ygz_slam_amd.scene import two_view_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipDeviceSynchronize() == 0
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_repeated_calls_do_not_grow_device_memory():
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    cam = make_camera(w, h)
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=4)
+    imgs = np.stack([synth_frame(60 + i, w, h) for i in range(4)])
+    A, B, _, bp = two_view_scene(9, w, h, EUROC)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    inv = ex.tables()["inv_scale"]
+
+    def one_round(i):
+        ex.extract_batch_host(imgs)
+        ex.match_batch_prev(cam, 15.0, True, True, True)
+        ex.align_batch_prev(cam, 7, 1, 10)
+        ex.batch_fetch(i % 4)
+        k, d = ex.extract(A if i % 2 else B)
+        pa, pb = ex.compute_pyramid(A), ex.compute_pyramid(B)
+        ex.sia_run(cam, k, bp(k["x"], k["y"]), ident, pa, ident, pb, inv, 7, 1)
+        ex.features_in_area(cam, k, np.array([[300, 200, 40]], np.float32))
+        ex.descriptor_distance(d[:100], d[100:200])
+
+    for i in range(6):                       # every buffer reaches its working size
+        one_round(i)
+    before = _free_bytes()
+    for i in range(150):
+        one_round(i)
+    after = _free_bytes()
+    assert before - after < (8 << 20), (before, after)      # allocator slack only: no growth with the call count
+
+
+def test_contexts_give_their_memory_back():
+    from orb_ygz_slam_amd import Extractor
+    w, h = 752, 480
+    img = synth_frame(61, w, h)
+    for _ in range(3):                       # the first contexts load code objects and warm the allocator
+        ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=8)
+        ex.extract(img)
+        ex.close()
+    before = _free_bytes()
+    for _ in range(40):
+        ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=8)
+        ex.extract(img)
+        ex.close()
+    after = _free_bytes()
+    assert before - after < (8 << 20), (before, after)
