@@ -202,13 +202,15 @@ class Extractor:
         return outs
 
     def extract(self, img):
-        img = np.ascontiguousarray(img, np.uint8)
-        h, w = img.shape
+        img = np.asarray(img, np.uint8)
+        if img.ndim != 2 or img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            img = np.ascontiguousarray(img)
+        h, w = img.shape                                   # a row-strided view (e.g. a crop) goes down as it is: stride = its row pitch
         cap = self.max_keypoints(w, h)
         k = np.zeros(max(cap, 1), KP_DTYPE)
         d = np.zeros((max(cap, 1), 32), np.uint8)
         n = C.c_int()
-        self._ck(self.L.ygzf_extract(self.h, _p(img), w, h, w, _p(k), _p(d), cap, C.byref(n)))
+        self._ck(self.L.ygzf_extract(self.h, img.ctypes.data_as(C.c_void_p), w, h, int(img.strides[0]), _p(k), _p(d), cap, C.byref(n)))
         return k[:n.value].copy(), d[:n.value].copy()
 
     def extract_batch_host(self, imgs):

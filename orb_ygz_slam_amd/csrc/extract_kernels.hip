@@ -1511,6 +1511,48 @@ hipError_t upload_constants(const int *umax16) {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int));
 }
 
+// All levels of frame 0 as tight (pitch = width) images, one after the other, into a linear buffer: what ORBextractor::mvImagePyramid holds
+// on the host.  The device levels have 64-byte pitches; a pitched device-to-host copy of an odd-width level is executed row by row by the
+// copy engine (1.3 ms per level), so the levels are packed here and leave in ONE linear copy.
+struct PackOffsets { unsigned v[kMaxLevels + 1]; };
+__global__ __launch_bounds__(256) void k_pack_levels(FrameSet fs, const LevelGeom *__restrict__ geom, PackOffsets off, uint8_t *__restrict__ dst) {
+    const int l = blockIdx.y;
+    const LevelGeom g = geom[l];
+    int pitch;
+    const uint8_t *src = level_ptr(fs, g, l, 0, &pitch);
+    const unsigned n = (unsigned) g.w * (unsigned) g.h;
+    uint8_t *d = dst + off.v[l];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const unsigned y = i / (unsigned) g.w, x = i - y * (unsigned) g.w;
+        d[i] = src[(size_t) y * pitch + x];
+    }
+}
+
+void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *offsets, uint8_t *dst) {
+    PackOffsets off;
+    for (int l = 0; l <= kMaxLevels; l++) off.v[l] = l <= nlevels ? offsets[l] : 0;
+    hipLaunchKernelGGL(k_pack_levels, dim3(128, nlevels), dim3(256), 0, st, fs, dGeom, off, dst);
+}
+
+// rows of `w` bytes from a linear staging buffer (row pitch srcPitch) into a pitched image: the device half of an upload whose pitched
+// host-to-device copy the copy engine would execute row by row (widths or pitches that are not multiples of 4: 2.6-3.3 ms for a 1241x376
+// or 641x479 frame instead of 0.1 ms)
+__global__ __launch_bounds__(256) void k_repitch_rows(const uint8_t *__restrict__ src, unsigned srcPitch, uint8_t *__restrict__ dst, unsigned dstPitch,
+                                                      unsigned w, unsigned long long n) {
+    for (unsigned long long i = (unsigned long long) blockIdx.x * 256u + threadIdx.x; i < n; i += (unsigned long long) gridDim.x * 256u) {
+        const unsigned long long y = i / w;
+        const unsigned x = (unsigned) (i - y * w);
+        dst[y * dstPitch + x] = src[y * srcPitch + x];
+    }
+}
+
+void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int w, size_t rows) {
+    const unsigned long long n = (unsigned long long) w * rows;
+    if (n == 0) return;
+    const unsigned blocks = (unsigned) std::min<unsigned long long>((n + 1023) / 1024, 4096);
+    hipLaunchKernelGGL(k_repitch_rows, dim3(blocks), dim3(256), 0, st, src, (unsigned) srcPitch, dst, (unsigned) dstPitch, (unsigned) w, n);
+}
+
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
     if (g.area2x || !g.tiledOk) {   // exact 2x levels (area mean) and steep pyramids (tile would not fit LDS): per-pixel kernel

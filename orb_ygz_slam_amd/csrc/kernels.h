@@ -9,6 +9,8 @@ hipError_t upload_constants(const int *umax16);
 
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
+void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int w, size_t rows);
+void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *offsets, uint8_t *dst);
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,

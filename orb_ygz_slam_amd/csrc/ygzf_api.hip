@@ -124,6 +124,9 @@ struct ygzf_ctx {
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
     Buf dFastStats;
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
+    Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
+    uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
+    size_t hStageBytes = 0;
     // batch state
     int lastFrames = 0;
     FrameSet lastFs{};
@@ -181,6 +184,16 @@ static int ensure(ygzf_ctx *c, ygzf_ctx::Buf &b, size_t bytes) {
 }
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static int ensure_stage(ygzf_ctx *c, size_t bytes) {
+    if (bytes <= c->hStageBytes) return YGZF_OK;
+    if (c->hStage) HIPCHECK(c, hipHostFree(c->hStage));
+    c->hStage = nullptr;
+    c->hStageBytes = 0;
+    HIPCHECK(c, hipHostMalloc((void **) &c->hStage, bytes));
+    c->hStageBytes = bytes;
+    return YGZF_OK;
+}
 
 // Per-(w,h) geometry: level sizes, resize coefficient tables (cv::resize INTER_LINEAR fixed point, restated from the
 // OpenCV 2.4/3.2 algorithm: fx = (float)((dx+0.5)*scale - 0.5), 11-bit coefficients), FAST cell grid (:733-745),
@@ -537,17 +550,37 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     return YGZF_OK;
 }
 
+// `rows` rows of `w` bytes from host memory (row pitch srcPitch) into a pitched device image.  The copy engine executes a pitched copy whose
+// width or pitches are not multiples of 4 row by row (measured: 2.6-3.3 ms for one 1241x376 or 641x479 frame); such images travel as ONE
+// linear copy into a landing buffer and are re-pitched by a kernel.
+static int upload_rows(ygzf_ctx *c, void *dst, size_t dstPitch, const uint8_t *src, size_t srcPitch, int w, size_t rows) {
+    if (rows == 0 || w <= 0) return YGZF_OK;
+    if ((w & 3) == 0 && (srcPitch & 3) == 0 && (dstPitch & 3) == 0 && ((uintptr_t) src & 3) == 0) {
+        HIPCHECK(c, hipMemcpy2DAsync(dst, dstPitch, src, srcPitch, (size_t) w, rows, hipMemcpyHostToDevice, c->stream));
+        return YGZF_OK;
+    }
+    const size_t bytes = (rows - 1) * srcPitch + (size_t) w;
+    int rc = ensure(c, c->dUpStage, bytes + 64);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->dUpStage.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    launch_repitch_rows(c->stream, (const uint8_t *) c->dUpStage.p, srcPitch, (uint8_t *) dst, dstPitch, w, rows);
+    HIPCHECK(c, hipGetLastError());
+    return YGZF_OK;
+}
+
 static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, int row_pitch, size_t frame_stride,
                          FrameSet *fs) {
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
-    if (nFrames > 1 && frame_stride == (size_t) row_pitch * h) {   // frames back to back: one 2-D copy of nFrames * h rows
-        HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, pitch, imgs, row_pitch, w, (size_t) nFrames * h, hipMemcpyHostToDevice, c->stream));
+    if (nFrames == 1 || frame_stride == (size_t) row_pitch * h) {   // frames back to back: one copy of nFrames * h rows
+        if ((rc = upload_rows(c, c->dImg0.p, (size_t) pitch, imgs, (size_t) row_pitch, w, (size_t) nFrames * h))) return rc;
     } else {
-        for (int f = 0; f < nFrames; f++)
-            HIPCHECK(c, hipMemcpy2DAsync((uint8_t *) c->dImg0.p + (size_t) f * pitch * h, pitch, imgs + f * frame_stride, row_pitch, w, h,
-                                         hipMemcpyHostToDevice, c->stream));
+        for (int f = 0; f < nFrames; f++) {
+            // (the landing buffer is reused: stream order keeps frame f's re-pitch ahead of frame f + 1's copy)
+            if ((rc = upload_rows(c, (uint8_t *) c->dImg0.p + (size_t) f * pitch * h, (size_t) pitch, imgs + f * frame_stride, (size_t) row_pitch, w, (size_t) h)))
+                return rc;
+        }
     }
     fs->img0 = (const uint8_t *) c->dImg0.p;
     fs->img0_stride = (long long) pitch * h;
@@ -641,7 +674,9 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dCacheImg.p) (void) hipFree(c->dCacheImg.p);
     if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
     if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
+    if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
     if (c->hFastStats) (void) hipHostFree(c->hFastStats);
+    if (c->hStage) (void) hipHostFree(c->hStage);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
@@ -735,12 +770,19 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
                           (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
     }
     HIPCHECK(c, hipGetLastError());
-    for (int l = 0; l < L; l++) {
-        int pitch;
-        const uint8_t *p = level_ptr(fs, G.lv[l], l, 0, &pitch);
-        HIPCHECK(c, hipMemcpy2DAsync(levels_out[l], G.lv[l].w, p, pitch, G.lv[l].w, G.lv[l].h, hipMemcpyDeviceToHost, c->stream));
-    }
+    // The levels go back tight (pitch = width) into caller memory that is pageable as a rule (cv::Mat buffers).  Eight pitched device-to-host
+    // copies took 10-13 ms for a 752x480 pyramid (the copy engine works an odd-width pitched copy off row by row, into page-locked memory
+    // as well): the levels are packed on the device and leave in one linear copy through the context's page-locked staging buffer.
+    unsigned offs[kMaxLevels + 1];
+    offs[0] = 0;
+    for (int l = 0; l < L; l++) offs[l + 1] = offs[l] + (unsigned) G.lv[l].w * (unsigned) G.lv[l].h;
+    const size_t total = offs[L];
+    if ((rc = ensure_stage(c, total)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
+    launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, L, offs, (uint8_t *) c->dTmpC.p);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    for (int l = 0; l < L; l++) memcpy(levels_out[l], c->hStage + offs[l], offs[l + 1] - offs[l]);
     c->lastFrames = 0;
     return YGZF_OK;
 }
@@ -829,7 +871,13 @@ int ygzf_batch_fetch_level(ygzf_ctx *c, int frame, int level, uint8_t *out) {
     int pitch;
     const LevelGeom &g = c->geo.lv[level];
     const uint8_t *p = level_ptr(c->lastFs, g, level, frame, &pitch);
-    HIPCHECK(c, hipMemcpy2DAsync(out, g.w, p, pitch, g.w, g.h, hipMemcpyDeviceToHost, c->stream));
+    // packed on the device, then one linear copy (a pitched copy of an odd-width level is executed row by row)
+    const size_t bytes = (size_t) g.w * g.h;
+    int rc = ensure(c, c->dTmpC, bytes + 64);
+    if (rc) return rc;
+    launch_repitch_rows(c->stream, p, (size_t) pitch, (uint8_t *) c->dTmpC.p, (size_t) g.w, g.w, (size_t) g.h);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(out, c->dTmpC.p, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }
@@ -1321,7 +1369,7 @@ int ygzf_fast10(ygzf_ctx *c, const uint8_t *img, int img_w, int img_h, int strid
         (rc = ensure(c, B[2], (size_t) (2 * h + 2) * sizeof(int))) || (rc = ensure(c, B[3], (size_t) std::max(cap, 1) * 2 * sizeof(short))) ||
         (rc = ensure(c, B[4], (size_t) std::max(cap, 1) * sizeof(int))) || (rc = ensure(c, B[5], (size_t) std::max(cap, 1) * sizeof(int))))
         return rc;
-    HIPCHECK(c, hipMemcpy2DAsync(B[0].p, pitch, img, stride, img_w, img_h, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_rows(c, B[0].p, (size_t) pitch, img, (size_t) stride, img_w, (size_t) img_h))) return rc;
     int *rowCnt = (int *) B[2].p, *rowKept = rowCnt + h, *totals = rowKept + h;
     {
         ProfScope ps(c, KK_FAST10);
@@ -2140,7 +2188,7 @@ int ygzf_image_cache_put(ygzf_ctx *c, int slot, const uint8_t *img, int w, int h
     FrameSet fs = cache_frameset(c);
     fs.img0 += (long long) slot * fs.img0_stride;      // the launchers address "frame 0" of the set they are given
     fs.pyr += (long long) slot * fs.pyr_stride;
-    HIPCHECK(c, hipMemcpy2DAsync((void *) fs.img0, c->cachePitch, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    if ((rc = upload_rows(c, (void *) fs.img0, (size_t) c->cachePitch, img, (size_t) stride, w, (size_t) h))) return rc;
     const int L = c->tab.cfg.nlevels;
     for (int l = 1; l < L; l++) {
         ProfScope ps(c, KK_PYR);

@@ -174,3 +174,28 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "keypoints:" in out.stdout
+
+
+def test_shell_latency_per_frame(tmp_path):
+    """One Tracking iteration through the class shells, one frame at a time (host cv::Mat in, std::vector / cv::Mat out): prints the
+    per-call latencies INTEGRATION.md quotes and checks that they stay in the range that makes the library a real-time drop-in."""
+    from orb_ygz_slam_amd import load_library
+    load_library()
+    host = os.path.join(ROOT, "orb_ygz_slam_amd", "csrc", "host")
+    lib = os.path.join(ROOT, "orb_ygz_slam_amd", "lib")
+    exe = os.path.join(str(tmp_path), "shell_latency")
+    srcs = [os.path.join(ROOT, "tests", "cpp", "shell_latency.cc")] + [os.path.join(host, f) for f in
+                                                                       ("ORBextractor.cc", "ORBmatcher.cc", "SparseImageAlign.cc", "ygzf_pool.cc")]
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", host, "-I", os.path.join(host, "standalone")] + srcs +
+                          ["-L", lib, "-lygzf", "-Wl,-rpath," + lib, "-o", exe])
+    imgA, imgB, _, _ = two_view_scene(9, 752, 480, EUROC, Z=4.0)
+    imgA.tofile(tmp_path / "a.u8")
+    imgB.tofile(tmp_path / "b.u8")
+    out = subprocess.run([exe, str(tmp_path), "200"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    print(out.stdout)
+    med = {l.split()[0]: float(l.split()[1]) for l in out.stdout.splitlines() if l and not l.startswith("info")}
+    assert {"extract_image", "frame_pyramid_plus_extract", "sparse_img_align_run", "search_by_projection_last"} <= set(med)
+    # a 30 Hz camera leaves 33 ms per frame; the CPU reference spends ~20 ms in the extractor alone
+    assert med["extract_image"] < 3000 and med["frame_pyramid_plus_extract"] < 4000
+    assert med["sparse_img_align_run"] < 5000 and med["search_by_projection_last"] < 3000

@@ -63,3 +63,38 @@ def test_contexts_give_their_memory_back():
         ex.close()
     after = _free_bytes()
     assert before - after < (8 << 20), (before, after)
+
+
+def test_awkward_widths_do_not_fall_off_the_copy_fast_path(oracle):
+    """Pitched host<->device copies whose width is not a multiple of 4 are executed row by row by the copy engine (3 ms per 1241x376 frame,
+    13 ms per pyramid read-back); the library re-pitches on the device instead.  Latency of such sizes must stay in the family of the
+    752x480 case, and the results must still be the oracle's."""
+    import time
+    from orb_ygz_slam_amd import Extractor
+
+    def med(f, n=30):
+        for _ in range(5):
+            f()
+        t = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            t.append(time.perf_counter() - t0)
+        return float(np.median(t))
+
+    lat = {}
+    for (w, h) in ((752, 480), (1241, 376), (641, 479), (1242, 375)):
+        ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+        img = synth_frame(5, w, h)
+        lat[(w, h)] = (med(lambda: ex.extract(img)), med(lambda: ex.compute_pyramid(img)))
+        k, d = ex.extract(img)
+        ok, od = oracle.Extractor(1000, 1.2, 8, 20, 7).extract(img)
+        assert np.array_equal(k["x"], ok["x"]) and np.array_equal(k["y"], ok["y"]) and np.array_equal(d, od), (w, h)
+        strided = np.zeros((h, w + 13), np.uint8)                      # a host image with a row pitch that is not its width
+        strided[:, :w] = img
+        k2, d2 = ex.extract(strided[:, :w])
+        assert np.array_equal(k2, k) and np.array_equal(d2, d), (w, h)
+    base_e, base_p = lat[(752, 480)]
+    for key, (e, p) in lat.items():
+        assert e < 3 * base_e + 2e-4 and p < 3 * base_p + 2e-4, (key, lat)
+    print({k: (round(1e6 * a), round(1e6 * b)) for k, (a, b) in lat.items()})
