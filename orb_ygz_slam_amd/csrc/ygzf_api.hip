@@ -1722,11 +1722,21 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     A.capLast = (int) nq;
     size_t lds;
     if ((rc = plan_match_lds(c, A, 1, &lds))) return rc;
+    if (c->matchDebug) {
+        if ((rc = ensure(c, c->dTmpC, 8 * sizeof(long long)))) return rc;
+        A.dbg = (long long *) c->dTmpC.p;
+    }
     {
         ProfScope ps(c, KK_MATCH);
         launch_match_last(c->stream, A, 1, lds);
     }
     HIPCHECK(c, hipGetLastError());
+    if (A.dbg) {
+        long long st[8];
+        HIPCHECK(c, hipMemcpy(st, A.dbg, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ygzf match mode %d, 100MHz ticks] grid %lld  proj %lld  spec %lld  seq %lld  tail %lld  rescans %lld of %lld queries\n", mode,
+                st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6], st[7]);
+    }
     if (fr) {
         if (fr->in_view) HIPCHECK(c, hipMemcpyAsync(fr->in_view, G[7].p, nq, hipMemcpyDeviceToHost, c->stream));
         if (fr->proj_x) HIPCHECK(c, hipMemcpyAsync(fr->proj_x, G[6].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
