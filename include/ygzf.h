@@ -71,6 +71,9 @@ const char *ygzf_last_error(const ygzf_ctx *ctx);
  * entries, any may be NULL. */
 int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat);
 
+/* Free / total memory of the context's device after draining the context's stream (diagnostics: leak checks, sizing of resident batches). */
+int ygzf_device_mem_info(ygzf_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
+
 /* Tuning knob of the cell loop of ComputeKeyPointsOctTree (src/ORBextractor.cc:747-781: FAST(iniThFAST), and FAST(minThFAST) where that
  * finds nothing).  The keypoints are the same under every plan; only the cost differs with the image content:
  *   YGZF_FAST_PLAN_AUTO       (default) chosen before every launch from statistics of the context's earlier launches

@@ -120,6 +120,7 @@ def load_library(build_if_missing=True):
     L.ygzf_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, C.POINTER(FrustumIn), vp, vp, C.c_float, C.c_int,
                                            C.c_float, vp, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ygzf_distinctive_descriptors_batch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ygzf_device_mem_info.argtypes = [vp, vp, vp]
     L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
@@ -473,6 +474,12 @@ class Extractor:
         self._ck(self.L.ygzf_search_local_points(self.h, C.byref(fv), C.byref(cam), n, C.byref(fi), _p(obs) if obs is not None else None, _p(md), th,
                                                  int(check_level), nnratio, _p(own), _p(match), C.byref(nm), _p(iv), None, None, None, None, None))
         return nm.value, match[:len(ck)], own[:len(ck)], iv[:n]
+
+    def device_mem_info(self):
+        """(free, total) bytes of the context's device after draining its stream."""
+        f, t = C.c_size_t(0), C.c_size_t(0)
+        self._ck(self.L.ygzf_device_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def set_fast_plan(self, plan):
         """0 auto (default), 1 one pass at minTh, 2 iniTh first -- same keypoints, different cost (include/ygzf.h)."""

@@ -690,6 +690,14 @@ const char *ygzf_last_error(const ygzf_ctx *c) {
     return g_create_err.c_str();
 }
 
+int ygzf_device_mem_info(ygzf_ctx *c, size_t *free_bytes, size_t *total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return fail(c, YGZF_ERR_INVALID, "null argument");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipMemGetInfo(free_bytes, total_bytes));
+    return YGZF_OK;
+}
+
 int ygzf_set_fast_plan(ygzf_ctx *c, int plan) {
     if (!c) return YGZF_ERR_INVALID;
     if (plan < YGZF_FAST_PLAN_AUTO || plan > YGZF_FAST_PLAN_INI_FIRST) return fail(c, YGZF_ERR_INVALID, "FAST plan %d (0 auto, 1 one pass, 2 iniTh first)", plan);
