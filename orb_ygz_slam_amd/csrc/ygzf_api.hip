@@ -121,6 +121,7 @@ struct ygzf_ctx {
     // minTh, 2 = iniTh first.  Identical results either way.
     int fastPlan = 0;
     bool fastIniFirst = false;
+    unsigned fastLaunches = 0;             // statistics are collected on the first launches and on every 8th one after that
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
     Buf dFastStats;
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
@@ -492,7 +493,9 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             }
         }
         const bool iniFirst = c->fastPlan == 2 || (c->fastPlan == 0 && c->fastIniFirst);
-        {
+        const bool collect = c->fastPlan == 0 && (c->fastLaunches < 4 || (c->fastLaunches & 7) == 0);   // content drifts slowly: sample it
+        c->fastLaunches++;
+        if (collect) {
             int rcS = ensure(c, c->dFastStats, kFastStatWords * sizeof(unsigned));
             if (rcS) return rcS;
             HIPCHECK(c, hipMemsetAsync(c->dFastStats.p, 0, kFastStatWords * sizeof(unsigned), c->stream));
@@ -501,9 +504,9 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             ProfScope ps(c, KK_FAST);
             launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                               (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
-                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase, iniFirst, (unsigned *) c->dFastStats.p);
+                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
         }
-        HIPCHECK(c, hipMemcpyAsync(c->hFastStats, c->dFastStats.p, kFastStatWords * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+        if (collect) HIPCHECK(c, hipMemcpyAsync(c->hFastStats, c->dFastStats.p, kFastStatWords * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         long long *odbg = nullptr;
         if (c->octDebug) {
             int rc2 = ensure(c, c->dTmpA, 16 * 8 * sizeof(long long));
