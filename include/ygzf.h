@@ -355,6 +355,14 @@ int ygzf_stereo_fetch(ygzf_ctx *ctx, int pair, float *u_right, float *depth, int
  *       patches_with_border (nullable, n x 100): the warped 10x10 reference patches, for tests.
  * Results equal the CPU definition bit for bit (one thread per candidate keeps the reference's sequential accumulation order). */
 int ygzf_image_cache_reserve(ygzf_ctx *ctx, int n_slots, int w, int h);
+/* SparseImgAlign::run on two image-cache slots (pyramids already on the device: the slots' level-0 images and what the resize kernel built
+ * from them -- the same bytes the extractor's pyramid holds).  `ref` supplies keys / mp_world / mp_valid / outlier / Tcw as in ygzf_sia_run;
+ * its level arrays are not read.  Saves the upload of both host pyramids on every call (the reference frame of one call was the current
+ * frame of the previous one). */
+int ygzf_sia_run_cached(ygzf_ctx *ctx, int ref_slot, int cur_slot, const ygzf_sia_frame *ref, const float *cur_Tcw7, const ygzf_camera *cam,
+                        const float *inv_scale_factors, int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info,
+                        float *H36);
+
 int ygzf_image_cache_put(ygzf_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride);
 int ygzf_find_direct_projection_batch(ygzf_ctx *ctx, const ygzf_camera *cam, int cur_slot, const float *cur_Tcw7, int n, const int *ref_slot,
                                       const float *ref_Tcw7, const ygzf_kp *ref_kp, const float *mp_world, float *px_curr, int *search_level,

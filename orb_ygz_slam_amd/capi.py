@@ -126,6 +126,8 @@ def load_library(build_if_missing=True):
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
+    L.ygzf_sia_run_cached.argtypes = [vp, C.c_int, C.c_int, C.POINTER(SiaFrame), vp, C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
+                                      C.POINTER(C.c_size_t), vp, vp]
     L.ygzf_align_batch_prev.argtypes = [vp, C.POINTER(Camera), C.c_int, C.c_int, C.c_int]
     L.ygzf_align_fetch.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_size_t), vp]
     L.ygzf_fast10.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip, ip]
@@ -550,6 +552,33 @@ class Extractor:
         ret = C.c_size_t()
         self._ck(self.L.ygzf_sia_run(self.h, C.byref(R), C.byref(Cf), C.byref(cam), _p(isf), max_level, min_level, n_iter, _p(out7),
                                      C.byref(ret), _p(info), _p(H)))
+        return int(ret.value), out7, info, H.reshape(6, 6)
+
+    def sia_run_cached(self, cam, ref_slot, cur_slot, ref_keys, ref_world, ref_Tcw7, cur_Tcw7, inv_scale, max_level, min_level, n_iter=10,
+                       mp_valid=None, outlier=None):
+        """SparseImgAlign::run on two image-cache slots (image_cache_put) -> (ret, TCR7, info[2], H 6x6)."""
+        keys = np.ascontiguousarray(ref_keys, KP_DTYPE)
+        world = np.ascontiguousarray(ref_world, np.float32)
+        keep = [keys, world]
+        f = SiaFrame()
+        f.n = len(keys)
+        f.keys = keys.ctypes.data
+        f.mp_world = world.ctypes.data
+        for name, a in (("mp_valid", mp_valid), ("outlier", outlier)):
+            if a is not None:
+                a = np.ascontiguousarray(a, np.uint8)
+                keep.append(a)
+                setattr(f, name, a.ctypes.data)
+        for i in range(7):
+            f.Tcw[i] = float(ref_Tcw7[i])
+        ct = np.ascontiguousarray(cur_Tcw7, np.float32)
+        isf = np.ascontiguousarray(inv_scale, np.float32)
+        out7 = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+        info = np.zeros(2, np.float32)
+        H = np.zeros(36, np.float32)
+        ret = C.c_size_t()
+        self._ck(self.L.ygzf_sia_run_cached(self.h, int(ref_slot), int(cur_slot), C.byref(f), _p(ct), C.byref(cam), _p(isf), max_level, min_level,
+                                            n_iter, _p(out7), C.byref(ret), _p(info), _p(H)))
         return int(ret.value), out7, info, H.reshape(6, 6)
 
     def align_batch_prev(self, cam, max_level=None, min_level=1, n_iter=10):

@@ -287,76 +287,23 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
 // src/ORBmatcher.cc:1574-1602 (+ GetWarpAffineMatrix :1525-1548, GetBestSearchLevel / GetBilateralInterpUchar include/ORBmatcher.h:185-211,
 // WarpAffine :1550-1572, ygz::Align2D src/Align.cc:8-104) for ONE (MapPoint, KeyFrame) candidate -- the signature Tracking::
 // SearchLocalPointsDirect calls (src/Tracking.cc:2210, :2289).  The KeyFrames' and the current frame's level-0 images live in an
-// HBM-resident cache on the device (their pyramids are rebuilt there by the same resize kernel the extractor used, so they equal the host
-// copies): a KeyFrame is uploaded the first time it is referenced, the current frame whenever its id changes; slots are recycled least
-// recently used.  A launch per candidate is latency-bound: callers that own the candidate loop should hand the whole list to
+// HBM-resident cache on the device shared with SparseImgAlign::run (ygzf_host::ImageCache: their pyramids are rebuilt there by the same
+// resize kernel the extractor used, so they equal the host copies): an image is uploaded the first time it is referenced; slots are
+// recycled least recently used.  A launch per candidate is latency-bound: callers that own the candidate loop should hand the whole list to
 // ygzf_find_direct_projection_batch instead (INTEGRATION.md shows that binding for SearchLocalPointsDirect); this member exists so that the
 // unmodified caller keeps working.
-namespace {
-struct DirectCache {
-    std::mutex mu;
-    ygzf_ctx *ctx = nullptr;
-    int w = 0, h = 0, nlevels = 0, device = -1;
-    float scaleFactor = 0;
-    static const int kSlots = 96;                    // 95 KeyFrames + the current frame
-    std::map<unsigned long, int> kfSlot;             // KeyFrame::mnId -> slot
-    std::vector<unsigned long> slotKf, slotUse;      // owner / last use per slot
-    unsigned long tick = 0, curId = ~0ul;
-    bool curValid = false;
-
-    bool prepare(int dev, int W, int H, int L, float sf) {
-        if (ctx && dev == device && W == w && H == h && L == nlevels && sf == scaleFactor) return true;
-        if (ctx) ygzf_destroy(ctx);
-        ctx = nullptr;
-        ygzf_extractor_cfg cfg = {1000, sf, L, 20, 7, 0};   // the pyramid geometry is all that matters here
-        if (ygzf_create(dev, &cfg, W, H, 1, &ctx) != YGZF_OK) { fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(nullptr)); ctx = nullptr; return false; }
-        if (ygzf_image_cache_reserve(ctx, kSlots, W, H) != YGZF_OK) { fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(ctx)); return false; }
-        device = dev; w = W; h = H; nlevels = L; scaleFactor = sf;
-        kfSlot.clear();
-        slotKf.assign(kSlots, ~0ul);
-        slotUse.assign(kSlots, 0);
-        curValid = false;
-        return true;
-    }
-    int keyframe_slot(unsigned long id, const cv::Mat &img0) {
-        auto it = kfSlot.find(id);
-        if (it != kfSlot.end()) { slotUse[it->second] = ++tick; return it->second; }
-        int victim = 1;                                // slot 0 is the current frame's
-        for (int s = 1; s < kSlots; s++)
-            if (slotUse[s] < slotUse[victim]) victim = s;
-        if (slotKf[victim] != ~0ul) kfSlot.erase(slotKf[victim]);
-        if (ygzf_image_cache_put(ctx, victim, img0.data, img0.cols, img0.rows, (int) img0.step) != YGZF_OK) {
-            fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(ctx));
-            slotKf[victim] = ~0ul;
-            return -1;
-        }
-        slotKf[victim] = id;
-        kfSlot[id] = victim;
-        slotUse[victim] = ++tick;
-        return victim;
-    }
-};
-DirectCache &direct_cache() { static DirectCache *c = new DirectCache(); return *c; }   // never destroyed (HIP may be gone at exit)
-}  // namespace
-
 bool ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level) {
     const int L = (int) ref->mvImagePyramid.size();
     if (L < 1 || (int) curr->mvImagePyramid.size() != L || (int) curr->mvScaleFactors.size() < L) return false;
     const cv::Mat &cur0 = curr->mvImagePyramid[0], &ref0 = ref->mvImagePyramid[0];
     if (cur0.cols != ref0.cols || cur0.rows != ref0.rows) return false;
-    DirectCache &dc = direct_cache();
-    std::lock_guard<std::mutex> lk(dc.mu);
-    if (!dc.prepare(device(), cur0.cols, cur0.rows, L, L > 1 ? curr->mvScaleFactors[1] : 1.2f)) return false;
-    if (!dc.curValid || dc.curId != curr->mnId) {
-        if (ygzf_image_cache_put(dc.ctx, 0, cur0.data, cur0.cols, cur0.rows, (int) cur0.step) != YGZF_OK) {
-            fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(dc.ctx));
-            return false;
-        }
-        dc.curId = curr->mnId;
-        dc.curValid = true;
-    }
-    const int slot = dc.keyframe_slot(ref->mnId, ref0);
-    if (slot < 0) return false;
+    static const char *who = "ygz::ORBmatcher::FindDirectProjection";
+    ygzf_host::ImageCache &dc = ygzf_host::ImageCache::instance();
+    ygzf_host::ImageCache::Guard lk(dc);
+    if (!dc.prepare(device(), cur0.cols, cur0.rows, L, L > 1 ? curr->mvScaleFactors[1] : 1.2f, who)) return false;
+    const int curSlot = dc.slot(ygzf_host::ImageCache::kFrame, curr->mnId, cur0.data, cur0.cols, cur0.rows, (int) cur0.step, who);
+    const int slot = dc.slot(ygzf_host::ImageCache::kKeyFrame, ref->mnId, ref0.data, ref0.cols, ref0.rows, (int) ref0.step, who);
+    if (curSlot < 0 || slot < 0) return false;
     const int index = (int) mp->GetObservations()[ref];
     const cv::KeyPoint kp = ref->mvKeys[index];
     float refT[7], curT[7], world[3], px[2] = {px_curr[0], px_curr[1]};
@@ -367,8 +314,8 @@ bool ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, 
     int level = 0;
     uint8_t ok = 0;
     static_assert(sizeof(cv::KeyPoint) == sizeof(ygzf_kp), "cv::KeyPoint layout");
-    if (ygzf_find_direct_projection_batch(dc.ctx, &cam, 0, curT, 1, &slot, refT, (const ygzf_kp *) &kp, world, px, &level, &ok, nullptr) != YGZF_OK) {
-        fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(dc.ctx));
+    if (ygzf_find_direct_projection_batch(dc.ctx(), &cam, curSlot, curT, 1, &slot, refT, (const ygzf_kp *) &kp, world, px, &level, &ok, nullptr) != YGZF_OK) {
+        fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(dc.ctx()));
         return false;
     }
     px_curr[0] = px[0];

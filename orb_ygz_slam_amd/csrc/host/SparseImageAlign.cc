@@ -31,9 +31,6 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
         fprintf(stderr, "SparseImgAlign: no features to track!\n");   // the reference logs the same and returns 0 (:24-27)
         return 0;
     }
-    ygzf_host::Lease lease(ORBextractor::sDevice);
-    if (!lease) return 0;
-    ygzf_ctx *ctx = lease.get();
     const int N = ref->N;
     std::vector<uint8_t> valid(N), outl(N);
     std::vector<float> world((size_t) N * 3);
@@ -43,30 +40,61 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
         outl[i] = ref->mvbOutlier[i];
         if (mp) ygz_compat::world_pos(mp, &world[3 * (size_t) i]);
     }
-    auto fill = [](Frame *f, ygzf_sia_frame &o, std::vector<const uint8_t *> &lv, std::vector<int> &w, std::vector<int> &h) {
-        const int L = (int) f->mvImagePyramid.size();
-        lv.resize(L); w.resize(L); h.resize(L);
-        for (int l = 0; l < L; l++) { lv[l] = f->mvImagePyramid[l].data; w[l] = f->mvImagePyramid[l].cols; h[l] = f->mvImagePyramid[l].rows; }
-        o.nlevels = L; o.levels = lv.data(); o.level_w = w.data(); o.level_h = h.data();
-        ygz_compat::se3_to7(f->mTcw, o.Tcw);
-    };
     ygzf_sia_frame R{}, C{};
-    std::vector<const uint8_t *> lr, lc;
-    std::vector<int> wr, hr, wc, hc;
-    fill(ref, R, lr, wr, hr);
-    fill(cur, C, lc, wc, hc);
     R.n = N;
     R.keys = (const ygzf_kp *) ref->mvKeys.data();
     R.mp_valid = valid.data();
     R.outlier = outl.data();
     R.mp_world = world.data();
+    ygz_compat::se3_to7(ref->mTcw, R.Tcw);
+    ygz_compat::se3_to7(cur->mTcw, C.Tcw);
     ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, 0, 0, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
     float T7[7], H36[36];
     size_t ret = 0;
     const int kIterations = 10;   // run() overrides the constructor's n_iter with iterations[level] = 10 on every level (:38-43)
-    if (ygzf_sia_run(ctx, &R, &C, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret, nullptr, H36) != YGZF_OK) {
-        fprintf(stderr, "ygz::SparseImgAlign::run: %s\n", ygzf_last_error(ctx));
-        return 0;
+    static const char *who = "ygz::SparseImgAlign::run";
+    // The two frames' images live in the device-resident image cache the direct matcher uses (ygzf_host::ImageCache): the reference frame
+    // of this call was the current frame of the previous one, so one level-0 upload per new frame replaces two pyramid uploads per call
+    // (their pyramids are rebuilt on the device by the extractor's resize kernel: the bytes the Frames' host pyramids hold).  Frames whose
+    // pyramids cannot come from the cache (no level 0, unequal sizes) go up from host memory.
+    const int L = (int) ref->mvImagePyramid.size();
+    bool done = false;
+    if (L >= 1 && (int) cur->mvImagePyramid.size() == L && (int) ref->mvScaleFactors.size() >= L && max_level_ < L &&
+        ref->mvImagePyramid[0].cols == cur->mvImagePyramid[0].cols && ref->mvImagePyramid[0].rows == cur->mvImagePyramid[0].rows) {
+        const cv::Mat &r0 = ref->mvImagePyramid[0], &c0 = cur->mvImagePyramid[0];
+        ygzf_host::ImageCache &ic = ygzf_host::ImageCache::instance();
+        ygzf_host::ImageCache::Guard lk(ic);
+        if (ic.prepare(ORBextractor::sDevice, r0.cols, r0.rows, L, L > 1 ? ref->mvScaleFactors[1] : 1.2f, who)) {
+            const int rs = ic.slot(ygzf_host::ImageCache::kFrame, ref->mnId, r0.data, r0.cols, r0.rows, (int) r0.step, who);
+            const int cs = ic.slot(ygzf_host::ImageCache::kFrame, cur->mnId, c0.data, c0.cols, c0.rows, (int) c0.step, who);
+            if (rs >= 0 && cs >= 0 && rs != cs) {
+                if (ygzf_sia_run_cached(ic.ctx(), rs, cs, &R, C.Tcw, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret,
+                                        nullptr, H36) != YGZF_OK) {
+                    fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ic.ctx()));
+                    return 0;
+                }
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        ygzf_host::Lease lease(ORBextractor::sDevice);
+        if (!lease) return 0;
+        ygzf_ctx *ctx = lease.get();
+        auto fill = [](Frame *f, ygzf_sia_frame &o, std::vector<const uint8_t *> &lv, std::vector<int> &w, std::vector<int> &h) {
+            const int n = (int) f->mvImagePyramid.size();
+            lv.resize(n); w.resize(n); h.resize(n);
+            for (int l = 0; l < n; l++) { lv[l] = f->mvImagePyramid[l].data; w[l] = f->mvImagePyramid[l].cols; h[l] = f->mvImagePyramid[l].rows; }
+            o.nlevels = n; o.levels = lv.data(); o.level_w = w.data(); o.level_h = h.data();
+        };
+        std::vector<const uint8_t *> lr, lc;
+        std::vector<int> wr, hr, wc, hc;
+        fill(ref, R, lr, wr, hr);
+        fill(cur, C, lc, wc, hc);
+        if (ygzf_sia_run(ctx, &R, &C, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret, nullptr, H36) != YGZF_OK) {
+            fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx));
+            return 0;
+        }
     }
     n_iter_ = kIterations;
     for (int r = 0; r < 6; r++)

@@ -38,4 +38,75 @@ Lease::~Lease() {
     std::lock_guard<std::mutex> lk(pool().mu);
     pool().free_[device_].push_back(c_);
 }
+
+struct ImageCache::Impl {
+    std::mutex mu;
+    int w = 0, h = 0, nlevels = 0, device = -1;
+    float scaleFactor = 0;
+    static const int kSlots = 96;
+    struct Key {
+        int kind; unsigned long id; const unsigned char *data;
+        bool operator<(const Key &o) const { return kind != o.kind ? kind < o.kind : id != o.id ? id < o.id : data < o.data; }
+    };
+    std::map<Key, int> slotOf;
+    std::vector<Key> keyOf;
+    std::vector<char> used;
+    std::vector<unsigned long> lastUse;
+    unsigned long tick = 0;
+};
+
+ImageCache &ImageCache::instance() {
+    static ImageCache *c = [] { ImageCache *p = new ImageCache(); p->impl_ = new Impl(); return p; }();   // never destroyed (HIP may be gone at exit)
+    return *c;
+}
+
+ImageCache::Guard::Guard(ImageCache &cache) : c(cache) { c.impl_->mu.lock(); }
+ImageCache::Guard::~Guard() { c.impl_->mu.unlock(); }
+
+bool ImageCache::prepare(int device, int w, int h, int nlevels, float scale_factor, const char *who) {
+    Impl &I = *impl_;
+    if (ctx_ && device == I.device && w == I.w && h == I.h && nlevels == I.nlevels && scale_factor == I.scaleFactor) return true;
+    if (ctx_) ygzf_destroy(ctx_);
+    ctx_ = nullptr;
+    ygzf_extractor_cfg cfg = {1000, scale_factor, nlevels, 20, 7, 0};   // the pyramid geometry is all that matters here
+    if (ygzf_create(device, &cfg, w, h, 1, &ctx_) != YGZF_OK) {
+        fprintf(stderr, "%s: %s\n", who, ygzf_last_error(nullptr));
+        ctx_ = nullptr;
+        return false;
+    }
+    if (ygzf_image_cache_reserve(ctx_, Impl::kSlots, w, h) != YGZF_OK) {
+        fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx_));
+        ygzf_destroy(ctx_);
+        ctx_ = nullptr;
+        return false;
+    }
+    I.device = device; I.w = w; I.h = h; I.nlevels = nlevels; I.scaleFactor = scale_factor;
+    I.slotOf.clear();
+    I.keyOf.assign(Impl::kSlots, Impl::Key{0, 0, nullptr});
+    I.used.assign(Impl::kSlots, 0);
+    I.lastUse.assign(Impl::kSlots, 0);
+    return true;
+}
+
+int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who) {
+    Impl &I = *impl_;
+    if (!ctx_ || cols != I.w || rows != I.h) return -1;
+    const Impl::Key key{(int) kind, id, data};
+    auto it = I.slotOf.find(key);
+    if (it != I.slotOf.end()) { I.lastUse[it->second] = ++I.tick; return it->second; }
+    int victim = 0;
+    for (int s = 1; s < Impl::kSlots; s++)
+        if (I.lastUse[s] < I.lastUse[victim]) victim = s;
+    if (I.used[victim]) I.slotOf.erase(I.keyOf[victim]);
+    I.used[victim] = 0;
+    if (ygzf_image_cache_put(ctx_, victim, data, cols, rows, step) != YGZF_OK) {
+        fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx_));
+        return -1;
+    }
+    I.used[victim] = 1;
+    I.keyOf[victim] = key;
+    I.slotOf[key] = victim;
+    I.lastUse[victim] = ++I.tick;
+    return victim;
+}
 }  // namespace ygzf_host

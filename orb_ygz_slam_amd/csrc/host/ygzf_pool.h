@@ -22,5 +22,33 @@ private:
     ygzf_ctx *c_;
     int device_;
 };
+
+// Device-resident level-0 images + pyramids of recent Frames and KeyFrames, shared by the shells that read images (FindDirectProjection,
+// SparseImgAlign::run): an image is uploaded the first time it is referenced and its pyramid rebuilt on the device by the extractor's
+// resize kernel (so it equals the host pyramid the Frame holds); slots are recycled least recently used.  One cache per process, one
+// context of its own; every use holds the mutex for the whole call (the cache's context is single-threaded like any other).
+class ImageCache {
+public:
+    enum Kind { kFrame = 0, kKeyFrame = 1 };
+    static ImageCache &instance();
+    // locks the cache for the caller's scope
+    struct Guard {
+        explicit Guard(ImageCache &c);
+        ~Guard();
+        ImageCache &c;
+    };
+    // (re)creates the context when the geometry changes; false on failure (message on stderr)
+    bool prepare(int device, int w, int h, int nlevels, float scale_factor, const char *who);
+    // slot holding this image (uploads it on a miss); -1 on failure.  The key is (kind, id, level-0 data pointer): a Frame copy shares id and
+    // buffer with its original, two different images never do.
+    int slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who);
+    ygzf_ctx *ctx() const { return ctx_; }
+
+private:
+    ImageCache() = default;
+    struct Impl;
+    Impl *impl_ = nullptr;
+    ygzf_ctx *ctx_ = nullptr;
+};
 }  // namespace ygzf_host
 #endif

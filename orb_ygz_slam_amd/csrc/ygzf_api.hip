@@ -1242,11 +1242,25 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
 }
 
 // ---- SparseImgAlign::run ------------------------------------------------------------------------------------------------
-int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, const ygzf_camera *cam, const float *inv_scale_factors,
-                 int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36) {
+// ygzf_sia_run (pyramids from host memory) and ygzf_sia_run_cached (pyramids of two image-cache slots, already on the device).
+// cached: ref_slot / cur_slot >= 0, cur carries the pose only (its level arrays are not read, ref's neither).
+static FrameSet cache_frameset(const ygzf_ctx *c);
+static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, int ref_slot, int cur_slot, const ygzf_camera *cam,
+                        const float *inv_scale_factors, int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36) {
     if (!c || !ref || !cur || !cam || !inv_scale_factors || !TCR_out || !ret) return fail(c, YGZF_ERR_INVALID, "null argument");
     *ret = 0;
-    if (max_level < min_level || min_level < 0 || max_level >= kMaxLevels || max_level >= ref->nlevels || max_level >= cur->nlevels)
+    const bool cached = ref_slot >= 0;
+    if (cached) {
+        if (c->cacheSlots <= 0) return fail(c, YGZF_ERR_STATE, "image cache not reserved");
+        if (ref_slot >= c->cacheSlots || cur_slot < 0 || cur_slot >= c->cacheSlots || !c->cacheFilled[ref_slot] || !c->cacheFilled[cur_slot])
+            return fail(c, YGZF_ERR_INVALID, "slot %d / %d is empty or outside the cache", ref_slot, cur_slot);
+        if (c->geo.w != c->cacheW || c->geo.h != c->cacheH) {
+            int rc0 = apply_geometry(c, c->cacheW, c->cacheH, 1);
+            if (rc0) return rc0;
+        }
+        if (max_level < min_level || min_level < 0 || max_level >= c->tab.cfg.nlevels)
+            return fail(c, YGZF_ERR_INVALID, "bad level range [%d,%d]", min_level, max_level);
+    } else if (max_level < min_level || min_level < 0 || max_level >= kMaxLevels || max_level >= ref->nlevels || max_level >= cur->nlevels)
         return fail(c, YGZF_ERR_INVALID, "bad level range [%d,%d]", min_level, max_level);
     if (ref->n < 0) return fail(c, YGZF_ERR_INVALID, "negative count");
     // T_cur_from_ref for the empty case is still cur*ref^-1 in the reference only after the early return; :24-27 returns 0 at once
@@ -1254,7 +1268,8 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
         if (info) { info[0] = 0; info[1] = 0; }
         return YGZF_OK;
     }
-    if (!ref->keys || !ref->mp_world || !ref->levels || !cur->levels || !ref->level_w || !ref->level_h || !cur->level_w || !cur->level_h)
+    if (!ref->keys || !ref->mp_world) return fail(c, YGZF_ERR_INVALID, "null array");
+    if (!cached && (!ref->levels || !cur->levels || !ref->level_w || !ref->level_h || !cur->level_w || !cur->level_h))
         return fail(c, YGZF_ERR_INVALID, "null array");
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t N = ref->n;
@@ -1267,25 +1282,45 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     HIPCHECK(c, hipMemcpyAsync(S[1].p, ref->mp_world, N * 12, hipMemcpyHostToDevice, c->stream));
     if (ref->mp_valid) HIPCHECK(c, hipMemcpyAsync(S[2].p, ref->mp_valid, N, hipMemcpyHostToDevice, c->stream));
     if (ref->outlier) HIPCHECK(c, hipMemcpyAsync(S[3].p, ref->outlier, N, hipMemcpyHostToDevice, c->stream));
-    size_t imgBytes = 0;
-    for (int l = min_level; l <= max_level; l++) {
-        if (ref->level_w[l] < 1 || ref->level_h[l] < 1 || cur->level_w[l] < 1 || cur->level_h[l] < 1 || !ref->levels[l] || !cur->levels[l])
-            return fail(c, YGZF_ERR_INVALID, "bad pyramid level %d", l);
-        imgBytes += (size_t) ref->level_w[l] * ref->level_h[l] + (size_t) cur->level_w[l] * cur->level_h[l] + 128;
-    }
-    if ((rc = ensure(c, S[4], imgBytes))) return rc;
     std::vector<SiaLevel> lv(2 * kMaxLevels);
     memset(lv.data(), 0, lv.size() * sizeof(SiaLevel));
-    size_t off = 0;
-    for (int l = min_level; l <= max_level; l++) {
+    size_t largestCur = 0;   // the largest current-frame level that may be staged in LDS beside the feature tables
+    if (cached) {
+        // the slots hold level 0 and the pyramid the resize kernel built from it (what the extractor computed for the same image)
         for (int side = 0; side < 2; side++) {
-            const ygzf_sia_frame *f = side ? cur : ref;
-            const size_t b = (size_t) f->level_w[l] * f->level_h[l];
-            uint8_t *d = (uint8_t *) S[4].p + off;
-            HIPCHECK(c, hipMemcpyAsync(d, f->levels[l], b, hipMemcpyHostToDevice, c->stream));   // Frame clones are tight (step == cols)
-            SiaLevel &L = lv[side * kMaxLevels + l];
-            L.img = d; L.w = f->level_w[l]; L.h = f->level_h[l]; L.pitch = f->level_w[l];
-            off += (b + 63) & ~(size_t) 63;
+            FrameSet fs = cache_frameset(c);
+            const int slot = side ? cur_slot : ref_slot;
+            fs.img0 += (long long) slot * fs.img0_stride;
+            fs.pyr += (long long) slot * fs.pyr_stride;
+            for (int l = min_level; l <= max_level; l++) {
+                const LevelGeom &g = c->geo.lv[l];
+                int pitch;
+                SiaLevel &L = lv[side * kMaxLevels + l];
+                L.img = level_ptr(fs, g, l, 0, &pitch);
+                L.w = g.w; L.h = g.h; L.pitch = pitch;
+                if (side) largestCur = std::max(largestCur, (size_t) pitch * g.h);
+            }
+        }
+    } else {
+        size_t imgBytes = 0;
+        for (int l = min_level; l <= max_level; l++) {
+            if (ref->level_w[l] < 1 || ref->level_h[l] < 1 || cur->level_w[l] < 1 || cur->level_h[l] < 1 || !ref->levels[l] || !cur->levels[l])
+                return fail(c, YGZF_ERR_INVALID, "bad pyramid level %d", l);
+            imgBytes += (size_t) ref->level_w[l] * ref->level_h[l] + (size_t) cur->level_w[l] * cur->level_h[l] + 128;
+        }
+        if ((rc = ensure(c, S[4], imgBytes))) return rc;
+        size_t off = 0;
+        for (int l = min_level; l <= max_level; l++) {
+            for (int side = 0; side < 2; side++) {
+                const ygzf_sia_frame *f = side ? cur : ref;
+                const size_t b = (size_t) f->level_w[l] * f->level_h[l];
+                uint8_t *d = (uint8_t *) S[4].p + off;
+                HIPCHECK(c, hipMemcpyAsync(d, f->levels[l], b, hipMemcpyHostToDevice, c->stream));   // Frame clones are tight (step == cols)
+                SiaLevel &L = lv[side * kMaxLevels + l];
+                L.img = d; L.w = f->level_w[l]; L.h = f->level_h[l]; L.pitch = f->level_w[l];
+                off += (b + 63) & ~(size_t) 63;
+                if (side) largestCur = std::max(largestCur, b);
+            }
         }
     }
     const size_t tabBytes = 14 * sizeof(float) + lv.size() * sizeof(SiaLevel);
@@ -1329,10 +1364,8 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
         A.jacLds = sia_jac_in_lds((int) N) ? 1 : 0;
         if (sl > 150 * 1024) return fail(c, YGZF_ERR_UNSUPPORTED, "SparseImgAlign supports at most %d features", (int) (150 * 1024 / 24));
         {
-            size_t largest = 0;   // the largest current-frame level that may be staged in LDS beside the feature tables
-            for (int l = min_level; l <= max_level; l++) largest = std::max(largest, (size_t) cur->level_w[l] * cur->level_h[l]);
             A.stageOff = (int) ((sl + 15) & ~(size_t) 15);
-            A.stageBytes = (int) sia_stage_bytes((size_t) A.stageOff, largest);
+            A.stageBytes = (int) sia_stage_bytes((size_t) A.stageOff, largestCur);
             sl = (size_t) A.stageOff + (size_t) A.stageBytes;
         }
         HIPCHECK(c, sia_prepare(sl));
@@ -1354,6 +1387,22 @@ int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *c
     if (info) { info[0] = out[8]; info[1] = out[9]; }
     if (H36) memcpy(H36, out + 12, 36 * sizeof(float));
     return YGZF_OK;
+}
+
+int ygzf_sia_run(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_frame *cur, const ygzf_camera *cam, const float *inv_scale_factors,
+                 int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info, float *H36) {
+    return sia_run_impl(c, ref, cur, -1, -1, cam, inv_scale_factors, max_level, min_level, n_iter, TCR_out, ret, info, H36);
+}
+
+int ygzf_sia_run_cached(ygzf_ctx *c, int ref_slot, int cur_slot, const ygzf_sia_frame *ref, const float *cur_Tcw7, const ygzf_camera *cam,
+                        const float *inv_scale_factors, int max_level, int min_level, int n_iter, float *TCR_out, size_t *ret, float *info,
+                        float *H36) {
+    if (!cur_Tcw7) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (ref_slot < 0) return fail(c, YGZF_ERR_INVALID, "slot %d", ref_slot);
+    ygzf_sia_frame cur;
+    memset(&cur, 0, sizeof cur);
+    memcpy(cur.Tcw, cur_Tcw7, 28);
+    return sia_run_impl(c, ref, &cur, ref_slot, cur_slot, cam, inv_scale_factors, max_level, min_level, n_iter, TCR_out, ret, info, H36);
 }
 
 // ---- Thirdparty/fast replacement ------------------------------------------------------------------------------------------

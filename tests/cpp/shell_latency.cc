@@ -59,6 +59,8 @@ int main(int argc, char **argv) {
     timeit("extract_image", iters, [&] { ex(imA, cv::Mat(), keys, cv::_OutputArray(desc)); });
 
     Frame A, B;
+    A.mnId = 1;
+    B.mnId = 2;
     Frame *fr[2] = {&A, &B};
     cv::Mat *im[2] = {&imA, &imB};
     for (int k = 0; k < 2; k++) {
@@ -110,7 +112,8 @@ int main(int argc, char **argv) {
     SparseImgAlign align(L - 1, 1);
     SE3f TCR;
     size_t ret = 0;
-    timeit("sparse_img_align_run", iters, [&] { TCR = SE3f(); ret = align.run(&A, &B, TCR); });
+    // every call sees a NEW current frame (fresh id: one level-0 upload + device pyramid) and the previous call's frame as reference
+    timeit("sparse_img_align_run", iters, [&] { TCR = SE3f(); B.mnId += 2; ret = align.run(&A, &B, TCR); });
     B.mTcw = TCR;
     ORBmatcher matcher(0.9f, true);
     int nm = 0;

@@ -55,6 +55,8 @@ int main(int argc, char **argv) {
         dump(dir + "/tables.bin", t.data(), t.size() * sizeof(float));
     }
     Frame A, B;
+    A.mnId = 1;                          // Frame::nNextId++ in the reference's constructors: ids are unique per image
+    B.mnId = 2;
     Frame *fr[2] = {&A, &B};
     std::vector<unsigned char> *im[2] = {&ia, &ib};
     for (int k = 0; k < 2; k++) {

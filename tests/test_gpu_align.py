@@ -128,3 +128,34 @@ def test_sia_large_feature_counts(oracle, nfeat):
     assert g_ret == o_ret and g_ret > nfeat // 2, (g_ret, o_ret)
     assert float(np.abs(g_T - o_T).max()) <= TOL, (g_T, o_T, g_info, o_info)
     assert np.abs(g_T[4:] - t).max() < 5e-3
+
+
+def test_sia_run_on_cached_slots_equals_the_host_pyramid_form(oracle):
+    """ygzf_sia_run_cached reads the pyramids of two image-cache slots (level 0 uploaded once, levels rebuilt on the device by the resize
+    kernel) instead of two host pyramids: same bytes, so the same TCR bit for bit -- and the oracle's within 1e-5."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    imgA, imgB, (R, t), backproject = two_view_scene(14, w, h, EUROC, rotvec=(0.003, 0.005, -0.002), trans=(-0.02, 0.01, 0.02))
+    ex = Extractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    oex = oracle.Extractor(800, 1.2, 8, 20, 7)
+    cam = make_camera(w, h)
+    k, _ = ex.extract(imgA)
+    world = backproject(k["x"], k["y"])
+    pyrA, pyrB = ex.compute_pyramid(imgA), ex.compute_pyramid(imgB)
+    inv = oex.tables()["inv_scale"]
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    h_ret, h_T, h_info, h_H = ex.sia_run(cam, k, world, ident, pyrA, ident, pyrB, inv, 7, 1)
+    ex.image_cache_reserve(3, w, h)
+    ex.image_cache_put(2, imgA)
+    ex.image_cache_put(0, imgB)
+    c_ret, c_T, c_info, c_H = ex.sia_run_cached(cam, 2, 0, k, world, ident, ident, inv, 7, 1)
+    assert c_ret == h_ret and np.array_equal(c_T, h_T) and np.array_equal(c_info, h_info) and np.array_equal(c_H, h_H)
+    o_ret, o_T, _, _ = oracle.sparse_img_align(k, world, ident, pyrA, ident, pyrB, inv, EUROC, 7, 1)
+    assert c_ret == o_ret and float(np.abs(c_T - o_T).max()) <= TOL
+    # level 0 in the range (the slot's own image), and an empty slot is refused
+    c0 = ex.sia_run_cached(cam, 2, 0, k, world, ident, ident, inv, 2, 0)
+    h0 = ex.sia_run(cam, k, world, ident, pyrA, ident, pyrB, inv, 2, 0)
+    assert c0[0] == h0[0] and np.array_equal(c0[1], h0[1])
+    from orb_ygz_slam_amd import YgzfError
+    with pytest.raises(YgzfError):
+        ex.sia_run_cached(cam, 1, 0, k, world, ident, ident, inv, 7, 1)
