@@ -71,6 +71,11 @@ const char *ygzf_last_error(const ygzf_ctx *ctx);
  * entries, any may be NULL. */
 int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat);
 
+/* ORBextractor::operator() on the image whose pyramid the context's previous call, ygzf_compute_pyramid, left on the device: FAST, octree,
+ * orientation and descriptors without a second upload and a second pyramid (Frame's constructors call ComputePyramid and then the
+ * extractor on the same image: src/Frame.cc:807-813, :332-348).  YGZF_ERR_STATE when any other image operation came in between. */
+int ygzf_extract_resident(ygzf_ctx *ctx, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
+
 /* Free / total memory of the context's device after draining the context's stream (diagnostics: leak checks, sizing of resident batches). */
 int ygzf_device_mem_info(ygzf_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 

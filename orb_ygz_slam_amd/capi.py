@@ -120,6 +120,7 @@ def load_library(build_if_missing=True):
     L.ygzf_search_local_points.argtypes = [vp, C.POINTER(FrameView), C.POINTER(Camera), C.c_int, C.POINTER(FrustumIn), vp, vp, C.c_float, C.c_int,
                                            C.c_float, vp, vp, ip, vp, vp, vp, vp, vp, vp]
     L.ygzf_distinctive_descriptors_batch.argtypes = [vp, C.c_int, vp, vp, vp]
+    L.ygzf_extract_resident.argtypes = [vp, vp, vp, C.c_int, vp]
     L.ygzf_device_mem_info.argtypes = [vp, vp, vp]
     L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
@@ -214,6 +215,15 @@ class Extractor:
         d = np.zeros((max(cap, 1), 32), np.uint8)
         n = C.c_int()
         self._ck(self.L.ygzf_extract(self.h, img.ctypes.data_as(C.c_void_p), w, h, int(img.strides[0]), _p(k), _p(d), cap, C.byref(n)))
+        return k[:n.value].copy(), d[:n.value].copy()
+
+    def extract_resident(self, w, h):
+        """Keypoints + descriptors of the image whose pyramid the previous compute_pyramid left on the device (no second upload)."""
+        cap = self.max_keypoints(w, h)
+        k = np.zeros(max(cap, 1), KP_DTYPE)
+        d = np.zeros((max(cap, 1), 32), np.uint8)
+        n = C.c_int()
+        self._ck(self.L.ygzf_extract_resident(self.h, _p(k), _p(d), cap, C.byref(n)))
         return k[:n.value].copy(), d[:n.value].copy()
 
     def extract_batch_host(self, imgs):

@@ -72,8 +72,12 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
         mvImagePyramid[l] = cv::Mat(lh, lw, CV_8UC1);   // fresh buffer: Frames keep (shared) references to earlier levels
         out[l] = mvImagePyramid[l].data;
     }
-    if (ygzf_compute_pyramid(c, image.data, image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK)
+    mResidentLevel0 = cv::Mat();
+    if (ygzf_compute_pyramid(c, image.data, image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK) {
         fprintf(stderr, "ygz::ORBextractor::ComputePyramid: %s\n", ygzf_last_error(c));
+        return;
+    }
+    mResidentLevel0 = mvImagePyramid[0];   // the context still holds this image and its pyramid (see operator()(Frame*, ...))
 }
 
 void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors) {
@@ -86,6 +90,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     _keypoints.resize(cap > 0 ? cap : 0);
     std::vector<uint8_t> desc((size_t) (cap > 0 ? cap : 0) * 32);
     int n = 0;
+    mResidentLevel0 = cv::Mat();
     if (ygzf_extract(c, image.data, image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
         YGZF_OK) {
         fprintf(stderr, "ygz::ORBextractor::operator(): %s\n", ygzf_last_error(c));
@@ -117,6 +122,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
     const cv::Mat &img = leftEye ? (frame->mvImagePyramid.empty() ? frame->mImGray : frame->mvImagePyramid[0]) : frame->mImRight;
     if (!leftEye) ComputePyramid(img);          // right eye: the extractor's own pyramid is read by ComputeStereoMatches
     else mvImagePyramid = frame->mvImagePyramid;
+    const cv::Mat resident_ = mResidentLevel0;   // (ComputePyramid above, or the Frame constructor's call, left it)
     const int N = leftEye ? frame->N : 0;       // existing keys of the frame (:1090-1092)
     if (img.empty()) return;
     ygzf_ctx *c = ensureContext(img.cols, img.rows);
@@ -145,7 +151,20 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         fresh.resize(cap > 0 ? cap : 0);
         descNew.resize((size_t) (cap > 0 ? cap : 0) * 32);
         int n = 0;
-        if (ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n) != YGZF_OK) {
+        // Frame's constructors call ComputePyramid(image) and then this overload on a clone of the very pyramid it produced
+        // (src/Frame.cc:807-813, :332-348): when the frame's level 0 still equals the image whose pyramid the context holds (one
+        // 360 KB comparison), FAST / octree / descriptors run on the resident pyramid -- no second upload, no second pyramid.
+        bool resident = false;
+        if (!resident_.empty() && resident_.cols == img.cols && resident_.rows == img.rows) {
+            resident = true;
+            for (int y = 0; y < img.rows && resident; y++) resident = std::memcmp(img.ptr(y), resident_.ptr(y), (size_t) img.cols) == 0;
+        }
+        int rcE = YGZF_ERR_STATE;
+        if (resident) rcE = ygzf_extract_resident(c, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
+        if (rcE == YGZF_ERR_STATE)   // nothing resident (another image operation came in between): the image goes up again
+            rcE = ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
+        mResidentLevel0 = cv::Mat();   // the extraction reuses the buffers: nothing is resident afterwards
+        if (rcE != YGZF_OK) {
             fprintf(stderr, "ygz::ORBextractor (ORBSLAM_KEYPOINT): %s\n", ygzf_last_error(c));
             return;
         }

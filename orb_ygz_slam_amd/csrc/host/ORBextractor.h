@@ -94,6 +94,7 @@ protected:
 private:
     ygzf_ctx *ensureContext(int w, int h);
     ygzf_ctx *mCtx = nullptr;
+    cv::Mat mResidentLevel0;     // level 0 of the pyramid the context still holds on the device (set by ComputePyramid), or empty
     int mCtxW = 0, mCtxH = 0;
     int mDevice = 0, mCvMode = 0;
 };

@@ -126,6 +126,8 @@ struct ygzf_ctx {
     Buf dFastStats;
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
+    bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
+    int pyrResW = 0, pyrResH = 0;
     uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
     size_t hStageBytes = 0;
     // batch state
@@ -336,6 +338,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         // c->geo is committed only after every fallible step below has succeeded: a failed attempt leaves (w, h) unset, so that a retry
         // runs the whole setup again instead of continuing on partial device tables
         c->geo.w = c->geo.h = 0;
+        c->pyrResident = false;
         c->carryValid = false;
         c->lastFrames = 0;
         HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -442,8 +445,9 @@ static void drain_profile(ygzf_ctx *c) {
 }
 
 // The launch sequence of ORBextractor::operator()(image...) for a batch resident on the device.
-static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
+static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady = false) {
     const Geometry &G = c->geo;
+    c->pyrResident = false;
     const int L = c->tab.cfg.nlevels;
     const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
     // slot 0 of the output arrays carries the last frame of the previous batch (Last frame of pair 0 in ygzf_match_batch_prev)
@@ -469,7 +473,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
             HIPCHECK(c, hipMemcpyAsync(c->dCarryPyr.p, (uint8_t *) c->dPyr.p + (size_t) (c->lastFrames - 1) * G.pyrBytes, (size_t) G.pyrBytes,
                                        hipMemcpyDeviceToDevice, c->stream));
     }
-    for (int l = 1; l < L; l++) {
+    for (int l = 1; l < L && !pyramidReady; l++) {
         ProfScope ps(c, KK_PYR);
         launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
                           (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
@@ -573,6 +577,7 @@ static int upload_rows(ygzf_ctx *c, void *dst, size_t dstPitch, const uint8_t *s
 
 static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, int row_pitch, size_t frame_stride,
                          FrameSet *fs) {
+    c->pyrResident = false;
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
@@ -795,6 +800,9 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     for (int l = 0; l < L; l++) memcpy(levels_out[l], c->hStage + offs[l], offs[l + 1] - offs[l]);
     c->lastFrames = 0;
+    c->pyrResident = true;
+    c->pyrResW = w;
+    c->pyrResH = h;
     return YGZF_OK;
 }
 
@@ -872,6 +880,24 @@ int ygzf_extract(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, ygzf
     if (!img || w <= 0 || h <= 0) return YGZF_OK;  // reference: `if (_image.empty()) return;`
     int rc = ygzf_extract_batch_host(c, img, 1, w, h, stride, 0);
     if (rc) return rc;
+    return ygzf_batch_fetch(c, 0, kps, desc, cap, n_out);
+}
+
+int ygzf_extract_resident(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
+    if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *n_out = 0;
+    if (!c->pyrResident) return fail(c, YGZF_ERR_STATE, "no resident pyramid (ygzf_compute_pyramid must be the context's previous image operation)");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const int w = c->pyrResW, h = c->pyrResH;
+    int rc = apply_geometry(c, w, h, 1);   // same geometry as the compute_pyramid call: no reallocation
+    if (rc) return rc;
+    FrameSet fs;
+    fs.img0 = (const uint8_t *) c->dImg0.p;
+    fs.img0_pitch = align_up(w, 64);
+    fs.img0_stride = (long long) fs.img0_pitch * h;
+    fs.pyr = (uint8_t *) c->dPyr.p;
+    fs.pyr_stride = c->geo.pyrBytes;
+    if ((rc = run_extract(c, fs, 1, true))) return rc;
     return ygzf_batch_fetch(c, 0, kps, desc, cap, n_out);
 }
 

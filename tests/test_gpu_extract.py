@@ -214,3 +214,28 @@ def test_two_host_threads_two_contexts(oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def test_extract_on_the_resident_pyramid(oracle):
+    """ygzf_extract_resident: the extractor on the image whose pyramid the previous ygzf_compute_pyramid left on the device (what Frame's
+    constructors do: ComputePyramid, then the extractor on the same image) == ygzf_extract of that image; refused once another image
+    operation has used the buffers."""
+    from orb_ygz_slam_amd import Extractor, YgzfError
+    for (w, h) in ((752, 480), (641, 479)):
+        ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+        a, b = synth_frame(70, w, h), synth_frame(71, w, h)
+        ka, da = ex.extract(a)
+        pyr = ex.compute_pyramid(a)
+        kr, dr = ex.extract_resident(w, h)
+        assert np.array_equal(kr, ka) and np.array_equal(dr, da)
+        assert all(np.array_equal(p, q) for p, q in zip(pyr, oracle.Extractor(1000, 1.2, 8, 20, 7).pyramid(a)))
+        with pytest.raises(YgzfError):
+            ex.extract_resident(w, h)              # the extraction itself consumed the resident state
+        ex.compute_pyramid(b)
+        ex.extract(a)                              # another image came in between
+        with pytest.raises(YgzfError):
+            ex.extract_resident(w, h)
+        ex.compute_pyramid(b)
+        kb, db = ex.extract_resident(w, h)
+        kb2, db2 = ex.extract(b)
+        assert np.array_equal(kb, kb2) and np.array_equal(db, db2)
