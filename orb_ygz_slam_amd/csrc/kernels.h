@@ -70,13 +70,14 @@ struct MatchArgs {
     // LDS plan
     int capCur, capLast, descInLds, qpInLds;
     int spill;                     // kSpill* bits: array groups that live in spillScratch instead of LDS
+    int specDeep;                  // speculative lists of eight entries instead of four (mode 1)
     void *spillScratch;
     long long spillStride;         // bytes per pair
     void *qpScratch;               // capLast * 32 bytes per pair when !qpInLds
     long long *dbg;                // nullable: 8 wall_clock64 stamps per pair (phase timing, debug)
 };
 constexpr int kSpillSpec = 1, kSpillMisc = 2;
-size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes);
+size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes, bool specDeep);
 hipError_t match_prepare(size_t ldsBytes);
 void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt, long long kpStride, int maxKp, int nFrames, float fx,
                              float fy, float cx, float cy, float *world);

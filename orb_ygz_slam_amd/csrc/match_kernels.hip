@@ -56,6 +56,8 @@ struct MatchLds {
     float *cx, *cy, *cang;      // Cur keypoint x, y, angle
     uint4 *specKey;             // per query: the 4 best acceptable candidates against the INITIAL ownership,
     ushort4 *specI2;            //   keys (dist << 16 | visiting order) ascending; key >= kNoKey: none
+    uint4 *specKeyB;            // entries 5..8 of the same list when A.specDeep (SearchByProjection(F, MapPoints) needs best AND
+    ushort4 *specI2B;           //   runner-up among the still-free candidates: four entries run out on 15 % of the queries)
     float *qang;                // Last keypoint angle
     unsigned char *qobs;        // MapPoint has observations
     unsigned char *owner, *octave;
@@ -214,6 +216,12 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     CARVE(L.qobs, unsigned char, A.capLast, 0);
     CARVE(L.specKey, uint4, A.capLast, kSpillSpec);
     CARVE(L.specI2, ushort4, A.capLast, kSpillSpec);
+    L.specKeyB = nullptr;
+    L.specI2B = nullptr;
+    if (A.specDeep) {
+        CARVE(L.specKeyB, uint4, A.capLast, kSpillSpec);
+        CARVE(L.specI2B, ushort4, A.capLast, kSpillSpec);
+    }
     CARVE(L.events, int, A.capLast, kSpillMisc);
     CARVE(L.qang, float, A.capLast, kSpillMisc);
     CARVE(L.cang, float, A.capCur, kSpillMisc);
@@ -394,6 +402,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         // been taken does it fall back to a full cooperative rescan.
         unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu;
         unsigned short j0 = 0, j1 = 0, j2 = 0, j3 = 0;
+        unsigned k4 = 0xFFFFFFFFu, k5 = 0xFFFFFFFFu, k6 = 0xFFFFFFFFu, k7 = 0xFFFFFFFFu;   // entries 5..8 (A.specDeep)
+        unsigned short j4 = 0, j5 = 0, j6 = 0, j7 = 0;
         if (q.valid) {
             const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
             const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
@@ -427,7 +437,16 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     if ((A.mode == 0 || A.mode == 2) && dist > (unsigned) A.maxDist) continue;   // modes 1, 3 need the runner-up even when it is far
                     const unsigned key = (dist << 16) | (ord & 0xFFFFu);
                     const unsigned short jj = (unsigned short) i2;
-                    if (key < k3) {   // insert into the sorted quadruple
+                    if (A.specDeep) {   // sorted list of eight: one compare-exchange sweep (branch-free)
+                        if (key < k7) {
+                            unsigned ck = key;
+                            unsigned short cj = jj;
+#define YGZF_CEX(K, J) do { if (ck < K) { const unsigned tk = K; const unsigned short tj = J; K = ck; J = cj; ck = tk; cj = tj; } } while (0)
+                            YGZF_CEX(k0, j0); YGZF_CEX(k1, j1); YGZF_CEX(k2, j2); YGZF_CEX(k3, j3);
+                            YGZF_CEX(k4, j4); YGZF_CEX(k5, j5); YGZF_CEX(k6, j6); YGZF_CEX(k7, j7);
+#undef YGZF_CEX
+                        }
+                    } else if (key < k3) {   // insert into the sorted quadruple
                         if (key < k2) {
                             k3 = k2; j3 = j2;
                             if (key < k1) {
@@ -442,6 +461,10 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         }
         L.specKey[i] = make_uint4(k0, k1, k2, k3);
         L.specI2[i] = make_ushort4(j0, j1, j2, j3);
+        if (A.specDeep) {
+            L.specKeyB[i] = make_uint4(k4, k5, k6, k7);
+            L.specI2B[i] = make_ushort4(j4, j5, j6, j7);
+        }
     }
     __syncthreads();
     STAMP(2);
@@ -554,19 +577,23 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         for (int tile = 0; tile < nq; tile += 64) {
             const int i = tile + lane;
             const bool active = i < nq;
-            uint4 keys = make_uint4(kNoKey, kNoKey, kNoKey, kNoKey);
-            ushort4 idx = make_ushort4(0, 0, 0, 0);
+            uint4 keys = make_uint4(kNoKey, kNoKey, kNoKey, kNoKey), keysB = keys;
+            ushort4 idx = make_ushort4(0, 0, 0, 0), idxB = idx;
             bool obs = false;
-            if (active) { keys = L.specKey[i]; idx = L.specI2[i]; obs = L.qobs[i] != 0; }
+            if (active) {
+                keys = L.specKey[i]; idx = L.specI2[i]; obs = L.qobs[i] != 0;
+                if (A.specDeep) { keysB = L.specKeyB[i]; idxB = L.specI2B[i]; }
+            }
+            const int depth = A.specDeep ? 8 : 4;
             bool pending = active && keys.x < kNoKey;
             while (__ballot(pending)) {
-                const unsigned kk[4] = {keys.x, keys.y, keys.z, keys.w};
-                const int ii[4] = {idx.x, idx.y, idx.z, idx.w};
+                const unsigned kk[8] = {keys.x, keys.y, keys.z, keys.w, keysB.x, keysB.y, keysB.z, keysB.w};
+                const int ii[8] = {idx.x, idx.y, idx.z, idx.w, idxB.x, idxB.y, idxB.z, idxB.w};
                 unsigned k1 = kNoKey, k2 = kNoKey;
                 int b1 = -1, b2 = -1;
-                bool exhausted = pending;     // walked all 4 entries and every one was a real candidate
+                bool exhausted = pending;     // walked all entries and every one was a real candidate
                 if (pending) {
-                    for (int e = 0; e < 4; e++) {
+                    for (int e = 0; e < depth; e++) {
                         if (kk[e] >= kNoKey) { exhausted = false; break; }
                         if (vowner[ii[e]] == 2) continue;
                         if (b1 < 0) { b1 = ii[e]; k1 = kk[e]; }
@@ -1146,11 +1173,11 @@ hipError_t launch_features_in_area(hipStream_t st, const FiaArgs &A) {
 }
 
 // LDS bytes / per-pair global spill bytes of the carve-up in k_match_last for a given plan
-size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes) {
+size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes, bool specDeep) {
     size_t lds = al16(sizeof(int) * (GRID_CELLS + 1)) + al16(sizeof(int) * GRID_CELLS) + al16(sizeof(int) * (size_t) capCur) +
                  2 * al16(sizeof(float) * (size_t) capCur) + 2 * al16((size_t) capCur) + al16((size_t) capLast);
     size_t gl = 0;
-    const size_t spec = al16(sizeof(uint4) * (size_t) capLast) + al16(sizeof(ushort4) * (size_t) capLast);
+    const size_t spec = (specDeep ? 2 : 1) * (al16(sizeof(uint4) * (size_t) capLast) + al16(sizeof(ushort4) * (size_t) capLast));
     const size_t misc = al16(sizeof(int) * (size_t) capLast) + al16(sizeof(float) * (size_t) capLast) + al16(sizeof(float) * (size_t) capCur) +
                         2 * al16(sizeof(int) * (size_t) capCur);
     if (spill & kSpillSpec) gl += spec; else lds += spec;

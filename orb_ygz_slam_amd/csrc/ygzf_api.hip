@@ -1057,7 +1057,7 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
     size_t b = 0, sp = 0;
     bool ok = false;
     for (const auto &pl : plans) {
-        b = match_lds_bytes(A.capCur, A.capLast, pl.desc != 0, pl.spill, &sp);
+        b = match_lds_bytes(A.capCur, A.capLast, pl.desc != 0, pl.spill, &sp, A.specDeep != 0);
         if (b <= budget) { A.descInLds = pl.desc; A.spill = pl.spill; ok = true; break; }
     }
     if (!ok) return fail(c, YGZF_ERR_UNSUPPORTED, "matcher needs %zu bytes of LDS for %d/%d keypoints", b, A.capCur, A.capLast);
@@ -1770,6 +1770,7 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     memset(&A, 0, sizeof A);
     A.maxDist = 100;   // TH_HIGH
     A.mode = mode;
+    A.specDeep = mode == 1 ? 1 : 0;   // best AND runner-up among the free candidates: lists of eight (match_kernels.hip)
     A.maxDist = max_dist;
     A.curKeys = (const ygzf_kp *) G[0].p;
     A.curDesc = (const uint8_t *) G[1].p;
