@@ -88,6 +88,13 @@ int ygzf_device_mem_info(ygzf_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
 enum ygzf_fast_plan { YGZF_FAST_PLAN_AUTO = 0, YGZF_FAST_PLAN_ONE_PASS = 1, YGZF_FAST_PLAN_INI_FIRST = 2 };
 int ygzf_set_fast_plan(ygzf_ctx *ctx, int plan);
 int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
+/* Which form of the same cell loop runs (identical results; tests run both against the oracle):
+ *   YGZF_FAST_KERNEL_AUTO      (default) persistent waves for batches that give every resident wave several cells, a wave per cell otherwise
+ *   YGZF_FAST_KERNEL_PER_CELL  k_fast_quads: one wave per 30-px cell, window staged through registers
+ *   YGZF_FAST_KERNEL_STREAM    k_fast_stream: persistent waves draw cells from per-XCD counters, the next cell's window arrives by LDS-DMA
+ *                              while the current one is tested (falls back to PER_CELL for cells wider than 38 px or unaligned input pitches) */
+enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_PER_CELL = 1, YGZF_FAST_KERNEL_STREAM = 2 };
+int ygzf_set_fast_kernel(ygzf_ctx *ctx, int kernel);
 
 /* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:84-106); arrays of nlevels floats, any may be NULL. */

@@ -124,6 +124,7 @@ def load_library(build_if_missing=True):
     L.ygzf_device_mem_info.argtypes = [vp, vp, vp]
     L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
+    L.ygzf_set_fast_kernel.argtypes = [vp, C.c_int]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
@@ -496,6 +497,10 @@ class Extractor:
     def set_fast_plan(self, plan):
         """0 auto (default), 1 one pass at minTh, 2 iniTh first -- same keypoints, different cost (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_fast_plan(self.h, int(plan)))
+
+    def set_fast_kernel(self, kernel):
+        """0 auto (default), 1 one wave per cell (k_fast_quads), 2 persistent waves + LDS-DMA prefetch (k_fast_stream) -- same results."""
+        self._ck(self.L.ygzf_set_fast_kernel(self.h, int(kernel)))
 
     def fast_plan(self):
         p = C.c_int(0)

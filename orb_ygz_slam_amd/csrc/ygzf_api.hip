@@ -75,7 +75,8 @@ struct Geometry {
     std::vector<short> xalpha, ybeta;
     long long pyrBytes = 0;   // per frame, levels >= 1
     int totalCells = 0, maxCellsPerLevel = 0;
-    int totalGroups = 0, fastSmapRows = 3, fastWinPitch = 16, fastWinRows = 7, fastQuadCap = 4;   // 2x2 cell groups of k_fast_quads   // 2x2 cell groups of k_fast_cells
+    int totalGroups = 0, fastSmapRows = 3, fastWinPitch = 16, fastWinRows = 7, fastQuadCap = 4;   // 2x2 cell groups of k_fast_quads
+    int fastWCellMax = 1, fastStreamQuadCap = 4;   // k_fast_stream: dword-aligned window copies (one more quad per row at most)
     long long totalSlots = 0;
     long long candStride = 0;
     int kpStride = 0, kpCapMax = 0;
@@ -124,6 +125,9 @@ struct ygzf_ctx {
     unsigned fastLaunches = 0;             // statistics are collected on the first launches and on every 8th one after that
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
     Buf dFastStats;
+    Buf dFastWork;                         // k_fast_stream's per-XCD work counters (kFastWorkWords u32, zero between launches)
+    int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per launch, 1 k_fast_quads (a wave per cell), 2 k_fast_stream (persistent waves)
+    int numCUs = 256;
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
     bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
@@ -287,6 +291,8 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
             G.fastWinPitch = std::max(G.fastWinPitch, (g.wCell + 6 + 1 + 3) / 4 * 4);   // per-wave window of k_fast_quads: column 0 unused
             G.fastWinRows = std::max(G.fastWinRows, g.hCell + 6);
             G.fastQuadCap = std::max(G.fastQuadCap, ((g.wCell + 3) / 4 * g.hCell + 3) / 4 * 4);
+            G.fastWCellMax = std::max(G.fastWCellMax, g.wCell);
+            G.fastStreamQuadCap = std::max(G.fastStreamQuadCap, ((g.wCell + 3 + 3) / 4 * g.hCell + 3) / 4 * 4);
             slotBase += (long long) nc * g.slotCap;
             g.candCap = nc * g.slotCap;
             candBase += g.candCap;
@@ -505,10 +511,23 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
             HIPCHECK(c, hipMemsetAsync(c->dFastStats.p, 0, kFastStatWords * sizeof(unsigned), c->stream));
         }
         {
+            // which form of the cell loop: the persistent one (waves pull cells, next window prefetched by LDS-DMA) needs enough cells to give every
+            // resident wave a few of them and cells no wider than its compile-time window pitches; single frames keep one wave per cell
+            int streamPitch = 0;
+            const bool streamOk = fast_stream_supported(G.fastWCellMax, &streamPitch) && (fs.img0_pitch & 3) == 0 && ((uintptr_t) fs.img0 & 3) == 0 &&
+                                  (fs.img0_stride & 3) == 0;
+            const long long cells = (long long) G.totalCells * nFrames;
+            const bool stream = streamOk && (c->fastKernel == 2 || (c->fastKernel == 0 && cells >= (long long) c->numCUs * 24 * 3));
             ProfScope ps(c, KK_FAST);
-            launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
-                              (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
-                              G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
+            if (stream)
+                launch_fast_stream(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast, (unsigned short *) c->dCellCnt.p,
+                                   (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows, nFrames, streamPitch,
+                                   G.fastWinRows, G.fastStreamQuadCap, groupBase, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr,
+                                   (unsigned *) c->dFastWork.p, c->numCUs);
+            else
+                launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
+                                  (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
+                                  G.fastSmapRows, nFrames, G.fastWinPitch, G.fastWinRows, G.fastQuadCap, groupBase, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
         }
         if (collect) HIPCHECK(c, hipMemcpyAsync(c->hFastStats, c->dFastStats.p, kFastStatWords * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         long long *odbg = nullptr;
@@ -641,6 +660,14 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     CK(upload_constants(c->tab.umax));
     CK(hipHostMalloc((void **) &c->hFastStats, kFastStatWords * sizeof(unsigned)));
     memset(c->hFastStats, 0, kFastStatWords * sizeof(unsigned));
+    CK(hipMalloc(&c->dFastWork.p, kFastWorkWords * sizeof(unsigned)));
+    c->dFastWork.bytes = kFastWorkWords * sizeof(unsigned);
+    CK(hipMemsetAsync(c->dFastWork.p, 0, kFastWorkWords * sizeof(unsigned), c->stream));
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->numCUs = cus;
+        if (const char *e = getenv("YGZF_FAST_KERNEL")) c->fastKernel = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
+    }
 #undef CK
     // validate the largest configuration up front (and size the buffers once)
     int rc = apply_geometry(c, max_width, max_height, max_batch);
@@ -682,6 +709,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dCacheImg.p) (void) hipFree(c->dCacheImg.p);
     if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
     if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
+    if (c->dFastWork.p) (void) hipFree(c->dFastWork.p);
     if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
     if (c->hFastStats) (void) hipHostFree(c->hFastStats);
     if (c->hStage) (void) hipHostFree(c->hStage);
@@ -710,6 +738,13 @@ int ygzf_set_fast_plan(ygzf_ctx *c, int plan) {
     if (!c) return YGZF_ERR_INVALID;
     if (plan < YGZF_FAST_PLAN_AUTO || plan > YGZF_FAST_PLAN_INI_FIRST) return fail(c, YGZF_ERR_INVALID, "FAST plan %d (0 auto, 1 one pass, 2 iniTh first)", plan);
     c->fastPlan = plan;
+    return YGZF_OK;
+}
+
+int ygzf_set_fast_kernel(ygzf_ctx *c, int kernel) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (kernel < YGZF_FAST_KERNEL_AUTO || kernel > YGZF_FAST_KERNEL_STREAM) return fail(c, YGZF_ERR_INVALID, "FAST kernel %d (0 auto, 1 wave per cell, 2 persistent)", kernel);
+    c->fastKernel = kernel;
     return YGZF_OK;
 }
 
