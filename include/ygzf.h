@@ -89,11 +89,11 @@ enum ygzf_fast_plan { YGZF_FAST_PLAN_AUTO = 0, YGZF_FAST_PLAN_ONE_PASS = 1, YGZF
 int ygzf_set_fast_plan(ygzf_ctx *ctx, int plan);
 int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
 /* Which form of the same cell loop runs (identical results; tests run both against the oracle):
- *   YGZF_FAST_KERNEL_AUTO      (default) persistent waves for batches that give every resident wave several cells, a wave per cell otherwise
- *   YGZF_FAST_KERNEL_PER_CELL  k_fast_quads: one wave per 30-px cell, window staged through registers
- *   YGZF_FAST_KERNEL_STREAM    k_fast_stream: persistent waves draw cells from per-XCD counters, the next cell's window arrives by LDS-DMA
- *                              while the current one is tested (falls back to PER_CELL for cells wider than 38 px or unaligned input pitches) */
-enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_PER_CELL = 1, YGZF_FAST_KERNEL_STREAM = 2 };
+ *   YGZF_FAST_KERNEL_AUTO              (default) the cell-table form wherever it applies (cells up to 41 px wide, i.e. every usual configuration)
+ *   YGZF_FAST_KERNEL_REGISTER_STAGING  k_fast_quads: every wave derives its cell from the level geometry and stages the window through registers
+ *   YGZF_FAST_KERNEL_CELL_TABLE        k_fast_tab: per-cell records precomputed with the geometry, window staged by LDS-DMA (falls back to
+ *                                      REGISTER_STAGING for wider cells) */
+enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_REGISTER_STAGING = 1, YGZF_FAST_KERNEL_CELL_TABLE = 2 };
 int ygzf_set_fast_kernel(ygzf_ctx *ctx, int kernel);
 
 /* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /

@@ -499,7 +499,7 @@ class Extractor:
         self._ck(self.L.ygzf_set_fast_plan(self.h, int(plan)))
 
     def set_fast_kernel(self, kernel):
-        """0 auto (default), 1 one wave per cell (k_fast_quads), 2 persistent waves + LDS-DMA prefetch (k_fast_stream) -- same results."""
+        """0 auto (default), 1 register staging (k_fast_quads), 2 cell table + LDS-DMA staging (k_fast_tab) -- same results (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_fast_kernel(self.h, int(kernel)))
 
     def fast_plan(self):

@@ -10,8 +10,6 @@
 // Built with -ffp-contract=off: the few float expressions (fastAtan2, the rBRIEF rotation) must round exactly like
 // the reference's scalar C++ (no FMA), see DESIGN.md "float details inside bit-exact descriptors".
 #include <cstdlib>
-#include <map>
-#include <mutex>
 
 #include "kernels.h"
 #include "wave_ops.h"
@@ -514,12 +512,10 @@ __device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh, int kSP) 
 // (<= 64 corners in the cell) keeps everything after the expansion in registers.  kP = compile-time window pitch (0: run-time).
 // one cell = one wave's unit of work; returns when the cell is done (all paths), so that a wave can take several cells in a row
 // Everything after the window is staged: pass 1 (quads), expansion, score, NMS, output -- see fast_cell.  The window holds image pixel
-// (cell-tested pixel x, row y) at byte (y + 3) * P + x + 4 + sft: sft = 0 when the staging shifted the bytes into place (fast_cell),
-// sft = 0..3 when the window is a dword-aligned copy of global memory (k_fast_stream's LDS-DMA staging): quad q of a row then covers
-// the tested pixels 4q - sft .. 4q + 3 - sft and the first / last quad of a row are masked to the cell.
+// (cell-tested pixel x, row y) at byte (y + 3) * P + x + 4.
 template <int kP, bool kIniFirst>
 __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, unsigned short *clist, const int P, const int dw, const int dh,
-                                                  const int sft, const int iniTh, const int minTh, unsigned short *cnt_out,
+                                                  const int iniTh, const int minTh, unsigned short *cnt_out,
                                                   unsigned *__restrict__ out, const int grp, const int lane, unsigned *__restrict__ stats) {
     const int kSP = P;   // score-map pitch
     unsigned *qlist = (unsigned *) smap;
@@ -543,9 +539,8 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
         // ---- pass 1: four pixels per lane, quads in raster order; quads that hold a corner are listed as  pol bytes | y << 2 | q << 10 ----
         int nQ = 0;
         {
-            const int nq = (dw + sft + 3) >> 2, nquads = nq * dh;
-            const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw - sft));
-            const unsigned firstMask = 0x03030303u << (8 * sft);   // sft > 0: the first quad of a row starts left of the cell
+            const int nq = (dw + 3) >> 2, nquads = nq * dh;
+            const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
             const unsigned mnq = kRcp16[nq];
             int y = div_small(lane, mnq), q = lane - __mul24(y, nq);
             const int qy = div_small(64, mnq), qx = 64 - qy * nq;
@@ -554,7 +549,6 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
                 if (base + lane < nquads) {
                     pb = fast9_quad((const unsigned *) (win + __mul24(y, P)) + q, P >> 2, th);
                     pb &= (q == nq - 1) ? lastMask : 0x03030303u;
-                    if (sft && q == 0) pb &= firstMask;
                 }
                 const unsigned long long m = __ballot(pb != 0);
                 if (m) {
@@ -586,7 +580,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const unsigned pj = (rec >> (8 * j)) & 3u;
-                if (pj) clist[pos++] = (unsigned short) ((yx + (unsigned) ((j - sft) * 4)) | pj);
+                if (pj) clist[pos++] = (unsigned short) (yx | (j << 2) | pj);
             }
             ncorn += add;
         }
@@ -605,7 +599,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
             uint8_t *sp = &smap[(y + 1) * kSP + x + 1];
             int sc = 0;
             if (have) {
-                sc = fast9_arc_score(&win[__mul24(y + 3, P) + x + 4 + sft], P, e & 3);
+                sc = fast9_arc_score(&win[__mul24(y + 3, P) + x + 4], P, e & 3);
                 sp[0] = (uint8_t) sc;
             }
             wave_lds_sync();
@@ -629,7 +623,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
                 if (qi < ncorn) {
                     const int e = clist[qi];
                     const int y = e >> 8, x = (e >> 2) & 63;
-                    smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&win[(y + 3) * P + x + 4 + sft], P, e & 3);
+                    smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(&win[(y + 3) * P + x + 4], P, e & 3);
                 }
             }
             wave_lds_sync();
@@ -671,7 +665,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
                 int y = div_small(lane, mdw), x = lane - y * dw;
                 for (int base = 0; base < npix; base += 64) {
                     if (base + lane < npix) {
-                        const uint8_t *cp = &win[(y + 3) * P + x + 4 + sft];
+                        const uint8_t *cp = &win[(y + 3) * P + x + 4];
                         const int pol = fast9_test(cp, P, th);
                         if (pol) smap[(y + 1) * kSP + x + 1] = (uint8_t) fast9_arc_score(cp, P, pol);
                     }
@@ -786,7 +780,7 @@ __device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *_
         }
     }
     wave_lds_sync();
-    fast_cell_process<kP, kIniFirst>(win, smap, clist, P, dw, dh, 0, iniTh, minTh, cnt_out,
+    fast_cell_process<kP, kIniFirst>(win, smap, clist, P, dw, dh, iniTh, minTh, cnt_out,
                                      slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap, grp, lane, stats);
 }
 
@@ -820,148 +814,68 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// K2s  The same cell loop as k_fast_quads, PERSISTENT: every wave pulls cells from a per-XCD work counter and keeps two window buffers,
-// so the next cell's window travels global memory -> LDS by LDS-DMA (global_load_lds_dword: no VGPR round trip, no ds_write) while the
-// current cell is tested.  What the one-cell-per-wave form pays per cell -- wave launch, argument / geometry loads, a full memory round
-// trip before the first test instruction -- is paid once per wave or hidden behind the previous cell's arithmetic; cells of unequal cost
-// no longer hold a workgroup's LDS until its slowest wave ends (work is dealt dynamically, a wave never waits for another).
-//   work item t of XCD x  ->  frame t / (4 * groupsPerXcd), cell group x * groupsPerXcd + (t % (4 * groupsPerXcd)) / 4, cell position t % 4
-// (the same XCD-contiguous group runs as k_fast_quads, so neighbouring windows still meet in one L2).
-// LDS-DMA writes lane-linearly (LDS byte = base + 4 * lane): the window is a plain copy of kP / 4 dwords per row starting at the dword
-// that holds image column iniX - 1, and the byte shift the register staging used to apply moves to the quad bookkeeping (sft, see
-// fast_cell_process).  work[0..7] = next item per XCD, work[8..15] = waves of the XCD that ran dry; the last wave to run dry zeroes both
-// for the next launch on the stream.
+// K2t  The same cell loop with the per-cell bookkeeping taken off the instruction stream.  Counters of k_fast_quads showed that a wave
+// spends about as many issue slots outside the corner test as inside it (per cell ~ 1050 vector + 410 scalar + 110 LDS instructions, of
+// which pass 1 is 4 x 165 vector), and that the kernel's time is the sum of those slots over the SIMD's waves -- every instruction of any
+// kind counts, a persistent variant that hid the window latency behind the previous cell (LDS-DMA double buffer, 6 waves per SIMD) was
+// slower.  So:
+//   * the level search, geometry load, group -> cell division and border arithmetic come precomputed: one FastCellRec per (group, wave)
+//     position, built on the host with the geometry, fetched by ONE scalar 32-byte load;
+//   * the window goes global memory -> LDS by LDS-DMA in 16-byte pieces (global_load_lds_dwordx4: lane i of a piece delivers LDS bytes
+//     16 i .. 16 i + 15, so a 48-byte window pitch makes lane i = row i / 3, chunk i % 3 -- two pieces for a 40-row window instead of
+//     twelve loads, six v_alignbyte and six ds_write per lane); gfx950's LDS-DMA takes byte-unaligned global addresses
+//     (tools/micro/glds_probe.hip), so the window still starts at image column iniX - 1 and nothing downstream changes.
+// Cells wider than 41 px (window > 48 bytes) keep k_fast_quads.
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int kTabPitch = 48;
 
-struct FastJob {              // one cell, wave-uniform
-    int kind;                 // 0: no cell at this position (nothing to write), 1: skipped by the reference's border rules (count 0), 2: run
-    int dw, dh, wh, sft, pitch, grp;
-    const uint8_t *src;       // first byte of the window copy
-    unsigned short *cnt_out;
-    unsigned *out;
-};
-
-__device__ __forceinline__ FastJob fast_job(unsigned t, unsigned totalItems, unsigned itemsPerFrame, unsigned itemsMagic, int xcd, int groupsPerXcd,
-                                            int totalGroups, const FrameSet &fs, const LevelGeom *__restrict__ geom, int nlevels,
-                                            unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells, long long totalSlots,
-                                            const FastGroupBases &gb) {
-    FastJob J;
-    J.kind = 0; J.dw = J.dh = J.wh = J.sft = J.pitch = J.grp = 0; J.src = nullptr; J.cnt_out = nullptr; J.out = nullptr;
-    if (t >= totalItems) return J;
-    unsigned f = __umulhi(t, itemsMagic);          // t / itemsPerFrame with itemsMagic = floor(2^32 / itemsPerFrame): short by at most one
-    unsigned rem = t - f * itemsPerFrame;
-    if (rem >= itemsPerFrame) { f++; rem -= itemsPerFrame; }
-    const int grp = xcd * groupsPerXcd + (int) (rem >> 2), wv = (int) (rem & 3u);
-    if (grp >= totalGroups) return J;
-    int l = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxLevels; k++)
-        if (k < nlevels && grp >= gb.v[k]) l = k;
-    const LevelGeom g = geom[l];
-    const int gl = grp - g.groupBase;
-    const int gCols = (g.nCols + 1) >> 1;
-    const int gi = gl / gCols, gj = gl - gi * gCols;
-    const int ci = 2 * gi + (wv >> 1), cj = 2 * gj + (wv & 1);
-    if (ci >= g.nRows || cj >= g.nCols) return J;
-    const int c = ci * g.nCols + cj;
-    J.grp = grp;
-    J.cnt_out = cellCnt + (long long) f * totalCells + g.cellBase + c;
-    const int iniX = kBorder + cj * g.wCell, iniY = kBorder + ci * g.hCell;
-    const int maxX = min(iniX + g.wCell + 6, g.maxBorderX), maxY = min(iniY + g.hCell + 6, g.maxBorderY);
-    const bool skip = (iniX >= g.maxBorderX - 6) || (iniY >= g.maxBorderY - 3);  // :751,:759 (asymmetric on purpose)
-    J.dw = maxX - iniX - 6; J.dh = maxY - iniY - 6;
-    J.kind = 1;
-    if (skip || J.dw <= 0 || J.dh <= 0) return J;
-    J.kind = 2;
-    J.wh = maxY - iniY;
-    int pitch;
-    const uint8_t *img = level_ptr(fs, g, l, (int) f, &pitch);
-    const unsigned g0 = (unsigned) (iniX - 1);
-    J.sft = (int) (g0 & 3u);
-    J.pitch = pitch;
-    J.src = img + (unsigned) iniY * (unsigned) pitch + (g0 & ~3u);
-    J.out = slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap;
-    return J;
-}
-
-// wh rows of kP bytes, lane-linear: item i = row i / (kP / 4), dword i % (kP / 4) lands at LDS byte 4 * i.  Reads at most kP - 1 bytes past
-// column iniX - 1: inside the image row's 16-px border margin or, for windows clipped at the right border, inside the next row -- never past
-// the image (the window's last row is at least 16 rows above the bottom).
-template <int kP>
-__device__ __forceinline__ void fast_window_dma(const FastJob &J, uint8_t *win, int lane) {
-    constexpr int P4 = kP / 4;
-    const int total = J.wh * P4;
-    for (int i0 = 0; i0 < total; i0 += 64) {
-        const int i = i0 + lane;
-        const int r = (int) (((unsigned) i * (unsigned) ((65536 + P4 - 1) / P4)) >> 16), d = i - r * P4;   // i / P4, exact for i < 4096
-        if (i < total)
-            __builtin_amdgcn_global_load_lds((const unsigned *) (J.src + __umul24((unsigned) r, (unsigned) J.pitch)) + d, (lds_void_t *) (win + 4 * i0), 4, 0, 0);
-    }
-}
-
-// lane 0 draws the next work item; the value stays in lane 0's register until fast_item_value() broadcasts it, so that the wait for the
-// atomic's return sits where the item is needed (a whole cell later), not where it was requested
-__device__ __forceinline__ unsigned fast_next_item(unsigned *ctr, int lane) {
-    unsigned t = 0;
-    // the zero offset is opaque to the compiler: an atomic on an address it can prove wave-uniform is rewritten by the atomic optimizer into
-    // "one lane adds the lane count, v_readfirstlane the result" -- and that v_readfirstlane waits for the return on the spot
-    unsigned zero = 0;
-    asm volatile("" : "+v"(zero));
-    if (lane == 0) t = __hip_atomic_fetch_add(ctr + zero, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-}
-__device__ __forceinline__ unsigned fast_item_value(unsigned raw) { return (unsigned) __builtin_amdgcn_readfirstlane((int) raw); }
-
-template <int kP, bool kIniFirst>
-__global__ __launch_bounds__(kFastBlock) void k_fast_stream(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels, int iniTh, int minTh,
-                                                            unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
-                                                            long long totalSlots, int totalGroups, int groupsPerXcd, int winRows, int smapRows,
-                                                            int quadCap, FastGroupBases gb, unsigned *__restrict__ stats, unsigned *__restrict__ work,
-                                                            unsigned totalItems, unsigned itemsPerFrame, unsigned itemsMagic) {
+template <bool kIniFirst>
+__global__ __launch_bounds__(kFastBlock) void k_fast_tab(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
+                                                         unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
+                                                         long long totalSlots, int totalGroups, int groupsPerXcd, int winRows, int smapRows,
+                                                         int quadCap, unsigned *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
     const int tid = threadIdx.x, lane = tid & 63;
+    if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
+    const int grp = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);   // XCD-aware: every XCD gets a contiguous run of groups
+    if (grp >= totalGroups) return;
+    const int f = blockIdx.y;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xcd = blockIdx.x & 7;
-    const int winBytes = (winRows * kP + 16 + 15) & ~15;
-    const int smapBytes = (max(smapRows * kP, quadCap * 4) + 15) & ~15;
-    const int perWave = 2 * winBytes + smapBytes + kCornerCap * 2;
-    uint8_t *wbase = fdyn + wv * perWave;
-    uint8_t *smap = wbase + 2 * winBytes;
+    const FastCellRec R = cells[grp * 4 + wv];
+    const unsigned fl = R.flags >> 8;
+    if (!(fl & kFastCellExists)) return;
+    unsigned short *cnt_out = cellCnt + (long long) f * totalCells + R.cell;
+    if (!(fl & kFastCellRun)) {
+        if (lane == 0) *cnt_out = 0;
+        return;
+    }
+    const int wh = (int) (R.flags & 0xFFu), dw = (int) ((R.geo >> 16) & 0xFFu), dh = (int) (R.geo >> 24);
+    const bool lvl0 = (R.flags >> 16) == 0;
+    const unsigned pitch = lvl0 ? (unsigned) fs.img0_pitch : (R.geo & 0xFFFFu);
+    const uint8_t *src = (lvl0 ? fs.img0 + (long long) f * fs.img0_stride : fs.pyr + (long long) f * fs.pyr_stride + R.off) +
+                         (R.xy >> 16) * pitch + (R.xy & 0xFFFFu);
+    constexpr int P = kTabPitch;
+    const int winBytes = (winRows * P + 16 + 15) & ~15;
+    const int smapBytes = (max(smapRows * P, quadCap * 4) + 15) & ~15;
+    const int perWave = winBytes + smapBytes + kCornerCap * 2;
+    uint8_t *win = fdyn + wv * perWave;
+    uint8_t *smap = win + winBytes;
     unsigned short *clist = (unsigned short *) (smap + smapBytes);
-    unsigned *ctr = work + xcd;
-#define YGZF_FAST_JOB(t) fast_job(t, totalItems, itemsPerFrame, itemsMagic, xcd, groupsPerXcd, totalGroups, fs, geom, nlevels, cellCnt, slots, totalCells, totalSlots, gb)
-    unsigned t0 = fast_item_value(fast_next_item(ctr, lane));
-    FastJob J0 = YGZF_FAST_JOB(t0);
-    int b = 0;
-    if (J0.kind == 2) fast_window_dma<kP>(J0, wbase, lane);
-    unsigned r1 = fast_next_item(ctr, lane);
-#pragma unroll 1
-    while (t0 < totalItems) {
-        const unsigned t1 = fast_item_value(r1);   // requested a whole cell ago
-        const FastJob J1 = YGZF_FAST_JOB(t1);
-        // the current window has landed (its DMA was issued a whole cell ago); nothing else of this wave is in flight
+    {   // window rows 0 .. wh - 1, 48 bytes each from column iniX - 1.  Reads at most 47 bytes past that column: inside the row's 16-px border
+        // margin or, for windows clipped at the right border, inside the next row -- never past the image (the last window row lies at
+        // least 16 rows above the bottom)
+        const int total = wh * 3;
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int i = i0 + lane;
+            const int r = (int) (((unsigned) i * 21846u) >> 16), c16 = i - 3 * r;   // i / 3, exact for i < 32768
+            if (i < total)
+                __builtin_amdgcn_global_load_lds((const unsigned *) (src + __umul24((unsigned) r, pitch) + 16 * c16), (lds_void_t *) (win + 16 * i0), 16, 0, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        wave_lds_sync();
-        if (J1.kind == 2) fast_window_dma<kP>(J1, wbase + (b ^ 1) * winBytes, lane);
-        r1 = fast_next_item(ctr, lane);
-        if (J0.kind == 1) {
-            if (lane == 0) *J0.cnt_out = 0;
-        } else if (J0.kind == 2) {
-            fast_cell_process<kP, kIniFirst>(wbase + b * winBytes, smap, clist, kP, J0.dw, J0.dh, J0.sft, iniTh, minTh, J0.cnt_out, J0.out, J0.grp, lane, stats);
-            wave_lds_sync();   // the next cell reuses the score map / lists
-        }
-        J0 = J1; t0 = t1; b ^= 1;
     }
-#undef YGZF_FAST_JOB
-    if (lane == 0) {
-        const unsigned wavesPerXcd = (gridDim.x >> 3) * (kFastBlock / 64);
-        const unsigned d = __hip_atomic_fetch_add(work + 8 + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == wavesPerXcd - 1) {   // every wave of this XCD has drawn its last item: leave the counters at zero for the next launch
-            __hip_atomic_store(work + xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(work + 8 + xcd, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    wave_lds_sync();
+    fast_cell_process<P, kIniFirst>(win, smap, clist, P, dw, dh, iniTh, minTh, cnt_out, slots + (long long) f * totalSlots + R.slot, grp, lane, stats);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1758,56 +1672,21 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 #undef YGZF_FAST_LAUNCH
 }
 
-// ---- persistent form (k_fast_stream) ----
-bool fast_stream_supported(int wCellMax, int *pitch) {   // window pitch of the dword-aligned copy: column (iniX - 1) & 3 .. + wCell + 6
-    const int P = (wCellMax + 6 + 1 + 3 + 3) / 4 * 4;
-    *pitch = P <= 40 ? 40 : P <= 44 ? 44 : 48;
-    return P <= 48;
-}
-size_t fast_stream_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap) {
-    const size_t smapBytes = (std::max((size_t) smapRows * winPitch, (size_t) quadCap * 4) + 15) & ~(size_t) 15;
-    return (size_t) (kFastBlock / 64) * (2 * (((size_t) winRows * winPitch + 16 + 15) & ~(size_t) 15) + smapBytes + kCornerCap * sizeof(unsigned short)) + 64;
-}
-// resident workgroups per CU of one instantiation at one LDS size (asked once per process and size: the answer depends on the kernel's
-// register count, which only the runtime knows)
-static int fast_stream_occupancy(const void *fn, size_t lds) {
-    static std::mutex mu;
-    static std::map<std::pair<const void *, size_t>, int> memo;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = memo.find({fn, lds});
-    if (it != memo.end()) return it->second;
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, kFastBlock, lds) != hipSuccess || n < 1) n = 1;
-    memo[{fn, lds}] = n;
-    return n;
-}
-void launch_fast_stream(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
-                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
-                        int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost, bool iniFirst, unsigned *stats,
-                        unsigned *work, int numCUs) {
+// ---- table-driven form (k_fast_tab) ----
+size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap) { return fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap); }
+void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
+                     int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
+                     unsigned *stats) {
     if (totalGroups <= 0) return;
-    FastGroupBases gb;
-    for (int k = 0; k < kMaxLevels; k++) gb.v[k] = k < nlevels ? groupBaseHost[k] : 0x7fffffff;
     const int groupsPerXcd = (totalGroups + 7) / 8;
-    const unsigned itemsPerFrame = 4u * (unsigned) groupsPerXcd;
-    const unsigned totalItems = itemsPerFrame * (unsigned) nFrames;
-    const unsigned itemsMagic = (unsigned) ((1ull << 32) / itemsPerFrame);
-    const size_t lds = fast_stream_lds_bytes(winPitch, winRows, smapRows, quadCap);
-#define YGZF_FAST_STREAM(KP, INI)                                                                                                                      \
-    do {                                                                                                                                              \
-        const int occ = fast_stream_occupancy((const void *) k_fast_stream<KP, INI>, lds);                                                           \
-        long long wgs = (long long) numCUs * occ;                                                                                                     \
-        wgs = std::max<long long>(8, (wgs + 7) / 8 * 8);                                                                                              \
-        hipLaunchKernelGGL((k_fast_stream<KP, INI>), dim3((unsigned) wgs), dim3(kFastBlock), lds, st, fs, dGeom, nlevels, iniTh, minTh, cellCnt,      \
-                           slots, totalCells, totalSlots, totalGroups, groupsPerXcd, winRows, smapRows, quadCap, gb, stats, work, totalItems,        \
-                           itemsPerFrame, itemsMagic);                                                                                                \
-    } while (0)
-    switch (winPitch) {
-        case 40: if (iniFirst) YGZF_FAST_STREAM(40, true); else YGZF_FAST_STREAM(40, false); break;
-        case 44: if (iniFirst) YGZF_FAST_STREAM(44, true); else YGZF_FAST_STREAM(44, false); break;
-        default: if (iniFirst) YGZF_FAST_STREAM(48, true); else YGZF_FAST_STREAM(48, false); break;
-    }
-#undef YGZF_FAST_STREAM
+    const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
+    const size_t lds = fast_tab_lds_bytes(winRows, smapRows, quadCap);
+    if (iniFirst)
+        hipLaunchKernelGGL(k_fast_tab<true>, grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalGroups,
+                           groupsPerXcd, winRows, smapRows, quadCap, stats);
+    else
+        hipLaunchKernelGGL(k_fast_tab<false>, grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalGroups,
+                           groupsPerXcd, winRows, smapRows, quadCap, stats);
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes) {

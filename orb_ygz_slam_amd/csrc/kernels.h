@@ -15,15 +15,12 @@ size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
                        int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost, bool iniFirst, unsigned *stats);
-// persistent form of the same cell loop (k_fast_stream): waves pull cells from per-XCD counters in `work` (kFastWorkWords zeroed u32,
-// left zeroed by every launch) and prefetch the next cell's window by LDS-DMA
-constexpr int kFastWorkWords = 16;
-bool fast_stream_supported(int wCellMax, int *pitch);
-size_t fast_stream_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);
-void launch_fast_stream(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
-                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
-                        int nFrames, int winPitch, int winRows, int quadCap, const int *groupBaseHost, bool iniFirst, unsigned *stats,
-                        unsigned *work, int numCUs);
+// table-driven form of the same cell loop (k_fast_tab): per-cell records built on the host, window staged by LDS-DMA; cells up to 41 px wide
+constexpr int kFastTabMaxCell = 41;
+size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap);
+void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
+                     int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
+                     unsigned *stats);
 constexpr int kFastStatWords = 4 * 64;   // `stats`: 64 x {cells sampled, cells whose keypoints are FAST(minTh)'s, score rounds beyond the first, plan: 1 one pass / 2 iniTh first}
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes);
 hipError_t octree_prepare(size_t ldsBytes, bool globalNodes);

@@ -76,7 +76,8 @@ struct Geometry {
     long long pyrBytes = 0;   // per frame, levels >= 1
     int totalCells = 0, maxCellsPerLevel = 0;
     int totalGroups = 0, fastSmapRows = 3, fastWinPitch = 16, fastWinRows = 7, fastQuadCap = 4;   // 2x2 cell groups of k_fast_quads
-    int fastWCellMax = 1, fastStreamQuadCap = 4;   // k_fast_stream: dword-aligned window copies (one more quad per row at most)
+    int fastWCellMax = 1;
+    std::vector<FastCellRec> fastCells;   // [group * 4 + position]: k_fast_tab's per-cell records
     long long totalSlots = 0;
     long long candStride = 0;
     int kpStride = 0, kpCapMax = 0;
@@ -125,9 +126,8 @@ struct ygzf_ctx {
     unsigned fastLaunches = 0;             // statistics are collected on the first launches and on every 8th one after that
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
     Buf dFastStats;
-    Buf dFastWork;                         // k_fast_stream's per-XCD work counters (kFastWorkWords u32, zero between launches)
-    int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per launch, 1 k_fast_quads (a wave per cell), 2 k_fast_stream (persistent waves)
-    int numCUs = 256;
+    Buf dFastCells;                        // FastCellRec table of the current geometry (k_fast_tab)
+    int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
     bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
@@ -292,7 +292,6 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
             G.fastWinRows = std::max(G.fastWinRows, g.hCell + 6);
             G.fastQuadCap = std::max(G.fastQuadCap, ((g.wCell + 3) / 4 * g.hCell + 3) / 4 * 4);
             G.fastWCellMax = std::max(G.fastWCellMax, g.wCell);
-            G.fastStreamQuadCap = std::max(G.fastStreamQuadCap, ((g.wCell + 3 + 3) / 4 * g.hCell + 3) / 4 * 4);
             slotBase += (long long) nc * g.slotCap;
             g.candCap = nc * g.slotCap;
             candBase += g.candCap;
@@ -324,6 +323,29 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
     G.pyrBytes = off;
     G.totalCells = cellBase;
     G.totalGroups = groupBase;
+    // per-cell records of k_fast_tab: the cell loop of ComputeKeyPointsOctTree (src/ORBextractor.cc:747-764) evaluated once per geometry
+    G.fastCells.assign((size_t) groupBase * 4, FastCellRec{0, 0, 0, 0, 0, 0, 0, 0});
+    for (int l = 0; l < L; l++) {
+        const LevelGeom &g = G.lv[l];
+        if (!g.nCols) continue;
+        const int gCols = (g.nCols + 1) / 2;
+        for (int ci = 0; ci < g.nRows; ci++)
+            for (int cj = 0; cj < g.nCols; cj++) {
+                FastCellRec &r = G.fastCells[(size_t) (g.groupBase + (ci / 2) * gCols + cj / 2) * 4 + (ci & 1) * 2 + (cj & 1)];
+                const int cidx = ci * g.nCols + cj;
+                const int iniX = kBorder + cj * g.wCell, iniY = kBorder + ci * g.hCell;
+                const int maxX = std::min(iniX + g.wCell + 6, g.maxBorderX), maxY = std::min(iniY + g.hCell + 6, g.maxBorderY);
+                const bool skip = (iniX >= g.maxBorderX - 6) || (iniY >= g.maxBorderY - 3);   // :751, :759
+                const int dw = maxX - iniX - 6, dh = maxY - iniY - 6;
+                const bool run = !skip && dw > 0 && dh > 0;
+                r.xy = (unsigned) (iniX - 1) | ((unsigned) iniY << 16);
+                r.geo = (unsigned) (l ? g.pitch : 0) | ((unsigned) (run ? dw : 0) << 16) | ((unsigned) (run ? dh : 0) << 24);
+                r.flags = (unsigned) (run ? maxY - iniY : 0) | ((kFastCellExists | (run ? kFastCellRun : 0u)) << 8) | ((unsigned) l << 16);
+                r.cell = (unsigned) (g.cellBase + cidx);
+                r.slot = (unsigned) (g.slotBase + (long long) cidx * g.slotCap);
+                r.off = (unsigned) g.off;
+            }
+    }
     G.totalSlots = slotBase;
     G.candStride = candBase;
     G.kpStride = kpBase;
@@ -361,6 +383,9 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             if (rc) return rc;
             if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
         }
+        rc = ensure(c, c->dFastCells, std::max<size_t>(G.fastCells.size() * sizeof(FastCellRec), 32));
+        if (rc) return rc;
+        if (!G.fastCells.empty()) HIPCHECK(c, hipMemcpy(c->dFastCells.p, G.fastCells.data(), G.fastCells.size() * sizeof(FastCellRec), hipMemcpyHostToDevice));
         // LDS-resident candidate sort buffers: as many as keep two workgroups per CU (<= ~78 KB each)
         {
             // per-list-position arrays (19 x cap ints) stay in LDS while one workgroup fits the CU; very large per-level feature budgets
@@ -511,19 +536,15 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
             HIPCHECK(c, hipMemsetAsync(c->dFastStats.p, 0, kFastStatWords * sizeof(unsigned), c->stream));
         }
         {
-            // which form of the cell loop: the persistent one (waves pull cells, next window prefetched by LDS-DMA) needs enough cells to give every
-            // resident wave a few of them and cells no wider than its compile-time window pitches; single frames keep one wave per cell
-            int streamPitch = 0;
-            const bool streamOk = fast_stream_supported(G.fastWCellMax, &streamPitch) && (fs.img0_pitch & 3) == 0 && ((uintptr_t) fs.img0 & 3) == 0 &&
-                                  (fs.img0_stride & 3) == 0;
-            const long long cells = (long long) G.totalCells * nFrames;
-            const bool stream = streamOk && (c->fastKernel == 2 || (c->fastKernel == 0 && cells >= (long long) c->numCUs * 24 * 3));
+            // which form of the cell loop: the table-driven one (per-cell records, LDS-DMA staging) wherever its 48-byte window pitch holds the
+            // widest cell and the pyramid offsets / frame sizes fit its 32-bit / 16-bit record fields
+            const bool tab = c->fastKernel != YGZF_FAST_KERNEL_REGISTER_STAGING && G.fastWCellMax <= kFastTabMaxCell && G.pyrBytes < (1ll << 32) &&
+                             G.w < 65536 && G.h < 65536 && G.totalSlots < (1ll << 32);
             ProfScope ps(c, KK_FAST);
-            if (stream)
-                launch_fast_stream(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast, (unsigned short *) c->dCellCnt.p,
-                                   (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows, nFrames, streamPitch,
-                                   G.fastWinRows, G.fastStreamQuadCap, groupBase, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr,
-                                   (unsigned *) c->dFastWork.p, c->numCUs);
+            if (tab)
+                launch_fast_tab(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
+                                (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,
+                                nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
             else
                 launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                   (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
@@ -660,14 +681,7 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     CK(upload_constants(c->tab.umax));
     CK(hipHostMalloc((void **) &c->hFastStats, kFastStatWords * sizeof(unsigned)));
     memset(c->hFastStats, 0, kFastStatWords * sizeof(unsigned));
-    CK(hipMalloc(&c->dFastWork.p, kFastWorkWords * sizeof(unsigned)));
-    c->dFastWork.bytes = kFastWorkWords * sizeof(unsigned);
-    CK(hipMemsetAsync(c->dFastWork.p, 0, kFastWorkWords * sizeof(unsigned), c->stream));
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->numCUs = cus;
-        if (const char *e = getenv("YGZF_FAST_KERNEL")) c->fastKernel = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
-    }
+    if (const char *e = getenv("YGZF_FAST_KERNEL")) c->fastKernel = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
 #undef CK
     // validate the largest configuration up front (and size the buffers once)
     int rc = apply_geometry(c, max_width, max_height, max_batch);
@@ -709,7 +723,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dCacheImg.p) (void) hipFree(c->dCacheImg.p);
     if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
     if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
-    if (c->dFastWork.p) (void) hipFree(c->dFastWork.p);
+    if (c->dFastCells.p) (void) hipFree(c->dFastCells.p);
     if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
     if (c->hFastStats) (void) hipHostFree(c->hFastStats);
     if (c->hStage) (void) hipHostFree(c->hStage);
@@ -743,7 +757,7 @@ int ygzf_set_fast_plan(ygzf_ctx *c, int plan) {
 
 int ygzf_set_fast_kernel(ygzf_ctx *c, int kernel) {
     if (!c) return YGZF_ERR_INVALID;
-    if (kernel < YGZF_FAST_KERNEL_AUTO || kernel > YGZF_FAST_KERNEL_STREAM) return fail(c, YGZF_ERR_INVALID, "FAST kernel %d (0 auto, 1 wave per cell, 2 persistent)", kernel);
+    if (kernel < YGZF_FAST_KERNEL_AUTO || kernel > YGZF_FAST_KERNEL_CELL_TABLE) return fail(c, YGZF_ERR_INVALID, "FAST kernel %d (0 auto, 1 register staging, 2 cell table + LDS-DMA)", kernel);
     c->fastKernel = kernel;
     return YGZF_OK;
 }

@@ -51,6 +51,20 @@ struct LevelGeom {
     float kpSize;             // (float)(int)(PATCH_SIZE*scale)
 };
 
+// One FAST cell as k_fast_tab wants it (host-built per (w, h) configuration, indexed [cell group * 4 + position in the 2x2 group]):
+// everything ComputeKeyPointsOctTree's cell loop derives per cell (src/ORBextractor.cc:747-764), so that a wave starts from ONE 32-byte
+// scalar load instead of a level search, a geometry load, an integer division and two dozen scalar operations.
+struct FastCellRec {
+    unsigned xy;        // (iniX - 1) | iniY << 16: first byte / row of the window inside the level image
+    unsigned geo;       // pitch (levels >= 1) | dw << 16 | dh << 24      dw x dh = tested pixels of the cell
+    unsigned flags;     // wh (window rows) | kFastCell* << 8 | level << 16
+    unsigned cell;      // index inside a frame's per-cell arrays (LevelGeom::cellBase + row-major cell)
+    unsigned slot;      // first candidate slot of the cell inside a frame's slot array
+    unsigned off;       // byte offset of the level inside a frame's pyramid slab (levels >= 1)
+    unsigned pad0, pad1;
+};
+constexpr unsigned kFastCellExists = 1, kFastCellRun = 2;   // no bit: no cell at this position of the group; Exists only: skipped by the border rules (:751, :759)
+
 struct FrameSet {
     const uint8_t *img0;      // level 0 of frame 0
     long long img0_stride;    // bytes between frames

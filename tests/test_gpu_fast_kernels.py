@@ -1,7 +1,7 @@
-"""k_fast_stream -- the persistent form of the FAST cell loop (waves draw cells from per-XCD counters, the next cell's window arrives by
-LDS-DMA as a dword-aligned copy) -- must return exactly what the wave-per-cell kernel and the oracle return: candidates (x, y, score,
-order) of every level, keypoints, descriptors; on both threshold plans, on every window alignment (iniX - 1) & 3, on all three compile-time
-window pitches, for batches that leave most waves without work, and launch after launch (the kernel zeroes its own counters)."""
+"""k_fast_tab -- the FAST cell loop started from host-built per-cell records with the window staged by LDS-DMA (16-byte pieces from
+byte-unaligned addresses) -- must return exactly what the register-staging kernel k_fast_quads and the oracle return: candidates (x, y,
+score, order) of every level, keypoints, descriptors; on both threshold plans, on every window alignment, for cells clipped at the right /
+bottom border, for cells too wide for its window pitch (fallback), launch after launch and across geometry changes."""
 import numpy as np
 import pytest
 
@@ -24,7 +24,7 @@ def _cmp(ex, oex, img, frame=0, what=""):
 
 @pytest.mark.parametrize("plan", [1, 2])
 @pytest.mark.parametrize("ini,mn", [(20, 7), (12, 12), (40, 5)])
-def test_stream_kernel_equals_the_oracle_on_every_content(oracle, plan, ini, mn):
+def test_table_kernel_equals_the_oracle_on_every_content(oracle, plan, ini, mn):
     from orb_ygz_slam_amd import Extractor
     w, h = 640, 480
     ex = Extractor(1000, 1.2, 8, ini, mn, max_width=w, max_height=h, max_batch=1)
@@ -36,11 +36,12 @@ def test_stream_kernel_equals_the_oracle_on_every_content(oracle, plan, ini, mn)
         _cmp(ex, oex, img, 0, (name, plan))
 
 
-# widths chosen so that the cell width, hence the window pitch (40 / 44 / 48) and the alignments (iniX - 1) & 3 of a level's cells, vary;
-# 1.5 / 2.0 pyramids reach small levels with single cells; the 1241x376 KITTI shape has the odd width the API re-pitches
+# widths chosen so that the cell width and the byte alignment (iniX - 1) & 15 of the windows vary; 1.5 / 2.0 pyramids reach small levels
+# with single cells; the 1241x376 KITTI shape has the odd width the API re-pitches; 91x91 and 123x200 have cells of 59 / 45 px, wider than
+# the table kernel's window (the library must fall back to k_fast_quads on its own)
 @pytest.mark.parametrize("w,h,sf,nl", [(752, 480, 1.2, 8), (640, 480, 1.2, 8), (631, 397, 1.2, 8), (517, 333, 1.3, 6), (1241, 376, 1.2, 8),
-                                       (401, 303, 1.5, 5), (322, 243, 2.0, 3), (96, 128, 1.2, 3), (1920, 1080, 1.2, 8)])
-def test_stream_kernel_sizes(oracle, w, h, sf, nl):
+                                       (401, 303, 1.5, 5), (322, 243, 2.0, 3), (96, 128, 1.2, 3), (91, 91, 1.2, 2), (123, 200, 1.2, 3), (1920, 1080, 1.2, 8)])
+def test_table_kernel_sizes(oracle, w, h, sf, nl):
     from orb_ygz_slam_amd import Extractor
     ex = Extractor(1500, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=2)
     ex.set_fast_kernel(2)
@@ -53,9 +54,8 @@ def test_stream_kernel_sizes(oracle, w, h, sf, nl):
             _cmp(ex, oex, imgs[f], f, (w, h, sf, nl, plan, f))
 
 
-def test_stream_kernel_launch_after_launch(oracle):
-    """batches of different sizes on one context: the work counters must be back at zero after every launch, and a batch with fewer cells than
-    resident waves must still cover every cell"""
+def test_table_kernel_launch_after_launch(oracle):
+    """batches of different sizes on one context, then the other kernel on the same context"""
     from orb_ygz_slam_amd import Extractor
     w, h = 752, 480
     ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=24)
@@ -68,7 +68,7 @@ def test_stream_kernel_launch_after_launch(oracle):
         for f in range(n):
             k, d = ex.batch_fetch(f)
             assert len(k) == len(want[f][0]) and (k == want[f][0]).all() and (d == want[f][1]).all(), (n, f)
-    ex.set_fast_kernel(1)                                      # and the wave-per-cell kernel on the same context still agrees
+    ex.set_fast_kernel(1)                                      # and the register-staging kernel on the same context still agrees
     ex.extract_batch_host(frames[:5])
     for f in range(5):
         k, d = ex.batch_fetch(f)
