@@ -929,6 +929,7 @@ struct OctShared {  // carved out of dynamic LDS
 
 // kGlobalNodes: the 19 per-list-position arrays live in a global arena (nodeArena, 19 * cap ints per (frame, level)) instead of LDS --
 // configurations whose per-level feature budget is too large for the LDS plan (e.g. one level with > 2000 features).
+constexpr unsigned kNoKeypoint = 0xFFFFFFFFu;   // procRec.y of a processing position without a keypoint
 template <bool kGlobalNodes>
 __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
                                                       const unsigned short *__restrict__ cellCnt,
@@ -954,6 +955,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     int *lvlCnt = lvlKpCnt + f * nlevels + l;
     if (nCells <= 0 || g.nCols <= 0) {
         if (tid == 0) { *lvlCnt = 0; lvlCandCnt[f * nlevels + l] = 0; }
+        for (int i = tid; i < g.kpCap; i += kOctBlock) procRec[(long long) f * kpStride + g.kpBase + i] = make_uint2(0u, kNoKeypoint);
         return;
     }
     OctShared S;
@@ -986,6 +988,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     __syncthreads();
     if (M == 0) {
         if (tid == 0) *lvlCnt = 0;
+        for (int i = tid; i < g.kpCap; i += kOctBlock) procRec[(long long) f * kpStride + g.kpBase + i] = make_uint2(0u, kNoKeypoint);
         return;
     }
     OSTAMP(1);
@@ -1227,10 +1230,13 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 12, histT, s_tmp, &ok, &ov);
         // k_describe's work list: processing position i -> (x | y << 16, score | list position << 8) in ONE record, so that a describe wave
         // knows its keypoint after a single memory round trip (it used to follow procOrder -> position / score: two dependent ones)
+        // (score | list position << 8 | level << 24; positions past the level's count carry kNoKeypoint so that the wave there leaves at once)
         uint2 *pr = procRec + (long long) f * kpStride + g.kpBase;
-        for (int i = tid; i < n; i += kOctBlock) {
-            const unsigned li = ov[i];
-            pr[i] = make_uint2((unsigned) S.b1[li], (unsigned) S.b2[li] | (li << 8));
+        for (int i = tid; i < g.kpCap; i += kOctBlock) {
+            if (i < n) {
+                const unsigned li = ov[i];
+                pr[i] = make_uint2((unsigned) S.b1[li], (unsigned) S.b2[li] | (li << 8) | ((unsigned) l << 24));
+            } else pr[i] = make_uint2(0u, kNoKeypoint);
         }
     }
     if (tid == 0) *lvlCnt = n;
@@ -1373,11 +1379,16 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         const unsigned long long a00 = (unsigned long long) img + (unsigned) (ky - 21) * (unsigned) pitch + (unsigned) (kx - 21);
         rowOff0 = (int) (a00 & 15);
         rowOffStep = pitch & 15;
-        for (int idx = lane; idx < kWin * 4; idx += 64) {
-            const int r = idx >> 2, q = idx & 3;
+        // LDS-DMA: lane idx & 63 of piece idx >> 6 delivers LDS bytes 16 idx .. 16 idx + 15 = row idx >> 2, quarter idx & 3 -- the window's own
+        // layout, so the 43 x 64 bytes go global memory -> LDS in three instructions without a register round trip or a ds_write
+#pragma unroll
+        for (int i0 = 0; i0 < kWin * 4; i0 += 64) {
+            const int idx = i0 + lane, r = idx >> 2, q = idx & 3;
             const unsigned long long a = a00 + __umul24((unsigned) r, (unsigned) pitch);
-            *(uint4 *) &L.rawp()[r * kWinP + 16 * q] = *(const uint4 *) ((a & ~15ull) + 16 * q);
+            if (idx < kWin * 4)
+                __builtin_amdgcn_global_load_lds((const unsigned *) ((a & ~15ull) + 16 * q), (lds_void_t *) (L.rawp() + 16 * i0), 16, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         for (int idx = lane; idx < kWin * kWin; idx += 64) {
             const int r = idx / kWin, c = idx - r * kWin;
@@ -1479,59 +1490,61 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
 #undef RAWP
 }
 
-struct DescLevelBases { int v[kMaxLevels]; };   // LevelGeom::kpBase of every level (first keypoint slot of the level inside a frame), by value
+// Output bookkeeping between the octree and k_describe: first output index of every level of every frame (the levels' keypoints are
+// concatenated in level order, src/ORBextractor.cc:1004-1026) and the frame's keypoint count.  One thread per frame.
+__global__ void k_level_bases(const int *__restrict__ lvlKpCnt, int nlevels, int nFrames, int *__restrict__ lvlBase, int *__restrict__ outCnt) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nFrames) return;
+    int acc = 0;
+    for (int l = 0; l < nlevels; l++) {
+        lvlBase[f * kMaxLevels + l] = acc;
+        acc += lvlKpCnt[f * nlevels + l];
+    }
+    outCnt[f] = acc;
+}
+
 template <int CVM>
-__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom, int nlevels,
-                                                            const int *__restrict__ lvlKpCnt,
+__global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom,
+                                                            const int *__restrict__ lvlBase,
                                                             const uint2 *__restrict__ procRec, int kpStride,
                                                             ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                            int *__restrict__ outCnt, int outStride, int blocksPerXcd, DescLevelBases kb) {
+                                                            int outStride, int blocksPerXcd) {
     __shared__ DescLds lds[kDescWaves];
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform: the keypoint record loads go scalar
     const int f = blockIdx.y;
     // XCD-aware: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (spatially ordered) keypoint slots so
-    // that overlapping 43x43 windows meet in the same L2.  s = slot of the frame's level-major capacity layout: the wave handles
-    // position s - kpBase[l] of level l's PROCESSING order, if the level has that many keypoints.
+    // that overlapping 43x43 windows meet in the same L2.  s = processing position inside the frame's level-major capacity layout.
     if ((int) (blockIdx.x >> 3) >= blocksPerXcd) return;
     const int s = ((blockIdx.x & 7) * blocksPerXcd + (blockIdx.x >> 3)) * kDescWaves + wave;
     if (s >= kpStride) return;
-    // The level comes from the kernel arguments (scalar compares), so the three things the wave needs from memory -- the level counts, its
-    // work record and the level geometry -- are requested together: ONE round trip before the window loads instead of four dependent ones
-    // (counts -> geometry -> processing order -> position / score), which were a quarter of the kernel's time.
-    int l = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxLevels; k++)
-        if (k < nlevels && s >= kb.v[k]) l = k;
-    const int p = s - kb.v[l];
-    const int *cnts = lvlKpCnt + f * nlevels;
+    // The octree leaves everything the wave needs to know about its keypoint in ONE 8-byte record (position, score, list position,
+    // level; kNoKeypoint where the level has fewer keypoints than capacity), k_level_bases the level's first output index: two scalar
+    // loads and a few scalar operations instead of a 16-way level search and a loop over the level counts (counters: as many issue
+    // slots went into this bookkeeping as into the row blur).
     const uint2 rec = procRec[(long long) f * kpStride + s];
-    const LevelGeom g = geom[l];
-    int base = 0, total = 0, mine = 0;
-    for (int i = 0; i < nlevels; i++) {
-        const int c = cnts[i];
-        if (i < l) base += c;
-        if (i == l) mine = c;
-        total += c;
-    }
-    if (s == 0 && lane == 0) outCnt[f] = total;
-    if (p >= mine) return;
-    const int li = (int) (rec.y >> 8);                                               // list position handled by this wave
-    const int slot = base + li;                                                     // output index: level-major, list order
+    if (rec.y == kNoKeypoint) return;
+    const int l = (int) (rec.y >> 24);
+    const int li = (int) ((rec.y >> 8) & 0xFFFFu);                                  // list position handled by this wave
+    const int slot = lvlBase[f * kMaxLevels + l] + li;                              // output index: level-major, list order
+    const LevelGeom *gp = geom + l;
+    const int gw = gp->w, gh = gp->h;
     const int kx = rec.x & 0xFFFFu, ky = rec.x >> 16;
     const int score = rec.y & 0xFFu;
     int pitch;
-    const uint8_t *img = level_ptr(fs, g, l, f, &pitch);
+    const uint8_t *img;
+    if (l == 0) { pitch = fs.img0_pitch; img = fs.img0 + (long long) f * fs.img0_stride; }
+    else { pitch = gp->pitch; img = fs.pyr + (long long) f * fs.pyr_stride + gp->off; }
     float angle;
     unsigned long long bits[4];
-    describe_window<CVM>(img, pitch, g.w, g.h, kx, ky, lds[wave], lane, &angle, bits);
+    describe_window<CVM>(img, pitch, gw, gh, kx, ky, lds[wave], lane, &angle, bits);
     ygzf_kp *ok = outKp + (long long) f * outStride + slot;
     uint8_t *od = outDesc + ((long long) f * outStride + slot) * 32;
     if (lane < 4) ((unsigned long long *) od)[lane] = bits[lane];
     if (lane == 0) {
         ygzf_kp kp;
         if (l == 0) { kp.x = (float) kx; kp.y = (float) ky; }
-        else { kp.x = (float) kx * g.scale; kp.y = (float) ky * g.scale; }  // keypoint->pt *= scale (:1016-1021)
-        kp.size = g.kpSize;
+        else { const float sc = gp->scale; kp.x = (float) kx * sc; kp.y = (float) ky * sc; }  // keypoint->pt *= scale (:1016-1021)
+        kp.size = gp->kpSize;
         kp.angle = angle;
         kp.response = (float) score;
         kp.octave = l;
@@ -1712,17 +1725,14 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const un
                            dbg, nodeArena);
 }
 
-void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
-                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const uint2 *procRec, int kpStride,
-                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode, const int *kpBaseHost) {
-    DescLevelBases kb;
-    for (int k = 0; k < kMaxLevels; k++) kb.v[k] = k < nlevels ? kpBaseHost[k] : 0x7fffffff;
+void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,
+                     const uint2 *procRec, int kpStride, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode) {
+    hipLaunchKernelGGL(k_level_bases, dim3((nFrames + 255) / 256), dim3(256), 0, st, lvlKpCnt, nlevels, nFrames, lvlBase, outCnt);
     const int nblk = (kpStride + kDescWaves - 1) / kDescWaves;
     const int blocksPerXcd = (nblk + 7) / 8;
     dim3 grid(8 * blocksPerXcd, nFrames);
 #define YGZF_DESC_LAUNCH(M)                                                                                                      \
-    hipLaunchKernelGGL(k_describe<M>, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, nlevels, lvlKpCnt,                       \
-                       procRec, kpStride, outKp, outDesc, outCnt, outStride, blocksPerXcd, kb)
+    hipLaunchKernelGGL(k_describe<M>, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, lvlBase, procRec, kpStride, outKp, outDesc, outStride, blocksPerXcd)
     switch (cvMode) {
         case YGZF_CV_LEGACY_INT: YGZF_DESC_LAUNCH(YGZF_CV_LEGACY_INT); break;
         case YGZF_CV_4: YGZF_DESC_LAUNCH(YGZF_CV_4); break;

@@ -28,9 +28,8 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const un
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
                    uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena);
-void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *lvlKpXY,
-                     const unsigned char *lvlKpScore, const int *lvlKpCnt, const uint2 *procRec, int kpStride,
-                     ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode, const int *kpBaseHost);
+void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,
+                     const uint2 *procRec, int kpStride, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode);
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out);
 
 // ---- matcher (match_kernels.hip) -----------------------------------------------------------------------------------

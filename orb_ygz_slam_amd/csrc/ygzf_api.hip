@@ -100,7 +100,7 @@ struct ygzf_ctx {
         size_t bytes = 0;
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
-        dLvlCnt, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
+        dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
         dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6];
     int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
@@ -418,7 +418,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
     const size_t kp1 = std::max<size_t>((B + 1) * G.kpStride, 16);  // + carry slot
     void *oldCnt = c->dOutCnt.p, *oldKp = c->dOutKp.p;
     if ((rc = ensure(c, c->dLvlXY, kp * sizeof(unsigned))) || (rc = ensure(c, c->dLvlScore, kp)) ||
-        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dProcOrder, kp * sizeof(uint2))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
+        (rc = ensure(c, c->dLvlCnt, B * L * sizeof(int))) || (rc = ensure(c, c->dLvlBase, B * kMaxLevels * sizeof(int))) || (rc = ensure(c, c->dProcOrder, kp * sizeof(uint2))) || (rc = ensure(c, c->dLvlCand, B * L * sizeof(int))) ||
         (rc = ensure(c, c->dOutKp, kp1 * sizeof(ygzf_kp))) || (rc = ensure(c, c->dOutDesc, kp1 * 32)) ||
         (rc = ensure(c, c->dOutCnt, (B + 1) * sizeof(int))))
         return rc;
@@ -575,12 +575,9 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
                         st[l * 8 + 2] - st[l * 8 + 1], st[l * 8 + 3] - st[l * 8 + 2], st[l * 8 + 4] - st[l * 8 + 3], st[l * 8 + 5] - st[l * 8 + 4], st[l * 8 + 6], st[l * 8 + 7]);
         }
         {
-            int kpBase[kMaxLevels];
-            for (int l = 0; l < L; l++) kpBase[l] = G.lv[l].kpBase;
             ProfScope ps(c, KK_DESCRIBE);
-            launch_describe(c->stream, fs, dGeom, L, (const unsigned *) c->dLvlXY.p, (const unsigned char *) c->dLvlScore.p,
-                            (const int *) c->dLvlCnt.p, (const uint2 *) c->dProcOrder.p, G.kpStride, outKp, outDesc, outCnt,
-                            G.kpStride, nFrames, c->tab.cfg.cv_mode, kpBase);
+            launch_describe(c->stream, fs, dGeom, L, (const int *) c->dLvlCnt.p, (int *) c->dLvlBase.p, (const uint2 *) c->dProcOrder.p, G.kpStride,
+                            outKp, outDesc, outCnt, G.kpStride, nFrames, c->tab.cfg.cv_mode);
         }
     } else {
         HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int) * nFrames, c->stream));
@@ -695,7 +692,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
-                             &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlCand,
+                             &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlBase, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
                              &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes};
     for (auto *b : bufs)
