@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r3a
-timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/r3a/pytest.log 2>&1; tail -5 gpurun_out/r3a/pytest.log
+timeout 120 tools/micro/bin/valu_peak f64 "s_add" salu > gpurun_out/r3a/valu_rates_f64_salu.txt 2>&1; cat gpurun_out/r3a/valu_rates_f64_salu.txt

@@ -6,6 +6,7 @@
 // with the shader clock taken from s_memtime deltas inside the kernel (clock64) and from wall time x 2.4 GHz beside it.
 // Build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/micro/valu_peak.hip -o /tmp/valu_peak && /tmp/valu_peak
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <cstdio>
 #include <vector>
 
@@ -123,9 +124,41 @@ __global__ __launch_bounds__(256) void k_pkfma(unsigned *out, long long *clk, un
     if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
+// double-precision forms (k_describe's sin / cos) and mixes of one vector with one or two scalar instructions of the same wave (does a
+// scalar instruction cost the wave a vector issue slot?)
+#define KERNEL_F64(NAME, INS)                                                                                    \
+    __global__ __launch_bounds__(256) void NAME(unsigned *out, long long *clk, unsigned seed) {                  \
+        double a0 = 1.0 + threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 0.5, a5 = a0 * 0.25, a6 = a0 * 9, a7 = a0 * 1.5; \
+        double b = 0.999999 + 1e-9 * seed, c = 1e-6 * seed;                                                      \
+        const long long t0 = clock64(), w0 = wall_clock64();                                                     \
+        CHAIN8(INS)                                                                                              \
+        const long long t1 = clock64(), w1 = wall_clock64();                                                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned) (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);         \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { clk[0] = t1 - t0; clk[1] = w1 - w0; }             \
+    }
+#define OP_MULF64(x) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x) : "v"(b));
+#define OP_ADDF64(x) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x) : "v"(c));
+#define OP_FMAF64(x) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
+KERNEL_F64(k_mulf64, OP_MULF64) KERNEL_F64(k_addf64, OP_ADDF64) KERNEL_F64(k_fmaf64, OP_FMAF64)
+#define OP_ADD_S1(x) asm volatile("v_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, 1" : "+v"(x), "+s"(sm) : "v"(b));
+#define OP_ADD_S2(x) asm volatile("v_add_u32 %0, %0, %3\n\ts_add_u32 %1, %1, 1\n\ts_xor_b32 %2, %2, %1" : "+v"(x), "+s"(sm), "+s"(msk) : "v"(b));
+#define OP_LERP_S1(x) asm volatile("v_lerp_u8 %0, %0, %2, %3\n\ts_add_u32 %1, %1, 1" : "+v"(x), "+s"(sm) : "v"(b), "v"(c));
+#define KERNEL_S(NAME, OP)                                                                                       \
+    __global__ __launch_bounds__(256) void NAME(unsigned *out, long long *clk, unsigned seed) {                  \
+        unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        unsigned b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x5bd1e995u;                                   \
+        unsigned msk = __builtin_amdgcn_readfirstlane(0x3333ccccu * seed), sm = __builtin_amdgcn_readfirstlane(seed);                                                           \
+        const long long t0 = clock64(), w0 = wall_clock64();                                                     \
+        CHAIN8(OP)                                                                                               \
+        const long long t1 = clock64(), w1 = wall_clock64();                                                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ sm ^ msk;           \
+        if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { clk[0] = t1 - t0; clk[1] = w1 - w0; }             \
+    }
+KERNEL_S(k_add_s1, OP_ADD_S1) KERNEL_S(k_add_s2, OP_ADD_S2) KERNEL_S(k_lerp_s1, OP_LERP_S1)
+
 typedef void (*kern_t)(unsigned *, long long *, unsigned);
 
-int main() {
+int main(int argc, char **argv) {   // optional arguments: substrings of the instruction names to run
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount, simds = cus * 4;
@@ -146,13 +179,18 @@ int main() {
                                                    {"v_pk_mul_lo_u16", k_pkmul}, {"v_mul_f32", k_mulf}, {"v_add_f32", k_addf}, {"v_cvt_f32_u32", k_cvtf},
                                                    {"v_cvt_f32_ubyte0", k_cvtub}, {"v_mul_hi_u32", k_mulhi}, {"v_xad_u32", k_xad}, {"v_sad_u16", k_sad16},
                                                    {"v_add_lshl_u32", k_addlshl}, {"v_not_b32", k_not}, {"v_bcnt_u32_b32", k_bcnt}, {"v_add_u32_sdwa", k_sdwa},
-                                                   {"v_mov_b32_dpp ror", k_dppror}, {"v_bitop3 (or3)", k_bitop2}};
+                                                   {"v_mov_b32_dpp ror", k_dppror}, {"v_bitop3 (or3)", k_bitop2},
+                                                   {"v_mul_f64", k_mulf64}, {"v_add_f64", k_addf64}, {"v_fma_f64", k_fmaf64},
+                                                   {"v_add + 1 s_add", k_add_s1}, {"v_add + 2 salu", k_add_s2}, {"v_lerp + 1 s_add", k_lerp_s1}};
     const double instr = (double) kIter * kUnroll * kChains;
     printf("%-18s %s\n", "instruction", "waves/SIMD: shader-clock cycles per wave-instruction per SIMD @ measured GHz (s_memtime / s_memrealtime)");
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     for (auto &k : ks) {
+        bool want = argc < 2;
+        for (int i = 1; i < argc; i++) want = want || strstr(k.name, argv[i]) != nullptr;
+        if (!want) continue;
         printf("%-18s", k.name);
         for (int wps : {1, 2, 4, 8}) {
             const int blocks = cus * wps;   // 256-thread blocks: one wave per SIMD each

@@ -7,8 +7,10 @@
   traffic.json                                          HBM bytes per launch per kernel (read by bench.py: roofline.traffic)
   valu_mix.json                                         VALU instructions per frame + mean issue cost per instruction (bench.py: roofline_valu);
                                                         the issue cost comes from tools/valu_mix.py's classification of the kernel's ISA
-Units: FETCH_SIZE / WRITE_SIZE are KB; hbm_bytes = (FETCH + WRITE) * 1024 (no gfx950 1/2 correction: these kernels read bytes /
-dwords, not 16 B per lane streams -- calibrated on k_pyr_resize's known bytes, see profiles/r01_a_pmc_hbm_b256.csv)."""
+Units: FETCH_SIZE / WRITE_SIZE are KB.  hbm_bytes = FETCH * 1024 * fetch_factor + WRITE * 1024 * write_factor with the factors of
+profiles/hbm_calibration.json (tools/hbm_calib.sh: known 1 GiB streams in the access widths of these kernels -- dword, dwordx4 and
+LDS-DMA reads all report exactly HALF their bytes on gfx950, writes report their bytes: fetch_factor 2.0, write_factor 1.0).  The raw
+counter bytes stay in the CSV beside the corrected ones."""
 import collections
 import csv
 import glob
@@ -42,17 +44,29 @@ def mean(v):
     return sum(v) / len(v) if v else 0.0
 
 
+def calibration():
+    """(fetch factor, write factor) of profiles/hbm_calibration.json: every read width these kernels use calibrated to the same factor."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "hbm_calibration.json")
+    if not os.path.exists(f):
+        return 1.0, 1.0, "uncalibrated (profiles/hbm_calibration.json missing)"
+    c = json.load(open(f))
+    ff = [c["fetch_factor"][k] for k in ("dword", "dwordx4", "ldsdma16") if k in c["fetch_factor"]]
+    wf = [c["write_factor"][k] for k in ("dword", "dwordx4") if k in c["write_factor"]]
+    return round(sum(ff) / len(ff), 3), round(sum(wf) / len(wf), 3), "profiles/hbm_calibration.json"
+
+
 def hbm_table(out, tag, prefix, what):
     fetch, write = counters(os.path.join(out, prefix + "fetch")), counters(os.path.join(out, prefix + "write"))
+    ff, wf, src = calibration()
     traffic = {}
     with open(os.path.join(out, "%s_%spmc_hbm.csv" % (tag, prefix)), "w") as f:
         f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), %s\n" % what)
-        f.write("# units: KB per launch (mean over launches); hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024\n")
-        f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB,hbm_bytes_per_launch\n")
+        f.write("# units: KB per launch (mean over launches); raw_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024; hbm_bytes = FETCH_SIZE * 1024 * %.3f + WRITE_SIZE * 1024 * %.3f (%s)\n" % (ff, wf, src))
+        f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB,raw_bytes_per_launch,hbm_bytes_per_launch\n")
         for k in sorted(set(fetch) | set(write)):
             fv, wv = fetch.get(k, {}).get("FETCH_SIZE", []), write.get(k, {}).get("WRITE_SIZE", [])
-            traffic[k] = int((mean(fv) + mean(wv)) * 1024)
-            f.write("%s,%d,%.1f,%.1f,%d\n" % (k, max(len(fv), len(wv)), mean(fv), mean(wv), traffic[k]))
+            traffic[k] = int(mean(fv) * 1024 * ff + mean(wv) * 1024 * wf)
+            f.write("%s,%d,%.1f,%.1f,%d,%d\n" % (k, max(len(fv), len(wv)), mean(fv), mean(wv), int((mean(fv) + mean(wv)) * 1024), traffic[k]))
     return traffic
 
 
@@ -95,7 +109,9 @@ def main():
             f.write(k + "," + str(n) + "," + ",".join("%.0f" % mean(sq[k].get(c, [])) for c in cols) + "\n")
     ins = insts_table(out, tag, "", "python bench.py --steps 3 --warmup 1")
     insts_table(out, tag, "all_", "python tools/all_kernels.py 2")
-    json.dump({"_source": "profiles/%s_pmc_hbm.csv (rocprofv3 PMC, HBM bytes per launch of one 256-frame sub-batch)" % tag,
+    ff, wf, src = calibration()
+    json.dump({"_source": "profiles/%s_pmc_hbm.csv (rocprofv3 PMC, HBM bytes per launch of one 256-frame sub-batch), CORRECTED: FETCH_SIZE x 1024 x %.3f + "
+                          "WRITE_SIZE x 1024 x %.3f (%s)" % (tag, ff, wf, src), "fetch_factor": ff, "write_factor": wf,
                "euroc752x480_8lvl_1000feat": traffic}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
     # VALU mix: instructions per frame from the counters, mean issue cost per instruction from the ISA classification (tools/valu_mix.py)
     cost = {}
