@@ -64,9 +64,9 @@ static inline short sat_short(float v) {
     return (short) (i < -32768 ? -32768 : i > 32767 ? 32767 : i);
 }
 
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_GRID, KK_COUNT };
-static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_quads", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes", "k_features_in_area"};
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_GRID, KK_FASTQ, KK_COUNT };
+static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_tab", "k_octree", "k_describe", "k_hamming_pairs",
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes", "k_features_in_area", "k_fast_quads"};
 
 struct Geometry {
     int w = 0, h = 0;
@@ -540,7 +540,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
             // widest cell and the pyramid offsets / frame sizes fit its 32-bit / 16-bit record fields
             const bool tab = c->fastKernel != YGZF_FAST_KERNEL_REGISTER_STAGING && G.fastWCellMax <= kFastTabMaxCell && G.pyrBytes < (1ll << 32) &&
                              G.w < 65536 && G.h < 65536 && G.totalSlots < (1ll << 32);
-            ProfScope ps(c, KK_FAST);
+            ProfScope ps(c, tab ? KK_FAST : KK_FASTQ);
             if (tab)
                 launch_fast_tab(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                 (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/fast_ab.py -- the two forms of the FAST cell loop side by side on the bench clip: per-kernel event timings (ygzf_profile_*) of an
-isolated 256-frame extract (+ match) with k_fast_quads (one wave per cell) and k_fast_stream (persistent waves, LDS-DMA prefetch), both
-threshold plans.  usage: python tools/fast_ab.py [frames=256] [reps=10]"""
+isolated 256-frame extract (+ match) with k_fast_quads (register staging, geometry derived per wave) and k_fast_tab (per-cell records,
+LDS-DMA staging), both threshold plans.  usage: python tools/fast_ab.py [frames=256] [reps=10]"""
 import json
 import os
 import sys
