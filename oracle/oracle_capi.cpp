@@ -143,6 +143,27 @@ int yo_extract_dso(void *e_, const uint8_t *img, int w, int h, int stride, KeyPo
     return n;
 }
 
+// operator()(Frame*, ..., FAST_KEYPOINT) (mode 1) / the Frame overload over the multi-level ComputeKeyPointsDSO (mode 3): keys holds
+// n_existing keys on entry; returns the total count (existing + new), -count when cap is too small
+int yo_extract_grid(void *e_, int mode, const uint8_t *img, int w, int h, int stride, KeyPoint *keys, int n_existing, int cap, uint8_t *desc, int *grid_size) {
+    Extractor *e = (Extractor *) e_;
+    std::vector<KeyPoint> k(keys, keys + n_existing);
+    std::vector<uint8_t> d;
+    if (mode == 1) e->ExtractFast(img, w, h, stride, k, d);
+    else {
+        e->mnGridSize = *grid_size;
+        e->ExtractDSOMultiLevel(img, w, h, stride, k, d);
+        *grid_size = e->mnGridSize;
+    }
+    const int n = (int) k.size();
+    if (n > cap) return -n;
+    if (n > 0) {
+        std::memcpy(keys, k.data(), sizeof(KeyPoint) * n);
+        std::memcpy(desc, d.data(), 32 * (size_t) n);
+    }
+    return n;
+}
+
 // the "existing ones" loop of the Frame overload (src/ORBextractor.cc:1093-1106) on the pyramid of `img`;
 // recompute != 0: IC_Angle first, as ComputeKeyPointsDSOSingleLevel :1380-1383 (angles are written back into keys)
 void yo_describe_keys(void *e_, const uint8_t *img, int w, int h, int stride, KeyPoint *keys, int n, int recompute, uint8_t *desc) {

@@ -500,4 +500,208 @@ void Extractor::ExtractDSO(const uint8_t *img, int w, int h, int stride, std::ve
     keys.insert(keys.end(), kps.begin(), kps.end());
 }
 
+// ---- FAST_KEYPOINT: ComputeKeyPointsFast :1189-1273 ---------------------------------------------------------------------
+// ComputeKeyPointsFast strips a 20-px margin at the top and the left only, so its corners come as close as 3 px to the right and bottom
+// borders, where IC_Angle's 15-px disc and the descriptor's rotated pattern (reach 19 px) read outside the level image: in the reference
+// those reads land in the next row or past the buffer (undefined; its author's warning at :1191).  DEFINED here: an out-of-image read sees
+// BORDER_REFLECT_101 of the image (what the extractor's own bordered pyramid, :1141-1146, holds around every level) -- identical to the
+// reference wherever the reference is defined (patch inside the image).
+static inline int reflect101(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+static inline int px_reflect(const Image &im, int x, int y) { return im.d[(size_t) reflect101(y, im.h) * im.w + reflect101(x, im.w)]; }
+static float ic_angle_reflect(const Extractor &E, const Image &image, float ptx, float pty) {
+    int m_01 = 0, m_10 = 0;
+    const int cx = cv_round(ptx), cy = cv_round(pty);
+    for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * px_reflect(image, cx + u, cy);
+    for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+        int v_sum = 0;
+        const int d = E.umax[v];
+        for (int u = -d; u <= d; ++u) {
+            const int val_plus = px_reflect(image, cx + u, cy + v), val_minus = px_reflect(image, cx + u, cy - v);
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return fast_atan2_deg((float) m_01, (float) m_10);
+}
+static void descriptor_reflect(const KeyPoint &kpt, const Image &img, uint8_t *desc) {
+    float a, b;
+    sincos_deg(kpt.angle, &a, &b);
+    const int cx = cv_round(kpt.x), cy = cv_round(kpt.y);
+    const int8_t *pattern = kOracleBriefPattern;
+#define GET_VALUE(idx)                                                                                             \
+    px_reflect(img, cx + cv_round((float) pattern[2 * (idx)] * a - (float) pattern[2 * (idx) + 1] * b),            \
+               cy + cv_round((float) pattern[2 * (idx)] * b + (float) pattern[2 * (idx) + 1] * a))
+    for (int i = 0; i < 32; ++i, pattern += 32) {
+        int val = 0;
+        for (int j = 0; j < 8; j++) {
+            const int t0 = GET_VALUE(2 * j), t1 = GET_VALUE(2 * j + 1);
+            val |= (t0 < t1) << j;
+        }
+        desc[i] = (uint8_t) val;
+    }
+#undef GET_VALUE
+}
+
+extern "C" void yo_fast10_score(const uint8_t *img, int stride, const short *xy, int n, int *scores);            // oracle_fast10.cpp
+extern "C" int yo_fast_nonmax_3x3(const short *xy, const int *scores, int n, int *out_idx, int cap);
+
+void Extractor::ComputeKeyPointsFast(std::vector<std::vector<KeyPoint>> &allKeypoints, std::vector<KeyPoint> &exist_kps) const {
+    const int mnCellSize = 5;
+    const int mnGridRows = mvImagePyramid[0].h / mnCellSize, mnGridCols = mvImagePyramid[0].w / mnCellSize;   // ceil() of an integer quotient (:1194-1195)
+    const long long nCells = (long long) mnGridCols * mnGridRows;
+    std::vector<uint8_t> occ((size_t) nCells, 0);
+    for (const KeyPoint &kp : exist_kps) {
+        const int gy = static_cast<int>((kp.y) / mnCellSize), gx = static_cast<int>((kp.x) / mnCellSize);
+        const long long k = (long long) gy * mnGridCols + gx;
+        if (k >= 0 && k < nCells) occ[(size_t) k] = 1;   // (the reference asserts / writes out of bounds otherwise)
+    }
+    std::vector<KeyPoint> gridFeatures((size_t) nCells);
+    for (KeyPoint &g : gridFeatures) { g.x = g.y = 0; g.size = 0; g.angle = -1; g.response = 0; g.octave = 0; g.class_id = -1; }
+    allKeypoints.assign(nlevels, std::vector<KeyPoint>());
+    for (int level = 0; level < nlevels; level++) {
+        const Image &img = mvImagePyramid[level];
+        const int scaledPatchSize = (int) (31 * mvScaleFactor[level]);
+        const float scale = mvScaleFactor[level];
+        const int boarder = 20;
+        if (img.w < 42 || img.h < 27) continue;   // DEFINED (header)
+        const uint8_t *data_start = &img.d[(size_t) boarder * img.w + boarder];
+        const int ww = img.w - boarder, wh = img.h - boarder;
+        std::vector<short> xy((size_t) 2 * ww * wh);
+        const int nc = yo_fast10_detect(data_start, ww, wh, img.w, iniThFAST, xy.data(), ww * wh);
+        std::vector<int> scores(std::max(nc, 1)), nm(std::max(nc, 1));
+        yo_fast10_score(data_start, img.w, xy.data(), nc, scores.data());
+        const int nn = yo_fast_nonmax_3x3(xy.data(), scores.data(), nc, nm.data(), nc);
+        for (int i = 0; i < nn; i++) {
+            const short x = (short) (xy[2 * nm[i]] + boarder), y = (short) (xy[2 * nm[i] + 1] + boarder);
+            const int gy = static_cast<int>((y * scale) / mnCellSize), gx = static_cast<int>((x * scale) / mnCellSize);
+            const long long k = (long long) gy * mnGridCols + gx;
+            if (k < 0 || k >= nCells) continue;   // DEFINED (header)
+            if (occ[(size_t) k]) continue;
+            const float s = ShiTomasiScore(img, x, y);
+            if (s > gridFeatures[(size_t) k].response) {
+                KeyPoint kp;
+                kp.x = x; kp.y = y; kp.size = (float) scaledPatchSize; kp.angle = -1; kp.response = s; kp.octave = level; kp.class_id = -1;
+                gridFeatures[(size_t) k] = kp;
+            }
+        }
+    }
+    for (KeyPoint &kp : gridFeatures)
+        if (kp.size > 0) {
+            kp.angle = ic_angle_reflect(*this, mvImagePyramid[kp.octave], kp.x, kp.y);
+            allKeypoints[kp.octave].push_back(kp);
+        }
+    for (KeyPoint &kp : exist_kps)
+        kp.angle = ic_angle_reflect(*this, mvImagePyramid[kp.octave], kp.x * mvInvScaleFactor[kp.octave], kp.y * mvInvScaleFactor[kp.octave]);
+}
+
+// the part of the Frame overload after the detector (:1063-1126): descriptors of the N existing keys at pt * invScale[octave] first, then
+// level after level the new keys (descriptor on the blurred level, pt *= scale for levels > 0)
+static void describe_and_concat(const Extractor &E, std::vector<std::vector<KeyPoint>> &all, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc) {
+    const int N = (int) keys.size();
+    size_t nk = (size_t) N;
+    for (auto &v : all) nk += v.size();
+    desc.assign(nk * 32, 0);
+    std::vector<Image> blurred(E.nlevels);
+    for (int i = 0; i < E.nlevels; i++) gaussian_blur7_s2_u8(E.mvImagePyramid[i], blurred[i]);
+    for (int i = 0; i < N; i++) {
+        KeyPoint tmp = keys[i];
+        tmp.x *= E.mvInvScaleFactor[tmp.octave];
+        tmp.y *= E.mvInvScaleFactor[tmp.octave];
+        descriptor_reflect(tmp, blurred[tmp.octave], &desc[(size_t) i * 32]);
+    }
+    size_t off = (size_t) N;
+    for (int level = 0; level < E.nlevels; level++) {
+        for (KeyPoint &kp : all[level]) {
+            descriptor_reflect(kp, blurred[level], &desc[off * 32]);
+            off++;
+        }
+        if (level != 0)
+            for (KeyPoint &kp : all[level]) { kp.x *= E.mvScaleFactor[level]; kp.y *= E.mvScaleFactor[level]; }
+        keys.insert(keys.end(), all[level].begin(), all[level].end());
+    }
+}
+
+void Extractor::ExtractFast(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc) {
+    ComputePyramid(img, w, h, stride);
+    std::vector<std::vector<KeyPoint>> all;
+    ComputeKeyPointsFast(all, keys);
+    describe_and_concat(*this, all, keys, desc);
+}
+
+// ---- multi-level DSO grid detector: ComputeKeyPointsDSO :1388-1507 -----------------------------------------------------------
+void Extractor::ComputeKeyPointsDSO(std::vector<std::vector<KeyPoint>> &allKeypoints, std::vector<KeyPoint> &exist_kps) {
+    const int w0 = mvImagePyramid[0].w, h0 = mvImagePyramid[0].h;
+    std::vector<uint8_t> occ((size_t) w0 * h0, 0);
+    for (KeyPoint &kp : exist_kps) {
+        const int ox = cv_round(kp.x), oy = cv_round(kp.y);
+        if (ox >= 0 && oy >= 0 && ox < w0 && oy < h0) occ[(size_t) oy * w0 + ox] = 255;
+    }
+    allKeypoints.assign(nlevels, std::vector<KeyPoint>());
+    std::vector<short> xy((size_t) 2 * 64 * 64 + 16);
+    for (int level = 0; level < nlevels; level++) {
+        const Image &img = mvImagePyramid[level];
+        const int h = img.h, w = img.w, n = mnFeaturesPerLevel[level];
+        if (n <= 0) continue;   // (sqrt of a division by zero in the reference)
+        mnGridSize = static_cast<int>(std::sqrt(1.0 * h * w / n));
+        if (mnGridSize < 1) mnGridSize = 1;
+        int cnt = 0;
+        while (cnt < n) {
+            if (cnt > 0) {
+                mnGridSize -= 5;
+                if (mnGridSize < 7) {
+                    mnGridSize = 7;
+                    break;
+                }
+            }
+            allKeypoints[level].clear();
+            const int grid_n_rows = h / mnGridSize, grid_n_cols = w / mnGridSize;
+            if ((size_t) mnGridSize * mnGridSize * 2 > xy.size()) xy.resize((size_t) mnGridSize * mnGridSize * 2);
+            cnt = 0;
+            for (int k = 0; k < grid_n_rows * grid_n_cols; k++) {
+                const int nn = k / grid_n_cols;
+                if (nn == 0 || nn == grid_n_rows - 1 || (k % grid_n_cols) == 0 || (k + 1) % grid_n_cols == 0) continue;
+                const int x_start = (k - nn * grid_n_cols) * mnGridSize, y_start = nn * mnGridSize;
+                const uint8_t *data = &img.d[(size_t) y_start * w + x_start];
+                int nc = yo_fast10_detect(data, mnGridSize, mnGridSize, w, iniThFAST, xy.data(), mnGridSize * mnGridSize);
+                if (nc == 0) nc = yo_fast10_detect(data, mnGridSize, mnGridSize, w, minThFAST, xy.data(), mnGridSize * mnGridSize);
+                if (nc == 0) continue;
+                std::vector<std::pair<std::pair<int, int>, float>> corner_score;
+                for (int c = 0; c < nc; c++) {
+                    const int x = xy[2 * c] + x_start, y = xy[2 * c + 1] + y_start;
+                    if (x < 20 || y < 20 || x >= w - 20 || y >= h - 20) continue;
+                    if (occ[(size_t) y * w0 + x] == 255) continue;   // level coordinates on the level-0 map (:1466)
+                    corner_score.push_back(std::make_pair(std::make_pair(x, y), ShiTomasiScore(img, x, y)));
+                }
+                std::stable_sort(corner_score.begin(), corner_score.end(),
+                                 [](const std::pair<std::pair<int, int>, float> &a, const std::pair<std::pair<int, int>, float> &b) { return a.second > b.second; });
+                const int take = corner_score.size() > 2 ? 2 : (int) corner_score.size();
+                for (int i = 0; i < take; i++) {
+                    KeyPoint kp;
+                    kp.x = (float) corner_score[i].first.first;
+                    kp.y = (float) corner_score[i].first.second;
+                    kp.size = 7; kp.response = 0; kp.octave = level; kp.class_id = -1;
+                    kp.angle = ICAngle(img, kp.x, kp.y);
+                    allKeypoints[level].push_back(kp);
+                    occ[(size_t) corner_score[i].first.second * w0 + corner_score[i].first.first] = 255;
+                    cnt++;
+                }
+            }
+            if (cnt == 0) break;   // DEFINED (header)
+        }
+    }
+    for (KeyPoint &kp : exist_kps) kp.angle = ICAngle(mvImagePyramid[kp.octave], kp.x * mvInvScaleFactor[kp.octave], kp.y * mvInvScaleFactor[kp.octave]);
+}
+
+void Extractor::ExtractDSOMultiLevel(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc) {
+    ComputePyramid(img, w, h, stride);
+    std::vector<std::vector<KeyPoint>> all;
+    ComputeKeyPointsDSO(all, keys);
+    describe_and_concat(*this, all, keys, desc);
+}
+
 }  // namespace ygzo

@@ -269,6 +269,19 @@ class RefFrameExtractor:
         assert n >= 0
         return _kp7_to_struct(kp[:n]), d[:n].copy()
 
+    def dso_multilevel(self, img, existing=None, cap=60000):
+        """ComputeKeyPointsDSO (the multi-level grid detector) -> (existing keys with fresh angles, new keys in LEVEL coordinates, mnGridSize)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        ex = _struct_to_kp7(existing) if existing is not None and len(existing) else np.zeros((0, 7), np.float32)
+        kp = np.zeros((cap, 7), np.float32)
+        g = C.c_int(-1)
+        self.L.yr_dso_multilevel.restype = C.c_int
+        self.L.yr_dso_multilevel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        n = self.L.yr_dso_multilevel(self.h, _p(img), w, h, w, _p(ex) if len(ex) else None, len(ex), _p(kp), cap, C.byref(g))
+        assert n >= 0
+        return _kp7_to_struct(ex), _kp7_to_struct(kp[:n]), g.value
+
 
 class Extractor:
     def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
@@ -353,6 +366,30 @@ class Extractor:
         n = self.L.yo_extract_dso(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g))
         assert n >= 0
         return k[:n].copy(), d[:n].copy(), g.value
+
+    def _extract_grid(self, mode, img, existing, grid_size, cap):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        existing = np.zeros(0, KP_DTYPE) if existing is None else np.ascontiguousarray(existing, KP_DTYPE)
+        cap = cap or (len(existing) + (w // 5) * (h // 5) * 2 + 16)
+        k = np.zeros(cap, KP_DTYPE)
+        k[:len(existing)] = existing
+        d = np.zeros((cap, 32), np.uint8)
+        g = C.c_int(grid_size)
+        self.L.yo_extract_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.POINTER(C.c_int)]
+        n = self.L.yo_extract_grid(self.h, mode, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g))
+        assert n >= 0
+        return k[:n].copy(), d[:n].copy(), g.value
+
+    def extract_fast(self, img, existing=None, cap=None):
+        """operator()(Frame*, ..., FAST_KEYPOINT) (ComputeKeyPointsFast) -> (keys (existing with fresh angles + new), desc)."""
+        k, d, _ = self._extract_grid(1, img, existing, -1, cap)
+        return k, d
+
+    def extract_dso_multilevel(self, img, existing=None, grid_size=-1, cap=None):
+        """The Frame overload over the multi-level ComputeKeyPointsDSO -> (keys, desc, mnGridSize after the call)."""
+        return self._extract_grid(3, img, existing, grid_size, cap)
 
     def describe_keys(self, img, keys, recompute_angle=False):
         """Descriptors (and optionally fresh IC_Angle) of existing keys -> (keys, desc)."""

@@ -46,7 +46,9 @@ YR_HIDDEN void operator delete[](void *, size_t) noexcept {}
 
 #include <opencv2/core/core.hpp>
 
-#include "ORBextractor.h"
+#define protected public   // test infrastructure only: ComputeKeyPointsDSO (the multi-level grid detector) is a protected member whose only call
+#include "ORBextractor.h"  // site in the reference is commented out (src/ORBextractor.cc:1053); the pin calls it directly
+#undef protected
 #include "Frame.h"
 
 static cv::Mat wrap(const uint8_t *img, int w, int h, int stride) {
@@ -125,6 +127,27 @@ int yr_frame_extract(void *h, const uint8_t *img, int w, int h_, int stride, int
     // Frame::ExtractFeatures passes the frame's own key vector as the output: (*mpORBextractorLeft)(this, mvKeys, mDescriptors, method, true)
     ex(&frame, frame.mvKeys, d, (ygz::ORBextractor::KeyPointMethod) method, true);
     return emit(frame.mvKeys, d, kp, desc, cap);
+}
+
+// ORBextractor::ComputeKeyPointsDSO (:1388-1507) on the pyramid of `img`: new keypoints of all levels in LEVEL coordinates (level order,
+// then the function's own order), the re-oriented angles of the existing keys, mnGridSize after the call.
+int yr_dso_multilevel(void *h, const uint8_t *img, int w, int h_, int stride, float *existing, int n_existing, float *kp, int cap, int *grid_size) {
+    ygz::ORBextractor &ex = *(ygz::ORBextractor *) h;
+    ex.ComputePyramid(wrap(img, w, h_, stride));
+    for (cv::Mat &m : ex.mvImagePyramid) m = m.clone();   // what the Frame overload installs (:1039): the Frame's border-less clones (src/Frame.cc:812);
+                                                          // the detector passes `cols` as the row stride (:1437)
+    std::vector<cv::KeyPoint> exist;
+    for (int i = 0; i < n_existing; i++) {
+        const float *e = existing + 7 * (size_t) i;
+        exist.push_back(cv::KeyPoint(e[0], e[1], e[2], e[3], e[4], (int) e[5], (int) e[6]));
+    }
+    std::vector<std::vector<cv::KeyPoint>> all;
+    ex.ComputeKeyPointsDSO(all, exist);
+    for (int i = 0; i < n_existing; i++) existing[7 * (size_t) i + 3] = exist[i].angle;
+    std::vector<cv::KeyPoint> flat;
+    for (auto &v : all) flat.insert(flat.end(), v.begin(), v.end());
+    *grid_size = ex.mnGridSize;
+    return emit(flat, cv::Mat(), kp, nullptr, cap);
 }
 
 }  // extern "C"

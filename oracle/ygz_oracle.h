@@ -91,6 +91,25 @@ public:
     // operator()(Frame*, vector<KeyPoint>&, OutputArray, DSO_KEYPOINT, leftEye = true) :1031-1127 on a frame whose pyramid is
     // computed from `img`: keys = frame->mvKeys (in: the N existing keys, out: + the new ones), desc = N_total x 32.
     void ExtractDSO(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc);
+    // ComputeKeyPointsFast :1189-1273 (the FAST_KEYPOINT branch of the Frame overload, :1045-1051): per level FAST-10 (libfast, barrier
+    // iniThFAST) on the image minus a 20-px top / left margin, score, >= non-maximum suppression; per 5x5-px cell of a level-0 grid the
+    // corner with the largest Shi-Tomasi score over all levels (first one on ties: level order, then libfast's order), cells holding an
+    // existing key excluded; IC_Angle; existing keys re-oriented.  DEFINED where the reference indexes out of bounds (its author: "has a
+    // bug which may corrupt the program", :1191): a key or corner whose cell index gy * cols + gx falls outside the grid is ignored
+    // (inside the grid the index is used as computed, row wrap included); levels narrower than 42 px or lower than 27 px are skipped (the
+    // SSE2 detector's plain fallback would read past the image rows).
+    void ComputeKeyPointsFast(std::vector<std::vector<KeyPoint>> &allKeypoints, std::vector<KeyPoint> &exist_kps) const;
+    // operator()(Frame*, ..., FAST_KEYPOINT, leftEye = true)
+    void ExtractFast(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc);
+    // ComputeKeyPointsDSO :1388-1507 (the multi-level grid detector; its call in the Frame overload is commented out, :1053): per level a
+    // grid of sqrt(h w / n_level) px, libfast at iniThFAST then minThFAST per inner cell, 20-px edge filter, occupancy test on the
+    // LEVEL-0-sized map indexed with LEVEL coordinates (:1466 -- kept), the 2 best Shi-Tomasi corners per cell, every selected corner
+    // marks the map at once and stays marked through the retry passes (grid - 5 while fewer than n_level corners, down to 7) and the
+    // later levels.  Ties of the score sort: raster order; a pass without a single corner ends the level (the reference would spin).
+    // mnGridSize is left at the last level's final value.
+    void ComputeKeyPointsDSO(std::vector<std::vector<KeyPoint>> &allKeypoints, std::vector<KeyPoint> &exist_kps);
+    // the Frame overload's descriptor / scaling / concatenation part (:1063-1126) over ComputeKeyPointsDSO's keypoints
+    void ExtractDSOMultiLevel(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &keys, std::vector<uint8_t> &desc);
     // operator()(InputArray, InputArray, vector<KeyPoint>&, OutputArray)  :970-1028
     void Extract(const uint8_t *img, int w, int h, int stride, std::vector<KeyPoint> &kps,
                  std::vector<uint8_t> &desc);
