@@ -330,6 +330,28 @@ int ygzf_align_fetch(ygzf_ctx *ctx, int frame, float *TCR_out, size_t *ret, floa
 int ygzf_extract_dso(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, ygzf_kp *keys, int n_existing, int cap, uint8_t *desc,
                      int *grid_size, int *n_total);
 
+/* ---- the same overload with method == FAST_KEYPOINT: ComputeKeyPointsFast   src/ORBextractor.cc:1045-1051, 1189-1273 -----------------
+ * Per level Thirdparty/fast's FAST-10 (barrier iniThFAST) on the level minus a 20-px top / left margin, fast_corner_score_10,
+ * fast_nonmax_3x3 (>=); one keypoint per 5x5-px cell of a level-0 grid: the corner with the largest Shi-Tomasi score over all levels
+ * (the first one on ties); cells that hold one of the frame's own keys stay empty; IC_Angle, descriptors, pt *= scale[level].
+ * keys in / out, desc, n_total as ygzf_extract_dso (new keys: size = (int)(31 * scale[level]), response = the Shi-Tomasi score).
+ * The reference's author marks the function "has a bug which may corrupt the program, don't call it" (:1191); defined here where it is
+ * undefined there: (i) it strips the margin on two sides only, so corners come within 3 px of the right / bottom borders, where IC_Angle and
+ * the descriptor read outside the level -- those reads see BORDER_REFLECT_101 (what the extractor's own bordered pyramid holds);
+ * (ii) a key or corner whose cell index falls outside the grid (image sizes that are no multiples of 5) is ignored; (iii) levels narrower
+ * than 42 px or lower than 27 px are skipped. */
+int ygzf_extract_fast_keypoint(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, ygzf_kp *keys, int n_existing, int cap, uint8_t *desc,
+                               int *n_total);
+
+/* ---- the same overload over the multi-level ComputeKeyPointsDSO   src/ORBextractor.cc:1388-1507 (its call is commented out at :1053) ----
+ * Per level: grid of sqrt(h w / mnFeaturesPerLevel) px, libfast at iniThFAST then minThFAST per inner cell, 20-px edge filter, the
+ * level-0-sized occupancy map indexed with level coordinates (:1466, kept), 2 best Shi-Tomasi corners per cell, every selected corner
+ * occupies its pixel at once and for the rest of the call; retry with grid - 5 (down to 7) while the level has fewer than its share.
+ * New keys: size 7, response 0, octave = level, pt *= scale[level].  grid_size: mnGridSize before / after (only the value after matters:
+ * the function recomputes it per level).  Definitions as ygzf_extract_dso. */
+int ygzf_extract_dso_multilevel(ygzf_ctx *ctx, const uint8_t *img, int w, int h, int stride, ygzf_kp *keys, int n_existing, int cap, uint8_t *desc,
+                                int *grid_size, int *n_total);
+
 /* Descriptors (and optionally IC_Angle) of keys that already exist in a frame -- the "existing ones" loop of the Frame overload,
  * src/ORBextractor.cc:1093-1106 -- on the pyramid of frame `frame` of the last extracted batch.  keys hold level-0 coordinates and the
  * octave they live on; the descriptor is taken at cvRound(pt * mvInvScaleFactor[octave]) on the blurred level.

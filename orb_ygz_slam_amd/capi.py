@@ -135,6 +135,8 @@ def load_library(build_if_missing=True):
     L.ygzf_fast10.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, ip, ip]
     L.ygzf_describe_keys.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
     L.ygzf_extract_dso.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, ip, ip]
+    L.ygzf_extract_dso_multilevel.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, ip, ip]
+    L.ygzf_extract_fast_keypoint.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
     L.ygzf_profile_enable.argtypes = [vp, C.c_int]
@@ -632,6 +634,32 @@ class Extractor:
         d = np.zeros((cap, 32), np.uint8)
         g, n = C.c_int(grid_size), C.c_int()
         self._ck(self.L.ygzf_extract_dso(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g), C.byref(n)))
+        return k[:n.value].copy(), d[:n.value].copy(), g.value
+
+    def extract_fast_keypoint(self, img, existing=None, cap=None):
+        """operator()(Frame*, ..., FAST_KEYPOINT) = ComputeKeyPointsFast: (keys = existing (re-oriented) + one per 5-px cell, desc)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        existing = np.zeros(0, KP_DTYPE) if existing is None else np.ascontiguousarray(existing, KP_DTYPE)
+        cap = cap or (len(existing) + (w // 5) * (h // 5) + 16)
+        k = np.zeros(cap, KP_DTYPE)
+        k[:len(existing)] = existing
+        d = np.zeros((cap, 32), np.uint8)
+        n = C.c_int()
+        self._ck(self.L.ygzf_extract_fast_keypoint(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(n)))
+        return k[:n.value].copy(), d[:n.value].copy()
+
+    def extract_dso_multilevel(self, img, existing=None, grid_size=-1, cap=None):
+        """The Frame overload over the multi-level ComputeKeyPointsDSO: (keys, desc, mnGridSize after the call)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        existing = np.zeros(0, KP_DTYPE) if existing is None else np.ascontiguousarray(existing, KP_DTYPE)
+        cap = cap or (len(existing) + 2 * (w // 5) * (h // 5) + 16)
+        k = np.zeros(cap, KP_DTYPE)
+        k[:len(existing)] = existing
+        d = np.zeros((cap, 32), np.uint8)
+        g, n = C.c_int(grid_size), C.c_int()
+        self._ck(self.L.ygzf_extract_dso_multilevel(self.h, _p(img), w, h, w, _p(k), len(existing), cap, _p(d), C.byref(g), C.byref(n)))
         return k[:n.value].copy(), d[:n.value].copy(), g.value
 
     def vocabulary_set(self, parent, desc, depth_levels):

@@ -110,14 +110,12 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
 //   ORBSLAM_KEYPOINT  octree keypoints on all levels; keys the frame already holds (direct-tracked) keep their angle and get
 //                     descriptors first (:1093-1106)
 //   DSO_KEYPOINT      FAST-10 grid keypoints on level 0 beside the frame's existing keys (ComputeKeyPointsDSOSingleLevel)
-//   FAST_KEYPOINT     never requested by the reference and marked "has a bug ... don't call" by its author (:1191): reported, not run.
+//   FAST_KEYPOINT     ComputeKeyPointsFast (:1189-1273): one Shi-Tomasi winner per 5-px cell over the libfast corners of all levels; never
+//                     requested by the reference's own callers and marked "has a bug ... don't call" by its author (:1191) -- provided with
+//                     the undefined parts defined (include/ygzf.h, ygzf_extract_fast_keypoint)
 // There is no CPU fallback: on a device error the outputs stay untouched and the error is printed.
 void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoints, cv::OutputArray _descriptors, KeyPointMethod method,
                               bool leftEye) {
-    if (method == FAST_KEYPOINT) {
-        fprintf(stderr, "ygz::ORBextractor: FAST_KEYPOINT (ComputeKeyPointsFast) is not provided -- the reference never calls it\n");
-        return;
-    }
     static_assert(sizeof(cv::KeyPoint) == sizeof(ygzf_kp), "cv::KeyPoint layout");
     const cv::Mat &img = leftEye ? (frame->mvImagePyramid.empty() ? frame->mImGray : frame->mvImagePyramid[0]) : frame->mImRight;
     if (!leftEye) ComputePyramid(img);          // right eye: the extractor's own pyramid is read by ComputeStereoMatches
@@ -129,7 +127,22 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
     if (!c) return;
     std::vector<cv::KeyPoint> fresh;            // the new keypoints
     std::vector<uint8_t> descExisting((size_t) N * 32), descNew;
-    if (method == DSO_KEYPOINT) {
+    if (method == FAST_KEYPOINT) {
+        const int cap = N + (img.cols / 5) * (img.rows / 5) + 16;
+        std::vector<cv::KeyPoint> all(cap);
+        std::vector<uint8_t> d((size_t) cap * 32);
+        for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];   // right eye: ComputeKeyPointsFast gets an empty list (:1049-1050)
+        int total = 0;
+        if (ygzf_extract_fast_keypoint(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &total) != YGZF_OK) {
+            fprintf(stderr, "ygz::ORBextractor (FAST_KEYPOINT): %s\n", ygzf_last_error(c));
+            return;
+        }
+        for (int i = 0; i < N; i++) frame->mvKeys[i].angle = all[i].angle;   // ComputeKeyPointsFast re-orients them (:1268-1271)
+        fresh.assign(all.begin() + N, all.begin() + total);
+        std::memcpy(descExisting.data(), d.data(), (size_t) N * 32);
+        descNew.assign(d.begin() + (size_t) N * 32, d.begin() + (size_t) total * 32);
+        mResidentLevel0 = cv::Mat();
+    } else if (method == DSO_KEYPOINT) {
         const int g0 = mnGridSize > 0 ? mnGridSize : std::max(1, (int) std::sqrt(1.0 * img.rows * img.cols / std::max(nfeatures, 1)));
         const int gm = std::max(1, std::min(7, g0));   // smallest grid the retry loop can reach
         const int cap = N + 3 * (img.cols / gm) * (img.rows / gm) + 16;

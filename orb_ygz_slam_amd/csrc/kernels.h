@@ -123,9 +123,14 @@ void launch_fast10(hipStream_t st, const uint8_t *img, int pitch, int x0, int y0
 // ---- FAST-10 grid detector of the DSO_KEYPOINT path (dso_kernels.hip) + list describe (extract_kernels.hip) -----------------
 constexpr int kDsoMaxGrid = 64;   // largest supported mnGridSize (cell side in px)
 void launch_dso_occ(hipStream_t st, const unsigned *xy, int n, int w, int h, unsigned *occ);
-void launch_dso_cells(hipStream_t st, const uint8_t *img, int pitch, int w, int h, int grid, int nCols, int nRows, const unsigned *occ, int *cellCnt,
-                      unsigned *cellXY, int *total);
-void launch_dso_compact(hipStream_t st, const int *cellCnt, const unsigned *cellXY, int nInner, int nExisting, void *list, unsigned *newXY);
+void launch_dso_cells(hipStream_t st, const uint8_t *img, int pitch, int w, int h, int grid, int nCols, int nRows, unsigned *occ, int *cellCnt,
+                      unsigned *cellXY, int *total, int th0, int th1, int take, int occW, bool mark);
+void launch_dso_compact(hipStream_t st, const int *cellCnt, const unsigned *cellXY, int nInner, int nExisting, void *list, unsigned *newXY, int level);
+// ComputeKeyPointsFast: per-cell Shi-Tomasi vote over the levels' non-max-suppressed libfast corners, then the winners' coordinates
+void launch_fgrid_vote(hipStream_t st, const uint8_t *img, int pitch, int w, int h, int level, float scale, const short *xy, const int *nonmax,
+                       const int *totals, int maxNonmax, int gridCols, long long nCells, const uint8_t *occ, unsigned long long *cellKey);
+void launch_fgrid_gather(hipStream_t st, const unsigned long long *cellKey, long long nCells, const short *xyAll, const int *nmAll, const long long *lvlOff,
+                         unsigned *cellXY);
 void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,
                           float *outAngle, uint8_t *outDesc, int cvMode);
 

@@ -161,6 +161,15 @@ int main(int argc, char **argv) {
         ex(&C2, C2.mvKeys, cv::_OutputArray(C2.mDescriptors), ORBextractor::DSO_KEYPOINT, true);
         dump(dir + "/c2_kps.bin", C2.mvKeys.data(), C2.mvKeys.size() * sizeof(cv::KeyPoint));
         dump(dir + "/c2_desc.bin", C2.mDescriptors.ptr(0), C2.mvKeys.size() * 32);
+        // FAST_KEYPOINT (ComputeKeyPointsFast) on a frame that already holds keys: occupancy of their 5-px cells, re-oriented, new keys appended
+        Frame E = B;
+        E.mvKeys.assign(B.mvKeys.begin() + 5, B.mvKeys.begin() + 125);
+        for (auto &k : E.mvKeys) k.angle = 0.f;
+        E.N = 120;
+        E.mDescriptors = cv::Mat();
+        ex(&E, E.mvKeys, cv::_OutputArray(E.mDescriptors), ORBextractor::FAST_KEYPOINT, true);
+        dump(dir + "/e_kps.bin", E.mvKeys.data(), E.mvKeys.size() * sizeof(cv::KeyPoint));
+        dump(dir + "/e_desc.bin", E.mDescriptors.ptr(0), E.mvKeys.size() * 32);
         // ORBSLAM_KEYPOINT on a frame that already holds keys: their angle is kept, descriptors first, new keys appended
         Frame D = B;
         D.mvKeys.assign(B.mvKeys.begin() + 10, B.mvKeys.begin() + 70);

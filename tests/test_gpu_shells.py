@@ -119,6 +119,12 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     kc2 = np.fromfile(tmp_path / "c2_kps.bin", KP_DTYPE)
     dc2 = np.fromfile(tmp_path / "c2_desc.bin", np.uint8).reshape(-1, 32)
     assert len(kc2) == len(ko2) > 80 and (kc2 == ko2).all() and (dc2 == do2).all()
+    stale_e = kb[5:125].copy()
+    stale_e["angle"] = 0
+    koe, doe = oex2.extract_fast(imgB, existing=stale_e)            # FAST_KEYPOINT branch
+    ke = np.fromfile(tmp_path / "e_kps.bin", KP_DTYPE)
+    de = np.fromfile(tmp_path / "e_desc.bin", np.uint8).reshape(-1, 32)
+    assert len(ke) == len(koe) > 1000 and (ke == koe).all() and (de == doe).all()
     kd = np.fromfile(tmp_path / "d_kps.bin", KP_DTYPE)
     dd = np.fromfile(tmp_path / "d_desc.bin", np.uint8).reshape(-1, 32)
     _, dex = oex2.describe_keys(imgB, kb[10:70])
