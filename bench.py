@@ -354,6 +354,31 @@ def end_to_end(pipe, min_seconds=1.2, depth=2):
     return B * batches, time.perf_counter() - t0
 
 
+def mgpu_end_to_end(devices, cfg, frames, min_seconds=1.0):
+    """The product's own multi-GPU entry point (ygzf_mgpu_extract_match, include/ygzf.h): host frames in, every keypoint / descriptor / match
+    out in input order, frame pairs dealt round-robin over the device slots (one host thread + context per slot).  With one device the two
+    slots both sit on it (what hides the transfers of one slot behind the kernels of the other)."""
+    from orb_ygz_slam_amd import MultiGpu, make_camera
+    w, h, nl, sf, nf, ini, mn = cfg
+    slots = list(devices) if len(devices) > 1 else [devices[0], devices[0]]
+    per = 128
+    n = per * len(slots)
+    clip = np.ascontiguousarray(np.concatenate([frames] * ((n + len(frames) - 1) // len(frames)))[:n])
+    mg = MultiGpu(slots, nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=per)
+    cam = make_camera(w, h)
+    out = mg.extract_match(clip, unit=2, cam=cam)
+    t0 = time.perf_counter()
+    calls = 0
+    while calls < 2 or time.perf_counter() - t0 < min_seconds:
+        mg.extract_match(clip, unit=2, cam=cam, out=out)
+        calls += 1
+    sec = time.perf_counter() - t0
+    mg.close()
+    return {"value": round(calls * n / sec, 1), "unit": "frames/s", "frames_per_call": n, "calls": calls, "device_slots": slots, "unit_frames": 2,
+            "what": "ygzf_mgpu_extract_match: pageable host frames -> per-slot page-locked staging -> H2D -> extract + match of every pair -> D2H -> "
+                    "host arrays in input order (synchronous calls: no overlap between calls, only between slots)"}
+
+
 def kernel_table(prof):
     return {name: {"launches": n, "avg_us": round(1e3 * ms / n, 2), "total_ms": round(ms, 3)} for name, (ms, n) in prof.items() if n}
 
@@ -491,14 +516,29 @@ def main():
         return float(t[0])
 
     if args.plumbing_selftest:
-        # exercises sharding, barrier and max-over-ranks reduction without a GPU; never a valid measurement
+        # exercises the N > 1 path without a GPU, with REAL data through every step it has: the clip is dealt round-robin over the ranks (the
+        # sharding of DESIGN.md section 5), every rank runs the CPU oracle on its shard, the per-frame keypoint counts are all-gathered,
+        # the elapsed time is max-reduced.  Never a valid measurement.
+        from oracle import oracle_py as O
+        from orb_ygz_slam_amd.synth import synth_frame
+        pw, ph, pn = 320, 240, 8
+        clip = np.stack([synth_frame(4000 + i, pw, ph) for i in range(pn)])
+        mine = list(range(rank, pn, world))
         barrier()
         t0 = time.perf_counter()
+        oex = O.Extractor(500, 1.2, 4, 20, 7)
+        counts = torch.full((pn,), -1, dtype=torch.int64)
+        for f in mine:
+            counts[f] = len(oex.extract(clip[f])[0])
         time.sleep(0.01 * (rank + 1))
         el = max_over_ranks(time.perf_counter() - t0)
+        if dist is not None:
+            gathered = [torch.empty_like(counts) for _ in range(world)]
+            dist.all_gather(gathered, counts)
+            counts = torch.stack(gathered).max(dim=0).values      # every frame was counted by exactly one rank
         if rank == 0:
             print(json.dumps({"plumbing_selftest": True, "n_gpus": world, "frames_per_rank": B, "max_elapsed_s": el,
-                              "valid_measurement": False}))
+                              "shard_keypoint_counts": [int(x) for x in counts], "sharding": "frame f -> rank f % world", "valid_measurement": False}))
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -571,6 +611,10 @@ def main():
                "what": "pinned host frames -> H2D -> extract + match -> D2H of all keypoints, descriptors and counts; two contexts "
                        "software-pipelined per GPU (device 0 of each process)"}
 
+    mgpu = None
+    if not args.no_extras and world == 1:
+        mgpu = mgpu_end_to_end(devices, cfg, frames0)
+
     # ---- short runs of the other BASELINE configurations (their own contexts; each rank its own clip) ----
     others = {}
     if not args.no_extras and args.workload == "euroc752x480_8lvl_1000feat" and not args.align and not args.stereo:
@@ -639,7 +683,7 @@ def main():
                        "match": "SearchByProjection(cur,last) th=15, identity pose", "fast_plan": fast_plan, "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
                        "sharding": "one clip per GPU, no collective"},
             "timed_region_s": round(elapsed, 4),
-            "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e,
+            "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "mgpu_end_to_end": mgpu,
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "roofline": hbm_roofline(args.workload, kernels, iso, per_kernel, sub, total_bytes, fps / n_gpus) if kernels else None,
             "roofline_valu": valu_roofline(args.workload, kernels, iso, sub) if kernels else None,

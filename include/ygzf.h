@@ -413,6 +413,27 @@ int ygzf_find_direct_projection_batch(ygzf_ctx *ctx, const ygzf_camera *cam, int
 int ygzf_fast10(ygzf_ctx *ctx, const uint8_t *img, int img_w, int img_h, int stride, int x0, int y0, int w, int h, int barrier, int16_t *xy,
                 int *scores, int *nonmax_idx, int cap, int *n_corners, int *n_nonmax);
 
+/* ---- multi-GPU: frames dealt over the devices of one node ----------------------------------------------------------------------
+ * Frames are independent and SearchByProjection couples frame t only with t - 1, so the split is "one unit per GPU, round-robin": a unit =
+ * `unit` consecutive frames that must stay together (1: single frames, 2: frame pairs / stereo pairs, k: clips of k frames); unit u is
+ * processed by devices[u % n_devices].  One host thread + one context + page-locked staging per device slot; results come back in INPUT order;
+ * no collective, no peer copy.  `devices` may name a device more than once (several slots on one GPU: how the 1-GPU test box exercises
+ * the split); a device index that does not exist is YGZF_ERR_NO_DEVICE.
+ * ygzf_mgpu_extract_match: ORBextractor::operator() of every frame and, when match / nmatches are given, SearchByProjection(frame i, frame
+ * i - 1) inside every unit with the synthetic scenario of ygzf_match_batch_prev (first frame of a unit: nmatches = -1, match row = -1).
+ * kps / desc / match hold n_frames rows of `stride` (>= ygzf_mgpu_keypoint_stride) entries; frame f's first n_kp[f] entries are valid. */
+typedef struct ygzf_mgpu ygzf_mgpu;
+int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg *cfg, int max_width, int max_height, int max_frames_per_device,
+                     ygzf_mgpu **out);
+void ygzf_mgpu_destroy(ygzf_mgpu *m);
+const char *ygzf_mgpu_last_error(const ygzf_mgpu *m);
+int ygzf_mgpu_device_count(const ygzf_mgpu *m);
+int ygzf_mgpu_keypoint_stride(const ygzf_mgpu *m);
+int ygzf_mgpu_slot_of_frame(const ygzf_mgpu *m, int frame, int unit);   /* which device slot processes this frame */
+int ygzf_mgpu_extract_match(ygzf_mgpu *m, const uint8_t *frames, int n_frames, int w, int h, int row_pitch, size_t frame_stride, int unit,
+                            const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation, ygzf_kp *kps, uint8_t *desc,
+                            int *n_kp, int stride, int *match, int *nmatches);
+
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------
  * HIP events recorded on the context stream (the stream every kernel of this context is launched on). */
 int ygzf_timer_start(ygzf_ctx *ctx);

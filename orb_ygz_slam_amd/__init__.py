@@ -5,4 +5,4 @@ This Python package is plumbing only: a ctypes binding of lib/libygzf.so used by
 is the shared library (hand-written HIP kernels + C++ host code).  There is NO CPU fallback: importing works without a
 GPU (so that the CPU test tier can check the exported symbols), but creating a context raises without a HIP device.
 """
-from .capi import Extractor, YgzfError, load_library, KP_DTYPE, Camera, make_camera, EUROC  # noqa: F401
+from .capi import Extractor, MultiGpu, YgzfError, load_library, KP_DTYPE, Camera, make_camera, EUROC  # noqa: F401

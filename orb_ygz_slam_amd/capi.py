@@ -139,6 +139,16 @@ def load_library(build_if_missing=True):
     L.ygzf_extract_fast_keypoint.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, ip]
     L.ygzf_timer_start.argtypes = [vp]
     L.ygzf_timer_stop.argtypes = [vp, fp]
+    L.ygzf_mgpu_create.argtypes = [ip, C.c_int, C.POINTER(ExtractorCfg), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ygzf_mgpu_destroy.argtypes = [vp]
+    L.ygzf_mgpu_destroy.restype = None
+    L.ygzf_mgpu_last_error.argtypes = [vp]
+    L.ygzf_mgpu_last_error.restype = C.c_char_p
+    L.ygzf_mgpu_device_count.argtypes = [vp]
+    L.ygzf_mgpu_keypoint_stride.argtypes = [vp]
+    L.ygzf_mgpu_slot_of_frame.argtypes = [vp, C.c_int, C.c_int]
+    L.ygzf_mgpu_extract_match.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.POINTER(Camera), C.c_float, C.c_int, C.c_int,
+                                          C.c_int, vp, vp, vp, C.c_int, vp, vp]
     L.ygzf_profile_enable.argtypes = [vp, C.c_int]
     L.ygzf_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), fp, ip, C.c_int]
     L.ygzf_profile_reset.argtypes = [vp]
@@ -752,3 +762,52 @@ class Extractor:
         n = (C.c_int * 32)()
         k = self._ck(self.L.ygzf_profile_read(self.h, names, ms, n, 32))
         return {names[i].decode(): (ms[i], n[i]) for i in range(k)}
+
+
+class MultiGpu:
+    """ygzf_mgpu_*: frames (or units of consecutive frames) dealt round-robin over device slots, one host thread + context per slot, results
+    in input order (include/ygzf.h).  `devices` may repeat a device index (several slots on one GPU)."""
+
+    def __init__(self, devices, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, max_width=752, max_height=480,
+                 max_frames_per_device=64, cv_mode=CV_LEGACY_SSE2):
+        self.L = load_library()
+        self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th, cv_mode)
+        dv = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.L.ygzf_mgpu_create(dv, len(devices), C.byref(self.cfg), max_width, max_height, max_frames_per_device, C.byref(h))
+        if rc != 0:
+            raise YgzfError("ygzf_mgpu_create failed (%d): %s" % (rc, self.L.ygzf_last_error(None).decode()))
+        self.h = h
+        self.stride = self.L.ygzf_mgpu_keypoint_stride(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ygzf_mgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_count(self):
+        return self.L.ygzf_mgpu_device_count(self.h)
+
+    def slot_of_frame(self, frame, unit=1):
+        return self.L.ygzf_mgpu_slot_of_frame(self.h, frame, unit)
+
+    def extract_match(self, frames, unit=1, cam=None, th=15.0, mono=True, check_level=True, check_ori=True, out=None):
+        """-> (kps [n, stride], desc [n, stride, 32], n_kp [n], match [n, stride] or None, nmatches [n] or None); matching when cam is given"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        if out is None:
+            out = (np.zeros((n, self.stride), KP_DTYPE), np.zeros((n, self.stride, 32), np.uint8), np.zeros(n, np.int32),
+                   np.full((n, self.stride), -1, np.int32) if cam is not None else None, np.zeros(n, np.int32) if cam is not None else None)
+        k, d, c, m, nm = out
+        rc = self.L.ygzf_mgpu_extract_match(self.h, _p(frames), n, w, h, w, w * h, unit, C.byref(cam) if cam is not None else None, th, int(mono),
+                                            int(check_level), int(check_ori), _p(k), _p(d), _p(c), self.stride, _p(m) if m is not None else None,
+                                            _p(nm) if nm is not None else None)
+        if rc != 0:
+            raise YgzfError("ygzf_mgpu_extract_match failed (%d): %s" % (rc, self.L.ygzf_mgpu_last_error(self.h).decode()))
+        return k, d, c, m, nm

@@ -1,5 +1,6 @@
 """CPU tier: the N > 1 path of bench.py (one process per GPU, barrier, max-over-ranks reduction, rank-0 JSON) exercised
-with world_size 2 on the gloo backend.  No GPU work is done in this mode and the line is marked as not a measurement."""
+with world_size 2 on the gloo backend, with real data: the ranks share a clip round-robin, run the CPU oracle on their shards and
+all-gather the per-frame keypoint counts, which must equal an unsharded run.  The line is marked as not a measurement."""
 import json
 import os
 import socket
@@ -29,6 +30,13 @@ def test_two_rank_gloo_plumbing():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["plumbing_selftest"] and not d["valid_measurement"]
     assert d["max_elapsed_s"] >= 0.02           # the MAX over ranks (rank 1 sleeps 20 ms)
+    # the sharded counts equal an unsharded oracle run over the same clip
+    sys.path.insert(0, ROOT)
+    from oracle import oracle_py as O
+    from orb_ygz_slam_amd.synth import synth_frame
+    oex = O.Extractor(500, 1.2, 4, 20, 7)
+    want = [len(oex.extract(synth_frame(4000 + i, 320, 240))[0]) for i in range(8)]
+    assert d["shard_keypoint_counts"] == want and min(want) > 50
 
 
 def test_algorithmic_bytes_match_survey():

@@ -1,0 +1,83 @@
+"""The product's multi-GPU split (ygzf_mgpu_*) on the one GPU the test box has: device slots mapped onto device 0 (every slot its own
+context, stream, staging and host thread).  A sharded batch must return the bytes of the unsharded one in input order, units (frame pairs) are
+never split over slots, a slot that gets no frame is harmless, a device that does not exist is an error -- and bench.py's in-process sharding
+flag still produces a valid line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(n, w, h):
+    frames = np.empty((n, h, w), np.uint8)
+    for i in range(n):
+        if i % 4 == 0:
+            scene = synth_frame(700 + i // 4, w + 16, h + 16)
+        frames[i] = scene[2 * (i % 4):2 * (i % 4) + h, 3 * (i % 4):3 * (i % 4) + w]
+    return frames
+
+
+@pytest.mark.parametrize("unit", [1, 2, 4])
+def test_sharded_equals_unsharded(oracle, unit):
+    from orb_ygz_slam_amd import MultiGpu, make_camera
+    w, h, n = 640, 480, 24
+    frames = _clip(n, w, h)
+    cam = make_camera(w, h)
+    one = MultiGpu([0], max_width=w, max_height=h, max_frames_per_device=n)
+    ref = one.extract_match(frames, unit=unit, cam=cam)
+    one.close()
+    for slots in ([0, 0], [0, 0, 0], [0] * 5):
+        mg = MultiGpu(slots, max_width=w, max_height=h, max_frames_per_device=n)
+        assert mg.device_count() == len(slots)
+        got = mg.extract_match(frames, unit=unit, cam=cam)
+        for f in range(n):                                            # a unit's frames share a slot, consecutive units take consecutive slots
+            assert mg.slot_of_frame(f, unit) == (f // unit) % len(slots)
+        mg.close()
+        for a, b, name in zip(ref, got, ("kps", "desc", "n_kp", "match", "nmatches")):
+            assert np.array_equal(a, b), (slots, unit, name)
+    k, d, c, m, nm = ref
+    assert (c > 500).all()
+    assert ((nm == -1) == (np.arange(n) % unit == 0)).all()           # first frame of a unit has no predecessor
+    if unit > 1:
+        assert (nm[np.arange(n) % unit != 0] > 100).all()
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)                         # and the contents are the extractor's
+    for f in (0, n // 2 + 1, n - 1):
+        ok, od = oex.extract(frames[f])
+        assert c[f] == len(ok) and (k[f, :c[f]] == ok).all() and (d[f, :c[f]] == od).all()
+
+
+def test_extract_only_and_idle_slots():
+    from orb_ygz_slam_amd import MultiGpu
+    w, h = 320, 240
+    frames = _clip(3, w, h)
+    mg = MultiGpu([0, 0, 0, 0, 0, 0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=4)      # more slots than frames
+    k, d, c, m, nm = mg.extract_match(frames)
+    assert m is None and nm is None and (c > 50).all()
+    k2, d2, c2, _, _ = mg.extract_match(frames[::-1].copy())             # a second call on the same handle
+    assert np.array_equal(c2, c[::-1]) and np.array_equal(k2, k[::-1]) and np.array_equal(d2, d[::-1])
+    mg.close()
+
+
+def test_missing_device_is_an_error():
+    from orb_ygz_slam_amd import MultiGpu, YgzfError
+    import torch
+    with pytest.raises(YgzfError):
+        MultiGpu([0, torch.cuda.device_count()], max_width=320, max_height=240, max_frames_per_device=2)
+
+
+def test_bench_in_process_devices_on_one_gpu():
+    """bench.py --devices-in-process 2 --reuse-devices: two logical devices (threads, contexts, gate barriers) on the box's single GPU"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--devices-in-process", "2", "--reuse-devices", "--steps", "2", "--warmup", "1",
+                          "--batch", "768", "--passes", "1", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["devices_reused"] is True and line["config"]["devices_per_process"] == 2 and line["n_gpus"] == 2
+    assert line["value"] > 0 and line["steps"] == 2 and line["config"]["frames_per_gpu_per_step"] == 768
