@@ -14,10 +14,29 @@ DeviceORBVocabulary::~DeviceORBVocabulary() { ygzf_destroy(mCtx); }
 void DeviceORBVocabulary::invalidateDevice() {
     std::lock_guard<std::mutex> lk(mMutex);
     mUploadedNodes = 0;
+    mUploadedPrint = 0;
+}
+
+// What identifies the tree the device holds: node count, depth, branching, and the centroid + weight of a spread of nodes (first, last and 62
+// in between).  The loaders (loadFromTextFile / loadFromBinaryFile / create) are untouched reference code and cannot tell this class that
+// they ran; a reloaded or retrained vocabulary of the same shape differs in these samples.
+unsigned long long DeviceORBVocabulary::treePrint() const {
+    unsigned long long hsh = 1469598103934665603ull ^ ((unsigned long long) m_nodes.size() << 16) ^ ((unsigned long long) m_L << 8) ^ (unsigned long long) m_k;
+    const size_t n = m_nodes.size();
+    for (size_t j = 0; j < 64 && n > 0; j++) {
+        const size_t i = n <= 64 ? (j < n ? j : n - 1) : j * (n - 1) / 63;
+        unsigned long long v[5] = {0, 0, 0, 0, 0};
+        if (m_nodes[i].descriptor.cols == 32 && m_nodes[i].descriptor.data) std::memcpy(v, m_nodes[i].descriptor.data, 32);
+        std::memcpy(&v[4], &m_nodes[i].weight, sizeof(double) < 8 ? sizeof(double) : 8);
+        for (unsigned long long x : v) hsh = (hsh ^ x) * 1099511628211ull;
+        hsh = (hsh ^ (unsigned long long) m_nodes[i].parent) * 1099511628211ull;
+    }
+    return hsh ? hsh : 1;
 }
 
 bool DeviceORBVocabulary::ensureDevice() const {
-    if (mCtx && mUploadedNodes == m_nodes.size()) return true;
+    const unsigned long long print = treePrint();
+    if (mCtx && mUploadedNodes == m_nodes.size() && mUploadedPrint == print) return true;
     if (!mCtx) {
         ygzf_extractor_cfg cfg = {1000, 1.2f, 8, 20, 7, 0};   // only the context's stream and buffers are used
         if (ygzf_create(ORBextractor::sDevice, &cfg, 64, 64, 1, &mCtx) != YGZF_OK) {
@@ -34,7 +53,8 @@ bool DeviceORBVocabulary::ensureDevice() const {
         if (i > 0 && m_nodes[i].descriptor.cols == 32) std::memcpy(&desc[(size_t) i * 32], m_nodes[i].descriptor.data, 32);
     }
     // children order on the device = ascending node id; the loaders push children in that order too (loadFromTextFile :1409-1416, load
-    // :1692-1705 for vocabularies saved by DBoW2).  Verified here, node by node: a vocabulary that breaks it falls back to the CPU class.
+    // :1692-1705 for vocabularies saved by DBoW2).  Verified here, node by node: a vocabulary that breaks it is refused with a message that
+    // says so (transform() then returns empty vectors: libygzf has no CPU fallback; ORBVocabulary::transform is the host path to call instead).
     for (int i = 0; i < n; i++) {
         const std::vector<DBoW2::NodeId> &ch = m_nodes[i].children;
         for (size_t k = 1; k < ch.size(); k++)
@@ -45,6 +65,7 @@ bool DeviceORBVocabulary::ensureDevice() const {
         return false;
     }
     mUploadedNodes = m_nodes.size();
+    mUploadedPrint = print;
     return true;
 }
 
@@ -58,9 +79,14 @@ void DeviceORBVocabulary::transform(const std::vector<DBoW2::FORB::TDescriptor> 
         std::lock_guard<std::mutex> lk(mMutex);   // Tracking and LoopClosing threads share the vocabulary object
         std::vector<uint8_t> desc((size_t) n * 32);
         for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t) i * 32], features[i].data, 32);
-        if (!ensureDevice() || ygzf_bow_transform(mCtx, n, desc.data(), levelsup, leaf.data(), nid.data()) != YGZF_OK) {
-            if (mCtx) fprintf(stderr, "ygz::DeviceORBVocabulary::transform: %s\n", ygzf_last_error(mCtx));
-            return;   // no CPU fallback: the vectors stay empty and the error is on stderr
+        if (!ensureDevice()) {   // the reason (no device, upload failure, children not in id order) is already on stderr
+            fprintf(stderr, "ygz::DeviceORBVocabulary::transform: the vocabulary is not on the device: BowVector / FeatureVector stay EMPTY for this frame "
+                            "(no CPU fallback; ORBVocabulary::transform is the host path)\n");
+            return;
+        }
+        if (ygzf_bow_transform(mCtx, n, desc.data(), levelsup, leaf.data(), nid.data()) != YGZF_OK) {
+            fprintf(stderr, "ygz::DeviceORBVocabulary::transform: %s: BowVector / FeatureVector stay EMPTY for this frame\n", ygzf_last_error(mCtx));
+            return;
         }
     }
     // from here: transform(features, v, fv, levelsup) of the base class with the per-feature descent replaced by the device result

@@ -26,14 +26,17 @@ public:
     using ORBVocabulary::transform;
     // Transform a set of descriptors into a bow vector and a feature vector (same contract as the base class)
     void transform(const std::vector<DBoW2::FORB::TDescriptor> &features, DBoW2::BowVector &v, DBoW2::FeatureVector &fv, int levelsup) const override;
-    // Drops the device copy (call after re-loading / re-training the vocabulary).
+    // Drops the device copy.  Not required after re-loading / re-training: every transform() compares a fingerprint of the tree (shape +
+    // sampled centroids and weights) with the one it uploaded.
     void invalidateDevice();
 
 private:
     bool ensureDevice() const;
+    unsigned long long treePrint() const;
     mutable std::mutex mMutex;
     mutable ygzf_ctx *mCtx = nullptr;
     mutable size_t mUploadedNodes = 0;
+    mutable unsigned long long mUploadedPrint = 0;
 };
 
 }  // namespace ygz

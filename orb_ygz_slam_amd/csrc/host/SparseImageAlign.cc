@@ -53,8 +53,10 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
     size_t ret = 0;
     const int kIterations = 10;   // run() overrides the constructor's n_iter with iterations[level] = 10 on every level (:38-43)
     static const char *who = "ygz::SparseImgAlign::run";
-    // The two frames' images live in the device-resident image cache the direct matcher uses (ygzf_host::ImageCache): the reference frame
-    // of this call was the current frame of the previous one, so one level-0 upload per new frame replaces two pyramid uploads per call
+    // The two frames' images live in the device-resident image cache the direct matcher uses (ygzf_host::ImageCache, keyed by (kind, id,
+    // content fingerprint)): the reference frame of this call is a COPY of the previous call's current frame (mLastFrame = Frame(mCurrentFrame),
+    // a deep clone of the pyramid: same id, same pixels, other address) and hits the slot that frame filled, so one level-0 upload per new
+    // frame replaces two pyramid uploads per call
     // (their pyramids are rebuilt on the device by the extractor's resize kernel: the bytes the Frames' host pyramids hold).  Frames whose
     // pyramids cannot come from the cache (no level 0, unequal sizes) go up from host memory.
     const int L = (int) ref->mvImagePyramid.size();

@@ -2,6 +2,8 @@
 #include "ygzf_pool.h"
 
 #include <cstdio>
+#include <algorithm>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -44,9 +46,13 @@ struct ImageCache::Impl {
     int w = 0, h = 0, nlevels = 0, device = -1;
     float scaleFactor = 0;
     static const int kSlots = 96;
+    // (kind, id) alone is recycled -- Tracking::Reset restarts Frame::nNextId / KeyFrame::nNextId at 0 while KeyFrames 0..5 may still sit in the
+    // cache (src/Tracking.cc:1926-1927) -- and so is the buffer address; the third component is a fingerprint of the image CONTENT (a sparse
+    // 64-bit hash over ~32 KB of level 0): a Frame copy, whose pyramid is a deep clone at another address (src/Frame.cc:185-187), hits the slot
+    // its original filled; the same id with other pixels never does.
     struct Key {
-        int kind; unsigned long id; const unsigned char *data;
-        bool operator<(const Key &o) const { return kind != o.kind ? kind < o.kind : id != o.id ? id < o.id : data < o.data; }
+        int kind; unsigned long id; unsigned long long print;
+        bool operator<(const Key &o) const { return kind != o.kind ? kind < o.kind : id != o.id ? id < o.id : print < o.print; }
     };
     std::map<Key, int> slotOf;
     std::vector<Key> keyOf;
@@ -82,16 +88,39 @@ bool ImageCache::prepare(int device, int w, int h, int nlevels, float scale_fact
     }
     I.device = device; I.w = w; I.h = h; I.nlevels = nlevels; I.scaleFactor = scale_factor;
     I.slotOf.clear();
-    I.keyOf.assign(Impl::kSlots, Impl::Key{0, 0, nullptr});
+    I.keyOf.assign(Impl::kSlots, Impl::Key{0, 0, 0});
     I.used.assign(Impl::kSlots, 0);
     I.lastUse.assign(Impl::kSlots, 0);
     return true;
 }
 
+void ImageCache::clear() {
+    Impl &I = *impl_;
+    I.slotOf.clear();
+    std::fill(I.used.begin(), I.used.end(), 0);
+    std::fill(I.lastUse.begin(), I.lastUse.end(), 0ul);
+}
+
+// 64 rows x 64 eight-byte words spread over the image, mixed FNV-1a style with the size: two different camera images agree on all of them with
+// negligible probability, and reading 32 KB costs a few microseconds against the 360 KB upload a wrong miss would cost
+static unsigned long long image_fingerprint(const unsigned char *data, int cols, int rows, int step) {
+    unsigned long long hsh = 1469598103934665603ull ^ ((unsigned long long) cols << 32 | (unsigned) rows);
+    const int ny = rows < 64 ? rows : 64, nx = cols / 8 < 64 ? cols / 8 : 64;
+    for (int j = 0; j < ny; j++) {
+        const unsigned char *row = data + (size_t) ((long long) j * (rows - 1) / (ny > 1 ? ny - 1 : 1)) * step;
+        for (int i = 0; i < nx; i++) {
+            unsigned long long v;
+            memcpy(&v, row + (size_t) ((long long) i * (cols - 8) / (nx > 1 ? nx - 1 : 1)), 8);
+            hsh = (hsh ^ v) * 1099511628211ull;
+        }
+    }
+    return hsh;
+}
+
 int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who) {
     Impl &I = *impl_;
-    if (!ctx_ || cols != I.w || rows != I.h) return -1;
-    const Impl::Key key{(int) kind, id, data};
+    if (!ctx_ || cols != I.w || rows != I.h || cols < 8) return -1;
+    const Impl::Key key{(int) kind, id, image_fingerprint(data, cols, rows, step)};
     auto it = I.slotOf.find(key);
     if (it != I.slotOf.end()) { I.lastUse[it->second] = ++I.tick; return it->second; }
     int victim = 0;

@@ -39,9 +39,13 @@ public:
     };
     // (re)creates the context when the geometry changes; false on failure (message on stderr)
     bool prepare(int device, int w, int h, int nlevels, float scale_factor, const char *who);
-    // slot holding this image (uploads it on a miss); -1 on failure.  The key is (kind, id, level-0 data pointer): a Frame copy shares id and
-    // buffer with its original, two different images never do.
+    // slot holding this image (uploads it on a miss); -1 on failure.  The key is (kind, id, fingerprint of the level-0 pixels): a Frame copy
+    // (same id, deep-cloned pyramid at another address, src/Frame.cc:185-187) hits the slot its original filled; an id or a buffer address
+    // that comes back with other pixels (Tracking::Reset restarts the id counters, src/Tracking.cc:1926-1927) misses.
     int slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who);
+    // forgets every cached image (the slots stay allocated).  Not needed for correctness -- the content fingerprint already keeps a recycled id
+    // from hitting a stale image -- but the natural call in Tracking::Reset beside mpMap->clear().
+    void clear();
     ygzf_ctx *ctx() const { return ctx_; }
 
 private:

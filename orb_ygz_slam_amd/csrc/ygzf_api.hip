@@ -182,6 +182,8 @@ static int fail(ygzf_ctx *c, int code, const char *fmt, ...) {
 
 static int ensure(ygzf_ctx *c, ygzf_ctx::Buf &b, size_t bytes) {
     if (bytes <= b.bytes) return YGZF_OK;
+    // a buffer that grows loses its contents: whatever ygzf_compute_pyramid left in the image / pyramid buffers is gone with them
+    if (&b == &c->dImg0 || &b == &c->dPyr) c->pyrResident = false;
     if (b.p) HIPCHECK(c, hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;

@@ -94,6 +94,31 @@ int main(int argc, char **argv) {
     ygz_compat::se3_to7(TCR, t7);
     t7[7] = (float) ret;
     dump(dir + "/tcr.bin", t7, sizeof t7);
+    // The image cache behind run(): (i) a COPY of B (deep-cloned pyramid at another address, same mnId: mLastFrame = Frame(mCurrentFrame)) must give
+    // the same answer (it hits B's slot); (ii) a frame that reuses B's id AND B's buffer with other pixels (Tracking::Reset restarts the id
+    // counters, malloc reuses addresses) must be aligned against its OWN pixels, not against the stale slot
+    {
+        Frame Bc = B;
+        for (auto &m : Bc.mvImagePyramid) m = m.clone();
+        SE3f T2;
+        const size_t r2 = align.run(&A, &Bc, T2);
+        float u7[8];
+        ygz_compat::se3_to7(T2, u7);
+        u7[7] = (float) r2;
+        dump(dir + "/tcr_copy.bin", u7, sizeof u7);
+        std::vector<cv::Mat> keep = B.mvImagePyramid;                 // B's pixels, to put back afterwards
+        std::vector<cv::Mat> saved;
+        for (auto &m : keep) saved.push_back(m.clone());
+        for (size_t l = 0; l < B.mvImagePyramid.size(); l++)          // same buffers, A's pixels: the alignment A -> "B" is now the identity
+            for (int y = 0; y < B.mvImagePyramid[l].rows; y++) std::memcpy(B.mvImagePyramid[l].ptr(y), A.mvImagePyramid[l].ptr(y), (size_t) B.mvImagePyramid[l].cols);
+        SE3f T3;
+        const size_t r3 = align.run(&A, &B, T3);
+        ygz_compat::se3_to7(T3, u7);
+        u7[7] = (float) r3;
+        dump(dir + "/tcr_reuse.bin", u7, sizeof u7);
+        for (size_t l = 0; l < B.mvImagePyramid.size(); l++)
+            for (int y = 0; y < B.mvImagePyramid[l].rows; y++) std::memcpy(B.mvImagePyramid[l].ptr(y), saved[l].ptr(y), (size_t) B.mvImagePyramid[l].cols);
+    }
     // TrackWithMotionModel: cur pose = TCR * last pose, then SearchByProjection(cur, last, 15, mono)  (:1072-1093)
     B.mTcw = TCR;
     ORBmatcher matcher(0.9f, true);

@@ -84,3 +84,27 @@ def test_misuse_is_reported_not_absorbed(oracle):
     kk, dd = ex.extract(img)
     ok, od = oracle.Extractor(1000, 1.2, 8, 20, 7).extract(img)
     assert (kk == ok).all() and (dd == od).all()
+
+
+def test_extract_resident_needs_the_pyramid_it_was_promised(oracle):
+    """ygzf_extract_resident runs on what ygzf_compute_pyramid left on the device: any image operation in between (another extraction, a batch
+    that makes the image / pyramid buffers grow, another geometry) must turn it into YGZF_ERR_STATE, never into an extraction of overwritten data"""
+    from orb_ygz_slam_amd import Extractor, YgzfError
+    from orb_ygz_slam_amd.synth import synth_frame
+    w, h = 320, 240
+    a, b = synth_frame(61, w, h), synth_frame(62, w, h)
+    oex = oracle.Extractor(500, 1.2, 4, 20, 7)
+    ex = Extractor(500, 1.2, 4, 20, 7, max_width=2 * w, max_height=2 * h, max_batch=8)
+    ex.compute_pyramid(a)
+    k, d = ex.extract_resident(w, h)                      # the promised case
+    ok, od = oex.extract(a)
+    assert (k == ok).all() and (d == od).all()
+    for spoil in (lambda: ex.extract(b), lambda: ex.extract_batch_host(np.stack([b] * 8)), lambda: ex.extract_dso(b),
+                  lambda: ex.extract_batch_host(np.stack([synth_frame(63, 2 * w, 2 * h)] * 8))):      # (the last one makes the buffers grow)
+        ex.compute_pyramid(a)
+        spoil()
+        try:
+            k2, d2 = ex.extract_resident(w, h)
+        except YgzfError:
+            continue
+        raise AssertionError("extract_resident succeeded after an intervening image operation")

@@ -76,6 +76,12 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     assert int(t7[7]) == o_ret and o_ret > 100
     assert np.abs(t7[:7] - o_T).max() <= 1e-5
     assert np.abs(t7[4:7] - t).max() < 5e-3
+    # image cache: a deep copy of B (other buffers, same id) gives B's answer; B's id + B's buffers with A's pixels give the identity, not a stale hit
+    t_copy = np.fromfile(tmp_path / "tcr_copy.bin", np.float32)
+    assert np.array_equal(t_copy, t7)
+    t_reuse = np.fromfile(tmp_path / "tcr_reuse.bin", np.float32)
+    r_ret, r_T, _, _ = oracle.sparse_img_align(ka, world, ident, pyrA, ident, pyrA, oex.tables()["inv_scale"], EUROC, 7, 1)
+    assert int(t_reuse[7]) == r_ret and np.abs(t_reuse[:7] - r_T).max() <= 1e-5 and np.abs(t_reuse[4:7]).max() < 1e-3
     # FindDirectProjection as a member, one candidate per call (KeyFrame = A at identity, current frame = B at TCR)
     dr = np.fromfile(tmp_path / "direct.bin", np.float32).reshape(-1, 4)
     nd = len(dr)
