@@ -256,7 +256,10 @@ def test_fuzz_sparse_img_align(oracle, seed):
     rng = np.random.default_rng(1400 + seed)
     w, h = 752, 480
     nl = int(rng.integers(3, 9))
-    nf = int(rng.choice([60, 300, 1000, 2000]))
+    # three seeds of four are runs as Tracking makes them (a few hundred features or more, at least two levels, at least three iterations: SparseImgAlign(nLevels - 1, 1)
+    # with 10 iterations, src/Tracking.cc:207); every fourth keeps the whole parameter space, 60-feature one-level one-iteration runs included
+    wild = seed % 4 == 3
+    nf = int(rng.choice([60, 300, 1000, 2000] if wild else [300, 1000, 2000]))
     rv = tuple(rng.uniform(-0.01, 0.01, 3))
     tr = tuple(rng.uniform(-0.05, 0.05, 3))
     imgA, imgB, _, backproject = two_view_scene(1500 + seed, w, h, EUROC, Z=float(rng.uniform(2, 8)), rotvec=rv, trans=tr)
@@ -267,9 +270,14 @@ def test_fuzz_sparse_img_align(oracle, seed):
     world = backproject(k["x"], k["y"])
     inv = oex.tables()["inv_scale"]
     ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
-    max_level = int(rng.integers(1, nl))
-    min_level = int(rng.integers(0, max_level + 1))
-    n_iter = int(rng.choice([1, 3, 10]))
+    if wild:
+        max_level = int(rng.integers(1, nl))
+        min_level = int(rng.integers(0, max_level + 1))
+        n_iter = int(rng.choice([1, 3, 10]))
+    else:
+        max_level = int(rng.integers(2, nl))
+        min_level = int(rng.integers(0, max_level))          # at least two levels
+        n_iter = int(rng.choice([3, 10, 10]))
     valid = (rng.uniform(size=len(k)) > 0.2).astype(np.uint8)
     outl = (rng.uniform(size=len(k)) > 0.9).astype(np.uint8)
     o = oracle.sparse_img_align(k, world, ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter, mp_valid=valid, outlier=outl)
@@ -293,17 +301,34 @@ def test_fuzz_sparse_img_align(oracle, seed):
         # ill-conditioned: a pose that differs in the last bits can flip a feature across a level's border test (discrete jumps); the device
         # is held to ten times the oracle's own re-ordering band and the case is counted
         ALIGN_STATS["ill"] += 1
+        ALIGN_STATS["worst_ill"] = max(ALIGN_STATS.get("worst_ill", 0.0), err)
+        ALIGN_STATS["worst_band"] = max(ALIGN_STATS.get("worst_band", 0.0), band)
         assert err <= max(1e-5, 10.0 * band), (nl, nf, max_level, min_level, n_iter, band, g[1], o[1])
 
 
 def test_fuzz_sparse_img_align_report():
-    """Runs after the seeds above: most cases must be well-conditioned ones held to 1e-5 (printed with -s / in the failure message)."""
+    """Runs after the seeds above: at least half of the cases must be well-conditioned ones held to north_star's 1e-5 without any allowance.  The
+    counts and worst errors go into the test log (a warning, shown in pytest's summary even with -q) and into gpurun_out/align_fuzz_report.json,
+    which travels back from the GPU box with the run's other files."""
+    import json
+    import os
+    import warnings
     n = ALIGN_STATS["well"] + ALIGN_STATS["ill"]
     if n == 0:
         pytest.skip("aligner fuzz did not run")
-    print("aligner fuzz: %d well-conditioned cases within 1e-5 (worst %.2e), %d ill-conditioned held to 10 x band" %
-          (ALIGN_STATS["well"], ALIGN_STATS["worst_well"], ALIGN_STATS["ill"]))
-    assert ALIGN_STATS["well"] >= max(1, 0.25 * n), ALIGN_STATS     # random level ranges / 1-iteration runs / 60-feature budgets make about half the cases ill-posed
+    rep = {"cases": n, "well_conditioned_held_to_1e-5": ALIGN_STATS["well"], "worst_error_well_conditioned": ALIGN_STATS["worst_well"],
+           "ill_conditioned_held_to_10x_reordering_band": ALIGN_STATS["ill"], "worst_error_ill_conditioned": ALIGN_STATS.get("worst_ill", 0.0),
+           "largest_reordering_band_of_the_oracle_itself": ALIGN_STATS.get("worst_band", 0.0)}
+    msg = "aligner fuzz: " + json.dumps(rep)
+    print(msg)
+    warnings.warn(msg)
+    try:
+        from tests.conftest import ROOT
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(rep, open(os.path.join(ROOT, "gpurun_out", "align_fuzz_report.json"), "w"), indent=1)
+    except OSError:
+        pass
+    assert ALIGN_STATS["well"] >= 0.5 * n, rep
 
 
 @pytest.mark.parametrize("seed", SEEDS)
