@@ -9,7 +9,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
+BENCH="python $REPO/bench.py --steps 3 --warmup 1 --passes 1 --no-cpu-baseline --no-extras"
 ALL="python $REPO/tools/all_kernels.py 2"
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats.log 2>&1
