@@ -1427,38 +1427,38 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     constexpr int k2 = CVM == YGZF_CV_4 ? 48 : 49, k3 = CVM == YGZF_CV_4 ? 56 : 55;
     constexpr unsigned kTapLo = 0x00002212u | ((unsigned) k2 << 16) | ((unsigned) k3 << 24);   // bytes (18, 34, k2, k3)
     constexpr unsigned kTapHi = 0x00122200u | (unsigned) k2;                                  // bytes (k2, 34, 18, 0)
-    // horizontal: 43 rows x 5 segments (8+8+8+8+5 columns)
-    for (int t = lane; t < kWin * 5; t += 64) {
-        const int r = (t * 205) >> 10, sg = t - 5 * r;      // t / 5, t % 5 for t < 1024
-        // 15 source bytes from an arbitrary byte address: five aligned dwords, shifted into place once (e[k] = bytes 4k..4k+3 of the
-        // run); output j = <bytes j..j+3, (18,34,49,55)> + <bytes j+4..j+7, (49,34,18,0)> -- two v_dot4_u32_u8 per output, exact
-        // (the sum is at most 65535).
-        const unsigned A = (unsigned) (RAWP(r) - L.rawp()) + 8u * (unsigned) sg;
+    // horizontal: 43 rows x 4 segments of 10 columns (the last one's columns 37..39 land in the row's slack and are never read): 172 items =
+    // three steps of the wave (eight-column segments made 215 items: a fourth step for 23 of the 64 lanes)
+    for (int t = lane; t < kWin * 4; t += 64) {
+        const int r = t >> 2, sg = t & 3;
+        // 16 source bytes from an arbitrary byte address: five aligned dwords, shifted into place once (e[k] = bytes 4k..4k+3 of the
+        // run); output j = <bytes j..j+3, (18,34,k2,k3)> + <bytes j+4..j+7, (k2,34,18,0)> -- two v_dot4_u32_u8 per output, exact
+        // (the sum is at most 65535); byte j+7 meets the zero tap, so output 9 never needs a sixth dword.
+        const unsigned A = (unsigned) (RAWP(r) - L.rawp()) + 10u * (unsigned) sg;
         const unsigned *dw = (const unsigned *) L.rawp() + (A >> 2);
         const unsigned sh = A & 3u;
         const unsigned d0 = dw[0], d1 = dw[1], d2 = dw[2], d3 = dw[3], d4 = dw[4];
-        unsigned X[12];
+        unsigned X[14];
         X[0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
         X[4] = __builtin_amdgcn_alignbyte(d2, d1, sh);
         X[8] = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        const unsigned e3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        X[12] = __builtin_amdgcn_alignbyte(d4, d3, sh);
 #pragma unroll
         for (int j = 1; j < 4; j++) {
             X[j] = __builtin_amdgcn_alignbyte(X[4], X[0], j);
             X[4 + j] = __builtin_amdgcn_alignbyte(X[8], X[4], j);
-            X[8 + j] = __builtin_amdgcn_alignbyte(e3, X[8], j);
+            X[8 + j] = __builtin_amdgcn_alignbyte(X[12], X[8], j);
         }
-        unsigned O[4];
+        X[13] = X[12] >> 8;
+        unsigned O[5];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < 5; k++) {
             const unsigned lo = __builtin_amdgcn_udot4(X[2 * k], kTapLo, __builtin_amdgcn_udot4(X[2 * k + 4], kTapHi, 0u, false), false);
             const unsigned hi = __builtin_amdgcn_udot4(X[2 * k + 1], kTapLo, __builtin_amdgcn_udot4(X[2 * k + 5], kTapHi, 0u, false), false);
             O[k] = lo | (hi << 16);
         }
-        unsigned *dst = (unsigned *) &L.hbp()[r * kHbP + 8 * sg];
-        dst[0] = O[0]; dst[1] = O[1];
-        if (sg < 4) { dst[2] = O[2]; dst[3] = O[3]; }
-        else { dst[2] = O[2] & 0xFFFFu; }                    // columns 32..36: 5 outputs (column 37.. unused)
+        unsigned *dst = (unsigned *) &L.hbp()[r * kHbP + 10 * sg];
+        dst[0] = O[0]; dst[1] = O[1]; dst[2] = O[2]; dst[3] = O[3]; dst[4] = O[4];
     }
     wave_lds_sync();
     // vertical pass only where the rotated pattern samples (512 points instead of the 37 x 37 patch): 7 taps straight from hb
@@ -1476,11 +1476,16 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         const int s1 = 18 * (p1[0] + p1[6 * kHbP]) + 34 * (p1[kHbP] + p1[5 * kHbP]) + k2 * (p1[2 * kHbP] + p1[4 * kHbP]) + k3 * p1[3 * kHbP];
         int t0 = (s0 + 32768) >> 16, t1 = (s1 + 32768) >> 16;
         if (CVM == YGZF_CV_LEGACY_SSE2) {
-            // exact tie (sum = q*65536 + 32768) inside the SSE2 body: cvtps2dq rounds to even, i.e. the half-up result loses its low bit
-            const int wv = gw & ~3;
-            const int c0 = reflect101(kx + q0, gw), c1 = reflect101(kx + q1, gw);
-            if ((s0 & 0xFFFF) == 0x8000 && c0 < wv) t0 &= ~1;
-            if ((s1 & 0xFFFF) == 0x8000 && c1 < wv) t1 &= ~1;
+            // exact tie (sum = q*65536 + 32768) inside the SSE2 body: cvtps2dq rounds to even, i.e. the half-up result loses its low bit.
+            // A tie is one sample in tens of thousands: the column bookkeeping it needs (ten vector instructions per sample, a tenth of this
+            // phase) runs only when some lane of the wave has one
+            const bool tie0 = (s0 & 0xFFFF) == 0x8000, tie1 = (s1 & 0xFFFF) == 0x8000;
+            if (__builtin_expect(__ballot(tie0 || tie1) != 0ull, 0)) {
+                const int wv = gw & ~3;
+                const int c0 = reflect101(kx + q0, gw), c1 = reflect101(kx + q1, gw);
+                if (tie0 && c0 < wv) t0 &= ~1;
+                if (tie1 && c1 < wv) t1 &= ~1;
+            }
         }
         t0 = min(t0, 255);
         t1 = min(t1, 255);

@@ -74,6 +74,7 @@ void ygzf_mgpu_destroy(ygzf_mgpu *m) {
     if (!m) return;
     for (auto &d : m->devs) {
         if (d.ctx) ygzf_destroy(d.ctx);
+        if (!d.hIn && !d.hKp && !d.hDesc && !d.hCnt) continue;   // a slot whose context was never created (e.g. a device index that does not exist)
         (void) hipSetDevice(d.device);
         if (d.hIn) (void) hipHostFree(d.hIn);
         if (d.hKp) (void) hipHostFree(d.hKp);

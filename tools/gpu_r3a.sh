@@ -1,1 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_fuzz.py -x -q -p no:cacheprovider -k "sparse_img_align" 2>&1 | tail -12; cat gpurun_out/align_fuzz_report.json
+mkdir -p gpurun_out/r3a
+timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/r3a/pytest.log 2>&1; tail -4 gpurun_out/r3a/pytest.log
