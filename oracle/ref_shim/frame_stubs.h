@@ -11,12 +11,23 @@ struct Vector3d {
     double v[3];
     Vector3d() { v[0] = v[1] = v[2] = 0; }
     static Vector3d Zero() { return Vector3d(); }
+    double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 };
+struct Matrix3d {
+    double m[9];
+    Matrix3d inverse() const { yr_unsupported("Matrix3d::inverse"); }
+    Matrix3d transpose() const { yr_unsupported("Matrix3d::transpose"); }
+};
+inline Vector3d operator*(const Matrix3d &, const Vector3d &) { yr_unsupported("Matrix3d * v"); }
+inline Matrix3d operator*(const Matrix3d &, const Matrix3d &) { yr_unsupported("Matrix3d * Matrix3d"); }
+inline Vector3d operator*(const Vector3d &, double) { yr_unsupported("Vector3d * s"); }
+inline Vector3d operator*(double, const Vector3d &) { yr_unsupported("s * Vector3d"); }
 inline Vector3d operator+(const Vector3d &, const Vector3d &) { yr_unsupported("Vector3d +"); }
 inline Vector3d operator-(const Vector3d &, const Vector3d &) { yr_unsupported("Vector3d -"); }
 inline Vector3d operator-(const Vector3d &) { yr_unsupported("-Vector3d"); }
 }  // namespace Eigen
 using Eigen::Vector3d;
+using Eigen::Matrix3d;
 using namespace Eigen;   // the IMU headers do that for the real include/Frame.h (Matrix<double, 15, 15> mMargCovInv)
 
 namespace Sophus {
@@ -29,6 +40,8 @@ struct SE3d {
     SO3d r; Vector3d p;
     SE3d() {}
     SE3d(const SO3d &, const Vector3d &) {}
+    template <class A, class B> SE3d(const A &, const B &) { yr_unsupported("SE3d(R, t)"); }
+    SE3d inverse() const { yr_unsupported("SE3d::inverse"); }
     const SO3d &so3() const { return r; }
     const Vector3d &translation() const { return p; }
     template <class T> SE3f cast() const { yr_unsupported("SE3d::cast"); }
@@ -36,6 +49,19 @@ struct SE3d {
 }  // namespace Sophus
 using Sophus::SE3d;
 using Sophus::SO3d;
+#ifdef YGZ_REF_TRACKING
+namespace Sophus {
+template <> struct SE3f::CastResult<double> { typedef SE3d type; };
+inline SE3d operator*(const SE3d &, const SE3d &) { yr_unsupported("SE3d * SE3d"); }
+struct SO3 {   // Sophus::SO3 (the non-templated double form of the IMU code)
+    template <class M> SO3(const M &) { yr_unsupported("Sophus::SO3"); }
+    SO3() {}
+    SO3 inverse() const { yr_unsupported("SO3::inverse"); }
+    template <class V> static SO3 exp(const V &) { yr_unsupported("SO3::exp"); }
+    Vector3d log() const { yr_unsupported("SO3::log"); }
+};
+}  // namespace Sophus
+#endif
 
 namespace ygz {
 struct IMUData { double _t = 0; Vector3d _g, _a; };
@@ -60,6 +86,17 @@ class IMUPreintegrator {
 public:
     void reset() {}
     void update(const Vector3d &, const Vector3d &, double) {}
+#ifdef YGZ_REF_TRACKING
+    Vector3d getDeltaP() const { yr_unsupported("IMUPreintegrator"); }
+    Vector3d getDeltaV() const { yr_unsupported("IMUPreintegrator"); }
+    Matrix3d getDeltaR() const { yr_unsupported("IMUPreintegrator"); }
+    double getDeltaTime() const { yr_unsupported("IMUPreintegrator"); }
+    Matrix3d getJPBiasg() const { yr_unsupported("IMUPreintegrator"); }
+    Matrix3d getJPBiasa() const { yr_unsupported("IMUPreintegrator"); }
+    Matrix3d getJVBiasg() const { yr_unsupported("IMUPreintegrator"); }
+    Matrix3d getJVBiasa() const { yr_unsupported("IMUPreintegrator"); }
+    Matrix3d getJRBiasg() const { yr_unsupported("IMUPreintegrator"); }
+#endif
 };
 // include/ORBVocabulary.h: DBoW2::TemplatedVocabulary<...>; Frame::ComputeBoW calls transform()
 #if defined(YGZ_REAL_DBOW2)

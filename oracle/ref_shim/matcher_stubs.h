@@ -42,6 +42,7 @@ struct Vector2f {
     float &operator()(int i) { return v[i]; }
     float operator()(int i) const { return v[i]; }
     Vector2f &operator*=(float s) { v[0] *= s; v[1] *= s; return *this; }
+    Vector2f &operator+=(const Vector2f &o) { v[0] += o.v[0]; v[1] += o.v[1]; return *this; }
     float x() const { return v[0]; }
     float y() const { return v[1]; }
     float operator()(int i, int) const { return v[i]; }
@@ -65,6 +66,7 @@ struct Vector3f {
     float norm() const { return std::sqrt(dot(*this)); }
     float operator()(int i, int) const { return v[i]; }
     void setZero() { v[0] = v[1] = v[2] = 0; }
+    Vector3f &operator*=(double s) { v[0] = (float) (v[0] * s); v[1] = (float) (v[1] * s); v[2] = (float) (v[2] * s); return *this; }
     void normalize() { const float n = norm(); v[0] /= n; v[1] /= n; v[2] /= n; }   // Eigen: *this /= norm()
     struct Row { const Vector3f *p; };
     Row transpose() const { return Row{this}; }
@@ -81,6 +83,7 @@ struct Matrix3f {
     float &operator()(int r, int c) { return m[3 * r + c]; }
     float operator()(int r, int c) const { return m[3 * r + c]; }
     static Matrix3f Zero() { return Matrix3f(); }
+    static Matrix3f Identity() { Matrix3f r; r(0, 0) = r(1, 1) = r(2, 2) = 1.f; return r; }
     void setZero() { for (float &x : m) x = 0; }
     Matrix3f &operator+=(const Matrix3f &o) { for (int i = 0; i < 9; i++) m[i] += o.m[i]; return *this; }
     Matrix3f inverse() const { Matrix3f r; ygzo::inverse3(m, r.m); return r; }
@@ -150,6 +153,11 @@ struct SE3f {
     Matrix3f rotationMatrix() const { return R; }
     Vector3f translation() const { return t; }
     SE3f inverse() const { return SE3f(q.Inverse()); }
+#ifdef YGZ_REF_TRACKING
+    SE3f(const Matrix3f &, const Vector3f &) { yr_unsupported("SE3f(R, t)"); }                 // only the monocular initialiser builds poses from matrices
+    template <class T> struct CastResult;
+    template <class T> typename CastResult<T>::type cast() const { yr_unsupported("SE3f::cast"); }   // IMU branches only
+#endif
     template <class V> static SE3f exp(const V &a) { float v[6]; for (int i = 0; i < 6; i++) v[i] = a[i]; return SE3f(ygzo::SE3f::Exp(v)); }
 };
 inline SE3f operator*(const SE3f &a, const SE3f &b) { return SE3f(a.q.Mul(b.q)); }
@@ -161,6 +169,12 @@ namespace ygz {
 
 class Frame;
 class KeyFrame;
+#ifdef YGZ_REF_TRACKING
+class Map;
+class KeyFrameDatabase;
+struct IMUData;
+class NavState;
+#endif
 
 #ifndef YGZ_REF_MAPPOINT
 // include/MapPoint.h, src/MapPoint.cc: the fields / accessors the matcher touches
@@ -194,6 +208,21 @@ public:
     int GetIndexInKeyFrame(KeyFrame *) { yr_unsupported("MapPoint::GetIndexInKeyFrame"); }
     void Replace(MapPoint *) { yr_unsupported("MapPoint::Replace"); }
     void AddObservation(KeyFrame *, size_t) { yr_unsupported("MapPoint::AddObservation"); }
+#ifdef YGZ_REF_TRACKING
+    // what src/Tracking.cc touches beyond the matcher: plain counters for the two members SearchLocalPoints calls, declarations for the rest
+    // (bodies: tests/cpp/tracking_outside.S -- every member of a class outside the hot path aborts when reached)
+    MapPoint() {}
+    MapPoint(const Vector3f &Pos, KeyFrame *pRefKF, Map *pMap);
+    MapPoint(const Vector3f &Pos, Map *pMap, Frame *pFrame, const int &idxF);
+    long unsigned int mnLastFrameSeen = 0, mnTrackReferenceForFrame = 0;
+    int mnVisible = 1, mnFound = 1;
+    void IncreaseVisible(int n = 1) { mnVisible += n; }      // src/MapPoint.cc:186-189 without the mutex
+    void IncreaseFound(int n = 1) { mnFound += n; }
+    void ComputeDistinctiveDescriptors();
+    void UpdateNormalAndDepth();
+    MapPoint *GetReplaced();
+    void SetWorldPos(const Vector3f &Pos);
+#endif
 };
 
 #else
@@ -270,6 +299,28 @@ public:
     Vector3f Pixel2Camera(const Vector2f &p_p, float depth = 1) const {   // include/KeyFrame.h:181-187
         return Vector3f((p_p(0) - cx) * depth / fx, (p_p(1) - cy) * depth / fy, depth);
     }
+#ifdef YGZ_REF_TRACKING
+    KeyFrame() {}
+    KeyFrame(Frame &F, Map *pMap, KeyFrameDatabase *pKFDB);
+    KeyFrame(Frame &F, Map *pMap, KeyFrameDatabase *pKFDB, std::vector<IMUData> vIMUData, KeyFrame *pLastKF = NULL);
+    static long unsigned int nNextId;
+    double mTimeStamp = 0;
+    long unsigned int mnTrackReferenceForFrame = 0;
+    void ComputeBoW();
+    void ComputePreInt(void);
+    float ComputeSceneMedianDepth(const int q);
+    std::vector<KeyFrame *> GetBestCovisibilityKeyFrames(const int &N);
+    std::set<KeyFrame *> GetChilds();
+    const NavState &GetNavState(void);
+    KeyFrame *GetParent();
+    KeyFrame *GetPrevKeyFrame(void);
+    SE3f GetPoseInverse();
+    void SetInitialNavStateAndBias(const NavState &ns);
+    void SetPose(const SE3f &Tcw) { mPose = Tcw; }
+    int TrackedMapPoints(const int &minObs);
+    void UpdateConnections();
+    DBoW2::BowVector mBowVec;
+#endif
 };
 
 // include/Map.h: what src/MapPoint.cc touches
@@ -277,6 +328,18 @@ class Map {
 public:
     std::mutex mMutexPointCreation;
     void EraseMapPoint(MapPoint *) {}
+#ifdef YGZ_REF_TRACKING
+    std::mutex mMutexMapUpdate;
+    std::vector<KeyFrame *> mvpKeyFrameOrigins;
+    void AddKeyFrame(KeyFrame *pKF);
+    void AddMapPoint(MapPoint *pMP);
+    std::vector<KeyFrame *> GetAllKeyFrames();
+    std::vector<MapPoint *> GetAllMapPoints();
+    long unsigned KeyFramesInMap();
+    long unsigned int MapPointsInMap();
+    void SetReferenceMapPoints(const std::vector<MapPoint *> &vpMPs);
+    void clear();
+#endif
 };
 
 // include/Converter.h: only the Sim3 / fuse functions use it
@@ -286,6 +349,11 @@ public:
     static cv::Mat toCvMat(const Matrix3f &) { yr_unsupported("Converter::toCvMat"); }
     template <class A, class B, class C> static void updateNS(A &, const B &, const C &) { yr_unsupported("Converter::updateNS"); }
 #ifdef YGZ_BOUNDARY_BUILD
+    struct SE3QuatStandIn {   // g2o::SE3Quat: only Relocalization's PnP branch names it
+        Matrix3f rotation() const { yr_unsupported("SE3Quat::rotation"); }
+        Vector3f translation() const { yr_unsupported("SE3Quat::translation"); }
+    };
+    template <class T> static SE3QuatStandIn toSE3Quat(const T &) { yr_unsupported("Converter::toSE3Quat"); }
     static std::vector<cv::Mat> toDescriptorVector(const cv::Mat &D) {   // src/Converter.cc:52-59
         std::vector<cv::Mat> v;
         for (int j = 0; j < D.rows; j++) v.push_back(D.row(j));

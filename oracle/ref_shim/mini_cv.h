@@ -154,8 +154,16 @@ public:
     Mat col(int) const { mini_cv_unsupported("Mat::col"); }
     Mat t() const { mini_cv_unsupported("Mat::t"); }
     double dot(const Mat &) const { mini_cv_unsupported("Mat::dot"); }
-    template <class T> T &at(int) { mini_cv_unsupported("Mat::at(int)"); }
-    template <class T> const T &at(int) const { mini_cv_unsupported("Mat::at(int)"); }
+    template <class T> T &at(int i) { assert(cols == 1); return *(T *) (data + (size_t) i * step.p[0]); }          // column vectors (Tracking's DistCoef)
+    template <class T> const T &at(int i) const { assert(cols == 1); return *(const T *) (data + (size_t) i * step.p[0]); }
+    int channels() const { return 1; }
+    void resize(size_t nrows) {   // column vector grown in place (Tracking.cc:122)
+        Mat o((int) nrows, cols, elem == 4 ? CV_32F : CV_8UC1);
+        for (int y = 0; y < (int) nrows; y++) std::memset(o.data + (size_t) y * o.step.p[0], 0, (size_t) cols * elem);
+        for (int y = 0; y < rows && y < (int) nrows; y++) std::memcpy(o.data + (size_t) y * o.step.p[0], data + (size_t) y * step.p[0], (size_t) cols * elem);
+        *this = o;
+    }
+    void convertTo(Mat &, int, double) const { mini_cv_unsupported("Mat::convertTo(dst, type, alpha)"); }
     template <class T> T &at(int y, int x) { return *(T *) (data + (size_t) y * step.p[0] + (size_t) x * sizeof(T)); }
     template <class T> const T &at(int y, int x) const { return *(const T *) (data + (size_t) y * step.p[0] + (size_t) x * sizeof(T)); }
     template <class T> T *ptr(int y = 0) { return (T *) (data + (size_t) y * step.p[0]); }

@@ -24,6 +24,7 @@
 #define protected public
 #include "ORBmatcher.h"          // the reference's: pulls the real Frame.h (whose ORBextractor.h is the product's, same guard)
 #include "SparseImageAlign.h"    // the reference's
+#include "Tracking.h"            // the reference's: src/Tracking.cc itself is in the link, compiled where it lies (tests/cpp/build_boundary.sh)
 #undef private
 #undef protected
 
@@ -62,6 +63,7 @@ int MapPoint::PredictScale(const float &currentDist, Frame *pF) {
     return nScale;
 }
 int MapPoint::PredictScale(const float &, KeyFrame *) { yr_unsupported("MapPoint::PredictScale(KeyFrame*)"); }
+long unsigned int KeyFrame::nNextId = 0;
 }  // namespace ygz
 #include "ORBVocabularyDevice.h"   // ygz::DeviceORBVocabulary over the reference's real DBoW2 (this build: -DYGZ_REAL_DBOW2)
 
@@ -235,6 +237,56 @@ int main(int argc, char **argv) {
             if (cur2.mvpMapPoints[i]) a2[i] = (int) (cur2.mvpMapPoints[i] - mps.data());
         dump(dir + "/m_match2.bin", a2.data(), a2.size() * sizeof(int));
         dump(dir + "/m_nmatch2.bin", &nm2, sizeof nm2);
+    }
+    // ---- the reference's own src/Tracking.cc (compiled unchanged, linked against the product's strong ORBmatcher / SparseImgAlign / ORBextractor
+    // symbols) drives the hot path: Tracking::Tracking builds its extractors and its aligner from the settings file (:83-213),
+    // TrackWithSparseAlignment (:2061-2105) calls SparseImgAlign::run, SearchLocalPoints (:1544-1593) calls Frame::isInFrustum and
+    // ORBmatcher::SearchByProjection(F, MapPoints).  Every class outside the hot path is a declaration whose members abort when reached.
+    {
+        System sys;
+        Map map;
+        KeyFrameDatabase kfdb;
+        FrameDrawer fdraw;
+        MapDrawer mdraw;
+        ConfigParam params;
+        Tracking trk(&sys, &voc, &fdraw, &mdraw, &map, &kfdb, dir + "/settings.yaml", System::MONOCULAR, &params);
+        if (!trk.mpORBextractorLeft || !trk.mpIniORBextractor || trk.mpORBextractorLeft->GetLevels() != L || !trk.mpAlign) {
+            fprintf(stderr, "Tracking::Tracking did not build its extractors / aligner from the settings\n");
+            return 6;
+        }
+        KeyFrame refKF;
+        refKF.mPose = SE3f();
+        for (auto &mp : mps) { mp.mnLastFrameSeen = 0; mp.mbTrackInView = false; }
+        trk.mLastFrame = Frame(last);                       // the reference's copy constructor: deep-cloned pyramid, same id
+        trk.mLastFrame.mpReferenceKF = &refKF;
+        trk.mlRelativeFramePoses.push_back(SE3f());          // Tlr of UpdateLastFrame (:981-986)
+        trk.mVelocity = SE3f();
+        Frame fresh(imN, 0.1, &ex, &voc, K, dist, bf, thDepth);
+        fresh.ExtractFeatures();
+        trk.mCurrentFrame = Frame(fresh);
+        const bool okA = trk.TrackWithSparseAlignment(false);
+        float p7[8];
+        { const Eigen::Quaternionf q = trk.mCurrentFrame.mTcw.unit_quaternion(); p7[0] = q.x(); p7[1] = q.y(); p7[2] = q.z(); p7[3] = q.w(); }
+        for (int i = 0; i < 3; i++) p7[4 + i] = trk.mCurrentFrame.mTcw.translation()[i];
+        p7[7] = okA ? 1.f : 0.f;
+        dump(dir + "/t_pose7.bin", p7, sizeof p7);
+        // SearchLocalPoints on the aligned frame: nothing matched yet, the local map = the last frame's points
+        trk.mCurrentFrame.mvpMapPoints.assign(trk.mCurrentFrame.N, (MapPoint *) nullptr);
+        trk.mvpLocalMapPoints.clear();
+        for (auto &mp : mps) trk.mvpLocalMapPoints.push_back(&mp);
+        trk.mnLastRelocFrameId = 0;
+        trk.mbDirectFailed = false;
+        trk.SearchLocalPoints();
+        std::vector<int> a3(trk.mCurrentFrame.N, -1);
+        int visible = 0;
+        for (int i = 0; i < trk.mCurrentFrame.N; i++)
+            if (trk.mCurrentFrame.mvpMapPoints[i]) a3[i] = (int) (trk.mCurrentFrame.mvpMapPoints[i] - mps.data());
+        for (auto &mp : mps) visible += mp.mnVisible - 1;
+        dump(dir + "/t_match.bin", a3.data(), a3.size() * sizeof(int));
+        const int info[3] = {(int) trk.mCurrentFrame.mnId, visible, trk.mCurrentFrame.N};
+        dump(dir + "/t_info.bin", info, sizeof info);
+        dump(dir + "/t_keys.bin", trk.mCurrentFrame.mvKeys.data(), trk.mCurrentFrame.mvKeys.size() * sizeof(cv::KeyPoint));
+        dump_desc(dir + "/t_desc.bin", trk.mCurrentFrame.mDescriptors, trk.mCurrentFrame.N);
     }
     // ---- direct-tracked frame: keys carried over from the last frame, no extraction yet -> ExtractORB takes DSO_KEYPOINT (src/Frame.cc:335-337)
     {

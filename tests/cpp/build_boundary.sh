@@ -8,6 +8,11 @@
 #     NLSSolver.h and define those classes' hot-path members;
 #   * the vocabulary is the reference's REAL DBoW2 (Thirdparty/DBoW2, compiled in), wrapped by ygz::DeviceORBVocabulary, whose virtual
 #     transform() Frame::ComputeBoW reaches unchanged;
+#   * the reference's own src/Tracking.cc is compiled where it lies, unchanged, against the product's ORBextractor.h and the reference's own
+#     ORBmatcher.h / SparseImageAlign.h / Frame.h, and linked in: its calls of ORBextractor / ORBmatcher::SearchBy* / FindDirectProjection /
+#     SparseImgAlign::run bind to the product's strong definitions.  Everything outside the hot path that it names (System, LocalMapping,
+#     LoopClosing, Optimizer, Initializer, PnPsolver, Map, KeyFrame machinery, viewer) is declarations (oracle/ref_shim/tracking/) whose
+#     members the link resolves to ONE aborting stand-in: the alias list is generated from the link's own undefined-symbol report;
 #   * OpenCV, Eigen and Sophus are not installed in this environment: oracle/ref_shim stands in for their headers (test infrastructure);
 #     its compute primitives are replaced by aborting bodies (tests/cpp/mini_cv_nocompute.cpp), the pose algebra behind the Sophus stand-in
 #     is oracle_align.cpp's.
@@ -20,27 +25,49 @@ S=$ROOT/oracle/ref_shim
 OUT=$ROOT/tests/cpp/bin
 if [ ! -f "$REF/src/Frame.cc" ]; then echo "reference checkout absent: keeping prebuilt $OUT/boundary_frame (if any)"; exit 0; fi
 mkdir -p "$OUT"
-FLAGS="-O2 -std=c++14 -msse4.2 -pthread -w -ffp-contract=off -DYGZ_REF_MATCHER -DYGZ_REF_FRAME -DYGZ_BOUNDARY_BUILD -DYGZ_REAL_DBOW2 -DYGZF_WITH_REFERENCE_HEADERS"
-INC="-I$S -I$ROOT/oracle -I$REF/include -I$REF -I$H -include $S/dbow2_stubs.h -include $H/ORBextractor.h"
+FLAGS="-O2 -std=c++14 -msse4.2 -pthread -w -ffp-contract=off -DYGZ_REF_TRACKING -DYGZ_REF_MATCHER -DYGZ_REF_FRAME -DYGZ_BOUNDARY_BUILD -DYGZ_REAL_DBOW2 -DYGZF_WITH_REFERENCE_HEADERS"
+INC="-I$S/tracking -I$S -I$ROOT/oracle -I$REF/include -I$REF -I$H -include $S/dbow2_stubs.h -include $H/ORBextractor.h -include $S/tracking/tracking_stubs.h"
 # The reference's own src/ORBmatcher.cc (+ src/Align.cc) stays in the link for the members outside the hot path (Fuse x2, SearchBySim3,
 # SearchForTriangulation, SearchByProjection(KF, Scw, ...), SearchByBoW(KF, KF, ...)): its definitions are made WEAK, so the strong
 # definitions of the hot-path members in the product's ORBmatcher.cc win at link time and nothing in the reference file is edited.
 g++ $FLAGS $INC -c "$REF/src/ORBmatcher.cc" -o "$OUT/ref_ORBmatcher.o"
 g++ $FLAGS $INC -c "$REF/src/Align.cc" -o "$OUT/ref_Align.o"
 objcopy --weaken "$OUT/ref_ORBmatcher.o"
-g++ -O2 -std=c++14 -msse4.2 -pthread -w -ffp-contract=off \
-    -DYGZ_REF_MATCHER -DYGZ_REF_FRAME -DYGZ_BOUNDARY_BUILD -DYGZ_REAL_DBOW2 -DYGZF_WITH_REFERENCE_HEADERS \
-    -I"$S" -I"$ROOT/oracle" -I"$REF/include" -I"$REF" -I"$H" \
-    -include "$S/dbow2_stubs.h" -include "$H/ORBextractor.h" \
-    "$REF/src/Frame.cc" "$OUT/ref_ORBmatcher.o" "$OUT/ref_Align.o" \
-    "$H/ORBextractor.cc" "$H/ORBmatcher.cc" "$H/SparseImageAlign.cc" "$H/ORBVocabularyDevice.cc" "$H/ygzf_pool.cc" \
-    "$REF/Thirdparty/DBoW2/DBoW2/FORB.cpp" "$REF/Thirdparty/DBoW2/DBoW2/BowVector.cpp" "$REF/Thirdparty/DBoW2/DBoW2/FeatureVector.cpp" \
-    "$REF/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp" "$REF/Thirdparty/DBoW2/DUtils/Random.cpp" "$REF/Thirdparty/DBoW2/DUtils/Timestamp.cpp" \
-    "$ROOT/tests/cpp/boundary_frame.cc" "$ROOT/tests/cpp/mini_cv_nocompute.cpp" \
-    "$ROOT/oracle/oracle_align.cpp" "$ROOT/oracle/oracle_direct.cpp" \
-    -L"$ROOT/orb_ygz_slam_amd/lib" -lygzf -Wl,-rpath,'$ORIGIN/../../../orb_ygz_slam_amd/lib' \
-    -o "$OUT/boundary_frame"
+g++ $FLAGS $INC -c "$REF/src/Tracking.cc" -o "$OUT/ref_Tracking.o"
+OBJS="$OUT/ref_Tracking.o $OUT/ref_ORBmatcher.o $OUT/ref_Align.o"
+SRCS="$REF/src/Frame.cc $H/ORBextractor.cc $H/ORBmatcher.cc $H/SparseImageAlign.cc $H/ORBVocabularyDevice.cc $H/ygzf_pool.cc \
+    $REF/Thirdparty/DBoW2/DBoW2/FORB.cpp $REF/Thirdparty/DBoW2/DBoW2/BowVector.cpp $REF/Thirdparty/DBoW2/DBoW2/FeatureVector.cpp \
+    $REF/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp $REF/Thirdparty/DBoW2/DUtils/Random.cpp $REF/Thirdparty/DBoW2/DUtils/Timestamp.cpp \
+    $ROOT/tests/cpp/boundary_frame.cc $ROOT/tests/cpp/mini_cv_nocompute.cpp $ROOT/oracle/oracle_align.cpp $ROOT/oracle/oracle_direct.cpp"
+i=0
+for f in $SRCS; do i=$((i+1)); g++ $FLAGS $INC -c "$f" -o "$OUT/b_$i.o"; OBJS="$OBJS $OUT/b_$i.o"; done
+LINK="-L$ROOT/orb_ygz_slam_amd/lib -lygzf -Wl,-rpath,\$ORIGIN/../../../orb_ygz_slam_amd/lib"
+# what the link still misses = the members of the classes outside the hot path: each becomes an alias of one aborting function
+cat > "$OUT/outside.S" <<'ASM'
+    .text
+    .globl ygz_outside_the_hot_path
+    .type ygz_outside_the_hot_path, @function
+ygz_outside_the_hot_path:
+    jmp ygz_outside_abort@PLT
+ASM
+cat > "$OUT/outside_abort.cc" <<'CC'
+#include <cstdio>
+#include <cstdlib>
+extern "C" void ygz_outside_abort() { std::fprintf(stderr, "boundary build: a member of a class outside the hot path was called (aborting stand-in)\n"); std::abort(); }
+CC
+g++ -O2 -c "$OUT/outside_abort.cc" -o "$OUT/outside_abort.o"
+( g++ -pthread $OBJS "$OUT/outside_abort.o" $LINK -Wl,--no-demangle -o "$OUT/boundary_frame.try" 2>&1 || true ) | grep -o "undefined reference to \`[^']*'" | sed "s/undefined reference to \`//; s/'\$//" | sort -u > "$OUT/outside.syms"
+while read -r sym; do
+    case "$sym" in
+        _ZN3ygz*|_ZNK3ygz*) printf '    .globl %s\n    .set %s, ygz_outside_the_hot_path\n' "$sym" "$sym" >> "$OUT/outside.S" ;;
+        *) echo "unexpected undefined symbol outside namespace ygz: $sym"; exit 1 ;;
+    esac
+done < "$OUT/outside.syms"
+g++ -c "$OUT/outside.S" -o "$OUT/outside.o"
+g++ -pthread $OBJS "$OUT/outside_abort.o" "$OUT/outside.o" $LINK -o "$OUT/boundary_frame"
+cp "$OUT/outside.syms" "$OUT/boundary_frame.outside"
+rm -f $OBJS "$OUT/outside.S" "$OUT/outside.o" "$OUT/outside_abort.cc" "$OUT/outside_abort.o" "$OUT/outside.syms" "$OUT/boundary_frame.try"
 rm -f "$OUT/ref_ORBmatcher.o" "$OUT/ref_Align.o"
 # strong (T) = the product's definition was linked; weak (W) = the reference's body is still the one in use
-nm -C "$OUT/boundary_frame" | grep -E " [TW] ygz::ORBmatcher::(SearchByProjection|SearchByBoW|SearchForInitialization|FindDirectProjection|Fuse|SearchBySim3|SearchForTriangulation|DescriptorDistance)\(" | sed 's/^[0-9a-f]* //' | sort > "$OUT/boundary_frame.symbols"
+nm -C "$OUT/boundary_frame" | grep -E " [TW] ygz::(ORBmatcher::(SearchByProjection|SearchByBoW|SearchForInitialization|FindDirectProjection|Fuse|SearchBySim3|SearchForTriangulation|DescriptorDistance)|SparseImgAlign::run|ORBextractor::operator\(\)|Tracking::(TrackWithSparseAlignment|TrackWithMotionModel|SearchLocalPoints|MonocularInitialization|Relocalization|SearchLocalPointsDirect|TrackReferenceKeyFrame))\(" | sed 's/^[0-9a-f]* //' | sort > "$OUT/boundary_frame.symbols"
 echo "built $OUT/boundary_frame"

@@ -33,6 +33,11 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     imgL.tofile(tmp_path / "left.u8"); imgR.tofile(tmp_path / "right.u8"); imgN.tofile(tmp_path / "next.u8")
     voc = oracle.make_vocabulary(23, 10, 5)          # ORBvoc's shape (k = 10) one level shallower: 111 111 nodes, levelsup = 4 -> FeatureVector keys at level 1
     oracle.write_vocabulary_text(voc, str(tmp_path / "voc.txt"))
+    # the settings file Tracking::Tracking reads (src/Tracking.cc:83-213; Examples/Monocular/EuRoC.yaml's keys)
+    (tmp_path / "settings.yaml").write_text("%%YAML:1.0\nCamera.fx: %r\nCamera.fy: %r\nCamera.cx: %r\nCamera.cy: %r\nCamera.k1: 0.0\nCamera.k2: 0.0\n"
+                                            "Camera.p1: 0.0\nCamera.p2: 0.0\nCamera.bf: 47.9\nCamera.fps: 20.0\nCamera.RGB: 1\nORBextractor.nFeatures: %d\n"
+                                            "ORBextractor.scaleFactor: 1.2\nORBextractor.nLevels: %d\nORBextractor.iniThFAST: 20\nORBextractor.minThFAST: 7\n"
+                                            % (EUROC["fx"], EUROC["fy"], EUROC["cx"], EUROC["cy"], NF, L))
     out = subprocess.run([EXE, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "boundary ok" in out.stdout
@@ -107,7 +112,16 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     sym = open(EXE + ".symbols").read().splitlines()
     strong = [l for l in sym if l.startswith("T ")]
     weak = [l for l in sym if l.startswith("W ")]
-    assert len(strong) == 7 and all(any(n in l for l in strong) for n in ("FindDirectProjection", "SearchForInitialization", "DescriptorDistance", "SearchByBoW(ygz::KeyFrame*, ygz::Frame&"))
+    assert all(any(n in l for l in strong) for n in ("FindDirectProjection", "SearchForInitialization", "DescriptorDistance", "SearchByBoW(ygz::KeyFrame*, ygz::Frame&",
+                                                       "SparseImgAlign::run", "ORBextractor::operator()(ygz::Frame*"))
+    assert sum("ORBmatcher::" in l for l in strong) == 7
+    # the reference's own src/Tracking.cc is in the binary, unchanged, and its hot-path callers are there to call the product's definitions above
+    for member in ("TrackWithSparseAlignment", "TrackWithMotionModel", "SearchLocalPoints()", "MonocularInitialization", "Relocalization", "SearchLocalPointsDirect",
+                   "TrackReferenceKeyFrame"):
+        assert any(l.startswith("T ygz::Tracking::" + member) for l in strong), member
+    outside = open(EXE + ".outside").read().split()
+    assert 30 < len(outside) < 120 and all(x.startswith(("_ZN3ygz", "_ZNK3ygz")) for x in outside)       # what aborts when reached: members of classes outside the hot path only
+    assert not any(("ORBmatcher" in x) or ("SparseImgAlign" in x) or ("ORBextractor" in x) or ("3ygz5Frame" in x) for x in outside)
     assert len(weak) == 6 and all(any(n in l for l in weak) for n in ("Fuse", "SearchBySim3", "SearchForTriangulation"))
     # SearchLocalPoints: the reference's isInFrustum (CPU) marks, the shell searches
     fr = rd("m_frustum.bin", np.float32).reshape(-1, 5)
@@ -123,6 +137,21 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
                                                           fr[:, 3].astype(np.int32), dl, 3.0, False, 0.8)
     assert int(rd("m_nmatch2.bin", np.int32)[0]) == e_n2 and e_n2 > 50
     assert (rd("m_match2.bin", np.int32) == np.where(e_m2 >= 0, e_m2, -1)).all()
+    # ---- the reference's src/Tracking.cc drove the same two calls itself ----
+    # Tracking::TrackWithSparseAlignment: UpdateLastFrame, motion-model pose (identity velocity), mpAlign->run, SetPose(TCR * last): same inputs as
+    # the direct call above, so the same SE3 bit for bit, and within 1e-5 of the oracle
+    p7 = rd("t_pose7.bin", np.float32)
+    assert p7[7] == 1.0 and np.array_equal(p7[:7], t7[:7]) and np.abs(p7[:7] - o_T).max() <= 1e-5
+    # Tracking::SearchLocalPoints: IncreaseVisible bookkeeping, the reference's Frame::isInFrustum per local point, then
+    # ORBmatcher(0.8).SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, false) with th = 5 right after a relocalisation id, 1 otherwise (:1578-1590)
+    fid, visible, tn = rd("t_info.bin", np.int32)
+    assert tn == len(kn) and (rd("t_keys.bin", KP_DTYPE) == kn).all() and (rd("t_desc.bin", np.uint8).reshape(-1, 32) == dn).all()
+    th = 5.0 if fid < 2 else 1.0
+    e_n3, e_m3, _ = oracle.search_by_projection_mappoints(kn, dn, tab["scale"], w, h, EUROC, iv, fr[:, 1].copy(), fr[:, 2].copy(), fr[:, 4].copy(),
+                                                          fr[:, 3].astype(np.int32), dl, th, False, 0.8)
+    a3 = rd("t_match.bin", np.int32)
+    assert (a3 == np.where(e_m3 >= 0, e_m3, -1)).all() and (a3 >= 0).sum() == e_n3 and e_n3 > 30
+    assert visible == int(iv.sum())                                                      # every point the frustum test accepted was counted visible once
     # direct-tracked frame: Frame::ExtractORB took the DSO_KEYPOINT branch
     ko, do, _ = oracle.Extractor(NF, 1.2, L, 20, 7).extract_dso(imgN, existing=kn[:120])
     kd = rd("d_keys.bin", KP_DTYPE)

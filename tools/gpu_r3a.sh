@@ -1,2 +1,1 @@
-mkdir -p gpurun_out/r3a
-timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/r3a/pytest.log 2>&1; tail -4 gpurun_out/r3a/pytest.log
+timeout 600 python -m pytest tests/test_gpu_boundary.py -x -q -p no:cacheprovider 2>&1 | tail -25
