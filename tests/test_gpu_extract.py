@@ -153,6 +153,39 @@ def test_bench_clip_parity(oracle):
             prev = (k, d)
 
 
+def test_real_image_clip_parity(oracle):
+    """The clip bench.py cuts from the one real image the reference ships (Thirdparty/fast/test/data/test1.png: mirror-padded, zoomed, shifted
+    crops -- `other_workloads.euroc752x480_test1png`): every stage of three frames of different zoom levels, and keypoints / descriptors / matches of
+    a 24-frame run, equal the oracle.  Real content is less corner-dense than the generator (the FAST plan statistics differ)."""
+    from bench import make_frames_test1png
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    frames = make_frames_test1png(24, w, h)
+    assert frames.std() > 20 and (frames[0] != frames[8]).mean() > 0.5          # a real image, and the zoom levels differ
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=24)
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    ex.extract_batch_host(frames)
+    cam = make_camera(w, h)
+    ex.match_batch_prev(cam, 15.0, True, True, True)
+    counts = ex.match_counts()
+    for f in (0, 9, 23):
+        assert _cmp_frame(oracle, ex, oex, frames[f], f) > 500
+    I, z = np.eye(3, dtype=np.float32), np.zeros(3, np.float32)
+    prev = None
+    for f in range(24):
+        k, d = ex.batch_fetch(f)
+        ok, od = oex.extract(frames[f])
+        assert len(k) == len(ok) and (k == ok).all() and (d == od).all()
+        m, o = ex.match_fetch(f)
+        if prev is not None:
+            pk, pd = prev
+            world = np.stack([(pk["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]),
+                              (pk["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]), np.ones(len(pk), np.float32)], -1).astype(np.float32)
+            e_n, e_m, e_o = oracle.search_by_projection_last(k, d, oex.tables()["scale"], w, h, EUROC, pk, world, pd, I, z, I, z, 15.0)
+            assert counts[f] == e_n and (m[:len(k)] == e_m).all() and (o[:len(k)] == e_o).all()
+        prev = (k, d)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("YGZF_FUZZ_SEEDS", "10"))))
 def test_extract_fuzz_sizes_and_configs(oracle, seed):
     """Random image sizes / pyramid depths / scale factors / feature budgets / thresholds."""
