@@ -127,6 +127,7 @@ struct ygzf_ctx {
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
     Buf dFastStats;
     Buf dFastCells;                        // FastCellRec table of the current geometry (k_fast_tab)
+    Buf dPack;                             // inputs + outputs of a one-frame entry point, one copy each way (PackedTransfer)
     int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
@@ -203,6 +204,38 @@ static int ensure_stage(ygzf_ctx *c, size_t bytes) {
     c->hStageBytes = bytes;
     return YGZF_OK;
 }
+
+// One-frame entry points hand over a dozen small host arrays and take a few back.  From pageable memory every hipMemcpyAsync is a staged copy
+// of its own (10-20 us of runtime work apiece; twelve of them cost more than the kernel they feed): the arrays are packed into the context's
+// page-locked staging area and cross the link as ONE copy each way.
+struct PackedTransfer {
+    ygzf_ctx *c;
+    struct Seg { const void *src; void *dst; size_t bytes, off; };
+    std::vector<Seg> in, out;
+    size_t inBytes = 0, outBytes = 0;
+    explicit PackedTransfer(ygzf_ctx *c_) : c(c_) {}
+    static size_t al(size_t b) { return (b + 255) & ~(size_t) 255; }
+    size_t add_in(const void *src, size_t bytes) { const size_t o = inBytes; in.push_back({src, nullptr, bytes, o}); inBytes += al(bytes); return o; }
+    size_t add_out(void *dst, size_t bytes) { const size_t o = outBytes; out.push_back({nullptr, dst, bytes, o}); outBytes += al(bytes); return o; }
+    // device layout: [inputs | outputs] in c->dPack; returns the base
+    int upload(uint8_t **dBase) {
+        int rc;
+        if ((rc = ensure_stage(c, inBytes + outBytes + 256)) || (rc = ensure(c, c->dPack, inBytes + outBytes + 256))) return rc;
+        for (const Seg &s : in)
+            if (s.bytes) memcpy(c->hStage + s.off, s.src, s.bytes);
+        if (inBytes) HIPCHECK(c, hipMemcpyAsync(c->dPack.p, c->hStage, inBytes, hipMemcpyHostToDevice, c->stream));
+        *dBase = (uint8_t *) c->dPack.p;
+        return YGZF_OK;
+    }
+    uint8_t *d_out(size_t off) const { return (uint8_t *) c->dPack.p + inBytes + off; }
+    int download() {   // one copy back, then scattered to the caller's arrays; synchronises the stream
+        if (outBytes) HIPCHECK(c, hipMemcpyAsync(c->hStage + inBytes, (uint8_t *) c->dPack.p + inBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        for (const Seg &s : out)
+            if (s.bytes && s.dst) memcpy(s.dst, c->hStage + inBytes + s.off, s.bytes);
+        return YGZF_OK;
+    }
+};
 
 // Per-(w,h) geometry: level sizes, resize coefficient tables (cv::resize INTER_LINEAR fixed point, restated from the
 // OpenCV 2.4/3.2 algorithm: fx = (float)((dx+0.5)*scale - 0.5), 11-bit coefficients), FAST cell grid (:733-745),
@@ -723,6 +756,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dCachePyr.p) (void) hipFree(c->dCachePyr.p);
     if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
     if (c->dFastCells.p) (void) hipFree(c->dFastCells.p);
+    if (c->dPack.p) (void) hipFree(c->dPack.p);
     if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
     if (c->hFastStats) (void) hipHostFree(c->hFastStats);
     if (c->hStage) (void) hipHostFree(c->hStage);
@@ -1251,53 +1285,49 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
     }
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t nt = cur->n, nq = last_n;
-    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
-    ygzf_ctx::Buf *G = c->dGen;
     int counts[2] = {cur->n, last_n};
     float pose[24];
     memcpy(pose, Rcw, 36); memcpy(pose + 9, tcw, 12); memcpy(pose + 12, Rlw, 36); memcpy(pose + 21, tlw, 12);
-    Up ups[] = {{&G[0], cur->keys, nt * sizeof(ygzf_kp)}, {&G[1], cur->desc, nt * 32}, {&G[2], cur->u_right, cur->u_right ? nt * 4 : 0},
-                {&G[3], cur_owner, nt}, {&G[4], last_keys, nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32}, {&G[6], mp_world, nq * 12},
-                {&G[7], mp_valid, mp_valid ? nq : 0}, {&G[8], outlier, outlier ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
-                {&G[10], counts, sizeof counts}, {&G[11], pose, sizeof pose}};
+    PackedTransfer P(c);
+    const size_t oCurK = P.add_in(cur->keys, nt * sizeof(ygzf_kp)), oCurD = P.add_in(cur->desc, nt * 32), oUR = P.add_in(cur->u_right, cur->u_right ? nt * 4 : 0),
+                 oOwn = P.add_in(cur_owner, nt), oLastK = P.add_in(last_keys, nq * sizeof(ygzf_kp)), oMpD = P.add_in(mp_desc, nq * 32),
+                 oWorld = P.add_in(mp_world, nq * 12), oValid = P.add_in(mp_valid, mp_valid ? nq : 0), oOutl = P.add_in(outlier, outlier ? nq : 0),
+                 oObs = P.add_in(mp_has_obs, mp_has_obs ? nq : 0), oCnt = P.add_in(counts, sizeof counts), oPose = P.add_in(pose, sizeof pose);
+    const size_t rOwner = P.add_out(cur_owner, nt), rMatch = P.add_out(cur_match, nt * sizeof(int)), rN = P.add_out(nmatches, sizeof(int));
     int rc;
-    for (auto &u : ups) {
-        if (!u.bytes) continue;
-        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
-        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
-    }
-    if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
+    uint8_t *dIn;
+    if ((rc = P.upload(&dIn))) return rc;
     MatchArgs A;
     memset(&A, 0, sizeof A);
     A.maxDist = 100;   // TH_HIGH
-    A.curKeys = (const ygzf_kp *) G[0].p;
-    A.curDesc = (const uint8_t *) G[1].p;
-    A.curURight = cur->u_right ? (const float *) G[2].p : nullptr;
-    A.ownerIn = (const uint8_t *) G[3].p;
-    A.curCnt = (const int *) G[10].p;
+    A.curKeys = (const ygzf_kp *) (dIn + oCurK);
+    A.curDesc = dIn + oCurD;
+    A.curURight = cur->u_right ? (const float *) (dIn + oUR) : nullptr;
+    A.ownerIn = dIn + oOwn;
+    A.curCnt = (const int *) (dIn + oCnt);
     A.kpStrideCur = (long long) nt;
     A.cntStrideCur = 0;
     A.cntOffCur = 0;
-    A.lastKeys = (const ygzf_kp *) G[4].p;
-    A.mpDesc = (const uint8_t *) G[5].p;
-    A.world = (const float *) G[6].p;
-    A.mpValid = mp_valid ? (const uint8_t *) G[7].p : nullptr;
-    A.outlier = outlier ? (const uint8_t *) G[8].p : nullptr;
-    A.hasObs = mp_has_obs ? (const uint8_t *) G[9].p : nullptr;
-    A.lastCnt = (const int *) G[10].p;
+    A.lastKeys = (const ygzf_kp *) (dIn + oLastK);
+    A.mpDesc = dIn + oMpD;
+    A.world = (const float *) (dIn + oWorld);
+    A.mpValid = mp_valid ? dIn + oValid : nullptr;
+    A.outlier = outlier ? dIn + oOutl : nullptr;
+    A.hasObs = mp_has_obs ? dIn + oObs : nullptr;
+    A.lastCnt = (const int *) (dIn + oCnt);
     A.kpStrideLast = (long long) nq;
     A.cntStrideLast = 0;
     A.cntOffLast = 1;
-    A.poses = (const float *) G[11].p;
+    A.poses = (const float *) (dIn + oPose);
     fill_camera(A, cam, c);
     if (cur->scale_factors) for (int l = 0; l < kMaxLevels && l < cur->nlevels; l++) A.scaleFactors[l] = cur->scale_factors[l];
     A.th = th;
     A.bMono = b_mono != 0;
     A.checkLevel = check_level != 0;
     A.checkOri = check_orientation != 0;
-    A.owner = (uint8_t *) c->dOwner.p;
-    A.match = (int *) c->dMatch.p;
-    A.nmatches = (int *) c->dNMatch.p;
+    A.owner = P.d_out(rOwner);
+    A.match = (int *) P.d_out(rMatch);
+    A.nmatches = (int *) P.d_out(rN);
     A.capCur = (int) nt;
     A.capLast = (int) nq;
     size_t lds;
@@ -1307,10 +1337,7 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
         launch_match_last(c->stream, A, 1, lds);
     }
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(cur_owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(cur_match, c->dMatch.p, nt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = P.download())) return rc;
     c->lastMatchPairs = 0;
     return YGZF_OK;
 }

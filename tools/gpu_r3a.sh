@@ -1,1 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_extract.py -x -q -p no:cacheprovider -k "real_image or bench_clip" 2>&1 | tail -8
+timeout 300 python -m pytest tests/test_gpu_match.py tests/test_gpu_shells.py -x -q -s -p no:cacheprovider 2>&1 | grep -v "^$" | tail -14
+timeout 200 python tools/call_latency.py 2>/dev/null | head -8
