@@ -1609,8 +1609,8 @@ hipError_t upload_constants(const int *umax16) {
 // on the host.  The device levels have 64-byte pitches; a pitched device-to-host copy of an odd-width level is executed row by row by the
 // copy engine (1.3 ms per level), so the levels are packed here and leave in ONE linear copy.
 struct PackOffsets { unsigned v[kMaxLevels + 1]; };
-__global__ __launch_bounds__(256) void k_pack_levels(FrameSet fs, const LevelGeom *__restrict__ geom, PackOffsets off, uint8_t *__restrict__ dst) {
-    const int l = blockIdx.y;
+__global__ __launch_bounds__(256) void k_pack_levels(FrameSet fs, const LevelGeom *__restrict__ geom, PackOffsets off, uint8_t *__restrict__ dst, int firstLevel) {
+    const int l = blockIdx.y + firstLevel;
     const LevelGeom g = geom[l];
     int pitch;
     const uint8_t *src = level_ptr(fs, g, l, 0, &pitch);
@@ -1622,10 +1622,11 @@ __global__ __launch_bounds__(256) void k_pack_levels(FrameSet fs, const LevelGeo
     }
 }
 
-void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *offsets, uint8_t *dst) {
+void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int firstLevel, int nlevels, const unsigned *offsets, uint8_t *dst) {
+    if (firstLevel >= nlevels) return;
     PackOffsets off;
     for (int l = 0; l <= kMaxLevels; l++) off.v[l] = l <= nlevels ? offsets[l] : 0;
-    hipLaunchKernelGGL(k_pack_levels, dim3(128, nlevels), dim3(256), 0, st, fs, dGeom, off, dst);
+    hipLaunchKernelGGL(k_pack_levels, dim3(128, nlevels - firstLevel), dim3(256), 0, st, fs, dGeom, off, dst, firstLevel);
 }
 
 // rows of `w` bytes from a linear staging buffer (row pitch srcPitch) into a pitched image: the device half of an upload whose pitched

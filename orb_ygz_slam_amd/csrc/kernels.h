@@ -10,7 +10,7 @@ hipError_t upload_constants(const int *umax16);
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int w, size_t rows);
-void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const unsigned *offsets, uint8_t *dst);
+void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int firstLevel, int nlevels, const unsigned *offsets, uint8_t *dst);
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,
                        unsigned short *cellCnt, unsigned *slots, int totalCells, long long totalSlots, int totalGroups, int smapRows,
@@ -222,6 +222,7 @@ struct SiaArgs {
     float eps;
     float *patchCache;              // kpStride*48 floats per pair (16-byte aligned): 12 planes of kpStride float4, plane 3*row + {patch, dx, dy}
     float *jacCache;                // unused (Jacobians are rebuilt from dx, dy each iteration)
+    float *momCache;                // 4 floats per keypoint (16-byte aligned), pair p at + p*kpStride*4: gradient moments of the reference patch
     uint8_t *visible;               // kpStride per pair
     float *out;                     // 48 floats per pair: TCR[7], ret, iters, chi2, pad[2], H[36]
     long long *dbg;                 // nullable: phase clocks of pair 0 (debug)

@@ -871,16 +871,19 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     // The levels go back tight (pitch = width) into caller memory that is pageable as a rule (cv::Mat buffers).  Eight pitched device-to-host
     // copies took 10-13 ms for a 752x480 pyramid (the copy engine works an odd-width pitched copy off row by row, into page-locked memory
     // as well): the levels are packed on the device and leave in one linear copy through the context's page-locked staging buffer.
+    // Level 0 IS the caller's image: it is copied on the host while the other levels are on the link.
     unsigned offs[kMaxLevels + 1];
-    offs[0] = 0;
-    for (int l = 0; l < L; l++) offs[l + 1] = offs[l] + (unsigned) G.lv[l].w * (unsigned) G.lv[l].h;
+    offs[0] = offs[1] = 0;
+    for (int l = 1; l < L; l++) offs[l + 1] = offs[l] + (unsigned) G.lv[l].w * (unsigned) G.lv[l].h;
     const size_t total = offs[L];
-    if ((rc = ensure_stage(c, total)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
-    launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, L, offs, (uint8_t *) c->dTmpC.p);
+    if ((rc = ensure_stage(c, total + 64)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
+    launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->dTmpC.p);
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (total) HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (levels_out[0] != img || stride != w)
+        for (int y = 0; y < h; y++) memcpy(levels_out[0] + (size_t) y * w, img + (size_t) y * stride, (size_t) w);
     HIPCHECK(c, hipStreamSynchronize(c->stream));
-    for (int l = 0; l < L; l++) memcpy(levels_out[l], c->hStage + offs[l], offs[l + 1] - offs[l]);
+    for (int l = 1; l < L; l++) memcpy(levels_out[l], c->hStage + offs[l], offs[l + 1] - offs[l]);
     c->lastFrames = 0;
     c->pyrResident = true;
     c->pyrResW = w;
@@ -1375,14 +1378,7 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t N = ref->n;
     int rc;
-    ygzf_ctx::Buf *S = c->dSia;
-    // 0 keys, 1 world, 2 valid, 3 outlier, 4 images, 5 tables (poses + levels), 6 caches, 7 out
-    if ((rc = ensure(c, S[0], N * sizeof(ygzf_kp))) || (rc = ensure(c, S[1], N * 12)) || (rc = ensure(c, S[2], N)) || (rc = ensure(c, S[3], N)))
-        return rc;
-    HIPCHECK(c, hipMemcpyAsync(S[0].p, ref->keys, N * sizeof(ygzf_kp), hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(S[1].p, ref->mp_world, N * 12, hipMemcpyHostToDevice, c->stream));
-    if (ref->mp_valid) HIPCHECK(c, hipMemcpyAsync(S[2].p, ref->mp_valid, N, hipMemcpyHostToDevice, c->stream));
-    if (ref->outlier) HIPCHECK(c, hipMemcpyAsync(S[3].p, ref->outlier, N, hipMemcpyHostToDevice, c->stream));
+    ygzf_ctx::Buf *S = c->dSia;   // 4 images, 6 caches; the small arrays cross the link as one packed copy each way (PackedTransfer)
     std::vector<SiaLevel> lv(2 * kMaxLevels);
     memset(lv.data(), 0, lv.size() * sizeof(SiaLevel));
     size_t largestCur = 0;   // the largest current-frame level that may be staged in LDS beside the feature tables
@@ -1424,25 +1420,27 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
             }
         }
     }
-    const size_t tabBytes = 14 * sizeof(float) + lv.size() * sizeof(SiaLevel);
-    if ((rc = ensure(c, S[5], tabBytes + 64))) return rc;
     float poses[14];
     memcpy(poses, ref->Tcw, 28);
     memcpy(poses + 7, cur->Tcw, 28);
-    HIPCHECK(c, hipMemcpyAsync(S[5].p, poses, sizeof poses, hipMemcpyHostToDevice, c->stream));
-    SiaLevel *dLv = (SiaLevel *) ((uint8_t *) S[5].p + 64);
-    HIPCHECK(c, hipMemcpyAsync(dLv, lv.data(), lv.size() * sizeof(SiaLevel), hipMemcpyHostToDevice, c->stream));
-    if ((rc = ensure(c, S[6], N * (16 + 96) * sizeof(float) + N + 64)) || (rc = ensure(c, S[7], 48 * sizeof(float)))) return rc;
+    float out[48];
+    PackedTransfer P(c);
+    const size_t oKeys = P.add_in(ref->keys, N * sizeof(ygzf_kp)), oWorld = P.add_in(ref->mp_world, N * 12), oValid = P.add_in(ref->mp_valid, ref->mp_valid ? N : 0),
+                 oOutl = P.add_in(ref->outlier, ref->outlier ? N : 0), oPoses = P.add_in(poses, sizeof poses), oLv = P.add_in(lv.data(), lv.size() * sizeof(SiaLevel));
+    const size_t rOut = P.add_out(out, sizeof out);
+    uint8_t *dIn;
+    if ((rc = ensure(c, S[6], N * (16 + 96) * sizeof(float) + N + 64)) || (rc = P.upload(&dIn))) return rc;
+    const SiaLevel *dLv = (const SiaLevel *) (dIn + oLv);
     SiaArgs A;
     memset(&A, 0, sizeof A);
-    A.keys = (const ygzf_kp *) S[0].p;
-    A.world = (const float *) S[1].p;
-    A.mpValid = ref->mp_valid ? (const uint8_t *) S[2].p : nullptr;
-    A.outlier = ref->outlier ? (const uint8_t *) S[3].p : nullptr;
+    A.keys = (const ygzf_kp *) (dIn + oKeys);
+    A.world = (const float *) (dIn + oWorld);
+    A.mpValid = ref->mp_valid ? dIn + oValid : nullptr;
+    A.outlier = ref->outlier ? dIn + oOutl : nullptr;
     A.kpStride = (long long) N;
     A.nRef = nullptr;
     A.n = (int) N;
-    A.poses = (const float *) S[5].p;
+    A.poses = (const float *) (dIn + oPoses);
     A.refLv = dLv;
     A.curLv = dLv + kMaxLevels;
     A.lvStride = 0;
@@ -1453,7 +1451,8 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
     A.patchCache = (float *) S[6].p;
     A.jacCache = nullptr;
     A.visible = (uint8_t *) (A.patchCache + N * 48);
-    A.out = (float *) S[7].p;
+    A.momCache = A.patchCache + N * 64;   // (the buffer holds 112 floats per feature)
+    A.out = (float *) P.d_out(rOut);
     {
         if (c->siaDebug) {
             if ((rc = ensure(c, c->dTmpB, 256))) return rc;
@@ -1474,9 +1473,7 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
         launch_sia(c->stream, A, 1, sl);
     }
     HIPCHECK(c, hipGetLastError());
-    float out[48];
-    HIPCHECK(c, hipMemcpyAsync(out, S[7].p, sizeof out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = P.download())) return rc;
     if (A.dbg) {
         long long st[16];
         HIPCHECK(c, hipMemcpy(st, A.dbg, sizeof st, hipMemcpyDeviceToHost));
@@ -2001,27 +1998,30 @@ struct FrustumHost {   // host-side inputs of the fused isInFrustum stage (ygzf_
     int *level;
 };
 
-static int fill_frustum_args(ygzf_ctx *c, FrustumArgs &A, const ygzf_frustum_in *in, const ygzf_camera *cam, int n, int nlevels) {
+// The frustum inputs join the caller's packed upload (frustum_add_inputs before PackedTransfer::upload, frustum_fill_args after it).
+struct FrustumOffsets { size_t world, normal, maxInv, minInv, mfMax, cand; };
+
+static int frustum_add_inputs(ygzf_ctx *c, PackedTransfer &P, FrustumOffsets &O, const ygzf_frustum_in *in, int n, int nlevels) {
     if (!in->world || !in->normal || !in->max_dist_inv || !in->min_dist_inv || !in->mf_max_distance) return fail(c, YGZF_ERR_INVALID, "null frustum array");
     if (nlevels < 1 || nlevels > kMaxLevels) return fail(c, YGZF_ERR_INVALID, "nlevels out of range");
-    ygzf_ctx::Buf *B = c->dFr;
-    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
-    Up ups[] = {{&B[0], in->world, 12 * (size_t) n}, {&B[1], in->normal, 12 * (size_t) n}, {&B[2], in->max_dist_inv, 4 * (size_t) n},
-                {&B[3], in->min_dist_inv, 4 * (size_t) n}, {&B[4], in->mf_max_distance, 4 * (size_t) n}, {&B[5], in->candidate, in->candidate ? (size_t) n : 0}};
-    int rc;
-    for (auto &u : ups) {
-        if (!u.bytes) continue;
-        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
-        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
-    }
+    O.world = P.add_in(in->world, 12 * (size_t) n);
+    O.normal = P.add_in(in->normal, 12 * (size_t) n);
+    O.maxInv = P.add_in(in->max_dist_inv, 4 * (size_t) n);
+    O.minInv = P.add_in(in->min_dist_inv, 4 * (size_t) n);
+    O.mfMax = P.add_in(in->mf_max_distance, 4 * (size_t) n);
+    O.cand = P.add_in(in->candidate, in->candidate ? (size_t) n : 0);
+    return YGZF_OK;
+}
+
+static void frustum_fill_args(FrustumArgs &A, const uint8_t *dIn, const FrustumOffsets &O, const ygzf_frustum_in *in, const ygzf_camera *cam, int n, int nlevels) {
     memset(&A, 0, sizeof A);
     A.n = n;
-    A.candidate = in->candidate ? (const uint8_t *) B[5].p : nullptr;
-    A.world = (const float *) B[0].p;
-    A.normal = (const float *) B[1].p;
-    A.maxDistInv = (const float *) B[2].p;
-    A.minDistInv = (const float *) B[3].p;
-    A.mfMaxDistance = (const float *) B[4].p;
+    A.candidate = in->candidate ? dIn + O.cand : nullptr;
+    A.world = (const float *) (dIn + O.world);
+    A.normal = (const float *) (dIn + O.normal);
+    A.maxDistInv = (const float *) (dIn + O.maxInv);
+    A.minDistInv = (const float *) (dIn + O.minInv);
+    A.mfMaxDistance = (const float *) (dIn + O.mfMax);
     memcpy(A.Rcw, in->Rcw, 36);
     memcpy(A.tcw, in->tcw, 12);
     memcpy(A.Ow, in->Ow, 12);
@@ -2030,7 +2030,6 @@ static int fill_frustum_args(ygzf_ctx *c, FrustumArgs &A, const ygzf_frustum_in 
     A.viewingCosLimit = in->viewing_cos_limit;
     predict_scale_steps(in->log_scale_factor, nlevels, A.levelStep);
     A.nLevels = nlevels;
-    return YGZF_OK;
 }
 
 // shared body of the two searches whose queries arrive already projected (mode 1: F x local MapPoints, mode 2: Cur x KeyFrame points)
@@ -2056,77 +2055,96 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     } else if (!last_keys || !match12) return fail(c, YGZF_ERR_INVALID, "null array");
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t nt = F->n, nq = n_mp;
-    ygzf_ctx::Buf *G = c->dGen;
     int counts[2] = {F->n, n_mp};
     float pose[24] = {0};
-    std::vector<ygzf_kp> dummyKeys(last_keys ? 0 : nq);   // the Last-keypoint array is not read in modes 1, 2; keep the pointer valid
-    if (!last_keys) memset(dummyKeys.data(), 0, nq * sizeof(ygzf_kp));
-    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
-    Up ups[] = {{&G[0], F->keys, nt * sizeof(ygzf_kp)}, {&G[1], F->desc, nt * 32}, {&G[2], F->u_right, F->u_right ? nt * 4 : 0},
-                {&G[3], owner, nt}, {&G[4], last_keys ? last_keys : dummyKeys.data(), nq * sizeof(ygzf_kp)}, {&G[5], mp_desc, nq * 32},
-                {&G[6], proj_x, fr ? 0 : nq * 4}, {&G[7], track_in_view, track_in_view && !fr ? nq : 0}, {&G[8], is_bad, is_bad ? nq : 0}, {&G[9], mp_has_obs, mp_has_obs ? nq : 0},
-                {&G[10], counts, sizeof counts}, {&G[11], pose, sizeof pose}};
+    const int frLevels = F->nlevels > 0 ? F->nlevels : c->tab.cfg.nlevels;
+    // one packed copy in, one out (PackedTransfer).  The per-MapPoint arrays the fused isInFrustum stage WRITES (projections, viewing cosine,
+    // predicted level, in-view flag) live in the output half so that the caller's optional copies of them ride the same copy back.
+    PackedTransfer P(c);
+    const size_t oCurK = P.add_in(F->keys, nt * sizeof(ygzf_kp)), oCurD = P.add_in(F->desc, nt * 32), oUR = P.add_in(F->u_right, F->u_right ? nt * 4 : 0),
+                 oOwn = P.add_in(owner, nt), oLastK = P.add_in(last_keys, last_keys ? nq * sizeof(ygzf_kp) : 0), oMpD = P.add_in(mp_desc, nq * 32),
+                 oBad = P.add_in(is_bad, is_bad ? nq : 0), oObs = P.add_in(mp_has_obs, mp_has_obs ? nq : 0), oCnt = P.add_in(counts, sizeof counts),
+                 oPose = P.add_in(pose, sizeof pose);
+    size_t oPX = 0, oPY = 0, oPXR = 0, oVC = 0, oLv = 0, oTV = 0;
+    size_t rPX = 0, rPY = 0, rPXR = 0, rVC = 0, rLv = 0, rTV = 0, rM12 = 0, rOwner = 0, rMatch = 0;
+    FrustumOffsets FO;
     int rc;
-    for (auto &u : ups) {
-        if (!u.bytes) continue;
-        if ((rc = ensure(c, *u.b, u.bytes))) return rc;
-        HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
+    if (fr) {
+        if ((rc = frustum_add_inputs(c, P, FO, fr->in, n_mp, frLevels))) return rc;
+        rLv = P.add_out(fr->level, nq * 4);
+        rTV = P.add_out(fr->in_view, nq);
+        rPX = P.add_out(fr->proj_x, nq * 4);
+        rPY = P.add_out(fr->proj_y, nq * 4);
+        rPXR = P.add_out(fr->proj_xr, nq * 4);
+        rVC = P.add_out(fr->view_cos, nq * 4);
+    } else {
+        oPX = P.add_in(proj_x, nq * 4);
+        oPY = P.add_in(proj_y, nq * 4);
+        oPXR = P.add_in(proj_xr, proj_xr ? nq * 4 : 0);
+        if (mode != 3) {
+            oTV = P.add_in(track_in_view, nq);
+            oVC = P.add_in(mode == 2 ? mp_angle : view_cos, nq * 4);
+            oLv = P.add_in(scale_level, nq * 4);
+        }
     }
-    // remaining per-MapPoint arrays share one scratch buffer: projY | projXR | viewCos | level
-    if ((rc = ensure(c, c->dTmpA, nq * 16))) return rc;
-    float *dY = (float *) c->dTmpA.p, *dXR = dY + nq, *dVC = dXR + nq;
-    int *dLv = (int *) (dVC + nq);
+    if (mode == 3) rM12 = P.add_out(match12, nq * sizeof(int));
+    rOwner = P.add_out(mode == 3 ? nullptr : owner, nt);            // mode 3 keeps them as kernel scratch (the caller derives them from match12)
+    rMatch = P.add_out(mode == 3 ? nullptr : (void *) match, nt * sizeof(int));
+    const size_t rN = P.add_out(nmatches, sizeof(int));
+    uint8_t *dIn;
+    if ((rc = P.upload(&dIn))) return rc;
+    const float *dPX, *dY, *dXR, *dVC;
+    const int *dLv;
+    const uint8_t *dTV;
     if (fr) {   // Frame::isInFrustum on the device: its outputs land where the matcher reads them
-        if ((rc = ensure(c, G[6], nq * 4)) || (rc = ensure(c, G[7], nq))) return rc;
         FrustumArgs FA;
-        if ((rc = fill_frustum_args(c, FA, fr->in, cam, n_mp, F->nlevels > 0 ? F->nlevels : c->tab.cfg.nlevels))) return rc;
-        FA.inView = (uint8_t *) G[7].p;
-        FA.projX = (float *) G[6].p;
-        FA.projY = dY;
-        FA.projXR = dXR;
-        FA.viewCos = dVC;
-        FA.level = dLv;
-        HIPCHECK(c, hipMemsetAsync(dLv, 0, nq * 4, c->stream));   // the matcher indexes scaleFactors[level] only for in-view points
+        frustum_fill_args(FA, dIn, FO, fr->in, cam, n_mp, frLevels);
+        FA.inView = P.d_out(rTV);
+        FA.projX = (float *) P.d_out(rPX);
+        FA.projY = (float *) P.d_out(rPY);
+        FA.projXR = (float *) P.d_out(rPXR);
+        FA.viewCos = (float *) P.d_out(rVC);
+        FA.level = (int *) P.d_out(rLv);
+        HIPCHECK(c, hipMemsetAsync(FA.level, 0, nq * 4, c->stream));   // the matcher indexes scaleFactors[level] only for in-view points
         {
             ProfScope ps(c, KK_FRUSTUM);
             launch_frustum(c->stream, FA);
         }
+        dPX = FA.projX; dY = FA.projY; dXR = FA.projXR; dVC = FA.viewCos; dLv = FA.level; dTV = FA.inView;
     } else {
-        HIPCHECK(c, hipMemcpyAsync(dY, proj_y, nq * 4, hipMemcpyHostToDevice, c->stream));
-        if (proj_xr) HIPCHECK(c, hipMemcpyAsync(dXR, proj_xr, nq * 4, hipMemcpyHostToDevice, c->stream));
+        dPX = (const float *) (dIn + oPX);
+        dY = (const float *) (dIn + oPY);
+        dXR = proj_xr ? (const float *) (dIn + oPXR) : nullptr;
+        dVC = (const float *) (dIn + oVC);     // unused in mode 3
+        dLv = (const int *) (dIn + oLv);
+        dTV = mode != 3 ? dIn + oTV : nullptr;
     }
-    if (fr) {
-    } else if (mode != 3) {
-        HIPCHECK(c, hipMemcpyAsync(dVC, mode == 2 ? mp_angle : view_cos, nq * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(c, hipMemcpyAsync(dLv, scale_level, nq * 4, hipMemcpyHostToDevice, c->stream));
-    } else if ((rc = ensure(c, c->dTmpB, nq * sizeof(int)))) return rc;
-    if ((rc = ensure(c, c->dOwner, nt)) || (rc = ensure(c, c->dMatch, nt * sizeof(int))) || (rc = ensure(c, c->dNMatch, sizeof(int)))) return rc;
     MatchArgs A;
     memset(&A, 0, sizeof A);
     A.maxDist = 100;   // TH_HIGH
     A.mode = mode;
     A.specDeep = mode == 1 ? 1 : 0;   // best AND runner-up among the free candidates: lists of eight (match_kernels.hip)
     A.maxDist = max_dist;
-    A.curKeys = (const ygzf_kp *) G[0].p;
-    A.curDesc = (const uint8_t *) G[1].p;
-    A.curURight = F->u_right ? (const float *) G[2].p : nullptr;
-    A.ownerIn = (const uint8_t *) G[3].p;
-    A.curCnt = (const int *) G[10].p;
+    A.curKeys = (const ygzf_kp *) (dIn + oCurK);
+    A.curDesc = dIn + oCurD;
+    A.curURight = F->u_right ? (const float *) (dIn + oUR) : nullptr;
+    A.ownerIn = dIn + oOwn;
+    A.curCnt = (const int *) (dIn + oCnt);
     A.kpStrideCur = (long long) nt;
-    A.lastKeys = (const ygzf_kp *) G[4].p;
-    A.mpDesc = (const uint8_t *) G[5].p;
-    A.world = (const float *) G[6].p;     // unused in this mode
-    A.mpValid = (track_in_view || fr) ? (const uint8_t *) G[7].p : nullptr;
-    A.match12 = (int *) c->dTmpB.p;
-    A.outlier = is_bad ? (const uint8_t *) G[8].p : nullptr;
-    A.hasObs = mp_has_obs ? (const uint8_t *) G[9].p : nullptr;
-    A.lastCnt = (const int *) G[10].p;
+    A.lastKeys = (const ygzf_kp *) (dIn + (last_keys ? oLastK : 0));   // not read in modes 1, 2: any valid address
+    A.mpDesc = dIn + oMpD;
+    A.world = dPX;     // unused in these modes
+    A.mpValid = dTV;
+    A.match12 = mode == 3 ? (int *) P.d_out(rM12) : nullptr;
+    A.outlier = is_bad ? dIn + oBad : nullptr;
+    A.hasObs = mp_has_obs ? dIn + oObs : nullptr;
+    A.lastCnt = (const int *) (dIn + oCnt);
     A.kpStrideLast = (long long) nq;
     A.cntOffLast = 1;
-    A.poses = (const float *) G[11].p;
-    A.mpProjX = (const float *) G[6].p;
+    A.poses = (const float *) (dIn + oPose);
+    A.mpProjX = dPX;
     A.mpProjY = dY;
-    A.mpProjXR = (proj_xr || fr) ? dXR : nullptr;
+    A.mpProjXR = dXR;
     A.mpViewCos = dVC;
     A.mpAngle = dVC;
     A.mpLevel = dLv;
@@ -2137,9 +2155,9 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     A.bMono = 1;
     A.checkLevel = check_level != 0;
     A.checkOri = check_ori != 0;
-    A.owner = (uint8_t *) c->dOwner.p;
-    A.match = (int *) c->dMatch.p;
-    A.nmatches = (int *) c->dNMatch.p;
+    A.owner = P.d_out(rOwner);
+    A.match = (int *) P.d_out(rMatch);
+    A.nmatches = (int *) P.d_out(rN);
     A.capCur = (int) nt;
     A.capLast = (int) nq;
     size_t lds;
@@ -2159,21 +2177,7 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         fprintf(stderr, "[ygzf match mode %d, 100MHz ticks] grid %lld  proj %lld  spec %lld  seq %lld  tail %lld  rescans %lld of %lld queries\n", mode,
                 st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6], st[7]);
     }
-    if (fr) {
-        if (fr->in_view) HIPCHECK(c, hipMemcpyAsync(fr->in_view, G[7].p, nq, hipMemcpyDeviceToHost, c->stream));
-        if (fr->proj_x) HIPCHECK(c, hipMemcpyAsync(fr->proj_x, G[6].p, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        if (fr->proj_y) HIPCHECK(c, hipMemcpyAsync(fr->proj_y, dY, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        if (fr->proj_xr) HIPCHECK(c, hipMemcpyAsync(fr->proj_xr, dXR, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        if (fr->view_cos) HIPCHECK(c, hipMemcpyAsync(fr->view_cos, dVC, nq * 4, hipMemcpyDeviceToHost, c->stream));
-        if (fr->level) HIPCHECK(c, hipMemcpyAsync(fr->level, dLv, nq * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    if (mode == 3) HIPCHECK(c, hipMemcpyAsync(match12, c->dTmpB.p, nq * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    else {
-        HIPCHECK(c, hipMemcpyAsync(owner, c->dOwner.p, nt, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(c, hipMemcpyAsync(match, c->dMatch.p, nt * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = P.download())) return rc;
     c->lastMatchPairs = 0;
     return YGZF_OK;
 }
@@ -2268,27 +2272,26 @@ int ygzf_is_in_frustum_batch(ygzf_ctx *c, const ygzf_camera *cam, int nlevels, i
     if (n == 0) return YGZF_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, c->dTmpA, (size_t) n * 20 + 64)) || (rc = ensure(c, c->dOwner, (size_t) n))) return rc;
+    PackedTransfer P(c);
+    FrustumOffsets FO;
+    if ((rc = frustum_add_inputs(c, P, FO, in, n, nlevels))) return rc;
+    const size_t N = (size_t) n;
+    const size_t rPX = P.add_out(proj_x, 4 * N), rPY = P.add_out(proj_y, 4 * N), rPXR = P.add_out(proj_xr, 4 * N), rVC = P.add_out(view_cos, 4 * N),
+                 rLv = P.add_out(level, 4 * N), rIV = P.add_out(in_view, N);
+    uint8_t *dIn;
+    if ((rc = P.upload(&dIn))) return rc;
     FrustumArgs A;
-    if ((rc = fill_frustum_args(c, A, in, cam, n, nlevels))) return rc;
-    float *base = (float *) c->dTmpA.p;
-    A.inView = (uint8_t *) c->dOwner.p;
-    A.projX = base; A.projY = base + n; A.projXR = base + 2 * (size_t) n; A.viewCos = base + 3 * (size_t) n;
-    A.level = (int *) (base + 4 * (size_t) n);
-    HIPCHECK(c, hipMemsetAsync(base, 0, (size_t) n * 20, c->stream));
+    frustum_fill_args(A, dIn, FO, in, cam, n, nlevels);
+    A.inView = P.d_out(rIV);
+    A.projX = (float *) P.d_out(rPX); A.projY = (float *) P.d_out(rPY); A.projXR = (float *) P.d_out(rPXR); A.viewCos = (float *) P.d_out(rVC);
+    A.level = (int *) P.d_out(rLv);
+    HIPCHECK(c, hipMemsetAsync(P.d_out(0), 0, P.outBytes, c->stream));   // rejected points read as zeros
     {
         ProfScope ps(c, KK_FRUSTUM);
         launch_frustum(c->stream, A);
     }
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(in_view, A.inView, (size_t) n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(proj_x, A.projX, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(proj_y, A.projY, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(proj_xr, A.projXR, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(view_cos, A.viewCos, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(level, A.level, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    return YGZF_OK;
+    return P.download();
 }
 
 int ygzf_search_local_points(ygzf_ctx *c, const ygzf_frame_view *F, const ygzf_camera *cam, int n_mp, const ygzf_frustum_in *in,
@@ -2764,6 +2767,7 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
     A.patchCache = (float *) S[2].p;
     A.jacCache = nullptr;
     A.visible = (uint8_t *) (A.patchCache + (size_t) B * G.kpStride * 48);
+    A.momCache = A.patchCache + (size_t) B * G.kpStride * 64;   // (the buffer holds 112 floats per keypoint slot)
     A.out = (float *) S[3].p;
     const int first = c->carryPyrValid ? 0 : 1;   // without a carried pyramid frame 0 has no reference image
     if (!c->carryPyrValid) HIPCHECK(c, hipMemsetAsync(S[3].p, 0, 48 * sizeof(float), c->stream));
@@ -2777,6 +2781,7 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
         A2.curLv += (size_t) first * A.lvStride;
         A2.patchCache += (size_t) first * G.kpStride * 48;
         A2.visible += (size_t) first * G.kpStride;
+        A2.momCache += (size_t) first * G.kpStride * 4;
         A2.out += (size_t) first * 48;
         size_t sl = sia_lds_bytes(G.kpStride);
         A2.ldsFeat = G.kpStride;
