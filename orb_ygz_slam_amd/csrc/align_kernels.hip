@@ -143,7 +143,126 @@ __device__ __forceinline__ void wave_sums_30(const float (&acc)[kAcc], float *ou
         if ((lane & 15) == 0 && k < kAcc) out[k] = v;
     }
 }
-  // 21 upper-triangular H entries + 6 b + chi2 + n_meas + n_visible_features
+
+// ---- the 6x6 solve and the SE3 update on the lanes of one wave --------------------------------------------------------------------
+// lane_get: a value of another lane (per-lane source, LDS crossbar); lane_bcast: the value of one lane, wave-uniform (source lane uniform)
+__device__ __forceinline__ float lane_get(float v, int srcLane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(srcLane << 2, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float lane_bcast(float v, int srcLane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), srcLane));
+}
+
+// x = H.ldlt().solve(b) with ldlt_solve6's arithmetic -- the same operations on the same operands in the same order, element by element --
+// spread over a wave: lane 8 i + j holds A[i][j] (j < 6), b[i] (j = 6) and the permutation entry perm[i] (j = 7).  Per elimination step the
+// pivot search reads the remaining diagonal through readlane (uniform), the row / column exchange is ONE permutation of the lanes (the
+// one-lane form spends 28 predicated moves per candidate row on it), every lane forms its own l = A[i][k] / d and updates its own element.
+// The right-hand side rides along as column 6 (b[i] -= l_i b[k] at step k is the forward substitution's j = k term).  What is left -- 6
+// divisions by D, the 15-term backward substitution, the un-permutation -- runs on uniform values.  Returns x[q] in lane q (q < 6).
+// All 64 lanes of the wave must be active.  52 us -> see DESIGN.md for the measured gain.
+template <int k>
+__device__ __forceinline__ float ldlt_step_wave(float a, int i, int j) {
+    if (k < 5) {
+        int p = k;
+        float best = fabsf(lane_bcast(a, 9 * k));
+#pragma unroll
+        for (int r = k + 1; r < 6; r++) {
+            const float v = fabsf(lane_bcast(a, 9 * r));
+            if (v > best) { best = v; p = r; }
+        }
+        if (p != k) {   // uniform: exchange rows / columns k and p (columns 6 and 7 follow their rows)
+            const int si = i == k ? p : (i == p ? k : i);
+            const int sj = j == k ? p : (j == p ? k : j);
+            a = lane_get(a, 8 * si + sj);
+        }
+    }
+    const float d = lane_bcast(a, 9 * k);
+    // A[i][k]: lane k of the own group of eight -- two DPP row broadcasts (a DPP row of 16 lanes holds matrix rows 2r and 2r + 1), so the
+    // division starts at once and covers the LDS-crossbar latency of the A[k][j] fetch
+    const float akj = lane_get(a, 8 * k + j);
+    const int ai = __builtin_bit_cast(int, a);
+    const float e0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x150 + k, 0xf, 0xf, false));       // row_newbcast:k
+    const float e1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ai, 0x150 + 8 + k, 0xf, 0xf, false));   // row_newbcast:8+k
+    const float aik = (i & 1) ? e1 : e0;
+    const float l = aik / d;
+    if (i > k && i < 6) {
+        if (j > k && j <= 6) a -= l * akj;
+        else if (j == k) a = l;
+    }
+    return a;
+}
+
+__device__ __forceinline__ float ldlt_solve6_wave(float a, int lane) {
+    const int i = lane >> 3, j = lane & 7;
+    if (j == 7) a = (float) i;   // perm[i] = i
+    a = ldlt_step_wave<0>(a, i, j);
+    a = ldlt_step_wave<1>(a, i, j);
+    a = ldlt_step_wave<2>(a, i, j);
+    a = ldlt_step_wave<3>(a, i, j);
+    a = ldlt_step_wave<4>(a, i, j);
+    a = ldlt_step_wave<5>(a, i, j);
+    // lane (i, i): D[i]; lane (i, j < i): L[i][j]; lane (i, 6): the forward-substituted right-hand side; lane (i, 7): perm[i]
+    const float q = a / lane_get(a, 9 * i);
+    float y[6], z[6];
+#pragma unroll
+    for (int r = 0; r < 6; r++) y[r] = lane_bcast(q, 8 * r + 6);
+#pragma unroll
+    for (int r = 5; r >= 0; r--) {
+        float sacc = y[r];
+#pragma unroll
+        for (int c = r + 1; c < 6; c++) sacc -= lane_bcast(a, 8 * c + r) * z[c];
+        z[r] = sacc;
+    }
+    float x = 0.f;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+        if ((int) lane_bcast(a, 8 * r + 7) == lane) x = z[r];
+    return x;
+}
+
+// se3_exp (se3_device.h) on a wave, uniform result: the four sinf / cosf evaluations -- most of its instructions -- become two, lane 0
+// working on theta / 2 and lane 1 on theta (the same functions on the same arguments as the one-lane form: the same bits).
+__device__ __forceinline__ Se3 se3_exp_wave(const float a[6], int lane) {
+    const float *om = a + 3;
+    const float theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const float theta = sqrtf(theta_sq);
+    const float half_theta = 0.5f * theta;
+    const bool small_angle = theta < kSophusEps;
+    float sin_half = 0.f, cos_half = 0.f, sin_th = 0.f, cos_th = 0.f;
+    if (!small_angle) {
+        const float arg = (lane & 1) ? theta : half_theta;
+        const float sv = sinf(arg), cv = cosf(arg);
+        sin_half = lane_bcast(sv, 0); cos_half = lane_bcast(cv, 0);
+        sin_th = lane_bcast(sv, 1); cos_th = lane_bcast(cv, 1);
+    }
+    float imag_factor, real_factor;
+    if (small_angle) {
+        const float theta_po4 = theta_sq * theta_sq;
+        imag_factor = 0.5f - (float) (1.0 / 48.0) * theta_sq + (float) (1.0 / 3840.0) * theta_po4;
+        real_factor = 1.f - 0.5f * theta_sq + (float) (1.0 / 384.0) * theta_po4;
+    } else {
+        imag_factor = sin_half / theta;
+        real_factor = cos_half;
+    }
+    Se3 r;
+    r.q[3] = real_factor;
+    r.q[0] = imag_factor * om[0]; r.q[1] = imag_factor * om[1]; r.q[2] = imag_factor * om[2];
+    quat_normalize(r.q);
+    const float O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
+    float O2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    float V[9];
+    if (small_angle) {
+        quat_to_R(r.q, V);
+    } else {
+        const float c1 = (1.f - cos_th) / theta_sq;
+        const float c2 = (theta - sin_th) / (theta_sq * theta);
+        for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * O[i] + c2 * O2[i];
+    }
+    for (int i = 0; i < 3; i++) r.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
+    return r;
+}
 
 // DBG: phase clocks (YGZF_SIA_DEBUG) are compiled in only in the instrumented instantiation; the production kernel reads no clock
 template <bool DBG>
@@ -153,7 +272,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     __shared__ float s_red[(kSiaBlock / 16) * kAcc];   // one partial per row of 16 lanes
     __shared__ float s_tot[kAcc];
     __shared__ Se3 s_T, s_Told, s_Tref;
-    __shared__ float s_H[36], s_b[6], s_x[6];
+    __shared__ float s_H[36];
     __shared__ float s_chi2, s_newchi2;
     __shared__ int s_stop, s_break, s_nmeas, s_iters;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -436,7 +555,8 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 if (lane == 0) A.dbg[8 + wave] += c1 - c0;
             }
             __syncthreads();
-            if (wave == 0) {
+            long long c2 = 0;
+            if (wave == 0) {   // the whole wave stays together from here to the barrier: totals, solve and update are wave-uniform
                 if (lane < kAcc) {
                     float v = 0.f;
 #pragma unroll
@@ -446,37 +566,48 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            const long long c2 = DBG ? wall_clock64() : 0;
-            if (tid == 0) {
-                float r[kAcc];
-                for (int k = 0; k < kAcc; k++) r[k] = s_tot[k];
-                int t = 0;
-                for (int a = 0; a < 6; a++)
-                    for (int b2 = a; b2 < 6; b2++, t++) { s_H[6 * a + b2] = r[t]; s_H[6 * b2 + a] = r[t]; }
-                for (int a = 0; a < 6; a++) s_b[a] = r[21 + a];
-                s_nmeas = (int) r[28];
-                s_iters++;
-                const float new_chi2 = r[27] / r[28];           // chi2 / n_meas_ (NaN when nothing is visible, as the reference)
-                float x[6];
+                if (DBG) c2 = wall_clock64();
+                // lane 8 i + j: H[i][j] (accumulator of the upper-triangular entry), b[i] for j = 6
+                const int ei = lane >> 3, ej = lane & 7;
+                const int lo = min(ei, ej), hi = max(ei, ej);
+                const int tIdx = ej < 6 ? 6 * lo - ((lo * (lo - 1)) >> 1) + (hi - lo) : 21 + ei;
+                float el = (ei < 6 && ej < 7) ? s_tot[tIdx] : 0.f;
+                const float chiSum = s_tot[27], nMeas = s_tot[28];
+                if (ei < 6 && ej < 6) s_H[6 * ei + ej] = el;
+                const float new_chi2 = chiSum / nMeas;           // chi2 / n_meas_ (NaN when nothing is visible, as the reference)
                 const long long q0 = DBG ? wall_clock64() : 0;
-                ldlt_solve6(s_H, s_b, x);
-                if (DBG && A.dbg) A.dbg[7] += wall_clock64() - q0;
-                for (int a = 0; a < 6; a++) s_x[a] = x[a];
-                if (isnan(x[0])) s_stop = 1;                     // solve() failed -> stop_ (:235-236)
-                if ((iter > 0 && (double) new_chi2 > 1.2 * (double) s_chi2) || s_stop) {
-                    s_T = s_Told;                                // rollback
-                    s_break = 1;
-                } else {
+                const float xl = ldlt_solve6_wave(el, lane);
+                if (DBG && lane == 0 && A.dbg) A.dbg[7] += wall_clock64() - q0;
+                float x[6];
+#pragma unroll
+                for (int a2 = 0; a2 < 6; a2++) x[a2] = lane_bcast(xl, a2);
+                const bool stop = s_stop || isnan(x[0]);         // solve() failed -> stop_ (:235-236)
+                const bool rollback = (iter > 0 && (double) new_chi2 > 1.2 * (double) s_chi2) || stop;
+                Se3 Tnew = T;
+                bool conv = false;
+                if (!rollback) {
                     float negx[6];
-                    for (int a = 0; a < 6; a++) negx[a] = -x[a];
-                    const Se3 Tnew = se3_mul(s_T, se3_exp(negx));   // update(): T_new = T_old * exp(-x)
-                    s_Told = s_T;
-                    s_T = Tnew;
-                    s_chi2 = new_chi2;
+#pragma unroll
+                    for (int a2 = 0; a2 < 6; a2++) negx[a2] = -x[a2];
+                    Tnew = se3_mul(T, se3_exp_wave(negx, lane));   // update(): T_new = T_old * exp(-x)
                     float nm = 0.f;
-                    for (int a = 0; a < 6; a++) nm = fmaxf(nm, fabsf(x[a]));
-                    if (nm <= A.eps) s_break = 1;                // converged
+#pragma unroll
+                    for (int a2 = 0; a2 < 6; a2++) nm = fmaxf(nm, fabsf(x[a2]));
+                    conv = nm <= A.eps;                          // converged
+                }
+                if (lane == 0) {
+                    s_nmeas = (int) nMeas;
+                    s_iters++;
+                    if (stop) s_stop = 1;
+                    if (rollback) {
+                        s_T = s_Told;
+                        s_break = 1;
+                    } else {
+                        s_Told = T;
+                        s_T = Tnew;
+                        s_chi2 = new_chi2;
+                        if (conv) s_break = 1;
+                    }
                 }
             }
             if (DBG && tid == 0 && A.dbg) { const long long c3 = wall_clock64(); A.dbg[0] += c1 - c0; A.dbg[1] += c2 - c1; A.dbg[2] += c3 - c2; A.dbg[3] += 1; }

@@ -80,8 +80,15 @@ struct MatchArgs {
     long long spillStride;         // bytes per pair
     void *qpScratch;               // capLast * 32 bytes per pair when !qpInLds
     long long *dbg;                // nullable: 8 wall_clock64 stamps per pair (phase timing, debug)
+    // A pair spread over `split` workgroups (few pairs per launch: one Tracking frame): every workgroup builds the grid, takes the queries
+    // i % split == its part through projection + speculative lists and leaves them in splitX; the workgroup that arrives last at
+    // splitCnt[pair] gathers all lists and runs the in-order pass.  split <= 1: one workgroup per pair, nothing crosses global memory.
+    int split;
+    int *splitCnt;                 // one counter per pair, zero between launches (the last workgroup resets it)
+    unsigned char *splitX;         // kMatchSplitRec * capLast bytes per pair
 };
 constexpr int kSpillSpec = 1, kSpillMisc = 2;
+constexpr int kMatchSplitRec = 56;   // uint4 + uint4 (lists of eight) + ushort4 + ushort4 + float angle + hasObs word
 size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_t *spillBytes, bool specDeep);
 hipError_t match_prepare(size_t ldsBytes);
 void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt, long long kpStride, int maxKp, int nFrames, float fx,

@@ -171,12 +171,38 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
     return wbest;
 }
 
+// Two lanes' ascending lists of eight (key, index) folded into the eight smallest of both, ascending, in BOTH lanes: the element-wise
+// minimum against the partner's reversed list is the lower half of a bitonic merge and itself bitonic; three compare-exchange stages
+// sort it.  Keys are unique (they carry the visiting order) except for the 0xFFFFFFFF of empty entries.
+template <int kDppCtrl>
+__device__ __forceinline__ void spec_merge8(unsigned (&K)[8], unsigned (&J)[8]) {
+    unsigned pk[8], pj[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        pk[e] = (unsigned) __builtin_amdgcn_update_dpp(0, (int) K[7 - e], kDppCtrl, 0xf, 0xf, false);
+        pj[e] = (unsigned) __builtin_amdgcn_update_dpp(0, (int) J[7 - e], kDppCtrl, 0xf, 0xf, false);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (pk[e] < K[e]) { K[e] = pk[e]; J[e] = pj[e]; }
+#pragma unroll
+    for (int st = 4; st >= 1; st >>= 1)
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if ((e & st) == 0 && K[e + st] < K[e]) {
+                const unsigned tk = K[e], tj = J[e];
+                K[e] = K[e + st]; J[e] = J[e + st];
+                K[e + st] = tk; J[e + st] = tj;
+            }
+}
+
 __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ int s_tmp[20];
     __shared__ int s_hist[HISTO_LENGTH];
     const int tid = threadIdx.x, lane = m_lane(), wave = tid >> 6;
-    const int pair = blockIdx.x;
+    const int S = A.split > 1 ? A.split : 1;
+    const int pair = S > 1 ? (int) blockIdx.x / S : (int) blockIdx.x, part = (int) blockIdx.x - pair * S;
     const int nt = A.curCnt[(long long) pair * A.cntStrideCur + A.cntOffCur];
     const int nq = A.lastCnt[(long long) pair * A.cntStrideLast + A.cntOffLast];
     const ygzf_kp *curKeys = A.curKeys + (long long) pair * A.kpStrideCur;
@@ -296,7 +322,13 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     tlc2 = (Rlw[6] * twc[0] + Rlw[7] * twc[1] + Rlw[8] * twc[2]) + tlw[2];
     const bool bForward = tlc2 > A.mb && !A.bMono;
     const bool bBackward = -tlc2 > A.mb && !A.bMono;
-    for (int i = tid; i < nq; i += kMatchBlock) {
+    // split mode: the queries of this part, eight to a wave (a wave waits for its slowest lane: few queries per wave, all SIMDs busy)
+    // and EIGHT LANES to a query: lane qr of the group scans every eighth entry of the query's candidate ranges and the group merges its
+    // sorted lists (the serial scan of the widest window was the phase's duration: ~100 ns per candidate, hundreds of candidates)
+    const int nLocal = (nq - part + S - 1) / S;
+    const int LPQ = S > 1 ? 8 : 1, qr = S > 1 ? (tid & 7) : 0;
+    for (int j = S > 1 ? (tid >> 3) : tid; j < nLocal; j += S > 1 ? (kMatchBlock >> 3) : kMatchBlock) {
+        const int i = j * S + part;
         QueryParam q;
         q.valid = 0;
         q.u = q.v = q.radius = q.ur = q.angle = 0;
@@ -393,26 +425,28 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 }
             }
         }
-        L.qp[i] = q;
-        L.qang[i] = q.angle;
-        L.qobs[i] = q.hasObs;
+        if (qr == 0) {
+            L.qp[i] = q;
+            L.qang[i] = q.angle;
+            L.qobs[i] = q.hasObs;
+        }
         // ---- speculative candidates: the 4 best acceptable (dist <= TH_HIGH) candidates against the INITIAL ownership,
         // one thread per query, no cross-lane traffic.  The in-order pass takes the first of them that is still free: the
         // current candidate set is a subset of the initial one, so that IS the current minimum.  Only when all four have
         // been taken does it fall back to a full cooperative rescan.
-        unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu;
-        unsigned short j0 = 0, j1 = 0, j2 = 0, j3 = 0;
-        unsigned k4 = 0xFFFFFFFFu, k5 = 0xFFFFFFFFu, k6 = 0xFFFFFFFFu, k7 = 0xFFFFFFFFu;   // entries 5..8 (A.specDeep)
-        unsigned short j4 = 0, j5 = 0, j6 = 0, j7 = 0;
+        unsigned K[8], J[8];   // (dist << 16 | visiting order, Cur index); entries 5..8 only with A.specDeep
+#pragma unroll
+        for (int e = 0; e < 8; e++) { K[e] = 0xFFFFFFFFu; J[e] = 0; }
         if (q.valid) {
             const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
             const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
             const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
-            unsigned ord = 0;
+            unsigned colBase = 0;   // candidates of the grid columns before ix: `ord` is the position in the reference's visiting order
             for (int ix = q.minCx; ix <= q.maxCx; ix++) {
                 const int c0 = ix * GRID_ROWS;
                 const int s = L.cellStart[c0 + q.minCy], e = L.cellStart[c0 + q.maxCy + 1];
-                for (int li = s; li < e; li++, ord++) {
+                for (int li = s + qr; li < e; li += LPQ) {
+                    const unsigned ord = colBase + (unsigned) (li - s);
                     const int i2 = L.list[li];
                     if (bCheckLevels) {
                         const int o = L.octave[i2];
@@ -436,34 +470,73 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
                     if ((A.mode == 0 || A.mode == 2) && dist > (unsigned) A.maxDist) continue;   // modes 1, 3 need the runner-up even when it is far
                     const unsigned key = (dist << 16) | (ord & 0xFFFFu);
-                    const unsigned short jj = (unsigned short) i2;
+                    const unsigned jj = (unsigned) i2;
                     if (A.specDeep) {   // sorted list of eight: one compare-exchange sweep (branch-free)
-                        if (key < k7) {
+                        if (key < K[7]) {
                             unsigned ck = key;
-                            unsigned short cj = jj;
-#define YGZF_CEX(K, J) do { if (ck < K) { const unsigned tk = K; const unsigned short tj = J; K = ck; J = cj; ck = tk; cj = tj; } } while (0)
-                            YGZF_CEX(k0, j0); YGZF_CEX(k1, j1); YGZF_CEX(k2, j2); YGZF_CEX(k3, j3);
-                            YGZF_CEX(k4, j4); YGZF_CEX(k5, j5); YGZF_CEX(k6, j6); YGZF_CEX(k7, j7);
+                            unsigned cj = jj;
+#define YGZF_CEX(K, J) do { if (ck < K) { const unsigned tk = K; const unsigned tj = J; K = ck; J = cj; ck = tk; cj = tj; } } while (0)
+                            YGZF_CEX(K[0], J[0]); YGZF_CEX(K[1], J[1]); YGZF_CEX(K[2], J[2]); YGZF_CEX(K[3], J[3]);
+                            YGZF_CEX(K[4], J[4]); YGZF_CEX(K[5], J[5]); YGZF_CEX(K[6], J[6]); YGZF_CEX(K[7], J[7]);
 #undef YGZF_CEX
                         }
-                    } else if (key < k3) {   // insert into the sorted quadruple
-                        if (key < k2) {
-                            k3 = k2; j3 = j2;
-                            if (key < k1) {
-                                k2 = k1; j2 = j1;
-                                if (key < k0) { k1 = k0; j1 = j0; k0 = key; j0 = jj; }
-                                else { k1 = key; j1 = jj; }
-                            } else { k2 = key; j2 = jj; }
-                        } else { k3 = key; j3 = jj; }
+                    } else if (key < K[3]) {   // insert into the sorted quadruple
+                        if (key < K[2]) {
+                            K[3] = K[2]; J[3] = J[2];
+                            if (key < K[1]) {
+                                K[2] = K[1]; J[2] = J[1];
+                                if (key < K[0]) { K[1] = K[0]; J[1] = J[0]; K[0] = key; J[0] = jj; }
+                                else { K[1] = key; J[1] = jj; }
+                            } else { K[2] = key; J[2] = jj; }
+                        } else { K[3] = key; J[3] = jj; }
                     }
                 }
+                colBase += (unsigned) (e - s);
             }
         }
-        L.specKey[i] = make_uint4(k0, k1, k2, k3);
-        L.specI2[i] = make_ushort4(j0, j1, j2, j3);
-        if (A.specDeep) {
-            L.specKeyB[i] = make_uint4(k4, k5, k6, k7);
-            L.specI2B[i] = make_ushort4(j4, j5, j6, j7);
+        if (LPQ > 1) {   // the eight lanes of a query fold their lists: pairs, quads, then the two quads of the group
+            spec_merge8<0xb1>(K, J);    // quad_perm [1,0,3,2]
+            spec_merge8<0x4e>(K, J);    // quad_perm [2,3,0,1]
+            spec_merge8<0x141>(K, J);   // row_half_mirror
+#pragma unroll
+            for (int e = 0; e < 8; e++) J[e] = K[e] == 0xFFFFFFFFu ? 0u : J[e];
+        }
+        if (qr != 0) continue;
+        if (S > 1) {
+            unsigned char *X = A.splitX + (long long) pair * A.capLast * kMatchSplitRec;
+            ((uint4 *) X)[i] = make_uint4(K[0], K[1], K[2], K[3]);
+            ((uint4 *) (X + 16 * (size_t) A.capLast))[i] = make_uint4(K[4], K[5], K[6], K[7]);
+            ((ushort4 *) (X + 32 * (size_t) A.capLast))[i] = make_ushort4((unsigned short) J[0], (unsigned short) J[1], (unsigned short) J[2], (unsigned short) J[3]);
+            ((ushort4 *) (X + 40 * (size_t) A.capLast))[i] = make_ushort4((unsigned short) J[4], (unsigned short) J[5], (unsigned short) J[6], (unsigned short) J[7]);
+            ((float *) (X + 48 * (size_t) A.capLast))[i] = q.angle;
+            ((unsigned *) (X + 52 * (size_t) A.capLast))[i] = q.hasObs;
+        } else {
+            L.specKey[i] = make_uint4(K[0], K[1], K[2], K[3]);
+            L.specI2[i] = make_ushort4((unsigned short) J[0], (unsigned short) J[1], (unsigned short) J[2], (unsigned short) J[3]);
+            if (A.specDeep) {
+                L.specKeyB[i] = make_uint4(K[4], K[5], K[6], K[7]);
+                L.specI2B[i] = make_ushort4((unsigned short) J[4], (unsigned short) J[5], (unsigned short) J[6], (unsigned short) J[7]);
+            }
+        }
+    }
+    if (S > 1) {   // hand-over: the last workgroup to arrive owns the pair from here on
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_tmp[19] = atomicAdd(&A.splitCnt[pair], 1);
+        __syncthreads();
+        if (s_tmp[19] != S - 1) return;
+        if (tid == 0) A.splitCnt[pair] = 0;
+        __threadfence();
+        const unsigned char *X = A.splitX + (long long) pair * A.capLast * kMatchSplitRec;
+        for (int i = tid; i < nq; i += kMatchBlock) {
+            L.specKey[i] = ((const uint4 *) X)[i];
+            L.specI2[i] = ((const ushort4 *) (X + 32 * (size_t) A.capLast))[i];
+            if (A.specDeep) {
+                L.specKeyB[i] = ((const uint4 *) (X + 16 * (size_t) A.capLast))[i];
+                L.specI2B[i] = ((const ushort4 *) (X + 40 * (size_t) A.capLast))[i];
+            }
+            L.qang[i] = ((const float *) (X + 48 * (size_t) A.capLast))[i];
+            L.qobs[i] = (unsigned char) ((const unsigned *) (X + 52 * (size_t) A.capLast))[i];
         }
     }
     __syncthreads();
@@ -1198,7 +1271,7 @@ void launch_backproject_unit(hipStream_t st, const ygzf_kp *keys, const int *cnt
 }
 
 void launch_match_last(hipStream_t st, const MatchArgs &A, int nPairs, size_t ldsBytes) {
-    hipLaunchKernelGGL(k_match_last, dim3(nPairs), dim3(kMatchBlock), ldsBytes, st, A);
+    hipLaunchKernelGGL(k_match_last, dim3(nPairs * (A.split > 1 ? A.split : 1)), dim3(kMatchBlock), ldsBytes, st, A);
 }
 
 }  // namespace ygzf

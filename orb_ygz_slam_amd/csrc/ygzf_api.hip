@@ -101,7 +101,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6];
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX;
     int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
@@ -145,6 +145,7 @@ struct ygzf_ctx {
     // debugging aids, read once per context (never on the launch path): synchronise after every kernel and name it on stderr /
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
     bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
+    int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
     bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
@@ -757,6 +758,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
     if (c->dFastCells.p) (void) hipFree(c->dFastCells.p);
     if (c->dPack.p) (void) hipFree(c->dPack.p);
+    if (c->dSplitCnt.p) (void) hipFree(c->dSplitCnt.p);
+    if (c->dSplitX.p) (void) hipFree(c->dSplitX.p);
     if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
     if (c->hFastStats) (void) hipHostFree(c->hFastStats);
     if (c->hStage) (void) hipHostFree(c->hStage);
@@ -1155,6 +1158,25 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
         if ((rc = ensure(c, c->dSpill, (size_t) nPairs * sp))) return rc;
         A.spillScratch = c->dSpill.p;
     }
+    // few pairs in the launch (a Tracking thread matches ONE): spread each over several workgroups (kernels.h, MatchArgs::split)
+    A.split = 1;
+    A.splitCnt = nullptr;
+    A.splitX = nullptr;
+    if (!A.spill && A.capLast >= 128 && c->matchSplit != 1) {
+        int sp2 = c->matchSplit > 1 ? c->matchSplit : 256 / (nPairs > 0 ? nPairs : 1);
+        sp2 = sp2 > 8 ? 8 : sp2;
+        if (sp2 > 1) {
+            const size_t cntBytes = (size_t) nPairs * sizeof(int);
+            if (c->dSplitCnt.bytes < cntBytes) {   // counters are zero between launches: a fresh buffer is cleared once
+                if ((rc = ensure(c, c->dSplitCnt, cntBytes > 4096 ? cntBytes : 4096))) return rc;
+                HIPCHECK(c, hipMemsetAsync(c->dSplitCnt.p, 0, c->dSplitCnt.bytes, c->stream));
+            }
+            if ((rc = ensure(c, c->dSplitX, (size_t) nPairs * A.capLast * kMatchSplitRec))) return rc;
+            A.split = sp2;
+            A.splitCnt = (int *) c->dSplitCnt.p;
+            A.splitX = (unsigned char *) c->dSplitX.p;
+        }
+    }
     HIPCHECK(c, match_prepare(b));
     *ldsBytes = b;
     return YGZF_OK;
@@ -1335,12 +1357,22 @@ int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, cons
     A.capLast = (int) nq;
     size_t lds;
     if ((rc = plan_match_lds(c, A, 1, &lds))) return rc;
+    if (c->matchDebug) {
+        if ((rc = ensure(c, c->dTmpC, 8 * sizeof(long long)))) return rc;
+        A.dbg = (long long *) c->dTmpC.p;
+    }
     {
         ProfScope ps(c, KK_MATCH);
         launch_match_last(c->stream, A, 1, lds);
     }
     HIPCHECK(c, hipGetLastError());
     if ((rc = P.download())) return rc;
+    if (A.dbg) {
+        long long st[8];
+        HIPCHECK(c, hipMemcpy(st, A.dbg, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[ygzf match (cur, last), 100MHz ticks] grid %lld  proj %lld  spec %lld  seq %lld  tail %lld  rescans %lld of %lld queries\n",
+                st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6], st[7]);
+    }
     c->lastMatchPairs = 0;
     return YGZF_OK;
 }
