@@ -95,6 +95,13 @@ int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
  *                                      REGISTER_STAGING for wider cells) */
 enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_REGISTER_STAGING = 1, YGZF_FAST_KERNEL_CELL_TABLE = 2 };
 int ygzf_set_fast_kernel(ygzf_ctx *ctx, int kernel);
+/* Extract-ahead (default off).  When on, ygzf_compute_pyramid queues the ORBSLAM_KEYPOINT extraction of the same image (FAST, octree,
+ * orientation, descriptors) right behind its pyramid kernels and reads the levels back on a second stream, so that the extraction runs while the
+ * levels cross the link and while the caller works on them -- ygz::Frame's constructor clones them (src/Frame.cc:807-813) before
+ * Frame::ExtractORB (:332-348) asks for the keypoints.  A following ygzf_extract_resident then launches nothing and only collects the
+ * results (same keypoints, same bytes).  The price: the extraction is computed for every pyramid, also when no ygzf_extract_resident
+ * follows, and it counts as an extraction for the batch calls' "previous frame" (ygzf_match_batch_prev / ygzf_align_batch_prev). */
+int ygzf_set_extract_ahead(ygzf_ctx *ctx, int on);
 
 /* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:84-106); arrays of nlevels floats, any may be NULL. */

@@ -125,6 +125,7 @@ def load_library(build_if_missing=True):
     L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
     L.ygzf_set_fast_kernel.argtypes = [vp, C.c_int]
+    L.ygzf_set_extract_ahead.argtypes = [vp, C.c_int]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
@@ -513,6 +514,10 @@ class Extractor:
     def set_fast_kernel(self, kernel):
         """0 auto (default), 1 register staging (k_fast_quads), 2 cell table + LDS-DMA staging (k_fast_tab) -- same results (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_fast_kernel(self.h, int(kernel)))
+
+    def set_extract_ahead(self, on):
+        """compute_pyramid also queues the extraction of the same image; extract_resident then only collects it (include/ygzf.h)."""
+        self._ck(self.L.ygzf_set_extract_ahead(self.h, 1 if on else 0))
 
     def fast_plan(self):
         p = C.c_int(0)

@@ -11,6 +11,7 @@
 // the reference's scalar C++ (no FMA), see DESIGN.md "float details inside bit-exact descriptors".
 #include <cstdlib>
 
+#include <cstring>
 #include "kernels.h"
 #include "wave_ops.h"
 #include "orb_pattern_table.h"
@@ -1508,12 +1509,15 @@ __global__ void k_level_bases(const int *__restrict__ lvlKpCnt, int nlevels, int
     outCnt[f] = acc;
 }
 
-template <int CVM>
+// kOwnBases (launches of a few frames: one Tracking frame): the wave sums the level counts itself (lvlBase = the octree's per-level counts,
+// nlevels of them per frame) and the wave at processing position 0 writes the frame's keypoint count -- k_level_bases, a launch of its own
+// between two short kernels, is not needed then.
+template <int CVM, bool kOwnBases>
 __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_describe(FrameSet fs, const LevelGeom *__restrict__ geom,
                                                             const int *__restrict__ lvlBase,
                                                             const uint2 *__restrict__ procRec, int kpStride,
                                                             ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc,
-                                                            int outStride, int blocksPerXcd) {
+                                                            int outStride, int blocksPerXcd, int nlevels, int *__restrict__ outCnt) {
     __shared__ DescLds lds[kDescWaves];
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform: the keypoint record loads go scalar
     const int f = blockIdx.y;
@@ -1527,10 +1531,18 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     // loads and a few scalar operations instead of a 16-way level search and a loop over the level counts (counters: as many issue
     // slots went into this bookkeeping as into the row blur).
     const uint2 rec = procRec[(long long) f * kpStride + s];
+    if (kOwnBases && s == 0) {
+        int tot = 0;
+        for (int q = 0; q < nlevels; q++) tot += lvlBase[f * nlevels + q];
+        if (lane == 0) outCnt[f] = tot;
+    }
     if (rec.y == kNoKeypoint) return;
     const int l = (int) (rec.y >> 24);
     const int li = (int) ((rec.y >> 8) & 0xFFFFu);                                  // list position handled by this wave
-    const int slot = lvlBase[f * kMaxLevels + l] + li;                              // output index: level-major, list order
+    int slot = li;                                                                  // output index: level-major, list order
+    if (kOwnBases) {
+        for (int q = 0; q < l; q++) slot += lvlBase[f * nlevels + q];
+    } else slot += lvlBase[f * kMaxLevels + l];
     const LevelGeom *gp = geom + l;
     const int gw = gp->w, gh = gp->h;
     const int kx = rec.x & 0xFFFFu, ky = rec.x >> 16;
@@ -1648,6 +1660,66 @@ void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, ui
     hipLaunchKernelGGL(k_repitch_rows, dim3(blocks), dim3(256), 0, st, src, (unsigned) srcPitch, dst, (unsigned) dstPitch, (unsigned) w, n);
 }
 
+// The pyramid chain of ONE frame (levels 1 .. nlevels - 1, each from the one before) as an explicit graph: built node by node (no stream
+// capture, which would put process-wide restrictions on other threads' calls while it is open), retargeted to another frame's buffers by
+// rewriting the nodes' FrameSet argument, launched with one call.
+static void pyr_node_params(hipKernelNodeParams *np, void **args, const LevelGeom &g) {
+    std::memset(np, 0, sizeof *np);
+    np->blockDim = dim3(256);
+    np->sharedMemBytes = 0;
+    np->kernelParams = args;
+    np->extra = nullptr;
+    if (g.area2x || !g.tiledOk) {
+        np->func = (void *) k_pyr_resize;
+        np->gridDim = dim3((g.w + 255) / 256, g.h, 1);
+    } else {
+        np->func = (void *) k_pyr_resize_tiled;
+        np->gridDim = dim3((g.w + kPyrTW - 1) / kPyrTW, (g.h + kPyrTH - 1) / kPyrTH, 1);
+    }
+}
+
+hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom *lv, int nlevels,
+                                 const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
+    std::memset(pg, 0, sizeof *pg);
+    hipError_t e = hipGraphCreate(&pg->graph, 0);
+    if (e != hipSuccess) return e;
+    pg->fs = fs; pg->geom = dGeom; pg->xofs = xofs; pg->xalpha = xalpha; pg->yofs = yofs; pg->ybeta = ybeta;
+    pg->nNodes = 0;
+    for (int l = 1; l < nlevels; l++) {
+        pg->level[l] = l;
+        pg->lv[l] = lv[l];
+        void *args[7] = {&pg->fs, &pg->geom, &pg->level[l], &pg->xofs, &pg->xalpha, &pg->yofs, &pg->ybeta};
+        hipKernelNodeParams np;
+        pyr_node_params(&np, args, lv[l]);
+        e = hipGraphAddKernelNode(&pg->nodes[l], pg->graph, l > 1 ? &pg->nodes[l - 1] : nullptr, l > 1 ? 1 : 0, &np);
+        if (e != hipSuccess) break;
+        pg->nNodes = l;
+    }
+    if (e == hipSuccess) e = hipGraphInstantiate(&pg->exec, pg->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) pyr_chain_graph_destroy(pg);
+    return e;
+}
+
+hipError_t pyr_chain_graph_retarget(PyrChainGraph *pg, const FrameSet &fs) {
+    pg->fs = fs;
+    for (int l = 1; l <= pg->nNodes; l++) {
+        void *args[7] = {&pg->fs, &pg->geom, &pg->level[l], &pg->xofs, &pg->xalpha, &pg->yofs, &pg->ybeta};
+        hipKernelNodeParams np;
+        pyr_node_params(&np, args, pg->lv[l]);
+        const hipError_t e = hipGraphExecKernelNodeSetParams(pg->exec, pg->nodes[l], &np);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+void pyr_chain_graph_destroy(PyrChainGraph *pg) {
+    if (pg->exec) (void) hipGraphExecDestroy(pg->exec);
+    if (pg->graph) (void) hipGraphDestroy(pg->graph);
+    pg->exec = nullptr;
+    pg->graph = nullptr;
+    pg->nNodes = 0;
+}
+
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
     if (g.area2x || !g.tiledOk) {   // exact 2x levels (area mean) and steep pyramids (tile would not fit LDS): per-pixel kernel
@@ -1733,18 +1805,48 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const un
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,
                      const uint2 *procRec, int kpStride, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode) {
-    hipLaunchKernelGGL(k_level_bases, dim3((nFrames + 255) / 256), dim3(256), 0, st, lvlKpCnt, nlevels, nFrames, lvlBase, outCnt);
+    const bool own = nFrames <= 4;
+    if (!own) hipLaunchKernelGGL(k_level_bases, dim3((nFrames + 255) / 256), dim3(256), 0, st, lvlKpCnt, nlevels, nFrames, lvlBase, outCnt);
     const int nblk = (kpStride + kDescWaves - 1) / kDescWaves;
     const int blocksPerXcd = (nblk + 7) / 8;
     dim3 grid(8 * blocksPerXcd, nFrames);
-#define YGZF_DESC_LAUNCH(M)                                                                                                      \
-    hipLaunchKernelGGL(k_describe<M>, grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, lvlBase, procRec, kpStride, outKp, outDesc, outStride, blocksPerXcd)
+#define YGZF_DESC_LAUNCH(M)                                                                                                                   \
+    do {                                                                                                                                      \
+        if (own) hipLaunchKernelGGL((k_describe<M, true>), grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, lvlKpCnt, procRec, kpStride, outKp, outDesc, \
+                                    outStride, blocksPerXcd, nlevels, outCnt);                                                                \
+        else hipLaunchKernelGGL((k_describe<M, false>), grid, dim3(64 * kDescWaves), 0, st, fs, dGeom, (const int *) lvlBase, procRec, kpStride, outKp, \
+                                outDesc, outStride, blocksPerXcd, nlevels, outCnt);                                                           \
+    } while (0)
     switch (cvMode) {
         case YGZF_CV_LEGACY_INT: YGZF_DESC_LAUNCH(YGZF_CV_LEGACY_INT); break;
         case YGZF_CV_4: YGZF_DESC_LAUNCH(YGZF_CV_4); break;
         default: YGZF_DESC_LAUNCH(YGZF_CV_LEGACY_SSE2); break;
     }
 #undef YGZF_DESC_LAUNCH
+}
+
+// The last frame's results of the previous launch become slot 0 of the output arrays (the "previous frame" of the batch matchers), or slot 0
+// is emptied: one launch instead of three device-to-device copies issued by the host.
+__global__ __launch_bounds__(256) void k_carry_slot(ygzf_kp *__restrict__ outKp, uint8_t *__restrict__ outDesc, int *__restrict__ outCnt, long long srcSlot,
+                                                    int kpStride) {
+    if (srcSlot <= 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) outCnt[0] = 0;
+        return;
+    }
+    const int n = outCnt[srcSlot];
+    const uint4 *sk = (const uint4 *) (outKp + srcSlot * kpStride);          // ygzf_kp: 28 bytes; kpStride entries = 7 * kpStride dwords
+    const unsigned *skw = (const unsigned *) (outKp + srcSlot * kpStride);
+    unsigned *dkw = (unsigned *) outKp;
+    const uint4 *sd = (const uint4 *) (outDesc + srcSlot * kpStride * 32);
+    uint4 *dd = (uint4 *) outDesc;
+    const int nk = n * 7, ndv = n * 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nk; i += gridDim.x * 256) dkw[i] = skw[i];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ndv; i += gridDim.x * 256) dd[i] = sd[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) outCnt[0] = n;
+}
+
+void launch_carry_slot(hipStream_t st, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, long long srcSlot, int kpStride) {
+    hipLaunchKernelGGL(k_carry_slot, dim3(srcSlot > 0 ? 16 : 1), dim3(256), 0, st, outKp, outDesc, outCnt, srcSlot, kpStride);
 }
 
 void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const void *list, int n, int frame,

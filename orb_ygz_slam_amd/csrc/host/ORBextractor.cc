@@ -16,13 +16,14 @@ namespace ygz {
 
 int ORBextractor::sDevice = 0;
 int ORBextractor::sCvMode = 0;
+bool ORBextractor::sExtractAhead = true;
 
 // src/ORBextractor.cc:412-470: the scale / sigma / per-level quota tables exist as soon as the object does -- Frame's constructors read
 // them before the first image is processed (src/Frame.cc:119-125 vs :148) -- so they are computed here on the host (ygzf_scale_tables_host:
 // the same arithmetic the device context uses), no device needed.
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
-      mDevice(sDevice), mCvMode(sCvMode) {
+      mDevice(sDevice), mCvMode(sCvMode), mExtractAhead(sExtractAhead) {
     const int L = std::max(nlevels, 0);
     mvScaleFactor.resize(L); mvInvScaleFactor.resize(L); mvLevelSigma2.resize(L); mvInvLevelSigma2.resize(L);
     mnFeaturesPerLevel.resize(L);
@@ -56,6 +57,7 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
         mCtx = nullptr;
         return nullptr;
     }
+    if (mExtractAhead && ygzf_set_extract_ahead(mCtx, 1) != YGZF_OK) fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(mCtx));
     mCtxW = w;
     mCtxH = h;
     return mCtx;

@@ -73,6 +73,10 @@ public:
     // ygzf_cv_mode of extractors constructed from now on: which OpenCV generation's 8-bit GaussianBlur the descriptors follow
     // (include/ygzf.h; default 0 = OpenCV 2.4 / 3.2 on x86, the versions the reference names).
     static int sCvMode;
+    // Extract-ahead (include/ygzf.h, ygzf_set_extract_ahead; default on): ComputePyramid queues the ORBSLAM_KEYPOINT extraction of the same image
+    // behind the pyramid, so that it runs while the levels return and the Frame constructor clones them; operator()(Frame *, ...) on that image
+    // then only collects keypoints and descriptors.  Frames that never extract (direct tracking) leave ~0.1 ms of GPU work unused per image.
+    static bool sExtractAhead;
 
 protected:
     int nfeatures = 0;
@@ -97,6 +101,7 @@ private:
     cv::Mat mResidentLevel0;     // level 0 of the pyramid the context still holds on the device (set by ComputePyramid), or empty
     int mCtxW = 0, mCtxH = 0;
     int mDevice = 0, mCvMode = 0;
+    bool mExtractAhead = true;
 };
 
 }  // namespace ygz

@@ -10,6 +10,23 @@ hipError_t upload_constants(const int *umax16);
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int w, size_t rows);
+struct PyrChainGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    hipGraphNode_t nodes[kMaxLevels];
+    int nNodes;                  // nodes 1 .. nNodes
+    FrameSet fs;                 // argument storage of the nodes
+    const LevelGeom *geom;
+    const int *xofs, *yofs;
+    const short *xalpha, *ybeta;
+    int level[kMaxLevels];
+    LevelGeom lv[kMaxLevels];
+};
+hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom *lv, int nlevels,
+                                 const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
+hipError_t pyr_chain_graph_retarget(PyrChainGraph *pg, const FrameSet &fs);
+void pyr_chain_graph_destroy(PyrChainGraph *pg);
+void launch_carry_slot(hipStream_t st, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, long long srcSlot, int kpStride);
 void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int firstLevel, int nlevels, const unsigned *offsets, uint8_t *dst);
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,

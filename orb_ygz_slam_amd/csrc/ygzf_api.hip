@@ -141,6 +141,14 @@ struct ygzf_ctx {
     int img0Pitch = 0;
     // timing
     hipEvent_t tStart = nullptr, tStop = nullptr;
+    // ygzf_set_extract_ahead: ygzf_compute_pyramid queues the extraction behind the pyramid and reads the levels back on a second stream
+    // one-frame pyramid chain as a captured graph: seven dependent launches cost the host more than the kernels take (pyramid_chain)
+    bool useGraphs = getenv("YGZF_NO_GRAPH") == nullptr;
+    PyrChainGraph pyrGraph = {};
+    const void *pyrGraphKey[6] = {nullptr};   // geometry tables + size the graph was built for
+    bool extractAhead = false, aheadPending = false;
+    hipStream_t streamCopy = nullptr;
+    hipEvent_t evPyramid = nullptr;
     bool profile = false;
     // debugging aids, read once per context (never on the launch path): synchronise after every kernel and name it on stderr /
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
@@ -403,6 +411,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         // runs the whole setup again instead of continuing on partial device tables
         c->geo.w = c->geo.h = 0;
         c->pyrResident = false;
+        c->aheadPending = false;
         c->carryValid = false;
         c->lastFrames = 0;
         HIPCHECK(c, hipStreamSynchronize(c->stream));
@@ -512,23 +521,58 @@ static void drain_profile(ygzf_ctx *c) {
 }
 
 // The launch sequence of ORBextractor::operator()(image...) for a batch resident on the device.
+// Pyramid levels 1 .. L-1 of the frames in fs.  For ONE frame the chain is seven (nlevels - 1) small dependent kernels whose launches take the
+// host longer than the kernels run; it is captured once per (buffers, geometry) into a graph and replayed with one call.
+static int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
+    const Geometry &G = c->geo;
+    const int L = c->tab.cfg.nlevels;
+    const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
+    auto launch_all = [&](bool prof) {
+        for (int l = 1; l < L; l++) {
+            if (prof) {
+                ProfScope ps(c, KK_PYR);
+                launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
+                                  (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+            } else
+                launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
+                                  (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+        }
+    };
+    if (nFrames != 1 || L < 3 || !c->useGraphs || c->profile || c->debugSync) {
+        launch_all(true);
+        return YGZF_OK;
+    }
+    const void *key[6] = {c->dGeom.p, c->dXofs.p, c->dXalpha.p, c->dYofs.p, c->dYbeta.p,
+                          (const void *) (((uintptr_t) G.w << 32) | (uintptr_t) (unsigned) G.h)};
+    if (!c->pyrGraph.exec || memcmp(key, c->pyrGraphKey, sizeof key) != 0) {
+        pyr_chain_graph_destroy(&c->pyrGraph);
+        const hipError_t e = pyr_chain_graph_build(&c->pyrGraph, fs, dGeom, G.lv.data(), L, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
+                                                   (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+        if (e != hipSuccess) {   // no graphs on this runtime: plain launches from now on
+            (void) hipGetLastError();
+            c->useGraphs = false;
+            launch_all(true);
+            return YGZF_OK;
+        }
+        memcpy(c->pyrGraphKey, key, sizeof key);
+    } else if (memcmp(&c->pyrGraph.fs, &fs, sizeof fs) != 0) {
+        HIPCHECK(c, pyr_chain_graph_retarget(&c->pyrGraph, fs));
+    }
+    HIPCHECK(c, hipGraphLaunch(c->pyrGraph.exec, c->stream));
+    return YGZF_OK;
+}
+
 static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady = false) {
     const Geometry &G = c->geo;
     c->pyrResident = false;
+    c->aheadPending = false;
     const int L = c->tab.cfg.nlevels;
     const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
     // slot 0 of the output arrays carries the last frame of the previous batch (Last frame of pair 0 in ygzf_match_batch_prev)
     ygzf_kp *outKp = (ygzf_kp *) c->dOutKp.p;
     uint8_t *outDesc = (uint8_t *) c->dOutDesc.p;
     int *outCnt = (int *) c->dOutCnt.p;
-    if (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) {
-        const size_t s = (size_t) c->lastFrames * G.kpStride;
-        HIPCHECK(c, hipMemcpyAsync(outKp, outKp + s, sizeof(ygzf_kp) * G.kpStride, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHECK(c, hipMemcpyAsync(outDesc, outDesc + s * 32, (size_t) 32 * G.kpStride, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHECK(c, hipMemcpyAsync(outCnt, outCnt + c->lastFrames, sizeof(int), hipMemcpyDeviceToDevice, c->stream));
-    } else {
-        HIPCHECK(c, hipMemsetAsync(outCnt, 0, sizeof(int), c->stream));
-    }
+    launch_carry_slot(c->stream, outKp, outDesc, outCnt, (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
     outKp += G.kpStride;
     outDesc += (size_t) G.kpStride * 32;
     outCnt += 1;
@@ -540,10 +584,9 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
             HIPCHECK(c, hipMemcpyAsync(c->dCarryPyr.p, (uint8_t *) c->dPyr.p + (size_t) (c->lastFrames - 1) * G.pyrBytes, (size_t) G.pyrBytes,
                                        hipMemcpyDeviceToDevice, c->stream));
     }
-    for (int l = 1; l < L && !pyramidReady; l++) {
-        ProfScope ps(c, KK_PYR);
-        launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
-                          (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+    if (!pyramidReady) {
+        int rcP = pyramid_chain(c, fs, nFrames);
+        if (rcP) return rcP;
     }
     if (G.totalCells > 0) {
         int groupBase[kMaxLevels];
@@ -651,6 +694,7 @@ static int upload_rows(ygzf_ctx *c, void *dst, size_t dstPitch, const uint8_t *s
 static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, int row_pitch, size_t frame_stride,
                          FrameSet *fs) {
     c->pyrResident = false;
+    c->aheadPending = false;
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
@@ -765,6 +809,9 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->hStage) (void) hipHostFree(c->hStage);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
+    pyr_chain_graph_destroy(&c->pyrGraph);
+    if (c->evPyramid) (void) hipEventDestroy(c->evPyramid);
+    if (c->streamCopy) (void) hipStreamDestroy(c->streamCopy);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
     if (c->tStop) (void) hipEventDestroy(c->tStop);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -795,6 +842,18 @@ int ygzf_set_fast_kernel(ygzf_ctx *c, int kernel) {
     if (!c) return YGZF_ERR_INVALID;
     if (kernel < YGZF_FAST_KERNEL_AUTO || kernel > YGZF_FAST_KERNEL_CELL_TABLE) return fail(c, YGZF_ERR_INVALID, "FAST kernel %d (0 auto, 1 register staging, 2 cell table + LDS-DMA)", kernel);
     c->fastKernel = kernel;
+    return YGZF_OK;
+}
+
+int ygzf_set_extract_ahead(ygzf_ctx *c, int on) {
+    if (!c) return YGZF_ERR_INVALID;
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (on && !c->streamCopy) {
+        HIPCHECK(c, hipStreamCreateWithFlags(&c->streamCopy, hipStreamNonBlocking));
+        HIPCHECK(c, hipEventCreateWithFlags(&c->evPyramid, hipEventDisableTiming));
+    }
+    c->extractAhead = on != 0;
+    if (!on) c->aheadPending = false;
     return YGZF_OK;
 }
 
@@ -865,11 +924,7 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     if ((rc = upload_frames(c, img, 1, w, h, stride, 0, &fs))) return rc;
     const Geometry &G = c->geo;
     const int L = c->tab.cfg.nlevels;
-    for (int l = 1; l < L; l++) {
-        ProfScope ps(c, KK_PYR);
-        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, G.lv[l], l, 1, (const int *) c->dXofs.p,
-                          (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
-    }
+    if ((rc = pyramid_chain(c, fs, 1))) return rc;
     HIPCHECK(c, hipGetLastError());
     // The levels go back tight (pitch = width) into caller memory that is pageable as a rule (cv::Mat buffers).  Eight pitched device-to-host
     // copies took 10-13 ms for a 752x480 pyramid (the copy engine works an odd-width pitched copy off row by row, into page-locked memory
@@ -882,11 +937,31 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     if ((rc = ensure_stage(c, total + 64)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
     launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->dTmpC.p);
     HIPCHECK(c, hipGetLastError());
-    if (total) HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, c->stream));
+    // extract-ahead: FAST / octree / descriptors of this image are queued behind the pyramid now and run while the levels travel back on
+    // the copy stream and the caller works on them (a Frame constructor clones them); ygzf_extract_resident then only collects the results.
+    // (Measured alternatives: the copy on the context's own stream with an event behind it and the extraction queued after that event --
+    // the event is reported 30 us later than on a stream that ends there; two half copies to overlap the host's copy-out -- slower too.)
+    hipStream_t rd = c->stream;
+    bool ahead = false;
+    if (c->extractAhead && c->streamCopy) {
+        HIPCHECK(c, hipEventRecord(c->evPyramid, c->stream));
+        HIPCHECK(c, hipStreamWaitEvent(c->streamCopy, c->evPyramid, 0));
+        rd = c->streamCopy;
+        ahead = true;
+    }
+    if (total) HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, rd));
+    if (ahead && (rc = run_extract(c, fs, 1, true))) return rc;   // (queued after the copy so that the copy starts while these launches are issued)
     if (levels_out[0] != img || stride != w)
         for (int y = 0; y < h; y++) memcpy(levels_out[0] + (size_t) y * w, img + (size_t) y * stride, (size_t) w);
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipStreamSynchronize(rd));
     for (int l = 1; l < L; l++) memcpy(levels_out[l], c->hStage + offs[l], offs[l + 1] - offs[l]);
+    if (ahead) {
+        c->pyrResident = true;
+        c->aheadPending = true;
+        c->pyrResW = w;
+        c->pyrResH = h;
+        return YGZF_OK;
+    }
     c->lastFrames = 0;
     c->pyrResident = true;
     c->pyrResW = w;
@@ -985,7 +1060,10 @@ int ygzf_extract_resident(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap, int
     fs.img0_stride = (long long) fs.img0_pitch * h;
     fs.pyr = (uint8_t *) c->dPyr.p;
     fs.pyr_stride = c->geo.pyrBytes;
-    if ((rc = run_extract(c, fs, 1, true))) return rc;
+    if (c->aheadPending) {   // queued by ygzf_compute_pyramid (ygzf_set_extract_ahead): nothing to launch
+        c->aheadPending = false;
+        c->pyrResident = false;
+    } else if ((rc = run_extract(c, fs, 1, true))) return rc;
     return ygzf_batch_fetch(c, 0, kps, desc, cap, n_out);
 }
 
@@ -2656,12 +2734,7 @@ int ygzf_image_cache_put(ygzf_ctx *c, int slot, const uint8_t *img, int w, int h
     fs.img0 += (long long) slot * fs.img0_stride;      // the launchers address "frame 0" of the set they are given
     fs.pyr += (long long) slot * fs.pyr_stride;
     if ((rc = upload_rows(c, (void *) fs.img0, (size_t) c->cachePitch, img, (size_t) stride, w, (size_t) h))) return rc;
-    const int L = c->tab.cfg.nlevels;
-    for (int l = 1; l < L; l++) {
-        ProfScope ps(c, KK_PYR);
-        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, c->geo.lv[l], l, 1, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
-                          (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
-    }
+    if ((rc = pyramid_chain(c, fs, 1))) return rc;
     HIPCHECK(c, hipGetLastError());
     c->cacheFilled[slot] = 1;
     return YGZF_OK;

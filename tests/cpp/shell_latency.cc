@@ -101,6 +101,22 @@ int main(int argc, char **argv) {
             ex(&F, F.mvKeys, cv::_OutputArray(F.mDescriptors), ORBextractor::ORBSLAM_KEYPOINT, true);
         });
     }
+    // the same without extract-ahead
+    {
+        ORBextractor::sExtractAhead = false;   // the C ABI's default: nothing is computed before it is asked for
+        ORBextractor exLazy(1000, 1.2f, L, 20, 7);
+        ORBextractor::sExtractAhead = true;
+        Frame F;
+        F.mImGray = imA;
+        timeit("frame_pyramid_plus_extract_lazy", iters, [&] {
+            exLazy.ComputePyramid(F.mImGray);
+            F.mvKeys.clear();
+            F.N = 0;
+            F.mvImagePyramid.clear();
+            for (int l = 0; l < L; l++) F.mvImagePyramid.push_back(exLazy.mvImagePyramid[l].clone());
+            exLazy(&F, F.mvKeys, cv::_OutputArray(F.mDescriptors), ORBextractor::ORBSLAM_KEYPOINT, true);
+        });
+    }
     std::vector<MapPoint> mps(A.N);
     for (int i = 0; i < A.N; i++) {
         mps[i].mWorldPos[0] = (A.mvKeys[i].pt.x - Frame::cx) / Frame::fx * depth;

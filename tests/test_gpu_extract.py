@@ -272,3 +272,39 @@ def test_extract_on_the_resident_pyramid(oracle):
         kb, db = ex.extract_resident(w, h)
         kb2, db2 = ex.extract(b)
         assert np.array_equal(kb, kb2) and np.array_equal(db, db2)
+
+
+@pytest.mark.gpu
+def test_extract_ahead_of_the_request(oracle):
+    """ygzf_set_extract_ahead: compute_pyramid queues the extraction behind the pyramid and returns the levels through a second stream;
+    extract_resident collects the same keypoints / descriptors as ygzf_extract (and as the oracle), the levels are the oracle's, the resident
+    state is consumed exactly as without the setting, and an image operation in between discards the queued result."""
+    from orb_ygz_slam_amd import Extractor, YgzfError
+    for (w, h) in ((752, 480), (641, 479)):
+        ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+        oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+        a, b = synth_frame(72, w, h), synth_frame(73, w, h)
+        ka, da = ex.extract(a)
+        ex.set_extract_ahead(True)
+        for rep in range(3):
+            pyr = ex.compute_pyramid(a)
+            assert all(np.array_equal(p, q) for p, q in zip(pyr, oex.pyramid(a)))
+            kr, dr = ex.extract_resident(w, h)
+            assert np.array_equal(kr, ka) and np.array_equal(dr, da)
+            with pytest.raises(YgzfError):
+                ex.extract_resident(w, h)
+        ok, od = oex.extract(a)
+        assert np.array_equal(ka["x"], ok["x"]) and np.array_equal(da, od)
+        ex.compute_pyramid(a)
+        kb2, db2 = ex.extract(b)                   # another image: the queued extraction of `a` is dropped
+        with pytest.raises(YgzfError):
+            ex.extract_resident(w, h)
+        pyr = ex.compute_pyramid(b)                # pyramid only: the next pyramid simply replaces it
+        pyr = ex.compute_pyramid(b)
+        kb, db = ex.extract_resident(w, h)
+        assert np.array_equal(kb, kb2) and np.array_equal(db, db2)
+        assert all(np.array_equal(p, q) for p, q in zip(pyr, oex.pyramid(b)))
+        ex.set_extract_ahead(False)
+        ex.compute_pyramid(a)
+        kr, dr = ex.extract_resident(w, h)
+        assert np.array_equal(kr, ka) and np.array_equal(dr, da)
