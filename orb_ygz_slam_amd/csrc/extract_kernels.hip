@@ -28,11 +28,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform by construction
 
 // Exclusive prefix of v over the threads of the block (thread order); *total = block sum.  tmp: >= 17 ints of LDS.
-// Contains block barriers: must be called by all threads.
+// Contains block barriers: must be called by all threads.  The caller orders its reads of tmp's results before the next call (a barrier).
 __device__ __forceinline__ int block_excl_scan(int v, int *tmp, int *total) {
     const int incl = wave_incl_scan(v);
     const int nw = (blockDim.x + 63) >> 6;
-    __syncthreads();  // tmp may still be read from a previous call
+    // (no barrier on entry: the only caller, block_scan_array, ends with one after the last read of tmp)
     if (lane_id() == 63) tmp[wave_id()] = incl;
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -73,7 +73,7 @@ __device__ __forceinline__ void block_scan_array3(int *a, int *b, int *c, int n,
     for (int i = lo; i < hi; i++) s += (unsigned long long) (unsigned) a[i] | ((unsigned long long) (unsigned) b[i] << 21) | ((unsigned long long) (unsigned) c[i] << 42);
     const unsigned long long incl = wave_incl_scan_u64(s);
     const int nw = (blockDim.x + 63) >> 6;
-    __syncthreads();  // tmp64 may still be read from a previous call
+    // (no barrier on entry: the previous call's reads of tmp64 lie before its closing barrier)
     if (lane_id() == 63) tmp64[wave_id()] = incl;
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -94,9 +94,12 @@ __device__ __forceinline__ void block_scan_array3(int *a, int *b, int *c, int n,
     *totA = (int) (total & 0x1FFFFFu); *totB = (int) ((total >> 21) & 0x1FFFFFu); *totC = (int) (total >> 42);
 }
 
-// Stable LSD radix sort (4-bit digits) of n (key,val) pairs on `bits` key bits by the whole block.
+// Stable LSD radix sort (kRadixBits-bit digits) of n (key,val) pairs on `bits` key bits by the whole block.
 // k0/v0 hold the input; result is left in *rk/*rv (one of the two buffers).  Buffers may be LDS or global.
-// histT: 256 ints of LDS, tmp: 17 ints of LDS.
+// histT: kRadixHist ints of LDS (digit-major, one counter per wave), tmp: 17 ints of LDS.
+// Seven-bit digits: the octree's 21-bit path keys take three passes (4-bit digits took six, at ~3.4 us of mostly barrier time each).
+constexpr int kRadixBits = 7;
+constexpr int kRadixHist = (1 << kRadixBits) * 16;   // up to 16 waves
 __device__ void block_radix_sort(unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, int n, int bits,
                                  volatile int *histT, int *tmp, unsigned **rk, unsigned **rv) {
     const int lane = lane_id(), wave = wave_id();
@@ -105,30 +108,25 @@ __device__ void block_radix_sort(unsigned *k0, unsigned *v0, unsigned *k1, unsig
     const int start = wave * seg;
     const int end = min(n, start + seg);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int shift = 0; shift < bits; shift += 4) {
-        if (threadIdx.x < 256) histT[threadIdx.x] = 0;
+    constexpr int NB = 1 << kRadixBits;
+    for (int shift = 0; shift < bits; shift += kRadixBits) {
+        for (int t = threadIdx.x; t < NB * 16; t += blockDim.x) histT[t] = 0;
         __syncthreads();
         for (int i = start + lane; i < end; i += 64) {
-            const int d = (k0[i] >> shift) & 15;
+            const int d = (k0[i] >> shift) & (NB - 1);
             atomicAdd((int *) &histT[d * 16 + wave], 1);
         }
         __syncthreads();
-        {
-            int v = threadIdx.x < 256 ? histT[threadIdx.x] : 0;
-            int total;
-            int ex = block_excl_scan(v, tmp, &total);
-            if (threadIdx.x < 256) histT[threadIdx.x] = ex;
-        }
-        __syncthreads();
+        block_scan_array((int *) histT, NB * 16, tmp);   // exclusive, digit-major then wave: the scatter base of every (digit, wave)
         for (int base = start; base < end; base += 64) {
             const int i = base + lane;
             const bool valid = i < end;
             const unsigned key = valid ? k0[i] : 0u;
             const unsigned val = valid ? v0[i] : 0u;
-            const int d = (key >> shift) & 15;
+            const int d = (key >> shift) & (NB - 1);
             unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
+            for (int b = 0; b < kRadixBits; b++) {
                 const bool bit = (d >> b) & 1;
                 const unsigned long long bal = __ballot(bit);
                 m &= bit ? bal : ~bal;
@@ -943,7 +941,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                                                       int *__restrict__ lvlCandCnt, uint2 *__restrict__ procRec,
                                                       int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena) {
     extern __shared__ __attribute__((aligned(16))) int dyn[];
-    __shared__ int histT[256];
+    __shared__ int histT[kRadixHist];
     __shared__ int s_tmp[20];
     __shared__ unsigned long long s_tmp64[17];
     __shared__ int s_n, s_nE, s_cut, s_flagA;
@@ -1227,8 +1225,10 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     }
     __syncthreads();
     {
-        unsigned *ok, *ov;
-        block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 12, histT, s_tmp, &ok, &ov);
+        // (launches of a few frames -- one Tracking frame -- keep the list order: the sort buys cache locality across many frames' windows and
+        // costs two block-wide passes of its own)
+        unsigned *ok = S.sk[0], *ov = S.sv[0];
+        if (gridDim.y > 4) block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], n, 12, histT, s_tmp, &ok, &ov);
         // k_describe's work list: processing position i -> (x | y << 16, score | list position << 8) in ONE record, so that a describe wave
         // knows its keypoint after a single memory round trip (it used to follow procOrder -> position / score: two dependent ones)
         // (score | list position << 8 | level << 24; positions past the level's count carry kNoKeypoint so that the wave there leaves at once)
@@ -1785,8 +1785,9 @@ size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalN
 }
 
 hipError_t octree_prepare(size_t ldsBytes, bool globalNodes) {
-    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds)
-                       : hipFuncSetAttribute((const void *) k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds);
+    constexpr int kOctMaxDyn = 160 * 1024 - 10 * 1024;   // the kernel's static LDS (radix histogram, scan scratch) is ~8.5 KB
+    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn)
+                       : hipFuncSetAttribute((const void *) k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn);
 }
 
 void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,

@@ -435,14 +435,14 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         {
             // per-list-position arrays (19 x cap ints) stay in LDS while one workgroup fits the CU; very large per-level feature budgets
             // move them to a global arena
-            c->octGlobalNodes = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, false) > 150 * 1024;
+            c->octGlobalNodes = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, false) > 142 * 1024;
             const size_t fixed = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, c->octGlobalNodes);
-            const size_t budget = 78 * 1024;
+            const size_t budget = 71 * 1024;   // two workgroups per CU beside 9 KB of static LDS each (radix histogram)
             c->octLdsCand = fixed + 16 * 256 < budget ? (int) ((budget - fixed) / 16) : 0;
             if (c->octLdsCand > 8192) c->octLdsCand = 8192;
         }
         c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, c->octLdsCand, c->octGlobalNodes);
-        if (c->octLds > 160 * 1024 - 2048)
+        if (c->octLds > 150 * 1024)
             return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
                         G.maxCellsPerLevel, G.kpCapMax);
         HIPCHECK(c, octree_prepare(c->octLds, c->octGlobalNodes));
