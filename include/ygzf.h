@@ -405,6 +405,14 @@ int ygzf_sia_run_cached(ygzf_ctx *ctx, int ref_slot, int cur_slot, const ygzf_si
                         float *H36);
 
 int ygzf_image_cache_put(ygzf_ctx *ctx, int slot, const uint8_t *img, int w, int h, int stride);
+/* The same from another context of the same device that still holds the image: its level 0 and pyramid (built by its last
+ * ygzf_compute_pyramid / ygzf_extract / ygzf_extract_resident, no other image operation since) are copied device to device -- no upload, no
+ * second pyramid.  A Frame's image reaches the device once, in ORBextractor::ComputePyramid (src/Frame.cc:807); SparseImgAlign::run and
+ * FindDirectProjection take it from there.  YGZF_ERR_STATE when the source holds no image of the cache's size (the caller then uploads with
+ * ygzf_image_cache_put); ygzf_has_resident_image asks without an error.  The copy is ordered behind the source's pending work and ahead of
+ * its later work. */
+int ygzf_image_cache_put_resident(ygzf_ctx *cache_ctx, int slot, ygzf_ctx *src_ctx);
+int ygzf_has_resident_image(const ygzf_ctx *ctx, int w, int h);
 int ygzf_find_direct_projection_batch(ygzf_ctx *ctx, const ygzf_camera *cam, int cur_slot, const float *cur_Tcw7, int n, const int *ref_slot,
                                       const float *ref_Tcw7, const ygzf_kp *ref_kp, const float *mp_world, float *px_curr, int *search_level,
                                       uint8_t *success, uint8_t *patches_with_border);

@@ -112,6 +112,8 @@ def load_library(build_if_missing=True):
     L.ygzf_stereo_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     L.ygzf_image_cache_reserve.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.ygzf_image_cache_put.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]
+    L.ygzf_image_cache_put_resident.argtypes = [vp, C.c_int, vp]
+    L.ygzf_has_resident_image.argtypes = [vp, C.c_int, C.c_int]
     L.ygzf_find_direct_projection_batch.argtypes = [vp, C.POINTER(Camera), C.c_int, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
     L.ygzf_vocabulary_set.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.ygzf_bow_transform.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
@@ -729,6 +731,13 @@ class Extractor:
         self._inflight.append(img)
         if len(self._inflight) > 64:
             self.sync()
+
+    def image_cache_put_resident(self, slot, src):
+        """Fills the slot device to device from `src` (another Extractor that still holds the image and its pyramid)."""
+        self._ck(self.L.ygzf_image_cache_put_resident(self.h, slot, src.h))
+
+    def has_resident_image(self, w, h):
+        return bool(self.L.ygzf_has_resident_image(self.h, w, h))
 
     def find_direct_projection_batch(self, cam, cur_slot, cur_Tcw7, ref_slot, ref_Tcw7, ref_kp, mp_world, px_curr, want_patches=False):
         """ORBmatcher::FindDirectProjection over a candidate batch -> (px_curr n x 2, search_level, success[, patches n x 100])."""

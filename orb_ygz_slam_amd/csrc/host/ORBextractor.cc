@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "../../../include/ygzf.h"
+#include "ygzf_pool.h"
 
 namespace ygz {
 
@@ -63,6 +64,11 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
     return mCtx;
 }
 
+ygzf_ctx *ORBextractor::ResidentContext(const cv::Mat &level0) const {
+    if (!mCtx || !mLastImagePrint || level0.empty() || !ygzf_has_resident_image(mCtx, level0.cols, level0.rows)) return nullptr;
+    return ygzf_host::image_fingerprint(level0.data, level0.cols, level0.rows, (int) level0.step) == mLastImagePrint ? mCtx : nullptr;
+}
+
 void ORBextractor::ComputePyramid(cv::Mat image) {
     if (image.empty()) return;
     ygzf_ctx *c = ensureContext(image.cols, image.rows);
@@ -75,6 +81,7 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
         out[l] = mvImagePyramid[l].data;
     }
     mResidentLevel0 = cv::Mat();
+    mLastImagePrint = ygzf_host::image_fingerprint(image.data, image.cols, image.rows, (int) image.step);
     if (ygzf_compute_pyramid(c, image.data, image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK) {
         fprintf(stderr, "ygz::ORBextractor::ComputePyramid: %s\n", ygzf_last_error(c));
         return;
@@ -93,6 +100,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     std::vector<uint8_t> desc((size_t) (cap > 0 ? cap : 0) * 32);
     int n = 0;
     mResidentLevel0 = cv::Mat();
+    mLastImagePrint = ygzf_host::image_fingerprint(image.data, image.cols, image.rows, (int) image.step);
     if (ygzf_extract(c, image.data, image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
         YGZF_OK) {
         fprintf(stderr, "ygz::ORBextractor::operator(): %s\n", ygzf_last_error(c));
@@ -135,6 +143,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         std::vector<uint8_t> d((size_t) cap * 32);
         for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];   // right eye: ComputeKeyPointsFast gets an empty list (:1049-1050)
         int total = 0;
+        mLastImagePrint = 0;   // (the grid detectors keep no complete pyramid on the device)
         if (ygzf_extract_fast_keypoint(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &total) != YGZF_OK) {
             fprintf(stderr, "ygz::ORBextractor (FAST_KEYPOINT): %s\n", ygzf_last_error(c));
             return;
@@ -152,6 +161,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         std::vector<uint8_t> d((size_t) cap * 32);
         for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];
         int total = 0;
+        mLastImagePrint = 0;
         if (ygzf_extract_dso(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &mnGridSize, &total) !=
             YGZF_OK) {
             fprintf(stderr, "ygz::ORBextractor (DSO_KEYPOINT): %s\n", ygzf_last_error(c));
@@ -176,8 +186,10 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         }
         int rcE = YGZF_ERR_STATE;
         if (resident) rcE = ygzf_extract_resident(c, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
-        if (rcE == YGZF_ERR_STATE)   // nothing resident (another image operation came in between): the image goes up again
+        if (rcE == YGZF_ERR_STATE) {   // nothing resident (another image operation came in between): the image goes up again
+            mLastImagePrint = ygzf_host::image_fingerprint(img.data, img.cols, img.rows, (int) img.step);
             rcE = ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
+        }
         mResidentLevel0 = cv::Mat();   // the extraction reuses the buffers: nothing is resident afterwards
         if (rcE != YGZF_OK) {
             fprintf(stderr, "ygz::ORBextractor (ORBSLAM_KEYPOINT): %s\n", ygzf_last_error(c));
@@ -215,6 +227,7 @@ void ORBextractor::ComputeStereoMatches(Frame &F) {
     for (int i = 0; i < F.N; i++) std::memcpy(&dl[(size_t) i * 32], F.mDescriptors.ptr(i), 32);
     for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t) i * 32], F.mDescriptorsRight.ptr(i), 32);
     if (imL.step != F.mImRight.step) { fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: left/right row steps differ\n"); return; }
+    mLastImagePrint = 0;
     if (ygzf_compute_stereo_matches(c, imL.data, F.mImRight.data, imL.cols, imL.rows, (int) imL.step, F.N,
                                     (const ygzf_kp *) F.mvKeys.data(), dl.data(), Nr, (const ygzf_kp *) F.mvKeysRight.data(), dr.data(), F.mb, F.mbf,
                                     F.mvuRight.data(), F.mvDepth.data()) != YGZF_OK)

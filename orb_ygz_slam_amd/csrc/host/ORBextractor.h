@@ -77,6 +77,10 @@ public:
     // behind the pyramid, so that it runs while the levels return and the Frame constructor clones them; operator()(Frame *, ...) on that image
     // then only collects keypoints and descriptors.  Frames that never extract (direct tracking) leave ~0.1 ms of GPU work unused per image.
     static bool sExtractAhead;
+    // The context, when it still holds `level0` (the image of this extractor's last operation, compared by content fingerprint) together with
+    // its pyramid on the device; nullptr otherwise.  The shells that read Frame images (SparseImgAlign::run, FindDirectProjection) pass it to
+    // the image cache, which then copies device to device instead of uploading the image a second time.
+    ygzf_ctx *ResidentContext(const cv::Mat &level0) const;
 
 protected:
     int nfeatures = 0;
@@ -102,6 +106,7 @@ private:
     int mCtxW = 0, mCtxH = 0;
     int mDevice = 0, mCvMode = 0;
     bool mExtractAhead = true;
+    unsigned long long mLastImagePrint = 0;   // fingerprint of the image of the last operation that sent ONE image to the context (0: none)
 };
 
 }  // namespace ygz

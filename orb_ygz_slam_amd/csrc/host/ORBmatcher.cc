@@ -301,7 +301,8 @@ bool ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, 
     ygzf_host::ImageCache &dc = ygzf_host::ImageCache::instance();
     ygzf_host::ImageCache::Guard lk(dc);
     if (!dc.prepare(device(), cur0.cols, cur0.rows, L, L > 1 ? curr->mvScaleFactors[1] : 1.2f, who)) return false;
-    const int curSlot = dc.slot(ygzf_host::ImageCache::kFrame, curr->mnId, cur0.data, cur0.cols, cur0.rows, (int) cur0.step, who);
+    const int curSlot = dc.slot(ygzf_host::ImageCache::kFrame, curr->mnId, cur0.data, cur0.cols, cur0.rows, (int) cur0.step, who,
+                                curr->mpORBextractorLeft ? curr->mpORBextractorLeft->ResidentContext(cur0) : nullptr);
     const int slot = dc.slot(ygzf_host::ImageCache::kKeyFrame, ref->mnId, ref0.data, ref0.cols, ref0.rows, (int) ref0.step, who);
     if (curSlot < 0 || slot < 0) return false;
     const int index = (int) mp->GetObservations()[ref];

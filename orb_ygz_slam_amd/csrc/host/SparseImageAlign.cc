@@ -67,8 +67,12 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
         ygzf_host::ImageCache &ic = ygzf_host::ImageCache::instance();
         ygzf_host::ImageCache::Guard lk(ic);
         if (ic.prepare(ORBextractor::sDevice, r0.cols, r0.rows, L, L > 1 ? ref->mvScaleFactors[1] : 1.2f, who)) {
-            const int rs = ic.slot(ygzf_host::ImageCache::kFrame, ref->mnId, r0.data, r0.cols, r0.rows, (int) r0.step, who);
-            const int cs = ic.slot(ygzf_host::ImageCache::kFrame, cur->mnId, c0.data, c0.cols, c0.rows, (int) c0.step, who);
+            // (a miss is served device to device when the frame's extractor still holds the image it built the pyramid from -- the current
+            // frame of a Tracking iteration, as a rule: src/Frame.cc:807 ran a moment ago)
+            const int rs = ic.slot(ygzf_host::ImageCache::kFrame, ref->mnId, r0.data, r0.cols, r0.rows, (int) r0.step, who,
+                                   ref->mpORBextractorLeft ? ref->mpORBextractorLeft->ResidentContext(r0) : nullptr);
+            const int cs = ic.slot(ygzf_host::ImageCache::kFrame, cur->mnId, c0.data, c0.cols, c0.rows, (int) c0.step, who,
+                                   cur->mpORBextractorLeft ? cur->mpORBextractorLeft->ResidentContext(c0) : nullptr);
             if (rs >= 0 && cs >= 0 && rs != cs) {
                 if (ygzf_sia_run_cached(ic.ctx(), rs, cs, &R, C.Tcw, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret,
                                         nullptr, H36) != YGZF_OK) {

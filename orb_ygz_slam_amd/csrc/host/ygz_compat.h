@@ -118,6 +118,7 @@ struct SE3f {  // Sophus::SE3f storage: unit quaternion (x,y,z,w) + translation
     float t[3] = {0, 0, 0};
 };
 class Frame;
+class ORBextractor;
 class MapPoint {  // the accessors the hot path calls (reference include/MapPoint.h)
 public:
     Vector3f mWorldPos{};
@@ -158,6 +159,7 @@ public:
     int mnScaleLevels = 0;
     DBoW2::FeatureVector mFeatVec;
     long unsigned int mnId = 0;
+    ORBextractor *mpORBextractorLeft = nullptr;   // the extractor whose ComputePyramid built mvImagePyramid (include/Frame.h:220)
 };
 inline int MapPoint::PredictScale(const float &currentDist, Frame *pF) {  // src/MapPoint.cc:359-373
     float ratio = mfMaxDistance / currentDist;

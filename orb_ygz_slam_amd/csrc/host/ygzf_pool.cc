@@ -103,7 +103,7 @@ void ImageCache::clear() {
 
 // 64 rows x 64 eight-byte words spread over the image, mixed FNV-1a style with the size: two different camera images agree on all of them with
 // negligible probability, and reading 32 KB costs a few microseconds against the 360 KB upload a wrong miss would cost
-static unsigned long long image_fingerprint(const unsigned char *data, int cols, int rows, int step) {
+unsigned long long image_fingerprint(const unsigned char *data, int cols, int rows, int step) {
     unsigned long long hsh = 1469598103934665603ull ^ ((unsigned long long) cols << 32 | (unsigned) rows);
     const int ny = rows < 64 ? rows : 64, nx = cols / 8 < 64 ? cols / 8 : 64;
     for (int j = 0; j < ny; j++) {
@@ -117,7 +117,7 @@ static unsigned long long image_fingerprint(const unsigned char *data, int cols,
     return hsh;
 }
 
-int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who) {
+int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who, ygzf_ctx *resident) {
     Impl &I = *impl_;
     if (!ctx_ || cols != I.w || rows != I.h || cols < 8) return -1;
     const Impl::Key key{(int) kind, id, image_fingerprint(data, cols, rows, step)};
@@ -128,7 +128,9 @@ int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int
         if (I.lastUse[s] < I.lastUse[victim]) victim = s;
     if (I.used[victim]) I.slotOf.erase(I.keyOf[victim]);
     I.used[victim] = 0;
-    if (ygzf_image_cache_put(ctx_, victim, data, cols, rows, step) != YGZF_OK) {
+    // the image is on the device already when the Frame's extractor still holds it: device-to-device, else upload + pyramid
+    if (!(resident && ygzf_image_cache_put_resident(ctx_, victim, resident) == YGZF_OK) &&
+        ygzf_image_cache_put(ctx_, victim, data, cols, rows, step) != YGZF_OK) {
         fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx_));
         return -1;
     }

@@ -23,6 +23,9 @@ private:
     int device_;
 };
 
+// 64-bit content hash over ~32 KB of an 8-bit image (64 rows x 64 eight-byte words spread over it, mixed with the size)
+unsigned long long image_fingerprint(const unsigned char *data, int cols, int rows, int step);
+
 // Device-resident level-0 images + pyramids of recent Frames and KeyFrames, shared by the shells that read images (FindDirectProjection,
 // SparseImgAlign::run): an image is uploaded the first time it is referenced and its pyramid rebuilt on the device by the extractor's
 // resize kernel (so it equals the host pyramid the Frame holds); slots are recycled least recently used.  One cache per process, one
@@ -42,7 +45,9 @@ public:
     // slot holding this image (uploads it on a miss); -1 on failure.  The key is (kind, id, fingerprint of the level-0 pixels): a Frame copy
     // (same id, deep-cloned pyramid at another address, src/Frame.cc:185-187) hits the slot its original filled; an id or a buffer address
     // that comes back with other pixels (Tracking::Reset restarts the id counters, src/Tracking.cc:1926-1927) misses.
-    int slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who);
+    // `resident`: a context of the same device that may still hold this very image with its pyramid (the Frame's extractor, which built the
+    // pyramid in the Frame's constructor): on a miss the slot is then filled device to device instead of by an upload and a second pyramid.
+    int slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who, ygzf_ctx *resident = nullptr);
     // forgets every cached image (the slots stay allocated).  Not needed for correctness -- the content fingerprint already keeps a recycled id
     // from hitting a stale image -- but the natural call in Tracking::Reset beside mpMap->clear().
     void clear();

@@ -131,6 +131,9 @@ struct ygzf_ctx {
     int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
+    bool pyrHeld = false;                  // dImg0 / dPyr frame 0 hold ONE image (pyrHeldW x pyrHeldH) and its complete pyramid (ygzf_image_cache_put_resident)
+    int pyrHeldW = 0, pyrHeldH = 0;
+    hipEvent_t evShare = nullptr;
     bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
     int pyrResW = 0, pyrResH = 0;
     uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
@@ -193,7 +196,7 @@ static int fail(ygzf_ctx *c, int code, const char *fmt, ...) {
 static int ensure(ygzf_ctx *c, ygzf_ctx::Buf &b, size_t bytes) {
     if (bytes <= b.bytes) return YGZF_OK;
     // a buffer that grows loses its contents: whatever ygzf_compute_pyramid left in the image / pyramid buffers is gone with them
-    if (&b == &c->dImg0 || &b == &c->dPyr) c->pyrResident = false;
+    if (&b == &c->dImg0 || &b == &c->dPyr) { c->pyrResident = false; c->pyrHeld = false; }
     if (b.p) HIPCHECK(c, hipFree(b.p));
     b.p = nullptr;
     b.bytes = 0;
@@ -411,6 +414,7 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         // runs the whole setup again instead of continuing on partial device tables
         c->geo.w = c->geo.h = 0;
         c->pyrResident = false;
+        c->pyrHeld = false;
         c->aheadPending = false;
         c->carryValid = false;
         c->lastFrames = 0;
@@ -664,6 +668,9 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
         HIPCHECK(c, hipMemsetAsync(c->dLvlCand.p, 0, sizeof(int) * nFrames * L, c->stream));
     }
     HIPCHECK(c, hipGetLastError());
+    c->pyrHeld = fs.img0 == (const uint8_t *) c->dImg0.p && fs.pyr == (uint8_t *) c->dPyr.p;   // frame 0 of the context's own buffers
+    c->pyrHeldW = G.w;
+    c->pyrHeldH = G.h;
     c->lastFrames = nFrames;
     c->lastFs = fs;
     c->carryValid = true;
@@ -695,6 +702,7 @@ static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, i
                          FrameSet *fs) {
     c->pyrResident = false;
     c->aheadPending = false;
+    c->pyrHeld = false;
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
@@ -810,6 +818,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
     pyr_chain_graph_destroy(&c->pyrGraph);
+    if (c->evShare) (void) hipEventDestroy(c->evShare);
     if (c->evPyramid) (void) hipEventDestroy(c->evPyramid);
     if (c->streamCopy) (void) hipStreamDestroy(c->streamCopy);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
@@ -926,6 +935,9 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     const int L = c->tab.cfg.nlevels;
     if ((rc = pyramid_chain(c, fs, 1))) return rc;
     HIPCHECK(c, hipGetLastError());
+    c->pyrHeld = true;
+    c->pyrHeldW = w;
+    c->pyrHeldH = h;
     // The levels go back tight (pitch = width) into caller memory that is pageable as a rule (cv::Mat buffers).  Eight pitched device-to-host
     // copies took 10-13 ms for a 752x480 pyramid (the copy engine works an odd-width pitched copy off row by row, into page-locked memory
     // as well): the levels are packed on the device and leave in one linear copy through the context's page-locked staging buffer.
@@ -2738,6 +2750,40 @@ int ygzf_image_cache_put(ygzf_ctx *c, int slot, const uint8_t *img, int w, int h
     HIPCHECK(c, hipGetLastError());
     c->cacheFilled[slot] = 1;
     return YGZF_OK;
+}
+
+int ygzf_image_cache_put_resident(ygzf_ctx *c, int slot, ygzf_ctx *src) {
+    if (!c || !src) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->cacheSlots <= 0) return fail(c, YGZF_ERR_STATE, "image cache not reserved");
+    if (slot < 0 || slot >= c->cacheSlots) return fail(c, YGZF_ERR_INVALID, "slot %d outside 0..%d", slot, c->cacheSlots - 1);
+    if (src == c || src->device != c->device) return fail(c, YGZF_ERR_INVALID, "the source must be another context on the same device");
+    if (!src->pyrHeld || src->pyrHeldW != c->cacheW || src->pyrHeldH != c->cacheH || src->geo.w != c->cacheW || src->geo.h != c->cacheH)
+        return fail(c, YGZF_ERR_STATE, "the source context holds no %dx%d image with its pyramid", c->cacheW, c->cacheH);
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, c->cacheW, c->cacheH, 1);
+    if (rc) return rc;
+    const int L = c->tab.cfg.nlevels;
+    if (src->tab.cfg.nlevels != L || src->geo.pyrBytes != c->geo.pyrBytes) return fail(c, YGZF_ERR_INVALID, "the two contexts' pyramids differ (levels / scale factor)");
+    for (int l = 0; l < L; l++) {
+        const LevelGeom &a = src->geo.lv[l], &b = c->geo.lv[l];
+        if (a.w != b.w || a.h != b.h || a.pitch != b.pitch || a.off != b.off) return fail(c, YGZF_ERR_INVALID, "the two contexts' pyramids differ (level %d)", l);
+    }
+    const size_t imgBytes = (size_t) c->cachePitch * c->cacheH;   // both sides: pitch = width rounded up to 64
+    if (!c->evShare) HIPCHECK(c, hipEventCreateWithFlags(&c->evShare, hipEventDisableTiming));
+    // order: the source's pending work (its pyramid kernels) -> the copies on this context's stream -> the source's later work
+    HIPCHECK(c, hipEventRecord(c->evShare, src->stream));
+    HIPCHECK(c, hipStreamWaitEvent(c->stream, c->evShare, 0));
+    HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dCacheImg.p + (size_t) slot * imgBytes, src->dImg0.p, imgBytes, hipMemcpyDeviceToDevice, c->stream));
+    if (c->geo.pyrBytes > 0)
+        HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dCachePyr.p + (size_t) slot * c->cachePyrBytes, src->dPyr.p, (size_t) c->geo.pyrBytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHECK(c, hipEventRecord(c->evShare, c->stream));
+    HIPCHECK(c, hipStreamWaitEvent(src->stream, c->evShare, 0));
+    c->cacheFilled[slot] = 1;
+    return YGZF_OK;
+}
+
+int ygzf_has_resident_image(const ygzf_ctx *c, int w, int h) {
+    return c && c->pyrHeld && c->pyrHeldW == w && c->pyrHeldH == h ? 1 : 0;
 }
 
 int ygzf_find_direct_projection_batch(ygzf_ctx *c, const ygzf_camera *cam, int cur_slot, const float *cur_Tcw7, int n, const int *ref_slot,

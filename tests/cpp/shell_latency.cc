@@ -130,6 +130,12 @@ int main(int argc, char **argv) {
     size_t ret = 0;
     // every call sees a NEW current frame (fresh id: one level-0 upload + device pyramid) and the previous call's frame as reference
     timeit("sparse_img_align_run", iters, [&] { TCR = SE3f(); B.mnId += 2; ret = align.run(&A, &B, TCR); });
+    // the same when the current frame's extractor still holds the image on the device -- what Tracking sees: the Frame constructor's
+    // ComputePyramid (src/Frame.cc:807) ran just before -- so that the cache takes level 0 and the pyramid device to device
+    ex.ComputePyramid(imB);
+    B.mpORBextractorLeft = &ex;
+    timeit("sparse_img_align_run_resident", iters, [&] { TCR = SE3f(); B.mnId += 2; ret = align.run(&A, &B, TCR); });
+    B.mpORBextractorLeft = nullptr;
     B.mTcw = TCR;
     ORBmatcher matcher(0.9f, true);
     int nm = 0;

@@ -159,3 +159,44 @@ def test_sia_run_on_cached_slots_equals_the_host_pyramid_form(oracle):
     from orb_ygz_slam_amd import YgzfError
     with pytest.raises(YgzfError):
         ex.sia_run_cached(cam, 1, 0, k, world, ident, ident, inv, 7, 1)
+
+
+def test_cache_slot_filled_from_the_extractor_that_holds_the_image(oracle):
+    """ygzf_image_cache_put_resident: a slot filled device to device from the context whose ComputePyramid / extract saw the image last holds
+    the same bytes as an uploaded one (SparseImgAlign on it returns the same TCR bit for bit, odd width included); refused when the source
+    holds nothing, another size, or is the cache's own context."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC, YgzfError
+    for (w, h) in ((752, 480), (641, 479)):
+        imgA, imgB, (R, t), backproject = two_view_scene(15, w, h, EUROC, rotvec=(0.002, -0.004, 0.001), trans=(0.02, 0.01, -0.01))
+        fe = Extractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)      # the Frame's extractor
+        cache = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)  # the image cache's context
+        cam = make_camera(w, h)
+        k, _ = fe.extract(imgA)
+        world = backproject(k["x"], k["y"])
+        inv = fe.tables()["inv_scale"]
+        ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+        cache.image_cache_reserve(4, w, h)
+        assert not cache.has_resident_image(w, h)
+        with pytest.raises(YgzfError):
+            cache.image_cache_put_resident(0, cache)
+        fresh = Extractor(800, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+        with pytest.raises(YgzfError):
+            cache.image_cache_put_resident(0, fresh)             # holds nothing yet
+        cache.image_cache_put(0, imgA)
+        cache.image_cache_put(1, imgB)
+        want = cache.sia_run_cached(cam, 0, 1, k, world, ident, ident, inv, 7, 1)
+        fe.extract(imgA)                                         # an extraction leaves image + pyramid in the context
+        assert fe.has_resident_image(w, h) and not fe.has_resident_image(w + 1, h)
+        cache.image_cache_put_resident(2, fe)
+        fe.set_extract_ahead(True)
+        fe.compute_pyramid(imgB)                                 # so does ComputePyramid (with the extraction queued behind it)
+        cache.image_cache_put_resident(3, fe)
+        got = cache.sia_run_cached(cam, 2, 3, k, world, ident, ident, inv, 7, 1)
+        assert got[0] == want[0] and all(np.array_equal(a, b) for a, b in zip(got[1:], want[1:]))
+        kb, db = fe.extract_resident(w, h)                       # the queued extraction is still collected afterwards
+        kb2, db2 = fe.extract(imgB)
+        assert np.array_equal(kb, kb2) and np.array_equal(db, db2)
+        small = Extractor(800, 1.2, 8, 20, 7, max_width=320, max_height=240, max_batch=1)
+        small.compute_pyramid(imgA[:240, :320].copy())
+        with pytest.raises(YgzfError):
+            cache.image_cache_put_resident(0, small)             # another size
