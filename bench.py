@@ -361,7 +361,7 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=1.0):
     from orb_ygz_slam_amd import MultiGpu, make_camera
     w, h, nl, sf, nf, ini, mn = cfg
     slots = list(devices) if len(devices) > 1 else [devices[0], devices[0]]
-    per = 128
+    per = 256
     n = per * len(slots)
     clip = np.ascontiguousarray(np.concatenate([frames] * ((n + len(frames) - 1) // len(frames)))[:n])
     mg = MultiGpu(slots, nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=per)
@@ -376,7 +376,8 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=1.0):
     mg.close()
     return {"value": round(calls * n / sec, 1), "unit": "frames/s", "frames_per_call": n, "calls": calls, "device_slots": slots, "unit_frames": 2,
             "what": "ygzf_mgpu_extract_match: pageable host frames -> per-slot page-locked staging -> H2D -> extract + match of every pair -> D2H -> "
-                    "host arrays in input order (synchronous calls: no overlap between calls, only between slots)"}
+                    "host arrays in input order (synchronous calls; inside a call every slot pipelines its frames in chunks of 128: host gather / scatter "
+                    "copies on four threads beside the device's work on the neighbouring chunk)"}
 
 
 def kernel_table(prof):

@@ -290,6 +290,9 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *ctx, const ygzf_frame_view *F,
 int ygzf_match_batch_prev(ygzf_ctx *ctx, const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation);
 int ygzf_match_counts(ygzf_ctx *ctx, int *nmatches /* n_frames ints */);
 int ygzf_match_fetch(ygzf_ctx *ctx, int frame, int *cur_match, uint8_t *cur_owner, int cap);
+/* All pairs of the last ygzf_match_batch_prev at once: row p of `match` (stride >= ygzf_max_keypoints ints per row) receives the match
+ * array of pair p in full row length (entries past the frame's keypoint count are -1 or stale: read n_kp of them). */
+int ygzf_match_fetch_all(ygzf_ctx *ctx, int *match, int stride);
 
 /* ---- ygz::SparseImgAlign(max_level, min_level, n_iter = 10, GaussNewton).run(Frame *ref, Frame *cur, SE3f &TCR)
  *      include/SparseImageAlign.h:14-51, src/SparseImageAlign.cc:7-49 (+ NLLSSolver<6,SE3f>::optimizeGaussNewton,

@@ -1378,6 +1378,17 @@ int ygzf_match_fetch(ygzf_ctx *c, int frame, int *cur_match, uint8_t *cur_owner,
     return YGZF_OK;
 }
 
+int ygzf_match_fetch_all(ygzf_ctx *c, int *match, int stride) {
+    if (!c || !match) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastMatchPairs < 1) return fail(c, YGZF_ERR_STATE, "no matched batch");
+    const int B = c->lastMatchPairs, ks = c->geo.kpStride;
+    if (stride < ks) return fail(c, YGZF_ERR_INVALID, "stride %d < %d (ygzf_max_keypoints)", stride, ks);
+    HIPCHECK(c, hipMemcpy2DAsync(match, sizeof(int) * (size_t) stride, c->dMatch.p, sizeof(int) * (size_t) ks, sizeof(int) * (size_t) ks, B,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
 int ygzf_search_by_projection_last(ygzf_ctx *c, const ygzf_frame_view *cur, const ygzf_camera *cam, int last_n, const ygzf_kp *last_keys,
                                    const uint8_t *mp_valid, const uint8_t *outlier, const uint8_t *mp_has_obs, const float *mp_world,
                                    const uint8_t *mp_desc, const float *Rcw, const float *tcw, const float *Rlw, const float *tlw, float th,
