@@ -1254,7 +1254,7 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
     A.splitX = nullptr;
     if (!A.spill && A.capLast >= 128 && c->matchSplit != 1) {
         int sp2 = c->matchSplit > 1 ? c->matchSplit : 256 / (nPairs > 0 ? nPairs : 1);
-        sp2 = sp2 > 8 ? 8 : sp2;
+        sp2 = std::min(sp2, c->matchSplit > 1 ? 16 : 8);   // (more than eight only on request: A/B runs)
         if (sp2 > 1) {
             const size_t cntBytes = (size_t) nPairs * sizeof(int);
             if (c->dSplitCnt.bytes < cntBytes) {   // counters are zero between launches: a fresh buffer is cleared once

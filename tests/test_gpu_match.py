@@ -16,8 +16,15 @@ def _unit_world(keys, cam):
     return w
 
 
-def test_match_batch_prev_equals_oracle(oracle):
+@pytest.mark.parametrize("split", [0, 1, 2, 3, 5, 8])
+def test_match_batch_prev_equals_oracle(oracle, split, monkeypatch):
+    """`split`: workgroups per pair of k_match_last (YGZF_MATCH_SPLIT, read when the context is created; 0 = the library's choice, which is 8
+    for a launch of five pairs, 1 = one workgroup per pair as in large batches): the same matches whichever way the queries are dealt."""
     from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    if split:
+        monkeypatch.setenv("YGZF_MATCH_SPLIT", str(split))
+    else:
+        monkeypatch.delenv("YGZF_MATCH_SPLIT", raising=False)
     w, h = 752, 480
     base = synth_frame(40, w + 16, h + 16)
     # consecutive frames = shifted crops of one scene (+ a different scene) so that matches exist

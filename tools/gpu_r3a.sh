@@ -1,14 +1,12 @@
-timeout 900 python -m pytest tests/test_gpu_mgpu.py tests/test_gpu_match.py -x -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -4
+timeout 900 python -m pytest tests/test_gpu_match.py -x -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -4
+H=orb_ygz_slam_amd/csrc/host; L=orb_ygz_slam_amd/lib
+g++ -std=c++17 -O2 -pthread -I $H -I $H/standalone tests/cpp/shell_latency.cc $H/ORBextractor.cc $H/ORBmatcher.cc $H/SparseImageAlign.cc $H/ygzf_pool.cc -L $L -lygzf -Wl,-rpath,$PWD/$L -o /tmp/shell_latency
 python - <<'PY'
-import sys, time, os
+import sys
 sys.path.insert(0,'.')
-import numpy as np
-import bench
-from orb_ygz_slam_amd.synth import synth_frame
-frames=np.stack([synth_frame(100+i,752,480) for i in range(64)])
-cfg=(752,480,8,1.2,1000,20,7)
-for T in (1,2,4,8):
-    os.environ['YGZF_MGPU_COPY_THREADS']=str(T)
-    r=bench.mgpu_end_to_end([0], cfg, frames, min_seconds=1.5)
-    print('copy threads',T, r['value'], r['calls'])
+from orb_ygz_slam_amd.scene import two_view_scene
+from orb_ygz_slam_amd import EUROC
+a,b,_,_=two_view_scene(9,752,480,EUROC,Z=4.0)
+a.tofile('/tmp/a.u8'); b.tofile('/tmp/b.u8')
 PY
+for s in 8 12 16; do echo split $s; YGZF_MATCH_SPLIT=$s YGZF_MATCH_DEBUG=1 /tmp/shell_latency /tmp 2 2>&1 | grep "ygzf match" | tail -1; YGZF_MATCH_SPLIT=$s /tmp/shell_latency /tmp 200 | grep search_by; done
