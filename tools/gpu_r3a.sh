@@ -1,14 +1,6 @@
-timeout 600 python -m pytest tests/test_gpu_extract.py tests/test_gpu_shells.py tests/test_gpu_direct.py tests/test_gpu_align.py tests/test_gpu_soak.py -x -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -4
-H=orb_ygz_slam_amd/csrc/host; L=orb_ygz_slam_amd/lib
-g++ -std=c++17 -O2 -pthread -I $H -I $H/standalone tests/cpp/shell_latency.cc $H/ORBextractor.cc $H/ORBmatcher.cc $H/SparseImageAlign.cc $H/ygzf_pool.cc -L $L -lygzf -Wl,-rpath,$PWD/$L -o /tmp/shell_latency
-python - <<'PY'
-import sys
-sys.path.insert(0,'.')
-from orb_ygz_slam_amd.scene import two_view_scene
-from orb_ygz_slam_amd import EUROC
-a,b,_,_=two_view_scene(9,752,480,EUROC,Z=4.0)
-a.tofile('/tmp/a.u8'); b.tofile('/tmp/b.u8')
-PY
-timeout 120 /tmp/shell_latency /tmp 200
-YGZF_NO_PYR_CHAIN=1 timeout 120 /tmp/shell_latency /tmp 200 | head -4
-timeout 120 python bench.py --no-cpu-baseline --no-profile --no-extras --streams 1 --batch 1 --sub-batch 1 --steps 200 --warmup 10 2>&1 | tail -1 | cut -c1-140
+bash tools/profile_round.sh r03_b > gpurun_out/prof_r03_b.log 2>&1
+tail -5 gpurun_out/prof_r03_b.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03_b_bench_default.json 2> gpurun_out/r03_b_bench_default.err
+tail -c 600 gpurun_out/r03_b_bench_default.json
+bash tools/round_numbers.sh > gpurun_out/r03_b_round_numbers.txt 2>&1
+cat gpurun_out/r03_b_round_numbers.txt
