@@ -66,6 +66,31 @@ def test_extract_only_and_idle_slots():
     mg.close()
 
 
+def test_long_slot_runs_in_chunks():
+    """A slot with more than 128 frames goes through in chunks (gather / device work / scatter overlapped): 300 frames on one slot and on two
+    return the same bytes, pair by pair, and the chunk borders (frames 127 | 128, 255 | 256 of the slot) are ordinary pairs."""
+    from orb_ygz_slam_amd import MultiGpu, make_camera
+    w, h, n = 320, 240, 300
+    frames = np.ascontiguousarray(np.concatenate([_clip(20, w, h)] * 15)[:n])
+    cam = make_camera(w, h)
+    one = MultiGpu([0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=n)
+    ref = one.extract_match(frames, unit=n, cam=cam)                     # one unit: every frame but the first has its predecessor
+    one.close()
+    k, d, c, m, nm = ref
+    assert nm[0] == -1 and (nm[1:] >= 0).all() and (c > 50).all()
+    for f in (1, 21, 127, 128, 129, 255, 256, 299):                       # a frame equals the one 20 before it: same keypoints, same match row
+        if f >= 21:
+            assert c[f] == c[f - 20] and np.array_equal(k[f, :c[f]], k[f - 20, :c[f]]) and np.array_equal(m[f, :c[f]], m[f - 20, :c[f]]) and nm[f] == nm[f - 20]
+    two = MultiGpu([0, 0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=n)
+    got = two.extract_match(frames, unit=150, cam=cam)                  # two units of 150 frames, one per slot (each more than one chunk)
+    two.close()
+    k2, d2, c2, m2, nm2 = got
+    assert np.array_equal(c2, c) and np.array_equal(k2, k) and np.array_equal(d2, d)
+    assert nm2[0] == -1 and nm2[150] == -1
+    keep = np.ones(n, bool); keep[[0, 150]] = False
+    assert np.array_equal(nm2[keep], nm[keep]) and np.array_equal(m2[keep], m[keep])
+
+
 def test_missing_device_is_an_error():
     from orb_ygz_slam_amd import MultiGpu, YgzfError
     import torch
