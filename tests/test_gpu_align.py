@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from orb_ygz_slam_amd.scene import two_view_scene, quat_to_R
+from orb_ygz_slam_amd.synth import synth_frame
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5  # on the 7 SE3 parameters (unit quaternion + translation in metres)
@@ -90,6 +91,29 @@ def test_align_batch_prev_matches_host_api(oracle):
             assert res[f][0] == ret, (rnd, f, res[f][0], ret)
             assert np.abs(res[f][1] - T).max() <= 1e-6
     assert res[1][0] > 100 and np.abs(res[1][1][4:]).max() > 1e-3   # A -> B really moved
+
+
+def test_align_large_batch_equals_small_batches():
+    """Launches of 128 pairs and more keep their workgroups to 74 KB of LDS (two per CU: the coarse levels are then gathered from L2 instead
+    of a staged copy): the same bytes read, so the same poses bit for bit as launches of a few pairs."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h, n = 320, 240, 132
+    base = synth_frame(55, w + 40, h + 40)
+    imgs = np.stack([base[(3 * i) % 17:(3 * i) % 17 + h, (5 * i) % 23:(5 * i) % 23 + w] for i in range(n)])
+    cam = make_camera(w, h, fx=200.0, fy=200.0, cx=160.0, cy=120.0)
+    big = Extractor(300, 1.2, 6, 20, 7, max_width=w, max_height=h, max_batch=n)
+    big.extract_batch_host(imgs)
+    big.align_batch_prev(cam, 5, 1, 10)
+    got = [big.align_fetch(f) for f in range(n)]
+    small = Extractor(300, 1.2, 6, 20, 7, max_width=w, max_height=h, max_batch=12)
+    want = []
+    for s0 in range(0, n, 12):
+        small.extract_batch_host(imgs[s0:s0 + 12])
+        small.align_batch_prev(cam, 5, 1, 10)
+        want += [small.align_fetch(f) for f in range(12)]
+    assert got[0][0] == 0 and sum(r[0] > 50 for r in got) > n // 2
+    for f in range(1, n):
+        assert got[f][0] == want[f][0] and np.array_equal(got[f][1], want[f][1]), f
 
 
 def ex2_run(ex, cam, k, world, ident, pyr_ref, pyr_cur, inv):
