@@ -1,7 +1,3 @@
-run() { python bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 3 --passes 1 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items() if 'match' in k}, {k:v for k,v in (d.get('kernels_isolated_avg_us') or {}).items() if 'match' in k})"; }
-run base
-YGZF_MATCH_PLAN=1 run plan1
-YGZF_MATCH_PLAN=2 run plan2
-YGZF_MATCH_PLAN=3 run plan3
+timeout 900 python -m pytest tests/test_gpu_match.py tests/test_gpu_frustum.py tests/test_gpu_fuzz.py tests/test_gpu_boundary.py tests/test_gpu_shells.py -x -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -4
+YGZF_MATCH_DEBUG=1 timeout 200 python tools/call_latency.py 2>&1 | grep "mode 1" | tail -2
+timeout 200 python tools/call_latency.py 2>/dev/null | grep -i "search\|frustum"
