@@ -133,7 +133,8 @@ struct ygzf_ctx {
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
     bool pyrHeld = false;                  // dImg0 / dPyr frame 0 hold ONE image (pyrHeldW x pyrHeldH) and its complete pyramid (ygzf_image_cache_put_resident)
     int pyrHeldW = 0, pyrHeldH = 0;
-    hipEvent_t evShare = nullptr;
+    hipEvent_t evShare = nullptr, evPyrDone = nullptr;
+    bool evPyrDoneValid = false;
     bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
     int pyrResW = 0, pyrResH = 0;
     uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
@@ -566,6 +567,15 @@ static int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     return YGZF_OK;
 }
 
+// marks "the pyramid of frame 0 is complete" on the context's stream: what another context waits for before it copies that pyramid
+// (ygzf_image_cache_put_resident) -- not the end of the stream, where an extraction queued ahead may still be running
+static int mark_pyramid_done(ygzf_ctx *c) {
+    if (!c->evPyrDone) HIPCHECK(c, hipEventCreateWithFlags(&c->evPyrDone, hipEventDisableTiming));
+    HIPCHECK(c, hipEventRecord(c->evPyrDone, c->stream));
+    c->evPyrDoneValid = true;
+    return YGZF_OK;
+}
+
 static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady = false) {
     const Geometry &G = c->geo;
     c->pyrResident = false;
@@ -590,7 +600,7 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
     }
     if (!pyramidReady) {
         int rcP = pyramid_chain(c, fs, nFrames);
-        if (rcP) return rcP;
+        if (rcP || (rcP = mark_pyramid_done(c))) return rcP;
     }
     if (G.totalCells > 0) {
         int groupBase[kMaxLevels];
@@ -819,6 +829,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     for (auto e : c->pool) (void) hipEventDestroy(e);
     pyr_chain_graph_destroy(&c->pyrGraph);
     if (c->evShare) (void) hipEventDestroy(c->evShare);
+    if (c->evPyrDone) (void) hipEventDestroy(c->evPyrDone);
     if (c->evPyramid) (void) hipEventDestroy(c->evPyramid);
     if (c->streamCopy) (void) hipStreamDestroy(c->streamCopy);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
@@ -933,7 +944,7 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     if ((rc = upload_frames(c, img, 1, w, h, stride, 0, &fs))) return rc;
     const Geometry &G = c->geo;
     const int L = c->tab.cfg.nlevels;
-    if ((rc = pyramid_chain(c, fs, 1))) return rc;
+    if ((rc = pyramid_chain(c, fs, 1)) || (rc = mark_pyramid_done(c))) return rc;
     HIPCHECK(c, hipGetLastError());
     c->pyrHeld = true;
     c->pyrHeldW = w;
@@ -2782,8 +2793,11 @@ int ygzf_image_cache_put_resident(ygzf_ctx *c, int slot, ygzf_ctx *src) {
     const size_t imgBytes = (size_t) c->cachePitch * c->cacheH;   // both sides: pitch = width rounded up to 64
     if (!c->evShare) HIPCHECK(c, hipEventCreateWithFlags(&c->evShare, hipEventDisableTiming));
     // order: the source's pending work (its pyramid kernels) -> the copies on this context's stream -> the source's later work
-    HIPCHECK(c, hipEventRecord(c->evShare, src->stream));
-    HIPCHECK(c, hipStreamWaitEvent(c->stream, c->evShare, 0));
+    if (src->evPyrDoneValid) HIPCHECK(c, hipStreamWaitEvent(c->stream, src->evPyrDone, 0));   // (not the end of its stream: see mark_pyramid_done)
+    else {
+        HIPCHECK(c, hipEventRecord(c->evShare, src->stream));
+        HIPCHECK(c, hipStreamWaitEvent(c->stream, c->evShare, 0));
+    }
     HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dCacheImg.p + (size_t) slot * imgBytes, src->dImg0.p, imgBytes, hipMemcpyDeviceToDevice, c->stream));
     if (c->geo.pyrBytes > 0)
         HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dCachePyr.p + (size_t) slot * c->cachePyrBytes, src->dPyr.p, (size_t) c->geo.pyrBytes, hipMemcpyDeviceToDevice, c->stream));

@@ -135,6 +135,16 @@ int main(int argc, char **argv) {
     ex.ComputePyramid(imB);
     B.mpORBextractorLeft = &ex;
     timeit("sparse_img_align_run_resident", iters, [&] { TCR = SE3f(); B.mnId += 2; ret = align.run(&A, &B, TCR); });
+    // one direct-tracking iteration as Tracking runs it: Frame construction (ComputePyramid + clones, src/Frame.cc:807-813), then
+    // TrackWithSparseAlignment's SparseImgAlign::run against the previous frame (src/Tracking.cc:2061-2105)
+    timeit("direct_frame_pyramid_plus_align", iters, [&] {
+        ex.ComputePyramid(imB);
+        B.mvImagePyramid.clear();
+        for (int l = 0; l < L; l++) B.mvImagePyramid.push_back(ex.mvImagePyramid[l].clone());
+        TCR = SE3f();
+        B.mnId += 2;
+        ret = align.run(&A, &B, TCR);
+    });
     B.mpORBextractorLeft = nullptr;
     B.mTcw = TCR;
     ORBmatcher matcher(0.9f, true);
