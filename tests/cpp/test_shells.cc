@@ -119,6 +119,23 @@ int main(int argc, char **argv) {
         for (size_t l = 0; l < B.mvImagePyramid.size(); l++)
             for (int y = 0; y < B.mvImagePyramid[l].rows; y++) std::memcpy(B.mvImagePyramid[l].ptr(y), saved[l].ptr(y), (size_t) B.mvImagePyramid[l].cols);
     }
+    // (iii) a frame whose extractor still holds its image on the device (the Frame constructor's ComputePyramid ran last on that extractor):
+    // the cache takes level 0 and the pyramid from that context device to device -- same bytes, same answer.  A fresh id makes it a miss.
+    {
+        Frame Bd = B;
+        for (auto &m : Bd.mvImagePyramid) m = m.clone();
+        Bd.mnId = B.mnId + 1000;
+        ex.ComputePyramid(Bd.mImGray);
+        Bd.mpORBextractorLeft = &ex;
+        if (!ex.ResidentContext(Bd.mvImagePyramid[0])) { fprintf(stderr, "the extractor does not report the image it just processed as resident\n"); return 1; }
+        if (ex.ResidentContext(A.mvImagePyramid[0])) { fprintf(stderr, "the extractor reports another image as resident\n"); return 1; }
+        SE3f T4;
+        const size_t r4 = align.run(&A, &Bd, T4);
+        float u7[8];
+        ygz_compat::se3_to7(T4, u7);
+        u7[7] = (float) r4;
+        dump(dir + "/tcr_resident.bin", u7, sizeof u7);
+    }
     // TrackWithMotionModel: cur pose = TCR * last pose, then SearchByProjection(cur, last, 15, mono)  (:1072-1093)
     B.mTcw = TCR;
     ORBmatcher matcher(0.9f, true);

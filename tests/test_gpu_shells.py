@@ -79,6 +79,7 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     # image cache: a deep copy of B (other buffers, same id) gives B's answer; B's id + B's buffers with A's pixels give the identity, not a stale hit
     t_copy = np.fromfile(tmp_path / "tcr_copy.bin", np.float32)
     assert np.array_equal(t_copy, t7)
+    assert np.array_equal(np.fromfile(tmp_path / "tcr_resident.bin", np.float32), t7)      # slot filled device to device from the extractor's context
     t_reuse = np.fromfile(tmp_path / "tcr_reuse.bin", np.float32)
     r_ret, r_T, _, _ = oracle.sparse_img_align(ka, world, ident, pyrA, ident, pyrA, oex.tables()["inv_scale"], EUROC, 7, 1)
     assert int(t_reuse[7]) == r_ret and np.abs(t_reuse[:7] - r_T).max() <= 1e-5 and np.abs(t_reuse[4:7]).max() < 1e-3
