@@ -92,3 +92,43 @@ def test_every_path_is_run_to_run_identical():
         dg = _digest(*parts)
         ref = ref or dg
         assert dg == ref, "single-frame paths differ in repetition %d" % rep
+
+
+def test_two_contexts_sharing_an_image_are_run_to_run_identical():
+    """The Tracking order of calls over two contexts and three streams, repeated: ComputePyramid with the extraction queued ahead (extractor
+    context: its stream + its copy stream), the image cache filled device to device from it (cache context, ordered by events), SparseImgAlign
+    on the slots, then the queued extraction collected -- alternating two images so that every buffer is overwritten each time."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    from orb_ygz_slam_amd.scene import two_view_scene
+    w, h = 752, 480
+    imgA, imgB, _, backproject = two_view_scene(21, w, h, EUROC, rotvec=(0.002, 0.001, -0.003), trans=(0.01, -0.02, 0.01))
+    fe = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    cache = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    cache.image_cache_reserve(4, w, h)
+    fe.set_extract_ahead(True)
+    cam = make_camera(w, h)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    inv = fe.tables()["inv_scale"]
+    keys = {}
+    for name, img in (("A", imgA), ("B", imgB)):
+        k, _ = fe.extract(img)
+        keys[name] = (k, backproject(k["x"], k["y"]) if name == "A" else np.stack([k["x"], k["y"], np.ones(len(k))], -1).astype(np.float32))
+    ref = {}
+    for rep in range(int(__import__('os').environ.get('YGZF_REPEATS', '30')) * 2):
+        cur, prev = ("A", "B") if rep % 2 == 0 else ("B", "A")
+        img = imgA if cur == "A" else imgB
+        pyr = fe.compute_pyramid(img)
+        slot = rep % 2
+        cache.image_cache_put_resident(slot, fe)
+        parts = list(pyr)
+        if rep > 0:
+            k, world = keys[prev]
+            r = cache.sia_run_cached(cam, 1 - slot, slot, k, world, ident, ident, inv, 7, 1)
+            parts += [np.asarray(r[1]), np.asarray([r[0]])]
+        kk, dd = fe.extract_resident(w, h)
+        parts += [kk, dd]
+        if rep < 2:
+            continue
+        dg = _digest(*parts)
+        ref.setdefault(cur, dg)
+        assert dg == ref[cur], "repetition %d (%s) differs" % (rep, cur)
