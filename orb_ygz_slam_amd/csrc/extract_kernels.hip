@@ -1103,7 +1103,22 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 if (tid == 0) s_cut = nE - 1;
                 __syncthreads();
                 unsigned *ek, *ev;
-                block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], nE, seqBits + cntBits, histT, s_tmp, &ek, &ev);
+                if (nE <= kOctBlock) {
+                    // a few hundred distinct keys (they carry the creation sequence): the position of a key is the number of smaller keys --
+                    // one thread per key counts them off broadcast LDS reads, no histogram, no scan, ONE barrier (the radix sort: three
+                    // passes of four)
+                    if (tid < nE) {
+                        const unsigned key = S.sk[0][tid];
+                        int rank = 0;
+                        for (int q = 0; q < nE; q++) rank += S.sk[0][q] < key;
+                        S.sk[1][rank] = key;
+                        S.sv[1][rank] = S.sv[0][tid];
+                    }
+                    __syncthreads();
+                    ek = S.sk[1];
+                    ev = S.sv[1];
+                } else
+                    block_radix_sort(S.sk[0], S.sv[0], S.sk[1], S.sv[1], nE, seqBits + cntBits, histT, s_tmp, &ek, &ev);
                 // processing order j: descending (size, creation seq)
                 for (int j = tid; j < nE; j += kOctBlock) {
                     const int e = (int) ev[nE - 1 - j];
