@@ -3,9 +3,9 @@
 
 One "step" = one pass of the hot path (ORBextractor::operator() on every frame of a batch + ORBmatcher::SearchByProjection
 of every frame against its predecessor) over one batch of synthetic frames that is already resident in HBM when the
-timed region starts.  The resident clip (default 10752 frames of 752x480 = 3.9 GB) is walked `--passes` times per step (default 5:
-53760 frames) in sub-batches of 256 frames that rotate over 3 independent extractor contexts (own HIP stream and buffers each), so a
-step is 210 sub-batch launches and the driver's 20 steps give a timed region of about five seconds.  One process per GPU; frames are independent, so each rank owns its own
+timed region starts.  The resident clip (default 10752 frames of 752x480 = 3.9 GB) is walked `--passes` times per step (default 6:
+64512 frames) in sub-batches of 256 frames that rotate over 3 independent extractor contexts (own HIP stream and buffers each), so a
+step is 252 sub-batch launches and the driver's 20 steps give a timed region of five to six seconds.  One process per GPU; frames are independent, so each rank owns its own
 clip (weak scaling) and there is no collective in the data path -- torch.distributed is used only for the barrier and
 the max-over-ranks time.
 
@@ -461,7 +461,7 @@ def main():
                     help="testing aid for --devices-in-process on a box with fewer GPUs: logical device i runs on physical device i %% count "
                          "(exercises the threaded path; the line is then NOT a scaling measurement and says so)")
     ap.add_argument("--passes", type=int, default=0,
-                    help="times the resident clip is walked per step (default 5 for the 752x480 / 640x480 workloads: the driver's 20 steps then time "
+                    help="times the resident clip is walked per step (default 6 for the 752x480 / 640x480 workloads: the driver's 20 steps then time "
                          "about five seconds; 1 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -488,7 +488,7 @@ def main():
         rounds = args.batch // (S * sub)
     if args.stereo and sub % 2:
         raise SystemExit("--stereo needs an even --sub-batch")
-    passes = args.passes if args.passes > 0 else (5 if args.workload in ("euroc752x480_8lvl_1000feat", "vga640x480_8lvl_1000feat") and not args.batch else 1)
+    passes = args.passes if args.passes > 0 else (6 if args.workload in ("euroc752x480_8lvl_1000feat", "vga640x480_8lvl_1000feat") and not args.batch else 1)
     B = S * sub * rounds * passes                  # frames per GPU per step
     ndev = max(1, args.devices_in_process)
 
