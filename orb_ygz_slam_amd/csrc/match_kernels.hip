@@ -659,18 +659,28 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             }
             const int depth = A.specDeep ? 8 : 4;
             bool pending = active && keys.x < kNoKey;
+            const unsigned kk[8] = {keys.x, keys.y, keys.z, keys.w, keysB.x, keysB.y, keysB.z, keysB.w};
+            const int ii[8] = {idx.x, idx.y, idx.z, idx.w, idxB.x, idxB.y, idxB.z, idxB.w};
+            // the levels of the list's keypoints do not change: read once per tile; the ownership bytes are read once per round, all of them
+            // together (the walk below then runs on registers: it used to follow the list through up to ten dependent LDS reads per round)
+            int lev[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) lev[e] = (e < depth && kk[e] < kNoKey) ? (int) L.octave[ii[e]] : -1;
             while (__ballot(pending)) {
-                const unsigned kk[8] = {keys.x, keys.y, keys.z, keys.w, keysB.x, keysB.y, keysB.z, keysB.w};
-                const int ii[8] = {idx.x, idx.y, idx.z, idx.w, idxB.x, idxB.y, idxB.z, idxB.w};
+                unsigned char own[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) own[e] = e < depth ? vowner[ii[e]] : (unsigned char) 0;
                 unsigned k1 = kNoKey, k2 = kNoKey;
-                int b1 = -1, b2 = -1;
+                int b1 = -1, b2 = -1, l1 = -1, l2 = -1;
                 bool exhausted = pending;     // walked all entries and every one was a real candidate
                 if (pending) {
-                    for (int e = 0; e < depth; e++) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        if (e >= depth) break;
                         if (kk[e] >= kNoKey) { exhausted = false; break; }
-                        if (vowner[ii[e]] == 2) continue;
-                        if (b1 < 0) { b1 = ii[e]; k1 = kk[e]; }
-                        else { b2 = ii[e]; k2 = kk[e]; exhausted = false; break; }
+                        if (own[e] == 2) continue;
+                        if (b1 < 0) { b1 = ii[e]; k1 = kk[e]; l1 = lev[e]; }
+                        else { b2 = ii[e]; k2 = kk[e]; l2 = lev[e]; exhausted = false; break; }
                     }
                 }
                 const bool rescan = pending && exhausted;
@@ -679,7 +689,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     const int bestDist = (int) (k1 >> 16);
                     if (bestDist <= TH_HIGH) {
                         const int bestDist2 = (int) (k2 >> 16);      // 256 when there is no runner-up
-                        const int bestLevel = L.octave[b1], bestLevel2 = (b2 >= 0 && bestDist2 < 256) ? L.octave[b2] : -1;
+                        const int bestLevel = l1, bestLevel2 = (b2 >= 0 && bestDist2 < 256) ? l2 : -1;
                         take = !(bestLevel == bestLevel2 && (float) bestDist > A.nnratio * (float) bestDist2);
                     }
                 }
@@ -762,14 +772,15 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             while (__ballot(pending)) {
                 int choice = -1;
                 bool rescan = false;
+                const unsigned char o0 = vowner[idx.x], o1 = vowner[idx.y], o2 = vowner[idx.z], o3 = vowner[idx.w];   // four reads in flight together
                 if (pending) {
-                    if (vowner[idx.x] != 2) choice = idx.x;
+                    if (o0 != 2) choice = idx.x;
                     else if (keys.y >= kNoKey) pending = false;
-                    else if (vowner[idx.y] != 2) choice = idx.y;
+                    else if (o1 != 2) choice = idx.y;
                     else if (keys.z >= kNoKey) pending = false;
-                    else if (vowner[idx.z] != 2) choice = idx.z;
+                    else if (o2 != 2) choice = idx.z;
                     else if (keys.w >= kNoKey) pending = false;
-                    else if (vowner[idx.w] != 2) choice = idx.w;
+                    else if (o3 != 2) choice = idx.w;
                     else rescan = true;
                 }
                 if (pending && choice >= 0 && obs) atomicMin((int *) &vclaim[choice], lane);
