@@ -62,6 +62,11 @@ def load_library(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = _build.lib_path()
+    alt = os.environ.get("YGZF_LIBRARY")   # A/B measurements: another build of the same ABI (tools/ab_libs.sh)
+    if alt:
+        if not os.path.exists(alt):
+            raise YgzfError("YGZF_LIBRARY=%s does not exist" % alt)
+        path, build_if_missing = alt, False
     if build_if_missing and _build.needs_build():
         try:
             _build.build()
