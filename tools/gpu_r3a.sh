@@ -1,7 +1,2 @@
-run() { python bench.py --no-cpu-baseline --no-extras --steps 10 --warmup 3 --passes 1 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d.get('kernels_isolated_avg_us'))"; }
-for i in 1 2 3; do
-YGZF_LIBRARY=$PWD/orb_ygz_slam_amd/lib_ab/libygzf_old.so run old
-run new
-done
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03_c_bench_default.json 2> gpurun_out/r03_c_bench_default.err
+tail -c 400 gpurun_out/r03_c_bench_default.json
