@@ -58,7 +58,7 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
         mCtx = nullptr;
         return nullptr;
     }
-    if (mExtractAhead && ygzf_set_extract_ahead(mCtx, 1) != YGZF_OK) fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(mCtx));
+    mAheadOn = false;
     mCtxW = w;
     mCtxH = h;
     return mCtx;
@@ -82,6 +82,14 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
     }
     mResidentLevel0 = cv::Mat();
     mLastImagePrint = ygzf_host::image_fingerprint(image.data, image.cols, image.rows, (int) image.step);
+    {   // extract-ahead follows the tracker's habit: on when the previous pyramid's image was extracted, off when it was not
+        const bool want = mExtractAhead && mExtractedSincePyramid;
+        if (want != mAheadOn) {
+            if (ygzf_set_extract_ahead(c, want ? 1 : 0) != YGZF_OK) fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(c));
+            else mAheadOn = want;
+        }
+        mExtractedSincePyramid = false;
+    }
     if (ygzf_compute_pyramid(c, image.data, image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK) {
         fprintf(stderr, "ygz::ORBextractor::ComputePyramid: %s\n", ygzf_last_error(c));
         return;
@@ -186,6 +194,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         }
         int rcE = YGZF_ERR_STATE;
         if (resident) rcE = ygzf_extract_resident(c, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
+        if (resident && rcE == YGZF_OK) mExtractedSincePyramid = true;
         if (rcE == YGZF_ERR_STATE) {   // nothing resident (another image operation came in between): the image goes up again
             mLastImagePrint = ygzf_host::image_fingerprint(img.data, img.cols, img.rows, (int) img.step);
             rcE = ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);

@@ -75,7 +75,9 @@ public:
     static int sCvMode;
     // Extract-ahead (include/ygzf.h, ygzf_set_extract_ahead; default on): ComputePyramid queues the ORBSLAM_KEYPOINT extraction of the same image
     // behind the pyramid, so that it runs while the levels return and the Frame constructor clones them; operator()(Frame *, ...) on that image
-    // then only collects keypoints and descriptors.  Frames that never extract (direct tracking) leave ~0.1 ms of GPU work unused per image.
+    // then only collects keypoints and descriptors.  The extractor does this only while it pays: it queues ahead when the PREVIOUS pyramid
+    // was followed by an extraction (a tracker that extracts on every frame), and not when it was not (direct tracking, where most frames
+    // never extract and would pay ~45 us of launch time per ComputePyramid for device work nobody collects).  false: never.
     static bool sExtractAhead;
     // The context, when it still holds `level0` (the image of this extractor's last operation, compared by content fingerprint) together with
     // its pyramid on the device; nullptr otherwise.  The shells that read Frame images (SparseImgAlign::run, FindDirectProjection) pass it to
@@ -106,6 +108,8 @@ private:
     int mCtxW = 0, mCtxH = 0;
     int mDevice = 0, mCvMode = 0;
     bool mExtractAhead = true;
+    bool mAheadOn = false;            // what the context is set to
+    bool mExtractedSincePyramid = true;   // the previous ComputePyramid was followed by an extraction of its image (optimistic start)
     unsigned long long mLastImagePrint = 0;   // fingerprint of the image of the last operation that sent ONE image to the context (0: none)
 };
 
