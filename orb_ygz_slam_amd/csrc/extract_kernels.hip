@@ -1334,12 +1334,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int kWin = 43, kWinP = 64;    // raw window: one 16-byte aligned 64-byte span per row (+ alignment slack)
 constexpr int kHb = 37, kHbP = 40;      // horizontally blurred: 43 rows x 37 cols (u16), pitch even for 32-bit stores
 constexpr int kBl = 37, kBlP = 40;      // blurred 37x37 (u8)
-constexpr int kDescWaves = 4;
+// waves (= keypoints) per workgroup of k_describe / k_describe_list.  A workgroup's LDS and wave slots stay allocated until its slowest wave
+// is done (interior windows and border windows differ by a factor of several): measured per 256 frames, same box, 1 / 2 / 4 / 8 waves per
+// workgroup: 279 / 284 / 292-298 / 315 us -- two it is (236.5 k frames/s in the bench against 233.0 k with four).
+#ifndef YGZF_DESC_WAVES
+#define YGZF_DESC_WAVES 2
+#endif
+constexpr int kDescWaves = YGZF_DESC_WAVES;
 
 // Per-wave LDS: the row-blurred window hb (43 rows x 40 u16 = 3440 B) and the raw window (43 rows x 64 B) share memory: hb rows 0..25
 // sit in front of raw, hb rows 26..42 overlay raw rows 0..21, which are dead by the time they are written (the orientation moments
 // are taken first, the horizontal pass consumes raw rows in ascending order and a wave's LDS operations execute in order).
-// 4.9 KB per wave -> 8 workgroups of 4 waves fit a CU.
+// 4.9 KB per wave -> the CU's 32 wave slots fill before its LDS does.
 constexpr int kHbFront = 26 * kHbP * 2;   // bytes of hb in front of raw (rows 0..25)
 struct DescLds {
     __attribute__((aligned(16))) uint8_t mem[kHbFront + kWin * kWinP + 16];
