@@ -828,20 +828,29 @@ __global__ __launch_bounds__(kFastBlock) void k_fast_quads(FrameSet fs, const Le
 // ------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int kTabPitch = 48;
+#ifndef YGZF_FAST_TAB_WAVES
+#define YGZF_FAST_TAB_WAVES 4
+#endif
+// cells (waves) per workgroup of k_fast_tab: a divisor of 4 (the cell table is built in groups of four).  Measured per 256 frames on one box,
+// isolated / in the three-stream bench: 4 waves 432 us / 235.8 k frames/s, 2 waves 418 us / 231.2 k, 1 wave 455 us / 225.6 k -- smaller
+// workgroups free their LDS sooner, but the pipeline as a whole runs best with four.
+constexpr int kFastTabWaves = YGZF_FAST_TAB_WAVES;
 
 template <bool kIniFirst>
-__global__ __launch_bounds__(kFastBlock) void k_fast_tab(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
+__global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
                                                          unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
                                                          long long totalSlots, int totalGroups, int groupsPerXcd, int winRows, int smapRows,
                                                          int quadCap, unsigned *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
     const int tid = threadIdx.x, lane = tid & 63;
     if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
-    const int grp = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);   // XCD-aware: every XCD gets a contiguous run of groups
-    if (grp >= totalGroups) return;
+    const int blk = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);   // XCD-aware: every XCD gets a contiguous run of cells
     const int f = blockIdx.y;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const FastCellRec R = cells[grp * 4 + wv];
+    const int rec = blk * kFastTabWaves + wv;                              // (groupsPerXcd / totalGroups count workgroups of kFastTabWaves cells here)
+    if (rec >= totalGroups * kFastTabWaves) return;
+    const int grp = rec >> 2;
+    const FastCellRec R = cells[rec];
     const unsigned fl = R.flags >> 8;
     if (!(fl & kFastCellExists)) return;
     unsigned short *cnt_out = cellCnt + (long long) f * totalCells + R.cell;
@@ -1785,19 +1794,22 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 }
 
 // ---- table-driven form (k_fast_tab) ----
-size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap) { return fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap); }
+size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap) {
+    return (fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap) - 64) / (kFastBlock / 64) * kFastTabWaves + 64;
+}
 void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
                      int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
                      unsigned *stats) {
     if (totalGroups <= 0) return;
-    const int groupsPerXcd = (totalGroups + 7) / 8;
-    const dim3 grid(8 * groupsPerXcd, nFrames), block(kFastBlock);
+    const int totalWgs = totalGroups * (4 / kFastTabWaves);                 // workgroups of kFastTabWaves cells
+    const int groupsPerXcd = (totalWgs + 7) / 8;
+    const dim3 grid(8 * groupsPerXcd, nFrames), block(64 * kFastTabWaves);
     const size_t lds = fast_tab_lds_bytes(winRows, smapRows, quadCap);
     if (iniFirst)
-        hipLaunchKernelGGL(k_fast_tab<true>, grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalGroups,
+        hipLaunchKernelGGL(k_fast_tab<true>, grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalWgs,
                            groupsPerXcd, winRows, smapRows, quadCap, stats);
     else
-        hipLaunchKernelGGL(k_fast_tab<false>, grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalGroups,
+        hipLaunchKernelGGL(k_fast_tab<false>, grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalWgs,
                            groupsPerXcd, winRows, smapRows, quadCap, stats);
 }
 
