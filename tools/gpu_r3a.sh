@@ -1,8 +1,7 @@
-run() { python bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 2 --passes 1 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], (d.get('kernels_isolated_avg_us') or {}).get('k_fast_tab'))"; }
-run f4
-for k in 1 2; do YGZF_LIBRARY=$PWD/orb_ygz_slam_amd/lib_ab/libygzf_f$k.so run f$k; done
-run f4
-for k in 1 2; do YGZF_LIBRARY=$PWD/orb_ygz_slam_amd/lib_ab/libygzf_f$k.so run f$k; done
-YGZF_LIBRARY=$PWD/orb_ygz_slam_amd/lib_ab/libygzf_f2.so timeout 600 python -m pytest tests/test_gpu_extract.py tests/test_gpu_fast_plans.py -x -q -p no:cacheprovider 2>&1 | tail -1
+python bench.py --steps 20 --warmup 5 > gpurun_out/r03_c_bench_default.json 2> gpurun_out/r03_c_bench_default.err
+tail -c 300 gpurun_out/r03_c_bench_default.json
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --passes 1 --no-cpu-baseline --no-extras > /tmp/st.log 2>&1
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/prof_r03_c; cp $(find /tmp/st -name "*kernel_stats.csv") gpurun_out/prof_r03_c/r03_c_kernel_stats_raw.csv
+head -12 gpurun_out/prof_r03_c/r03_c_kernel_stats_raw.csv | cut -c1-150
