@@ -1,7 +1,13 @@
-python bench.py --steps 20 --warmup 5 > gpurun_out/r03_c_bench_default.json 2> gpurun_out/r03_c_bench_default.err
-tail -c 300 gpurun_out/r03_c_bench_default.json
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -o stats -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --passes 1 --no-cpu-baseline --no-extras > /tmp/st.log 2>&1
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof_r03_c; cp $(find /tmp/st -name "*kernel_stats.csv") gpurun_out/prof_r03_c/r03_c_kernel_stats_raw.csv
-head -12 gpurun_out/prof_r03_c/r03_c_kernel_stats_raw.csv | cut -c1-150
+timeout 900 python -m pytest tests/test_gpu_mgpu.py -x -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -3
+python - <<'PY'
+import sys, os
+sys.path.insert(0,'.')
+import numpy as np
+import bench
+from orb_ygz_slam_amd.synth import synth_frame
+frames=np.stack([synth_frame(100+i,752,480) for i in range(64)])
+cfg=(752,480,8,1.2,1000,20,7)
+r=bench.mgpu_end_to_end([0], cfg, frames, min_seconds=2.0); print('registered', r['value'], r['calls'])
+os.environ['YGZF_MGPU_NO_REGISTER']='1'
+r=bench.mgpu_end_to_end([0], cfg, frames, min_seconds=2.0); print('staged', r['value'], r['calls'])
+PY
