@@ -188,9 +188,15 @@ __global__ __launch_bounds__(256) void k_pyr_resize(FrameSet fs, const LevelGeom
 // Tiled variant (the one normally launched): a workgroup produces a 256 x 32 output tile.  The <= 41 x 312 byte source
 // region is staged in LDS with coalesced aligned dword loads; every thread owns 4 adjacent columns (their xofs / alpha
 // stay in registers) over 8 rows, so the per-pixel memory instruction count drops from 8 (gathers + table loads) to ~0.2.
-constexpr int kPyrTW = 256, kPyrTH = 32, kPyrSrcRows = 44, kPyrSrcPitch = 328;
+#ifndef YGZF_PYR_WAVES
+#define YGZF_PYR_WAVES 4
+#endif
+// Waves per workgroup (a wave = 8 rows of the tile), same-box A/B on the default bench: 4 -> 29.5 us per launch, 235.1 k frames/s;
+// 2 -> 33.7 us, 227.1 k; 1 -> 44.6 us, 209.3 k (the halo rows of the source tile are re-staged per workgroup, so shorter tiles pay more).
+constexpr int kPyrWaves = YGZF_PYR_WAVES, kPyrThreads = 64 * kPyrWaves;
+constexpr int kPyrTW = 256, kPyrTH = 8 * kPyrWaves, kPyrSrcRows = 44, kPyrSrcPitch = 328;
 
-__global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const LevelGeom *__restrict__ geom, int level,
+__global__ __launch_bounds__(kPyrThreads) void k_pyr_resize_tiled(FrameSet fs, const LevelGeom *__restrict__ geom, int level,
                                                           const int *__restrict__ xofs, const short *__restrict__ xalpha,
                                                           const int *__restrict__ yofs, const short *__restrict__ ybeta) {
     __shared__ __attribute__((aligned(16))) uint8_t tile[kPyrSrcRows * kPyrSrcPitch];
@@ -207,9 +213,9 @@ __global__ __launch_bounds__(256) void k_pyr_resize_tiled(FrameSet fs, const Lev
     {
         const unsigned total = (unsigned) sh * (unsigned) sp;          // bytes of the source level that may be touched
         int r = tid / nd, c = tid - r * nd;
-        const int sr = 256 / nd, sc = 256 - sr * nd;
+        const int sr = kPyrThreads / nd, sc = kPyrThreads - sr * nd;
         constexpr int kU = 4;   // loads of a chunk are all in flight before the first LDS store; threads past the end repeat the last dword
-        for (int i0 = 0; i0 < nd * nr; i0 += 256 * kU) {
+        for (int i0 = 0; i0 < nd * nr; i0 += kPyrThreads * kU) {
             unsigned v[kU];
             int dst[kU];
 #pragma unroll
@@ -1695,7 +1701,7 @@ void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, ui
 // rewriting the nodes' FrameSet argument, launched with one call.
 static void pyr_node_params(hipKernelNodeParams *np, void **args, const LevelGeom &g) {
     std::memset(np, 0, sizeof *np);
-    np->blockDim = dim3(256);
+    np->blockDim = dim3((g.area2x || !g.tiledOk) ? 256 : kPyrThreads);
     np->sharedMemBytes = 0;
     np->kernelParams = args;
     np->extra = nullptr;
@@ -1758,7 +1764,7 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
         return;
     }
     dim3 grid((g.w + kPyrTW - 1) / kPyrTW, (g.h + kPyrTH - 1) / kPyrTH, nFrames);
-    hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+    hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(kPyrThreads), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
 }
 
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap) {
