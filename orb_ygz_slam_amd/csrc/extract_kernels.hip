@@ -313,6 +313,169 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_resize_tiled(FrameSet fs, c
     }
 }
 
+// Strip variant (a few frames at a time: one Tracking frame, a stereo pair): the WHOLE chain of one frame in ONE launch.  Seven dependent
+// launches of a 752x480 frame cost ~6 us each whatever they compute; here a workgroup owns a horizontal strip of the LAST level and
+// produces, level by level in LDS, every row of the levels above it that the strip depends on (the host plans the row ranges from the
+// yofs tables: PyrStripPlan) -- neighbouring strips recompute each other's halo rows instead of waiting for each other, so no workgroup
+// ever reads what another one wrote.  Rows a strip owns (a partition of every level) also go to the pyramid slab.  Same integers as
+// k_pyr_resize_tiled: same coefficient tables, same row sums, same rounding.  Level l - 1 and level l ping-pong between two LDS regions.
+// The kernel is a chain of short dependent phases, so nothing inside the level loop waits for global memory: the column coefficients of
+// all levels (source column, alpha pair: 8 bytes per column) and the row coefficients of every row the strip produces (source rows, beta
+// pair) go to LDS together with level 0; sizes and row ranges are scalar loads of two small tables.
+constexpr int kPyrStripThreads = kPyrStripMaxThreads;
+
+__global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, int nlevels, const PyrStripPlan *__restrict__ plans,
+                                                                 const PyrStripLevel *__restrict__ levels, int offCol, int offA, int offB,
+                                                                 const int *__restrict__ xofs, const short *__restrict__ xalpha,
+                                                                 const int *__restrict__ yofs, const short *__restrict__ ybeta) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t pyrLds[];
+    uint2 *rowTab = (uint2 *) pyrLds;                 // (r0 | r1 << 16, beta0 | beta1 << 16) per produced row, levels 1 .. in order
+    uint2 *colTab = (uint2 *) (pyrLds + offCol);      // (sx, alpha0 | alpha1 << 16) per column, levels 1 .. in order (the order of the xofs table)
+    const int tid = threadIdx.x, f = blockIdx.y;
+    const PyrStripPlan *__restrict__ pl = plans + blockIdx.x;
+    const int xtab1 = levels[1].xtab;
+    // Everything the strip needs from global memory is requested before the first LDS write waits for any of it: this thread's row
+    // coefficients (one row of one level), the first 4096 column coefficients, the first eight dwords per thread of level 0.
+    bool rowHas = false;
+    int rowSy = 0, rowSh = 1, rowSca = 0;
+    unsigned rowBeta = 0;
+    {
+        int i = tid, y = 0, ytab = 0;
+        for (int l = 1; l < nlevels; l++) {   // uniform walk over the levels (scalar loads), selects per thread
+            const int ca = (int) (pl->lv[l].x & 0xFFFFu), n = (int) (pl->lv[l].x >> 16) - ca;
+            const bool hit = i >= 0 && i < n;
+            y = hit ? ca + i : y;
+            ytab = hit ? levels[l].ytab : ytab;
+            rowSh = hit ? levels[l - 1].h : rowSh;
+            rowSca = hit ? (int) (pl->lv[l - 1].x & 0xFFFFu) : rowSca;
+            rowHas |= hit;
+            i -= n;
+        }
+        if (rowHas) {
+            rowSy = yofs[ytab + y];
+            rowBeta = *(const unsigned *) (ybeta + 2 * (ytab + y));
+        }
+    }
+    const int nCols = levels[nlevels - 1].xtab + levels[nlevels - 1].w - xtab1;
+    constexpr int kC = 4;
+    uint2 colv[kC];
+#pragma unroll
+    for (int u = 0; u < kC; u++) {
+        const int i = min(tid + u * kPyrStripThreads, nCols - 1);
+        colv[u] = make_uint2((unsigned) xofs[xtab1 + i], *(const unsigned *) (xalpha + 2 * (xtab1 + i)));
+    }
+    {   // level 0 rows [ca, cb) -> region A, whole rows, aligned dwords of the row
+        const uint8_t *src = fs.img0 + (long long) f * fs.img0_stride;
+        const int sp = fs.img0_pitch;
+        const int w0 = levels[0].w, h0 = levels[0].h;
+        const int ca = (int) (pl->lv[0].x & 0xFFFFu), nr = (int) (pl->lv[0].x >> 16) - ca;
+        const int nd = (w0 + 3) >> 2, P = pyr_strip_lds_pitch(w0) >> 2;
+        const unsigned total = (unsigned) h0 * (unsigned) sp;
+        unsigned *A = (unsigned *) (pyrLds + offA);
+        int r = tid / nd, c = tid - r * nd;
+        const int sr = kPyrStripThreads / nd, sc = kPyrStripThreads - sr * nd;
+        constexpr int kU = 8;
+        bool first = true;
+        for (int i0 = 0; i0 < nd * nr; i0 += kPyrStripThreads * kU) {
+            unsigned v[kU];
+            int dst[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++) {
+                const bool in = r < nr;
+                const int rr = in ? r : nr - 1, cc = in ? c : nd - 1;
+                const unsigned off = (unsigned) (ca + rr) * (unsigned) sp + (unsigned) (4 * cc);
+                if (off + 4 <= total) v[u] = *(const unsigned *) (src + off);
+                else {
+                    v[u] = 0;
+                    for (int b = 0; b < 4; b++) if (off + b < total) v[u] |= (unsigned) src[off + b] << (8 * b);
+                }
+                dst[u] = rr * P + cc;
+                r += sr; c += sc;
+                if (c >= nd) { c -= nd; r++; }
+            }
+            if (first) {   // the tables, requested before the image
+                first = false;
+                if (rowHas) {
+                    const unsigned r0 = (unsigned) (min(max(rowSy, 0), rowSh - 1) - rowSca), r1 = (unsigned) (min(max(rowSy + 1, 0), rowSh - 1) - rowSca);
+                    rowTab[tid] = make_uint2(r0 | (r1 << 16), rowBeta);
+                }
+#pragma unroll
+                for (int u = 0; u < kC; u++)
+                    if (tid + u * kPyrStripThreads < nCols) colTab[tid + u * kPyrStripThreads] = colv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++) A[dst[u]] = v[u];
+        }
+        for (int i = tid + kC * kPyrStripThreads; i < nCols; i += kPyrStripThreads)   // pyramids with more than 4096 columns in all
+            colTab[i] = make_uint2((unsigned) xofs[xtab1 + i], *(const unsigned *) (xalpha + 2 * (xtab1 + i)));
+    }
+    __syncthreads();
+    int rowOff = 0;
+    for (int l = 1; l < nlevels; l++) {
+        // sizes and row ranges: scalar loads of two small tables that the staging phase has already pulled into the scalar cache
+        const int w = levels[l].w, pitch = levels[l].pitch;
+        const unsigned goff = (unsigned) levels[l].off;
+        const int sw = levels[l - 1].w;
+        const uint8_t *sb = pyrLds + ((l - 1) & 1 ? offB : offA);
+        uint8_t *db = pyrLds + (l & 1 ? offB : offA);
+        const int Ps = pyr_strip_lds_pitch(sw), Pd = pyr_strip_lds_pitch(w);
+        const uint2 pv = pl->lv[l];
+        const int ca = (int) (pv.x & 0xFFFFu), cb = (int) (pv.x >> 16), wa = (int) (pv.y & 0xFFFFu), wb = (int) (pv.y >> 16);
+        const int nq = (w + 3) >> 2, nrp = kPyrStripThreads / nq;
+        const int rp = tid / nq, cq = tid - rp * nq;
+        if (rp < nrp) {   // this thread: column quad cq of rows ca + rp, ca + rp + nrp, ...
+            const int xb = 4 * cq;
+            unsigned sel[4], ap[4];
+            const uint2 *ct = colTab + (levels[l].xtab - xtab1);
+            const int lx0 = (int) ct[xb].x;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint2 cc = ct[min(xb + k, w - 1)];
+                const int sx1 = min((int) cc.x + 1, sw - 1);
+                sel[k] = (unsigned) ((int) cc.x - lx0) | 0x0C00u | ((unsigned) (sx1 - lx0) << 16) | 0x0C000000u;
+                ap[k] = cc.y;
+            }
+            const int bd4 = lx0 & ~3;
+            const unsigned osh = (unsigned) lx0 & 3u;
+            uint8_t *dstf = fs.pyr + (long long) f * fs.pyr_stride + goff;
+            auto hrow = [&](int r, unsigned (&H)[4]) {
+                const unsigned *p = (const unsigned *) (sb + r * Ps + bd4);
+                const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
+                const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, osh), e1 = __builtin_amdgcn_alignbyte(d2, d1, osh);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, __builtin_amdgcn_perm(e1, e0, sel[k])), __builtin_bit_cast(v2u, ap[k]), 0u, false);
+            };
+            for (int y = ca + rp; y < cb; y += 2 * nrp) {   // two rows per turn: their LDS reads travel together
+                const int y2 = y + nrp;
+                const bool two = y2 < cb;
+                const uint2 rcA = rowTab[rowOff + y - ca], rcB = rowTab[rowOff + (two ? y2 : y) - ca];
+                unsigned HA0[4], HA1[4], HB0[4], HB1[4];
+                hrow((int) (rcA.x & 0xFFFFu), HA0);
+                hrow((int) (rcA.x >> 16), HA1);
+                hrow((int) (rcB.x & 0xFFFFu), HB0);
+                hrow((int) (rcB.x >> 16), HB1);
+                const int a0 = (int) (short) (rcA.y & 0xFFFFu), a1 = (int) (short) (rcA.y >> 16);
+                const int c0 = (int) (short) (rcB.y & 0xFFFFu), c1 = (int) (short) (rcB.y >> 16);
+                unsigned outA = 0, outB = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    outA |= (unsigned) (((__mul24(a0, (int) (HA0[k] >> 4)) >> 16) + (__mul24(a1, (int) (HA1[k] >> 4)) >> 16) + 2) >> 2) << (8 * k);
+                    outB |= (unsigned) (((__mul24(c0, (int) (HB0[k] >> 4)) >> 16) + (__mul24(c1, (int) (HB1[k] >> 4)) >> 16) + 2) >> 2) << (8 * k);
+                }
+                *(unsigned *) (db + (y - ca) * Pd + xb) = outA;
+                if (y >= wa && y < wb) *(unsigned *) (dstf + (unsigned) y * (unsigned) pitch + xb) = outA;
+                if (two) {
+                    *(unsigned *) (db + (y2 - ca) * Pd + xb) = outB;
+                    if (y2 >= wa && y2 < wb) *(unsigned *) (dstf + (unsigned) y2 * (unsigned) pitch + xb) = outB;
+                }
+            }
+        }
+        rowOff += cb - ca;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // K2  FAST-9/16 per 30-px cell.  One wave per (cell, frame): the (wCell+6)x(hCell+6) window is staged in LDS, corners are
 // found at minTh (byte-sliced test, four pixels per lane), their score (max arc margin - 1 == cv::FAST's cornerScore) is
@@ -1765,6 +1928,15 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
     }
     dim3 grid((g.w + kPyrTW - 1) / kPyrTW, (g.h + kPyrTH - 1) / kPyrTH, nFrames);
     hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(kPyrThreads), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+}
+
+hipError_t pyr_strips_prepare(size_t ldsBytes) {
+    return hipFuncSetAttribute((const void *) k_pyr_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+}
+
+void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips, int offCol,
+                       int offA, int offB, size_t ldsBytes, int nFrames, const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
+    hipLaunchKernelGGL(k_pyr_strips, dim3(nStrips, nFrames), dim3(kPyrStripThreads), ldsBytes, st, fs, nlevels, plans, levels, offCol, offA, offB, xofs, xalpha, yofs, ybeta);
 }
 
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap) {

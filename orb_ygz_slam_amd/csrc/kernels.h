@@ -26,6 +26,22 @@ hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const Le
                                  const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 hipError_t pyr_chain_graph_retarget(PyrChainGraph *pg, const FrameSet &fs);
 void pyr_chain_graph_destroy(PyrChainGraph *pg);
+// one frame's whole pyramid chain in one launch (k_pyr_strips): per strip and level, the rows [ca, cb) the strip produces in LDS (level 0:
+// stages) and the rows [wa, wb) of them it owns, i.e. writes to the pyramid slab
+struct PyrStripPlan {
+    uint2 lv[kMaxLevels];   // x = ca | cb << 16, y = wa | wb << 16 (32-bit words: the kernel reads them with scalar loads)
+};
+struct PyrStripLevel {   // what the kernel needs of a level, 32 bytes
+    int w, h, pitch, xtab, ytab, pad;
+    long long off;
+};
+constexpr int kPyrStripMaxThreads = 1024;
+__host__ __device__ inline int pyr_strip_lds_pitch(int w) { return ((w + 3) & ~3) + 12; }
+// LDS: row table (8 bytes per produced row of the levels >= 1), column table from offCol (8 bytes per column of the levels >= 1), region A from
+// offA (even levels), region B from offB (odd levels)
+hipError_t pyr_strips_prepare(size_t ldsBytes);
+void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips, int offCol,
+                       int offA, int offB, size_t ldsBytes, int nFrames, const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 void launch_carry_slot(hipStream_t st, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, long long srcSlot, int kpStride);
 void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int firstLevel, int nlevels, const unsigned *offsets, uint8_t *dst);
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);

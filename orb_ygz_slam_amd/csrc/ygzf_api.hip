@@ -74,6 +74,10 @@ struct Geometry {
     std::vector<int> xofs, yofs;
     std::vector<short> xalpha, ybeta;
     long long pyrBytes = 0;   // per frame, levels >= 1
+    std::vector<PyrStripPlan> pyrPlan;   // k_pyr_strips: one entry per strip (empty: this geometry takes one launch per level)
+    int pyrStripOffCol = 0, pyrStripOffA = 0, pyrStripOffB = 0;
+    PyrStripLevel pyrLevels[kMaxLevels];
+    size_t pyrStripLds = 0;
     int totalCells = 0, maxCellsPerLevel = 0;
     int totalGroups = 0, fastSmapRows = 3, fastWinPitch = 16, fastWinRows = 7, fastQuadCap = 4;   // 2x2 cell groups of k_fast_quads
     int fastWCellMax = 1;
@@ -101,7 +105,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX;
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan;
     int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
@@ -148,6 +152,7 @@ struct ygzf_ctx {
     // ygzf_set_extract_ahead: ygzf_compute_pyramid queues the extraction behind the pyramid and reads the levels back on a second stream
     // one-frame pyramid chain as a captured graph: seven dependent launches cost the host more than the kernels take (pyramid_chain)
     bool useGraphs = getenv("YGZF_NO_GRAPH") == nullptr;
+    int pyrStripFrames = getenv("YGZF_PYR_STRIP_FRAMES") ? atoi(getenv("YGZF_PYR_STRIP_FRAMES")) : 16;   // k_pyr_strips up to this many frames per launch (0: never)
     PyrChainGraph pyrGraph = {};
     const void *pyrGraphKey[6] = {nullptr};   // geometry tables + size the graph was built for
     bool extractAhead = false, aheadPending = false;
@@ -253,6 +258,65 @@ struct PackedTransfer {
 // Per-(w,h) geometry: level sizes, resize coefficient tables (cv::resize INTER_LINEAR fixed point, restated from the
 // OpenCV 2.4/3.2 algorithm: fx = (float)((dx+0.5)*scale - 0.5), 11-bit coefficients), FAST cell grid (:733-745),
 // octree root layout (:537-557) and buffer offsets.
+// Row ranges of k_pyr_strips (extract_kernels.hip): the last level is cut into S strips; walking up, a strip needs of level l the source
+// rows of the rows it produces of level l + 1 (yofs is monotone: first row's sy .. last row's sy + 1, clamped as the kernel clamps) and
+// owns the S-th part of every level.  S grows until the two LDS regions (even / odd levels) fit.
+static void plan_pyr_strips(Geometry &G, int L) {
+    G.pyrPlan.clear();
+    if (L < 3) return;
+    for (int l = 1; l < L; l++)
+        if (G.lv[l].area2x || !G.lv[l].tiledOk || (G.lv[l].w + 3) / 4 > kPyrStripMaxThreads) return;
+    // 752x480, one frame: 16 strips 148 us per resident extraction, 24 146, 32 144, 48 143 (the halo rows grow with the strip count: 1.23 x
+    // the pixels of the pyramid at 16); eight frames: 16 strips 218 us, 32 215
+    const int candidates[] = {32, 48, 64};
+    const int minS = getenv("YGZF_PYR_STRIPS") ? atoi(getenv("YGZF_PYR_STRIPS")) : 0;   // A/B runs: at least this many strips
+    for (int S : candidates) {
+        if (S < minS) continue;
+        if (G.lv[L - 1].h < 2 * S) break;
+        std::vector<PyrStripPlan> plan(S);
+        size_t bytes[2] = {0, 0};
+        int maxRows = 0;
+        for (int s = 0; s < S; s++) {
+            int rows = 0, pca = 0, pcb = 0;   // the range produced of the level below the one in hand
+            PyrStripPlan &p = plan[s];
+            std::memset(&p, 0, sizeof p);
+            for (int l = L - 1; l >= 0; l--) {
+                const int hl = G.lv[l].h;
+                int wa = (int) ((long long) hl * s / S), wb = (int) ((long long) hl * (s + 1) / S), ca = wa, cb = wb;
+                if (l < L - 1) {
+                    const LevelGeom &n = G.lv[l + 1];
+                    const int na = std::min(std::max(G.yofs[n.ytab + pca], 0), hl - 1);
+                    const int nb = std::min(std::max(G.yofs[n.ytab + pcb - 1] + 1, 0), hl - 1) + 1;
+                    if (l == 0) { ca = na; cb = nb; wa = wb = 0; }
+                    else { ca = std::min(wa, na); cb = std::max(wb, nb); }
+                }
+                p.lv[l] = make_uint2((unsigned) ca | ((unsigned) cb << 16), (unsigned) wa | ((unsigned) wb << 16));
+                pca = ca; pcb = cb;
+                bytes[l & 1] = std::max(bytes[l & 1], (size_t) (cb - ca) * pyr_strip_lds_pitch(G.lv[l].w));
+                if (l >= 1) rows += cb - ca;
+            }
+            maxRows = std::max(maxRows, rows);
+        }
+        if (maxRows > kPyrStripMaxThreads) continue;   // one thread per row fills the row table
+        size_t nCols = 0;
+        for (int l = 1; l < L; l++) nCols += (size_t) G.lv[l].w;
+        const size_t rowBytes = ((size_t) maxRows * 8 + 15) & ~(size_t) 15, head = rowBytes + ((nCols * 8 + 15) & ~(size_t) 15);
+        const size_t a = (bytes[0] + 16 + 15) & ~(size_t) 15, b = (bytes[1] + 16 + 15) & ~(size_t) 15;   // hrow reads up to 11 bytes past a row's pixels
+        if (head + a + b > 160 * 1024) continue;
+        G.pyrPlan = plan;
+        G.pyrStripOffCol = (int) rowBytes;
+        G.pyrStripOffA = (int) head;
+        G.pyrStripOffB = (int) (head + a);
+        G.pyrStripLds = head + a + b;
+        std::memset(G.pyrLevels, 0, sizeof G.pyrLevels);
+        for (int l = 0; l < L; l++) {
+            const LevelGeom &g = G.lv[l];
+            G.pyrLevels[l] = PyrStripLevel{g.w, g.h, g.pitch, g.xtab, g.ytab, 0, (long long) g.off};
+        }
+        return;
+    }
+}
+
 static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
     const Tables &T = c->tab;
     const int L = T.cfg.nlevels;
@@ -369,6 +433,7 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
         G.kpCapMax = std::max(G.kpCapMax, g.kpCap);
     }
     G.pyrBytes = off;
+    plan_pyr_strips(G, L);
     G.totalCells = cellBase;
     G.totalGroups = groupBase;
     // per-cell records of k_fast_tab: the cell loop of ComputeKeyPointsOctTree (src/ORBextractor.cc:747-764) evaluated once per geometry
@@ -432,6 +497,16 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             rc = ensure(c, *u.b, std::max<size_t>(u.bytes, 16));
             if (rc) return rc;
             if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
+        }
+        if (!G.pyrPlan.empty()) {
+            rc = ensure(c, c->dPyrPlan, sizeof G.pyrLevels + G.pyrPlan.size() * sizeof(PyrStripPlan));   // level table, then one plan per strip
+            if (rc) return rc;
+            HIPCHECK(c, hipMemcpy(c->dPyrPlan.p, G.pyrLevels, sizeof G.pyrLevels, hipMemcpyHostToDevice));
+            HIPCHECK(c, hipMemcpy((char *) c->dPyrPlan.p + sizeof G.pyrLevels, G.pyrPlan.data(), G.pyrPlan.size() * sizeof(PyrStripPlan), hipMemcpyHostToDevice));
+            if (pyr_strips_prepare(G.pyrStripLds) != hipSuccess) {   // no such LDS allotment on this device: one launch per level
+                (void) hipGetLastError();
+                G.pyrPlan.clear();
+            }
         }
         rc = ensure(c, c->dFastCells, std::max<size_t>(G.fastCells.size() * sizeof(FastCellRec), 32));
         if (rc) return rc;
@@ -543,6 +618,13 @@ static int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                                   (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
         }
     };
+    if (!G.pyrPlan.empty() && nFrames <= c->pyrStripFrames) {   // a few frames: the whole chain in one launch
+        ProfScope ps(c, KK_PYR);
+        launch_pyr_strips(c->stream, fs, L, (const PyrStripPlan *) ((const char *) c->dPyrPlan.p + sizeof G.pyrLevels), (const PyrStripLevel *) c->dPyrPlan.p,
+                          (int) G.pyrPlan.size(), G.pyrStripOffCol, G.pyrStripOffA, G.pyrStripOffB, G.pyrStripLds, nFrames,
+                          (const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+        return YGZF_OK;
+    }
     if (nFrames != 1 || L < 3 || !c->useGraphs || c->profile || c->debugSync) {
         launch_all(true);
         return YGZF_OK;

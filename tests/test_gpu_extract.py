@@ -308,3 +308,28 @@ def test_extract_ahead_of_the_request(oracle):
         ex.compute_pyramid(a)
         kr, dr = ex.extract_resident(w, h)
         assert np.array_equal(kr, ka) and np.array_equal(dr, da)
+
+
+@pytest.mark.parametrize("w,h,nl,sf", [(752, 480, 8, 1.2), (641, 479, 8, 1.2), (1241, 376, 8, 1.2), (333, 517, 6, 1.25), (200, 150, 3, 1.2),
+                                       (1920, 1080, 8, 1.2), (752, 480, 12, 1.1), (130, 110, 8, 1.2)])
+def test_pyramid_one_launch_and_level_by_level(oracle, monkeypatch, w, h, nl, sf):
+    """ComputePyramid (src/ORBextractor.cc:1130-1150) two ways: the whole chain of a frame in one launch (k_pyr_strips: strips of the
+    last level with recomputed halo rows, what a context takes for a few frames at a time) and one launch per level (batches): every
+    level byte for byte the oracle's, for widths that are no multiple of four, short pyramids, narrow scale steps, and batches that put
+    several frames into one launch."""
+    from orb_ygz_slam_amd import Extractor
+    imgs = np.stack([synth_frame(60 + i, w, h) for i in range(3)])
+    oex = oracle.Extractor(500, sf, nl, 20, 7)
+    want = [oex.pyramid(imgs[i]) for i in range(3)]
+    for strip_frames in ("8", "0"):
+        monkeypatch.setenv("YGZF_PYR_STRIP_FRAMES", strip_frames)
+        for strips in ("0", "32"):
+            monkeypatch.setenv("YGZF_PYR_STRIPS", strips)
+            ex = Extractor(500, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+            for batch in (imgs[:1], imgs):
+                ex.extract_batch_host(batch)
+                for f in range(len(batch)):
+                    for l in range(nl):
+                        got = ex.batch_fetch_level(f, l)
+                        assert got.shape == want[f][l].shape and (got == want[f][l]).all(), (strip_frames, strips, f, l)
+            del ex
