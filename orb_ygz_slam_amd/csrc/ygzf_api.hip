@@ -268,11 +268,12 @@ static void plan_pyr_strips(Geometry &G, int L) {
         if (G.lv[l].area2x || !G.lv[l].tiledOk || (G.lv[l].w + 3) / 4 > kPyrStripMaxThreads) return;
     // 752x480, one frame: 16 strips 148 us per resident extraction, 24 146, 32 144, 48 143 (the halo rows grow with the strip count: 1.23 x
     // the pixels of the pyramid at 16); eight frames: 16 strips 218 us, 32 215
-    const int candidates[] = {32, 48, 64};
+    // (more strips when the LDS regions do not fit, fewer for images whose last level has fewer than 64 rows).
+    const int candidates[] = {32, 48, 64, 16, 8};
     const int minS = getenv("YGZF_PYR_STRIPS") ? atoi(getenv("YGZF_PYR_STRIPS")) : 0;   // A/B runs: at least this many strips
     for (int S : candidates) {
         if (S < minS) continue;
-        if (G.lv[L - 1].h < 2 * S) break;
+        if (G.lv[L - 1].h < 2 * S) continue;
         std::vector<PyrStripPlan> plan(S);
         size_t bytes[2] = {0, 0};
         int maxRows = 0;

@@ -1,7 +1,28 @@
-timeout 900 python -m pytest tests/test_gpu_extract.py tests/test_gpu_align.py tests/test_gpu_stereo.py tests/test_gpu_repeat.py -x -q -p no:cacheprovider 2>&1 | tail -3
-p() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
-lat() { for b in $2; do python bench.py --no-cpu-baseline --no-profile --no-extras --streams 1 --sub-batch $b --batch $b --steps 100 --warmup 10 2>&1 | p "$1 lat_b$b"; done; }
-YGZF_PYR_STRIP_FRAMES=0 lat old "1 16"
-lat s32 "1 2 8 16"
-YGZF_PYR_STRIPS=48 lat s48 "1 16"
-python bench.py --no-cpu-baseline --no-extras --streams 1 --sub-batch 1 --batch 1 --steps 50 --warmup 5 2>&1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lat kernels', {k:v['avg_us'] for k,v in d['kernels'].items()})"
+timeout 900 python -m pytest tests/test_gpu_extract.py -x -q -p no:cacheprovider 2>&1 | tail -3
+run() { python bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 2 --passes 1 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], (d.get('kernels_isolated_avg_us') or {}).get('k_pyr_resize'))"; }
+YGZF_PYR_TAIL_FROM=0 run notail
+run tail3
+YGZF_PYR_TAIL_FROM=4 run tail4
+YGZF_PYR_TAIL_FROM=2 run tail2
+YGZF_PYR_STRIPS=24 run tail3s24
+YGZF_PYR_TAIL_FROM=0 run notail
+run tail3
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt -o kt -- python bench.py --no-cpu-baseline --no-extras --no-profile --steps 2 --warmup 1 --passes 1 --streams 1 > /dev/null 2>&1
+f=$(find gpurun_out/kt -name "*kernel_trace.csv" | head -1)
+python - "$f" <<'PY'
+import csv,sys,collections
+rows=list(csv.DictReader(open(sys.argv[1])))
+agg=collections.defaultdict(list)
+for r in rows:
+    n=r['Kernel_Name']
+    if 'pyr' in n:
+        key=(n.split('(')[0][-28:], r.get('Grid_Size_X') or r.get('Grid_Size'), r.get('Grid_Size_Y'), r.get('Grid_Size_Z'))
+        agg[key].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
+for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1])):
+    v.sort(); print(k, len(v), 'median us', v[len(v)//2]/1e3, 'min', v[0]/1e3)
+PY
+rm -rf gpurun_out/kt
