@@ -1083,14 +1083,22 @@ __device__ __forceinline__ unsigned path_key(int x, int y, const LevelGeom &g) {
     return k;
 }
 
-// first index in [lo, lo+cnt) whose 2-bit digit at `shift` is >= c (keys in the range share all higher bits)
-__device__ __forceinline__ int digit_lower_bound(const unsigned *keys, int lo, int cnt, int shift, unsigned c) {
-    int a = lo, b = lo + cnt;
-    while (a < b) {
-        const int m = (a + b) >> 1;
-        if (((keys[m] >> shift) & 3u) < c) a = m + 1; else b = m;
+// the three child boundaries of a node at once: a_c = first index in [lo, lo+cnt) whose digit is >= c (c = 1, 2, 3).  The range is sorted by
+// that digit, so each boundary is a lower bound over the WHOLE range -- the same values as three nested searches, but the three walks
+// advance together: 11 dependent LDS round trips for a 2000-candidate node instead of 33
+__device__ __forceinline__ void digit_bounds3(const unsigned *keys, int lo, int cnt, int shift, int *a1, int *a2, int *a3) {
+    int a[3] = {lo, lo, lo}, b[3] = {lo + cnt, lo + cnt, lo + cnt};
+    while (a[0] < b[0] || a[1] < b[1] || a[2] < b[2]) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const bool go = a[c] < b[c];
+            const int m = go ? (a[c] + b[c]) >> 1 : lo;
+            const bool less = ((keys[m] >> shift) & 3u) < (unsigned) (c + 1);
+            a[c] = go && less ? m + 1 : a[c];
+            b[c] = go && !less ? m : b[c];
+        }
     }
-    return a;
+    *a1 = a[0]; *a2 = a[1]; *a3 = a[2];
 }
 
 struct OctShared {  // carved out of dynamic LDS
@@ -1172,19 +1180,99 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     // ---- 2. path keys: one thread per candidate (its cell by binary search in the prefix table) ----
     const bool inLds = M <= ldsCand;
     if (inLds) { key0 = S.cand; val0 = S.cand + ldsCand; key1 = S.cand + 2 * ldsCand; val1 = S.cand + 3 * ldsCand; }
-    for (int i = tid; i < M; i += kOctBlock) {
-        int a = 0, b = nCells;                       // last cell c with cellPref[c] <= i
-        while (b - a > 1) {
-            const int m = (a + b) >> 1;
-            if (S.cellPref[m] <= i) a = m; else b = m;
+    // A workgroup has ONE CU: 2800 candidates x ~300 instructions of cell decode (a division), root (a float division) and ten
+    // subdivision steps were 7 us of a 752x480 level 0.  x and y subdivide independently, so the key is the OR of a per-column word
+    // (root, x bits spread to the even positions) and a per-row word (y bits on the odd positions): both tables and the cells' origins
+    // are built once per workgroup in the node arrays (idle until the tree passes) when they fit there.
+    const int lenX = max(g.regW, g.nCols * g.wCell) + 9, lenY = max(g.regH, g.nRows * g.hCell) + 9;
+    const bool useTab = lenX + lenY + nCells <= 19 * cap && g.depth <= 15;
+    unsigned *xTab = (unsigned *) S.nlo[0], *yTab = xTab + lenX, *orgTab = yTab + lenY;
+    if (useTab) {
+        auto spread = [](unsigned v) {
+            v = (v | (v << 8)) & 0x00FF00FFu;
+            v = (v | (v << 4)) & 0x0F0F0F0Fu;
+            v = (v | (v << 2)) & 0x33333333u;
+            return (v | (v << 1)) & 0x55555555u;
+        };
+        for (int t = tid; t < lenX + lenY + nCells; t += kOctBlock) {
+            if (t < lenX) {
+                const int x = t;
+                int root = (int) ((float) x / g.hX);
+                root = min(root, g.nIni - 1);
+                int xl = (int) (g.hX * (float) root), xr = (int) (g.hX * (float) (root + 1));
+                unsigned kx = 0;
+                for (int d = 0; d < g.depth; d++) {
+                    const int mx = xl + ((xr - xl + 1) >> 1);
+                    const unsigned bx = x >= mx;
+                    if (bx) xl = mx; else xr = mx;
+                    kx = (kx << 1) | bx;
+                }
+                xTab[t] = ((unsigned) root << (2 * g.depth)) | spread(kx);
+            } else if (t < lenX + lenY) {
+                const int y = t - lenX;
+                int yl = 0, yr = g.regH;
+                unsigned ky = 0;
+                for (int d = 0; d < g.depth; d++) {
+                    const int my = yl + ((yr - yl + 1) >> 1);
+                    const unsigned by = y >= my;
+                    if (by) yl = my; else yr = my;
+                    ky = (ky << 1) | by;
+                }
+                yTab[y] = spread(ky) << 1;
+            } else {
+                const int c = t - lenX - lenY;
+                const int ci = c / g.nCols, cj = c - ci * g.nCols;
+                orgTab[c] = (unsigned) (cj * g.wCell) | ((unsigned) (ci * g.hCell) << 16);
+            }
         }
-        const int c = a, k = i - S.cellPref[c];
-        const int ci = c / g.nCols, cj = c - ci * g.nCols;
-        const unsigned e = sl[(long long) c * g.slotCap + k];
-        const int x = (int) (e & 255u) + cj * g.wCell, y = (int) ((e >> 8) & 255u) + ci * g.hCell;
-        key0[i] = path_key(x, y, g);
-        val0[i] = ((e >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
-        xy[i] = (unsigned) x | ((unsigned) y << 16);
+        __syncthreads();
+    }
+    {
+        // four candidates per thread at a time: their binary searches advance together (the LDS reads of a step travel together) and their
+        // slot reads are all in flight before the first key is assembled
+        int steps = 0;
+        while ((1 << steps) < nCells) steps++;
+        constexpr int kKU = 4;
+        for (int i0 = tid; i0 < M; i0 += kKU * kOctBlock) {
+            int ia[kKU], a[kKU], b[kKU];
+#pragma unroll
+            for (int u = 0; u < kKU; u++) { ia[u] = min(i0 + u * kOctBlock, M - 1); a[u] = 0; b[u] = nCells; }
+            for (int st = 0; st < steps; st++) {             // a[u] = last cell c with cellPref[c] <= ia[u]
+#pragma unroll
+                for (int u = 0; u < kKU; u++) {
+                    const int m = (a[u] + b[u]) >> 1;
+                    const bool go = b[u] - a[u] > 1, le = S.cellPref[m] <= ia[u];
+                    a[u] = go && le ? m : a[u];
+                    b[u] = go && !le ? m : b[u];
+                }
+            }
+            unsigned e[kKU];
+            int ox[kKU], oy[kKU];
+#pragma unroll
+            for (int u = 0; u < kKU; u++) {
+                const int c = a[u], k = ia[u] - S.cellPref[c];
+                e[u] = sl[(long long) c * g.slotCap + k];
+                if (useTab) {
+                    const unsigned o = orgTab[c];
+                    ox[u] = (int) (o & 0xFFFFu);
+                    oy[u] = (int) (o >> 16);
+                } else {
+                    const int ci = c / g.nCols, cj = c - ci * g.nCols;
+                    ox[u] = cj * g.wCell;
+                    oy[u] = ci * g.hCell;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kKU; u++) {
+                const int i = i0 + u * kOctBlock;
+                if (i < M) {
+                    const int x = (int) (e[u] & 255u) + ox[u], y = (int) ((e[u] >> 8) & 255u) + oy[u];
+                    key0[i] = useTab ? (xTab[x] | yTab[y]) : path_key(x, y, g);
+                    val0[i] = ((e[u] >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
+                    xy[i] = (unsigned) x | ((unsigned) y << 16);
+                }
+            }
+        }
     }
     __syncthreads();
     OSTAMP(2);
@@ -1221,9 +1309,8 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
             int k = 0, e = 0;
             if (cnt > 1) {
                 const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[i] + 1));
-                const int a1 = digit_lower_bound(skeys, lo, cnt, shift, 1u);
-                const int a2 = digit_lower_bound(skeys, a1, lo + cnt - a1, shift, 2u);
-                const int a3 = digit_lower_bound(skeys, a2, lo + cnt - a2, shift, 3u);
+                int a1, a2, a3;
+                digit_bounds3(skeys, lo, cnt, shift, &a1, &a2, &a3);
                 S.b1[i] = a1; S.b2[i] = a2; S.b3[i] = a3;
                 const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
                 k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
@@ -1302,9 +1389,8 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                     const int e = (int) ev[nE - 1 - j];
                     const int pos = S.Epos[e];
                     const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[pos] + 1));
-                    const int a1 = digit_lower_bound(skeys, lo, cnt, shift, 1u);
-                    const int a2 = digit_lower_bound(skeys, a1, lo + cnt - a1, shift, 2u);
-                    const int a3 = digit_lower_bound(skeys, a2, lo + cnt - a2, shift, 3u);
+                    int a1, a2, a3;
+                    digit_bounds3(skeys, lo, cnt, shift, &a1, &a2, &a3);
                     S.b1[j] = a1; S.b2[j] = a2; S.b3[j] = a3;
                     const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
                     S.kArr[j] = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) - 1;  // growth of the list
@@ -1394,12 +1480,17 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     unsigned *oxy = lvlKpXY + (long long) f * kpStride + g.kpBase;
     unsigned char *osc = lvlKpScore + (long long) f * kpStride + g.kpBase;
     const int lane = lane_id(), wave = wave_id();
-    for (int i = wave; i < n; i += kOctBlock / 64) {   // a wave per node: arg-max over its range (LDS / DPP only)
-        const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
+    for (int i0 = wave * 4; i0 < n; i0 += (kOctBlock / 64) * 4) {   // sixteen lanes (a DPP row) per node: arg-max over its range (LDS / DPP only);
+        const int i = i0 + (lane >> 4), sl16 = lane & 15;           // the final nodes hold ~10 candidates each
+        const bool ok = i < n;
+        const int lo = ok ? (cur ? S.nlo[1] : S.nlo[0])[i] : 0, cnt = ok ? (cur ? S.ncnt[1] : S.ncnt[0])[i] : 0;
         unsigned best = 0;
-        for (int k = lane; k < cnt; k += 64) best = max(best, svals[lo + k]);
-        best = wave_max_u32(best);
-        if (lane == 0) S.kArr[i] = (int) best;
+        for (int k = sl16; k < cnt; k += 16) best = max(best, svals[lo + k]);
+        best = max(best, (unsigned) __builtin_amdgcn_update_dpp(0, (int) best, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        best = max(best, (unsigned) __builtin_amdgcn_update_dpp(0, (int) best, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        best = max(best, (unsigned) __builtin_amdgcn_update_dpp(0, (int) best, 0x141, 0xF, 0xF, true));   // row_half_mirror
+        best = max(best, (unsigned) __builtin_amdgcn_update_dpp(0, (int) best, 0x140, 0xF, 0xF, true));   // row_mirror
+        if (ok && sl16 == 0) S.kArr[i] = (int) best;
     }
     __syncthreads();
     for (int i = tid; i < n; i += kOctBlock) {         // a thread per node: the dependent global read of the winner's position, all in flight at once
