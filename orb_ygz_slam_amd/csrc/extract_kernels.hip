@@ -1131,6 +1131,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     __shared__ int s_tmp[20];
     __shared__ unsigned long long s_tmp64[17];
     __shared__ int s_n, s_nE, s_cut, s_flagA;
+    __shared__ int s_tot[2][3];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, f = blockIdx.y;
 #define OSTAMP(k) do { if (dbg && tid == 0 && f == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
@@ -1301,51 +1302,88 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     __syncthreads();
     int n = s_n;
     bool finish = false;
+    int passNo = 0;   // parity of the one-wave passes' totals slot: a wave still reading the previous pass's totals is never overwritten
     while (!finish) {
         const int prevSize = n;
         // -- full pass (:588-640): every node with more than one point is divided
-        for (int i = tid; i < n; i += kOctBlock) {
-            const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
-            int k = 0, e = 0;
-            if (cnt > 1) {
-                const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[i] + 1));
-                int a1, a2, a3;
-                digit_bounds3(skeys, lo, cnt, shift, &a1, &a2, &a3);
-                S.b1[i] = a1; S.b2[i] = a2; S.b3[i] = a3;
-                const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
-                k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
-                e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
-            }
-            S.kArr[i] = k; S.eArr[i] = e; S.sArr[i] = (cnt == 1);
-        }
-        __syncthreads();
         int totK, totE, totS;
-        block_scan_array3(S.kArr, S.eArr, S.sArr, n, s_tmp64, &totK, &totE, &totS);
         const int nxt = cur ^ 1;
-        for (int i = tid; i < n; i += kOctBlock) {
-            const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i], lo = (cur ? S.nlo[1] : S.nlo[0])[i], dep = (cur ? S.ndep[1] : S.ndep[0])[i];
+        // children of node (lo, cnt, dep) with boundaries a1..a3 into the next list; exK / exE / exS = the exclusive sums over the nodes before it
+        auto emit = [&](int lo, int cnt, int dep, int a1, int a2, int a3, int exK, int exE, int exS, int sumK) {
             if (cnt == 1) {
-                const int p = totK + S.sArr[i];
+                const int p = sumK + exS;
                 (nxt ? S.nlo[1] : S.nlo[0])[p] = lo; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = 1; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep;
             } else {
-                const int bb[5] = {lo, S.b1[i], S.b2[i], S.b3[i], lo + cnt};
+                const int bb[5] = {lo, a1, a2, a3, lo + cnt};
                 int k = 0;
                 for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
-                int p = totK - (S.kArr[i] + k);  // children of later parents sit in front (push_front)
+                int p = sumK - (exK + k);  // children of later parents sit in front (push_front)
                 int epos[4];
                 for (int c = 3; c >= 0; c--) {   // list order n4,n3,n2,n1
                     const int cc2 = bb[c + 1] - bb[c];
                     epos[c] = p;
                     if (cc2 > 0) { (nxt ? S.nlo[1] : S.nlo[0])[p] = bb[c]; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = cc2; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep + 1; p++; }
                 }
-                int es = S.eArr[i];
+                int es = exE;
                 for (int c = 0; c < 4; c++) {    // creation order n1..n4
                     const int cc2 = bb[c + 1] - bb[c];
                     if (cc2 > 1) { S.Epos[es] = epos[c]; S.Ecnt[es] = cc2; es++; }
                 }
             }
+        };
+        if (n <= 64) {
+            // the first passes (2, 8, 32 nodes): one wave does the whole pass on its lanes -- bounds, the three prefix sums as one wave
+            // scan, the children -- and the block meets at ONE barrier instead of five
+            if (wave_id() == 0) {
+                const int i = lane_id();
+                const bool act = i < n;
+                int lo = 0, cnt = 0, dep = 0, a1 = 0, a2 = 0, a3 = 0, k = 0, e = 0;
+                if (act) {
+                    cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
+                    lo = (cur ? S.nlo[1] : S.nlo[0])[i];
+                    dep = (cur ? S.ndep[1] : S.ndep[0])[i];
+                    if (cnt > 1) {
+                        digit_bounds3(skeys, lo, cnt, 2 * (D - (dep + 1)), &a1, &a2, &a3);
+                        const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
+                        k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                        e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                    }
+                }
+                const unsigned long long mine = (unsigned long long) (unsigned) k | ((unsigned long long) (unsigned) e << 21) |
+                                                ((unsigned long long) (act && cnt == 1 ? 1u : 0u) << 42);
+                const unsigned long long incl = wave_incl_scan_u64(mine), ex = incl - mine;
+                const unsigned long long tot = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane((int) (incl >> 32), 63) << 32) |
+                                               (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
+                const int sumK = (int) (tot & 0x1FFFFFu);
+                if (act) emit(lo, cnt, dep, a1, a2, a3, (int) (ex & 0x1FFFFFu), (int) ((ex >> 21) & 0x1FFFFFu), (int) (ex >> 42), sumK);
+                if (i == 0) { s_tot[passNo & 1][0] = sumK; s_tot[passNo & 1][1] = (int) ((tot >> 21) & 0x1FFFFFu); s_tot[passNo & 1][2] = (int) (tot >> 42); }
+            }
+            __syncthreads();
+            totK = s_tot[passNo & 1][0]; totE = s_tot[passNo & 1][1]; totS = s_tot[passNo & 1][2];
+            passNo++;
+        } else {
+            for (int i = tid; i < n; i += kOctBlock) {
+                const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
+                int k = 0, e = 0;
+                if (cnt > 1) {
+                    const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[i] + 1));
+                    int a1, a2, a3;
+                    digit_bounds3(skeys, lo, cnt, shift, &a1, &a2, &a3);
+                    S.b1[i] = a1; S.b2[i] = a2; S.b3[i] = a3;
+                    const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
+                    k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                    e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                }
+                S.kArr[i] = k; S.eArr[i] = e; S.sArr[i] = (cnt == 1);
+            }
+            __syncthreads();
+            block_scan_array3(S.kArr, S.eArr, S.sArr, n, s_tmp64, &totK, &totE, &totS);
+            for (int i = tid; i < n; i += kOctBlock) {
+                const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i], lo = (cur ? S.nlo[1] : S.nlo[0])[i], dep = (cur ? S.ndep[1] : S.ndep[0])[i];
+                emit(lo, cnt, dep, cnt > 1 ? S.b1[i] : 0, cnt > 1 ? S.b2[i] : 0, cnt > 1 ? S.b3[i] : 0, S.kArr[i], S.eArr[i], S.sArr[i], totK);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         cur = nxt;
         n = totK + totS;
         int nE = totE;
