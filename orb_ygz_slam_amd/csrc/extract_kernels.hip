@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     __shared__ int s_tmp[20];
     __shared__ unsigned long long s_tmp64[17];
     __shared__ int s_n, s_nE, s_cut, s_flagA;
-    __shared__ int s_tot[2][3];
+    __shared__ int s_head[4];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, f = blockIdx.y;
 #define OSTAMP(k) do { if (dbg && tid == 0 && f == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
@@ -1284,84 +1284,111 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     // ---- 4. breadth-first subdivision on ranges ----
     const int D = g.depth;
     const int N = g.nFeat;
-    int cur = 0;
-    if (tid == 0) {
-        int n = 0;
-        int lo = 0;
-        for (int r = 0; r < g.nIni; r++) {  // roots in order; empty ones are erased (:566-575)
-            int a = lo, b = M;
-            while (a < b) {
-                const int m = (a + b) >> 1;
-                if ((int) (skeys[m] >> (2 * D)) <= r) a = m + 1; else b = m;
+    // children of node (lo, cnt, dep) with boundaries a1..a3 into list `nxt`; exK / exE / exS = the exclusive sums over the nodes before it
+    auto emit = [&](int nxt, int lo, int cnt, int dep, int a1, int a2, int a3, int exK, int exE, int exS, int sumK) {
+        if (cnt == 1) {
+            const int p = sumK + exS;
+            (nxt ? S.nlo[1] : S.nlo[0])[p] = lo; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = 1; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep;
+        } else {
+            const int bb[5] = {lo, a1, a2, a3, lo + cnt};
+            int k = 0;
+            for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
+            int p = sumK - (exK + k);  // children of later parents sit in front (push_front)
+            int epos[4];
+            for (int c = 3; c >= 0; c--) {   // list order n4,n3,n2,n1
+                const int cc2 = bb[c + 1] - bb[c];
+                epos[c] = p;
+                if (cc2 > 0) { (nxt ? S.nlo[1] : S.nlo[0])[p] = bb[c]; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = cc2; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep + 1; p++; }
             }
-            if (a > lo) { S.nlo[0][n] = lo; S.ncnt[0][n] = a - lo; S.ndep[0][n] = 0; n++; }
-            lo = a;
+            int es = exE;
+            for (int c = 0; c < 4; c++) {    // creation order n1..n4
+                const int cc2 = bb[c + 1] - bb[c];
+                if (cc2 > 1) { S.Epos[es] = epos[c]; S.Ecnt[es] = cc2; es++; }
+            }
         }
-        s_n = n;
+    };
+    // -- the head of the subdivision on ONE wave, the block waiting at one barrier: the roots (:566-575, a lane each) and every full pass
+    //    (:588-640) while the list has at most 64 nodes (2, 8, 32 for a 752x480 level) -- bounds, the three prefix sums as one wave scan, the
+    //    children, all on the wave's lanes, with nothing but the wave's own LDS order between the passes
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        int n = 0, cur = 0, nE = 0, state = 0;   // state: 0 = go on block-wide, 1 = finished, 2 = continue with the expand phase
+        if (g.nIni <= 64) {
+            int hi = M;                           // first index of a root > lane
+            if (lane < g.nIni) {
+                int a = 0, b = M;
+                while (a < b) {
+                    const int m = (a + b) >> 1;
+                    if ((int) (skeys[m] >> (2 * D)) <= lane) a = m + 1; else b = m;
+                }
+                hi = a;
+            }
+            int lo = __shfl_up(hi, 1);
+            if (lane == 0) lo = 0;
+            const bool some = lane < g.nIni && hi > lo;   // empty roots are erased
+            const unsigned long long bal = __ballot(some);
+            if (some) {
+                const int p = __popcll(bal & ((1ull << lane) - 1ull));
+                S.nlo[0][p] = lo; S.ncnt[0][p] = hi - lo; S.ndep[0][p] = 0;
+            }
+            n = __popcll(bal);
+        } else {
+            if (lane == 0) {
+                int lo = 0;
+                for (int r = 0; r < g.nIni; r++) {
+                    int a = lo, b = M;
+                    while (a < b) {
+                        const int m = (a + b) >> 1;
+                        if ((int) (skeys[m] >> (2 * D)) <= r) a = m + 1; else b = m;
+                    }
+                    if (a > lo) { S.nlo[0][n] = lo; S.ncnt[0][n] = a - lo; S.ndep[0][n] = 0; n++; }
+                    lo = a;
+                }
+            }
+            n = __builtin_amdgcn_readfirstlane(n);
+        }
+        wave_lds_sync();
+        while (n <= 64) {
+            const int prevSize = n, nxt = cur ^ 1;
+            const bool act = lane < n;
+            int lo = 0, cnt = 0, dep = 0, a1 = 0, a2 = 0, a3 = 0, k = 0, e = 0;
+            if (act) {
+                cnt = (cur ? S.ncnt[1] : S.ncnt[0])[lane];
+                lo = (cur ? S.nlo[1] : S.nlo[0])[lane];
+                dep = (cur ? S.ndep[1] : S.ndep[0])[lane];
+                if (cnt > 1) {
+                    digit_bounds3(skeys, lo, cnt, 2 * (D - (dep + 1)), &a1, &a2, &a3);
+                    const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
+                    k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                    e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                }
+            }
+            const unsigned long long mine = (unsigned long long) (unsigned) k | ((unsigned long long) (unsigned) e << 21) |
+                                            ((unsigned long long) (act && cnt == 1 ? 1u : 0u) << 42);
+            const unsigned long long incl = wave_incl_scan_u64(mine), ex = incl - mine;
+            const unsigned long long tot = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane((int) (incl >> 32), 63) << 32) |
+                                           (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
+            const int sumK = (int) (tot & 0x1FFFFFu);
+            if (act) emit(nxt, lo, cnt, dep, a1, a2, a3, (int) (ex & 0x1FFFFFu), (int) ((ex >> 21) & 0x1FFFFFu), (int) (ex >> 42), sumK);
+            wave_lds_sync();
+            cur = nxt;
+            n = sumK + (int) (tot >> 42);
+            nE = (int) ((tot >> 21) & 0x1FFFFFu);
+            if (n >= N || n == prevSize) { state = 1; break; }
+            if (n + 3 * nE > N) { state = 2; break; }
+        }
+        if (lane == 0) { s_head[0] = n; s_head[1] = cur; s_head[2] = nE; s_head[3] = state; }
     }
     __syncthreads();
-    int n = s_n;
-    bool finish = false;
-    int passNo = 0;   // parity of the one-wave passes' totals slot: a wave still reading the previous pass's totals is never overwritten
+    int n = s_head[0], cur = s_head[1];
+    int nE = s_head[2];
+    bool finish = s_head[3] == 1, toExpand = s_head[3] == 2;
     while (!finish) {
-        const int prevSize = n;
-        // -- full pass (:588-640): every node with more than one point is divided
-        int totK, totE, totS;
-        const int nxt = cur ^ 1;
-        // children of node (lo, cnt, dep) with boundaries a1..a3 into the next list; exK / exE / exS = the exclusive sums over the nodes before it
-        auto emit = [&](int lo, int cnt, int dep, int a1, int a2, int a3, int exK, int exE, int exS, int sumK) {
-            if (cnt == 1) {
-                const int p = sumK + exS;
-                (nxt ? S.nlo[1] : S.nlo[0])[p] = lo; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = 1; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep;
-            } else {
-                const int bb[5] = {lo, a1, a2, a3, lo + cnt};
-                int k = 0;
-                for (int c = 0; c < 4; c++) k += (bb[c + 1] - bb[c]) > 0;
-                int p = sumK - (exK + k);  // children of later parents sit in front (push_front)
-                int epos[4];
-                for (int c = 3; c >= 0; c--) {   // list order n4,n3,n2,n1
-                    const int cc2 = bb[c + 1] - bb[c];
-                    epos[c] = p;
-                    if (cc2 > 0) { (nxt ? S.nlo[1] : S.nlo[0])[p] = bb[c]; (nxt ? S.ncnt[1] : S.ncnt[0])[p] = cc2; (nxt ? S.ndep[1] : S.ndep[0])[p] = dep + 1; p++; }
-                }
-                int es = exE;
-                for (int c = 0; c < 4; c++) {    // creation order n1..n4
-                    const int cc2 = bb[c + 1] - bb[c];
-                    if (cc2 > 1) { S.Epos[es] = epos[c]; S.Ecnt[es] = cc2; es++; }
-                }
-            }
-        };
-        if (n <= 64) {
-            // the first passes (2, 8, 32 nodes): one wave does the whole pass on its lanes -- bounds, the three prefix sums as one wave
-            // scan, the children -- and the block meets at ONE barrier instead of five
-            if (wave_id() == 0) {
-                const int i = lane_id();
-                const bool act = i < n;
-                int lo = 0, cnt = 0, dep = 0, a1 = 0, a2 = 0, a3 = 0, k = 0, e = 0;
-                if (act) {
-                    cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
-                    lo = (cur ? S.nlo[1] : S.nlo[0])[i];
-                    dep = (cur ? S.ndep[1] : S.ndep[0])[i];
-                    if (cnt > 1) {
-                        digit_bounds3(skeys, lo, cnt, 2 * (D - (dep + 1)), &a1, &a2, &a3);
-                        const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
-                        k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
-                        e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
-                    }
-                }
-                const unsigned long long mine = (unsigned long long) (unsigned) k | ((unsigned long long) (unsigned) e << 21) |
-                                                ((unsigned long long) (act && cnt == 1 ? 1u : 0u) << 42);
-                const unsigned long long incl = wave_incl_scan_u64(mine), ex = incl - mine;
-                const unsigned long long tot = ((unsigned long long) (unsigned) __builtin_amdgcn_readlane((int) (incl >> 32), 63) << 32) |
-                                               (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
-                const int sumK = (int) (tot & 0x1FFFFFu);
-                if (act) emit(lo, cnt, dep, a1, a2, a3, (int) (ex & 0x1FFFFFu), (int) ((ex >> 21) & 0x1FFFFFu), (int) (ex >> 42), sumK);
-                if (i == 0) { s_tot[passNo & 1][0] = sumK; s_tot[passNo & 1][1] = (int) ((tot >> 21) & 0x1FFFFFu); s_tot[passNo & 1][2] = (int) (tot >> 42); }
-            }
-            __syncthreads();
-            totK = s_tot[passNo & 1][0]; totE = s_tot[passNo & 1][1]; totS = s_tot[passNo & 1][2];
-            passNo++;
-        } else {
+        if (!toExpand) {
+            const int prevSize = n;
+            // -- full pass (:588-640): every node with more than one point is divided
+            int totK, totE, totS;
+            const int nxt = cur ^ 1;
             for (int i = tid; i < n; i += kOctBlock) {
                 const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
                 int k = 0, e = 0;
@@ -1380,16 +1407,17 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
             block_scan_array3(S.kArr, S.eArr, S.sArr, n, s_tmp64, &totK, &totE, &totS);
             for (int i = tid; i < n; i += kOctBlock) {
                 const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i], lo = (cur ? S.nlo[1] : S.nlo[0])[i], dep = (cur ? S.ndep[1] : S.ndep[0])[i];
-                emit(lo, cnt, dep, cnt > 1 ? S.b1[i] : 0, cnt > 1 ? S.b2[i] : 0, cnt > 1 ? S.b3[i] : 0, S.kArr[i], S.eArr[i], S.sArr[i], totK);
+                emit(nxt, lo, cnt, dep, cnt > 1 ? S.b1[i] : 0, cnt > 1 ? S.b2[i] : 0, cnt > 1 ? S.b3[i] : 0, S.kArr[i], S.eArr[i], S.sArr[i], totK);
             }
             __syncthreads();
+            cur = nxt;
+            n = totK + totS;
+            nE = totE;
+            if (n >= N || n == prevSize) { finish = true; break; }
+            if (n + 3 * nE <= N) continue;
         }
-        cur = nxt;
-        n = totK + totS;
-        int nE = totE;
-        if (n >= N || n == prevSize) {
-            finish = true;
-        } else if (n + 3 * nE > N) {
+        toExpand = false;
+        {
             // -- "expand the biggest first" phase (:647-700)
             while (!finish) {
                 const int prev2 = n;

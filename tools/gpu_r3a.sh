@@ -1,9 +1,8 @@
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
-python bench.py --steps 20 --warmup 5 > gpurun_out/r03_e_bench_default.json 2> gpurun_out/r03_e_bench_default.err
-tail -c 300 gpurun_out/r03_e_bench_default.json
-bash tools/round_numbers.sh > gpurun_out/r03_e_round_numbers.txt 2>&1
-cat gpurun_out/r03_e_round_numbers.txt
-timeout 600 python -m pytest tests/test_gpu_shells.py -x -q -p no:cacheprovider -k latency -s 2>&1 | grep -E "^[a-z_]+ [0-9.]+ [0-9.]+|passed|failed" | tee gpurun_out/r03_e_shell_latency.txt
-bash tools/profile_round.sh r03_e > gpurun_out/profile_round.log 2>&1
-tail -3 gpurun_out/profile_round.log
+YGZF_FUZZ_SEEDS=60 timeout 900 python -m pytest tests/test_gpu_extract.py tests/test_gpu_fast_plans.py tests/test_gpu_fuzz.py -x -q -p no:cacheprovider 2>&1 | tail -2
+p() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
+lat() { for b in $2; do python bench.py --no-cpu-baseline --no-profile --no-extras --streams 1 --sub-batch $b --batch $b --steps 100 --warmup 10 2>&1 | p "$1 lat_b$b"; done; }
+lat new "1 1"
+YGZF_OCT_DEBUG=1 python bench.py --no-cpu-baseline --no-profile --no-extras --streams 1 --sub-batch 1 --batch 1 --steps 3 --warmup 1 2>&1 | grep "octree lvl" | tail -8
+python bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 2 --passes 1 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d.get('kernels_isolated_avg_us'))"
