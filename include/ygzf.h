@@ -70,6 +70,13 @@ const char *ygzf_last_error(const ygzf_ctx *ctx);
  * arrives (src/ORBextractor.cc:419-445) -- Frame's constructors read them first thing (src/Frame.cc:119-125).  Arrays of cfg->nlevels
  * entries, any may be NULL. */
 int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2, int *nfeat);
+/* How ComputePyramid (src/ORBextractor.cc:1130-1150) of ONE w x h frame is launched, without a context or a device (host arithmetic only; for
+ * inspection and for tests of the plan's invariants).  *n_strips = 0: one launch per level.  Otherwise the whole chain is one launch of n_strips
+ * workgroups (k_pyr_strips): workgroup s produces rows [ca, cb) of level l in LDS -- for level 0: stages them -- and
+ * writes the rows [wa, wb) of them it owns to the pyramid; rows[(s * nlevels + l) * 4 + {0,1,2,3}] = ca, cb, wa, wb (rows_cap entries available,
+ * at least n_strips * nlevels * 4 are needed; pass rows = NULL to ask for n_strips first: at most 64).  level_wh[2 l], level_wh[2 l + 1] = size
+ * of level l.  lds_bytes = LDS per workgroup.  lds_bytes, level_wh and rows may be NULL. */
+int ygzf_pyramid_plan_host(const ygzf_extractor_cfg *cfg, int w, int h, int *n_strips, int *lds_bytes, int *level_wh, unsigned short *rows, int rows_cap);
 
 /* ORBextractor::operator() on the image whose pyramid the context's previous call, ygzf_compute_pyramid, left on the device: FAST, octree,
  * orientation and descriptors without a second upload and a second pyramid (Frame's constructors call ComputePyramid and then the

@@ -83,6 +83,7 @@ def load_library(build_if_missing=True):
     L.ygzf_last_error.argtypes = [vp]
     L.ygzf_last_error.restype = C.c_char_p
     L.ygzf_scale_tables_host.argtypes = [C.POINTER(ExtractorCfg), vp, vp, vp, vp, vp]
+    L.ygzf_pyramid_plan_host.argtypes = [C.POINTER(ExtractorCfg), C.c_int, C.c_int, ip, ip, vp, vp, C.c_int]
     L.ygzf_get_levels.argtypes = [vp]
     L.ygzf_get_scale_tables.argtypes = [vp, vp, vp, vp, vp]
     L.ygzf_get_features_per_level.argtypes = [vp, vp]
@@ -168,6 +169,21 @@ def load_library(build_if_missing=True):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def pyramid_plan_host(nfeatures, scale_factor, nlevels, w, h):
+    """ygzf_pyramid_plan_host: how ComputePyramid of one w x h frame is launched (host arithmetic only, no device).  Returns a dict with
+    `strips` (0 = one launch per level), `lds_bytes`, `levels` = [(w, h)] and `rows`, an int array [strips, nlevels, 4] of (ca, cb, wa, wb)."""
+    L = load_library()
+    cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, 20, 7, 0)
+    n, lds = C.c_int(0), C.c_int(0)
+    wh = np.zeros(2 * nlevels, np.int32)
+    rows = np.zeros(64 * nlevels * 4, np.uint16)
+    rc = L.ygzf_pyramid_plan_host(C.byref(cfg), w, h, C.byref(n), C.byref(lds), _p(wh), _p(rows), rows.size)
+    if rc != 0:
+        raise YgzfError("ygzf_pyramid_plan_host failed (%d)" % rc)
+    return {"strips": n.value, "lds_bytes": lds.value, "levels": [(int(wh[2 * l]), int(wh[2 * l + 1])) for l in range(nlevels)],
+            "rows": rows[:n.value * nlevels * 4].astype(np.int64).reshape(n.value, nlevels, 4)}
 
 
 class Extractor:

@@ -979,6 +979,32 @@ int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *i
     return YGZF_OK;
 }
 
+int ygzf_pyramid_plan_host(const ygzf_extractor_cfg *cfg, int w, int h, int *n_strips, int *lds_bytes, int *level_wh, unsigned short *rows, int rows_cap) {
+    if (!cfg || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 0 || !(cfg->scale_factor > 1.0f) || w < 1 || h < 1 || !n_strips)
+        return YGZF_ERR_INVALID;
+    ygzf_ctx tmp;   // never touches a device: carries the tables and receives the error text
+    tmp.tab.init(*cfg);
+    Geometry G;
+    const int rc = build_geometry(&tmp, w, h, G);
+    if (rc) return rc;
+    const int L = cfg->nlevels, S = (int) G.pyrPlan.size();
+    *n_strips = S;
+    if (lds_bytes) *lds_bytes = (int) G.pyrStripLds;
+    if (level_wh)
+        for (int l = 0; l < L; l++) { level_wh[2 * l] = G.lv[l].w; level_wh[2 * l + 1] = G.lv[l].h; }
+    if (rows) {
+        if (rows_cap < S * L * 4) return YGZF_ERR_INVALID;
+        for (int s = 0; s < S; s++)
+            for (int l = 0; l < L; l++) {
+                const uint2 v = G.pyrPlan[s].lv[l];
+                unsigned short *o = rows + ((size_t) s * L + l) * 4;
+                o[0] = (unsigned short) (v.x & 0xFFFFu); o[1] = (unsigned short) (v.x >> 16);
+                o[2] = (unsigned short) (v.y & 0xFFFFu); o[3] = (unsigned short) (v.y >> 16);
+            }
+    }
+    return YGZF_OK;
+}
+
 int ygzf_get_levels(const ygzf_ctx *c) { return c ? c->tab.cfg.nlevels : YGZF_ERR_INVALID; }
 
 int ygzf_get_scale_tables(const ygzf_ctx *c, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2) {

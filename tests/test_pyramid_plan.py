@@ -1,0 +1,52 @@
+"""The launch plan of the one-launch pyramid chain (k_pyr_strips) is host arithmetic: checked here without a device.
+A workgroup owns a strip of the last level and recomputes, level by level in LDS, every row above that the strip depends on; nothing is ever
+read that another workgroup wrote.  That only holds if, for every strip and level, the rows it produces of level l - 1 contain the two source
+rows cv::resize takes for every row it produces of level l (fy = (float)((y + 0.5) * scale_y - 0.5), sy = floor(fy), rows
+sy and sy + 1 clamped to the level), and if the rows the strips OWN partition every level (each pyramid row is written exactly once)."""
+import math
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.capi import pyramid_plan_host
+
+CASES = [(752, 480, 8, 1.2), (640, 480, 8, 1.2), (1241, 376, 8, 1.2), (1920, 1080, 8, 1.2), (641, 479, 8, 1.2), (333, 517, 6, 1.25),
+         (752, 480, 12, 1.1), (752, 480, 4, 1.2), (320, 240, 8, 1.2), (200, 150, 3, 1.2), (130, 110, 8, 1.2), (4128, 2000, 6, 1.2)]
+
+
+def _yofs(sh, dh):
+    scale_y = 1.0 / (dh / sh)
+    return [int(math.floor(np.float32((dy + 0.5) * scale_y - 0.5))) for dy in range(dh)]
+
+
+@pytest.mark.parametrize("w,h,nl,sf", CASES)
+def test_strips_cover_what_they_read_and_partition_what_they_write(w, h, nl, sf):
+    plan = pyramid_plan_host(1000, sf, nl, w, h)
+    S, lv, rows = plan["strips"], plan["levels"], plan["rows"]
+    assert lv[0] == (w, h)
+    if S == 0:
+        pytest.skip("this geometry takes one launch per level")
+    assert S in (8, 16, 32, 48, 64) and 0 < plan["lds_bytes"] <= 160 * 1024
+    for l in range(1, nl):
+        hl, sh = lv[l][1], lv[l - 1][1]
+        yofs = _yofs(sh, hl)
+        written = np.zeros(hl, np.int32)
+        for s in range(S):
+            ca, cb, wa, wb = rows[s, l]
+            pa, pb = rows[s, l - 1][:2]
+            assert 0 <= ca <= wa <= wb <= cb <= hl and wa < wb, (s, l, ca, cb, wa, wb)
+            written[wa:wb] += 1
+            need = [min(max(yofs[y] + d, 0), sh - 1) for y in range(ca, cb) for d in (0, 1)]
+            assert pa <= min(need) and max(need) < pb, "strip %d: level %d rows [%d, %d) need level %d rows %d..%d, produced [%d, %d)" % (
+                s, l, ca, cb, l - 1, min(need), max(need), pa, pb)
+        assert (written == 1).all(), "level %d: rows written %s times" % (l, sorted(set(written.tolist())))
+    # the halo rows the strips recompute stay a modest multiple of the pyramid
+    total = sum(a * b for a, b in lv[1:])
+    produced = sum((rows[s, l, 1] - rows[s, l, 0]) * lv[l][0] for s in range(S) for l in range(1, nl))
+    assert produced <= 2.5 * total
+
+
+def test_large_images_keep_one_launch_per_level():
+    assert pyramid_plan_host(8000, 1.2, 12, 3840, 2160)["strips"] == 0          # the LDS regions do not fit
+    assert pyramid_plan_host(500, 2.0, 4, 640, 480)["strips"] == 0              # exact 2x levels take the area kernel
+    assert pyramid_plan_host(1000, 1.2, 2, 752, 480)["strips"] == 0             # one level to produce: nothing to chain
