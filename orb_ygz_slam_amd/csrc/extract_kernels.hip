@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include <cstring>
+#include <mutex>
 #include "kernels.h"
 #include "wave_ops.h"
 #include "orb_pattern_table.h"
@@ -2087,8 +2088,20 @@ void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
     hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(kPyrThreads), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
 }
 
+// The attribute belongs to the kernel on a device, not to a context: contexts of different geometries share it, so it only ever grows (a
+// context of small images prepared after one of large images must not take the large one's LDS allotment away).
 hipError_t pyr_strips_prepare(size_t ldsBytes) {
-    return hipFuncSetAttribute((const void *) k_pyr_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+    static std::mutex mu;
+    static size_t granted[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipFuncSetAttribute((const void *) k_pyr_strips, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    std::lock_guard<std::mutex> lock(mu);
+    if (ldsBytes <= granted[dev]) return hipSuccess;
+    e = hipFuncSetAttribute((const void *) k_pyr_strips, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsBytes);
+    if (e == hipSuccess) granted[dev] = ldsBytes;
+    return e;
 }
 
 void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips, int offCol,

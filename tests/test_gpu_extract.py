@@ -333,3 +333,22 @@ def test_pyramid_one_launch_and_level_by_level(oracle, monkeypatch, w, h, nl, sf
                         got = ex.batch_fetch_level(f, l)
                         assert got.shape == want[f][l].shape and (got == want[f][l]).all(), (strip_frames, strips, f, l)
             del ex
+
+
+def test_pyramid_contexts_of_different_sizes_on_one_device(oracle):
+    """The one-launch pyramid chain asks the runtime for a large LDS allotment per workgroup (123 KB for 1920x1080, 44 KB for 320x240); the
+    allotment belongs to the kernel on the device, not to a context: a context of small images prepared AFTER one of large images must not
+    take the large one's away (it once did: the large context's next launch was refused)."""
+    from orb_ygz_slam_amd import Extractor
+    sizes = [(1920, 1080), (320, 240)]
+    imgs = [synth_frame(70 + i, w, h) for i, (w, h) in enumerate(sizes)]
+    oex = oracle.Extractor(500, 1.2, 8, 20, 7)
+    want = [oex.pyramid(im) for im in imgs]
+    exs = []
+    for k in (0, 1, 0, 1):
+        if k >= len(exs):
+            exs.append(Extractor(500, 1.2, 8, 20, 7, max_width=sizes[k][0], max_height=sizes[k][1], max_batch=1))
+        exs[k].extract_batch_host(imgs[k][None])
+        for l in range(8):
+            got = exs[k].batch_fetch_level(0, l)
+            assert (got == want[k][l]).all(), (k, l)
