@@ -463,6 +463,8 @@ def main():
     ap.add_argument("--passes", type=int, default=0,
                     help="times the resident clip is walked per step (default 6 for the 752x480 / 640x480 workloads: the driver's 20 steps then time "
                          "about five seconds; 1 otherwise)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic frames of the resident clip (default streams x sub-batch; the clip "
+                                                            "tiles them) -- profiling runs of the 4K shape use 8 so that the host-side synthesis stays short")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -559,14 +561,15 @@ def main():
 
     # ---- CPU baselines FIRST (rank 0 of a 1-GPU run): the GPU's timed region then lies in the second half of the command, where an external
     # utilisation sampler sees it, instead of being followed by ~18 s of host-only work
-    frames0 = make_frames(S * sub, w, h, seed0=1000 + 97 * (rank * ndev))
+    frames0 = make_frames(min(S * sub, args.distinct) if args.distinct > 0 else S * sub, w, h, seed0=1000 + 97 * (rank * ndev))
     cpu_base = cpu_ref = anchor = None
     if rank == 0 and world * ndev == 1 and not args.no_cpu_baseline:
         cpu_base = cpu_baseline(frames0, cfg, args.cpu_seconds)
         cpu_ref = cpu_baseline_reference(frames0, cfg, min(6.0, args.cpu_seconds))
         anchor = libfast_anchor(frames0)
 
-    pipes = [Pipeline(d, args.workload, sub, rounds, S, 1000 + 97 * (rank * ndev + i), args.align, args.stereo, frames=frames0 if i == 0 else None, passes=passes)
+    pipes = [Pipeline(d, args.workload, sub, rounds, S, 1000 + 97 * (rank * ndev + i), args.align, args.stereo, frames=frames0 if i == 0 else None, passes=passes,
+                      distinct=args.distinct if args.distinct > 0 else None)
              for i, d in enumerate(devices)]
     if not args.no_profile:
         pipes[0].passes = 1

@@ -934,3 +934,29 @@ class RefVocabulary:
             self.L.yr_voc_free(self.h)
         except Exception:
             pass
+
+
+def ref_fast9_corners(img, barrier):
+    """The REFERENCE's own FAST-9 decision tree (Thirdparty/fast/include/fast/corner_9.h:1, is_corner_9<Less|Greater>) over the interior
+    [3, w-3) x [3, h-3): (xs, ys) of the corners in raster order.  None when oracle/_ref was never built."""
+    R = ref_fast()
+    if R is None or not hasattr(R, "ref_fast9_corners"):
+        return None
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    flags = np.zeros((h, w), np.uint8)
+    n = R.ref_fast9_corners(_p(img), w, h, w, int(barrier), _p(flags))
+    ys, xs = np.nonzero(flags)
+    assert len(xs) == n
+    return xs.astype(np.int32), ys.astype(np.int32)
+
+
+def ref_fast9_max_barrier(img, xs, ys):
+    """Largest barrier at which the reference's tree still calls (x, y) a corner (-1: not even at 0)."""
+    R = ref_fast()
+    img = np.ascontiguousarray(img, np.uint8)
+    xs = np.ascontiguousarray(xs, np.int32)
+    ys = np.ascontiguousarray(ys, np.int32)
+    out = np.zeros(len(xs), np.int32)
+    R.ref_fast9_max_barrier(_p(img), img.shape[1], _p(xs), _p(ys), len(xs), _p(out))
+    return out
