@@ -175,11 +175,12 @@ void launch_describe_list(hipStream_t st, const FrameSet &fs, const LevelGeom *d
                           float *outAngle, uint8_t *outDesc, int cvMode);
 
 // ---- Frame::ComputeStereoMatches (stereo_kernels.hip) ---------------------------------------------------------------------
-struct StereoRec {   // per right keypoint: x, row band (min | max << 16), octave
+struct StereoRec {   // per right keypoint: x, row band (min | max << 16), octave | index << 16 (octave 1000: empty band)
     float x;
     unsigned band;
     int octave;
 };
+constexpr int kStereoBinInts = 4096 + 1;   // bin table of one pair (k_stereo_prep): first sorted record of every bin of rows, then the count
 struct StereoArgs {
     // keys / descriptors of pair p: left at keys[p*keyStride + keyOffL + i], right at keys[p*keyStride + keyOffR + i] (desc alike, x32)
     const ygzf_kp *keys;
@@ -195,8 +196,11 @@ struct StereoArgs {
     float scale[kMaxLevels], invScale[kMaxLevels];
     float mb, mbf;
     int nRows;                     // rows of level 0
-    StereoRec *rec;                // scratch, pair p at rec + p*recStride
+    StereoRec *rec;                // scratch, pair p at rec + p*recStride: the right keypoints' records sorted by the bin of their band's first row
     long long recStride;
+    int *binStart;                 // scratch, pair p at binStart + p*kStereoBinInts
+    int nBins, binShift;           // bins of 2^binShift rows, nBins = ((nRows - 1) >> binShift) + 1 <= 4096
+    int bandMax;                   // >= last row - first row of every band: 2 * (2 * largest scale factor) + 2
     float *uRight, *depth;         // outputs, pair p at + p*outStride, one per left keypoint
     int *sad;                      // accepted SAD per left keypoint (-1: no match), same stride
     long long outStride;

@@ -1,6 +1,7 @@
 // stereo_kernels.hip -- ygz::Frame::ComputeStereoMatches on gfx950 (product code), reference src/Frame.cc:509-682.
 //
-//   k_stereo_prep    per right keypoint: the row band [floor(y - r), ceil(y + r)], r = 2 * scale[octave]   (:526-538)
+//   k_stereo_prep    per right keypoint: the row band [floor(y - r), ceil(y + r)], r = 2 * scale[octave]   (:526-538); the records sorted by
+//                    the band's first row (bins of 2^binShift rows) so that a left keypoint only meets the records near its row
 //   k_stereo_match   one wave per left keypoint: best Hamming match among the right keypoints whose band covers its row (:552-593),
 //                    11x11 SAD of the centre-subtracted patches over +-5 px on the keypoint's pyramid level (:596-640), parabola
 //                    sub-pixel fit, disparity gates, depth (:646-668)
@@ -16,20 +17,71 @@
 
 namespace ygzf {
 
-__global__ void k_stereo_prep(StereoArgs A) {
-    const int pair = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+// exclusive prefix sum of a[0..n) in LDS by the whole block (n <= a few thousand); tmp: 17 ints of LDS
+__device__ __forceinline__ void block_scan_small(int *a, int n, int *tmp) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const int per = (n + nt - 1) / nt;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += a[i];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) tmp[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int w = 0; w < nw; w++) { const int t = tmp[w]; tmp[w] = acc; acc += t; }
+    }
+    __syncthreads();
+    int run = tmp[wave] + incl - sum;
+    for (int i = lo; i < hi; i++) { const int t = a[i]; a[i] = run; run += t; }
+    __syncthreads();
+}
+
+// One workgroup per pair.  The reference keeps, per image row, the list of right keypoints whose band covers it (:526-538); here the right
+// keypoints are counting-sorted by the bin of their band's FIRST row (bins of 2^binShift rows): a left keypoint on row v then scans the bins of
+// rows [v - bandMax, v] only (bandMax >= the longest band), a few hundred records instead of every right keypoint of the frame.  The order inside
+// a bin is whatever the atomics make it: the matcher's (distance << 16 | index) minimum does not depend on the order of the scan.
+constexpr int kStereoPrepBlock = 1024;
+constexpr int kStereoMaxBins = 4096;
+__global__ __launch_bounds__(kStereoPrepBlock) void k_stereo_prep(StereoArgs A) {
+    __shared__ int s_bin[kStereoMaxBins + 1];
+    __shared__ int s_tmp[20];
+    const int pair = blockIdx.x, tid = threadIdx.x;
     const int nr = A.cnt[(long long) pair * A.cntStride + A.cntOffR];
-    if (i >= nr) return;
-    const ygzf_kp k = A.keys[(long long) pair * A.keyStride + A.keyOffR + i];
-    const float r = 2.0f * A.scale[k.octave];
-    int maxr = (int) ceilf(k.y + r), minr = (int) floorf(k.y - r);
-    minr = max(minr, 0);
-    maxr = min(maxr, A.nRows - 1);
-    StereoRec rec;
-    rec.x = k.x;
-    rec.band = (unsigned) (minr & 0xFFFF) | ((unsigned) (maxr & 0xFFFF) << 16);
-    rec.octave = maxr >= minr ? k.octave : 1000;   // an empty band never matches
-    A.rec[(long long) pair * A.recStride + i] = rec;
+    const int nb = A.nBins;
+    int *binStart = A.binStart + (long long) pair * (kStereoMaxBins + 1);
+    for (int b = tid; b <= nb; b += kStereoPrepBlock) s_bin[b] = 0;
+    __syncthreads();
+    auto make = [&](int i, StereoRec *rec) {
+        const ygzf_kp k = A.keys[(long long) pair * A.keyStride + A.keyOffR + i];
+        const float r = 2.0f * A.scale[k.octave];
+        int maxr = (int) ceilf(k.y + r), minr = (int) floorf(k.y - r);
+        minr = max(minr, 0);
+        maxr = min(maxr, A.nRows - 1);
+        rec->x = k.x;
+        rec->band = (unsigned) (minr & 0xFFFF) | ((unsigned) (maxr & 0xFFFF) << 16);
+        rec->octave = (maxr >= minr ? (k.octave & 0xFFFF) : 1000) | (i << 16);   // an empty band never matches; index of the keypoint above it
+        return min(min(minr, A.nRows - 1) >> A.binShift, nb - 1);
+    };
+    for (int i = tid; i < nr; i += kStereoPrepBlock) {
+        StereoRec rec;
+        atomicAdd(&s_bin[make(i, &rec)], 1);
+    }
+    __syncthreads();
+    block_scan_small(s_bin, nb + 1, s_tmp);            // exclusive: s_bin[b] = first sorted position of bin b, s_bin[nb] = nr
+    for (int b = tid; b <= nb; b += kStereoPrepBlock) binStart[b] = s_bin[b];
+    __syncthreads();
+    StereoRec *out = A.rec + (long long) pair * A.recStride;
+    for (int i = tid; i < nr; i += kStereoPrepBlock) {
+        StereoRec rec;
+        const int b = make(i, &rec);
+        out[atomicAdd(&s_bin[b], 1)] = rec;
+    }
 }
 
 __device__ __forceinline__ int s_wave_sum(int v) { return wave_sum(v); }
@@ -58,11 +110,15 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
         const unsigned long long q0 = dL[0], q1 = dL[1], q2 = dL[2], q3 = dL[3];
         const StereoRec *rec = A.rec + (long long) pair * A.recStride;
         const uint8_t *descR = A.desc + ((long long) pair * A.keyStride + A.keyOffR) * 32;
-        for (int iR = lane; iR < nr; iR += 64) {
-            const StereoRec rc = rec[iR];
+        const int *binStart = A.binStart + (long long) pair * (kStereoMaxBins + 1);
+        const int b0 = max(row - A.bandMax, 0) >> A.binShift, b1 = min(row >> A.binShift, A.nBins - 1);
+        const int lo = binStart[b0], hi = binStart[b1 + 1];
+        for (int j = lo + lane; j < hi; j += 64) {
+            const StereoRec rc = rec[j];
             const int minr = (int) (rc.band & 0xFFFFu), maxr = (int) (rc.band >> 16);
+            const int oct = rc.octave & 0xFFFF, iR = (int) ((unsigned) rc.octave >> 16);
             if (row < minr || row > maxr) continue;
-            if (rc.octave < levelL - 1 || rc.octave > levelL + 1) continue;
+            if (oct < levelL - 1 || oct > levelL + 1) continue;
             if (!(rc.x >= minU && rc.x <= maxU)) continue;
             const unsigned long long *d = (const unsigned long long *) (descR + (long long) iR * 32);
             const unsigned dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
@@ -74,7 +130,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
     const int bestDist = (int) (best >> 16);
     if (alive && bestDist < thOrbDist) {
         const int bestIdxR = (int) (best & 0xFFFFu);
-        const float uR0 = A.rec[(long long) pair * A.recStride + bestIdxR].x;
+        const float uR0 = A.keys[(long long) pair * A.keyStride + A.keyOffR + bestIdxR].x;
         const float scaleFactor = A.invScale[levelL];
         const float scaleduL = roundf(kL.x * scaleFactor);
         const float scaledvL = roundf(kL.y * scaleFactor);
@@ -193,7 +249,7 @@ __global__ __launch_bounds__(1024) void k_stereo_cut(StereoArgs A) {
 
 void launch_stereo(hipStream_t st, const StereoArgs &A, int nPairs, int maxLeft, int maxRight) {
     if (nPairs <= 0 || maxLeft <= 0) return;
-    if (maxRight > 0) hipLaunchKernelGGL(k_stereo_prep, dim3((maxRight + 255) / 256, nPairs), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_stereo_prep, dim3(nPairs), dim3(kStereoPrepBlock), 0, st, A);
     hipLaunchKernelGGL(k_stereo_match, dim3((maxLeft + 3) / 4, nPairs), dim3(256), 0, st, A);
     hipLaunchKernelGGL(k_stereo_cut, dim3(nPairs), dim3(1024), 0, st, A);
 }

@@ -105,7 +105,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan;
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dStBins, dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan;
     int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
@@ -659,7 +659,10 @@ static int mark_pyramid_done(ygzf_ctx *c) {
     return YGZF_OK;
 }
 
-static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady = false) {
+// pyramidReady: dPyr already holds the pyramid of the frame to extract (ygzf_compute_pyramid / ygzf_extract_resident) -- the previous
+// extraction's pyramid is gone from it, so the pyramid carry of ygzf_align_batch_prev is valid only when the caller copied it out BEFORE
+// overwriting dPyr (pyramidCarried; ygzf_compute_pyramid in extract-ahead mode does).
+static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady = false, bool pyramidCarried = false) {
     const Geometry &G = c->geo;
     c->pyrResident = false;
     c->aheadPending = false;
@@ -676,8 +679,8 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
     if (c->alignCarry && G.pyrBytes > 0) {   // the previous batch's last pyramid is the reference of pair 0 in ygzf_align_batch_prev
         int rc2 = ensure(c, c->dCarryPyr, (size_t) G.pyrBytes + 256);
         if (rc2) return rc2;
-        c->carryPyrValid = c->carryValid && c->lastFrames > 0;
-        if (c->carryPyrValid)
+        c->carryPyrValid = c->carryValid && c->lastFrames > 0 && (!pyramidReady || pyramidCarried);
+        if (c->carryPyrValid && !pyramidReady)
             HIPCHECK(c, hipMemcpyAsync(c->dCarryPyr.p, (uint8_t *) c->dPyr.p + (size_t) (c->lastFrames - 1) * G.pyrBytes, (size_t) G.pyrBytes,
                                        hipMemcpyDeviceToDevice, c->stream));
     }
@@ -894,6 +897,7 @@ void ygzf_destroy(ygzf_ctx *c) {
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dSt)
         if (b.p) (void) hipFree(b.p);
+    if (c->dStBins.p) (void) hipFree(c->dStBins.p);
     for (auto &b : c->dDir)
         if (b.p) (void) hipFree(b.p);
     for (auto &b : c->dFr)
@@ -1050,6 +1054,15 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     int rc = apply_geometry(c, w, h, 1);
     if (rc) return rc;
     FrameSet fs;
+    // extract-ahead counts as an extraction for ygzf_align_batch_prev: the previous extraction's last pyramid (the reference image of pair 0)
+    // leaves dPyr before this frame's pyramid is written over it
+    bool pyramidCarried = false;
+    if (c->extractAhead && c->streamCopy && c->alignCarry && c->geo.pyrBytes > 0 && c->carryValid && c->lastFrames > 0) {
+        if ((rc = ensure(c, c->dCarryPyr, (size_t) c->geo.pyrBytes + 256))) return rc;
+        HIPCHECK(c, hipMemcpyAsync(c->dCarryPyr.p, (uint8_t *) c->dPyr.p + (size_t) (c->lastFrames - 1) * c->geo.pyrBytes, (size_t) c->geo.pyrBytes,
+                                   hipMemcpyDeviceToDevice, c->stream));
+        pyramidCarried = true;
+    }
     if ((rc = upload_frames(c, img, 1, w, h, stride, 0, &fs))) return rc;
     const Geometry &G = c->geo;
     const int L = c->tab.cfg.nlevels;
@@ -1082,7 +1095,7 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
         ahead = true;
     }
     if (total) HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, rd));
-    if (ahead && (rc = run_extract(c, fs, 1, true))) return rc;   // (queued after the copy so that the copy starts while these launches are issued)
+    if (ahead && (rc = run_extract(c, fs, 1, true, pyramidCarried))) return rc;   // (queued after the copy so that the copy starts while these launches are issued)
     if (levels_out[0] != img || stride != w)
         for (int y = 0; y < h; y++) memcpy(levels_out[0] + (size_t) y * w, img + (size_t) y * stride, (size_t) w);
     HIPCHECK(c, hipStreamSynchronize(rd));
@@ -2698,6 +2711,12 @@ static void fill_stereo_common(ygzf_ctx *c, StereoArgs &A, float mb, float mbf, 
     A.mbf = mbf;
     A.nRows = h;
     A.geom = (const LevelGeom *) c->dGeom.p;
+    float smax = 1.f;
+    for (int l = 0; l < L; l++) smax = std::max(smax, c->tab.scale[l]);
+    A.bandMax = (int) std::ceil(4.0 * (double) smax) + 2;      // ceil(y + r) - floor(y - r) <= 2 r + 2, r = 2 * scale
+    A.binShift = 3;
+    while ((((std::max(h, 1) - 1) >> A.binShift) + 1) > kStereoBinInts - 1) A.binShift++;
+    A.nBins = ((std::max(h, 1) - 1) >> A.binShift) + 1;
 }
 
 int ygzf_stereo_batch(ygzf_ctx *c, float mb, float mbf) {
@@ -2711,7 +2730,8 @@ int ygzf_stereo_batch(ygzf_ctx *c, float mb, float mbf) {
     int rc;
     const size_t per = (size_t) G.kpStride;
     if ((rc = ensure(c, c->dSt[0], sizeof(StereoRec) * per * P + 64)) || (rc = ensure(c, c->dSt[1], 4 * per * P + 64)) ||
-        (rc = ensure(c, c->dSt[2], 4 * per * P + 64)) || (rc = ensure(c, c->dSt[3], 4 * per * P + 64)))
+        (rc = ensure(c, c->dSt[2], 4 * per * P + 64)) || (rc = ensure(c, c->dSt[3], 4 * per * P + 64)) ||
+        (rc = ensure(c, c->dStBins, sizeof(int) * kStereoBinInts * (size_t) P)))
         return rc;
     StereoArgs A;
     memset(&A, 0, sizeof A);
@@ -2730,6 +2750,7 @@ int ygzf_stereo_batch(ygzf_ctx *c, float mb, float mbf) {
     fill_stereo_common(c, A, mb, mbf, G.h);
     A.rec = (StereoRec *) c->dSt[0].p;
     A.recStride = (long long) per;
+    A.binStart = (int *) c->dStBins.p;
     A.uRight = (float *) c->dSt[1].p;
     A.depth = (float *) c->dSt[2].p;
     A.sad = (int *) c->dSt[3].p;
@@ -2793,7 +2814,8 @@ int ygzf_compute_stereo_matches(ygzf_ctx *c, const uint8_t *img_left, const uint
     int counts[2] = {n_left, n_right};
     if ((rc = ensure(c, c->dSt[0], sizeof(StereoRec) * (size_t) (n_right + 1))) || (rc = ensure(c, c->dSt[1], 4 * (size_t) n_left)) ||
         (rc = ensure(c, c->dSt[2], 4 * (size_t) n_left)) || (rc = ensure(c, c->dSt[3], 4 * (size_t) n_left)) ||
-        (rc = ensure(c, c->dSt[4], sizeof(ygzf_kp) * nk + 64)) || (rc = ensure(c, c->dSt[5], 32 * nk + 64)))
+        (rc = ensure(c, c->dSt[4], sizeof(ygzf_kp) * nk + 64)) || (rc = ensure(c, c->dSt[5], 32 * nk + 64)) ||
+        (rc = ensure(c, c->dStBins, sizeof(int) * kStereoBinInts)))
         return rc;
     uint8_t *dk = (uint8_t *) c->dSt[4].p, *dd = (uint8_t *) c->dSt[5].p;
     HIPCHECK(c, hipMemcpyAsync(dk, keys_left, sizeof(ygzf_kp) * (size_t) n_left, hipMemcpyHostToDevice, c->stream));
@@ -2821,6 +2843,7 @@ int ygzf_compute_stereo_matches(ygzf_ctx *c, const uint8_t *img_left, const uint
     fill_stereo_common(c, A, mb, mbf, h);
     A.rec = (StereoRec *) c->dSt[0].p;
     A.recStride = n_right + 1;
+    A.binStart = (int *) c->dStBins.p;
     A.uRight = (float *) c->dSt[1].p;
     A.depth = (float *) c->dSt[2].p;
     A.sad = (int *) c->dSt[3].p;

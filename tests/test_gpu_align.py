@@ -93,6 +93,40 @@ def test_align_batch_prev_matches_host_api(oracle):
     assert res[1][0] > 100 and np.abs(res[1][1][4:]).max() > 1e-3   # A -> B really moved
 
 
+def test_align_batch_prev_after_extract_ahead(oracle):
+    """ygzf_set_extract_ahead: ygzf_compute_pyramid queues the extraction behind the pyramid, and "counts as an extraction for
+    ygzf_align_batch_prev" (ygzf.h) -- the previous frame's pyramid has to leave the context's pyramid buffer BEFORE the new frame's pyramid is
+    written over it (round 3 copied it afterwards: pair 0 aligned the new frame against itself).  Frame by frame, as Tracking would call it."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    imgA, imgB, _, _ = two_view_scene(11, w, h, EUROC, Z=1.0, rotvec=(0.002, -0.003, 0.001), trans=(0.004, -0.003, 0.002))
+    imgC, _, _, _ = two_view_scene(11, w, h, EUROC, Z=1.0, rotvec=(-0.001, 0.002, 0.002), trans=(-0.003, 0.002, 0.001))
+    ex = Extractor(600, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    cam = make_camera(w, h)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    inv = ex.tables()["inv_scale"]
+    ex.set_extract_ahead(True)
+    prev = None
+    moved = 0
+    for step, img in enumerate((imgA, imgB, imgC, imgA)):
+        pyr = ex.compute_pyramid(img)
+        k, d = ex.extract_resident(w, h)
+        ex.align_batch_prev(cam, 7, 1, 10)
+        ret, T = ex.align_fetch(0)[:2]
+        if step == 0:
+            assert ret == 0                     # no predecessor (and the carry is only switched on by this first call)
+        else:                                   # (the carry was switched on by the call of step 0: frame A's pyramid is kept when B's is computed)
+            pk, ppyr = prev
+            world = np.stack([(pk["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]),
+                              (pk["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]), np.ones(len(pk), np.float32)], -1)
+            want_ret, want_T, _, _ = ex2_run(ex, cam, pk, world, ident, ppyr, pyr, inv)
+            assert ret == want_ret and ret > 100, (step, ret, want_ret)
+            assert np.abs(T - want_T).max() <= 1e-6, (step, T, want_T)
+            moved += np.abs(T[4:]).max() > 1e-3
+        prev = (k, [np.ascontiguousarray(p) for p in pyr])
+    assert moved == 3                           # a frame aligned against itself would give the identity
+
+
 def test_align_large_batch_equals_small_batches():
     """Launches of 128 pairs and more keep their workgroups to 74 KB of LDS (two per CU: the coarse levels are then gathered from L2 instead
     of a staged copy): the same bytes read, so the same poses bit for bit as launches of a few pairs."""
