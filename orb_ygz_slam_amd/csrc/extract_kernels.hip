@@ -113,36 +113,53 @@ __device__ void block_radix_sort(unsigned *k0, unsigned *v0, unsigned *k1, unsig
     for (int shift = 0; shift < bits; shift += kRadixBits) {
         for (int t = threadIdx.x; t < NB * 16; t += blockDim.x) histT[t] = 0;
         __syncthreads();
-        for (int i = start + lane; i < end; i += 64) {
-            const int d = (k0[i] >> shift) & (NB - 1);
-            atomicAdd((int *) &histT[d * 16 + wave], 1);
+        // (four 64-key pieces of the wave's segment per step: their loads are in flight together -- a level of 60 000 candidates sorted through
+        // global memory spent 1.4 ms in these two loops at one dependent round trip per piece)
+        constexpr int kRU = 4;
+        for (int base = start; base < end; base += 64 * kRU) {
+            int d[kRU];
+#pragma unroll
+            for (int u = 0; u < kRU; u++) {
+                const int i = base + u * 64 + lane;
+                d[u] = i < end ? (int) ((k0[i] >> shift) & (NB - 1)) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < kRU; u++)
+                if (d[u] >= 0) atomicAdd((int *) &histT[d[u] * 16 + wave], 1);
         }
         __syncthreads();
         block_scan_array((int *) histT, NB * 16, tmp);   // exclusive, digit-major then wave: the scatter base of every (digit, wave)
-        for (int base = start; base < end; base += 64) {
-            const int i = base + lane;
-            const bool valid = i < end;
-            const unsigned key = valid ? k0[i] : 0u;
-            const unsigned val = valid ? v0[i] : 0u;
-            const int d = (key >> shift) & (NB - 1);
-            unsigned long long m = __ballot(valid);
+        for (int base = start; base < end; base += 64 * kRU) {
+            unsigned key[kRU], val[kRU];
 #pragma unroll
-            for (int b = 0; b < kRadixBits; b++) {
-                const bool bit = (d >> b) & 1;
-                const unsigned long long bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
+            for (int u = 0; u < kRU; u++) {
+                const int i = base + u * 64 + lane;
+                key[u] = i < end ? k0[i] : 0u;
+                val[u] = i < end ? v0[i] : 0u;
             }
-            const int rank = __popcll(m & lt);
-            const int cnt = __popcll(m);
-            int pos = 0;
-            if (valid) pos = histT[d * 16 + wave] + rank;
-            __builtin_amdgcn_wave_barrier();
-            if (valid) {
-                k1[pos] = key;
-                v1[pos] = val;
-                if (rank == cnt - 1) histT[d * 16 + wave] = pos + 1;
+#pragma unroll
+            for (int u = 0; u < kRU; u++) {
+                const bool valid = base + u * 64 + lane < end;
+                const int d = (key[u] >> shift) & (NB - 1);
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < kRadixBits; b++) {
+                    const bool bit = (d >> b) & 1;
+                    const unsigned long long bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                const int rank = __popcll(m & lt);
+                const int cnt = __popcll(m);
+                int pos = 0;
+                if (valid) pos = histT[d * 16 + wave] + rank;
+                __builtin_amdgcn_wave_barrier();
+                if (valid) {
+                    k1[pos] = key[u];
+                    v1[pos] = val[u];
+                    if (rank == cnt - 1) histT[d * 16 + wave] = pos + 1;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         unsigned *t = k0; k0 = k1; k1 = t;
@@ -1116,8 +1133,19 @@ struct OctShared {  // carved out of dynamic LDS
 // kGlobalNodes: the 19 per-list-position arrays live in a global arena (nodeArena, 19 * cap ints per (frame, level)) instead of LDS --
 // configurations whose per-level feature budget is too large for the LDS plan (e.g. one level with > 2000 features).
 constexpr unsigned kNoKeypoint = 0xFFFFFFFFu;   // procRec.y of a processing position without a keypoint
-template <bool kGlobalNodes>
-__global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_octree(const LevelGeom *__restrict__ geom, int nlevels,
+//
+// kHist (the plan of configurations whose levels hold tens of thousands of candidates -- 1920x1080 / 4000, 3840x2160 / 8000): NO SORT.  What the
+// tree passes ask of the sorted key array is (a) the child boundaries of a node = counts of candidates per key prefix and (b) the best
+// response per final node.  Both come from a histogram over the key prefixes of depth dm (nIni << 2 dm <= histBins bins, LDS atomics while the
+// keys are computed) and its exclusive prefix sum PS: the node (lo, cnt, dep) starts at the aligned bin f0 with PS[f0] == lo, its child
+// boundaries are PS[f0 + c * 4^(dm - dep - 1)] -- the very values digit_bounds3 finds in the sorted array, so the tree passes run unchanged; the
+// best response per node is one more pass over the candidates (bin -> final node table, LDS atomic max).  A level of 60 000 candidates spent
+// 1.4-1.7 ms in four scattered radix passes through global memory (4.6 GB written per 64-frame launch against 0.9 GB of keys) and 0.2-0.5 ms
+// in tree passes whose every boundary search was 11 dependent global reads; here the candidates are read twice, linearly, and the tree passes
+// stay in LDS.  A tree that wants to split a node BELOW depth dm (a few very crowded spots in an otherwise empty level) raises s_overflow and
+// the workgroup starts over on the sorting path -- same result, the old speed.
+template <bool kGlobalNodes, bool kHist>
+__global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist ? 4 : 8, 8))) void k_octree(const LevelGeom *__restrict__ geom, int nlevels, int levelBase,
                                                       const unsigned short *__restrict__ cellCnt,
                                                       const unsigned *__restrict__ slots, int totalCells,
                                                       long long totalSlots, unsigned *__restrict__ candKey0,
@@ -1126,15 +1154,17 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                                                       long long candStride, unsigned *__restrict__ lvlKpXY,
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
                                                       int *__restrict__ lvlCandCnt, uint2 *__restrict__ procRec,
-                                                      int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena) {
+                                                      int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena,
+                                                      int regionInts, int histBins) {
+    static_assert(!(kGlobalNodes && kHist), "the histogram plan keeps the node arrays in LDS");
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[kRadixHist];
     __shared__ int s_tmp[20];
     __shared__ unsigned long long s_tmp64[17];
-    __shared__ int s_n, s_nE, s_cut, s_flagA;
+    __shared__ int s_n, s_nE, s_cut, s_flagA, s_overflow;
     __shared__ int s_head[4];
     const int tid = threadIdx.x;
-    const int l = blockIdx.x, f = blockIdx.y;
+    const int l = blockIdx.x + levelBase, f = blockIdx.y;
 #define OSTAMP(k) do { if (dbg && tid == 0 && f == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
     OSTAMP(0);
     const LevelGeom g = geom[l];
@@ -1146,11 +1176,14 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         return;
     }
     OctShared S;
+    int *PS = nullptr;        // kHist: histBins + 1 ints behind the region the cell table, the key tables and (later) the node arrays share
     {
         int *p = dyn;
-        S.cellPref = p; p += nCells + 1;
+        S.cellPref = p;
+        if (kHist) PS = dyn + regionInts;        // (the node arrays start at dyn as well: the cell prefix table is dead once the keys exist)
+        else p += nCells + 1;
         int *candLds = p;
-        if (kGlobalNodes) p = nodeArena + ((long long) blockIdx.y * nlevels + blockIdx.x) * (19LL * cap);
+        if (kGlobalNodes) p = nodeArena + ((long long) blockIdx.y * nlevels + l) * (19LL * cap);
         for (int b = 0; b < 2; b++) { S.nlo[b] = p; p += cap; S.ncnt[b] = p; p += cap; S.ndep[b] = p; p += cap; }
         S.kArr = p; p += cap; S.eArr = p; p += cap; S.sArr = p; p += cap;
         S.b1 = p; p += cap; S.b2 = p; p += cap; S.b3 = p; p += cap;
@@ -1167,6 +1200,17 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     unsigned *val1 = candVal1 + (long long) f * candStride + g.candBase;
     unsigned *xy = candXY + (long long) f * candStride + g.candBase;
 
+    // kHist: depth dm of the histogram's key prefixes -- as deep as the bin budget allows (a level whose tree is fully resolved at dm cannot overflow)
+    int dm = 0;
+    if (kHist) {
+        dm = g.depth;
+        while (dm > 0 && ((long long) g.nIni << (2 * dm)) > (long long) histBins) dm--;
+    }
+    bool useHist = kHist && dm >= 1;
+    const int nBins = g.nIni << (2 * dm);
+    const int binShift = 2 * (g.depth - dm);
+restart:   // (kHist: a second time, on the sorting path, after the tree asked for a split below depth dm)
+    if (kHist && tid == 0) s_overflow = 0;
     // ---- 1. candidate offsets per cell (cell-major order == the reference's vToDistributeKeys order) ----
     for (int i = tid; i < nCells; i += kOctBlock) S.cellPref[i] = cc[i];
     __syncthreads();
@@ -1187,8 +1231,9 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     // (root, x bits spread to the even positions) and a per-row word (y bits on the odd positions): both tables and the cells' origins
     // are built once per workgroup in the node arrays (idle until the tree passes) when they fit there.
     const int lenX = max(g.regW, g.nCols * g.wCell) + 9, lenY = max(g.regH, g.nRows * g.hCell) + 9;
-    const bool useTab = lenX + lenY + nCells <= 19 * cap && g.depth <= 15;
-    unsigned *xTab = (unsigned *) S.nlo[0], *yTab = xTab + lenX, *orgTab = yTab + lenY;
+    const bool useTab = (kHist ? lenX + lenY + nCells <= regionInts - (nCells + 1) : lenX + lenY + nCells <= 19 * cap) && g.depth <= 15;
+    unsigned *xTab = (unsigned *) (kHist ? dyn + nCells + 1 : S.nlo[0]), *yTab = xTab + lenX, *orgTab = yTab + lenY;
+
     if (useTab) {
         auto spread = [](unsigned v) {
             v = (v | (v << 8)) & 0x00FF00FFu;
@@ -1227,6 +1272,10 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 orgTab[c] = (unsigned) (cj * g.wCell) | ((unsigned) (ci * g.hCell) << 16);
             }
         }
+        __syncthreads();
+    }
+    if (kHist && useHist) {
+        for (int b = tid; b <= nBins; b += kOctBlock) PS[b] = 0;
         __syncthreads();
     }
     {
@@ -1269,8 +1318,15 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 const int i = i0 + u * kOctBlock;
                 if (i < M) {
                     const int x = (int) (e[u] & 255u) + ox[u], y = (int) ((e[u] >> 8) & 255u) + oy[u];
-                    key0[i] = useTab ? (xTab[x] | yTab[y]) : path_key(x, y, g);
-                    val0[i] = ((e[u] >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
+                    const unsigned key = useTab ? (xTab[x] | yTab[y]) : path_key(x, y, g);
+                    if (kHist && useHist) {
+                        const unsigned bin = key >> binShift;
+                        atomicAdd(&PS[bin], 1);
+                        key0[i] = bin | ((e[u] >> 16) << 16);      // bin < 65536; the score rides along for the selection pass
+                    } else {
+                        key0[i] = key;
+                        val0[i] = ((e[u] >> 16) << 24) | (0xFFFFFFu - (unsigned) i);  // max() picks best score, then smallest index
+                    }
                     xy[i] = (unsigned) x | ((unsigned) y << 16);
                 }
             }
@@ -1279,9 +1335,33 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
     __syncthreads();
     OSTAMP(2);
     // ---- 3. sort by path key ----
-    unsigned *skeys, *svals;
-    block_radix_sort(key0, val0, key1, val1, M, g.keyBits, histT, s_tmp, &skeys, &svals);
+    unsigned *skeys = key0, *svals = val0;
+    if (kHist && useHist) {
+        block_scan_array(PS, nBins, s_tmp);        // exclusive: PS[b] = candidates in front of bin b in path-key order
+        if (tid == 0) PS[nBins] = M;
+        __syncthreads();
+    } else
+        block_radix_sort(key0, val0, key1, val1, M, g.keyBits, histT, s_tmp, &skeys, &svals);
     OSTAMP(3);
+    // child boundaries of the node (lo, cnt, dep): a_c = first position in [lo, lo + cnt] whose child digit is >= c
+    auto bounds = [&](int lo, int cnt, int dep, int *a1, int *a2, int *a3) {
+        if (kHist && useHist) {
+            if (dep + 1 > dm) {                    // finer than the histogram: start over on the sorting path (the dummy answer keeps every loop finite)
+                s_overflow = 1;
+                *a1 = *a2 = *a3 = lo + cnt;
+                return;
+            }
+            const int sh = 2 * (dm - dep);         // a node of depth dep spans 2^sh bins, aligned
+            int a = 0, b = nBins >> sh;            // its index among the nodes of its depth: the largest j with PS[j << sh] <= lo (the node is not empty)
+            while (b - a > 1) {
+                const int m = (a + b) >> 1;
+                if (PS[m << sh] <= lo) a = m; else b = m;
+            }
+            const int f0 = a << sh, s1 = 1 << (sh - 2);
+            *a1 = PS[f0 + s1]; *a2 = PS[f0 + 2 * s1]; *a3 = PS[f0 + 3 * s1];
+        } else
+            digit_bounds3(skeys, lo, cnt, 2 * (g.depth - (dep + 1)), a1, a2, a3);
+    };
     // ---- 4. breadth-first subdivision on ranges ----
     const int D = g.depth;
     const int N = g.nFeat;
@@ -1317,12 +1397,15 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
         if (g.nIni <= 64) {
             int hi = M;                           // first index of a root > lane
             if (lane < g.nIni) {
-                int a = 0, b = M;
-                while (a < b) {
-                    const int m = (a + b) >> 1;
-                    if ((int) (skeys[m] >> (2 * D)) <= lane) a = m + 1; else b = m;
+                if (kHist && useHist) hi = PS[(lane + 1) << (2 * dm)];
+                else {
+                    int a = 0, b = M;
+                    while (a < b) {
+                        const int m = (a + b) >> 1;
+                        if ((int) (skeys[m] >> (2 * D)) <= lane) a = m + 1; else b = m;
+                    }
+                    hi = a;
                 }
-                hi = a;
             }
             int lo = __shfl_up(hi, 1);
             if (lane == 0) lo = 0;
@@ -1338,6 +1421,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 int lo = 0;
                 for (int r = 0; r < g.nIni; r++) {
                     int a = lo, b = M;
+                    if (kHist && useHist) a = b = PS[(r + 1) << (2 * dm)];
                     while (a < b) {
                         const int m = (a + b) >> 1;
                         if ((int) (skeys[m] >> (2 * D)) <= r) a = m + 1; else b = m;
@@ -1358,7 +1442,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 lo = (cur ? S.nlo[1] : S.nlo[0])[lane];
                 dep = (cur ? S.ndep[1] : S.ndep[0])[lane];
                 if (cnt > 1) {
-                    digit_bounds3(skeys, lo, cnt, 2 * (D - (dep + 1)), &a1, &a2, &a3);
+                    bounds(lo, cnt, dep, &a1, &a2, &a3);
                     const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
                     e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
@@ -1394,9 +1478,9 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[i];
                 int k = 0, e = 0;
                 if (cnt > 1) {
-                    const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[i] + 1));
+                    const int lo = (cur ? S.nlo[1] : S.nlo[0])[i];
                     int a1, a2, a3;
-                    digit_bounds3(skeys, lo, cnt, shift, &a1, &a2, &a3);
+                    bounds(lo, cnt, (cur ? S.ndep[1] : S.ndep[0])[i], &a1, &a2, &a3);
                     S.b1[i] = a1; S.b2[i] = a2; S.b3[i] = a3;
                     const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
                     k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
@@ -1455,9 +1539,9 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
                 for (int j = tid; j < nE; j += kOctBlock) {
                     const int e = (int) ev[nE - 1 - j];
                     const int pos = S.Epos[e];
-                    const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos], shift = 2 * (D - ((cur ? S.ndep[1] : S.ndep[0])[pos] + 1));
+                    const int cnt = (cur ? S.ncnt[1] : S.ncnt[0])[pos], lo = (cur ? S.nlo[1] : S.nlo[0])[pos];
                     int a1, a2, a3;
-                    digit_bounds3(skeys, lo, cnt, shift, &a1, &a2, &a3);
+                    bounds(lo, cnt, (cur ? S.ndep[1] : S.ndep[0])[pos], &a1, &a2, &a3);
                     S.b1[j] = a1; S.b2[j] = a2; S.b3[j] = a3;
                     const int c0 = a1 - lo, c1 = a2 - a1, c2 = a3 - a2, c3 = lo + cnt - a3;
                     S.kArr[j] = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0) - 1;  // growth of the list
@@ -1542,11 +1626,48 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(8, 8)
             }
         }
     }
+    if (kHist && useHist) {
+        if (s_overflow) {          // (uniform: every write of the flag lies before the barrier that ended the tree passes)
+            __syncthreads();
+            useHist = false;
+            if (dbg && tid == 0) atomicAdd((unsigned long long *) &dbg[16 * 8 + l], 1ull);   // restarts of this level over the launch's frames
+            goto restart;
+        }
+    }
     OSTAMP(4);
     // ---- 5. best response per node (:702-720), output in list order ----
     unsigned *oxy = lvlKpXY + (long long) f * kpStride + g.kpBase;
     unsigned char *osc = lvlKpScore + (long long) f * kpStride + g.kpBase;
     const int lane = lane_id(), wave = wave_id();
+    if (kHist && useHist) {
+        // first bin and log2 of the bin count of every final node (PS is still the prefix table)
+        for (int i = tid; i < n; i += kOctBlock) {
+            const int lo = (cur ? S.nlo[1] : S.nlo[0])[i], sh = 2 * (dm - (cur ? S.ndep[1] : S.ndep[0])[i]);
+            int a = 0, b = nBins >> sh;
+            while (b - a > 1) {
+                const int m = (a + b) >> 1;
+                if (PS[m << sh] <= lo) a = m; else b = m;
+            }
+            S.b1[i] = a << sh;
+            S.b2[i] = sh;
+            S.kArr[i] = 0;
+        }
+        __syncthreads();
+        // bin -> final node, written over the prefix table (sixteen lanes per node; bins outside every node hold no candidate)
+        for (int i0 = wave * 4; i0 < n; i0 += (kOctBlock / 64) * 4) {
+            const int i = i0 + (lane >> 4), sl16 = lane & 15;
+            if (i < n) {
+                const int f0 = S.b1[i], len = 1 << S.b2[i];
+                for (int k = sl16; k < len; k += 16) PS[f0 + k] = i;
+            }
+        }
+        __syncthreads();
+        // the candidates once more, linearly: best (score, then smallest index) per node
+        for (int i = tid; i < M; i += kOctBlock) {
+            const unsigned w = key0[i];
+            atomicMax((unsigned *) &S.kArr[PS[w & 0xFFFFu]], ((w >> 16) << 24) | (0xFFFFFFu - (unsigned) i));
+        }
+    } else
     for (int i0 = wave * 4; i0 < n; i0 += (kOctBlock / 64) * 4) {   // sixteen lanes (a DPP row) per node: arg-max over its range (LDS / DPP only);
         const int i = i0 + (lane >> 4), sl16 = lane & 15;           // the final nodes hold ~10 candidates each
         const bool ok = i < n;
@@ -2165,24 +2286,34 @@ size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalN
     return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + (globalNodes ? 0 : 19 * (size_t) cap) + 4 * (size_t) ldsCand);
 }
 
-hipError_t octree_prepare(size_t ldsBytes, bool globalNodes) {
+size_t octree_hist_lds_bytes(int regionInts, int histBins) { return sizeof(int) * ((size_t) regionInts + (size_t) histBins + 1); }
+
+hipError_t octree_prepare(size_t ldsBytes, bool globalNodes, bool hist) {
     constexpr int kOctMaxDyn = 160 * 1024 - 10 * 1024;   // the kernel's static LDS (radix histogram, scan scratch) is ~8.5 KB
-    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn)
-                       : hipFuncSetAttribute((const void *) k_octree<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn);
+    if (hist) return hipFuncSetAttribute((const void *) k_octree<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn);
+    return globalNodes ? hipFuncSetAttribute((const void *) k_octree<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn)
+                       : hipFuncSetAttribute((const void *) k_octree<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kOctMaxDyn);
 }
 
-void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
+// levels [level0, level0 + nLaunchLevels) of every frame; histBins > 0 selects the histogram plan (regionInts ints shared by the cell table, the
+// key tables and the node arrays, then histBins + 1 ints of prefix table)
+void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, int level0, int nLaunchLevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena) {
-    if (nodeArena)
-        hipLaunchKernelGGL(k_octree<true>, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots, totalCells,
+                   uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena,
+                   int regionInts, int histBins) {
+    if (histBins > 0)
+        hipLaunchKernelGGL((k_octree<false, true>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
+                           totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, 0,
+                           dbg, nullptr, regionInts, histBins);
+    else if (nodeArena)
+        hipLaunchKernelGGL((k_octree<true, false>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
-                           dbg, nodeArena);
+                           dbg, nodeArena, 0, 0);
     else
-        hipLaunchKernelGGL(k_octree<false>, dim3(nlevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, cellCnt, slots, totalCells,
+        hipLaunchKernelGGL((k_octree<false, false>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
-                           dbg, nodeArena);
+                           dbg, nodeArena, 0, 0);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,

@@ -56,11 +56,14 @@ void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCel
                      unsigned *stats);
 constexpr int kFastStatWords = 4 * 64;   // `stats`: 64 x {cells sampled, cells whose keypoints are FAST(minTh)'s, score rounds beyond the first, plan: 1 one pass / 2 iniTh first}
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes);
-hipError_t octree_prepare(size_t ldsBytes, bool globalNodes);
-void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, const unsigned short *cellCnt, const unsigned *slots,
+size_t octree_hist_lds_bytes(int regionInts, int histBins);
+hipError_t octree_prepare(size_t ldsBytes, bool globalNodes, bool hist);
+void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, int level0, int nLaunchLevels, const unsigned short *cellCnt, const unsigned *slots,
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
-                   uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena);
+                   uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena,
+                   int regionInts, int histBins);
+constexpr int kOctDbgWords = 16 * 8 + 16;   // per level: six phase stamps, M, n; then per level the workgroups that left the histogram plan
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,
                      const uint2 *procRec, int kpStride, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode);
 void launch_hamming_pairs(hipStream_t st, const void *a, const void *b, int n, int *out);

@@ -122,6 +122,9 @@ struct ygzf_ctx {
     size_t octLds = 0;
     int octLdsCand = 0;
     bool octGlobalNodes = false;
+    // histogram plan of the octree (levels with tens of thousands of candidates): launches of consecutive levels, each with its own LDS allotment
+    struct OctGroup { int l0 = 0, n = 0, cap = 0, regionInts = 0, histBins = 0; size_t lds = 0; };
+    std::vector<OctGroup> octGroups;
     Buf dOctNodes;
     // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at
     // minTh, 2 = iniTh first.  Identical results either way.
@@ -523,10 +526,50 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             if (c->octLdsCand > 8192) c->octLdsCand = 8192;
         }
         c->octLds = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, c->octLdsCand, c->octGlobalNodes);
-        if (c->octLds > 150 * 1024)
-            return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
-                        G.maxCellsPerLevel, G.kpCapMax);
-        HIPCHECK(c, octree_prepare(c->octLds, c->octGlobalNodes));
+        // Levels too large for LDS-resident candidate buffers (1920x1080 / 4000 and up) take the histogram plan: no sort, tree passes in LDS
+        // (extract_kernels.hip, k_octree<.., kHist>).  Consecutive levels are launched together while their list caps stay within a factor of two of
+        // the group's first level, so that the small levels do not reserve the LDS of the large ones.
+        c->octGroups.clear();
+        // (YGZF_OCT_PLAN=hist / sort forces one plan, YGZF_OCT_HIST_BINS bounds the histogram: the tests run every geometry through both plans
+        // and through the fall-back from one to the other)
+        const char *planEnv = getenv("YGZF_OCT_PLAN");
+        const bool wantHist = planEnv && !strcmp(planEnv, "hist") ? true : planEnv && !strcmp(planEnv, "sort") ? false : (c->octGlobalNodes || c->octLdsCand == 0);
+        const int binsEnv = getenv("YGZF_OCT_HIST_BINS") ? atoi(getenv("YGZF_OCT_HIST_BINS")) : 0;
+        if (wantHist) {
+            bool ok = true;
+            for (int l = 0; l < L && ok;) {
+                ygzf_ctx::OctGroup grp;
+                grp.l0 = l;
+                int cells = 0, tabs = 0;
+                for (; l < L && (grp.n == 0 || 2 * G.lv[l].kpCap > G.lv[grp.l0].kpCap); l++, grp.n++) {
+                    const LevelGeom &g = G.lv[l];
+                    const int nc = g.nCols * g.nRows;
+                    grp.cap = std::max(grp.cap, g.kpCap);
+                    cells = std::max(cells, nc + 1);
+                    if (nc > 0)
+                        tabs = std::max(tabs, nc + 1 + std::max(g.regW, g.nCols * g.wCell) + 9 + std::max(g.regH, g.nRows * g.hCell) + 9 + nc);
+                }
+                if (grp.cap < 1) grp.cap = 1;
+                const size_t budget = 150 * 1024;
+                grp.histBins = binsEnv >= 4 && binsEnv <= 8192 ? binsEnv : 8192;
+                grp.regionInts = std::max(std::max(19 * grp.cap, cells), tabs);
+                if (octree_hist_lds_bytes(grp.regionInts, grp.histBins) > budget) grp.regionInts = std::max(19 * grp.cap, cells);   // keys without the tables
+                while (grp.histBins > 1024 && !binsEnv && octree_hist_lds_bytes(grp.regionInts, grp.histBins) > budget) grp.histBins /= 2;
+                grp.lds = octree_hist_lds_bytes(grp.regionInts, grp.histBins);
+                if (grp.lds > budget) ok = false;
+                c->octGroups.push_back(grp);
+            }
+            if (!ok) c->octGroups.clear();
+        }
+        if (c->octGroups.empty()) {
+            if (c->octLds > 150 * 1024)
+                return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
+                            G.maxCellsPerLevel, G.kpCapMax);
+            HIPCHECK(c, octree_prepare(c->octLds, c->octGlobalNodes, false));
+        } else {
+            c->octGlobalNodes = false;
+            HIPCHECK(c, octree_prepare(0, false, true));
+        }
         c->geo = G;
     }
     const Geometry &G = c->geo;
@@ -732,26 +775,42 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
         if (collect) HIPCHECK(c, hipMemcpyAsync(c->hFastStats, c->dFastStats.p, kFastStatWords * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
         long long *odbg = nullptr;
         if (c->octDebug) {
-            int rc2 = ensure(c, c->dTmpA, 16 * 8 * sizeof(long long));
+            int rc2 = ensure(c, c->dTmpA, kOctDbgWords * sizeof(long long));
             if (rc2) return rc2;
             odbg = (long long *) c->dTmpA.p;
+            HIPCHECK(c, hipMemsetAsync(odbg, 0, kOctDbgWords * sizeof(long long), c->stream));
         }
         {
             ProfScope ps(c, KK_OCTREE);
-            launch_octree(c->stream, dGeom, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
-                          G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
-                          (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
-                          (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
-                          (uint2 *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg,
-                          c->octGlobalNodes ? (int *) c->dOctNodes.p : nullptr);
+            if (c->octGroups.empty())
+                launch_octree(c->stream, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                              G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
+                              (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
+                              (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
+                              (uint2 *) c->dProcOrder.p, G.kpStride, G.kpCapMax, c->octLdsCand, c->octLds, nFrames, odbg,
+                              c->octGlobalNodes ? (int *) c->dOctNodes.p : nullptr, 0, 0);
+            else
+                for (const auto &grp : c->octGroups)
+                    launch_octree(c->stream, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                                  G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
+                                  (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
+                                  (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
+                                  (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins);
         }
         if (odbg) {
-            long long st[16 * 8];
+            long long st[kOctDbgWords];
             HIPCHECK(c, hipStreamSynchronize(c->stream));
             HIPCHECK(c, hipMemcpy(st, odbg, sizeof st, hipMemcpyDeviceToHost));
             for (int l = 0; l < L; l++)
                 fprintf(stderr, "[ygzf octree lvl %d, 10ns ticks] prefix %lld keys %lld sort %lld bfs %lld final %lld  M=%lld n=%lld\n", l, st[l * 8 + 1] - st[l * 8],
                         st[l * 8 + 2] - st[l * 8 + 1], st[l * 8 + 3] - st[l * 8 + 2], st[l * 8 + 4] - st[l * 8 + 3], st[l * 8 + 5] - st[l * 8 + 4], st[l * 8 + 6], st[l * 8 + 7]);
+            if (!c->octGroups.empty()) {
+                fprintf(stderr, "[ygzf octree histogram plan: %zu launches;", c->octGroups.size());
+                for (const auto &grp : c->octGroups) fprintf(stderr, " levels %d-%d cap %d bins %d lds %zu;", grp.l0, grp.l0 + grp.n - 1, grp.cap, grp.histBins, grp.lds);
+                fprintf(stderr, " workgroups of %d frames that fell back to the sort, per level:", nFrames);
+                for (int l = 0; l < L; l++) fprintf(stderr, " %lld", st[16 * 8 + l]);
+                fprintf(stderr, "]\n");
+            }
         }
         {
             ProfScope ps(c, KK_DESCRIBE);

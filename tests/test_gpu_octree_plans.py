@@ -1,0 +1,90 @@
+"""DistributeOctTree (src/ORBextractor.cc:533-723) on the device has two plans (extract_kernels.hip, k_octree): candidates SORTED by path key
+(levels whose candidates fit LDS: the 752x480 class) and the HISTOGRAM plan (1920x1080 / 3840x2160: counts per key prefix + prefix sum instead
+of a sort; a tree that splits below the histogram's depth sends its workgroup back to the sorting path).  Same bytes from every plan, from the
+fall-back between them, and from launches grouped by level: octree list order per level, keypoints, descriptors -- against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+from tests.test_gpu_extract import _cmp_frame
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _clustered(seed, w, h):
+    """corners crowded into two small spots of an otherwise empty image: the tree subdivides far below any histogram depth"""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 120, np.uint8)
+    for (cx, cy) in ((w // 5, h // 4), (w - 90, h - 80)):
+        img[cy - 40:cy + 40, cx - 40:cx + 40] = rng.integers(0, 256, (80, 80), dtype=np.uint8)
+    return img
+
+
+CASES = [
+    # (w, h, nlevels, nfeatures, image)                          what it exercises
+    (752, 480, 8, 1000, lambda: synth_frame(41, 752, 480)),       # the default geometry, forced through the histogram plan
+    (640, 480, 8, 1000, lambda: np.random.default_rng(3).integers(0, 256, (480, 640), dtype=np.uint8)),   # pure noise: ~20 k candidates on level 0
+    (333, 517, 8, 1500, lambda: synth_frame(42, 333, 517)),       # tall: one octree root
+    (1280, 360, 6, 1200, lambda: synth_frame(43, 1280, 360)),     # wide: four roots
+    (752, 480, 8, 1000, lambda: _clustered(7, 752, 480)),         # deep trees -> overflow of every histogram depth
+    (320, 240, 4, 3000, lambda: synth_frame(44, 320, 240)),       # quota above the number of corners: the tree runs until nothing divides
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("plan,bins", [("hist", 8192), ("hist", 512), ("hist", 16), ("sort", 0)])
+def test_every_plan_gives_the_oracles_tree(oracle, case, plan, bins):
+    from orb_ygz_slam_amd import Extractor
+    w, h, nl, nf, make = CASES[case]
+    img = make()
+    with _env(YGZF_OCT_PLAN=plan, YGZF_OCT_HIST_BINS=bins if bins else None):
+        ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+        oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
+        imgs = np.stack([img, np.ascontiguousarray(img[::-1]), img])
+        ex.extract_batch_host(imgs)
+        _cmp_frame(oracle, ex, oex, imgs[0], frame=0)
+        _cmp_frame(oracle, ex, oex, imgs[1], frame=1)
+        k0, d0 = ex.batch_fetch(0)
+        k2, d2 = ex.batch_fetch(2)
+        assert np.array_equal(k0, k2) and np.array_equal(d0, d2)
+        ex.close()
+
+
+def test_automatic_plan_of_the_large_configs(oracle):
+    """1920x1080 / 8 / 4000 picks the histogram plan by itself (level groups with their own LDS allotment); the forced sorting plan returns the
+    same bytes -- and both equal the oracle."""
+    from orb_ygz_slam_amd import Extractor
+    w, h, nl, nf = 1920, 1080, 8, 4000
+    img = synth_frame(77, w, h)
+    oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
+    res = []
+    for plan in (None, "sort"):
+        with _env(YGZF_OCT_PLAN=plan, YGZF_OCT_HIST_BINS=None):
+            ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+            ex.extract_batch_host(img[None])
+            _cmp_frame(oracle, ex, oex, img, frame=0)
+            res.append(ex.batch_fetch(0))
+            ex.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
