@@ -232,7 +232,7 @@ int ygzf_features_in_area(ygzf_ctx *ctx, const ygzf_camera *cam, int n_keys, con
 /* ---- MapPoint::ComputeDistinctiveDescriptors()   src/MapPoint.cc:211-271 over a MapPoint batch -----------------------------
  * Point p owns the observation descriptors desc[obs_off[p] .. obs_off[p+1]) (32 bytes each, those of its non-bad KeyFrames in map order);
  * best_idx[p] = index within the point's observations of the descriptor with the least median Hamming distance to the others (first
- * minimum, median = sorted row element (size_t)(0.5*(N-1))), -1 for a point without observations.  At most 256 observations per point. */
+ * minimum, median = sorted row element (size_t)(0.5*(N-1))), -1 for a point without observations.  Any number of observations per point (up to 256 in registers, beyond that through a distance histogram). */
 int ygzf_distinctive_descriptors_batch(ygzf_ctx *ctx, int n_points, const int *obs_off, const uint8_t *desc, int *best_idx);
 
 /* ---- ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)

@@ -131,6 +131,7 @@ public:
     void release() { buf.reset(); rows = cols = 0; data = nullptr; }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return CV_8UC1; }
+    bool isContinuous() const { return rows <= 1 || step.p[0] == (size_t) cols * elem; }
     size_t step1() const { return step.p[0]; }
     Mat clone() const {
         Mat m(rows, cols, elem == 4 ? CV_32F : CV_8UC1);

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../../include/ygzf.h"
+#include "ygzf_pool.h"
 
 namespace ygz {
 
@@ -40,7 +41,7 @@ bool DeviceORBVocabulary::ensureDevice() const {
     if (!mCtx) {
         ygzf_extractor_cfg cfg = {1000, 1.2f, 8, 20, 7, 0};   // only the context's stream and buffers are used
         if (ygzf_create(ORBextractor::sDevice, &cfg, 64, 64, 1, &mCtx) != YGZF_OK) {
-            fprintf(stderr, "ygz::DeviceORBVocabulary: %s\n", ygzf_last_error(nullptr));
+            ygzf_host::report_failure("ygz::DeviceORBVocabulary", ygzf_last_error(nullptr));
             mCtx = nullptr;
             return false;
         }
@@ -58,10 +59,15 @@ bool DeviceORBVocabulary::ensureDevice() const {
     for (int i = 0; i < n; i++) {
         const std::vector<DBoW2::NodeId> &ch = m_nodes[i].children;
         for (size_t k = 1; k < ch.size(); k++)
-            if (ch[k] < ch[k - 1]) { fprintf(stderr, "ygz::DeviceORBVocabulary: children of node %d are not in ascending id order\n", i); return false; }
+            if (ch[k] < ch[k - 1]) {
+                char msg[96];
+                snprintf(msg, sizeof msg, "children of node %d are not in ascending id order", i);
+                ygzf_host::report_failure("ygz::DeviceORBVocabulary", msg);
+                return false;
+            }
     }
     if (ygzf_vocabulary_set(mCtx, n, m_L, parent.data(), desc.data()) != YGZF_OK) {
-        fprintf(stderr, "ygz::DeviceORBVocabulary: %s\n", ygzf_last_error(mCtx));
+        ygzf_host::report_failure("ygz::DeviceORBVocabulary", ygzf_last_error(mCtx));
         return false;
     }
     mUploadedNodes = m_nodes.size();
@@ -80,12 +86,12 @@ void DeviceORBVocabulary::transform(const std::vector<DBoW2::FORB::TDescriptor> 
         std::vector<uint8_t> desc((size_t) n * 32);
         for (int i = 0; i < n; i++) std::memcpy(&desc[(size_t) i * 32], features[i].data, 32);
         if (!ensureDevice()) {   // the reason (no device, upload failure, children not in id order) is already on stderr
-            fprintf(stderr, "ygz::DeviceORBVocabulary::transform: the vocabulary is not on the device: BowVector / FeatureVector stay EMPTY for this frame "
-                            "(no CPU fallback; ORBVocabulary::transform is the host path)\n");
+            ygzf_host::report_failure("ygz::DeviceORBVocabulary::transform", "the vocabulary is not on the device: BowVector / FeatureVector stay EMPTY for this frame "
+                                                                                "(no CPU fallback; ORBVocabulary::transform is the host path)");
             return;
         }
         if (ygzf_bow_transform(mCtx, n, desc.data(), levelsup, leaf.data(), nid.data()) != YGZF_OK) {
-            fprintf(stderr, "ygz::DeviceORBVocabulary::transform: %s: BowVector / FeatureVector stay EMPTY for this frame\n", ygzf_last_error(mCtx));
+            ygzf_host::report_failure("ygz::DeviceORBVocabulary::transform (BowVector / FeatureVector stay EMPTY for this frame)", ygzf_last_error(mCtx));
             return;
         }
     }

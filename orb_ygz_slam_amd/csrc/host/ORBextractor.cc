@@ -32,7 +32,11 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     ygzf_extractor_cfg cfg = {nfeatures, (float) scaleFactor, nlevels, iniThFAST, minThFAST, mCvMode};
     if (L > 0 && ygzf_scale_tables_host(&cfg, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(), mvInvLevelSigma2.data(),
                                         mnFeaturesPerLevel.data()) != YGZF_OK)
-        fprintf(stderr, "ygz::ORBextractor: bad configuration (nfeatures %d, scaleFactor %g, nlevels %d)\n", nfeatures, (double) scaleFactor, nlevels);
+    {
+        char msg[128];
+        snprintf(msg, sizeof msg, "bad configuration (nfeatures %d, scaleFactor %g, nlevels %d)", nfeatures, (double) scaleFactor, nlevels);
+        ygzf_host::report_failure("ygz::ORBextractor", msg);
+    }
     // row ends of the 31-px circular patch (:455-469), kept for parity with the reference's member; the device holds its own copy
     const int HALF_PATCH_SIZE = 15;
     umax.assign(HALF_PATCH_SIZE + 1, 0);
@@ -54,7 +58,7 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
     mCtx = nullptr;
     ygzf_extractor_cfg cfg = {nfeatures, (float) scaleFactor, nlevels, iniThFAST, minThFAST, mCvMode};
     if (ygzf_create(mDevice, &cfg, w, h, 2, &mCtx) != YGZF_OK) {   // 2 frames: the stereo matcher stages both eyes
-        fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(nullptr));
+        ygzf_host::report_failure("ygz::ORBextractor", ygzf_last_error(nullptr));
         mCtx = nullptr;
         return nullptr;
     }
@@ -85,13 +89,13 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
     {   // extract-ahead follows the tracker's habit: on when the previous pyramid's image was extracted, off when it was not
         const bool want = mExtractAhead && mExtractedSincePyramid;
         if (want != mAheadOn) {
-            if (ygzf_set_extract_ahead(c, want ? 1 : 0) != YGZF_OK) fprintf(stderr, "ygz::ORBextractor: %s\n", ygzf_last_error(c));
+            if (ygzf_set_extract_ahead(c, want ? 1 : 0) != YGZF_OK) ygzf_host::report_failure("ygz::ORBextractor", ygzf_last_error(c));
             else mAheadOn = want;
         }
         mExtractedSincePyramid = false;
     }
     if (ygzf_compute_pyramid(c, image.data, image.cols, image.rows, (int) image.step, out.data()) != YGZF_OK) {
-        fprintf(stderr, "ygz::ORBextractor::ComputePyramid: %s\n", ygzf_last_error(c));
+        ygzf_host::report_failure("ygz::ORBextractor::ComputePyramid", ygzf_last_error(c));
         return;
     }
     mResidentLevel0 = mvImagePyramid[0];   // the context still holds this image and its pyramid (see operator()(Frame*, ...))
@@ -111,7 +115,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     mLastImagePrint = ygzf_host::image_fingerprint(image.data, image.cols, image.rows, (int) image.step);
     if (ygzf_extract(c, image.data, image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
         YGZF_OK) {
-        fprintf(stderr, "ygz::ORBextractor::operator(): %s\n", ygzf_last_error(c));
+        ygzf_host::report_failure("ygz::ORBextractor::operator()", ygzf_last_error(c));
         n = 0;
     }
     _keypoints.resize(n);
@@ -153,7 +157,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         int total = 0;
         mLastImagePrint = 0;   // (the grid detectors keep no complete pyramid on the device)
         if (ygzf_extract_fast_keypoint(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &total) != YGZF_OK) {
-            fprintf(stderr, "ygz::ORBextractor (FAST_KEYPOINT): %s\n", ygzf_last_error(c));
+            ygzf_host::report_failure("ygz::ORBextractor (FAST_KEYPOINT)", ygzf_last_error(c));
             return;
         }
         for (int i = 0; i < N; i++) frame->mvKeys[i].angle = all[i].angle;   // ComputeKeyPointsFast re-orients them (:1268-1271)
@@ -172,7 +176,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         mLastImagePrint = 0;
         if (ygzf_extract_dso(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &mnGridSize, &total) !=
             YGZF_OK) {
-            fprintf(stderr, "ygz::ORBextractor (DSO_KEYPOINT): %s\n", ygzf_last_error(c));
+            ygzf_host::report_failure("ygz::ORBextractor (DSO_KEYPOINT)", ygzf_last_error(c));
             return;
         }
         for (int i = 0; i < N; i++) frame->mvKeys[i].angle = all[i].angle;   // ComputeKeyPointsDSOSingleLevel re-orients them (:1380-1383)
@@ -201,12 +205,12 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         }
         mResidentLevel0 = cv::Mat();   // the extraction reuses the buffers: nothing is resident afterwards
         if (rcE != YGZF_OK) {
-            fprintf(stderr, "ygz::ORBextractor (ORBSLAM_KEYPOINT): %s\n", ygzf_last_error(c));
+            ygzf_host::report_failure("ygz::ORBextractor (ORBSLAM_KEYPOINT)", ygzf_last_error(c));
             return;
         }
         fresh.resize(n);
         if (N > 0 && ygzf_describe_keys(c, 0, (const ygzf_kp *) frame->mvKeys.data(), N, 0, nullptr, descExisting.data()) != YGZF_OK) {
-            fprintf(stderr, "ygz::ORBextractor (existing keys): %s\n", ygzf_last_error(c));
+            ygzf_host::report_failure("ygz::ORBextractor (existing keys)", ygzf_last_error(c));
             return;
         }
     }
@@ -235,12 +239,12 @@ void ORBextractor::ComputeStereoMatches(Frame &F) {
     std::vector<uint8_t> dl((size_t) F.N * 32), dr((size_t) Nr * 32);
     for (int i = 0; i < F.N; i++) std::memcpy(&dl[(size_t) i * 32], F.mDescriptors.ptr(i), 32);
     for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t) i * 32], F.mDescriptorsRight.ptr(i), 32);
-    if (imL.step != F.mImRight.step) { fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: left/right row steps differ\n"); return; }
+    if (imL.step != F.mImRight.step) { ygzf_host::report_failure("ygz::ORBextractor::ComputeStereoMatches", "left/right row steps differ"); return; }
     mLastImagePrint = 0;
     if (ygzf_compute_stereo_matches(c, imL.data, F.mImRight.data, imL.cols, imL.rows, (int) imL.step, F.N,
                                     (const ygzf_kp *) F.mvKeys.data(), dl.data(), Nr, (const ygzf_kp *) F.mvKeysRight.data(), dr.data(), F.mb, F.mbf,
                                     F.mvuRight.data(), F.mvDepth.data()) != YGZF_OK)
-        fprintf(stderr, "ygz::ORBextractor::ComputeStereoMatches: %s\n", ygzf_last_error(c));
+        ygzf_host::report_failure("ygz::ORBextractor::ComputeStereoMatches", ygzf_last_error(c));
 }
 
 }  // namespace ygz

@@ -88,7 +88,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
                                                   obs.data(), world.data(), mpdesc.data(), Rcw, tcw, Rlw, tlw, th, bMono, checkLevel,
                                                   mbCheckOrientation, owner.data(), match.data(), &nmatches);
     if (rc != YGZF_OK) {
-        fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
+        ygzf_host::report_failure("ygz::ORBmatcher::SearchByProjection", ygzf_last_error(c));
         return 0;
     }
     for (int i2 = 0; i2 < nt; i2++) {
@@ -138,7 +138,7 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     const int rc = ygzf_search_by_projection_mappoints(c, &fv, &cam, M, tiv.data(), bad.data(), obs.data(), px.data(), py.data(), pxr.data(),
                                                        vc.data(), lvl.data(), mpdesc.data(), th, checkLevel, mfNNratio, owner.data(),
                                                        match.data(), &nmatches);
-    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
+    if (rc != YGZF_OK) ygzf_host::report_failure("ygz::ORBmatcher::SearchByProjection", ygzf_last_error(c));
     if (rc != YGZF_OK) return 0;
     for (int i = 0; i < nt; i++)
         if (match[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[match[i]];
@@ -205,7 +205,7 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
     int nmatches = 0;
     const int rc = ygzf_search_by_projection_kf(c, &cur, &cam, M, valid.data(), pu.data(), pv.data(), lvl.data(), ang.data(), mpdesc.data(), th, ORBdist,
                                                 mbCheckOrientation, owner.data(), match.data(), &nmatches);
-    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByProjection: %s\n", ygzf_last_error(c));
+    if (rc != YGZF_OK) ygzf_host::report_failure("ygz::ORBmatcher::SearchByProjection", ygzf_last_error(c));
     if (rc != YGZF_OK) return 0;
     for (int i2 = 0; i2 < nt; i2++) {
         if (match[i2] >= 0) CurrentFrame.mvpMapPoints[i2] = vpMPs[match[i2]];
@@ -253,7 +253,7 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     const int rc = ygzf_search_by_bow(c, nNodes, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF, valid.data(), (const ygzf_kp *) pKF->mvKeys.data(),
                                       kfDesc.data(), F.N, (const ygzf_kp *) F.mvKeys.data(), fDesc.data(), mfNNratio, mbCheckOrientation, match.data(),
                                       &nmatches);
-    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchByBoW: %s\n", ygzf_last_error(c));
+    if (rc != YGZF_OK) ygzf_host::report_failure("ygz::ORBmatcher::SearchByBoW", ygzf_last_error(c));
     if (rc != YGZF_OK) return 0;
     for (int i = 0; i < F.N; i++)
         if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
@@ -280,7 +280,7 @@ int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Po
     int nmatches = 0;
     const int rc = ygzf_search_for_initialization(c, &v1, &v2, &cam, (float *) vbPrevMatched.data(), windowSize, mfNNratio, mbCheckOrientation,
                                                   vnMatches12.data(), &nmatches);
-    if (rc != YGZF_OK) fprintf(stderr, "ygz::ORBmatcher::SearchForInitialization: %s\n", ygzf_last_error(c));
+    if (rc != YGZF_OK) ygzf_host::report_failure("ygz::ORBmatcher::SearchForInitialization", ygzf_last_error(c));
     return rc == YGZF_OK ? nmatches : 0;
 }
 
@@ -316,7 +316,7 @@ bool ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, 
     uint8_t ok = 0;
     static_assert(sizeof(cv::KeyPoint) == sizeof(ygzf_kp), "cv::KeyPoint layout");
     if (ygzf_find_direct_projection_batch(dc.ctx(), &cam, curSlot, curT, 1, &slot, refT, (const ygzf_kp *) &kp, world, px, &level, &ok, nullptr) != YGZF_OK) {
-        fprintf(stderr, "ygz::ORBmatcher::FindDirectProjection: %s\n", ygzf_last_error(dc.ctx()));
+        ygzf_host::report_failure("ygz::ORBmatcher::FindDirectProjection", ygzf_last_error(dc.ctx()));
         return false;
     }
     px_curr[0] = px[0];

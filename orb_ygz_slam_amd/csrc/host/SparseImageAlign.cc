@@ -76,7 +76,7 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
             if (rs >= 0 && cs >= 0 && rs != cs) {
                 if (ygzf_sia_run_cached(ic.ctx(), rs, cs, &R, C.Tcw, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret,
                                         nullptr, H36) != YGZF_OK) {
-                    fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ic.ctx()));
+                    ygzf_host::report_failure(who, ygzf_last_error(ic.ctx()));
                     return 0;
                 }
                 done = true;
@@ -98,7 +98,7 @@ size_t SparseImgAlign::run(Frame *ref, Frame *cur, SE3f &TCR) {
         fill(ref, R, lr, wr, hr);
         fill(cur, C, lc, wc, hc);
         if (ygzf_sia_run(ctx, &R, &C, &cam, ref->mvInvScaleFactors.data(), max_level_, min_level_, kIterations, T7, &ret, nullptr, H36) != YGZF_OK) {
-            fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx));
+            ygzf_host::report_failure(who, ygzf_last_error(ctx));
             return 0;
         }
     }

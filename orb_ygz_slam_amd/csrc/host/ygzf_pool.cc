@@ -1,6 +1,7 @@
 // ygzf_pool.cc -- see ygzf_pool.h (product code, host side).
 #include "ygzf_pool.h"
 
+#include <atomic>
 #include <cstdio>
 #include <algorithm>
 #include <cstring>
@@ -22,6 +23,45 @@ Pool &pool() {
 }
 }  // namespace
 
+namespace {
+struct Failures {
+    std::mutex mu;
+    std::atomic<unsigned long> count{0};
+    std::string last;
+    failure_callback cb = nullptr;
+    void *user = nullptr;
+};
+Failures &failures() {
+    static Failures *f = new Failures();   // leaked on purpose, like the pool
+    return *f;
+}
+}  // namespace
+
+void report_failure(const char *who, const char *what) {
+    Failures &F = failures();
+    failure_callback cb;
+    void *user;
+    {
+        std::lock_guard<std::mutex> lk(F.mu);
+        F.count.fetch_add(1);
+        F.last = std::string(who ? who : "libygzf") + ": " + (what ? what : "unknown error");
+        cb = F.cb;
+        user = F.user;
+    }
+    fprintf(stderr, "%s: %s\n", who ? who : "libygzf", what ? what : "unknown error");
+    if (cb) cb(who, what, user);
+}
+unsigned long failure_count() { return failures().count.load(); }
+std::string last_failure() {
+    std::lock_guard<std::mutex> lk(failures().mu);
+    return failures().last;
+}
+void set_failure_callback(failure_callback cb, void *user) {
+    std::lock_guard<std::mutex> lk(failures().mu);
+    failures().cb = cb;
+    failures().user = user;
+}
+
 Lease::Lease(int device) : c_(nullptr), device_(device) {
     {
         std::lock_guard<std::mutex> lk(pool().mu);
@@ -30,7 +70,9 @@ Lease::Lease(int device) : c_(nullptr), device_(device) {
     }
     ygzf_extractor_cfg cfg = {1000, 1.2f, 8, 20, 7, 0};   // matcher / aligner entry points only use the context's stream and scratch buffers
     if (ygzf_create(device, &cfg, 64, 64, 1, &c_) != YGZF_OK) {
-        fprintf(stderr, "libygzf context pool (device %d): %s\n", device, ygzf_last_error(nullptr));
+        char who[64];
+        snprintf(who, sizeof who, "libygzf context pool (device %d)", device);
+        report_failure(who, ygzf_last_error(nullptr));
         c_ = nullptr;
     }
 }
@@ -61,6 +103,8 @@ struct ImageCache::Impl {
     unsigned long tick = 0;
 };
 
+int ImageCache::capacity() { return Impl::kSlots; }
+
 ImageCache &ImageCache::instance() {
     static ImageCache *c = [] { ImageCache *p = new ImageCache(); p->impl_ = new Impl(); return p; }();   // never destroyed (HIP may be gone at exit)
     return *c;
@@ -76,12 +120,12 @@ bool ImageCache::prepare(int device, int w, int h, int nlevels, float scale_fact
     ctx_ = nullptr;
     ygzf_extractor_cfg cfg = {1000, scale_factor, nlevels, 20, 7, 0};   // the pyramid geometry is all that matters here
     if (ygzf_create(device, &cfg, w, h, 1, &ctx_) != YGZF_OK) {
-        fprintf(stderr, "%s: %s\n", who, ygzf_last_error(nullptr));
+        ygzf_host::report_failure(who, ygzf_last_error(nullptr));
         ctx_ = nullptr;
         return false;
     }
     if (ygzf_image_cache_reserve(ctx_, Impl::kSlots, w, h) != YGZF_OK) {
-        fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx_));
+        ygzf_host::report_failure(who, ygzf_last_error(ctx_));
         ygzf_destroy(ctx_);
         ctx_ = nullptr;
         return false;
@@ -131,7 +175,7 @@ int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int
     // the image is on the device already when the Frame's extractor still holds it: device-to-device, else upload + pyramid
     if (!(resident && ygzf_image_cache_put_resident(ctx_, victim, resident) == YGZF_OK) &&
         ygzf_image_cache_put(ctx_, victim, data, cols, rows, step) != YGZF_OK) {
-        fprintf(stderr, "%s: %s\n", who, ygzf_last_error(ctx_));
+        ygzf_host::report_failure(who, ygzf_last_error(ctx_));
         return -1;
     }
     I.used[victim] = 1;

@@ -6,9 +6,22 @@
 #ifndef YGZF_HOST_POOL_H
 #define YGZF_HOST_POOL_H
 
+#include <string>
+
 struct ygzf_ctx;
 
 namespace ygzf_host {
+// ---- failure channel of the class shells ------------------------------------------------------------------------------------------------
+// The reference's signatures have no error channel (void / count returns), so a shell whose device call fails can only return
+// "0 matches" / an empty result -- which Tracking cannot tell from a frame with nothing to match.  Every such return goes through
+// report_failure: it counts, remembers the message, calls the registered callback and prints to stderr.  A SLAM system polls failure_count()
+// once per frame (or installs a callback that raises its own "lost" flag); the tests provoke failures and read it.
+typedef void (*failure_callback)(const char *who, const char *what, void *user);
+void report_failure(const char *who, const char *what);
+unsigned long failure_count();                 // process-wide, monotone
+std::string last_failure();                    // "who: what" of the most recent one ("" when none)
+void set_failure_callback(failure_callback cb, void *user);   // nullptr removes it; called on the failing thread
+
 class Lease {
 public:
     explicit Lease(int device);
@@ -52,6 +65,7 @@ public:
     // from hitting a stale image -- but the natural call in Tracking::Reset beside mpMap->clear().
     void clear();
     ygzf_ctx *ctx() const { return ctx_; }
+    static int capacity();                 // slots: a batch call may reference at most capacity() distinct images
 
 private:
     ImageCache() = default;

@@ -153,7 +153,7 @@ struct FrustumArgs {
 };
 void launch_frustum(hipStream_t st, const FrustumArgs &A);
 // MapPoint::ComputeDistinctiveDescriptors over a MapPoint batch (<= 256 observations per point)
-void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best);
+void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best, int nLarge, const int *large);   // large: points with > 256 observations
 
 // Frame::ComputeBoW: descriptor -> vocabulary tree descent (match_kernels.hip)
 void launch_bow_descend(hipStream_t st, int n, const uint8_t *desc, const int *childOff, const int *childIdx, const uint8_t *nodeDesc, int nidLevel,

@@ -1053,6 +1053,7 @@ __global__ __launch_bounds__(256) void k_distinctive(int nPoints, const int *__r
     if (p >= nPoints) return;
     const int o0 = obsOff[p], N = obsOff[p + 1] - o0;
     if (N <= 0) { if (lane == 0) best[p] = -1; return; }
+    if (N > kDistinctMaxObs) return;   // k_distinctive_large's
     const int k = (int) (0.5 * (N - 1));
     const int per = (N + 63) >> 6;   // <= 4
     unsigned long long d[4][4];
@@ -1088,8 +1089,57 @@ __global__ __launch_bounds__(256) void k_distinctive(int nPoints, const int *__r
     if (lane == 0) best[p] = bestIdx;
 }
 
-void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best) {
+// The same for points with more than kDistinctMaxObs observations (long sessions: a landmark seen from hundreds of KeyFrames), which do not fit
+// the register-resident form: one wave per such point, the median of row i from a 257-bin histogram of its distances (LDS atomics over the
+// observations in steps of 64, then the first bin whose running count exceeds k).  `large` lists the points to process; the others are left
+// to k_distinctive, which skips them.
+__global__ __launch_bounds__(256) void k_distinctive_large(int nLarge, const int *__restrict__ large, const int *__restrict__ obsOff,
+                                                           const uint8_t *__restrict__ desc, int *__restrict__ best) {
+    __shared__ int s_hist[4][260];
+    const int lane = m_lane(), wv = threadIdx.x >> 6, q = blockIdx.x * 4 + wv;
+    if (q >= nLarge) return;
+    const int p = large[q];
+    const int o0 = obsOff[p], N = obsOff[p + 1] - o0;
+    const int k = (int) (0.5 * (N - 1));
+    int *hist = s_hist[wv];
+    int bestMedian = 0x7FFFFFFF, bestIdx = 0;
+    for (int i = 0; i < N; i++) {
+        for (int b = lane; b < 260; b += 64) hist[b] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long *qi = (const unsigned long long *) (desc + (size_t) (o0 + i) * 32);
+        const unsigned long long q0 = qi[0], q1 = qi[1], q2 = qi[2], q3 = qi[3];
+        for (int j = lane; j < N; j += 64) {
+            const unsigned long long *d = (const unsigned long long *) (desc + (size_t) (o0 + j) * 32);
+            atomicAdd(&hist[__popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3])], 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // smallest value m with #{dist <= m} > k: lane l sums bins 5 l .. 5 l + 4 (257 bins over 52 lanes), wave prefix, then the lane whose run crosses k
+        int loc[5], sum = 0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) { const int b = 5 * lane + t; loc[t] = b < 257 ? hist[b] : 0; sum += loc[t]; }
+        int incl = sum;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const int o = __shfl_up(incl, dlt);
+            if (lane >= dlt) incl += o;
+        }
+        int run = incl - sum, med = 1 << 20;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            run += loc[t];
+            if (run > k && med == 1 << 20) med = 5 * lane + t;
+        }
+        const unsigned long long has = __ballot(med != 1 << 20);
+        const int median = __shfl(med, __ffsll((long long) has) - 1);
+        if (median < bestMedian) { bestMedian = median; bestIdx = i; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) best[p] = bestIdx;
+}
+
+void launch_distinctive(hipStream_t st, int nPoints, const int *obsOff, const uint8_t *desc, int *best, int nLarge, const int *large) {
     if (nPoints > 0) hipLaunchKernelGGL(k_distinctive, dim3((nPoints + 3) / 4), dim3(256), 0, st, nPoints, obsOff, desc, best);
+    if (nLarge > 0) hipLaunchKernelGGL(k_distinctive_large, dim3((nLarge + 3) / 4), dim3(256), 0, st, nLarge, large, obsOff, desc, best);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

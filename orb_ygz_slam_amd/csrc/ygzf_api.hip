@@ -2674,22 +2674,26 @@ int ygzf_distinctive_descriptors_batch(ygzf_ctx *c, int n_points, const int *obs
     if (!c || (n_points > 0 && (!obs_off || !best_idx))) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (n_points <= 0) return YGZF_OK;
     const int total = obs_off[n_points];
+    std::vector<int> large;          // points beyond the register-resident form (> 256 observations): the histogram kernel's
     for (int p = 0; p < n_points; p++) {
         const int n = obs_off[p + 1] - obs_off[p];
         if (n < 0 || obs_off[p] < 0) return fail(c, YGZF_ERR_INVALID, "observation offsets not ascending");
-        if (n > 256) return fail(c, YGZF_ERR_UNSUPPORTED, "more than 256 observations of one MapPoint");
+        if (n > 256) large.push_back(p);
     }
     if (total > 0 && !desc) return fail(c, YGZF_ERR_INVALID, "null descriptors");
     HIPCHECK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, c->dTmpA, 4 * (size_t) (n_points + 1))) || (rc = ensure(c, c->dTmpB, 4 * (size_t) n_points)) ||
+    const size_t offBytes = (4 * (size_t) (n_points + 1) + 15) & ~(size_t) 15;
+    if ((rc = ensure(c, c->dTmpA, offBytes + 4 * large.size() + 16)) || (rc = ensure(c, c->dTmpB, 4 * (size_t) n_points)) ||
         (rc = ensure(c, c->dTmpC, 32 * (size_t) (total + 1))))
         return rc;
     HIPCHECK(c, hipMemcpyAsync(c->dTmpA.p, obs_off, 4 * (size_t) (n_points + 1), hipMemcpyHostToDevice, c->stream));
+    if (!large.empty()) HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dTmpA.p + offBytes, large.data(), 4 * large.size(), hipMemcpyHostToDevice, c->stream));
     if (total > 0) HIPCHECK(c, hipMemcpyAsync(c->dTmpC.p, desc, 32 * (size_t) total, hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, KK_DISTINCTIVE);
-        launch_distinctive(c->stream, n_points, (const int *) c->dTmpA.p, (const uint8_t *) c->dTmpC.p, (int *) c->dTmpB.p);
+        launch_distinctive(c->stream, n_points, (const int *) c->dTmpA.p, (const uint8_t *) c->dTmpC.p, (int *) c->dTmpB.p, (int) large.size(),
+                           (const int *) ((uint8_t *) c->dTmpA.p + offBytes));
     }
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipMemcpyAsync(best_idx, c->dTmpB.p, 4 * (size_t) n_points, hipMemcpyDeviceToHost, c->stream));

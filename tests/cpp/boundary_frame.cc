@@ -28,6 +28,8 @@
 #undef private
 #undef protected
 
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <string>
 
@@ -64,7 +66,12 @@ int MapPoint::PredictScale(const float &currentDist, Frame *pF) {
 }
 int MapPoint::PredictScale(const float &, KeyFrame *) { yr_unsupported("MapPoint::PredictScale(KeyFrame*)"); }
 long unsigned int KeyFrame::nNextId = 0;
+void Map::SetReferenceMapPoints(const std::vector<MapPoint *> &) {}   // "This is for visualization" (src/Tracking.cc:1603): the first line of UpdateLocalMap
 }  // namespace ygz
+// the reference's OWN bodies of the three members the batch bindings replace (renamed copies, tests/cpp/build_boundary.sh)
+extern "C" void ygz_ref_Tracking_SearchLocalPoints(ygz::Tracking *);
+extern "C" void ygz_ref_Tracking_SearchLocalPointsDirect(ygz::Tracking *);
+extern "C" void ygz_ref_Frame_ComputeStereoMatches(ygz::Frame *);
 #include "ORBVocabularyDevice.h"   // ygz::DeviceORBVocabulary over the reference's real DBoW2 (this build: -DYGZ_REAL_DBOW2)
 
 int main(int argc, char **argv) {
@@ -138,12 +145,23 @@ int main(int argc, char **argv) {
             if (c->first != d->first || c->second != d->second) { fprintf(stderr, "FeatureVector differs from the CPU class at node %u\n", c->first); return 5; }
         if (S.mBowVec.empty()) { fprintf(stderr, "empty BowVector\n"); return 5; }
     }
-    {   // the shell's device ComputeStereoMatches on the same frame: must equal the reference's CPU result
+    {   // Frame::ComputeStereoMatches is the product's strong definition in this binary (FrameStereo.cc): what ExtractFeatures left in S came from the
+        // device.  Beside it the reference's own CPU body (same Frame contents) -- and the extractor shell's entry point called directly
         Frame S2(S);
         S2.mpORBextractorLeft = &exL;
-        exL.ComputeStereoMatches(S2);
-        dump(dir + "/s_uright_dev.bin", S2.mvuRight.data(), S2.mvuRight.size() * sizeof(float));
-        dump(dir + "/s_depth_dev.bin", S2.mvDepth.data(), S2.mvDepth.size() * sizeof(float));
+        ygz_ref_Frame_ComputeStereoMatches(&S2);
+        dump(dir + "/s_uright_ref.bin", S2.mvuRight.data(), S2.mvuRight.size() * sizeof(float));
+        dump(dir + "/s_depth_ref.bin", S2.mvDepth.data(), S2.mvDepth.size() * sizeof(float));
+        if (S2.mvuRight.size() != S.mvuRight.size() || std::memcmp(S2.mvuRight.data(), S.mvuRight.data(), S.mvuRight.size() * sizeof(float)) ||
+            std::memcmp(S2.mvDepth.data(), S.mvDepth.data(), S.mvDepth.size() * sizeof(float))) {
+            fprintf(stderr, "Frame::ComputeStereoMatches: the device binding differs from the reference's CPU body\n");
+            return 7;
+        }
+        Frame S3(S);
+        S3.mpORBextractorLeft = &exL;
+        exL.ComputeStereoMatches(S3);
+        dump(dir + "/s_uright_dev.bin", S3.mvuRight.data(), S3.mvuRight.size() * sizeof(float));
+        dump(dir + "/s_depth_dev.bin", S3.mvDepth.data(), S3.mvDepth.size() * sizeof(float));
     }
 
     // ---- monocular frames: last = left image, cur = next image ---------------------------------------------------------------------------
@@ -276,7 +294,57 @@ int main(int argc, char **argv) {
         for (auto &mp : mps) trk.mvpLocalMapPoints.push_back(&mp);
         trk.mnLastRelocFrameId = 0;
         trk.mbDirectFailed = false;
+        // ---- the reference's own body of SearchLocalPoints (per point isInFrustum on the CPU, then the per-call matcher member) on this state ...
+        struct MpState { bool inView; float x, y, xr, vc; int lvl, visible; unsigned long seen; };
+        auto snapshot = [&]() {
+            std::vector<MpState> v;
+            for (auto &mp : mps) v.push_back(MpState{mp.mbTrackInView, mp.mTrackProjX, mp.mTrackProjY, mp.mTrackProjXR, mp.mTrackViewCos, mp.mnTrackScaleLevel, mp.mnVisible, mp.mnLastFrameSeen});
+            return v;
+        };
+        auto same_state = [](const std::vector<MpState> &a, const std::vector<MpState> &b) {
+            if (a.size() != b.size()) return false;
+            for (size_t i = 0; i < a.size(); i++) {
+                if (a[i].inView != b[i].inView || a[i].visible != b[i].visible || a[i].seen != b[i].seen) return false;
+                if (a[i].inView && (std::memcmp(&a[i].x, &b[i].x, 4 * sizeof(float)) || a[i].lvl != b[i].lvl)) return false;
+            }
+            return true;
+        };
+        const std::vector<MpState> before = snapshot();
+        ygz_ref_Tracking_SearchLocalPoints(&trk);
+        const std::vector<MapPoint *> refAssigned = trk.mCurrentFrame.mvpMapPoints;
+        const std::vector<MpState> refState = snapshot();
+        // ... and, from the same starting state, the batch binding (TrackingBatched.cc: one ygzf_search_local_points call)
+        trk.mCurrentFrame.mvpMapPoints.assign(trk.mCurrentFrame.N, (MapPoint *) nullptr);
+        for (size_t i = 0; i < mps.size(); i++) {
+            mps[i].mbTrackInView = before[i].inView; mps[i].mTrackProjX = before[i].x; mps[i].mTrackProjY = before[i].y; mps[i].mTrackProjXR = before[i].xr;
+            mps[i].mTrackViewCos = before[i].vc; mps[i].mnTrackScaleLevel = before[i].lvl; mps[i].mnVisible = before[i].visible; mps[i].mnLastFrameSeen = before[i].seen;
+        }
         trk.SearchLocalPoints();
+        if (trk.mCurrentFrame.mvpMapPoints != refAssigned || !same_state(snapshot(), refState)) {
+            fprintf(stderr, "Tracking::SearchLocalPoints: the batch binding differs from the reference's per-call body\n");
+            return 7;
+        }
+        {
+            auto restore = [&]() {
+                trk.mCurrentFrame.mvpMapPoints.assign(trk.mCurrentFrame.N, (MapPoint *) nullptr);
+                for (size_t i = 0; i < mps.size(); i++) { mps[i].mnVisible = before[i].visible; mps[i].mnLastFrameSeen = before[i].seen; mps[i].mbTrackInView = before[i].inView; }
+            };
+            auto med = [&](bool batch) {
+                std::vector<double> us;
+                for (int it = 0; it < 9; it++) {
+                    restore();
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (batch) trk.SearchLocalPoints(); else ygz_ref_Tracking_SearchLocalPoints(&trk);
+                    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+                }
+                std::sort(us.begin(), us.end());
+                return us[4];
+            };
+            const double a = med(false), b = med(true);
+            printf("latency search_local_points percall_us %.1f batch_us %.1f local_points %zu\n", a, b, mps.size());
+            restore();
+            trk.SearchLocalPoints();      // leave the state the dumps below expect
+        }
         std::vector<int> a3(trk.mCurrentFrame.N, -1);
         int visible = 0;
         for (int i = 0; i < trk.mCurrentFrame.N; i++)
@@ -287,6 +355,91 @@ int main(int argc, char **argv) {
         dump(dir + "/t_info.bin", info, sizeof info);
         dump(dir + "/t_keys.bin", trk.mCurrentFrame.mvKeys.data(), trk.mCurrentFrame.mvKeys.size() * sizeof(cv::KeyPoint));
         dump_desc(dir + "/t_desc.bin", trk.mCurrentFrame.mDescriptors, trk.mCurrentFrame.N);
+
+        // ---- Tracking::SearchLocalPointsDirect (:2174-2326): the reference's body (FindDirectProjection once per candidate through the per-call member)
+        // against the batch binding (one ygzf_is_in_frustum_batch + one ygzf_find_direct_projection_batch per half), both halves of the function:
+        //   phase 0  empty cache: UpdateLocalMap, then every local point;   phase 1  the cache phase 0 filled, enough hits to return early
+        KeyFrame KF1, KF0;                      // KF1 observes every point (the last frame as a KeyFrame); KF0 is mpLastKeyFrame (SelectNearestKeyframe skips it)
+        KF1.mnId = 3; KF0.mnId = 1;
+        KF1.mvKeys = last.mvKeys;
+        KF1.mvImagePyramid = last.mvImagePyramid;
+        KF1.mPose = last.mTcw;
+        KF0.mvImagePyramid = last.mvImagePyramid;
+        for (size_t i = 0; i < mps.size(); i++) {
+            mps[i].mObservations.clear();
+            mps[i].mObservations[&KF1] = i;
+            KF1.mvpMapPoints.push_back(&mps[i]);
+        }
+        const Frame aligned(trk.mCurrentFrame);           // pose from TrackWithSparseAlignment, keys of the extraction
+        struct DirectOut { std::vector<cv::KeyPoint> keys; std::vector<MapPoint *> mp; std::vector<int> from; std::set<MapPoint *> cache; int N; };
+        auto run_direct = [&](bool batch, int phase, const std::set<MapPoint *> &cache0) {
+            trk.mCurrentFrame = Frame(aligned);
+            trk.mCurrentFrame.mvpMapPoints.assign(trk.mCurrentFrame.N, (MapPoint *) nullptr);   // nothing matched yet: UpdateLocalKeyFrames keeps the list below
+            trk.mCurrentFrame.mvMatchedFrom.clear();
+            trk.mvpLocalKeyFrames.assign(1, &KF1);
+            trk.mpLastKeyFrame = &KF0;
+            trk.mvpLocalMapPoints.clear();
+            trk.mvpDirectMapPointsCache = cache0;
+            trk.mnCacheHitTh = phase == 0 ? 150 : 10;
+            for (auto &mp : mps) { mp.mnTrackReferenceForFrame = 0; mp.mbTrackInView = false; }
+            if (batch) trk.SearchLocalPointsDirect();
+            else ygz_ref_Tracking_SearchLocalPointsDirect(&trk);
+            DirectOut o;
+            const int n0 = aligned.N;
+            o.keys.assign(trk.mCurrentFrame.mvKeys.begin() + n0, trk.mCurrentFrame.mvKeys.end());
+            o.mp.assign(trk.mCurrentFrame.mvpMapPoints.begin() + n0, trk.mCurrentFrame.mvpMapPoints.end());
+            o.from = trk.mCurrentFrame.mvMatchedFrom;
+            o.cache = trk.mvpDirectMapPointsCache;
+            o.N = trk.mCurrentFrame.N;
+            return o;
+        };
+        auto same_direct = [](const DirectOut &a, const DirectOut &b) {
+            return a.N == b.N && a.mp == b.mp && a.from == b.from && a.cache == b.cache && a.keys.size() == b.keys.size() &&
+                   (a.keys.empty() || !std::memcmp(a.keys.data(), b.keys.data(), a.keys.size() * sizeof(cv::KeyPoint)));
+        };
+        const DirectOut r0 = run_direct(false, 0, std::set<MapPoint *>()), b0 = run_direct(true, 0, std::set<MapPoint *>());
+        const DirectOut r1 = run_direct(false, 1, r0.cache), b1 = run_direct(true, 1, r0.cache);
+        if (!same_direct(r0, b0) || !same_direct(r1, b1)) {
+            fprintf(stderr, "Tracking::SearchLocalPointsDirect: the batch binding differs from the reference's per-call body (phase 0: %zu vs %zu keys, phase 1: %zu vs %zu)\n",
+                    r0.keys.size(), b0.keys.size(), r1.keys.size(), b1.keys.size());
+            return 7;
+        }
+        auto dump_direct = [&](const std::string &tag, const DirectOut &o) {
+            dump(dir + "/" + tag + "_keys.bin", o.keys.data(), o.keys.size() * sizeof(cv::KeyPoint));
+            std::vector<int> idx;
+            for (MapPoint *m : o.mp) idx.push_back((int) (m - mps.data()));
+            dump(dir + "/" + tag + "_mp.bin", idx.data(), idx.size() * sizeof(int));
+            dump(dir + "/" + tag + "_from.bin", o.from.data(), o.from.size() * sizeof(int));
+            std::vector<int> c;
+            for (MapPoint *m : o.cache) c.push_back((int) (m - mps.data()));
+            dump(dir + "/" + tag + "_cache.bin", c.data(), c.size() * sizeof(int));
+        };
+        dump_direct("x0", b0);
+        dump_direct("x1", b1);
+        {   // what the two forms cost per frame (median of 7 runs each; the images are in the HBM cache by now)
+            auto med = [&](bool batch, int phase, const std::set<MapPoint *> &c0) {
+                std::vector<double> us;
+                for (int it = 0; it < 7; it++) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    run_direct(batch, phase, c0);
+                    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+                }
+                std::sort(us.begin(), us.end());
+                return us[3];
+            };
+            printf("latency search_local_points_direct_local_map percall_us %.1f batch_us %.1f candidates %zu\n", med(false, 0, std::set<MapPoint *>()),
+                   med(true, 0, std::set<MapPoint *>()), mps.size());
+            printf("latency search_local_points_direct_cache percall_us %.1f batch_us %.1f cached %zu\n", med(false, 1, r0.cache), med(true, 1, r0.cache), r0.cache.size());
+        }
+        {
+            const Eigen::Quaternionf q = aligned.mTcw.unit_quaternion();
+            const float c7[7] = {q.x(), q.y(), q.z(), q.w(), aligned.mTcw.translation()[0], aligned.mTcw.translation()[1], aligned.mTcw.translation()[2]};
+            dump(dir + "/x_pose7.bin", c7, sizeof c7);
+            float Rt[12];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rt[3 * r + c] = aligned.mRcw(r, c);
+            for (int r = 0; r < 3; r++) Rt[9 + r] = aligned.mtcw[r];
+            dump(dir + "/x_pose.bin", Rt, sizeof Rt);
+        }
     }
     // ---- direct-tracked frame: keys carried over from the last frame, no extraction yet -> ExtractORB takes DSO_KEYPOINT (src/Frame.cc:335-337)
     {

@@ -34,8 +34,19 @@ g++ $FLAGS $INC -c "$REF/src/ORBmatcher.cc" -o "$OUT/ref_ORBmatcher.o"
 g++ $FLAGS $INC -c "$REF/src/Align.cc" -o "$OUT/ref_Align.o"
 objcopy --weaken "$OUT/ref_ORBmatcher.o"
 g++ $FLAGS $INC -c "$REF/src/Tracking.cc" -o "$OUT/ref_Tracking.o"
-OBJS="$OUT/ref_Tracking.o $OUT/ref_ORBmatcher.o $OUT/ref_Align.o"
-SRCS="$REF/src/Frame.cc $H/ORBextractor.cc $H/ORBmatcher.cc $H/SparseImageAlign.cc $H/ORBVocabularyDevice.cc $H/ygzf_pool.cc \
+g++ $FLAGS $INC -c "$REF/src/Frame.cc" -o "$OUT/ref_Frame.o"
+# The BATCH bindings (TrackingBatched.cc, FrameStereo.cc) are strong definitions of Tracking::SearchLocalPoints, Tracking::SearchLocalPointsDirect and
+# Frame::ComputeStereoMatches: the reference's objects are weakened, so the product's bodies win and every other member stays the reference's.
+# The reference's OWN bodies of those three stay callable for the comparison the driver makes (same objects, same inputs, per-call form against
+# batch form): a second, all-weak copy of each object in which just these symbols carry another name (its duplicates of everything else lose
+# against the strong originals).
+objcopy --redefine-sym _ZN3ygz8Tracking17SearchLocalPointsEv=ygz_ref_Tracking_SearchLocalPoints \
+        --redefine-sym _ZN3ygz8Tracking23SearchLocalPointsDirectEv=ygz_ref_Tracking_SearchLocalPointsDirect --weaken "$OUT/ref_Tracking.o" "$OUT/ref_Tracking_orig.o"
+objcopy --redefine-sym _ZN3ygz5Frame20ComputeStereoMatchesEv=ygz_ref_Frame_ComputeStereoMatches --weaken "$OUT/ref_Frame.o" "$OUT/ref_Frame_orig.o"
+objcopy --weaken-symbol=_ZN3ygz8Tracking17SearchLocalPointsEv --weaken-symbol=_ZN3ygz8Tracking23SearchLocalPointsDirectEv "$OUT/ref_Tracking.o"
+objcopy --weaken-symbol=_ZN3ygz5Frame20ComputeStereoMatchesEv "$OUT/ref_Frame.o"
+OBJS="$OUT/ref_Tracking.o $OUT/ref_Tracking_orig.o $OUT/ref_Frame.o $OUT/ref_Frame_orig.o $OUT/ref_ORBmatcher.o $OUT/ref_Align.o"
+SRCS="$H/TrackingBatched.cc $H/FrameStereo.cc $H/ORBextractor.cc $H/ORBmatcher.cc $H/SparseImageAlign.cc $H/ORBVocabularyDevice.cc $H/ygzf_pool.cc \
     $REF/Thirdparty/DBoW2/DBoW2/FORB.cpp $REF/Thirdparty/DBoW2/DBoW2/BowVector.cpp $REF/Thirdparty/DBoW2/DBoW2/FeatureVector.cpp \
     $REF/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp $REF/Thirdparty/DBoW2/DUtils/Random.cpp $REF/Thirdparty/DBoW2/DUtils/Timestamp.cpp \
     $ROOT/tests/cpp/boundary_frame.cc $ROOT/tests/cpp/mini_cv_nocompute.cpp $ROOT/oracle/oracle_align.cpp $ROOT/oracle/oracle_direct.cpp"
@@ -67,7 +78,25 @@ g++ -c "$OUT/outside.S" -o "$OUT/outside.o"
 g++ -pthread $OBJS "$OUT/outside_abort.o" "$OUT/outside.o" $LINK -o "$OUT/boundary_frame"
 cp "$OUT/outside.syms" "$OUT/boundary_frame.outside"
 rm -f $OBJS "$OUT/outside.S" "$OUT/outside.o" "$OUT/outside_abort.cc" "$OUT/outside_abort.o" "$OUT/outside.syms" "$OUT/boundary_frame.try"
-rm -f "$OUT/ref_ORBmatcher.o" "$OUT/ref_Align.o"
+rm -f "$OUT/ref_ORBmatcher.o" "$OUT/ref_Align.o" "$OUT/ref_Tracking_orig.o" "$OUT/ref_Frame.o" "$OUT/ref_Frame_orig.o"
 # strong (T) = the product's definition was linked; weak (W) = the reference's body is still the one in use
-nm -C "$OUT/boundary_frame" | grep -E " [TW] ygz::(ORBmatcher::(SearchByProjection|SearchByBoW|SearchForInitialization|FindDirectProjection|Fuse|SearchBySim3|SearchForTriangulation|DescriptorDistance)|SparseImgAlign::run|ORBextractor::operator\(\)|Tracking::(TrackWithSparseAlignment|TrackWithMotionModel|SearchLocalPoints|MonocularInitialization|Relocalization|SearchLocalPointsDirect|TrackReferenceKeyFrame))\(" | sed 's/^[0-9a-f]* //' | sort > "$OUT/boundary_frame.symbols"
+nm -C "$OUT/boundary_frame" | grep -E " [TW] ygz::(ORBmatcher::(SearchByProjection|SearchByBoW|SearchForInitialization|FindDirectProjection|Fuse|SearchBySim3|SearchForTriangulation|DescriptorDistance)|SparseImgAlign::run|ORBextractor::operator\(\)|Frame::ComputeStereoMatches|Tracking::(TrackWithSparseAlignment|TrackWithMotionModel|SearchLocalPoints|MonocularInitialization|Relocalization|SearchLocalPointsDirect|TrackReferenceKeyFrame))\(" | sed 's/^[0-9a-f]* //' | sort > "$OUT/boundary_frame.symbols"
 echo "built $OUT/boundary_frame"
+
+# ---- second target: tests/cpp/bin/libboundary_mappoint.so -- the reference's own src/MapPoint.cc with the REAL include/MapPoint.h (the recipe of
+# oracle/Makefile's ref_mappoint) under the product's MapPointBatch.cc: strong MapPoint::ComputeDistinctiveDescriptors + the batch front end; the
+# reference's body stays reachable as ygz_ref_MapPoint_ComputeDistinctiveDescriptors (tests/cpp/boundary_mappoint.cc compares the three forms).
+MFLAGS="-O2 -std=c++14 -msse4.2 -fPIC -pthread -w -ffp-contract=off -DYGZ_REF_MATCHER -DYGZ_REF_MAPPOINT -DYGZF_WITH_REFERENCE_HEADERS"
+MINC="-I$S -I$ROOT/oracle -I$REF/include -I$REF -I$H -include $S/mini_cv.h"
+g++ $MFLAGS $MINC -c "$REF/src/MapPoint.cc" -o "$OUT/m_MapPoint.o"
+objcopy --redefine-sym _ZN3ygz8MapPoint29ComputeDistinctiveDescriptorsEv=ygz_ref_MapPoint_ComputeDistinctiveDescriptors --weaken "$OUT/m_MapPoint.o" "$OUT/m_MapPoint_orig.o"
+objcopy --weaken-symbol=_ZN3ygz8MapPoint29ComputeDistinctiveDescriptorsEv "$OUT/m_MapPoint.o"
+MOBJS="$OUT/m_MapPoint.o $OUT/m_MapPoint_orig.o"
+i=0
+for f in "$REF/src/ORBmatcher.cc" "$REF/src/Align.cc" "$H/MapPointBatch.cc" "$H/ygzf_pool.cc" "$ROOT/tests/cpp/boundary_mappoint.cc" "$ROOT/oracle/oracle_align.cpp" "$ROOT/oracle/oracle_direct.cpp"; do
+    i=$((i+1)); g++ $MFLAGS $MINC -c "$f" -o "$OUT/m_$i.o"; MOBJS="$MOBJS $OUT/m_$i.o"
+done
+g++ -shared -pthread $MOBJS -L$ROOT/orb_ygz_slam_amd/lib -lygzf -Wl,-rpath,\$ORIGIN/../../../orb_ygz_slam_amd/lib -o "$OUT/libboundary_mappoint.so"
+nm -C "$OUT/libboundary_mappoint.so" | grep -E " [TW] (ygz::MapPoint::ComputeDistinctiveDescriptors|ygz::ComputeDistinctiveDescriptorsBatch|ygz_ref_MapPoint)" | sed 's/^[0-9a-f]* //' | sort > "$OUT/libboundary_mappoint.symbols"
+rm -f $MOBJS
+echo "built $OUT/libboundary_mappoint.so"

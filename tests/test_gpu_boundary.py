@@ -41,6 +41,16 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     out = subprocess.run([EXE, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "boundary ok" in out.stdout
+    lat = [l for l in out.stdout.splitlines() if l.startswith("latency ")]
+    assert len(lat) == 3
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "r04"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04", "boundary_latency.txt"), "w") as fh:
+        fh.write("# tests/cpp/boundary_frame: the reference's own loop bodies (per-call members) against the batch bindings of TrackingBatched.cc, 752x480, ~1000 local points\n")
+        fh.write("\n".join(lat) + "\n")
+    for l in lat:
+        t = l.split()
+        if t[1].startswith("search_local_points_direct"):
+            assert float(t[5]) < float(t[3]), l          # one launch chain per frame beats one per candidate
     rd = lambda name, dt: np.fromfile(tmp_path / name, dt)
     f = np.float32
     oex = oracle.Extractor(NF, 1.2, L, 20, 7)
@@ -57,7 +67,11 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     mb = mbf / f(EUROC["fx"])
     our, odp = oex.compute_stereo_matches(imgL, imgR, kl, dl, kr, dr, float(mb), float(mbf))
     sur, sdp = rd("s_uright.bin", np.float32), rd("s_depth.bin", np.float32)
-    assert (sur.view(np.uint32) == our.view(np.uint32)).all() and (sdp.view(np.uint32) == odp.view(np.uint32)).all()     # reference CPU code on HIP pyramids
+    # Frame::ComputeStereoMatches as ExtractFeatures called it = the product's strong member (FrameStereo.cc -> device); the reference's own CPU body on the
+    # same Frame (the binary has already demanded equality); the extractor shell's entry point called directly
+    assert (sur.view(np.uint32) == our.view(np.uint32)).all() and (sdp.view(np.uint32) == odp.view(np.uint32)).all()
+    assert (rd("s_uright_ref.bin", np.float32).view(np.uint32) == our.view(np.uint32)).all()                               # reference CPU code on HIP pyramids
+    assert (rd("s_depth_ref.bin", np.float32).view(np.uint32) == odp.view(np.uint32)).all()
     assert (rd("s_uright_dev.bin", np.float32).view(np.uint32) == our.view(np.uint32)).all()                               # device ComputeStereoMatches
     assert (rd("s_depth_dev.bin", np.float32).view(np.uint32) == odp.view(np.uint32)).all()
     assert (our >= 0).sum() > 100
@@ -113,7 +127,7 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     strong = [l for l in sym if l.startswith("T ")]
     weak = [l for l in sym if l.startswith("W ")]
     assert all(any(n in l for l in strong) for n in ("FindDirectProjection", "SearchForInitialization", "DescriptorDistance", "SearchByBoW(ygz::KeyFrame*, ygz::Frame&",
-                                                       "SparseImgAlign::run", "ORBextractor::operator()(ygz::Frame*"))
+                                                       "SparseImgAlign::run", "ORBextractor::operator()(ygz::Frame*", "Frame::ComputeStereoMatches"))
     assert sum("ORBmatcher::" in l for l in strong) == 7
     # the reference's own src/Tracking.cc is in the binary, unchanged, and its hot-path callers are there to call the product's definitions above
     for member in ("TrackWithSparseAlignment", "TrackWithMotionModel", "SearchLocalPoints()", "MonocularInitialization", "Relocalization", "SearchLocalPointsDirect",
@@ -152,8 +166,111 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     a3 = rd("t_match.bin", np.int32)
     assert (a3 == np.where(e_m3 >= 0, e_m3, -1)).all() and (a3 >= 0).sum() == e_n3 and e_n3 > 30
     assert visible == int(iv.sum())                                                      # every point the frustum test accepted was counted visible once
+    # ---- Tracking::SearchLocalPointsDirect, batch binding (TrackingBatched.cc; the binary has already demanded that it equals the reference's own body
+    # calling FindDirectProjection once per candidate): against the oracle -- frustum of every point, one candidate per point (its observation in
+    # KF1 = the last frame), keys appended for the successes at least 20 px inside the image
+    x7 = rd("x_pose7.bin", np.float32)
+    assert np.array_equal(x7, p7[:7])
+    xp = rd("x_pose.bin", np.float32)                       # mRcw / mtcw as the Frame holds them
+    Rx, tx = xp[:9].reshape(3, 3), xp[9:]
+    Owx = -(Rx.T @ tx)
+    ivx, pxx, pyx, _, lvx, _ = oracle.is_in_frustum(kn, dn, tab["scale"], w, h, EUROC, world, np.tile(np.array([0, 0, 1], np.float32), (len(kl), 1)),
+                                                    (f(1.2) * mf_max).astype(np.float32), (f(0.8) * mf_max / tab["scale"][L - 1]).astype(np.float32), mf_max,
+                                                    Rx, tx, Owx.astype(np.float32), np.log(f(1.2)), 0.5)
+    sel = np.nonzero(ivx)[0]
+    px0 = np.stack([pxx[sel], pyx[sel]], -1).astype(np.float32)
+    opx, _, ook, _ = oex.find_direct_projection_batch([imgL], imgN, x7, EUROC, np.zeros(len(sel), np.int32), np.tile(ident, (len(sel), 1)), kl[sel], world[sel], px0)
+    inside = (opx[:, 0] >= 20) & (opx[:, 1] >= 20) & (opx[:, 0] < w - 20) & (opx[:, 1] < h - 20)
+    good = ook.astype(bool) & inside
+    k0 = rd("x0_keys.bin", KP_DTYPE)
+    assert len(k0) == good.sum() > 100
+    assert np.array_equal(np.stack([k0["x"], k0["y"]], -1).view(np.uint32), opx[good].view(np.uint32)) and (k0["size"] == 7).all() and (k0["octave"] == 0).all()
+    assert np.array_equal(rd("x0_mp.bin", np.int32), sel[good]) and (rd("x0_from.bin", np.int32) == 3).all()
+    assert np.array_equal(rd("x0_cache.bin", np.int32), sel[good])                    # every matched point went into the cache (a std::set: ascending addresses)
+    # second frame on that cache (the function's first half): coverage grid of 5-px cells, carried from point to point in cache order
+    gcols, taken, exp_mp, exp_xy, exp_cache = w // 5, set(), [], [], []
+    res = {int(i): (bool(g), opx[j]) for j, (i, g) in enumerate(zip(sel, good))}
+    for i in sel[good]:
+        i = int(i)                                                                    # (every cached point is in view again: same pose)
+        cell = int(pyx[i] / f(5)) * gcols + int(pxx[i] / f(5))
+        if cell in taken:
+            exp_cache.append(i)
+            continue
+        g, q = res[i]
+        assert g
+        exp_mp.append(i); exp_xy.append(q); exp_cache.append(i)
+        taken.add(int(q[1] / f(5)) * gcols + int(q[0] / f(5)))
+    k1 = rd("x1_keys.bin", KP_DTYPE)
+    assert len(exp_mp) > 10 and np.array_equal(rd("x1_mp.bin", np.int32), np.array(exp_mp, np.int32))
+    assert np.array_equal(np.stack([k1["x"], k1["y"]], -1).view(np.uint32), np.array(exp_xy, np.float32).view(np.uint32))
+    assert np.array_equal(rd("x1_cache.bin", np.int32), np.array(exp_cache, np.int32)) and len(exp_mp) < len(exp_cache)   # some points were skipped by the grid
     # direct-tracked frame: Frame::ExtractORB took the DSO_KEYPOINT branch
     ko, do, _ = oracle.Extractor(NF, 1.2, L, 20, 7).extract_dso(imgN, existing=kn[:120])
     kd = rd("d_keys.bin", KP_DTYPE)
     assert len(kd) == len(ko) > 120 and (kd == ko).all()
     assert (rd("d_desc.bin", np.uint8).reshape(-1, 32) == do).all()
+
+
+def test_reference_mappoint_over_product_batch(oracle):
+    """tests/cpp/bin/libboundary_mappoint.so: the reference's own src/MapPoint.cc (REAL include/MapPoint.h: private members, mutexes) under the product's
+    MapPointBatch.cc.  On the same MapPoint objects: the reference's own CPU body of ComputeDistinctiveDescriptors, the product's strong member called
+    per point (one device call each) and ygz::ComputeDistinctiveDescriptorsBatch (ONE device call) must pick the same observation -- and the oracle's.
+    Includes points without observations, with one, with bad KeyFrames among them, with identical descriptors (first minimum wins) and with more
+    than 256 observations (the histogram kernel)."""
+    import ctypes as C
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call([os.path.join(ROOT, "tests", "cpp", "build_boundary.sh")])
+    lib = os.path.join(ROOT, "tests", "cpp", "bin", "libboundary_mappoint.so")
+    assert os.path.exists(lib), "tests/cpp/bin/libboundary_mappoint.so missing: run tests/cpp/build_boundary.sh where /root/reference exists"
+    from orb_ygz_slam_amd import load_library
+    load_library()
+    B = C.CDLL(lib)
+    rng = np.random.default_rng(11)
+    counts = [0, 1, 2, 3, 7, 40, 64, 65, 200, 256, 257, 300, 700] + [int(c) for c in rng.integers(1, 30, 60)]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    total = int(off[-1])
+    centres = rng.integers(0, 256, (len(counts), 32), dtype=np.uint8)
+    desc = np.zeros((total, 32), np.uint8)
+    for p, n in enumerate(counts):
+        noise = (rng.random((n, 256)) < 0.12)
+        desc[off[p]:off[p + 1]] = centres[p] ^ np.packbits(noise, axis=1)
+    desc[off[6]:off[6] + 5] = desc[off[6]]                      # ties: several identical rows
+    bad = (rng.random(total) < 0.1).astype(np.uint8)
+    bad[off[1]] = 0
+    bad[off[8]:off[9]] = 1                                      # a point whose KeyFrames are all bad: the descriptor stays untouched
+    out = np.full((len(counts), 3), -9, np.int32)
+    fails = B.bm_distinctive(len(counts), off.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert fails == 0
+    assert (out[:, 0] == out[:, 1]).all() and (out[:, 0] == out[:, 2]).all(), out[(out[:, 0] != out[:, 1]) | (out[:, 0] != out[:, 2])]
+    assert out[0, 0] == -1 and out[8, 0] == -1 and out[1, 0] == 0
+    # and the oracle, on the rows of the KeyFrames that are not bad
+    keep = bad == 0
+    goff = np.concatenate([[0], np.cumsum([int(keep[off[p]:off[p + 1]].sum()) for p in range(len(counts))])]).astype(np.int32)
+    ob = oracle.distinctive_descriptors(goff, desc[keep])
+    for p in range(len(counts)):
+        if goff[p + 1] == goff[p]:
+            assert out[p, 0] == -1
+            continue
+        win = desc[keep][goff[p] + ob[p]]
+        first = next(i for i in range(off[p], off[p + 1]) if (desc[i] == win).all())
+        assert out[p, 0] == first - off[p], p
+    sym = open(lib[:-3] + ".symbols").read()
+    assert "T ygz::MapPoint::ComputeDistinctiveDescriptors()" in sym and "T ygz::ComputeDistinctiveDescriptorsBatch" in sym and "ygz_ref_MapPoint_ComputeDistinctiveDescriptors" in sym
+
+
+def test_shell_failures_are_observable():
+    """The reference's signatures have no error channel, so a shell whose device call fails can only return "nothing": ygzf_host::failure_count() /
+    last_failure() / set_failure_callback make that visible.  Provoked here with a device that does not exist."""
+    import ctypes as C
+    lib = os.path.join(ROOT, "tests", "cpp", "bin", "libboundary_mappoint.so")
+    assert os.path.exists(lib)
+    from orb_ygz_slam_amd import load_library
+    load_library()
+    B = C.CDLL(lib)
+    msg = C.create_string_buffer(512)
+    ncb = C.c_int(0)
+    n = B.bm_provoke_failure(msg, 512, C.byref(ncb))
+    assert n >= 2 and ncb.value == n                  # the batch call and the member's own call both failed, both were counted, the callback saw both
+    text = msg.value.decode()
+    assert "ygz::" in text or "libygzf" in text
+    assert "device" in text.lower()
