@@ -22,7 +22,11 @@
 #include "ygzf_pool.h"
 
 extern "C" void ygz_ref_MapPoint_ComputeDistinctiveDescriptors(ygz::MapPoint *);
-namespace ygz { int ORBextractor::sDevice = 0; }
+namespace ygz {
+int ORBextractor::sDevice = 0;
+// the reference's src/ORBmatcher.cc (in the link for MapPoint.cc's DescriptorDistance) names it; nothing here reaches it
+std::vector<size_t> Frame::GetFeaturesInArea(const float &, const float &, const float &, const int, const int) const { yr_unsupported("Frame::GetFeaturesInArea"); }
+}
 
 extern "C" {
 // points p = 0 .. n_points-1 with the observation descriptors desc[obs_off[p] .. obs_off[p+1]) (one stand-in KeyFrame per observation, bad[...] marks

@@ -99,4 +99,5 @@ done
 g++ -shared -pthread $MOBJS -L$ROOT/orb_ygz_slam_amd/lib -lygzf -Wl,-rpath,\$ORIGIN/../../../orb_ygz_slam_amd/lib -o "$OUT/libboundary_mappoint.so"
 nm -C "$OUT/libboundary_mappoint.so" | grep -E " [TW] (ygz::MapPoint::ComputeDistinctiveDescriptors|ygz::ComputeDistinctiveDescriptorsBatch|ygz_ref_MapPoint)" | sed 's/^[0-9a-f]* //' | sort > "$OUT/libboundary_mappoint.symbols"
 rm -f $MOBJS
+if ldd -r "$OUT/libboundary_mappoint.so" 2>&1 | grep -q "undefined symbol"; then ldd -r "$OUT/libboundary_mappoint.so" 2>&1 | grep "undefined symbol"; exit 1; fi
 echo "built $OUT/libboundary_mappoint.so"

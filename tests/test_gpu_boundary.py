@@ -48,9 +48,9 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
         fh.write("# tests/cpp/boundary_frame: the reference's own loop bodies (per-call members) against the batch bindings of TrackingBatched.cc, 752x480, ~1000 local points\n")
         fh.write("\n".join(lat) + "\n")
     for l in lat:
-        t = l.split()
-        if t[1].startswith("search_local_points_direct"):
-            assert float(t[5]) < float(t[3]), l          # one launch chain per frame beats one per candidate
+        tok = l.split()
+        if tok[1].startswith("search_local_points_direct"):
+            assert float(tok[5]) < float(tok[3]), l          # one launch chain per frame beats one per candidate
     rd = lambda name, dt: np.fromfile(tmp_path / name, dt)
     f = np.float32
     oex = oracle.Extractor(NF, 1.2, L, 20, 7)
