@@ -196,6 +196,16 @@ struct Aligner {
     bool stop_ = false;
     float eps_ = 0.000001f;
     int iters_total = 0;
+    // ---- device-order mode (test infrastructure for the HIP kernel, not a restatement of the reference) ---------------------------------------
+    // The reference sums J J^T, J res and res^2 pixel by pixel, feature after feature.  k_sia_run (orb_ygz_slam_amd/csrc/align_kernels.hip) forms the
+    // same sums from per-feature gradient moments (H_feature = Sxx Jf0 Jf0^T + Sxy (Jf0 Jf1^T + Jf1 Jf0^T) + Syy Jf1 Jf1^T), with fused multiply-adds
+    // at stated places, 512 threads striding over the features and a fixed reduction tree.  With device_order_ this class evaluates computeResiduals
+    // with exactly that arithmetic -- same formulation, same fmaf placement, same tree -- so that the kernel's H, b and chi2 can be demanded BIT FOR
+    // BIT (tests/test_gpu_align.py, tests/test_gpu_fuzz.py) instead of being bounded by a re-ordering allowance.  Everything else (precompute values,
+    // visibility, solve, update, stop rules) is shared with the reference-order mode.
+    bool device_order_ = false;
+    std::vector<float> dx_cache_, dy_cache_;   // N x 16: central-difference gradients of the reference patch (device-order mode)
+    std::vector<float> mom_cache_;             // N x 3: sum dx*dx, dx*dy, dy*dy over the patch, fmaf chain in pixel order
 
     Aligner(const AlignFrame &r, const AlignFrame &c) : ref(r), cur(c) {}
 
@@ -256,16 +266,119 @@ struct Aligner {
                                        (w_ref_tl * p[-stride] + w_ref_tr * p[1 - stride] + w_ref_bl * p[0] + w_ref_br * p[1]));
                     float *J = &jacobian_cache_[((size_t) i * patch_area_ + pixel_counter) * 6];
                     for (int k = 0; k < 6; k++) J[k] = (dx * frame_jac[k] + dy * frame_jac[6 + k]) * (focal_length * scale);
+                    if (device_order_) {
+                        dx_cache_[(size_t) i * patch_area_ + pixel_counter] = dx;
+                        dy_cache_[(size_t) i * patch_area_ + pixel_counter] = dy;
+                    }
                 }
+            }
+            if (device_order_) {   // align_kernels.hip: sxx / sxy / syy, one fmaf per term in pixel order
+                float sxx = 0.f, sxy = 0.f, syy = 0.f;
+                for (int p2 = 0; p2 < patch_area_; p2++) {
+                    const float dx = dx_cache_[(size_t) i * patch_area_ + p2], dy = dy_cache_[(size_t) i * patch_area_ + p2];
+                    sxx = std::fmaf(dx, dx, sxx);
+                    sxy = std::fmaf(dx, dy, sxy);
+                    syy = std::fmaf(dy, dy, syy);
+                }
+                mom_cache_[3 * (size_t) i] = sxx; mom_cache_[3 * (size_t) i + 1] = sxy; mom_cache_[3 * (size_t) i + 2] = syy;
             }
         }
         have_ref_patch_cache_ = true;
     }
 
     // :130-231 (use_weights_ == false, display_ == false in the reference's only call site)
+    // k_sia_run's accumulate phase and reduction (align_kernels.hip: the feature loop of optimizeGaussNewton, wave_sums_30, the cross-wave sum)
+    float computeResidualsDeviceOrder(const SE3f &T) {
+        const Image &cur_img = *cur.pyramid[level_];
+        const int stride = cur_img.w, border = patch_halfsize_ + 1;
+        const float scale = ref.invScaleFactors[level_];
+        const int kBlock = 512, kAcc = 30;
+        std::vector<float> acc((size_t) kBlock * kAcc, 0.f);     // thread t, accumulator k at [t * 30 + k]
+        for (int i = 0; i < ref.N; i++) {
+            if (!visible_fts_[i]) continue;
+            float *a = &acc[(size_t) (i % kBlock) * kAcc];        // thread i % 512 takes features i, i + 512, ... in ascending order
+            float xr[3], xc[3];
+            ref.Tcw.Act(&ref.mp_world[3 * i], xr);
+            T.Act(xr, xc);
+            const float ucx = cur.fx * xc[0] / xc[2] + cur.cx, ucy = cur.fy * xc[1] / xc[2] + cur.cy;
+            const float u_cur = ucx * scale, v_cur = ucy * scale;
+            const int ui = (int) floorf(u_cur), vi = (int) floorf(v_cur);
+            if (ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 || ui + border >= cur_img.w || vi + border >= cur_img.h) continue;
+            a[29] += 1.f;
+            const float su = u_cur - ui, sv = v_cur - vi;
+            const float usu = 1.f - su, usv = 1.f - sv;
+            const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
+            float J[12];
+            JacobXYZ2Cam(xr, J);
+            const float fs = ref.fx * scale;
+            float Jf[12];
+            for (int k = 0; k < 12; k++) Jf[k] = J[k] * fs;
+            a[28] += 16.f;
+            float sxr = 0.f, syr = 0.f;
+            for (int y = 0; y < patch_size_; y++) {
+                const uint8_t *p = &cur_img.d[(size_t) (vi + y - patch_halfsize_) * stride + (ui - patch_halfsize_)];
+                for (int x = 0; x < patch_size_; x++, p++) {
+                    const float I = std::fmaf(w_br, (float) p[stride + 1], std::fmaf(w_bl, (float) p[stride], std::fmaf(w_tr, (float) p[1], w_tl * (float) p[0])));
+                    const size_t pc = (size_t) i * patch_area_ + 4 * y + x;
+                    const float res = I - ref_patch_cache_[pc];
+                    a[27] = std::fmaf(res, res, a[27]);
+                    sxr = std::fmaf(dx_cache_[pc], res, sxr);
+                    syr = std::fmaf(dy_cache_[pc], res, syr);
+                }
+            }
+            const float Sx = mom_cache_[3 * (size_t) i], Sy = mom_cache_[3 * (size_t) i + 1], Sz = mom_cache_[3 * (size_t) i + 2];
+            float P[6], Q[6];
+            P[0] = Sx * Jf[0]; Q[0] = Sy * Jf[0];
+            P[1] = Sy * Jf[7]; Q[1] = Sz * Jf[7];
+            for (int k = 2; k < 6; k++) {
+                P[k] = std::fmaf(Sy, Jf[6 + k], Sx * Jf[k]);
+                Q[k] = std::fmaf(Sz, Jf[6 + k], Sy * Jf[k]);
+            }
+            for (int b2 = 0; b2 < 6; b2++) a[b2] = std::fmaf(Jf[0], P[b2], a[b2]);
+            for (int b2 = 1; b2 < 6; b2++) a[5 + b2] = std::fmaf(Jf[7], Q[b2], a[5 + b2]);
+            int t = 11;
+            for (int r = 2; r < 6; r++)
+                for (int b2 = r; b2 < 6; b2++, t++) {
+                    a[t] = std::fmaf(Jf[r], P[b2], a[t]);
+                    a[t] = std::fmaf(Jf[6 + r], Q[b2], a[t]);
+                }
+            a[21] = std::fmaf(-Jf[0], sxr, a[21]);
+            a[22] = std::fmaf(-Jf[7], syr, a[22]);
+            for (int k = 2; k < 6; k++) {
+                a[21 + k] = std::fmaf(-Jf[k], sxr, a[21 + k]);
+                a[21 + k] = std::fmaf(-Jf[6 + k], syr, a[21 + k]);
+            }
+        }
+        // wave_sums_30: lanes l and l + 32, then rows of 16 lanes, then inside a row pairs, quads, the quad 12 lanes on, the half 8 lanes on (DPP
+        // row_ror); then the eight waves in order
+        float tot[30];
+        for (int k = 0; k < kAcc; k++) {
+            float v = 0.f;
+            for (int w = 0; w < kBlock / 64; w++) {
+                float y[16];
+                for (int j = 0; j < 16; j++) {
+                    auto X = [&](int l) { return acc[(size_t) (64 * w + l) * kAcc + k]; };
+                    y[j] = (X(j) + X(j + 32)) + (X(j + 16) + X(j + 48));
+                }
+                float q[4];
+                for (int g = 0; g < 4; g++) q[g] = (y[4 * g] + y[4 * g + 1]) + (y[4 * g + 2] + y[4 * g + 3]);
+                v += (q[0] + q[3]) + (q[2] + q[1]);
+            }
+            tot[k] = v;
+        }
+        std::memset(H_, 0, sizeof(H_));
+        int t = 0;
+        for (int r = 0; r < 6; r++)
+            for (int c = r; c < 6; c++, t++) H_[6 * r + c] = H_[6 * c + r] = tot[t];
+        for (int k = 0; k < 6; k++) Jres_[k] = tot[21 + k];
+        n_meas_ = (size_t) tot[28];
+        return tot[27] / tot[28];
+    }
+
     float computeResiduals(const SE3f &T_cur_from_ref, bool linearize_system) {
         const Image &cur_img = *cur.pyramid[level_];
         if (!have_ref_patch_cache_) precomputeReferencePatches();
+        if (device_order_ && linearize_system) return computeResidualsDeviceOrder(T_cur_from_ref);
         const int stride = cur_img.w;
         const int border = patch_halfsize_ + 1;
         const float scale = ref.invScaleFactors[level_];
@@ -338,11 +451,17 @@ struct Aligner {
 };
 }  // namespace
 
-AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level, int n_iter) {
+AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level, int n_iter, bool device_order) {
     AlignResult out;
     std::memset(out.H, 0, sizeof(out.H));
     if (ref.N == 0) return out;  // :24-27
     Aligner A(ref, cur);
+    A.device_order_ = device_order;
+    if (device_order) {
+        A.dx_cache_.assign((size_t) ref.N * 16, 0.f);
+        A.dy_cache_.assign((size_t) ref.N * 16, 0.f);
+        A.mom_cache_.assign((size_t) ref.N * 3, 0.f);
+    }
     A.ref_patch_cache_.assign((size_t) ref.N * 16, 0.f);
     A.jacobian_cache_.assign((size_t) ref.N * 16 * 6, 0.f);
     A.visible_fts_.assign(ref.N, 0);

@@ -395,8 +395,8 @@ struct yo_align_frame {
 };
 
 // returns n_meas/16; out7 = TCR; info[0] = total linearisations, info[1] = chi2
-size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur, int max_level, int min_level, int n_iter,
-                           float out7[7], float info[2], float H36[36]) {
+size_t yo_sparse_img_align_mode(const yo_align_frame *ref, const yo_align_frame *cur, int max_level, int min_level, int n_iter,
+                                float out7[7], float info[2], float H36[36], int device_order) {
     std::vector<Image> rimgs(ref->nlevels), cimgs(cur->nlevels);
     AlignFrame R, C;
     auto fill = [](const yo_align_frame *f, std::vector<Image> &imgs, AlignFrame &A) {
@@ -417,12 +417,16 @@ size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur,
     };
     fill(ref, rimgs, R);
     fill(cur, cimgs, C);
-    AlignResult r = sparse_img_align(R, C, max_level, min_level, n_iter);
+    AlignResult r = sparse_img_align(R, C, max_level, min_level, n_iter, device_order != 0);
     std::memcpy(out7, r.TCR.q, 16);
     std::memcpy(out7 + 4, r.TCR.t, 12);
     if (info) { info[0] = (float) r.iters_total; info[1] = r.chi2; }
     if (H36) std::memcpy(H36, r.H, sizeof(r.H));
     return r.ret;
+}
+size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur, int max_level, int min_level, int n_iter,
+                           float out7[7], float info[2], float H36[36]) {
+    return yo_sparse_img_align_mode(ref, cur, max_level, min_level, n_iter, out7, info, H36, 0);
 }
 
 // Frame::ComputeStereoMatches on two images: both pyramids are computed with extractor e (as the two ORBextractor instances do)

@@ -623,8 +623,9 @@ def _align_frame(keys, mp_valid, outlier, mp_world, Tcw7, pyramid, inv_scale, ca
 
 
 def sparse_img_align(ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, cam, max_level, min_level, n_iter=10,
-                     mp_valid=None, outlier=None):
-    """Oracle SparseImgAlign(max_level, min_level, n_iter).run(ref, cur, TCR) -> (ret, TCR7 (qx qy qz qw tx ty tz), info, H)."""
+                     mp_valid=None, outlier=None, device_order=False):
+    """Oracle SparseImgAlign(max_level, min_level, n_iter).run(ref, cur, TCR) -> (ret, TCR7 (qx qy qz qw tx ty tz), info, H).
+    device_order: the normal equations in the HIP kernel's formulation / fused multiply-adds / reduction tree (bit-for-bit comparison mode)."""
     keep = []
     R = _align_frame(ref_keys, mp_valid, outlier, ref_world, ref_Tcw7, ref_pyr, inv_scale, cam, keep)
     Cf = _align_frame(np.zeros(0, KP_DTYPE), None, None, None, cur_Tcw7, cur_pyr, inv_scale, cam, keep)
@@ -632,6 +633,12 @@ def sparse_img_align(ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, 
     info = np.zeros(2, np.float32)
     H = np.zeros(36, np.float32)
     L = lib()
+    if device_order:
+        L.yo_sparse_img_align_mode.restype = C.c_size_t
+        L.yo_sparse_img_align_mode.argtypes = [C.POINTER(_YoAlignFrame), C.POINTER(_YoAlignFrame), C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_int]
+        ret = L.yo_sparse_img_align_mode(C.byref(R), C.byref(Cf), max_level, min_level, n_iter, _p(out7), _p(info), _p(H), 1)
+        return int(ret), out7, info, H.reshape(6, 6)
     L.yo_sparse_img_align.argtypes = [C.POINTER(_YoAlignFrame), C.POINTER(_YoAlignFrame), C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]
     ret = L.yo_sparse_img_align(C.byref(R), C.byref(Cf), max_level, min_level, n_iter, _p(out7), _p(info), _p(H))

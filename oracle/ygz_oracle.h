@@ -253,8 +253,10 @@ struct AlignResult {
 };
 bool ldlt_solve6(const float H[36], const float b[6], float x[6]);   // x = H.ldlt().solve(b): pivoted LDL^T in float (oracle_align.cpp)
 // SparseImgAlign(max_level, min_level, n_iter=10, GaussNewton).run(ref, cur, TCR)  src/SparseImageAlign.cc:20-49
+// device_order: the normal equations evaluated with the HIP kernel's formulation, fused multiply-adds and reduction tree (oracle_align.cpp) --
+// the mode the kernel is compared with BIT FOR BIT; false = the reference's own pixel-by-pixel order
 AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level,
-                             int n_iter);
+                             int n_iter, bool device_order = false);
 
 // ---- ORBmatcher::FindDirectProjection + Align2D  src/ORBmatcher.cc:1525-1602, src/Align.cc:8-104 -------------------------------------
 struct DirectRef {   // the reference KeyFrame's slice

@@ -398,10 +398,14 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                     rc[(3 * y) * plane] = make_float4(o[0], o[1], o[2], o[3]);
                     rc[(3 * y + 1) * plane] = make_float4(o[4], o[5], o[6], o[7]);
                     rc[(3 * y + 2) * plane] = make_float4(o[8], o[9], o[10], o[11]);
-                    {
-#pragma clang fp contract(fast)
+                    // (explicit fused multiply-adds, here and in the accumulate phase below: the library is built -ffp-contract=off, and WHICH
+                    // products are fused is part of this kernel's definition -- oracle/oracle_align.cpp's device-order mode repeats them with
+                    // fmaf and must reproduce H, b and chi2 bit for bit, tests/test_gpu_align.py)
 #pragma unroll
-                        for (int x = 0; x < 4; x++) { sxx += o[4 + x] * o[4 + x]; sxy += o[4 + x] * o[8 + x]; syy += o[8 + x] * o[8 + x]; }
+                    for (int x = 0; x < 4; x++) {
+                        sxx = __builtin_fmaf(o[4 + x], o[4 + x], sxx);
+                        sxy = __builtin_fmaf(o[4 + x], o[8 + x], sxy);
+                        syy = __builtin_fmaf(o[8 + x], o[8 + x], syy);
                     }
                 }
                 mom[i] = make_float4(sxx, sxy, syy, 0.f);
@@ -495,9 +499,8 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 // -- moments of the reference patch, constant over the iterations of a level (precompute above) -- and its share of
                 // Jres = -sum_p J_p res_p is -(Jf0 * sum dx*res + Jf1 * sum dy*res).  Per pixel that leaves the interpolation, the residual and
                 // three multiply-adds (8 instructions instead of ~45); per feature 66 for H and 12 for Jres.  This block -- and only this
-                // block -- lets the compiler contract a*b + c into v_fma_f32: the accumulate phase is issue-bound at two waves per SIMD.
+                // block -- uses fused multiply-adds (v_fma_f32, written out: the accumulate phase is issue-bound at two waves per SIMD).
                 {
-#pragma clang fp contract(fast)
                     float sxr = 0.f, syr = 0.f;
 #pragma unroll
                     for (int y = 0; y < 4; y++) {
@@ -505,11 +508,11 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                         const float pcv[4] = {pc.x, pc.y, pc.z, pc.w}, dxa[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, dya[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
 #pragma unroll
                         for (int x = 0; x < 4; x++) {
-                            const float I = w_tl * tf[y][x] + w_tr * tf[y][x + 1] + w_bl * tf[y + 1][x] + w_br * tf[y + 1][x + 1];
+                            const float I = __builtin_fmaf(w_br, tf[y + 1][x + 1], __builtin_fmaf(w_bl, tf[y + 1][x], __builtin_fmaf(w_tr, tf[y][x + 1], w_tl * tf[y][x])));
                             const float res = I - pcv[x];
-                            acc[27] += res * res;
-                            sxr += dxa[x] * res;
-                            syr += dya[x] * res;
+                            acc[27] = __builtin_fmaf(res, res, acc[27]);
+                            sxr = __builtin_fmaf(dxa[x], res, sxr);
+                            syr = __builtin_fmaf(dya[x], res, syr);
                         }
                     }
                     // Jf[1] and Jf[6] are structural zeros of JacobXYZ2Cam (their products are exact zeros in the reference's sums): left out
@@ -519,28 +522,28 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                     P[1] = S.y * Jf[7]; Q[1] = S.z * Jf[7];
 #pragma unroll
                     for (int k = 2; k < 6; k++) {
-                        P[k] = S.x * Jf[k] + S.y * Jf[6 + k];
-                        Q[k] = S.y * Jf[k] + S.z * Jf[6 + k];
+                        P[k] = __builtin_fmaf(S.y, Jf[6 + k], S.x * Jf[k]);
+                        Q[k] = __builtin_fmaf(S.z, Jf[6 + k], S.y * Jf[k]);
                     }
                     // H[a][b] += Jf0[a] * P[b] + Jf1[a] * Q[b], upper triangle in the accumulators' order
 #pragma unroll
-                    for (int b2 = 0; b2 < 6; b2++) acc[b2] += Jf[0] * P[b2];
+                    for (int b2 = 0; b2 < 6; b2++) acc[b2] = __builtin_fmaf(Jf[0], P[b2], acc[b2]);
 #pragma unroll
-                    for (int b2 = 1; b2 < 6; b2++) acc[5 + b2] += Jf[7] * Q[b2];
+                    for (int b2 = 1; b2 < 6; b2++) acc[5 + b2] = __builtin_fmaf(Jf[7], Q[b2], acc[5 + b2]);
                     int t = 11;
 #pragma unroll
                     for (int a = 2; a < 6; a++)
 #pragma unroll
                         for (int b2 = a; b2 < 6; b2++, t++) {
-                            acc[t] += Jf[a] * P[b2];
-                            acc[t] += Jf[6 + a] * Q[b2];
+                            acc[t] = __builtin_fmaf(Jf[a], P[b2], acc[t]);
+                            acc[t] = __builtin_fmaf(Jf[6 + a], Q[b2], acc[t]);
                         }
-                    acc[21] -= Jf[0] * sxr;
-                    acc[22] -= Jf[7] * syr;
+                    acc[21] = __builtin_fmaf(-Jf[0], sxr, acc[21]);
+                    acc[22] = __builtin_fmaf(-Jf[7], syr, acc[22]);
 #pragma unroll
                     for (int k = 2; k < 6; k++) {
-                        acc[21 + k] -= Jf[k] * sxr;
-                        acc[21 + k] -= Jf[6 + k] * syr;
+                        acc[21 + k] = __builtin_fmaf(-Jf[k], sxr, acc[21 + k]);
+                        acc[21 + k] = __builtin_fmaf(-Jf[6 + k], syr, acc[21 + k]);
                     }
                 }
             }

@@ -127,6 +127,32 @@ def test_align_batch_prev_after_extract_ahead(oracle):
     assert moved >= 2                           # a frame aligned against itself would give the identity
 
 
+def test_normal_equations_bit_identical_to_the_device_order_oracle(oracle):
+    """One linearisation per pyramid level (n_iter = 1, max_level = min_level): the kernel's H, chi2, measurement count and updated SE3 equal the oracle's
+    device-order mode bit for bit -- the kernel's per-feature moment formulation, its fused multiply-adds and its reduction tree are restated there
+    (oracle/oracle_align.cpp) on top of the reference's algorithm.  And so does a full coarse-to-fine run."""
+    from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+    w, h = 752, 480
+    imgA, imgB, _, bp = two_view_scene(11, w, h, EUROC, Z=3.0, rotvec=(0.002, -0.003, 0.001), trans=(0.01, -0.003, 0.002))
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    k, _ = ex.extract(imgA)
+    pa, pb = ex.compute_pyramid(imgA), ex.compute_pyramid(imgB)
+    world = bp(k["x"], k["y"])
+    inv = ex.tables()["inv_scale"]
+    cam = make_camera(w, h)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    bits = lambda a: np.ascontiguousarray(np.asarray(a, np.float32)).reshape(-1).view(np.uint32)
+    for (mx, mn, it) in [(l, l, 1) for l in range(8)] + [(7, 1, 10), (4, 0, 3)]:
+        g = ex.sia_run(cam, k, world, ident, pa, ident, pb, inv, mx, mn, it)
+        o = oracle.sparse_img_align(k, world, ident, pa, ident, pb, inv, EUROC, mx, mn, it, device_order=True)
+        assert g[0] == o[0] > 500
+        assert np.array_equal(bits(g[3]), bits(o[3])), ("H", mx, mn, it)
+        assert np.array_equal(bits(g[2]), bits(o[2])), ("iterations / chi2", mx, mn, it, g[2], o[2])
+        assert np.array_equal(bits(g[1]), bits(o[1])), ("SE3", mx, mn, it, g[1], o[1])
+        r = oracle.sparse_img_align(k, world, ident, pa, ident, pb, inv, EUROC, mx, mn, it)      # the reference's own summation order: north_star's tolerance
+        assert np.abs(g[1] - r[1]).max() <= TOL
+
+
 def test_align_large_batch_equals_small_batches():
     """Launches of 128 pairs and more keep their workgroups to 74 KB of LDS (two per CU: the coarse levels are then gathered from L2 instead
     of a staged copy): the same bytes read, so the same poses bit for bit as launches of a few pairs."""

@@ -104,3 +104,25 @@ def test_sparse_img_align_recovers_motion(oracle):
     r1, _, _, _ = oracle.sparse_img_align(s["k"], s["world"], ident, s["pyrA"], ident, s["pyrB"], s["inv"], EUROC, 7, 1,
                                           outlier=np.ones(len(s["k"]), np.uint8))
     assert r1 == 0
+
+
+def test_device_order_mode_is_the_same_algorithm(oracle):
+    """The oracle's device-order mode (the summation the HIP kernel is compared with bit for bit) differs from the reference-order mode by rounding
+    only: same measurement count, same iteration count, SE3 within a few 1e-7 on a well-conditioned scene; and it is deterministic."""
+    from orb_ygz_slam_amd.capi import EUROC
+    from orb_ygz_slam_amd.scene import two_view_scene
+    w, h = 752, 480
+    A, B, _, bp = two_view_scene(11, w, h, EUROC, Z=3.0, rotvec=(0.002, -0.003, 0.001), trans=(0.01, -0.003, 0.002))
+    oex = oracle.Extractor(600, 1.2, 8, 20, 7)
+    k, _ = oex.extract(A)
+    world = bp(k["x"], k["y"])
+    ident = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)
+    inv = oex.tables()["inv_scale"]
+    pa, pb = oex.pyramid(A), oex.pyramid(B)
+    r = oracle.sparse_img_align(k, world, ident, pa, ident, pb, inv, EUROC, 7, 1)
+    d = oracle.sparse_img_align(k, world, ident, pa, ident, pb, inv, EUROC, 7, 1, device_order=True)
+    d2 = oracle.sparse_img_align(k, world, ident, pa, ident, pb, inv, EUROC, 7, 1, device_order=True)
+    assert r[0] == d[0] > 300 and abs(r[2][0] - d[2][0]) <= 1
+    assert np.abs(r[1] - d[1]).max() < 2e-6 and not np.array_equal(r[1], d[1])
+    assert np.array_equal(d[1], d2[1]) and np.array_equal(d[3], d2[3])
+    assert np.allclose(np.asarray(r[3]), np.asarray(d[3]), rtol=1e-4)
