@@ -145,6 +145,9 @@ int ygzf_extract_batch_device(ygzf_ctx *ctx, const uint8_t *d_imgs, int n_frames
 /* Same, host frames (H2D copy of each frame included).  The copy is asynchronous too: `imgs` must stay valid and unchanged until the next
  * synchronising call on this context (ygzf_sync, ygzf_batch_counts, ygzf_batch_fetch*, ...); page-locked memory gives the full PCIe rate. */
 int ygzf_extract_batch_host(ygzf_ctx *ctx, const uint8_t *imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride);
+/* Same from a list of frame pointers (the data pointers of an array of cv::Mat; a round-robin share of a larger clip): frames[f] = level 0 of
+ * frame f, rows of row_pitch bytes.  One copy per frame on the context's stream, asynchronous when the memory is page-locked. */
+int ygzf_extract_batch_host_frames(ygzf_ctx *ctx, const uint8_t *const *frames, int n_frames, int w, int h, int row_pitch);
 int ygzf_batch_counts(ygzf_ctx *ctx, int *n_kp /* n_frames ints */);
 int ygzf_batch_fetch(ygzf_ctx *ctx, int frame, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out);
 /* All frames of the batch with one synchronisation: kps / desc hold n_frames rows of `stride` (>= ygzf_max_keypoints) entries, frame f's
@@ -390,6 +393,8 @@ int ygzf_compute_stereo_matches(ygzf_ctx *ctx, const uint8_t *img_left, const ui
  * on the device.  ygzf_stereo_fetch copies pair p's mvuRight / mvDepth (as many as the left frame has keypoints). */
 int ygzf_stereo_batch(ygzf_ctx *ctx, float mb, float mbf);
 int ygzf_stereo_fetch(ygzf_ctx *ctx, int pair, float *u_right, float *depth, int cap);
+/* all pairs at once: rows of `stride` (>= ygzf_max_keypoints) floats; row p's first n_kp[2 p] entries (left keypoints) are valid */
+int ygzf_stereo_fetch_all(ygzf_ctx *ctx, float *u_right, float *depth, int stride);
 
 /* ---- ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level)
  *      src/ORBmatcher.cc:1574-1602 with GetWarpAffineMatrix :1525-1548, GetBestSearchLevel / GetBilateralInterpUchar
@@ -446,7 +451,15 @@ int ygzf_fast10(ygzf_ctx *ctx, const uint8_t *img, int img_w, int img_h, int str
  * the split); a device index that does not exist is YGZF_ERR_NO_DEVICE.
  * ygzf_mgpu_extract_match: ORBextractor::operator() of every frame and, when match / nmatches are given, SearchByProjection(frame i, frame
  * i - 1) inside every unit with the synthetic scenario of ygzf_match_batch_prev (first frame of a unit: nmatches = -1, match row = -1).
- * kps / desc / match hold n_frames rows of `stride` (>= ygzf_mgpu_keypoint_stride) entries; frame f's first n_kp[f] entries are valid. */
+ * kps / desc / match hold n_frames rows of `stride` (>= ygzf_mgpu_keypoint_stride) entries; frame f's first n_kp[f] entries are valid.
+ * ygzf_mgpu_extract_stereo: the frames are (left, right) pairs (frames 2p, 2p + 1; BASELINE.json's 3840x2160 stereo configuration): extraction of
+ * both eyes and Frame::ComputeStereoMatches of every pair (ygzf_stereo_batch), a pair never leaves its device.  u_right / depth hold n_frames / 2
+ * rows of `stride` floats, row p's first n_kp[2 p] entries valid (-1: no match).
+ * Inside a device slot the frames go through in unit-aligned chunks on two alternating contexts: while one chunk is in its kernels the next
+ * one's frames go up and the previous one's results come down.  Frames that already lie in page-locked host memory (hipHostMalloc /
+ * hipHostRegister -- detected with hipPointerGetAttributes) are copied to the device from where they lie; pageable frames are gathered into the
+ * slot's own page-locked staging first.  The slot threads are bound to the CPUs of their device's NUMA node when sysfs reports one
+ * (YGZF_MGPU_NUMA=0 switches that off). */
 typedef struct ygzf_mgpu ygzf_mgpu;
 int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg *cfg, int max_width, int max_height, int max_frames_per_device,
                      ygzf_mgpu **out);
@@ -458,6 +471,9 @@ int ygzf_mgpu_slot_of_frame(const ygzf_mgpu *m, int frame, int unit);   /* which
 int ygzf_mgpu_extract_match(ygzf_mgpu *m, const uint8_t *frames, int n_frames, int w, int h, int row_pitch, size_t frame_stride, int unit,
                             const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation, ygzf_kp *kps, uint8_t *desc,
                             int *n_kp, int stride, int *match, int *nmatches);
+int ygzf_mgpu_extract_stereo(ygzf_mgpu *m, const uint8_t *frames, int n_frames, int w, int h, int row_pitch, size_t frame_stride, float mb, float mbf,
+                             ygzf_kp *kps, uint8_t *desc, int *n_kp, int stride, float *u_right, float *depth);
+int ygzf_mgpu_chunk_frames(const ygzf_mgpu *m);   /* frames per chunk inside a slot (units up to this size alternate between the slot's two contexts) */
 
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------
  * HIP events recorded on the context stream (the stream every kernel of this context is launched on). */

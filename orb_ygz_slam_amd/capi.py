@@ -846,3 +846,21 @@ class MultiGpu:
         if rc != 0:
             raise YgzfError("ygzf_mgpu_extract_match failed (%d): %s" % (rc, self.L.ygzf_mgpu_last_error(self.h).decode()))
         return k, d, c, m, nm
+
+    def chunk_frames(self):
+        return self.L.ygzf_mgpu_chunk_frames(self.h)
+
+    def extract_stereo(self, frames, mb, mbf, out=None):
+        """frames = (left, right) pairs -> (kps [n, stride], desc [n, stride, 32], n_kp [n], u_right [n/2, stride], depth [n/2, stride])"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w = frames.shape
+        if out is None:
+            out = (np.zeros((n, self.stride), KP_DTYPE), np.zeros((n, self.stride, 32), np.uint8), np.zeros(n, np.int32),
+                   np.full((n // 2, self.stride), -1, np.float32), np.full((n // 2, self.stride), -1, np.float32))
+        k, d, c, ur, dp = out
+        self.L.ygzf_mgpu_extract_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        rc = self.L.ygzf_mgpu_extract_stereo(self.h, _p(frames), n, w, h, w, w * h, mb, mbf, _p(k), _p(d), _p(c), self.stride, _p(ur), _p(dp))
+        if rc != 0:
+            raise YgzfError("ygzf_mgpu_extract_stereo failed (%d): %s" % (rc, self.L.ygzf_mgpu_last_error(self.h).decode()))
+        return k, d, c, ur, dp

@@ -1201,6 +1201,34 @@ int ygzf_extract_batch_host(ygzf_ctx *c, const uint8_t *imgs, int n_frames, int 
     return run_extract(c, fs, n_frames);
 }
 
+// The same from a list of frame pointers (frames that do not sit at one stride: the rows of an array of cv::Mat, a round-robin share of a
+// larger clip).  Each frame is one (asynchronous, when the memory is page-locked) copy on the context's stream; the call returns once the
+// extraction is queued, like ygzf_extract_batch_host.
+int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, int n_frames, int w, int h, int row_pitch) {
+    if (!c || !frames) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (n_frames < 1) return fail(c, YGZF_ERR_INVALID, "no frames");
+    if (row_pitch < w) return fail(c, YGZF_ERR_INVALID, "row_pitch %d < width %d", row_pitch, w);
+    for (int f = 0; f < n_frames; f++)
+        if (!frames[f]) return fail(c, YGZF_ERR_INVALID, "frame %d is null", f);
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = apply_geometry(c, w, h, n_frames);
+    if (rc) return rc;
+    c->pyrResident = false;
+    c->aheadPending = false;
+    c->pyrHeld = false;
+    const int pitch = align_up(w, 64);
+    if ((rc = ensure(c, c->dImg0, (size_t) n_frames * pitch * h))) return rc;
+    for (int f = 0; f < n_frames; f++)
+        if ((rc = upload_rows(c, (uint8_t *) c->dImg0.p + (size_t) f * pitch * h, (size_t) pitch, frames[f], (size_t) row_pitch, w, (size_t) h))) return rc;
+    FrameSet fs;
+    fs.img0 = (const uint8_t *) c->dImg0.p;
+    fs.img0_stride = (long long) pitch * h;
+    fs.img0_pitch = pitch;
+    fs.pyr = (uint8_t *) c->dPyr.p;
+    fs.pyr_stride = c->geo.pyrBytes;
+    return run_extract(c, fs, n_frames);
+}
+
 int ygzf_batch_counts(ygzf_ctx *c, int *n_kp) {
     if (!c || !n_kp) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
@@ -2838,6 +2866,18 @@ int ygzf_stereo_fetch(ygzf_ctx *c, int pair, float *u_right, float *depth, int c
     const size_t off = (size_t) pair * c->geo.kpStride;
     HIPCHECK(c, hipMemcpyAsync(u_right, (float *) c->dSt[1].p + off, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipMemcpyAsync(depth, (float *) c->dSt[2].p + off, 4 * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+// every pair of the last ygzf_stereo_batch at once: rows of `stride` floats (>= ygzf_max_keypoints), pair p's first n_kp[2 p] entries valid
+int ygzf_stereo_fetch_all(ygzf_ctx *c, float *u_right, float *depth, int stride) {
+    if (!c || !u_right || !depth) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastStereoPairs < 1) return fail(c, YGZF_ERR_STATE, "no stereo result");
+    const int ks = c->geo.kpStride, P = c->lastStereoPairs;
+    if (stride < ks) return fail(c, YGZF_ERR_INVALID, "stride %d < %d (ygzf_max_keypoints)", stride, ks);
+    HIPCHECK(c, hipMemcpy2DAsync(u_right, 4 * (size_t) stride, c->dSt[1].p, 4 * (size_t) ks, 4 * (size_t) ks, P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpy2DAsync(depth, 4 * (size_t) stride, c->dSt[2].p, 4 * (size_t) ks, 4 * (size_t) ks, P, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }

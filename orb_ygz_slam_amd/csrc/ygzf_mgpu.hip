@@ -1,8 +1,11 @@
 // ygzf_mgpu.hip -- the multi-GPU split of SURVEY 8(e) inside the product: frames (or indivisible units of consecutive frames: frame pairs,
-// stereo pairs) are dealt round-robin over the devices, one host thread + one context (own HIP stream, own buffers) + page-locked staging per
-// device, results concatenated on the host in input order.  Frames are independent, a unit's frames stay on one device, so nothing crosses
-// between devices: no collective, no peer copy, no RCCL.  Host code over the public C ABI of this library (include/ygzf.h).
+// stereo pairs) are dealt round-robin over the devices, one host thread + two alternating contexts (own HIP streams, own buffers) + page-locked
+// staging per device slot, results concatenated on the host in input order.  Frames are independent, a unit's frames stay on one device, so
+// nothing crosses between devices: no collective, no peer copy, no RCCL.  Host code over the public C ABI of this library (include/ygzf.h).
 #include <hip/hip_runtime.h>
+
+#include <pthread.h>
+#include <sched.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -19,17 +22,20 @@
 struct ygzf_mgpu {
     struct Dev {
         int device = 0;
-        ygzf_ctx *ctx = nullptr;
-        uint8_t *hIn = nullptr;        // page-locked: this device's frames of one call, tight
-        ygzf_kp *hKp = nullptr;        // page-locked: results of one call
-        uint8_t *hDesc = nullptr;
-        int *hCnt = nullptr;
-        int *hMatch = nullptr;         // page-locked: match rows of one call
+        ygzf_ctx *ctx[2] = {nullptr, nullptr};   // chunks alternate between them: the upload of one overlaps the kernels of the other
+        uint8_t *hIn[2] = {nullptr, nullptr};    // page-locked: the frames of one chunk, tight (used when the caller's frames are pageable)
+        ygzf_kp *hKp[2] = {nullptr, nullptr};    // page-locked: results of one chunk
+        uint8_t *hDesc[2] = {nullptr, nullptr};
+        int *hCnt[2] = {nullptr, nullptr};
+        int *hAux[2] = {nullptr, nullptr};       // page-locked: match rows (int) or uRight rows followed by depth rows (float) of one chunk
+        cpu_set_t cpus;                          // CPUs of the device's NUMA node (empty: unknown, threads stay where they are)
+        bool haveCpus = false;
         int rc = 0;
         std::string err;
     };
     std::vector<Dev> devs;
     int maxW = 0, maxH = 0, maxFrames = 0, stride = 0;
+    int chunk = 0;                 // frames per chunk (the contexts' max_batch)
     int copyThreads = 4;           // host threads per device for the gather / scatter copies (YGZF_MGPU_COPY_THREADS)
     std::string err;
 };
@@ -44,33 +50,79 @@ static int mfail(ygzf_mgpu *m, int rc, const char *fmt, ...) {
     return rc;
 }
 
+// CPUs of the NUMA node the device hangs on: /sys/bus/pci/devices/<bus id>/numa_node -> /sys/devices/system/node/node<N>/cpulist ("0-31,64-95")
+static bool numa_cpus_of_device(int device, cpu_set_t *set) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) { (void) hipGetLastError(); return false; }
+    for (char *p = bus; *p; p++) *p = (char) tolower(*p);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    int node = -1;
+    const int got = fscanf(f, "%d", &node);
+    fclose(f);
+    if (got != 1 || node < 0) return false;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return false;
+    char list[4096] = {0};
+    const bool ok = fgets(list, sizeof list, f) != nullptr;
+    fclose(f);
+    if (!ok) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int a = 0, b = 0;
+        const int k = sscanf(tok, "%d-%d", &a, &b);
+        if (k == 1) b = a;
+        if (k < 1) continue;
+        for (int c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET(c, set); n++; }
+    }
+    return n > 0;
+}
+
 extern "C" {
 
 int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg *cfg, int max_width, int max_height, int max_frames_per_device,
                      ygzf_mgpu **out) {
-    if (!devices || n_devices < 1 || !cfg || !out || max_frames_per_device < 1) return YGZF_ERR_INVALID;
+    if (!devices || n_devices < 1 || !cfg || !out || max_frames_per_device < 1 || max_width < 1 || max_height < 1) return YGZF_ERR_INVALID;
     *out = nullptr;
     ygzf_mgpu *m = new ygzf_mgpu();
     m->maxW = max_width; m->maxH = max_height; m->maxFrames = max_frames_per_device;
     if (const char *e = getenv("YGZF_MGPU_COPY_THREADS")) m->copyThreads = std::max(1, std::min(32, atoi(e)));
+    // frames per chunk: what a context and its staging are sized for -- 128 frames of 752x480, about 96 MB of level-0 pixels for larger images (46
+    // frames of 1920x1080, 10 of 3840x2160), never more than the slot will be given
+    const size_t px = (size_t) max_width * max_height;
+    int chunk = (int) std::min<size_t>(128, std::max<size_t>(2, (96u << 20) / px));
+    if (const char *e = getenv("YGZF_MGPU_CHUNK")) chunk = std::max(1, atoi(e));
+    m->chunk = std::max(1, std::min(chunk, max_frames_per_device));
+    const bool numa = !(getenv("YGZF_MGPU_NUMA") && atoi(getenv("YGZF_MGPU_NUMA")) == 0);
     m->devs.resize(n_devices);
     for (int i = 0; i < n_devices; i++) {
         ygzf_mgpu::Dev &d = m->devs[i];
         d.device = devices[i];
-        int rc = ygzf_create(devices[i], cfg, max_width, max_height, max_frames_per_device, &d.ctx);
-        if (rc != YGZF_OK) {                      // e.g. YGZF_ERR_NO_DEVICE for an index past the last device: never a silent fall-back
-            fprintf(stderr, "ygzf_mgpu_create: device %d: %s\n", devices[i], ygzf_last_error(nullptr));
-            ygzf_mgpu_destroy(m);
-            return rc;
+        CPU_ZERO(&d.cpus);
+        for (int b = 0; b < 2; b++) {
+            int rc = ygzf_create(devices[i], cfg, max_width, max_height, m->chunk, &d.ctx[b]);
+            if (rc != YGZF_OK) {                  // e.g. YGZF_ERR_NO_DEVICE for an index past the last device: never a silent fall-back
+                fprintf(stderr, "ygzf_mgpu_create: device %d: %s\n", devices[i], ygzf_last_error(nullptr));
+                ygzf_mgpu_destroy(m);
+                return rc;
+            }
         }
-        if (i == 0) m->stride = ygzf_max_keypoints(d.ctx, max_width, max_height);
-        const size_t F = (size_t) max_frames_per_device;
-        if (hipSetDevice(devices[i]) != hipSuccess || hipHostMalloc((void **) &d.hIn, F * max_width * max_height) != hipSuccess ||
-            hipHostMalloc((void **) &d.hKp, F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
-            hipHostMalloc((void **) &d.hDesc, F * m->stride * 32) != hipSuccess || hipHostMalloc((void **) &d.hCnt, F * sizeof(int)) != hipSuccess ||
-            hipHostMalloc((void **) &d.hMatch, F * m->stride * sizeof(int)) != hipSuccess) {
-            ygzf_mgpu_destroy(m);
-            return YGZF_ERR_HIP;
+        if (i == 0) m->stride = ygzf_max_keypoints(d.ctx[0], max_width, max_height);
+        if (numa) d.haveCpus = numa_cpus_of_device(devices[i], &d.cpus);
+        const size_t F = (size_t) m->chunk;
+        if (hipSetDevice(devices[i]) != hipSuccess) { ygzf_mgpu_destroy(m); return YGZF_ERR_HIP; }
+        for (int b = 0; b < 2; b++) {
+            if (hipHostMalloc((void **) &d.hIn[b], F * px) != hipSuccess || hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
+                hipHostMalloc((void **) &d.hDesc[b], F * m->stride * 32) != hipSuccess || hipHostMalloc((void **) &d.hCnt[b], F * sizeof(int)) != hipSuccess ||
+                hipHostMalloc((void **) &d.hAux[b], F * m->stride * sizeof(int)) != hipSuccess) {
+                (void) hipGetLastError();
+                ygzf_mgpu_destroy(m);
+                return YGZF_ERR_HIP;
+            }
         }
     }
     *out = m;
@@ -80,14 +132,19 @@ int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg
 void ygzf_mgpu_destroy(ygzf_mgpu *m) {
     if (!m) return;
     for (auto &d : m->devs) {
-        if (d.ctx) ygzf_destroy(d.ctx);
-        if (!d.hIn && !d.hKp && !d.hDesc && !d.hCnt && !d.hMatch) continue;   // a slot whose context was never created (e.g. a device index that does not exist)
+        for (int b = 0; b < 2; b++)
+            if (d.ctx[b]) ygzf_destroy(d.ctx[b]);
+        bool any = false;
+        for (int b = 0; b < 2; b++) any = any || d.hIn[b] || d.hKp[b] || d.hDesc[b] || d.hCnt[b] || d.hAux[b];
+        if (!any) continue;   // a slot whose contexts were never created (e.g. a device index that does not exist)
         (void) hipSetDevice(d.device);
-        if (d.hIn) (void) hipHostFree(d.hIn);
-        if (d.hKp) (void) hipHostFree(d.hKp);
-        if (d.hDesc) (void) hipHostFree(d.hDesc);
-        if (d.hCnt) (void) hipHostFree(d.hCnt);
-        if (d.hMatch) (void) hipHostFree(d.hMatch);
+        for (int b = 0; b < 2; b++) {
+            if (d.hIn[b]) (void) hipHostFree(d.hIn[b]);
+            if (d.hKp[b]) (void) hipHostFree(d.hKp[b]);
+            if (d.hDesc[b]) (void) hipHostFree(d.hDesc[b]);
+            if (d.hCnt[b]) (void) hipHostFree(d.hCnt[b]);
+            if (d.hAux[b]) (void) hipHostFree(d.hAux[b]);
+        }
     }
     delete m;
 }
@@ -95,10 +152,164 @@ void ygzf_mgpu_destroy(ygzf_mgpu *m) {
 const char *ygzf_mgpu_last_error(const ygzf_mgpu *m) { return m ? m->err.c_str() : "null handle"; }
 int ygzf_mgpu_device_count(const ygzf_mgpu *m) { return m ? (int) m->devs.size() : 0; }
 int ygzf_mgpu_keypoint_stride(const ygzf_mgpu *m) { return m ? m->stride : 0; }
+int ygzf_mgpu_chunk_frames(const ygzf_mgpu *m) { return m ? m->chunk : 0; }
 int ygzf_mgpu_slot_of_frame(const ygzf_mgpu *m, int frame, int unit) {
     if (!m || frame < 0 || unit < 1) return -1;
     return (frame / unit) % (int) m->devs.size();
 }
+
+}  // extern "C"
+
+namespace {
+enum Mode { kExtractOnly, kMatch, kStereo };
+struct Job {
+    Mode mode;
+    const uint8_t *frames; int n_frames, w, h, row_pitch; size_t frame_stride; int unit;
+    const ygzf_camera *cam; float th; int b_mono, check_level, check_orientation;
+    float mb, mbf;
+    ygzf_kp *kps; uint8_t *desc; int *n_kp; int stride;
+    int *match, *nmatches;
+    float *u_right, *depth;
+};
+
+int run_job(ygzf_mgpu *m, const Job &J) {
+    const int nd = (int) m->devs.size();
+    const int w = J.w, h = J.h, unit = J.unit;
+    // unit u -> device slot u % nd; a slot's frames keep their input order
+    std::vector<std::vector<int>> mine(nd);
+    for (int f = 0; f < J.n_frames; f++) mine[(f / unit) % nd].push_back(f);
+    for (int s = 0; s < nd; s++)
+        if ((int) mine[s].size() > m->maxFrames) return mfail(m, YGZF_ERR_INVALID, "%zu frames for device slot %d (maximum %d)", mine[s].size(), s, m->maxFrames);
+    // Units that fit a chunk: whole units per chunk, chunks alternate between the slot's two contexts (nothing is carried from chunk to chunk, so the
+    // upload of one overlaps the kernels of the other).  Longer units (a clip whose every frame is matched against its predecessor): all chunks on
+    // ONE context, whose carried "previous frame" links frame k * chunk to frame k * chunk - 1, one chunk after the other.
+    const bool alternate = unit <= m->chunk;
+    const int chunk = alternate ? (m->chunk / unit) * unit : m->chunk;
+    // frames in page-locked host memory go to the device from where they lie
+    bool pinned = false;
+    {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, J.frames) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+        else (void) hipGetLastError();                // an ordinary malloc pointer is "invalid value" to the runtime: pageable
+        if (const char *e = getenv("YGZF_MGPU_PINNED")) pinned = pinned && atoi(e) != 0;
+    }
+    const int nCopy = m->copyThreads;
+    auto work = [&](int s, bool ownThread) {
+        ygzf_mgpu::Dev &d = m->devs[s];
+        d.rc = YGZF_OK;
+        const std::vector<int> &fr = mine[s];
+        const int n = (int) fr.size();
+        if (n == 0) return;
+        // (never the caller's own thread: its affinity is the caller's business)
+        if (ownThread && d.haveCpus) (void) pthread_setaffinity_np(pthread_self(), sizeof d.cpus, &d.cpus);   // copy threads inherit it
+        auto parallel = [&](int cnt, const std::function<void(int)> &fn) {
+            if (cnt <= 0) return;
+            const int T = std::min(nCopy, cnt);
+            std::vector<std::thread> ts;
+            for (int t = 1; t < T; t++) ts.emplace_back([&, t] { for (int i = t; i < cnt; i += T) fn(i); });
+            for (int i = 0; i < cnt; i += T) fn(i);
+            for (auto &t : ts) t.join();
+        };
+        const int nChunks = (n + chunk - 1) / chunk;
+        auto lo = [&](int k) { return k * chunk; };
+        auto cnt = [&](int k) { return std::min(chunk, n - k * chunk); };
+        std::vector<const uint8_t *> ptrs((size_t) chunk);
+        std::vector<int> nm(n, 0);
+        auto cx = [&](int k) { return d.ctx[alternate ? (k & 1) : 0]; };
+        auto prepare = [&](int k) {      // pageable frames: gather chunk k into its page-locked staging area, tight rows
+            if (pinned) return;
+            const int b = k & 1;
+            parallel(cnt(k), [&](int j) {
+                const uint8_t *src = J.frames + (size_t) fr[lo(k) + j] * J.frame_stride;
+                uint8_t *dst = d.hIn[b] + (size_t) j * h * w;
+                if (J.row_pitch == w) memcpy(dst, src, (size_t) w * h);
+                else for (int y = 0; y < h; y++) memcpy(dst + (size_t) y * w, src + (size_t) y * J.row_pitch, (size_t) w);
+            });
+        };
+        auto launch = [&](int k) {       // queue chunk k on its context: upload, extraction, matching / stereo (returns without waiting)
+            const int b = k & 1;
+            int rc;
+            if (pinned) {
+                for (int j = 0; j < cnt(k); j++) ptrs[j] = J.frames + (size_t) fr[lo(k) + j] * J.frame_stride;
+                rc = ygzf_extract_batch_host_frames(cx(k), ptrs.data(), cnt(k), w, h, J.row_pitch);
+            } else
+                rc = ygzf_extract_batch_host(cx(k), d.hIn[b], cnt(k), w, h, w, (size_t) w * h);
+            if (rc == YGZF_OK && J.mode == kMatch) rc = ygzf_match_batch_prev(cx(k), J.cam, J.th, J.b_mono, J.check_level, J.check_orientation);
+            if (rc == YGZF_OK && J.mode == kStereo) rc = ygzf_stereo_batch(cx(k), J.mb, J.mbf);
+            if (rc != YGZF_OK) d.err = ygzf_last_error(cx(k));
+            return rc;
+        };
+        auto fetch = [&](int k) {        // waits for chunk k and brings its results into the page-locked staging of its context
+            const int b = k & 1;
+            int rc = ygzf_batch_fetch_all(cx(k), d.hKp[b], d.hDesc[b], d.hCnt[b], m->stride);
+            if (rc == YGZF_OK && J.mode == kMatch) rc = ygzf_match_counts(cx(k), nm.data() + lo(k));
+            if (rc == YGZF_OK && J.mode == kMatch && J.match) rc = ygzf_match_fetch_all(cx(k), d.hAux[b], m->stride);
+            if (rc == YGZF_OK && J.mode == kStereo) {
+                float *u = (float *) d.hAux[b];
+                rc = ygzf_stereo_fetch_all(cx(k), u, u + (size_t) (cnt(k) / 2) * m->stride, m->stride);
+            }
+            if (rc != YGZF_OK) d.err = ygzf_last_error(cx(k));
+            return rc;
+        };
+        auto scatter = [&](int k) {      // to the caller's rows: input order
+            const int b = k & 1;
+            parallel(cnt(k), [&](int j) {
+                const int i = lo(k) + j, f = fr[i];
+                const int c = d.hCnt[b][j];
+                J.n_kp[f] = c;
+                memcpy(J.kps + (size_t) f * J.stride, d.hKp[b] + (size_t) j * m->stride, sizeof(ygzf_kp) * (size_t) c);
+                memcpy(J.desc + (size_t) f * J.stride * 32, d.hDesc[b] + (size_t) j * m->stride * 32, 32 * (size_t) c);
+                if (J.mode == kMatch) {
+                    const bool first = (f % unit) == 0;                           // no predecessor inside the unit
+                    if (J.nmatches) J.nmatches[f] = first ? -1 : nm[i];
+                    if (J.match) {
+                        int *row = J.match + (size_t) f * J.stride;
+                        if (first) for (int q = 0; q < J.stride; q++) row[q] = -1;
+                        else {
+                            memcpy(row, d.hAux[b] + (size_t) j * m->stride, sizeof(int) * (size_t) c);
+                            for (int q = c; q < J.stride; q++) row[q] = -1;
+                        }
+                    }
+                } else if (J.mode == kStereo && (f & 1) == 0) {                   // left eye of pair f / 2: row j / 2 of this chunk
+                    const float *u = (const float *) d.hAux[b] + (size_t) (j / 2) * m->stride;
+                    const float *dp = u + (size_t) (cnt(k) / 2) * m->stride;
+                    float *ur = J.u_right + (size_t) (f / 2) * J.stride, *dr = J.depth + (size_t) (f / 2) * J.stride;
+                    memcpy(ur, u, sizeof(float) * (size_t) c);
+                    memcpy(dr, dp, sizeof(float) * (size_t) c);
+                    for (int q = c; q < J.stride; q++) { ur[q] = -1.f; dr[q] = -1.f; }
+                }
+            });
+        };
+        prepare(0);
+        int rc = launch(0);
+        for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
+            const bool more = k + 1 < nChunks;
+            if (more) prepare(k + 1);                            // the device works on chunk k meanwhile
+            if (more && alternate) rc = launch(k + 1);           // the other context: its upload runs beside chunk k's kernels
+            if (rc == YGZF_OK) rc = fetch(k);
+            if (rc == YGZF_OK && more && !alternate) rc = launch(k + 1);   // one context: its outputs had to be read first
+            if (rc == YGZF_OK) scatter(k);                       // the device works on chunk k + 1 meanwhile
+        }
+        if (rc != YGZF_OK) {                                     // leave no copy in flight behind the caller's frames
+            (void) ygzf_sync(d.ctx[0]);
+            (void) ygzf_sync(d.ctx[1]);
+        }
+        d.rc = rc;
+    };
+    if (nd == 1) work(0, false);
+    else {
+        std::vector<std::thread> th_;                            // one host thread per device slot (bound to the device's NUMA node)
+        for (int s = 0; s < nd; s++) th_.emplace_back(work, s, true);
+        for (auto &t : th_) t.join();
+    }
+    for (int s = 0; s < nd; s++)
+        if (m->devs[s].rc != YGZF_OK) return mfail(m, m->devs[s].rc, "device slot %d (device %d): %s", s, m->devs[s].device, m->devs[s].err.c_str());
+    return YGZF_OK;
+}
+}  // namespace
+
+extern "C" {
 
 int ygzf_mgpu_extract_match(ygzf_mgpu *m, const uint8_t *frames, int n_frames, int w, int h, int row_pitch, size_t frame_stride, int unit,
                             const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation, ygzf_kp *kps, uint8_t *desc,
@@ -107,95 +318,28 @@ int ygzf_mgpu_extract_match(ygzf_mgpu *m, const uint8_t *frames, int n_frames, i
     if (n_frames < 1 || unit < 1 || w < 1 || h < 1 || w > m->maxW || h > m->maxH || row_pitch < w || stride < m->stride)
         return mfail(m, YGZF_ERR_INVALID, "bad geometry (frames %d, unit %d, %dx%d, stride %d < %d)", n_frames, unit, w, h, stride, m->stride);
     if ((match || nmatches) && !cam) return mfail(m, YGZF_ERR_INVALID, "matching needs a camera");
-    const int nd = (int) m->devs.size();
-    // unit u -> device slot u % nd; a slot's frames keep their input order
-    std::vector<std::vector<int>> mine(nd);
-    for (int f = 0; f < n_frames; f++) mine[(f / unit) % nd].push_back(f);
-    for (int s = 0; s < nd; s++)
-        if ((int) mine[s].size() > m->maxFrames) return mfail(m, YGZF_ERR_INVALID, "%zu frames for device slot %d (maximum %d)", mine[s].size(), s, m->maxFrames);
-    const bool doMatch = match != nullptr || nmatches != nullptr;
-    // A device's frames go through in chunks: while the device works on chunk k the host gathers chunk k + 1 into page-locked memory and
-    // scatters the results of chunk k - 1 (several copy threads: one thread moves ~10 GB/s, a 752x480 frame every 35 us).  The chunks of a
-    // slot form one frame sequence for ygzf_match_batch_prev (its "previous frame" is carried from launch to launch), so the pairs are
-    // those of one large batch.
-    const int kChunk = 128;
-    const int nCopy = m->copyThreads;
-    auto parallel = [&](int n, const std::function<void(int)> &fn) {
-        if (n <= 0) return;
-        const int T = std::min(nCopy, n);
-        std::vector<std::thread> ts;
-        for (int t = 1; t < T; t++) ts.emplace_back([&, t] { for (int i = t; i < n; i += T) fn(i); });
-        for (int i = 0; i < n; i += T) fn(i);
-        for (auto &t : ts) t.join();
-    };
-    auto work = [&](int s) {
-        ygzf_mgpu::Dev &d = m->devs[s];
-        d.rc = YGZF_OK;
-        const std::vector<int> &fr = mine[s];
-        const int n = (int) fr.size();
-        if (n == 0) return;
-        const int nChunks = (n + kChunk - 1) / kChunk;
-        auto lo = [&](int k) { return k * kChunk; };
-        auto cnt = [&](int k) { return std::min(kChunk, n - k * kChunk); };
-        auto gather = [&](int k) {   // into the page-locked staging area, tight rows
-            parallel(cnt(k), [&](int j) {
-                const int i = lo(k) + j;
-                const uint8_t *src = frames + (size_t) fr[i] * frame_stride;
-                uint8_t *dst = d.hIn + (size_t) i * h * w;
-                if (row_pitch == w) memcpy(dst, src, (size_t) w * h);
-                else for (int y = 0; y < h; y++) memcpy(dst + (size_t) y * w, src + (size_t) y * row_pitch, (size_t) w);
-            });
-        };
-        auto launch = [&](int k) {
-            int rc = ygzf_extract_batch_host(d.ctx, d.hIn + (size_t) lo(k) * h * w, cnt(k), w, h, w, (size_t) w * h);
-            if (rc == YGZF_OK && doMatch) rc = ygzf_match_batch_prev(d.ctx, cam, th, b_mono, check_level, check_orientation);
-            return rc;
-        };
-        std::vector<int> nm(n, 0);
-        auto fetch = [&](int k) {
-            const size_t o = (size_t) lo(k) * m->stride;
-            int rc = ygzf_batch_fetch_all(d.ctx, d.hKp + o, d.hDesc + o * 32, d.hCnt + lo(k), m->stride);
-            if (rc == YGZF_OK && doMatch) rc = ygzf_match_counts(d.ctx, nm.data() + lo(k));
-            if (rc == YGZF_OK && match) rc = ygzf_match_fetch_all(d.ctx, d.hMatch + o, m->stride);
-            return rc;
-        };
-        auto scatter = [&](int k) {   // to the caller's rows: input order
-            parallel(cnt(k), [&](int j) {
-                const int i = lo(k) + j, f = fr[i];
-                n_kp[f] = d.hCnt[i];
-                memcpy(kps + (size_t) f * stride, d.hKp + (size_t) i * m->stride, sizeof(ygzf_kp) * (size_t) d.hCnt[i]);
-                memcpy(desc + (size_t) f * stride * 32, d.hDesc + (size_t) i * m->stride * 32, 32 * (size_t) d.hCnt[i]);
-                if (!doMatch) return;
-                const bool first = (f % unit) == 0;                           // no predecessor inside the unit
-                if (nmatches) nmatches[f] = first ? -1 : nm[i];
-                if (match) {
-                    int *row = match + (size_t) f * stride;
-                    if (first) for (int q = 0; q < stride; q++) row[q] = -1;
-                    else {
-                        memcpy(row, d.hMatch + (size_t) i * m->stride, sizeof(int) * (size_t) d.hCnt[i]);
-                        for (int q = d.hCnt[i]; q < stride; q++) row[q] = -1;
-                    }
-                }
-            });
-        };
-        gather(0);
-        int rc = launch(0);
-        for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
-            if (k + 1 < nChunks) gather(k + 1);                  // the device works on chunk k meanwhile
-            rc = fetch(k);
-            if (rc == YGZF_OK && k + 1 < nChunks) rc = launch(k + 1);
-            if (rc == YGZF_OK) scatter(k);                       // the device works on chunk k + 1 meanwhile
-        }
-        d.rc = rc;
-        if (rc != YGZF_OK) d.err = ygzf_last_error(d.ctx);
-    };
-    std::vector<std::thread> th_;
-    for (int s = 1; s < nd; s++) th_.emplace_back(work, s);               // one host thread per device; slot 0 on the calling thread
-    work(0);
-    for (auto &t : th_) t.join();
-    for (int s = 0; s < nd; s++)
-        if (m->devs[s].rc != YGZF_OK) return mfail(m, m->devs[s].rc, "device slot %d (device %d): %s", s, m->devs[s].device, m->devs[s].err.c_str());
-    return YGZF_OK;
+    Job J;
+    memset(&J, 0, sizeof J);
+    J.mode = (match || nmatches) ? kMatch : kExtractOnly;
+    J.frames = frames; J.n_frames = n_frames; J.w = w; J.h = h; J.row_pitch = row_pitch; J.frame_stride = frame_stride; J.unit = unit;
+    J.cam = cam; J.th = th; J.b_mono = b_mono; J.check_level = check_level; J.check_orientation = check_orientation;
+    J.kps = kps; J.desc = desc; J.n_kp = n_kp; J.stride = stride; J.match = match; J.nmatches = nmatches;
+    return run_job(m, J);
+}
+
+int ygzf_mgpu_extract_stereo(ygzf_mgpu *m, const uint8_t *frames, int n_frames, int w, int h, int row_pitch, size_t frame_stride, float mb, float mbf,
+                             ygzf_kp *kps, uint8_t *desc, int *n_kp, int stride, float *u_right, float *depth) {
+    if (!m || !frames || !kps || !desc || !n_kp || !u_right || !depth) return mfail(m, YGZF_ERR_INVALID, "null argument");
+    if (n_frames < 2 || (n_frames & 1) || w < 1 || h < 1 || w > m->maxW || h > m->maxH || row_pitch < w || stride < m->stride)
+        return mfail(m, YGZF_ERR_INVALID, "bad geometry (frames %d: (left, right) pairs, %dx%d, stride %d < %d)", n_frames, w, h, stride, m->stride);
+    if (!(mb > 0)) return mfail(m, YGZF_ERR_INVALID, "baseline mb must be positive");
+    Job J;
+    memset(&J, 0, sizeof J);
+    J.mode = kStereo;
+    J.frames = frames; J.n_frames = n_frames; J.w = w; J.h = h; J.row_pitch = row_pitch; J.frame_stride = frame_stride; J.unit = 2;
+    J.mb = mb; J.mbf = mbf;
+    J.kps = kps; J.desc = desc; J.n_kp = n_kp; J.stride = stride; J.u_right = u_right; J.depth = depth;
+    return run_job(m, J);
 }
 
 }  // extern "C"

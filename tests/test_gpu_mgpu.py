@@ -91,6 +91,79 @@ def test_long_slot_runs_in_chunks():
     assert np.array_equal(nm2[keep], nm[keep]) and np.array_equal(m2[keep], m[keep])
 
 
+@pytest.mark.parametrize("nslots", [8, 16])
+def test_eight_and_sixteen_slots(oracle, nslots):
+    """BASELINE.json's literal multi-GPU configurations, on the one GPU the box has: batch = 8 frames, one per device slot (unit 1); batch = 16 frames =
+    8 stereo pairs, a pair per slot (unit 2, ygzf_mgpu_extract_stereo: both eyes' extraction + ComputeStereoMatches).  Same bytes as one slot doing
+    everything, and as the oracle."""
+    from orb_ygz_slam_amd import MultiGpu, Extractor, make_camera, EUROC
+    w, h = 640, 480
+    frames = _clip(16, w, h)
+    cam = make_camera(w, h)
+    one = MultiGpu([0], max_width=w, max_height=h, max_frames_per_device=16)
+    ref8 = one.extract_match(frames[:8], unit=1, cam=cam)
+    stereo = np.ascontiguousarray(frames.copy())
+    for p in range(8):                                                   # right eye = the left image shifted by a disparity
+        stereo[2 * p + 1, :, :w - 6 - p] = stereo[2 * p, :, 6 + p:]
+    mb, mbf = 0.11, 47.9
+    refs = one.extract_stereo(stereo, mb, mbf)
+    one.close()
+    mg = MultiGpu([0] * nslots, max_width=w, max_height=h, max_frames_per_device=4)
+    got8 = mg.extract_match(frames[:8], unit=1, cam=cam)
+    gots = mg.extract_stereo(stereo, mb, mbf)
+    mg.close()
+    for a, b, name in zip(ref8, got8, ("kps", "desc", "n_kp", "match", "nmatches")):
+        assert np.array_equal(a, b), (nslots, name)
+    for a, b, name in zip(refs, gots, ("kps", "desc", "n_kp", "u_right", "depth")):
+        assert np.array_equal(a.view(np.uint8) if a.dtype == np.float32 else a, b.view(np.uint8) if b.dtype == np.float32 else b), (nslots, name)
+    k, d, c, ur, dp = gots
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    for p in (0, 5):
+        kl, dl = oex.extract(stereo[2 * p])
+        kr, dr = oex.extract(stereo[2 * p + 1])
+        our, odp = oex.compute_stereo_matches(stereo[2 * p], stereo[2 * p + 1], kl, dl, kr, dr, mb, mbf)
+        n = len(kl)
+        assert c[2 * p] == n and np.array_equal(ur[p, :n].view(np.uint32), our.view(np.uint32)) and np.array_equal(dp[p, :n].view(np.uint32), odp.view(np.uint32))
+        assert (our >= 0).sum() > 100 and (ur[p, n:] == -1).all()
+
+
+def test_page_locked_frames_skip_the_staging_copy():
+    """Frames that already lie in page-locked host memory are copied to the device from where they lie (hipPointerGetAttributes decides); same bytes
+    as from pageable memory, chunks alternating between a slot's two contexts included (YGZF_MGPU_CHUNK makes them small)."""
+    import ctypes as C
+    from orb_ygz_slam_amd import MultiGpu, make_camera
+    w, h, n = 320, 240, 44
+    frames = np.ascontiguousarray(np.concatenate([_clip(20, w, h)] * 3)[:n])
+    cam = make_camera(w, h)
+    os.environ["YGZF_MGPU_CHUNK"] = "6"
+    try:
+        mg = MultiGpu([0, 0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=n)
+        assert mg.chunk_frames() == 6
+        ref = mg.extract_match(frames, unit=2, cam=cam)
+        hip = C.CDLL("libamdhip64.so")
+        ptr = C.c_void_p()
+        assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(frames.nbytes), C.c_uint(0)) == 0
+        pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(frames.nbytes,)).reshape(frames.shape)
+        pinned[:] = frames
+        got = mg.extract_match(pinned, unit=2, cam=cam)
+        ref4 = mg.extract_match(frames, unit=4, cam=cam)               # 4 does not divide 6: chunks of 4 frames
+        got4 = mg.extract_match(pinned, unit=4, cam=cam)
+        mg.close()
+        del pinned
+        hip.hipHostFree(ptr)
+    finally:
+        del os.environ["YGZF_MGPU_CHUNK"]
+    for a, b, name in zip(ref, got, ("kps", "desc", "n_kp", "match", "nmatches")):
+        assert np.array_equal(a, b), name
+    for a, b, name in zip(ref4, got4, ("kps", "desc", "n_kp", "match", "nmatches")):
+        assert np.array_equal(a, b), name
+    big = MultiGpu([0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=n)      # one slot, one chunk: the unchunked answer
+    want = big.extract_match(frames, unit=2, cam=cam)
+    big.close()
+    for a, b, name in zip(want, got, ("kps", "desc", "n_kp", "match", "nmatches")):
+        assert np.array_equal(a, b), name
+
+
 def test_missing_device_is_an_error():
     from orb_ygz_slam_amd import MultiGpu, YgzfError
     import torch
