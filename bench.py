@@ -55,6 +55,7 @@ WORKLOADS = {
 SHAPES = {"euroc752x480_8lvl_1000feat": (256, 14), "vga640x480_8lvl_1000feat": (256, 14), "fhd1920x1080_8lvl_4000feat": (128, 4),
           "uhd3840x2160_12lvl_8000feat": (64, 2)}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PCIE_PEAK_GBS = 63.0           # PCIe 5.0 x16, one direction (what the end-to-end rate is bound by: every frame crosses the link)
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs, peak shader clock
 
 
@@ -323,9 +324,7 @@ def end_to_end(pipe, min_seconds=1.2, depth=2):
     stride = exs[0].max_keypoints(w, h)
     pins, outs, keep = [], [], []
     for i in range(depth):
-        src = pipe.frames[(i * B) % len(pipe.frames):][:B]
-        if len(src) < B:
-            src = np.concatenate([src, pipe.frames[:B - len(src)]])
+        src = np.take(pipe.frames, (np.arange(B) + i * B) % len(pipe.frames), axis=0)      # (the clip may hold fewer distinct frames than a sub-batch)
         pf = torch.from_numpy(np.ascontiguousarray(src)).pin_memory()
         ok = torch.empty((B, stride, KP_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
         od = torch.empty((B, stride, 32), dtype=torch.uint8).pin_memory()
@@ -337,6 +336,8 @@ def end_to_end(pipe, min_seconds=1.2, depth=2):
     def submit(i):
         exs[i].extract_batch_host(pins[i])
         exs[i].match_batch_prev(pipe.cam, 15.0, True, True, True)
+        if pipe.stereo:
+            exs[i].stereo_batch(0.11, 47.9)                                # (its mvuRight / mvDepth rows stay on the device: 8 more bytes per keypoint)
     for i in range(depth):                                                 # warm-up
         submit(i)
     for i in range(depth):
@@ -351,40 +352,118 @@ def end_to_end(pipe, min_seconds=1.2, depth=2):
     batches = it
     for it in range(batches, batches + depth):                             # drain
         exs[it % depth].batch_fetch_all(B, outs[it % depth])
-    return B * batches, time.perf_counter() - t0
+    sec = time.perf_counter() - t0
+    for e in exs[len(pipe.exs[:depth]):]:
+        e.close()
+    # what crosses the link per frame: the level-0 pixels up; keypoint + descriptor rows of `stride` entries and the count down
+    return B * batches, sec, {"up": w * h, "down": stride * (KP_DTYPE.itemsize + 32) + 4}
 
 
-def mgpu_end_to_end(devices, cfg, frames, min_seconds=1.0):
+def pcie_roofline(link, fps_per_gpu):
+    """The bound of the end-to-end rate: bytes that cross the PCIe link per frame (both directions run concurrently; the upstream direction
+    carries the pixels and is the one that saturates) x frames/s against one direction's peak."""
+    up, down = link["up"] * fps_per_gpu / 1e9, link["down"] * fps_per_gpu / 1e9
+    return {"bound": "pcie", "achieved": round(max(up, down), 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": round(max(up, down) / PCIE_PEAK_GBS, 4),
+            "up_GBs": round(up, 2), "down_GBs": round(down, 2), "bytes_per_frame": link}
+
+
+def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
     """The product's own multi-GPU entry point (ygzf_mgpu_extract_match, include/ygzf.h): host frames in, every keypoint / descriptor / match
-    out in input order, frame pairs dealt round-robin over the device slots (one host thread + context per slot).  With one device the two
-    slots both sit on it (what hides the transfers of one slot behind the kernels of the other)."""
+    out in input order, frame pairs dealt round-robin over the device slots (one host thread + two alternating contexts per slot).  With one
+    device the two slots both sit on it.  Twice: frames in pageable memory (gathered into the slot's page-locked staging first) and in page-locked
+    memory (copied to the device from where they lie)."""
+    import torch
     from orb_ygz_slam_amd import MultiGpu, make_camera
     w, h, nl, sf, nf, ini, mn = cfg
     slots = list(devices) if len(devices) > 1 else [devices[0], devices[0]]
-    per = 256
+    per = 512                       # frames per slot and call: four chunks of 128 (the call is synchronous: its first upload and last read-back are not overlapped)
     n = per * len(slots)
     clip = np.ascontiguousarray(np.concatenate([frames] * ((n + len(frames) - 1) // len(frames)))[:n])
     mg = MultiGpu(slots, nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=per)
     cam = make_camera(w, h)
-    out = mg.extract_match(clip, unit=2, cam=cam)
-    t0 = time.perf_counter()
-    calls = 0
-    while calls < 2 or time.perf_counter() - t0 < min_seconds:
-        mg.extract_match(clip, unit=2, cam=cam, out=out)
-        calls += 1
-    sec = time.perf_counter() - t0
+    res = {}
+    keep = torch.from_numpy(clip).pin_memory()
+    for name, src in (("pageable", clip), ("page_locked", keep.numpy())):
+        out = mg.extract_match(src, unit=2, cam=cam)
+        t0 = time.perf_counter()
+        calls = 0
+        while calls < 2 or time.perf_counter() - t0 < min_seconds:
+            mg.extract_match(src, unit=2, cam=cam, out=out)
+            calls += 1
+        sec = time.perf_counter() - t0
+        res[name] = {"value": round(calls * n / sec, 1), "calls": calls, "ms_per_call": round(1e3 * sec / calls, 3)}
+    chunk = mg.chunk_frames()
     mg.close()
-    return {"value": round(calls * n / sec, 1), "unit": "frames/s", "frames_per_call": n, "calls": calls, "device_slots": slots, "unit_frames": 2,
-            "what": "ygzf_mgpu_extract_match: pageable host frames -> per-slot page-locked staging -> H2D -> extract + match of every pair -> D2H -> "
-                    "host arrays in input order (synchronous calls; inside a call every slot pipelines its frames in chunks of 128: host gather / scatter "
-                    "copies on four threads beside the device's work on the neighbouring chunk)"}
+    return {"value": res["page_locked"]["value"], "value_pageable": res["pageable"]["value"], "unit": "frames/s", "frames_per_call": n, "runs": res,
+            "device_slots": slots, "unit_frames": 2, "chunk_frames": chunk,
+            "what": "ygzf_mgpu_extract_match: host frames -> H2D -> extract + match of every pair -> D2H -> host arrays in input order (synchronous calls; "
+                    "inside a call every slot sends its frames through in chunks that alternate between two contexts: the upload of one chunk runs beside "
+                    "the kernels of the other; page-locked frames are copied from where they lie, pageable ones are gathered into page-locked staging by four "
+                    "host threads per slot)"}
+
+
+def mgpu_literal_configs(devices):
+    """BASELINE.json configs[3] and configs[4] as literally stated, through the product's multi-GPU API: 1920x1080 / 8 levels / 4000 features with a batch of
+    8 frames, one per device slot; 3840x2160 stereo / 12 levels / 8000 features with a batch of 16 frames = 8 (left, right) pairs, a pair per slot
+    (extraction of both eyes + ComputeStereoMatches).  Eight slots: the eight GPUs of the node, or -- on the one-GPU box -- eight slots on its GPU.
+    Latency of one call and the rate it amounts to; host frames page-locked."""
+    import torch
+    from orb_ygz_slam_amd import MultiGpu
+    nd = 8
+    slots = [devices[i % len(devices)] for i in range(nd)]
+    out = {}
+    for key, wl, nfr, stereo in (("fhd1920x1080_8lvl_4000feat_batch8", "fhd1920x1080_8lvl_4000feat", 8, False),
+                                 ("uhd3840x2160_12lvl_8000feat_stereo_batch16", "uhd3840x2160_12lvl_8000feat", 16, True)):
+        w, h, nl, sf, nf, ini, mn = WORKLOADS[wl]
+        base = make_frames(8, w, h, seed0=7000)
+        clip = np.ascontiguousarray(np.concatenate([base] * ((nfr + 7) // 8))[:nfr])
+        if stereo:
+            clip[1::2, :, :w - 24] = clip[0::2, :, 24:]           # right eye = the left image shifted by a disparity
+        keep = torch.from_numpy(clip).pin_memory()
+        src = keep.numpy()
+        mg = MultiGpu(slots, nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=2)
+        run = (lambda o=None: mg.extract_stereo(src, 0.11, 47.9, out=o)) if stereo else (lambda o=None: mg.extract_match(src, unit=1, out=o))
+        o = run()
+        lat = []
+        t0 = time.perf_counter()
+        while len(lat) < 5 or time.perf_counter() - t0 < 0.5:
+            t1 = time.perf_counter()
+            run(o)
+            lat.append(time.perf_counter() - t1)
+        lat.sort()
+        med = lat[len(lat) // 2]
+        kp = int(np.asarray(o[2]).mean())
+        matched = int((np.asarray(o[3]) >= 0).sum(axis=1).mean()) if stereo else None
+        mg.close()
+        out[key] = {"frames_per_call": nfr, "device_slots": slots, "unit_frames": 2 if stereo else 1, "ms_per_call": round(1e3 * med, 3),
+                    "value": round(nfr / med, 1), "unit": "frames/s", "calls": len(lat), "keypoints_per_frame": kp,
+                    "stereo_matches_per_pair": matched,
+                    "what": ("ygzf_mgpu_extract_stereo" if stereo else "ygzf_mgpu_extract_match (extraction only)") +
+                            ": page-locked host frames in, keypoints / descriptors" + (" / uRight / depth" if stereo else "") + " out, one synchronous call"}
+    return out
+
+
+def isolated_pass(pipe, reps=2):
+    """Untimed extra launches, one context at a time, so that per-kernel durations are not stretched by the other streams."""
+    acc = {}
+    for s, e in enumerate(pipe.exs):
+        e.profile_enable(True)
+        e.profile_reset()
+        for _ in range(reps):
+            pipe.launch(e, pipe.ptrs[0][s])
+            e.sync()
+        for name, (ms, n) in e.profile_read().items():
+            a = acc.get(name, (0.0, 0))
+            acc[name] = (a[0] + ms, a[1] + n)
+        e.profile_enable(False)
+    return {k: round(1e3 * v[0] / v[1], 2) for k, v in acc.items() if v[1]}
 
 
 def kernel_table(prof):
     return {name: {"launches": n, "avg_us": round(1e3 * ms / n, 2), "total_ms": round(ms, 3)} for name, (ms, n) in prof.items() if n}
 
 
-def hbm_roofline(workload, kernels, iso, per_kernel, frames_per_launch, total_bytes, fps_per_gpu, only=None, with_traffic=True):
+def hbm_roofline(workload, kernels, iso, per_kernel, frames_per_launch, total_bytes, fps_per_gpu, only=None, with_traffic=True, traffic_key=None):
     cand = [k for k in kernels if per_kernel.get(k, 0) > 0 and (only is None or k == only)]
     if not cand:
         return None
@@ -397,7 +476,7 @@ def hbm_roofline(workload, kernels, iso, per_kernel, frames_per_launch, total_by
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if with_traffic and os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get(workload, {}).get(dom)
+            traffic = json.load(open(tfile)).get(traffic_key or workload, {}).get(dom)
         except Exception:
             traffic = None
     iso_us = iso.get(dom)
@@ -590,18 +669,7 @@ def main():
         # the profile covers warm-up + timed steps of device 0 (same launches; events are only read here, after the region)
         kernels = kernel_table(prof)
         # untimed extra pass: one context at a time, so that per-kernel durations are not stretched by the other streams
-        acc = {}
-        for s, e in enumerate(pipe.exs):
-            e.profile_enable(True)
-            e.profile_reset()
-            for _ in range(2):
-                pipe.launch(e, pipe.ptrs[0][s])
-                e.sync()
-            for name, (ms, n) in e.profile_read().items():
-                a = acc.get(name, (0.0, 0))
-                acc[name] = (a[0] + ms, a[1] + n)
-            e.profile_enable(False)
-        iso = {k: round(1e3 * v[0] / v[1], 2) for k, v in acc.items() if v[1]}
+        iso = isolated_pass(pipe)
     kp_counts = np.concatenate([e.batch_counts() for e in pipe.exs])
     m_counts = np.concatenate([e.match_counts() for e in pipe.exs])
 
@@ -609,13 +677,13 @@ def main():
     e2e = None
     if not args.no_extras:
         barrier()
-        nfr, sec = end_to_end(pipe)
+        nfr, sec, link = end_to_end(pipe)
         sec = max_over_ranks(sec)
-        e2e = {"value": round(world * nfr / sec, 1), "unit": "frames/s", "frames": world * nfr,
+        e2e = {"value": round(world * nfr / sec, 1), "unit": "frames/s", "frames": world * nfr, "roofline_pcie": pcie_roofline(link, nfr / sec),
                "what": "pinned host frames -> H2D -> extract + match -> D2H of all keypoints, descriptors and counts; two contexts "
                        "software-pipelined per GPU (device 0 of each process)"}
 
-    mgpu = None
+    mgpu = mgpu_lit = None
     if not args.no_extras and world == 1:
         mgpu = mgpu_end_to_end(devices, cfg, frames0)
 
@@ -642,6 +710,7 @@ def main():
             el = max_over_ranks(run_timed(ps, o_steps, 1, barrier, sync_all))
             oprof = kernel_table(ps[0].profile_read())
             ps[0].profile(False)
+            oiso = isolated_pass(ps[0], reps=1)
             ofps = n_gpus * ps[0].batch * o_steps / el
             ow, oh, onl, osf, onf = WORKLOADS[wl][:5]
             tb, per = algorithmic_bytes(ow, oh, onl, osf, onf)
@@ -654,20 +723,30 @@ def main():
                 tb += per["k_sia_run"]
             entry = {"value": round(ofps, 1), "unit": "frames/s" if not o_stereo else "frames/s (2 frames = 1 stereo pair)", "ms_per_step": round(1e3 * el / o_steps, 3),
                      "frames_per_gpu_per_step": ps[0].batch, "steps": o_steps,
-                     "roofline": hbm_roofline(wl, oprof, {}, per, osub, tb, ofps / n_gpus, with_traffic=False),
+                     "roofline": hbm_roofline(wl, oprof, oiso, per, osub, tb, ofps / n_gpus, traffic_key=name),
                      "kernels": {k: v["avg_us"] for k, v in oprof.items()},
+                     "kernels_isolated_avg_us": oiso,
                      "keypoints_per_frame": round(float(okp.mean()), 1),
                      "matches_per_frame": round(float(np.concatenate([e.match_counts() for e in ps[0].exs]).mean()), 1)}
             if o_real:
                 entry["data"] = ("96 frames cut from the reference's Thirdparty/fast/test/data/test1.png (the one real image it ships; pixels from "
                                  "tests/golden/fast10_test1.npz): mirror-padded, 12 zoom levels 1.00 .. 1.22, shifted crops")
                 entry["fast_plan"] = {1: "one pass at minTh", 2: "iniTh first"}.get(ps[0].exs[0].fast_plan(), "?")
+            if not o_real and not o_align:
+                # SURVEY 8(d)'s rate for this shape too: H2D of every frame and D2H of every keypoint / descriptor inside
+                onfr, osec, olink = end_to_end(ps[0], min_seconds=0.6)
+                osec = max_over_ranks(osec)
+                entry["value_end_to_end"] = round(world * onfr / osec, 1)
+                entry["roofline_pcie"] = pcie_roofline(olink, onfr / osec)
             others[name] = entry
             for p in ps:
                 for e in p.exs:
                     e.close()
             del ps
             torch.cuda.empty_cache()
+
+    if not args.no_extras and world == 1 and args.workload == "euroc752x480_8lvl_1000feat" and not args.align and not args.stereo:
+        mgpu_lit = mgpu_literal_configs(devices)
 
     if rank == 0:
         total_bytes, per_kernel = algorithmic_bytes(w, h, nl, sf, nf)
@@ -687,7 +766,8 @@ def main():
                        "match": "SearchByProjection(cur,last) th=15, identity pose", "fast_plan": fast_plan, "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
                        "sharding": "one clip per GPU, no collective"},
             "timed_region_s": round(elapsed, 4),
-            "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "mgpu_end_to_end": mgpu,
+            "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "roofline_pcie": e2e["roofline_pcie"] if e2e else None,
+            "mgpu_end_to_end": mgpu, "mgpu_literal_configs": mgpu_lit,
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "roofline": hbm_roofline(args.workload, kernels, iso, per_kernel, sub, total_bytes, fps / n_gpus) if kernels else None,
             "roofline_valu": valu_roofline(args.workload, kernels, iso, sub) if kernels else None,

@@ -2138,6 +2138,37 @@ void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, ui
     hipLaunchKernelGGL(k_repitch_rows, dim3(blocks), dim3(256), 0, st, src, (unsigned) srcPitch, dst, (unsigned) dstPitch, (unsigned) w, n);
 }
 
+// Frames that lie in page-locked, device-visible HOST memory, read by the kernel itself over the link (no copy-engine call per frame: a batch whose
+// frames do not sit at one stride -- a round-robin share of a clip, the rows of an array of cv::Mat -- would cost one pitched copy per frame, ~40 us
+// of copy-engine set-up each).  Block (x, frame): 16 bytes per lane and step where source and destination allow it (a wave asks for 1 KB of
+// consecutive host bytes at a time), single bytes at the ragged ends.
+__global__ __launch_bounds__(256) void k_gather_host_frames(HostFrameList L, unsigned srcPitch, uint8_t *__restrict__ dst, unsigned dstPitch,
+                                                            unsigned long long dstFrameStride, unsigned w, unsigned h) {
+    const uint8_t *src = (const uint8_t *) L.addr[blockIdx.y];
+    uint8_t *out = dst + (unsigned long long) blockIdx.y * dstFrameStride;
+    const bool vec = (((unsigned long long) src | srcPitch) & 15u) == 0 && (dstPitch & 15u) == 0;   // (dst is 256-byte aligned: the context's own buffer)
+    const unsigned wq = vec ? w >> 4 : 0;                       // whole 16-byte pieces per row
+    const unsigned long long nq = (unsigned long long) wq * h;
+    for (unsigned long long i = (unsigned long long) blockIdx.x * 256u + threadIdx.x; i < nq; i += (unsigned long long) gridDim.x * 256u) {
+        const unsigned y = (unsigned) (i / wq), q = (unsigned) (i - (unsigned long long) y * wq);
+        *(uint4 *) (out + (unsigned long long) y * dstPitch + 16u * q) = *(const uint4 *) (src + (unsigned long long) y * srcPitch + 16u * q);
+    }
+    const unsigned tail = w - 16u * wq;                          // the ragged end of every row (or whole rows when nothing is aligned)
+    const unsigned long long nt = (unsigned long long) tail * h;
+    for (unsigned long long i = (unsigned long long) blockIdx.x * 256u + threadIdx.x; i < nt; i += (unsigned long long) gridDim.x * 256u) {
+        const unsigned y = (unsigned) (i / tail), x = 16u * wq + (unsigned) (i - (unsigned long long) y * tail);
+        out[(unsigned long long) y * dstPitch + x] = src[(unsigned long long) y * srcPitch + x];
+    }
+}
+
+void launch_gather_host_frames(hipStream_t st, const HostFrameList &L, int nFrames, size_t srcPitch, uint8_t *dst, size_t dstPitch, size_t dstFrameStride, int w, int h) {
+    if (nFrames <= 0 || w <= 0 || h <= 0) return;
+    const unsigned long long n16 = ((unsigned long long) w * h + 15) / 16;
+    const unsigned blocks = (unsigned) std::min<unsigned long long>((n16 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_gather_host_frames, dim3(blocks, nFrames), dim3(256), 0, st, L, (unsigned) srcPitch, dst, (unsigned) dstPitch,
+                       (unsigned long long) dstFrameStride, (unsigned) w, (unsigned) h);
+}
+
 // The pyramid chain of ONE frame (levels 1 .. nlevels - 1, each from the one before) as an explicit graph: built node by node (no stream
 // capture, which would put process-wide restrictions on other threads' calls while it is open), retargeted to another frame's buffers by
 // rewriting the nodes' FrameSet argument, launched with one call.

@@ -10,6 +10,9 @@ hipError_t upload_constants(const int *umax16);
 void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
                        const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int w, size_t rows);
+constexpr int kHostFrameListMax = 128;
+struct HostFrameList { unsigned long long addr[kHostFrameListMax]; };   // device-visible addresses of page-locked host frames (by value: kernel argument)
+void launch_gather_host_frames(hipStream_t st, const HostFrameList &L, int nFrames, size_t srcPitch, uint8_t *dst, size_t dstPitch, size_t dstFrameStride, int w, int h);
 struct PyrChainGraph {
     hipGraph_t graph;
     hipGraphExec_t exec;

@@ -1218,8 +1218,67 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
     c->pyrHeld = false;
     const int pitch = align_up(w, 64);
     if ((rc = ensure(c, c->dImg0, (size_t) n_frames * pitch * h))) return rc;
-    for (int f = 0; f < n_frames; f++)
-        if ((rc = upload_rows(c, (uint8_t *) c->dImg0.p + (size_t) f * pitch * h, (size_t) pitch, frames[f], (size_t) row_pitch, w, (size_t) h))) return rc;
+    // frames in page-locked, device-visible host memory are read by a kernel over the link (one launch per 128 frames instead of one pitched copy per
+    // frame); anything else goes through the copy engine frame by frame
+    bool gathered = false;
+    const char *modeEnv = getenv("YGZF_HOST_FRAMES_MODE");      // 1: the kernel reads the host frames itself; 2 (default): one linear copy per frame + one re-pitch launch; 0: pitched copies
+    const int mode = modeEnv ? atoi(modeEnv) : 2;
+    if (mode == 2) {
+        // Into a tight staging buffer with the copy engine's fast paths, then ONE launch per 128 frames that lays the rows out at the context's
+        // pitch.  Frames that come as runs of u back-to-back frames at one distance S (a device slot's round-robin share of a tight clip: units of u
+        // frames, S = slots x u frames) go up as ONE two-dimensional copy whose "rows" are the runs; anything else as one linear copy per frame.
+        const size_t frameBytes = (size_t) (h - 1) * row_pitch + w;
+        const size_t tight = (size_t) h * row_pitch;
+        int u = n_frames;
+        for (int f = 1; f < n_frames; f++)
+            if (frames[f] != frames[f - 1] + tight) { u = f; break; }
+        const int runs = n_frames / u;
+        bool regular = row_pitch == w && n_frames % u == 0;
+        ptrdiff_t S = 0;
+        if (regular && runs > 1) {
+            S = frames[u] - frames[0];
+            regular = S > 0 && (size_t) S >= (size_t) u * tight;
+            for (int f = 0; f < n_frames && regular; f++) regular = frames[f] == frames[0] + (ptrdiff_t) (f / u) * S + (ptrdiff_t) (f % u) * (ptrdiff_t) tight;
+        }
+        const size_t slot = regular ? tight : ((frameBytes + 255) & ~(size_t) 255);
+        if ((rc = ensure(c, c->dUpStage, slot * n_frames + 64))) return rc;
+        if (regular) {
+            if (runs > 1) HIPCHECK(c, hipMemcpy2DAsync(c->dUpStage.p, (size_t) u * tight, frames[0], (size_t) S, (size_t) u * tight, (size_t) runs, hipMemcpyHostToDevice, c->stream));
+            else HIPCHECK(c, hipMemcpyAsync(c->dUpStage.p, frames[0], (size_t) n_frames * tight, hipMemcpyHostToDevice, c->stream));
+        }
+        for (int f0 = 0; f0 < n_frames; f0 += kHostFrameListMax) {
+            HostFrameList L;
+            const int nf = std::min(kHostFrameListMax, n_frames - f0);
+            for (int f = 0; f < nf; f++) {
+                uint8_t *d = (uint8_t *) c->dUpStage.p + slot * (size_t) (f0 + f);
+                if (!regular) HIPCHECK(c, hipMemcpyAsync(d, frames[f0 + f], frameBytes, hipMemcpyHostToDevice, c->stream));
+                L.addr[f] = (unsigned long long) (uintptr_t) d;
+            }
+            launch_gather_host_frames(c->stream, L, nf, (size_t) row_pitch, (uint8_t *) c->dImg0.p + (size_t) f0 * pitch * h, (size_t) pitch, (size_t) pitch * h, w, h);
+        }
+        HIPCHECK(c, hipGetLastError());
+        gathered = true;
+    }
+    if (mode == 1) {
+        gathered = true;
+        for (int f0 = 0; f0 < n_frames && gathered; f0 += kHostFrameListMax) {
+            HostFrameList L;
+            const int nf = std::min(kHostFrameListMax, n_frames - f0);
+            for (int f = 0; f < nf && gathered; f++) {
+                hipPointerAttribute_t at;
+                memset(&at, 0, sizeof at);
+                if (hipPointerGetAttributes(&at, frames[f0 + f]) != hipSuccess) { (void) hipGetLastError(); gathered = false; break; }
+                if (at.type != hipMemoryTypeHost || !at.devicePointer) { gathered = false; break; }
+                L.addr[f] = (unsigned long long) (uintptr_t) at.devicePointer;
+            }
+            if (!gathered) break;
+            launch_gather_host_frames(c->stream, L, nf, (size_t) row_pitch, (uint8_t *) c->dImg0.p + (size_t) f0 * pitch * h, (size_t) pitch, (size_t) pitch * h, w, h);
+        }
+        if (gathered) HIPCHECK(c, hipGetLastError());
+    }
+    if (!gathered)
+        for (int f = 0; f < n_frames; f++)
+            if ((rc = upload_rows(c, (uint8_t *) c->dImg0.p + (size_t) f * pitch * h, (size_t) pitch, frames[f], (size_t) row_pitch, w, (size_t) h))) return rc;
     FrameSet fs;
     fs.img0 = (const uint8_t *) c->dImg0.p;
     fs.img0_stride = (long long) pitch * h;
