@@ -70,7 +70,8 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
 
 ygzf_ctx *ORBextractor::ResidentContext(const cv::Mat &level0) const {
     if (!mCtx || !mLastImagePrint || level0.empty() || !ygzf_has_resident_image(mCtx, level0.cols, level0.rows)) return nullptr;
-    return ygzf_host::image_fingerprint(level0.data, level0.cols, level0.rows, (int) level0.step) == mLastImagePrint ? mCtx : nullptr;
+    // every pixel counts: nothing but the content says that this Frame's level 0 is the image the context holds
+    return ygzf_host::image_hash_full(level0.data, level0.cols, level0.rows, (int) level0.step) == mLastImagePrint ? mCtx : nullptr;
 }
 
 void ORBextractor::ComputePyramid(cv::Mat image) {
@@ -85,7 +86,7 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
         out[l] = mvImagePyramid[l].data;
     }
     mResidentLevel0 = cv::Mat();
-    mLastImagePrint = ygzf_host::image_fingerprint(image.data, image.cols, image.rows, (int) image.step);
+    mLastImagePrint = ygzf_host::image_hash_full(image.data, image.cols, image.rows, (int) image.step);
     {   // extract-ahead follows the tracker's habit: on when the previous pyramid's image was extracted, off when it was not
         const bool want = mExtractAhead && mExtractedSincePyramid;
         if (want != mAheadOn) {
@@ -112,7 +113,7 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     std::vector<uint8_t> desc((size_t) (cap > 0 ? cap : 0) * 32);
     int n = 0;
     mResidentLevel0 = cv::Mat();
-    mLastImagePrint = ygzf_host::image_fingerprint(image.data, image.cols, image.rows, (int) image.step);
+    mLastImagePrint = ygzf_host::image_hash_full(image.data, image.cols, image.rows, (int) image.step);
     if (ygzf_extract(c, image.data, image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
         YGZF_OK) {
         ygzf_host::report_failure("ygz::ORBextractor::operator()", ygzf_last_error(c));
@@ -200,7 +201,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         if (resident) rcE = ygzf_extract_resident(c, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
         if (resident && rcE == YGZF_OK) mExtractedSincePyramid = true;
         if (rcE == YGZF_ERR_STATE) {   // nothing resident (another image operation came in between): the image goes up again
-            mLastImagePrint = ygzf_host::image_fingerprint(img.data, img.cols, img.rows, (int) img.step);
+            mLastImagePrint = ygzf_host::image_hash_full(img.data, img.cols, img.rows, (int) img.step);
             rcE = ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
         }
         mResidentLevel0 = cv::Mat();   // the extraction reuses the buffers: nothing is resident afterwards

@@ -110,7 +110,7 @@ private:
     bool mExtractAhead = true;
     bool mAheadOn = false;            // what the context is set to
     bool mExtractedSincePyramid = true;   // the previous ComputePyramid was followed by an extraction of its image (optimistic start)
-    unsigned long long mLastImagePrint = 0;   // fingerprint of the image of the last operation that sent ONE image to the context (0: none)
+    unsigned long long mLastImagePrint = 0;   // full-content hash (ygzf_host::image_hash_full) of the image of the last operation that sent ONE image to the context (0: none)
 };
 
 }  // namespace ygz

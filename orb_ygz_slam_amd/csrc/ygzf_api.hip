@@ -267,6 +267,7 @@ struct PackedTransfer {
 static void plan_pyr_strips(Geometry &G, int L) {
     G.pyrPlan.clear();
     if (L < 3) return;
+    if (G.lv[0].h >= 65536) return;   // the strip plan packs row ranges into 16-bit fields: taller images keep one launch per level
     for (int l = 1; l < L; l++)
         if (G.lv[l].area2x || !G.lv[l].tiledOk || (G.lv[l].w + 3) / 4 > kPyrStripMaxThreads) return;
     // 752x480, one frame: 16 strips 148 us per resident extraction, 24 146, 32 144, 48 143 (the halo rows grow with the strip count: 1.23 x
@@ -428,6 +429,8 @@ static int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
             g.keyBits = rootBits + 2 * g.depth;
             if (g.keyBits > 32) return fail(c, YGZF_ERR_UNSUPPORTED, "octree path key needs %d bits at level %d", g.keyBits, l);
             g.kpCap = std::max(g.nFeat + 3, 4 * nIni) + 1;
+            // k_octree's work records carry the list position in 16 bits (score | position << 8 | level << 24)
+            if (g.kpCap > 65535) return fail(c, YGZF_ERR_UNSUPPORTED, "level %d would keep up to %d keypoints (at most 65535 per level)", l, g.kpCap);
         } else {
             g.nIni = 1;
             g.hX = 1.f;
@@ -2191,6 +2194,8 @@ int ygzf_extract_fast_keypoint(ygzf_ctx *c, const uint8_t *img, int w, int h, in
     for (int l = 0; l < L; l++) {
         const LevelGeom &g = G.lv[l];
         const long long win = (g.w >= 42 && g.h >= 27) ? (long long) (g.w - 20) * (g.h - 20) : 0;   // narrower / lower levels are skipped (defined; include/ygzf.h)
+        // the vote key carries level << 24 | corner index (dso_kernels.hip, k_fgrid_vote): a level's corners are at most its window's pixels
+        if (win >= (1ll << 24)) return fail(c, YGZF_ERR_UNSUPPORTED, "FAST_KEYPOINT: level %d has %lld candidate positions (at most 2^24 - 1 per level)", l, win);
         lvlOff[l + 1] = lvlOff[l] + win;
         maxWin = std::max(maxWin, (size_t) win);
         maxH = std::max(maxH, g.h);
