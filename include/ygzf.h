@@ -473,6 +473,10 @@ int ygzf_mgpu_extract_match(ygzf_mgpu *m, const uint8_t *frames, int n_frames, i
                             int *n_kp, int stride, int *match, int *nmatches);
 int ygzf_mgpu_extract_stereo(ygzf_mgpu *m, const uint8_t *frames, int n_frames, int w, int h, int row_pitch, size_t frame_stride, float mb, float mbf,
                              ygzf_kp *kps, uint8_t *desc, int *n_kp, int stride, float *u_right, float *depth);
+/* Page-locked, device-visible host memory for frames (what ygzf_mgpu_* and ygzf_extract_batch_host* copy from at the link's full rate, without a
+ * staging copy) for callers that do not link the HIP runtime themselves: hipHostMalloc / hipHostFree on the given device.  NULL on failure. */
+void *ygzf_alloc_host(int device, size_t bytes);
+void ygzf_free_host(void *p);
 int ygzf_mgpu_chunk_frames(const ygzf_mgpu *m);   /* frames per chunk inside a slot (units up to this size alternate between the slot's two contexts) */
 
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------

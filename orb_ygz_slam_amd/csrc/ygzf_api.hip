@@ -144,6 +144,14 @@ struct ygzf_ctx {
     bool evPyrDoneValid = false;
     bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
     int pyrResW = 0, pyrResH = 0;
+    // one-frame uploads from pageable caller memory (a cv::Mat): the rows are copied into this page-locked, device-visible buffer by the host and
+    // read from there by a kernel that writes them at the context's pitch -- the runtime's own pageable path (pin / stage / blit) cost ~50 us for a
+    // 752x480 frame, this ~25.  evIn marks the moment the kernel has read the buffer (the next upload waits for it before overwriting).
+    uint8_t *hIn = nullptr;
+    void *hInDev = nullptr;
+    size_t hInBytes = 0;
+    hipEvent_t evIn = nullptr;
+    bool evInPending = false;
     uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
     size_t hStageBytes = 0;
     // batch state
@@ -864,6 +872,41 @@ static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, i
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
+    if (nFrames == 1 && !getenv("YGZF_NO_STAGED_UPLOAD")) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        bool pageable = true;
+        if (hipPointerGetAttributes(&at, imgs) == hipSuccess) pageable = at.type != hipMemoryTypeHost && at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged;
+        else (void) hipGetLastError();
+        if (pageable) {
+            const size_t bytes = (size_t) w * h;
+            if (bytes > c->hInBytes) {
+                if (c->evInPending) { HIPCHECK(c, hipEventSynchronize(c->evIn)); c->evInPending = false; }
+                if (c->hIn) HIPCHECK(c, hipHostFree(c->hIn));
+                c->hIn = nullptr;
+                c->hInBytes = 0;
+                HIPCHECK(c, hipHostMalloc((void **) &c->hIn, bytes + 64, hipHostMallocMapped));
+                HIPCHECK(c, hipHostGetDevicePointer(&c->hInDev, c->hIn, 0));
+                c->hInBytes = bytes;
+            }
+            if (!c->evIn) HIPCHECK(c, hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
+            if (c->evInPending) { HIPCHECK(c, hipEventSynchronize(c->evIn)); c->evInPending = false; }   // the previous upload's kernel has read the buffer
+            if (row_pitch == w) memcpy(c->hIn, imgs, bytes);
+            else for (int y = 0; y < h; y++) memcpy(c->hIn + (size_t) y * w, imgs + (size_t) y * row_pitch, (size_t) w);
+            HostFrameList L;
+            L.addr[0] = (unsigned long long) (uintptr_t) c->hInDev;
+            launch_gather_host_frames(c->stream, L, 1, (size_t) w, (uint8_t *) c->dImg0.p, (size_t) pitch, (size_t) pitch * h, w, h);
+            HIPCHECK(c, hipGetLastError());
+            HIPCHECK(c, hipEventRecord(c->evIn, c->stream));
+            c->evInPending = true;
+            fs->img0 = (const uint8_t *) c->dImg0.p;
+            fs->img0_stride = (long long) pitch * h;
+            fs->img0_pitch = pitch;
+            fs->pyr = (uint8_t *) c->dPyr.p;
+            fs->pyr_stride = c->geo.pyrBytes;
+            return YGZF_OK;
+        }
+    }
     if (nFrames == 1 || frame_stride == (size_t) row_pitch * h) {   // frames back to back: one copy of nFrames * h rows
         if ((rc = upload_rows(c, c->dImg0.p, (size_t) pitch, imgs, (size_t) row_pitch, w, (size_t) nFrames * h))) return rc;
     } else {
@@ -974,6 +1017,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
     if (c->hFastStats) (void) hipHostFree(c->hFastStats);
     if (c->hStage) (void) hipHostFree(c->hStage);
+    if (c->hIn) (void) hipHostFree(c->hIn);
+    if (c->evIn) (void) hipEventDestroy(c->evIn);
     for (auto &r : c->recs) { (void) hipEventDestroy(r.a); (void) hipEventDestroy(r.b); }
     for (auto e : c->pool) (void) hipEventDestroy(e);
     pyr_chain_graph_destroy(&c->pyrGraph);

@@ -149,6 +149,15 @@ void ygzf_mgpu_destroy(ygzf_mgpu *m) {
     delete m;
 }
 
+void *ygzf_alloc_host(int device, size_t bytes) {
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    return p;
+}
+void ygzf_free_host(void *p) {
+    if (p) (void) hipHostFree(p);
+}
+
 const char *ygzf_mgpu_last_error(const ygzf_mgpu *m) { return m ? m->err.c_str() : "null handle"; }
 int ygzf_mgpu_device_count(const ygzf_mgpu *m) { return m ? (int) m->devs.size() : 0; }
 int ygzf_mgpu_keypoint_stride(const ygzf_mgpu *m) { return m ? m->stride : 0; }

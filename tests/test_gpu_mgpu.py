@@ -140,9 +140,12 @@ def test_page_locked_frames_skip_the_staging_copy():
         mg = MultiGpu([0, 0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=n)
         assert mg.chunk_frames() == 6
         ref = mg.extract_match(frames, unit=2, cam=cam)
-        hip = C.CDLL("libamdhip64.so")
-        ptr = C.c_void_p()
-        assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(frames.nbytes), C.c_uint(0)) == 0
+        L = mg.L                                       # (page-locked memory from the library itself: ctypes finding "libamdhip64.so" by name may hand
+        L.ygzf_alloc_host.restype = C.c_void_p         #  back another copy of the runtime -- torch bundles one -- that has no device initialised)
+        L.ygzf_alloc_host.argtypes = [C.c_int, C.c_size_t]
+        L.ygzf_free_host.argtypes = [C.c_void_p]
+        ptr = C.c_void_p(L.ygzf_alloc_host(0, frames.nbytes))
+        assert ptr.value
         pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(frames.nbytes,)).reshape(frames.shape)
         pinned[:] = frames
         got = mg.extract_match(pinned, unit=2, cam=cam)
@@ -150,7 +153,7 @@ def test_page_locked_frames_skip_the_staging_copy():
         got4 = mg.extract_match(pinned, unit=4, cam=cam)
         mg.close()
         del pinned
-        hip.hipHostFree(ptr)
+        L.ygzf_free_host(ptr)
     finally:
         del os.environ["YGZF_MGPU_CHUNK"]
     for a, b, name in zip(ref, got, ("kps", "desc", "n_kp", "match", "nmatches")):
