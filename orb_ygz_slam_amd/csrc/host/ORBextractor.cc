@@ -69,9 +69,16 @@ ygzf_ctx *ORBextractor::ensureContext(int w, int h) {
 }
 
 ygzf_ctx *ORBextractor::ResidentContext(const cv::Mat &level0) const {
-    if (!mCtx || !mLastImagePrint || level0.empty() || !ygzf_has_resident_image(mCtx, level0.cols, level0.rows)) return nullptr;
-    // every pixel counts: nothing but the content says that this Frame's level 0 is the image the context holds
-    return ygzf_host::image_hash_full(level0.data, level0.cols, level0.rows, (int) level0.step) == mLastImagePrint ? mCtx : nullptr;
+    if (!mCtx || mHeldImage.empty() || level0.empty() || level0.cols != mHeldImage.cols || level0.rows != mHeldImage.rows ||
+        !ygzf_has_resident_image(mCtx, level0.cols, level0.rows))
+        return nullptr;
+    if (level0.data == mVerifiedData || level0.data == mHeldImage.data) return mCtx;     // asked before (or the very buffer that went up)
+    // nothing but the content says that this Frame's level 0 is the image the context holds: every pixel is compared (a Frame's level 0 is a
+    // deep clone of the extractor's, src/Frame.cc:812)
+    for (int y = 0; y < level0.rows; y++)
+        if (std::memcmp(level0.ptr(y), mHeldImage.ptr(y), (size_t) level0.cols) != 0) return nullptr;
+    mVerifiedData = level0.data;
+    return mCtx;
 }
 
 void ORBextractor::ComputePyramid(cv::Mat image) {
@@ -86,7 +93,8 @@ void ORBextractor::ComputePyramid(cv::Mat image) {
         out[l] = mvImagePyramid[l].data;
     }
     mResidentLevel0 = cv::Mat();
-    mLastImagePrint = ygzf_host::image_hash_full(image.data, image.cols, image.rows, (int) image.step);
+    mHeldImage = image;
+    mVerifiedData = nullptr;
     {   // extract-ahead follows the tracker's habit: on when the previous pyramid's image was extracted, off when it was not
         const bool want = mExtractAhead && mExtractedSincePyramid;
         if (want != mAheadOn) {
@@ -113,7 +121,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray, std::vector
     std::vector<uint8_t> desc((size_t) (cap > 0 ? cap : 0) * 32);
     int n = 0;
     mResidentLevel0 = cv::Mat();
-    mLastImagePrint = ygzf_host::image_hash_full(image.data, image.cols, image.rows, (int) image.step);
+    mHeldImage = image;
+    mVerifiedData = nullptr;
     if (ygzf_extract(c, image.data, image.cols, image.rows, (int) image.step, (ygzf_kp *) _keypoints.data(), desc.data(), cap, &n) !=
         YGZF_OK) {
         ygzf_host::report_failure("ygz::ORBextractor::operator()", ygzf_last_error(c));
@@ -156,7 +165,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         std::vector<uint8_t> d((size_t) cap * 32);
         for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];   // right eye: ComputeKeyPointsFast gets an empty list (:1049-1050)
         int total = 0;
-        mLastImagePrint = 0;   // (the grid detectors keep no complete pyramid on the device)
+        mHeldImage = cv::Mat();   // (the grid detectors keep no complete pyramid on the device)
         if (ygzf_extract_fast_keypoint(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &total) != YGZF_OK) {
             ygzf_host::report_failure("ygz::ORBextractor (FAST_KEYPOINT)", ygzf_last_error(c));
             return;
@@ -174,7 +183,7 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         std::vector<uint8_t> d((size_t) cap * 32);
         for (int i = 0; i < N; i++) all[i] = frame->mvKeys[i];
         int total = 0;
-        mLastImagePrint = 0;
+        mHeldImage = cv::Mat();
         if (ygzf_extract_dso(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) all.data(), N, cap, d.data(), &mnGridSize, &total) !=
             YGZF_OK) {
             ygzf_host::report_failure("ygz::ORBextractor (DSO_KEYPOINT)", ygzf_last_error(c));
@@ -201,7 +210,8 @@ void ORBextractor::operator()(Frame *frame, std::vector<cv::KeyPoint> &_keypoint
         if (resident) rcE = ygzf_extract_resident(c, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
         if (resident && rcE == YGZF_OK) mExtractedSincePyramid = true;
         if (rcE == YGZF_ERR_STATE) {   // nothing resident (another image operation came in between): the image goes up again
-            mLastImagePrint = ygzf_host::image_hash_full(img.data, img.cols, img.rows, (int) img.step);
+            mHeldImage = img;
+            mVerifiedData = nullptr;
             rcE = ygzf_extract(c, img.data, img.cols, img.rows, (int) img.step, (ygzf_kp *) fresh.data(), descNew.data(), cap, &n);
         }
         mResidentLevel0 = cv::Mat();   // the extraction reuses the buffers: nothing is resident afterwards
@@ -241,7 +251,7 @@ void ORBextractor::ComputeStereoMatches(Frame &F) {
     for (int i = 0; i < F.N; i++) std::memcpy(&dl[(size_t) i * 32], F.mDescriptors.ptr(i), 32);
     for (int i = 0; i < Nr; i++) std::memcpy(&dr[(size_t) i * 32], F.mDescriptorsRight.ptr(i), 32);
     if (imL.step != F.mImRight.step) { ygzf_host::report_failure("ygz::ORBextractor::ComputeStereoMatches", "left/right row steps differ"); return; }
-    mLastImagePrint = 0;
+    mHeldImage = cv::Mat();
     if (ygzf_compute_stereo_matches(c, imL.data, F.mImRight.data, imL.cols, imL.rows, (int) imL.step, F.N,
                                     (const ygzf_kp *) F.mvKeys.data(), dl.data(), Nr, (const ygzf_kp *) F.mvKeysRight.data(), dr.data(), F.mb, F.mbf,
                                     F.mvuRight.data(), F.mvDepth.data()) != YGZF_OK)

@@ -110,7 +110,11 @@ private:
     bool mExtractAhead = true;
     bool mAheadOn = false;            // what the context is set to
     bool mExtractedSincePyramid = true;   // the previous ComputePyramid was followed by an extraction of its image (optimistic start)
-    unsigned long long mLastImagePrint = 0;   // full-content hash (ygzf_host::image_hash_full) of the image of the last operation that sent ONE image to the context (0: none)
+    // The image of the last operation that sent ONE image to the context (a header sharing the caller's / the pyramid's buffer; empty: none), for
+    // ResidentContext: "is this Frame's level 0 exactly what the device holds?" is answered by comparing the pixels themselves -- every one of
+    // them, no hash, nothing to collide -- the first time a buffer is asked about, and by that buffer's address afterwards.
+    cv::Mat mHeldImage;
+    mutable const void *mVerifiedData = nullptr;
 };
 
 }  // namespace ygz

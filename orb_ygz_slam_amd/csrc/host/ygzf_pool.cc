@@ -161,26 +161,6 @@ unsigned long long image_fingerprint(const unsigned char *data, int cols, int ro
     return hsh;
 }
 
-unsigned long long image_hash_full(const unsigned char *data, int cols, int rows, int step) {
-    unsigned long long a[4] = {0x9E3779B97F4A7C15ull ^ (unsigned long long) cols, 0xC2B2AE3D27D4EB4Full ^ (unsigned long long) rows, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
-    const int nw = cols / 8;
-    for (int y = 0; y < rows; y++) {
-        const unsigned char *row = data + (size_t) y * step;
-        int i = 0;
-        for (; i + 4 <= nw; i += 4) {
-            unsigned long long v[4];
-            memcpy(v, row + 8 * (size_t) i, 32);
-            for (int k = 0; k < 4; k++) { a[k] = (a[k] ^ v[k]) * 0x100000001B3ull; a[k] ^= a[k] >> 29; }
-        }
-        unsigned long long tail = 0;
-        for (int b = 8 * i; b < cols; b++) tail = (tail << 8 | row[b]) * 0x100000001B3ull;
-        a[y & 3] = (a[y & 3] ^ tail ^ (unsigned long long) y) * 0x100000001B3ull;
-    }
-    unsigned long long hsh = a[0];
-    for (int k = 1; k < 4; k++) hsh = (hsh ^ (a[k] + 0x9E3779B97F4A7C15ull + (hsh << 6) + (hsh >> 2))) * 0x100000001B3ull;
-    return hsh ? hsh : 1;
-}
-
 int ImageCache::slot(Kind kind, unsigned long id, const unsigned char *data, int cols, int rows, int step, const char *who, ygzf_ctx *resident) {
     Impl &I = *impl_;
     if (!ctx_ || cols != I.w || rows != I.h || cols < 8) return -1;

@@ -38,10 +38,6 @@ private:
 
 // 64-bit content hash over ~32 KB of an 8-bit image (64 rows x 64 eight-byte words spread over it, mixed with the size)
 unsigned long long image_fingerprint(const unsigned char *data, int cols, int rows, int step);
-// 64-bit hash over EVERY pixel (four interleaved multiply-mix lanes: ~15 us for 752x480).  Used where nothing but the content identifies an image
-// (ORBextractor::ResidentContext: "does the device still hold exactly this Frame's image?"): two frames of a static or synthetic scene can agree on
-// every pixel image_fingerprint samples and still differ.
-unsigned long long image_hash_full(const unsigned char *data, int cols, int rows, int step);
 
 // Device-resident level-0 images + pyramids of recent Frames and KeyFrames, shared by the shells that read images (FindDirectProjection,
 // SparseImgAlign::run): an image is uploaded the first time it is referenced and its pyramid rebuilt on the device by the extractor's

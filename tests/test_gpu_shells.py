@@ -207,6 +207,11 @@ def test_shell_latency_per_frame(tmp_path):
     out = subprocess.run([exe, str(tmp_path), "200"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     print(out.stdout)
+    try:                                                    # travels back from the GPU box with the run's other files (profiles/rNN_*_shell_latency.txt)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "shell_latency.txt"), "w").write(out.stdout)
+    except OSError:
+        pass
     med = {l.split()[0]: float(l.split()[1]) for l in out.stdout.splitlines() if l and not l.startswith("info")}
     assert {"extract_image", "frame_pyramid_plus_extract", "sparse_img_align_run", "search_by_projection_last"} <= set(med)
     # a 30 Hz camera leaves 33 ms per frame; the CPU reference spends ~20 ms in the extractor alone
