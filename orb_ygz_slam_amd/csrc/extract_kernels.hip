@@ -113,53 +113,36 @@ __device__ void block_radix_sort(unsigned *k0, unsigned *v0, unsigned *k1, unsig
     for (int shift = 0; shift < bits; shift += kRadixBits) {
         for (int t = threadIdx.x; t < NB * 16; t += blockDim.x) histT[t] = 0;
         __syncthreads();
-        // (four 64-key pieces of the wave's segment per step: their loads are in flight together -- a level of 60 000 candidates sorted through
-        // global memory spent 1.4 ms in these two loops at one dependent round trip per piece)
-        constexpr int kRU = 4;
-        for (int base = start; base < end; base += 64 * kRU) {
-            int d[kRU];
-#pragma unroll
-            for (int u = 0; u < kRU; u++) {
-                const int i = base + u * 64 + lane;
-                d[u] = i < end ? (int) ((k0[i] >> shift) & (NB - 1)) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < kRU; u++)
-                if (d[u] >= 0) atomicAdd((int *) &histT[d[u] * 16 + wave], 1);
+        for (int i = start + lane; i < end; i += 64) {
+            const int d = (k0[i] >> shift) & (NB - 1);
+            atomicAdd((int *) &histT[d * 16 + wave], 1);
         }
         __syncthreads();
         block_scan_array((int *) histT, NB * 16, tmp);   // exclusive, digit-major then wave: the scatter base of every (digit, wave)
-        for (int base = start; base < end; base += 64 * kRU) {
-            unsigned key[kRU], val[kRU];
+        for (int base = start; base < end; base += 64) {
+            const int i = base + lane;
+            const bool valid = i < end;
+            const unsigned key = valid ? k0[i] : 0u;
+            const unsigned val = valid ? v0[i] : 0u;
+            const int d = (key >> shift) & (NB - 1);
+            unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (int u = 0; u < kRU; u++) {
-                const int i = base + u * 64 + lane;
-                key[u] = i < end ? k0[i] : 0u;
-                val[u] = i < end ? v0[i] : 0u;
+            for (int b = 0; b < kRadixBits; b++) {
+                const bool bit = (d >> b) & 1;
+                const unsigned long long bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
             }
-#pragma unroll
-            for (int u = 0; u < kRU; u++) {
-                const bool valid = base + u * 64 + lane < end;
-                const int d = (key[u] >> shift) & (NB - 1);
-                unsigned long long m = __ballot(valid);
-#pragma unroll
-                for (int b = 0; b < kRadixBits; b++) {
-                    const bool bit = (d >> b) & 1;
-                    const unsigned long long bal = __ballot(bit);
-                    m &= bit ? bal : ~bal;
-                }
-                const int rank = __popcll(m & lt);
-                const int cnt = __popcll(m);
-                int pos = 0;
-                if (valid) pos = histT[d * 16 + wave] + rank;
-                __builtin_amdgcn_wave_barrier();
-                if (valid) {
-                    k1[pos] = key[u];
-                    v1[pos] = val[u];
-                    if (rank == cnt - 1) histT[d * 16 + wave] = pos + 1;
-                }
-                __builtin_amdgcn_wave_barrier();
+            const int rank = __popcll(m & lt);
+            const int cnt = __popcll(m);
+            int pos = 0;
+            if (valid) pos = histT[d * 16 + wave] + rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                k1[pos] = key;
+                v1[pos] = val;
+                if (rank == cnt - 1) histT[d * 16 + wave] = pos + 1;
             }
+            __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
         unsigned *t = k0; k0 = k1; k1 = t;
