@@ -41,6 +41,15 @@ namespace {
 // ORBmatcher objects are created on the stack per call from several threads: every call leases a context of the device
 // extractors are created on (ORBextractor::sDevice) from the per-device pool.
 inline int device() { return ORBextractor::sDevice; }
+// the rows of an N x 32 descriptor matrix as one block: the Mat's own buffer when it is continuous (what the extractor produces), a packed copy
+// in `hold` otherwise (a Mat assembled from row ranges)
+inline const uint8_t *desc_rows(const cv::Mat &D, int n, std::vector<uint8_t> &hold) {
+    if (n <= 0) return nullptr;
+    if (D.isContinuous() && D.cols == 32) return D.ptr<uint8_t>(0);
+    hold.resize((size_t) n * 32);
+    for (int i = 0; i < n; i++) std::memcpy(&hold[(size_t) i * 32], D.ptr<uint8_t>(i), 32);
+    return hold.data();
+}
 }  // namespace
 
 int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono, bool checkLevel) {
@@ -64,16 +73,16 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, 
         }
     }
     // ---- pack CurrentFrame ----
-    std::vector<uint8_t> owner(nt), cdesc((size_t) nt * 32);
+    std::vector<uint8_t> owner(nt), cdescHold;
     for (int i = 0; i < nt; i++) {
         MapPoint *mp = CurrentFrame.mvpMapPoints[i];
         owner[i] = mp ? (mp->Observations() > 0 ? 2 : 1) : 0;
-        std::memcpy(&cdesc[(size_t) i * 32], CurrentFrame.mDescriptors.ptr<uint8_t>(i), 32);
     }
+    const uint8_t *cdesc = desc_rows(CurrentFrame.mDescriptors, nt, cdescHold);
     ygzf_frame_view cur;
     cur.n = nt;
     cur.keys = (const ygzf_kp *) CurrentFrame.mvKeys.data();
-    cur.desc = cdesc.data();
+    cur.desc = cdesc;
     cur.u_right = CurrentFrame.mvuRight.empty() ? nullptr : CurrentFrame.mvuRight.data();
     cur.scale_factors = CurrentFrame.mvScaleFactors.data();
     cur.nlevels = (int) CurrentFrame.mvScaleFactors.size();
@@ -119,16 +128,16 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
         const cv::Mat d = mp->GetDescriptor();
         std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
     }
-    std::vector<uint8_t> owner(nt), cdesc((size_t) nt * 32);
+    std::vector<uint8_t> owner(nt), cdescHold;
     for (int i = 0; i < nt; i++) {
         MapPoint *mp = F.mvpMapPoints[i];
         owner[i] = mp ? (mp->Observations() > 0 ? 2 : 1) : 0;
-        std::memcpy(&cdesc[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
     }
+    const uint8_t *cdesc = desc_rows(F.mDescriptors, nt, cdescHold);
     ygzf_frame_view fv;
     fv.n = nt;
     fv.keys = (const ygzf_kp *) F.mvKeys.data();
-    fv.desc = cdesc.data();
+    fv.desc = cdesc;
     fv.u_right = F.mvuRight.empty() ? nullptr : F.mvuRight.data();
     fv.scale_factors = F.mvScaleFactors.data();
     fv.nlevels = (int) F.mvScaleFactors.size();
@@ -184,15 +193,13 @@ int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const std
         const cv::Mat d = pMP->GetDescriptor();
         std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
     }
-    std::vector<uint8_t> owner(nt), cdesc((size_t) nt * 32);
-    for (int i = 0; i < nt; i++) {
-        owner[i] = CurrentFrame.mvpMapPoints[i] != nullptr;
-        std::memcpy(&cdesc[(size_t) i * 32], CurrentFrame.mDescriptors.ptr<uint8_t>(i), 32);
-    }
+    std::vector<uint8_t> owner(nt), cdescHold;
+    for (int i = 0; i < nt; i++) owner[i] = CurrentFrame.mvpMapPoints[i] != nullptr;
+    const uint8_t *cdesc = desc_rows(CurrentFrame.mDescriptors, nt, cdescHold);
     ygzf_frame_view cur;
     cur.n = nt;
     cur.keys = (const ygzf_kp *) CurrentFrame.mvKeys.data();
-    cur.desc = cdesc.data();
+    cur.desc = cdesc;
     cur.u_right = nullptr;
     cur.scale_factors = CurrentFrame.mvScaleFactors.data();
     cur.nlevels = (int) CurrentFrame.mvScaleFactors.size();
@@ -239,19 +246,16 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     }
     const int nNodes = (int) kfOff.size() - 1, nKF = (int) vpMapPointsKF.size();
     if (nNodes <= 0 || F.N <= 0 || nKF <= 0) return 0;
-    std::vector<uint8_t> valid(nKF), kfDesc((size_t) nKF * 32), fDesc((size_t) F.N * 32);
-    for (int i = 0; i < nKF; i++) {
-        valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
-        std::memcpy(&kfDesc[(size_t) i * 32], pKF->mDescriptors.ptr<uint8_t>(i), 32);
-    }
-    for (int i = 0; i < F.N; i++) std::memcpy(&fDesc[(size_t) i * 32], F.mDescriptors.ptr<uint8_t>(i), 32);
+    std::vector<uint8_t> valid(nKF), kfHold, fHold;
+    for (int i = 0; i < nKF; i++) valid[i] = vpMapPointsKF[i] && !vpMapPointsKF[i]->isBad();
+    const uint8_t *kfDesc = desc_rows(pKF->mDescriptors, nKF, kfHold), *fDesc = desc_rows(F.mDescriptors, F.N, fHold);
     ygzf_host::Lease lease(device());
     if (!lease) return 0;
     ygzf_ctx *c = lease.get();
     std::vector<int> match(F.N, -1);
     int nmatches = 0;
     const int rc = ygzf_search_by_bow(c, nNodes, kfOff.data(), kfIdx.data(), fOff.data(), fIdx.data(), nKF, valid.data(), (const ygzf_kp *) pKF->mvKeys.data(),
-                                      kfDesc.data(), F.N, (const ygzf_kp *) F.mvKeys.data(), fDesc.data(), mfNNratio, mbCheckOrientation, match.data(),
+                                      kfDesc, F.N, (const ygzf_kp *) F.mvKeys.data(), fDesc, mfNNratio, mbCheckOrientation, match.data(),
                                       &nmatches);
     if (rc != YGZF_OK) ygzf_host::report_failure("ygz::ORBmatcher::SearchByBoW", ygzf_last_error(c));
     if (rc != YGZF_OK) return 0;
@@ -264,13 +268,12 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
 int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize) {
     vnMatches12 = std::vector<int>(F1.N, -1);
     if (F1.N <= 0 || F2.N <= 0) return 0;
-    std::vector<uint8_t> d1((size_t) F1.N * 32), d2((size_t) F2.N * 32);
-    for (int i = 0; i < F1.N; i++) std::memcpy(&d1[(size_t) i * 32], F1.mDescriptors.ptr<uint8_t>(i), 32);
-    for (int i = 0; i < F2.N; i++) std::memcpy(&d2[(size_t) i * 32], F2.mDescriptors.ptr<uint8_t>(i), 32);
+    std::vector<uint8_t> h1, h2;
+    const uint8_t *d1 = desc_rows(F1.mDescriptors, F1.N, h1), *d2 = desc_rows(F2.mDescriptors, F2.N, h2);
     ygzf_frame_view v1, v2;
-    v1.n = F1.N; v1.keys = (const ygzf_kp *) F1.mvKeys.data(); v1.desc = d1.data(); v1.u_right = nullptr;
+    v1.n = F1.N; v1.keys = (const ygzf_kp *) F1.mvKeys.data(); v1.desc = d1; v1.u_right = nullptr;
     v1.scale_factors = F1.mvScaleFactors.data(); v1.nlevels = (int) F1.mvScaleFactors.size();
-    v2.n = F2.N; v2.keys = (const ygzf_kp *) F2.mvKeys.data(); v2.desc = d2.data(); v2.u_right = nullptr;
+    v2.n = F2.N; v2.keys = (const ygzf_kp *) F2.mvKeys.data(); v2.desc = d2; v2.u_right = nullptr;
     v2.scale_factors = F2.mvScaleFactors.data(); v2.nlevels = (int) F2.mvScaleFactors.size();
     ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F2.mb, F2.mbf, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
     static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f layout");

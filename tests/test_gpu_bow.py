@@ -39,6 +39,26 @@ def test_bow_descent_bit_exact(oracle, tmp_path, k, L, levelsup, seed):
         assert sorted(g_fv) == sorted(r_fv) and all((g_fv[key] == r_fv[key]).all() for key in g_fv)
 
 
+def test_bow_descent_at_orbvoc_size(oracle):
+    """The shape of the reference's ORBvoc (k = 10, L = 6: 1 111 111 nodes, 10^6 words, levelsup 4 as Frame::ComputeBoW asks -- the blob itself is
+    not shipped, /root/reference/.MISSING_LARGE_BLOBS): the whole tree resident in HBM (36 MB of centroids), 4000 descriptors, leaf and level-2 node of
+    every one equal to the oracle's descent; the BowVector / FeatureVector assembled from the device's descent equal the oracle's, doubles bit for bit."""
+    from orb_ygz_slam_amd import Extractor
+    k, L, levelsup = 10, 6, 4
+    voc = oracle.make_vocabulary(11, k, L)
+    assert len(voc["parent"]) == 1111111 and int(voc["is_leaf"].sum()) == 1000000
+    ex = Extractor(max_width=64, max_height=64)
+    ex.vocabulary_set(voc["parent"], voc["desc"], L)
+    d = _descs(voc, 4000, 77)
+    leaf, nid = ex.bow_transform(d, levelsup)
+    o_leaf, o_nid = oracle.bow_descend(voc, d, levelsup)
+    assert (leaf == o_leaf).all() and (nid == o_nid).all() and voc["is_leaf"][leaf].all()
+    assert len(np.unique(leaf)) > 3000 and len(np.unique(nid)) > 90          # spread over the tree: words of many branches, the 100 level-2 nodes
+    g = oracle.bow_vectors(voc, leaf, nid)
+    o = oracle.bow_vectors(voc, o_leaf, o_nid)
+    assert (g[0] == o[0]).all() and (g[1].view(np.uint64) == o[1].view(np.uint64)).all() and sorted(g[2]) == sorted(o[2])
+
+
 def test_bow_ties_ragged_and_errors(oracle):
     from orb_ygz_slam_amd import Extractor
     from orb_ygz_slam_amd.capi import YgzfError
