@@ -319,6 +319,24 @@ void Tracking::SearchLocalPointsDirect() {
         }
     };
 
+    // a point aligned at `at`: the frame gets a key there (size 7, level 0, no angle) that belongs to the point (:2228-2236 / :2307-2313)
+    auto append_key = [&](MapPoint *mp, const Vector2f &at) {
+        mCurrentFrame.mvKeys.push_back(cv::KeyPoint(cv::Point2f(at[0], at[1]), 7, -1, 0, 0));
+        mCurrentFrame.mvpMapPoints.push_back(mp);
+        mCurrentFrame.mvDepth.push_back(-1);
+        mCurrentFrame.mvbOutlier.push_back(false);
+    };
+    // mean of the accepted pixels of one point (the reference averages a list that holds at most one entry: the candidate loop stops at the first success)
+    auto mean_px = [](const std::vector<Vector2f> &v) {
+        Vector2f m(0, 0);
+        for (const Vector2f &q : v) m += q;
+        return Vector2f(m / v.size());
+    };
+    auto finish = [&]() {
+        mCurrentFrame.N = mCurrentFrame.mvKeys.size();
+        mCurrentFrame.mvuRight.resize(mCurrentFrame.N, -1);
+    };
+
     if (!mvpDirectMapPointsCache.empty()) {
         // the cached points: frustum of all of them at once, every candidate of those in view at once, then the reference's loop (:2185-2256)
         const std::vector<MapPoint *> pts(mvpDirectMapPointsCache.begin(), mvpDirectMapPointsCache.end());
@@ -326,8 +344,7 @@ void Tracking::SearchLocalPointsDirect() {
         for (size_t i = 0; i < pts.size(); i++) notBad[i] = !pts[i]->isBad();
         DirectBatch B;
         if (!frustum_batch(mCurrentFrame, pts, notBad, inView, who) || !run_batch(pts, inView, B)) {
-            mCurrentFrame.N = mCurrentFrame.mvKeys.size();
-            mCurrentFrame.mvuRight.resize(mCurrentFrame.N, -1);
+            finish();
             return;
         }
         int p = 0;
@@ -346,28 +363,19 @@ void Tracking::SearchLocalPointsDirect() {
             }
             std::vector<Vector2f> matched_pixels;
             consume(B, p, matched_pixels);
-            if (!matched_pixels.empty()) {
-                Vector2f px_ave(0, 0);
-                for (Vector2f &q : matched_pixels) px_ave += q;
-                px_ave = px_ave / matched_pixels.size();
-                mCurrentFrame.mvKeys.push_back(cv::KeyPoint(cv::Point2f(px_ave[0], px_ave[1]), 7, -1, 0, 0));
-                mCurrentFrame.mvpMapPoints.push_back(mp);
-                mCurrentFrame.mvDepth.push_back(-1);
-                mCurrentFrame.mvbOutlier.push_back(false);
-                gx = static_cast<int>(px_ave[0] / grid_size);
-                gy = static_cast<int>(px_ave[1] / grid_size);
-                k = gy * grid_cols + gx;
-                grid[k] = true;
-                iter++;
-                cntSuccess++;
-            } else {
+            if (matched_pixels.empty()) {                       // never aligned: the point leaves the cache
                 iter = mvpDirectMapPointsCache.erase(iter);
+                continue;
             }
+            const Vector2f px_ave = mean_px(matched_pixels);
+            append_key(mp, px_ave);
+            grid[static_cast<int>(px_ave[1] / grid_size) * grid_cols + static_cast<int>(px_ave[0] / grid_size)] = true;   // the cell of the ALIGNED position
+            iter++;
+            cntSuccess++;
         }
     }
-    if (cntSuccess > mnCacheHitTh) {
-        mCurrentFrame.N = mCurrentFrame.mvKeys.size();
-        mCurrentFrame.mvuRight.resize(mCurrentFrame.N, -1);
+    if (cntSuccess > mnCacheHitTh) {   // enough hits in the cache: the local map is not consulted (:2248-2254)
+        finish();
         return;
     }
     UpdateLocalMap();
@@ -385,21 +393,13 @@ void Tracking::SearchLocalPointsDirect() {
                 if (!eval[p] || mvpDirectMapPointsCache.find(mp) != mvpDirectMapPointsCache.end() || !inView[p]) continue;
                 std::vector<Vector2f> matched_pixels;
                 consume(B, (int) p, matched_pixels);
-                if (!matched_pixels.empty()) {
-                    Vector2f px_ave(0, 0);
-                    for (Vector2f &q : matched_pixels) px_ave += q;
-                    px_ave = px_ave / matched_pixels.size();
-                    mCurrentFrame.mvKeys.push_back(cv::KeyPoint(cv::Point2f(px_ave[0], px_ave[1]), 7, -1, 0, 0));
-                    mCurrentFrame.mvpMapPoints.push_back(mp);
-                    mCurrentFrame.mvDepth.push_back(-1);
-                    mCurrentFrame.mvbOutlier.push_back(false);
-                    mvpDirectMapPointsCache.insert(mp);
-                }
+                if (matched_pixels.empty()) continue;
+                append_key(mp, mean_px(matched_pixels));
+                mvpDirectMapPointsCache.insert(mp);
             }
         }
     }
-    mCurrentFrame.N = mCurrentFrame.mvKeys.size();
-    mCurrentFrame.mvuRight.resize(mCurrentFrame.N, -1);
+    finish();
 }
 
 }  // namespace ygz

@@ -17,6 +17,11 @@
 //   Frame::isInFrustum (reference, CPU) feeding ORBmatcher(0.8).SearchByProjection(F, mappoints, th) (Tracking::SearchLocalPoints),
 //   SparseImgAlign(nLevels-1, 1).run(&last, &cur, TCR) (Tracking.cc:207, :2087) through the reference's own class declaration,
 //   and the shell's device ComputeStereoMatches(F) beside the reference's CPU one.
+// Round 4: the BATCH bindings (orb_ygz_slam_amd/csrc/host/TrackingBatched.cc, FrameStereo.cc) are linked as the strong definitions of
+//   Tracking::SearchLocalPoints, Tracking::SearchLocalPointsDirect and Frame::ComputeStereoMatches; the reference's own bodies of the three stay
+//   callable under other names (ygz_ref_*: a renamed, all-weak second copy of the objects, tests/cpp/build_boundary.sh).  Both forms run here on the
+//   same objects -- identical mvpMapPoints / MapPoint tracking fields / appended keys / mvMatchedFrom / cache / mvuRight / mvDepth are demanded in
+//   this process, and the medians of both forms are printed ("latency ..." lines).
 // usage: boundary_frame <dir>   reads <dir>/left.u8 right.u8 next.u8 (W x H u8, sizes in <dir>/size.i32), writes *.bin
 #include <opencv2/core/core.hpp>
 
