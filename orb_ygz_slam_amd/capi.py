@@ -270,6 +270,18 @@ class Extractor:
         self._inflight.append(imgs)   # the H2D copy is asynchronous: the frames must stay alive until the next synchronising call
         self._wh = (w, h, n)
 
+    def extract_batch_host_frames(self, frames, row_pitch=None):
+        """ygzf_extract_batch_host_frames: a list of 2-D uint8 arrays (or views with a common row pitch) of one size, anywhere in host memory."""
+        frames = [f if (f.dtype == np.uint8 and f.strides[1] == 1) else np.ascontiguousarray(f, np.uint8) for f in frames]
+        h, w = frames[0].shape
+        pitch = row_pitch or frames[0].strides[0]
+        assert all(f.shape == (h, w) and f.strides[0] == pitch for f in frames)
+        ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        self.L.ygzf_extract_batch_host_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        self._ck(self.L.ygzf_extract_batch_host_frames(self.h, ptrs, len(frames), w, h, pitch))
+        self._inflight.append(frames)
+        self._wh = (w, h, len(frames))
+
     def extract_batch_device(self, dptr, n, w, h, row_pitch=None, frame_stride=None):
         row_pitch = row_pitch or w
         frame_stride = frame_stride or row_pitch * h

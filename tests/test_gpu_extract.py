@@ -352,3 +352,46 @@ def test_pyramid_contexts_of_different_sizes_on_one_device(oracle):
         for l in range(8):
             got = exs[k].batch_fetch_level(0, l)
             assert (got == want[k][l]).all(), (k, l)
+
+
+def test_frames_from_a_pointer_list(oracle):
+    """ygzf_extract_batch_host_frames: frames anywhere in host memory -- out of order, row-strided views (crops of a larger image), a regular round-robin
+    share of a clip (one two-dimensional copy), frames in page-locked memory -- give the bytes of the same frames handed over as one tight block."""
+    import ctypes as C
+    from orb_ygz_slam_amd import Extractor
+    w, h, n = 320, 240, 12
+    big = np.stack([synth_frame(300 + i // 3, w + 24, h + 16) for i in range(n)])
+    views = [big[i, (i % 3):(i % 3) + h, 2 * (i % 4):2 * (i % 4) + w] for i in range(n)]           # crops: row pitch w + 24, arbitrary column offset
+    tight = np.ascontiguousarray(np.stack(views))
+    ex = Extractor(400, 1.2, 5, 20, 7, max_width=w, max_height=h, max_batch=n)
+    ex.extract_batch_host(tight)
+    want = [ex.batch_fetch(f) for f in range(n)]
+    oex = oracle.Extractor(400, 1.2, 5, 20, 7)
+    ok, od = oex.extract(tight[5])
+    assert (want[5][0] == ok).all() and (want[5][1] == od).all()
+
+    def check(frames, order=None):
+        ex.extract_batch_host_frames(frames)
+        for j in range(len(frames)):
+            k, d = ex.batch_fetch(j)
+            f = order[j] if order is not None else j
+            assert np.array_equal(k, want[f][0]) and np.array_equal(d, want[f][1]), (j, f)
+    check(views)                                                        # strided crops, one copy per frame
+    order = [7, 2, 11, 0, 5, 9, 1]
+    check([tight[f] for f in order], order)                             # tight frames out of order
+    order = [0, 1, 4, 5, 8, 9]
+    check([tight[f] for f in order], order)                             # runs of two at one distance: the two-dimensional copy
+    L = ex.L
+    L.ygzf_alloc_host.restype = C.c_void_p
+    L.ygzf_alloc_host.argtypes = [C.c_int, C.c_size_t]
+    L.ygzf_free_host.argtypes = [C.c_void_p]
+    ptr = C.c_void_p(L.ygzf_alloc_host(0, tight.nbytes))
+    assert ptr.value
+    pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(tight.nbytes,)).reshape(tight.shape)
+    pinned[:] = tight
+    order = [3, 10, 4, 6]
+    check([pinned[f] for f in order], order)                            # page-locked, irregular
+    check([pinned[f] for f in range(n)])                                # page-locked, one block
+    ex.sync()
+    del pinned
+    L.ygzf_free_host(ptr)
