@@ -544,6 +544,9 @@ def main():
                          "about five seconds; 1 otherwise)")
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic frames of the resident clip (default streams x sub-batch; the clip "
                                                             "tiles them) -- profiling runs of the 4K shape use 8 so that the host-side synthesis stays short")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: every rank of a multi-process run uses device 0 and the ranks rendezvous over gloo -- the N > 1 control flow (barriers, "
+                         "max-over-ranks, per-rank extras) on a box with one GPU; never a valid measurement (the line says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -576,16 +579,20 @@ def main():
     import torch
     dist = None
     use_gpu = not args.plumbing_selftest
+    share = bool(args.share_gpu)
+    if share:
+        local_rank = 0
+    nccl = use_gpu and not share
     if use_gpu and torch.cuda.is_available():
         torch.cuda.set_device(local_rank * ndev)   # before the process group: RCCL binds its communicator to the current device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if use_gpu else "gloo")
+        dist.init_process_group(backend="nccl" if nccl else "gloo")
 
     def barrier():
         if dist is not None:
-            if use_gpu:
+            if nccl:
                 dist.barrier(device_ids=[local_rank * ndev])
             else:
                 dist.barrier()
@@ -593,7 +600,7 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=("cuda:%d" % (local_rank * ndev)) if use_gpu else "cpu")
+        t = torch.tensor([x], dtype=torch.float64, device=("cuda:%d" % (local_rank * ndev)) if nccl else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0])
 
@@ -764,7 +771,7 @@ def main():
                        "resident_clip_frames": S * sub * rounds, "streams": S, "distinct_frames": min(B, S * sub),
                        "align": bool(args.align), "stereo": bool(args.stereo),
                        "match": "SearchByProjection(cur,last) th=15, identity pose", "fast_plan": fast_plan, "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
-                       "sharding": "one clip per GPU, no collective"},
+                       "sharding": "one clip per GPU, no collective", "valid_measurement": not share},
             "timed_region_s": round(elapsed, 4),
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "roofline_pcie": e2e["roofline_pcie"] if e2e else None,
             "mgpu_end_to_end": mgpu, "mgpu_literal_configs": mgpu_lit,

@@ -182,3 +182,22 @@ def test_bench_in_process_devices_on_one_gpu():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["config"]["devices_reused"] is True and line["config"]["devices_per_process"] == 2 and line["n_gpus"] == 2
     assert line["value"] > 0 and line["steps"] == 2 and line["config"]["frames_per_gpu_per_step"] == 768
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """The driver's N > 1 launch (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) with both ranks on the box's one GPU
+    (`--share-gpu`: rendezvous over gloo instead of RCCL, which refuses two ranks on one device): every barrier, every max-over-ranks reduction and the
+    per-rank extras of the REAL bench path (the end-to-end pipeline, the other workloads) run in two processes -- what cannot be tried here is RCCL itself."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "768", "--passes", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 prints the one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["valid_measurement"] is False and line["config"]["processes"] == 2
+    assert line["value"] > 0 and line["value_end_to_end"] > 0 and line["cpu_baseline"] is None and line["mgpu_end_to_end"] is None
+    ow = line["other_workloads"]
+    assert set(ow) >= {"fhd1920x1080_8lvl_4000feat", "uhd3840x2160_12lvl_8000feat_stereo", "euroc752x480_8lvl_1000feat_align"}
+    assert all(v["value"] > 0 for v in ow.values()) and ow["fhd1920x1080_8lvl_4000feat"]["value_end_to_end"] > 0
