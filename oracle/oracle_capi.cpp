@@ -315,6 +315,18 @@ int yo_search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int
     return search_by_bow(nNodes, kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, nF, f_keys, f_desc, nnratio, checkOri != 0, match);
 }
 
+// flat form of ygzo::TriangulationInput; cam2 = {fx, fy, cx, cy} of KF2
+int yo_search_for_triangulation(int nNodes, const int *off1, const int *idx1, const int *off2, const int *idx2, int n1, const KeyPoint *keys1,
+                                const uint8_t *desc1, const uint8_t *has_mp1, const float *uRight1, int n2, const KeyPoint *keys2,
+                                const uint8_t *desc2, const uint8_t *has_mp2, const float *uRight2, int nlevels2, const float *scaleFactors2,
+                                const float *levelSigma2_2, const float *F12, const float *Cw1, const float *R2w, const float *t2w,
+                                const float *cam2, int onlyStereo, int checkOri, int *match12) {
+    (void) nlevels2;
+    TriangulationInput in{nNodes, off1, idx1, off2, idx2, n1, keys1, desc1, has_mp1, uRight1, n2, keys2, desc2, has_mp2, uRight2,
+                          scaleFactors2, levelSigma2_2, F12, Cw1, R2w, t2w, cam2[0], cam2[1], cam2[2], cam2[3]};
+    return search_for_triangulation(in, onlyStereo != 0, checkOri != 0, match12);
+}
+
 void yo_is_in_frustum(const yo_frame *F, int M, const float *world, const float *normal, const float *maxDistInv, const float *minDistInv,
                       const float *mfMaxDistance, const float *Rcw, const float *tcw, const float *Ow, float logScaleFactor, int nScaleLevels,
                       float viewingCosLimit, uint8_t *in_view, float *projX, float *projY, float *projXR, int *level, float *viewCos) {

@@ -370,6 +370,86 @@ int search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int *f
     return nmatches;
 }
 
+// CheckDistEpipolarLine :136-153.  F12 row-major: F12(r, c) = F[3 * r + c].
+static inline bool check_dist_epipolar_line(const KeyPoint &kp1, const KeyPoint &kp2, const float *F, const float *levelSigma2) {
+    const float a = kp1.x * F[0] + kp1.y * F[3] + F[6];
+    const float b = kp1.x * F[1] + kp1.y * F[4] + F[7];
+    const float c = kp1.x * F[2] + kp1.y * F[5] + F[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * levelSigma2[kp2.octave];   // double comparison, as in the reference
+}
+
+// :596-741
+int search_for_triangulation(const TriangulationInput &in, bool onlyStereo, bool checkOrientation, int *match12) {
+    // epipole in the second image (:601-608)
+    float C2[3];
+    mat3_mul_vec(in.R2w, in.Cw1, C2);
+    for (int k = 0; k < 3; k++) C2[k] = C2[k] + in.t2w[k];
+    const float invz = 1.0f / C2[2];
+    const float ex = in.fx2 * C2[0] * invz + in.cx2;
+    const float ey = in.fy2 * C2[1] * invz + in.cy2;
+
+    for (int i = 0; i < in.n1; i++) match12[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    for (int k = 0; k < in.nNodes; k++) {
+        for (int a = in.off1[k]; a < in.off1[k + 1]; a++) {
+            const int idx1 = in.idx1[a];
+            if (in.has_mp1[idx1]) continue;
+            const bool bStereo1 = in.uRight1 && in.uRight1[idx1] >= 0;
+            if (onlyStereo && !bStereo1) continue;
+            const KeyPoint &kp1 = in.keys1[idx1];
+            const uint8_t *d1 = &in.desc1[32 * (size_t) idx1];
+            int bestDist = TH_LOW, bestIdx2 = -1;
+            for (int b = in.off2[k]; b < in.off2[k + 1]; b++) {
+                const int idx2 = in.idx2[b];
+                if (in.has_mp2[idx2]) continue;   // vbMatched2 is never set by the reference (:616, :655): only the MapPoint test acts
+                const bool bStereo2 = in.uRight2 && in.uRight2[idx2] >= 0;
+                if (onlyStereo && !bStereo2) continue;
+                const int dist = descriptor_distance(d1, &in.desc2[32 * (size_t) idx2]);
+                if (dist > TH_LOW || dist > bestDist) continue;
+                const KeyPoint &kp2 = in.keys2[idx2];
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = ex - kp2.x;
+                    const float distey = ey - kp2.y;
+                    if (distex * distex + distey * distey < 100 * in.scaleFactors2[kp2.octave]) continue;
+                }
+                if (check_dist_epipolar_line(kp1, kp2, in.F12, in.levelSigma2_2)) {
+                    bestIdx2 = idx2;
+                    bestDist = dist;
+                }
+            }
+            if (bestIdx2 >= 0) {
+                match12[idx1] = bestIdx2;
+                nmatches++;
+                if (checkOrientation) {
+                    float rot = kp1.angle - in.keys2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int) std::round(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    rotHist[bin].push_back(idx1);
+                }
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+                match12[rotHist[i][j]] = -2;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 // src/Frame.cc:363-422
 void is_in_frustum(const FrameView &F, const FrustumInput &in, float viewingCosLimit, uint8_t *in_view, float *projX, float *projY,
                    float *projXR, int *level, float *viewCos) {

@@ -730,6 +730,33 @@ def search_by_bow(kf_off, kf_idx, f_off, f_idx, kf_valid, kf_keys, kf_desc, f_ke
     return r, match[:len(fk)]
 
 
+def search_for_triangulation(off1, idx1, off2, idx2, kf1, kf2, scale_factors2, level_sigma2_2, F12, Cw1, R2w, t2w, cam2,
+                             only_stereo=False, check_ori=True):
+    """Oracle ORBmatcher::SearchForTriangulation on a joined node list.  kf1 / kf2: dicts with keys (KP_DTYPE), desc (n x 32), has_mp
+    (n bytes), u_right (n floats or None); cam2 = (fx, fy, cx, cy) of KF2 -> (nmatches, match12 per KF1 feature)."""
+    o1, i1, o2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
+    keep = []
+
+    def side(kf):
+        k = np.ascontiguousarray(kf["keys"], KP_DTYPE)
+        d = np.ascontiguousarray(kf["desc"], np.uint8)
+        m = np.ascontiguousarray(kf["has_mp"], np.uint8)
+        u = None if kf.get("u_right") is None else np.ascontiguousarray(kf["u_right"], np.float32)
+        keep.extend([k, d, m, u])
+        return len(k), _p(k), _p(d), _p(m), (_p(u) if u is not None else None)
+
+    sf, sg = np.ascontiguousarray(scale_factors2, np.float32), np.ascontiguousarray(level_sigma2_2, np.float32)
+    Fm, Cw, Rm, tm, cam = (np.ascontiguousarray(a, np.float32).reshape(-1) for a in (F12, Cw1, R2w, t2w, cam2))
+    a, b = side(kf1), side(kf2)
+    match = np.full(max(a[0], 1), -1, np.int32)
+    L = lib()
+    L.yo_search_for_triangulation.argtypes = ([C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 4 + [C.c_int] +
+                                              [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p])
+    r = L.yo_search_for_triangulation(len(o1) - 1, _p(o1), _p(i1), _p(o2), _p(i2), *a, *b, len(sf), _p(sf), _p(sg), _p(Fm), _p(Cw), _p(Rm), _p(tm),
+                                      _p(cam), int(only_stereo), int(check_ori), _p(match))
+    return r, match[:a[0]]
+
+
 def is_in_frustum(keys, desc, scale_factors, w, h, cam, world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow,
                   log_scale_factor, viewing_cos_limit=0.5):
     """Oracle Frame::isInFrustum for M points -> (in_view, projX, projY, projXR, level, viewCos)."""

@@ -277,6 +277,61 @@ int yo_search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int
     return n;
 }
 
+// ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, Matrix3f &F12, vector<pair<size_t,size_t>> &vMatchedPairs,
+//                                    const bool bOnlyStereo)                                             :596-741 (+ CheckDistEpipolarLine :136-153)
+// Joined node list -> two FeatureVectors as in yo_search_by_bow.  The reference returns only the surviving pairs: match12 = -1 wherever
+// the oracle reports -1 (never matched) or -2 (culled by the rotation check).
+int yo_search_for_triangulation(int nNodes, const int *off1, const int *idx1, const int *off2, const int *idx2, int n1, const ygzo::KeyPoint *keys1,
+                                const uint8_t *desc1, const uint8_t *has_mp1, const float *uRight1, int n2, const ygzo::KeyPoint *keys2,
+                                const uint8_t *desc2, const uint8_t *has_mp2, const float *uRight2, int nlevels2, const float *scaleFactors2,
+                                const float *levelSigma2_2, const float *F12, const float *Cw1, const float *R2w, const float *t2w,
+                                const float *cam2, int onlyStereo, int checkOri, int *match12) {
+    ygz::KeyFrame K1, K2;
+    ygz::MapPoint some;
+    auto fill = [&](ygz::KeyFrame &K, int n, const ygzo::KeyPoint *keys, const uint8_t *desc, const uint8_t *has_mp, const float *uR) {
+        K.N = n;
+        K.mvKeys = to_cv_keys(keys, n);
+        K.mDescriptors = desc_rows(desc, n);
+        K.mvuRight.assign(n, -1.f);
+        if (uR) K.mvuRight.assign(uR, uR + n);
+        K.mvpMapPoints.assign(n, (ygz::MapPoint *) nullptr);
+        for (int i = 0; i < n; i++)
+            if (has_mp[i]) K.mvpMapPoints[i] = &some;
+    };
+    fill(K1, n1, keys1, desc1, has_mp1, uRight1);
+    fill(K2, n2, keys2, desc2, has_mp2, uRight2);
+    K1.mOw = Vector3f(Cw1[0], Cw1[1], Cw1[2]);
+    K2.mHasPose = true;
+    for (int i = 0; i < 9; i++) K2.mRcw.m[i] = R2w[i];
+    K2.mtcw = Vector3f(t2w[0], t2w[1], t2w[2]);
+    K2.fx = cam2[0]; K2.fy = cam2[1]; K2.cx = cam2[2]; K2.cy = cam2[3];
+    K2.mnScaleLevels = nlevels2;
+    K2.mvScaleFactors.assign(scaleFactors2, scaleFactors2 + nlevels2);
+    K2.mvLevelSigma2.assign(levelSigma2_2, levelSigma2_2 + nlevels2);
+    for (int k = 0; k < nNodes; k++) {
+        const unsigned id = 2u * (unsigned) k + 1u;
+        for (int j = off1[k]; j < off1[k + 1]; j++) K1.mFeatVec[id].push_back((unsigned) idx1[j]);
+        for (int j = off2[k]; j < off2[k + 1]; j++) K2.mFeatVec[id].push_back((unsigned) idx2[j]);
+    }
+    K1.mFeatVec[0];                       // nodes on one side only: the merge-join's lower_bound skips run as well
+    K2.mFeatVec[2u * (unsigned) nNodes + 2u];
+    if (nNodes > 1) { K1.mFeatVec[2]; K2.mFeatVec[4]; }
+    Matrix3f F;
+    for (int i = 0; i < 9; i++) F.m[i] = F12[i];
+    std::vector<std::pair<size_t, size_t> > pairs;
+    ygz::ORBmatcher matcher(0.6f, checkOri != 0);
+    const int n = matcher.SearchForTriangulation(&K1, &K2, F, pairs, onlyStereo != 0);
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    size_t prev = 0;
+    for (size_t j = 0; j < pairs.size(); j++) {
+        if (j && pairs[j].first <= prev) return -1000;   // :731-736 emits ascending i1
+        prev = pairs[j].first;
+        match12[pairs[j].first] = (int) pairs[j].second;
+    }
+    if ((int) pairs.size() != n) return -1001;
+    return n;
+}
+
 // ORBmatcher::FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level)   :1573-1602, with
 // GetWarpAffineMatrix :1525-1548, WarpAffine :1550-1572, GetBestSearchLevel / GetBilateralInterpUchar (include/ORBmatcher.h:185-211) and
 // the reference's own ygz::Align2D (src/Align.cc, compiled into this library).  Pyramids come in level by level (tight 8-bit images).

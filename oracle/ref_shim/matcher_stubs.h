@@ -282,8 +282,11 @@ public:
     MapPoint *GetMapPoint(const size_t &i) { return mvpMapPoints[i]; }
     std::set<MapPoint *> GetMapPoints() { yr_unsupported("KeyFrame::GetMapPoints"); }
     void AddMapPoint(MapPoint *, const size_t &) { yr_unsupported("KeyFrame::AddMapPoint"); }
-    Matrix3f GetRotation() { yr_unsupported("KeyFrame::GetRotation"); }
-    Vector3f GetTranslation() { yr_unsupported("KeyFrame::GetTranslation"); }
+    bool mHasPose = false;                     // set by the SearchForTriangulation entry point; Fuse / Sim3 stay outside the pinned path
+    Matrix3f mRcw;
+    Vector3f mtcw;
+    Matrix3f GetRotation() { if (!mHasPose) yr_unsupported("KeyFrame::GetRotation"); return mRcw; }
+    Vector3f GetTranslation() { if (!mHasPose) yr_unsupported("KeyFrame::GetTranslation"); return mtcw; }
     Vector3f mOw;
     Vector3f GetCameraCenter() { return mOw; }
     long unsigned int mnFrameId = 0;

@@ -220,6 +220,29 @@ int search_by_bow(int nNodes, const int *kf_off, const int *kf_idx, const int *f
                   const KeyPoint *kf_keys, const uint8_t *kf_desc, int nF, const KeyPoint *f_keys, const uint8_t *f_desc, float nnratio,
                   bool checkOrientation, int *match);
 
+// SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, Matrix3f &F12, vector<pair<size_t,size_t>> &vMatchedPairs, bool bOnlyStereo)
+// src/ORBmatcher.cc:596-741 with CheckDistEpipolarLine :136-153 (LocalMapping::CreateNewMapPoints' matcher).  Joined node list as in
+// search_by_bow: node k pairs KF1 features idx1[off1[k]..off1[k+1]) with KF2 features idx2[off2[k]..off2[k+1]).  has_mp[i] = the
+// KeyFrame already holds a MapPoint in slot i (GetMapPoint(i) != NULL).  match12[i1] = matched KF2 feature, -1 none, -2 culled by the
+// rotation check; vMatchedPairs = the (i1, match12[i1] >= 0) pairs in ascending i1 (:731-736).
+struct TriangulationInput {
+    int nNodes;
+    const int *off1, *idx1, *off2, *idx2;
+    int n1;
+    const KeyPoint *keys1;
+    const uint8_t *desc1, *has_mp1;
+    const float *uRight1;        // mvuRight of KF1, or nullptr (monocular: all -1)
+    int n2;
+    const KeyPoint *keys2;
+    const uint8_t *desc2, *has_mp2;
+    const float *uRight2;
+    const float *scaleFactors2, *levelSigma2_2;   // pKF2->mvScaleFactors, pKF2->mvLevelSigma2
+    const float *F12;            // row-major 3 x 3
+    const float *Cw1, *R2w, *t2w;   // pKF1->GetCameraCenter(), pKF2->GetRotation() (row-major), pKF2->GetTranslation()
+    float fx2, fy2, cx2, cy2;
+};
+int search_for_triangulation(const TriangulationInput &in, bool onlyStereo, bool checkOrientation, int *match12);
+
 // ---- Sophus SE3f + SparseImgAlign --------------------------------------------------------------------------
 struct SE3f {
     float q[4] = {0, 0, 0, 1};  // x,y,z,w (Eigen coeffs order)

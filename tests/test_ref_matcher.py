@@ -190,6 +190,60 @@ def test_search_by_bow_equals_reference(pair):
             assert e_n > 20
 
 
+def test_search_for_triangulation_equals_reference(pair):
+    """SearchForTriangulation + CheckDistEpipolarLine (src/ORBmatcher.cc:596-741, :136-153): the reference's surviving pairs are the
+    oracle's match12 >= 0, for epipoles outside and inside the image, mono / stereo keypoints, bOnlyStereo and the rotation check."""
+    from tests.tri_cases import cases
+    ka, da, kb, db, sf = pair
+    sigma2 = (sf * sf).astype(np.float32)
+    seen = {}
+    for label, kw in cases(ka, da, kb, db):
+        e_n, e_m = O.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sigma2, **kw)
+        with O.reference_matcher():
+            r_n, r_m = O.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sigma2, **kw)
+        assert r_n == e_n and (r_m == canon(e_m)).all(), (label, r_n, e_n)
+        assert e_n == int((e_m >= 0).sum())
+        seen[label] = (e_n, int((e_m == -2).sum()))
+    assert seen["lateral"][0] > 100 and seen["lateral"][1] > 0          # many pairs on their epipolar lines; the rotation check culls some
+    assert seen["forward"][0] < seen["lateral"][0]                         # radial epipolar lines: fewer shifted pairs lie on them
+    assert seen["epipole-stereo"][0] > seen["epipole-mono"][0]             # stereo keypoints skip the epipole-distance test (:668-673)
+    assert 0 < seen["only-stereo"][0] < seen["lateral"][0]
+    assert seen["zero-F"] == (0, 0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_triangulation_equals_reference(seed):
+    """Random scenes, node granularities, relative poses and flags through SearchForTriangulation."""
+    from tests.tri_cases import fake_feature_vector, join, geometry
+    rng = np.random.default_rng(4100 + seed)
+    w, h = int(rng.integers(320, 800)), int(rng.integers(240, 520))
+    base = synth_frame(4200 + seed, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[10:10 + h, 5:5 + w]
+    oex = O.Extractor(int(rng.choice([300, 900])), 1.2, 8, 20, 7)
+    sf = oex.tables()["scale"]
+    ka, da = oex.extract(a)
+    kb, db = oex.extract(b)
+    if len(ka) < 20 or len(kb) < 20:
+        pytest.skip("too few keypoints")
+    for _ in range(4):
+        bits = int(rng.integers(1, 9))
+        o1, i1, o2, i2 = join(fake_feature_vector(da, bits), fake_feature_vector(db, bits))
+        ep = None if rng.uniform() < 0.5 else (rng.uniform(0, w), rng.uniform(0, h))
+        F12, Cw1, R2w, t2w, cam2 = geometry(float(rng.choice([0.002, 0.05, 0.8])), float(rng.uniform(-0.5, 0.5)), epipole=ep)
+        Cw1 = rng.uniform(-0.01, 0.01, 3).astype(np.float32)   # not consistent with F12: only the epipole moves, the matcher does not care
+        stereo = rng.uniform() < 0.5
+        kf1 = dict(keys=ka, desc=da, has_mp=(rng.uniform(size=len(ka)) < rng.uniform(0, 0.6)).astype(np.uint8),
+                   u_right=np.where(rng.uniform(size=len(ka)) < 0.5, ka["x"] - 3, -1).astype(np.float32) if stereo else None)
+        kf2 = dict(keys=kb, desc=db, has_mp=(rng.uniform(size=len(kb)) < rng.uniform(0, 0.6)).astype(np.uint8),
+                   u_right=np.where(rng.uniform(size=len(kb)) < 0.5, kb["x"] - 3, -1).astype(np.float32) if stereo else None)
+        kw = dict(off1=o1, idx1=i1, off2=o2, idx2=i2, kf1=kf1, kf2=kf2, scale_factors2=sf, level_sigma2_2=(sf * sf).astype(np.float32), F12=F12,
+                  Cw1=Cw1, R2w=R2w, t2w=t2w, cam2=cam2, only_stereo=bool(stereo and rng.uniform() < 0.3), check_ori=bool(rng.uniform() < 0.7))
+        e_n, e_m = O.search_for_triangulation(**kw)
+        with O.reference_matcher():
+            r_n, r_m = O.search_for_triangulation(**kw)
+        assert r_n == e_n and (r_m == canon(e_m)).all(), (seed, bits, r_n, e_n)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_fuzz_projection_searches_equal_reference(seed):
     """Random image pairs, poses, thresholds and flag combinations through the three projection searches."""
