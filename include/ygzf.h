@@ -269,6 +269,22 @@ int ygzf_search_by_bow(ygzf_ctx *ctx, int n_nodes, const int *kf_off, const int 
                        const uint8_t *kf_valid, const ygzf_kp *kf_keys, const uint8_t *kf_desc, int n_f, const ygzf_kp *f_keys, const uint8_t *f_desc,
                        float nnratio, int check_orientation, int *match, int *nmatches);
 
+/* ---- ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, Matrix3f &F12, vector<pair<size_t,size_t>> &vMatchedPairs,
+ *      const bool bOnlyStereo)   src/ORBmatcher.cc:596-741, with CheckDistEpipolarLine :136-153 (LocalMapping::CreateNewMapPoints) -----------
+ * Joined node list as for ygzf_search_by_bow: node k pairs the features idx1[off1[k] .. off1[k+1]) of KF1 with idx2[off2[k] .. off2[k+1])
+ * of KF2.  kf1 / kf2: mvKeys (the reference reads the DISTORTED keys here), mDescriptors, mvuRight (NULL: monocular); kf2's scale_factors
+ * = pKF2->mvScaleFactors (NULL: the context's tables), level_sigma2_2 = pKF2->mvLevelSigma2 (NULL: scale factor squared).
+ * has_mp[i] != 0 <=> the KeyFrame holds a MapPoint in slot i (GetMapPoint(i) != NULL): such features are skipped on either side.
+ * F12 row-major 3x3; Cw1 = pKF1->GetCameraCenter(), R2w (row-major) / t2w = pKF2->GetRotation() / GetTranslation(), cam2 = KF2's
+ * fx fy cx cy: the epipole of :601-608 is computed from them.  The device runs the per-node brute force (TH_LOW, least distance, last of
+ * equals), the epipole exclusion disc (:668-673), the epipolar-line gate (3.84 sigma2) and the rotation histogram.
+ * match12 (kf1->n ints): matched KF2 feature; -1 none; -2 culled by the rotation check.  vMatchedPairs = {(i, match12[i]) : match12[i] >= 0}
+ * in ascending i (:731-736); *nmatches = their number.  At most 65535 KF2 features per node. */
+int ygzf_search_for_triangulation(ygzf_ctx *ctx, int n_nodes, const int *off1, const int *idx1, const int *off2, const int *idx2,
+                                  const ygzf_frame_view *kf1, const uint8_t *has_mp1, const ygzf_frame_view *kf2, const uint8_t *has_mp2,
+                                  const float *level_sigma2_2, const float *F12, const float *Cw1, const float *R2w, const float *t2w,
+                                  const ygzf_camera *cam2, int only_stereo, int check_orientation, int *match12, int *nmatches);
+
 /* ---- Frame::ComputeBoW()   src/Frame.cc:495-500 -> ORBVocabulary::transform(features, BowVector, FeatureVector, levelsup = 4), i.e.
  *      DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform   Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1151-1283 ---
  * The vocabulary tree lives on the device.  ygzf_vocabulary_set uploads it as the reference's loaders build it (loadFromTextFile

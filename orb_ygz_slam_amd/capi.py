@@ -113,6 +113,8 @@ def load_library(build_if_missing=True):
     L.ygzf_search_for_initialization.argtypes = [vp, C.POINTER(FrameView), C.POINTER(FrameView), C.POINTER(Camera), vp, C.c_int, C.c_float, C.c_int,
                                                  vp, ip]
     L.ygzf_search_by_bow.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, C.c_float, C.c_int, vp, ip]
+    L.ygzf_search_for_triangulation.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.POINTER(FrameView), vp, C.POINTER(FrameView), vp, vp, vp, vp, vp, vp,
+                                                C.POINTER(Camera), C.c_int, C.c_int, vp, ip]
     L.ygzf_compute_stereo_matches.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, C.c_float, C.c_float, vp, vp]
     L.ygzf_stereo_batch.argtypes = [vp, C.c_float, C.c_float]
     L.ygzf_stereo_fetch.argtypes = [vp, C.c_int, vp, vp, C.c_int]
@@ -479,6 +481,38 @@ class Extractor:
         self._ck(self.L.ygzf_search_by_bow(self.h, len(ko) - 1, _p(ko), _p(ki), _p(fo), _p(fi), len(kk), _p(kv), _p(kk), _p(kd), len(fk), _p(fk),
                                            _p(fd), nnratio, int(check_ori), _p(match), C.byref(n)))
         return n.value, match[:len(fk)]
+
+    def search_for_triangulation(self, off1, idx1, off2, idx2, kf1, kf2, scale_factors2, level_sigma2_2, F12, Cw1, R2w, t2w, cam2,
+                                 only_stereo=False, check_ori=True):
+        """ORBmatcher::SearchForTriangulation on a joined node list.  kf1 / kf2: dicts with keys (KP_DTYPE), desc, has_mp (bytes), u_right
+        (floats or None); scale_factors2 / level_sigma2_2: KF2's tables or None (the context's); cam2 = (fx, fy, cx, cy) of KF2
+        -> (nmatches, match12 per KF1 feature: KF2 feature, -1 none, -2 culled by the rotation check)."""
+        o1, i1, o2, i2 = (np.ascontiguousarray(a, np.int32) for a in (off1, idx1, off2, idx2))
+        keep = []
+
+        def side(kf):
+            k, d = np.ascontiguousarray(kf["keys"], KP_DTYPE), np.ascontiguousarray(kf["desc"], np.uint8)
+            m = np.ascontiguousarray(kf["has_mp"], np.uint8)
+            u = None if kf.get("u_right") is None else np.ascontiguousarray(kf["u_right"], np.float32)
+            keep.extend([k, d, m, u])
+            return FrameView(len(k), k.ctypes.data, d.ctypes.data, None if u is None else u.ctypes.data, None, self.nlevels), m
+
+        f1, m1 = side(kf1)
+        f2, m2 = side(kf2)
+        sf = sg = None
+        if scale_factors2 is not None:
+            sf = np.ascontiguousarray(scale_factors2, np.float32)
+            f2.scale_factors, f2.nlevels = sf.ctypes.data, len(sf)
+        if level_sigma2_2 is not None:
+            sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+        Fm, Cw, Rm, tm = (np.ascontiguousarray(a, np.float32).reshape(-1) for a in (F12, Cw1, R2w, t2w))
+        cam = Camera(float(cam2[0]), float(cam2[1]), float(cam2[2]), float(cam2[3]), 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
+        match = np.full(max(f1.n, 1), -1, np.int32)
+        n = C.c_int()
+        self._ck(self.L.ygzf_search_for_triangulation(self.h, len(o1) - 1, _p(o1), _p(i1), _p(o2), _p(i2), C.byref(f1), _p(m1), C.byref(f2), _p(m2),
+                                                      None if sg is None else _p(sg), _p(Fm), _p(Cw), _p(Rm), _p(tm), C.byref(cam), int(only_stereo),
+                                                      int(check_ori), _p(match), C.byref(n)))
+        return n.value, match[:f1.n]
 
     @staticmethod
     def _frustum_in(world, normal, max_dist_inv, min_dist_inv, mf_max_distance, Rcw, tcw, Ow, log_scale_factor, viewing_cos_limit, candidate, keep):

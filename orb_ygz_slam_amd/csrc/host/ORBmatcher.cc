@@ -2,9 +2,9 @@
 // KeyFrame fields the reference function reads into the plain arrays of its ygzf_* entry point and scatters the result back.
 // Inside the reference tree this file is compiled against the reference's own, unchanged include/ORBmatcher.h and replaces the bodies of
 //   ORBmatcher(float, bool), DescriptorDistance, the three Tracking-side SearchByProjection overloads, SearchByBoW(KeyFrame*, Frame&, ...),
-//   SearchForInitialization, FindDirectProjection                                (src/ORBmatcher.cc:36-133, 155-263, 375-478, 1218-1602);
-// the LocalMapping / LoopClosing members (Fuse x2, SearchBySim3, SearchForTriangulation, SearchByProjection(KF, Scw, ...),
-// SearchByBoW(KF, KF, ...)) are outside the hot path and keep their reference bodies (link recipe).
+//   SearchForInitialization, SearchForTriangulation, FindDirectProjection   (src/ORBmatcher.cc:36-133, 155-263, 375-478, 596-741, 1218-1602);
+// the other LocalMapping / LoopClosing members (Fuse x2, SearchBySim3, SearchByProjection(KF, Scw, ...), SearchByBoW(KF, KF, ...)) are
+// outside the hot path and keep their reference bodies (link recipe).
 #include "ORBextractor.h"   // first: inside the reference tree this is the replacement header (same include guard)
 #include "ORBmatcher.h"     // the reference's own header (reference tree) or standalone/ORBmatcher.h, by include path
 #include "ygz_compat.h"
@@ -261,6 +261,72 @@ int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vp
     if (rc != YGZF_OK) return 0;
     for (int i = 0; i < F.N; i++)
         if (match[i] >= 0) vpMapPointMatches[i] = vpMapPointsKF[match[i]];
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:596-741 (LocalMapping::CreateNewMapPoints, once per neighbour KeyFrame of every new KeyFrame).  The FeatureVector
+// merge-join runs here as in the reference (:631-717); the per-node brute force, the epipole exclusion disc, CheckDistEpipolarLine
+// (:136-153) and the rotation histogram run on the device (ygzf_search_for_triangulation).
+int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, Matrix3f &F12, std::vector<std::pair<size_t, size_t> > &vMatchedPairs,
+                                       const bool bOnlyStereo) {
+    vMatchedPairs.clear();
+    const DBoW2::FeatureVector &vFeatVec1 = pKF1->mFeatVec;
+    const DBoW2::FeatureVector &vFeatVec2 = pKF2->mFeatVec;
+    std::vector<int> off1{0}, off2{0}, idx1, idx2;
+    DBoW2::FeatureVector::const_iterator f1it = vFeatVec1.begin(), f2it = vFeatVec2.begin();
+    const DBoW2::FeatureVector::const_iterator f1end = vFeatVec1.end(), f2end = vFeatVec2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            idx1.insert(idx1.end(), f1it->second.begin(), f1it->second.end());
+            idx2.insert(idx2.end(), f2it->second.begin(), f2it->second.end());
+            off1.push_back((int) idx1.size());
+            off2.push_back((int) idx2.size());
+            f1it++;
+            f2it++;
+        } else if (f1it->first < f2it->first) {
+            f1it = vFeatVec1.lower_bound(f2it->first);
+        } else {
+            f2it = vFeatVec2.lower_bound(f1it->first);
+        }
+    }
+    const int nNodes = (int) off1.size() - 1, n1 = pKF1->N, n2 = pKF2->N;
+    if (nNodes <= 0 || n1 <= 0 || n2 <= 0) return 0;
+    std::vector<uint8_t> has1(n1), has2(n2), hold1, hold2;
+    for (int i = 0; i < n1; i++) has1[i] = pKF1->GetMapPoint(i) != nullptr;
+    for (int i = 0; i < n2; i++) has2[i] = pKF2->GetMapPoint(i) != nullptr;
+    ygzf_frame_view v1, v2;
+    v1.n = n1; v1.keys = (const ygzf_kp *) pKF1->mvKeys.data(); v1.desc = desc_rows(pKF1->mDescriptors, n1, hold1);
+    v1.u_right = (int) pKF1->mvuRight.size() == n1 ? pKF1->mvuRight.data() : nullptr;
+    v1.scale_factors = nullptr; v1.nlevels = 0;
+    v2.n = n2; v2.keys = (const ygzf_kp *) pKF2->mvKeys.data(); v2.desc = desc_rows(pKF2->mDescriptors, n2, hold2);
+    v2.u_right = (int) pKF2->mvuRight.size() == n2 ? pKF2->mvuRight.data() : nullptr;
+    v2.scale_factors = pKF2->mvScaleFactors.data(); v2.nlevels = (int) pKF2->mvScaleFactors.size();
+    if (pKF2->mvLevelSigma2.size() != pKF2->mvScaleFactors.size()) return 0;
+    float F[9], R[9], t[3], Cw[3];
+    const Vector3f Cw1 = pKF1->GetCameraCenter();
+    const Matrix3f R2w = pKF2->GetRotation();
+    const Vector3f t2w = pKF2->GetTranslation();
+    for (int r = 0; r < 3; r++) {
+        for (int cc = 0; cc < 3; cc++) { F[3 * r + cc] = F12(r, cc); R[3 * r + cc] = R2w(r, cc); }
+        t[r] = t2w[r];
+        Cw[r] = Cw1[r];
+    }
+    ygzf_camera cam2 = {pKF2->fx, pKF2->fy, pKF2->cx, pKF2->cy, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ygzf_host::Lease lease(device());
+    if (!lease) return 0;
+    ygzf_ctx *c = lease.get();
+    std::vector<int> match12(n1, -1);
+    int nmatches = 0;
+    const int rc = ygzf_search_for_triangulation(c, nNodes, off1.data(), idx1.data(), off2.data(), idx2.data(), &v1, has1.data(), &v2, has2.data(),
+                                                 pKF2->mvLevelSigma2.data(), F, Cw, R, t, &cam2, bOnlyStereo, mbCheckOrientation, match12.data(),
+                                                 &nmatches);
+    if (rc != YGZF_OK) {
+        ygzf_host::report_failure("ygz::ORBmatcher::SearchForTriangulation", ygzf_last_error(c));
+        return 0;
+    }
+    vMatchedPairs.reserve(nmatches);
+    for (int i = 0; i < n1; i++)       // :731-736
+        if (match12[i] >= 0) vMatchedPairs.push_back(std::make_pair((size_t) i, (size_t) match12[i]));
     return nmatches;
 }
 

@@ -31,6 +31,8 @@ public:
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
     // Matching for the map initialisation (monocular only).
     int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10);
+    // Matching to triangulate new MapPoints; checks the epipolar constraint (LocalMapping::CreateNewMapPoints).
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, Matrix3f &F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo);
     // Direct (photometric) projection of a MapPoint observed in `ref` into `curr` (Tracking::SearchLocalPointsDirect): affine warp of the
     // reference patch + Align2D.  px_curr: initial guess in, refined pixel out.
     bool FindDirectProjection(KeyFrame *ref, Frame *curr, MapPoint *mp, Vector2f &px_curr, int &search_level);
@@ -38,7 +40,6 @@ public:
     // ---- outside the hot path (LocalMapping / LoopClosing threads): declared for interface parity, bodies stay the reference's --------
     int SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const std::vector<MapPoint *> &vpPoints, std::vector<MapPoint *> &vpMatched, int th);
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
-    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, Matrix3f &F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo);
     int SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12, const float &s12, const cv::Mat &R12, const cv::Mat &t12,
                      const float th);
     int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0);

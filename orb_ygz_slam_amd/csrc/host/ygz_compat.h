@@ -110,7 +110,7 @@ typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector;   // no
 
 namespace ygz {
 struct Vector3f { float v[3]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
-struct Matrix3f { float m[9]; };
+struct Matrix3f { float m[9]; float &operator()(int r, int c) { return m[3 * r + c]; } const float &operator()(int r, int c) const { return m[3 * r + c]; } };
 struct Vector2f { float v[2]; float &operator[](int i) { return v[i]; } const float &operator[](int i) const { return v[i]; } };
 class KeyFrame;
 struct SE3f {  // Sophus::SE3f storage: unit quaternion (x,y,z,w) + translation
@@ -180,6 +180,16 @@ public:
     std::vector<cv::Mat> mvImagePyramid;
     SE3f mPose;
     SE3f GetPose() const { return mPose; }
+    // read by SearchForTriangulation (src/ORBmatcher.cc:596-741)
+    int N = 0;
+    std::vector<float> mvuRight, mvScaleFactors, mvLevelSigma2;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    MapPoint *GetMapPoint(const size_t &i) const { return mvpMapPoints[i]; }
+    Matrix3f mRcw{};
+    Vector3f mtcw{}, mOw{};
+    Matrix3f GetRotation() const { return mRcw; }
+    Vector3f GetTranslation() const { return mtcw; }
+    Vector3f GetCameraCenter() const { return mOw; }
 };
 }  // namespace ygz
 

@@ -140,6 +140,24 @@ void launch_bow(hipStream_t st, int nNodes, const int *kfOff, const int *kfIdx, 
                 const ygzf_kp *kfKeys, const uint8_t *kfDesc, int nF, const ygzf_kp *fKeys, const uint8_t *fDesc, float nnratio, int checkOri, int *match,
                 unsigned char *binOf, int *hist, int *nmatches);
 
+// SearchForTriangulation per-node brute force with the epipolar tests (match_kernels.hip); match12 (n1 ints) pre-set to -1, hist (30 ints) and
+// nmatches to 0
+struct TriArgs {
+    int nEntries, nNodes, n1;       // nEntries = off1[nNodes]
+    const int *off1, *idx1, *off2, *idx2;
+    const ygzf_kp *keys1, *keys2;
+    const uint8_t *desc1, *desc2, *hasMp1, *hasMp2;
+    const float *uR1, *uR2;         // nullable: monocular
+    const float *sf2, *sigma2;      // mvScaleFactors / mvLevelSigma2 of KF2
+    float F[9];                     // F12 row-major
+    float ex, ey;                   // epipole of KF1's centre in KF2
+    int onlyStereo, checkOri;
+    int *match12;
+    unsigned char *binOf;
+    int *hist, *nmatches;
+};
+void launch_triangulation(hipStream_t st, const TriArgs &A);
+
 // Frame::isInFrustum over a MapPoint batch (match_kernels.hip); outputs are the mode-1 inputs of k_match_last
 struct FrustumArgs {
     int n;

@@ -998,6 +998,83 @@ void launch_bow(hipStream_t st, int nNodes, const int *kfOff, const int *kfIdx, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation  src/ORBmatcher.cc:596-741 with CheckDistEpipolarLine :136-153 (LocalMapping::CreateNewMapPoints).
+// The reference never sets vbMatched2 (:616 declares it, nothing writes it), so every KF1 feature is an independent problem: of the KF2
+// features of its vocabulary node that carry no MapPoint, pass the stereo filter, lie within TH_LOW, outside the epipole's exclusion disc
+// (both keypoints monocular, :668-673) and close enough to the epipolar line, it takes the least distance, the LAST of equals (the scan's
+// `dist > bestDist` test lets an equal distance replace the holder, :662).  Whether a candidate passes does not depend on the scan's state,
+// so the scan order is free: one wave per KF1 list entry, its lanes spread over the node's KF2 list, the answer is the minimum of
+// (distance << 16 | 0xFFFF - position).  Rotation votes go to the same histogram + k_bow_finish as SearchByBoW.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_nodes(TriArgs A) {
+    const int lane = m_lane();
+    const int a = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= A.nEntries) return;
+    int lo = 0, hi = A.nNodes;      // off1[lo] <= a < off1[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.off1[mid] <= a) lo = mid;
+        else hi = mid;
+    }
+    const int i1 = A.idx1[a];
+    if (A.hasMp1[i1]) return;
+    const bool stereo1 = A.uR1 && A.uR1[i1] >= 0;
+    if (A.onlyStereo && !stereo1) return;
+    const ygzf_kp kp1 = A.keys1[i1];
+    const unsigned long long *qd = (const unsigned long long *) (A.desc1 + (size_t) i1 * 32);
+    const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
+    // epipolar line of kp1 in the second image, l = x1' F12 = [la lb lc]  (:139-141)
+    const float la = kp1.x * A.F[0] + kp1.y * A.F[3] + A.F[6];
+    const float lb = kp1.x * A.F[1] + kp1.y * A.F[4] + A.F[7];
+    const float lc = kp1.x * A.F[2] + kp1.y * A.F[5] + A.F[8];
+    const float den = la * la + lb * lb;
+    const int b0 = A.off2[lo], nB = A.off2[lo + 1] - b0;
+    const int TH_LOW = 50;
+    unsigned best = 0xFFFFFFFFu;
+    if (den != 0) {                 // den == 0: CheckDistEpipolarLine is false for every candidate (:146-147)
+        for (int b = lane; b < nB; b += 64) {
+            const int i2 = A.idx2[b0 + b];
+            if (A.hasMp2[i2]) continue;
+            const bool stereo2 = A.uR2 && A.uR2[i2] >= 0;
+            if (A.onlyStereo && !stereo2) continue;
+            const unsigned long long *d = (const unsigned long long *) (A.desc2 + (size_t) i2 * 32);
+            const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+            if (dist > TH_LOW) continue;
+            const ygzf_kp kp2 = A.keys2[i2];
+            if (!stereo1 && !stereo2) {
+                const float distex = A.ex - kp2.x;
+                const float distey = A.ey - kp2.y;
+                if (distex * distex + distey * distey < 100.0f * A.sf2[kp2.octave]) continue;
+            }
+            const float num = la * kp2.x + lb * kp2.y + lc;
+            const float dsqr = num * num / den;
+            if (!((double) dsqr < 3.84 * (double) A.sigma2[kp2.octave])) continue;
+            const unsigned key = ((unsigned) dist << 16) | (unsigned) (0xFFFF - b);
+            best = min(best, key);
+        }
+    }
+    const unsigned wbest = wave_min_dpp(best);
+    if (lane != 0) return;
+    if (wbest == 0xFFFFFFFFu) return;
+    const int i2 = A.idx2[b0 + (0xFFFF - (int) (wbest & 0xFFFFu))];
+    A.match12[i1] = i2;
+    atomicAdd(A.nmatches, 1);
+    if (A.checkOri) {
+        float rot = kp1.angle - A.keys2[i2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int) roundf(rot * (1.0f / HISTO_LENGTH));
+        if (bin == HISTO_LENGTH) bin = 0;
+        A.binOf[i1] = (unsigned char) bin;
+        atomicAdd(&A.hist[bin], 1);
+    }
+}
+
+void launch_triangulation(hipStream_t st, const TriArgs &A) {
+    if (A.nEntries > 0) hipLaunchKernelGGL(k_tri_nodes, dim3((A.nEntries + 3) / 4), dim3(256), 0, st, A);
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, A.n1, A.checkOri, A.match12, A.binOf, A.hist, A.nmatches);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Frame::isInFrustum for a batch of MapPoints  (src/Frame.cc:363-422; Tracking::SearchLocalPoints src/Tracking.cc:1544-1593 calls it
 // for every local MapPoint before SearchByProjection).  One thread per point; its outputs are exactly the MapPoint fields mode 1 of
 // k_match_last reads, so the two chain on the device without a host round trip.  MapPoint::PredictScale's

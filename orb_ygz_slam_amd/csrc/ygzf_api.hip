@@ -2690,6 +2690,83 @@ int ygzf_search_by_bow(ygzf_ctx *c, int n_nodes, const int *kf_off, const int *k
     return YGZF_OK;
 }
 
+int ygzf_search_for_triangulation(ygzf_ctx *c, int n_nodes, const int *off1, const int *idx1, const int *off2, const int *idx2,
+                                  const ygzf_frame_view *kf1, const uint8_t *has_mp1, const ygzf_frame_view *kf2, const uint8_t *has_mp2,
+                                  const float *level_sigma2_2, const float *F12, const float *Cw1, const float *R2w, const float *t2w,
+                                  const ygzf_camera *cam2, int only_stereo, int check_orientation, int *match12, int *nmatches) {
+    if (!c || !kf1 || !kf2 || !nmatches || (kf1->n > 0 && !match12)) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *nmatches = 0;
+    const int n1 = kf1->n, n2 = kf2->n;
+    for (int i = 0; i < n1; i++) match12[i] = -1;   // vMatches12 = vector<int>(pKF1->N, -1)  (:617)
+    if (n_nodes <= 0 || n1 <= 0 || n2 <= 0) return YGZF_OK;
+    if (!off1 || !idx1 || !off2 || !idx2 || !has_mp1 || !has_mp2 || !kf1->keys || !kf1->desc || !kf2->keys || !kf2->desc || !F12 || !Cw1 || !R2w ||
+        !t2w || !cam2)
+        return fail(c, YGZF_ERR_INVALID, "null array");
+    const int L = kf2->scale_factors ? kf2->nlevels : c->tab.cfg.nlevels;
+    if (L <= 0) return fail(c, YGZF_ERR_INVALID, "no scale levels");
+    if (off1[0] != 0 || off2[0] != 0) return fail(c, YGZF_ERR_INVALID, "node offsets do not start at 0");
+    for (int k = 0; k < n_nodes; k++) {
+        if (off1[k] > off1[k + 1] || off2[k] > off2[k + 1]) return fail(c, YGZF_ERR_INVALID, "node offsets not ascending");
+        if (off2[k + 1] - off2[k] > 65535) return fail(c, YGZF_ERR_UNSUPPORTED, "more than 65535 features of the second KeyFrame in one vocabulary node");
+    }
+    const int ne1 = off1[n_nodes], ne2 = off2[n_nodes];
+    for (int i = 0; i < ne1; i++) if (idx1[i] < 0 || idx1[i] >= n1) return fail(c, YGZF_ERR_INVALID, "feature index of the first KeyFrame out of range");
+    for (int i = 0; i < ne2; i++) if (idx2[i] < 0 || idx2[i] >= n2) return fail(c, YGZF_ERR_INVALID, "feature index of the second KeyFrame out of range");
+    for (int i = 0; i < n2; i++)
+        if (kf2->keys[i].octave < 0 || kf2->keys[i].octave >= L) return fail(c, YGZF_ERR_INVALID, "keypoint octave outside the scale tables");
+    HIPCHECK(c, hipSetDevice(c->device));
+    std::vector<float> sf(L), sg(L);
+    for (int l = 0; l < L; l++) {
+        sf[l] = kf2->scale_factors ? kf2->scale_factors[l] : c->tab.scale[l];
+        sg[l] = level_sigma2_2 ? level_sigma2_2[l] : sf[l] * sf[l];   // mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i]  (src/ORBextractor.cc:422)
+    }
+    TriArgs A;
+    {   // epipole in the second image (:601-608): C2 = R2w * Cw + t2w, coefficient order of the 3x3 product
+        float C2[3];
+        for (int r = 0; r < 3; r++) C2[r] = R2w[3 * r] * Cw1[0] + R2w[3 * r + 1] * Cw1[1] + R2w[3 * r + 2] * Cw1[2];
+        for (int r = 0; r < 3; r++) C2[r] = C2[r] + t2w[r];
+        const float invz = 1.0f / C2[2];
+        A.ex = cam2->fx * C2[0] * invz + cam2->cx;
+        A.ey = cam2->fy * C2[1] * invz + cam2->cy;
+    }
+    for (int i = 0; i < 9; i++) A.F[i] = F12[i];
+    int rc;
+    PackedTransfer P(c);
+    const size_t N1 = (size_t) n1, N2 = (size_t) n2;
+    const size_t iO1 = P.add_in(off1, 4 * (size_t) (n_nodes + 1)), iI1 = P.add_in(idx1, 4 * (size_t) ne1), iO2 = P.add_in(off2, 4 * (size_t) (n_nodes + 1)),
+                 iI2 = P.add_in(idx2, 4 * (size_t) ne2), iK1 = P.add_in(kf1->keys, sizeof(ygzf_kp) * N1), iK2 = P.add_in(kf2->keys, sizeof(ygzf_kp) * N2),
+                 iD1 = P.add_in(kf1->desc, 32 * N1), iD2 = P.add_in(kf2->desc, 32 * N2), iM1 = P.add_in(has_mp1, N1), iM2 = P.add_in(has_mp2, N2),
+                 iU1 = P.add_in(kf1->u_right, kf1->u_right ? 4 * N1 : 0), iU2 = P.add_in(kf2->u_right, kf2->u_right ? 4 * N2 : 0),
+                 iSf = P.add_in(sf.data(), 4 * (size_t) L), iSg = P.add_in(sg.data(), 4 * (size_t) L);
+    int tail[64];   // [0] nmatches, [4 .. 34) rotation histogram
+    const size_t oM = P.add_out(match12, 4 * N1), oT = P.add_out(tail, sizeof(tail));
+    uint8_t *d;
+    if ((rc = P.upload(&d)) || (rc = ensure(c, c->dGen[9], N1 + 16))) return rc;
+    A.nEntries = ne1; A.nNodes = n_nodes; A.n1 = n1;
+    A.off1 = (const int *) (d + iO1); A.idx1 = (const int *) (d + iI1); A.off2 = (const int *) (d + iO2); A.idx2 = (const int *) (d + iI2);
+    A.keys1 = (const ygzf_kp *) (d + iK1); A.keys2 = (const ygzf_kp *) (d + iK2);
+    A.desc1 = d + iD1; A.desc2 = d + iD2; A.hasMp1 = d + iM1; A.hasMp2 = d + iM2;
+    A.uR1 = kf1->u_right ? (const float *) (d + iU1) : nullptr;
+    A.uR2 = kf2->u_right ? (const float *) (d + iU2) : nullptr;
+    A.sf2 = (const float *) (d + iSf); A.sigma2 = (const float *) (d + iSg);
+    A.onlyStereo = only_stereo != 0; A.checkOri = check_orientation != 0;
+    A.match12 = (int *) P.d_out(oM);
+    A.binOf = (unsigned char *) c->dGen[9].p;
+    A.nmatches = (int *) P.d_out(oT);
+    A.hist = A.nmatches + 4;
+    HIPCHECK(c, hipMemsetAsync(P.d_out(oM), 0xFF, 4 * N1, c->stream));
+    HIPCHECK(c, hipMemsetAsync(P.d_out(oT), 0, sizeof(tail), c->stream));
+    {
+        ProfScope ps(c, KK_BOWNODES);
+        launch_triangulation(c->stream, A);
+    }
+    HIPCHECK(c, hipGetLastError());
+    if ((rc = P.download())) return rc;
+    *nmatches = tail[0];
+    c->lastMatchPairs = 0;
+    return YGZF_OK;
+}
+
 int ygzf_search_for_initialization(ygzf_ctx *c, const ygzf_frame_view *F1, const ygzf_frame_view *F2, const ygzf_camera *cam, float *prev_matched_xy,
                                    int window_size, float nnratio, int check_orientation, int *matches12, int *nmatches) {
     if (!c || !F1 || !F2 || !cam || !nmatches || !matches12 || !prev_matched_xy) return fail(c, YGZF_ERR_INVALID, "null argument");

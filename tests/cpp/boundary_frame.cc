@@ -77,6 +77,8 @@ void Map::SetReferenceMapPoints(const std::vector<MapPoint *> &) {}   // "This i
 extern "C" void ygz_ref_Tracking_SearchLocalPoints(ygz::Tracking *);
 extern "C" void ygz_ref_Tracking_SearchLocalPointsDirect(ygz::Tracking *);
 extern "C" void ygz_ref_Frame_ComputeStereoMatches(ygz::Frame *);
+extern "C" int ygz_ref_ORBmatcher_SearchForTriangulation(ygz::ORBmatcher *, ygz::KeyFrame *, ygz::KeyFrame *, Matrix3f &,
+                                                         std::vector<std::pair<size_t, size_t> > &, bool);
 #include "ORBVocabularyDevice.h"   // ygz::DeviceORBVocabulary over the reference's real DBoW2 (this build: -DYGZ_REAL_DBOW2)
 
 int main(int argc, char **argv) {
@@ -260,6 +262,73 @@ int main(int argc, char **argv) {
             if (cur2.mvpMapPoints[i]) a2[i] = (int) (cur2.mvpMapPoints[i] - mps.data());
         dump(dir + "/m_match2.bin", a2.data(), a2.size() * sizeof(int));
         dump(dir + "/m_nmatch2.bin", &nm2, sizeof nm2);
+    }
+    // LocalMapping::CreateNewMapPoints (src/LocalMapping.cc:1038-1042): SearchForTriangulation(KF1, KF2, F12, pairs, false) between the two
+    // monocular frames as KeyFrames, with the FeatureVectors the device vocabulary gave them (REAL DBoW2 node ids) and the pose the aligner
+    // found.  ORBmatcher::SearchForTriangulation is the product's strong definition in this binary; the reference's own body runs beside it.
+    {
+        KeyFrame K1, K2;
+        Frame *src[2] = {&last, &cur};
+        KeyFrame *kf[2] = {&K1, &K2};
+        for (int s = 0; s < 2; s++) {
+            KeyFrame &Kf = *kf[s];
+            const Frame &F = *src[s];
+            Kf.N = F.N;
+            Kf.mvKeys = F.mvKeys;
+            Kf.mvuRight.assign(F.N, -1.f);
+            for (int i = 0; i < F.N; i += 3) Kf.mvuRight[i] = F.mvKeys[i].pt.x - 4.f;     // every third keypoint has a stereo match
+            Kf.mDescriptors = F.mDescriptors;
+            Kf.mFeatVec = F.mFeatVec;
+            Kf.mvpMapPoints.assign(F.N, (MapPoint *) nullptr);
+            for (int i = s; i < F.N; i += 5) Kf.mvpMapPoints[i] = &mps[0];                  // slots that already hold a MapPoint
+            Kf.fx = Frame::fx; Kf.fy = Frame::fy; Kf.cx = Frame::cx; Kf.cy = Frame::cy;
+            Kf.mvScaleFactors = F.mvScaleFactors;
+            Kf.mvLevelSigma2 = F.mvLevelSigma2;
+            Kf.mnScaleLevels = L;
+            Kf.mHasPose = true;
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Kf.mRcw(r, c) = F.mRcw(r, c); Kf.mtcw[r] = F.mtcw[r]; }
+            Kf.mOw = F.mOw;
+        }
+        if (K1.mFeatVec.empty() || K2.mFeatVec.empty()) { fprintf(stderr, "SearchForTriangulation: empty FeatureVector\n"); return 7; }
+        // ComputeF12 (src/LocalMapping.cc:1329-1344) in double, rounded once: K1^-T [t12]x R12 K2^-1
+        Matrix3f F12;
+        {
+            double R1[9], R2[9], t1[3], t2[3], R12[9], t12[3], Ki[9] = {1.0 / Frame::fx, 0, -Frame::cx / (double) Frame::fx, 0, 1.0 / Frame::fy, -Frame::cy / (double) Frame::fy, 0, 0, 1};
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { R1[3 * r + c] = K1.mRcw(r, c); R2[3 * r + c] = K2.mRcw(r, c); } t1[r] = K1.mtcw[r]; t2[r] = K2.mtcw[r]; }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += R1[3 * r + k] * R2[3 * c + k]; R12[3 * r + c] = a; }
+            for (int r = 0; r < 3; r++) { double a = 0; for (int k = 0; k < 3; k++) a += R12[3 * r + k] * t2[k]; t12[r] = -a + t1[r]; }
+            const double tx[9] = {0, -t12[2], t12[1], t12[2], 0, -t12[0], -t12[1], t12[0], 0};
+            double A[9], B[9], C[9];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += Ki[3 * k + r] * tx[3 * k + c]; A[3 * r + c] = a; }   // K^-T [t]x
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += A[3 * r + k] * R12[3 * k + c]; B[3 * r + c] = a; }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { double a = 0; for (int k = 0; k < 3; k++) a += B[3 * r + k] * Ki[3 * k + c]; C[3 * r + c] = a; }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) F12(r, c) = (float) C[3 * r + c];
+        }
+        for (int only = 0; only < 2; only++) {
+            std::vector<std::pair<size_t, size_t> > got, want;
+            ORBmatcher mt(0.6f, true);
+            const int ng = mt.SearchForTriangulation(&K1, &K2, F12, got, only != 0);
+            const int nw = ygz_ref_ORBmatcher_SearchForTriangulation(&mt, &K1, &K2, F12, want, only != 0);
+            if (ng != nw || got != want) { fprintf(stderr, "SearchForTriangulation(onlyStereo=%d): device %d pairs, the reference's own body %d\n", only, ng, nw); return 7; }
+            if (only == 0 && ng < 50) { fprintf(stderr, "SearchForTriangulation: only %d pairs between two views of one plane\n", ng); return 7; }
+            printf("info search_for_triangulation only_stereo %d pairs %d nodes %zu / %zu\n", only, ng, K1.mFeatVec.size(), K2.mFeatVec.size());
+        }
+        {
+            auto med = [&](bool device) {
+                std::vector<double> us;
+                for (int it = 0; it < 40; it++) {
+                    std::vector<std::pair<size_t, size_t> > pr;
+                    ORBmatcher mt(0.6f, true);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (device) mt.SearchForTriangulation(&K1, &K2, F12, pr, false); else ygz_ref_ORBmatcher_SearchForTriangulation(&mt, &K1, &K2, F12, pr, false);
+                    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+                }
+                std::sort(us.begin(), us.end());
+                return us[us.size() / 2];
+            };
+            const double dev = med(true), ref = med(false);
+            printf("latency search_for_triangulation reference_us %.1f device_us %.1f keys %d / %d\n", ref, dev, K1.N, K2.N);
+        }
     }
     // ---- the reference's own src/Tracking.cc (compiled unchanged, linked against the product's strong ORBmatcher / SparseImgAlign / ORBextractor
     // symbols) drives the hot path: Tracking::Tracking builds its extractors and its aligner from the settings file (:83-213),

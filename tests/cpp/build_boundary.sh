@@ -28,10 +28,14 @@ mkdir -p "$OUT"
 FLAGS="-O2 -std=c++14 -msse4.2 -pthread -w -ffp-contract=off -DYGZ_REF_TRACKING -DYGZ_REF_MATCHER -DYGZ_REF_FRAME -DYGZ_BOUNDARY_BUILD -DYGZ_REAL_DBOW2 -DYGZF_WITH_REFERENCE_HEADERS"
 INC="-I$S/tracking -I$S -I$ROOT/oracle -I$REF/include -I$REF -I$H -include $S/dbow2_stubs.h -include $H/ORBextractor.h -include $S/tracking/tracking_stubs.h"
 # The reference's own src/ORBmatcher.cc (+ src/Align.cc) stays in the link for the members outside the hot path (Fuse x2, SearchBySim3,
-# SearchForTriangulation, SearchByProjection(KF, Scw, ...), SearchByBoW(KF, KF, ...)): its definitions are made WEAK, so the strong
+# SearchByProjection(KF, Scw, ...), SearchByBoW(KF, KF, ...)): its definitions are made WEAK, so the strong
 # definitions of the hot-path members in the product's ORBmatcher.cc win at link time and nothing in the reference file is edited.
 g++ $FLAGS $INC -c "$REF/src/ORBmatcher.cc" -o "$OUT/ref_ORBmatcher.o"
 g++ $FLAGS $INC -c "$REF/src/Align.cc" -o "$OUT/ref_Align.o"
+# (the reference's OWN body of SearchForTriangulation stays callable as ygz_ref_ORBmatcher_SearchForTriangulation through a renamed, all-weak copy
+# of the object: the driver runs it beside the product's strong definition, as with the three batch bindings below)
+TRI=_ZN3ygz10ORBmatcher22SearchForTriangulationEPNS_8KeyFrameES2_RN5Eigen8Matrix3fERSt6vectorISt4pairImmESaIS8_EEb
+objcopy --redefine-sym $TRI=ygz_ref_ORBmatcher_SearchForTriangulation --weaken "$OUT/ref_ORBmatcher.o" "$OUT/ref_ORBmatcher_orig.o"
 objcopy --weaken "$OUT/ref_ORBmatcher.o"
 g++ $FLAGS $INC -c "$REF/src/Tracking.cc" -o "$OUT/ref_Tracking.o"
 g++ $FLAGS $INC -c "$REF/src/Frame.cc" -o "$OUT/ref_Frame.o"
@@ -45,7 +49,7 @@ objcopy --redefine-sym _ZN3ygz8Tracking17SearchLocalPointsEv=ygz_ref_Tracking_Se
 objcopy --redefine-sym _ZN3ygz5Frame20ComputeStereoMatchesEv=ygz_ref_Frame_ComputeStereoMatches --weaken "$OUT/ref_Frame.o" "$OUT/ref_Frame_orig.o"
 objcopy --weaken-symbol=_ZN3ygz8Tracking17SearchLocalPointsEv --weaken-symbol=_ZN3ygz8Tracking23SearchLocalPointsDirectEv "$OUT/ref_Tracking.o"
 objcopy --weaken-symbol=_ZN3ygz5Frame20ComputeStereoMatchesEv "$OUT/ref_Frame.o"
-OBJS="$OUT/ref_Tracking.o $OUT/ref_Tracking_orig.o $OUT/ref_Frame.o $OUT/ref_Frame_orig.o $OUT/ref_ORBmatcher.o $OUT/ref_Align.o"
+OBJS="$OUT/ref_Tracking.o $OUT/ref_Tracking_orig.o $OUT/ref_Frame.o $OUT/ref_Frame_orig.o $OUT/ref_ORBmatcher.o $OUT/ref_ORBmatcher_orig.o $OUT/ref_Align.o"
 SRCS="$H/TrackingBatched.cc $H/FrameStereo.cc $H/ORBextractor.cc $H/ORBmatcher.cc $H/SparseImageAlign.cc $H/ORBVocabularyDevice.cc $H/ygzf_pool.cc \
     $REF/Thirdparty/DBoW2/DBoW2/FORB.cpp $REF/Thirdparty/DBoW2/DBoW2/BowVector.cpp $REF/Thirdparty/DBoW2/DBoW2/FeatureVector.cpp \
     $REF/Thirdparty/DBoW2/DBoW2/ScoringObject.cpp $REF/Thirdparty/DBoW2/DUtils/Random.cpp $REF/Thirdparty/DBoW2/DUtils/Timestamp.cpp \
@@ -78,7 +82,7 @@ g++ -c "$OUT/outside.S" -o "$OUT/outside.o"
 g++ -pthread $OBJS "$OUT/outside_abort.o" "$OUT/outside.o" $LINK -o "$OUT/boundary_frame"
 cp "$OUT/outside.syms" "$OUT/boundary_frame.outside"
 rm -f $OBJS "$OUT/outside.S" "$OUT/outside.o" "$OUT/outside_abort.cc" "$OUT/outside_abort.o" "$OUT/outside.syms" "$OUT/boundary_frame.try"
-rm -f "$OUT/ref_ORBmatcher.o" "$OUT/ref_Align.o" "$OUT/ref_Tracking_orig.o" "$OUT/ref_Frame.o" "$OUT/ref_Frame_orig.o"
+rm -f "$OUT/ref_ORBmatcher.o" "$OUT/ref_ORBmatcher_orig.o" "$OUT/ref_Align.o" "$OUT/ref_Tracking_orig.o" "$OUT/ref_Frame.o" "$OUT/ref_Frame_orig.o"
 # strong (T) = the product's definition was linked; weak (W) = the reference's body is still the one in use
 nm -C "$OUT/boundary_frame" | grep -E " [TW] ygz::(ORBmatcher::(SearchByProjection|SearchByBoW|SearchForInitialization|FindDirectProjection|Fuse|SearchBySim3|SearchForTriangulation|DescriptorDistance)|SparseImgAlign::run|ORBextractor::operator\(\)|Frame::ComputeStereoMatches|Tracking::(TrackWithSparseAlignment|TrackWithMotionModel|SearchLocalPoints|MonocularInitialization|Relocalization|SearchLocalPointsDirect|TrackReferenceKeyFrame))\(" | sed 's/^[0-9a-f]* //' | sort > "$OUT/boundary_frame.symbols"
 echo "built $OUT/boundary_frame"

@@ -1,6 +1,6 @@
 // test_shells.cc -- drives the three class shells (reference signatures) the way Tracking.cc does and dumps their
 // outputs as raw binaries for tests/test_gpu_shells.py to compare with the oracle.
-// usage: test_shells <dir>   reads <dir>/a.u8, <dir>/b.u8 (752x480 u8) and <dir>/depth.f32 (plane depth).
+// usage: test_shells <dir>   reads <dir>/a.u8, <dir>/b.u8 (752x480 u8), <dir>/depth.f32 (plane depth) and <dir>/tri.f32 (two-view geometry).
 #include <cmath>
 #include <cstdio>
 #include <set>
@@ -278,6 +278,42 @@ int main(int argc, char **argv) {
             if (out[i]) assigned5[i] = (int) (out[i] - mps.data());
         dump(dir + "/match5.bin", assigned5.data(), assigned5.size() * sizeof(int));
         dump(dir + "/nmatch5.bin", &nm5, sizeof nm5);
+    }
+    // LocalMapping::CreateNewMapPoints: SearchForTriangulation(KF1 = A, KF2 = B, F12, pairs, false)  (src/LocalMapping.cc); F12 / R2w / t2w / Cw1
+    // come from <dir>/tri.f32 (9 + 9 + 3 + 3 floats, written by the Python side); node = leading descriptor bits, node 5 absent in KF1
+    {
+        std::vector<unsigned char> tr = slurp(dir + "/tri.f32");
+        const float *tf = (const float *) tr.data();
+        KeyFrame K1, K2;
+        Frame *src[2] = {&A, &B};
+        KeyFrame *kf[2] = {&K1, &K2};
+        for (int s = 0; s < 2; s++) {
+            KeyFrame &K = *kf[s];
+            const Frame &F = *src[s];
+            K.N = F.N;
+            K.mvKeys = F.mvKeys;
+            K.mDescriptors = F.mDescriptors;
+            K.mvScaleFactors = F.mvScaleFactors;
+            for (float x : F.mvScaleFactors) K.mvLevelSigma2.push_back(x * x);
+            K.fx = Frame::fx; K.fy = Frame::fy; K.cx = Frame::cx; K.cy = Frame::cy;
+            for (int i = 0; i < F.N; i++) {
+                K.mvpMapPoints.push_back((i % 5 == s) ? &mps[0] : nullptr);
+                K.mvuRight.push_back((i % 3 == 0) ? F.mvKeys[i].pt.x - 4.f : -1.f);
+                const unsigned node = F.mDescriptors.ptr<unsigned char>(i)[0] >> 4;
+                if (!(s == 0 && node == 5)) K.mFeatVec[node].push_back(i);
+            }
+        }
+        Matrix3f F12;
+        for (int i = 0; i < 9; i++) { F12.m[i] = tf[i]; K2.mRcw.m[i] = tf[9 + i]; }
+        for (int i = 0; i < 3; i++) { K2.mtcw[i] = tf[18 + i]; K1.mOw[i] = tf[21 + i]; }
+        std::vector<std::pair<size_t, size_t>> pairs;
+        ORBmatcher matcher6(0.6f, true);
+        const int nm6 = matcher6.SearchForTriangulation(&K1, &K2, F12, pairs, false);
+        std::vector<int> m6(A.N, -1);
+        for (const auto &pr : pairs) m6[pr.first] = (int) pr.second;
+        if ((int) pairs.size() != nm6) { fprintf(stderr, "SearchForTriangulation: %zu pairs, return value %d\n", pairs.size(), nm6); return 5; }
+        dump(dir + "/match6.bin", m6.data(), m6.size() * sizeof(int));
+        dump(dir + "/nmatch6.bin", &nm6, sizeof nm6);
     }
     // stereo: left = A, right eye image r.u8 -> ExtractORB(1, imRight) then ComputeStereoMatches  (src/Frame.cc:728-738)
     {

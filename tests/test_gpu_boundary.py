@@ -42,7 +42,9 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "boundary ok" in out.stdout
     lat = [l for l in out.stdout.splitlines() if l.startswith("latency ")]
-    assert len(lat) == 3
+    assert len(lat) == 4
+    tri = [l for l in out.stdout.splitlines() if l.startswith("info search_for_triangulation")]
+    assert len(tri) == 2 and int(tri[0].split()[5]) >= 50, tri      # device pairs == the reference's own body (the driver exits 7 otherwise)
     os.makedirs(os.path.join(ROOT, "gpurun_out", "r04"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "r04", "boundary_latency.txt"), "w") as fh:
         fh.write("# tests/cpp/boundary_frame: the reference's own loop bodies (per-call members) against the batch bindings of TrackingBatched.cc, 752x480, ~1000 local points\n")
@@ -126,9 +128,10 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     sym = open(EXE + ".symbols").read().splitlines()
     strong = [l for l in sym if l.startswith("T ")]
     weak = [l for l in sym if l.startswith("W ")]
-    assert all(any(n in l for l in strong) for n in ("FindDirectProjection", "SearchForInitialization", "DescriptorDistance", "SearchByBoW(ygz::KeyFrame*, ygz::Frame&",
+    assert all(any(n in l for l in strong) for n in ("FindDirectProjection", "SearchForInitialization", "SearchForTriangulation", "DescriptorDistance",
+                                                       "SearchByBoW(ygz::KeyFrame*, ygz::Frame&",
                                                        "SparseImgAlign::run", "ORBextractor::operator()(ygz::Frame*", "Frame::ComputeStereoMatches"))
-    assert sum("ORBmatcher::" in l for l in strong) == 7
+    assert sum("ORBmatcher::" in l for l in strong) == 8
     # the reference's own src/Tracking.cc is in the binary, unchanged, and its hot-path callers are there to call the product's definitions above
     for member in ("TrackWithSparseAlignment", "TrackWithMotionModel", "SearchLocalPoints()", "MonocularInitialization", "Relocalization", "SearchLocalPointsDirect",
                    "TrackReferenceKeyFrame"):
@@ -136,7 +139,7 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     outside = open(EXE + ".outside").read().split()
     assert 30 < len(outside) < 120 and all(x.startswith(("_ZN3ygz", "_ZNK3ygz")) for x in outside)       # what aborts when reached: members of classes outside the hot path only
     assert not any(("ORBmatcher" in x) or ("SparseImgAlign" in x) or ("ORBextractor" in x) or ("3ygz5Frame" in x) for x in outside)
-    assert len(weak) == 6 and all(any(n in l for l in weak) for n in ("Fuse", "SearchBySim3", "SearchForTriangulation"))
+    assert len(weak) == 5 and all(any(n in l for l in weak) for n in ("Fuse", "SearchBySim3", "SearchByBoW(ygz::KeyFrame*, ygz::KeyFrame*"))
     # SearchLocalPoints: the reference's isInFrustum (CPU) marks, the shell searches
     fr = rd("m_frustum.bin", np.float32).reshape(-1, 5)
     Ow = -(Rcw.T @ tcw)

@@ -203,6 +203,21 @@ def test_fuzz_projected_searches(oracle, seed):
         e = oracle.search_by_bow(ko, ki, fo, fi, tiv, ka, da, kb, db, ratio, ori2)
         g = ex.search_by_bow(ko, ki, fo, fi, tiv, ka, da, kb, db, ratio, ori2)
         assert g[0] == e[0] and (g[1] == e[1]).all(), ("bow", w, h, nf, bits)
+    # SearchForTriangulation on the same joined node list: random relative pose, epipole inside or outside the image, stereo flags
+    from tests.tri_cases import geometry
+    ep = None if rng.uniform() < 0.5 else (rng.uniform(0, w), rng.uniform(0, h))
+    F12, Cw1, R2w, t2w, cam2 = geometry(float(rng.choice([0.002, 0.05, 0.8])), float(rng.uniform(-0.5, 0.5)), epipole=ep)
+    Cw1 = rng.uniform(-0.01, 0.01, 3).astype(np.float32)
+    stereo = rng.uniform() < 0.5
+    kf1 = dict(keys=ka, desc=da, has_mp=(rng.uniform(size=M) < rng.uniform(0, 0.6)).astype(np.uint8),
+               u_right=np.where(rng.uniform(size=M) < 0.5, ka["x"] - 3, -1).astype(np.float32) if stereo else None)
+    kf2 = dict(keys=kb, desc=db, has_mp=(rng.uniform(size=N) < rng.uniform(0, 0.6)).astype(np.uint8),
+               u_right=np.where(rng.uniform(size=N) < 0.5, kb["x"] - 3, -1).astype(np.float32) if stereo else None)
+    kw = dict(off1=ko, idx1=ki, off2=fo, idx2=fi, kf1=kf1, kf2=kf2, scale_factors2=sf, level_sigma2_2=(sf * sf).astype(np.float32), F12=F12, Cw1=Cw1,
+              R2w=R2w, t2w=t2w, cam2=cam2, only_stereo=bool(stereo and rng.uniform() < 0.3), check_ori=ori2)
+    e = oracle.search_for_triangulation(**kw)
+    g = ex.search_for_triangulation(**kw)
+    assert g[0] == e[0] and (g[1] == e[1]).all(), ("triangulation", w, h, nf, bits, stereo)
 
 
 @pytest.mark.parametrize("seed", SEEDS)

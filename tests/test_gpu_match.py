@@ -240,6 +240,67 @@ def test_search_by_bow(oracle):
             assert e_n > 20
 
 
+def test_search_for_triangulation(oracle):
+    """SearchForTriangulation + CheckDistEpipolarLine (src/ORBmatcher.cc:596-741, :136-153) against the oracle: the cases of the CPU pin
+    (tests/test_ref_matcher.py holds the oracle to the reference's own source on exactly these) + the context's tables instead of KF2's."""
+    from orb_ygz_slam_amd import Extractor
+    from tests.tri_cases import cases
+    w, h = 752, 480
+    base = synth_frame(50, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[10:10 + h, 5:5 + w]
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    sf = oracle.Extractor(1000, 1.2, 8, 20, 7).tables()["scale"]
+    sg = (sf * sf).astype(np.float32)
+    total = 0
+    for label, kw in cases(ka, da, kb, db):
+        e_n, e_m = oracle.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sg, **kw)
+        g_n, g_m = ex.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sg, **kw)
+        assert g_n == e_n and (g_m == e_m).all(), (label, g_n, e_n)
+        g_n2, g_m2 = ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **kw)   # the extractor's own tables
+        assert g_n2 == e_n and (g_m2 == e_m).all(), label
+        total += e_n
+    assert total > 1500
+    # other tables than the extractor's: a coarser sigma2 admits more pairs
+    label, kw = cases(ka, da, kb, db)[0]
+    sg4 = (4 * sg).astype(np.float32)
+    e_n, e_m = oracle.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sg4, **kw)
+    g_n, g_m = ex.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sg4, **kw)
+    assert g_n == e_n and (g_m == e_m).all()
+    # degenerate inputs: no common node, an empty KeyFrame
+    z = np.zeros(1, np.int32)
+    kw0 = dict(kw, off1=z, idx1=z[:0], off2=z, idx2=z[:0])
+    assert ex.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sg, **kw0)[0] == 0
+    empty = dict(keys=ka[:0], desc=da[:0], has_mp=np.zeros(0, np.uint8), u_right=None)
+    kw1 = dict(kw, kf1=empty, off1=np.zeros_like(kw["off1"]), idx1=z[:0])
+    n, m = ex.search_for_triangulation(scale_factors2=sf, level_sigma2_2=sg, **kw1)
+    assert n == 0 and len(m) == 0
+
+
+def test_search_for_triangulation_rejects_bad_input():
+    from orb_ygz_slam_amd import Extractor
+    from orb_ygz_slam_amd.capi import YgzfError
+    from tests.tri_cases import cases
+    w, h = 640, 480
+    a = synth_frame(51, w, h)
+    ex = Extractor(500, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    ka, da = ex.extract(a)
+    label, kw = cases(ka, da, ka, da)[0]
+    bad = dict(kw, idx2=kw["idx2"] + len(ka))
+    with pytest.raises(YgzfError):
+        ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **bad)
+    k2 = ka.copy()
+    k2["octave"][0] = 9
+    with pytest.raises(YgzfError):
+        ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **dict(kw, kf2=dict(kw["kf2"], keys=k2)))
+    off = kw["off1"].copy()
+    off[1], off[2] = off[2], off[1]
+    if off[1] != off[2]:
+        with pytest.raises(YgzfError):
+            ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **dict(kw, off1=off))
+
+
 def test_matcher_is_deterministic_over_repeats(oracle):
     """Regression for a missing barrier between the grid's per-cell sort and the candidate scans (found by the 9000-case fuzz sweep:
     about 1 run in 50 of two particular cases lost a match): the same search repeated many times must equal the oracle every time."""

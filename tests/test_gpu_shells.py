@@ -49,6 +49,13 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     for bnd, dsp in enumerate((4, 9, 15, 22, 30, 6)):
         imgR[bnd * 80:(bnd + 1) * 80, :w - dsp] = imgA[bnd * 80:(bnd + 1) * 80, dsp:]
     imgR.tofile(tmp_path / "r.u8")
+    # two-view geometry for SearchForTriangulation: KF1 = A at the origin, KF2 = B at (R, t); F12 as LocalMapping::ComputeF12 builds it
+    K = np.array([[EUROC["fx"], 0, EUROC["cx"]], [0, EUROC["fy"], EUROC["cy"]], [0, 0, 1]], np.float64)
+    R64, t64 = np.asarray(R, np.float64), np.asarray(t, np.float64).reshape(3)
+    t12 = -R64.T @ t64
+    F12 = (np.linalg.inv(K).T @ np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]]) @ R64.T @ np.linalg.inv(K)).astype(np.float32)
+    R2w, t2w, Cw1 = R64.astype(np.float32), t64.astype(np.float32), np.zeros(3, np.float32)
+    np.concatenate([F12.ravel(), R2w.ravel(), t2w, Cw1]).astype(np.float32).tofile(tmp_path / "tri.f32")
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shells ok" in out.stdout
@@ -167,6 +174,20 @@ def test_class_shells_end_to_end(oracle, tmp_path):
     e_n5, e_m5 = oracle.search_by_bow(ko, ki, fo, fi, (idx % 9 != 0).astype(np.uint8), ka, da, kb, db, 0.7, True)
     assert int(np.fromfile(tmp_path / "nmatch5.bin", np.int32)[0]) == e_n5 and e_n5 > 20
     assert (np.fromfile(tmp_path / "match5.bin", np.int32) == np.where(e_m5 >= 0, e_m5, -1)).all()
+    # SearchForTriangulation(KF1 = A, KF2 = B): node = first descriptor byte >> 4, node 5 absent in KF1
+    na, nb = da[:, 0].astype(np.int32) >> 4, db[:, 0].astype(np.int32) >> 4
+    nodes = sorted((set(na.tolist()) - {5}) & set(nb.tolist()))
+    o1, o2, i1, i2 = [0], [0], [], []
+    for n in nodes:
+        i1.extend(np.nonzero(na == n)[0]); i2.extend(np.nonzero(nb == n)[0])
+        o1.append(len(i1)); o2.append(len(i2))
+    ia, ib = np.arange(len(ka)), np.arange(len(kb))
+    kf1 = dict(keys=ka, desc=da, has_mp=(ia % 5 == 0).astype(np.uint8), u_right=np.where(ia % 3 == 0, ka["x"] - f(4), f(-1)).astype(np.float32))
+    kf2 = dict(keys=kb, desc=db, has_mp=(ib % 5 == 1).astype(np.uint8), u_right=np.where(ib % 3 == 0, kb["x"] - f(4), f(-1)).astype(np.float32))
+    e_n6, e_m6 = oracle.search_for_triangulation(o1, i1, o2, i2, kf1, kf2, sf, (sf * sf).astype(np.float32), F12, Cw1, R2w, t2w,
+                                                 (EUROC["fx"], EUROC["fy"], EUROC["cx"], EUROC["cy"]), False, True)
+    assert int(np.fromfile(tmp_path / "nmatch6.bin", np.int32)[0]) == e_n6 and e_n6 > 20
+    assert (np.fromfile(tmp_path / "match6.bin", np.int32) == np.where(e_m6 >= 0, e_m6, -1)).all()
     # stereo: right-eye extraction through the shell (leftEye = false) + ComputeStereoMatches
     kr, dr = oex.extract(imgR)
     assert (np.fromfile(tmp_path / "s_kpsr.bin", KP_DTYPE) == kr).all()
