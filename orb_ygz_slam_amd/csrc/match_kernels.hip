@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
                                                unsigned long long q1, unsigned long long q2, unsigned long long q3,
                                                const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2,
                                                unsigned *secondKey = nullptr, int *secondIdx2 = nullptr,
-                                               const volatile int *matchedDist = nullptr) {
+                                               const volatile int *matchedDist = nullptr, const int *claimant = nullptr, int self = 0) {
     const int nCx = q.maxCx - q.minCx + 1;   // <= 64 (one lane per grid column)
     const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
     int rs = 0, rlen = 0;
@@ -139,6 +139,7 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         const float distx = L.cx[i2] - q.u, disty = L.cy[i2] - q.v;
         if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
         if (L.owner[i2] == 2) continue;  // mvpMapPoints[i2] && Observations() > 0
+        if (claimant && claimant[i2] < self) continue;   // fixpoint pass: taken by an earlier query whose MapPoint has observations
         if (uRight && uRight[i2] > 0) {
             const float er = fabsf(q.ur - uRight[i2]);
             if (er > q.radius) continue;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
 
     long long *dbg = A.dbg ? A.dbg + (long long) pair * 8 : nullptr;
 #define STAMP(k) do { if (dbg && tid == 0) dbg[k] = wall_clock64(); } while (0)
-    STAMP(0);
+    const long long tStart = dbg ? wall_clock64() : 0;   // (with several workgroups per pair only the one that survives the hand-over reports)
     // ---- LDS carve-up ----
     MatchLds L;
     // Arrays that do not fit the LDS budget (large keypoint counts: 4000 / 8000 features) live in a per-pair global
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         }
     }
     __syncthreads();   // the candidate scans below read the cells other threads have just sorted
-    STAMP(1);
+    const long long tGrid = dbg ? wall_clock64() : 0;
     // ---- per-query projection (:1243-1272) ----
     const float *Rcw = pose, *tcw = pose + 9, *Rlw = pose + 12, *tlw = pose + 21;
     float twc[3], tlc2;
@@ -441,55 +442,63 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
             const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
             const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
+            // One candidate = a chain of dependent LDS reads (list -> level / position / owner -> descriptor): the filters are evaluated as
+            // predicates, not as early exits, so that the reads behind them are issued together (three waits per candidate instead of six).
+            // Measured and dropped: four candidates per step (the runs are short: wasted evaluations), whole grid columns per lane.
+            auto eval = [&](int li, unsigned ord, unsigned &jj) -> unsigned {
+                const int i2 = L.list[li];
+                jj = (unsigned) i2;
+                bool ok = true;
+                if (bCheckLevels) {
+                    const int o = L.octave[i2];
+                    ok = ok && !(o < q.minLevel) && !(q.maxLevel >= 0 && o > q.maxLevel);
+                }
+                const float distx = L.cx[i2] - q.u, disty = L.cy[i2] - q.v;
+                ok = ok && (fabsf(distx) < q.radius && fabsf(disty) < q.radius) && L.owner[i2] != 2;
+                if (uRight) {
+                    const float ur2 = uRight[i2];
+                    if (ur2 > 0 && fabsf(q.ur - ur2) > q.radius) ok = false;
+                }
+                unsigned long long d0, d1, d2, d3;
+                if (A.descInLds) {
+                    d0 = L.desc[4 * i2]; d1 = L.desc[4 * i2 + 1]; d2 = L.desc[4 * i2 + 2]; d3 = L.desc[4 * i2 + 3];
+                } else {
+                    const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
+                    d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
+                }
+                const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
+                if ((A.mode == 0 || A.mode == 2) && dist > (unsigned) A.maxDist) ok = false;   // modes 1, 3 need the runner-up even when it is far
+                return ok ? ((dist << 16) | (ord & 0xFFFFu)) : 0xFFFFFFFFu;
+            };
+            auto insert = [&](unsigned key, unsigned jj) {
+                if (A.specDeep) {   // sorted list of eight: one compare-exchange sweep (branch-free)
+                    if (key < K[7]) {
+                        unsigned ck = key;
+                        unsigned cj = jj;
+#define YGZF_CEX(K, J) do { if (ck < K) { const unsigned tk = K; const unsigned tj = J; K = ck; J = cj; ck = tk; cj = tj; } } while (0)
+                        YGZF_CEX(K[0], J[0]); YGZF_CEX(K[1], J[1]); YGZF_CEX(K[2], J[2]); YGZF_CEX(K[3], J[3]);
+                        YGZF_CEX(K[4], J[4]); YGZF_CEX(K[5], J[5]); YGZF_CEX(K[6], J[6]); YGZF_CEX(K[7], J[7]);
+#undef YGZF_CEX
+                    }
+                } else if (key < K[3]) {   // insert into the sorted quadruple
+                    if (key < K[2]) {
+                        K[3] = K[2]; J[3] = J[2];
+                        if (key < K[1]) {
+                            K[2] = K[1]; J[2] = J[1];
+                            if (key < K[0]) { K[1] = K[0]; J[1] = J[0]; K[0] = key; J[0] = jj; }
+                            else { K[1] = key; J[1] = jj; }
+                        } else { K[2] = key; J[2] = jj; }
+                    } else { K[3] = key; J[3] = jj; }
+                }
+            };
             unsigned colBase = 0;   // candidates of the grid columns before ix: `ord` is the position in the reference's visiting order
             for (int ix = q.minCx; ix <= q.maxCx; ix++) {
                 const int c0 = ix * GRID_ROWS;
                 const int s = L.cellStart[c0 + q.minCy], e = L.cellStart[c0 + q.maxCy + 1];
                 for (int li = s + qr; li < e; li += LPQ) {
-                    const unsigned ord = colBase + (unsigned) (li - s);
-                    const int i2 = L.list[li];
-                    if (bCheckLevels) {
-                        const int o = L.octave[i2];
-                        if (o < q.minLevel) continue;
-                        if (q.maxLevel >= 0 && o > q.maxLevel) continue;
-                    }
-                    const float distx = L.cx[i2] - q.u, disty = L.cy[i2] - q.v;
-                    if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
-                    if (L.owner[i2] == 2) continue;
-                    if (uRight && uRight[i2] > 0) {
-                        const float er = fabsf(q.ur - uRight[i2]);
-                        if (er > q.radius) continue;
-                    }
-                    unsigned long long d0, d1, d2, d3;
-                    if (A.descInLds) {
-                        d0 = L.desc[4 * i2]; d1 = L.desc[4 * i2 + 1]; d2 = L.desc[4 * i2 + 2]; d3 = L.desc[4 * i2 + 3];
-                    } else {
-                        const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
-                        d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
-                    }
-                    const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
-                    if ((A.mode == 0 || A.mode == 2) && dist > (unsigned) A.maxDist) continue;   // modes 1, 3 need the runner-up even when it is far
-                    const unsigned key = (dist << 16) | (ord & 0xFFFFu);
-                    const unsigned jj = (unsigned) i2;
-                    if (A.specDeep) {   // sorted list of eight: one compare-exchange sweep (branch-free)
-                        if (key < K[7]) {
-                            unsigned ck = key;
-                            unsigned cj = jj;
-#define YGZF_CEX(K, J) do { if (ck < K) { const unsigned tk = K; const unsigned tj = J; K = ck; J = cj; ck = tk; cj = tj; } } while (0)
-                            YGZF_CEX(K[0], J[0]); YGZF_CEX(K[1], J[1]); YGZF_CEX(K[2], J[2]); YGZF_CEX(K[3], J[3]);
-                            YGZF_CEX(K[4], J[4]); YGZF_CEX(K[5], J[5]); YGZF_CEX(K[6], J[6]); YGZF_CEX(K[7], J[7]);
-#undef YGZF_CEX
-                        }
-                    } else if (key < K[3]) {   // insert into the sorted quadruple
-                        if (key < K[2]) {
-                            K[3] = K[2]; J[3] = J[2];
-                            if (key < K[1]) {
-                                K[2] = K[1]; J[2] = J[1];
-                                if (key < K[0]) { K[1] = K[0]; J[1] = J[0]; K[0] = key; J[0] = jj; }
-                                else { K[1] = key; J[1] = jj; }
-                            } else { K[2] = key; J[2] = jj; }
-                        } else { K[3] = key; J[3] = jj; }
-                    }
+                    unsigned jj;
+                    const unsigned key = eval(li, colBase + (unsigned) (li - s), jj);
+                    insert(key, jj);
                 }
                 colBase += (unsigned) (e - s);
             }
@@ -519,6 +528,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             }
         }
     }
+    if (dbg) __syncthreads();   // (debug builds of the launch only: the stamp is the workgroup's scan time, not the first wave's)
+    const long long tScan = dbg ? wall_clock64() : 0;
     if (S > 1) {   // hand-over: the last workgroup to arrive owns the pair from here on
         __threadfence();
         __syncthreads();
@@ -540,8 +551,149 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         }
     }
     __syncthreads();
-    STAMP(2);
+    if (dbg && tid == 0) { dbg[0] = tStart; dbg[1] = tGrid; dbg[2] = tScan; }
     STAMP(3);
+    if ((A.mode == 0 || A.mode == 2) && !A.serialOrder) {
+        // ---- in-order resolution as a FIXPOINT, all waves (modes 0 and 2: first free entry of the list, no runner-up).
+        // Sequentially, query q takes the first entry of its speculative list that no EARLIER query whose MapPoint has observations has taken
+        // (entries owned at the start are not in the list; a MapPoint without observations does not block, :1301-1303).  Iterate
+        //     choice'(q) = first entry e of list(q) with  min{ q' blocking : choice(q') = e } >= q
+        // from choice(q) = first entry: after k rounds the first k queries hold their sequential answer (query q's pick only depends on the
+        // picks of the queries before it), so the iteration ends, and a fixpoint IS the sequential assignment (same induction).  Chains of
+        // queries that push each other along are short in practice (3-6 rounds for 1000 queries; the one-wave pass below needs one round per
+        // conflict and 64 queries per tile: 30 of the 55 us of a one-pair launch).  A query whose whole list is taken needs the full rescan of
+        // the serial pass (rare): then, or after 48 rounds, the pair is handed to that pass untouched.
+        constexpr int BIG = 0x7FFFFFFF;
+        int *claimBuf[2] = {L.claim, L.match};
+        int *choiceOf = L.events;                    // entry i is only ever touched by the thread that owns query i (i mod kMatchBlock)
+        for (int i = tid; i < nt; i += kMatchBlock) { L.claim[i] = BIG; L.match[i] = BIG; }
+        for (int i = tid; i < nq; i += kMatchBlock) choiceOf[i] = L.specKey[i].x < kNoKey ? (int) L.specI2[i].x : -1;
+        if (tid < 2) s_tmp[16 + tid] = 0;
+        __syncthreads();
+        bool serial = false;
+        int rounds = 0, nRescanned = 0;
+        for (;; rounds++) {
+            int *cl = claimBuf[rounds & 1], *other = claimBuf[(rounds & 1) ^ 1];
+            for (int i = tid; i < nq; i += kMatchBlock) {
+                const int ch = choiceOf[i];
+                if (ch >= 0 && L.qobs[i]) atomicMin(&cl[ch], i);
+            }
+            if (tid == 0) s_tmp[18] = BIG;
+            __syncthreads();
+            int changed = 0;
+            for (int i = tid; i < nq; i += kMatchBlock) {
+                const uint4 keys = L.specKey[i];
+                if (keys.x >= kNoKey) continue;
+                const ushort4 idx = L.specI2[i];
+                const int c0 = cl[idx.x], c1 = cl[idx.y], c2 = cl[idx.z], c3 = cl[idx.w];   // four reads in flight together
+                int pick;
+                if (c0 >= i) pick = idx.x;
+                else if (keys.y >= kNoKey) pick = -1;
+                else if (c1 >= i) pick = idx.y;
+                else if (keys.z >= kNoKey) pick = -1;
+                else if (c2 >= i) pick = idx.z;
+                else if (keys.w >= kNoKey) pick = -1;
+                else if (c3 >= i) pick = idx.w;
+                else pick = -2;                      // list exhausted
+                if (pick != choiceOf[i]) { choiceOf[i] = pick; changed = 1; }
+                if (pick == -2) atomicMin(&s_tmp[18], i);
+            }
+            for (int i = tid; i < nt; i += kMatchBlock) other[i] = BIG;     // the next round's claims start clean (nobody reads `other` now)
+            if (tid == 0) s_tmp[16 + ((rounds & 1) ^ 1)] = 0;
+            if (changed) s_tmp[16 + (rounds & 1)] = 1;
+            __syncthreads();
+            if (rounds >= 95) { serial = true; break; }
+            if (s_tmp[16 + (rounds & 1)]) continue;  // some pick moved: another round, on the other claim buffer
+            // a fixpoint of the system in which exhausted queries take nothing: every query BEFORE the first exhausted one is final.  That one is
+            // rescanned against the claims of those (one wave, the whole window) and gets its answer as a one-entry list; then the iteration goes on.
+            const int qx = s_tmp[18];
+            if (qx == BIG) break;
+            if (wave == 0) {
+                const QueryParam q = L.qp[qx];
+                const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) qx * 32);
+                int b = -1;
+                const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &b, nullptr, nullptr, nullptr, cl, qx);
+                if (lane == 0) {
+                    const bool ok = b >= 0 && (int) (key >> 16) <= A.maxDist;
+                    L.specKey[qx] = make_uint4(ok ? key : kNoKey, kNoKey, kNoKey, kNoKey);
+                    L.specI2[qx] = make_ushort4((unsigned short) (ok ? b : 0), 0, 0, 0);
+                    choiceOf[qx] = ok ? b : -1;
+                }
+            }
+            nRescanned++;
+            __syncthreads();
+        }
+        if (dbg && tid == 0) dbg[6] = serial ? -1 : nRescanned * 1000 + rounds + 1;
+        if (serial) {
+            for (int i = tid; i < nt; i += kMatchBlock) { L.claim[i] = 64; L.match[i] = -1; }
+            __syncthreads();
+        } else {
+            // commit: the LAST query that picked a keypoint holds it (an earlier holder without observations is overwritten, :1301-1303);
+            // every pick counts as a match and votes (the reference's rotHist keeps the overwritten vote too, :1327-1345)
+            STAMP(4);
+            for (int i = tid; i < nt; i += kMatchBlock) L.match[i] = -1;
+            if (tid == 0) { s_tmp[16] = 0; s_tmp[17] = 0; }
+            __syncthreads();
+            const bool doOri = A.checkOri != 0;
+            const float factor = 1.0f / HISTO_LENGTH;
+            int mine = 0;
+            for (int i = tid; i < nq; i += kMatchBlock) {
+                const int ch = choiceOf[i];
+                if (ch < 0) { choiceOf[i] = -1; continue; }
+                atomicMax(&L.match[ch], i);
+                mine++;
+                if (doOri) {
+                    float rot = L.qang[i] - L.cang[ch];
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int) roundf(rot * factor);
+                    if (bin == HISTO_LENGTH) bin = 0;
+                    atomicAdd(&s_hist[bin], 1);
+                    choiceOf[i] = (bin << 24) | ch;
+                }
+            }
+            mine = wave_sum(mine);
+            if (lane == 0 && mine) atomicAdd(&s_tmp[16], mine);
+            __syncthreads();
+            for (int i = tid; i < nq; i += kMatchBlock) {
+                const int ev = choiceOf[i];
+                if (ev < 0) continue;
+                const int ch = ev & 0xFFFFFF;
+                if (L.match[ch] == i) L.owner[ch] = L.qobs[i] ? 2 : 1;
+            }
+            __syncthreads();
+            if (doOri) {
+                int ind1 = -1, ind2 = -1, ind3 = -1;
+                int max1 = 0, max2 = 0, max3 = 0;
+                for (int b = 0; b < HISTO_LENGTH; b++) {
+                    const int s = s_hist[b];
+                    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
+                    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
+                    else if (s > max3) { max3 = s; ind3 = b; }
+                }
+                if (max2 < 0.1f * (float) max1) { ind2 = -1; ind3 = -1; }
+                else if (max3 < 0.1f * (float) max1) { ind3 = -1; }
+                int removed = 0;
+                for (int i = tid; i < nq; i += kMatchBlock) {
+                    const int ev = choiceOf[i];
+                    if (ev < 0) continue;
+                    const int bin = ev >> 24, idx = ev & 0xFFFFFF;
+                    if (bin != ind1 && bin != ind2 && bin != ind3) {
+                        L.owner[idx] = 0;
+                        L.match[idx] = -2;
+                        removed++;
+                    }
+                }
+                removed = wave_sum(removed);
+                if (lane == 0 && removed) atomicAdd(&s_tmp[17], removed);
+                __syncthreads();
+            }
+            for (int i = tid; i < nt; i += kMatchBlock) { ownerOut[i] = L.owner[i]; matchOut[i] = L.match[i]; }
+            if (tid == 0) A.nmatches[pair] = s_tmp[16] - s_tmp[17];
+            STAMP(5);
+            if (dbg && tid == 0) dbg[7] = nq;
+            return;
+        }
+    }
     if (wave != 0) return;
 
     // ---- in-order resolution by one wave.  Only LDS is touched inside the loop (a global store followed by the

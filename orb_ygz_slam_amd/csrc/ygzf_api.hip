@@ -174,6 +174,7 @@ struct ygzf_ctx {
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
     bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
     int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
+    int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass for modes 0 / 2 too (A/B runs, tests)
     bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
@@ -1576,6 +1577,7 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
         A.spillScratch = c->dSpill.p;
     }
     // few pairs in the launch (a Tracking thread matches ONE): spread each over several workgroups (kernels.h, MatchArgs::split)
+    A.serialOrder = c->matchSerial;
     A.split = 1;
     A.splitCnt = nullptr;
     A.splitX = nullptr;

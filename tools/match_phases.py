@@ -1,18 +1,16 @@
-#!/usr/bin/env python3
-"""tools/match_phases.py -- phase clocks of k_match_last (SearchByProjection(Cur, Last)) for the first pair of a 256-frame batch
-(YGZF_MATCH_DEBUG: the switch is read when the context is created)."""
-import os
-import sys
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["YGZF_MATCH_DEBUG"] = "1"
-import bench  # noqa: E402
-from orb_ygz_slam_amd import Extractor, make_camera  # noqa: E402
-
-frames = bench.make_frames(256, 752, 480, seed0=1000)
-ex = Extractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=256)
-cam = make_camera(752, 480)
-for _ in range(2):
-    ex.extract_batch_host(frames)
-    ex.match_batch_prev(cam, 15.0, True, True, True)
-    ex.sync()
+"""tools/match_phases.py -- phase times of one SearchByProjection(cur, last) launch (YGZF_MATCH_DEBUG=1 prints them): grid build, candidate scan,
+hand-over between the workgroups of a pair, in-order resolution (fixpoint rounds / rescans), commit.  YGZF_MATCH_SPLIT / YGZF_MATCH_SERIAL select the plans."""
+import numpy as np, os, sys
+sys.path.insert(0, os.getcwd())
+from orb_ygz_slam_amd import Extractor, make_camera, EUROC
+from orb_ygz_slam_amd.scene import two_view_scene
+w,h=752,480
+imgA, imgB, (R,t), bp = two_view_scene(9, w, h, EUROC, Z=4.0)
+ex = Extractor(1000,1.2,8,20,7,max_width=w,max_height=h,max_batch=1)
+ka,da = ex.extract(imgA); kb,db = ex.extract(imgB)
+cam = make_camera(w,h)
+world = bp(ka["x"], ka["y"])
+I=np.eye(3,dtype=np.float32); z=np.zeros(3,np.float32)
+for k in range(3):
+    r = ex.search_by_projection_last(cam, kb, db, ka, world, da, R.astype(np.float32), t.astype(np.float32), I, z, 15.0, True, True, True)
+    print("nmatches", r[0])
