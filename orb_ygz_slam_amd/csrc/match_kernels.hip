@@ -48,6 +48,7 @@ struct QueryParam {  // per Last keypoint, precomputed by all waves (32 bytes)
 
 constexpr int kMatchBlock = 1024;
 constexpr unsigned kNoKey = (256u << 16);
+constexpr int kExtSlots = 64;
 
 struct MatchLds {
     int *cellStart, *cellFill, *list, *events;
@@ -63,6 +64,11 @@ struct MatchLds {
     unsigned char *owner, *octave;
     int *match;                 // per Cur keypoint: accepted Last index (flushed to global at the end)
     int *claim;                 // per Cur keypoint: lowest pending lane that wants it this round (64 = none)
+    // fixpoint pass: list extensions.  extOf[2 q], extOf[2 q + 1]: slots of query q's first / second extension (0xFF: none)
+    unsigned char *extOf;
+    unsigned *extKey;           // kExtSlots x 8 keys
+    unsigned short *extI2;      // kExtSlots x 8 Cur indices
+    int *extWork;               // queries waiting for an extension this round
 };
 
 // GetFeaturesInArea + best-candidate scan of one query by one wave.
@@ -86,11 +92,11 @@ __device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
     return ab < cd ? ab : cd;
 }
 
-__device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
-                                               unsigned long long q1, unsigned long long q2, unsigned long long q3,
-                                               const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2,
-                                               unsigned *secondKey = nullptr, int *secondIdx2 = nullptr,
-                                               const volatile int *matchedDist = nullptr, const int *claimant = nullptr, int self = 0) {
+template <class Visit>
+__device__ __forceinline__ void for_each_candidate(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
+                                                   unsigned long long q1, unsigned long long q2, unsigned long long q3,
+                                                   const uint8_t *curDesc, const float *uRight, int lane, const volatile int *matchedDist,
+                                                   const int *claimant, int self, Visit visit) {
     const int nCx = q.maxCx - q.minCx + 1;   // <= 64 (one lane per grid column)
     const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
     int rs = 0, rlen = 0;
@@ -111,8 +117,6 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         if (a3 >= 0 && a3 < ln) li3 = st + a3;
         total += ln;
     }
-    unsigned best = (256u << 16) | 0xFFFFu, best2 = (256u << 16) | 0xFFFFu;   // per-lane best and runner-up
-    int bestI2 = -1, best2I2 = -1;
     for (int jb = 0; jb < total; jb += 64) {
         const int j = jb + lane;
         int li;
@@ -139,7 +143,7 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         const float distx = L.cx[i2] - q.u, disty = L.cy[i2] - q.v;
         if (!(fabsf(distx) < q.radius && fabsf(disty) < q.radius)) continue;
         if (L.owner[i2] == 2) continue;  // mvpMapPoints[i2] && Observations() > 0
-        if (claimant && claimant[i2] < self) continue;   // fixpoint pass: taken by an earlier query whose MapPoint has observations
+        if (claimant && claimant[i2] < self) continue;   // taken by an earlier query whose MapPoint has observations
         if (uRight && uRight[i2] > 0) {
             const float er = fabsf(q.ur - uRight[i2]);
             if (er > q.radius) continue;
@@ -153,10 +157,21 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         }
         const unsigned dist = __popcll(q0 ^ d0) + __popcll(q1 ^ d1) + __popcll(q2 ^ d2) + __popcll(q3 ^ d3);
         if (matchedDist && matchedDist[i2] <= (int) dist) continue;   // SearchForInitialization :414-415
-        const unsigned key = (dist << 16) | (unsigned) j;
+        visit((dist << 16) | (unsigned) j, i2);
+    }
+}
+
+__device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
+                                               unsigned long long q1, unsigned long long q2, unsigned long long q3,
+                                               const uint8_t *curDesc, const float *uRight, int lane, int *bestIdx2,
+                                               unsigned *secondKey = nullptr, int *secondIdx2 = nullptr,
+                                               const volatile int *matchedDist = nullptr) {
+    unsigned best = (256u << 16) | 0xFFFFu, best2 = (256u << 16) | 0xFFFFu;   // per-lane best and runner-up
+    int bestI2 = -1, best2I2 = -1;
+    for_each_candidate(A, L, q, q0, q1, q2, q3, curDesc, uRight, lane, matchedDist, nullptr, 0, [&](unsigned key, int i2) {
         if (key < best) { best2 = best; best2I2 = bestI2; best = key; bestI2 = i2; }
         else if (key < best2) { best2 = key; best2I2 = i2; }
-    }
+    });
     const unsigned wbest = wave_min_dpp(best);
     const unsigned long long who = __ballot(best == wbest);
     const int src = __ffsll((long long) who) - 1;
@@ -170,6 +185,38 @@ __device__ __forceinline__ unsigned scan_query(const MatchArgs &A, const MatchLd
         *secondIdx2 = __builtin_amdgcn_readlane(cand2, src2);
     }
     return wbest;
+}
+
+// The next eight entries of a query's (dist, order)-sorted candidate list after `afterKey`, by one wave: what the speculative scan would have
+// put into positions 9..16 (17..24) had its lists been longer.  Independent of who has taken what since (only the INITIAL ownership excludes,
+// as in the speculative scan), so any number of queries can be extended at any time.  maxDist < 256: candidates beyond it do not count (modes
+// 0 / 2: the list simply ends).  outK / outJ are wave-uniform; missing entries are kNoKey-or-larger.
+__device__ __forceinline__ void scan_after(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0, unsigned long long q1,
+                                           unsigned long long q2, unsigned long long q3, const uint8_t *curDesc, const float *uRight, int lane,
+                                           unsigned afterKey, unsigned maxDist, unsigned (&outK)[8], unsigned (&outJ)[8]) {
+    unsigned K[8], J[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { K[e] = 0xFFFFFFFFu; J[e] = 0; }
+    for_each_candidate(A, L, q, q0, q1, q2, q3, curDesc, uRight, lane, nullptr, nullptr, 0, [&](unsigned key, int i2) {
+        if (key <= afterKey || (key >> 16) > maxDist || !(key < K[7])) return;
+        unsigned ck = key, cj = (unsigned) i2;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (ck < K[e]) { const unsigned tk = K[e], tj = J[e]; K[e] = ck; J[e] = cj; ck = tk; cj = tj; }
+    });
+#pragma unroll
+    for (int r = 0; r < 8; r++) {   // the wave's r-th smallest = the least of the lanes' heads; its lane pops
+        const unsigned m = wave_min_dpp(K[0]);
+        const unsigned long long who = __ballot(K[0] == m);
+        const int src = __ffsll((long long) who) - 1;
+        outK[r] = m;
+        outJ[r] = (unsigned) __builtin_amdgcn_readlane((int) J[0], src);
+        if (lane == src && m != 0xFFFFFFFFu) {
+#pragma unroll
+            for (int e = 0; e < 7; e++) { K[e] = K[e + 1]; J[e] = J[e + 1]; }
+            K[7] = 0xFFFFFFFFu;
+        }
+    }
 }
 
 // Two lanes' ascending lists of eight (key, index) folded into the eight smallest of both, ascending, in BOTH lanes: the element-wise
@@ -254,6 +301,10 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     CARVE(L.cang, float, A.capCur, kSpillMisc);
     CARVE(L.match, int, A.capCur, kSpillMisc);
     CARVE(L.claim, int, A.capCur, kSpillMisc);
+    CARVE(L.extOf, unsigned char, 2 * (size_t) A.capLast, kSpillMisc);
+    CARVE(L.extKey, unsigned, 8 * kExtSlots, kSpillMisc);
+    CARVE(L.extI2, unsigned short, 8 * kExtSlots, kSpillMisc);
+    CARVE(L.extWork, int, kExtSlots, kSpillMisc);
     L.desc = nullptr;
     if (A.descInLds) CARVE(L.desc, unsigned long long, 4 * (size_t) A.capCur, 0);
 #undef CARVE
@@ -553,77 +604,146 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     __syncthreads();
     if (dbg && tid == 0) { dbg[0] = tStart; dbg[1] = tGrid; dbg[2] = tScan; }
     STAMP(3);
-    if ((A.mode == 0 || A.mode == 2) && !A.serialOrder) {
-        // ---- in-order resolution as a FIXPOINT, all waves (modes 0 and 2: first free entry of the list, no runner-up).
-        // Sequentially, query q takes the first entry of its speculative list that no EARLIER query whose MapPoint has observations has taken
-        // (entries owned at the start are not in the list; a MapPoint without observations does not block, :1301-1303).  Iterate
-        //     choice'(q) = first entry e of list(q) with  min{ q' blocking : choice(q') = e } >= q
-        // from choice(q) = first entry: after k rounds the first k queries hold their sequential answer (query q's pick only depends on the
-        // picks of the queries before it), so the iteration ends, and a fixpoint IS the sequential assignment (same induction).  Chains of
-        // queries that push each other along are short in practice (3-6 rounds for 1000 queries; the one-wave pass below needs one round per
-        // conflict and 64 queries per tile: 30 of the 55 us of a one-pair launch).  A query whose whole list is taken needs the full rescan of
-        // the serial pass (rare): then, or after 48 rounds, the pair is handed to that pass untouched.
+    if (A.mode != 3 && A.serialOrder != 1) {
+        // ---- in-order resolution as a FIXPOINT, all waves (modes 0, 1, 2).
+        // Sequentially, query q sees as taken what EARLIER queries whose MapPoint has observations have taken (entries owned at the start are not in
+        // its list; a MapPoint without observations does not block, :1301-1303): it picks the first free entry of its (dist, order)-sorted list
+        // (mode 1: the first two, best and runner-up, and applies the accept rule :112-121 to them).  Iterate
+        //     claim(e) = min{ q' : q' blocking, q' currently takes e },   q re-picks among the entries with claim(e) >= q
+        // from "nobody takes anything": after k rounds the first k queries hold their sequential answer (a query's pick only depends on the picks
+        // of the queries before it), so the iteration ends, and a fixpoint IS the sequential assignment (same induction).  The chains of queries
+        // that push each other along are short (6-10 rounds for 1000 queries; the one-wave pass below retires a handful of queries per round).
+        // A query whose list runs out gets the NEXT eight entries of its sorted candidate list (scan_after: independent of the claims, so every
+        // such query is extended in the same pass, one wave each); two extensions per query, kExtSlots in all, 96 rounds -- beyond that the
+        // pair is handed, untouched, to the one-wave pass.
         constexpr int BIG = 0x7FFFFFFF;
+        const bool two = A.mode == 1;
         int *claimBuf[2] = {L.claim, L.match};
         int *choiceOf = L.events;                    // entry i is only ever touched by the thread that owns query i (i mod kMatchBlock)
         for (int i = tid; i < nt; i += kMatchBlock) { L.claim[i] = BIG; L.match[i] = BIG; }
-        for (int i = tid; i < nq; i += kMatchBlock) choiceOf[i] = L.specKey[i].x < kNoKey ? (int) L.specI2[i].x : -1;
-        if (tid < 2) s_tmp[16 + tid] = 0;
+        for (int i = tid; i < nq; i += kMatchBlock) {
+            choiceOf[i] = (!two && L.specKey[i].x < kNoKey) ? (int) L.specI2[i].x : -1;   // (modes 0 / 2: the first entries, one round saved)
+            L.extOf[2 * i] = 0xFF; L.extOf[2 * i + 1] = 0xFF;
+        }
+        if (tid < 4) s_tmp[16 + tid] = 0;            // [16], [17]: "a pick moved" of even / odd rounds; [18]: queries to extend; [19]: slots in use
+        if (tid == 0) s_tmp[15] = 0;                 // hand the pair to the one-wave pass
         __syncthreads();
-        bool serial = false;
-        int rounds = 0, nRescanned = 0;
+        int rounds = 0, nExtended = 0;
         for (;; rounds++) {
             int *cl = claimBuf[rounds & 1], *other = claimBuf[(rounds & 1) ^ 1];
             for (int i = tid; i < nq; i += kMatchBlock) {
                 const int ch = choiceOf[i];
                 if (ch >= 0 && L.qobs[i]) atomicMin(&cl[ch], i);
             }
-            if (tid == 0) s_tmp[18] = BIG;
             __syncthreads();
             int changed = 0;
             for (int i = tid; i < nq; i += kMatchBlock) {
                 const uint4 keys = L.specKey[i];
                 if (keys.x >= kNoKey) continue;
                 const ushort4 idx = L.specI2[i];
-                const int c0 = cl[idx.x], c1 = cl[idx.y], c2 = cl[idx.z], c3 = cl[idx.w];   // four reads in flight together
+                unsigned k1 = kNoKey, k2 = kNoKey;
+                int b1 = -1, b2 = -1;
+                bool ended = false, enough = false;      // the list has no further entry / the picks are complete
+                if (!two) {     // modes 0 / 2, lists of four: the first free entry
+                    const int c0 = cl[idx.x], c1 = cl[idx.y], c2 = cl[idx.z], c3 = cl[idx.w];   // four reads in flight together
+                    if (c0 >= i) { b1 = idx.x; enough = true; }
+                    else if (keys.y >= kNoKey) ended = true;
+                    else if (c1 >= i) { b1 = idx.y; enough = true; }
+                    else if (keys.z >= kNoKey) ended = true;
+                    else if (c2 >= i) { b1 = idx.z; enough = true; }
+                    else if (keys.w >= kNoKey) ended = true;
+                    else if (c3 >= i) { b1 = idx.w; enough = true; }
+                } else {        // mode 1, lists of eight: the first two free entries
+                    const uint4 kb = L.specKeyB[i];
+                    const ushort4 ib = L.specI2B[i];
+                    const unsigned kk[8] = {keys.x, keys.y, keys.z, keys.w, kb.x, kb.y, kb.z, kb.w};
+                    const int ii[8] = {idx.x, idx.y, idx.z, idx.w, ib.x, ib.y, ib.z, ib.w};
+                    int cv[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) cv[e] = cl[ii[e]];      // the claims of the whole list in flight together
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        if (ended || enough) continue;
+                        if (kk[e] >= kNoKey) { ended = true; continue; }
+                        if (cv[e] < i) continue;
+                        if (b1 < 0) { b1 = ii[e]; k1 = kk[e]; }
+                        else { b2 = ii[e]; k2 = kk[e]; enough = true; }
+                    }
+                }
+                bool exhausted = !ended && !enough;
+                if (exhausted && L.extOf[2 * i] != 0xFF) {              // the extensions of this query (rare)
+                    for (int blk = 0; blk < 2 && exhausted; blk++) {
+                        const int slot = L.extOf[2 * i + blk];
+                        if (slot == 0xFF) break;
+                        for (int e = 0; e < 8 && !ended && !enough; e++) {
+                            const unsigned key = L.extKey[8 * slot + e];
+                            const int i2 = L.extI2[8 * slot + e];
+                            if (key >= kNoKey) { ended = true; break; }
+                            if (cl[i2] < i) continue;
+                            if (b1 < 0) { b1 = i2; k1 = key; enough = !two; }
+                            else { b2 = i2; k2 = key; enough = true; }
+                        }
+                        exhausted = !ended && !enough;
+                    }
+                }
                 int pick;
-                if (c0 >= i) pick = idx.x;
-                else if (keys.y >= kNoKey) pick = -1;
-                else if (c1 >= i) pick = idx.y;
-                else if (keys.z >= kNoKey) pick = -1;
-                else if (c2 >= i) pick = idx.z;
-                else if (keys.w >= kNoKey) pick = -1;
-                else if (c3 >= i) pick = idx.w;
-                else pick = -2;                      // list exhausted
+                if (exhausted) {
+                    pick = -2;
+                    const int w = atomicAdd(&s_tmp[18], 1);
+                    if (w < kExtSlots) L.extWork[w] = i;
+                } else if (!two) {
+                    pick = b1;                           // modes 0 / 2: every list entry is acceptable (dist <= maxDist)
+                } else {
+                    pick = -1;
+                    const int bestDist = (int) (k1 >> 16);
+                    if (b1 >= 0 && bestDist <= TH_HIGH) {
+                        const int bestDist2 = (int) (k2 >> 16);      // 256 when there is no runner-up
+                        const int bestLevel = L.octave[b1], bestLevel2 = (b2 >= 0 && bestDist2 < 256) ? (int) L.octave[b2] : -1;
+                        if (!(bestLevel == bestLevel2 && (float) bestDist > A.nnratio * (float) bestDist2)) pick = b1;
+                    }
+                }
                 if (pick != choiceOf[i]) { choiceOf[i] = pick; changed = 1; }
-                if (pick == -2) atomicMin(&s_tmp[18], i);
             }
             for (int i = tid; i < nt; i += kMatchBlock) other[i] = BIG;     // the next round's claims start clean (nobody reads `other` now)
             if (tid == 0) s_tmp[16 + ((rounds & 1) ^ 1)] = 0;
             if (changed) s_tmp[16 + (rounds & 1)] = 1;
             __syncthreads();
-            if (rounds >= 95) { serial = true; break; }
-            if (s_tmp[16 + (rounds & 1)]) continue;  // some pick moved: another round, on the other claim buffer
-            // a fixpoint of the system in which exhausted queries take nothing: every query BEFORE the first exhausted one is final.  That one is
-            // rescanned against the claims of those (one wave, the whole window) and gets its answer as a one-entry list; then the iteration goes on.
-            const int qx = s_tmp[18];
-            if (qx == BIG) break;
-            if (wave == 0) {
+            if (rounds >= 95) { if (tid == 0) s_tmp[15] = 1; break; }
+            const int nWork = min(s_tmp[18], kExtSlots);
+            if (nWork == 0) {
+                if (s_tmp[16 + (rounds & 1)]) continue;  // some pick moved: another round, on the other claim buffer
+                break;                                   // fixpoint, nobody waits for an extension
+            }
+            // extensions: one wave per query; the claims play no part, so all of them at once
+            for (int w = wave; w < nWork; w += kMatchBlock / 64) {
+                const int qx = L.extWork[w];
+                const int blk = L.extOf[2 * qx] == 0xFF ? 0 : (L.extOf[2 * qx + 1] == 0xFF ? 1 : 2);
+                int slot = 0;
+                if (lane == 0) slot = (blk < 2 && A.serialOrder != 2) ? atomicAdd(&s_tmp[19], 1) : kExtSlots;
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                if (slot >= kExtSlots) { if (lane == 0) s_tmp[15] = 1; continue; }
+                unsigned afterKey;
+                if (blk == 0) afterKey = two ? L.specKeyB[qx].w : L.specKey[qx].w;
+                else afterKey = L.extKey[8 * (int) L.extOf[2 * qx] + 7];
                 const QueryParam q = L.qp[qx];
                 const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) qx * 32);
-                int b = -1;
-                const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &b, nullptr, nullptr, nullptr, cl, qx);
+                unsigned oK[8], oJ[8];
+                scan_after(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, afterKey, two ? 256u : (unsigned) A.maxDist, oK, oJ);
                 if (lane == 0) {
-                    const bool ok = b >= 0 && (int) (key >> 16) <= A.maxDist;
-                    L.specKey[qx] = make_uint4(ok ? key : kNoKey, kNoKey, kNoKey, kNoKey);
-                    L.specI2[qx] = make_ushort4((unsigned short) (ok ? b : 0), 0, 0, 0);
-                    choiceOf[qx] = ok ? b : -1;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { L.extKey[8 * slot + e] = oK[e]; L.extI2[8 * slot + e] = (unsigned short) oJ[e]; }
+                    L.extOf[2 * qx + blk] = (unsigned char) slot;
                 }
             }
-            nRescanned++;
+            nExtended += nWork;
             __syncthreads();
+            if (tid == 0) s_tmp[18] = 0;
+            if (s_tmp[15]) break;
+            // (the barrier at the top of the next round orders the reset above against that round's requests)
         }
-        if (dbg && tid == 0) dbg[6] = serial ? -1 : nRescanned * 1000 + rounds + 1;
+        __syncthreads();
+        const bool serial = s_tmp[15] != 0;
+        if (dbg && tid == 0) dbg[6] = serial ? -1 : nExtended * 1000 + rounds + 1;
         if (serial) {
             for (int i = tid; i < nt; i += kMatchBlock) { L.claim[i] = 64; L.match[i] = -1; }
             __syncthreads();
@@ -634,7 +754,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             for (int i = tid; i < nt; i += kMatchBlock) L.match[i] = -1;
             if (tid == 0) { s_tmp[16] = 0; s_tmp[17] = 0; }
             __syncthreads();
-            const bool doOri = A.checkOri != 0;
+            const bool doOri = A.checkOri != 0 && !two;
             const float factor = 1.0f / HISTO_LENGTH;
             int mine = 0;
             for (int i = tid; i < nq; i += kMatchBlock) {
@@ -665,10 +785,10 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 int ind1 = -1, ind2 = -1, ind3 = -1;
                 int max1 = 0, max2 = 0, max3 = 0;
                 for (int b = 0; b < HISTO_LENGTH; b++) {
-                    const int s = s_hist[b];
-                    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = b; }
-                    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = b; }
-                    else if (s > max3) { max3 = s; ind3 = b; }
+                    const int sc = s_hist[b];
+                    if (sc > max1) { max3 = max2; max2 = max1; max1 = sc; ind3 = ind2; ind2 = ind1; ind1 = b; }
+                    else if (sc > max2) { max3 = max2; max2 = sc; ind3 = ind2; ind2 = b; }
+                    else if (sc > max3) { max3 = sc; ind3 = b; }
                 }
                 if (max2 < 0.1f * (float) max1) { ind2 = -1; ind3 = -1; }
                 else if (max3 < 0.1f * (float) max1) { ind3 = -1; }
@@ -1542,7 +1662,8 @@ size_t match_lds_bytes(int capCur, int capLast, bool descInLds, int spill, size_
     size_t gl = 0;
     const size_t spec = (specDeep ? 2 : 1) * (al16(sizeof(uint4) * (size_t) capLast) + al16(sizeof(ushort4) * (size_t) capLast));
     const size_t misc = al16(sizeof(int) * (size_t) capLast) + al16(sizeof(float) * (size_t) capLast) + al16(sizeof(float) * (size_t) capCur) +
-                        2 * al16(sizeof(int) * (size_t) capCur);
+                        2 * al16(sizeof(int) * (size_t) capCur) + al16(2 * (size_t) capLast) + al16(sizeof(unsigned) * 8 * kExtSlots) +
+                        al16(sizeof(unsigned short) * 8 * kExtSlots) + al16(sizeof(int) * kExtSlots);
     if (spill & kSpillSpec) gl += spec; else lds += spec;
     if (spill & kSpillMisc) gl += misc; else lds += misc;
     if (descInLds) lds += al16((size_t) 32 * capCur);

@@ -174,7 +174,7 @@ struct ygzf_ctx {
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
     bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
     int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
-    int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass for modes 0 / 2 too (A/B runs, tests)
+    int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
     bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;

@@ -14,3 +14,16 @@ I=np.eye(3,dtype=np.float32); z=np.zeros(3,np.float32)
 for k in range(3):
     r = ex.search_by_projection_last(cam, kb, db, ka, world, da, R.astype(np.float32), t.astype(np.float32), I, z, 15.0, True, True, True)
     print("nmatches", r[0])
+
+# mode 1: SearchByProjection(F, MapPoints) with the projections of the same points (what Tracking::SearchLocalPoints runs per frame)
+Rf, tf = R.astype(np.float32), t.astype(np.float32)
+pc = world @ Rf.T + tf
+px = (np.float32(EUROC["fx"]) * pc[:, 0] / pc[:, 2] + np.float32(EUROC["cx"])).astype(np.float32)
+py = (np.float32(EUROC["fy"]) * pc[:, 1] / pc[:, 2] + np.float32(EUROC["cy"])).astype(np.float32)
+M = len(ka)
+tiv = np.ones(M, np.uint8)
+vc = np.full(M, 0.9995, np.float32)
+lvl = ka["octave"].astype(np.int32)
+for k in range(3):
+    r = ex.search_by_projection_mappoints(cam, kb, db, tiv, px, py, vc, lvl, da, 3.0, True, 0.8)
+    print("mode 1 nmatches", r[0])
