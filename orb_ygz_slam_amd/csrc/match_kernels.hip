@@ -92,6 +92,34 @@ __device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
     return ab < cd ? ab : cd;
 }
 
+// Device-scope accesses for what one workgroup of a pair hands to another (several workgroups per pair, MatchArgs::split): written through /
+// read past the XCD's own L2 per access.  The alternative -- plain stores and a __threadfence() on either side -- writes back and invalidates
+// the WHOLE L2 of the XCD, dirty lines of the kernels before included: 6 of the 9 us of the hand-over.
+__device__ __forceinline__ void st_dev(void *p, unsigned v) { __hip_atomic_store((unsigned *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_dev(const void *p) { return __hip_atomic_load((const unsigned *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev4(void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
+    unsigned *q = (unsigned *) p;
+    st_dev(q, a); st_dev(q + 1, b); st_dev(q + 2, c); st_dev(q + 3, d);
+}
+__device__ __forceinline__ uint4 ld_dev4(const void *p) {
+    const unsigned *q = (const unsigned *) p;
+    return make_uint4(ld_dev(q), ld_dev(q + 1), ld_dev(q + 2), ld_dev(q + 3));
+}
+__device__ __forceinline__ void store_qp(QueryParam *dst, const QueryParam &q) {
+    unsigned w[8];
+    __builtin_memcpy(w, &q, 32);
+    st_dev4(dst, w[0], w[1], w[2], w[3]);
+    st_dev4((unsigned *) dst + 4, w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ QueryParam load_qp(const QueryParam *src) {
+    const uint4 a = ld_dev4(src), b = ld_dev4((const unsigned *) src + 4);
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    QueryParam q;
+    __builtin_memcpy(&q, w, 32);
+    return q;
+}
+static_assert(sizeof(QueryParam) == 32, "QueryParam is handed over as eight dwords");
+
 template <class Visit>
 __device__ __forceinline__ void for_each_candidate(const MatchArgs &A, const MatchLds &L, const QueryParam &q, unsigned long long q0,
                                                    unsigned long long q1, unsigned long long q2, unsigned long long q3,
@@ -444,7 +472,12 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 }
             }
         } else if (has) {
-            const float *X = world + 3 * (size_t) i;
+            float Xu[3];
+            if (A.unitWorld) {   // k_backproject_unit's expressions
+                const ygzf_kp lkw = lastKeys[i];
+                Xu[0] = (lkw.x - A.cx) / A.fx; Xu[1] = (lkw.y - A.cy) / A.fy; Xu[2] = 1.f;
+            }
+            const float *X = A.unitWorld ? Xu : world + 3 * (size_t) i;
             const float xc = (Rcw[0] * X[0] + Rcw[1] * X[1] + Rcw[2] * X[2]) + tcw[0];
             const float yc = (Rcw[3] * X[0] + Rcw[4] * X[1] + Rcw[5] * X[2]) + tcw[1];
             const float zc = (Rcw[6] * X[0] + Rcw[7] * X[1] + Rcw[8] * X[2]) + tcw[2];
@@ -478,7 +511,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             }
         }
         if (qr == 0) {
-            L.qp[i] = q;
+            if (S > 1) store_qp(&L.qp[i], q);   // read back by the workgroup that takes the pair over
+            else L.qp[i] = q;
             L.qang[i] = q.angle;
             L.qobs[i] = q.hasObs;
         }
@@ -564,12 +598,14 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         if (qr != 0) continue;
         if (S > 1) {
             unsigned char *X = A.splitX + (long long) pair * A.capLast * kMatchSplitRec;
-            ((uint4 *) X)[i] = make_uint4(K[0], K[1], K[2], K[3]);
-            ((uint4 *) (X + 16 * (size_t) A.capLast))[i] = make_uint4(K[4], K[5], K[6], K[7]);
-            ((ushort4 *) (X + 32 * (size_t) A.capLast))[i] = make_ushort4((unsigned short) J[0], (unsigned short) J[1], (unsigned short) J[2], (unsigned short) J[3]);
-            ((ushort4 *) (X + 40 * (size_t) A.capLast))[i] = make_ushort4((unsigned short) J[4], (unsigned short) J[5], (unsigned short) J[6], (unsigned short) J[7]);
-            ((float *) (X + 48 * (size_t) A.capLast))[i] = q.angle;
-            ((unsigned *) (X + 52 * (size_t) A.capLast))[i] = q.hasObs;
+            st_dev4(X + 16 * (size_t) i, K[0], K[1], K[2], K[3]);
+            st_dev4(X + 16 * (size_t) A.capLast + 16 * (size_t) i, K[4], K[5], K[6], K[7]);
+            st_dev(X + 32 * (size_t) A.capLast + 8 * (size_t) i, (J[0] & 0xFFFFu) | (J[1] << 16));
+            st_dev(X + 32 * (size_t) A.capLast + 8 * (size_t) i + 4, (J[2] & 0xFFFFu) | (J[3] << 16));
+            st_dev(X + 40 * (size_t) A.capLast + 8 * (size_t) i, (J[4] & 0xFFFFu) | (J[5] << 16));
+            st_dev(X + 40 * (size_t) A.capLast + 8 * (size_t) i + 4, (J[6] & 0xFFFFu) | (J[7] << 16));
+            st_dev(X + 48 * (size_t) A.capLast + 4 * (size_t) i, __float_as_uint(q.angle));
+            st_dev(X + 52 * (size_t) A.capLast + 4 * (size_t) i, q.hasObs);
         } else {
             L.specKey[i] = make_uint4(K[0], K[1], K[2], K[3]);
             L.specI2[i] = make_ushort4((unsigned short) J[0], (unsigned short) J[1], (unsigned short) J[2], (unsigned short) J[3]);
@@ -582,23 +618,27 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     if (dbg) __syncthreads();   // (debug builds of the launch only: the stamp is the workgroup's scan time, not the first wave's)
     const long long tScan = dbg ? wall_clock64() : 0;
     if (S > 1) {   // hand-over: the last workgroup to arrive owns the pair from here on
-        __threadfence();
+        // the records and query parameters above went out as device-scope stores: once they are acknowledged (vmcnt 0) the counter may move
+        if (A.handoverFence) __threadfence();
+        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) s_tmp[19] = atomicAdd(&A.splitCnt[pair], 1);
         __syncthreads();
         if (s_tmp[19] != S - 1) return;
         if (tid == 0) A.splitCnt[pair] = 0;
-        __threadfence();
+        if (A.handoverFence) __threadfence();
         const unsigned char *X = A.splitX + (long long) pair * A.capLast * kMatchSplitRec;
         for (int i = tid; i < nq; i += kMatchBlock) {
-            L.specKey[i] = ((const uint4 *) X)[i];
-            L.specI2[i] = ((const ushort4 *) (X + 32 * (size_t) A.capLast))[i];
+            L.specKey[i] = ld_dev4(X + 16 * (size_t) i);
+            const unsigned ja = ld_dev(X + 32 * (size_t) A.capLast + 8 * (size_t) i), jb = ld_dev(X + 32 * (size_t) A.capLast + 8 * (size_t) i + 4);
+            L.specI2[i] = make_ushort4((unsigned short) ja, (unsigned short) (ja >> 16), (unsigned short) jb, (unsigned short) (jb >> 16));
             if (A.specDeep) {
-                L.specKeyB[i] = ((const uint4 *) (X + 16 * (size_t) A.capLast))[i];
-                L.specI2B[i] = ((const ushort4 *) (X + 40 * (size_t) A.capLast))[i];
+                L.specKeyB[i] = ld_dev4(X + 16 * (size_t) A.capLast + 16 * (size_t) i);
+                const unsigned jc = ld_dev(X + 40 * (size_t) A.capLast + 8 * (size_t) i), jd = ld_dev(X + 40 * (size_t) A.capLast + 8 * (size_t) i + 4);
+                L.specI2B[i] = make_ushort4((unsigned short) jc, (unsigned short) (jc >> 16), (unsigned short) jd, (unsigned short) (jd >> 16));
             }
-            L.qang[i] = ((const float *) (X + 48 * (size_t) A.capLast))[i];
-            L.qobs[i] = (unsigned char) ((const unsigned *) (X + 52 * (size_t) A.capLast))[i];
+            L.qang[i] = __uint_as_float(ld_dev(X + 48 * (size_t) A.capLast + 4 * (size_t) i));
+            L.qobs[i] = (unsigned char) ld_dev(X + 52 * (size_t) A.capLast + 4 * (size_t) i);
         }
     }
     __syncthreads();
@@ -725,7 +765,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 unsigned afterKey;
                 if (blk == 0) afterKey = two ? L.specKeyB[qx].w : L.specKey[qx].w;
                 else afterKey = L.extKey[8 * (int) L.extOf[2 * qx] + 7];
-                const QueryParam q = L.qp[qx];
+                const QueryParam q = load_qp(&L.qp[qx]);
                 const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) qx * 32);
                 unsigned oK[8], oJ[8];
                 scan_after(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, afterKey, two ? 256u : (unsigned) A.maxDist, oK, oJ);
@@ -854,7 +894,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 else { b2 = ii[e]; k2 = kk[e]; exhausted = false; break; }
             }
             if (exhausted) {
-                const QueryParam q = L.qp[i];
+                const QueryParam q = load_qp(&L.qp[i]);
                 const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
                 k1 = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, nullptr, lane, &b1, &k2, &b2, vdist);
                 nRescan++;
@@ -1002,7 +1042,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const int qi = tile + first;
-                    const QueryParam q = L.qp[qi];
+                    const QueryParam q = load_qp(&L.qp[qi]);
                     const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) qi * 32);
                     int c1 = -1, c2 = -1;
                     unsigned s2 = kNoKey;
@@ -1100,7 +1140,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     const int qi = tile + first;
-                    const QueryParam q = L.qp[qi];
+                    const QueryParam q = load_qp(&L.qp[qi]);
                     const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) qi * 32);
                     int b = -1;
                     const unsigned key = scan_query(A, L, q, qd[0], qd[1], qd[2], qd[3], curDesc, uRight, lane, &b);

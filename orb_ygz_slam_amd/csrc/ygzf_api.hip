@@ -174,6 +174,7 @@ struct ygzf_ctx {
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
     bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
     int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
+    int matchFence = getenv("YGZF_MATCH_FENCE") ? atoi(getenv("YGZF_MATCH_FENCE")) : 0;   // 1: full fences around the matcher's hand-over (A/B runs)
     int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
     bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
     struct Rec { int kind; hipEvent_t a, b; };
@@ -1578,6 +1579,7 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
     }
     // few pairs in the launch (a Tracking thread matches ONE): spread each over several workgroups (kernels.h, MatchArgs::split)
     A.serialOrder = c->matchSerial;
+    A.handoverFence = c->matchFence;
     A.split = 1;
     A.splitCnt = nullptr;
     A.splitX = nullptr;
@@ -1629,13 +1631,10 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
     const ygzf_kp *kp = (const ygzf_kp *) c->dOutKp.p;
     const uint8_t *desc = (const uint8_t *) c->dOutDesc.p;
     const int *cnt = (const int *) c->dOutCnt.p;
-    {
-        ProfScope ps(c, KK_BACKPROJ);
-        launch_backproject_unit(c->stream, kp, cnt, G.kpStride, G.kpStride, B, cam->fx, cam->fy, cam->cx, cam->cy, (float *) c->dWorld.p);
-    }
     MatchArgs A;
     memset(&A, 0, sizeof A);
     A.maxDist = 100;   // TH_HIGH
+    A.unitWorld = 1;   // world point of a Last keypoint = its back-projection to depth 1, computed where it is used (a launch of its own until round 4)
     A.curKeys = kp + G.kpStride;            // pair p: Cur = slot p+1, Last = slot p
     A.curDesc = desc + (size_t) G.kpStride * 32;
     A.curURight = nullptr;
