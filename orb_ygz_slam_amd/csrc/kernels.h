@@ -123,6 +123,7 @@ struct MatchArgs {
     // i % split == its part through projection + speculative lists and leaves them in splitX; the workgroup that arrives last at
     // splitCnt[pair] gathers all lists and runs the in-order pass.  split <= 1: one workgroup per pair, nothing crosses global memory.
     int handoverFence;             // 1: __threadfence() on both sides of the hand-over as well (A/B runs: YGZF_MATCH_FENCE)
+    int fixedLanes;                // 1: eight lanes per query in the multi-workgroup scan whatever its level (A/B runs: YGZF_MATCH_LANES=fixed)
     int unitWorld;                 // mode 0: the world point of Last keypoint i is ((x - cx) / fx, (y - cy) / fy, 1), not world[3 i ..]
     int serialOrder;               // 1: the one-wave in-order pass instead of the block-wide fixpoint; 2: fixpoint without list extensions, i.e. the
                                    // hand-over to the one-wave pass at the first exhausted list (tests, A/B runs: YGZF_MATCH_SERIAL)

@@ -50,6 +50,19 @@ constexpr int kMatchBlock = 1024;
 constexpr unsigned kNoKey = (256u << 16);
 constexpr int kExtSlots = 64;
 
+// The Cur descriptors live either in LDS or in global memory (MatchArgs::descInLds).  Read through generic pointers the compiler folds the two
+// branches into ONE flat load with a selected address -- and a flat load that lands in LDS costs ~1 us per candidate at this kernel's occupancy
+// (measured: 13 candidates per lane = 12.5 us).  The LDS side is therefore read through an LDS-typed pointer (ds_read_b128).
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4u_t lds_uint4_t;
+__device__ __forceinline__ void lds_desc(const unsigned long long *base, int i2, unsigned long long &d0, unsigned long long &d1, unsigned long long &d2,
+                                         unsigned long long &d3) {
+    lds_uint4_t *p = (lds_uint4_t *) (base + 4 * (size_t) i2);
+    const v4u_t a = p[0], b = p[1];
+    d0 = ((unsigned long long) a.y << 32) | a.x; d1 = ((unsigned long long) a.w << 32) | a.z;
+    d2 = ((unsigned long long) b.y << 32) | b.x; d3 = ((unsigned long long) b.w << 32) | b.z;
+}
+
 struct MatchLds {
     int *cellStart, *cellFill, *list, *events;
     QueryParam *qp;
@@ -178,7 +191,7 @@ __device__ __forceinline__ void for_each_candidate(const MatchArgs &A, const Mat
         }
         unsigned long long d0, d1, d2, d3;
         if (A.descInLds) {
-            d0 = L.desc[4 * i2]; d1 = L.desc[4 * i2 + 1]; d2 = L.desc[4 * i2 + 2]; d3 = L.desc[4 * i2 + 3];
+            lds_desc(L.desc, i2, d0, d1, d2, d3);
         } else {
             const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
             d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
@@ -257,6 +270,30 @@ __device__ __forceinline__ void spec_merge8(unsigned (&K)[8], unsigned (&J)[8]) 
     for (int e = 0; e < 8; e++) {
         pk[e] = (unsigned) __builtin_amdgcn_update_dpp(0, (int) K[7 - e], kDppCtrl, 0xf, 0xf, false);
         pj[e] = (unsigned) __builtin_amdgcn_update_dpp(0, (int) J[7 - e], kDppCtrl, 0xf, 0xf, false);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        if (pk[e] < K[e]) { K[e] = pk[e]; J[e] = pj[e]; }
+#pragma unroll
+    for (int st = 4; st >= 1; st >>= 1)
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if ((e & st) == 0 && K[e + st] < K[e]) {
+                const unsigned tk = K[e], tj = J[e];
+                K[e] = K[e + st]; J[e] = J[e + st];
+                K[e + st] = tk; J[e + st] = tj;
+            }
+}
+
+// The same fold with the partner lane ^ kXor (16, 32: across DPP rows), through the LDS crossbar.
+template <int kXor>
+__device__ __forceinline__ void spec_merge8_xor(unsigned (&K)[8], unsigned (&J)[8], int lane) {
+    const int addr = (lane ^ kXor) << 2;
+    unsigned pk[8], pj[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        pk[e] = (unsigned) __builtin_amdgcn_ds_bpermute(addr, (int) K[7 - e]);
+        pj[e] = (unsigned) __builtin_amdgcn_ds_bpermute(addr, (int) J[7 - e]);
     }
 #pragma unroll
     for (int e = 0; e < 8; e++)
@@ -406,8 +443,54 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     // and EIGHT LANES to a query: lane qr of the group scans every eighth entry of the query's candidate ranges and the group merges its
     // sorted lists (the serial scan of the widest window was the phase's duration: ~100 ns per candidate, hundreds of candidates)
     const int nLocal = (nq - part + S - 1) / S;
-    const int LPQ = S > 1 ? 8 : 1, qr = S > 1 ? (tid & 7) : 0;
-    for (int j = S > 1 ? (tid >> 3) : tid; j < nLocal; j += S > 1 ? (kMatchBlock >> 3) : kMatchBlock) {
+    int LPQ = S > 1 ? 8 : 1, qr = S > 1 ? (tid & 7) : 0;
+    int jFirst = S > 1 ? (tid >> 3) : tid, jStep = S > 1 ? (kMatchBlock >> 3) : kMatchBlock, jEnd = nLocal;
+    if (S > 1 && nLocal <= kMatchBlock && !A.fixedLanes) {
+        // Lanes by expected work.  A query's window grows with the square of its level's scale factor (radius = th * scale), and the queries
+        // arrive sorted by level, so with eight lanes for everybody the wave that holds the coarsest level's queries ran ten times longer than
+        // the first (its 250-candidate windows at eight lanes: 32 steps of ~1000 cycles) while the others idled.  Each wave gets a contiguous
+        // run of queries of (about) a sixteenth of the total weight scale^2 and spreads its 64 lanes over them: 2 lanes per level-0 query,
+        // 32 per level-7 query.
+        int *wsum = L.events;                 // free until the in-order phase
+        int wgt = 0;
+        if (tid < nLocal) {
+            const int i = tid * S + part;
+            int lvl = (A.mode == 0 || A.mode == 3) ? lastKeys[i].octave : A.mpLevel[(long long) pair * A.kpStrideLast + i];
+            lvl = min(max(lvl, 0), (int) kMaxLevels - 1);
+            const float sf = A.scaleFactors[lvl];
+            wgt = max(1, (int) (sf * sf * 16.f));
+        }
+        const int incl = m_wave_incl_scan(wgt);
+        if (lane == 63) s_tmp[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w2 = 0; w2 < wave; w2++) woff += s_tmp[w2];
+        if (tid < nLocal) wsum[tid] = woff + incl;
+        __syncthreads();
+        const int W = wsum[nLocal - 1];
+        int bound = 0;                        // lane k <= 16: first query whose inclusive weight exceeds k sixteenths of the total
+        if (lane <= kMatchBlock / 64) {
+            const long long target = (long long) W * lane / (kMatchBlock / 64);
+            int lo = 0, hi = nLocal;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((long long) wsum[mid] <= target) lo = mid + 1;
+                else hi = mid;
+            }
+            bound = lane == kMatchBlock / 64 ? nLocal : lo;
+        }
+        const int jb = __shfl(bound, wave), je = __shfl(bound, wave + 1);
+        __syncthreads();                      // wsum (= L.events) is free again
+        const int cnt = je - jb;
+        int g = 1;
+        while (g < cnt && g < 64) g <<= 1;
+        LPQ = 64 / g;
+        qr = lane & (LPQ - 1);
+        jFirst = jb + lane / LPQ;
+        jStep = g;
+        jEnd = je;
+    }
+    for (int j = jFirst; j < jEnd; j += jStep) {
         const int i = j * S + part;
         QueryParam q;
         q.valid = 0;
@@ -416,13 +499,34 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         q.minLevel = q.maxLevel = -1;
         q.hasObs = hasObs ? (hasObs[i] != 0) : 1;
         q.pad = 0;
+        // everything this query reads from global memory is requested up front, together (flags -> position -> keypoint -> descriptor were
+        // dependent round trips)
+        const unsigned long long *qdp = (const unsigned long long *) (mpDesc + (size_t) i * 32);
+        const unsigned long long q0 = qdp[0], q1 = qdp[1], q2 = qdp[2], q3 = qdp[3];
+        ygzf_kp lk0;
+        lk0.x = lk0.y = lk0.angle = 0; lk0.octave = 0;
+        if (A.mode == 0 || A.mode == 3) lk0 = lastKeys[i];
+        float X0 = 0, X1 = 0, X2 = 0;
+        if (A.mode == 0 && !A.unitWorld) { X0 = world[3 * (size_t) i]; X1 = world[3 * (size_t) i + 1]; X2 = world[3 * (size_t) i + 2]; }
+        float pX = 0, pY = 0, pXR = 0, pVC = 0, pAng = 0;
+        int pLvl = 0;
+        if (A.mode != 0) {
+            const long long o = (long long) pair * A.kpStrideLast + i;
+            pX = A.mpProjX[o]; pY = A.mpProjY[o];
+            if (A.mode != 3) {
+                pLvl = A.mpLevel[o];
+                if (A.mpProjXR) pXR = A.mpProjXR[o];
+                if (A.mode == 2) pAng = A.mpAngle[o];
+                else pVC = A.mpViewCos[o];
+            }
+        }
         const bool has = (mpValid ? mpValid[i] != 0 : true) && !(outlier ? outlier[i] != 0 : false);
         if (A.mode == 3) {
             // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  src/ORBmatcher.cc:375-478: queries = the level-0
             // keys of F1 (:390-392), window windowSize around the previously matched position, level 0 only
-            const ygzf_kp lk = lastKeys[i];
+            const ygzf_kp lk = lk0;
             if (lk.octave <= 0) {
-                const float u = A.mpProjX[(long long) pair * A.kpStrideLast + i], v = A.mpProjY[(long long) pair * A.kpStrideLast + i];
+                const float u = pX, v = pY;
                 const float rad = A.th;
                 const int nMinCellX = max(0, (int) floorf((u - A.minX - rad) * A.gridInvW));
                 const int nMaxCellX = min(GRID_COLS - 1, (int) ceilf((u - A.minX + rad) * A.gridInvW));
@@ -442,14 +546,14 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             // done by Frame::isInFrustum; mpValid = mbTrackInView, outlier = isBad()
             // mode 2: SearchByProjection(Cur, KeyFrame, found, th, ORBdist)  :1352-1469: projection / distance gate / PredictScale on the host
             if (has) {
-                const int lvl = A.mpLevel[(long long) pair * A.kpStrideLast + i];
+                const int lvl = pLvl;
                 float r;
                 if (A.mode == 2) r = A.th;                                                             // radius = th * scale[nPredictedLevel]
                 else {
-                    r = A.mpViewCos[(long long) pair * A.kpStrideLast + i] > 0.998 ? 2.5f : 4.0f;      // RadiusByViewingCos
+                    r = pVC > 0.998 ? 2.5f : 4.0f;                                                     // RadiusByViewingCos
                     if (A.th != 1.0) r *= A.th;
                 }
-                const float u = A.mpProjX[(long long) pair * A.kpStrideLast + i], v = A.mpProjY[(long long) pair * A.kpStrideLast + i];
+                const float u = pX, v = pY;
                 const float rad = r * A.scaleFactors[lvl];
                 const int nMinCellX = max(0, (int) floorf((u - A.minX - rad) * A.gridInvW));
                 const int nMaxCellX = min(GRID_COLS - 1, (int) ceilf((u - A.minX + rad) * A.gridInvW));
@@ -459,12 +563,12 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                     nMaxCellY >= nMinCellY) {
                     q.valid = 1;
                     q.u = u; q.v = v; q.radius = rad;
-                    q.ur = A.mpProjXR ? A.mpProjXR[(long long) pair * A.kpStrideLast + i] : 0.f;
+                    q.ur = A.mpProjXR ? pXR : 0.f;
                     q.minCx = (unsigned char) nMinCellX; q.maxCx = (unsigned char) nMaxCellX;
                     q.minCy = (unsigned char) nMinCellY; q.maxCy = (unsigned char) nMaxCellY;
                     if (A.mode == 2) {
                         q.minLevel = (signed char) (lvl - 1); q.maxLevel = (signed char) (lvl + 1);
-                        q.angle = A.mpAngle[(long long) pair * A.kpStrideLast + i];
+                        q.angle = pAng;
                     } else {
                         q.minLevel = (signed char) (A.checkLevel ? lvl - 1 : -1);
                         q.maxLevel = (signed char) (A.checkLevel ? lvl : -1);
@@ -472,12 +576,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 }
             }
         } else if (has) {
-            float Xu[3];
-            if (A.unitWorld) {   // k_backproject_unit's expressions
-                const ygzf_kp lkw = lastKeys[i];
-                Xu[0] = (lkw.x - A.cx) / A.fx; Xu[1] = (lkw.y - A.cy) / A.fy; Xu[2] = 1.f;
-            }
-            const float *X = A.unitWorld ? Xu : world + 3 * (size_t) i;
+            float X[3] = {X0, X1, X2};
+            if (A.unitWorld) { X[0] = (lk0.x - A.cx) / A.fx; X[1] = (lk0.y - A.cy) / A.fy; X[2] = 1.f; }   // k_backproject_unit's expressions
             const float xc = (Rcw[0] * X[0] + Rcw[1] * X[1] + Rcw[2] * X[2]) + tcw[0];
             const float yc = (Rcw[3] * X[0] + Rcw[4] * X[1] + Rcw[5] * X[2]) + tcw[1];
             const float zc = (Rcw[6] * X[0] + Rcw[7] * X[1] + Rcw[8] * X[2]) + tcw[2];
@@ -486,7 +586,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 const float u = A.fx * xc * invzc + A.cx;
                 const float v = A.fy * yc * invzc + A.cy;
                 if (!(u < A.minX || u > A.maxX) && !(v < A.minY || v > A.maxY)) {
-                    const ygzf_kp lk = lastKeys[i];
+                    const ygzf_kp lk = lk0;
                     const int oct = lk.octave;
                     const float r = A.th * A.scaleFactors[oct];
                     int minL, maxL;
@@ -524,8 +624,6 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
 #pragma unroll
         for (int e = 0; e < 8; e++) { K[e] = 0xFFFFFFFFu; J[e] = 0; }
         if (q.valid) {
-            const unsigned long long *qd = (const unsigned long long *) (mpDesc + (size_t) i * 32);
-            const unsigned long long q0 = qd[0], q1 = qd[1], q2 = qd[2], q3 = qd[3];
             const bool bCheckLevels = (q.minLevel > 0) || (q.maxLevel >= 0);
             // One candidate = a chain of dependent LDS reads (list -> level / position / owner -> descriptor): the filters are evaluated as
             // predicates, not as early exits, so that the reads behind them are issued together (three waits per candidate instead of six).
@@ -546,7 +644,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 }
                 unsigned long long d0, d1, d2, d3;
                 if (A.descInLds) {
-                    d0 = L.desc[4 * i2]; d1 = L.desc[4 * i2 + 1]; d2 = L.desc[4 * i2 + 2]; d3 = L.desc[4 * i2 + 3];
+                    lds_desc(L.desc, i2, d0, d1, d2, d3);
                 } else {
                     const unsigned long long *d = (const unsigned long long *) (curDesc + (size_t) i2 * 32);
                     d0 = d[0]; d1 = d[1]; d2 = d[2]; d3 = d[3];
@@ -588,10 +686,13 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
                 colBase += (unsigned) (e - s);
             }
         }
-        if (LPQ > 1) {   // the eight lanes of a query fold their lists: pairs, quads, then the two quads of the group
-            spec_merge8<0xb1>(K, J);    // quad_perm [1,0,3,2]
-            spec_merge8<0x4e>(K, J);    // quad_perm [2,3,0,1]
-            spec_merge8<0x141>(K, J);   // row_half_mirror
+        if (LPQ > 1) {   // the lanes of a query fold their lists: pairs, quads, eights, ... (LPQ is the same for the whole wave)
+            spec_merge8<0xb1>(K, J);                      // quad_perm [1,0,3,2]
+            if (LPQ >= 4) spec_merge8<0x4e>(K, J);        // quad_perm [2,3,0,1]
+            if (LPQ >= 8) spec_merge8<0x141>(K, J);       // row_half_mirror
+            if (LPQ >= 16) spec_merge8<0x140>(K, J);      // row_mirror
+            if (LPQ >= 32) spec_merge8_xor<16>(K, J, lane);
+            if (LPQ >= 64) spec_merge8_xor<32>(K, J, lane);
 #pragma unroll
             for (int e = 0; e < 8; e++) J[e] = K[e] == 0xFFFFFFFFu ? 0u : J[e];
         }

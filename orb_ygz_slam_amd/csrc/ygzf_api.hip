@@ -174,6 +174,7 @@ struct ygzf_ctx {
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
     bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
     int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
+    int matchFixedLanes = getenv("YGZF_MATCH_LANES") && !strcmp(getenv("YGZF_MATCH_LANES"), "fixed");   // (A/B runs)
     int matchFence = getenv("YGZF_MATCH_FENCE") ? atoi(getenv("YGZF_MATCH_FENCE")) : 0;   // 1: full fences around the matcher's hand-over (A/B runs)
     int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
     bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
@@ -1580,12 +1581,13 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
     // few pairs in the launch (a Tracking thread matches ONE): spread each over several workgroups (kernels.h, MatchArgs::split)
     A.serialOrder = c->matchSerial;
     A.handoverFence = c->matchFence;
+    A.fixedLanes = c->matchFixedLanes;
     A.split = 1;
     A.splitCnt = nullptr;
     A.splitX = nullptr;
     if (!A.spill && A.capLast >= 128 && c->matchSplit != 1) {
         int sp2 = c->matchSplit > 1 ? c->matchSplit : 256 / (nPairs > 0 ? nPairs : 1);
-        sp2 = std::min(sp2, c->matchSplit > 1 ? 16 : 8);   // (more than eight only on request: A/B runs)
+        sp2 = std::min(sp2, c->matchSplit > 1 ? 64 : 8);   // (more than eight only on request: A/B runs)
         if (sp2 > 1) {
             const size_t cntBytes = (size_t) nPairs * sizeof(int);
             if (c->dSplitCnt.bytes < cntBytes) {   // counters are zero between launches: a fresh buffer is cleared once
