@@ -468,18 +468,21 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         if (tid < nLocal) wsum[tid] = woff + incl;
         __syncthreads();
         const int W = wsum[nLocal - 1];
-        int bound = 0;                        // lane k <= 16: first query whose inclusive weight exceeds k sixteenths of the total
-        if (lane <= kMatchBlock / 64) {
-            const long long target = (long long) W * lane / (kMatchBlock / 64);
+        // ... over as many waves as give a query eight lanes on average, at least one per SIMD, not always over all sixteen: a wave's prologue,
+        // folds and stores are ~1300 instructions whatever its lanes do, and the SIMDs issue them one at a time
+        const int nUse = min(kMatchBlock / 64, max(4, (nLocal * 8 + 63) / 64));
+        int bound = 0;                        // lane k <= nUse: first query whose inclusive weight exceeds k parts of the total
+        if (lane <= nUse) {
+            const long long target = (long long) W * lane / nUse;
             int lo = 0, hi = nLocal;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if ((long long) wsum[mid] <= target) lo = mid + 1;
                 else hi = mid;
             }
-            bound = lane == kMatchBlock / 64 ? nLocal : lo;
+            bound = lane == nUse ? nLocal : lo;
         }
-        const int jb = __shfl(bound, wave), je = __shfl(bound, wave + 1);
+        const int jb = __shfl(bound, min(wave, nUse)), je = __shfl(bound, min(wave + 1, nUse));
         __syncthreads();                      // wsum (= L.events) is free again
         const int cnt = je - jb;
         int g = 1;
