@@ -3,7 +3,7 @@
 one rocprofv3 run (tools/profile_round.sh) yields kernel stats and PMC counters for all of SURVEY 8a / 8f:
   k_sia_run (config 3: --align batch), k_stereo_* (config 5 shape), k_dso_cells + k_dso_* + k_describe_list (DSO_KEYPOINT), k_f10_* (libfast),
   k_direct_projection (2000 candidates over 20 KeyFrames), k_frustum + k_match_last mode 1 (4000 local MapPoints), k_match_last modes 2 / 3,
-  k_distinctive (2000 MapPoints x 8 observations), k_features_in_area (1000 windows), k_bow_nodes (SearchByBoW), k_bow_descend (Frame::ComputeBoW, k = 10 / L = 6 vocabulary),
+  k_distinctive (2000 MapPoints x 8 observations), k_features_in_area (1000 windows), k_bow_nodes (SearchByBoW), k_tri_nodes (SearchForTriangulation), k_bow_descend (Frame::ComputeBoW, k = 10 / L = 6 vocabulary),
   k_hamming_pairs.
 Prints one JSON line with the library's own per-kernel event timings (ygzf_profile_*)."""
 import json
@@ -93,6 +93,13 @@ def main():
             ki.extend(np.nonzero(na == node)[0]); fi.extend(np.nonzero(nb == node)[0])
             ko.append(len(ki)); fo.append(len(fi))
         ex.search_by_bow(ko, ki, fo, fi, np.ones(len(ka), np.uint8), ka, da, kb, db, 0.7, True)
+        # SearchForTriangulation on the same node list (LocalMapping::CreateNewMapPoints): k_tri_nodes
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        from tests.tri_cases import geometry
+        F12, Cw1, R2w, t2w, cam2 = geometry(0.002)
+        none = np.zeros(max(len(ka), len(kb)), np.uint8)
+        ex.search_for_triangulation(ko, ki, fo, fi, dict(keys=ka, desc=da, has_mp=none[:len(ka)], u_right=None),
+                                    dict(keys=kb, desc=db, has_mp=none[:len(kb)], u_right=None), None, None, F12, Cw1, R2w, t2w, cam2, False, True)
         ex.descriptor_distance(da[:1000], db[:1000])
         # Frame::GetFeaturesInArea: 1000 windows of the matcher's size around the frame's own keypoints
         ex.features_in_area(cam, kb, np.stack([ka["x"][:1000], ka["y"][:1000], np.full(min(1000, len(ka)), 15.0 * 1.2, np.float32)], 1), cap=256)
