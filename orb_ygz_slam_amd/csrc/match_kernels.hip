@@ -451,6 +451,12 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         // the first (its 250-candidate windows at eight lanes: 32 steps of ~1000 cycles) while the others idled.  Each wave gets a contiguous
         // run of queries of (about) a sixteenth of the total weight scale^2 and spreads its 64 lanes over them: 2 lanes per level-0 query,
         // 32 per level-7 query.
+        const int nUse = min(kMatchBlock / 64, max(4, (nLocal * 8 + 63) / 64));
+        int jb, je;
+        if (nLocal <= 32) {                   // a handful of queries per workgroup (one pair over 64 workgroups): equal counts, no weighing
+            jb = nLocal * min(wave, nUse) / nUse;
+            je = nLocal * min(wave + 1, nUse) / nUse;
+        } else {
         int *wsum = L.events;                 // free until the in-order phase
         int wgt = 0;
         if (tid < nLocal) {
@@ -470,7 +476,6 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         const int W = wsum[nLocal - 1];
         // ... over as many waves as give a query eight lanes on average, at least one per SIMD, not always over all sixteen: a wave's prologue,
         // folds and stores are ~1300 instructions whatever its lanes do, and the SIMDs issue them one at a time
-        const int nUse = min(kMatchBlock / 64, max(4, (nLocal * 8 + 63) / 64));
         int bound = 0;                        // lane k <= nUse: first query whose inclusive weight exceeds k parts of the total
         if (lane <= nUse) {
             const long long target = (long long) W * lane / nUse;
@@ -482,8 +487,10 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             }
             bound = lane == nUse ? nLocal : lo;
         }
-        const int jb = __shfl(bound, min(wave, nUse)), je = __shfl(bound, min(wave + 1, nUse));
+        jb = __shfl(bound, min(wave, nUse));
+        je = __shfl(bound, min(wave + 1, nUse));
         __syncthreads();                      // wsum (= L.events) is free again
+        }
         const int cnt = je - jb;
         int g = 1;
         while (g < cnt && g < 64) g <<= 1;
