@@ -125,6 +125,9 @@ struct ygzf_ctx {
     // histogram plan of the octree (levels with tens of thousands of candidates): launches of consecutive levels, each with its own LDS allotment
     struct OctGroup { int l0 = 0, n = 0, cap = 0, regionInts = 0, histBins = 0; size_t lds = 0; };
     std::vector<OctGroup> octGroups;
+    OctGroup octSmall;                     // all levels in ONE histogram-plan launch: launches of a few frames (see run_extract)
+    bool haveOctSmall = false;
+    int octSmallWgs = getenv("YGZF_OCT_SMALL_WGS") ? atoi(getenv("YGZF_OCT_SMALL_WGS")) : 128;   // launches of up to this many workgroups take it (A/B runs; 752x480: 16 frames 0.211 against 0.221 ms, 64 frames 0.439 against 0.430)
     Buf dOctNodes;
     // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at
     // minTh, 2 = iniTh first.  Identical results either way.
@@ -575,6 +578,35 @@ static int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             }
             if (!ok) c->octGroups.clear();
         }
+        // A launch of ONE frame is eight workgroups whose duration is a level's: there the histogram plan (no sort: 11 of the sort plan's 40 us
+        // per level; its tree passes 12 us against 20) wins even where the candidates would fit LDS -- if all levels go in ONE launch, sized for
+        // the largest (with a handful of workgroups nobody else wants the LDS).  Launches of up to 128 workgroups take it (YGZF_OCT_SMALL_WGS; YGZF_OCT_PLAN=sort: never).
+        c->haveOctSmall = false;
+        if (!(planEnv && !strcmp(planEnv, "sort"))) {
+            ygzf_ctx::OctGroup grp;
+            grp.l0 = 0;
+            grp.n = L;
+            int cells = 0, tabs = 0;
+            for (int l = 0; l < L; l++) {
+                const LevelGeom &g = G.lv[l];
+                const int nc = g.nCols * g.nRows;
+                grp.cap = std::max(grp.cap, g.kpCap);
+                cells = std::max(cells, nc + 1);
+                if (nc > 0) tabs = std::max(tabs, nc + 1 + std::max(g.regW, g.nCols * g.wCell) + 9 + std::max(g.regH, g.nRows * g.hCell) + 9 + nc);
+            }
+            if (grp.cap < 1) grp.cap = 1;
+            const size_t budget = 150 * 1024;
+            grp.histBins = binsEnv >= 4 && binsEnv <= 8192 ? binsEnv : 8192;
+            grp.regionInts = std::max(std::max(19 * grp.cap, cells), tabs);
+            if (octree_hist_lds_bytes(grp.regionInts, grp.histBins) > budget) grp.regionInts = std::max(19 * grp.cap, cells);
+            while (grp.histBins > 1024 && !binsEnv && octree_hist_lds_bytes(grp.regionInts, grp.histBins) > budget) grp.histBins /= 2;
+            grp.lds = octree_hist_lds_bytes(grp.regionInts, grp.histBins);
+            if (grp.lds <= budget) {
+                c->octSmall = grp;
+                c->haveOctSmall = true;
+                HIPCHECK(c, octree_prepare(0, false, true));
+            }
+        }
         if (c->octGroups.empty()) {
             if (c->octLds > 150 * 1024)
                 return fail(c, YGZF_ERR_UNSUPPORTED, "octree kernel needs %zu bytes of LDS (cells/level %d, list cap %d)", c->octLds,
@@ -796,7 +828,15 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
         }
         {
             ProfScope ps(c, KK_OCTREE);
-            if (c->octGroups.empty())
+            const bool small = c->haveOctSmall && nFrames * L <= c->octSmallWgs;
+            if (small) {
+                const auto &grp = c->octSmall;
+                launch_octree(c->stream, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                              G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
+                              (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
+                              (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
+                              (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins);
+            } else if (c->octGroups.empty())
                 launch_octree(c->stream, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                               (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
