@@ -243,6 +243,7 @@ static int ensure_stage(ygzf_ctx *c, size_t bytes) {
 // One-frame entry points hand over a dozen small host arrays and take a few back.  From pageable memory every hipMemcpyAsync is a staged copy
 // of its own (10-20 us of runtime work apiece; twelve of them cost more than the kernel they feed): the arrays are packed into the context's
 // page-locked staging area and cross the link as ONE copy each way.
+constexpr size_t kPackedMax = 4u << 20;   // callers with more than this in flight keep their own copies (the staging area is page-locked memory)
 struct PackedTransfer {
     ygzf_ctx *c;
     struct Seg { const void *src; void *dst; size_t bytes, off; };
@@ -1531,6 +1532,18 @@ int ygzf_descriptor_distance(ygzf_ctx *c, const uint8_t *a, const uint8_t *b, in
     if (n == 0) return YGZF_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     int rc;
+    if ((size_t) n * 68 <= kPackedMax) {   // a frame's worth of pairs: one packed copy each way
+        PackedTransfer P(c);
+        const size_t iA = P.add_in(a, (size_t) n * 32), iB = P.add_in(b, (size_t) n * 32), oD = P.add_out(dist, (size_t) n * sizeof(int));
+        uint8_t *d;
+        if ((rc = P.upload(&d))) return rc;
+        {
+            ProfScope ps(c, KK_HAMMING);
+            launch_hamming_pairs(c->stream, d + iA, d + iB, n, (int *) P.d_out(oD));
+        }
+        HIPCHECK(c, hipGetLastError());
+        return P.download();
+    }
     if ((rc = ensure(c, c->dTmpA, (size_t) n * 32)) || (rc = ensure(c, c->dTmpB, (size_t) n * 32)) ||
         (rc = ensure(c, c->dTmpC, (size_t) n * sizeof(int))))
         return rc;
@@ -2703,32 +2716,28 @@ int ygzf_search_by_bow(ygzf_ctx *c, int n_nodes, const int *kf_off, const int *k
     for (int i = 0; i < nk; i++) if (kf_idx[i] < 0 || kf_idx[i] >= n_kf) return fail(c, YGZF_ERR_INVALID, "KeyFrame feature index out of range");
     for (int i = 0; i < nfi; i++) if (f_idx[i] < 0 || f_idx[i] >= n_f) return fail(c, YGZF_ERR_INVALID, "Frame feature index out of range");
     HIPCHECK(c, hipSetDevice(c->device));
-    ygzf_ctx::Buf *G = c->dGen;
-    struct Up { ygzf_ctx::Buf *b; const void *src; size_t bytes; };
-    Up ups[] = {{&G[0], kf_off, 4 * (size_t) (n_nodes + 1)}, {&G[1], kf_idx, 4 * (size_t) nk}, {&G[2], f_off, 4 * (size_t) (n_nodes + 1)},
-                {&G[3], f_idx, 4 * (size_t) nfi}, {&G[4], kf_valid, (size_t) n_kf}, {&G[5], kf_keys, sizeof(ygzf_kp) * (size_t) n_kf},
-                {&G[6], kf_desc, 32 * (size_t) n_kf}, {&G[7], f_keys, sizeof(ygzf_kp) * (size_t) n_f}, {&G[8], f_desc, 32 * (size_t) n_f}};
+    // nine small host arrays in, two out: one packed copy each way (PackedTransfer; nine staged copies of their own until round 4)
     int rc;
-    for (auto &u : ups) {
-        if ((rc = ensure(c, *u.b, u.bytes + 16))) return rc;
-        if (u.bytes) HIPCHECK(c, hipMemcpyAsync(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice, c->stream));
-    }
-    if ((rc = ensure(c, c->dMatch, 4 * (size_t) n_f)) || (rc = ensure(c, c->dOwner, (size_t) n_f)) || (rc = ensure(c, c->dNMatch, 4)) ||
-        (rc = ensure(c, G[9], 4 * 32)))
-        return rc;
-    HIPCHECK(c, hipMemsetAsync(c->dMatch.p, 0xFF, 4 * (size_t) n_f, c->stream));
-    HIPCHECK(c, hipMemsetAsync(c->dNMatch.p, 0, 4, c->stream));
-    HIPCHECK(c, hipMemsetAsync(G[9].p, 0, 4 * 32, c->stream));
+    PackedTransfer P(c);
+    const size_t iKO = P.add_in(kf_off, 4 * (size_t) (n_nodes + 1)), iKI = P.add_in(kf_idx, 4 * (size_t) nk), iFO = P.add_in(f_off, 4 * (size_t) (n_nodes + 1)),
+                 iFI = P.add_in(f_idx, 4 * (size_t) nfi), iKV = P.add_in(kf_valid, (size_t) n_kf), iKK = P.add_in(kf_keys, sizeof(ygzf_kp) * (size_t) n_kf),
+                 iKD = P.add_in(kf_desc, 32 * (size_t) n_kf), iFK = P.add_in(f_keys, sizeof(ygzf_kp) * (size_t) n_f), iFD = P.add_in(f_desc, 32 * (size_t) n_f);
+    int tail[64];   // [0] nmatches, [4 .. 34) rotation histogram
+    const size_t oM = P.add_out(match, 4 * (size_t) n_f), oT = P.add_out(tail, sizeof tail);
+    uint8_t *d;
+    if ((rc = P.upload(&d)) || (rc = ensure(c, c->dOwner, (size_t) n_f))) return rc;
+    int *dMatch = (int *) P.d_out(oM), *dTail = (int *) P.d_out(oT);
+    HIPCHECK(c, hipMemsetAsync(dMatch, 0xFF, 4 * (size_t) n_f, c->stream));
+    HIPCHECK(c, hipMemsetAsync(dTail, 0, sizeof tail, c->stream));
     {
         ProfScope ps(c, KK_BOWNODES);
-        launch_bow(c->stream, n_nodes, (const int *) G[0].p, (const int *) G[1].p, (const int *) G[2].p, (const int *) G[3].p, (const uint8_t *) G[4].p,
-                   (const ygzf_kp *) G[5].p, (const uint8_t *) G[6].p, n_f, (const ygzf_kp *) G[7].p, (const uint8_t *) G[8].p, nnratio, check_orientation != 0,
-                   (int *) c->dMatch.p, (unsigned char *) c->dOwner.p, (int *) G[9].p, (int *) c->dNMatch.p);
+        launch_bow(c->stream, n_nodes, (const int *) (d + iKO), (const int *) (d + iKI), (const int *) (d + iFO), (const int *) (d + iFI), d + iKV,
+                   (const ygzf_kp *) (d + iKK), d + iKD, n_f, (const ygzf_kp *) (d + iFK), d + iFD, nnratio, check_orientation != 0, dMatch,
+                   (unsigned char *) c->dOwner.p, dTail + 4, dTail);
     }
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(match, c->dMatch.p, 4 * (size_t) n_f, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(nmatches, c->dNMatch.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if ((rc = P.download())) return rc;
+    *nmatches = tail[0];
     c->lastMatchPairs = 0;
     return YGZF_OK;
 }
@@ -2898,6 +2907,31 @@ int ygzf_features_in_area(ygzf_ctx *c, const ygzf_camera *cam, int n_keys, const
     const size_t qBytes = (size_t) n_queries * 12, lBytes = levels ? (size_t) n_queries * 8 : 0;
     const size_t oBytes = (size_t) n_queries * (size_t) cap * 4, nBytes = (size_t) n_queries * 4;
     const size_t nPad = (nBytes + 15) & ~(size_t) 15;
+    if ((size_t) n_keys * sizeof(ygzf_kp) + qBytes + lBytes + nBytes + oBytes <= kPackedMax) {   // one packed copy each way
+        PackedTransfer P(c);
+        const size_t iK = P.add_in(keys, (size_t) n_keys * sizeof(ygzf_kp)), iQ = P.add_in(xyr, qBytes), iL = P.add_in(levels, lBytes);
+        const size_t oN = P.add_out(out_n, nBytes), oI = P.add_out(out_idx, oBytes);
+        uint8_t *d;
+        if ((rc = P.upload(&d))) return rc;
+        FiaArgs A;
+        A.keys = (const ygzf_kp *) (d + iK);
+        A.n = n_keys;
+        A.minX = cam->min_x; A.minY = cam->min_y;
+        A.gridInvW = (float) 64 / (cam->max_x - cam->min_x);
+        A.gridInvH = (float) 48 / (cam->max_y - cam->min_y);
+        A.nq = n_queries;
+        A.xyr = (const float *) (d + iQ);
+        A.levels = levels ? (const int *) (d + iL) : nullptr;
+        A.cap = cap;
+        A.outN = (int *) P.d_out(oN);
+        A.outIdx = (int *) P.d_out(oI);
+        {
+            ProfScope ps(c, KK_GRID);
+            HIPCHECK(c, launch_features_in_area(c->stream, A));
+        }
+        HIPCHECK(c, hipGetLastError());
+        return P.download();
+    }
     if ((rc = ensure(c, c->dTmpA, (size_t) n_keys * sizeof(ygzf_kp) + 64)) || (rc = ensure(c, c->dTmpB, qBytes + lBytes + 64)) ||
         (rc = ensure(c, c->dTmpC, nPad + oBytes + 64)))
         return rc;
