@@ -448,9 +448,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     if (S > 1 && nLocal <= kMatchBlock && !A.fixedLanes) {
         // Lanes by expected work.  A query's window grows with the square of its level's scale factor (radius = th * scale), and the queries
         // arrive sorted by level, so with eight lanes for everybody the wave that holds the coarsest level's queries ran ten times longer than
-        // the first (its 250-candidate windows at eight lanes: 32 steps of ~1000 cycles) while the others idled.  Each wave gets a contiguous
-        // run of queries of (about) a sixteenth of the total weight scale^2 and spreads its 64 lanes over them: 2 lanes per level-0 query,
-        // 32 per level-7 query.
+        // the first while the others idled.  Each of the nUse waves that take part gets a contiguous run of queries of equal total weight
+        // scale^2 and spreads its 64 lanes over them (2 lanes per level-0 query, 32 per level-7 query when a workgroup holds a hundred of them).
         const int nUse = min(kMatchBlock / 64, max(4, (nLocal * 8 + 63) / 64));
         int jb, je;
         if (nLocal <= 32) {                   // a handful of queries per workgroup (one pair over 64 workgroups): equal counts, no weighing
@@ -761,7 +760,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         // its list; a MapPoint without observations does not block, :1301-1303): it picks the first free entry of its (dist, order)-sorted list
         // (mode 1: the first two, best and runner-up, and applies the accept rule :112-121 to them).  Iterate
         //     claim(e) = min{ q' : q' blocking, q' currently takes e },   q re-picks among the entries with claim(e) >= q
-        // from "nobody takes anything": after k rounds the first k queries hold their sequential answer (a query's pick only depends on the picks
+        // from "everybody takes his first entry" (mode 1: "nobody takes anything"): after k rounds the first k queries hold their sequential answer (a query's pick only depends on the picks
         // of the queries before it), so the iteration ends, and a fixpoint IS the sequential assignment (same induction).  The chains of queries
         // that push each other along are short (6-10 rounds for 1000 queries; the one-wave pass below retires a handful of queries per round).
         // A query whose list runs out gets the NEXT eight entries of its sorted candidate list (scan_after: independent of the claims, so every
