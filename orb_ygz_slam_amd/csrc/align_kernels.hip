@@ -264,6 +264,99 @@ __device__ __forceinline__ Se3 se3_exp_wave(const float a[6], int lane) {
     return r;
 }
 
+// precomputeReferencePatches for ONE feature at one level (src/SparseImageAlign.cc:57-128): false when the patch leaves the level's border;
+// otherwise the 12 cache rows (plane 3 * row + {patch, dx, dy}) and the gradient moments.  The arithmetic -- which products are fused included -- is
+// part of the aligner's definition (oracle/oracle_align.cpp's device-order mode repeats it): k_sia_run and k_sia_precompute share this one body.
+__device__ __forceinline__ bool sia_ref_patch(const SiaLevel &Lr, float scale, float2 kp, float4 (&rows)[12], float4 &mom) {
+    const int border = 3;                       // patch_halfsize_ + 1
+    const float u_ref = kp.x * scale, v_ref = kp.y * scale;
+    const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
+    if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) return false;
+    const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
+    // the reference forms these in double and rounds to float: with u, v >= 3 the fractions are multiples of 2^-22, so 1 - su and
+    // 1 - sv are exact in fp32 and the fp32 product is the same single rounding of the same exact product
+    // (tests/test_kernel_models.py::test_bilinear_weights_fp32)
+    const float usu = 1.f - su, usv = 1.f - sv;
+    const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
+    const int st = Lr.pitch;
+    // columns u-3 .. u+4 of rows v-3 .. v+3: p[k] of the scalar form (p = row + u - 2) is byte k + 1
+    const uint8_t *rt = Lr.img + (long long) (v_ref_i - 3) * st;
+    unsigned long long R[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) R[r] = row_bytes8(rt + (long long) r * st, u_ref_i - 3, Lr.w);
+    float sxx = 0.f, sxy = 0.f, syy = 0.f;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const unsigned long long bm = R[y], b0 = R[y + 1], b1 = R[y + 2], b2 = R[y + 3];
+        float o[12];
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            o[x] = w_tl * byte_f(b0, x + 1) + w_tr * byte_f(b0, x + 2) + w_bl * byte_f(b1, x + 1) + w_br * byte_f(b1, x + 2);
+            o[4 + x] = 0.5f * ((w_tl * byte_f(b0, x + 2) + w_tr * byte_f(b0, x + 3) + w_bl * byte_f(b1, x + 2) + w_br * byte_f(b1, x + 3)) -
+                               (w_tl * byte_f(b0, x) + w_tr * byte_f(b0, x + 1) + w_bl * byte_f(b1, x) + w_br * byte_f(b1, x + 1)));
+            o[8 + x] = 0.5f * ((w_tl * byte_f(b1, x + 1) + w_tr * byte_f(b1, x + 2) + w_bl * byte_f(b2, x + 1) + w_br * byte_f(b2, x + 2)) -
+                               (w_tl * byte_f(bm, x + 1) + w_tr * byte_f(bm, x + 2) + w_bl * byte_f(b0, x + 1) + w_br * byte_f(b0, x + 2)));
+        }
+        rows[3 * y] = make_float4(o[0], o[1], o[2], o[3]);
+        rows[3 * y + 1] = make_float4(o[4], o[5], o[6], o[7]);
+        rows[3 * y + 2] = make_float4(o[8], o[9], o[10], o[11]);
+        // (explicit fused multiply-adds, here and in the accumulate phase: the library is built -ffp-contract=off, and WHICH products are
+        // fused is part of this kernel's definition -- the device-order oracle repeats them with fmaf and must reproduce H, b and chi2 bit
+        // for bit, tests/test_gpu_align.py)
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            sxx = __builtin_fmaf(o[4 + x], o[4 + x], sxx);
+            sxy = __builtin_fmaf(o[4 + x], o[8 + x], sxy);
+            syy = __builtin_fmaf(o[8 + x], o[8 + x], syy);
+        }
+    }
+    mom = make_float4(sxx, sxy, syy, 0.f);
+    return true;
+}
+
+// The reference patches of EVERY level before the alignment starts (SiaArgs::perLevel): they depend on the reference frame only, so all
+// (pair, level, feature) items are independent and run chip-wide -- inside k_sia_run they were 71 of its 355 us (seven times 1008 features
+// on the one workgroup of the pair, each a chain of global loads).  Per level a cache of its own (level l at + (l - minLevel) * stride) and a
+// flag "visible at this level or a coarser one" (visible_fts_ is cumulative, src/SparseImageAlign.cc:41-45).  A feature that is visible from
+// a coarser level but leaves THIS level's border keeps, in the reference, the patch of the last level that held it (the patch cache is
+// never cleared) under a zeroed Jacobian: that level's patch rows are rebuilt here, the gradient rows and moments are zero.
+__global__ __launch_bounds__(256) void k_sia_precompute(SiaArgs A) {
+    const int pair = blockIdx.z, level = A.maxLevel - (int) blockIdx.y;
+    const int N = A.nRef ? A.nRef[pair] : A.n;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N || level < A.minLevel) return;
+    const long long po = (long long) pair * A.kpStride;
+    const uint8_t *mpValid = A.mpValid ? A.mpValid + po : nullptr;
+    const uint8_t *outlier = A.outlier ? A.outlier + po : nullptr;
+    const bool excluded = (mpValid && !mpValid[i]) || (outlier && outlier[i]);
+    const ygzf_kp k = A.keys[po + i];
+    const float2 kp = excluded ? make_float2(-100.f, -100.f) : make_float2(k.x, k.y);
+    const size_t plane = (size_t) A.kpStride;
+    const int li = level - A.minLevel;
+    float4 *rc = (float4 *) (A.patchCache + (size_t) li * A.pcLevelStride + (size_t) po * 48) + i;
+    float4 *mom = (float4 *) (A.momCache + (size_t) li * A.momLevelStride) + po + i;
+    uint8_t *flag = A.levelFlags + (size_t) li * A.flagLevelStride + po + i;
+    const SiaLevel *refLv = A.refLv + (long long) pair * A.lvStride;
+    float4 rows[12], m;
+    int src = level;
+    bool ok = sia_ref_patch(refLv[level], A.invScale[level], kp, rows, m);
+    if (!ok)
+        for (src = level + 1; src <= A.maxLevel; src++)
+            if (sia_ref_patch(refLv[src], A.invScale[src], kp, rows, m)) { ok = true; break; }
+    *flag = ok ? 1 : 0;
+    if (level == A.minLevel) A.visible[po + i] = ok ? 1 : 0;
+    if (!ok) return;
+    if (src != level) {
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int y = 0; y < 4; y++) { rows[3 * y + 1] = z4; rows[3 * y + 2] = z4; }
+        m = z4;
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) rc[j * plane] = rows[j];
+    *mom = m;
+}
+
 // DBG: phase clocks (YGZF_SIA_DEBUG) are compiled in only in the instrumented instantiation; the production kernel reads no clock
 template <bool DBG>
 __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
@@ -284,6 +377,7 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     const uint8_t *outlier = A.outlier ? A.outlier + (long long) pair * A.kpStride : nullptr;
     // reference patch cache of this pair: 12 planes of float4, plane 3 * row + {0 patch, 1 dx, 2 dy}, feature i at [plane * kpStride + i]
     // (a lane works on one feature: consecutive lanes read consecutive float4s of a plane)
+    // (SiaArgs::perLevel: one such cache per level, filled by k_sia_precompute before this kernel starts; the level loop below re-points both)
     float4 *rowCache = (float4 *) (A.patchCache + (long long) pair * A.kpStride * 48);
     const size_t plane = (size_t) A.kpStride;
     uint8_t *visible = A.visible + (long long) pair * A.kpStride;
@@ -306,14 +400,15 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     float2 *s_uv = (float2 *) (s_feat + A.ldsFeat);
     float4 *s_jac = (float4 *) (s_uv + A.ldsFeat);   // two per feature when A.jacLds
     uint8_t *s_img = (uint8_t *) s_feat + A.stageOff;   // A.stageBytes: the current image of a level that fits (coarse levels)
-    for (int j = 0; j < 12; j++)
-        for (int i = tid; i < N; i += kSiaBlock) rowCache[j * plane + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!A.perLevel)
+        for (int j = 0; j < 12; j++)
+            for (int i = tid; i < N; i += kSiaBlock) rowCache[j * plane + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();                                            // s_Tref is set
     {   // per-feature terms that do not depend on the level, once per run: the keypoint, the exclusion flags and Tref * Xw go to LDS
         // (the level loop below used to re-read keys / world / flags for every (feature, row) item: two dependent global latencies each)
         const Se3 Tref = s_Tref;
         for (int i = tid; i < N; i += kSiaBlock) {              // visible_fts_: allocated once in run(), never cleared between levels
-            visible[i] = 0;
+            if (!A.perLevel) visible[i] = 0;
             const bool excluded = (mpValid && !mpValid[i]) || (outlier && outlier[i]);
             const ygzf_kp kp = keys[i];
             s_uv[i] = excluded ? make_float2(-100.f, -100.f) : make_float2(kp.x, kp.y);   // fails every level's border test
@@ -351,15 +446,20 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         }
         const uint8_t *s_cur = s_img;
         const long long p0c = DBG ? wall_clock64() : 0;
-        {
+        if (A.perLevel) {
+            const int li = level - A.minLevel;
+            rowCache = (float4 *) (A.patchCache + (size_t) li * A.pcLevelStride + (size_t) pair * A.kpStride * 48);
+            mom = (float4 *) (A.momCache + (size_t) li * A.momLevelStride) + (long long) pair * A.kpStride;
+            const uint8_t *fl = A.levelFlags + (size_t) li * A.flagLevelStride + (long long) pair * A.kpStride;
+            for (int i = tid; i < N; i += kSiaBlock) s_feat[i].w = fl[i] ? 1.f : 0.f;     // visible at this level or a coarser one
+        } else {
             // work item = feature: the 7 x 8 image bytes under its 4 x 4 patch and the one-pixel gradient ring are loaded once (seven
             // 8-byte row loads, all in flight together) instead of four rows per (feature, row) item
             for (int i = tid; i < N; i += kSiaBlock) {
                 const float2 kp = s_uv[i];
-                const float u_ref = kp.x * scale, v_ref = kp.y * scale;
-                const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
                 float4 *rc = rowCache + i;
-                if (u_ref_i - border < 0 || v_ref_i - border < 0 || u_ref_i + border >= Lr.w || v_ref_i + border >= Lr.h) {
+                float4 rows[12], m;
+                if (!sia_ref_patch(Lr, scale, kp, rows, m)) {
                     if (s_feat[i].w != 0.f) {   // visible from an earlier level: its Jacobian counts as zero at this level
                         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -370,45 +470,9 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
                 }
                 visible[i] = 1;
                 s_feat[i].w = 1.f;
-                const float su = u_ref - u_ref_i, sv = v_ref - v_ref_i;
-                // the reference forms these in double and rounds to float: with u, v >= 3 the fractions are multiples of 2^-22, so 1 - su and
-                // 1 - sv are exact in fp32 and the fp32 product is the same single rounding of the same exact product
-                // (tests/test_kernel_models.py::test_bilinear_weights_fp32)
-                const float usu = 1.f - su, usv = 1.f - sv;
-                const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
-                const int st = Lr.pitch;
-                // columns u-3 .. u+4 of rows v-3 .. v+3: p[k] of the scalar form (p = row + u - 2) is byte k + 1
-                const uint8_t *rt = Lr.img + (long long) (v_ref_i - 3) * st;
-                unsigned long long R[7];
 #pragma unroll
-                for (int r = 0; r < 7; r++) R[r] = row_bytes8(rt + (long long) r * st, u_ref_i - 3, Lr.w);
-                float sxx = 0.f, sxy = 0.f, syy = 0.f;
-#pragma unroll
-                for (int y = 0; y < 4; y++) {
-                    const unsigned long long bm = R[y], b0 = R[y + 1], b1 = R[y + 2], b2 = R[y + 3];
-                    float o[12];
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        o[x] = w_tl * byte_f(b0, x + 1) + w_tr * byte_f(b0, x + 2) + w_bl * byte_f(b1, x + 1) + w_br * byte_f(b1, x + 2);
-                        o[4 + x] = 0.5f * ((w_tl * byte_f(b0, x + 2) + w_tr * byte_f(b0, x + 3) + w_bl * byte_f(b1, x + 2) + w_br * byte_f(b1, x + 3)) -
-                                           (w_tl * byte_f(b0, x) + w_tr * byte_f(b0, x + 1) + w_bl * byte_f(b1, x) + w_br * byte_f(b1, x + 1)));
-                        o[8 + x] = 0.5f * ((w_tl * byte_f(b1, x + 1) + w_tr * byte_f(b1, x + 2) + w_bl * byte_f(b2, x + 1) + w_br * byte_f(b2, x + 2)) -
-                                           (w_tl * byte_f(bm, x + 1) + w_tr * byte_f(bm, x + 2) + w_bl * byte_f(b0, x + 1) + w_br * byte_f(b0, x + 2)));
-                    }
-                    rc[(3 * y) * plane] = make_float4(o[0], o[1], o[2], o[3]);
-                    rc[(3 * y + 1) * plane] = make_float4(o[4], o[5], o[6], o[7]);
-                    rc[(3 * y + 2) * plane] = make_float4(o[8], o[9], o[10], o[11]);
-                    // (explicit fused multiply-adds, here and in the accumulate phase below: the library is built -ffp-contract=off, and WHICH
-                    // products are fused is part of this kernel's definition -- oracle/oracle_align.cpp's device-order mode repeats them with
-                    // fmaf and must reproduce H, b and chi2 bit for bit, tests/test_gpu_align.py)
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        sxx = __builtin_fmaf(o[4 + x], o[4 + x], sxx);
-                        sxy = __builtin_fmaf(o[4 + x], o[8 + x], sxy);
-                        syy = __builtin_fmaf(o[8 + x], o[8 + x], syy);
-                    }
-                }
-                mom[i] = make_float4(sxx, sxy, syy, 0.f);
+                for (int j = 0; j < 12; j++) rc[j * plane] = rows[j];
+                mom[i] = m;
             }
         }
         __syncthreads();
@@ -668,6 +732,12 @@ hipError_t sia_prepare(size_t ldsBytes) {
     e = hipFuncSetAttribute((const void *) k_sia_run<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute((const void *) k_sia_run<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ceiling);
+}
+
+// A.perLevel: fills the per-level caches k_sia_run then reads (maxN = largest feature count of a pair)
+void launch_sia_precompute(hipStream_t st, const SiaArgs &A, int nPairs, int maxN) {
+    if (maxN <= 0 || nPairs <= 0) return;
+    hipLaunchKernelGGL(k_sia_precompute, dim3((maxN + 255) / 256, A.maxLevel - A.minLevel + 1, nPairs), dim3(256), 0, st, A);
 }
 
 void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes) {

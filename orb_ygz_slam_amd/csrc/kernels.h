@@ -297,6 +297,12 @@ struct SiaArgs {
     float *jacCache;                // unused (Jacobians are rebuilt from dx, dy each iteration)
     float *momCache;                // 4 floats per keypoint (16-byte aligned), pair p at + p*kpStride*4: gradient moments of the reference patch
     uint8_t *visible;               // kpStride per pair
+    // perLevel: the reference patches of all levels come from k_sia_precompute (launch_sia_precompute) instead of k_sia_run's own per-level
+    // phase: patchCache / momCache hold one block per level (level l at + (l - minLevel) * pcLevelStride / momLevelStride floats, pairs inside
+    // a block as before), levelFlags one byte per (level, pair, keypoint): visible at this level or a coarser one
+    int perLevel;
+    size_t pcLevelStride, momLevelStride, flagLevelStride;
+    uint8_t *levelFlags;
     float *out;                     // 48 floats per pair: TCR[7], ret, iters, chi2, pad[2], H[36]
     long long *dbg;                 // nullable: phase clocks of pair 0 (debug)
 };
@@ -304,6 +310,7 @@ size_t sia_lds_bytes(int maxFeatures);
 bool sia_jac_in_lds(int maxFeatures);
 size_t sia_stage_bytes(size_t featBytes, size_t largestLevelBytes);
 hipError_t sia_prepare(size_t ldsBytes);
+void launch_sia_precompute(hipStream_t st, const SiaArgs &A, int nPairs, int maxN);
 void launch_sia(hipStream_t st, const SiaArgs &A, int nPairs, size_t ldsBytes);
 
 }  // namespace ygzf

@@ -180,6 +180,7 @@ struct ygzf_ctx {
     int matchFixedLanes = getenv("YGZF_MATCH_LANES") && !strcmp(getenv("YGZF_MATCH_LANES"), "fixed");   // (A/B runs)
     int matchFence = getenv("YGZF_MATCH_FENCE") ? atoi(getenv("YGZF_MATCH_FENCE")) : 0;   // 1: full fences around the matcher's hand-over (A/B runs)
     int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
+    bool siaPerLevel = !(getenv("YGZF_SIA_PRECOMPUTE") && atoi(getenv("YGZF_SIA_PRECOMPUTE")) == 0);   // reference patches of all levels in a kernel of their own (0: inside k_sia_run, as until round 4)
     bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
@@ -1601,6 +1602,11 @@ int ygzf_profile_reset(ygzf_ctx *c) {
 void *ygzf_stream(ygzf_ctx *c) { return c ? (void *) c->stream : nullptr; }
 
 // ---- matcher ----------------------------------------------------------------------------------------------------------
+// The reference patches of all levels in a kernel of their own (k_sia_precompute) pay for launches of a few pairs -- one pair: 365 -> 305 us, the
+// 71 us the pair's one workgroup spent on them become 10 us chip-wide -- and cost large ones: at 256 pairs the in-kernel form overlaps one pair's
+// patches with another pair's solve on the same CU and its single cache stays L2-resident (971 against 1075 us per launch, 142 k against 134 k frames/s).
+constexpr int kSiaPerLevelPairs = 32;
+
 static void fill_camera(MatchArgs &A, const ygzf_camera *cam, const ygzf_ctx *c) {
     A.fx = cam->fx; A.fy = cam->fy; A.cx = cam->cx; A.cy = cam->cy; A.mb = cam->mb; A.mbf = cam->mbf;
     A.minX = cam->min_x; A.minY = cam->min_y; A.maxX = cam->max_x; A.maxY = cam->max_y;
@@ -1945,7 +1951,9 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
                  oOutl = P.add_in(ref->outlier, ref->outlier ? N : 0), oPoses = P.add_in(poses, sizeof poses), oLv = P.add_in(lv.data(), lv.size() * sizeof(SiaLevel));
     const size_t rOut = P.add_out(out, sizeof out);
     uint8_t *dIn;
-    if ((rc = ensure(c, S[6], N * (16 + 96) * sizeof(float) + N + 64)) || (rc = P.upload(&dIn))) return rc;
+    const size_t nLv = (size_t) (max_level - min_level + 1);
+    const bool perLevel = c->siaPerLevel;
+    if ((rc = ensure(c, S[6], perLevel ? nLv * N * (52 * sizeof(float) + 1) + N + 64 : N * (16 + 96) * sizeof(float) + N + 64)) || (rc = P.upload(&dIn))) return rc;
     const SiaLevel *dLv = (const SiaLevel *) (dIn + oLv);
     SiaArgs A;
     memset(&A, 0, sizeof A);
@@ -1968,6 +1976,15 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
     A.jacCache = nullptr;
     A.visible = (uint8_t *) (A.patchCache + N * 48);
     A.momCache = A.patchCache + N * 64;   // (the buffer holds 112 floats per feature)
+    if (perLevel) {   // [patch rows: nLv x N x 48 floats | moments: nLv x N x 4 floats | flags: nLv x N bytes | visible: N bytes]
+        A.perLevel = 1;
+        A.pcLevelStride = N * 48;
+        A.momLevelStride = N * 4;
+        A.flagLevelStride = N;
+        A.momCache = A.patchCache + nLv * N * 48;
+        A.levelFlags = (uint8_t *) (A.momCache + nLv * N * 4);
+        A.visible = A.levelFlags + nLv * N;
+    }
     A.out = (float *) P.d_out(rOut);
     {
         if (c->siaDebug) {
@@ -1986,6 +2003,7 @@ static int sia_run_impl(ygzf_ctx *c, const ygzf_sia_frame *ref, const ygzf_sia_f
         }
         HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
+        if (A.perLevel) launch_sia_precompute(c->stream, A, 1, (int) N);
         launch_sia(c->stream, A, 1, sl);
     }
     HIPCHECK(c, hipGetLastError());
@@ -3389,7 +3407,8 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
     ygzf_ctx::Buf *S = c->dAl;   // 0 level tables, 1 poses, 2 caches, 3 out, (world = dWorld)
     if ((rc = ensure(c, c->dWorld, (size_t) (B + 1) * G.kpStride * 3 * sizeof(float))) ||
         (rc = ensure(c, S[0], (size_t) B * 2 * kMaxLevels * sizeof(SiaLevel))) || (rc = ensure(c, S[1], (size_t) B * 14 * sizeof(float))) ||
-        (rc = ensure(c, S[2], (size_t) B * G.kpStride * ((16 + 96) * sizeof(float) + 1) + 64)) ||
+        (rc = ensure(c, S[2], c->siaPerLevel && B <= kSiaPerLevelPairs ? (size_t) (max_level - min_level + 1) * B * G.kpStride * (52 * sizeof(float) + 1) + (size_t) B * G.kpStride + 64
+                                              : (size_t) B * G.kpStride * ((16 + 96) * sizeof(float) + 1) + 64)) ||
         (rc = ensure(c, S[3], (size_t) B * 48 * sizeof(float))) || (rc = ensure(c, c->dCarryPyr, (size_t) G.pyrBytes + 256)))
         return rc;
     // level tables + identity poses: uploaded when anything they depend on changed
@@ -3442,6 +3461,16 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
     A.jacCache = nullptr;
     A.visible = (uint8_t *) (A.patchCache + (size_t) B * G.kpStride * 48);
     A.momCache = A.patchCache + (size_t) B * G.kpStride * 64;   // (the buffer holds 112 floats per keypoint slot)
+    if (c->siaPerLevel && B <= kSiaPerLevelPairs) {   // [patch rows: nLv x B x kpStride x 48 floats | moments: nLv x B x kpStride x 4 | flags: nLv x B x kpStride bytes | visible]
+        const size_t nLv = (size_t) (max_level - min_level + 1), slots = (size_t) B * G.kpStride;
+        A.perLevel = 1;
+        A.pcLevelStride = slots * 48;
+        A.momLevelStride = slots * 4;
+        A.flagLevelStride = slots;
+        A.momCache = A.patchCache + nLv * slots * 48;
+        A.levelFlags = (uint8_t *) (A.momCache + nLv * slots * 4);
+        A.visible = A.levelFlags + nLv * slots;
+    }
     A.out = (float *) S[3].p;
     const int first = c->carryPyrValid ? 0 : 1;   // without a carried pyramid frame 0 has no reference image
     if (!c->carryPyrValid) HIPCHECK(c, hipMemsetAsync(S[3].p, 0, 48 * sizeof(float), c->stream));
@@ -3456,6 +3485,7 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
         A2.patchCache += (size_t) first * G.kpStride * 48;
         A2.visible += (size_t) first * G.kpStride;
         A2.momCache += (size_t) first * G.kpStride * 4;
+        if (A2.perLevel) A2.levelFlags += (size_t) first * G.kpStride;
         A2.out += (size_t) first * 48;
         size_t sl = sia_lds_bytes(G.kpStride);
         A2.ldsFeat = G.kpStride;
@@ -3477,6 +3507,7 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
         }
         HIPCHECK(c, sia_prepare(sl));
         ProfScope ps(c, KK_SIA);
+        if (A2.perLevel) launch_sia_precompute(c->stream, A2, B - first, G.kpStride);
         launch_sia(c->stream, A2, B - first, sl);
     }
     HIPCHECK(c, hipGetLastError());
