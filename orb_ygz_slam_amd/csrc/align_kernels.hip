@@ -413,7 +413,11 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
             const ygzf_kp kp = keys[i];
             s_uv[i] = excluded ? make_float2(-100.f, -100.f) : make_float2(kp.x, kp.y);   // fails every level's border test
             float xyz[3];
-            se3_act(Tref, world + 3 * (size_t) i, xyz);
+            if (A.unitWorld) {   // the world point is the keypoint's back-projection to depth 1 (k_backproject_unit's expressions, a launch of its own until round 4)
+                const float Xu[3] = {(kp.x - A.cx) / A.fx, (kp.y - A.cy) / A.fy, 1.f};
+                se3_act(Tref, Xu, xyz);
+            } else
+                se3_act(Tref, world + 3 * (size_t) i, xyz);
             s_feat[i] = make_float4(xyz[0], xyz[1], xyz[2], 0.f);
             if (A.jacLds) jac_terms(xyz, s_jac[2 * i], s_jac[2 * i + 1]);
         }

@@ -300,6 +300,7 @@ struct SiaArgs {
     // perLevel: the reference patches of all levels come from k_sia_precompute (launch_sia_precompute) instead of k_sia_run's own per-level
     // phase: patchCache / momCache hold one block per level (level l at + (l - minLevel) * pcLevelStride / momLevelStride floats, pairs inside
     // a block as before), levelFlags one byte per (level, pair, keypoint): visible at this level or a coarser one
+    int unitWorld;                  // the world point of keypoint i is ((x - cx) / fx, (y - cy) / fy, 1), not world[3 i ..]
     int perLevel;
     size_t pcLevelStride, momLevelStride, flagLevelStride;
     uint8_t *levelFlags;

@@ -3439,14 +3439,11 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
     }
     const ygzf_kp *kp = (const ygzf_kp *) c->dOutKp.p;
     const int *cnt = (const int *) c->dOutCnt.p;
-    {
-        ProfScope ps(c, KK_BACKPROJ);
-        launch_backproject_unit(c->stream, kp, cnt, G.kpStride, G.kpStride, B, cam->fx, cam->fy, cam->cx, cam->cy, (float *) c->dWorld.p);
-    }
     SiaArgs A;
     memset(&A, 0, sizeof A);
     A.keys = kp;                 // pair p: reference = output slot p (slot 0 = carry), current = slot p + 1
     A.world = (const float *) c->dWorld.p;
+    A.unitWorld = 1;             // MapPoints at unit depth along the keypoints' rays, computed where they are used
     A.kpStride = G.kpStride;
     A.nRef = cnt;
     A.poses = (const float *) S[1].p;
