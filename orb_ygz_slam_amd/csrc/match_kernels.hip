@@ -445,8 +445,8 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     const int nLocal = (nq - part + S - 1) / S;
     int LPQ = S > 1 ? 8 : 1, qr = S > 1 ? (tid & 7) : 0;
     int jFirst = S > 1 ? (tid >> 3) : tid, jStep = S > 1 ? (kMatchBlock >> 3) : kMatchBlock, jEnd = nLocal;
-    if (S > 1 && nLocal <= kMatchBlock && !A.fixedLanes) {
-        // Lanes by expected work.  A query's window grows with the square of its level's scale factor (radius = th * scale), and the queries
+    if (nLocal <= kMatchBlock && !A.fixedLanes) {
+        // Lanes by expected work (one workgroup per pair, the form of large batches, included: 256 pairs 161 -> 149 us).  A query's window grows with the square of its level's scale factor (radius = th * scale), and the queries
         // arrive sorted by level, so with eight lanes for everybody the wave that holds the coarsest level's queries ran ten times longer than
         // the first while the others idled.  Each of the nUse waves that take part gets a contiguous run of queries of equal total weight
         // scale^2 and spreads its 64 lanes over them (2 lanes per level-0 query, 32 per level-7 query when a workgroup holds a hundred of them).

@@ -301,17 +301,18 @@ def test_search_for_triangulation_rejects_bad_input():
             ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **dict(kw, off1=off))
 
 
-@pytest.mark.parametrize("plan", ["1", "2"])
+@pytest.mark.parametrize("plan", ["YGZF_MATCH_SERIAL=1", "YGZF_MATCH_SERIAL=2", "YGZF_MATCH_SPLIT=1", "YGZF_MATCH_LANES=fixed"])
 def test_in_order_plans_agree(plan):
     """The matcher resolves the reference's in-order semantics as a block-wide fixpoint (match_kernels.hip); the one-wave in-order pass it
     replaced stays as the fall-back (list extensions used up, no convergence).  YGZF_MATCH_SERIAL=1 runs that pass alone, =2 the fixpoint
-    with no extension slots, i.e. with the hand-over at the first exhausted list: the matcher tests and two dense fuzz seeds must hold
-    against the oracle under both."""
+    with no extension slots, i.e. with the hand-over at the first exhausted list; YGZF_MATCH_SPLIT=1 keeps a pair on ONE workgroup (the form
+    of 256-pair launches, which the single pairs of the tests otherwise never take), YGZF_MATCH_LANES=fixed gives every query eight lanes.
+    The matcher tests and the projected-search fuzzers must hold against the oracle under each."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, YGZF_MATCH_SERIAL=plan)
+    env = dict(os.environ, **dict([plan.split("=")]))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_match.py"),
                           os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
                           "(search_by_projection or search_by_bow or search_for_initialization or test_fuzz_projected_searches or test_fuzz_search_by_projection_last) and not in_order_plans"],
