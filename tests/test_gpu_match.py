@@ -278,6 +278,29 @@ def test_search_for_triangulation(oracle):
     assert n == 0 and len(m) == 0
 
 
+def test_search_for_triangulation_against_reference_golden():
+    """The device against tests/golden/triangulation_ref.npz: the surviving pairs the reference's own src/ORBmatcher.cc produced for these cases
+    (tools/make_golden_triangulation.py); culled slots read -1 there (the reference returns pairs only)."""
+    import hashlib
+    import os
+    from orb_ygz_slam_amd import Extractor
+    from tests.tri_cases import cases
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "triangulation_ref.npz"))
+    w, h = 752, 480
+    base = synth_frame(50, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[10:10 + h, 5:5 + w]
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=1)
+    ka, da = ex.extract(a)
+    kb, db = ex.extract(b)
+    hsh = hashlib.sha256()
+    for arr in (ka, da, kb, db):
+        hsh.update(np.ascontiguousarray(arr).tobytes())
+    assert hsh.hexdigest() == str(g["inputs_sha256"]), "device keypoints / descriptors differ from the golden cases' inputs"
+    for label, kw in cases(ka, da, kb, db):
+        n, m = ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **kw)
+        assert n == int(g["n_" + label]) and (np.where(m == -2, -1, m) == g["m_" + label]).all(), label
+
+
 def test_search_for_triangulation_rejects_bad_input():
     from orb_ygz_slam_amd import Extractor
     from orb_ygz_slam_amd.capi import YgzfError

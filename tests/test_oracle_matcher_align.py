@@ -126,3 +126,33 @@ def test_device_order_mode_is_the_same_algorithm(oracle):
     assert np.abs(r[1] - d[1]).max() < 2e-6 and not np.array_equal(r[1], d[1])
     assert np.array_equal(d[1], d2[1]) and np.array_equal(d[3], d2[3])
     assert np.allclose(np.asarray(r[3]), np.asarray(d[3]), rtol=1e-4)
+
+
+def test_search_for_triangulation_against_reference_golden():
+    """tests/golden/triangulation_ref.npz holds what the REFERENCE'S OWN src/ORBmatcher.cc returned for the cases of tests/tri_cases.py
+    (tools/make_golden_triangulation.py, run where the reference checkout is): the oracle must reproduce it anywhere -- the file travels, the
+    checkout does not."""
+    import hashlib
+    import os
+    from oracle import oracle_py as O
+    from orb_ygz_slam_amd.scene import synth_frame
+    from tests.tri_cases import cases
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "triangulation_ref.npz"))
+    w, h = 752, 480
+    base = synth_frame(50, w + 16, h + 16)
+    a, b = base[8:8 + h, 8:8 + w], base[10:10 + h, 5:5 + w]
+    oex = O.Extractor(1000, 1.2, 8, 20, 7)
+    ka, da = oex.extract(a)
+    kb, db = oex.extract(b)
+    hsh = hashlib.sha256()
+    for arr in (ka, da, kb, db):
+        hsh.update(np.ascontiguousarray(arr).tobytes())
+    assert hsh.hexdigest() == str(g["inputs_sha256"]), "the inputs of the golden cases drifted (extractor output changed?)"
+    sf = oex.tables()["scale"]
+    labels = [str(x) for x in g["labels"]]
+    got = cases(ka, da, kb, db)
+    assert [l for l, _ in got] == labels
+    for label, kw in got:
+        n, m = O.search_for_triangulation(scale_factors2=sf, level_sigma2_2=(sf * sf).astype(np.float32), **kw)
+        assert n == int(g["n_" + label]) and (np.where(m == -2, -1, m) == g["m_" + label]).all(), label
+
