@@ -250,3 +250,79 @@ def test_bilinear_weights_fp32():
         got = [(one - su) * (one - sv), su * (one - sv), (one - su) * sv]
         for r, g in zip(ref, got):
             assert g.dtype == np.float32 and np.array_equal(r, g)
+
+
+def _sequential_matcher(lists, blocking, two, accept):
+    """The reference's loop over the queries, in order (SearchByProjection(Cur, Last) / (F, MapPoints), src/ORBmatcher.cc:43-126, 1218-1350) on
+    abstract inputs: lists[q] = the candidate keypoints of query q in (distance, visiting order) order; a keypoint taken by an EARLIER blocking
+    query (a MapPoint with observations) is skipped; `two`: best and runner-up feed an accept rule, else the first free candidate is taken."""
+    taken, pick = set(), []
+    for q, cand in enumerate(lists):
+        free = [c for c in cand if c not in taken]
+        p = -1
+        if two:
+            if free and accept(q, free[0], free[1] if len(free) > 1 else -1):
+                p = free[0]
+        elif free:
+            p = free[0]
+        pick.append(p)
+        if p >= 0 and blocking[q]:
+            taken.add(p)
+    return pick
+
+
+def _fixpoint_matcher(lists, blocking, two, accept, depth, max_rounds=1000):
+    """k_match_last's block-wide form: every query holds a pick; claim[e] = lowest blocking query that picks e; everybody re-picks among the entries
+    of his list with claim[e] >= q; lists are known `depth` entries at a time and extended by eight when they run out (scan_after)."""
+    n = len(lists)
+    known = [min(depth, len(c)) for c in lists]
+    pick = [-1] * n
+    rounds = 0
+    while True:
+        rounds += 1
+        assert rounds <= max_rounds
+        claim = {}
+        for q in range(n):
+            if pick[q] >= 0 and blocking[q]:
+                claim[pick[q]] = min(claim.get(pick[q], n), q)
+        changed, extend = False, []
+        for q in range(n):
+            free = [c for c in lists[q][:known[q]] if claim.get(c, n) >= q]
+            need = 2 if two else 1
+            if len(free) < need and known[q] < len(lists[q]):
+                new = -2                       # list exhausted before the picks are complete: wait for the extension, take nothing
+                extend.append(q)
+            elif two:
+                new = free[0] if free and accept(q, free[0], free[1] if len(free) > 1 else -1) else -1
+            else:
+                new = free[0] if free else -1
+            if new != pick[q]:
+                pick[q] = new
+                changed = True
+        for q in extend:
+            known[q] = min(known[q] + 8, len(lists[q]))
+        if not changed and not extend:
+            return pick, rounds
+
+
+def test_matcher_fixpoint_equals_the_sequential_loop():
+    """The block-wide fixpoint of k_match_last (match_kernels.hip) against the sequential loop it replaces, on random instances: dense conflicts
+    (many queries, few keypoints), MapPoints without observations (non-blocking takers), lists that run out and are extended, both modes."""
+    rng = np.random.default_rng(2024)
+    worst = 0
+    for trial in range(300):
+        n = int(rng.integers(1, 120))
+        m = int(rng.integers(1, 60 if trial % 3 else 400))
+        lists = []
+        for _ in range(n):
+            k = int(rng.integers(0, min(m, 30) + 1))
+            lists.append([int(x) for x in rng.choice(m, size=k, replace=False)])
+        blocking = [bool(b) for b in rng.uniform(size=n) < rng.choice([0.5, 0.9, 1.0])]
+        table = rng.uniform(size=(n, m + 1)) < 0.8      # an arbitrary accept rule of (query, best, runner-up)
+        accept = lambda q, b1, b2: bool(table[q, b1] ^ (b2 >= 0 and table[q, b2] and (b1 + b2) % 3 == 0))
+        for two, depth in ((False, 4), (True, 8)):
+            want = _sequential_matcher(lists, blocking, two, accept)
+            got, rounds = _fixpoint_matcher(lists, blocking, two, accept, depth)
+            assert [p if p >= 0 else -1 for p in got] == want, (trial, two)
+            worst = max(worst, rounds)
+    assert worst <= 121         # never more rounds than queries + 1 (each round settles at least the next query)
