@@ -13,7 +13,7 @@ from oracle import oracle_py as O  # noqa: E402
 from tests import align_ref_cases as A  # noqa: E402
 
 
-def main():
+def main(path=None):
     if O.ref_matcher_lib() is None:
         sys.exit("oracle/_ref/libref_orbmatcher.so is missing: build it from the reference checkout first (make -C oracle ref_matcher)")
     out = {}
@@ -25,7 +25,7 @@ def main():
                                                   mp_valid=valid, outlier=outl)
         out["ret%d" % j], out["T%d" % j], out["info%d" % j], out["H%d" % j] = np.int64(ret), np.asarray(T, np.float32), np.asarray(info, np.float32), np.asarray(Hm, np.float32)
         print("scene", j, "ret", ret, "T", np.asarray(T), "info", np.asarray(info))
-    path = os.path.join(ROOT, "tests", "golden", "align_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "align_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
 

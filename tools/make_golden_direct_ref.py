@@ -14,7 +14,7 @@ from tests import direct_ref_cases as D  # noqa: E402
 from tests.test_ref_matcher import _ref_find_direct_projection_batch  # noqa: E402
 
 
-def main():
+def main(path=None):
     if O.ref_matcher_lib() is None:
         sys.exit("oracle/_ref/libref_orbmatcher.so is missing: build it from the reference checkout first (make -C oracle ref_matcher)")
     out = {}
@@ -24,7 +24,7 @@ def main():
         px, sl, ok, pt = _ref_find_direct_projection_batch(oex, [A], B, cur7, D.CAM, slot, ref7, ka, world, px0)
         out["px%d" % j], out["level%d" % j], out["ok%d" % j], out["patch%d" % j] = px.astype(np.float32), sl.astype(np.int32), ok.astype(np.uint8), pt.astype(np.uint8)
         print("scene", j, len(ka), "candidates,", int(ok.sum()), "aligned")
-    path = os.path.join(ROOT, "tests", "golden", "direct_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "direct_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
 

@@ -14,7 +14,7 @@ from oracle import oracle_py as O  # noqa: E402
 from tests import extract_ref_cases as C  # noqa: E402
 
 
-def main():
+def main(path=None):
     if O.ref_extractor_lib() is None:
         sys.exit("oracle/_ref/libref_orbextractor.so is missing: build it from the reference checkout first (make -C oracle ref)")
     names, counts, digs = [], [], []
@@ -22,7 +22,7 @@ def main():
         k, d = O.ref_extract(img, nf, sf, nl, ini, mn)
         names.append(name); counts.append(len(k)); digs.append(C.digest(k, d))
         print(name, len(k))
-    path = os.path.join(ROOT, "tests", "golden", "extract_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "extract_ref.npz")
     np.savez_compressed(path, names=np.array(names), counts=np.array(counts, np.int32), digests=np.array(digs))
     print("wrote", path)
 

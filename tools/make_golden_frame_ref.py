@@ -13,7 +13,7 @@ from oracle import oracle_py as O  # noqa: E402
 from tests import frame_ref_cases as C  # noqa: E402
 
 
-def main():
+def main(path=None):
     if O.ref_frame_lib() is None or O.ref_mappoint_lib() is None:
         sys.exit("oracle/_ref/libref_frame.so / libref_mappoint.so missing: build them from the reference checkout first (make -C oracle)")
     k, d, sf = C.frame(O.Extractor(1000, 1.2, 8, 20, 7))
@@ -34,7 +34,7 @@ def main():
     with O.reference_mappoint():
         best = O.distinctive_descriptors(off, desc)
     out["distinctive_desc"] = np.stack([desc[off[p] + best[p]] for p in range(len(off) - 1)])     # the reference keeps the winning DESCRIPTOR
-    path = os.path.join(ROOT, "tests", "golden", "frame_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "frame_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "windows", len(cnt), "indices", int(out["fia_cnt"].sum()), "in view", int(out["frustum0.5_iv"].sum()), int(out["frustum0.9_iv"].sum()))
 

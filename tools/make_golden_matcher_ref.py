@@ -15,7 +15,7 @@ from oracle import oracle_py as O  # noqa: E402
 from tests import matcher_ref_cases as C  # noqa: E402
 
 
-def main():
+def main(path=None):
     if O.ref_matcher_lib() is None:
         sys.exit("oracle/_ref/libref_orbmatcher.so is missing: build it from the reference checkout first (make -C oracle ref_matcher)")
     ka, da, kb, db, sf = C.inputs(O.Extractor(1000, 1.2, 8, 20, 7))
@@ -32,7 +32,7 @@ def main():
         names.append(name)
         print(name, int(res[0]))
     out["names"] = np.array(names)
-    path = os.path.join(ROOT, "tests", "golden", "matcher_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "matcher_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
 

@@ -16,7 +16,7 @@ from orb_ygz_slam_amd.scene import stereo_scene  # noqa: E402
 from tests import stereo_bow_ref_cases as S  # noqa: E402
 
 
-def main():
+def main(path=None):
     L = O.ref_frame_lib()
     if L is None or O.ref_dbow2_lib() is None:
         sys.exit("oracle/_ref/libref_frame.so / libref_dbow2.so missing: build them from the reference checkout first (make -C oracle)")
@@ -40,12 +40,12 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for j, (k, Lv, levelsup, seed) in enumerate(S.BOW):
             voc = O.make_vocabulary(seed, k, Lv)
-            path = os.path.join(tmp, "voc%d.txt" % j)
-            O.write_vocabulary_text(voc, path)
-            ids, vals, fv = O.RefVocabulary(path).transform(S.bow_descs(voc, 700, seed + 100), levelsup)
+            vpath = os.path.join(tmp, "voc%d.txt" % j)
+            O.write_vocabulary_text(voc, vpath)
+            ids, vals, fv = O.RefVocabulary(vpath).transform(S.bow_descs(voc, 700, seed + 100), levelsup)
             out["bow%d_ids" % j], out["bow%d_vals" % j], out["bow%d_fv" % j] = np.asarray(ids), np.asarray(vals, np.float64), S.fv_flat(fv)
             print("bow", j, len(ids), "words")
-    path = os.path.join(ROOT, "tests", "golden", "stereo_bow_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "stereo_bow_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
 

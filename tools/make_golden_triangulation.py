@@ -32,7 +32,7 @@ def digest(*arrays):
     return h.hexdigest()
 
 
-def main():
+def main(path=None):
     if O.ref_matcher_lib() is None:
         sys.exit("oracle/_ref/libref_orbmatcher.so is missing: build it from the reference checkout first (make -C oracle ref_matcher)")
     a, b = frames()
@@ -48,7 +48,7 @@ def main():
         out["n_" + label] = np.int32(n)
         out["m_" + label] = m.astype(np.int32)
     out["labels"] = np.array(out["labels"])
-    path = os.path.join(ROOT, "tests", "golden", "triangulation_ref.npz")
+    path = path or os.path.join(ROOT, "tests", "golden", "triangulation_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {l: int(out["n_" + l]) for l in out["labels"]})
 
