@@ -166,6 +166,16 @@ def effective_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(frames, cfg, seconds_budget=12.0):
     """The CPU oracle ('port' of the reference path) on this host's cores: every worker thread runs extract + projection match over its own
     run of consecutive frames of the same clip for a bounded time (about `seconds_budget` s)."""
@@ -177,7 +187,7 @@ def cpu_baseline(frames, cfg, seconds_budget=12.0):
     sec, nk, nm, n = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=cores, frames_per_thread=100000,
                                            max_seconds=seconds_budget)
     n = max(n, 1)
-    return {"value": round(n / sec, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": round(n / sec, 2), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d threads, each on its own run of consecutive frames of the bench clip, time-bounded: %d frames in %.1f s; "
                       "1 thread: %.2f frames/s" % (cores, n, sec, fps1),
             "keypoints_per_frame": round(nk / n, 1), "matches_per_frame": round(nm / n, 1)}
@@ -308,7 +318,7 @@ def run_timed(pipes, steps, warmup, barrier, sync_all):
     return el
 
 
-def end_to_end(pipe, min_seconds=1.2, depth=2):
+def end_to_end(pipe, min_seconds=1.2, depth=2, host_pitch=None):
     """SURVEY 8(d) 'end-to-end': page-locked host frames in (H2D), kernels, every keypoint + descriptor + count out (D2H) -- `depth` contexts
     software-pipelined: while one sub-batch is in its kernels the next ones' frames go up and the previous one's results come down (the
     upload alone is 1.7 ms per 256 frames, the kernels 1.3 ms; measured: depth 2 134 k, depth 3 133 k, depth 4 113 k frames/s -- the link
@@ -322,15 +332,18 @@ def end_to_end(pipe, min_seconds=1.2, depth=2):
     while len(exs) < depth:
         exs.append(Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=pipe.device))
     stride = exs[0].max_keypoints(w, h)
+    from orb_ygz_slam_amd.capi import host_row_pitch
+    hp = host_row_pitch(w) if host_pitch is None else host_pitch      # frames laid out at the device's row pitch go up as whole frames, not row by row
     pins, outs, keep = [], [], []
     for i in range(depth):
         src = np.take(pipe.frames, (np.arange(B) + i * B) % len(pipe.frames), axis=0)      # (the clip may hold fewer distinct frames than a sub-batch)
-        pf = torch.from_numpy(np.ascontiguousarray(src)).pin_memory()
+        pf = torch.zeros((B, h, hp), dtype=torch.uint8).pin_memory()
+        pf.numpy()[:, :, :w] = src
         ok = torch.empty((B, stride, KP_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
         od = torch.empty((B, stride, 32), dtype=torch.uint8).pin_memory()
         on = torch.empty(B, dtype=torch.int32).pin_memory()
         keep += [pf, ok, od, on]
-        pins.append(pf.numpy())
+        pins.append(pf.numpy()[:, :, :w])
         outs.append((ok.numpy().view(KP_DTYPE).reshape(B, stride), od.numpy(), on.numpy()))
 
     def submit(i):
@@ -356,15 +369,17 @@ def end_to_end(pipe, min_seconds=1.2, depth=2):
     for e in exs[len(pipe.exs[:depth]):]:
         e.close()
     # what crosses the link per frame: the level-0 pixels up; keypoint + descriptor rows of `stride` entries and the count down
-    return B * batches, sec, {"up": w * h, "down": stride * (KP_DTYPE.itemsize + 32) + 4}
+    return B * batches, sec, {"up": w * h, "down": stride * (KP_DTYPE.itemsize + 32) + 4, "host_row_pitch": hp}
 
 
 def pcie_roofline(link, fps_per_gpu):
     """The bound of the end-to-end rate: bytes that cross the PCIe link per frame (both directions run concurrently; the upstream direction
     carries the pixels and is the one that saturates) x frames/s against one direction's peak."""
+    link = dict(link)
+    hp = link.pop("host_row_pitch", None)
     up, down = link["up"] * fps_per_gpu / 1e9, link["down"] * fps_per_gpu / 1e9
     return {"bound": "pcie", "achieved": round(max(up, down), 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": round(max(up, down) / PCIE_PEAK_GBS, 4),
-            "up_GBs": round(up, 2), "down_GBs": round(down, 2), "bytes_per_frame": link}
+            "up_GBs": round(up, 2), "down_GBs": round(down, 2), "bytes_per_frame": link, "host_row_pitch": hp}
 
 
 def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
@@ -382,8 +397,10 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
     mg = MultiGpu(slots, nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=per)
     cam = make_camera(w, h)
     res = {}
-    keep = torch.from_numpy(clip).pin_memory()
-    for name, src in (("pageable", clip), ("page_locked", keep.numpy())):
+    from orb_ygz_slam_amd.capi import host_row_pitch
+    keep = torch.zeros((n, h, host_row_pitch(w)), dtype=torch.uint8).pin_memory()      # page-locked frames at the device's row pitch: whole-frame uploads
+    keep.numpy()[:, :, :w] = clip
+    for name, src in (("pageable", clip), ("page_locked", keep.numpy()[:, :, :w])):
         out = mg.extract_match(src, unit=2, cam=cam)
         t0 = time.perf_counter()
         calls = 0
@@ -400,6 +417,23 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
                     "inside a call every slot sends its frames through in chunks that alternate between two contexts: the upload of one chunk runs beside "
                     "the kernels of the other; page-locked frames are copied from where they lie, pageable ones are gathered into page-locked staging by four "
                     "host threads per slot)"}
+
+
+def one_unit_kernels(device, wl, unit, stereo):
+    """Kernel breakdown (HIP events, us per launch) of one resident step over ONE frame / ONE stereo pair of the workload."""
+    p = Pipeline(device, wl, unit, 1, 1, 7100, False, stereo, distinct=unit)
+    for _ in range(3):
+        p.step()
+    p.sync()
+    p.profile(True)
+    for _ in range(10):
+        p.step()
+    p.sync()
+    k = {name: v["avg_us"] for name, v in kernel_table(p.profile_read()).items()}
+    p.profile(False)
+    for e in p.exs:
+        e.close()
+    return k
 
 
 def mgpu_literal_configs(devices):
@@ -435,7 +469,27 @@ def mgpu_literal_configs(devices):
         kp = int(np.asarray(o[2]).mean())
         matched = int((np.asarray(o[3]) >= 0).sum(axis=1).mean()) if stereo else None
         mg.close()
-        out[key] = {"frames_per_call": nfr, "device_slots": slots, "unit_frames": 2 if stereo else 1, "ms_per_call": round(1e3 * med, 3),
+        # what ONE GPU of the node does in such a call: one FHD frame / one UHD stereo pair, alone on its device (one slot)
+        unit = 2 if stereo else 1
+        mg1 = MultiGpu([devices[0]], nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=2)
+        src1 = src[:unit]
+        run1 = (lambda o=None: mg1.extract_stereo(src1, 0.11, 47.9, out=o)) if stereo else (lambda o=None: mg1.extract_match(src1, unit=1, out=o))
+        o1 = run1()
+        lat1 = []
+        t0 = time.perf_counter()
+        while len(lat1) < 9 or time.perf_counter() - t0 < 0.4:
+            t1 = time.perf_counter()
+            run1(o1)
+            lat1.append(time.perf_counter() - t1)
+        lat1.sort()
+        med1 = lat1[len(lat1) // 2]
+        mg1.close()
+        one = {"frames_per_call": unit, "ms_per_call": round(1e3 * med1, 3), "min_ms": round(1e3 * lat1[0], 3), "calls": len(lat1),
+               "predicted_8gpu_frames_per_s": round(8 * unit / med1, 1),
+               "kernels_us": one_unit_kernels(devices[0], wl, unit, stereo),
+               "what": "ONE %s per call on ONE device slot, page-locked host frames in, results out: the per-GPU work of this configuration; "
+                       "predicted_8gpu = 8 x frames / this latency (eight GPUs, eight links, one unit each)" % ("(left, right) pair" if stereo else "frame")}
+        out[key] = {"frames_per_call": nfr, "device_slots": slots, "unit_frames": 2 if stereo else 1, "ms_per_call": round(1e3 * med, 3), "one_unit": one,
                     "value": round(nfr / med, 1), "unit": "frames/s", "calls": len(lat), "keypoints_per_frame": kp,
                     "stereo_matches_per_pair": matched,
                     "what": ("ygzf_mgpu_extract_stereo" if stereo else "ygzf_mgpu_extract_match (extraction only)") +
@@ -547,6 +601,14 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: every rank of a multi-process run uses device 0 and the ranks rendezvous over gloo -- the N > 1 control flow (barriers, "
                          "max-over-ranks, per-rank extras) on a box with one GPU; never a valid measurement (the line says so)")
+    ap.add_argument("--backend", default="auto", choices=("auto", "nccl", "gloo"),
+                    help="what carries the timing barrier and the max-over-ranks reduction of an N > 1 run (there is no collective on the data path): "
+                         "nccl = RCCL, gloo = TCP on the host, auto (default) = RCCL when its communicator comes up on every rank, gloo otherwise")
+    ap.add_argument("--fill-cus", type=int, default=None,
+                    help="ygzf_set_stream_partition: k_octree / k_match_last on a second stream restricted to this many compute units (-1 unrestricted, 0 off; "
+                         "default: the library's own choice)")
+    ap.add_argument("--main-complement", action="store_true", help="with --fill-cus: the contexts' own streams get the remaining compute units only")
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the rank's host thread to the NUMA node of its GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -555,6 +617,9 @@ def main():
                     help="CPU-only check of the multi-process plumbing (gloo): no GPU work, output is NOT a measurement")
     args = ap.parse_args()
 
+    if args.fill_cus is not None:                  # read by every context the process creates (ygzf_create)
+        os.environ["YGZF_FILL_CUS"] = str(args.fill_cus)
+        os.environ["YGZF_MAIN_MODE"] = "1" if args.main_complement else "0"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -582,18 +647,42 @@ def main():
     share = bool(args.share_gpu)
     if share:
         local_rank = 0
-    nccl = use_gpu and not share
+    nccl = use_gpu and not share and args.backend != "gloo"
     if use_gpu and torch.cuda.is_available():
         torch.cuda.set_device(local_rank * ndev)   # before the process group: RCCL binds its communicator to the current device
+    group = None
+    backend_note = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if nccl else "gloo")
+        # The control plane (rendezvous, agreement on what carries the barrier) is gloo: it needs nothing from the GPUs.  The timing barrier and the
+        # max-over-ranks reduction go over RCCL when its communicator comes up on EVERY rank; a rank where it does not reports that over gloo and all
+        # ranks fall back together (--backend auto), so a hiccup of RCCL costs the run its transport, not its result.
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+        if nccl:
+            ok = 1
+            try:
+                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                t = torch.ones(1, device="cuda:%d" % (local_rank * ndev))
+                dist.all_reduce(t, group=group)
+                torch.cuda.synchronize(local_rank * ndev)
+                ok = int(float(t[0]) == world)
+            except Exception as e:                   # noqa: BLE001 -- whatever RCCL raised, the answer is the same
+                ok = 0
+                backend_note = "RCCL unavailable on rank %d: %s" % (rank, str(e).splitlines()[0][:200])
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0:
+                if args.backend == "nccl":
+                    raise SystemExit("--backend nccl: the RCCL communicator did not come up on every rank (%s)" % backend_note)
+                nccl, group = False, None
+                backend_note = backend_note or "RCCL unavailable on another rank"
 
     def barrier():
         if dist is not None:
             if nccl:
-                dist.barrier(device_ids=[local_rank * ndev])
+                dist.barrier(group=group, device_ids=[local_rank * ndev])
             else:
                 dist.barrier()
 
@@ -601,7 +690,7 @@ def main():
         if dist is None:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=("cuda:%d" % (local_rank * ndev)) if nccl else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
         return float(t[0])
 
     if args.plumbing_selftest:
@@ -653,6 +742,14 @@ def main():
         cpu_base = cpu_baseline(frames0, cfg, args.cpu_seconds)
         cpu_ref = cpu_baseline_reference(frames0, cfg, min(6.0, args.cpu_seconds))
         anchor = libfast_anchor(frames0)
+
+    # the rank's host thread onto the CPUs of its GPU's NUMA node BEFORE anything is page-locked: the frames of value_end_to_end are then first
+    # touched on the socket the GPU's link ends on (a two-socket 8-GPU node would otherwise stage half of its ranks across the socket link).
+    # After the CPU baselines, which use every core the launcher allowed.
+    numa_cpus = 0
+    if not args.no_numa_bind and ndev == 1:
+        from orb_ygz_slam_amd.capi import bind_host_thread_to_device
+        numa_cpus = max(0, bind_host_thread_to_device(devices[0]))
 
     pipes = [Pipeline(d, args.workload, sub, rounds, S, 1000 + 97 * (rank * ndev + i), args.align, args.stereo, frames=frames0 if i == 0 else None, passes=passes,
                       distinct=args.distinct if args.distinct > 0 else None)
@@ -771,7 +868,9 @@ def main():
                        "resident_clip_frames": S * sub * rounds, "streams": S, "distinct_frames": min(B, S * sub),
                        "align": bool(args.align), "stereo": bool(args.stereo),
                        "match": "SearchByProjection(cur,last) th=15, identity pose", "fast_plan": fast_plan, "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
-                       "sharding": "one clip per GPU, no collective", "valid_measurement": not share},
+                       "sharding": "one clip per GPU, no collective", "valid_measurement": not share,
+                       "barrier_backend": ("rccl" if nccl else "gloo") if world > 1 else None, "barrier_backend_note": backend_note,
+                       "numa_bound_cpus": numa_cpus, "stream_partition": {"fill_cus": os.environ.get("YGZF_FILL_CUS"), "main_mode": os.environ.get("YGZF_MAIN_MODE")}},
             "timed_region_s": round(elapsed, 4),
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "roofline_pcie": e2e["roofline_pcie"] if e2e else None,
             "mgpu_end_to_end": mgpu, "mgpu_literal_configs": mgpu_lit,

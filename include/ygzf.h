@@ -102,6 +102,14 @@ int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
  *                                      REGISTER_STAGING for wider cells) */
 enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_REGISTER_STAGING = 1, YGZF_FAST_KERNEL_CELL_TABLE = 2 };
 int ygzf_set_fast_kernel(ygzf_ctx *ctx, int kernel);
+/* Scheduling knob of the batch chain (no counterpart in the reference, whose ORBextractor::operator() src/ORBextractor.cc:962-1028 and
+ * ORBmatcher::SearchByProjection src/ORBmatcher.cc:1218-1350 run on one CPU thread): DistributeOctTree (k_octree, :533-723) and the matcher
+ * (k_match_last) are latency-bound -- long-lived workgroups that issue little -- while the cell loop (:747-781), the descriptors and the pyramid
+ * are issue-bound.  fill_cus > 0 runs the two latency-bound kernels on a second stream of the context that is restricted to fill_cus compute
+ * units (spread evenly over the XCDs), ordered against the context's own stream by events; fill_cus = -1 the same without a restriction; 0
+ * (default) everything on one stream.  main_mode 1 restricts the context's own stream to the remaining compute units.  Results are identical
+ * under every setting.  Drains the context; any stream handle the caller derived earlier is invalid afterwards. */
+int ygzf_set_stream_partition(ygzf_ctx *ctx, int fill_cus, int main_mode);
 /* Extract-ahead (default off).  When on, ygzf_compute_pyramid queues the ORBSLAM_KEYPOINT extraction of the same image (FAST, octree,
  * orientation, descriptors) right behind its pyramid kernels and reads the levels back on a second stream, so that the extraction runs while the
  * levels cross the link and while the caller works on them -- ygz::Frame's constructor clones them (src/Frame.cc:807-813) before
@@ -118,6 +126,10 @@ int ygzf_get_scale_tables(const ygzf_ctx *ctx, float *scale, float *inv_scale, f
 int ygzf_get_features_per_level(const ygzf_ctx *ctx, int *nfeat);
 /* Size of pyramid level `level` for a w x h input (src/ORBextractor.cc:1131-1132). */
 int ygzf_level_size(const ygzf_ctx *ctx, int w, int h, int level, int *lw, int *lh);
+/* Row pitch of level 0 on the device for images w pixels wide (w rounded up to 64).  Host frames laid out at this pitch (cv::Mat rows of a
+ * wider allocation, or ygzf_alloc_host memory) are uploaded by ygzf_extract_batch_host / ygzf_mgpu_* as whole frames instead of row by row --
+ * where the image enters the reference: src/Frame.cc:807-813 (ComputePyramid + ExtractORB on the caller's cv::Mat).  Any other pitch works too. */
+int ygzf_host_row_pitch(int w);
 /* Upper bound on keypoints returned per frame for a w x h input (sum over levels of N_l + 3, or 4*nIni). */
 int ygzf_max_keypoints(const ygzf_ctx *ctx, int w, int h);
 
@@ -492,6 +504,12 @@ int ygzf_mgpu_extract_stereo(ygzf_mgpu *m, const uint8_t *frames, int n_frames, 
 /* Page-locked, device-visible host memory for frames (what ygzf_mgpu_* and ygzf_extract_batch_host* copy from at the link's full rate, without a
  * staging copy) for callers that do not link the HIP runtime themselves: hipHostMalloc / hipHostFree on the given device.  NULL on failure. */
 void *ygzf_alloc_host(int device, size_t bytes);
+/* Binds the CALLING thread to the CPUs of the NUMA node the device hangs on (/sys/bus/pci/devices/<bus id>/numa_node), intersected with the
+ * affinity it already has -- what a one-process-per-GPU caller (bench.py --gpus N: BASELINE.json configs[3], configs[4]) does once per rank
+ * BEFORE it page-locks its frame buffers, so that they are first touched on the socket the GPU's link ends on (ygzf_mgpu_* does the same for its
+ * own slot threads and never touches the caller's).  Returns the number of CPUs bound to, 0 when there is no NUMA information or nothing to do,
+ * YGZF_ERR_NO_DEVICE for a device that does not exist. */
+int ygzf_bind_host_thread_to_device(int device);
 void ygzf_free_host(void *p);
 int ygzf_mgpu_chunk_frames(const ygzf_mgpu *m);   /* frames per chunk inside a slot (units up to this size alternate between the slot's two contexts) */
 

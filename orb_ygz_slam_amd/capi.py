@@ -135,6 +135,7 @@ def load_library(build_if_missing=True):
     L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
     L.ygzf_set_fast_kernel.argtypes = [vp, C.c_int]
+    L.ygzf_set_stream_partition.argtypes = [vp, C.c_int, C.c_int]
     L.ygzf_set_extract_ahead.argtypes = [vp, C.c_int]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
@@ -171,6 +172,16 @@ def load_library(build_if_missing=True):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def bind_host_thread_to_device(device):
+    """ygzf_bind_host_thread_to_device: the calling thread onto the CPUs of the device's NUMA node; number of CPUs bound to (0: nothing done)."""
+    return load_library().ygzf_bind_host_thread_to_device(int(device))
+
+
+def host_row_pitch(w):
+    """ygzf_host_row_pitch: the row pitch at which host frames take the whole-frame upload."""
+    return load_library().ygzf_host_row_pitch(int(w))
 
 
 def pyramid_plan_host(nfeatures, scale_factor, nlevels, w, h):
@@ -266,9 +277,13 @@ class Extractor:
         return k[:n.value].copy(), d[:n.value].copy()
 
     def extract_batch_host(self, imgs):
-        imgs = np.ascontiguousarray(imgs, np.uint8)
+        """(n, h, w) uint8 frames; a view with padded rows / frames (unit stride along x) is handed over as it lies -- e.g. a [:, :, :w] view of
+        frames allocated at ygzf_host_row_pitch(w), which take the long-row upload."""
+        if not (imgs.dtype == np.uint8 and imgs.ndim == 3 and imgs.strides[2] == 1 and imgs.strides[1] >= imgs.shape[2] and
+                (imgs.shape[0] == 1 or imgs.strides[0] >= imgs.strides[1] * imgs.shape[1])):
+            imgs = np.ascontiguousarray(imgs, np.uint8)
         n, h, w = imgs.shape
-        self._ck(self.L.ygzf_extract_batch_host(self.h, _p(imgs), n, w, h, w, w * h))
+        self._ck(self.L.ygzf_extract_batch_host(self.h, C.c_void_p(imgs.ctypes.data), n, w, h, imgs.strides[1], imgs.strides[0]))
         self._inflight.append(imgs)   # the H2D copy is asynchronous: the frames must stay alive until the next synchronising call
         self._wh = (w, h, n)
 
@@ -584,6 +599,11 @@ class Extractor:
         """0 auto (default), 1 register staging (k_fast_quads), 2 cell table + LDS-DMA staging (k_fast_tab) -- same results (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_fast_kernel(self.h, int(kernel)))
 
+    def set_stream_partition(self, fill_cus, main_mode=0):
+        """k_octree / k_match_last on a second stream restricted to fill_cus compute units (-1 unrestricted, 0 off); main_mode 1 restricts the
+        context's own stream to the rest (include/ygzf.h)."""
+        self._ck(self.L.ygzf_set_stream_partition(self.h, int(fill_cus), int(main_mode)))
+
     def set_extract_ahead(self, on):
         """compute_pyramid also queues the extraction of the same image; extract_resident then only collects it (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_extract_ahead(self.h, 1 if on else 0))
@@ -845,6 +865,16 @@ class Extractor:
         return {names[i].decode(): (ms[i], n[i]) for i in range(k)}
 
 
+def _frames_view(frames):
+    """(n, h, w) uint8 frames as they lie when rows / frames are merely padded (unit stride along x), a contiguous copy otherwise;
+    -> (array, row_pitch, frame_stride)"""
+    f = frames
+    if not (isinstance(f, np.ndarray) and f.dtype == np.uint8 and f.ndim == 3 and f.strides[2] == 1 and f.strides[1] >= f.shape[2] and
+            (f.shape[0] == 1 or f.strides[0] >= f.strides[1] * f.shape[1])):
+        f = np.ascontiguousarray(f, np.uint8)
+    return f, f.strides[1], f.strides[0]
+
+
 class MultiGpu:
     """ygzf_mgpu_*: frames (or units of consecutive frames) dealt round-robin over device slots, one host thread + context per slot, results
     in input order (include/ygzf.h).  `devices` may repeat a device index (several slots on one GPU)."""
@@ -880,13 +910,13 @@ class MultiGpu:
 
     def extract_match(self, frames, unit=1, cam=None, th=15.0, mono=True, check_level=True, check_ori=True, out=None):
         """-> (kps [n, stride], desc [n, stride, 32], n_kp [n], match [n, stride] or None, nmatches [n] or None); matching when cam is given"""
-        frames = np.ascontiguousarray(frames, np.uint8)
+        frames, rp, fst = _frames_view(frames)
         n, h, w = frames.shape
         if out is None:
             out = (np.zeros((n, self.stride), KP_DTYPE), np.zeros((n, self.stride, 32), np.uint8), np.zeros(n, np.int32),
                    np.full((n, self.stride), -1, np.int32) if cam is not None else None, np.zeros(n, np.int32) if cam is not None else None)
         k, d, c, m, nm = out
-        rc = self.L.ygzf_mgpu_extract_match(self.h, _p(frames), n, w, h, w, w * h, unit, C.byref(cam) if cam is not None else None, th, int(mono),
+        rc = self.L.ygzf_mgpu_extract_match(self.h, C.c_void_p(frames.ctypes.data), n, w, h, rp, fst, unit, C.byref(cam) if cam is not None else None, th, int(mono),
                                             int(check_level), int(check_ori), _p(k), _p(d), _p(c), self.stride, _p(m) if m is not None else None,
                                             _p(nm) if nm is not None else None)
         if rc != 0:
@@ -898,7 +928,7 @@ class MultiGpu:
 
     def extract_stereo(self, frames, mb, mbf, out=None):
         """frames = (left, right) pairs -> (kps [n, stride], desc [n, stride, 32], n_kp [n], u_right [n/2, stride], depth [n/2, stride])"""
-        frames = np.ascontiguousarray(frames, np.uint8)
+        frames, rp, fst = _frames_view(frames)
         n, h, w = frames.shape
         if out is None:
             out = (np.zeros((n, self.stride), KP_DTYPE), np.zeros((n, self.stride, 32), np.uint8), np.zeros(n, np.int32),
@@ -906,7 +936,7 @@ class MultiGpu:
         k, d, c, ur, dp = out
         self.L.ygzf_mgpu_extract_stereo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_float, C.c_float,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
-        rc = self.L.ygzf_mgpu_extract_stereo(self.h, _p(frames), n, w, h, w, w * h, mb, mbf, _p(k), _p(d), _p(c), self.stride, _p(ur), _p(dp))
+        rc = self.L.ygzf_mgpu_extract_stereo(self.h, C.c_void_p(frames.ctypes.data), n, w, h, rp, fst, mb, mbf, _p(k), _p(d), _p(c), self.stride, _p(ur), _p(dp))
         if rc != 0:
             raise YgzfError("ygzf_mgpu_extract_stereo failed (%d): %s" % (rc, self.L.ygzf_mgpu_last_error(self.h).decode()))
         return k, d, c, ur, dp

@@ -172,6 +172,12 @@ struct ygzf_ctx {
     bool extractAhead = false, aheadPending = false;
     hipStream_t streamCopy = nullptr;
     hipEvent_t evPyramid = nullptr;
+    // ygzf_set_stream_partition: the latency-bound kernels of the chain (k_octree, k_match_last) on a second stream restricted to a share of the
+    // compute units, so that their long-lived, rarely-issuing workgroups do not take wave slots from the issue-bound kernels of other contexts
+    hipStream_t streamFill = nullptr;
+    int fillCUs = 0, mainMode = 0;
+    hipEvent_t evHop[8] = {nullptr};
+    unsigned hopSeq = 0;
     bool profile = false;
     // debugging aids, read once per context (never on the launch path): synchronise after every kernel and name it on stderr /
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
@@ -662,25 +668,42 @@ struct ProfScope {
     ygzf_ctx *c;
     int kind;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(ygzf_ctx *c_, int k) : c(c_), kind(k) {
+    hipStream_t s;
+    ProfScope(ygzf_ctx *c_, int k, hipStream_t s_ = nullptr) : c(c_), kind(k), s(s_ ? s_ : c_->stream) {
         if (c->profile) {
             a = take_event(c);
             b = take_event(c);
-            (void) hipEventRecord(a, c->stream);
+            (void) hipEventRecord(a, s);
         }
     }
     ~ProfScope() {
         if (c->debugSync) {
             fprintf(stderr, "[ygzf] %s ...", kKernelNames[kind]);
-            const hipError_t e = hipStreamSynchronize(c->stream);
+            const hipError_t e = hipStreamSynchronize(s);
             fprintf(stderr, " %s\n", hipGetErrorString(e));
         }
         if (c->profile) {
-            (void) hipEventRecord(b, c->stream);
+            (void) hipEventRecord(b, s);
             c->recs.push_back({kind, a, b});
         }
     }
 };
+// The filler stream (ygzf_set_stream_partition): fill_begin makes it wait for everything queued on the context's stream so far and returns it
+// (the context's own stream when there is no partition); fill_end makes the context's stream wait for what was queued on it.  Every hop is
+// closed before an entry point returns, so that synchronising c->stream still drains the whole context.
+static hipStream_t fill_begin(ygzf_ctx *c) {
+    if (!c->streamFill) return c->stream;
+    hipEvent_t e = c->evHop[c->hopSeq++ & 7];
+    (void) hipEventRecord(e, c->stream);
+    (void) hipStreamWaitEvent(c->streamFill, e, 0);
+    return c->streamFill;
+}
+static void fill_end(ygzf_ctx *c) {
+    if (!c->streamFill) return;
+    hipEvent_t e = c->evHop[c->hopSeq++ & 7];
+    (void) hipEventRecord(e, c->streamFill);
+    (void) hipStreamWaitEvent(c->stream, e, 0);
+}
 static void drain_profile(ygzf_ctx *c) {
     if (c->recs.empty()) return;
     (void) hipStreamSynchronize(c->stream);
@@ -833,17 +856,19 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
             HIPCHECK(c, hipMemsetAsync(odbg, 0, kOctDbgWords * sizeof(long long), c->stream));
         }
         {
-            ProfScope ps(c, KK_OCTREE);
+            hipStream_t so = fill_begin(c);
+            {
+            ProfScope ps(c, KK_OCTREE, so);
             const bool small = c->haveOctSmall && nFrames * L <= c->octSmallWgs;
             if (small) {
                 const auto &grp = c->octSmall;
-                launch_octree(c->stream, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                launch_octree(so, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                               (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                               (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
                               (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins);
             } else if (c->octGroups.empty())
-                launch_octree(c->stream, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                launch_octree(so, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                               (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                               (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
@@ -851,11 +876,13 @@ static int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyrami
                               c->octGlobalNodes ? (int *) c->dOctNodes.p : nullptr, 0, 0);
             else
                 for (const auto &grp : c->octGroups)
-                    launch_octree(c->stream, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
+                    launch_octree(so, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                                   G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                                   (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                                   (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
                                   (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins);
+            }
+            fill_end(c);
         }
         if (odbg) {
             long long st[kOctDbgWords];
@@ -956,7 +983,23 @@ static int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, i
             return YGZF_OK;
         }
     }
-    if (nFrames == 1 || frame_stride == (size_t) row_pitch * h) {   // frames back to back: one copy of nFrames * h rows
+    // Host frames that already carry the device's row pitch (ygzf_host_row_pitch): the copy engine pays per ROW of a pitched copy (752-byte rows:
+    // 48 GB/s where 1920-byte rows reach 55), so the rows handed to it are runs of k image rows -- (k - 1) x pitch + w bytes, k = the whole
+    // frame by default -- and the padding bytes between image rows travel with them.
+    static const int upK = getenv("YGZF_UPLOAD_K") ? atoi(getenv("YGZF_UPLOAD_K")) : 0;   // 0: whole frames; 1: image rows (as before); k: runs of k rows (k divides h) -- A/B runs
+    if (row_pitch == pitch && pitch != w && upK != 1 && (frame_stride == 0 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
+        (frame_stride & 3) == 0) {
+        const size_t fsd = (size_t) pitch * h, fss = nFrames == 1 ? fsd : frame_stride;
+        const int k = (upK > 1 && h % upK == 0) ? upK : h;
+        if (k == h) {
+            HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, fsd, imgs, fss, (size_t) (h - 1) * pitch + w, (size_t) nFrames, hipMemcpyHostToDevice, c->stream));
+        } else if (fss == fsd) {
+            HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, (size_t) k * pitch, imgs, (size_t) k * pitch, (size_t) (k - 1) * pitch + w, (size_t) nFrames * (h / k), hipMemcpyHostToDevice, c->stream));
+        } else {
+            for (int f = 0; f < nFrames; f++)
+                HIPCHECK(c, hipMemcpy2DAsync((uint8_t *) c->dImg0.p + f * fsd, (size_t) k * pitch, imgs + f * fss, (size_t) k * pitch, (size_t) (k - 1) * pitch + w, (size_t) (h / k), hipMemcpyHostToDevice, c->stream));
+        }
+    } else if (nFrames == 1 || frame_stride == (size_t) row_pitch * h) {   // frames back to back: one copy of nFrames * h rows
         if ((rc = upload_rows(c, c->dImg0.p, (size_t) pitch, imgs, (size_t) row_pitch, w, (size_t) nFrames * h))) return rc;
     } else {
         for (int f = 0; f < nFrames; f++) {
@@ -1021,6 +1064,10 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     // validate the largest configuration up front (and size the buffers once)
     int rc = apply_geometry(c, max_width, max_height, max_batch);
     if (rc) return bail(rc);
+    if (const char *e = getenv("YGZF_FILL_CUS")) {   // A/B runs: the stream partition of every context of the process (ygzf_set_stream_partition)
+        const int mm = getenv("YGZF_MAIN_MODE") ? atoi(getenv("YGZF_MAIN_MODE")) : 0;
+        if ((atoi(e) != 0 || mm != 0) && (rc = ygzf_set_stream_partition(c, atoi(e), mm))) return bail(rc);
+    }
     *out = c;
     return YGZF_OK;
 }
@@ -1075,6 +1122,9 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->evPyrDone) (void) hipEventDestroy(c->evPyrDone);
     if (c->evPyramid) (void) hipEventDestroy(c->evPyramid);
     if (c->streamCopy) (void) hipStreamDestroy(c->streamCopy);
+    if (c->streamFill) (void) hipStreamDestroy(c->streamFill);
+    for (auto e : c->evHop)
+        if (e) (void) hipEventDestroy(e);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
     if (c->tStop) (void) hipEventDestroy(c->tStop);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -1117,6 +1167,43 @@ int ygzf_set_extract_ahead(ygzf_ctx *c, int on) {
     }
     c->extractAhead = on != 0;
     if (!on) c->aheadPending = false;
+    return YGZF_OK;
+}
+
+int ygzf_set_stream_partition(ygzf_ctx *c, int fill_cus, int main_mode) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (main_mode < 0 || main_mode > 1) return fail(c, YGZF_ERR_INVALID, "main_mode %d (0 all compute units, 1 the complement of the filler's share)", main_mode);
+    HIPCHECK(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIPCHECK(c, hipGetDeviceProperties(&prop, c->device));
+    const int nCU = prop.multiProcessorCount;
+    if (fill_cus < -1 || fill_cus >= nCU) return fail(c, YGZF_ERR_INVALID, "fill_cus %d (-1 unmasked second stream, 0 off, 1..%d compute units)", fill_cus, nCU - 1);
+    if (main_mode == 1 && fill_cus <= 0) return fail(c, YGZF_ERR_INVALID, "main_mode 1 needs a filler share");
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    if (c->streamFill) {
+        HIPCHECK(c, hipStreamSynchronize(c->streamFill));
+        HIPCHECK(c, hipStreamDestroy(c->streamFill));
+        c->streamFill = nullptr;
+    }
+    // mask bit i is compute unit i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs and, inside one, over its shader
+    // engines): the first n bits are n / 8 compute units of every XCD
+    const int words = (nCU + 31) / 32;
+    std::vector<uint32_t> fill((size_t) words, 0u), rest((size_t) words, 0u);
+    for (int i = 0; i < nCU; i++) (i < fill_cus ? fill : rest)[(size_t) i / 32] |= 1u << (i % 32);
+    if (c->mainMode != main_mode || (main_mode == 1 && c->fillCUs != fill_cus)) {   // the context's own stream changes its share
+        hipStream_t ns = nullptr;
+        if (main_mode == 1) HIPCHECK(c, hipExtStreamCreateWithCUMask(&ns, (uint32_t) words, rest.data()));
+        else HIPCHECK(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        HIPCHECK(c, hipStreamDestroy(c->stream));
+        c->stream = ns;
+    }
+    if (fill_cus > 0) HIPCHECK(c, hipExtStreamCreateWithCUMask(&c->streamFill, (uint32_t) words, fill.data()));
+    else if (fill_cus < 0) HIPCHECK(c, hipStreamCreateWithFlags(&c->streamFill, hipStreamNonBlocking));
+    if (c->streamFill)
+        for (auto &e : c->evHop)
+            if (!e) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->fillCUs = fill_cus;
+    c->mainMode = main_mode;
     return YGZF_OK;
 }
 
@@ -1188,6 +1275,8 @@ int ygzf_level_size(const ygzf_ctx *c, int w, int h, int level, int *lw, int *lh
     c->tab.levelSize(w, h, level, lw, lh);
     return YGZF_OK;
 }
+
+int ygzf_host_row_pitch(int w) { return w > 0 ? align_up(w, 64) : YGZF_ERR_INVALID; }
 
 int ygzf_max_keypoints(const ygzf_ctx *c_, int w, int h) {
     ygzf_ctx *c = const_cast<ygzf_ctx *>(c_);
@@ -1330,13 +1419,20 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
         for (int f = 1; f < n_frames; f++)
             if (frames[f] != frames[f - 1] + tight) { u = f; break; }
         const int runs = n_frames / u;
-        bool regular = row_pitch == w && n_frames % u == 0;
+        bool regular = n_frames % u == 0;
         ptrdiff_t S = 0;
         if (regular && runs > 1) {
             S = frames[u] - frames[0];
             regular = S > 0 && (size_t) S >= (size_t) u * tight;
             for (int f = 0; f < n_frames && regular; f++) regular = frames[f] == frames[0] + (ptrdiff_t) (f / u) * S + (ptrdiff_t) (f % u) * (ptrdiff_t) tight;
         }
+        if (regular && row_pitch == pitch && pitch != w && (w & 3) == 0 && ((uintptr_t) frames[0] & 3) == 0 && (S & 3) == 0) {
+            // frames that carry the device's pitch (ygzf_host_row_pitch): the runs go straight to their place, no staging and no re-pitch launch
+            const size_t width = (size_t) u * tight - (size_t) (pitch - w);
+            HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, (size_t) u * tight, frames[0], runs > 1 ? (size_t) S : (size_t) u * tight, width, (size_t) runs, hipMemcpyHostToDevice, c->stream));
+            goto uploaded;
+        }
+        regular = regular && row_pitch == w;
         const size_t slot = regular ? tight : ((frameBytes + 255) & ~(size_t) 255);
         if ((rc = ensure(c, c->dUpStage, slot * n_frames + 64))) return rc;
         if (regular) {
@@ -1376,6 +1472,7 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
     if (!gathered)
         for (int f = 0; f < n_frames; f++)
             if ((rc = upload_rows(c, (uint8_t *) c->dImg0.p + (size_t) f * pitch * h, (size_t) pitch, frames[f], (size_t) row_pitch, w, (size_t) h))) return rc;
+uploaded:
     FrameSet fs;
     fs.img0 = (const uint8_t *) c->dImg0.p;
     fs.img0_stride = (long long) pitch * h;
@@ -1733,8 +1830,12 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
     size_t lds;
     if ((rc = plan_match_lds(c, A, B, &lds))) return rc;
     {
-        ProfScope ps(c, KK_MATCH);
-        launch_match_last(c->stream, A, B, lds);
+        hipStream_t sm = fill_begin(c);
+        {
+            ProfScope ps(c, KK_MATCH, sm);
+            launch_match_last(sm, A, B, lds);
+        }
+        fill_end(c);
     }
     HIPCHECK(c, hipGetLastError());
     if (A.dbg) {

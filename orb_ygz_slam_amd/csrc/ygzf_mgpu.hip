@@ -116,7 +116,7 @@ int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg
         const size_t F = (size_t) m->chunk;
         if (hipSetDevice(devices[i]) != hipSuccess) { ygzf_mgpu_destroy(m); return YGZF_ERR_HIP; }
         for (int b = 0; b < 2; b++) {
-            if (hipHostMalloc((void **) &d.hIn[b], F * px) != hipSuccess || hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
+            if (hipHostMalloc((void **) &d.hIn[b], F * (size_t) ygzf_host_row_pitch(max_width) * max_height) != hipSuccess || hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
                 hipHostMalloc((void **) &d.hDesc[b], F * m->stride * 32) != hipSuccess || hipHostMalloc((void **) &d.hCnt[b], F * sizeof(int)) != hipSuccess ||
                 hipHostMalloc((void **) &d.hAux[b], F * m->stride * sizeof(int)) != hipSuccess) {
                 (void) hipGetLastError();
@@ -158,6 +158,20 @@ void ygzf_free_host(void *p) {
     if (p) (void) hipHostFree(p);
 }
 
+int ygzf_bind_host_thread_to_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { (void) hipGetLastError(); return YGZF_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) return YGZF_ERR_NO_DEVICE;
+    cpu_set_t want, have, both;
+    if (!numa_cpus_of_device(device, &want)) return 0;            // no NUMA information (one-socket box, container without sysfs): nothing to do
+    if (sched_getaffinity(0, sizeof have, &have) != 0) return 0;
+    CPU_AND(&both, &want, &have);                                 // never widen what the launcher (taskset, cgroup cpuset) allowed
+    const int n = CPU_COUNT(&both);
+    if (n == 0) return 0;
+    if (sched_setaffinity(0, sizeof both, &both) != 0) return 0;
+    return n;
+}
+
 const char *ygzf_mgpu_last_error(const ygzf_mgpu *m) { return m ? m->err.c_str() : "null handle"; }
 int ygzf_mgpu_device_count(const ygzf_mgpu *m) { return m ? (int) m->devs.size() : 0; }
 int ygzf_mgpu_keypoint_stride(const ygzf_mgpu *m) { return m ? m->stride : 0; }
@@ -194,6 +208,9 @@ int run_job(ygzf_mgpu *m, const Job &J) {
     // ONE context, whose carried "previous frame" links frame k * chunk to frame k * chunk - 1, one chunk after the other.
     const bool alternate = unit <= m->chunk;
     const int chunk = alternate ? (m->chunk / unit) * unit : m->chunk;
+    // a (left, right) pair never straddles two chunks: ygzf_stereo_batch pairs frames 2p / 2p + 1 of ONE launch, and the aux staging rows are per pair
+    if (J.mode == kStereo && (!alternate || (chunk & 1)))
+        return mfail(m, YGZF_ERR_INVALID, "stereo pairs need chunks of at least 2 frames (chunk %d: max_frames_per_device / YGZF_MGPU_CHUNK)", m->chunk);
     // frames in page-locked host memory go to the device from where they lie
     bool pinned = false;
     {
@@ -226,14 +243,15 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         std::vector<const uint8_t *> ptrs((size_t) chunk);
         std::vector<int> nm(n, 0);
         auto cx = [&](int k) { return d.ctx[alternate ? (k & 1) : 0]; };
-        auto prepare = [&](int k) {      // pageable frames: gather chunk k into its page-locked staging area, tight rows
+        const int sp = ygzf_host_row_pitch(w);   // the staging area carries the device's row pitch: a chunk goes up as whole frames, not row by row
+        auto prepare = [&](int k) {      // pageable frames: gather chunk k into its page-locked staging area
             if (pinned) return;
             const int b = k & 1;
             parallel(cnt(k), [&](int j) {
                 const uint8_t *src = J.frames + (size_t) fr[lo(k) + j] * J.frame_stride;
-                uint8_t *dst = d.hIn[b] + (size_t) j * h * w;
-                if (J.row_pitch == w) memcpy(dst, src, (size_t) w * h);
-                else for (int y = 0; y < h; y++) memcpy(dst + (size_t) y * w, src + (size_t) y * J.row_pitch, (size_t) w);
+                uint8_t *dst = d.hIn[b] + (size_t) j * h * sp;
+                if (J.row_pitch == sp) memcpy(dst, src, (size_t) sp * (h - 1) + w);
+                else for (int y = 0; y < h; y++) memcpy(dst + (size_t) y * sp, src + (size_t) y * J.row_pitch, (size_t) w);
             });
         };
         auto launch = [&](int k) {       // queue chunk k on its context: upload, extraction, matching / stereo (returns without waiting)
@@ -243,7 +261,7 @@ int run_job(ygzf_mgpu *m, const Job &J) {
                 for (int j = 0; j < cnt(k); j++) ptrs[j] = J.frames + (size_t) fr[lo(k) + j] * J.frame_stride;
                 rc = ygzf_extract_batch_host_frames(cx(k), ptrs.data(), cnt(k), w, h, J.row_pitch);
             } else
-                rc = ygzf_extract_batch_host(cx(k), d.hIn[b], cnt(k), w, h, w, (size_t) w * h);
+                rc = ygzf_extract_batch_host(cx(k), d.hIn[b], cnt(k), w, h, sp, (size_t) sp * h);
             if (rc == YGZF_OK && J.mode == kMatch) rc = ygzf_match_batch_prev(cx(k), J.cam, J.th, J.b_mono, J.check_level, J.check_orientation);
             if (rc == YGZF_OK && J.mode == kStereo) rc = ygzf_stereo_batch(cx(k), J.mb, J.mbf);
             if (rc != YGZF_OK) d.err = ygzf_last_error(cx(k));

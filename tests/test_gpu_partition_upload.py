@@ -1,0 +1,142 @@
+"""Round-5 scheduling / transfer knobs change nothing but time:
+  * ygzf_set_stream_partition (k_octree / k_match_last on a CU-masked second stream): keypoints, descriptors and matches of a batch are the bytes of
+    the unpartitioned run for every setting, also when three contexts run at once;
+  * host frames laid out at ygzf_host_row_pitch (whole-frame uploads, YGZF_UPLOAD_K runs) give the bytes of tight frames, through
+    ygzf_extract_batch_host, ygzf_extract_batch_host_frames and ygzf_mgpu_* (page-locked and pageable)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from orb_ygz_slam_amd.synth import synth_frame
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(n, w, h, seed=900):
+    frames = np.empty((n, h, w), np.uint8)
+    for i in range(n):
+        if i % 4 == 0:
+            scene = synth_frame(seed + i // 4, w + 16, h + 16)
+        frames[i] = scene[2 * (i % 4):2 * (i % 4) + h, 3 * (i % 4):3 * (i % 4) + w]
+    return frames
+
+
+def _run(ex, frames, cam):
+    ex.extract_batch_host(frames)
+    ex.match_batch_prev(cam, 15.0, True, True, True)
+    n = len(frames)
+    out = []
+    for f in range(n):
+        k, d = ex.batch_fetch(f)
+        m, o = ex.match_fetch(f)
+        out.append((k.copy(), d.copy(), m.copy(), o.copy()))
+    return out, ex.match_counts().copy()
+
+
+def _same(a, b):
+    # (frame 0 is matched against whatever the context's previous batch left behind: its keypoints / descriptors are compared, its matches are not)
+    (ra, ca), (rb, cb) = a, b
+    assert (np.asarray(ca)[1:] == np.asarray(cb)[1:]).all()
+    for f, (x, y) in enumerate(zip(ra, rb)):
+        for u, v in list(zip(x, y))[:2 if f == 0 else 4]:
+            assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("w,h", [(752, 480), (640, 480)])
+def test_stream_partition_changes_nothing(w, h):
+    from orb_ygz_slam_amd import Extractor, make_camera
+    n = 12
+    frames = _clip(n, w, h)
+    cam = make_camera(w, h)
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=n, device=0)
+    ref = _run(ex, frames, cam)
+    assert (ref[1][1:] > 50).any()
+    for fill, mm in ((-1, 0), (32, 0), (64, 1), (128, 1), (8, 0), (0, 0)):
+        ex.set_stream_partition(fill, mm)
+        for _ in range(2):
+            _same(ref, _run(ex, frames, cam))
+    with pytest.raises(Exception):
+        ex.set_stream_partition(100000, 0)
+    with pytest.raises(Exception):
+        ex.set_stream_partition(0, 1)
+    ex.close()
+
+
+def test_partitioned_contexts_side_by_side():
+    """three contexts with filler streams on the same 64 compute units, launched back to back without waiting: each returns its own clip's bytes"""
+    from orb_ygz_slam_amd import Extractor, make_camera
+    w, h, n = 752, 480, 16
+    cam = make_camera(w, h)
+    clips = [_clip(n, w, h, seed=1200 + 10 * i) for i in range(3)]
+    exs = [Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=n, device=0) for _ in range(3)]
+    refs = [_run(e, c, cam) for e, c in zip(exs, clips)]
+    for e in exs:
+        e.set_stream_partition(64, 0)
+    for rep in range(5):
+        for e, c in zip(exs, clips):
+            e.extract_batch_host(c)
+            e.match_batch_prev(cam, 15.0, True, True, True)
+        for e, r in zip(exs, refs):
+            got = [(e.batch_fetch(f) + e.match_fetch(f)) for f in range(n)]
+            _same(r, (got, e.match_counts()))
+    for e in exs:
+        e.close()
+
+
+@pytest.mark.parametrize("w,h,k", [(752, 480, "0"), (752, 480, "8"), (752, 480, "1"), (500, 376, "0")])
+def test_pitched_host_frames(w, h, k):
+    """the library reads YGZF_UPLOAD_K once per process: every setting in a process of its own"""
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r)
+from orb_ygz_slam_amd import Extractor, MultiGpu, make_camera
+from orb_ygz_slam_amd.capi import host_row_pitch
+from tests.test_gpu_partition_upload import _clip, _run, _same
+w, h, n = %d, %d, 10
+frames = _clip(n, w, h)
+cam = make_camera(w, h)
+P = host_row_pitch(w)
+assert P %% 64 == 0 and P >= w
+ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=n, device=0)
+ref = _run(ex, frames, cam)
+wide = np.full((n, h + 3, P), 0xAB, np.uint8)            # rows at the device pitch, frames three rows apart: padding full of garbage
+wide[:, :h, :w] = frames
+_same(ref, _run(ex, wide[:, :h, :w], cam))
+back = np.full((n, h, P), 0xCD, np.uint8)                # frames back to back at the pitch
+back[:, :, :w] = frames
+_same(ref, _run(ex, back[:, :, :w], cam))
+ex.extract_batch_host(back[:1, :, :w]); k1, d1 = ex.batch_fetch(0)
+assert np.array_equal(k1, ref[0][0][0]) and np.array_equal(d1, ref[0][0][1])
+# frame-pointer lists: pitched frames, runs of 2 at a distance (a slot's round-robin share)
+views = [back[f, :, :w] for f in range(n)]
+ex.extract_batch_host_frames(views); ex.match_batch_prev(cam, 15.0, True, True, True)
+got = [(ex.batch_fetch(f) + ex.match_fetch(f)) for f in range(n)]
+_same(ref, (got, ex.match_counts()))
+share = [back[f, :, :w] for f in range(n) if (f // 2) %% 2 == 0]
+ex.extract_batch_host_frames(share)
+for j, f in enumerate([f for f in range(n) if (f // 2) %% 2 == 0]):
+    kk, dd = ex.batch_fetch(j)
+    assert np.array_equal(kk, ref[0][f][0]) and np.array_equal(dd, ref[0][f][1])
+ex.close()
+# the multi-GPU entry point: pageable tight / pageable pitched / page-locked pitched
+import torch
+one = MultiGpu([0], max_width=w, max_height=h, max_frames_per_device=n)
+r0 = one.extract_match(frames, unit=2, cam=cam)
+one.close()
+pin = torch.zeros((n, h, P), dtype=torch.uint8).pin_memory(); pin.numpy()[:, :, :w] = frames
+for slots in ([0, 0], [0, 0, 0]):
+    mg = MultiGpu(slots, max_width=w, max_height=h, max_frames_per_device=n)
+    for src in (frames, back[:, :, :w], pin.numpy()[:, :, :w]):
+        g = mg.extract_match(src, unit=2, cam=cam)
+        for a, b in zip(r0, g):
+            assert np.array_equal(a, b)
+    mg.close()
+print("OK")
+""" % (ROOT, w, h)
+    env = dict(os.environ, YGZF_UPLOAD_K=k)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
