@@ -39,6 +39,36 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def check_handover_isa(verbose=False):
+    """The matcher's fence-free hand-over between the workgroups of a pair (csrc/match_kernels.hip: st_dev / ld_dev) is correct because of what
+    these builtins compile to on gfx950, so the build looks: the device assembly of that file must show k_handover_probe as exactly one
+    `global_load_dword ... sc1` and one `global_store_dword ... sc1`, and k_match_last must carry the scoped accesses of its hand-over (22 stores of
+    records / query parameters, at least as many loads) plus the fenced alternative.  Raises RuntimeError otherwise -- the library is not built."""
+    import re
+    src = "csrc/match_kernels.hip"
+    cmd = [hipcc()] + [f for f in FLAGS if not f.startswith("-W")] + FILE_FLAGS.get(src, []) + ["-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src, "-o", "-"]
+    if verbose:
+        print(" ".join(cmd))
+    asm = subprocess.run(cmd, cwd=HERE, check=True, capture_output=True, text=True).stdout
+    bodies = {m.group(1): m.group(2) for m in re.finditer(r"^(_ZN4ygzf\w+):[^\n]*\n(.*?)^\s*s_endpgm", asm, re.S | re.M)}
+
+    def count(body, op):
+        return len(re.findall(r"global_%s_dword\w* [^\n]*\bsc1\b" % op, body))
+    probe = next((b for n, b in bodies.items() if "k_handover_probe" in n), None)
+    match = next((b for n, b in bodies.items() if "k_match_last" in n), None)
+    if probe is None or match is None:
+        raise RuntimeError("check_handover_isa: k_handover_probe / k_match_last not found in the assembly of %s" % src)
+    got = {"probe_loads_sc1": count(probe, "load"), "probe_stores_sc1": count(probe, "store"),
+           "probe_plain": len(re.findall(r"global_(load|store)_dword\w* ", probe)) - count(probe, "load") - count(probe, "store"),
+           "match_stores_sc1": count(match, "store"), "match_loads_sc1": count(match, "load"), "match_wbl2": match.count("buffer_wbl2"), "match_inv": match.count("buffer_inv")}
+    ok = (got["probe_loads_sc1"] == 1 and got["probe_stores_sc1"] == 1 and got["probe_plain"] == 0 and got["match_stores_sc1"] >= 22 and
+          got["match_loads_sc1"] >= 22 and got["match_wbl2"] >= 1 and got["match_inv"] >= 1)
+    if not ok:
+        raise RuntimeError("check_handover_isa: the compiler no longer lowers the matcher's device-scope accesses to sc1 loads / stores (%r): "
+                           "build with YGZF_MATCH_FENCE=1 semantics (match_kernels.hip: kHandoverScopedAccess = false) instead" % (got,))
+    return got
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return lib_path()
@@ -62,8 +92,10 @@ def build(force=False, verbose=False):
                     print(" ".join(cmd))
                 subprocess.check_call(cmd, cwd=HERE)
                 return obj
-            with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            with ThreadPoolExecutor(max_workers=min(len(srcs) + 1, os.cpu_count() or 1)) as pool:
+                isa = pool.submit(check_handover_isa, verbose)
                 objs = list(pool.map(compile_one, srcs))
+                isa.result()                                             # raises: no library from a build whose hand-over is unproven
             cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))

@@ -108,8 +108,26 @@ __device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
 // Device-scope accesses for what one workgroup of a pair hands to another (several workgroups per pair, MatchArgs::split): written through /
 // read past the XCD's own L2 per access.  The alternative -- plain stores and a __threadfence() on either side -- writes back and invalidates
 // the WHOLE L2 of the XCD, dirty lines of the kernels before included: 6 of the 9 us of the hand-over.
+//
+// What makes the fence-free hand-over correct is a property of THIS target, not of the HIP memory model (under which relaxed accesses order
+// nothing): on gfx942 / gfx950 (LLVM AMDGPU memory model, "gfx942" code sequences) a monotonic agent-scope atomic store IS `global_store ... sc1`
+// (written through the XCD's L2 to the device-coherent level), a monotonic agent-scope atomic load IS `global_load ... sc1` (served from that
+// level, never from a stale line of this XCD's L2), and gfx9 counts stores in vmcnt, so `s_waitcnt vmcnt(0)` after the stores means every one of them
+// has been acknowledged at that level before the counter moves; the winner's sc1 loads, issued after its agent-scope atomicAdd returned, then
+// read exactly those bytes.  Both halves are checked instead of assumed: (1) this translation unit refuses to take the fence-free path on any
+// other target (kHandoverScopedAccess below: targets that count stores separately, vscnt on gfx10+, or lower these builtins differently, get the
+// fenced path unconditionally); (2) the build (orb_ygz_slam_amd/build.py: check_handover_isa) disassembles this file and fails unless
+// k_handover_probe -- the same two inline functions, same flags -- is exactly one sc1 load and one sc1 store and k_match_last carries the
+// scoped accesses of its hand-over; (3) tests/test_gpu_handover.py runs the split path hundreds of times under load against the serial pass.
+#if defined(__gfx950__) || defined(__gfx942__)
+constexpr bool kHandoverScopedAccess = true;
+#else
+constexpr bool kHandoverScopedAccess = false;   // host pass of the compilation, or a target the argument above was not made for
+#endif
 __device__ __forceinline__ void st_dev(void *p, unsigned v) { __hip_atomic_store((unsigned *) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_dev(const void *p) { return __hip_atomic_load((const unsigned *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (build-time probe, never launched: see above)
+__global__ void k_handover_probe(unsigned *dst, const unsigned *src) { st_dev(dst, ld_dev(src)); }
 __device__ __forceinline__ void st_dev4(void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
     unsigned *q = (unsigned *) p;
     st_dev(q, a); st_dev(q + 1, b); st_dev(q + 2, c); st_dev(q + 3, d);
@@ -729,14 +747,14 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
     const long long tScan = dbg ? wall_clock64() : 0;
     if (S > 1) {   // hand-over: the last workgroup to arrive owns the pair from here on
         // the records and query parameters above went out as device-scope stores: once they are acknowledged (vmcnt 0) the counter may move
-        if (A.handoverFence) __threadfence();
+        if (A.handoverFence || !kHandoverScopedAccess) __threadfence();
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) s_tmp[19] = atomicAdd(&A.splitCnt[pair], 1);
         __syncthreads();
         if (s_tmp[19] != S - 1) return;
         if (tid == 0) A.splitCnt[pair] = 0;
-        if (A.handoverFence) __threadfence();
+        if (A.handoverFence || !kHandoverScopedAccess) __threadfence();
         const unsigned char *X = A.splitX + (long long) pair * A.capLast * kMatchSplitRec;
         for (int i = tid; i < nq; i += kMatchBlock) {
             L.specKey[i] = ld_dev4(X + 16 * (size_t) i);

@@ -92,6 +92,8 @@ def test_pitched_host_frames(w, h, k):
     """the library reads YGZF_UPLOAD_K once per process: every setting in a process of its own"""
     code = r"""
 import numpy as np, sys
+import torch
+torch.cuda.init()            # before the library creates its own HIP context (as bench.py does)
 sys.path.insert(0, %r)
 from orb_ygz_slam_amd import Extractor, MultiGpu, make_camera
 from orb_ygz_slam_amd.capi import host_row_pitch
@@ -123,7 +125,6 @@ for j, f in enumerate([f for f in range(n) if (f // 2) %% 2 == 0]):
     assert np.array_equal(kk, ref[0][f][0]) and np.array_equal(dd, ref[0][f][1])
 ex.close()
 # the multi-GPU entry point: pageable tight / pageable pitched / page-locked pitched
-import torch
 one = MultiGpu([0], max_width=w, max_height=h, max_frames_per_device=n)
 r0 = one.extract_match(frames, unit=2, cam=cam)
 one.close()
