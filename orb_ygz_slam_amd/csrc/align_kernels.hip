@@ -11,6 +11,8 @@
 // waves -> bit-reproducible run to run), the 6x6 pivoted LDL^T solve and the SE3 update on lane 0, no host round trip.
 // fp32 throughout, like the reference (Eigen float / Sophus float); parity with the CPU oracle is graded at 1e-5 on the
 // SE3 output because the summation order differs from the reference's sequential loop.
+#include <type_traits>
+
 #include "kernels.h"
 #include "se3_device.h"
 
@@ -264,10 +266,16 @@ __device__ __forceinline__ Se3 se3_exp_wave(const float a[6], int lane) {
     return r;
 }
 
-// precomputeReferencePatches for ONE feature at one level (src/SparseImageAlign.cc:57-128): false when the patch leaves the level's border;
-// otherwise the 12 cache rows (plane 3 * row + {patch, dx, dy}) and the gradient moments.  The arithmetic -- which products are fused included -- is
-// part of the aligner's definition (oracle/oracle_align.cpp's device-order mode repeats it): k_sia_run and k_sia_precompute share this one body.
-__device__ __forceinline__ bool sia_ref_patch(const SiaLevel &Lr, float scale, float2 kp, float4 (&rows)[12], float4 &mom) {
+// precomputeReferencePatches for ONE feature at one level (src/SparseImageAlign.cc:57-128): false (V, mom untouched) when the patch leaves the
+// level's border.  What the reference caches per patch pixel -- the interpolated value and the central differences dx, dy of the interpolated
+// image -- are all differences of ONE 6 x 6 grid of interpolated values V[6 r + c] = I_ref(u - 3 + c + su, v - 3 + r + sv):
+//     patch(y, x) = V[y+1][x+1],   dx(y, x) = 0.5 (V[y+1][x+2] - V[y+1][x]),   dy(y, x) = 0.5 (V[y+2][x+1] - V[y][x+1])
+// (the reference writes each of them out as w_tl p[..] + w_tr p[..] + w_bl p[..] + w_br p[..] over the four bytes around the position: the same
+// expression on the same operands wherever two of them name the same position, so the grid holds the same floats).  32 values (the corners are
+// never used) instead of 48: what makes a thread's features fit its registers (k_sia_run).  mom = (sum dx dx, sum dx dy, sum dy dy, 0) over the 16
+// pixels.  The arithmetic -- which products are fused included -- is part of the aligner's definition (oracle/oracle_align.cpp's device-order mode
+// repeats it): k_sia_run and k_sia_precompute share this one body.
+__device__ __forceinline__ bool sia_ref_patch(const SiaLevel &Lr, float scale, float2 kp, float (&V)[36], float4 &mom) {
     const int border = 3;                       // patch_halfsize_ + 1
     const float u_ref = kp.x * scale, v_ref = kp.y * scale;
     const int u_ref_i = (int) floorf(u_ref), v_ref_i = (int) floorf(v_ref);
@@ -279,47 +287,42 @@ __device__ __forceinline__ bool sia_ref_patch(const SiaLevel &Lr, float scale, f
     const float usu = 1.f - su, usv = 1.f - sv;
     const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
     const int st = Lr.pitch;
-    // columns u-3 .. u+4 of rows v-3 .. v+3: p[k] of the scalar form (p = row + u - 2) is byte k + 1
+    // columns u-3 .. u+4 of rows v-3 .. v+3: seven 8-byte row loads, all in flight together
     const uint8_t *rt = Lr.img + (long long) (v_ref_i - 3) * st;
     unsigned long long R[7];
 #pragma unroll
     for (int r = 0; r < 7; r++) R[r] = row_bytes8(rt + (long long) r * st, u_ref_i - 3, Lr.w);
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const bool corner = (r == 0 || r == 5) && (c == 0 || c == 5);
+            V[6 * r + c] = corner ? 0.f : w_tl * byte_f(R[r], c) + w_tr * byte_f(R[r], c + 1) + w_bl * byte_f(R[r + 1], c) + w_br * byte_f(R[r + 1], c + 1);
+        }
+    // (explicit fused multiply-adds, here and in the accumulate phase: the library is built -ffp-contract=off, and WHICH products are
+    // fused is part of this kernel's definition -- the device-order oracle repeats them with fmaf and must reproduce H, b and chi2 bit
+    // for bit, tests/test_gpu_align.py)
     float sxx = 0.f, sxy = 0.f, syy = 0.f;
 #pragma unroll
-    for (int y = 0; y < 4; y++) {
-        const unsigned long long bm = R[y], b0 = R[y + 1], b1 = R[y + 2], b2 = R[y + 3];
-        float o[12];
+    for (int y = 0; y < 4; y++)
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-            o[x] = w_tl * byte_f(b0, x + 1) + w_tr * byte_f(b0, x + 2) + w_bl * byte_f(b1, x + 1) + w_br * byte_f(b1, x + 2);
-            o[4 + x] = 0.5f * ((w_tl * byte_f(b0, x + 2) + w_tr * byte_f(b0, x + 3) + w_bl * byte_f(b1, x + 2) + w_br * byte_f(b1, x + 3)) -
-                               (w_tl * byte_f(b0, x) + w_tr * byte_f(b0, x + 1) + w_bl * byte_f(b1, x) + w_br * byte_f(b1, x + 1)));
-            o[8 + x] = 0.5f * ((w_tl * byte_f(b1, x + 1) + w_tr * byte_f(b1, x + 2) + w_bl * byte_f(b2, x + 1) + w_br * byte_f(b2, x + 2)) -
-                               (w_tl * byte_f(bm, x + 1) + w_tr * byte_f(bm, x + 2) + w_bl * byte_f(b0, x + 1) + w_br * byte_f(b0, x + 2)));
+            const float dx = 0.5f * (V[6 * (y + 1) + x + 2] - V[6 * (y + 1) + x]), dy = 0.5f * (V[6 * (y + 2) + x + 1] - V[6 * y + x + 1]);
+            sxx = __builtin_fmaf(dx, dx, sxx);
+            sxy = __builtin_fmaf(dx, dy, sxy);
+            syy = __builtin_fmaf(dy, dy, syy);
         }
-        rows[3 * y] = make_float4(o[0], o[1], o[2], o[3]);
-        rows[3 * y + 1] = make_float4(o[4], o[5], o[6], o[7]);
-        rows[3 * y + 2] = make_float4(o[8], o[9], o[10], o[11]);
-        // (explicit fused multiply-adds, here and in the accumulate phase: the library is built -ffp-contract=off, and WHICH products are
-        // fused is part of this kernel's definition -- the device-order oracle repeats them with fmaf and must reproduce H, b and chi2 bit
-        // for bit, tests/test_gpu_align.py)
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            sxx = __builtin_fmaf(o[4 + x], o[4 + x], sxx);
-            sxy = __builtin_fmaf(o[4 + x], o[8 + x], sxy);
-            syy = __builtin_fmaf(o[8 + x], o[8 + x], syy);
-        }
-    }
     mom = make_float4(sxx, sxy, syy, 0.f);
     return true;
 }
 
 // The reference patches of EVERY level before the alignment starts (SiaArgs::perLevel): they depend on the reference frame only, so all
 // (pair, level, feature) items are independent and run chip-wide -- inside k_sia_run they were 71 of its 355 us (seven times 1008 features
-// on the one workgroup of the pair, each a chain of global loads).  Per level a cache of its own (level l at + (l - minLevel) * stride) and a
+// on the one workgroup of the pair, each a chain of global loads).  Per level a cache of its own (level l at + (l - minLevel) * stride: nine
+// planes of float4 = the 6 x 6 grid of sia_ref_patch, feature i at [plane * kpStride + i]; the moments as a float4 of their own) and a
 // flag "visible at this level or a coarser one" (visible_fts_ is cumulative, src/SparseImageAlign.cc:41-45).  A feature that is visible from
 // a coarser level but leaves THIS level's border keeps, in the reference, the patch of the last level that held it (the patch cache is
-// never cleared) under a zeroed Jacobian: that level's patch rows are rebuilt here, the gradient rows and moments are zero.
+// never cleared) under a zeroed Jacobian: that level's grid is rebuilt here and the moments carry the mark "gradients are zero" (w = 1).
 __global__ __launch_bounds__(256) void k_sia_precompute(SiaArgs A) {
     const int pair = blockIdx.z, level = A.maxLevel - (int) blockIdx.y;
     const int N = A.nRef ? A.nRef[pair] : A.n;
@@ -337,24 +340,148 @@ __global__ __launch_bounds__(256) void k_sia_precompute(SiaArgs A) {
     float4 *mom = (float4 *) (A.momCache + (size_t) li * A.momLevelStride) + po + i;
     uint8_t *flag = A.levelFlags + (size_t) li * A.flagLevelStride + po + i;
     const SiaLevel *refLv = A.refLv + (long long) pair * A.lvStride;
-    float4 rows[12], m;
+    float V[36];
+    float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
     int src = level;
-    bool ok = sia_ref_patch(refLv[level], A.invScale[level], kp, rows, m);
+    bool ok = sia_ref_patch(refLv[level], A.invScale[level], kp, V, m);
     if (!ok)
         for (src = level + 1; src <= A.maxLevel; src++)
-            if (sia_ref_patch(refLv[src], A.invScale[src], kp, rows, m)) { ok = true; break; }
+            if (sia_ref_patch(refLv[src], A.invScale[src], kp, V, m)) { ok = true; break; }
     *flag = ok ? 1 : 0;
     if (level == A.minLevel) A.visible[po + i] = ok ? 1 : 0;
     if (!ok) return;
-    if (src != level) {
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (src != level) m = make_float4(0.f, 0.f, 0.f, 1.f);
 #pragma unroll
-        for (int y = 0; y < 4; y++) { rows[3 * y + 1] = z4; rows[3 * y + 2] = z4; }
-        m = z4;
-    }
-#pragma unroll
-    for (int j = 0; j < 12; j++) rc[j * plane] = rows[j];
+    for (int j = 0; j < 9; j++) rc[j * plane] = make_float4(V[4 * j], V[4 * j + 1], V[4 * j + 2], V[4 * j + 3]);
     *mom = m;
+}
+
+// One feature's share of an iteration's normal equations (computeResiduals, src/SparseImageAlign.cc:130-231): projection into the current
+// level, the 5 x 5 bytes under the warped patch, residuals against the reference patch, H / Jres / chi2 into the thread's accumulators.
+// V: the feature's 6 x 6 reference grid (sia_ref_patch), S: its gradient moments (w != 0: gradients are zero at this level).
+__device__ __forceinline__ void sia_accumulate_feature(const SiaArgs &A, const Se3 &T, const SiaLevel &Lc, float scale, bool staged, const uint8_t *s_cur,
+                                                       const float4 ft, const float4 *jacp, const float (&V)[36], const float4 S, float (&acc)[kAcc]) {
+    const int border = 3;                       // patch_halfsize_ + 1
+        if (ft.w == 0.f) return;
+    const float xr[3] = {ft.x, ft.y, ft.z};
+    float xc[3];
+    se3_act(T, xr, xc);
+    const float ucx = A.fx * xc[0] / xc[2] + A.cx, ucy = A.fy * xc[1] / xc[2] + A.cy;   // Frame::Camera2Pixel
+    const float u_cur = ucx * scale, v_cur = ucy * scale;
+    const int ui = (int) floorf(u_cur), vi = (int) floorf(v_cur);
+    if (ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 || ui + border >= Lc.w || vi + border >= Lc.h) return;
+    acc[29] += 1.f;
+    const float su = u_cur - ui, sv = v_cur - vi;
+    // the reference forms these in double and rounds to float: with u, v >= 3 the fractions are multiples of 2^-22, so 1 - su and
+    // 1 - sv are exact in fp32 and the fp32 product is the same single rounding of the same exact product
+    // (tests/test_kernel_models.py::test_bilinear_weights_fp32)
+    const float usu = 1.f - su, usv = 1.f - sv;
+    const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
+    const int st = Lc.pitch;
+    const uint8_t *p = Lc.img + (long long) (vi - 2) * st + (ui - 2);
+    // rows vi-2 .. vi+2, columns ui-2 .. ui+2.  Each row is fetched as the two aligned dwords around its first byte (the patch
+    // stays 3 pixels inside the image, so both dwords lie inside the level) and byte-aligned in registers.
+    unsigned rlo[5], rhi[5];
+    if (staged) {
+        const unsigned o0 = (unsigned) (vi - 2) * (unsigned) st + (unsigned) (ui - 2);
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const uint8_t *q = s_cur + o0 + (unsigned) r * (unsigned) st;
+            const unsigned sh = (unsigned) (unsigned long long) q & 3u;   // LDS addresses: the low bits of the generic pointer are the LDS offset's
+            const unsigned *qa = (const unsigned *) (q - sh);
+            const unsigned v0 = qa[0], v1 = qa[1];
+            rlo[r] = __builtin_amdgcn_alignbyte(v1, v0, sh);
+            rhi[r] = v1 >> (8 * sh);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 5; r++) {
+            const uint8_t *q = p + (long long) r * st;
+            const unsigned sh = (unsigned) (unsigned long long) q & 3u;
+            const uint2 v = *(const uint2 *) __builtin_assume_aligned(q - sh, 4);
+            rlo[r] = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+            rhi[r] = v.y >> (8 * sh);
+        }
+    }
+    float tf[5][5];
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) tf[r][k] = (float) ((rlo[r] >> (8 * k)) & 0xFFu);
+        tf[r][4] = (float) (rhi[r] & 0xFFu);
+    }
+    // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point: the cached quantity of the reference,
+    // (dx*J.row0 + dy*J.row1) * (fx*scale), is re-evaluated with the same operations, so only patch/dx/dy (12 B per pixel
+    // instead of 28 B) stream from memory every iteration.  The point-only terms come from LDS when they fit (staged once per run).
+    float J[12];
+    {
+        float4 ja, jb;
+        if (A.jacLds) { ja = jacp[0]; jb = jacp[1]; }
+        else jac_terms(xr, ja, jb);
+        J[0] = -ja.x; J[1] = 0.f; J[2] = ja.y; J[3] = ja.z; J[4] = ja.w; J[5] = jb.x;
+        J[6] = 0.f; J[7] = -ja.x; J[8] = jb.y; J[9] = jb.z; J[10] = -ja.z; J[11] = jb.w;
+    }
+    const float fs = A.fx * scale;
+    float Jf[12];   // J * (fx * scale): folded once per feature (the reference scales every (dx*J0 + dy*J1) row; see the note below)
+#pragma unroll
+    for (int k = 0; k < 12; k++) Jf[k] = J[k] * fs;
+    acc[28] += 16.f;   // n_meas: one per patch pixel (exact in fp32)
+    // The normal equations are sums of thousands of products: their rounding is not part of the reference's definition (its own
+    // result moves in the 7th digit when features are summed in another order, tests/test_gpu_fuzz.py) and the SE3 is graded at
+    // 1e-5.  The pixel Jacobian of the reference is J_p = dx_p * Jf0 + dy_p * Jf1 with the SAME two 6-vectors for the 16 pixels of
+    // a feature, so the feature's share of H = sum_p J_p J_p^T is
+    //     Sxx * Jf0 Jf0^T + Sxy * (Jf0 Jf1^T + Jf1 Jf0^T) + Syy * Jf1 Jf1^T,       Sxx = sum dx^2, Sxy = sum dx*dy, Syy = sum dy^2
+    // -- moments of the reference patch, constant over the iterations of a level (precompute above) -- and its share of
+    // Jres = -sum_p J_p res_p is -(Jf0 * sum dx*res + Jf1 * sum dy*res).  Per pixel that leaves the interpolation, the residual and
+    // three multiply-adds (8 instructions instead of ~45); per feature 66 for H and 12 for Jres.  This block -- and only this
+    // block -- uses fused multiply-adds (v_fma_f32, written out: the accumulate phase is issue-bound at two waves per SIMD).
+    {
+        float sxr = 0.f, syr = 0.f;
+        // gradients marked zero (a feature that left this level's border but is visible from a coarser one): hz = 0 makes dx = dy = +-0, the sums
+        // keep their +0 -- what the reference's zeroed Jacobian rows add
+        const float hz = S.w != 0.f ? 0.f : 0.5f;
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const float I = __builtin_fmaf(w_br, tf[y + 1][x + 1], __builtin_fmaf(w_bl, tf[y + 1][x], __builtin_fmaf(w_tr, tf[y][x + 1], w_tl * tf[y][x])));
+                const float res = I - V[6 * (y + 1) + x + 1];
+                const float dxa = hz * (V[6 * (y + 1) + x + 2] - V[6 * (y + 1) + x]), dya = hz * (V[6 * (y + 2) + x + 1] - V[6 * y + x + 1]);
+                acc[27] = __builtin_fmaf(res, res, acc[27]);
+                sxr = __builtin_fmaf(dxa, res, sxr);
+                syr = __builtin_fmaf(dya, res, syr);
+            }
+        }
+        // Jf[1] and Jf[6] are structural zeros of JacobXYZ2Cam (their products are exact zeros in the reference's sums): left out
+        float P[6], Q[6];
+        P[0] = S.x * Jf[0]; Q[0] = S.y * Jf[0];
+        P[1] = S.y * Jf[7]; Q[1] = S.z * Jf[7];
+#pragma unroll
+        for (int k = 2; k < 6; k++) {
+            P[k] = __builtin_fmaf(S.y, Jf[6 + k], S.x * Jf[k]);
+            Q[k] = __builtin_fmaf(S.z, Jf[6 + k], S.y * Jf[k]);
+        }
+        // H[a][b] += Jf0[a] * P[b] + Jf1[a] * Q[b], upper triangle in the accumulators' order
+#pragma unroll
+        for (int b2 = 0; b2 < 6; b2++) acc[b2] = __builtin_fmaf(Jf[0], P[b2], acc[b2]);
+#pragma unroll
+        for (int b2 = 1; b2 < 6; b2++) acc[5 + b2] = __builtin_fmaf(Jf[7], Q[b2], acc[5 + b2]);
+        int t = 11;
+#pragma unroll
+        for (int a = 2; a < 6; a++)
+#pragma unroll
+            for (int b2 = a; b2 < 6; b2++, t++) {
+                acc[t] = __builtin_fmaf(Jf[a], P[b2], acc[t]);
+                acc[t] = __builtin_fmaf(Jf[6 + a], Q[b2], acc[t]);
+            }
+        acc[21] = __builtin_fmaf(-Jf[0], sxr, acc[21]);
+        acc[22] = __builtin_fmaf(-Jf[7], syr, acc[22]);
+#pragma unroll
+        for (int k = 2; k < 6; k++) {
+            acc[21 + k] = __builtin_fmaf(-Jf[k], sxr, acc[21 + k]);
+            acc[21 + k] = __builtin_fmaf(-Jf[6 + k], syr, acc[21 + k]);
+        }
+    }
 }
 
 // DBG: phase clocks (YGZF_SIA_DEBUG) are compiled in only in the instrumented instantiation; the production kernel reads no clock
@@ -400,8 +527,8 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
     float2 *s_uv = (float2 *) (s_feat + A.ldsFeat);
     float4 *s_jac = (float4 *) (s_uv + A.ldsFeat);   // two per feature when A.jacLds
     uint8_t *s_img = (uint8_t *) s_feat + A.stageOff;   // A.stageBytes: the current image of a level that fits (coarse levels)
-    if (!A.perLevel)
-        for (int j = 0; j < 12; j++)
+    if (!A.perLevel && N > 2 * kSiaBlock)   // (only pairs beyond the register form ever read the cache)
+        for (int j = 0; j < 9; j++)
             for (int i = tid; i < N; i += kSiaBlock) rowCache[j * plane + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();                                            // s_Tref is set
     {   // per-feature terms that do not depend on the level, once per run: the keypoint, the exclusion flags and Tref * Xw go to LDS
@@ -427,7 +554,20 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         if (tid == 0) { for (int i = 0; i < 48; i++) out[i] = 0; out[3] = 1.f; }
         return;
     }
-    const int border = 3;                       // patch_halfsize_ + 1
+    // The level loop exists twice.  REG (pairs of up to 2 x kSiaBlock features -- every usual configuration): the reference grids / gradient moments
+    // of features tid and tid + kSiaBlock (sia_ref_patch) live in the thread's registers across the iterations of a level, 72 registers that replace
+    // 208 bytes per feature and iteration from caches in global memory.  Otherwise every feature goes through the cache of its level (nine float4
+    // planes + moments).  Two instantiations of one body instead of one loop with both paths: the register form has no room for the loads of the other.
+    auto run_levels = [&](auto regTag) {
+    constexpr bool REG = decltype(regTag)::value;
+    float Vg[2][36];
+    float4 mg[2];
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        mg[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 36; j++) Vg[f][j] = 0.f;
+    }
     for (int level = A.maxLevel; level >= A.minLevel; level--) {
         const SiaLevel Lr = A.refLv[(long long) pair * A.lvStride + level], Lc = A.curLv[(long long) pair * A.lvStride + level];
         const float scale = A.invScale[level];
@@ -456,27 +596,44 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
             mom = (float4 *) (A.momCache + (size_t) li * A.momLevelStride) + (long long) pair * A.kpStride;
             const uint8_t *fl = A.levelFlags + (size_t) li * A.flagLevelStride + (long long) pair * A.kpStride;
             for (int i = tid; i < N; i += kSiaBlock) s_feat[i].w = fl[i] ? 1.f : 0.f;     // visible at this level or a coarser one
-        } else {
-            // work item = feature: the 7 x 8 image bytes under its 4 x 4 patch and the one-pixel gradient ring are loaded once (seven
-            // 8-byte row loads, all in flight together) instead of four rows per (feature, row) item
-            for (int i = tid; i < N; i += kSiaBlock) {
-                const float2 kp = s_uv[i];
-                float4 *rc = rowCache + i;
-                float4 rows[12], m;
-                if (!sia_ref_patch(Lr, scale, kp, rows, m)) {
-                    if (s_feat[i].w != 0.f) {   // visible from an earlier level: its Jacobian counts as zero at this level
-                        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                        for (int y = 0; y < 4; y++) { rc[(3 * y + 1) * plane] = z4; rc[(3 * y + 2) * plane] = z4; }
-                        mom[i] = z4;
+            for (int f = 0; f < 2; f++) {       // this level's grids of the thread's own two features: one read per level, registers from here on
+                const int i = tid + f * kSiaBlock;
+                if (REG && i < N && fl[i]) {
+#pragma unroll
+                    for (int j = 0; j < 9; j++) {
+                        const float4 v = rowCache[j * plane + i];
+                        Vg[f][4 * j] = v.x; Vg[f][4 * j + 1] = v.y; Vg[f][4 * j + 2] = v.z; Vg[f][4 * j + 3] = v.w;
                     }
-                    continue;
+                    mg[f] = mom[i];
                 }
-                visible[i] = 1;
-                s_feat[i].w = 1.f;
+            }
+        } else {
+            // work item = feature: the 7 x 8 image bytes under its 6 x 6 grid are loaded once (seven 8-byte row loads, all in flight together).
+            // A feature that fails this level's border test but was visible at a coarser one keeps that level's grid (registers / cache are
+            // simply not overwritten -- the reference's patch cache is never cleared) and gets the mark "gradients are zero".
 #pragma unroll
-                for (int j = 0; j < 12; j++) rc[j * plane] = rows[j];
-                mom[i] = m;
+            for (int f = 0; f < 2; f++) {
+                const int i = tid + f * kSiaBlock;
+                if (REG && i < N) {
+                    if (sia_ref_patch(Lr, scale, s_uv[i], Vg[f], mg[f])) {
+                        visible[i] = 1;
+                        s_feat[i].w = 1.f;
+                    } else if (s_feat[i].w != 0.f)
+                        mg[f] = make_float4(0.f, 0.f, 0.f, 1.f);
+                }
+            }
+            for (int i = tid; !REG && i < N; i += kSiaBlock) {   // through the cache in global memory
+                float Vt[36];
+                float4 m;
+                if (sia_ref_patch(Lr, scale, s_uv[i], Vt, m)) {
+                    visible[i] = 1;
+                    s_feat[i].w = 1.f;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) rowCache[j * plane + i] = make_float4(Vt[4 * j], Vt[4 * j + 1], Vt[4 * j + 2], Vt[4 * j + 3]);
+                    mom[i] = m;
+                } else if (s_feat[i].w != 0.f)
+                    mom[i] = make_float4(0.f, 0.f, 0.f, 1.f);
             }
         }
         __syncthreads();
@@ -486,134 +643,30 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         __syncthreads();
         for (int iter = 0; iter < A.nIter; iter++) {
             const long long c0 = DBG ? wall_clock64() : 0;
-            const Se3 T = s_T, Tref = s_Tref;
+            const Se3 T = s_T;
             float acc[kAcc];
 #pragma unroll
             for (int k = 0; k < kAcc; k++) acc[k] = 0.f;
             // work item = feature: projection, interpolation weights and the point's Jacobian terms once per feature (they were rebuilt for
             // each of its four patch rows), five dword-aligned 8-byte row loads for the 5 x 5 bytes under the patch
-            for (int i = tid; i < N; i += kSiaBlock) {
+            // A thread owns the same features in every iteration -- REG: tid and tid + kSiaBlock, from its registers (the grids built / loaded at the top
+            // of the level); otherwise tid, tid + kSiaBlock, ... through the caches in global memory -- and takes them in ascending order (the order
+            // is part of the definition: the device-order oracle sums the same way).
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const int i = tid + f * kSiaBlock;
+                if (REG && i < N) sia_accumulate_feature(A, T, Lc, scale, staged, s_cur, s_feat[i], s_jac + 2 * i, Vg[f], mg[f], acc);
+            }
+            for (int i = tid; !REG && i < N; i += kSiaBlock) {
                 const float4 ft = s_feat[i];
                 if (ft.w == 0.f) continue;
-                const float xr[3] = {ft.x, ft.y, ft.z};
-                float xc[3];
-                se3_act(T, xr, xc);
-                const float ucx = A.fx * xc[0] / xc[2] + A.cx, ucy = A.fy * xc[1] / xc[2] + A.cy;   // Frame::Camera2Pixel
-                const float u_cur = ucx * scale, v_cur = ucy * scale;
-                const int ui = (int) floorf(u_cur), vi = (int) floorf(v_cur);
-                if (ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 || ui + border >= Lc.w || vi + border >= Lc.h) continue;
-                acc[29] += 1.f;
-                const float su = u_cur - ui, sv = v_cur - vi;
-                // the reference forms these in double and rounds to float: with u, v >= 3 the fractions are multiples of 2^-22, so 1 - su and
-                // 1 - sv are exact in fp32 and the fp32 product is the same single rounding of the same exact product
-                // (tests/test_kernel_models.py::test_bilinear_weights_fp32)
-                const float usu = 1.f - su, usv = 1.f - sv;
-                const float w_tl = usu * usv, w_tr = su * usv, w_bl = usu * sv, w_br = su * sv;
-                const int st = Lc.pitch;
-                const uint8_t *p = Lc.img + (long long) (vi - 2) * st + (ui - 2);
-                // rows vi-2 .. vi+2, columns ui-2 .. ui+2.  Each row is fetched as the two aligned dwords around its first byte (the patch
-                // stays 3 pixels inside the image, so both dwords lie inside the level) and byte-aligned in registers.
-                unsigned rlo[5], rhi[5];
-                if (staged) {
-                    const unsigned o0 = (unsigned) (vi - 2) * (unsigned) st + (unsigned) (ui - 2);
+                float Vt[36];
 #pragma unroll
-                    for (int r = 0; r < 5; r++) {
-                        const uint8_t *q = s_cur + o0 + (unsigned) r * (unsigned) st;
-                        const unsigned sh = (unsigned) (unsigned long long) q & 3u;   // LDS addresses: the low bits of the generic pointer are the LDS offset's
-                        const unsigned *qa = (const unsigned *) (q - sh);
-                        const unsigned v0 = qa[0], v1 = qa[1];
-                        rlo[r] = __builtin_amdgcn_alignbyte(v1, v0, sh);
-                        rhi[r] = v1 >> (8 * sh);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 5; r++) {
-                        const uint8_t *q = p + (long long) r * st;
-                        const unsigned sh = (unsigned) (unsigned long long) q & 3u;
-                        const uint2 v = *(const uint2 *) __builtin_assume_aligned(q - sh, 4);
-                        rlo[r] = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
-                        rhi[r] = v.y >> (8 * sh);
-                    }
+                for (int j = 0; j < 9; j++) {
+                    const float4 v = rowCache[j * plane + i];
+                    Vt[4 * j] = v.x; Vt[4 * j + 1] = v.y; Vt[4 * j + 2] = v.z; Vt[4 * j + 3] = v.w;
                 }
-                float tf[5][5];
-#pragma unroll
-                for (int r = 0; r < 5; r++) {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) tf[r][k] = (float) ((rlo[r] >> (8 * k)) & 0xFFu);
-                    tf[r][4] = (float) (rhi[r] & 0xFFu);
-                }
-                // JacobXYZ2Cam (include/SparseImageAlign.h:90-111) of the reference-frame point: the cached quantity of the reference,
-                // (dx*J.row0 + dy*J.row1) * (fx*scale), is re-evaluated with the same operations, so only patch/dx/dy (12 B per pixel
-                // instead of 28 B) stream from memory every iteration.  The point-only terms come from LDS when they fit (staged once per run).
-                float J[12];
-                {
-                    float4 ja, jb;
-                    if (A.jacLds) { ja = s_jac[2 * i]; jb = s_jac[2 * i + 1]; }
-                    else jac_terms(xr, ja, jb);
-                    J[0] = -ja.x; J[1] = 0.f; J[2] = ja.y; J[3] = ja.z; J[4] = ja.w; J[5] = jb.x;
-                    J[6] = 0.f; J[7] = -ja.x; J[8] = jb.y; J[9] = jb.z; J[10] = -ja.z; J[11] = jb.w;
-                }
-                const float fs = A.fx * scale;
-                float Jf[12];   // J * (fx * scale): folded once per feature (the reference scales every (dx*J0 + dy*J1) row; see the note below)
-#pragma unroll
-                for (int k = 0; k < 12; k++) Jf[k] = J[k] * fs;
-                acc[28] += 16.f;   // n_meas: one per patch pixel (exact in fp32)
-                const float4 *rcp = rowCache + i;
-                // The normal equations are sums of thousands of products: their rounding is not part of the reference's definition (its own
-                // result moves in the 7th digit when features are summed in another order, tests/test_gpu_fuzz.py) and the SE3 is graded at
-                // 1e-5.  The pixel Jacobian of the reference is J_p = dx_p * Jf0 + dy_p * Jf1 with the SAME two 6-vectors for the 16 pixels of
-                // a feature, so the feature's share of H = sum_p J_p J_p^T is
-                //     Sxx * Jf0 Jf0^T + Sxy * (Jf0 Jf1^T + Jf1 Jf0^T) + Syy * Jf1 Jf1^T,       Sxx = sum dx^2, Sxy = sum dx*dy, Syy = sum dy^2
-                // -- moments of the reference patch, constant over the iterations of a level (precompute above) -- and its share of
-                // Jres = -sum_p J_p res_p is -(Jf0 * sum dx*res + Jf1 * sum dy*res).  Per pixel that leaves the interpolation, the residual and
-                // three multiply-adds (8 instructions instead of ~45); per feature 66 for H and 12 for Jres.  This block -- and only this
-                // block -- uses fused multiply-adds (v_fma_f32, written out: the accumulate phase is issue-bound at two waves per SIMD).
-                {
-                    float sxr = 0.f, syr = 0.f;
-#pragma unroll
-                    for (int y = 0; y < 4; y++) {
-                        const float4 pc = rcp[(3 * y) * plane], dxv = rcp[(3 * y + 1) * plane], dyv = rcp[(3 * y + 2) * plane];
-                        const float pcv[4] = {pc.x, pc.y, pc.z, pc.w}, dxa[4] = {dxv.x, dxv.y, dxv.z, dxv.w}, dya[4] = {dyv.x, dyv.y, dyv.z, dyv.w};
-#pragma unroll
-                        for (int x = 0; x < 4; x++) {
-                            const float I = __builtin_fmaf(w_br, tf[y + 1][x + 1], __builtin_fmaf(w_bl, tf[y + 1][x], __builtin_fmaf(w_tr, tf[y][x + 1], w_tl * tf[y][x])));
-                            const float res = I - pcv[x];
-                            acc[27] = __builtin_fmaf(res, res, acc[27]);
-                            sxr = __builtin_fmaf(dxa[x], res, sxr);
-                            syr = __builtin_fmaf(dya[x], res, syr);
-                        }
-                    }
-                    // Jf[1] and Jf[6] are structural zeros of JacobXYZ2Cam (their products are exact zeros in the reference's sums): left out
-                    const float4 S = mom[i];
-                    float P[6], Q[6];
-                    P[0] = S.x * Jf[0]; Q[0] = S.y * Jf[0];
-                    P[1] = S.y * Jf[7]; Q[1] = S.z * Jf[7];
-#pragma unroll
-                    for (int k = 2; k < 6; k++) {
-                        P[k] = __builtin_fmaf(S.y, Jf[6 + k], S.x * Jf[k]);
-                        Q[k] = __builtin_fmaf(S.z, Jf[6 + k], S.y * Jf[k]);
-                    }
-                    // H[a][b] += Jf0[a] * P[b] + Jf1[a] * Q[b], upper triangle in the accumulators' order
-#pragma unroll
-                    for (int b2 = 0; b2 < 6; b2++) acc[b2] = __builtin_fmaf(Jf[0], P[b2], acc[b2]);
-#pragma unroll
-                    for (int b2 = 1; b2 < 6; b2++) acc[5 + b2] = __builtin_fmaf(Jf[7], Q[b2], acc[5 + b2]);
-                    int t = 11;
-#pragma unroll
-                    for (int a = 2; a < 6; a++)
-#pragma unroll
-                        for (int b2 = a; b2 < 6; b2++, t++) {
-                            acc[t] = __builtin_fmaf(Jf[a], P[b2], acc[t]);
-                            acc[t] = __builtin_fmaf(Jf[6 + a], Q[b2], acc[t]);
-                        }
-                    acc[21] = __builtin_fmaf(-Jf[0], sxr, acc[21]);
-                    acc[22] = __builtin_fmaf(-Jf[7], syr, acc[22]);
-#pragma unroll
-                    for (int k = 2; k < 6; k++) {
-                        acc[21 + k] = __builtin_fmaf(-Jf[k], sxr, acc[21 + k]);
-                        acc[21 + k] = __builtin_fmaf(-Jf[6 + k], syr, acc[21 + k]);
-                    }
-                }
+                sia_accumulate_feature(A, T, Lc, scale, staged, s_cur, ft, s_jac + 2 * i, Vt, mom[i], acc);
             }
             const long long c1 = DBG ? wall_clock64() : 0;
             // fixed-shape reduction: wave totals of the 30 accumulators (wave_sums_30) -> one LDS partial per wave (8 x 30 floats); after ONE block barrier
@@ -687,6 +740,9 @@ __global__ __launch_bounds__(kSiaBlock) void k_sia_run(SiaArgs A) {
         }
         __syncthreads();
     }
+    };
+    if (N <= 2 * kSiaBlock) run_levels(std::true_type{});
+    else run_levels(std::false_type{});
     if (tid == 0) {
         for (int i = 0; i < 4; i++) out[i] = s_T.q[i];
         for (int i = 0; i < 3; i++) out[4 + i] = s_T.t[i];
