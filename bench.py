@@ -774,6 +774,7 @@ def main():
         kernels = kernel_table(prof)
         # untimed extra pass: one context at a time, so that per-kernel durations are not stretched by the other streams
         iso = isolated_pass(pipe)
+    match_fallbacks = sum(e.match_fallbacks() for e in pipe.exs)
     kp_counts = np.concatenate([e.batch_counts() for e in pipe.exs])
     m_counts = np.concatenate([e.match_counts() for e in pipe.exs])
 
@@ -875,6 +876,7 @@ def main():
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "roofline_pcie": e2e["roofline_pcie"] if e2e else None,
             "mgpu_end_to_end": mgpu, "mgpu_literal_configs": mgpu_lit,
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
+            "match_serial_fallback_pairs": match_fallbacks,   # pairs of device 0 (whole run) that lost the matcher's fixpoint to the one-wave pass
             "roofline": hbm_roofline(args.workload, kernels, iso, per_kernel, sub, total_bytes, fps / n_gpus) if kernels else None,
             "roofline_valu": valu_roofline(args.workload, kernels, iso, sub) if kernels else None,
             "kernels": kernels,

@@ -327,6 +327,11 @@ int ygzf_search_by_projection_mappoints(ygzf_ctx *ctx, const ygzf_frame_view *F,
  * descriptor is the keypoint's own -- the synthetic scenario of the extract+match metric. */
 int ygzf_match_batch_prev(ygzf_ctx *ctx, const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation);
 int ygzf_match_counts(ygzf_ctx *ctx, int *nmatches /* n_frames ints */);
+/* Diagnostics: how many (Cur, Last) / (Frame, MapPoints) pairs of this context's matcher launches so far resolved their in-order ownership
+ * (src/ORBmatcher.cc:1296-1345, :98-121) through the one-wave serial pass because the block-wide fixpoint ran out of rounds or list
+ * extensions -- identical matches, but a crowded frame (th = 5 after relocalisation, thousands of features) silently loses the speed-up;
+ * bench.py prints it.  Synchronises the context. */
+int ygzf_match_fallbacks(ygzf_ctx *ctx, unsigned *pairs);
 int ygzf_match_fetch(ygzf_ctx *ctx, int frame, int *cur_match, uint8_t *cur_owner, int cap);
 /* All pairs of the last ygzf_match_batch_prev at once: row p of `match` (stride >= ygzf_max_keypoints ints per row) receives the match
  * array of pair p in full row length (entries past the frame's keypoint count are -1 or stale: read n_kp of them). */

@@ -371,6 +371,13 @@ class Extractor:
         self._inflight.clear()
         return n
 
+    def match_fallbacks(self):
+        """pairs whose in-order resolution fell back to the one-wave serial pass since the context was created (include/ygzf.h)"""
+        n = C.c_uint(0)
+        self.L.ygzf_match_fallbacks.argtypes = [C.c_void_p, C.c_void_p]
+        self._ck(self.L.ygzf_match_fallbacks(self.h, C.byref(n)))
+        return n.value
+
     def match_fetch(self, frame):
         w, h, _ = self._wh
         cap = self.max_keypoints(w, h)

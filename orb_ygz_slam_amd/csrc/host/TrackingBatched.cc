@@ -113,6 +113,16 @@ void Tracking::SearchLocalPoints() {
     }
     const int M = (int) mvpLocalMapPoints.size(), nt = mCurrentFrame.N;
     if (M <= 0) return;
+    // The device builds the Frame grid over ALL nt keys and reads their descriptor rows; the reference only touches the rows of keys its grid
+    // returns.  A frame whose key count ran ahead of its descriptors (SearchLocalPointsDirect appends keys without descriptors; the reference's own
+    // flow re-extracts before TrackLocalMap, src/Tracking.cc:1105-1118) would make either read past mDescriptors: refuse it loudly instead.
+    if (nt > 0 && (mCurrentFrame.mDescriptors.rows < nt || (int) mCurrentFrame.mvpMapPoints.size() < nt || (int) mCurrentFrame.mvKeys.size() < nt)) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "frame holds %d keys but %d descriptor rows / %zu MapPoint slots / %zu keypoints: no matching done", nt,
+                 mCurrentFrame.mDescriptors.rows, mCurrentFrame.mvpMapPoints.size(), mCurrentFrame.mvKeys.size());
+        ygzf_host::report_failure("ygz::Tracking::SearchLocalPoints", msg);
+        return;
+    }
     // the points the reference's loop hands to isInFrustum (:1564-1575)
     std::vector<uint8_t> cand(M, 0);
     int nCand = 0;

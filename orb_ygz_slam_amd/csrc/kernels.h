@@ -130,6 +130,7 @@ struct MatchArgs {
     int split;
     int *splitCnt;                 // one counter per pair, zero between launches (the last workgroup resets it)
     unsigned char *splitX;         // kMatchSplitRec * capLast bytes per pair
+    unsigned *serialFallbacks;     // nullable: counts the pairs whose in-order resolution fell back from the block-wide fixpoint to the one-wave pass
 };
 constexpr int kSpillSpec = 1, kSpillMisc = 2;
 constexpr int kMatchSplitRec = 56;   // uint4 + uint4 (lists of eight) + ushort4 + ushort4 + float angle + hasObs word

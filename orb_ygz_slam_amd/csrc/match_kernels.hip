@@ -876,12 +876,10 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
             if (tid == 0) s_tmp[16 + ((rounds & 1) ^ 1)] = 0;
             if (changed) s_tmp[16 + (rounds & 1)] = 1;
             __syncthreads();
-            if (rounds >= 95) { if (tid == 0) s_tmp[15] = 1; break; }
             const int nWork = min(s_tmp[18], kExtSlots);
-            if (nWork == 0) {
-                if (s_tmp[16 + (rounds & 1)]) continue;  // some pick moved: another round, on the other claim buffer
-                break;                                   // fixpoint, nobody waits for an extension
-            }
+            if (nWork == 0 && !s_tmp[16 + (rounds & 1)]) break;   // fixpoint, nobody waits for an extension (tested BEFORE the round cap: a converged state is never thrown away)
+            if (rounds >= 95) { if (tid == 0) s_tmp[15] = 1; break; }
+            if (nWork == 0) continue;                    // some pick moved: another round, on the other claim buffer
             // extensions: one wave per query; the claims play no part, so all of them at once
             for (int w = wave; w < nWork; w += kMatchBlock / 64) {
                 const int qx = L.extWork[w];
@@ -912,6 +910,7 @@ __global__ __launch_bounds__(kMatchBlock) void k_match_last(MatchArgs A) {
         __syncthreads();
         const bool serial = s_tmp[15] != 0;
         if (dbg && tid == 0) dbg[6] = serial ? -1 : nExtended * 1000 + rounds + 1;
+        if (serial && tid == 0 && A.serialFallbacks) atomicAdd(A.serialFallbacks, 1u);   // always on: a crowded frame that loses the fixpoint's speed shows up in the profile
         if (serial) {
             for (int i = tid; i < nt; i += kMatchBlock) { L.claim[i] = 64; L.match[i] = -1; }
             __syncthreads();

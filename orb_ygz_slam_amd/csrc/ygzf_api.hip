@@ -137,6 +137,7 @@ struct ygzf_ctx {
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
     Buf dFastStats;
     Buf dFastCells;                        // FastCellRec table of the current geometry (k_fast_tab)
+    Buf dMatchStat;                        // one counter: pairs that fell back to the matcher's one-wave pass (ygzf_match_fallbacks)
     Buf dPack;                             // inputs + outputs of a one-frame entry point, one copy each way (PackedTransfer)
     int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
@@ -150,7 +151,7 @@ struct ygzf_ctx {
     // one-frame uploads from pageable caller memory (a cv::Mat): the rows are copied into this page-locked, device-visible buffer by the host and
     // read from there by a kernel that writes them at the context's pitch -- the runtime's own pageable path (pin / stage / blit) cost ~50 us for a
     // 752x480 frame, this ~25.  evIn marks the moment the kernel has read the buffer (the next upload waits for it before overwriting).
-    uint8_t *hIn = nullptr;
+    uint8_t *hIn = nullptr;                // (one tight frame: at most maxW x maxH bytes, apply_geometry refuses anything larger)
     void *hInDev = nullptr;
     size_t hInBytes = 0;
     hipEvent_t evIn = nullptr;
@@ -250,7 +251,9 @@ static int ensure_stage(ygzf_ctx *c, size_t bytes) {
 // One-frame entry points hand over a dozen small host arrays and take a few back.  From pageable memory every hipMemcpyAsync is a staged copy
 // of its own (10-20 us of runtime work apiece; twelve of them cost more than the kernel they feed): the arrays are packed into the context's
 // page-locked staging area and cross the link as ONE copy each way.
-constexpr size_t kPackedMax = 4u << 20;   // callers with more than this in flight keep their own copies (the staging area is page-locked memory)
+// callers with more than this in flight keep their own copies (the staging area is page-locked memory); YGZF_PACKED_MAX (bytes) lowers it so
+// that tests reach the large-transfer paths with ordinary frames
+static const size_t kPackedMax = getenv("YGZF_PACKED_MAX") ? (size_t) atoll(getenv("YGZF_PACKED_MAX")) : (size_t) (4u << 20);
 struct PackedTransfer {
     ygzf_ctx *c;
     struct Seg { const void *src; void *dst; size_t bytes, off; };
@@ -261,17 +264,32 @@ struct PackedTransfer {
     size_t add_in(const void *src, size_t bytes) { const size_t o = inBytes; in.push_back({src, nullptr, bytes, o}); inBytes += al(bytes); return o; }
     size_t add_out(void *dst, size_t bytes) { const size_t o = outBytes; out.push_back({nullptr, dst, bytes, o}); outBytes += al(bytes); return o; }
     // device layout: [inputs | outputs] in c->dPack; returns the base
+    // A transfer beyond kPackedMax (a KeyFrame with tens of thousands of features) does not grow the page-locked staging area: its arrays cross
+    // one by one from / to the caller's own memory -- same device layout, so the kernels' pointers do not care which way the bytes came.
+    bool direct() const { return inBytes + outBytes > kPackedMax; }
     int upload(uint8_t **dBase) {
         int rc;
-        if ((rc = ensure_stage(c, inBytes + outBytes + 256)) || (rc = ensure(c, c->dPack, inBytes + outBytes + 256))) return rc;
-        for (const Seg &s : in)
-            if (s.bytes) memcpy(c->hStage + s.off, s.src, s.bytes);
-        if (inBytes) HIPCHECK(c, hipMemcpyAsync(c->dPack.p, c->hStage, inBytes, hipMemcpyHostToDevice, c->stream));
+        if ((rc = ensure(c, c->dPack, inBytes + outBytes + 256))) return rc;
+        if (direct()) {
+            for (const Seg &s : in)
+                if (s.bytes) HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dPack.p + s.off, s.src, s.bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            if ((rc = ensure_stage(c, inBytes + outBytes + 256))) return rc;
+            for (const Seg &s : in)
+                if (s.bytes) memcpy(c->hStage + s.off, s.src, s.bytes);
+            if (inBytes) HIPCHECK(c, hipMemcpyAsync(c->dPack.p, c->hStage, inBytes, hipMemcpyHostToDevice, c->stream));
+        }
         *dBase = (uint8_t *) c->dPack.p;
         return YGZF_OK;
     }
     uint8_t *d_out(size_t off) const { return (uint8_t *) c->dPack.p + inBytes + off; }
     int download() {   // one copy back, then scattered to the caller's arrays; synchronises the stream
+        if (direct()) {
+            for (const Seg &s : out)
+                if (s.bytes && s.dst) HIPCHECK(c, hipMemcpyAsync(s.dst, d_out(s.off), s.bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            return YGZF_OK;
+        }
         if (outBytes) HIPCHECK(c, hipMemcpyAsync(c->hStage + inBytes, (uint8_t *) c->dPack.p + inBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         for (const Seg &s : out)
@@ -1108,6 +1126,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->dFastStats.p) (void) hipFree(c->dFastStats.p);
     if (c->dFastCells.p) (void) hipFree(c->dFastCells.p);
     if (c->dPack.p) (void) hipFree(c->dPack.p);
+    if (c->dMatchStat.p) (void) hipFree(c->dMatchStat.p);
     if (c->dSplitCnt.p) (void) hipFree(c->dSplitCnt.p);
     if (c->dSplitX.p) (void) hipFree(c->dSplitX.p);
     if (c->dUpStage.p) (void) hipFree(c->dUpStage.p);
@@ -1739,6 +1758,11 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
         A.spillScratch = c->dSpill.p;
     }
     // few pairs in the launch (a Tracking thread matches ONE): spread each over several workgroups (kernels.h, MatchArgs::split)
+    if (!c->dMatchStat.p) {
+        if ((rc = ensure(c, c->dMatchStat, 64))) return rc;
+        HIPCHECK(c, hipMemsetAsync(c->dMatchStat.p, 0, 64, c->stream));
+    }
+    A.serialFallbacks = (unsigned *) c->dMatchStat.p;
     A.serialOrder = c->matchSerial;
     A.handoverFence = c->matchFence;
     A.fixedLanes = c->matchFixedLanes;
@@ -1846,6 +1870,16 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
                 st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6], st[7]);
     }
     c->lastMatchPairs = B;
+    return YGZF_OK;
+}
+
+int ygzf_match_fallbacks(ygzf_ctx *c, unsigned *pairs) {
+    if (!c || !pairs) return fail(c, YGZF_ERR_INVALID, "null argument");
+    *pairs = 0;
+    if (!c->dMatchStat.p) return YGZF_OK;   // no matcher launch yet
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipMemcpyAsync(pairs, c->dMatchStat.p, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
     return YGZF_OK;
 }
 

@@ -368,3 +368,20 @@ def test_matcher_is_deterministic_over_repeats(oracle):
             g0 = ex.search_by_projection_last(cam, kb, db, ka, _unit_world(ka, EUROC), da, I, z, I, z, 15.0, scale_factors=sf)
             assert g[0] == e[0] and (g[1] == e[1]).all()
             assert g0[0] == e0[0] and (g0[1] == e0[1]).all()
+
+
+def test_large_transfers_bypass_the_page_locked_staging():
+    """One-frame entry points pack their host arrays into a page-locked staging area that must not grow without bound: beyond kPackedMax the
+    arrays cross one by one from / to the caller's memory (PackedTransfer::direct, csrc/ygzf_api.hip).  With YGZF_PACKED_MAX=4096 every matcher /
+    BoW / triangulation / aligner call of an ordinary frame takes that path: the suites must hold unchanged."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YGZF_PACKED_MAX="4096")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_match.py"),
+                          os.path.join(root, "tests", "test_gpu_frustum.py"), os.path.join(root, "tests", "test_gpu_grid.py"), os.path.join(root, "tests", "test_gpu_align.py"),
+                          "-k", "not large_transfers and not in_kernel_reference_patches and not deterministic"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
