@@ -178,6 +178,7 @@ class NavState;
 
 #ifndef YGZ_REF_MAPPOINT
 // include/MapPoint.h, src/MapPoint.cc: the fields / accessors the matcher touches
+#define YGZ_STUB_MAPPOINT 1   // (no mutexes, GetDescriptor() hands out a header: code that reaches into the real class's privates asks for this)
 class MapPoint {
 public:
     Vector3f mWorldPos, mNormal;

@@ -103,6 +103,7 @@ struct MatZerosExpr { int rows, cols; };
     std::abort();
 }
 
+#define YGZ_MINI_CV 1   // (lets code that must look inside cv::Mat -- the reference count -- tell this stand-in from a real OpenCV)
 // 8-bit single-channel matrix header over a shared buffer (views: rowRange / colRange / operator()(Rect) keep the parent's step)
 class Mat {
 public:
@@ -129,6 +130,7 @@ public:
         return *this;
     }
     void release() { buf.reset(); rows = cols = 0; data = nullptr; }
+    int use_count() const { return buf ? (int) buf.use_count() : 0; }   // what cv::Mat::u->refcount (OpenCV >= 3) / *cv::Mat::refcount (2.4) tell
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     int type() const { return CV_8UC1; }
     bool isContinuous() const { return rows <= 1 || step.p[0] == (size_t) cols * elem; }

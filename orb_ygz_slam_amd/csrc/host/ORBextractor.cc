@@ -81,18 +81,35 @@ ygzf_ctx *ORBextractor::ResidentContext(const cv::Mat &level0) const {
     return mCtx;
 }
 
+cv::Mat ORBextractor::acquireLevel(int level, int rows, int cols) {
+    constexpr size_t kGenerations = 4;   // the pyramid in mvImagePyramid, the one a caller may still be cloning from, and slack
+    if ((int) mLevelPool.size() < nlevels) mLevelPool.resize(nlevels);
+    std::vector<cv::Mat> &pool = mLevelPool[level];
+    for (size_t i = 0; i < pool.size(); i++) {
+        if (pool[i].rows != rows || pool[i].cols != cols) {                 // another image size: drop the entry (its buffer lives on with whoever holds it)
+            pool.erase(pool.begin() + i--);
+            continue;
+        }
+        if (ygz_compat::mat_refcount(pool[i]) == 1) return pool[i];      // only the pool refers to it
+    }
+    cv::Mat m(rows, cols, CV_8UC1);
+    if (pool.size() < kGenerations) pool.push_back(m);
+    return m;
+}
+
 void ORBextractor::ComputePyramid(cv::Mat image) {
     if (image.empty()) return;
     ygzf_ctx *c = ensureContext(image.cols, image.rows);
     if (!c) return;
     std::vector<uint8_t *> out(nlevels);
+    mResidentLevel0 = cv::Mat();
     for (int l = 0; l < nlevels; l++) {
         int lw, lh;
         ygzf_level_size(c, image.cols, image.rows, l, &lw, &lh);
-        mvImagePyramid[l] = cv::Mat(lh, lw, CV_8UC1);   // fresh buffer: Frames keep (shared) references to earlier levels
+        mvImagePyramid[l] = cv::Mat();                  // this pyramid's own hold on its previous level buffer goes first
+        mvImagePyramid[l] = acquireLevel(l, lh, lw);    // a buffer nobody else refers to: Frames keep (shared) references to earlier levels
         out[l] = mvImagePyramid[l].data;
     }
-    mResidentLevel0 = cv::Mat();
     mHeldImage = image;
     mVerifiedData = nullptr;
     {   // extract-ahead follows the tracker's habit: on when the previous pyramid's image was extracted, off when it was not

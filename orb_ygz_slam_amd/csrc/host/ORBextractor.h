@@ -115,6 +115,11 @@ private:
     // them, no hash, nothing to collide -- the first time a buffer is asked about, and by that buffer's address afterwards.
     cv::Mat mHeldImage;
     mutable const void *mVerifiedData = nullptr;
+    // Level buffers of earlier pyramids, handed out again by ComputePyramid once nobody but this pool refers to them (cv::Mat's own reference
+    // count decides: a Frame or KeyFrame that kept a header keeps the buffer).  A fresh 752x480 pyramid is 1.1 MB of never-touched pages:
+    // ~270 page faults, more than the pyramid kernel takes -- a recycled buffer has none.
+    cv::Mat acquireLevel(int level, int rows, int cols);
+    std::vector<std::vector<cv::Mat>> mLevelPool;   // [level] -> a few generations
 };
 
 }  // namespace ygz

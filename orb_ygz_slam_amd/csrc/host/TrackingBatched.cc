@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../../include/ygzf.h"
@@ -41,6 +42,35 @@ struct MaxDistanceTag {
 };
 template struct MemberOf<MaxDistanceTag, &ygz::MapPoint::mfMaxDistance>;
 inline float max_distance(ygz::MapPoint *mp) { return mp->*member_ptr(MaxDistanceTag()); }
+// MapPoint::GetDescriptor() returns mDescriptor.clone(): one heap allocation per MapPoint, a thousand per frame (the reference's own loop pays
+// them only for the points in view).  The 32 bytes are read in place instead, under the MapPoint's own feature mutex -- the lock GetDescriptor and
+// Observations take (src/MapPoint.cc:80-86, :127-130) -- together with the observation count.
+#ifdef YGZ_STUB_MAPPOINT   // this repository's boundary build: the MapPoint stand-in of oracle/ref_shim has no mutexes and its GetDescriptor() does not clone
+inline void descriptor_and_observations(ygz::MapPoint *mp, uint8_t *desc32, uint8_t *hasObs) {
+    const cv::Mat d = mp->GetDescriptor();
+    if (!d.empty()) std::memcpy(desc32, d.ptr<uint8_t>(0), 32);
+    else std::memset(desc32, 0, 32);
+    *hasObs = mp->Observations() > 0;
+}
+#else
+struct DescriptorTag {
+    typedef cv::Mat ygz::MapPoint::*type;
+    friend type member_ptr(DescriptorTag);
+};
+template struct MemberOf<DescriptorTag, &ygz::MapPoint::mDescriptor>;
+struct FeatureMutexTag {
+    typedef std::mutex ygz::MapPoint::*type;
+    friend type member_ptr(FeatureMutexTag);
+};
+template struct MemberOf<FeatureMutexTag, &ygz::MapPoint::mMutexFeatures>;
+inline void descriptor_and_observations(ygz::MapPoint *mp, uint8_t *desc32, uint8_t *hasObs) {
+    std::unique_lock<std::mutex> lock(mp->*member_ptr(FeatureMutexTag()));
+    const cv::Mat &d = mp->*member_ptr(DescriptorTag());
+    if (!d.empty()) std::memcpy(desc32, d.ptr<uint8_t>(0), 32);
+    else std::memset(desc32, 0, 32);
+    *hasObs = mp->nObs > 0;
+}
+#endif
 
 inline int device() { return ygz::ORBextractor::sDevice; }
 
@@ -50,7 +80,9 @@ struct FrustumPack {   // the MapPoint fields Frame::isInFrustum reads (src/Fram
     ygzf_frustum_in in;
     void gather(const std::vector<ygz::MapPoint *> &pts, const std::vector<uint8_t> &candidate, ygz::Frame &F) {
         const size_t n = pts.size();
-        world.assign(3 * n, 0.f); normal.assign(3 * n, 0.f); maxInv.assign(n, 0.f); minInv.assign(n, 0.f); maxDist.assign(n, 0.f);
+        // (entries of points that are not candidates are never read: the device tests the candidate flag first -- no zero fill, and the pack
+        // itself is kept from frame to frame by its callers, so the steady state allocates nothing)
+        world.resize(3 * n); normal.resize(3 * n); maxInv.resize(n); minInv.resize(n); maxDist.resize(n);
         cand = candidate;
         for (size_t i = 0; i < n; i++) {
             if (!cand[i]) continue;
@@ -139,17 +171,24 @@ void Tracking::SearchLocalPoints() {
     if (mSensor == System::RGBD) th = 3;
     if (mCurrentFrame.mnId < mnLastRelocFrameId + 2) th = 5;
     if (mbDirectFailed) th = 5;
-    FrustumPack fp;
+    // scratch of this thread's calls, kept from frame to frame (fifteen vectors of a thousand entries were allocated and zeroed per call)
+    struct Scratch {
+        FrustumPack fp;
+        std::vector<uint8_t> hasObs, mpdesc, owner, inView;
+        std::vector<float> px, py, pxr, vc;
+        std::vector<int> lvl, match;
+    };
+    static thread_local Scratch S;
+    FrustumPack &fp = S.fp;
     fp.gather(mvpLocalMapPoints, cand, mCurrentFrame);
-    std::vector<uint8_t> hasObs(M, 0), mpdesc((size_t) M * 32, 0);
+    std::vector<uint8_t> &hasObs = S.hasObs, &mpdesc = S.mpdesc;
+    hasObs.resize(M); mpdesc.resize((size_t) M * 32);
     for (int i = 0; i < M; i++) {
-        if (!cand[i]) continue;
-        MapPoint *pMP = mvpLocalMapPoints[i];
-        hasObs[i] = pMP->Observations() > 0;
-        const cv::Mat d = pMP->GetDescriptor();
-        std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
+        if (!cand[i]) { hasObs[i] = 0; continue; }
+        descriptor_and_observations(mvpLocalMapPoints[i], &mpdesc[(size_t) i * 32], &hasObs[i]);
     }
-    std::vector<uint8_t> owner(std::max(nt, 1), 0), cdescHold;
+    std::vector<uint8_t> &owner = S.owner, cdescHold;
+    owner.assign(std::max(nt, 1), 0);
     for (int i = 0; i < nt; i++) {
         MapPoint *mp = mCurrentFrame.mvpMapPoints[i];
         owner[i] = mp ? (mp->Observations() > 0 ? 2 : 1) : 0;
@@ -171,9 +210,13 @@ void Tracking::SearchLocalPoints() {
     fv.scale_factors = mCurrentFrame.mvScaleFactors.data();
     fv.nlevels = (int) mCurrentFrame.mvScaleFactors.size();
     const ygzf_camera cam = camera_of(mCurrentFrame);
-    std::vector<uint8_t> inView(M, 0);
-    std::vector<float> px(M), py(M), pxr(M), vc(M);
-    std::vector<int> lvl(M), match(std::max(nt, 1), -1);
+    std::vector<uint8_t> &inView = S.inView;
+    std::vector<float> &px = S.px, &py = S.py, &pxr = S.pxr, &vc = S.vc;
+    inView.assign(M, 0);
+    px.resize(M); py.resize(M); pxr.resize(M); vc.resize(M);
+    std::vector<int> &lvl = S.lvl, &match = S.match;
+    lvl.resize(M);
+    match.assign(std::max(nt, 1), -1);
     int nmatches = 0;
     ygzf_host::Lease lease(device());
     if (!lease) return;

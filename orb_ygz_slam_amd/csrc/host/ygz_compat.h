@@ -29,6 +29,17 @@ inline void se3_to_Rt(const SE3f &T, float R[9], float t[3]) {
     for (int r = 0; r < 3; r++) t[r] = T.translation()[r];
 }
 inline void world_pos(ygz::MapPoint *mp, float o[3]) { const Vector3f p = mp->GetWorldPos(); o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+// how many cv::Mat headers share m's buffer (0: no buffer of its own / external data): the level pool of ORBextractor::ComputePyramid hands a
+// buffer out again only when nobody but the pool refers to it
+inline int mat_refcount(const cv::Mat &m) {
+#if defined(YGZ_MINI_CV)
+    return m.use_count();
+#elif defined(CV_MAJOR_VERSION) && CV_MAJOR_VERSION >= 3
+    return m.u ? (int) m.u->refcount : 0;
+#else
+    return m.refcount ? *m.refcount : 0;
+#endif
+}
 }  // namespace ygz_compat
 #else  // ---------------------------------------------------------------------------------------------- stand-alone shim
 #include <cstdint>
@@ -73,6 +84,7 @@ public:
     unsigned char *ptr(int r = 0) { return data + (size_t) r * step; }
     const unsigned char *ptr(int r = 0) const { return data + (size_t) r * step; }
     Mat row(int r) const { Mat m(1, cols, type_, (void *) (data + (size_t) r * step), step); m.hold_ = hold_; return m; }
+    int refcount() const { return hold_ ? (int) hold_.use_count() : 0; }   // (stand-in for cv::Mat::u->refcount)
     Mat clone() const {
         Mat m(rows, cols, type_);
         for (int r = 0; r < rows; r++) std::memcpy(m.ptr(r), ptr(r), (size_t) cols * esz(type_));
@@ -194,6 +206,7 @@ public:
 }  // namespace ygz
 
 namespace ygz_compat {
+inline int mat_refcount(const cv::Mat &m) { return m.refcount(); }
 inline void se3_to7(const ygz::SE3f &T, float o[7]) { std::memcpy(o, T.q, 16); std::memcpy(o + 4, T.t, 12); }
 inline ygz::SE3f se3_from7(const float i[7]) { ygz::SE3f T; std::memcpy(T.q, i, 16); std::memcpy(T.t, i + 4, 12); return T; }
 inline void se3_to_Rt(const ygz::SE3f &T, float R[9], float t[3]) {  // Eigen Quaternion::toRotationMatrix

@@ -1524,6 +1524,7 @@ __global__ void k_frustum(FrustumArgs A) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     A.inView[i] = 0;
+    A.level[i] = 0;            // (the matcher indexes scaleFactors[level] only for in-view points; callers get 0 for the others -- no memset launch)
     if (A.candidate && !A.candidate[i]) return;
     const float *P = A.world + 3 * (size_t) i;
     const float PcX = (A.Rcw[0] * P[0] + A.Rcw[1] * P[1] + A.Rcw[2] * P[2]) + A.tcw[0];

@@ -1541,13 +1541,36 @@ int ygzf_batch_fetch_all(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int *n_kp, in
     return YGZF_OK;
 }
 
+// Results of frame 0 of a one-frame extraction with ONE synchronisation: the count and the frame's whole keypoint / descriptor rows (kpStride
+// entries, ~60 KB: a microsecond on the link) come back together through the page-locked staging area, the first n entries go on to the
+// caller.  ygzf_batch_fetch reads the count, waits, then copies exactly n entries and waits again: two host wake-ups of 10-20 us each, which
+// is what a Tracking thread's ORBextractor::operator() spent beside 74 us of kernels.
+static int fetch_frame0_packed(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
+    const size_t ks = (size_t) c->geo.kpStride;
+    if (ks == 0) { *n_out = 0; return YGZF_OK; }
+    const size_t oK = 256, oD = oK + ((ks * sizeof(ygzf_kp) + 255) & ~(size_t) 255), total = oD + ks * 32;
+    int rc = ensure_stage(c, total + 256);
+    if (rc) return rc;
+    HIPCHECK(c, hipMemcpyAsync(c->hStage, (int *) c->dOutCnt.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->hStage + oK, (ygzf_kp *) c->dOutKp.p + ks, ks * sizeof(ygzf_kp), hipMemcpyDeviceToHost, c->stream));   // slot 1 = frame 0
+    HIPCHECK(c, hipMemcpyAsync(c->hStage + oD, (uint8_t *) c->dOutDesc.p + ks * 32, ks * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const int n = *(const int *) c->hStage;
+    *n_out = n;
+    if (n == 0) return YGZF_OK;
+    if (n > cap || !kps || !desc) return fail(c, YGZF_ERR_INVALID, "capacity %d < %d keypoints", cap, n);
+    memcpy(kps, c->hStage + oK, sizeof(ygzf_kp) * (size_t) n);
+    memcpy(desc, c->hStage + oD, (size_t) 32 * n);
+    return YGZF_OK;
+}
+
 int ygzf_extract(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
     if (!c || !n_out) return fail(c, YGZF_ERR_INVALID, "null argument");
     *n_out = 0;
     if (!img || w <= 0 || h <= 0) return YGZF_OK;  // reference: `if (_image.empty()) return;`
     int rc = ygzf_extract_batch_host(c, img, 1, w, h, stride, 0);
     if (rc) return rc;
-    return ygzf_batch_fetch(c, 0, kps, desc, cap, n_out);
+    return fetch_frame0_packed(c, kps, desc, cap, n_out);
 }
 
 int ygzf_extract_resident(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap, int *n_out) {
@@ -1568,7 +1591,7 @@ int ygzf_extract_resident(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap, int
         c->aheadPending = false;
         c->pyrResident = false;
     } else if ((rc = run_extract(c, fs, 1, true))) return rc;
-    return ygzf_batch_fetch(c, 0, kps, desc, cap, n_out);
+    return fetch_frame0_packed(c, kps, desc, cap, n_out);
 }
 
 int ygzf_batch_fetch_level(ygzf_ctx *c, int frame, int level, uint8_t *out) {
@@ -2780,7 +2803,6 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
         FA.projXR = (float *) P.d_out(rPXR);
         FA.viewCos = (float *) P.d_out(rVC);
         FA.level = (int *) P.d_out(rLv);
-        HIPCHECK(c, hipMemsetAsync(FA.level, 0, nq * 4, c->stream));   // the matcher indexes scaleFactors[level] only for in-view points
         {
             ProfScope ps(c, KK_FRUSTUM);
             launch_frustum(c->stream, FA);

@@ -45,8 +45,8 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     assert len(lat) == 4
     tri = [l for l in out.stdout.splitlines() if l.startswith("info search_for_triangulation")]
     assert len(tri) == 2 and int(tri[0].split()[5]) >= 50, tri      # device pairs == the reference's own body (the driver exits 7 otherwise)
-    os.makedirs(os.path.join(ROOT, "gpurun_out", "r04"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04", "boundary_latency.txt"), "w") as fh:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "boundary_latency.txt"), "w") as fh:
         fh.write("# tests/cpp/boundary_frame: the reference's own loop bodies (per-call members) against the batch bindings of TrackingBatched.cc, 752x480, ~1000 local points\n")
         fh.write("\n".join(lat) + "\n")
     for l in lat:

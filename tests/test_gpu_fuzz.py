@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 NSEEDS = int(os.environ.get("YGZF_FUZZ_SEEDS", "32"))
 SEEDS = range(NSEEDS)
 SEEDS_HEAVY = range(max(NSEEDS // 4, 4))
+SEEDS_ALIGN = range(NSEEDS)            # the aligner's well-conditioned / ill-conditioned split is reported as a fraction: enough cases to be one
 ALIGN_STATS = {"well": 0, "ill": 0, "worst_well": 0.0}
 
 
@@ -262,7 +263,7 @@ def test_fuzz_frustum_and_distinctive(oracle, seed):
     assert (ex.distinctive_descriptors_batch(off, desc) == oracle.distinctive_descriptors(off, desc)).all()
 
 
-@pytest.mark.parametrize("seed", SEEDS_HEAVY)
+@pytest.mark.parametrize("seed", SEEDS_ALIGN)
 def test_fuzz_sparse_img_align(oracle, seed):
     """SparseImgAlign::run with random motions, level ranges, iteration counts, feature budgets and invalid / outlier MapPoints: bit-identical to the
     oracle's device-order mode, within 1e-5 of its reference-order mode on well-conditioned problems, same measurement count."""

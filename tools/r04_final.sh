@@ -15,7 +15,7 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_default.js
 timeout 600 bash tools/round_numbers.sh > $OUT/${TAG}_round_numbers.txt 2>&1
 timeout 300 python -m pytest tests/test_gpu_shells.py tests/test_gpu_boundary.py -x -q -k "latency or reference_frame" > $OUT/shells.log 2>&1
 cp gpurun_out/shell_latency.txt $OUT/${TAG}_shell_latency.txt
-cp gpurun_out/r04/boundary_latency.txt $OUT/${TAG}_boundary_latency.txt
+cp gpurun_out/boundary_latency.txt $OUT/${TAG}_boundary_latency.txt
 tail -3 $OUT/shells.log
 python - <<PY
 import json
