@@ -228,12 +228,12 @@ def cpu_baseline_reference(frames, cfg, seconds_budget=6.0):
 class Pipeline:
     """One device's share of the work: `streams` extractor contexts, a resident clip of rounds x streams x sub frames."""
 
-    def __init__(self, device, workload, sub, rounds, streams, seed0, align=False, stereo=False, distinct=None, frames=None, passes=1):
+    def __init__(self, device, workload, sub, rounds, streams, seed0, align=False, stereo=False, distinct=None, frames=None, passes=1, match=True):
         import torch
         from orb_ygz_slam_amd import Extractor, make_camera
         self.cfg = WORKLOADS[workload]
         w, h, nl, sf, nf, ini, mn = self.cfg
-        self.device, self.sub, self.rounds, self.S, self.align, self.stereo = device, sub, rounds, streams, align, stereo
+        self.device, self.sub, self.rounds, self.S, self.align, self.stereo, self.match = device, sub, rounds, streams, align, stereo, match
         D = streams * sub if distinct is None else distinct          # distinct synthetic frames; the resident batch tiles them
         self.frames = make_frames(D, w, h, seed0=seed0) if frames is None else frames
         D = len(self.frames)
@@ -251,7 +251,8 @@ class Pipeline:
 
     def launch(self, e, ptr):
         e.extract_batch_device(ptr, self.sub, self.w, self.h)
-        e.match_batch_prev(self.cam, 15.0, True, True, True)
+        if self.match:
+            e.match_batch_prev(self.cam, 15.0, True, True, True)
         if self.align:
             e.align_batch_prev(self.cam, self.nl - 1, 1, 10)
         if self.stereo:
@@ -421,7 +422,7 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
 
 def one_unit_kernels(device, wl, unit, stereo):
     """Kernel breakdown (HIP events, us per launch) of one resident step over ONE frame / ONE stereo pair of the workload."""
-    p = Pipeline(device, wl, unit, 1, 1, 7100, False, stereo, distinct=unit)
+    p = Pipeline(device, wl, unit, 1, 1, 7100, False, stereo, distinct=unit, match=False)   # (these configurations extract; the pair form adds ComputeStereoMatches)
     for _ in range(3):
         p.step()
     p.sync()

@@ -102,8 +102,11 @@ SE3f SE3f::Exp(const float a[6]) {  // se3.hpp:406-428
     if (theta < kSophusEps) {
         r.RotationMatrix(V);
     } else {
-        const float c1 = (1.f - std::cos(theta)) / theta_sq;
-        const float c2 = (theta - std::sin(theta)) / (theta_sq * theta);
+        // se3.hpp:419-422: `Scalar theta_sq = theta*theta;` -- the SQUARE OF THE ROOT, not omega.squaredNorm() (they differ in the last bit now
+        // and then; found by tests/test_ref_sophus.py, which runs the reference's own header beside this function)
+        const float theta_sq2 = theta * theta;
+        const float c1 = (1.f - std::cos(theta)) / theta_sq2;
+        const float c2 = (theta - std::sin(theta)) / (theta_sq2 * theta);
         for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * O[i] + c2 * O2[i];
     }
     for (int i = 0; i < 3; i++) r.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];

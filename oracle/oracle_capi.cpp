@@ -392,6 +392,12 @@ void yo_se3_inverse(const float a7[7], float out7[7]) {
     std::memcpy(out7, r.q, 16);
     std::memcpy(out7 + 4, r.t, 12);
 }
+void yo_se3_act(const float a7[7], const float p3[3], float out3[3]) {
+    SE3f a;
+    std::memcpy(a.q, a7, 16);
+    std::memcpy(a.t, a7 + 4, 12);
+    a.Act(p3, out3);
+}
 
 struct yo_align_frame {
     int N;

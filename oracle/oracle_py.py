@@ -645,6 +645,28 @@ def sparse_img_align(ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, 
     return int(ret), out7, info, H.reshape(6, 6)
 
 
+_ref_sophus = None
+
+
+def ref_sophus_lib():
+    """oracle/_ref/libref_sophus.so: the reference's own Thirdparty/sophus headers over ref_shim/eigen_min (None when oracle/_ref was never built)."""
+    global _ref_sophus
+    if _ref_sophus is None:
+        build()
+        p = os.path.join(_HERE, "_ref", "libref_sophus.so")
+        if not os.path.exists(p):
+            return None
+        _ref_sophus = C.CDLL(p)
+    return _ref_sophus
+
+
+def se3_act(a7, p3):
+    a, p = np.ascontiguousarray(a7, np.float32), np.ascontiguousarray(p3, np.float32)
+    out = np.zeros(3, np.float32)
+    lib().yo_se3_act(_p(a), _p(p), _p(out))
+    return out
+
+
 def se3_exp(a6):
     a = np.ascontiguousarray(a6, np.float32)
     out = np.zeros(7, np.float32)

@@ -258,8 +258,9 @@ __device__ __forceinline__ Se3 se3_exp_wave(const float a[6], int lane) {
     if (small_angle) {
         quat_to_R(r.q, V);
     } else {
-        const float c1 = (1.f - cos_th) / theta_sq;
-        const float c2 = (theta - sin_th) / (theta_sq * theta);
+        const float theta_sq2 = theta * theta;   // se3.hpp:419: the square of the root, not the squared norm above
+        const float c1 = (1.f - cos_th) / theta_sq2;
+        const float c2 = (theta - sin_th) / (theta_sq2 * theta);
         for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.f : 0.f) + c1 * O[i] + c2 * O2[i];
     }
     for (int i = 0; i < 3; i++) r.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];

@@ -23,7 +23,8 @@ struct ygzf_mgpu {
     struct Dev {
         int device = 0;
         ygzf_ctx *ctx[2] = {nullptr, nullptr};   // chunks alternate between them: the upload of one overlaps the kernels of the other
-        uint8_t *hIn[2] = {nullptr, nullptr};    // page-locked: the frames of one chunk, tight (used when the caller's frames are pageable)
+        uint8_t *hIn[3] = {nullptr, nullptr, nullptr};   // page-locked: the frames of one chunk at the device's row pitch (used when the caller's frames are pageable);
+                                                         // three, so that chunk k + 2 is gathered while chunk k's upload may still be reading its own
         ygzf_kp *hKp[2] = {nullptr, nullptr};    // page-locked: results of one chunk
         uint8_t *hDesc[2] = {nullptr, nullptr};
         int *hCnt[2] = {nullptr, nullptr};
@@ -115,6 +116,11 @@ int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg
         if (numa) d.haveCpus = numa_cpus_of_device(devices[i], &d.cpus);
         const size_t F = (size_t) m->chunk;
         if (hipSetDevice(devices[i]) != hipSuccess) { ygzf_mgpu_destroy(m); return YGZF_ERR_HIP; }
+        if (hipHostMalloc((void **) &d.hIn[2], F * (size_t) ygzf_host_row_pitch(max_width) * max_height) != hipSuccess) {
+            (void) hipGetLastError();
+            ygzf_mgpu_destroy(m);
+            return YGZF_ERR_HIP;
+        }
         for (int b = 0; b < 2; b++) {
             if (hipHostMalloc((void **) &d.hIn[b], F * (size_t) ygzf_host_row_pitch(max_width) * max_height) != hipSuccess || hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
                 hipHostMalloc((void **) &d.hDesc[b], F * m->stride * 32) != hipSuccess || hipHostMalloc((void **) &d.hCnt[b], F * sizeof(int)) != hipSuccess ||
@@ -136,10 +142,12 @@ void ygzf_mgpu_destroy(ygzf_mgpu *m) {
             if (d.ctx[b]) ygzf_destroy(d.ctx[b]);
         bool any = false;
         for (int b = 0; b < 2; b++) any = any || d.hIn[b] || d.hKp[b] || d.hDesc[b] || d.hCnt[b] || d.hAux[b];
+        any = any || d.hIn[2];
         if (!any) continue;   // a slot whose contexts were never created (e.g. a device index that does not exist)
         (void) hipSetDevice(d.device);
         for (int b = 0; b < 2; b++) {
             if (d.hIn[b]) (void) hipHostFree(d.hIn[b]);
+            if (b == 0 && d.hIn[2]) (void) hipHostFree(d.hIn[2]);
             if (d.hKp[b]) (void) hipHostFree(d.hKp[b]);
             if (d.hDesc[b]) (void) hipHostFree(d.hDesc[b]);
             if (d.hCnt[b]) (void) hipHostFree(d.hCnt[b]);
@@ -246,7 +254,7 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         const int sp = ygzf_host_row_pitch(w);   // the staging area carries the device's row pitch: a chunk goes up as whole frames, not row by row
         auto prepare = [&](int k) {      // pageable frames: gather chunk k into its page-locked staging area
             if (pinned) return;
-            const int b = k & 1;
+            const int b = k % 3;
             parallel(cnt(k), [&](int j) {
                 const uint8_t *src = J.frames + (size_t) fr[lo(k) + j] * J.frame_stride;
                 uint8_t *dst = d.hIn[b] + (size_t) j * h * sp;
@@ -261,7 +269,7 @@ int run_job(ygzf_mgpu *m, const Job &J) {
                 for (int j = 0; j < cnt(k); j++) ptrs[j] = J.frames + (size_t) fr[lo(k) + j] * J.frame_stride;
                 rc = ygzf_extract_batch_host_frames(cx(k), ptrs.data(), cnt(k), w, h, J.row_pitch);
             } else
-                rc = ygzf_extract_batch_host(cx(k), d.hIn[b], cnt(k), w, h, sp, (size_t) sp * h);
+                rc = ygzf_extract_batch_host(cx(k), d.hIn[k % 3], cnt(k), w, h, sp, (size_t) sp * h);
             if (rc == YGZF_OK && J.mode == kMatch) rc = ygzf_match_batch_prev(cx(k), J.cam, J.th, J.b_mono, J.check_level, J.check_orientation);
             if (rc == YGZF_OK && J.mode == kStereo) rc = ygzf_stereo_batch(cx(k), J.mb, J.mbf);
             if (rc != YGZF_OK) d.err = ygzf_last_error(cx(k));
@@ -310,13 +318,26 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         };
         prepare(0);
         int rc = launch(0);
-        for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
-            const bool more = k + 1 < nChunks;
-            if (more) prepare(k + 1);                            // the device works on chunk k meanwhile
-            if (more && alternate) rc = launch(k + 1);           // the other context: its upload runs beside chunk k's kernels
-            if (rc == YGZF_OK) rc = fetch(k);
-            if (rc == YGZF_OK && more && !alternate) rc = launch(k + 1);   // one context: its outputs had to be read first
-            if (rc == YGZF_OK) scatter(k);                       // the device works on chunk k + 1 meanwhile
+        if (alternate) {
+            // Two contexts: chunk k + 1 is queued (upload, kernels) before chunk k is waited for, and the moment chunk k's results are in the staging
+            // area its context takes chunk k + 2 -- BEFORE the host copies those results out: the link, which bounds the whole call, then never waits
+            // for a host-side copy (scattering a chunk of 128 frames is 8 MB of memcpy, gathering a pageable one 46 MB: with either between two
+            // uploads the entry point reached 127 k frames/s where the bare two-context pipeline does 153 k).
+            if (nChunks > 1 && rc == YGZF_OK) { prepare(1); rc = launch(1); }
+            for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
+                if (k + 2 < nChunks) prepare(k + 2);             // into the third staging area, while the device works on chunks k and k + 1
+                rc = fetch(k);
+                if (rc == YGZF_OK && k + 2 < nChunks) rc = launch(k + 2);
+                if (rc == YGZF_OK) scatter(k);
+            }
+        } else {
+            for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
+                const bool more = k + 1 < nChunks;
+                if (more) prepare(k + 1);                        // the device works on chunk k meanwhile
+                if (rc == YGZF_OK) rc = fetch(k);
+                if (rc == YGZF_OK && more) rc = launch(k + 1);   // one context: its outputs had to be read first
+                if (rc == YGZF_OK) scatter(k);                   // the device works on chunk k + 1 meanwhile
+            }
         }
         if (rc != YGZF_OK) {                                     // leave no copy in flight behind the caller's frames
             (void) ygzf_sync(d.ctx[0]);
