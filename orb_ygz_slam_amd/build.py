@@ -7,7 +7,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SRCS = ["csrc/extract_kernels.hip", "csrc/match_kernels.hip", "csrc/align_kernels.hip", "csrc/fast10_kernels.hip", "csrc/dso_kernels.hip", "csrc/stereo_kernels.hip", "csrc/direct_kernels.hip", "csrc/ygzf_api.hip", "csrc/ygzf_mgpu.hip"]
+SRCS = ["csrc/extract_kernels.hip", "csrc/match_kernels.hip", "csrc/align_kernels.hip", "csrc/fast10_kernels.hip", "csrc/dso_kernels.hip", "csrc/stereo_kernels.hip", "csrc/direct_kernels.hip", "csrc/ygzf_api.hip", "csrc/ygzf_api_match.hip", "csrc/ygzf_api_align.hip", "csrc/ygzf_api_detect.hip",
+        "csrc/ygzf_api_stereo.hip", "csrc/ygzf_mgpu.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-ffp-contract=off",                               # bit-exact float paths: no FMA contraction
          "-fhip-fp32-correctly-rounded-divide-sqrt",        # IEEE division in fastAtan2

@@ -1,0 +1,333 @@
+// ygzf_ctx.h -- the context of libygzf and the small helpers every translation unit of the C ABI shares (product code, internal: nothing here
+// is part of include/ygzf.h).  The entry points live in
+//   ygzf_api.hip         context, geometry tables, buffers, the extractor's launch sequence, batch fetches, timers / profile
+//   ygzf_api_match.hip   ORBmatcher: SearchByProjection / SearchByBoW / SearchForInitialization / SearchForTriangulation, the Frame grid, isInFrustum,
+//                        distinctive descriptors, the vocabulary
+//   ygzf_api_align.hip   SparseImgAlign (one pair, cached, resident batch), the image cache, FindDirectProjection
+//   ygzf_api_detect.hip  Thirdparty/fast replacement, DSO / FAST_KEYPOINT detectors, descriptors of existing keys
+//   ygzf_api_stereo.hip  Frame::ComputeStereoMatches
+#ifndef YGZF_CTX_H
+#define YGZF_CTX_H
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+
+#include "kernels.h"
+
+#define YGZF_HIDDEN __attribute__((visibility("hidden")))
+
+namespace ygzf {
+YGZF_HIDDEN int cv_round_host(double v);
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_GRID, KK_FASTQ, KK_TRI, KK_COUNT };
+static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_tab", "k_octree", "k_describe", "k_hamming_pairs",
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes", "k_features_in_area", "k_fast_quads", "k_tri_nodes"};
+
+struct Geometry {
+    int w = 0, h = 0;
+    std::vector<LevelGeom> lv;
+    std::vector<int> xofs, yofs;
+    std::vector<short> xalpha, ybeta;
+    long long pyrBytes = 0;   // per frame, levels >= 1
+    std::vector<PyrStripPlan> pyrPlan;   // k_pyr_strips: one entry per strip (empty: this geometry takes one launch per level)
+    int pyrStripOffCol = 0, pyrStripOffA = 0, pyrStripOffB = 0;
+    PyrStripLevel pyrLevels[kMaxLevels];
+    size_t pyrStripLds = 0;
+    int totalCells = 0, maxCellsPerLevel = 0;
+    int totalGroups = 0, fastSmapRows = 3, fastWinPitch = 16, fastWinRows = 7, fastQuadCap = 4;   // 2x2 cell groups of k_fast_quads
+    int fastWCellMax = 1;
+    std::vector<FastCellRec> fastCells;   // [group * 4 + position]: k_fast_tab's per-cell records
+    long long totalSlots = 0;
+    long long candStride = 0;
+    int kpStride = 0, kpCapMax = 0;
+};
+
+}  // namespace ygzf
+
+using namespace ygzf;
+
+struct ygzf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Tables tab;
+    int maxW = 0, maxH = 0, maxBatch = 0;
+    Geometry geo;
+    std::string err;
+    // device buffers (grow-only)
+    struct Buf {
+        void *p = nullptr;
+        size_t bytes = 0;
+    };
+    Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
+        dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dStBins, dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan;
+    int vocNodes = 0, vocLevels = 0;
+    int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
+    long long cachePyrBytes = 0;
+    std::vector<unsigned char> cacheFilled;
+    int lastStereoPairs = 0;
+    bool alignCarry = false;      // keep the last frame's pyramid across batches (enabled by the first ygzf_align_batch_prev)
+    bool carryPyrValid = false;
+    int lastAlignPairs = 0;
+    std::vector<unsigned char> alKey;   // cache key of the uploaded SiaLevel tables
+    bool carryValid = false;
+    int lastMatchPairs = 0;
+    int identityPoses = 0;
+    void *identityPosesPtr = nullptr;
+    size_t octLds = 0;
+    int octLdsCand = 0;
+    bool octGlobalNodes = false;
+    // histogram plan of the octree (levels with tens of thousands of candidates): launches of consecutive levels, each with its own LDS allotment
+    struct OctGroup { int l0 = 0, n = 0, cap = 0, regionInts = 0, histBins = 0; size_t lds = 0; };
+    std::vector<OctGroup> octGroups;
+    OctGroup octSmall;                     // all levels in ONE histogram-plan launch: launches of a few frames (see run_extract)
+    bool haveOctSmall = false;
+    int octSmallWgs = getenv("YGZF_OCT_SMALL_WGS") ? atoi(getenv("YGZF_OCT_SMALL_WGS")) : 128;   // launches of up to this many workgroups take it (A/B runs; 752x480: 16 frames 0.211 against 0.221 ms, 64 frames 0.439 against 0.430)
+    Buf dOctNodes;
+    // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at
+    // minTh, 2 = iniTh first.  Identical results either way.
+    int fastPlan = 0;
+    bool fastIniFirst = false;
+    unsigned fastLaunches = 0;             // statistics are collected on the first launches and on every 8th one after that
+    double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
+    Buf dFastStats;
+    Buf dFastCells;                        // FastCellRec table of the current geometry (k_fast_tab)
+    Buf dMatchStat;                        // one counter: pairs that fell back to the matcher's one-wave pass (ygzf_match_fallbacks)
+    Buf dPack;                             // inputs + outputs of a one-frame entry point, one copy each way (PackedTransfer)
+    int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
+    unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
+    Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
+    bool pyrHeld = false;                  // dImg0 / dPyr frame 0 hold ONE image (pyrHeldW x pyrHeldH) and its complete pyramid (ygzf_image_cache_put_resident)
+    int pyrHeldW = 0, pyrHeldH = 0;
+    hipEvent_t evShare = nullptr, evPyrDone = nullptr;
+    bool evPyrDoneValid = false;
+    bool pyrResident = false;              // dImg0 / dPyr frame 0 hold the image and pyramid of the last ygzf_compute_pyramid (pyrResW x pyrResH)
+    int pyrResW = 0, pyrResH = 0;
+    // one-frame uploads from pageable caller memory (a cv::Mat): the rows are copied into this page-locked, device-visible buffer by the host and
+    // read from there by a kernel that writes them at the context's pitch -- the runtime's own pageable path (pin / stage / blit) cost ~50 us for a
+    // 752x480 frame, this ~25.  evIn marks the moment the kernel has read the buffer (the next upload waits for it before overwriting).
+    uint8_t *hIn = nullptr;                // (one tight frame: at most maxW x maxH bytes, apply_geometry refuses anything larger)
+    void *hInDev = nullptr;
+    size_t hInBytes = 0;
+    hipEvent_t evIn = nullptr;
+    bool evInPending = false;
+    uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
+    size_t hStageBytes = 0;
+    // batch state
+    int lastFrames = 0;
+    FrameSet lastFs{};
+    int img0Pitch = 0;
+    // timing
+    hipEvent_t tStart = nullptr, tStop = nullptr;
+    // ygzf_set_extract_ahead: ygzf_compute_pyramid queues the extraction behind the pyramid and reads the levels back on a second stream
+    // one-frame pyramid chain as a captured graph: seven dependent launches cost the host more than the kernels take (pyramid_chain)
+    bool useGraphs = getenv("YGZF_NO_GRAPH") == nullptr;
+    int pyrStripFrames = getenv("YGZF_PYR_STRIP_FRAMES") ? atoi(getenv("YGZF_PYR_STRIP_FRAMES")) : 16;   // k_pyr_strips up to this many frames per launch (0: never)
+    PyrChainGraph pyrGraph = {};
+    const void *pyrGraphKey[6] = {nullptr};   // geometry tables + size the graph was built for
+    bool extractAhead = false, aheadPending = false;
+    hipStream_t streamCopy = nullptr;
+    hipEvent_t evPyramid = nullptr;
+    // ygzf_set_stream_partition: the latency-bound kernels of the chain (k_octree, k_match_last) on a second stream restricted to a share of the
+    // compute units, so that their long-lived, rarely-issuing workgroups do not take wave slots from the issue-bound kernels of other contexts
+    hipStream_t streamFill = nullptr;
+    int fillCUs = 0, mainMode = 0;
+    hipEvent_t evHop[8] = {nullptr};
+    unsigned hopSeq = 0;
+    bool profile = false;
+    // debugging aids, read once per context (never on the launch path): synchronise after every kernel and name it on stderr /
+    // phase clocks of the octree, matcher and aligner kernels printed to stderr
+    bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
+    int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
+    int matchFixedLanes = getenv("YGZF_MATCH_LANES") && !strcmp(getenv("YGZF_MATCH_LANES"), "fixed");   // (A/B runs)
+    int matchFence = getenv("YGZF_MATCH_FENCE") ? atoi(getenv("YGZF_MATCH_FENCE")) : 0;   // 1: full fences around the matcher's hand-over (A/B runs)
+    int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
+    bool siaPerLevel = !(getenv("YGZF_SIA_PRECOMPUTE") && atoi(getenv("YGZF_SIA_PRECOMPUTE")) == 0);   // reference patches of all levels in a kernel of their own (0: inside k_sia_run, as until round 4)
+    bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
+    struct Rec { int kind; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    float profMs[KK_COUNT] = {0};
+    int profN[KK_COUNT] = {0};
+};
+
+// last failed ygzf_create of THIS thread (the reference constructs its left / right extractors from different threads)
+extern YGZF_HIDDEN thread_local std::string g_create_err;
+
+// Every error return goes through here.  Entry points queue asynchronous uploads from caller-owned or local host arrays and synchronise
+// at their end: an early error return must not leave such a copy in flight behind a source that is about to disappear, so the stream is
+// drained first (errors are not a fast path).
+static int fail(ygzf_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) {
+        if (c->stream) (void) hipStreamSynchronize(c->stream);
+        c->err = buf;
+    } else {
+        g_create_err = buf;
+    }
+    return code;
+}
+
+#define HIPCHECK(c, expr)                                                                                         \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) return fail(c, YGZF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                                    \
+    } while (0)
+
+static int ensure(ygzf_ctx *c, ygzf_ctx::Buf &b, size_t bytes) {
+    if (bytes <= b.bytes) return YGZF_OK;
+    // a buffer that grows loses its contents: whatever ygzf_compute_pyramid left in the image / pyramid buffers is gone with them
+    if (&b == &c->dImg0 || &b == &c->dPyr) { c->pyrResident = false; c->pyrHeld = false; }
+    if (b.p) HIPCHECK(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+    HIPCHECK(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return YGZF_OK;
+}
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static int ensure_stage(ygzf_ctx *c, size_t bytes) {
+    if (bytes <= c->hStageBytes) return YGZF_OK;
+    if (c->hStage) HIPCHECK(c, hipHostFree(c->hStage));
+    c->hStage = nullptr;
+    c->hStageBytes = 0;
+    HIPCHECK(c, hipHostMalloc((void **) &c->hStage, bytes));
+    c->hStageBytes = bytes;
+    return YGZF_OK;
+}
+
+// One-frame entry points hand over a dozen small host arrays and take a few back.  From pageable memory every hipMemcpyAsync is a staged copy
+// of its own (10-20 us of runtime work apiece; twelve of them cost more than the kernel they feed): the arrays are packed into the context's
+// page-locked staging area and cross the link as ONE copy each way.
+// callers with more than this in flight keep their own copies (the staging area is page-locked memory); YGZF_PACKED_MAX (bytes) lowers it so
+// that tests reach the large-transfer paths with ordinary frames
+static const size_t kPackedMax = getenv("YGZF_PACKED_MAX") ? (size_t) atoll(getenv("YGZF_PACKED_MAX")) : (size_t) (4u << 20);
+struct PackedTransfer {
+    ygzf_ctx *c;
+    struct Seg { const void *src; void *dst; size_t bytes, off; };
+    std::vector<Seg> in, out;
+    size_t inBytes = 0, outBytes = 0;
+    explicit PackedTransfer(ygzf_ctx *c_) : c(c_) {}
+    static size_t al(size_t b) { return (b + 255) & ~(size_t) 255; }
+    size_t add_in(const void *src, size_t bytes) { const size_t o = inBytes; in.push_back({src, nullptr, bytes, o}); inBytes += al(bytes); return o; }
+    size_t add_out(void *dst, size_t bytes) { const size_t o = outBytes; out.push_back({nullptr, dst, bytes, o}); outBytes += al(bytes); return o; }
+    // device layout: [inputs | outputs] in c->dPack; returns the base
+    // A transfer beyond kPackedMax (a KeyFrame with tens of thousands of features) does not grow the page-locked staging area: its arrays cross
+    // one by one from / to the caller's own memory -- same device layout, so the kernels' pointers do not care which way the bytes came.
+    bool direct() const { return inBytes + outBytes > kPackedMax; }
+    int upload(uint8_t **dBase) {
+        int rc;
+        if ((rc = ensure(c, c->dPack, inBytes + outBytes + 256))) return rc;
+        if (direct()) {
+            for (const Seg &s : in)
+                if (s.bytes) HIPCHECK(c, hipMemcpyAsync((uint8_t *) c->dPack.p + s.off, s.src, s.bytes, hipMemcpyHostToDevice, c->stream));
+        } else {
+            if ((rc = ensure_stage(c, inBytes + outBytes + 256))) return rc;
+            for (const Seg &s : in)
+                if (s.bytes) memcpy(c->hStage + s.off, s.src, s.bytes);
+            if (inBytes) HIPCHECK(c, hipMemcpyAsync(c->dPack.p, c->hStage, inBytes, hipMemcpyHostToDevice, c->stream));
+        }
+        *dBase = (uint8_t *) c->dPack.p;
+        return YGZF_OK;
+    }
+    uint8_t *d_out(size_t off) const { return (uint8_t *) c->dPack.p + inBytes + off; }
+    int download() {   // one copy back, then scattered to the caller's arrays; synchronises the stream
+        if (direct()) {
+            for (const Seg &s : out)
+                if (s.bytes && s.dst) HIPCHECK(c, hipMemcpyAsync(s.dst, d_out(s.off), s.bytes, hipMemcpyDeviceToHost, c->stream));
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            return YGZF_OK;
+        }
+        if (outBytes) HIPCHECK(c, hipMemcpyAsync(c->hStage + inBytes, (uint8_t *) c->dPack.p + inBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        for (const Seg &s : out)
+            if (s.bytes && s.dst) memcpy(s.dst, c->hStage + inBytes + s.off, s.bytes);
+        return YGZF_OK;
+    }
+};
+
+// ---- per-kernel event bracketing ------------------------------------------------------------------------------------
+static hipEvent_t take_event(ygzf_ctx *c) {
+    if (!c->pool.empty()) {
+        hipEvent_t e = c->pool.back();
+        c->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    ygzf_ctx *c;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    ProfScope(ygzf_ctx *c_, int k, hipStream_t s_ = nullptr) : c(c_), kind(k), s(s_ ? s_ : c_->stream) {
+        if (c->profile) {
+            a = take_event(c);
+            b = take_event(c);
+            (void) hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (c->debugSync) {
+            fprintf(stderr, "[ygzf] %s ...", kKernelNames[kind]);
+            const hipError_t e = hipStreamSynchronize(s);
+            fprintf(stderr, " %s\n", hipGetErrorString(e));
+        }
+        if (c->profile) {
+            (void) hipEventRecord(b, s);
+            c->recs.push_back({kind, a, b});
+        }
+    }
+};
+// The filler stream (ygzf_set_stream_partition): fill_begin makes it wait for everything queued on the context's stream so far and returns it
+// (the context's own stream when there is no partition); fill_end makes the context's stream wait for what was queued on it.  Every hop is
+// closed before an entry point returns, so that synchronising c->stream still drains the whole context.
+static hipStream_t fill_begin(ygzf_ctx *c) {
+    if (!c->streamFill) return c->stream;
+    hipEvent_t e = c->evHop[c->hopSeq++ & 7];
+    (void) hipEventRecord(e, c->stream);
+    (void) hipStreamWaitEvent(c->streamFill, e, 0);
+    return c->streamFill;
+}
+static void fill_end(ygzf_ctx *c) {
+    if (!c->streamFill) return;
+    hipEvent_t e = c->evHop[c->hopSeq++ & 7];
+    (void) hipEventRecord(e, c->streamFill);
+    (void) hipStreamWaitEvent(c->stream, e, 0);
+}
+static void drain_profile(ygzf_ctx *c) {
+    if (c->recs.empty()) return;
+    (void) hipStreamSynchronize(c->stream);
+    for (auto &r : c->recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->profMs[r.kind] += ms;
+            c->profN[r.kind]++;
+        }
+        c->pool.push_back(r.a);
+        c->pool.push_back(r.b);
+    }
+    c->recs.clear();
+}
+
+// ---- defined in ygzf_api.hip, used by the other translation units ---------------------------------------------------------------------
+YGZF_HIDDEN int build_geometry(ygzf_ctx *c, int w, int h, ygzf::Geometry &G);
+YGZF_HIDDEN int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames);
+YGZF_HIDDEN int pyramid_chain(ygzf_ctx *c, const ygzf::FrameSet &fs, int nFrames);
+YGZF_HIDDEN int mark_pyramid_done(ygzf_ctx *c);
+YGZF_HIDDEN int run_extract(ygzf_ctx *c, const ygzf::FrameSet &fs, int nFrames, bool pyramidReady = false, bool pyramidCarried = false);
+YGZF_HIDDEN int upload_rows(ygzf_ctx *c, void *dst, size_t dstPitch, const uint8_t *src, size_t srcPitch, int w, size_t rows);
+YGZF_HIDDEN int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, int row_pitch, size_t frame_stride, ygzf::FrameSet *fs);
+#endif

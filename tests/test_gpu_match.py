@@ -372,7 +372,7 @@ def test_matcher_is_deterministic_over_repeats(oracle):
 
 def test_large_transfers_bypass_the_page_locked_staging():
     """One-frame entry points pack their host arrays into a page-locked staging area that must not grow without bound: beyond kPackedMax the
-    arrays cross one by one from / to the caller's memory (PackedTransfer::direct, csrc/ygzf_api.hip).  With YGZF_PACKED_MAX=4096 every matcher /
+    arrays cross one by one from / to the caller's memory (PackedTransfer::direct, csrc/ygzf_ctx.h).  With YGZF_PACKED_MAX=4096 every matcher /
     BoW / triangulation / aligner call of an ordinary frame takes that path: the suites must hold unchanged."""
     import os
     import subprocess
