@@ -392,7 +392,10 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
     from orb_ygz_slam_amd import MultiGpu, make_camera
     w, h, nl, sf, nf, ini, mn = cfg
     slots = list(devices) if len(devices) > 1 else [devices[0], devices[0]]
-    per = 512                       # frames per slot and call: four chunks of 128 (the call is synchronous: its first upload and last read-back are not overlapped)
+    # frames per slot and call: sixteen chunks of 128.  The call is synchronous -- its first upload and its last kernels / read-back / scatter overlap
+    # nothing -- so its rate depends on its length: 512 frames per slot (round 4's setting) spend a fifth of the call filling and draining the
+    # pipeline (100-127 k frames/s box to box); a recorded sequence handed over whole (EuRoC MH01 has 3682 frames) is the case the entry point is for
+    per = 2048
     n = per * len(slots)
     clip = np.ascontiguousarray(np.concatenate([frames] * ((n + len(frames) - 1) // len(frames)))[:n])
     mg = MultiGpu(slots, nf, sf, nl, ini, mn, max_width=w, max_height=h, max_frames_per_device=per)

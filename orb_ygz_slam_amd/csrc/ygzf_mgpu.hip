@@ -318,7 +318,8 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         };
         prepare(0);
         int rc = launch(0);
-        if (alternate) {
+        static const bool lateLaunch = getenv("YGZF_MGPU_ORDER") && atoi(getenv("YGZF_MGPU_ORDER")) == 0;   // A/B runs: round 4's order (chunk k + 2 queued after chunk k is scattered)
+        if (alternate && !lateLaunch) {
             // Two contexts: chunk k + 1 is queued (upload, kernels) before chunk k is waited for, and the moment chunk k's results are in the staging
             // area its context takes chunk k + 2 -- BEFORE the host copies those results out: the link, which bounds the whole call, then never waits
             // for a host-side copy (scattering a chunk of 128 frames is 8 MB of memcpy, gathering a pageable one 46 MB: with either between two
@@ -334,8 +335,9 @@ int run_job(ygzf_mgpu *m, const Job &J) {
             for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
                 const bool more = k + 1 < nChunks;
                 if (more) prepare(k + 1);                        // the device works on chunk k meanwhile
+                if (more && alternate) rc = launch(k + 1);       // (A/B order only) the other context
                 if (rc == YGZF_OK) rc = fetch(k);
-                if (rc == YGZF_OK && more) rc = launch(k + 1);   // one context: its outputs had to be read first
+                if (rc == YGZF_OK && more && !alternate) rc = launch(k + 1);   // one context: its outputs had to be read first
                 if (rc == YGZF_OK) scatter(k);                   // the device works on chunk k + 1 meanwhile
             }
         }
