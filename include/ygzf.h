@@ -102,6 +102,15 @@ int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
  *                                      REGISTER_STAGING for wider cells) */
 enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_REGISTER_STAGING = 1, YGZF_FAST_KERNEL_CELL_TABLE = 2 };
 int ygzf_set_fast_kernel(ygzf_ctx *ctx, int kernel);
+/* Two-phase corner test of the cell-table form (same cell loop, src/ORBextractor.cc:765-768; the predicate is cv::FAST's 9-of-16, pinned to
+ * Thirdparty/fast/include/fast/corner_9.h): a cheap NECESSARY condition on the eight even ring positions first (four consecutive of them must agree
+ * for any arc of nine), the full bit-sliced test only on the quads that survive, gathered into whole wave steps.  Measured on MI355X it pays only
+ * where the full test is then left with (almost) nothing -- nearly empty frames; a real image with a sixth of its quads surviving is 3 % slower, the
+ * corner-dense synthetic clip 10 %: mode 0 (default) switches it on for such content only, from the statistics earlier launches leave behind, 1 never,
+ * 2 always.  Keypoints are identical under every mode.  ygzf_get_fast_stats: what the next launch will do and the
+ * last sampled statistics (corner-bearing quads per pass-1 run; survivors of the pre-test per run, when it ran); any pointer may be NULL. */
+int ygzf_set_fast_pretest(ygzf_ctx *ctx, int mode);
+int ygzf_get_fast_stats(const ygzf_ctx *ctx, int *pretest_on, float *corner_quads_per_pass, float *survivors_per_pass);
 /* Scheduling knob of the batch chain (no counterpart in the reference, whose ORBextractor::operator() src/ORBextractor.cc:962-1028 and
  * ORBmatcher::SearchByProjection src/ORBmatcher.cc:1218-1350 run on one CPU thread): DistributeOctTree (k_octree, :533-723) and the matcher
  * (k_match_last) are latency-bound -- long-lived workgroups that issue little -- while the cell loop (:747-781), the descriptors and the pyramid

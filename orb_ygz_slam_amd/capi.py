@@ -606,6 +606,18 @@ class Extractor:
         """0 auto (default), 1 register staging (k_fast_quads), 2 cell table + LDS-DMA staging (k_fast_tab) -- same results (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_fast_kernel(self.h, int(kernel)))
 
+    def set_fast_pretest(self, mode):
+        """0 auto (default), 1 never, 2 always: the two-phase corner test of k_fast_tab -- same keypoints (include/ygzf.h)."""
+        self.L.ygzf_set_fast_pretest.argtypes = [C.c_void_p, C.c_int]
+        self._ck(self.L.ygzf_set_fast_pretest(self.h, int(mode)))
+
+    def fast_stats(self):
+        """(pre-test on for the next launch, corner-bearing quads per pass-1 run, pre-test survivors per run) from the last sampled launch"""
+        on, a, b = C.c_int(0), C.c_float(0), C.c_float(0)
+        self.L.ygzf_get_fast_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._ck(self.L.ygzf_get_fast_stats(self.h, C.byref(on), C.byref(a), C.byref(b)))
+        return bool(on.value), a.value, b.value
+
     def set_stream_partition(self, fill_cus, main_mode=0):
         """k_octree / k_match_last on a second stream restricted to fill_cus compute units (-1 unrestricted, 0 off); main_mode 1 restricts the
         context's own stream to the rest (include/ygzf.h)."""

@@ -536,16 +536,34 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
         // threshold plan of this launch: from the statistics of an earlier launch of this context (whatever the asynchronous copy has
         // delivered by now; a stale or half-written snapshot only affects speed -- both plans return the same keypoints)
         {
-            unsigned cells = 0, usedMin = 0, extra = 0, plan = 0;
+            unsigned cells = 0, usedMin = 0, extra = 0, planBits = 0, cornerQuads = 0, survivors = 0, runs = 0;
             const volatile unsigned *hs = c->hFastStats;   // written by the copy engine, possibly right now
             for (int k = 0; k < 64; k++) {
-                cells += hs[4 * k]; usedMin += hs[4 * k + 1]; extra += hs[4 * k + 2]; plan |= hs[4 * k + 3];
+                cells += hs[8 * k]; usedMin += hs[8 * k + 1]; extra += hs[8 * k + 2]; planBits |= hs[8 * k + 3];
+                cornerQuads += hs[8 * k + 4]; survivors += hs[8 * k + 6]; runs += hs[8 * k + 7];
             }
+            const unsigned plan = planBits & 3u;
             if (cells >= 32 && (plan == 1 || plan == 2)) {
                 if (plan == 1) c->fastExtraRounds = (double) extra / cells;   // only the one-pass plan sees every FAST(minTh) corner
                 // a score round costs ~180 vector instructions per wave, a second pass 1 ~700: iniTh first pays when the rounds it saves
                 // outweigh the second passes of the cells that are empty at iniTh
                 c->fastIniFirst = c->fastExtraRounds * 180.0 > ((double) usedMin / cells) * 700.0;
+                // Two-phase pass 1 (fast9_pre_quad).  Measured (profiles/r05_d_fast_pretest_ab.jsonl, 256 frames per launch, isolated): the
+                // corner-dense synthetic clip, 60 of 240 quads surviving per run, 421 -> 463 us; the clip cut from the one real image the
+                // reference ships, 39 survivors (21 corner-bearing quads), 358 -> 370 us -- the cheap test is eleven LDS reads and sixty
+                // vector instructions on EVERY quad and only pays back where the full test then has (almost) nothing to do.  So it is
+                // switched on only for nearly empty content (dark, blank or defocused frames: a handful of corner-bearing quads per cell)
+                // and off again as soon as a launch that ran it reports more than a dozen survivors per run.
+                if (runs > 0) {
+                    const double perRun = (double) cornerQuads / runs;
+                    if (planBits & 4u) {
+                        c->fastPreAuto = (double) survivors / runs <= 12.0;
+                        if (!c->fastPreAuto) c->fastPreRejectedAt = perRun;
+                    } else if (!c->fastPreAuto)
+                        c->fastPreAuto = perRun <= 3.0 && (c->fastPreRejectedAt <= 0.0 || perRun < 0.7 * c->fastPreRejectedAt);
+                    c->fastCornerQuadsPerRun = perRun;
+                    if (planBits & 4u) c->fastSurvivorsPerRun = (double) survivors / runs;
+                }
             }
         }
         const bool iniFirst = c->fastPlan == 2 || (c->fastPlan == 0 && c->fastIniFirst);
@@ -565,7 +583,8 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             if (tab)
                 launch_fast_tab(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                 (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,
-                                nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
+                                nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr,
+                                c->fastPre == 2 || (c->fastPre == 0 && c->fastPlan == 0 && c->fastPreAuto));
             else
                 launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                   (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
@@ -873,6 +892,21 @@ int ygzf_set_fast_plan(ygzf_ctx *c, int plan) {
     if (!c) return YGZF_ERR_INVALID;
     if (plan < YGZF_FAST_PLAN_AUTO || plan > YGZF_FAST_PLAN_INI_FIRST) return fail(c, YGZF_ERR_INVALID, "FAST plan %d (0 auto, 1 one pass, 2 iniTh first)", plan);
     c->fastPlan = plan;
+    return YGZF_OK;
+}
+
+int ygzf_set_fast_pretest(ygzf_ctx *c, int mode) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (mode < 0 || mode > 2) return fail(c, YGZF_ERR_INVALID, "FAST pre-test mode %d (0 auto, 1 never, 2 always)", mode);
+    c->fastPre = mode;
+    return YGZF_OK;
+}
+
+int ygzf_get_fast_stats(const ygzf_ctx *c, int *pretest_on, float *corner_quads_per_pass, float *survivors_per_pass) {
+    if (!c) return YGZF_ERR_INVALID;
+    if (pretest_on) *pretest_on = (c->fastPre == 2 || (c->fastPre == 0 && c->fastPlan == 0 && c->fastPreAuto)) ? 1 : 0;
+    if (corner_quads_per_pass) *corner_quads_per_pass = (float) c->fastCornerQuadsPerRun;
+    if (survivors_per_pass) *survivors_per_pass = (float) c->fastSurvivorsPerRun;
     return YGZF_OK;
 }
 

@@ -93,6 +93,10 @@ struct ygzf_ctx {
     bool fastIniFirst = false;
     unsigned fastLaunches = 0;             // statistics are collected on the first launches and on every 8th one after that
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
+    // two-phase pass 1 of k_fast_tab (fast9_pre_quad): 0 chosen per batch from the statistics, 1 never, 2 always (ygzf_set_fast_pretest)
+    int fastPre = getenv("YGZF_FAST_PRETEST") ? atoi(getenv("YGZF_FAST_PRETEST")) : 0;
+    bool fastPreAuto = false;
+    double fastPreRejectedAt = 0.0, fastCornerQuadsPerRun = 0.0, fastSurvivorsPerRun = 0.0;
     Buf dFastStats;
     Buf dFastCells;                        // FastCellRec table of the current geometry (k_fast_tab)
     Buf dMatchStat;                        // one counter: pairs that fell back to the matcher's one-wave pass (ygzf_match_fallbacks)
