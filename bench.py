@@ -807,7 +807,7 @@ def main():
         for name, wl, o_align, o_stereo, o_steps, o_real in (("fhd1920x1080_8lvl_4000feat", "fhd1920x1080_8lvl_4000feat", False, False, 3, False),
                                                              ("uhd3840x2160_12lvl_8000feat_stereo", "uhd3840x2160_12lvl_8000feat", False, True, 3, False),
                                                              ("euroc752x480_8lvl_1000feat_align", "euroc752x480_8lvl_1000feat", True, False, 3, False),
-                                                             ("euroc752x480_test1png", "euroc752x480_8lvl_1000feat", False, False, 3, True)):
+                                                             ("euroc752x480_test1png", "euroc752x480_8lvl_1000feat", False, False, 20, True)):
             osub, orounds = SHAPES[wl]
             orounds = 1 if wl != "euroc752x480_8lvl_1000feat" else max(1, orounds // 4)
             oframes = make_frames_test1png(96, WORKLOADS[wl][0], WORKLOADS[wl][1]) if o_real else None
