@@ -613,6 +613,9 @@ def main():
                          "default: the library's own choice)")
     ap.add_argument("--main-complement", action="store_true", help="with --fill-cus: the contexts' own streams get the remaining compute units only")
     ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the rank's host thread to the NUMA node of its GPU")
+    ap.add_argument("--share-gpu-try-rccl", action="store_true",
+                    help="TEST ONLY, with --share-gpu: still try to bring up the RCCL communicator (two ranks on one device: it is expected to refuse) so that "
+                         "the all-ranks-together fallback to gloo is exercised on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -651,7 +654,7 @@ def main():
     share = bool(args.share_gpu)
     if share:
         local_rank = 0
-    nccl = use_gpu and not share and args.backend != "gloo"
+    nccl = use_gpu and (not share or args.share_gpu_try_rccl) and args.backend != "gloo"
     if use_gpu and torch.cuda.is_available():
         torch.cuda.set_device(local_rank * ndev)   # before the process group: RCCL binds its communicator to the current device
     group = None

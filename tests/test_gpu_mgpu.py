@@ -201,3 +201,31 @@ def test_bench_two_ranks_on_one_gpu():
     ow = line["other_workloads"]
     assert set(ow) >= {"fhd1920x1080_8lvl_4000feat", "uhd3840x2160_12lvl_8000feat_stereo", "euroc752x480_8lvl_1000feat_align"}
     assert all(v["value"] > 0 for v in ow.values()) and ow["fhd1920x1080_8lvl_4000feat"]["value_end_to_end"] > 0
+
+
+def test_bench_falls_back_from_rccl_to_gloo_together():
+    """`--backend auto`: the control plane is gloo, RCCL carries the timing barrier only when its communicator comes up on EVERY rank.  Two ranks on the
+    box's one GPU make RCCL refuse (duplicate device): both ranks must agree on gloo over the control plane and the run must still produce its line,
+    saying which transport it used and why."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29573",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--share-gpu-try-rccl", "--backend", "auto", "--steps", "2", "--warmup", "1",
+           "--batch", "768", "--passes", "1", "--no-extras"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and cfg["processes"] == 2
+    assert cfg["barrier_backend"] in ("gloo", "rccl")
+    if cfg["barrier_backend"] == "gloo":
+        assert cfg["barrier_backend_note"]                              # the reason travels with the line
+    # and an explicit --backend gloo needs no RCCL at all
+    cmd2 = [c for c in cmd if c != "--share-gpu-try-rccl"]
+    cmd2[cmd2.index("auto")] = "gloo"
+    cmd2[cmd2.index("29573")] = "29574"
+    out = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["barrier_backend"] == "gloo" and line["value"] > 0
