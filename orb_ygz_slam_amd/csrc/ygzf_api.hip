@@ -336,7 +336,8 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             // move them to a global arena
             c->octGlobalNodes = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, false) > 142 * 1024;
             const size_t fixed = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, c->octGlobalNodes);
-            const size_t budget = 71 * 1024;   // two workgroups per CU beside 9 KB of static LDS each (radix histogram)
+            static const long octKb = getenv("YGZF_OCT_LDS_KB") ? atol(getenv("YGZF_OCT_LDS_KB")) : 71;   // A/B runs
+            const size_t budget = (size_t) octKb * 1024;   // default: two workgroups per CU beside 9 KB of static LDS each (radix histogram)
             c->octLdsCand = fixed + 16 * 256 < budget ? (int) ((budget - fixed) / 16) : 0;
             if (c->octLdsCand > 8192) c->octLdsCand = 8192;
         }
