@@ -731,7 +731,7 @@ int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, i
     // 48 GB/s where 1920-byte rows reach 55), so the rows handed to it are runs of k image rows -- (k - 1) x pitch + w bytes, k = the whole
     // frame by default -- and the padding bytes between image rows travel with them.
     static const int upK = getenv("YGZF_UPLOAD_K") ? atoi(getenv("YGZF_UPLOAD_K")) : 0;   // 0: whole frames; 1: image rows (as before); k: runs of k rows (k divides h) -- A/B runs
-    if (row_pitch == pitch && pitch != w && upK != 1 && (frame_stride == 0 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
+    if (row_pitch == pitch && pitch != w && upK != 1 && (nFrames == 1 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
         (frame_stride & 3) == 0) {
         const size_t fsd = (size_t) pitch * h, fss = nFrames == 1 ? fsd : frame_stride;
         const int k = (upK > 1 && h % upK == 0) ? upK : h;
