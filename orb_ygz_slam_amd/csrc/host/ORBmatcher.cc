@@ -114,9 +114,19 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     ygzf_host::Lease lease(device());
     if (!lease) return 0;
     ygzf_ctx *c = lease.get();
-    std::vector<uint8_t> tiv(M), bad(M), obs(M), mpdesc((size_t) M * 32);
-    std::vector<float> px(M), py(M), pxr(M), vc(M);
-    std::vector<int> lvl(M);
+    // (scratch of this thread's calls, kept from frame to frame: nine vectors of a thousand entries were allocated and zeroed per call; entries of
+    // points that are not in view are never read by the device -- it tests the in-view flag first)
+    struct Scratch {
+        std::vector<uint8_t> tiv, bad, obs, mpdesc, owner;
+        std::vector<float> px, py, pxr, vc;
+        std::vector<int> lvl, match;
+    };
+    static thread_local Scratch S;
+    std::vector<uint8_t> &tiv = S.tiv, &bad = S.bad, &obs = S.obs, &mpdesc = S.mpdesc;
+    std::vector<float> &px = S.px, &py = S.py, &pxr = S.pxr, &vc = S.vc;
+    std::vector<int> &lvl = S.lvl;
+    tiv.resize(M); bad.assign(M, 0); obs.assign(M, 0); mpdesc.resize((size_t) M * 32);
+    px.resize(M); py.resize(M); pxr.resize(M); vc.resize(M); lvl.assign(M, 0);
     for (int i = 0; i < M; i++) {
         MapPoint *mp = vpMapPoints[i];
         tiv[i] = mp->mbTrackInView;
@@ -128,7 +138,8 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
         const cv::Mat d = mp->GetDescriptor();
         std::memcpy(&mpdesc[(size_t) i * 32], d.ptr<uint8_t>(0), 32);
     }
-    std::vector<uint8_t> owner(nt), cdescHold;
+    std::vector<uint8_t> &owner = S.owner, cdescHold;
+    owner.resize(nt);
     for (int i = 0; i < nt; i++) {
         MapPoint *mp = F.mvpMapPoints[i];
         owner[i] = mp ? (mp->Observations() > 0 ? 2 : 1) : 0;
@@ -142,7 +153,8 @@ int ORBmatcher::SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMa
     fv.scale_factors = F.mvScaleFactors.data();
     fv.nlevels = (int) F.mvScaleFactors.size();
     ygzf_camera cam = {Frame::fx, Frame::fy, Frame::cx, Frame::cy, F.mb, F.mbf, Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY};
-    std::vector<int> match(nt, -1);
+    std::vector<int> &match = S.match;
+    match.assign(nt, -1);
     int nmatches = 0;
     const int rc = ygzf_search_by_projection_mappoints(c, &fv, &cam, M, tiv.data(), bad.data(), obs.data(), px.data(), py.data(), pxr.data(),
                                                        vc.data(), lvl.data(), mpdesc.data(), th, checkLevel, mfNNratio, owner.data(),

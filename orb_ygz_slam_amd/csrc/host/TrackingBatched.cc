@@ -20,6 +20,7 @@
 #include "ygz_compat.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -126,6 +127,9 @@ inline ygzf_camera camera_of(const ygz::Frame &F) {
 }
 }  // namespace
 
+// candidates from which Tracking::SearchLocalPoints takes the fused device frustum + matcher call (below: the reference's own loop over the per-call members)
+int ygzf_host_device_frustum_min = getenv("YGZF_FRUSTUM_DEVICE_MIN") ? atoi(getenv("YGZF_FRUSTUM_DEVICE_MIN")) : 1500;
+
 namespace ygz {
 
 // ---- src/Tracking.cc:1544-1593 ------------------------------------------------------------------------------------------------------------
@@ -171,6 +175,26 @@ void Tracking::SearchLocalPoints() {
     if (mSensor == System::RGBD) th = 3;
     if (mCurrentFrame.mnId < mnLastRelocFrameId + 2) th = 5;
     if (mbDirectFailed) th = 5;
+    // A local map of a thousand points: Frame::isInFrustum on the host is ~25 us for all of them, which is what shipping the frustum inputs / outputs
+    // and one more launch cost the fused call -- measured 122-125 us fused against 118-120 us for the reference's own loop (profiles/r05_*_boundary_latency.txt).
+    // Below kDeviceFrustumMin points the binding therefore IS the reference's loop (isInFrustum per point, then the matcher's device call); the fused
+    // device stage takes over where the host loop would dominate.  ygzf_host_device_frustum_min (initialised from YGZF_FRUSTUM_DEVICE_MIN; 0: always fused).
+    if (nCand < ygzf_host_device_frustum_min) {
+        int nToMatch = 0;
+        for (int i = 0; i < M; i++) {
+            if (!cand[i]) continue;
+            MapPoint *pMP = mvpLocalMapPoints[i];
+            if (mCurrentFrame.isInFrustum(pMP, 0.5)) {   // (:1569-1574)
+                pMP->IncreaseVisible();
+                nToMatch++;
+            }
+        }
+        if (nToMatch > 0) {
+            ORBmatcher matcher(0.8);
+            matcher.SearchByProjection(mCurrentFrame, mvpLocalMapPoints, th, false);
+        }
+        return;
+    }
     // scratch of this thread's calls, kept from frame to frame (fifteen vectors of a thousand entries were allocated and zeroed per call)
     struct Scratch {
         FrustumPack fp;

@@ -75,6 +75,7 @@ void Map::SetReferenceMapPoints(const std::vector<MapPoint *> &) {}   // "This i
 }  // namespace ygz
 // the reference's OWN bodies of the three members the batch bindings replace (renamed copies, tests/cpp/build_boundary.sh)
 extern "C" void ygz_ref_Tracking_SearchLocalPoints(ygz::Tracking *);
+extern int ygzf_host_device_frustum_min;   // orb_ygz_slam_amd/csrc/host/TrackingBatched.cc
 extern "C" void ygz_ref_Tracking_SearchLocalPointsDirect(ygz::Tracking *);
 extern "C" void ygz_ref_Frame_ComputeStereoMatches(ygz::Frame *);
 extern "C" int ygz_ref_ORBmatcher_SearchForTriangulation(ygz::ORBmatcher *, ygz::KeyFrame *, ygz::KeyFrame *, Matrix3f &,
@@ -415,7 +416,17 @@ int main(int argc, char **argv) {
                 return us[4];
             };
             const double a = med(false), b = med(true);
-            printf("latency search_local_points percall_us %.1f batch_us %.1f local_points %zu\n", a, b, mps.size());
+            const int keepMin = ygzf_host_device_frustum_min;
+            ygzf_host_device_frustum_min = 0;                 // the fused device frustum + matcher call whatever the size of the local map
+            restore();
+            trk.SearchLocalPoints();
+            if (trk.mCurrentFrame.mvpMapPoints != refAssigned || !same_state(snapshot(), refState)) {
+                fprintf(stderr, "Tracking::SearchLocalPoints: the fused device form differs from the reference's per-call body\n");
+                return 7;
+            }
+            const double f = med(true);
+            ygzf_host_device_frustum_min = keepMin;
+            printf("latency search_local_points percall_us %.1f batch_us %.1f local_points %zu fused_device_us %.1f\n", a, b, mps.size(), f);
             restore();
             trk.SearchLocalPoints();      // leave the state the dumps below expect
         }
