@@ -85,3 +85,16 @@ def test_scale_tables_without_a_device(oracle):
         t = oracle.Extractor(nf, sf, nl, 20, 7).tables()
         assert (sc == t["scale"]).all() and (inv == t["inv_scale"]).all() and (s2 == t["sigma2"]).all() and (is2 == t["inv_sigma2"]).all()
         assert (nfeat == t["nfeat"]).all()
+
+
+def test_host_layout_helpers_without_a_device():
+    """ygzf_host_row_pitch is host arithmetic (the device's level-0 row pitch: w rounded up to 64); ygzf_bind_host_thread_to_device names a device
+    that is not there as such and leaves the caller's affinity alone."""
+    from orb_ygz_slam_amd.capi import bind_host_thread_to_device, host_row_pitch
+    assert [host_row_pitch(w) for w in (752, 640, 1920, 3840, 1, 65)] == [768, 640, 1920, 3840, 64, 128]
+    assert host_row_pitch(0) < 0
+    if have_gpu():
+        pytest.skip("GPU present (bench.py binds its rank there)")
+    before = os.sched_getaffinity(0)
+    assert bind_host_thread_to_device(0) == -2 and bind_host_thread_to_device(5) == -2
+    assert os.sched_getaffinity(0) == before
