@@ -87,7 +87,7 @@ def test_partitioned_contexts_side_by_side():
         e.close()
 
 
-@pytest.mark.parametrize("w,h,k", [(752, 480, "0"), (752, 480, "8"), (752, 480, "1"), (500, 376, "0")])
+@pytest.mark.parametrize("w,h,k", [(752, 480, "0"), (752, 480, "8"), (752, 480, "1"), (500, 376, "0"), (640, 480, "0"), (322, 250, "0")])
 def test_pitched_host_frames(w, h, k):
     """the library reads YGZF_UPLOAD_K once per process: every setting in a process of its own"""
     code = r"""
