@@ -18,7 +18,10 @@ constexpr int kBorder = kEdgeThreshold - 3;  // minBorderX of ComputeKeyPointsOc
 constexpr int kMaxLevels = 16;
 constexpr int kMaxCellWin = 66;       // window side of one FAST cell: wCell(<60)+6
 constexpr int kFastBlock = 256;   // 4 waves (cell positions) per workgroup; single-wave workgroups measured slower: 739 vs 625 us per 256 frames
-constexpr int kOctBlock = 1024;
+#ifndef YGZF_OCT_BLOCK
+#define YGZF_OCT_BLOCK 1024
+#endif
+constexpr int kOctBlock = YGZF_OCT_BLOCK;   // threads per (level, frame) workgroup of k_octree (A/B builds: -DYGZF_OCT_BLOCK=512)
 // The dynamic-LDS ceiling of a kernel is a per-process attribute of the function: it is always set to the same value (the CU's 160 KB
 // minus room for static LDS), never to a per-call size, so that contexts used from different threads cannot lower it under each other.
 constexpr int kMaxDynLds = 160 * 1024 - 2048;
