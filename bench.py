@@ -608,10 +608,6 @@ def main():
     ap.add_argument("--backend", default="auto", choices=("auto", "nccl", "gloo"),
                     help="what carries the timing barrier and the max-over-ranks reduction of an N > 1 run (there is no collective on the data path): "
                          "nccl = RCCL, gloo = TCP on the host, auto (default) = RCCL when its communicator comes up on every rank, gloo otherwise")
-    ap.add_argument("--fill-cus", type=int, default=None,
-                    help="ygzf_set_stream_partition: k_octree / k_match_last on a second stream restricted to this many compute units (-1 unrestricted, 0 off; "
-                         "default: the library's own choice)")
-    ap.add_argument("--main-complement", action="store_true", help="with --fill-cus: the contexts' own streams get the remaining compute units only")
     ap.add_argument("--no-numa-bind", action="store_true", help="do not bind the rank's host thread to the NUMA node of its GPU")
     ap.add_argument("--share-gpu-try-rccl", action="store_true",
                     help="TEST ONLY, with --share-gpu: still try to bring up the RCCL communicator (two ranks on one device: it is expected to refuse) so that "
@@ -624,9 +620,6 @@ def main():
                     help="CPU-only check of the multi-process plumbing (gloo): no GPU work, output is NOT a measurement")
     args = ap.parse_args()
 
-    if args.fill_cus is not None:                  # read by every context the process creates (ygzf_create)
-        os.environ["YGZF_FILL_CUS"] = str(args.fill_cus)
-        os.environ["YGZF_MAIN_MODE"] = "1" if args.main_complement else "0"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -878,7 +871,7 @@ def main():
                        "match": "SearchByProjection(cur,last) th=15, identity pose", "fast_plan": fast_plan, "processes": world, "devices_per_process": ndev, "devices_reused": bool(args.reuse_devices and len(set(devices)) < len(devices)),
                        "sharding": "one clip per GPU, no collective", "valid_measurement": not share,
                        "barrier_backend": ("rccl" if nccl else "gloo") if world > 1 else None, "barrier_backend_note": backend_note,
-                       "numa_bound_cpus": numa_cpus, "stream_partition": {"fill_cus": os.environ.get("YGZF_FILL_CUS"), "main_mode": os.environ.get("YGZF_MAIN_MODE")}},
+                       "numa_bound_cpus": numa_cpus},
             "timed_region_s": round(elapsed, 4),
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "roofline_pcie": e2e["roofline_pcie"] if e2e else None,
             "mgpu_end_to_end": mgpu, "mgpu_literal_configs": mgpu_lit,

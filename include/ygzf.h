@@ -102,23 +102,14 @@ int ygzf_get_fast_plan(const ygzf_ctx *ctx, int *plan);
  *                                      REGISTER_STAGING for wider cells) */
 enum ygzf_fast_kernel { YGZF_FAST_KERNEL_AUTO = 0, YGZF_FAST_KERNEL_REGISTER_STAGING = 1, YGZF_FAST_KERNEL_CELL_TABLE = 2 };
 int ygzf_set_fast_kernel(ygzf_ctx *ctx, int kernel);
-/* Two-phase corner test of the cell-table form (same cell loop, src/ORBextractor.cc:765-768; the predicate is cv::FAST's 9-of-16, pinned to
- * Thirdparty/fast/include/fast/corner_9.h): a cheap NECESSARY condition on the eight even ring positions first (four consecutive of them must agree
- * for any arc of nine), the full bit-sliced test only on the quads that survive, gathered into whole wave steps.  Measured on MI355X it pays only
- * where the full test is then left with (almost) nothing -- nearly empty frames; a real image with a sixth of its quads surviving is 3 % slower, the
- * corner-dense synthetic clip 10 %: mode 0 (default) switches it on for such content only, from the statistics earlier launches leave behind, 1 never,
- * 2 always.  Keypoints are identical under every mode.  ygzf_get_fast_stats: what the next launch will do and the
- * last sampled statistics (corner-bearing quads per pass-1 run; survivors of the pre-test per run, when it ran); any pointer may be NULL. */
-int ygzf_set_fast_pretest(ygzf_ctx *ctx, int mode);
-int ygzf_get_fast_stats(const ygzf_ctx *ctx, int *pretest_on, float *corner_quads_per_pass, float *survivors_per_pass);
-/* Scheduling knob of the batch chain (no counterpart in the reference, whose ORBextractor::operator() src/ORBextractor.cc:962-1028 and
- * ORBmatcher::SearchByProjection src/ORBmatcher.cc:1218-1350 run on one CPU thread): DistributeOctTree (k_octree, :533-723) and the matcher
- * (k_match_last) are latency-bound -- long-lived workgroups that issue little -- while the cell loop (:747-781), the descriptors and the pyramid
- * are issue-bound.  fill_cus > 0 runs the two latency-bound kernels on a second stream of the context that is restricted to fill_cus compute
- * units (spread evenly over the XCDs), ordered against the context's own stream by events; fill_cus = -1 the same without a restriction; 0
- * (default) everything on one stream.  main_mode 1 restricts the context's own stream to the remaining compute units.  Results are identical
- * under every setting.  Drains the context; any stream handle the caller derived earlier is invalid afterwards. */
-int ygzf_set_stream_partition(ygzf_ctx *ctx, int fill_cus, int main_mode);
+/* Statistics the cell loop left behind on its last sampled launch (every 16th 2x2 cell group reports): corner-bearing quads (4 pixels) per
+ * pass-1 run of a cell, and pass-1 runs per cell -- 1.0 under ONE_PASS; under INI_FIRST 1 + the fraction of cells that were empty at iniThFAST and
+ * ran the corner test a second time at minThFAST (src/ORBextractor.cc:765-768).  Any pointer may be NULL. */
+int ygzf_get_fast_stats(const ygzf_ctx *ctx, float *corner_quads_per_pass, float *passes_per_cell);
+/* Phase clocks of k_fast_tab (kernel 0) and k_describe (kernel 1): shader-clock cycles summed over the sampled waves (one in 64, the last 8192 samples) since the last
+ * reset -- out16[0..7] per phase, out16[14] pass-1 runs (kernel 0), out16[15] waves.  Only a library built with -DYGZF_PHASE_CLOCK (python -m
+ * orb_ygz_slam_amd.build --phase-clock -> lib_ab/libygzf_clk.so, tools/fast_phases.py) carries the stamps; the product build returns YGZF_ERR_INVALID. */
+int ygzf_phase_clocks(ygzf_ctx *ctx, int kernel, unsigned long long *out16, int reset);
 /* Extract-ahead (default off).  When on, ygzf_compute_pyramid queues the ORBSLAM_KEYPOINT extraction of the same image (FAST, octree,
  * orientation, descriptors) right behind its pyramid kernels and reads the levels back on a second stream, so that the extraction runs while the
  * levels cross the link and while the caller works on them -- ygz::Frame's constructor clones them (src/Frame.cc:807-813) before

@@ -484,4 +484,217 @@ AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int m
     return out;
 }
 
+
+// ---- fp64 evaluation of the same Gauss-Newton: the THIRD PARTY of the tolerance argument (test infrastructure) ---------------------------------
+// The device (fp32, per-feature moments, tree reduction) and the reference-order mode above (fp32, pixel by pixel) are two roundings of one
+// algorithm; on ill-conditioned scenes they differ from each other by more than north_star's 1e-5 and neither is "the" answer.  This is the same
+// algorithm -- src/SparseImageAlign.cc:20-244 + NLSSolver_impl.hpp:17-91, same features, same visibility / border tests, same stop and rollback
+// rules, T <- T * exp(-x) -- with EVERY quantity in double: poses, projections, interpolation weights, patches, Jacobians, the sums of the normal
+// equations, the pivoted LDL^T, exp.  Inputs are the same floats widened.  tests/test_gpu_fuzz.py reports |device - fp64| beside
+// |reference_order - fp64| per case: the device is held to being no further from this than the reference's own arithmetic is.
+namespace f64 {
+struct SE3d {
+    double q[4] = {0, 0, 0, 1}, t[3] = {0, 0, 0};
+};
+static void qmul(const double a[4], const double b[4], double o[4]) {
+    double r[4];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    std::memcpy(o, r, sizeof r);
+}
+static void qnorm(double q[4]) {
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= n;
+}
+static void qrot(const double q[4], const double v[3], double o[3]) {
+    double uv[3] = {q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0]};
+    for (int i = 0; i < 3; i++) uv[i] += uv[i];
+    const double c[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+    for (int i = 0; i < 3; i++) o[i] = v[i] + q[3] * uv[i] + c[i];
+}
+static void act(const SE3d &T, const double p[3], double o[3]) {
+    double r[3];
+    qrot(T.q, p, r);
+    for (int i = 0; i < 3; i++) o[i] = r[i] + T.t[i];
+}
+static SE3d inverse(const SE3d &T) {
+    SE3d o;
+    o.q[0] = -T.q[0]; o.q[1] = -T.q[1]; o.q[2] = -T.q[2]; o.q[3] = T.q[3];
+    qnorm(o.q);
+    const double nt[3] = {-T.t[0], -T.t[1], -T.t[2]};
+    qrot(o.q, nt, o.t);
+    return o;
+}
+static SE3d mul(const SE3d &a, const SE3d &b) {
+    SE3d r = a;
+    double rt[3];
+    qrot(a.q, b.t, rt);
+    for (int i = 0; i < 3; i++) r.t[i] += rt[i];
+    qmul(a.q, b.q, r.q);
+    qnorm(r.q);
+    return r;
+}
+static SE3d expd(const double a[6]) {   // se3.hpp:406-428 in double (series below 1e-10 of rotation)
+    const double *w = a + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
+    SE3d r;
+    double imag, real, c1, c2;
+    if (th < 1e-10) {
+        imag = 0.5 - th2 / 48.0; real = 1.0 - th2 / 8.0; c1 = 0.5; c2 = 1.0 / 6.0;
+    } else {
+        imag = std::sin(0.5 * th) / th; real = std::cos(0.5 * th);
+        c1 = (1.0 - std::cos(th)) / th2; c2 = (th - std::sin(th)) / (th2 * th);
+    }
+    r.q[3] = real; r.q[0] = imag * w[0]; r.q[1] = imag * w[1]; r.q[2] = imag * w[2];
+    qnorm(r.q);
+    const double O[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    double O2[9], V[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
+    for (int i = 0; i < 9; i++) V[i] = ((i % 4 == 0) ? 1.0 : 0.0) + c1 * O[i] + c2 * O2[i];
+    for (int i = 0; i < 3; i++) r.t[i] = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
+    return r;
+}
+static void ldlt6(const double Hin[36], const double bin[6], double x[6]) {   // the same pivoted LDL^T as ldlt_solve6, in double
+    double A[36], b[6];
+    int perm[6];
+    std::memcpy(A, Hin, sizeof A);
+    std::memcpy(b, bin, sizeof b);
+    for (int i = 0; i < 6; i++) perm[i] = i;
+    for (int k = 0; k < 6; k++) {
+        int p = k;
+        double best = std::fabs(A[7 * k]);
+        for (int i = k + 1; i < 6; i++)
+            if (std::fabs(A[7 * i]) > best) { best = std::fabs(A[7 * i]); p = i; }
+        if (p != k) {
+            for (int j = 0; j < 6; j++) std::swap(A[6 * k + j], A[6 * p + j]);
+            for (int j = 0; j < 6; j++) std::swap(A[6 * j + k], A[6 * j + p]);
+            std::swap(b[k], b[p]);
+            std::swap(perm[k], perm[p]);
+        }
+        const double d = A[7 * k];
+        for (int i = k + 1; i < 6; i++) {
+            const double l = A[6 * i + k] / d;
+            for (int j = k + 1; j < 6; j++) A[6 * i + j] -= l * A[6 * k + j];
+            A[6 * i + k] = l;
+        }
+    }
+    double y[6], z[6];
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+        for (int j = 0; j < i; j++) s -= A[6 * i + j] * y[j];
+        y[i] = s;
+    }
+    for (int i = 0; i < 6; i++) y[i] /= A[7 * i];
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+        for (int j = i + 1; j < 6; j++) s -= A[6 * j + i] * z[j];
+        z[i] = s;
+    }
+    for (int i = 0; i < 6; i++) x[perm[i]] = z[i];
+}
+static void jac(const double p[3], double J[12]) {   // SparseImageAlign.h:90-111
+    const double x = p[0], y = p[1], zi = 1.0 / p[2], zi2 = zi * zi;
+    J[0] = -zi; J[1] = 0; J[2] = x * zi2; J[3] = y * J[2]; J[4] = -(1.0 + x * J[2]); J[5] = y * zi;
+    J[6] = 0; J[7] = -zi; J[8] = y * zi2; J[9] = 1.0 + y * J[8]; J[10] = -J[3]; J[11] = -x * zi;
+}
+}  // namespace f64
+
+AlignResultF64 sparse_img_align_f64(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level, int n_iter) {
+    using namespace f64;
+    AlignResultF64 out;
+    if (ref.N == 0) return out;
+    auto widen = [](const SE3f &T) { SE3d o; for (int i = 0; i < 4; i++) o.q[i] = T.q[i]; for (int i = 0; i < 3; i++) o.t[i] = T.t[i]; return o; };
+    const SE3d Tref = widen(ref.Tcw);
+    SE3d T = mul(widen(cur.Tcw), inverse(Tref));
+    const int N = ref.N, hp = 2, border = 3;
+    std::vector<double> patch((size_t) N * 16), Jc((size_t) N * 16 * 6);
+    std::vector<uint8_t> vis(N, 0);                 // (visible_fts_ is never cleared between levels in the reference either)
+    double chi2_ = 1e10;
+    size_t n_meas = 0;
+    int iters_total = 0;
+    bool stop = false;
+    for (int level = max_level; level >= min_level; level--) {
+        const Image &ri = *ref.pyramid[level], &ci = *cur.pyramid[level];
+        const double scale = ref.invScaleFactors[level];
+        std::fill(Jc.begin(), Jc.end(), 0.0);
+        for (int i = 0; i < N; i++) {                                   // precomputeReferencePatches, :57-128
+            if (!ref.mp_valid[i] || ref.outlier[i]) continue;
+            const double u = (double) ref.keys[i].x * scale, v = (double) ref.keys[i].y * scale;
+            const int ui = (int) std::floor(u), vi = (int) std::floor(v);
+            if (ui - border < 0 || vi - border < 0 || ui + border >= ri.w || vi + border >= ri.h) continue;
+            vis[i] = 1;
+            const double pw[3] = {ref.mp_world[3 * i], ref.mp_world[3 * i + 1], ref.mp_world[3 * i + 2]};
+            double xr[3], J[12];
+            act(Tref, pw, xr);
+            jac(xr, J);
+            const double su = u - ui, sv = v - vi, wtl = (1 - su) * (1 - sv), wtr = su * (1 - sv), wbl = (1 - su) * sv, wbr = su * sv;
+            const int st = ri.w;
+            for (int y = 0; y < 4; y++) {
+                const uint8_t *p = &ri.d[(size_t) (vi + y - hp) * st + (ui - hp)];
+                for (int x = 0; x < 4; x++, p++) {
+                    const size_t pc = (size_t) i * 16 + 4 * y + x;
+                    patch[pc] = wtl * p[0] + wtr * p[1] + wbl * p[st] + wbr * p[st + 1];
+                    const double dx = 0.5 * ((wtl * p[1] + wtr * p[2] + wbl * p[st + 1] + wbr * p[st + 2]) - (wtl * p[-1] + wtr * p[0] + wbl * p[st - 1] + wbr * p[st]));
+                    const double dy = 0.5 * ((wtl * p[st] + wtr * p[1 + st] + wbl * p[2 * st] + wbr * p[2 * st + 1]) - (wtl * p[-st] + wtr * p[1 - st] + wbl * p[0] + wbr * p[1]));
+                    for (int k = 0; k < 6; k++) Jc[pc * 6 + k] = (dx * J[k] + dy * J[6 + k]) * ((double) ref.fx * scale);
+                }
+            }
+        }
+        SE3d old = T;                                                   // optimizeGaussNewton, NLSSolver_impl.hpp:17-91
+        for (int iter = 0; iter < n_iter; iter++) {
+            double H[36] = {0}, b[6] = {0}, chi2 = 0;
+            n_meas = 0;
+            const int st = ci.w;
+            for (int i = 0; i < N; i++) {                               // computeResiduals, :130-231
+                if (!vis[i]) continue;
+                const double pw[3] = {ref.mp_world[3 * i], ref.mp_world[3 * i + 1], ref.mp_world[3 * i + 2]};
+                double xr[3], xc[3];
+                act(Tref, pw, xr);
+                act(T, xr, xc);
+                const double u = ((double) cur.fx * xc[0] / xc[2] + cur.cx) * scale, v = ((double) cur.fy * xc[1] / xc[2] + cur.cy) * scale;
+                const int ui = (int) std::floor(u), vi = (int) std::floor(v);
+                if (ui < 0 || vi < 0 || ui - border < 0 || vi - border < 0 || ui + border >= ci.w || vi + border >= ci.h) continue;
+                const double su = u - ui, sv = v - vi, wtl = (1 - su) * (1 - sv), wtr = su * (1 - sv), wbl = (1 - su) * sv, wbr = su * sv;
+                for (int y = 0; y < 4; y++) {
+                    const uint8_t *p = &ci.d[(size_t) (vi + y - hp) * st + (ui - hp)];
+                    for (int x = 0; x < 4; x++, p++) {
+                        const size_t pc = (size_t) i * 16 + 4 * y + x;
+                        const double res = (wtl * p[0] + wtr * p[1] + wbl * p[st] + wbr * p[st + 1]) - patch[pc];
+                        chi2 += res * res;
+                        n_meas++;
+                        const double *J = &Jc[pc * 6];
+                        for (int r = 0; r < 6; r++)
+                            for (int c = 0; c < 6; c++) H[6 * r + c] += J[r] * J[c];
+                        for (int r = 0; r < 6; r++) b[r] -= J[r] * res;
+                    }
+                }
+            }
+            const double new_chi2 = chi2 / (double) n_meas;
+            iters_total++;
+            double x[6];
+            ldlt6(H, b, x);
+            if (std::isnan(x[0])) stop = true;
+            if ((iter > 0 && new_chi2 > 1.2 * chi2_) || stop) { T = old; break; }
+            double nx[6];
+            for (int k = 0; k < 6; k++) nx[k] = -x[k];
+            const SE3d Tn = mul(T, expd(nx));
+            old = T;
+            T = Tn;
+            chi2_ = new_chi2;
+            double nm = 0;
+            for (int k = 0; k < 6; k++) nm = std::max(nm, std::fabs(x[k]));
+            if (nm <= 0.000001) break;                                  // eps_ (float 1e-6 in the reference)
+        }
+    }
+    for (int i = 0; i < 4; i++) out.T[i] = T.q[i];
+    for (int i = 0; i < 3; i++) out.T[4 + i] = T.t[i];
+    out.ret = n_meas / 16;
+    out.iters_total = iters_total;
+    out.chi2 = chi2_;
+    return out;
+}
+
 }  // namespace ygzo

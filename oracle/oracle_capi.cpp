@@ -442,6 +442,30 @@ size_t yo_sparse_img_align_mode(const yo_align_frame *ref, const yo_align_frame 
     if (H36) std::memcpy(H36, r.H, sizeof(r.H));
     return r.ret;
 }
+// fp64 evaluation of the same algorithm (sparse_img_align_f64): out7 / info in double
+size_t yo_sparse_img_align_f64(const yo_align_frame *ref, const yo_align_frame *cur, int max_level, int min_level, int n_iter, double out7[7],
+                               double info[2]) {
+    std::vector<Image> rimgs(ref->nlevels), cimgs(cur->nlevels);
+    AlignFrame R, C;
+    auto fill = [](const yo_align_frame *f, std::vector<Image> &imgs, AlignFrame &A) {
+        A.N = f->N; A.keys = f->keys; A.mp_valid = f->mp_valid; A.outlier = f->outlier; A.mp_world = f->mp_world;
+        std::memcpy(A.Tcw.q, f->Tcw, 16);
+        std::memcpy(A.Tcw.t, f->Tcw + 4, 12);
+        for (int l = 0; l < f->nlevels; l++) {
+            imgs[l] = Image(f->level_w[l], f->level_h[l]);
+            std::memcpy(imgs[l].d.data(), f->levels[l], imgs[l].d.size());
+            A.pyramid.push_back(&imgs[l]);
+        }
+        A.invScaleFactors = f->invScaleFactors;
+        A.fx = f->fx; A.fy = f->fy; A.cx = f->cx; A.cy = f->cy;
+    };
+    fill(ref, rimgs, R);
+    fill(cur, cimgs, C);
+    const AlignResultF64 r = sparse_img_align_f64(R, C, max_level, min_level, n_iter);
+    std::memcpy(out7, r.T, sizeof r.T);
+    if (info) { info[0] = (double) r.iters_total; info[1] = r.chi2; }
+    return r.ret;
+}
 size_t yo_sparse_img_align(const yo_align_frame *ref, const yo_align_frame *cur, int max_level, int min_level, int n_iter,
                            float out7[7], float info[2], float H36[36]) {
     return yo_sparse_img_align_mode(ref, cur, max_level, min_level, n_iter, out7, info, H36, 0);

@@ -645,6 +645,22 @@ def sparse_img_align(ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, 
     return int(ret), out7, info, H.reshape(6, 6)
 
 
+def sparse_img_align_f64(ref_keys, ref_world, ref_Tcw7, ref_pyr, cur_Tcw7, cur_pyr, inv_scale, cam, max_level, min_level, n_iter=10,
+                         mp_valid=None, outlier=None):
+    """The same Gauss-Newton with every quantity in double (oracle_align.cpp, sparse_img_align_f64): (ret, TCR7 as float64, (iterations, chi2)).
+    The third party of the aligner's tolerance argument: tests report |device - this| beside |reference_order - this|."""
+    keep = []
+    R = _align_frame(ref_keys, mp_valid, outlier, ref_world, ref_Tcw7, ref_pyr, inv_scale, cam, keep)
+    Cf = _align_frame(np.zeros(0, KP_DTYPE), None, None, None, cur_Tcw7, cur_pyr, inv_scale, cam, keep)
+    out7 = np.zeros(7, np.float64)
+    info = np.zeros(2, np.float64)
+    L = lib()
+    L.yo_sparse_img_align_f64.restype = C.c_size_t
+    L.yo_sparse_img_align_f64.argtypes = [C.POINTER(_YoAlignFrame), C.POINTER(_YoAlignFrame), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ret = L.yo_sparse_img_align_f64(C.byref(R), C.byref(Cf), max_level, min_level, n_iter, _p(out7), _p(info))
+    return int(ret), out7, info
+
+
 _ref_sophus = None
 
 

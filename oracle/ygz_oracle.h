@@ -280,6 +280,14 @@ bool ldlt_solve6(const float H[36], const float b[6], float x[6]);   // x = H.ld
 // the mode the kernel is compared with BIT FOR BIT; false = the reference's own pixel-by-pixel order
 AlignResult sparse_img_align(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level,
                              int n_iter, bool device_order = false);
+// the same algorithm with every quantity in double (oracle_align.cpp): the third party of the aligner's tolerance argument
+struct AlignResultF64 {
+    double T[7] = {0, 0, 0, 1, 0, 0, 0};   // qx qy qz qw tx ty tz of T_cur_from_ref
+    size_t ret = 0;
+    int iters_total = 0;
+    double chi2 = 0;
+};
+AlignResultF64 sparse_img_align_f64(const AlignFrame &ref, const AlignFrame &cur, int max_level, int min_level, int n_iter);
 
 // ---- ORBmatcher::FindDirectProjection + Align2D  src/ORBmatcher.cc:1525-1602, src/Align.cc:8-104 -------------------------------------
 struct DirectRef {   // the reference KeyFrame's slice

@@ -44,7 +44,7 @@ def check_handover_isa(verbose=False):
     """The matcher's fence-free hand-over between the workgroups of a pair (csrc/match_kernels.hip: st_dev / ld_dev) is correct because of what
     these builtins compile to on gfx950, so the build looks: the device assembly of that file must show k_handover_probe as exactly one
     `global_load_dword ... sc1` and one `global_store_dword ... sc1`, and k_match_last must carry the scoped accesses of its hand-over (22 stores of
-    records / query parameters, at least as many loads) plus the fenced alternative.  Raises RuntimeError otherwise -- the library is not built."""
+    records / query parameters, at least as many loads) plus the fenced alternative.  Raises RuntimeError otherwise (build() then falls back to the fenced hand-over with a warning)."""
     import re
     src = "csrc/match_kernels.hip"
     cmd = [hipcc()] + [f for f in FLAGS if not f.startswith("-W")] + FILE_FLAGS.get(src, []) + ["-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src, "-o", "-"]
@@ -65,30 +65,34 @@ def check_handover_isa(verbose=False):
     ok = (got["probe_loads_sc1"] == 1 and got["probe_stores_sc1"] == 1 and got["probe_plain"] == 0 and got["match_stores_sc1"] >= 22 and
           got["match_loads_sc1"] >= 22 and got["match_wbl2"] >= 1 and got["match_inv"] >= 1)
     if not ok:
-        raise RuntimeError("check_handover_isa: the compiler no longer lowers the matcher's device-scope accesses to sc1 loads / stores (%r): "
-                           "build with YGZF_MATCH_FENCE=1 semantics (match_kernels.hip: kHandoverScopedAccess = false) instead" % (got,))
+        raise RuntimeError("check_handover_isa: the compiler no longer lowers the matcher's device-scope accesses to sc1 loads / stores (%r)" % (got,))
     return got
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return lib_path()
+def build(force=False, verbose=False, phase_clock=False):
+    """phase_clock: the instrumented variant (-DYGZF_PHASE_CLOCK: s_memtime stamps in k_fast_tab / k_describe, tools/fast_phases.py) into
+    lib_ab/libygzf_clk.so -- loaded with YGZF_LIBRARY; the product library carries none of it."""
+    out = os.path.join(HERE, "lib_ab", "libygzf_clk.so") if phase_clock else lib_path()
+    if not force and not phase_clock and not needs_build():
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     os.makedirs(os.path.join(HERE, "lib"), exist_ok=True)
     import fcntl
     with open(os.path.join(HERE, "lib", ".build.lock"), "w") as lock:   # several ranks of one node may get here at once
         fcntl.flock(lock, fcntl.LOCK_EX)
-        if not force and not needs_build():
-            return lib_path()
+        if not force and not phase_clock and not needs_build():
+            return out
         srcs = [s for s in SRCS if os.path.exists(os.path.join(HERE, s))]
-        tmp = lib_path() + ".tmp.%d" % os.getpid()
+        tmp = out + ".tmp.%d" % os.getpid()
         objdir = os.path.join(HERE, "lib", "obj.%d" % os.getpid())
         os.makedirs(objdir, exist_ok=True)
         try:
             from concurrent.futures import ThreadPoolExecutor
+            extra = ["-DYGZF_PHASE_CLOCK"] if phase_clock else []
 
-            def compile_one(src):
+            def compile_one(src, more=()):
                 obj = os.path.join(objdir, os.path.basename(src) + ".o")
-                cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+                cmd = [hipcc()] + FLAGS + FILE_FLAGS.get(src, []) + extra + list(more) + ["-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd, cwd=HERE)
@@ -96,16 +100,23 @@ def build(force=False, verbose=False):
             with ThreadPoolExecutor(max_workers=min(len(srcs) + 1, os.cpu_count() or 1)) as pool:
                 isa = pool.submit(check_handover_isa, verbose)
                 objs = list(pool.map(compile_one, srcs))
-                isa.result()                                             # raises: no library from a build whose hand-over is unproven
+                try:
+                    isa.result()
+                except RuntimeError as e:
+                    # The fence-free hand-over is an optimisation whose proof is the ISA; the fenced path is always correct.  A compiler that lowers
+                    # the scoped accesses differently (or renames what the check greps for) costs the library a few microseconds per matcher
+                    # launch, not its build: recompile that one file with full fences and say so.  tests/test_handover_isa.py keeps the strict check.
+                    sys.stderr.write("[ygzf build] WARNING: %s\n[ygzf build] building csrc/match_kernels.hip with -DYGZF_FORCE_HANDOVER_FENCE\n" % e)
+                    compile_one("csrc/match_kernels.hip", ["-DYGZF_FORCE_HANDOVER_FENCE"])
             cmd = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", tmp]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=HERE)
-            os.replace(tmp, lib_path())                                  # a loaded library is never rewritten in place
+            os.replace(tmp, out)                                         # a loaded library is never rewritten in place
         finally:
             shutil.rmtree(objdir, ignore_errors=True)
-    return lib_path()
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, phase_clock="--phase-clock" in sys.argv))

@@ -56,6 +56,19 @@ def make_camera(w, h, fx=EUROC["fx"], fy=EUROC["fy"], cx=EUROC["cx"], cy=EUROC["
 _lib = None
 
 
+def force_env(base=None, **kv):
+    """YGZF_FORCE string (csrc/ygzf_internal.h: key=value,... pins a plan the library otherwise picks itself; read when a context is created):
+    `base` (default: the current environment's) with the given keys set, or removed when their value is None."""
+    cur = os.environ.get("YGZF_FORCE", "") if base is None else base
+    items = dict(p.split("=", 1) for p in cur.split(",") if "=" in p)
+    for k, v in kv.items():
+        if v is None:
+            items.pop(k, None)
+        else:
+            items[k] = str(v)
+    return ",".join("%s=%s" % kv for kv in items.items())
+
+
 def load_library(build_if_missing=True):
     """Loads libygzf.so (building it with hipcc first when it is missing/stale).  Fails loudly: there is no fallback."""
     global _lib
@@ -135,7 +148,6 @@ def load_library(build_if_missing=True):
     L.ygzf_set_fast_plan.argtypes = [vp, C.c_int]
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
     L.ygzf_set_fast_kernel.argtypes = [vp, C.c_int]
-    L.ygzf_set_stream_partition.argtypes = [vp, C.c_int, C.c_int]
     L.ygzf_set_extract_ahead.argtypes = [vp, C.c_int]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
@@ -606,22 +618,19 @@ class Extractor:
         """0 auto (default), 1 register staging (k_fast_quads), 2 cell table + LDS-DMA staging (k_fast_tab) -- same results (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_fast_kernel(self.h, int(kernel)))
 
-    def set_fast_pretest(self, mode):
-        """0 auto (default), 1 never, 2 always: the two-phase corner test of k_fast_tab -- same keypoints (include/ygzf.h)."""
-        self.L.ygzf_set_fast_pretest.argtypes = [C.c_void_p, C.c_int]
-        self._ck(self.L.ygzf_set_fast_pretest(self.h, int(mode)))
-
     def fast_stats(self):
-        """(pre-test on for the next launch, corner-bearing quads per pass-1 run, pre-test survivors per run) from the last sampled launch"""
-        on, a, b = C.c_int(0), C.c_float(0), C.c_float(0)
-        self.L.ygzf_get_fast_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        self._ck(self.L.ygzf_get_fast_stats(self.h, C.byref(on), C.byref(a), C.byref(b)))
-        return bool(on.value), a.value, b.value
+        """(corner-bearing quads per pass-1 run, pass-1 runs per cell) from the last sampled launch of the cell loop (include/ygzf.h)"""
+        a, b = C.c_float(0), C.c_float(0)
+        self.L.ygzf_get_fast_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._ck(self.L.ygzf_get_fast_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
-    def set_stream_partition(self, fill_cus, main_mode=0):
-        """k_octree / k_match_last on a second stream restricted to fill_cus compute units (-1 unrestricted, 0 off); main_mode 1 restricts the
-        context's own stream to the rest (include/ygzf.h)."""
-        self._ck(self.L.ygzf_set_stream_partition(self.h, int(fill_cus), int(main_mode)))
+    def phase_clocks(self, kernel, reset=True):
+        """16 u64 counters of the phase-clock build (kernel 0 = k_fast_tab, 1 = k_describe); raises on the product build (include/ygzf.h)."""
+        out = np.zeros(16, np.uint64)
+        self.L.ygzf_phase_clocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        self._ck(self.L.ygzf_phase_clocks(self.h, int(kernel), out.ctypes.data_as(C.c_void_p), 1 if reset else 0))
+        return out
 
     def set_extract_ahead(self, on):
         """compute_pyramid also queues the extraction of the same image; extract_resident then only collects it (include/ygzf.h)."""

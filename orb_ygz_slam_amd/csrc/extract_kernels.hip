@@ -28,6 +28,71 @@ typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }   // wave-uniform by construction
 
+// Phase clock of the two kernels that carry half of the chain (k_fast_tab, k_describe): a wave stamps s_memtime (shader clock) at the phase
+// borders of its one cell / keypoint and one wave in 64 leaves its per-phase cycles in a record of g_phase_rec[kernel].  Compiled in only with -DYGZF_PHASE_CLOCK (python -m orb_ygz_slam_amd.build --phase-clock builds
+// lib_ab/libygzf_clk.so; tools/fast_phases.py reads it through ygzf_phase_clocks): the product library carries none of it -- the struct is empty
+// and every call folds away.  A stamp first drains the wave's outstanding memory / LDS operations, so that a phase is charged with its own waits.
+#ifdef YGZF_PHASE_CLOCK
+// No atomics: a sampled wave (one in 64) stores its record into slot (sample index % kPhaseSlots) of its kernel's table -- later samples overwrite
+// earlier ones, the host averages the slots that were written.  (A first version added every 16th wave's cycles to ten global counters: the
+// contended atomics backed up the memory pipeline and stretched k_fast_tab 5.5x -- the clock measured itself.)
+constexpr int kPhaseSlots = 8192;
+__device__ unsigned g_phase_rec[2][kPhaseSlots][10];   // 8 phases, [8] pass-1 runs, [9] written flag
+struct PhaseClk {
+    unsigned long long t;
+    unsigned a[8], extra;
+    __device__ __forceinline__ void bump() { extra++; }
+    __device__ __forceinline__ void start() {
+        extra = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        t = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = 0;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void mark(int k) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long n = __builtin_amdgcn_s_memtime();
+        a[k] += (unsigned) (n - t);
+        t = n;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // `index`: the wave's running number inside the launch (any numbering that spreads over the grid)
+    __device__ __forceinline__ void flush(int kernel, int lane, unsigned index) {
+        if ((index & 63u) != 0 || lane >= 10) return;
+        unsigned v = lane == 9 ? 1u : lane == 8 ? extra : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v = lane == k ? a[k] : v;
+        g_phase_rec[kernel][(index >> 6) % kPhaseSlots][lane] = v;
+    }
+};
+hipError_t phase_clocks_read(int kernel, unsigned long long *out16, bool reset) {
+    static unsigned host[kPhaseSlots][10];
+    const size_t bytes = sizeof host, off = (size_t) kernel * bytes;
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phase_rec), bytes, off);
+    if (e != hipSuccess) return e;
+    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (int s = 0; s < kPhaseSlots; s++) {
+        if (!host[s][9]) continue;
+        for (int k = 0; k < 8; k++) out16[k] += host[s][k];
+        out16[14] += host[s][8];
+        out16[15] += 1;
+    }
+    if (!reset) return e;
+    memset(host, 0, bytes);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase_rec), host, bytes, off);
+}
+#else
+struct PhaseClk {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void bump() {}
+    __device__ __forceinline__ void flush(int, int, unsigned) {}
+};
+hipError_t phase_clocks_read(int, unsigned long long *, bool) { return hipErrorNotSupported; }
+#endif
+
 // Exclusive prefix of v over the threads of the block (thread order); *total = block sum.  tmp: >= 17 ints of LDS.
 // Contains block barriers: must be called by all threads.  The caller orders its reads of tmp's results before the next call (a barrier).
 __device__ __forceinline__ int block_excl_scan(int v, int *tmp, int *total) {
@@ -659,60 +724,6 @@ __device__ __forceinline__ unsigned fast9_quad(const unsigned *w, int pd, int t)
     return (fb >> 7) | (fd >> 6);   // per byte: 1 bright corner, 2 dark corner, 0 none
 }
 
-// A NECESSARY condition of fast9_quad on the same four pixels, from the eight EVEN ring positions only: nine contiguous positions of the sixteen
-// hold four or five even ones, contiguous among the evens -- so a corner has four consecutive even positions brighter than c + t (or four darker
-// than c - t).  Same byte-sliced comparisons as the full test (the same predicate per ring pixel, so no corner is ever missed), 11 window dwords
-// instead of 21, 16 lerps instead of 32, 44 logic operations instead of 84: ~0.55 of the full test.  Nonzero = the quad may hold a corner.
-// Natural images leave ~12 % of their quads (the one real image the reference ships), corner-dense synthetic content 27-36 %: the cell loop runs
-// this first only where the statistics of earlier launches say the survivors fit one wave step (fast_cell_process, kPre).
-__device__ __forceinline__ unsigned fast9_pre_quad(const unsigned *w, int pd, int t) {
-#define QROW(r) const unsigned a##r = w[(r) * pd], b##r = w[(r) * pd + 1], c##r = w[(r) * pd + 2];
-    QROW(1) QROW(3) QROW(5)
-#undef QROW
-    const unsigned b0 = w[1], b6 = w[6 * pd + 1];
-#define AB(hi, lo, sh) __builtin_amdgcn_alignbyte(hi, lo, sh)
-    unsigned R[8];   // ring positions 0, 2, 4, ..., 14
-    R[0] = b6;               // (0, +3)
-    R[1] = AB(c5, b5, 2);    // (+2, +2)
-    R[2] = AB(c3, b3, 3);    // (+3, 0)
-    R[3] = AB(c1, b1, 2);    // (+2, -2)
-    R[4] = b0;               // (0, -3)
-    R[5] = AB(b1, a1, 2);    // (-2, -2)
-    R[6] = AB(b3, a3, 1);    // (-3, 0)
-    R[7] = AB(b5, a5, 2);    // (-2, +2)
-#undef AB
-    const unsigned nc = ~b3;
-    const unsigned ev = nc & 0x00FF00FFu, od = (nc >> 8) & 0x00FF00FFu;
-    const unsigned tt = (unsigned) t * 0x10001u;
-    const v2u tv = __builtin_bit_cast(v2u, tt), cap = __builtin_bit_cast(v2u, 0x00FF00FFu);
-    const unsigned nhiE = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, ev), tv));
-    const unsigned nhiO = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, od), tv));
-    const unsigned nloE = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(v2u, ev) + tv, cap));
-    const unsigned nloO = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(v2u, od) + tv, cap));
-    const unsigned nhi = nhiE | (nhiO << 8), nlo = nloE | (nloO << 8);
-    unsigned B[8], N[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        B[k] = __builtin_amdgcn_lerp(R[k], nhi, 0u);
-        N[k] = __builtin_amdgcn_lerp(R[k], nlo, 0x01010101u);
-    }
-#define AND3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0x80)
-#define OR3(a, b, c) __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE)
-    unsigned A4[8], O4[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        A4[k] = AND3(B[k], B[(k + 1) & 7], B[(k + 2) & 7]) & B[(k + 3) & 7];
-        O4[k] = OR3(N[k], N[(k + 1) & 7], N[(k + 2) & 7]) | N[(k + 3) & 7];
-    }
-    unsigned bright = OR3(A4[0], A4[1], A4[2]), ndark = AND3(O4[0], O4[1], O4[2]);
-    bright = OR3(bright, A4[3], A4[4]); ndark = AND3(ndark, O4[3], O4[4]);
-    bright = OR3(bright, A4[5], A4[6]); ndark = AND3(ndark, O4[5], O4[6]);
-    bright |= A4[7]; ndark &= O4[7];
-#undef AND3
-#undef OR3
-    return (bright | ~ndark) & 0x80808080u;
-}
-
 // a / x for 0 <= a <= 64, 1 <= x <= 64 as (a * kRcp16[x]) >> 16 (exact in that range): lane -> (row, column) splits without the
 // 30-instruction integer division sequence; x is wave-uniform, so the table read is one scalar load.
 __constant__ unsigned kRcp16[65] = {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097, 3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1025};
@@ -736,10 +747,10 @@ __device__ __forceinline__ int nms_flags(const uint8_t *sp, int iniTh, int kSP) 
 // one cell = one wave's unit of work; returns when the cell is done (all paths), so that a wave can take several cells in a row
 // Everything after the window is staged: pass 1 (quads), expansion, score, NMS, output -- see fast_cell.  The window holds image pixel
 // (cell-tested pixel x, row y) at byte (y + 3) * P + x + 4.
-template <int kP, bool kIniFirst, bool kPre = false>
+template <int kP, bool kIniFirst>
 __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, unsigned short *clist, const int P, const int dw, const int dh,
                                                   const int iniTh, const int minTh, unsigned short *cnt_out,
-                                                  unsigned *__restrict__ out, const int grp, const int lane, unsigned *__restrict__ stats) {
+                                                  unsigned *__restrict__ out, const int grp, const int lane, unsigned *__restrict__ stats, PhaseClk &pc) {
     const int kSP = P;   // score-map pitch
     unsigned *qlist = (unsigned *) smap;
     const unsigned long long lane_lt = (1ull << lane) - 1ull;
@@ -762,45 +773,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
         // ---- pass 1: four pixels per lane, quads in raster order; quads that hold a corner are listed as  pol bytes | y << 2 | q << 10 ----
         int nQ = 0;
         const int nquadsAll = ((dw + 3) >> 2) * dh;
-        if (kPre && nquadsAll <= kCornerCap) {
-            // ---- two-phase pass 1 (kPre): the cheap necessary test on every quad, survivors listed in raster order (the corner list's bytes are free
-            // until the expansion); the full test then runs on the LIST -- whole wave steps of it, whatever the survivors' positions -- and its own
-            // compaction keeps the raster order.  Same quad list as the one-phase loop below, so everything downstream is unchanged.
-            const int nq = (dw + 3) >> 2, nquads = nquadsAll;
-            const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
-            const unsigned mnq = kRcp16[nq];
-            int y = div_small(lane, mnq), q = lane - __mul24(y, nq);
-            const int qy = div_small(64, mnq), qx = 64 - qy * nq;
-            unsigned short *plist = clist;
-            int nP = 0;
-            for (int base = 0; base < nquads; base += 64) {
-                unsigned pre = 0;
-                if (base + lane < nquads) pre = fast9_pre_quad((const unsigned *) (win + __mul24(y, P)) + q, P >> 2, th);
-                const unsigned long long m = __ballot(pre != 0);
-                if (m) {
-                    if (pre) plist[nP + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] = (unsigned short) (y | (q << 8));
-                    nP += __popcll(m);
-                }
-                y += qy; q += qx;
-                if (q >= nq) { q -= nq; y++; }
-            }
-            wave_lds_sync();
-            for (int base = 0; base < nP; base += 64) {
-                unsigned pb = 0, yy = 0, qq = 0;
-                if (base + lane < nP) {
-                    const unsigned e = plist[base + lane];
-                    yy = e & 0xFFu; qq = e >> 8;
-                    pb = fast9_quad((const unsigned *) (win + __mul24((int) yy, P)) + qq, P >> 2, th);
-                    pb &= ((int) qq == nq - 1) ? lastMask : 0x03030303u;
-                }
-                const unsigned long long m = __ballot(pb != 0);
-                if (m) {
-                    if (pb) qlist[nQ + (int) __builtin_amdgcn_mbcnt_hi((unsigned) (m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) m, 0u))] = pb | (yy << 2) | (qq << 10);
-                    nQ += __popcll(m);
-                }
-            }
-            if (sampled && lane == 0) { atomicAdd(&st[6], (unsigned) nP); }
-        } else {
+        {
             const int nq = (dw + 3) >> 2, nquads = nq * dh;
             const unsigned lastMask = 0x03030303u >> (8 * (4 * nq - dw));
             const unsigned mnq = kRcp16[nq];
@@ -824,6 +797,8 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
         }
         if (sampled && lane == 0) { atomicAdd(&st[4], (unsigned) nQ); atomicAdd(&st[5], (unsigned) nquadsAll); atomicAdd(&st[7], 1u); }   // corner-bearing quads / quads / pass-1 runs
         wave_lds_sync();
+        pc.mark(1);
+        pc.bump();
         // ---- expansion: quad list -> corner list (y << 8 | x << 2 | polarity), still raster order ----
         int ncorn = 0;
         bool overflow = false;
@@ -848,9 +823,11 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
             ncorn += add;
         }
         wave_lds_sync();
+        pc.mark(2);
         // the quad list is consumed: its bytes become the (zeroed) score map
         for (int idx = lane; idx < ((dh + 2) * kSP + 15) / 16; idx += 64) ((uint4 *) smap)[idx] = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
+        pc.mark(3);
         if (sampled && lane == 0 && !kIniFirst && ncorn > 64) atomicAdd(&st[2], (unsigned) ((min(ncorn, kCornerCap) - 1) >> 6));   // score rounds beyond the first
         int total = 0;          // keypoints this pass keeps
         bool usedMin = false;   // the single-pass plan fell back to the minTh survivors
@@ -866,6 +843,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
                 sp[0] = (uint8_t) sc;
             }
             wave_lds_sync();
+            pc.mark(4);
             const int fl = have ? nms_flags(sp, iniTh, kSP) : 0;
             bool keep;
             if (kIniFirst) keep = (fl & 2) != 0;                      // survivors of FAST(th)
@@ -890,6 +868,7 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
                 }
             }
             wave_lds_sync();
+            pc.mark(4);
             // 3x3 NMS at both thresholds over the corner list
             int nIni = 0;
             for (int qb = 0; qb < ncorn; qb += 64) {
@@ -959,11 +938,12 @@ __device__ __forceinline__ void fast_cell_process(uint8_t *win, uint8_t *smap, u
                 usedMin = !kIniFirst;
             }
         }
+        pc.mark(5);
         if (total > 0 || lastPass) {
             if (lane == 0) *cnt_out = (unsigned short) total;
             if (sampled && lane == 0) {
                 atomicAdd(&st[0], 1u);
-                st[3] = (kIniFirst ? 2u : 1u) | (kPre ? 4u : 0u);   // which plan these numbers come from
+                st[3] = kIniFirst ? 2u : 1u;   // which plan these numbers come from
                 if (usedMin || (nPass == 2 && pass == 1)) atomicAdd(&st[1], 1u);   // the cell's keypoints are FAST(minTh)'s
             }
             return;
@@ -1043,8 +1023,10 @@ __device__ __forceinline__ void fast_cell(const FrameSet &fs, const LevelGeom *_
         }
     }
     wave_lds_sync();
+    PhaseClk pc;   // (the phase clock reports k_fast_tab; here it is only the argument)
+    pc.start();
     fast_cell_process<kP, kIniFirst>(win, smap, clist, P, dw, dh, iniTh, minTh, cnt_out,
-                                     slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap, grp, lane, stats);
+                                     slots + (long long) f * totalSlots + g.slotBase + (long long) c * g.slotCap, grp, lane, stats, pc);
 }
 
 
@@ -1100,13 +1082,15 @@ constexpr int kTabPitch = 48;
 // workgroups free their LDS sooner, but the pipeline as a whole runs best with four.
 constexpr int kFastTabWaves = YGZF_FAST_TAB_WAVES;
 
-template <bool kIniFirst, bool kPre>
+template <bool kIniFirst>
 __global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
                                                          unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
                                                          long long totalSlots, int totalGroups, int groupsPerXcd, int winRows, int smapRows,
                                                          int quadCap, unsigned *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
     const int tid = threadIdx.x, lane = tid & 63;
+    PhaseClk pc;
+    pc.start();
     if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
     const int blk = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);   // XCD-aware: every XCD gets a contiguous run of cells
     const int f = blockIdx.y;
@@ -1147,7 +1131,9 @@ __global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     wave_lds_sync();
-    fast_cell_process<P, kIniFirst, kPre>(win, smap, clist, P, dw, dh, iniTh, minTh, cnt_out, slots + (long long) f * totalSlots + R.slot, grp, lane, stats);
+    pc.mark(0);
+    fast_cell_process<P, kIniFirst>(win, smap, clist, P, dw, dh, iniTh, minTh, cnt_out, slots + (long long) f * totalSlots + R.slot, grp, lane, stats, pc);
+    pc.flush(0, lane, (unsigned) rec + (unsigned) f * (unsigned) (totalGroups * kFastTabWaves));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1806,16 +1792,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
     const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k,
                 p7 = -0.04432655554792128f * k;
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float) 2.2204460492503131e-16);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float) 2.2204460492503131e-16);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // the two branches of the source (ax >= ay: ay / (ax + eps); else ax / (ay + eps), 90 - ...) share their operations: select the operands
+    // first and divide ONCE -- the correctly rounded division is a dozen instructions, and left as two branches both were executed
+    const bool wide = ax >= ay;
+    const float c = (wide ? ay : ax) / ((wide ? ax : ay) + (float) 2.2204460492503131e-16);
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (!wide) a = 90.f - a;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
@@ -1920,7 +1903,7 @@ __constant__ int c_umax[16];
 //   YGZF_CV_4            Q8.8 kernel {18,34,48,56,48,34,18}, (sum + 2^15) >> 16
 template <int CVM>
 __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img, int pitch, int gw, int gh, int kx, int ky, DescLds &L,
-                                                int lane, float *angleOut, unsigned long long bits[4], bool presetAngle = false,
+                                                int lane, float *angleOut, unsigned long long bits[4], PhaseClk &pc, bool presetAngle = false,
                                                 float preset = 0.f) {
     // ---- stage the 43x43 window (rows ky-21..ky+21).  Interior keypoints: the 43 bytes of a row lie inside one 16-byte
     // aligned 64-byte span -> 4 lanes x dwordx4 per row, 3 wave-level loads for the whole window, all in flight at once.
@@ -1954,6 +1937,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     }
 #define RAWP(r) (&L.rawp()[(r) * kWinP + ((rowOff0 + (r) * rowOffStep) & 15)])
     wave_lds_sync();
+    pc.mark(0);
     // ---- intensity centroid on the 31x31 disc (centre = window (21,21)).  Work item = four pixels (row v, columns u = 4j-15 .. 4j-12):
     // two aligned dwords shifted into place, masked with the disc membership bytes, then m01 += v * (sum of the bytes) [v_sad_u8] and
     // m10 += <bytes, (4j .. 4j+3)> - 15 * sum [v_dot4_u32_u8].  248 items = 4 steps of the wave; integer sums, any order is exact.
@@ -1978,7 +1962,12 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
+    pc.mark(1);
     const float angle = presetAngle ? preset : fast_atan2_deg((float) m01, (float) m10);
+#ifdef YGZF_PHASE_CLOCK
+    asm volatile("" :: "v"(angle));   // the stamp below must see the angle computed
+#endif
+    pc.mark(2);
     // ---- separable 7-tap blur {18,34,k2,k3,k2,34,18}: each lane produces runs of 8 outputs
     constexpr int k2 = CVM == YGZF_CV_4 ? 48 : 49, k3 = CVM == YGZF_CV_4 ? 56 : 55;
     constexpr unsigned kTapLo = 0x00002212u | ((unsigned) k2 << 16) | ((unsigned) k3 << 24);   // bytes (18, 34, k2, k3)
@@ -2017,9 +2006,14 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         dst[0] = O[0]; dst[1] = O[1]; dst[2] = O[2]; dst[3] = O[3]; dst[4] = O[4];
     }
     wave_lds_sync();
+    pc.mark(3);
     // vertical pass only where the rotated pattern samples (512 points instead of the 37 x 37 patch): 7 taps straight from hb
     float a, b;
     sincos_deg(angle, &a, &b);
+#ifdef YGZF_PHASE_CLOCK
+    asm volatile("" :: "v"(a), "v"(b));
+#endif
+    pc.mark(4);
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int p = it * 64 + lane;
@@ -2047,6 +2041,7 @@ __device__ __forceinline__ void describe_window(const uint8_t *__restrict__ img,
         t1 = min(t1, 255);
         bits[it] = __ballot(t0 < t1);
     }
+    pc.mark(5);
     *angleOut = angle;
 #undef RAWP
 }
@@ -2075,6 +2070,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
                                                             int outStride, int blocksPerXcd, int nlevels, int *__restrict__ outCnt) {
     __shared__ DescLds lds[kDescWaves];
     const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(wave_id());   // wave-uniform: the keypoint record loads go scalar
+    PhaseClk pc;
+    pc.start();
     const int f = blockIdx.y;
     // XCD-aware: workgroup b runs on XCD b % 8; every XCD gets a contiguous run of (spatially ordered) keypoint slots so
     // that overlapping 43x43 windows meet in the same L2.  s = processing position inside the frame's level-major capacity layout.
@@ -2108,7 +2105,7 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
     else { pitch = gp->pitch; img = fs.pyr + (long long) f * fs.pyr_stride + gp->off; }
     float angle;
     unsigned long long bits[4];
-    describe_window<CVM>(img, pitch, gw, gh, kx, ky, lds[wave], lane, &angle, bits);
+    describe_window<CVM>(img, pitch, gw, gh, kx, ky, lds[wave], lane, &angle, bits, pc);
     ygzf_kp *ok = outKp + (long long) f * outStride + slot;
     uint8_t *od = outDesc + ((long long) f * outStride + slot) * 32;
     if (lane < 4) ((unsigned long long *) od)[lane] = bits[lane];
@@ -2123,6 +2120,8 @@ __global__ __launch_bounds__(64 * kDescWaves) __attribute__((amdgpu_waves_per_eu
         kp.class_id = -1;
         *ok = kp;
     }
+    pc.mark(6);
+    pc.flush(1, lane, (unsigned) s + (unsigned) f * (unsigned) kpStride);
 }
 
 // Orientation + descriptor of an explicit keypoint list (the Frame* overload, src/ORBextractor.cc:1031-1127: keys that already
@@ -2143,7 +2142,9 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe_list(FrameSet fs, 
     const uint8_t *img = level_ptr(fs, g, level, frame, &pitch);
     float angle;
     unsigned long long bits[4];
-    describe_window<CVM>(img, pitch, g.w, g.h, e.x, e.y, lds[wave], lane, &angle, bits, (e.z & 0x100) != 0, __int_as_float(e.w));
+    PhaseClk pc;   // (the phase clock reports k_describe; here it is only the argument)
+    pc.start();
+    describe_window<CVM>(img, pitch, g.w, g.h, e.x, e.y, lds[wave], lane, &angle, bits, pc, (e.z & 0x100) != 0, __int_as_float(e.w));
     if (lane < 4) ((unsigned long long *) (outDesc + (long long) i * 32))[lane] = bits[lane];
     if (lane == 0) outAngle[i] = angle;
 }
@@ -2376,16 +2377,15 @@ size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap) {
 }
 void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
                      int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
-                     unsigned *stats, bool preTest) {
+                     unsigned *stats) {
     if (totalGroups <= 0) return;
     const int totalWgs = totalGroups * (4 / kFastTabWaves);                 // workgroups of kFastTabWaves cells
     const int groupsPerXcd = (totalWgs + 7) / 8;
     const dim3 grid(8 * groupsPerXcd, nFrames), block(64 * kFastTabWaves);
     const size_t lds = fast_tab_lds_bytes(winRows, smapRows, quadCap);
-#define YGZF_LAUNCH_TAB(INI, PRE) hipLaunchKernelGGL((k_fast_tab<INI, PRE>), grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalWgs, \
+#define YGZF_LAUNCH_TAB(INI) hipLaunchKernelGGL((k_fast_tab<INI>), grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, totalWgs, \
                                                    groupsPerXcd, winRows, smapRows, quadCap, stats)
-    if (iniFirst) { if (preTest) YGZF_LAUNCH_TAB(true, true); else YGZF_LAUNCH_TAB(true, false); }
-    else { if (preTest) YGZF_LAUNCH_TAB(false, true); else YGZF_LAUNCH_TAB(false, false); }
+    if (iniFirst) YGZF_LAUNCH_TAB(true); else YGZF_LAUNCH_TAB(false);
 #undef YGZF_LAUNCH_TAB
 }
 

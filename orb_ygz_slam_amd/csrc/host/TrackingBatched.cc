@@ -128,7 +128,20 @@ inline ygzf_camera camera_of(const ygz::Frame &F) {
 }  // namespace
 
 // candidates from which Tracking::SearchLocalPoints takes the fused device frustum + matcher call (below: the reference's own loop over the per-call members)
-int ygzf_host_device_frustum_min = getenv("YGZF_FRUSTUM_DEVICE_MIN") ? atoi(getenv("YGZF_FRUSTUM_DEVICE_MIN")) : 1500;
+// YGZF_FRUSTUM_DEVICE_MIN overrides the default (a non-negative integer; anything else is ignored with a warning).  0 = always fused.
+static int frustum_min_from_env() {
+    const int dflt = 1500;
+    const char *e = getenv("YGZF_FRUSTUM_DEVICE_MIN");
+    if (!e || !*e) return dflt;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (*end != '\0' || v < 0 || v > 100000000) {
+        fprintf(stderr, "[ygzf] YGZF_FRUSTUM_DEVICE_MIN=%s ignored (want a non-negative integer); using %d\n", e, dflt);
+        return dflt;
+    }
+    return (int) v;
+}
+int ygzf_host_device_frustum_min = frustum_min_from_env();
 
 namespace ygz {
 

@@ -56,8 +56,9 @@ constexpr int kFastTabMaxCell = 41;
 size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap);
 void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
                      int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
-                     unsigned *stats, bool preTest);
-constexpr int kFastStatWords = 8 * 64;   // `stats`: 64 x {cells sampled, cells whose keypoints are FAST(minTh)'s, score rounds beyond the first, plan: 1 one pass / 2 iniTh first, corner-bearing quads, quads, pre-test survivors, -}
+                     unsigned *stats);
+hipError_t phase_clocks_read(int kernel, unsigned long long *out16, bool reset);   // -DYGZF_PHASE_CLOCK builds only (hipErrorNotSupported otherwise)
+constexpr int kFastStatWords = 8 * 64;   // `stats`: 64 x {cells sampled, cells whose keypoints are FAST(minTh)'s, score rounds beyond the first, plan: 1 one pass / 2 iniTh first, corner-bearing quads, quads, -, pass-1 runs}
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes);
 size_t octree_hist_lds_bytes(int regionInts, int histBins);
 hipError_t octree_prepare(size_t ldsBytes, bool globalNodes, bool hist);

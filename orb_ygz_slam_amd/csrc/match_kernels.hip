@@ -119,7 +119,7 @@ __device__ __forceinline__ unsigned wave_min_dpp(unsigned v) {
 // fenced path unconditionally); (2) the build (orb_ygz_slam_amd/build.py: check_handover_isa) disassembles this file and fails unless
 // k_handover_probe -- the same two inline functions, same flags -- is exactly one sc1 load and one sc1 store and k_match_last carries the
 // scoped accesses of its hand-over; (3) tests/test_gpu_handover.py runs the split path hundreds of times under load against the serial pass.
-#if defined(__gfx950__) || defined(__gfx942__)
+#if (defined(__gfx950__) || defined(__gfx942__)) && !defined(YGZF_FORCE_HANDOVER_FENCE)   // (the macro: build.py, when its ISA check fails)
 constexpr bool kHandoverScopedAccess = true;
 #else
 constexpr bool kHandoverScopedAccess = false;   // host pass of the compilation, or a target the argument above was not made for

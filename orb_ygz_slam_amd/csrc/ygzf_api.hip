@@ -86,7 +86,7 @@ static void plan_pyr_strips(Geometry &G, int L) {
     // the pixels of the pyramid at 16); eight frames: 16 strips 218 us, 32 215
     // (more strips when the LDS regions do not fit, fewer for images whose last level has fewer than 64 rows).
     const int candidates[] = {32, 48, 64, 16, 8};
-    const int minS = getenv("YGZF_PYR_STRIPS") ? atoi(getenv("YGZF_PYR_STRIPS")) : 0;   // A/B runs: at least this many strips
+    const int minS = (int) forced("pyr_strips", 0);   // at least this many strips (tests: the strip plans of large images on small ones)
     for (int S : candidates) {
         if (S < minS) continue;
         if (G.lv[L - 1].h < 2 * S) continue;
@@ -336,8 +336,7 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             // move them to a global arena
             c->octGlobalNodes = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, false) > 142 * 1024;
             const size_t fixed = octree_lds_bytes(G.maxCellsPerLevel, G.kpCapMax, 0, c->octGlobalNodes);
-            static const long octKb = getenv("YGZF_OCT_LDS_KB") ? atol(getenv("YGZF_OCT_LDS_KB")) : 71;   // A/B runs
-            const size_t budget = (size_t) octKb * 1024;   // default: two workgroups per CU beside 9 KB of static LDS each (radix histogram)
+            const size_t budget = (size_t) 71 * 1024;   // two workgroups per CU beside 9 KB of static LDS each (radix histogram); 48 / 36 / 24 KB measured slower (profiles/r05_f_octree_lds_and_streams.txt)
             c->octLdsCand = fixed + 16 * 256 < budget ? (int) ((budget - fixed) / 16) : 0;
             if (c->octLdsCand > 8192) c->octLdsCand = 8192;
         }
@@ -346,11 +345,10 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         // (extract_kernels.hip, k_octree<.., kHist>).  Consecutive levels are launched together while their list caps stay within a factor of two of
         // the group's first level, so that the small levels do not reserve the LDS of the large ones.
         c->octGroups.clear();
-        // (YGZF_OCT_PLAN=hist / sort forces one plan, YGZF_OCT_HIST_BINS bounds the histogram: the tests run every geometry through both plans
+        // (YGZF_FORCE=oct_plan=hist / sort pins one plan, oct_hist_bins bounds the histogram: the tests run every geometry through both plans
         // and through the fall-back from one to the other)
-        const char *planEnv = getenv("YGZF_OCT_PLAN");
-        const bool wantHist = planEnv && !strcmp(planEnv, "hist") ? true : planEnv && !strcmp(planEnv, "sort") ? false : (c->octGlobalNodes || c->octLdsCand == 0);
-        const int binsEnv = getenv("YGZF_OCT_HIST_BINS") ? atoi(getenv("YGZF_OCT_HIST_BINS")) : 0;
+        const bool wantHist = forced_is("oct_plan", "hist") ? true : forced_is("oct_plan", "sort") ? false : (c->octGlobalNodes || c->octLdsCand == 0);
+        const int binsEnv = (int) forced("oct_hist_bins", 0);
         if (wantHist) {
             bool ok = true;
             for (int l = 0; l < L && ok;) {
@@ -381,7 +379,7 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         // per level; its tree passes 12 us against 20) wins even where the candidates would fit LDS -- if all levels go in ONE launch, sized for
         // the largest (with a handful of workgroups nobody else wants the LDS).  Launches of up to 128 workgroups take it (YGZF_OCT_SMALL_WGS; YGZF_OCT_PLAN=sort: never).
         c->haveOctSmall = false;
-        if (!(planEnv && !strcmp(planEnv, "sort"))) {
+        if (!forced_is("oct_plan", "sort")) {
             ygzf_ctx::OctGroup grp;
             grp.l0 = 0;
             grp.n = L;
@@ -537,11 +535,11 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
         // threshold plan of this launch: from the statistics of an earlier launch of this context (whatever the asynchronous copy has
         // delivered by now; a stale or half-written snapshot only affects speed -- both plans return the same keypoints)
         {
-            unsigned cells = 0, usedMin = 0, extra = 0, planBits = 0, cornerQuads = 0, survivors = 0, runs = 0;
+            unsigned cells = 0, usedMin = 0, extra = 0, planBits = 0, cornerQuads = 0, runs = 0;
             const volatile unsigned *hs = c->hFastStats;   // written by the copy engine, possibly right now
             for (int k = 0; k < 64; k++) {
                 cells += hs[8 * k]; usedMin += hs[8 * k + 1]; extra += hs[8 * k + 2]; planBits |= hs[8 * k + 3];
-                cornerQuads += hs[8 * k + 4]; survivors += hs[8 * k + 6]; runs += hs[8 * k + 7];
+                cornerQuads += hs[8 * k + 4]; runs += hs[8 * k + 7];
             }
             const unsigned plan = planBits & 3u;
             if (cells >= 32 && (plan == 1 || plan == 2)) {
@@ -549,21 +547,9 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                 // a score round costs ~180 vector instructions per wave, a second pass 1 ~700: iniTh first pays when the rounds it saves
                 // outweigh the second passes of the cells that are empty at iniTh
                 c->fastIniFirst = c->fastExtraRounds * 180.0 > ((double) usedMin / cells) * 700.0;
-                // Two-phase pass 1 (fast9_pre_quad).  Measured (profiles/r05_d_fast_pretest_ab.jsonl, 256 frames per launch, isolated): the
-                // corner-dense synthetic clip, 60 of 240 quads surviving per run, 421 -> 463 us; the clip cut from the one real image the
-                // reference ships, 39 survivors (21 corner-bearing quads), 358 -> 370 us -- the cheap test is eleven LDS reads and sixty
-                // vector instructions on EVERY quad and only pays back where the full test then has (almost) nothing to do.  So it is
-                // switched on only for nearly empty content (dark, blank or defocused frames: a handful of corner-bearing quads per cell)
-                // and off again as soon as a launch that ran it reports more than a dozen survivors per run.
                 if (runs > 0) {
-                    const double perRun = (double) cornerQuads / runs;
-                    if (planBits & 4u) {
-                        c->fastPreAuto = (double) survivors / runs <= 12.0;
-                        if (!c->fastPreAuto) c->fastPreRejectedAt = perRun;
-                    } else if (!c->fastPreAuto)
-                        c->fastPreAuto = perRun <= 3.0 && (c->fastPreRejectedAt <= 0.0 || perRun < 0.7 * c->fastPreRejectedAt);
-                    c->fastCornerQuadsPerRun = perRun;
-                    if (planBits & 4u) c->fastSurvivorsPerRun = (double) survivors / runs;
+                    c->fastCornerQuadsPerRun = (double) cornerQuads / runs;
+                    c->fastRunsPerCell = (double) runs / cells;
                 }
             }
         }
@@ -584,8 +570,7 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             if (tab)
                 launch_fast_tab(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                 (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,
-                                nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr,
-                                c->fastPre == 2 || (c->fastPre == 0 && c->fastPlan == 0 && c->fastPreAuto));
+                                nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
             else
                 launch_fast_cells(c->stream, fs, dGeom, L, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                   (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups,
@@ -600,8 +585,7 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             HIPCHECK(c, hipMemsetAsync(odbg, 0, kOctDbgWords * sizeof(long long), c->stream));
         }
         {
-            hipStream_t so = fill_begin(c);
-            {
+            hipStream_t so = c->stream;
             ProfScope ps(c, KK_OCTREE, so);
             const bool small = c->haveOctSmall && nFrames * L <= c->octSmallWgs;
             if (small) {
@@ -625,8 +609,6 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                                   (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                                   (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
                                   (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins);
-            }
-            fill_end(c);
         }
         if (odbg) {
             long long st[kOctDbgWords];
@@ -692,7 +674,7 @@ int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, i
     const int pitch = align_up(w, 64);
     int rc = ensure(c, c->dImg0, (size_t) nFrames * pitch * h);
     if (rc) return rc;
-    if (nFrames == 1 && !getenv("YGZF_NO_STAGED_UPLOAD")) {
+    if (nFrames == 1) {
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof at);
         bool pageable = true;
@@ -727,22 +709,13 @@ int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, i
             return YGZF_OK;
         }
     }
-    // Host frames that already carry the device's row pitch (ygzf_host_row_pitch): the copy engine pays per ROW of a pitched copy (752-byte rows:
-    // 48 GB/s where 1920-byte rows reach 55), so the rows handed to it are runs of k image rows -- (k - 1) x pitch + w bytes, k = the whole
-    // frame by default -- and the padding bytes between image rows travel with them.
-    static const int upK = getenv("YGZF_UPLOAD_K") ? atoi(getenv("YGZF_UPLOAD_K")) : 0;   // 0: whole frames; 1: image rows (as before); k: runs of k rows (k divides h) -- A/B runs
-    if (row_pitch == pitch && pitch != w && upK != 1 && (nFrames == 1 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
+    // Host frames that already carry the device's row pitch (ygzf_host_row_pitch): the copy engine pays per ROW of a pitched copy whose source rows
+    // are not multiples of 64 bytes (752-byte rows: 48 GB/s where 1920-byte rows reach 55), so a whole frame -- (h - 1) x pitch + w bytes, padding
+    // included -- is handed to it as ONE row (runs of 8 / 60 image rows measured the same: profiles/r05_a_h2d_shapes.txt)
+    if (row_pitch == pitch && pitch != w && (nFrames == 1 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
         (frame_stride & 3) == 0) {
         const size_t fsd = (size_t) pitch * h, fss = nFrames == 1 ? fsd : frame_stride;
-        const int k = (upK > 1 && h % upK == 0) ? upK : h;
-        if (k == h) {
-            HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, fsd, imgs, fss, (size_t) (h - 1) * pitch + w, (size_t) nFrames, hipMemcpyHostToDevice, c->stream));
-        } else if (fss == fsd) {
-            HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, (size_t) k * pitch, imgs, (size_t) k * pitch, (size_t) (k - 1) * pitch + w, (size_t) nFrames * (h / k), hipMemcpyHostToDevice, c->stream));
-        } else {
-            for (int f = 0; f < nFrames; f++)
-                HIPCHECK(c, hipMemcpy2DAsync((uint8_t *) c->dImg0.p + f * fsd, (size_t) k * pitch, imgs + f * fss, (size_t) k * pitch, (size_t) (k - 1) * pitch + w, (size_t) (h / k), hipMemcpyHostToDevice, c->stream));
-        }
+        HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, fsd, imgs, fss, (size_t) (h - 1) * pitch + w, (size_t) nFrames, hipMemcpyHostToDevice, c->stream));
     } else if (nFrames == 1 || frame_stride == (size_t) row_pitch * h) {   // frames back to back: one copy of nFrames * h rows
         if ((rc = upload_rows(c, c->dImg0.p, (size_t) pitch, imgs, (size_t) row_pitch, w, (size_t) nFrames * h))) return rc;
     } else {
@@ -803,15 +776,10 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     CK(upload_constants(c->tab.umax));
     CK(hipHostMalloc((void **) &c->hFastStats, kFastStatWords * sizeof(unsigned)));
     memset(c->hFastStats, 0, kFastStatWords * sizeof(unsigned));
-    if (const char *e = getenv("YGZF_FAST_KERNEL")) c->fastKernel = atoi(e) == 1 ? 1 : atoi(e) == 2 ? 2 : 0;
 #undef CK
     // validate the largest configuration up front (and size the buffers once)
     int rc = apply_geometry(c, max_width, max_height, max_batch);
     if (rc) return bail(rc);
-    if (const char *e = getenv("YGZF_FILL_CUS")) {   // A/B runs: the stream partition of every context of the process (ygzf_set_stream_partition)
-        const int mm = getenv("YGZF_MAIN_MODE") ? atoi(getenv("YGZF_MAIN_MODE")) : 0;
-        if ((atoi(e) != 0 || mm != 0) && (rc = ygzf_set_stream_partition(c, atoi(e), mm))) return bail(rc);
-    }
     *out = c;
     return YGZF_OK;
 }
@@ -867,9 +835,6 @@ void ygzf_destroy(ygzf_ctx *c) {
     if (c->evPyrDone) (void) hipEventDestroy(c->evPyrDone);
     if (c->evPyramid) (void) hipEventDestroy(c->evPyramid);
     if (c->streamCopy) (void) hipStreamDestroy(c->streamCopy);
-    if (c->streamFill) (void) hipStreamDestroy(c->streamFill);
-    for (auto e : c->evHop)
-        if (e) (void) hipEventDestroy(e);
     if (c->tStart) (void) hipEventDestroy(c->tStart);
     if (c->tStop) (void) hipEventDestroy(c->tStop);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -896,18 +861,20 @@ int ygzf_set_fast_plan(ygzf_ctx *c, int plan) {
     return YGZF_OK;
 }
 
-int ygzf_set_fast_pretest(ygzf_ctx *c, int mode) {
+int ygzf_get_fast_stats(const ygzf_ctx *c, float *corner_quads_per_pass, float *passes_per_cell) {
     if (!c) return YGZF_ERR_INVALID;
-    if (mode < 0 || mode > 2) return fail(c, YGZF_ERR_INVALID, "FAST pre-test mode %d (0 auto, 1 never, 2 always)", mode);
-    c->fastPre = mode;
+    if (corner_quads_per_pass) *corner_quads_per_pass = (float) c->fastCornerQuadsPerRun;
+    if (passes_per_cell) *passes_per_cell = (float) c->fastRunsPerCell;
     return YGZF_OK;
 }
 
-int ygzf_get_fast_stats(const ygzf_ctx *c, int *pretest_on, float *corner_quads_per_pass, float *survivors_per_pass) {
-    if (!c) return YGZF_ERR_INVALID;
-    if (pretest_on) *pretest_on = (c->fastPre == 2 || (c->fastPre == 0 && c->fastPlan == 0 && c->fastPreAuto)) ? 1 : 0;
-    if (corner_quads_per_pass) *corner_quads_per_pass = (float) c->fastCornerQuadsPerRun;
-    if (survivors_per_pass) *survivors_per_pass = (float) c->fastSurvivorsPerRun;
+int ygzf_phase_clocks(ygzf_ctx *c, int kernel, unsigned long long *out16, int reset) {
+    if (!c || !out16 || kernel < 0 || kernel > 1) return YGZF_ERR_INVALID;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const hipError_t e = phase_clocks_read(kernel, out16, reset != 0);
+    if (e == hipErrorNotSupported) return fail(c, YGZF_ERR_INVALID, "this library was built without -DYGZF_PHASE_CLOCK (python -m orb_ygz_slam_amd.build --phase-clock)");
+    HIPCHECK(c, e);
     return YGZF_OK;
 }
 
@@ -927,43 +894,6 @@ int ygzf_set_extract_ahead(ygzf_ctx *c, int on) {
     }
     c->extractAhead = on != 0;
     if (!on) c->aheadPending = false;
-    return YGZF_OK;
-}
-
-int ygzf_set_stream_partition(ygzf_ctx *c, int fill_cus, int main_mode) {
-    if (!c) return YGZF_ERR_INVALID;
-    if (main_mode < 0 || main_mode > 1) return fail(c, YGZF_ERR_INVALID, "main_mode %d (0 all compute units, 1 the complement of the filler's share)", main_mode);
-    HIPCHECK(c, hipSetDevice(c->device));
-    hipDeviceProp_t prop;
-    HIPCHECK(c, hipGetDeviceProperties(&prop, c->device));
-    const int nCU = prop.multiProcessorCount;
-    if (fill_cus < -1 || fill_cus >= nCU) return fail(c, YGZF_ERR_INVALID, "fill_cus %d (-1 unmasked second stream, 0 off, 1..%d compute units)", fill_cus, nCU - 1);
-    if (main_mode == 1 && fill_cus <= 0) return fail(c, YGZF_ERR_INVALID, "main_mode 1 needs a filler share");
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
-    if (c->streamFill) {
-        HIPCHECK(c, hipStreamSynchronize(c->streamFill));
-        HIPCHECK(c, hipStreamDestroy(c->streamFill));
-        c->streamFill = nullptr;
-    }
-    // mask bit i is compute unit i / 8 of XCD i % 8 (the driver deals the bits round-robin over the XCDs and, inside one, over its shader
-    // engines): the first n bits are n / 8 compute units of every XCD
-    const int words = (nCU + 31) / 32;
-    std::vector<uint32_t> fill((size_t) words, 0u), rest((size_t) words, 0u);
-    for (int i = 0; i < nCU; i++) (i < fill_cus ? fill : rest)[(size_t) i / 32] |= 1u << (i % 32);
-    if (c->mainMode != main_mode || (main_mode == 1 && c->fillCUs != fill_cus)) {   // the context's own stream changes its share
-        hipStream_t ns = nullptr;
-        if (main_mode == 1) HIPCHECK(c, hipExtStreamCreateWithCUMask(&ns, (uint32_t) words, rest.data()));
-        else HIPCHECK(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
-        HIPCHECK(c, hipStreamDestroy(c->stream));
-        c->stream = ns;
-    }
-    if (fill_cus > 0) HIPCHECK(c, hipExtStreamCreateWithCUMask(&c->streamFill, (uint32_t) words, fill.data()));
-    else if (fill_cus < 0) HIPCHECK(c, hipStreamCreateWithFlags(&c->streamFill, hipStreamNonBlocking));
-    if (c->streamFill)
-        for (auto &e : c->evHop)
-            if (!e) HIPCHECK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    c->fillCUs = fill_cus;
-    c->mainMode = main_mode;
     return YGZF_OK;
 }
 
@@ -1164,12 +1094,7 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
     c->pyrHeld = false;
     const int pitch = align_up(w, 64);
     if ((rc = ensure(c, c->dImg0, (size_t) n_frames * pitch * h))) return rc;
-    // frames in page-locked, device-visible host memory are read by a kernel over the link (one launch per 128 frames instead of one pitched copy per
-    // frame); anything else goes through the copy engine frame by frame
-    bool gathered = false;
-    const char *modeEnv = getenv("YGZF_HOST_FRAMES_MODE");      // 1: the kernel reads the host frames itself; 2 (default): one linear copy per frame + one re-pitch launch; 0: pitched copies
-    const int mode = modeEnv ? atoi(modeEnv) : 2;
-    if (mode == 2) {
+    {
         // Into a tight staging buffer with the copy engine's fast paths, then ONE launch per 128 frames that lays the rows out at the context's
         // pitch.  Frames that come as runs of u back-to-back frames at one distance S (a device slot's round-robin share of a tight clip: units of u
         // frames, S = slots x u frames) go up as ONE two-dimensional copy whose "rows" are the runs; anything else as one linear copy per frame.
@@ -1210,28 +1135,7 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
             launch_gather_host_frames(c->stream, L, nf, (size_t) row_pitch, (uint8_t *) c->dImg0.p + (size_t) f0 * pitch * h, (size_t) pitch, (size_t) pitch * h, w, h);
         }
         HIPCHECK(c, hipGetLastError());
-        gathered = true;
     }
-    if (mode == 1) {
-        gathered = true;
-        for (int f0 = 0; f0 < n_frames && gathered; f0 += kHostFrameListMax) {
-            HostFrameList L;
-            const int nf = std::min(kHostFrameListMax, n_frames - f0);
-            for (int f = 0; f < nf && gathered; f++) {
-                hipPointerAttribute_t at;
-                memset(&at, 0, sizeof at);
-                if (hipPointerGetAttributes(&at, frames[f0 + f]) != hipSuccess) { (void) hipGetLastError(); gathered = false; break; }
-                if (at.type != hipMemoryTypeHost || !at.devicePointer) { gathered = false; break; }
-                L.addr[f] = (unsigned long long) (uintptr_t) at.devicePointer;
-            }
-            if (!gathered) break;
-            launch_gather_host_frames(c->stream, L, nf, (size_t) row_pitch, (uint8_t *) c->dImg0.p + (size_t) f0 * pitch * h, (size_t) pitch, (size_t) pitch * h, w, h);
-        }
-        if (gathered) HIPCHECK(c, hipGetLastError());
-    }
-    if (!gathered)
-        for (int f = 0; f < n_frames; f++)
-            if ((rc = upload_rows(c, (uint8_t *) c->dImg0.p + (size_t) f * pitch * h, (size_t) pitch, frames[f], (size_t) row_pitch, w, (size_t) h))) return rc;
 uploaded:
     FrameSet fs;
     fs.img0 = (const uint8_t *) c->dImg0.p;

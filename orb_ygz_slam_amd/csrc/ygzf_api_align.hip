@@ -431,8 +431,8 @@ int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, in
             // Many pairs in flight: the workgroup keeps to 74 KB of LDS so that TWO share a CU -- one pair's solve (a single wave) and barriers
             // then overlap the other's accumulate; the coarse levels that no longer fit the staging area are gathered from L2 instead
             // (measured on 256-pair launches from three streams: 141.1 -> 147.2 k frames/s; a lone pair keeps the full staging area).
-            static const long capKb = getenv("YGZF_SIA_LDS_CAP") ? atol(getenv("YGZF_SIA_LDS_CAP")) : 74;   // A/B runs (0: no cap)
-            if (B - first >= 128 && capKb > 0) {
+            constexpr long capKb = 74;
+            if (B - first >= 128) {
                 const long cap = capKb * 1024 - A2.stageOff;
                 A2.stageBytes = cap > 4096 ? (int) std::min<long>(A2.stageBytes, cap & ~15L) : 0;
             }

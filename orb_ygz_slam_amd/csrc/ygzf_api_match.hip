@@ -131,12 +131,8 @@ int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_m
     size_t lds;
     if ((rc = plan_match_lds(c, A, B, &lds))) return rc;
     {
-        hipStream_t sm = fill_begin(c);
-        {
-            ProfScope ps(c, KK_MATCH, sm);
-            launch_match_last(sm, A, B, lds);
-        }
-        fill_end(c);
+        ProfScope ps(c, KK_MATCH);
+        launch_match_last(c->stream, A, B, lds);
     }
     HIPCHECK(c, hipGetLastError());
     if (A.dbg) {

@@ -85,7 +85,7 @@ struct ygzf_ctx {
     std::vector<OctGroup> octGroups;
     OctGroup octSmall;                     // all levels in ONE histogram-plan launch: launches of a few frames (see run_extract)
     bool haveOctSmall = false;
-    int octSmallWgs = getenv("YGZF_OCT_SMALL_WGS") ? atoi(getenv("YGZF_OCT_SMALL_WGS")) : 128;   // launches of up to this many workgroups take it (A/B runs; 752x480: 16 frames 0.211 against 0.221 ms, 64 frames 0.439 against 0.430)
+    static constexpr int octSmallWgs = 128;   // launches of up to this many workgroups take it (752x480: 16 frames 0.211 against 0.221 ms, 64 frames 0.439 against 0.430)
     Buf dOctNodes;
     // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at
     // minTh, 2 = iniTh first.  Identical results either way.
@@ -93,10 +93,7 @@ struct ygzf_ctx {
     bool fastIniFirst = false;
     unsigned fastLaunches = 0;             // statistics are collected on the first launches and on every 8th one after that
     double fastExtraRounds = 0.0;          // score rounds beyond the first per cell, last measured by the one-pass plan
-    // two-phase pass 1 of k_fast_tab (fast9_pre_quad): 0 chosen per batch from the statistics, 1 never, 2 always (ygzf_set_fast_pretest)
-    int fastPre = getenv("YGZF_FAST_PRETEST") ? atoi(getenv("YGZF_FAST_PRETEST")) : 0;
-    bool fastPreAuto = false;
-    double fastPreRejectedAt = 0.0, fastCornerQuadsPerRun = 0.0, fastSurvivorsPerRun = 0.0;
+    double fastCornerQuadsPerRun = 0.0, fastRunsPerCell = 0.0;   // last sampled: corner-bearing quads per pass-1 run, pass-1 runs per cell (ygzf_get_fast_stats)
     Buf dFastStats;
     Buf dFastCells;                        // FastCellRec table of the current geometry (k_fast_tab)
     Buf dMatchStat;                        // one counter: pairs that fell back to the matcher's one-wave pass (ygzf_match_fallbacks)
@@ -128,29 +125,24 @@ struct ygzf_ctx {
     hipEvent_t tStart = nullptr, tStop = nullptr;
     // ygzf_set_extract_ahead: ygzf_compute_pyramid queues the extraction behind the pyramid and reads the levels back on a second stream
     // one-frame pyramid chain as a captured graph: seven dependent launches cost the host more than the kernels take (pyramid_chain)
-    bool useGraphs = getenv("YGZF_NO_GRAPH") == nullptr;
-    int pyrStripFrames = getenv("YGZF_PYR_STRIP_FRAMES") ? atoi(getenv("YGZF_PYR_STRIP_FRAMES")) : 16;   // k_pyr_strips up to this many frames per launch (0: never)
+    bool useGraphs = !debug_flag("nograph");
+    int pyrStripFrames = (int) forced("pyr_strip_frames", 16);   // k_pyr_strips up to this many frames per launch (0: never)
     PyrChainGraph pyrGraph = {};
     const void *pyrGraphKey[6] = {nullptr};   // geometry tables + size the graph was built for
     bool extractAhead = false, aheadPending = false;
     hipStream_t streamCopy = nullptr;
     hipEvent_t evPyramid = nullptr;
-    // ygzf_set_stream_partition: the latency-bound kernels of the chain (k_octree, k_match_last) on a second stream restricted to a share of the
-    // compute units, so that their long-lived, rarely-issuing workgroups do not take wave slots from the issue-bound kernels of other contexts
-    hipStream_t streamFill = nullptr;
-    int fillCUs = 0, mainMode = 0;
-    hipEvent_t evHop[8] = {nullptr};
-    unsigned hopSeq = 0;
     bool profile = false;
     // debugging aids, read once per context (never on the launch path): synchronise after every kernel and name it on stderr /
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
-    bool debugSync = getenv("YGZF_DEBUG_SYNC") != nullptr;
-    int matchSplit = getenv("YGZF_MATCH_SPLIT") ? atoi(getenv("YGZF_MATCH_SPLIT")) : 0;   // 0 automatic, 1 off, n workgroups per pair (A/B runs)
-    int matchFixedLanes = getenv("YGZF_MATCH_LANES") && !strcmp(getenv("YGZF_MATCH_LANES"), "fixed");   // (A/B runs)
-    int matchFence = getenv("YGZF_MATCH_FENCE") ? atoi(getenv("YGZF_MATCH_FENCE")) : 0;   // 1: full fences around the matcher's hand-over (A/B runs)
-    int matchSerial = getenv("YGZF_MATCH_SERIAL") ? atoi(getenv("YGZF_MATCH_SERIAL")) : 0;   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
-    bool siaPerLevel = !(getenv("YGZF_SIA_PRECOMPUTE") && atoi(getenv("YGZF_SIA_PRECOMPUTE")) == 0);   // reference patches of all levels in a kernel of their own (0: inside k_sia_run, as until round 4)
-    bool octDebug = getenv("YGZF_OCT_DEBUG") != nullptr, matchDebug = getenv("YGZF_MATCH_DEBUG") != nullptr, siaDebug = getenv("YGZF_SIA_DEBUG") != nullptr;
+    bool debugSync = debug_flag("sync");
+    // the plans below are the library's own choice unless YGZF_FORCE pins them (tests: every plan against the oracle; ygzf_internal.h)
+    int matchSplit = (int) forced("match_split", 0);   // 0 automatic, 1 off, n workgroups per pair
+    int matchFixedLanes = forced_is("match_lanes", "fixed");   // eight lanes per query whatever the launch
+    int matchFence = (int) forced("match_fence", 0);   // 1: full fences around the matcher's hand-over
+    int matchSerial = (int) forced("match_serial", 0);   // 1: the one-wave in-order pass instead of the fixpoint; 2: fixpoint that hands over at the first exhausted list (tests)
+    bool siaPerLevel = forced("sia_precompute", 1) != 0;   // reference patches of all levels in a kernel of their own (0: inside k_sia_run, as until round 4)
+    bool octDebug = debug_flag("oct"), matchDebug = debug_flag("match"), siaDebug = debug_flag("sia");
     struct Rec { int kind; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -213,9 +205,9 @@ static int ensure_stage(ygzf_ctx *c, size_t bytes) {
 // One-frame entry points hand over a dozen small host arrays and take a few back.  From pageable memory every hipMemcpyAsync is a staged copy
 // of its own (10-20 us of runtime work apiece; twelve of them cost more than the kernel they feed): the arrays are packed into the context's
 // page-locked staging area and cross the link as ONE copy each way.
-// callers with more than this in flight keep their own copies (the staging area is page-locked memory); YGZF_PACKED_MAX (bytes) lowers it so
+// callers with more than this in flight keep their own copies (the staging area is page-locked memory); YGZF_FORCE=packed_max=<bytes> lowers it so
 // that tests reach the large-transfer paths with ordinary frames
-static const size_t kPackedMax = getenv("YGZF_PACKED_MAX") ? (size_t) atoll(getenv("YGZF_PACKED_MAX")) : (size_t) (4u << 20);
+static const size_t kPackedMax = (size_t) forced("packed_max", 4l << 20);
 struct PackedTransfer {
     ygzf_ctx *c;
     struct Seg { const void *src; void *dst; size_t bytes, off; };
@@ -295,22 +287,6 @@ struct ProfScope {
         }
     }
 };
-// The filler stream (ygzf_set_stream_partition): fill_begin makes it wait for everything queued on the context's stream so far and returns it
-// (the context's own stream when there is no partition); fill_end makes the context's stream wait for what was queued on it.  Every hop is
-// closed before an entry point returns, so that synchronising c->stream still drains the whole context.
-static hipStream_t fill_begin(ygzf_ctx *c) {
-    if (!c->streamFill) return c->stream;
-    hipEvent_t e = c->evHop[c->hopSeq++ & 7];
-    (void) hipEventRecord(e, c->stream);
-    (void) hipStreamWaitEvent(c->streamFill, e, 0);
-    return c->streamFill;
-}
-static void fill_end(ygzf_ctx *c) {
-    if (!c->streamFill) return;
-    hipEvent_t e = c->evHop[c->hopSeq++ & 7];
-    (void) hipEventRecord(e, c->streamFill);
-    (void) hipStreamWaitEvent(c->stream, e, 0);
-}
 static void drain_profile(ygzf_ctx *c) {
     if (c->recs.empty()) return;
     (void) hipStreamSynchronize(c->stream);

@@ -3,6 +3,8 @@
 #define YGZF_INTERNAL_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -18,10 +20,7 @@ constexpr int kBorder = kEdgeThreshold - 3;  // minBorderX of ComputeKeyPointsOc
 constexpr int kMaxLevels = 16;
 constexpr int kMaxCellWin = 66;       // window side of one FAST cell: wCell(<60)+6
 constexpr int kFastBlock = 256;   // 4 waves (cell positions) per workgroup; single-wave workgroups measured slower: 739 vs 625 us per 256 frames
-#ifndef YGZF_OCT_BLOCK
-#define YGZF_OCT_BLOCK 1024
-#endif
-constexpr int kOctBlock = YGZF_OCT_BLOCK;   // threads per (level, frame) workgroup of k_octree (A/B builds: -DYGZF_OCT_BLOCK=512)
+constexpr int kOctBlock = 1024;   // threads per (level, frame) workgroup of k_octree (512 / 256 measured: no schedule effect, profiles/r05_f_octree_block_sweep.txt)
 // The dynamic-LDS ceiling of a kernel is a per-process attribute of the function: it is always set to the same value (the CU's 160 KB
 // minus room for static LDS), never to a per-call size, so that contexts used from different threads cannot lower it under each other.
 constexpr int kMaxDynLds = 160 * 1024 - 2048;
@@ -96,6 +95,44 @@ struct Tables {
 };
 
 int cv_round_host(double v);
+
+// ---- the library's environment switches, all of them -------------------------------------------------------------------------------
+// Two variables, read when a context (or a multi-GPU handle) is created, never on the launch path.  Neither changes a result.
+//   YGZF_DEBUG=flag,flag,...   sync     synchronise after every kernel and name it on stderr
+//                              nograph  launch the pyramid chain kernel by kernel instead of replaying its hipGraph
+//                              oct / match / sia   phase clocks of k_octree / k_match_last / k_sia_run printed to stderr (tools/*_phases.py)
+//   YGZF_FORCE=key=value,...   pins a plan that the library otherwise chooses itself from the shape of the launch, so that the tests can run EVERY
+//                              plan of a kernel against the oracle on small inputs (INTEGRATION.md lists the keys); a key that is absent leaves the
+//                              library's own choice in place.
+// (host/TrackingBatched.cc reads a third one, YGZF_FRUSTUM_DEVICE_MIN, documented there.)
+inline const char *env_find(const char *var, const char *key, size_t *len) {   // value of `key` inside the comma list $var; flags have an empty value
+    const char *e = getenv(var);
+    const size_t kl = strlen(key);
+    while (e && *e) {
+        const char *end = strchr(e, ',');
+        const size_t n = end ? (size_t) (end - e) : strlen(e);
+        if (n >= kl && !strncmp(e, key, kl) && (n == kl || e[kl] == '=')) {
+            *len = n == kl ? 0 : n - kl - 1;
+            return n == kl ? e + kl : e + kl + 1;
+        }
+        e = end ? end + 1 : nullptr;
+    }
+    return nullptr;
+}
+inline bool debug_flag(const char *flag) {
+    size_t n;
+    return env_find("YGZF_DEBUG", flag, &n) != nullptr;
+}
+inline long forced(const char *key, long dflt) {
+    size_t n;
+    const char *v = env_find("YGZF_FORCE", key, &n);
+    return v && n ? atol(v) : dflt;
+}
+inline bool forced_is(const char *key, const char *value) {
+    size_t n;
+    const char *v = env_find("YGZF_FORCE", key, &n);
+    return v && n == strlen(value) && !strncmp(v, value, n);
+}
 
 }  // namespace ygzf
 #endif

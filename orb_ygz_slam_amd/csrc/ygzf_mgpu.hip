@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/ygzf.h"
+#include "ygzf_internal.h"   // the environment switches (YGZF_FORCE)
 
 struct ygzf_mgpu {
     struct Dev {
@@ -91,14 +92,16 @@ int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg
     *out = nullptr;
     ygzf_mgpu *m = new ygzf_mgpu();
     m->maxW = max_width; m->maxH = max_height; m->maxFrames = max_frames_per_device;
-    if (const char *e = getenv("YGZF_MGPU_COPY_THREADS")) m->copyThreads = std::max(1, std::min(32, atoi(e)));
+    // (YGZF_FORCE keys of this entry point: mgpu_copy_threads, mgpu_chunk, mgpu_numa=0, mgpu_pinned=0 -- the tests make chunks small and treat
+    // page-locked frames as pageable with them; ygzf_internal.h)
+    m->copyThreads = (int) std::max(1l, std::min(32l, ygzf::forced("mgpu_copy_threads", m->copyThreads)));
     // frames per chunk: what a context and its staging are sized for -- 128 frames of 752x480, about 96 MB of level-0 pixels for larger images (46
     // frames of 1920x1080, 10 of 3840x2160), never more than the slot will be given
     const size_t px = (size_t) max_width * max_height;
     int chunk = (int) std::min<size_t>(128, std::max<size_t>(2, (96u << 20) / px));
-    if (const char *e = getenv("YGZF_MGPU_CHUNK")) chunk = std::max(1, atoi(e));
+    chunk = (int) std::max(1l, ygzf::forced("mgpu_chunk", chunk));
     m->chunk = std::max(1, std::min(chunk, max_frames_per_device));
-    const bool numa = !(getenv("YGZF_MGPU_NUMA") && atoi(getenv("YGZF_MGPU_NUMA")) == 0);
+    const bool numa = ygzf::forced("mgpu_numa", 1) != 0;
     m->devs.resize(n_devices);
     for (int i = 0; i < n_devices; i++) {
         ygzf_mgpu::Dev &d = m->devs[i];
@@ -226,7 +229,7 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         memset(&at, 0, sizeof at);
         if (hipPointerGetAttributes(&at, J.frames) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
         else (void) hipGetLastError();                // an ordinary malloc pointer is "invalid value" to the runtime: pageable
-        if (const char *e = getenv("YGZF_MGPU_PINNED")) pinned = pinned && atoi(e) != 0;
+        pinned = pinned && ygzf::forced("mgpu_pinned", 1) != 0;
     }
     const int nCopy = m->copyThreads;
     auto work = [&](int s, bool ownThread) {
@@ -318,8 +321,7 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         };
         prepare(0);
         int rc = launch(0);
-        static const bool lateLaunch = getenv("YGZF_MGPU_ORDER") && atoi(getenv("YGZF_MGPU_ORDER")) == 0;   // A/B runs: round 4's order (chunk k + 2 queued after chunk k is scattered)
-        if (alternate && !lateLaunch) {
+        if (alternate) {
             // Two contexts: chunk k + 1 is queued (upload, kernels) before chunk k is waited for, and the moment chunk k's results are in the staging
             // area its context takes chunk k + 2 -- BEFORE the host copies those results out: the link, which bounds the whole call, then never waits
             // for a host-side copy (scattering a chunk of 128 frames is 8 MB of memcpy, gathering a pageable one 46 MB: with either between two
@@ -335,9 +337,8 @@ int run_job(ygzf_mgpu *m, const Job &J) {
             for (int k = 0; k < nChunks && rc == YGZF_OK; k++) {
                 const bool more = k + 1 < nChunks;
                 if (more) prepare(k + 1);                        // the device works on chunk k meanwhile
-                if (more && alternate) rc = launch(k + 1);       // (A/B order only) the other context
                 if (rc == YGZF_OK) rc = fetch(k);
-                if (rc == YGZF_OK && more && !alternate) rc = launch(k + 1);   // one context: its outputs had to be read first
+                if (rc == YGZF_OK && more) rc = launch(k + 1);   // one context: its outputs had to be read first
                 if (rc == YGZF_OK) scatter(k);                   // the device works on chunk k + 1 meanwhile
             }
         }

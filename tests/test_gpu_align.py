@@ -288,13 +288,14 @@ def test_cache_slot_filled_from_the_extractor_that_holds_the_image(oracle):
 
 def test_in_kernel_reference_patches_agree():
     """Launches of up to 32 pairs build the reference patches of all levels in a kernel of their own (k_sia_precompute); larger ones -- and
-    YGZF_SIA_PRECOMPUTE=0 -- keep the per-level phase inside k_sia_run.  Both share one body (sia_ref_patch): the aligner tests, the bit-identity
+    YGZF_FORCE=sia_precompute=0 -- keep the per-level phase inside k_sia_run.  Both share one body (sia_ref_patch): the aligner tests, the bit-identity
     against the device-order oracle included, must hold with the in-kernel form too."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, YGZF_SIA_PRECOMPUTE="0")
+    from orb_ygz_slam_amd.capi import force_env
+    env = dict(os.environ, YGZF_FORCE=force_env(sia_precompute=0))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_align.py"),
                           os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k", "(align or sia) and not in_kernel_reference_patches"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)

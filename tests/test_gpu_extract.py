@@ -321,10 +321,10 @@ def test_pyramid_one_launch_and_level_by_level(oracle, monkeypatch, w, h, nl, sf
     imgs = np.stack([synth_frame(60 + i, w, h) for i in range(3)])
     oex = oracle.Extractor(500, sf, nl, 20, 7)
     want = [oex.pyramid(imgs[i]) for i in range(3)]
+    from orb_ygz_slam_amd.capi import force_env
     for strip_frames in ("8", "0"):
-        monkeypatch.setenv("YGZF_PYR_STRIP_FRAMES", strip_frames)
         for strips in ("0", "32"):
-            monkeypatch.setenv("YGZF_PYR_STRIPS", strips)
+            monkeypatch.setenv("YGZF_FORCE", force_env(pyr_strip_frames=strip_frames, pyr_strips=strips))
             ex = Extractor(500, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
             for batch in (imgs[:1], imgs):
                 ex.extract_batch_host(batch)

@@ -177,15 +177,26 @@ def test_fuzz_projected_searches(oracle, seed):
     g = ex.search_by_projection_mappoints(cam, kb, db, tiv, px, py, vc, lvl, da, th, chk, ratio, is_bad=bad, mp_has_obs=obs, owner=own,
                                           scale_factors=sf)
     assert g[0] == e[0] and (g[1] == e[1]).all() and (g[2] == e[2]).all(), ("mappoints", w, h, nf, th, chk, ratio)
-    # (Cur, KF, found): device part
-    valid = tiv
+    # (Cur, KF, found), src/ORBmatcher.cc:1352-1469: the oracle runs the WHOLE function from a random pose and per-point scale-invariance ranges
+    # (its prologue: projection, frustum / distance tests, PredictScale) and hands out the (valid, u, v, level) it derived; the device gets exactly
+    # those and must return its assignment, ownership and count
+    depth = rng.uniform(1.5, 9.0, M).astype(np.float32)
+    worldk = np.stack([(ka["x"] - np.float32(EUROC["cx"])) / np.float32(EUROC["fx"]), (ka["y"] - np.float32(EUROC["cy"])) / np.float32(EUROC["fy"]),
+                       np.ones(M, np.float32)], -1).astype(np.float32) * depth[:, None]
+    ang = np.float32(rng.uniform(-0.01, 0.01))
+    Rk = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    tk = rng.uniform(-0.05, 0.05, 3).astype(np.float32)
+    distk = np.linalg.norm(worldk, axis=1).astype(np.float32)
+    mf_max = (distk * sf[ka["octave"]]).astype(np.float32)
+    mf_min = (mf_max / sf[7]).astype(np.float32)
+    max_inv, min_inv = (np.float32(1.2) * mf_max).astype(np.float32), (np.float32(0.8) * mf_min).astype(np.float32)
     own2 = (rng.uniform(size=N) > 0.85).astype(np.uint8)
-    thk, od, ori = float(rng.choice([3.0, 10.0])), int(rng.choice([64, 100])), bool(rng.integers(0, 2))
-    g = ex.search_by_projection_kf(cam, kb, db, valid, px, py, lvl, ka["angle"], da, thk, od, ori, owner=own2, scale_factors=sf)
-    # oracle of the device part = mode-2 rules expressed through the mappoints oracle is not available: use the full KF oracle with a
-    # world/pose that reproduces (px, py, lvl) is overkill here; the dedicated test covers it.  Check invariants instead.
-    gm = g[1]
-    assert g[0] == (gm >= 0).sum() and not (gm[own2 != 0] >= 0).any()
+    thk, od, ori = float(rng.choice([3.0, 10.0, 25.0])), int(rng.choice([64, 100, 256])), bool(rng.integers(0, 2))
+    e_n, e_m, e_o, (kvalid, ku, kv, klvl) = oracle.search_by_projection_kf(kb, db, sf, w, h, EUROC, tiv, worldk, max_inv, min_inv, mf_max, ka["angle"], da,
+                                                                           Rk, tk, np.log(np.float32(1.2)), thk, od, ori, owner=own2)
+    g = ex.search_by_projection_kf(cam, kb, db, kvalid, ku, kv, klvl, ka["angle"], da, thk, od, ori, owner=own2, scale_factors=sf)
+    assert g[0] == e_n and (g[1] == e_m).all() and ((g[2] != 0) == (e_o != 0)).all(), ("keyframe", w, h, nf, thk, od, ori)
+    assert g[0] == (g[1] >= 0).sum() and not (g[1][own2 != 0] >= 0).any()
     # SearchForInitialization
     prev = np.stack([ka["x"], ka["y"]], -1).astype(np.float32) + rng.uniform(-2, 2, (M, 2)).astype(np.float32)
     win, r2, ori2 = int(rng.choice([10, 50, 100])), float(rng.choice([0.6, 0.9])), bool(rng.integers(0, 2))
@@ -266,7 +277,8 @@ def test_fuzz_frustum_and_distinctive(oracle, seed):
 @pytest.mark.parametrize("seed", SEEDS_ALIGN)
 def test_fuzz_sparse_img_align(oracle, seed):
     """SparseImgAlign::run with random motions, level ranges, iteration counts, feature budgets and invalid / outlier MapPoints: bit-identical to the
-    oracle's device-order mode, within 1e-5 of its reference-order mode on well-conditioned problems, same measurement count."""
+    oracle's device-order mode, within 1e-5 of the fp64 evaluation of the same algorithm in EVERY case, within 1e-5 of the oracle's reference-order
+    mode on well-conditioned problems, same measurement count."""
     from orb_ygz_slam_amd import Extractor, make_camera, EUROC
     from orb_ygz_slam_amd.scene import two_view_scene
     rng = np.random.default_rng(1400 + seed)
@@ -315,6 +327,15 @@ def test_fuzz_sparse_img_align(oracle, seed):
                                      mp_valid=valid[perm], outlier=outl[perm])
         band = max(band, float(np.abs(op[1] - o[1]).max()))
     err = float(np.abs(g[1] - o[1]).max())
+    # (3) the third party: the same Gauss-Newton with every quantity in double (oracle/oracle_align.cpp, sparse_img_align_f64).  north_star's 1e-5 is
+    # demanded of the DEVICE against it in every case, conditioning or not; the reference-order oracle's own distance from it is recorded beside it
+    # (on the cases (2) calls ill-conditioned the reference's pixel-by-pixel fp32 sums are the ones that stray: up to 3.4e-5 over 480 seeds, the
+    # device's per-feature moments + tree stay within 1.1e-6 -- tools/align_fp64_study.py, profiles/r06_align_fp64_480_seeds.json)
+    f64 = oracle.sparse_img_align_f64(k, world, ident, pyrA, ident, pyrB, inv, EUROC, max_level, min_level, n_iter, mp_valid=valid, outlier=outl)
+    e_dev, e_ref = float(np.abs(g[1].astype(np.float64) - f64[1]).max()), float(np.abs(o[1].astype(np.float64) - f64[1]).max())
+    ALIGN_STATS.setdefault("cases", []).append({"seed": seed, "features": int(len(k)), "max_level": max_level, "min_level": min_level, "n_iter": n_iter,
+                                                 "reordering_band": band, "device_vs_fp64": e_dev, "reference_order_vs_fp64": e_ref, "device_vs_reference_order": err})
+    assert e_dev <= 1e-5, (nl, nf, max_level, min_level, n_iter, e_dev, e_ref, g[1], f64[1])
     if band < 1e-6:
         ALIGN_STATS["well"] += 1
         ALIGN_STATS["worst_well"] = max(ALIGN_STATS["worst_well"], err)
@@ -339,7 +360,17 @@ def test_fuzz_sparse_img_align_report():
            "every_case_bit_identical_to_the_device_order_oracle": True,
            "ill_conditioned_no_reference_order_tolerance_claimed": ALIGN_STATS["ill"], "worst_error_ill_conditioned": ALIGN_STATS.get("worst_ill", 0.0),
            "largest_reordering_band_of_the_oracle_itself": ALIGN_STATS.get("worst_band", 0.0)}
-    msg = "aligner fuzz: " + json.dumps(rep)
+    cases = ALIGN_STATS.get("cases", [])
+    if cases:
+        dv, rf = np.array([c["device_vs_fp64"] for c in cases]), np.array([c["reference_order_vs_fp64"] for c in cases])
+        ill = np.array([c["reordering_band"] >= 1e-6 for c in cases])
+        rep["against_the_fp64_evaluation"] = {
+            "device_max": float(dv.max()), "device_median": float(np.median(dv)), "reference_order_max": float(rf.max()), "reference_order_median": float(np.median(rf)),
+            "every_case_device_within_1e-5": bool((dv <= 1e-5).all()),
+            "ill_conditioned_device_max": float(dv[ill].max()) if ill.any() else None, "ill_conditioned_reference_order_max": float(rf[ill].max()) if ill.any() else None,
+            "ill_conditioned_cases_where_device_is_no_further_than_reference_order": int((dv[ill] <= rf[ill]).sum()) if ill.any() else 0}
+        rep["cases"] = cases
+    msg = "aligner fuzz: " + json.dumps({k: v for k, v in rep.items() if k != "cases"})
     print(msg)
     warnings.warn(msg)
     try:

@@ -1,7 +1,7 @@
 """The matcher's split path (several workgroups per pair, hand-over through device-scope accesses: csrc/match_kernels.hip) under load: one context
 runs few-pair launches (split = 64 workgroups per pair) hundreds of times while two other contexts keep the chip busy with the 256-frame
 pipeline on their own streams; every repetition must return the bytes of (a) the first one and (b) a context that takes the one-wave serial pass
-without any split (YGZF_MATCH_SERIAL=1, YGZF_MATCH_SPLIT=1) and (c) one that keeps the full fences (YGZF_MATCH_FENCE=1).  The reference:
+without any split (YGZF_FORCE=match_serial=1,match_split=1) and (c) one that keeps the full fences (match_fence=1).  The reference:
 ORBmatcher::SearchByProjection(Cur, Last) src/ORBmatcher.cc:1218-1350 (sequential ownership)."""
 import hashlib
 import os
@@ -13,19 +13,19 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _ctx(env, **kw):
-    """the library reads its A/B switches when a context is created"""
+def _ctx(force, **kw):
+    """the library reads YGZF_FORCE (plan pins, csrc/ygzf_internal.h) when a context is created"""
     from orb_ygz_slam_amd import Extractor
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    from orb_ygz_slam_amd.capi import force_env
+    old = os.environ.get("YGZF_FORCE")
+    os.environ["YGZF_FORCE"] = force_env(**force)
     try:
         return Extractor(1000, 1.2, 8, 20, 7, **kw)
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        if old is None:
+            os.environ.pop("YGZF_FORCE", None)
+        else:
+            os.environ["YGZF_FORCE"] = old
 
 
 def test_split_matcher_under_load_equals_serial_pass():
@@ -37,8 +37,8 @@ def test_split_matcher_under_load_equals_serial_pass():
     cam = make_camera(w, h)
     small = clip[8:13]                                            # 5 frames -> 5 pairs per launch (the first against the carried frame): split path
     split = _ctx({}, max_width=w, max_height=h, max_batch=5)
-    serial = _ctx({"YGZF_MATCH_SERIAL": "1", "YGZF_MATCH_SPLIT": "1"}, max_width=w, max_height=h, max_batch=5)
-    fenced = _ctx({"YGZF_MATCH_FENCE": "1"}, max_width=w, max_height=h, max_batch=5)
+    serial = _ctx({"match_serial": 1, "match_split": 1}, max_width=w, max_height=h, max_batch=5)
+    fenced = _ctx({"match_fence": 1}, max_width=w, max_height=h, max_batch=5)
     loaders = [_ctx({}, max_width=w, max_height=h, max_batch=256) for _ in range(2)]
 
     # one-pair form too: SearchByProjection(cur, last) on host arrays

@@ -18,13 +18,11 @@ def _unit_world(keys, cam):
 
 @pytest.mark.parametrize("split", [0, 1, 2, 3, 5, 8])
 def test_match_batch_prev_equals_oracle(oracle, split, monkeypatch):
-    """`split`: workgroups per pair of k_match_last (YGZF_MATCH_SPLIT, read when the context is created; 0 = the library's choice, which is 8
+    """`split`: workgroups per pair of k_match_last (YGZF_FORCE=match_split=n, read when the context is created; 0 = the library's choice, which is 8
     for a launch of five pairs, 1 = one workgroup per pair as in large batches): the same matches whichever way the queries are dealt."""
     from orb_ygz_slam_amd import Extractor, make_camera, EUROC
-    if split:
-        monkeypatch.setenv("YGZF_MATCH_SPLIT", str(split))
-    else:
-        monkeypatch.delenv("YGZF_MATCH_SPLIT", raising=False)
+    from orb_ygz_slam_amd.capi import force_env
+    monkeypatch.setenv("YGZF_FORCE", force_env(match_split=split if split else None))
     w, h = 752, 480
     base = synth_frame(40, w + 16, h + 16)
     # consecutive frames = shifted crops of one scene (+ a different scene) so that matches exist
@@ -324,18 +322,19 @@ def test_search_for_triangulation_rejects_bad_input():
             ex.search_for_triangulation(scale_factors2=None, level_sigma2_2=None, **dict(kw, off1=off))
 
 
-@pytest.mark.parametrize("plan", ["YGZF_MATCH_SERIAL=1", "YGZF_MATCH_SERIAL=2", "YGZF_MATCH_SPLIT=1", "YGZF_MATCH_LANES=fixed"])
+@pytest.mark.parametrize("plan", ["match_serial=1", "match_serial=2", "match_split=1", "match_lanes=fixed"])
 def test_in_order_plans_agree(plan):
     """The matcher resolves the reference's in-order semantics as a block-wide fixpoint (match_kernels.hip); the one-wave in-order pass it
-    replaced stays as the fall-back (list extensions used up, no convergence).  YGZF_MATCH_SERIAL=1 runs that pass alone, =2 the fixpoint
-    with no extension slots, i.e. with the hand-over at the first exhausted list; YGZF_MATCH_SPLIT=1 keeps a pair on ONE workgroup (the form
-    of 256-pair launches, which the single pairs of the tests otherwise never take), YGZF_MATCH_LANES=fixed gives every query eight lanes.
+    replaced stays as the fall-back (list extensions used up, no convergence).  YGZF_FORCE=match_serial=1 runs that pass alone, =2 the fixpoint
+    with no extension slots, i.e. with the hand-over at the first exhausted list; match_split=1 keeps a pair on ONE workgroup (the form
+    of 256-pair launches, which the single pairs of the tests otherwise never take), match_lanes=fixed gives every query eight lanes.
     The matcher tests and the projected-search fuzzers must hold against the oracle under each."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **dict([plan.split("=")]))
+    from orb_ygz_slam_amd.capi import force_env
+    env = dict(os.environ, YGZF_FORCE=force_env(**dict([plan.split("=")])))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_match.py"),
                           os.path.join(root, "tests", "test_gpu_fuzz.py"), "-k",
                           "(search_by_projection or search_by_bow or search_for_initialization or test_fuzz_projected_searches or test_fuzz_search_by_projection_last) and not in_order_plans"],
@@ -372,13 +371,14 @@ def test_matcher_is_deterministic_over_repeats(oracle):
 
 def test_large_transfers_bypass_the_page_locked_staging():
     """One-frame entry points pack their host arrays into a page-locked staging area that must not grow without bound: beyond kPackedMax the
-    arrays cross one by one from / to the caller's memory (PackedTransfer::direct, csrc/ygzf_ctx.h).  With YGZF_PACKED_MAX=4096 every matcher /
+    arrays cross one by one from / to the caller's memory (PackedTransfer::direct, csrc/ygzf_ctx.h).  With YGZF_FORCE=packed_max=4096 every matcher /
     BoW / triangulation / aligner call of an ordinary frame takes that path: the suites must hold unchanged."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, YGZF_PACKED_MAX="4096")
+    from orb_ygz_slam_amd.capi import force_env
+    env = dict(os.environ, YGZF_FORCE=force_env(packed_max=4096))
     out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_match.py"),
                           os.path.join(root, "tests", "test_gpu_frustum.py"), os.path.join(root, "tests", "test_gpu_grid.py"), os.path.join(root, "tests", "test_gpu_align.py"),
                           "-k", "not large_transfers and not in_kernel_reference_patches and not deterministic"],

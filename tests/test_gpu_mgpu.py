@@ -129,13 +129,15 @@ def test_eight_and_sixteen_slots(oracle, nslots):
 
 def test_page_locked_frames_skip_the_staging_copy():
     """Frames that already lie in page-locked host memory are copied to the device from where they lie (hipPointerGetAttributes decides); same bytes
-    as from pageable memory, chunks alternating between a slot's two contexts included (YGZF_MGPU_CHUNK makes them small)."""
+    as from pageable memory, chunks alternating between a slot's two contexts included (YGZF_FORCE=mgpu_chunk=6 makes them small)."""
     import ctypes as C
     from orb_ygz_slam_amd import MultiGpu, make_camera
     w, h, n = 320, 240, 44
     frames = np.ascontiguousarray(np.concatenate([_clip(20, w, h)] * 3)[:n])
     cam = make_camera(w, h)
-    os.environ["YGZF_MGPU_CHUNK"] = "6"
+    from orb_ygz_slam_amd.capi import force_env
+    old_force = os.environ.get("YGZF_FORCE")
+    os.environ["YGZF_FORCE"] = force_env(mgpu_chunk=6)
     try:
         mg = MultiGpu([0, 0], 500, 1.2, 4, 20, 7, max_width=w, max_height=h, max_frames_per_device=n)
         assert mg.chunk_frames() == 6
@@ -155,7 +157,10 @@ def test_page_locked_frames_skip_the_staging_copy():
         del pinned
         L.ygzf_free_host(ptr)
     finally:
-        del os.environ["YGZF_MGPU_CHUNK"]
+        if old_force is None:
+            del os.environ["YGZF_FORCE"]
+        else:
+            os.environ["YGZF_FORCE"] = old_force
     for a, b, name in zip(ref, got, ("kps", "desc", "n_kp", "match", "nmatches")):
         assert np.array_equal(a, b), name
     for a, b, name in zip(ref4, got4, ("kps", "desc", "n_kp", "match", "nmatches")):

@@ -14,23 +14,20 @@ pytestmark = pytest.mark.gpu
 
 
 class _env:
+    """YGZF_FORCE=oct_plan=..,oct_hist_bins=.. (csrc/ygzf_internal.h) while a context is created"""
     def __init__(self, **kv):
         self.kv = kv
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
+        from orb_ygz_slam_amd.capi import force_env
+        self.old = os.environ.get("YGZF_FORCE")
+        os.environ["YGZF_FORCE"] = force_env(**self.kv)
 
     def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        if self.old is None:
+            os.environ.pop("YGZF_FORCE", None)
+        else:
+            os.environ["YGZF_FORCE"] = self.old
 
 
 def _clustered(seed, w, h):
@@ -59,7 +56,7 @@ def test_every_plan_gives_the_oracles_tree(oracle, case, plan, bins):
     from orb_ygz_slam_amd import Extractor
     w, h, nl, nf, make = CASES[case]
     img = make()
-    with _env(YGZF_OCT_PLAN=plan, YGZF_OCT_HIST_BINS=bins if bins else None):
+    with _env(oct_plan=plan, oct_hist_bins=bins if bins else None):
         ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
         oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
         imgs = np.stack([img, np.ascontiguousarray(img[::-1]), img])
@@ -81,7 +78,7 @@ def test_automatic_plan_of_the_large_configs(oracle):
     oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
     res = []
     for plan in (None, "sort"):
-        with _env(YGZF_OCT_PLAN=plan, YGZF_OCT_HIST_BINS=None):
+        with _env(oct_plan=plan, oct_hist_bins=None):
             ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
             ex.extract_batch_host(img[None])
             _cmp_frame(oracle, ex, oex, img, frame=0)

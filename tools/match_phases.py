@@ -1,5 +1,5 @@
-"""tools/match_phases.py -- phase times of one SearchByProjection(cur, last) launch (YGZF_MATCH_DEBUG=1 prints them): grid build, candidate scan,
-hand-over between the workgroups of a pair, in-order resolution (fixpoint rounds / rescans), commit.  YGZF_MATCH_SPLIT / YGZF_MATCH_SERIAL select the plans."""
+"""tools/match_phases.py -- phase times of one SearchByProjection(cur, last) launch (YGZF_DEBUG=match prints them): grid build, candidate scan,
+hand-over between the workgroups of a pair, in-order resolution (fixpoint rounds / rescans), commit.  YGZF_FORCE=match_split=n / match_serial=1 select the plans."""
 import numpy as np, os, sys
 sys.path.insert(0, os.getcwd())
 from orb_ygz_slam_amd import Extractor, make_camera, EUROC

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/sia_phases.py -- one SparseImgAlign pair (752x480, 1000 features, levels 7..1): kernel time from the library's own events; with
-YGZF_SIA_DEBUG=1 the instrumented kernel also prints its accumulate / reduce / solve / precompute phase clocks."""
+YGZF_DEBUG=sia the instrumented kernel also prints its accumulate / reduce / solve / precompute phase clocks."""
 import os
 import sys
 
