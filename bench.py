@@ -92,15 +92,17 @@ def algorithmic_bytes(w, h, nlevels, sf, nfeat):
 def make_frames(n, w, h, seed0=1000):
     """Synthetic clip: groups of 8 consecutive frames are shifted crops of one scene so that frame-to-frame matching
     has something to find; every 8th frame is a scene cut."""
+    from concurrent.futures import ThreadPoolExecutor
     from orb_ygz_slam_amd.synth import synth_frame
     frames = np.empty((n, h, w), np.uint8)
     m = 24
-    scene = None
+    nscenes = (n + 7) // 8
+    # (a 3840x2160 scene takes seconds of numpy; the scenes of a clip are independent and numpy releases the GIL on arrays of this size)
+    with ThreadPoolExecutor(max_workers=max(1, min(nscenes, effective_cores()))) as pool:
+        scenes = list(pool.map(lambda k: synth_frame(seed0 + k, w + m, h + m), range(nscenes)))
     for i in range(n):
-        if i % 8 == 0:
-            scene = synth_frame(seed0 + i // 8, w + m, h + m)
         dx, dy = (3 * (i % 8)) % m, (2 * (i % 8)) % m
-        frames[i] = scene[dy:dy + h, dx:dx + w]
+        frames[i] = scenes[i // 8][dy:dy + h, dx:dx + w]
     return frames
 
 
@@ -176,20 +178,27 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(frames, cfg, seconds_budget=12.0):
-    """The CPU oracle ('port' of the reference path) on this host's cores: every worker thread runs extract + projection match over its own
-    run of consecutive frames of the same clip for a bounded time (about `seconds_budget` s)."""
+def cpu_baseline(frames, cfg, seconds_budget=12.0, match=True, align=False, stereo=False, one_thread=True):
+    """The CPU oracle ('port' of the reference path) on this host's cores: every worker thread runs the workload's own steps -- extract, + projection
+    match of consecutive frames, + SparseImgAlign of the same pair (`align`), + ComputeStereoMatches on (left, right) pairs (`stereo`) -- over its own
+    run of consecutive frames of the same clip for a bounded time (about `seconds_budget` s; a frame that was started is finished, so that even a
+    3840x2160 clip at ~2 frames/s/thread yields at least one frame / pair per thread)."""
     from oracle import oracle_py as O
     w, h, nl, sf, nf, ini, mn = cfg
     cores = effective_cores()
-    sec1, _, _, n1 = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=1, frames_per_thread=1000, max_seconds=2.0)
-    fps1 = n1 / max(sec1, 1e-6)
+    kw = dict(match=match, align=align, stereo=stereo)
+    fps1 = None
+    if one_thread:
+        sec1, _, _, n1 = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=1, frames_per_thread=1000, max_seconds=2.0, **kw)
+        fps1 = n1 / max(sec1, 1e-6)
     sec, nk, nm, n = O.bench_extract_match(frames, nf, sf, nl, ini, mn, threads=cores, frames_per_thread=100000,
-                                           max_seconds=seconds_budget)
+                                           max_seconds=seconds_budget, **kw)
     n = max(n, 1)
-    return {"value": round(n / sec, 2), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
-            "sample": "%d threads, each on its own run of consecutive frames of the bench clip, time-bounded: %d frames in %.1f s; "
-                      "1 thread: %.2f frames/s" % (cores, n, sec, fps1),
+    steps = "extract" + (" + SearchByProjection(cur, last)" if match else "") + (" + SparseImgAlign(L-1..1, 10 iterations)" if align else "") + \
+            (" + ComputeStereoMatches per (left, right) pair" if stereo else "")
+    return {"value": round(n / sec, 2), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "steps": steps,
+            "sample": "%d threads, each on its own run of consecutive frames of the workload's clip, time-bounded: %d frames in %.1f s%s" %
+                      (cores, n, sec, ("; 1 thread: %.2f frames/s" % fps1) if fps1 is not None else ""),
             "keypoints_per_frame": round(nk / n, 1), "matches_per_frame": round(nm / n, 1)}
 
 
@@ -370,7 +379,8 @@ def end_to_end(pipe, min_seconds=1.2, depth=2, host_pitch=None):
     for e in exs[len(pipe.exs[:depth]):]:
         e.close()
     # what crosses the link per frame: the level-0 pixels up; keypoint + descriptor rows of `stride` entries and the count down
-    return B * batches, sec, {"up": w * h, "down": stride * (KP_DTYPE.itemsize + 32) + 4, "host_row_pitch": hp}
+    # (a frame goes up as ONE run of (h - 1) x pitch + w bytes: the padding between the rows travels with them)
+    return B * batches, sec, {"up": (h - 1) * hp + w, "down": stride * (KP_DTYPE.itemsize + 32) + 4, "host_row_pitch": hp}
 
 
 def pcie_roofline(link, fps_per_gpu):
@@ -415,7 +425,7 @@ def mgpu_end_to_end(devices, cfg, frames, min_seconds=0.8):
         res[name] = {"value": round(calls * n / sec, 1), "calls": calls, "ms_per_call": round(1e3 * sec / calls, 3)}
     chunk = mg.chunk_frames()
     mg.close()
-    return {"value": res["page_locked"]["value"], "value_pageable": res["pageable"]["value"], "unit": "frames/s", "frames_per_call": n, "runs": res,
+    return {"value": res["page_locked"]["value"], "value_pageable": res["pageable"]["value"], "unit": "frames/s", "frames_per_call": n, "frames_per_slot": per, "runs": res,
             "device_slots": slots, "unit_frames": 2, "chunk_frames": chunk,
             "what": "ygzf_mgpu_extract_match: host frames -> H2D -> extract + match of every pair -> D2H -> host arrays in input order (synchronous calls; "
                     "inside a call every slot sends its frames through in chunks that alternate between two contexts: the upload of one chunk runs beside "
@@ -489,10 +499,10 @@ def mgpu_literal_configs(devices):
         med1 = lat1[len(lat1) // 2]
         mg1.close()
         one = {"frames_per_call": unit, "ms_per_call": round(1e3 * med1, 3), "min_ms": round(1e3 * lat1[0], 3), "calls": len(lat1),
-               "predicted_8gpu_frames_per_s": round(8 * unit / med1, 1),
+               "extrapolated_8gpu_frames_per_s": round(8 * unit / med1, 1),
                "kernels_us": one_unit_kernels(devices[0], wl, unit, stereo),
                "what": "ONE %s per call on ONE device slot, page-locked host frames in, results out: the per-GPU work of this configuration; "
-                       "predicted_8gpu = 8 x frames / this latency (eight GPUs, eight links, one unit each)" % ("(left, right) pair" if stereo else "frame")}
+                       "extrapolated_8gpu = 8 x frames / this latency (an EXTRAPOLATION from one GPU -- eight GPUs, eight links, one unit each -- not a measurement)" % ("(left, right) pair" if stereo else "frame")}
         out[key] = {"frames_per_call": nfr, "device_slots": slots, "unit_frames": 2 if stereo else 1, "ms_per_call": round(1e3 * med, 3), "one_unit": one,
                     "value": round(nfr / med, 1), "unit": "frames/s", "calls": len(lat), "keypoints_per_frame": kp,
                     "stereo_matches_per_pair": matched,
@@ -612,6 +622,7 @@ def main():
     ap.add_argument("--share-gpu-try-rccl", action="store_true",
                     help="TEST ONLY, with --share-gpu: still try to bring up the RCCL communicator (two ranks on one device: it is expected to refuse) so that "
                          "the all-ranks-together fallback to gloo is exercised on a one-GPU box")
+    ap.add_argument("--other-steps", type=int, default=0, help="timed steps of every other_workloads entry (default: max(20, --steps), i.e. >= 1 s each; tests shorten it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -759,7 +770,15 @@ def main():
         pipes[0].step(); pipes[0].sync()           # first-touch allocations out of the way before events are recorded
         pipes[0].passes = passes
         pipes[0].profile(True)
-    elapsed = max_over_ranks(run_timed(pipes, args.steps, args.warmup, barrier, sync_all))
+    my_elapsed = run_timed(pipes, args.steps, args.warmup, barrier, sync_all)
+    elapsed = max_over_ranks(my_elapsed)
+    per_rank = None
+    if dist is not None:          # a straggler must be visible in ONE scaling run, not hidden by the max-reduce
+        allel = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allel, torch.tensor([my_elapsed], dtype=torch.float64))
+        allel = [float(t[0]) for t in allel]
+        per_rank = {"elapsed_s": [round(x, 4) for x in allel], "min_s": round(min(allel), 4), "max_s": round(max(allel), 4),
+                    "slowest_rank": int(np.argmax(allel)), "spread": round(max(allel) / max(min(allel), 1e-9) - 1.0, 4)}
     n_gpus = world * ndev
     total_frames = n_gpus * B * args.steps
     fps = total_frames / elapsed
@@ -788,6 +807,19 @@ def main():
                "what": "pinned host frames -> H2D -> extract + match -> D2H of all keypoints, descriptors and counts; two contexts "
                        "software-pipelined per GPU (device 0 of each process)"}
 
+    # ---- what the host's memory can feed (no GPU work): the 8-GPU transfers-included rate needs eight links' worth of DRAM reads at once ----
+    host_stream = None
+    if not args.no_extras and rank == 0:
+        from orb_ygz_slam_amd.capi import host_stream_probe
+        nthr = min(effective_cores(), 16)
+        gbs = host_stream_probe(devices[0], nthr, 256 << 20, 1.0)
+        up_one = (e2e["roofline_pcie"]["up_GBs"] if e2e else None)
+        host_stream = {"host_stream_GBs": round(gbs, 1), "threads": nthr, "bytes_per_thread": 256 << 20, "seconds": 1.0,
+                       "one_gpu_upload_GBs": up_one, "eight_gpus_would_read_GBs": round(8 * up_one / max(world, 1), 1) if up_one else None,
+                       "what": "threads bound to the GPU's NUMA node stream-read page-locked frame buffers, no GPU involved (ygzf_host_stream_probe); "
+                               "eight_gpus_would_read = 8 x this GPU's measured upload rate: an 8-GPU transfers-included run is host-memory-bound "
+                               "when that exceeds what ALL the node's cores can stream (this probe used only the cores this process may use)"}
+
     mgpu = mgpu_lit = None
     if not args.no_extras and world == 1:
         mgpu = mgpu_end_to_end(devices, cfg, frames0)
@@ -800,23 +832,33 @@ def main():
                 e.close()
         del pipes
         torch.cuda.empty_cache()
-        for name, wl, o_align, o_stereo, o_steps, o_real in (("fhd1920x1080_8lvl_4000feat", "fhd1920x1080_8lvl_4000feat", False, False, 3, False),
-                                                             ("uhd3840x2160_12lvl_8000feat_stereo", "uhd3840x2160_12lvl_8000feat", False, True, 3, False),
-                                                             ("euroc752x480_8lvl_1000feat_align", "euroc752x480_8lvl_1000feat", True, False, 3, False),
-                                                             ("euroc752x480_test1png", "euroc752x480_8lvl_1000feat", False, False, 20, True)):
+        # (name, workload, SparseImgAlign, stereo pairs, real-image clip, matcher, passes over the resident clip per step): every one is timed over
+        # max(20, --steps) steps of >= 50 ms, i.e. >= 1 s, after 2 warm-up steps -- >= 200 frames after >= 20 warm-up frames many times
+        # over -- and gets its own cpu_baseline on a bounded sample of its own clip
+        o_steps = args.other_steps if args.other_steps > 0 else max(20, args.steps)
+        for name, wl, o_align, o_stereo, o_real, o_match, o_passes in (
+                ("fhd1920x1080_8lvl_4000feat", "fhd1920x1080_8lvl_4000feat", False, False, False, True, 7),
+                ("uhd3840x2160_12lvl_8000feat_stereo", "uhd3840x2160_12lvl_8000feat", False, True, False, True, 4),
+                ("euroc752x480_8lvl_1000feat_align", "euroc752x480_8lvl_1000feat", True, False, False, True, 4),
+                ("vga640x480_8lvl_1000feat_extract_only", "vga640x480_8lvl_1000feat", False, False, False, False, 7),
+                ("euroc752x480_test1png", "euroc752x480_8lvl_1000feat", False, False, True, True, 6)):
             osub, orounds = SHAPES[wl]
-            orounds = 1 if wl != "euroc752x480_8lvl_1000feat" else max(1, orounds // 4)
+            orounds = 1 if wl not in ("euroc752x480_8lvl_1000feat", "vga640x480_8lvl_1000feat") else max(1, orounds // 4)
             oframes = make_frames_test1png(96, WORKLOADS[wl][0], WORKLOADS[wl][1]) if o_real else None
-            ps = [Pipeline(d, wl, osub, orounds, S, 5000 + 31 * (rank * ndev + i), o_align, o_stereo,
-                           distinct=min(S * osub, 8 if "uhd" in wl else 24 if "fhd" in wl else 96), frames=oframes)
+            odistinct = min(S * osub, 64 if ("uhd" in wl or "fhd" in wl) else 96)
+            ps = [Pipeline(d, wl, osub, orounds, S, 5000 + 31 * (rank * ndev + i), o_align, o_stereo, distinct=odistinct, frames=oframes, passes=o_passes,
+                           match=o_match)
                   for i, d in enumerate(devices)]
+            ps[0].passes = 1
             ps[0].step(); ps[0].sync()
+            ps[0].passes = o_passes
             ps[0].profile(True)
-            el = max_over_ranks(run_timed(ps, o_steps, 1, barrier, sync_all))
+            el = max_over_ranks(run_timed(ps, o_steps, 2, barrier, sync_all))
             oprof = kernel_table(ps[0].profile_read())
             ps[0].profile(False)
             oiso = isolated_pass(ps[0], reps=1)
-            ofps = n_gpus * ps[0].batch * o_steps / el
+            oframes_step = ps[0].batch * o_passes
+            ofps = n_gpus * oframes_step * o_steps / el
             ow, oh, onl, osf, onf = WORKLOADS[wl][:5]
             tb, per = algorithmic_bytes(ow, oh, onl, osf, onf)
             okp = np.concatenate([e.batch_counts() for e in ps[0].exs])
@@ -827,19 +869,24 @@ def main():
                 per["k_sia_run"] = int((onl - 1) * float(okp.mean()) * (56 + 10 * (40 + 25)))
                 tb += per["k_sia_run"]
             entry = {"value": round(ofps, 1), "unit": "frames/s" if not o_stereo else "frames/s (2 frames = 1 stereo pair)", "ms_per_step": round(1e3 * el / o_steps, 3),
-                     "frames_per_gpu_per_step": ps[0].batch, "steps": o_steps,
+                     "frames_per_gpu_per_step": oframes_step, "steps": o_steps, "warmup": 2, "timed_region_s": round(el, 3), "distinct_frames": len(ps[0].frames),
+                     "what": "extract" + (" + match" if o_match else " only (BASELINE.json configs[1])") + (" + SparseImgAlign" if o_align else "") + (" + ComputeStereoMatches" if o_stereo else ""),
                      "roofline": hbm_roofline(wl, oprof, oiso, per, osub, tb, ofps / n_gpus, traffic_key=name),
                      "kernels": {k: v["avg_us"] for k, v in oprof.items()},
                      "kernels_isolated_avg_us": oiso,
                      "keypoints_per_frame": round(float(okp.mean()), 1),
-                     "matches_per_frame": round(float(np.concatenate([e.match_counts() for e in ps[0].exs]).mean()), 1)}
+                     "matches_per_frame": round(float(np.concatenate([e.match_counts() for e in ps[0].exs]).mean()), 1) if o_match else None}
+            if rank == 0 and world * ndev == 1 and not args.no_cpu_baseline:
+                # the CPU beside it, on this workload's own clip (north_star: "timed on the node's own host cores in the same run")
+                entry["cpu_baseline"] = cpu_baseline(ps[0].frames, WORKLOADS[wl], seconds_budget=min(args.cpu_seconds, 6.0 if "uhd" in wl else 4.0),
+                                                     match=o_match, align=o_align, stereo=o_stereo, one_thread=False)
             if o_real:
                 entry["data"] = ("96 frames cut from the reference's Thirdparty/fast/test/data/test1.png (the one real image it ships; pixels from "
                                  "tests/golden/fast10_test1.npz): mirror-padded, 12 zoom levels 1.00 .. 1.22, shifted crops")
                 entry["fast_plan"] = {1: "one pass at minTh", 2: "iniTh first"}.get(ps[0].exs[0].fast_plan(), "?")
             if not o_real and not o_align:
                 # SURVEY 8(d)'s rate for this shape too: H2D of every frame and D2H of every keypoint / descriptor inside
-                onfr, osec, olink = end_to_end(ps[0], min_seconds=0.6)
+                onfr, osec, olink = end_to_end(ps[0], min_seconds=1.0)
                 osec = max_over_ranks(osec)
                 entry["value_end_to_end"] = round(world * onfr / osec, 1)
                 entry["roofline_pcie"] = pcie_roofline(olink, onfr / osec)
@@ -856,6 +903,7 @@ def main():
     if rank == 0:
         total_bytes, per_kernel = algorithmic_bytes(w, h, nl, sf, nf)
         fast_plan = {1: "one pass at minTh", 2: "iniTh first"}.get(fast_plan_id, "?") + " (chosen by the library from the clip's statistics)"
+        roofline = hbm_roofline(args.workload, kernels, iso, per_kernel, sub, total_bytes, fps / n_gpus) if kernels else None
         out = {
             "metric": "frames/s ORB extract+match, 752x480 8-lvl 1000-feat; 1->8 GPU scaling",
             "value": round(fps, 1), "unit": "frames/s",
@@ -872,17 +920,23 @@ def main():
                        "sharding": "one clip per GPU, no collective", "valid_measurement": not share,
                        "barrier_backend": ("rccl" if nccl else "gloo") if world > 1 else None, "barrier_backend_note": backend_note,
                        "numa_bound_cpus": numa_cpus},
-            "timed_region_s": round(elapsed, 4),
+            "timed_region_s": round(elapsed, 4), "per_rank": per_rank, "host_stream": host_stream,
             "value_end_to_end": e2e["value"] if e2e else None, "end_to_end": e2e, "roofline_pcie": e2e["roofline_pcie"] if e2e else None,
             "mgpu_end_to_end": mgpu, "mgpu_literal_configs": mgpu_lit,
             "keypoints_per_frame": round(float(kp_counts.mean()), 1), "matches_per_frame": round(float(m_counts.mean()), 1),
             "match_serial_fallback_pairs": match_fallbacks,   # pairs of device 0 (whole run) that lost the matcher's fixpoint to the one-wave pass
-            "roofline": hbm_roofline(args.workload, kernels, iso, per_kernel, sub, total_bytes, fps / n_gpus) if kernels else None,
+            "roofline": roofline,
             "roofline_valu": valu_roofline(args.workload, kernels, iso, sub) if kernels else None,
             "kernels": kernels,
             "kernels_isolated_avg_us": iso,   # one stream at a time (untimed pass)
             "other_workloads": others or None,
         }
+        if roofline is not None and e2e:
+            # the two blocks the driver's record keeps verbatim carry SURVEY 8(d)'s own number too: `value` is the resident (kernel-only) rate
+            roofline["value_end_to_end"] = e2e["value"]
+            roofline["value_end_to_end_pcie_frac"] = e2e["roofline_pcie"]["frac"]
+            out["config"]["value_end_to_end"] = e2e["value"]
+            out["config"]["value_end_to_end_pcie_frac"] = e2e["roofline_pcie"]["frac"]
         out["cpu_baseline"] = cpu_base
         if cpu_ref is not None:
             out["cpu_baseline_reference"] = cpu_ref

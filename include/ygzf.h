@@ -516,6 +516,10 @@ void *ygzf_alloc_host(int device, size_t bytes);
  * YGZF_ERR_NO_DEVICE for a device that does not exist. */
 int ygzf_bind_host_thread_to_device(int device);
 void ygzf_free_host(void *p);
+/* What the host's memory can feed (no GPU work): n_threads threads, bound to `device`'s NUMA node when device >= 0, stream-read page-locked
+ * buffers of bytes_per_thread each for `seconds`; *gb_per_s = bytes read / time.  One GPU's transfers-included rate reads its frames at the
+ * link's rate (~55 GB/s); an 8-GPU node wants eight times that from DRAM at once (bench.py reports both). */
+int ygzf_host_stream_probe(int device, int n_threads, size_t bytes_per_thread, double seconds, double *gb_per_s);
 int ygzf_mgpu_chunk_frames(const ygzf_mgpu *m);   /* frames per chunk inside a slot (units up to this size alternate between the slot's two contexts) */
 
 /* ---- timing / profiling helpers for bench.py -------------------------------------------------------------------------

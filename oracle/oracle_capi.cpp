@@ -524,38 +524,42 @@ void yo_find_direct_projection_batch(void *e_, int n_refs, const uint8_t *const 
 // Frames are u8 images of identical size laid out back to back.  Frame f (f >= 1) is matched against frame f-1
 // with an identity relative pose and unit-depth back-projected points (SURVEY §8d metric definition).
 // Returns elapsed seconds; n_kp_total / n_match_total are checksums so the work cannot be optimised away.
+// mode: bit 0 SearchByProjection(cur, last) of every frame against its predecessor; bit 1 SparseImgAlign(nlevels - 1, 1, 10 iterations) of the same
+// pair (features = the predecessor's keypoints with MapPoints at their unit-depth back-projection, both poses identity: what ygzf_align_batch_prev
+// computes); bit 2 the clip holds (left, right) pairs: Frame::ComputeStereoMatches on frames (2p, 2p + 1) after their extraction, matching only
+// between left frames.  The CPU side of bench.py's per-workload cpu_baseline (test infrastructure).
 double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, const uint8_t *frames,
                               int nframes, int w, int h, int threads, int frames_per_thread, double max_seconds, float fx, float fy,
-                              float cx, float cy, long *n_kp_total, long *n_match_total, long *n_frames_done) {
+                              float cx, float cy, int mode, long *n_kp_total, long *n_match_total, long *n_frames_done) {
     std::vector<long> kp_acc(threads, 0), m_acc(threads, 0), f_acc(threads, 0);
+    const bool doMatch = mode & 1, doAlign = (mode & 2) != 0, stereo = (mode & 4) != 0;
     auto t0 = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
-        Extractor ex(nfeatures, scaleFactor, nlevels, iniTh, minTh);
-        std::vector<KeyPoint> kprev, kcur;
-        std::vector<uint8_t> dprev, dcur;
+        Extractor ex(nfeatures, scaleFactor, nlevels, iniTh, minTh), exR(nfeatures, scaleFactor, nlevels, iniTh, minTh);
+        std::vector<KeyPoint> kprev, kcur, kright;
+        std::vector<uint8_t> dprev, dcur, dright;
+        std::vector<Image> pyrPrev;
         // each worker walks `frames_per_thread` consecutive frames of the clip (wrapping around), starting at its own offset,
         // so that the t-1 -> t pairs stay on one worker and every worker does the same amount of work
-        const int start = (int) (((long) tid * 8) % nframes);
-        for (int j = 0; j < frames_per_thread; j++) {
+        const int step = stereo ? 2 : 1;
+        const int start = (int) (((long) tid * 8) % nframes) & ~(step - 1);
+        for (int j = 0; j < frames_per_thread; j += step) {
             // time-bounded sample: stop at the deadline (the host may give this process far fewer cores than it shows)
             if (max_seconds > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_seconds) break;
             const int f = (start + j) % nframes;
             ex.Extract(frames + (size_t) f * w * h, w, h, w, kcur, dcur);
             kp_acc[tid] += (long) kcur.size();
-            if (j > 0 && !kprev.empty() && !kcur.empty()) {
-                FrameView cur;
-                cur.N = (int) kcur.size();
-                cur.keys = kcur.data();
-                cur.desc = dcur.data();
-                cur.uRight = nullptr;
-                cur.minX = 0; cur.minY = 0; cur.maxX = (float) w; cur.maxY = (float) h;
-                cur.gridInvW = (float) Grid::COLS / (cur.maxX - cur.minX);
-                cur.gridInvH = (float) Grid::ROWS / (cur.maxY - cur.minY);
-                cur.fx = fx; cur.fy = fy; cur.cx = cx; cur.cy = cy; cur.mb = 0; cur.mbf = 0;
-                cur.scaleFactors = ex.mvScaleFactor.data();
-                cur.nlevels = nlevels;
-                Grid g;
-                g.Assign(cur);
+            if (stereo) {
+                const int fr = (f + 1) % nframes;
+                exR.Extract(frames + (size_t) fr * w * h, w, h, w, kright, dright);
+                kp_acc[tid] += (long) kright.size();
+                std::vector<const Image *> pl, pr;
+                for (int l = 0; l < nlevels; l++) { pl.push_back(&ex.mvImagePyramid[l]); pr.push_back(&exR.mvImagePyramid[l]); }
+                std::vector<float> ur(kcur.size() + 1), dp(kcur.size() + 1);
+                compute_stereo_matches((int) kcur.size(), kcur.data(), dcur.data(), (int) kright.size(), kright.data(), dright.data(), pl, pr,
+                                       ex.mvScaleFactor.data(), ex.mvInvScaleFactor.data(), 0.11f, 47.9f, ur.data(), dp.data());
+            }
+            if (j > 0 && !kprev.empty() && !kcur.empty() && (doMatch || doAlign)) {
                 int n = (int) kprev.size();
                 std::vector<uint8_t> ones(n, 1), zeros(n, 0);
                 std::vector<float> world((size_t) 3 * n);
@@ -564,24 +568,49 @@ double yo_bench_extract_match(int nfeatures, float scaleFactor, int nlevels, int
                     world[3 * i + 1] = (kprev[i].y - cy) / fy;
                     world[3 * i + 2] = 1.f;
                 }
-                ProjLastInput in;
-                in.N = n;
-                in.keys = kprev.data();
-                in.mp_valid = ones.data();
-                in.outlier = zeros.data();
-                in.mp_has_obs = ones.data();
-                in.mp_world = world.data();
-                in.mp_desc = dprev.data();
-                const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
-                std::memcpy(in.Rcw, I, 36); std::memcpy(in.tcw, z, 12);
-                std::memcpy(in.Rlw, I, 36); std::memcpy(in.tlw, z, 12);
-                std::vector<uint8_t> owner(cur.N, 0);
-                std::vector<int> match(cur.N, -1);
-                m_acc[tid] += search_by_projection_last(cur, g, in, 15.f, true, true, true, owner.data(), match.data());
+                if (doMatch) {
+                    FrameView cur;
+                    cur.N = (int) kcur.size();
+                    cur.keys = kcur.data();
+                    cur.desc = dcur.data();
+                    cur.uRight = nullptr;
+                    cur.minX = 0; cur.minY = 0; cur.maxX = (float) w; cur.maxY = (float) h;
+                    cur.gridInvW = (float) Grid::COLS / (cur.maxX - cur.minX);
+                    cur.gridInvH = (float) Grid::ROWS / (cur.maxY - cur.minY);
+                    cur.fx = fx; cur.fy = fy; cur.cx = cx; cur.cy = cy; cur.mb = 0; cur.mbf = 0;
+                    cur.scaleFactors = ex.mvScaleFactor.data();
+                    cur.nlevels = nlevels;
+                    Grid g;
+                    g.Assign(cur);
+                    ProjLastInput in;
+                    in.N = n;
+                    in.keys = kprev.data();
+                    in.mp_valid = ones.data();
+                    in.outlier = zeros.data();
+                    in.mp_has_obs = ones.data();
+                    in.mp_world = world.data();
+                    in.mp_desc = dprev.data();
+                    const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z[3] = {0, 0, 0};
+                    std::memcpy(in.Rcw, I, 36); std::memcpy(in.tcw, z, 12);
+                    std::memcpy(in.Rlw, I, 36); std::memcpy(in.tlw, z, 12);
+                    std::vector<uint8_t> owner(cur.N, 0);
+                    std::vector<int> match(cur.N, -1);
+                    m_acc[tid] += search_by_projection_last(cur, g, in, 15.f, true, true, true, owner.data(), match.data());
+                }
+                if (doAlign && nlevels >= 2 && (int) pyrPrev.size() == nlevels) {
+                    AlignFrame R, C;
+                    R.N = n; R.keys = kprev.data(); R.mp_valid = ones.data(); R.outlier = zeros.data(); R.mp_world = world.data();
+                    for (int l = 0; l < nlevels; l++) { R.pyramid.push_back(&pyrPrev[l]); C.pyramid.push_back(&ex.mvImagePyramid[l]); }
+                    R.invScaleFactors = C.invScaleFactors = ex.mvInvScaleFactor.data();
+                    R.fx = C.fx = fx; R.fy = C.fy = fy; R.cx = C.cx = cx; R.cy = C.cy = cy;
+                    const AlignResult ar = sparse_img_align(R, C, nlevels - 1, 1, 10);
+                    m_acc[tid] += doMatch ? 0 : (long) ar.ret;
+                }
             }
+            if (doAlign) pyrPrev = ex.mvImagePyramid;
             kprev.swap(kcur);
             dprev.swap(dcur);
-            f_acc[tid]++;
+            f_acc[tid] += step;
         }
     };
     std::vector<std::thread> th;

@@ -154,10 +154,6 @@ def lib():
         L.yo_ic_angle.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         L.yo_descriptor.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.yo_sparse_img_align.restype = C.c_size_t
-        L.yo_bench_extract_match.restype = C.c_double
-        L.yo_bench_extract_match.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                             C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float,
-                                             C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     return _lib
 
 
@@ -531,16 +527,22 @@ def ref_fast10(img, barrier, which=1):
 
 
 def bench_extract_match(frames, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, threads=1,
-                        frames_per_thread=None, max_seconds=0.0, fx=458.654, fy=457.296, cx=367.215, cy=248.375):
-    """CPU baseline ('port'): seconds for `threads` workers each doing extract + frame-to-frame projection match on
-    `frames_per_thread` consecutive frames of the clip `frames` (n,h,w) u8.  Stops early at `max_seconds` (0 = no limit).  Returns (seconds, keypoints, matches, frames_done)."""
+                        frames_per_thread=None, max_seconds=0.0, fx=458.654, fy=457.296, cx=367.215, cy=248.375, match=True, align=False, stereo=False):
+    """CPU baseline ('port'): seconds for `threads` workers each doing extract (+ frame-to-frame projection match, + SparseImgAlign of the same
+    pair, + ComputeStereoMatches on (left, right) pairs) on `frames_per_thread` consecutive frames of the clip `frames` (n,h,w) u8.  Stops early at
+    `max_seconds` (0 = no limit; a frame / pair that was started is finished).  Returns (seconds, keypoints, matches, frames_done)."""
     frames = np.ascontiguousarray(frames, np.uint8)
     n, h, w = frames.shape
     if frames_per_thread is None:
         frames_per_thread = max(1, n // threads)
     nk, nm, nf = C.c_long(), C.c_long(), C.c_long()
-    sec = lib().yo_bench_extract_match(nfeatures, scale_factor, nlevels, ini_th, min_th, _p(frames), n, w, h, threads,
-                                       frames_per_thread, max_seconds, fx, fy, cx, cy, C.byref(nk), C.byref(nm), C.byref(nf))
+    L = lib()
+    L.yo_bench_extract_match.restype = C.c_double
+    L.yo_bench_extract_match.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    mode = (1 if match else 0) | (2 if align else 0) | (4 if stereo else 0)
+    sec = L.yo_bench_extract_match(nfeatures, scale_factor, nlevels, ini_th, min_th, _p(frames), n, w, h, threads, frames_per_thread, max_seconds,
+                                   fx, fy, cx, cy, mode, C.byref(nk), C.byref(nm), C.byref(nf))
     return sec, nk.value, nm.value, nf.value
 
 

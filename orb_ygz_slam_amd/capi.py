@@ -56,6 +56,17 @@ def make_camera(w, h, fx=EUROC["fx"], fy=EUROC["fy"], cx=EUROC["cx"], cy=EUROC["
 _lib = None
 
 
+def host_stream_probe(device, threads, bytes_per_thread, seconds):
+    """GB/s that `threads` host threads (bound to the device's NUMA node) stream-read from page-locked buffers; no GPU work (include/ygzf.h)."""
+    L = load_library()
+    L.ygzf_host_stream_probe.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_double, C.POINTER(C.c_double)]
+    out = C.c_double(0.0)
+    rc = L.ygzf_host_stream_probe(int(device), int(threads), int(bytes_per_thread), float(seconds), C.byref(out))
+    if rc != 0:
+        raise YgzfError("ygzf_host_stream_probe failed (%d)" % rc)
+    return out.value
+
+
 def force_env(base=None, **kv):
     """YGZF_FORCE string (csrc/ygzf_internal.h: key=value,... pins a plan the library otherwise picks itself; read when a context is created):
     `base` (default: the current environment's) with the given keys set, or removed when their value is None."""

@@ -431,10 +431,14 @@ static int projected_match(ygzf_ctx *c, int mode, const ygzf_frame_view *F, cons
     }
     MatchArgs A;
     memset(&A, 0, sizeof A);
-    A.maxDist = 100;   // TH_HIGH
     A.mode = mode;
     A.specDeep = mode == 1 ? 1 : 0;   // best AND runner-up among the free candidates: lists of eight (match_kernels.hip)
-    A.maxDist = max_dist;
+    // accept threshold (TH_HIGH, ORBdist of mode 2).  A candidate becomes "best" only with dist < 256 (`int bestDist = 256 ... if (dist < bestDist)`,
+    // src/ORBmatcher.cc:1413-1429), so a threshold of 256 or more accepts exactly what 255 accepts -- except that the reference then also "accepts" a
+    // MapPoint without any free candidate and writes mvpMapPoints[-1] (:1431-1432, undefined; its callers pass 100 and 64).  Defined here, as in the
+    // oracle, as: no candidate, no match.  (Found by the fuzzer once its KeyFrame leg compared with the oracle: 256 reached the kernel, whose keys
+    // reserve dist > 255 for "nothing" -- wrong counts and an out-of-bounds store.)
+    A.maxDist = max_dist > 255 ? 255 : max_dist < 0 ? 0 : max_dist;
     A.curKeys = (const ygzf_kp *) (dIn + oCurK);
     A.curDesc = dIn + oCurD;
     A.curURight = F->u_right ? (const float *) (dIn + oUR) : nullptr;

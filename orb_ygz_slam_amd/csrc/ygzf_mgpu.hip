@@ -10,6 +10,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -119,13 +121,10 @@ int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg
         if (numa) d.haveCpus = numa_cpus_of_device(devices[i], &d.cpus);
         const size_t F = (size_t) m->chunk;
         if (hipSetDevice(devices[i]) != hipSuccess) { ygzf_mgpu_destroy(m); return YGZF_ERR_HIP; }
-        if (hipHostMalloc((void **) &d.hIn[2], F * (size_t) ygzf_host_row_pitch(max_width) * max_height) != hipSuccess) {
-            (void) hipGetLastError();
-            ygzf_mgpu_destroy(m);
-            return YGZF_ERR_HIP;
-        }
+        // (the three input staging areas -- chunk x pitch x height bytes each, GBs for 4K -- are page-locked by the first call that brings PAGEABLE
+        // frames, run_job: a caller whose frames are page-locked never pays for them)
         for (int b = 0; b < 2; b++) {
-            if (hipHostMalloc((void **) &d.hIn[b], F * (size_t) ygzf_host_row_pitch(max_width) * max_height) != hipSuccess || hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
+            if (hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
                 hipHostMalloc((void **) &d.hDesc[b], F * m->stride * 32) != hipSuccess || hipHostMalloc((void **) &d.hCnt[b], F * sizeof(int)) != hipSuccess ||
                 hipHostMalloc((void **) &d.hAux[b], F * m->stride * sizeof(int)) != hipSuccess) {
                 (void) hipGetLastError();
@@ -144,13 +143,13 @@ void ygzf_mgpu_destroy(ygzf_mgpu *m) {
         for (int b = 0; b < 2; b++)
             if (d.ctx[b]) ygzf_destroy(d.ctx[b]);
         bool any = false;
-        for (int b = 0; b < 2; b++) any = any || d.hIn[b] || d.hKp[b] || d.hDesc[b] || d.hCnt[b] || d.hAux[b];
-        any = any || d.hIn[2];
+        for (int b = 0; b < 2; b++) any = any || d.hKp[b] || d.hDesc[b] || d.hCnt[b] || d.hAux[b];
+        for (int b = 0; b < 3; b++) any = any || d.hIn[b];
         if (!any) continue;   // a slot whose contexts were never created (e.g. a device index that does not exist)
         (void) hipSetDevice(d.device);
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < 3; b++)
             if (d.hIn[b]) (void) hipHostFree(d.hIn[b]);
-            if (b == 0 && d.hIn[2]) (void) hipHostFree(d.hIn[2]);
+        for (int b = 0; b < 2; b++) {
             if (d.hKp[b]) (void) hipHostFree(d.hKp[b]);
             if (d.hDesc[b]) (void) hipHostFree(d.hDesc[b]);
             if (d.hCnt[b]) (void) hipHostFree(d.hCnt[b]);
@@ -167,6 +166,53 @@ void *ygzf_alloc_host(int device, size_t bytes) {
 }
 void ygzf_free_host(void *p) {
     if (p) (void) hipHostFree(p);
+}
+
+// What the node's DRAM can feed: n_threads host threads (bound to `device`'s NUMA node when device >= 0, like a slot's copy threads) each
+// stream-read their own page-locked buffer of frames for `seconds`; no GPU work, no copy.  The transfers-included rate of one GPU reads its frames
+// at the link's 55 GB/s -- eight of them want 440 GB/s from the host's memory at once, and this says whether the box has it.
+int ygzf_host_stream_probe(int device, int n_threads, size_t bytes_per_thread, double seconds, double *gb_per_s) {
+    if (n_threads < 1 || n_threads > 256 || bytes_per_thread < (1u << 20) || !(seconds > 0) || !gb_per_s) return YGZF_ERR_INVALID;
+    cpu_set_t cpus;
+    const bool bind = device >= 0 && numa_cpus_of_device(device, &cpus);
+    std::vector<double> bytesDone((size_t) n_threads, 0.0);
+    std::vector<unsigned long long> sink((size_t) n_threads, 0ull);
+    std::vector<void *> bufs((size_t) n_threads, nullptr);
+    std::atomic<int> ready{0};
+    std::atomic<bool> go{false}, failed{false};
+    const size_t words = bytes_per_thread / 8;
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int t) {
+        if (bind) (void) pthread_setaffinity_np(pthread_self(), sizeof cpus, &cpus);
+        void *p = nullptr;
+        if (hipSetDevice(device >= 0 ? device : 0) != hipSuccess || hipHostMalloc(&p, words * 8) != hipSuccess) { (void) hipGetLastError(); failed = true; }
+        bufs[(size_t) t] = p;
+        if (p) memset(p, t + 1, words * 8);                      // first touch on this thread's node
+        ready++;
+        while (!go.load()) std::this_thread::yield();
+        if (!p) return;
+        const unsigned long long *q = (const unsigned long long *) p;
+        unsigned long long a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        double done = 0;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+            for (size_t i = 0; i + 8 <= words; i += 8) { a0 += q[i] + q[i + 4]; a1 += q[i + 1] + q[i + 5]; a2 += q[i + 2] + q[i + 6]; a3 += q[i + 3] + q[i + 7]; }
+            done += (double) (words * 8);
+        }
+        bytesDone[(size_t) t] = done;
+        sink[(size_t) t] = a0 + a1 + a2 + a3;
+    };
+    std::vector<std::thread> ts;
+    for (int t = 0; t < n_threads; t++) ts.emplace_back(worker, t);
+    while (ready.load() < n_threads) std::this_thread::yield();
+    t0 = std::chrono::steady_clock::now();
+    go = true;
+    for (auto &t : ts) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    double total = 0;
+    unsigned long long s = 0;
+    for (int t = 0; t < n_threads; t++) { total += bytesDone[(size_t) t]; s += sink[(size_t) t]; if (bufs[(size_t) t]) (void) hipHostFree(bufs[(size_t) t]); }
+    *gb_per_s = (s == 0x5bd1e995ull ? 0.0 : 1.0) * total / sec / 1e9;   // (the sums are used, so the reads are not optimised away)
+    return failed.load() ? YGZF_ERR_HIP : YGZF_OK;
 }
 
 int ygzf_bind_host_thread_to_device(int device) {
@@ -221,7 +267,7 @@ int run_job(ygzf_mgpu *m, const Job &J) {
     const int chunk = alternate ? (m->chunk / unit) * unit : m->chunk;
     // a (left, right) pair never straddles two chunks: ygzf_stereo_batch pairs frames 2p / 2p + 1 of ONE launch, and the aux staging rows are per pair
     if (J.mode == kStereo && (!alternate || (chunk & 1)))
-        return mfail(m, YGZF_ERR_INVALID, "stereo pairs need chunks of at least 2 frames (chunk %d: max_frames_per_device / YGZF_MGPU_CHUNK)", m->chunk);
+        return mfail(m, YGZF_ERR_INVALID, "stereo pairs need chunks of at least 2 frames (chunk %d: max_frames_per_device / YGZF_FORCE=mgpu_chunk)", m->chunk);
     // frames in page-locked host memory go to the device from where they lie
     bool pinned = false;
     {
@@ -255,6 +301,18 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         std::vector<int> nm(n, 0);
         auto cx = [&](int k) { return d.ctx[alternate ? (k & 1) : 0]; };
         const int sp = ygzf_host_row_pitch(w);   // the staging area carries the device's row pitch: a chunk goes up as whole frames, not row by row
+        if (!pinned && !d.hIn[0]) {              // first pageable job of this slot: page-lock its three input staging areas (sized for the handle's maxima)
+            const size_t bytes = (size_t) m->chunk * (size_t) ygzf_host_row_pitch(m->maxW) * (size_t) m->maxH;
+            bool ok = hipSetDevice(d.device) == hipSuccess;
+            for (int b = 0; b < 3 && ok; b++) ok = hipHostMalloc((void **) &d.hIn[b], bytes) == hipSuccess;
+            if (!ok) {
+                (void) hipGetLastError();
+                for (int b = 0; b < 3; b++) { if (d.hIn[b]) (void) hipHostFree(d.hIn[b]); d.hIn[b] = nullptr; }
+                d.err = "page-locking the input staging areas failed";
+                d.rc = YGZF_ERR_HIP;
+                return;
+            }
+        }
         auto prepare = [&](int k) {      // pageable frames: gather chunk k into its page-locked staging area
             if (pinned) return;
             const int b = k % 3;

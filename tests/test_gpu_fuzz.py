@@ -369,8 +369,8 @@ def test_fuzz_sparse_img_align_report():
             "every_case_device_within_1e-5": bool((dv <= 1e-5).all()),
             "ill_conditioned_device_max": float(dv[ill].max()) if ill.any() else None, "ill_conditioned_reference_order_max": float(rf[ill].max()) if ill.any() else None,
             "ill_conditioned_cases_where_device_is_no_further_than_reference_order": int((dv[ill] <= rf[ill]).sum()) if ill.any() else 0}
-        rep["cases"] = cases
-    msg = "aligner fuzz: " + json.dumps({k: v for k, v in rep.items() if k != "cases"})
+        rep["per_case"] = cases
+    msg = "aligner fuzz: " + json.dumps({k: v for k, v in rep.items() if k != "per_case"})
     print(msg)
     warnings.warn(msg)
     try:

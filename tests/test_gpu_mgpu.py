@@ -195,8 +195,8 @@ def test_bench_two_ranks_on_one_gpu():
     per-rank extras of the REAL bench path (the end-to-end pipeline, the other workloads) run in two processes -- what cannot be tried here is RCCL itself."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29571",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "768", "--passes", "1"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "768", "--passes", "1", "--other-steps", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                              # rank 0 prints the one line
@@ -206,6 +206,29 @@ def test_bench_two_ranks_on_one_gpu():
     ow = line["other_workloads"]
     assert set(ow) >= {"fhd1920x1080_8lvl_4000feat", "uhd3840x2160_12lvl_8000feat_stereo", "euroc752x480_8lvl_1000feat_align"}
     assert all(v["value"] > 0 for v in ow.values()) and ow["fhd1920x1080_8lvl_4000feat"]["value_end_to_end"] > 0
+    assert "vga640x480_8lvl_1000feat_extract_only" in ow and ow["vga640x480_8lvl_1000feat_extract_only"]["matches_per_frame"] is None
+    pr = line["per_rank"]                                                 # a straggler shows: every rank's own elapsed time, not only the maximum
+    assert len(pr["elapsed_s"]) == 2 and pr["max_s"] >= pr["min_s"] > 0 and pr["slowest_rank"] in (0, 1)
+    assert abs(line["timed_region_s"] - pr["max_s"]) < 1e-3
+    assert line["roofline"]["value_end_to_end"] == line["value_end_to_end"] == line["config"]["value_end_to_end"]
+
+
+def test_bench_two_ranks_on_one_gpu_uhd_stereo():
+    """the same two-process control flow on the workload the 4K scaling curve uses (BASELINE.json configs[4]: 3840x2160 stereo pairs, 12 levels, 8000
+    features): every rank its own clip of pairs, ComputeStereoMatches inside the step, barriers and max-over-ranks around it"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29577",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "uhd3840x2160_12lvl_8000feat", "--stereo", "--steps", "2", "--warmup", "1",
+           "--sub-batch", "8", "--streams", "2", "--distinct", "8", "--no-extras"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["workload"] == "uhd3840x2160_12lvl_8000feat" and cfg["stereo"] is True and cfg["valid_measurement"] is False
+    assert line["value"] > 0 and 7000 < line["keypoints_per_frame"] <= 8100
+    assert len(line["per_rank"]["elapsed_s"]) == 2
 
 
 def test_bench_falls_back_from_rccl_to_gloo_together():
