@@ -165,6 +165,11 @@ int ygzf_batch_fetch(ygzf_ctx *ctx, int frame, ygzf_kp *kps, uint8_t *desc, int 
 /* All frames of the batch with one synchronisation: kps / desc hold n_frames rows of `stride` (>= ygzf_max_keypoints) entries, frame f's
  * first n_kp[f] entries are valid.  Pass page-locked host memory (hipHostMalloc / hipHostRegister) for full PCIe rate. */
 int ygzf_batch_fetch_all(ygzf_ctx *ctx, ygzf_kp *kps, uint8_t *desc, int *n_kp, int stride);
+/* The same results as ONE block and ONE copy, for launches of a few frames (a Tracking frame, a stereo pair): host (page-locked for the link's rate)
+ * receives [n_kp: n_frames ints | keypoint rows | descriptor rows], rows of *row_entries entries (ygzf_max_keypoints of the batch's image size), the
+ * parts at offsets 0, *off_kps and *off_desc (256-byte aligned); *bytes_out = bytes written (may be NULL).  Three separate device-to-host copies
+ * cost a one-frame call 20 us more. */
+int ygzf_batch_fetch_packed(ygzf_ctx *ctx, void *host, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries, size_t *bytes_out);
 /* Copies pyramid level `level` of batch frame `frame` back to the host, tight. */
 int ygzf_batch_fetch_level(ygzf_ctx *ctx, int frame, int level, uint8_t *out);
 int ygzf_sync(ygzf_ctx *ctx);

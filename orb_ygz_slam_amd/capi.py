@@ -231,6 +231,7 @@ class Extractor:
         self.nlevels = nlevels
         self.cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, ini_th, min_th, cv_mode)
         self._wh = (max_width, max_height, 0)   # (w, h, frames) of the last extracted batch
+        self.max_width, self.max_height = max_width, max_height
         self._inflight = []                     # host arrays handed to asynchronous uploads, kept alive until the next synchronisation
         self.h = C.c_void_p()
         rc = self.L.ygzf_create(device, C.byref(self.cfg), max_width, max_height, max_batch, C.byref(self.h))
@@ -358,6 +359,28 @@ class Extractor:
         self._ck(self.L.ygzf_batch_fetch_all(self.h, _p(k), _p(d), _p(n), stride))
         self._inflight.clear()
         return k, d, n
+
+    def batch_fetch_packed(self):
+        """ygzf_batch_fetch_packed: the last batch's counts / keypoint rows / descriptor rows gathered on the device and brought over in ONE copy;
+        returns (n_kp[B], kps[B, row], desc[B, row, 32]) as views of one host block."""
+        B = self._last_frames()
+        cap = 512 + B * (self._kp_stride_max() * (KP_DTYPE.itemsize + 32) + 512)
+        host = np.zeros(cap, np.uint8)
+        ok, od, by = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        re = C.c_int(0)
+        self.L.ygzf_batch_fetch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._ck(self.L.ygzf_batch_fetch_packed(self.h, host.ctypes.data_as(C.c_void_p), cap, C.byref(ok), C.byref(od), C.byref(re), C.byref(by)))
+        r = re.value
+        n = host[:4 * B].view(np.int32).copy()
+        kps = host[ok.value:ok.value + B * r * KP_DTYPE.itemsize].view(KP_DTYPE).reshape(B, r)
+        desc = host[od.value:od.value + B * r * 32].reshape(B, r, 32)
+        return n, kps, desc
+
+    def _last_frames(self):
+        return len(self.batch_counts())
+
+    def _kp_stride_max(self):
+        return self.max_keypoints(self.max_width, self.max_height)
 
     def batch_fetch_level(self, frame, level):
         w, h, _ = self._wh

@@ -385,21 +385,33 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyr_resize_tiled(FrameSet fs, c
 // yofs tables: PyrStripPlan) -- neighbouring strips recompute each other's halo rows instead of waiting for each other, so no workgroup
 // ever reads what another one wrote.  Rows a strip owns (a partition of every level) also go to the pyramid slab.  Same integers as
 // k_pyr_resize_tiled: same coefficient tables, same row sums, same rounding.  Level l - 1 and level l ping-pong between two LDS regions.
-// The kernel is a chain of short dependent phases, so nothing inside the level loop waits for global memory: the column coefficients of
-// all levels (source column, alpha pair: 8 bytes per column) and the row coefficients of every row the strip produces (source rows, beta
-// pair) go to LDS together with level 0; sizes and row ranges are scalar loads of two small tables.
+// The kernel is a chain of short dependent phases, so nothing inside the level loop waits for global memory: the row coefficients of every row the
+// strip produces (source rows, beta pair) go to LDS together with level 0; a thread's column coefficients (source column, alpha pair of the four
+// columns it produces on a level -- the same for every row) are read from the global tables one level AHEAD, while the level in hand is computed
+// (until round 6 a table of all levels' columns sat in LDS: 8 bytes per column, 55 KB of the 160 for 1920x1080, which therefore had no one-launch
+// plan); sizes and row ranges are scalar loads of two small tables.
 constexpr int kPyrStripThreads = kPyrStripMaxThreads;
 
 __global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, int nlevels, const PyrStripPlan *__restrict__ plans,
-                                                                 const PyrStripLevel *__restrict__ levels, int offCol, int offA, int offB,
+                                                                 const PyrStripLevel *__restrict__ levels, int offA, int offB,
                                                                  const int *__restrict__ xofs, const short *__restrict__ xalpha,
                                                                  const int *__restrict__ yofs, const short *__restrict__ ybeta) {
     extern __shared__ __attribute__((aligned(16))) uint8_t pyrLds[];
     uint2 *rowTab = (uint2 *) pyrLds;                 // (r0 | r1 << 16, beta0 | beta1 << 16) per produced row, levels 1 .. in order
-    uint2 *colTab = (uint2 *) (pyrLds + offCol);      // (sx, alpha0 | alpha1 << 16) per column, levels 1 .. in order (the order of the xofs table)
     const int tid = threadIdx.x, f = blockIdx.y;
     const PyrStripPlan *__restrict__ pl = plans + blockIdx.x;
-    const int xtab1 = levels[1].xtab;
+    // this thread's four columns of level l: (source column, alpha0 | alpha1 << 16) each, straight from the coefficient tables
+    auto load_cols = [&](int l, uint2 (&cv)[4], bool *active) {
+        const int w = levels[l].w, nq = (w + 3) >> 2, nrp = kPyrStripThreads / nq;
+        const int rp = tid / nq, cq = tid - rp * nq;
+        *active = rp < nrp;
+        const int xt = levels[l].xtab;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int gx = xt + min(4 * cq + k, w - 1);
+            cv[k] = make_uint2((unsigned) xofs[gx], *(const unsigned *) (xalpha + 2 * gx));
+        }
+    };
     // Everything the strip needs from global memory is requested before the first LDS write waits for any of it: this thread's row
     // coefficients (one row of one level), the first 4096 column coefficients, the first eight dwords per thread of level 0.
     bool rowHas = false;
@@ -422,14 +434,9 @@ __global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, in
             rowBeta = *(const unsigned *) (ybeta + 2 * (ytab + y));
         }
     }
-    const int nCols = levels[nlevels - 1].xtab + levels[nlevels - 1].w - xtab1;
-    constexpr int kC = 4;
-    uint2 colv[kC];
-#pragma unroll
-    for (int u = 0; u < kC; u++) {
-        const int i = min(tid + u * kPyrStripThreads, nCols - 1);
-        colv[u] = make_uint2((unsigned) xofs[xtab1 + i], *(const unsigned *) (xalpha + 2 * (xtab1 + i)));
-    }
+    uint2 colNext[4];                                 // level 1's, requested with the row coefficients, ahead of the image
+    bool actNext;
+    load_cols(1, colNext, &actNext);
     {   // level 0 rows [ca, cb) -> region A, whole rows, aligned dwords of the row
         const uint8_t *src = fs.img0 + (long long) f * fs.img0_stride;
         const int sp = fs.img0_pitch;
@@ -465,15 +472,10 @@ __global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, in
                     const unsigned r0 = (unsigned) (min(max(rowSy, 0), rowSh - 1) - rowSca), r1 = (unsigned) (min(max(rowSy + 1, 0), rowSh - 1) - rowSca);
                     rowTab[tid] = make_uint2(r0 | (r1 << 16), rowBeta);
                 }
-#pragma unroll
-                for (int u = 0; u < kC; u++)
-                    if (tid + u * kPyrStripThreads < nCols) colTab[tid + u * kPyrStripThreads] = colv[u];
             }
 #pragma unroll
             for (int u = 0; u < kU; u++) A[dst[u]] = v[u];
         }
-        for (int i = tid + kC * kPyrStripThreads; i < nCols; i += kPyrStripThreads)   // pyramids with more than 4096 columns in all
-            colTab[i] = make_uint2((unsigned) xofs[xtab1 + i], *(const unsigned *) (xalpha + 2 * (xtab1 + i)));
     }
     __syncthreads();
     int rowOff = 0;
@@ -489,14 +491,17 @@ __global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, in
         const int ca = (int) (pv.x & 0xFFFFu), cb = (int) (pv.x >> 16), wa = (int) (pv.y & 0xFFFFu), wb = (int) (pv.y >> 16);
         const int nq = (w + 3) >> 2, nrp = kPyrStripThreads / nq;
         const int rp = tid / nq, cq = tid - rp * nq;
+        uint2 colCur[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) colCur[k] = colNext[k];
+        if (l + 1 < nlevels) load_cols(l + 1, colNext, &actNext);   // in flight while this level is computed
         if (rp < nrp) {   // this thread: column quad cq of rows ca + rp, ca + rp + nrp, ...
             const int xb = 4 * cq;
             unsigned sel[4], ap[4];
-            const uint2 *ct = colTab + (levels[l].xtab - xtab1);
-            const int lx0 = (int) ct[xb].x;
+            const int lx0 = (int) colCur[0].x;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint2 cc = ct[min(xb + k, w - 1)];
+                const uint2 cc = colCur[k];
                 const int sx1 = min((int) cc.x + 1, sw - 1);
                 sel[k] = (unsigned) ((int) cc.x - lx0) | 0x0C00u | ((unsigned) (sx1 - lx0) << 16) | 0x0C000000u;
                 ap[k] = cc.y;
@@ -2334,9 +2339,9 @@ hipError_t pyr_strips_prepare(size_t ldsBytes) {
     return e;
 }
 
-void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips, int offCol,
+void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips,
                        int offA, int offB, size_t ldsBytes, int nFrames, const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
-    hipLaunchKernelGGL(k_pyr_strips, dim3(nStrips, nFrames), dim3(kPyrStripThreads), ldsBytes, st, fs, nlevels, plans, levels, offCol, offA, offB, xofs, xalpha, yofs, ybeta);
+    hipLaunchKernelGGL(k_pyr_strips, dim3(nStrips, nFrames), dim3(kPyrStripThreads), ldsBytes, st, fs, nlevels, plans, levels, offA, offB, xofs, xalpha, yofs, ybeta);
 }
 
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap) {
@@ -2463,6 +2468,23 @@ __global__ __launch_bounds__(256) void k_carry_slot(ygzf_kp *__restrict__ outKp,
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nk; i += gridDim.x * 256) dkw[i] = skw[i];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ndv; i += gridDim.x * 256) dd[i] = sd[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) outCnt[0] = n;
+}
+
+// Results of the frames of a SMALL launch gathered into one contiguous block -- [counts | keypoint rows | descriptor rows], every part 256-byte
+// aligned -- so that they cross the link as ONE copy: three device-to-host copies of a one-frame call cost 7 us each plus 8 us between them, this
+// kernel 2 us (ygzf_batch_fetch_packed).  Dword copies; nKp / nDesc = dwords of the keypoint / descriptor rows of all frames.
+__global__ __launch_bounds__(256) void k_pack_results(const unsigned *__restrict__ cnt, const unsigned *__restrict__ kp, const unsigned *__restrict__ desc, unsigned nCnt,
+                                                      unsigned nKp, unsigned nDesc, unsigned *__restrict__ dst, unsigned offKp, unsigned offDesc) {
+    const unsigned stride = gridDim.x * 256u;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nCnt; i += stride) dst[i] = cnt[i];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nKp; i += stride) dst[offKp + i] = kp[i];
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nDesc; i += stride) dst[offDesc + i] = desc[i];
+}
+void launch_pack_results(hipStream_t st, const int *cnt, const ygzf_kp *kp, const uint8_t *desc, int nFrames, int kpStride, void *dst, size_t offKp, size_t offDesc) {
+    const unsigned nKp = (unsigned) ((size_t) nFrames * kpStride * sizeof(ygzf_kp) / 4), nDesc = (unsigned) ((size_t) nFrames * kpStride * 8);
+    const unsigned blocks = std::min(1024u, (nDesc + 255u) / 256u + 1u);
+    hipLaunchKernelGGL(k_pack_results, dim3(blocks), dim3(256), 0, st, (const unsigned *) cnt, (const unsigned *) kp, (const unsigned *) desc, (unsigned) nFrames, nKp, nDesc,
+                       (unsigned *) dst, (unsigned) (offKp / 4), (unsigned) (offDesc / 4));
 }
 
 void launch_carry_slot(hipStream_t st, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, long long srcSlot, int kpStride) {

@@ -40,12 +40,13 @@ struct PyrStripLevel {   // what the kernel needs of a level, 32 bytes
 };
 constexpr int kPyrStripMaxThreads = 1024;
 __host__ __device__ inline int pyr_strip_lds_pitch(int w) { return ((w + 3) & ~3) + 12; }
-// LDS: row table (8 bytes per produced row of the levels >= 1), column table from offCol (8 bytes per column of the levels >= 1), region A from
+// LDS: row table (8 bytes per produced row of the levels >= 1), region A from
 // offA (even levels), region B from offB (odd levels)
 hipError_t pyr_strips_prepare(size_t ldsBytes);
-void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips, int offCol,
+void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips,
                        int offA, int offB, size_t ldsBytes, int nFrames, const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
 void launch_carry_slot(hipStream_t st, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, long long srcSlot, int kpStride);
+void launch_pack_results(hipStream_t st, const int *cnt, const ygzf_kp *kp, const uint8_t *desc, int nFrames, int kpStride, void *dst, size_t offKp, size_t offDesc);
 void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int firstLevel, int nlevels, const unsigned *offsets, uint8_t *dst);
 size_t fast_quads_lds_bytes(int winPitch, int winRows, int smapRows, int quadCap);
 void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, int iniTh, int minTh,

@@ -115,13 +115,10 @@ static void plan_pyr_strips(Geometry &G, int L) {
             maxRows = std::max(maxRows, rows);
         }
         if (maxRows > kPyrStripMaxThreads) continue;   // one thread per row fills the row table
-        size_t nCols = 0;
-        for (int l = 1; l < L; l++) nCols += (size_t) G.lv[l].w;
-        const size_t rowBytes = ((size_t) maxRows * 8 + 15) & ~(size_t) 15, head = rowBytes + ((nCols * 8 + 15) & ~(size_t) 15);
+        const size_t rowBytes = ((size_t) maxRows * 8 + 15) & ~(size_t) 15, head = rowBytes;   // (the column coefficients stay in global memory: k_pyr_strips)
         const size_t a = (bytes[0] + 16 + 15) & ~(size_t) 15, b = (bytes[1] + 16 + 15) & ~(size_t) 15;   // hrow reads up to 11 bytes past a row's pixels
         if (head + a + b > 160 * 1024) continue;
         G.pyrPlan = plan;
-        G.pyrStripOffCol = (int) rowBytes;
         G.pyrStripOffA = (int) head;
         G.pyrStripOffB = (int) (head + a);
         G.pyrStripLds = head + a + b;
@@ -463,7 +460,7 @@ int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
     if (!G.pyrPlan.empty() && nFrames <= c->pyrStripFrames) {   // a few frames: the whole chain in one launch
         ProfScope ps(c, KK_PYR);
         launch_pyr_strips(c->stream, fs, L, (const PyrStripPlan *) ((const char *) c->dPyrPlan.p + sizeof G.pyrLevels), (const PyrStripLevel *) c->dPyrPlan.p,
-                          (int) G.pyrPlan.size(), G.pyrStripOffCol, G.pyrStripOffA, G.pyrStripOffB, G.pyrStripLds, nFrames,
+                          (int) G.pyrPlan.size(), G.pyrStripOffA, G.pyrStripOffB, G.pyrStripLds, nFrames,
                           (const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
         return YGZF_OK;
     }
@@ -513,7 +510,8 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
     ygzf_kp *outKp = (ygzf_kp *) c->dOutKp.p;
     uint8_t *outDesc = (uint8_t *) c->dOutDesc.p;
     int *outCnt = (int *) c->dOutCnt.p;
-    launch_carry_slot(c->stream, outKp, outDesc, outCnt, (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
+    if (!c->carryLaunched) launch_carry_slot(c->stream, outKp, outDesc, outCnt, (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
+    c->carryLaunched = false;
     outKp += G.kpStride;
     outDesc += (size_t) G.kpStride * 32;
     outCnt += 1;
@@ -712,7 +710,7 @@ int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, i
     // Host frames that already carry the device's row pitch (ygzf_host_row_pitch): the copy engine pays per ROW of a pitched copy whose source rows
     // are not multiples of 64 bytes (752-byte rows: 48 GB/s where 1920-byte rows reach 55), so a whole frame -- (h - 1) x pitch + w bytes, padding
     // included -- is handed to it as ONE row (runs of 8 / 60 image rows measured the same: profiles/r05_a_h2d_shapes.txt)
-    if (row_pitch == pitch && pitch != w && (nFrames == 1 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
+    if (row_pitch == pitch && (nFrames == 1 || frame_stride >= (size_t) pitch * h) && ((uintptr_t) imgs & 3) == 0 && (w & 3) == 0 &&
         (frame_stride & 3) == 0) {
         const size_t fsd = (size_t) pitch * h, fss = nFrames == 1 ? fsd : frame_stride;
         HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, fsd, imgs, fss, (size_t) (h - 1) * pitch + w, (size_t) nFrames, hipMemcpyHostToDevice, c->stream));
@@ -791,7 +789,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlBase, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes, &c->dResPack};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)
@@ -1066,12 +1064,22 @@ int ygzf_extract_batch_device(ygzf_ctx *c, const uint8_t *d_imgs, int n_frames, 
     return run_extract(c, fs, n_frames);
 }
 
+// The carry (last frame of the previous batch -> slot 0 of the outputs) depends on nothing an upload brings: queued BEFORE the host frames, it runs
+// while they cross the link instead of between their arrival and the pyramid (6 us of a one-frame call).  run_extract then skips its own.
+static void carry_early(ygzf_ctx *c) {
+    const Geometry &G = c->geo;
+    launch_carry_slot(c->stream, (ygzf_kp *) c->dOutKp.p, (uint8_t *) c->dOutDesc.p, (int *) c->dOutCnt.p,
+                      (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
+    c->carryLaunched = true;
+}
+
 int ygzf_extract_batch_host(ygzf_ctx *c, const uint8_t *imgs, int n_frames, int w, int h, int row_pitch, size_t frame_stride) {
     if (!c || !imgs) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (row_pitch < w) return fail(c, YGZF_ERR_INVALID, "row_pitch %d < width %d", row_pitch, w);
     HIPCHECK(c, hipSetDevice(c->device));
     int rc = apply_geometry(c, w, h, n_frames);
     if (rc) return rc;
+    carry_early(c);
     FrameSet fs;
     if ((rc = upload_frames(c, imgs, n_frames, w, h, row_pitch, frame_stride, &fs))) return rc;
     return run_extract(c, fs, n_frames);
@@ -1089,6 +1097,7 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
     HIPCHECK(c, hipSetDevice(c->device));
     int rc = apply_geometry(c, w, h, n_frames);
     if (rc) return rc;
+    carry_early(c);
     c->pyrResident = false;
     c->aheadPending = false;
     c->pyrHeld = false;
@@ -1111,8 +1120,9 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
             regular = S > 0 && (size_t) S >= (size_t) u * tight;
             for (int f = 0; f < n_frames && regular; f++) regular = frames[f] == frames[0] + (ptrdiff_t) (f / u) * S + (ptrdiff_t) (f % u) * (ptrdiff_t) tight;
         }
-        if (regular && row_pitch == pitch && pitch != w && (w & 3) == 0 && ((uintptr_t) frames[0] & 3) == 0 && (S & 3) == 0) {
-            // frames that carry the device's pitch (ygzf_host_row_pitch): the runs go straight to their place, no staging and no re-pitch launch
+        if (regular && row_pitch == pitch && (w & 3) == 0 && ((uintptr_t) frames[0] & 3) == 0 && (S & 3) == 0) {
+            // frames that carry the device's pitch (ygzf_host_row_pitch; tight frames whose width is a multiple of 64 -- 640, 1920, 3840 -- do so by
+            // themselves): the runs go straight to their place, no staging and no re-pitch launch
             const size_t width = (size_t) u * tight - (size_t) (pitch - w);
             HIPCHECK(c, hipMemcpy2DAsync(c->dImg0.p, (size_t) u * tight, frames[0], runs > 1 ? (size_t) S : (size_t) u * tight, width, (size_t) runs, hipMemcpyHostToDevice, c->stream));
             goto uploaded;
@@ -1183,6 +1193,27 @@ int ygzf_batch_fetch_all(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int *n_kp, in
     HIPCHECK(c, hipMemcpy2DAsync(desc, 32 * (size_t) stride, (uint8_t *) c->dOutDesc.p + 32 * (size_t) ks, 32 * (size_t) ks, 32 * (size_t) ks, B,
                                  hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+int ygzf_batch_fetch_packed(ygzf_ctx *c, void *host, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries, size_t *bytes_out) {
+    if (!c || !host || !off_kps || !off_desc || !row_entries) return fail(c, YGZF_ERR_INVALID, "null argument");
+    if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    const size_t B = (size_t) c->lastFrames, ks = (size_t) c->geo.kpStride;
+    const size_t oK = (B * sizeof(int) + 255) & ~(size_t) 255, oD = oK + ((B * ks * sizeof(ygzf_kp) + 255) & ~(size_t) 255), total = oD + B * ks * 32;
+    if (total > host_bytes) return fail(c, YGZF_ERR_INVALID, "packed results need %zu bytes, %zu given", total, host_bytes);
+    if (total >= (1ull << 32)) return fail(c, YGZF_ERR_UNSUPPORTED, "packed results of %zu bytes: use ygzf_batch_fetch_all", total);
+    int rc = ensure(c, c->dResPack, total + 256);
+    if (rc) return rc;
+    launch_pack_results(c->stream, (const int *) c->dOutCnt.p + 1, (const ygzf_kp *) c->dOutKp.p + ks, (const uint8_t *) c->dOutDesc.p + ks * 32, (int) B, (int) ks,
+                        c->dResPack.p, oK, oD);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(host, c->dResPack.p, total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *off_kps = oK;
+    *off_desc = oD;
+    *row_entries = (int) ks;
+    if (bytes_out) *bytes_out = total;
     return YGZF_OK;
 }
 

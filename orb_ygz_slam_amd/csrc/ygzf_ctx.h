@@ -33,7 +33,7 @@ struct Geometry {
     std::vector<short> xalpha, ybeta;
     long long pyrBytes = 0;   // per frame, levels >= 1
     std::vector<PyrStripPlan> pyrPlan;   // k_pyr_strips: one entry per strip (empty: this geometry takes one launch per level)
-    int pyrStripOffCol = 0, pyrStripOffA = 0, pyrStripOffB = 0;
+    int pyrStripOffA = 0, pyrStripOffB = 0;
     PyrStripLevel pyrLevels[kMaxLevels];
     size_t pyrStripLds = 0;
     int totalCells = 0, maxCellsPerLevel = 0;
@@ -100,6 +100,8 @@ struct ygzf_ctx {
     Buf dPack;                             // inputs + outputs of a one-frame entry point, one copy each way (PackedTransfer)
     int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
+    Buf dResPack;                          // [counts | keypoint rows | descriptor rows] of a small launch, contiguous (ygzf_batch_fetch_packed)
+    bool carryLaunched = false;            // k_carry_slot already queued for the extraction being set up (ahead of its upload)
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)
     bool pyrHeld = false;                  // dImg0 / dPyr frame 0 hold ONE image (pyrHeldW x pyrHeldH) and its complete pyramid (ygzf_image_cache_put_resident)
     int pyrHeldW = 0, pyrHeldH = 0;

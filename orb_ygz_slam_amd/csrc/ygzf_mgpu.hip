@@ -28,9 +28,12 @@ struct ygzf_mgpu {
         ygzf_ctx *ctx[2] = {nullptr, nullptr};   // chunks alternate between them: the upload of one overlaps the kernels of the other
         uint8_t *hIn[3] = {nullptr, nullptr, nullptr};   // page-locked: the frames of one chunk at the device's row pitch (used when the caller's frames are pageable);
                                                          // three, so that chunk k + 2 is gathered while chunk k's upload may still be reading its own
-        ygzf_kp *hKp[2] = {nullptr, nullptr};    // page-locked: results of one chunk
+        uint8_t *hRes[2] = {nullptr, nullptr};   // page-locked: results of one chunk, ONE block [counts | keypoint rows | descriptor rows] ...
+        size_t hResBytes = 0;
+        ygzf_kp *hKp[2] = {nullptr, nullptr};    // ... into which these point: where the last fetch of the chunk's context left each part
         uint8_t *hDesc[2] = {nullptr, nullptr};
         int *hCnt[2] = {nullptr, nullptr};
+        int resRow[2] = {0, 0};                  // entries per keypoint / descriptor row of that fetch
         int *hAux[2] = {nullptr, nullptr};       // page-locked: match rows (int) or uRight rows followed by depth rows (float) of one chunk
         cpu_set_t cpus;                          // CPUs of the device's NUMA node (empty: unknown, threads stay where they are)
         bool haveCpus = false;
@@ -123,10 +126,13 @@ int ygzf_mgpu_create(const int *devices, int n_devices, const ygzf_extractor_cfg
         if (hipSetDevice(devices[i]) != hipSuccess) { ygzf_mgpu_destroy(m); return YGZF_ERR_HIP; }
         // (the three input staging areas -- chunk x pitch x height bytes each, GBs for 4K -- are page-locked by the first call that brings PAGEABLE
         // frames, run_job: a caller whose frames are page-locked never pays for them)
+        const size_t oK = (F * sizeof(int) + 255) & ~(size_t) 255, oD = oK + ((F * m->stride * sizeof(ygzf_kp) + 255) & ~(size_t) 255);
+        d.hResBytes = oD + F * m->stride * 32;
         for (int b = 0; b < 2; b++) {
-            if (hipHostMalloc((void **) &d.hKp[b], F * m->stride * sizeof(ygzf_kp)) != hipSuccess ||
-                hipHostMalloc((void **) &d.hDesc[b], F * m->stride * 32) != hipSuccess || hipHostMalloc((void **) &d.hCnt[b], F * sizeof(int)) != hipSuccess ||
-                hipHostMalloc((void **) &d.hAux[b], F * m->stride * sizeof(int)) != hipSuccess) {
+            if (hipHostMalloc((void **) &d.hRes[b], d.hResBytes) == hipSuccess) {
+                d.hCnt[b] = (int *) d.hRes[b]; d.hKp[b] = (ygzf_kp *) (d.hRes[b] + oK); d.hDesc[b] = d.hRes[b] + oD;
+            }
+            if (!d.hRes[b] || hipHostMalloc((void **) &d.hAux[b], F * m->stride * sizeof(int)) != hipSuccess) {
                 (void) hipGetLastError();
                 ygzf_mgpu_destroy(m);
                 return YGZF_ERR_HIP;
@@ -143,16 +149,14 @@ void ygzf_mgpu_destroy(ygzf_mgpu *m) {
         for (int b = 0; b < 2; b++)
             if (d.ctx[b]) ygzf_destroy(d.ctx[b]);
         bool any = false;
-        for (int b = 0; b < 2; b++) any = any || d.hKp[b] || d.hDesc[b] || d.hCnt[b] || d.hAux[b];
+        for (int b = 0; b < 2; b++) any = any || d.hRes[b] || d.hAux[b];
         for (int b = 0; b < 3; b++) any = any || d.hIn[b];
         if (!any) continue;   // a slot whose contexts were never created (e.g. a device index that does not exist)
         (void) hipSetDevice(d.device);
         for (int b = 0; b < 3; b++)
             if (d.hIn[b]) (void) hipHostFree(d.hIn[b]);
         for (int b = 0; b < 2; b++) {
-            if (d.hKp[b]) (void) hipHostFree(d.hKp[b]);
-            if (d.hDesc[b]) (void) hipHostFree(d.hDesc[b]);
-            if (d.hCnt[b]) (void) hipHostFree(d.hCnt[b]);
+            if (d.hRes[b]) (void) hipHostFree(d.hRes[b]);
             if (d.hAux[b]) (void) hipHostFree(d.hAux[b]);
         }
     }
@@ -338,7 +342,18 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         };
         auto fetch = [&](int k) {        // waits for chunk k and brings its results into the page-locked staging of its context
             const int b = k & 1;
-            int rc = ygzf_batch_fetch_all(cx(k), d.hKp[b], d.hDesc[b], d.hCnt[b], m->stride);
+            int rc;
+            const size_t F = (size_t) m->chunk, oK = (F * sizeof(int) + 255) & ~(size_t) 255, oD = oK + ((F * m->stride * sizeof(ygzf_kp) + 255) & ~(size_t) 255);
+            if ((size_t) cnt(k) * m->stride * 60 <= (2u << 20)) {
+                // a few frames (one Tracking frame, one stereo pair): the three parts gathered on the device and brought over in ONE copy
+                size_t pk = 0, pd = 0;
+                rc = ygzf_batch_fetch_packed(cx(k), d.hRes[b], d.hResBytes, &pk, &pd, &d.resRow[b], nullptr);
+                d.hCnt[b] = (int *) d.hRes[b]; d.hKp[b] = (ygzf_kp *) (d.hRes[b] + pk); d.hDesc[b] = d.hRes[b] + pd;
+            } else {
+                d.hCnt[b] = (int *) d.hRes[b]; d.hKp[b] = (ygzf_kp *) (d.hRes[b] + oK); d.hDesc[b] = d.hRes[b] + oD;
+                rc = ygzf_batch_fetch_all(cx(k), d.hKp[b], d.hDesc[b], d.hCnt[b], m->stride);
+                d.resRow[b] = m->stride;
+            }
             if (rc == YGZF_OK && J.mode == kMatch) rc = ygzf_match_counts(cx(k), nm.data() + lo(k));
             if (rc == YGZF_OK && J.mode == kMatch && J.match) rc = ygzf_match_fetch_all(cx(k), d.hAux[b], m->stride);
             if (rc == YGZF_OK && J.mode == kStereo) {
@@ -354,8 +369,8 @@ int run_job(ygzf_mgpu *m, const Job &J) {
                 const int i = lo(k) + j, f = fr[i];
                 const int c = d.hCnt[b][j];
                 J.n_kp[f] = c;
-                memcpy(J.kps + (size_t) f * J.stride, d.hKp[b] + (size_t) j * m->stride, sizeof(ygzf_kp) * (size_t) c);
-                memcpy(J.desc + (size_t) f * J.stride * 32, d.hDesc[b] + (size_t) j * m->stride * 32, 32 * (size_t) c);
+                memcpy(J.kps + (size_t) f * J.stride, d.hKp[b] + (size_t) j * d.resRow[b], sizeof(ygzf_kp) * (size_t) c);
+                memcpy(J.desc + (size_t) f * J.stride * 32, d.hDesc[b] + (size_t) j * d.resRow[b] * 32, 32 * (size_t) c);
                 if (J.mode == kMatch) {
                     const bool first = (f % unit) == 0;                           // no predecessor inside the unit
                     if (J.nmatches) J.nmatches[f] = first ? -1 : nm[i];

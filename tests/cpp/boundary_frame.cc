@@ -430,6 +430,72 @@ int main(int argc, char **argv) {
             restore();
             trk.SearchLocalPoints();      // leave the state the dumps below expect
         }
+        {
+            // ---- a local map ABOVE the binding's threshold (ygzf_host_device_frustum_min, 1500 by default): the last frame's points plus a second
+            // point beside every one of them (~2000 candidates, what a well-mapped scene offers).  Nothing is forced here: the default
+            // binding takes the fused device frustum + matcher call by itself, and must leave every MapPoint and every slot of the frame as the
+            // reference's own body (per-point Frame::isInFrustum, per-call matcher) does.
+            std::vector<MapPoint> extra;
+            extra.reserve(mps.size());
+            for (size_t i = 0; i < mps.size(); i++) {
+                // a second point per keypoint of the last frame: ~35 px to the side at the same depth, carrying ANOTHER point's descriptor -- most
+                // of them find keypoints in their window and no acceptable match, as the points of a local map that left the view's appearance do
+                MapPoint q = mps[i];
+                q.mWorldPos = mps[i].mWorldPos + Vector3f((i & 1) ? 0.3f : -0.3f, (i & 2) ? 0.2f : -0.2f, 0.f);
+                q.mDescriptor = mps[(i * 7 + 13) % mps.size()].mDescriptor.clone();
+                q.mnVisible = 1; q.mnLastFrameSeen = 0; q.mbTrackInView = false;
+                extra.push_back(q);
+            }
+            std::vector<MapPoint *> big;
+            for (auto &mp : mps) big.push_back(&mp);
+            for (auto &mp : extra) big.push_back(&mp);
+            struct St { bool inView; float x, y, xr, vc; int lvl, visible; unsigned long seen; };
+            auto snap = [&]() { std::vector<St> v; for (MapPoint *m : big) v.push_back(St{m->mbTrackInView, m->mTrackProjX, m->mTrackProjY, m->mTrackProjXR, m->mTrackViewCos, m->mnTrackScaleLevel, m->mnVisible, m->mnLastFrameSeen}); return v; };
+            auto reset = [&]() {
+                trk.mCurrentFrame.mvpMapPoints.assign(trk.mCurrentFrame.N, (MapPoint *) nullptr);
+                for (MapPoint *m : big) { m->mnVisible = 1; m->mnLastFrameSeen = 0; m->mbTrackInView = false; }
+            };
+            auto same = [](const std::vector<St> &a, const std::vector<St> &b2) {
+                for (size_t i = 0; i < a.size(); i++) {
+                    if (a[i].inView != b2[i].inView || a[i].visible != b2[i].visible || a[i].seen != b2[i].seen) return false;
+                    if (a[i].inView && (std::memcmp(&a[i].x, &b2[i].x, 4 * sizeof(float)) || a[i].lvl != b2[i].lvl)) return false;
+                }
+                return true;
+            };
+            const std::vector<MapPoint *> keepLocal = trk.mvpLocalMapPoints;
+            trk.mvpLocalMapPoints = big;
+            if ((int) big.size() < ygzf_host_device_frustum_min) { fprintf(stderr, "large local map: %zu points do not reach the threshold %d\n", big.size(), ygzf_host_device_frustum_min); return 7; }
+            reset();
+            ygz_ref_Tracking_SearchLocalPoints(&trk);
+            const std::vector<MapPoint *> refA = trk.mCurrentFrame.mvpMapPoints;
+            const std::vector<St> refS = snap();
+            reset();
+            trk.SearchLocalPoints();                                            // default threshold: the fused device call
+            if (trk.mCurrentFrame.mvpMapPoints != refA || !same(snap(), refS)) {
+                fprintf(stderr, "Tracking::SearchLocalPoints (large local map, default threshold): the binding differs from the reference's body\n");
+                return 7;
+            }
+            int matched = 0;
+            for (MapPoint *m : refA) matched += m != nullptr;
+            auto med2 = [&](bool batch) {
+                std::vector<double> us;
+                for (int it = 0; it < 9; it++) {
+                    reset();
+                    const auto t0 = std::chrono::steady_clock::now();
+                    if (batch) trk.SearchLocalPoints(); else ygz_ref_Tracking_SearchLocalPoints(&trk);
+                    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+                }
+                std::sort(us.begin(), us.end());
+                return us[4];
+            };
+            const double a2 = med2(false), b2 = med2(true);
+            printf("latency search_local_points_large percall_us %.1f binding_default_us %.1f local_points %zu matched %d\n", a2, b2, big.size(), matched);
+            // back to the state the dumps below expect
+            trk.mvpLocalMapPoints = keepLocal;
+            trk.mCurrentFrame.mvpMapPoints.assign(trk.mCurrentFrame.N, (MapPoint *) nullptr);
+            for (size_t i = 0; i < mps.size(); i++) { mps[i].mnVisible = before[i].visible; mps[i].mnLastFrameSeen = before[i].seen; mps[i].mbTrackInView = before[i].inView; }
+            trk.SearchLocalPoints();
+        }
         std::vector<int> a3(trk.mCurrentFrame.N, -1);
         int visible = 0;
         for (int i = 0; i < trk.mCurrentFrame.N; i++)

@@ -42,7 +42,7 @@ def test_reference_frame_over_product_shells(oracle, tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "boundary ok" in out.stdout
     lat = [l for l in out.stdout.splitlines() if l.startswith("latency ")]
-    assert len(lat) == 4
+    assert len(lat) == 5
     tri = [l for l in out.stdout.splitlines() if l.startswith("info search_for_triangulation")]
     assert len(tri) == 2 and int(tri[0].split()[5]) >= 50, tri      # device pairs == the reference's own body (the driver exits 7 otherwise)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -395,3 +395,19 @@ def test_frames_from_a_pointer_list(oracle):
     ex.sync()
     del pinned
     L.ygzf_free_host(ptr)
+
+
+def test_packed_fetch_equals_fetch_all():
+    """ygzf_batch_fetch_packed (counts / keypoint rows / descriptor rows gathered by a kernel, ONE device-to-host copy: the result path of one-frame
+    and one-pair calls) returns the bytes of ygzf_batch_fetch_all, for full and partial batches and for images smaller than the context's maximum."""
+    from orb_ygz_slam_amd import Extractor
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=4)
+    for (w, h, n) in ((752, 480, 4), (752, 480, 1), (640, 400, 3), (752, 480, 2)):
+        imgs = np.stack([synth_frame(300 + i, w, h) for i in range(n)])
+        ex.extract_batch_host(imgs)
+        cnt, kps, desc = ex.batch_fetch_packed()
+        assert len(cnt) == n and (cnt > 300).all()
+        for f in range(n):
+            k, d = ex.batch_fetch(f)
+            assert cnt[f] == len(k) and np.array_equal(kps[f, :cnt[f]], k) and np.array_equal(desc[f, :cnt[f]], d), (w, h, n, f)
+    ex.close()

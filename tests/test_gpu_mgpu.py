@@ -257,3 +257,21 @@ def test_bench_falls_back_from_rccl_to_gloo_together():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert line["config"]["barrier_backend"] == "gloo" and line["value"] > 0
+
+
+def test_small_calls_take_the_packed_result_path(oracle):
+    """One frame / one pair per call (BASELINE.json's literal multi-GPU configurations; a Tracking frame): the slot brings the results over in ONE copy
+    (ygzf_batch_fetch_packed) -- also for frames smaller than the handle's maximum, whose keypoint rows are shorter than the handle's stride."""
+    from orb_ygz_slam_amd import MultiGpu, make_camera
+    mg = MultiGpu([0], max_width=752, max_height=480, max_frames_per_device=2)
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    for (w, h) in ((752, 480), (640, 400), (320, 240)):
+        frames = _clip(2, w, h)
+        k, d, c, m, nm = mg.extract_match(frames, unit=2, cam=make_camera(w, h))
+        for f in range(2):
+            ok, od = oex.extract(frames[f])
+            assert c[f] == len(ok) and (k[f, :c[f]] == ok).all() and (d[f, :c[f]] == od).all(), (w, h, f)
+        assert nm[0] == -1 and nm[1] > 50
+        k1, d1, c1, _, _ = mg.extract_match(frames[:1])                   # one frame, extraction only
+        assert c1[0] == c[0] and (k1[0, :c1[0]] == k[0, :c[0]]).all() and (d1[0, :c1[0]] == d[0, :c[0]]).all()
+    mg.close()
