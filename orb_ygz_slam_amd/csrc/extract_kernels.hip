@@ -655,7 +655,10 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol
 
 // LDS pitch of a cell's score map = the window pitch (wCell + 2 columns used, the window pitch is >= wCell + 7)
 struct FastGroupBases { int v[kMaxLevels]; };   // first 2x2 cell group of every level inside a frame (LevelGeom::groupBase), by value
-constexpr int kCornerCap = 512;  // corners listed per cell before the dense fallback takes over
+#ifndef YGZF_CORNER_CAP
+#define YGZF_CORNER_CAP 512
+#endif
+constexpr int kCornerCap = YGZF_CORNER_CAP;  // corners listed per cell before the dense fallback takes over
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2q  The same cell loop with FOUR pixels per lane in pass 1 (byte-sliced FAST-9 test).
@@ -1087,21 +1090,11 @@ constexpr int kTabPitch = 48;
 // workgroups free their LDS sooner, but the pipeline as a whole runs best with four.
 constexpr int kFastTabWaves = YGZF_FAST_TAB_WAVES;
 
+// one cell of the table: record load, window by LDS-DMA, fast_cell_process.  `win` = this wave's LDS region.
 template <bool kIniFirst>
-__global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
-                                                         unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
-                                                         long long totalSlots, int totalGroups, int groupsPerXcd, int winRows, int smapRows,
-                                                         int quadCap, unsigned *__restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    PhaseClk pc;
-    pc.start();
-    if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
-    const int blk = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);   // XCD-aware: every XCD gets a contiguous run of cells
-    const int f = blockIdx.y;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rec = blk * kFastTabWaves + wv;                              // (groupsPerXcd / totalGroups count workgroups of kFastTabWaves cells here)
-    if (rec >= totalGroups * kFastTabWaves) return;
+__device__ __forceinline__ void fast_tab_cell(const FrameSet &fs, const FastCellRec *__restrict__ cells, int rec, int f, int iniTh, int minTh,
+                                              unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells, long long totalSlots,
+                                              uint8_t *win, int winBytes, int smapBytes, int lane, unsigned *__restrict__ stats, PhaseClk &pc) {
     const int grp = rec >> 2;
     const FastCellRec R = cells[rec];
     const unsigned fl = R.flags >> 8;
@@ -1117,10 +1110,6 @@ __global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, co
     const uint8_t *src = (lvl0 ? fs.img0 + (long long) f * fs.img0_stride : fs.pyr + (long long) f * fs.pyr_stride + R.off) +
                          (R.xy >> 16) * pitch + (R.xy & 0xFFFFu);
     constexpr int P = kTabPitch;
-    const int winBytes = (winRows * P + 16 + 15) & ~15;
-    const int smapBytes = (max(smapRows * P, quadCap * 4) + 15) & ~15;
-    const int perWave = winBytes + smapBytes + kCornerCap * 2;
-    uint8_t *win = fdyn + wv * perWave;
     uint8_t *smap = win + winBytes;
     unsigned short *clist = (unsigned short *) (smap + smapBytes);
     {   // window rows 0 .. wh - 1, 48 bytes each from column iniX - 1.  Reads at most 47 bytes past that column: inside the row's 16-px border
@@ -1138,7 +1127,89 @@ __global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, co
     wave_lds_sync();
     pc.mark(0);
     fast_cell_process<P, kIniFirst>(win, smap, clist, P, dw, dh, iniTh, minTh, cnt_out, slots + (long long) f * totalSlots + R.slot, grp, lane, stats, pc);
+}
+
+template <bool kIniFirst>
+__global__ __launch_bounds__(64 * kFastTabWaves) void k_fast_tab(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
+                                                         unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
+                                                         long long totalSlots, int totalGroups, int groupsPerXcd, int winRows, int smapRows,
+                                                         int quadCap, unsigned *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    PhaseClk pc;
+    pc.start();
+    if ((int) (blockIdx.x >> 3) >= groupsPerXcd) return;
+    const int blk = (blockIdx.x & 7) * groupsPerXcd + (blockIdx.x >> 3);   // XCD-aware: every XCD gets a contiguous run of cells
+    const int f = blockIdx.y;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rec = blk * kFastTabWaves + wv;                              // (groupsPerXcd / totalGroups count workgroups of kFastTabWaves cells here)
+    if (rec >= totalGroups * kFastTabWaves) return;
+    const int winBytes = (winRows * kTabPitch + 16 + 15) & ~15;
+    const int smapBytes = (max(smapRows * kTabPitch, quadCap * 4) + 15) & ~15;
+    const int perWave = winBytes + smapBytes + kCornerCap * 2;
+    fast_tab_cell<kIniFirst>(fs, cells, rec, f, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, fdyn + wv * perWave, winBytes, smapBytes, lane, stats, pc);
     pc.flush(0, lane, (unsigned) rec + (unsigned) f * (unsigned) (totalGroups * kFastTabWaves));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K2p  The same cells, PERSISTENT waves.  Counters of k_fast_tab on a 256-frame launch (profiles/r06_spi_*.txt): 21 of a CU's 32 wave slots are
+// occupied on average although LDS and registers allow all 32 -- the dispatcher places the four waves of a workgroup on the four SIMDs in order
+// and stalls on the first full one (SPI_RA_WAVE_SIMD_FULL 71 % of the cycles, LDS_CU_FULL 61 %) while slots elsewhere stand empty, because the
+// waves of 270 000 ten-microsecond workgroups end in no particular order.  Here as many workgroups as the chip holds are launched ONCE and every
+// wave draws cells from a counter until none is left: no wave is ever launched again, every slot stays occupied to the end, and a wave that
+// met an expensive cell simply draws fewer.  Items = (frame, cell record) in frame-major order, cut into eight contiguous chunks, one per XCD
+// (workgroup b runs on XCD b % 8: a frame's windows meet in one L2), each with its own counter; a wave whose chunk is exhausted helps the next
+// XCD's share.  The draw for the NEXT cell is issued before the current one's window is requested, so its round trip hides behind that window's.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool kIniFirst>
+__global__ __launch_bounds__(256) void k_fast_tab_persist(FrameSet fs, const FastCellRec *__restrict__ cells, int iniTh, int minTh,
+                                                          unsigned short *__restrict__ cellCnt, unsigned *__restrict__ slots, int totalCells,
+                                                          long long totalSlots, unsigned recsPerFrame, unsigned long long recMagic, unsigned totalItems,
+                                                          unsigned itemsPerXcd, int winRows, int smapRows, int quadCap, unsigned *__restrict__ stats,
+                                                          unsigned *__restrict__ counters) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fdyn[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int winBytes = (winRows * kTabPitch + 16 + 15) & ~15;
+    const int smapBytes = (max(smapRows * kTabPitch, quadCap * 4) + 15) & ~15;
+    const int perWave = winBytes + smapBytes + kCornerCap * 2;
+    uint8_t *win = fdyn + wv * perWave;
+    PhaseClk pc;
+    pc.start();
+    // 64 counters, 256 bytes apart: XCD x (= blockIdx.x % 8) owns counters 8 x .. 8 x + 7, each over an eighth of the XCD's items.  The draws are
+    // WORKGROUP-scope atomics: they execute in the XCD's own L2 (an agent-scope one is carried out at the memory side, ~14 ns apiece on one
+    // line for the whole device: 270 000 draws of a launch took 3.8 ms that way).  That is enough: a counter is only ever drawn from by waves of
+    // its own XCD -- and should the hardware ever place a workgroup elsewhere, two L2s would each count from zero and some cells would be
+    // computed twice, to the same bytes (the work is idempotent), never skipped.
+    const unsigned xcd = blockIdx.x & 7u;
+    unsigned sub = (blockIdx.x >> 3) & 7u;
+    int chunksTried = 0;
+    const unsigned xLo = xcd * itemsPerXcd, xHi = min(xLo + itemsPerXcd, totalItems);
+    const unsigned perSub = (itemsPerXcd + 7u) >> 3;
+    auto draw = [&](unsigned sb) { return __hip_atomic_fetch_add(&counters[(xcd * 8u + sb) * 64u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    unsigned pend = 0;                                  // lane 0: the draw in flight
+    if (lane == 0) pend = draw(sub);
+#pragma unroll 1
+    while (true) {
+        const unsigned idx = (unsigned) __builtin_amdgcn_readfirstlane((int) pend);
+        const unsigned lo = min(xLo + sub * perSub, xHi), hi = min(lo + perSub, xHi);
+        if (idx >= hi - lo) {                           // this share is done: help the XCD's next one
+            if (++chunksTried == 8) break;
+            sub = (sub + 1u) & 7u;
+            if (lane == 0) pend = draw(sub);
+            continue;
+        }
+        const unsigned item = lo + idx;
+        if (lane == 0) pend = draw(sub);                // the next draw: in flight while this cell's record and window are fetched
+        unsigned f = (unsigned) (((unsigned long long) item * recMagic) >> 40);   // item / recsPerFrame (magic multiply, corrected below)
+        if (f * recsPerFrame > item) f--;
+        if ((f + 1u) * recsPerFrame <= item) f++;
+        const unsigned rec = item - f * recsPerFrame;
+        fast_tab_cell<kIniFirst>(fs, cells, (int) rec, (int) f, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, win, winBytes, smapBytes, lane, stats, pc);
+        pc.flush(0, lane, item);
+        pc.start();
+        wave_lds_sync();                                // the next cell reuses this wave's LDS region
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2377,8 +2448,11 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 }
 
 // ---- table-driven form (k_fast_tab) ----
+#ifndef YGZF_FAST_LDS_PAD
+#define YGZF_FAST_LDS_PAD 0
+#endif
 size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap) {
-    return (fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap) - 64) / (kFastBlock / 64) * kFastTabWaves + 64;
+    return (fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap) - 64) / (kFastBlock / 64) * kFastTabWaves + 64 + YGZF_FAST_LDS_PAD;
 }
 void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
                      int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
@@ -2392,6 +2466,26 @@ void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCel
                                                    groupsPerXcd, winRows, smapRows, quadCap, stats)
     if (iniFirst) YGZF_LAUNCH_TAB(true); else YGZF_LAUNCH_TAB(false);
 #undef YGZF_LAUNCH_TAB
+}
+
+// persistent form: `counters` = kFastPersistCounterBytes zeroed bytes (64 draw counters, 256 bytes apart); nWorkgroups = what the device holds at once
+void launch_fast_tab_persist(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
+                             int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
+                             unsigned *stats, unsigned *counters, int nWorkgroups) {
+    if (totalGroups <= 0) return;
+    const unsigned recsPerFrame = (unsigned) totalGroups * 4u;
+    const unsigned long long magic = ((1ull << 40) + recsPerFrame - 1) / recsPerFrame;
+    const unsigned totalItems = recsPerFrame * (unsigned) nFrames;
+    // whole frames per XCD where the frames divide (a frame's windows then meet in one L2), equal shares of the items otherwise
+    const unsigned perXcd = nFrames >= 8 ? recsPerFrame * (unsigned) ((nFrames + 7) / 8) : (totalItems + 7u) / 8u;
+    const size_t lds = fast_tab_lds_bytes(winRows, smapRows, quadCap);
+    const dim3 grid((unsigned) nWorkgroups), block(256);
+    if (iniFirst)
+        hipLaunchKernelGGL((k_fast_tab_persist<true>), grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, recsPerFrame, magic,
+                           totalItems, perXcd, winRows, smapRows, quadCap, stats, counters);
+    else
+        hipLaunchKernelGGL((k_fast_tab_persist<false>), grid, block, lds, st, fs, dCells, iniTh, minTh, cellCnt, slots, totalCells, totalSlots, recsPerFrame, magic,
+                           totalItems, perXcd, winRows, smapRows, quadCap, stats, counters);
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes) {

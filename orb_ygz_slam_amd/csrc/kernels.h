@@ -59,6 +59,10 @@ void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCel
                      int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
                      unsigned *stats);
 hipError_t phase_clocks_read(int kernel, unsigned long long *out16, bool reset);   // -DYGZF_PHASE_CLOCK builds only (hipErrorNotSupported otherwise)
+constexpr size_t kFastPersistCounterBytes = 64 * 256;
+void launch_fast_tab_persist(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
+                             int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
+                             unsigned *stats, unsigned *counters, int nWorkgroups);
 constexpr int kFastStatWords = 8 * 64;   // `stats`: 64 x {cells sampled, cells whose keypoints are FAST(minTh)'s, score rounds beyond the first, plan: 1 one pass / 2 iniTh first, corner-bearing quads, quads, -, pass-1 runs}
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes);
 size_t octree_hist_lds_bytes(int regionInts, int histBins);

@@ -564,8 +564,29 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             // widest cell and the pyramid offsets / frame sizes fit its 32-bit / 16-bit record fields
             const bool tab = c->fastKernel != YGZF_FAST_KERNEL_REGISTER_STAGING && G.fastWCellMax <= kFastTabMaxCell && G.pyrBytes < (1ll << 32) &&
                              G.w < 65536 && G.h < 65536 && G.totalSlots < (1ll << 32);
+            // Large frames in large launches: persistent waves that draw their cells from per-XCD counters (extract_kernels.hip, k_fast_tab_persist) -- as many
+            // workgroups as the device holds at once.  Measured on MI355X (profiles/r06_fast_persist_ab.txt), isolated and inside the three-context
+            // pipeline: 1920x1080 (1620 cell groups per frame) 1484 -> 1248 us per 128 frames, 48.9 -> 51.3 k frames/s; 3840x2160 stereo 3.5 -> 2.7 ms
+            // per 64 frames, 11.6 -> 12.7 k frames/s; 752x480 (259 groups) 473 -> 443 us per 256 frames alone but 237 -> 228 k frames/s in the pipeline:
+            // waves that never leave keep the other contexts' octree / matcher workgroups (71 KB of LDS each) waiting for a CU, and at that size
+            // the cell loop gains less than they lose.  Hence the rule: frames of >= 1000 cell groups.
+            const size_t fastLds = tab ? fast_tab_lds_bytes(G.fastWinRows, G.fastSmapRows, G.fastQuadCap) : 0;
+            const int perCu = tab ? (int) std::min<size_t>((size_t) forced("fast_persist_wgs", 8), (size_t) (160 * 1024) / std::max<size_t>(fastLds, 1)) : 0;
+            const int resident = perCu * c->cuCount;
+            const int persistMode = (int) forced("fast_persist", -1);   // tests: 1 always, 0 never
+            const bool persist = tab && resident > 0 && (persistMode == 1 || (persistMode != 0 && G.totalGroups >= 1000 && (long long) nFrames * G.totalGroups >= 4LL * resident));
+            if (persist) {
+                int rcC = ensure(c, c->dFastCtr, kFastPersistCounterBytes);
+                if (rcC) return rcC;
+                HIPCHECK(c, hipMemsetAsync(c->dFastCtr.p, 0, kFastPersistCounterBytes, c->stream));
+            }
             ProfScope ps(c, tab ? KK_FAST : KK_FASTQ);
-            if (tab)
+            if (persist)
+                launch_fast_tab_persist(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
+                                        (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,
+                                        nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr,
+                                        (unsigned *) c->dFastCtr.p, (int) std::min<long long>(resident, (long long) nFrames * G.totalGroups));
+            else if (tab)
                 launch_fast_tab(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                 (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,
                                 nFrames, G.fastWinRows, G.fastQuadCap, iniFirst, collect ? (unsigned *) c->dFastStats.p : nullptr);
@@ -769,6 +790,11 @@ int ygzf_create(int device, const ygzf_extractor_cfg *cfg, int max_width, int ma
     } while (0)
     CK(hipSetDevice(device));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int cus = 0;
+        CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        c->cuCount = cus > 0 ? cus : 256;
+    }
     CK(hipEventCreate(&c->tStart));
     CK(hipEventCreate(&c->tStop));
     CK(upload_constants(c->tab.umax));
@@ -789,7 +815,7 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlBase, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes, &c->dResPack};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes, &c->dResPack, &c->dFastCtr};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)

@@ -100,6 +100,8 @@ struct ygzf_ctx {
     Buf dPack;                             // inputs + outputs of a one-frame entry point, one copy each way (PackedTransfer)
     int fastKernel = 0;                    // ygzf_fast_kernel: 0 chosen per geometry, 1 k_fast_quads (register staging), 2 k_fast_tab (cell table + LDS-DMA)
     unsigned *hFastStats = nullptr;        // page-locked mirror, refreshed by an asynchronous copy after every FAST launch
+    Buf dFastCtr;                          // eight draw counters of k_fast_tab_persist (one per XCD), zeroed before every launch
+    int cuCount = 256;
     Buf dResPack;                          // [counts | keypoint rows | descriptor rows] of a small launch, contiguous (ygzf_batch_fetch_packed)
     bool carryLaunched = false;            // k_carry_slot already queued for the extraction being set up (ahead of its upload)
     Buf dUpStage;                          // linear landing area of uploads that are re-pitched on the device (upload_rows)

@@ -83,3 +83,45 @@ def test_pass1_statistics(oracle):
     if ex.fast_plan() == 1:
         assert runs == 1.0
     ex.close()
+
+
+def test_persistent_cell_loop_agrees():
+    """The cell loop has a persistent form (k_fast_tab_persist: as many workgroups as the device holds, every wave draws cells from XCD-local counters)
+    that the library takes for large frames in large launches (1920x1080 and up, hundreds of thousands of cells).  YGZF_FORCE=fast_persist=1 takes it
+    for every launch: the extractor suites, both threshold plans and the extraction fuzzers must hold against the oracle unchanged -- and a batch
+    large enough to take it by itself must equal the same batch under fast_persist=0."""
+    import os
+    import subprocess
+    import sys
+    from orb_ygz_slam_amd.capi import force_env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YGZF_FORCE=force_env(fast_persist=1))
+    out = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.join(root, "tests", "test_gpu_extract.py"),
+                          os.path.join(root, "tests", "test_gpu_fast_plans.py"), os.path.join(root, "tests", "test_gpu_fast_kernels.py"), os.path.join(root, "tests", "test_gpu_fuzz.py"),
+                          "-k", "(extract or plan or fast or pyramid or baseline) and not persistent_cell_loop"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+    code = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, %r)
+from orb_ygz_slam_amd import Extractor
+from orb_ygz_slam_amd.synth import synth_frame
+w, h, n = 1920, 1080, 8
+base = [synth_frame(900 + i, w, h) for i in range(2)]
+imgs = np.stack([base[i %% 2] if i < 4 else np.ascontiguousarray(base[i %% 2][::-1]) for i in range(n)])
+ex = Extractor(4000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=n)
+ex.extract_batch_host(imgs)
+hsh = hashlib.sha256()
+for f in range(n):
+    k, d = ex.batch_fetch(f)
+    hsh.update(k.tobytes()); hsh.update(d.tobytes())
+print("DIGEST", hsh.hexdigest(), int(ex.batch_counts().sum()))
+""" % root
+    digests = []
+    for mode in (0, -1):          # never / the library's own choice (8 frames x 1620 cell groups: the persistent form)
+        env = dict(os.environ, YGZF_FORCE=force_env(fast_persist=mode if mode >= 0 else None))
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DIGEST" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+        digests.append(r.stdout.split("DIGEST")[1].split())
+    assert digests[0] == digests[1] and int(digests[0][1]) > 8 * 3000
