@@ -655,10 +655,7 @@ __device__ __forceinline__ int fast9_arc_score(const uint8_t *c, int tp, int pol
 
 // LDS pitch of a cell's score map = the window pitch (wCell + 2 columns used, the window pitch is >= wCell + 7)
 struct FastGroupBases { int v[kMaxLevels]; };   // first 2x2 cell group of every level inside a frame (LevelGeom::groupBase), by value
-#ifndef YGZF_CORNER_CAP
-#define YGZF_CORNER_CAP 512
-#endif
-constexpr int kCornerCap = YGZF_CORNER_CAP;  // corners listed per cell before the dense fallback takes over
+constexpr int kCornerCap = 512;  // corners listed per cell before the dense fallback takes over
 
 // ------------------------------------------------------------------------------------------------------------------
 // K2q  The same cell loop with FOUR pixels per lane in pass 1 (byte-sliced FAST-9 test).
@@ -2448,11 +2445,8 @@ void launch_fast_cells(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeo
 }
 
 // ---- table-driven form (k_fast_tab) ----
-#ifndef YGZF_FAST_LDS_PAD
-#define YGZF_FAST_LDS_PAD 0
-#endif
 size_t fast_tab_lds_bytes(int winRows, int smapRows, int quadCap) {
-    return (fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap) - 64) / (kFastBlock / 64) * kFastTabWaves + 64 + YGZF_FAST_LDS_PAD;
+    return (fast_quads_lds_bytes(kTabPitch, winRows, smapRows, quadCap) - 64) / (kFastBlock / 64) * kFastTabWaves + 64;
 }
 void launch_fast_tab(hipStream_t st, const FrameSet &fs, const FastCellRec *dCells, int iniTh, int minTh, unsigned short *cellCnt, unsigned *slots,
                      int totalCells, long long totalSlots, int totalGroups, int smapRows, int nFrames, int winRows, int quadCap, bool iniFirst,
