@@ -81,6 +81,7 @@ def algorithmic_bytes(w, h, nlevels, sf, nfeat):
         "k_pyr_resize": (P - Pl) + (P - P0),              # read levels 0..L-2, write levels 1..L-1
         "k_fast_tab": P,                                   # FAST read of every level (k_fast_quads: the register-staging form of the same loop)
         "k_fast_quads": P,
+        "k_fast_tab_persist": P,                           # the persistent form of the same loop (frames of >= 1000 cell groups)
         "k_describe": 2 * P + K * (749 + 512 + 32 + 28),   # blur read+write, orientation disc, samples, descriptor, KeyPoint
         "k_match_last": (K + K) * 32 + K * 8,              # B_match
         "k_octree": 0,                                     # candidate lists only (not part of SURVEY's formula)

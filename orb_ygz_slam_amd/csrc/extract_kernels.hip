@@ -1865,13 +1865,16 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
     const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k, p5 = 0.1555786518463281f * k,
                 p7 = -0.04432655554792128f * k;
     const float ax = fabsf(x), ay = fabsf(y);
-    // the two branches of the source (ax >= ay: ay / (ax + eps); else ax / (ay + eps), 90 - ...) share their operations: select the operands
-    // first and divide ONCE -- the correctly rounded division is a dozen instructions, and left as two branches both were executed
-    const bool wide = ax >= ay;
-    const float c = (wide ? ay : ax) / ((wide ? ax : ay) + (float) 2.2204460492503131e-16);
-    const float c2 = c * c;
-    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    if (!wide) a = 90.f - a;
+    float a, c, c2;
+    if (ax >= ay) {   // (wave-uniform where one wave = one keypoint: only the taken side executes -- a select-then-divide-once form executed MORE, round 6)
+        c = ay / (ax + (float) 2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float) 2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;

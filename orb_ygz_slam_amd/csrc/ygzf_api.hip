@@ -580,7 +580,7 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                 if (rcC) return rcC;
                 HIPCHECK(c, hipMemsetAsync(c->dFastCtr.p, 0, kFastPersistCounterBytes, c->stream));
             }
-            ProfScope ps(c, tab ? KK_FAST : KK_FASTQ);
+            ProfScope ps(c, persist ? KK_FASTP : tab ? KK_FAST : KK_FASTQ);
             if (persist)
                 launch_fast_tab_persist(c->stream, fs, (const FastCellRec *) c->dFastCells.p, c->tab.cfg.ini_th_fast, c->tab.cfg.min_th_fast,
                                         (unsigned short *) c->dCellCnt.p, (unsigned *) c->dSlots.p, G.totalCells, G.totalSlots, G.totalGroups, G.fastSmapRows,

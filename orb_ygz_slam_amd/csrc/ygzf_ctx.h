@@ -22,9 +22,9 @@
 
 namespace ygzf {
 YGZF_HIDDEN int cv_round_host(double v);
-enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_GRID, KK_FASTQ, KK_TRI, KK_COUNT };
+enum KernelKind { KK_PYR = 0, KK_FAST, KK_OCTREE, KK_DESCRIBE, KK_HAMMING, KK_BACKPROJ, KK_MATCH, KK_SIA, KK_FAST10, KK_DSO, KK_STEREO, KK_DIRECT, KK_BOW, KK_FRUSTUM, KK_DISTINCTIVE, KK_BOWNODES, KK_GRID, KK_FASTQ, KK_TRI, KK_FASTP, KK_COUNT };
 static const char *kKernelNames[KK_COUNT] = {"k_pyr_resize", "k_fast_tab", "k_octree", "k_describe", "k_hamming_pairs",
-                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes", "k_features_in_area", "k_fast_quads", "k_tri_nodes"};
+                                             "k_backproject_unit", "k_match_last", "k_sia_run", "k_f10_*", "k_dso_cells", "k_stereo_*", "k_direct_projection", "k_bow_descend", "k_frustum", "k_distinctive", "k_bow_nodes", "k_features_in_area", "k_fast_quads", "k_tri_nodes", "k_fast_tab_persist"};
 
 struct Geometry {
     int w = 0, h = 0;
