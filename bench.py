@@ -536,8 +536,11 @@ def hbm_roofline(workload, kernels, iso, per_kernel, frames_per_launch, total_by
     cand = [k for k in kernels if per_kernel.get(k, 0) > 0 and (only is None or k == only)]
     if not cand:
         return None
-    dom = max(cand, key=lambda k: kernels[k]["total_ms"])
-    div = WORKLOADS[workload][2] - 1 if dom == "k_pyr_resize" else 1      # the L-1 resize launches share the pyramid's bytes
+    # dominant = the kernel that takes the most device time per sub-batch when it runs ALONE (isolated mean x its launches per sub-batch); the
+    # in-pipeline totals rank by how much a kernel is stretched by the other contexts, not by what it costs
+    nl1 = WORKLOADS[workload][2] - 1
+    dom = max(cand, key=lambda k: (iso.get(k) or kernels[k]["avg_us"]) * (nl1 if k == "k_pyr_resize" else 1))
+    div = nl1 if dom == "k_pyr_resize" else 1      # the L-1 resize launches share the pyramid's bytes
     bytes_per_launch = per_kernel[dom] * frames_per_launch / div
     avg_s = kernels[dom]["avg_us"] * 1e-6
     achieved = bytes_per_launch / avg_s / 1e9
