@@ -430,6 +430,14 @@ int ygzf_compute_stereo_matches(ygzf_ctx *ctx, const uint8_t *img_left, const ui
 /* Batch-resident form: the last extracted batch holds (left, right) image pairs, frames 2p / 2p+1; keys, descriptors and pyramids stay
  * on the device.  ygzf_stereo_fetch copies pair p's mvuRight / mvDepth (as many as the left frame has keypoints). */
 int ygzf_stereo_batch(ygzf_ctx *ctx, float mb, float mbf);
+/* ONE (left, right) pair from host memory with its eyes on two contexts of one device, so that the right eye's upload runs beside the left eye's
+ * kernels (a 3840x2160 pair is 16.6 MB on the link: a third of the call when both eyes go up before anything runs).  Results: the packed blocks of
+ * ygzf_batch_fetch_packed for each eye (host_left / host_right, host_bytes each; the same offsets and row length for both), mvuRight / mvDepth of the
+ * left keypoints in u_right / depth (ygzf_max_keypoints floats each).  Same bytes as ygzf_extract_batch_host(left, right) + ygzf_stereo_batch.
+ * Page-locked frames and result buffers give the overlap; pageable ones work and serialise. */
+int ygzf_stereo_pair_host(ygzf_ctx *left_ctx, ygzf_ctx *right_ctx, const uint8_t *left, const uint8_t *right, int w, int h, int row_pitch, float mb, float mbf,
+                          void *host_left, void *host_right, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries, float *u_right,
+                          float *depth);
 int ygzf_stereo_fetch(ygzf_ctx *ctx, int pair, float *u_right, float *depth, int cap);
 /* all pairs at once: rows of `stride` (>= ygzf_max_keypoints) floats; row p's first n_kp[2 p] entries (left keypoints) are valid */
 int ygzf_stereo_fetch_all(ygzf_ctx *ctx, float *u_right, float *depth, int stride);

@@ -225,6 +225,12 @@ struct StereoArgs {
     int keyOffL, keyOffR;
     const int *cnt;                // counts of pair p at cnt[p*cntStride + cntOffL / cntOffR]
     int cntStride, cntOffL, cntOffR;
+    // The right eye may live in ANOTHER context's arrays (ygzf_stereo_pair_host: the two eyes of one pair extracted on two streams): keysR / descR /
+    // cntR non-null = the right keys of pair p at keysR[p*keyStride + keyOffR + i] etc., its pyramid = frame frame0 + p*frameStep + 1 of fsR
+    const ygzf_kp *keysR;
+    const uint8_t *descR;
+    const int *cntR;
+    FrameSet fsR;
     // pyramids: left image of pair p = frame frame0 + p*frameStep of fs, right = the next frame
     FrameSet fs;
     const LevelGeom *geom;

@@ -52,13 +52,13 @@ __global__ __launch_bounds__(kStereoPrepBlock) void k_stereo_prep(StereoArgs A) 
     __shared__ int s_bin[kStereoMaxBins + 1];
     __shared__ int s_tmp[20];
     const int pair = blockIdx.x, tid = threadIdx.x;
-    const int nr = A.cnt[(long long) pair * A.cntStride + A.cntOffR];
+    const int nr = (A.cntR ? A.cntR : A.cnt)[(long long) pair * A.cntStride + A.cntOffR];
     const int nb = A.nBins;
     int *binStart = A.binStart + (long long) pair * (kStereoMaxBins + 1);
     for (int b = tid; b <= nb; b += kStereoPrepBlock) s_bin[b] = 0;
     __syncthreads();
     auto make = [&](int i, StereoRec *rec) {
-        const ygzf_kp k = A.keys[(long long) pair * A.keyStride + A.keyOffR + i];
+        const ygzf_kp k = (A.keysR ? A.keysR : A.keys)[(long long) pair * A.keyStride + A.keyOffR + i];
         const float r = 2.0f * A.scale[k.octave];
         int maxr = (int) ceilf(k.y + r), minr = (int) floorf(k.y - r);
         minr = max(minr, 0);
@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned s_wave_min(unsigned v) { return wave_min_u32
 __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nl = A.cnt[(long long) pair * A.cntStride + A.cntOffL], nr = A.cnt[(long long) pair * A.cntStride + A.cntOffR];
+    const int nl = A.cnt[(long long) pair * A.cntStride + A.cntOffL], nr = (A.cntR ? A.cntR : A.cnt)[(long long) pair * A.cntStride + A.cntOffR];
     if (iL >= nl) return;
     float *outU = A.uRight + (long long) pair * A.outStride, *outD = A.depth + (long long) pair * A.outStride;
     int *outS = A.sad + (long long) pair * A.outStride;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
         const unsigned long long *dL = (const unsigned long long *) (A.desc + ((long long) pair * A.keyStride + A.keyOffL + iL) * 32);
         const unsigned long long q0 = dL[0], q1 = dL[1], q2 = dL[2], q3 = dL[3];
         const StereoRec *rec = A.rec + (long long) pair * A.recStride;
-        const uint8_t *descR = A.desc + ((long long) pair * A.keyStride + A.keyOffR) * 32;
+        const uint8_t *descR = (A.descR ? A.descR : A.desc) + ((long long) pair * A.keyStride + A.keyOffR) * 32;
         const int *binStart = A.binStart + (long long) pair * (kStereoMaxBins + 1);
         const int b0 = max(row - A.bandMax, 0) >> A.binShift, b1 = min(row >> A.binShift, A.nBins - 1);
         const int lo = binStart[b0], hi = binStart[b1 + 1];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
     const int bestDist = (int) (best >> 16);
     if (alive && bestDist < thOrbDist) {
         const int bestIdxR = (int) (best & 0xFFFFu);
-        const float uR0 = A.keys[(long long) pair * A.keyStride + A.keyOffR + bestIdxR].x;
+        const float uR0 = (A.keysR ? A.keysR : A.keys)[(long long) pair * A.keyStride + A.keyOffR + bestIdxR].x;
         const float scaleFactor = A.invScale[levelL];
         const float scaleduL = roundf(kL.x * scaleFactor);
         const float scaledvL = roundf(kL.y * scaleFactor);
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(StereoArgs A) {
         const LevelGeom g = A.geom[levelL];
         int pitchL, pitchR;
         const uint8_t *imL = level_ptr(A.fs, g, levelL, A.frame0 + pair * A.frameStep, &pitchL);
-        const uint8_t *imR = level_ptr(A.fs, g, levelL, A.frame0 + pair * A.frameStep + 1, &pitchR);
+        const uint8_t *imR = level_ptr(A.keysR ? A.fsR : A.fs, g, levelL, A.frame0 + pair * A.frameStep + 1, &pitchR);
         const int cxL = (int) scaleduL, cyL = (int) scaledvL, cxR0 = (int) scaleduR0;
         const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
         // rowRange / colRange outside the level throw in OpenCV (left keys sit >= 16 px inside their level); :618-620

@@ -1222,8 +1222,8 @@ int ygzf_batch_fetch_all(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int *n_kp, in
     return YGZF_OK;
 }
 
-int ygzf_batch_fetch_packed(ygzf_ctx *c, void *host, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries, size_t *bytes_out) {
-    if (!c || !host || !off_kps || !off_desc || !row_entries) return fail(c, YGZF_ERR_INVALID, "null argument");
+// queues the gather kernel and the ONE copy of ygzf_batch_fetch_packed on the context's stream; the caller synchronises
+int queue_packed_fetch(ygzf_ctx *c, void *host, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries, size_t *bytes_out) {
     if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
     const size_t B = (size_t) c->lastFrames, ks = (size_t) c->geo.kpStride;
     const size_t oK = (B * sizeof(int) + 255) & ~(size_t) 255, oD = oK + ((B * ks * sizeof(ygzf_kp) + 255) & ~(size_t) 255), total = oD + B * ks * 32;
@@ -1235,11 +1235,61 @@ int ygzf_batch_fetch_packed(ygzf_ctx *c, void *host, size_t host_bytes, size_t *
                         c->dResPack.p, oK, oD);
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, hipMemcpyAsync(host, c->dResPack.p, total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
     *off_kps = oK;
     *off_desc = oD;
     *row_entries = (int) ks;
     if (bytes_out) *bytes_out = total;
+    return YGZF_OK;
+}
+
+int ygzf_batch_fetch_packed(ygzf_ctx *c, void *host, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries, size_t *bytes_out) {
+    if (!c || !host || !off_kps || !off_desc || !row_entries) return fail(c, YGZF_ERR_INVALID, "null argument");
+    int rc = queue_packed_fetch(c, host, host_bytes, off_kps, off_desc, row_entries, bytes_out);
+    if (rc) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return YGZF_OK;
+}
+
+// One stereo pair from host memory with its two eyes on TWO contexts / streams of the same device (ygzf_mgpu_extract_stereo for a slot that is handed
+// exactly one pair: BASELINE.json's 3840x2160 configuration, a pair per GPU).  In one context the pair is one upload of both frames followed by one
+// kernel chain: 16.6 MB on the link (300 us) during which no kernel of the pair can run.  Here the right eye's upload waits for the LEFT eye's upload
+// only, so it crosses the link while the left eye's pyramid / FAST / octree / descriptors run; the right eye's chain then overlaps the left one's
+// tail; ComputeStereoMatches runs on the left context's stream once both are done, reading the right eye's keypoints, descriptors and pyramid where
+// the right context left them.  Same kernels on the same inputs: the bytes of ygzf_extract_batch_host(both frames) + ygzf_stereo_batch.
+int ygzf_stereo_pair_host(ygzf_ctx *l, ygzf_ctx *r, const uint8_t *left, const uint8_t *right, int w, int h, int row_pitch, float mb, float mbf,
+                          void *host_left, void *host_right, size_t host_bytes, size_t *off_kps, size_t *off_desc, int *row_entries,
+                          float *u_right, float *depth) {
+    if (!l || !r || l == r || !left || !right || !host_left || !host_right || !off_kps || !off_desc || !row_entries || !u_right || !depth)
+        return fail(l, YGZF_ERR_INVALID, "null argument");
+    if (l->device != r->device) return fail(l, YGZF_ERR_INVALID, "the two contexts of a pair must be on one device");
+    if (row_pitch < w) return fail(l, YGZF_ERR_INVALID, "row_pitch %d < width %d", row_pitch, w);
+    HIPCHECK(l, hipSetDevice(l->device));
+    int rc;
+    if ((rc = apply_geometry(l, w, h, 1))) return rc;
+    if ((rc = apply_geometry(r, w, h, 1))) { l->err = r->err; return rc; }
+    if (!l->evShare) HIPCHECK(l, hipEventCreateWithFlags(&l->evShare, hipEventDisableTiming));
+    if (!r->evShare) HIPCHECK(l, hipEventCreateWithFlags(&r->evShare, hipEventDisableTiming));
+    carry_early(l);
+    carry_early(r);
+    FrameSet fl, fr;
+    if ((rc = upload_frames(l, left, 1, w, h, row_pitch, 0, &fl))) return rc;
+    HIPCHECK(l, hipEventRecord(l->evShare, l->stream));                 // the left eye is on the device ...
+    HIPCHECK(l, hipStreamWaitEvent(r->stream, l->evShare, 0));          // ... and only then does the right eye take the link
+    if ((rc = upload_frames(r, right, 1, w, h, row_pitch, 0, &fr))) { l->err = r->err; return rc; }
+    if ((rc = run_extract(l, fl, 1))) return rc;
+    if ((rc = run_extract(r, fr, 1))) { l->err = r->err; return rc; }
+    HIPCHECK(l, hipEventRecord(r->evShare, r->stream));
+    size_t ok2 = 0, od2 = 0;
+    int re2 = 0;
+    if ((rc = queue_packed_fetch(r, host_right, host_bytes, &ok2, &od2, &re2, nullptr))) { l->err = r->err; return rc; }
+    if ((rc = queue_packed_fetch(l, host_left, host_bytes, off_kps, off_desc, row_entries, nullptr))) return rc;
+    HIPCHECK(l, hipStreamWaitEvent(l->stream, r->evShare, 0));
+    if ((rc = stereo_across(l, r, mb, mbf))) return rc;
+    const size_t ks = (size_t) l->geo.kpStride;
+    HIPCHECK(l, hipMemcpyAsync(u_right, l->dSt[1].p, 4 * ks, hipMemcpyDeviceToHost, l->stream));
+    HIPCHECK(l, hipMemcpyAsync(depth, l->dSt[2].p, 4 * ks, hipMemcpyDeviceToHost, l->stream));
+    HIPCHECK(l, hipStreamSynchronize(r->stream));
+    HIPCHECK(l, hipStreamSynchronize(l->stream));
     return YGZF_OK;
 }
 

@@ -67,6 +67,60 @@ int ygzf_stereo_batch(ygzf_ctx *c, float mb, float mbf) {
     return YGZF_OK;
 }
 
+}  // extern "C"
+
+// ComputeStereoMatches of ONE pair whose left eye is frame 0 of context l's last extraction and whose right eye is frame 0 of context r's
+// (ygzf_stereo_pair_host); queued on l's stream, which the caller has made wait for r's extraction.  Results where ygzf_stereo_batch leaves pair 0's.
+int stereo_across(ygzf_ctx *l, ygzf_ctx *r, float mb, float mbf) {
+    if (l->lastFrames != 1 || r->lastFrames != 1) return fail(l, YGZF_ERR_STATE, "stereo across contexts needs one extracted frame in each");
+    if (!(mb > 0)) return fail(l, YGZF_ERR_INVALID, "baseline mb must be positive");
+    const Geometry &G = l->geo;
+    if (G.kpStride != r->geo.kpStride || G.w != r->geo.w || G.h != r->geo.h) return fail(l, YGZF_ERR_STATE, "the two eyes differ in geometry");
+    if (G.kpStride > 65535) return fail(l, YGZF_ERR_UNSUPPORTED, "more than 65535 keypoints per frame");
+    int rc;
+    const size_t per = (size_t) G.kpStride;
+    if ((rc = ensure(l, l->dSt[0], sizeof(StereoRec) * per + 64)) || (rc = ensure(l, l->dSt[1], 4 * per + 64)) || (rc = ensure(l, l->dSt[2], 4 * per + 64)) ||
+        (rc = ensure(l, l->dSt[3], 4 * per + 64)) || (rc = ensure(l, l->dStBins, sizeof(int) * kStereoBinInts)))
+        return rc;
+    StereoArgs A;
+    memset(&A, 0, sizeof A);
+    A.keys = (const ygzf_kp *) l->dOutKp.p;       // slot 0 = carry; frame 0 lives in slot 1 -- of either context
+    A.desc = (const uint8_t *) l->dOutDesc.p;
+    A.keysR = (const ygzf_kp *) r->dOutKp.p;
+    A.descR = (const uint8_t *) r->dOutDesc.p;
+    A.cntR = (const int *) r->dOutCnt.p;
+    A.keyStride = (long long) G.kpStride;
+    A.keyOffL = G.kpStride;
+    A.keyOffR = G.kpStride;
+    A.cnt = (const int *) l->dOutCnt.p;
+    A.cntStride = 1;
+    A.cntOffL = 1;
+    A.cntOffR = 1;
+    A.fs = l->lastFs;
+    A.fsR = r->lastFs;                            // the kernels address the right image as frame frame0 + 1: one frame back, so that this is r's frame 0
+    A.fsR.img0 -= A.fsR.img0_stride;
+    A.fsR.pyr -= A.fsR.pyr_stride;
+    A.frame0 = 0;
+    A.frameStep = 0;
+    fill_stereo_common(l, A, mb, mbf, G.h);
+    A.rec = (StereoRec *) l->dSt[0].p;
+    A.recStride = (long long) per;
+    A.binStart = (int *) l->dStBins.p;
+    A.uRight = (float *) l->dSt[1].p;
+    A.depth = (float *) l->dSt[2].p;
+    A.sad = (int *) l->dSt[3].p;
+    A.outStride = (long long) per;
+    {
+        ProfScope ps(l, KK_STEREO);
+        launch_stereo(l->stream, A, 1, G.kpStride, G.kpStride);
+    }
+    HIPCHECK(l, hipGetLastError());
+    l->lastStereoPairs = 1;
+    return YGZF_OK;
+}
+
+extern "C" {
+
 int ygzf_stereo_fetch(ygzf_ctx *c, int pair, float *u_right, float *depth, int cap) {
     if (!c || !u_right || !depth) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (pair < 0 || pair >= c->lastStereoPairs) return fail(c, YGZF_ERR_STATE, "pair %d: no stereo result", pair);

@@ -310,6 +310,7 @@ static void drain_profile(ygzf_ctx *c) {
 YGZF_HIDDEN int build_geometry(ygzf_ctx *c, int w, int h, ygzf::Geometry &G);
 YGZF_HIDDEN int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames);
 YGZF_HIDDEN int pyramid_chain(ygzf_ctx *c, const ygzf::FrameSet &fs, int nFrames);
+YGZF_HIDDEN int stereo_across(ygzf_ctx *l, ygzf_ctx *r, float mb, float mbf);   // ygzf_api_stereo.hip
 YGZF_HIDDEN int mark_pyramid_done(ygzf_ctx *c);
 YGZF_HIDDEN int run_extract(ygzf_ctx *c, const ygzf::FrameSet &fs, int nFrames, bool pyramidReady = false, bool pyramidCarried = false);
 YGZF_HIDDEN int upload_rows(ygzf_ctx *c, void *dst, size_t dstPitch, const uint8_t *src, size_t srcPitch, int w, size_t rows);

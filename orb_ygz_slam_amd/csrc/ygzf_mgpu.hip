@@ -392,6 +392,29 @@ int run_job(ygzf_mgpu *m, const Job &J) {
                 }
             });
         };
+        if (J.mode == kStereo && n == 2 && pinned) {
+            // exactly one (left, right) pair for this slot (BASELINE.json's 3840x2160 configuration, a pair per GPU): the eyes go to the slot's two
+            // contexts, the right eye's upload beside the left eye's kernels (ygzf_stereo_pair_host)
+            size_t ok = 0, od = 0;
+            int row = 0;
+            float *u = (float *) d.hAux[0], *dp = u + m->stride;
+            int rc1 = ygzf_stereo_pair_host(d.ctx[0], d.ctx[1], J.frames + (size_t) fr[0] * J.frame_stride, J.frames + (size_t) fr[1] * J.frame_stride, w, h, J.row_pitch,
+                                            J.mb, J.mbf, d.hRes[0], d.hRes[1], d.hResBytes, &ok, &od, &row, u, dp);
+            if (rc1 != YGZF_OK) { d.err = ygzf_last_error(d.ctx[0]); d.rc = rc1; return; }
+            for (int e = 0; e < 2; e++) {
+                const int f = fr[e], c = *(const int *) d.hRes[e];
+                J.n_kp[f] = c;
+                memcpy(J.kps + (size_t) f * J.stride, d.hRes[e] + ok, sizeof(ygzf_kp) * (size_t) c);
+                memcpy(J.desc + (size_t) f * J.stride * 32, d.hRes[e] + od, 32 * (size_t) c);
+            }
+            const int cl = *(const int *) d.hRes[0], pr = fr[0] / 2;
+            float *ur = J.u_right + (size_t) pr * J.stride, *dr = J.depth + (size_t) pr * J.stride;
+            memcpy(ur, u, sizeof(float) * (size_t) cl);
+            memcpy(dr, dp, sizeof(float) * (size_t) cl);
+            for (int q = cl; q < J.stride; q++) { ur[q] = -1.f; dr[q] = -1.f; }
+            d.rc = YGZF_OK;
+            return;
+        }
         prepare(0);
         int rc = launch(0);
         if (alternate) {

@@ -275,3 +275,42 @@ def test_small_calls_take_the_packed_result_path(oracle):
         k1, d1, c1, _, _ = mg.extract_match(frames[:1])                   # one frame, extraction only
         assert c1[0] == c[0] and (k1[0, :c1[0]] == k[0, :c[0]]).all() and (d1[0, :c1[0]] == d[0, :c[0]]).all()
     mg.close()
+
+
+def test_one_pair_per_slot_takes_two_streams(oracle):
+    """A slot that is handed exactly ONE (left, right) pair in page-locked memory puts the eyes on its two contexts -- the right eye's upload beside the
+    left eye's kernels, ComputeStereoMatches across the two contexts (ygzf_stereo_pair_host) -- and must return the bytes of the one-context path
+    (the same pair from pageable memory) and of the oracle: keypoints, descriptors of both eyes, mvuRight / mvDepth."""
+    import ctypes as C
+    from orb_ygz_slam_amd import MultiGpu
+    mb, mbf = 0.11, 47.9
+    mg = MultiGpu([0], max_width=752, max_height=480, max_frames_per_device=2)
+    L = mg.L
+    L.ygzf_alloc_host.restype = C.c_void_p
+    L.ygzf_alloc_host.argtypes = [C.c_int, C.c_size_t]
+    L.ygzf_free_host.argtypes = [C.c_void_p]
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    for (w, h, dsp) in ((752, 480, 9), (640, 400, 14), (752, 480, 3)):
+        left = _clip(1, w, h)[0]
+        pair = np.stack([left, np.zeros_like(left)])
+        pair[1, :, :w - dsp] = left[:, dsp:]
+        ref = mg.extract_stereo(np.ascontiguousarray(pair), mb, mbf)                      # pageable: one context, both eyes in one launch
+        ptr = C.c_void_p(L.ygzf_alloc_host(0, pair.nbytes))
+        assert ptr.value
+        pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(pair.nbytes,)).reshape(pair.shape)
+        pinned[:] = pair
+        for _ in range(2):                                                                # twice: the contexts' carry / reuse paths
+            got = mg.extract_stereo(pinned, mb, mbf)
+            for a, b, name in zip(ref, got, ("kps", "desc", "n_kp", "u_right", "depth")):
+                assert np.array_equal(a.view(np.uint8) if a.dtype == np.float32 else a, b.view(np.uint8) if b.dtype == np.float32 else b), (w, h, name)
+        del pinned
+        L.ygzf_free_host(ptr)
+        k, d, c, ur, dp = ref
+        kl, dl = oex.extract(pair[0])
+        kr, dr = oex.extract(pair[1])
+        our, odp = oex.compute_stereo_matches(pair[0], pair[1], kl, dl, kr, dr, mb, mbf)
+        n = len(kl)
+        assert c[0] == n and c[1] == len(kr) and (k[1, :c[1]] == kr).all() and (d[1, :c[1]] == dr).all()
+        assert np.array_equal(ur[0, :n].view(np.uint32), our.view(np.uint32)) and np.array_equal(dp[0, :n].view(np.uint32), odp.view(np.uint32))
+        assert (our >= 0).sum() > 100
+    mg.close()
