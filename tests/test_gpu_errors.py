@@ -108,3 +108,51 @@ def test_extract_resident_needs_the_pyramid_it_was_promised(oracle):
         except YgzfError:
             continue
         raise AssertionError("extract_resident succeeded after an intervening image operation")
+
+
+def test_round6_entry_points_report_misuse():
+    """ygzf_batch_fetch_packed, ygzf_stereo_pair_host, ygzf_host_stream_probe, ygzf_phase_clocks: bad arguments come back as a negative status with a
+    message, the contexts stay usable."""
+    from orb_ygz_slam_amd import Extractor
+    from orb_ygz_slam_amd.capi import YgzfError, load_library, host_stream_probe
+    L = load_library()
+    w, h = 320, 240
+    a = Extractor(300, 1.2, 4, 20, 7, max_width=w, max_height=h, max_batch=2)
+    b = Extractor(300, 1.2, 4, 20, 7, max_width=w, max_height=h, max_batch=2)
+    img = synth_frame(5, w, h)
+    host = np.zeros(1 << 20, np.uint8)
+    ok, od, by = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    row = C.c_int(0)
+    L.ygzf_batch_fetch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    # nothing extracted yet; then a buffer that is too small
+    assert L.ygzf_batch_fetch_packed(a.h, host.ctypes.data_as(C.c_void_p), host.nbytes, C.byref(ok), C.byref(od), C.byref(row), C.byref(by)) < 0
+    a.extract_batch_host(img[None])
+    assert L.ygzf_batch_fetch_packed(a.h, host.ctypes.data_as(C.c_void_p), 1000, C.byref(ok), C.byref(od), C.byref(row), C.byref(by)) < 0
+    assert b"packed results need" in L.ygzf_last_error(a.h)
+    assert L.ygzf_batch_fetch_packed(a.h, host.ctypes.data_as(C.c_void_p), host.nbytes, C.byref(ok), C.byref(od), C.byref(row), C.byref(by)) == 0 and by.value > 0
+    # the pair entry point: the same context twice, a null eye, a pitch below the width
+    L.ygzf_stereo_pair_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    hl, hr = np.zeros(1 << 20, np.uint8), np.zeros(1 << 20, np.uint8)
+    ur, dp = np.zeros(4096, np.float32), np.zeros(4096, np.float32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    args = lambda l, r, le, ri, pitch: (l, r, le, ri, w, h, pitch, 0.11, 47.9, p(hl), p(hr), hl.nbytes, C.byref(ok), C.byref(od), C.byref(row), p(ur), p(dp))
+    assert L.ygzf_stereo_pair_host(*args(a.h, a.h, p(img), p(img), w)) < 0
+    assert L.ygzf_stereo_pair_host(*args(a.h, b.h, p(img), None, w)) < 0
+    assert L.ygzf_stereo_pair_host(*args(a.h, b.h, p(img), p(img), w - 8)) < 0
+    right = np.zeros_like(img)
+    right[:, :w - 9] = img[:, 9:]                                                      # the left image seen 9 px to the side
+    assert L.ygzf_stereo_pair_host(*args(a.h, b.h, p(img), p(right), w)) == 0         # and the well-formed call works
+    n = int(hl[:4].view(np.int32)[0])
+    assert n > 50 and (ur[:n] >= 0).sum() > n // 4
+    k0, d0 = a.batch_fetch(0)
+    assert len(k0) == n
+    # the probe and the phase clocks
+    with pytest.raises(YgzfError):
+        host_stream_probe(0, 0, 1 << 26, 0.1)
+    with pytest.raises(YgzfError):
+        host_stream_probe(0, 2, 1000, 0.1)
+    assert host_stream_probe(0, 2, 8 << 20, 0.05) > 0.1
+    with pytest.raises(YgzfError):
+        a.phase_clocks(0)                                                              # the product library carries no stamps
+    a.close(); b.close()
