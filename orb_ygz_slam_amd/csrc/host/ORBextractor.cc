@@ -12,19 +12,46 @@
 
 #include "../../../include/ygzf.h"
 #include "ygzf_pool.h"
+#if defined(YGZF_WITH_REFERENCE_HEADERS) && !defined(YGZ_MINI_CV)
+#define YGZF_BLUR_PROBE_WITH_CV 1   // a real OpenCV is in scope: the probe may call cv::GaussianBlur
+#endif
+#include "cv_blur_probe.h"
 
 namespace ygz {
 
 int ORBextractor::sDevice = 0;
-int ORBextractor::sCvMode = 0;
 bool ORBextractor::sExtractAhead = true;
+
+// Which generation of cv::GaussianBlur's 8-bit arithmetic the descriptors follow (ygzf_cv_mode).  Built against a real OpenCV the default is
+// "detect": the first extractor of the process blurs a 16 x 12 probe image with the OpenCV it is linked against and takes the generation whose
+// integers come back (cv_blur_probe.h) -- a user whose OpenCV is >= 3.4.11 gets the Q8.8 kernel's descriptors without knowing that there was
+// anything to set; an OpenCV that matches none of the three (an IPP / OpenCL dispatch of GaussianBlur) is reported once and generation 0 is used.
+// Over the stand-in headers (this repository's tests) there is nothing to probe: generation 0, the versions the reference names.
+#if defined(YGZF_WITH_REFERENCE_HEADERS) && !defined(YGZ_MINI_CV)
+int ORBextractor::sCvMode = -1;
+static int detect_cv_blur_generation() {
+    static int cached = -2;
+    if (cached != -2) return cached;
+    cached = ygzf_host::blur_probe_run_opencv();
+    if (cached < 0) {
+        ygzf_host::report_failure("ygz::ORBextractor", "this OpenCV's 8-bit GaussianBlur matches none of the three known generations (IPP / OpenCL dispatch?): "
+                                                      "descriptors follow OpenCV 2.4 / 3.2 on x86 and may differ from the CPU path's in their last bit; set ORBextractor::sCvMode to choose");
+        cached = 0;
+    }
+    return cached;
+}
+static int resolve_cv_mode(int m) { return m < 0 ? detect_cv_blur_generation() : m; }
+#else
+int ORBextractor::sCvMode = 0;
+static int resolve_cv_mode(int m) { return m < 0 ? 0 : m; }
+#endif
 
 // src/ORBextractor.cc:412-470: the scale / sigma / per-level quota tables exist as soon as the object does -- Frame's constructors read
 // them before the first image is processed (src/Frame.cc:119-125 vs :148) -- so they are computed here on the host (ygzf_scale_tables_host:
 // the same arithmetic the device context uses), no device needed.
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
     : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST),
-      mDevice(sDevice), mCvMode(sCvMode), mExtractAhead(sExtractAhead) {
+      mDevice(sDevice), mCvMode(resolve_cv_mode(sCvMode)), mExtractAhead(sExtractAhead) {
     const int L = std::max(nlevels, 0);
     mvScaleFactor.resize(L); mvInvScaleFactor.resize(L); mvLevelSigma2.resize(L); mvInvLevelSigma2.resize(L);
     mnFeaturesPerLevel.resize(L);

@@ -71,7 +71,9 @@ public:
     // HIP device on which extractors constructed from now on create their context (default 0).
     static int sDevice;
     // ygzf_cv_mode of extractors constructed from now on: which OpenCV generation's 8-bit GaussianBlur the descriptors follow
-    // (include/ygzf.h; default 0 = OpenCV 2.4 / 3.2 on x86, the versions the reference names).
+    // (include/ygzf.h: 0 = OpenCV 2.4 / 3.2 on x86, the versions the reference names; 1 = the same without SSE2; 2 = >= 3.4.11 / 4.x).
+    // -1 = detect: built against a real OpenCV (the default there) the first extractor blurs a probe image with the linked OpenCV and takes the
+    // generation that comes back (host/cv_blur_probe.h); over the stand-in headers -1 means 0.
     static int sCvMode;
     // Extract-ahead (include/ygzf.h, ygzf_set_extract_ahead; default on): ComputePyramid queues the ORBSLAM_KEYPOINT extraction of the same image
     // behind the pyramid, so that it runs while the levels return and the Frame constructor clones them; operator()(Frame *, ...) on that image
