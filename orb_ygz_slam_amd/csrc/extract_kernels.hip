@@ -251,131 +251,174 @@ __global__ __launch_bounds__(256) void k_pyr_resize(FrameSet fs, const LevelGeom
     dst[(long long) y * g.pitch + x] = (uint8_t) ((((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2);
 }
 
-// Tiled variant (the one normally launched): a workgroup produces a 256 x 32 output tile.  The <= 41 x 312 byte source
-// region is staged in LDS with coalesced aligned dword loads; every thread owns 4 adjacent columns (their xofs / alpha
-// stay in registers) over 8 rows, so the per-pixel memory instruction count drops from 8 (gathers + table loads) to ~0.2.
-#ifndef YGZF_PYR_WAVES
-#define YGZF_PYR_WAVES 4
-#endif
-// Waves per workgroup (a wave = 8 rows of the tile), same-box A/B on the default bench: 4 -> 29.5 us per launch, 235.1 k frames/s;
-// 2 -> 33.7 us, 227.1 k; 1 -> 44.6 us, 209.3 k (the halo rows of the source tile are re-staged per workgroup, so shorter tiles pay more).
-constexpr int kPyrWaves = YGZF_PYR_WAVES, kPyrThreads = 64 * kPyrWaves;
-constexpr int kPyrTW = 256, kPyrTH = 8 * kPyrWaves, kPyrSrcRows = 44, kPyrSrcPitch = 328;
+// Tiled variant (the one normally launched).  A workgroup produces one tile of 8192 output pixels (host-built list, PyrTileRec): the source
+// region goes to LDS in 16-byte chunks, every lane owns 4 adjacent output columns -- selectors and alpha pairs from its PyrColRec stay in
+// registers -- and walks down 8 rows.  Tiles are 256 columns x 32 rows; what is left of a level's width after the 256-column tiles is cut
+// into 128- / 64- / 32-column tiles whose waves fold 2 / 4 / 8 rows into one pass (lane = row-in-pass x column group), so that a 522-column
+// level does not pay a third 256-column tile for its last 10 columns (752x480 / 1.2: 75 % of the lanes of plain 256-column tiles carry a pixel,
+// 95 % of these).  Everything a row or a column needs is a table record (PyrRowRec: scalar loads at fold 1): no clamp, table search or
+// coefficient unpacking per wave.  Round 6 measured the previous form at 641 vector instructions per wave of which 384 were the row loop.
+constexpr int kPyrWaves = 4, kPyrThreads = 64 * kPyrWaves, kPyrPasses = 8;
+static_assert(kPyrPasses * kPyrWaves == kPyrTileRows, "tile rows");
+constexpr int kPyrLdsBytes = 16384;
+static_assert(pyr_fold_rows(0) * pyr_fold_pitch(0) + 16 <= kPyrLdsBytes && pyr_fold_rows(1) * pyr_fold_pitch(1) + 16 <= kPyrLdsBytes &&
+              pyr_fold_rows(2) * pyr_fold_pitch(2) + 16 <= kPyrLdsBytes && pyr_fold_rows(3) * pyr_fold_pitch(3) + 16 <= kPyrLdsBytes, "staging area");
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(kPyrThreads) void k_pyr_resize_tiled(FrameSet fs, const LevelGeom *__restrict__ geom, int level,
-                                                          const int *__restrict__ xofs, const short *__restrict__ xalpha,
-                                                          const int *__restrict__ yofs, const short *__restrict__ ybeta) {
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kPyrSrcRows * kPyrSrcPitch];
-    const LevelGeom g = geom[level];
+// the last chunk of the last row of a caller-owned level-0 buffer: never read past its end
+__device__ __noinline__ u32x4 pyr_tail_chunk(const uint8_t *src, unsigned o, unsigned total) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    for (unsigned b = 0; b < 16; b++)
+        if (o + b < total) v[b >> 2] |= (unsigned) src[o + b] << (8 * (b & 3));
+    return v;
+}
+
+template <int FL>
+__device__ __forceinline__ void pyr_tile(uint8_t *tile, uint8_t *__restrict__ dstf, const int gw, const int gh, const int gpitch, const uint8_t *__restrict__ src,
+                                         const int sp, const int sh, const int x0, const int y0, const int sxa, const int nc,
+                                         const PyrColRec *__restrict__ cols, const PyrRowRec *__restrict__ rows) {
+    constexpr int kLX = 64 >> FL, kPitch = pyr_fold_pitch(FL), kStageLanes = 32 >> FL, kStageRows = kPyrThreads / kStageLanes;
+    constexpr int kIters = (pyr_fold_rows(FL) + kStageRows - 1) / kStageRows;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kPyrTW, y0 = blockIdx.y * kPyrTH, f = blockIdx.z;
-    int sp;
-    const uint8_t *src = level_ptr(fs, geom[level - 1], level - 1, f, &sp);
-    const int sw = geom[level - 1].w, sh = geom[level - 1].h;
-    const int xl = min(x0 + kPyrTW, g.w) - 1, yl = min(y0 + kPyrTH, g.h) - 1;
-    const int sxa = xofs[g.xtab + x0] & ~3, sxb = min(xofs[g.xtab + xl] + 1, sw - 1);
-    const int sya = min(max(yofs[g.ytab + y0], 0), sh - 1), syb = min(max(yofs[g.ytab + yl] + 1, 0), sh - 1);
-    const int nd = (sxb - sxa) / 4 + 1, nr = syb - sya + 1;          // dwords per row (<= 82), rows (<= 42)
-    {
-        const unsigned total = (unsigned) sh * (unsigned) sp;          // bytes of the source level that may be touched
-        int r = tid / nd, c = tid - r * nd;
-        const int sr = kPyrThreads / nd, sc = kPyrThreads - sr * nd;
-        constexpr int kU = 4;   // loads of a chunk are all in flight before the first LDS store; threads past the end repeat the last dword
-        for (int i0 = 0; i0 < nd * nr; i0 += kPyrThreads * kU) {
-            unsigned v[kU];
-            int dst[kU];
+    const int yl = min(y0 + (kPyrTileRows << FL), gh) - 1;
+    const int sya = (int) (rows[y0].r01 & 0xffffu), syb = (int) (rows[yl].r01 >> 16);
+    const int nr = syb - sya + 1;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int yw = y0 + ((wv * kPyrPasses) << FL);   // first row of this wave
+    const int cg = lane & (kLX - 1), rj = lane >> (6 - FL);
+    const int xb = x0 + 4 * cg;
+    const bool colIn = xb < gw;
+    // requested before the staging, needed after it: the lane's column record, and at fold 1 the records of the wave's 8 rows -- wave-uniform and
+    // adjacent (the host pads a level's table, so no clamp), four wide scalar loads (in assembly: the compiler sinks plain loads into the row loop,
+    // where every row would wait for its own)
+    const PyrColRec *cr = cols + (min(xb, gw - 1) >> 2);
+    const int sx0 = cr->sx0;
+    const u32x4 s4 = *(const u32x4 *) cr->sel, a4 = *(const u32x4 *) cr->ap;
+    u32x8 R01, R23, R45, R67;
+    if constexpr (FL == 0) {
+        const PyrRowRec *rp = rows + min(yw, gh - 1);
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\ts_load_dwordx8 %3, %4, 0x60"
+                     : "=&s"(R01), "=&s"(R23), "=&s"(R45), "=&s"(R67) : "s"(rp) : "memory");
+    }
+    {   // a source row is nc <= kStageLanes chunks: kStageLanes lanes per row, kStageRows rows per round, every load in flight before the first LDS store
+        const int c = tid & (kStageLanes - 1), r = tid >> (5 - FL);
+        const unsigned total = (unsigned) sh * (unsigned) sp;
+        const bool colOk = c < nc;
+        const unsigned o = (unsigned) (sya + r) * (unsigned) sp + (unsigned) (sxa + 16 * c);
+        u32x4 v[kIters];
 #pragma unroll
-            for (int u = 0; u < kU; u++) {
-                const bool in = r < nr;
-                const int rr = in ? r : nr - 1, cc = in ? c : nd - 1;
-                const unsigned off = (unsigned) (sya + rr) * (unsigned) sp + (unsigned) (sxa + 4 * cc);
-                if (off + 4 <= total) v[u] = *(const unsigned *) (src + off);
-                else {   // last dword of the last row of a caller-owned level-0 buffer: never read past its end
-                    v[u] = 0;
-                    for (int b = 0; b < 4; b++) if (off + b < total) v[u] |= (unsigned) src[off + b] << (8 * b);
-                }
-                dst[u] = rr * (kPyrSrcPitch / 4) + cc;
-                r += sr; c += sc;
-                if (c >= nd) { c -= nd; r++; }
+        for (int it = 0; it < kIters; it++) {
+            const int rr = r + it * kStageRows;
+            if (colOk && rr < nr) {
+                const unsigned oo = o + (unsigned) (it * kStageRows) * (unsigned) sp;
+                if (oo + 16 <= total) v[it] = *(const u32x4_a4 *) (src + oo);
+                else v[it] = pyr_tail_chunk(src, oo, total);
             }
+        }
 #pragma unroll
-            for (int u = 0; u < kU; u++) ((unsigned *) tile)[dst[u]] = v[u];
+        for (int it = 0; it < kIters; it++) {
+            const int rr = r + it * kStageRows;
+            if (colOk && rr < nr) *(u32x4 *) (tile + rr * kPitch + 16 * c) = v[it];
         }
     }
     __syncthreads();
-    const int lane = tid & 63, rg = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int xb = x0 + 4 * lane;
-    if (xb >= g.w) return;
-    // The four columns of a lane read source bytes lx[0] .. lx[0] + 5 (scale < 1.28, see tiledOk): per visited source row three aligned
-    // dwords are shifted to start at lx[0] (v_alignbyte), one v_perm_b32 per column picks its (left, right) pixel pair into 16-bit halves
-    // and one v_dot2_u32_u16 applies (alpha0, alpha1).  The row sums H of a source row are kept for the next output row, which reuses
-    // the lower row of this one five times out of six at scale 1.2.
+    if (yw >= gh) {
+        if constexpr (FL == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R01), "+s"(R23), "+s"(R45), "+s"(R67));
+        return;
+    }
+    // The four columns of a lane read source bytes sx0 .. sx0 + 7 at most: per visited source row three aligned dwords are shifted to start
+    // at sx0 (v_alignbyte), one v_perm_b32 per column picks its (left, right) pixel pair into 16-bit halves and one v_dot2_u32_u16 applies
+    // (alpha0, alpha1).  H & ~15 keeps what (H >> 4) keeps: v_mul_hi_u32(H & ~15, beta << 12) = (beta * (H >> 4)) >> 16, one instruction.
     unsigned sel[4], ap[4];
-    int bd4;
-    unsigned osh;
-    {
-        int lx0 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = min(xb + k, g.w - 1);
-            const int sx = xofs[g.xtab + x];
-            const int lx = sx - sxa, lx1 = min(sx + 1, sw - 1) - sxa;
-            if (k == 0) lx0 = lx;
-            sel[k] = (unsigned) (lx - lx0) | 0x0C00u | ((unsigned) (lx1 - lx0) << 16) | 0x0C000000u;
-            ap[k] = (unsigned) (unsigned short) xalpha[2 * (g.xtab + x)] | ((unsigned) (unsigned short) xalpha[2 * (g.xtab + x) + 1] << 16);
-        }
-        bd4 = lx0 & ~3;
-        osh = (unsigned) lx0 & 3u;
-    }
-    uint8_t *dstf = fs.pyr + (long long) f * fs.pyr_stride + g.off;
-    // the 8 rows of this wave: their y coefficients are wave-uniform -> scalar loads, all issued before the arithmetic
-    int r0s[8], r1s[8], b0s[8], b1s[8];
-#pragma unroll
-    for (int ry = 0; ry < 8; ry++) {
-        const int y = min(y0 + rg * 8 + ry, g.h - 1);
-        const int sy = yofs[g.ytab + y];
-        r0s[ry] = min(max(sy, 0), sh - 1) - sya;
-        r1s[ry] = min(max(sy + 1, 0), sh - 1) - sya;
-        b0s[ry] = ybeta[2 * (g.ytab + y)];
-        b1s[ry] = ybeta[2 * (g.ytab + y) + 1];
-    }
-    auto hrow = [&](int r, unsigned (&H)[4]) {
-        const unsigned *p = (const unsigned *) (tile + r * kPyrSrcPitch + bd4);
+    for (int k = 0; k < 4; k++) { sel[k] = s4[k]; ap[k] = a4[k]; }
+    const int lx0 = sx0 - sxa;
+    const int bd4 = lx0 & ~3;
+    const unsigned osh = (unsigned) lx0 & 3u;
+    auto hrow = [&](int rowByte, unsigned (&H)[4]) {
+        const unsigned *p = (const unsigned *) (tile + rowByte + bd4);
         const unsigned d0 = p[0], d1 = p[1], d2 = p[2];
         const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, osh), e1 = __builtin_amdgcn_alignbyte(d2, d1, osh);
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, __builtin_amdgcn_perm(e1, e0, sel[k])), __builtin_bit_cast(v2u, ap[k]), 0u, false);
+            H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, __builtin_amdgcn_perm(e1, e0, sel[k])), __builtin_bit_cast(v2u, ap[k]), 0u, false) & ~15u;
     };
-    int have = -1;
-    unsigned Hc[4] = {0, 0, 0, 0};
+    auto vout = [&](const unsigned (&H0)[4], const unsigned (&H1)[4], unsigned b0, unsigned b1) -> unsigned {
+        unsigned sum[4];   // (b0 * (H0 >> 4) >> 16) + (b1 * (H1 >> 4) >> 16) + 2 <= 1023: the pixel is bits 2 .. 9
 #pragma unroll
-    for (int ry = 0; ry < 8; ry++) {
-        const int y = y0 + rg * 8 + ry;
-        if (y >= g.h) break;
-        const int b0 = b0s[ry], b1 = b1s[ry];
-        unsigned H0[4], H1[4];
-        if (r0s[ry] == have) {
+        for (int k = 0; k < 4; k++) sum[k] = __umulhi(H0[k], b0) + __umulhi(H1[k], b1) + 2u;
+        const unsigned t01 = (sum[0] | (sum[1] << 16)) >> 2, t23 = (sum[2] | (sum[3] << 16)) >> 2;
+        return __builtin_amdgcn_perm(t23, t01, 0x06040200u);
+    };
+    if constexpr (FL == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(R01), "+s"(R23), "+s"(R45), "+s"(R67));
+        const unsigned r01s[kPyrPasses] = {R01[0], R01[4], R23[0], R23[4], R45[0], R45[4], R67[0], R67[4]};
+        const unsigned b0s[kPyrPasses] = {R01[1], R01[5], R23[1], R23[5], R45[1], R45[5], R67[1], R67[5]};
+        const unsigned b1s[kPyrPasses] = {R01[2], R01[6], R23[2], R23[6], R45[2], R45[6], R67[2], R67[6]};
+        int have = -1;
+        unsigned Hc[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; k++) H0[k] = Hc[k];
-        } else {
-            hrow(r0s[ry], H0);
+        for (int p = 0; p < kPyrPasses; p++) {
+            const int y = yw + p;
+            if (y >= gh) break;
+            const int r0 = (int) (r01s[p] & 0xffffu) - sya, r1 = (int) (r01s[p] >> 16) - sya;
+            unsigned H0[4], H1[4];
+            if (r0 == have) {   // the lower row of the previous output row: five times out of six at scale 1.2
+#pragma unroll
+                for (int k = 0; k < 4; k++) H0[k] = Hc[k];
+            } else {
+                hrow(r0 * kPitch, H0);
+            }
+            if (r1 == r0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) H1[k] = H0[k];
+            } else {
+                hrow(r1 * kPitch, H1);
+            }
+            have = r1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) Hc[k] = H1[k];
+            const unsigned out = vout(H0, H1, b0s[p], b1s[p]);
+            if (colIn) *(unsigned *) (dstf + (unsigned) y * (unsigned) gpitch + xb) = out;
         }
-        if (r1s[ry] == r0s[ry]) {
+    } else {
+        // folded: the lanes of a pass are on 2^FL different rows, so the records are per lane and nothing is shared between passes
+        u32x4 rec[kPyrPasses];
 #pragma unroll
-            for (int k = 0; k < 4; k++) H1[k] = H0[k];
-        } else {
-            hrow(r1s[ry], H1);
-        }
-        have = r1s[ry];
-        unsigned out = 0;
+        for (int p = 0; p < kPyrPasses; p++) rec[p] = *(const u32x4 *) (rows + min(yw + (p << FL) + rj, gh - 1));
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            Hc[k] = H1[k];
-            // operands fit 24 bits (beta <= 2048, H >> 4 <= 32640): full-rate 24-bit multiplies, same integers as the 32-bit form
-            out |= (unsigned) (((__mul24(b0, (int) (H0[k] >> 4)) >> 16) + (__mul24(b1, (int) (H1[k] >> 4)) >> 16) + 2) >> 2) << (8 * k);
+        for (int p = 0; p < kPyrPasses; p++) {
+            if (yw + (p << FL) >= gh) break;
+            const int y = yw + (p << FL) + rj;
+            const int r0 = (int) (rec[p][0] & 0xffffu) - sya, r1 = (int) (rec[p][0] >> 16) - sya;
+            unsigned H0[4], H1[4];
+            hrow(r0 * kPitch, H0);
+            hrow(r1 * kPitch, H1);
+            const unsigned out = vout(H0, H1, rec[p][1], rec[p][2]);
+            if (colIn && y < gh) *(unsigned *) (dstf + (unsigned) y * (unsigned) gpitch + xb) = out;
         }
-        *(unsigned *) (dstf + (unsigned) y * (unsigned) g.pitch + xb) = out;
+    }
+}
+
+__global__ __launch_bounds__(kPyrThreads) void k_pyr_resize_tiled(FrameSet fs, const LevelGeom *__restrict__ geom, int level, const PyrColRec *__restrict__ cols,
+                                                                  const PyrRowRec *__restrict__ rows, const PyrTileRec *__restrict__ tiles) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kPyrLdsBytes];
+    const LevelGeom g = geom[level];
+    const int f = blockIdx.y;
+    const PyrTileRec t = tiles[g.pyrTile + blockIdx.x];
+    int sp;
+    const uint8_t *src = level_ptr(fs, geom[level - 1], level - 1, f, &sp);
+    const int sh = geom[level - 1].h;
+    uint8_t *dstf = fs.pyr + (long long) f * fs.pyr_stride + g.off;
+    cols += g.pyrCol;
+    rows += g.pyrRow;
+    switch (t.foldLog2) {   // (uniform)
+    case 0: pyr_tile<0>(tile, dstf, g.w, g.h, g.pitch, src, sp, sh, t.x0, t.y0, t.sxa, t.nc, cols, rows); break;
+    case 1: pyr_tile<1>(tile, dstf, g.w, g.h, g.pitch, src, sp, sh, t.x0, t.y0, t.sxa, t.nc, cols, rows); break;
+    case 2: pyr_tile<2>(tile, dstf, g.w, g.h, g.pitch, src, sp, sh, t.x0, t.y0, t.sxa, t.nc, cols, rows); break;
+    default: pyr_tile<3>(tile, dstf, g.w, g.h, g.pitch, src, sp, sh, t.x0, t.y0, t.sxa, t.nc, cols, rows); break;
     }
 }
 
@@ -2326,34 +2369,38 @@ void launch_gather_host_frames(hipStream_t st, const HostFrameList &L, int nFram
 // The pyramid chain of ONE frame (levels 1 .. nlevels - 1, each from the one before) as an explicit graph: built node by node (no stream
 // capture, which would put process-wide restrictions on other threads' calls while it is open), retargeted to another frame's buffers by
 // rewriting the nodes' FrameSet argument, launched with one call.
-static void pyr_node_params(hipKernelNodeParams *np, void **args, const LevelGeom &g) {
+static void pyr_node_params(hipKernelNodeParams *np, void **args, PyrChainGraph *pg, int l) {
+    const LevelGeom &g = pg->lv[l];
+    const bool perPixel = g.area2x || !g.tiledOk;
     std::memset(np, 0, sizeof *np);
-    np->blockDim = dim3((g.area2x || !g.tiledOk) ? 256 : kPyrThreads);
+    np->blockDim = dim3(perPixel ? 256 : kPyrThreads);
     np->sharedMemBytes = 0;
     np->kernelParams = args;
     np->extra = nullptr;
-    if (g.area2x || !g.tiledOk) {
+    args[0] = &pg->fs; args[1] = &pg->geom; args[2] = &pg->level[l];
+    if (perPixel) {
+        args[3] = &pg->tabs.xofs; args[4] = &pg->tabs.xalpha; args[5] = &pg->tabs.yofs; args[6] = &pg->tabs.ybeta;
         np->func = (void *) k_pyr_resize;
         np->gridDim = dim3((g.w + 255) / 256, g.h, 1);
     } else {
+        args[3] = &pg->tabs.cols; args[4] = &pg->tabs.rows; args[5] = &pg->tabs.tiles;
         np->func = (void *) k_pyr_resize_tiled;
-        np->gridDim = dim3((g.w + kPyrTW - 1) / kPyrTW, (g.h + kPyrTH - 1) / kPyrTH, 1);
+        np->gridDim = dim3(g.nPyrTiles, 1, 1);
     }
 }
 
-hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom *lv, int nlevels,
-                                 const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
+hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom *lv, int nlevels, const PyrTabs &T) {
     std::memset(pg, 0, sizeof *pg);
     hipError_t e = hipGraphCreate(&pg->graph, 0);
     if (e != hipSuccess) return e;
-    pg->fs = fs; pg->geom = dGeom; pg->xofs = xofs; pg->xalpha = xalpha; pg->yofs = yofs; pg->ybeta = ybeta;
+    pg->fs = fs; pg->geom = dGeom; pg->tabs = T;
     pg->nNodes = 0;
     for (int l = 1; l < nlevels; l++) {
         pg->level[l] = l;
         pg->lv[l] = lv[l];
-        void *args[7] = {&pg->fs, &pg->geom, &pg->level[l], &pg->xofs, &pg->xalpha, &pg->yofs, &pg->ybeta};
+        void *args[7];
         hipKernelNodeParams np;
-        pyr_node_params(&np, args, lv[l]);
+        pyr_node_params(&np, args, pg, l);
         e = hipGraphAddKernelNode(&pg->nodes[l], pg->graph, l > 1 ? &pg->nodes[l - 1] : nullptr, l > 1 ? 1 : 0, &np);
         if (e != hipSuccess) break;
         pg->nNodes = l;
@@ -2366,9 +2413,9 @@ hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const Le
 hipError_t pyr_chain_graph_retarget(PyrChainGraph *pg, const FrameSet &fs) {
     pg->fs = fs;
     for (int l = 1; l <= pg->nNodes; l++) {
-        void *args[7] = {&pg->fs, &pg->geom, &pg->level[l], &pg->xofs, &pg->xalpha, &pg->yofs, &pg->ybeta};
+        void *args[7];
         hipKernelNodeParams np;
-        pyr_node_params(&np, args, pg->lv[l]);
+        pyr_node_params(&np, args, pg, l);
         const hipError_t e = hipGraphExecKernelNodeSetParams(pg->exec, pg->nodes[l], &np);
         if (e != hipSuccess) return e;
     }
@@ -2383,15 +2430,13 @@ void pyr_chain_graph_destroy(PyrChainGraph *pg) {
     pg->nNodes = 0;
 }
 
-void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
-                       const int *xofs, const short *xalpha, const int *yofs, const short *ybeta) {
-    if (g.area2x || !g.tiledOk) {   // exact 2x levels (area mean) and steep pyramids (tile would not fit LDS): per-pixel kernel
+void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames, const PyrTabs &T) {
+    if (g.area2x || !g.tiledOk) {   // exact 2x levels (area mean) and steep pyramids (a tile's source would not fit LDS): per-pixel kernel
         dim3 grid((g.w + 255) / 256, g.h, nFrames);
-        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+        hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, st, fs, dGeom, level, T.xofs, T.xalpha, T.yofs, T.ybeta);
         return;
     }
-    dim3 grid((g.w + kPyrTW - 1) / kPyrTW, (g.h + kPyrTH - 1) / kPyrTH, nFrames);
-    hipLaunchKernelGGL(k_pyr_resize_tiled, grid, dim3(kPyrThreads), 0, st, fs, dGeom, level, xofs, xalpha, yofs, ybeta);
+    hipLaunchKernelGGL(k_pyr_resize_tiled, dim3(g.nPyrTiles, nFrames), dim3(kPyrThreads), 0, st, fs, dGeom, level, T.cols, T.rows, T.tiles);
 }
 
 // The attribute belongs to the kernel on a device, not to a context: contexts of different geometries share it, so it only ever grows (a

@@ -7,8 +7,23 @@ namespace ygzf {
 
 hipError_t upload_constants(const int *umax16);
 
-void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames,
-                       const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
+struct PyrTabs {   // device tables of one geometry's pyramid
+    const int *xofs;
+    const short *xalpha;
+    const int *yofs;
+    const short *ybeta;
+    const PyrColRec *cols;
+    const PyrRowRec *rows;
+    const PyrTileRec *tiles;
+};
+void launch_pyr_resize(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom &g, int level, int nFrames, const PyrTabs &T);
+// k_pyr_resize_tiled's staging area per fold (a wave's lanes cover `fold` rows x 256 / fold columns per pass): 16-byte chunks per staged
+// source row, staged rows, LDS row pitch
+constexpr int kPyrFolds = 4;
+__host__ __device__ constexpr int pyr_fold_chunks(int foldLog2) { return foldLog2 == 0 ? 21 : foldLog2 == 1 ? 11 : foldLog2 == 2 ? 6 : 3; }
+__host__ __device__ constexpr int pyr_fold_pitch(int foldLog2) { return 16 * pyr_fold_chunks(foldLog2); }
+__host__ __device__ constexpr int pyr_fold_rows(int foldLog2) { return foldLog2 == 0 ? 44 : foldLog2 == 1 ? 84 : foldLog2 == 2 ? 166 : 330; }
+constexpr int kPyrTileRows = 32;   // output rows of a tile at fold 1 (fold f: 32 f rows x 256 / f columns)
 void launch_repitch_rows(hipStream_t st, const uint8_t *src, size_t srcPitch, uint8_t *dst, size_t dstPitch, int w, size_t rows);
 constexpr int kHostFrameListMax = 128;
 struct HostFrameList { unsigned long long addr[kHostFrameListMax]; };   // device-visible addresses of page-locked host frames (by value: kernel argument)
@@ -20,13 +35,11 @@ struct PyrChainGraph {
     int nNodes;                  // nodes 1 .. nNodes
     FrameSet fs;                 // argument storage of the nodes
     const LevelGeom *geom;
-    const int *xofs, *yofs;
-    const short *xalpha, *ybeta;
+    PyrTabs tabs;
     int level[kMaxLevels];
     LevelGeom lv[kMaxLevels];
 };
-hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom *lv, int nlevels,
-                                 const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
+hipError_t pyr_chain_graph_build(PyrChainGraph *pg, const FrameSet &fs, const LevelGeom *dGeom, const LevelGeom *lv, int nlevels, const PyrTabs &T);
 hipError_t pyr_chain_graph_retarget(PyrChainGraph *pg, const FrameSet &fs);
 void pyr_chain_graph_destroy(PyrChainGraph *pg);
 // one frame's whole pyramid chain in one launch (k_pyr_strips): per strip and level, the rows [ca, cb) the strip produces in LDS (level 0:

@@ -177,19 +177,56 @@ int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
                 G.ybeta.push_back(sat_short((1.f - fy) * 2048));
                 G.ybeta.push_back(sat_short(fy * 2048));
             }
-            // the LDS-tiled resize kernel stages <= 44 rows x 328 bytes of source per 256 x 32 output tile: true for the usual scale
-            // factors (<= ~1.27); steeper pyramids take the per-pixel kernel
+            // k_pyr_resize_tiled's tables.  A level is cut into tiles of 8192 output pixels: 256-column tiles of 32 rows while >= 225 columns
+            // remain, then the rest in binary pieces of 128 / 64 / 32 columns whose waves fold 2 / 4 / 8 rows into one pass.  True for the
+            // usual scale factors (<= ~1.27): steeper pyramids (a tile's source region would not fit the staging area) take the per-pixel kernel.
             g.tiledOk = 1;
-            for (int x0 = 0; x0 < g.w && g.tiledOk; x0 += 256) {
-                const int xl = std::min(x0 + 256, g.w) - 1;
+            g.pyrCol = (int) G.pyrCols.size();
+            g.pyrRow = (int) G.pyrRows.size();
+            g.pyrTile = (int) G.pyrTiles.size();
+            for (int xb = 0; xb < g.w; xb += 4) {
+                PyrColRec r;
+                memset(&r, 0, sizeof r);
+                r.sx0 = G.xofs[g.xtab + xb];
+                for (int k = 0; k < 4; k++) {
+                    const int x = std::min(xb + k, g.w - 1);
+                    const int sx = G.xofs[g.xtab + x], sx1 = std::min(sx + 1, s.w - 1);
+                    if (sx1 - r.sx0 > 7 || sx < r.sx0) g.tiledOk = 0;   // the pair of every column comes out of the eight bytes from sx0 on
+                    r.sel[k] = (unsigned) ((sx - r.sx0) & 7) | 0x0C00u | ((unsigned) ((sx1 - r.sx0) & 7) << 16) | 0x0C000000u;
+                    r.ap[k] = (unsigned) (unsigned short) G.xalpha[2 * (g.xtab + x)] | ((unsigned) (unsigned short) G.xalpha[2 * (g.xtab + x) + 1] << 16);
+                    if (G.xalpha[2 * (g.xtab + x)] < 0 || G.xalpha[2 * (g.xtab + x) + 1] < 0) g.tiledOk = 0;
+                }
+                G.pyrCols.push_back(r);
+            }
+            for (int y = 0; y < g.h; y++) {
+                const int sy = G.yofs[g.ytab + y];
+                const int r0 = std::min(std::max(sy, 0), s.h - 1), r1 = std::min(std::max(sy + 1, 0), s.h - 1);
+                const int b0 = G.ybeta[2 * (g.ytab + y)], b1 = G.ybeta[2 * (g.ytab + y) + 1];
+                if (b0 < 0 || b1 < 0 || b0 > 2048 || b1 > 2048 || s.h > 65535) g.tiledOk = 0;
+                G.pyrRows.push_back(PyrRowRec{(unsigned) r0 | ((unsigned) r1 << 16), (unsigned) b0 << 12, (unsigned) b1 << 12, 0u});
+            }
+            for (int p = 1; p < 8; p++) G.pyrRows.push_back(G.pyrRows.back());   // a wave reads the records of its 8 rows in one go
+            for (int x0 = 0; x0 < g.w && g.tiledOk;) {
+                const int rest = g.w - x0;
+                int fl = 0;   // fold: the widest piece of the binary decomposition of the rest, in units of 32 columns
+                if (rest <= 224) {
+                    const int units = (rest + 31) / 32;
+                    fl = units >= 4 ? 1 : units >= 2 ? 2 : 3;
+                }
+                const int tw = 256 >> fl, th = kPyrTileRows << fl;
+                const int xl = std::min(x0 + tw, g.w) - 1;
                 const int sxa = G.xofs[g.xtab + x0] & ~3, sxb = std::min(G.xofs[g.xtab + xl] + 1, s.w - 1);
-                if ((sxb - sxa) / 4 + 1 > 328 / 4) g.tiledOk = 0;
+                const int nc = (sxb - sxa) / 16 + 1;
+                if (nc > pyr_fold_chunks(fl) || sxa > 65535) g.tiledOk = 0;
+                for (int y0 = 0; y0 < g.h && g.tiledOk; y0 += th) {
+                    const int yl = std::min(y0 + th, g.h) - 1;
+                    const int sya = (int) (G.pyrRows[g.pyrRow + y0].r01 & 0xffffu), syb = (int) (G.pyrRows[g.pyrRow + yl].r01 >> 16);
+                    if (syb - sya + 1 > pyr_fold_rows(fl) || syb < sya) g.tiledOk = 0;
+                    G.pyrTiles.push_back(PyrTileRec{(unsigned short) x0, (unsigned short) y0, (unsigned short) sxa, (unsigned char) nc, (unsigned char) fl});
+                }
+                x0 += tw;
             }
-            for (int y0 = 0; y0 < g.h && g.tiledOk; y0 += 32) {
-                const int yl = std::min(y0 + 32, g.h) - 1;
-                const int sya = std::min(std::max(G.yofs[g.ytab + y0], 0), s.h - 1), syb = std::min(std::max(G.yofs[g.ytab + yl] + 1, 0), s.h - 1);
-                if (syb - sya + 1 > 44) g.tiledOk = 0;
-            }
+            g.nPyrTiles = (int) G.pyrTiles.size() - g.pyrTile;
         }
         // FAST cells
         g.maxBorderX = g.w - kEdgeThreshold + 3;
@@ -313,6 +350,17 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             rc = ensure(c, *u.b, std::max<size_t>(u.bytes, 16));
             if (rc) return rc;
             if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
+        }
+        {
+            struct { ygzf_ctx::Buf *b; const void *src; size_t bytes; } up2[3] = {
+                {&c->dPyrCols, G.pyrCols.data(), G.pyrCols.size() * sizeof(PyrColRec)},
+                {&c->dPyrRows, G.pyrRows.data(), G.pyrRows.size() * sizeof(PyrRowRec)},
+                {&c->dPyrTiles, G.pyrTiles.data(), G.pyrTiles.size() * sizeof(PyrTileRec)}};
+            for (auto &u : up2) {
+                rc = ensure(c, *u.b, std::max<size_t>(u.bytes, 64));
+                if (rc) return rc;
+                if (u.bytes) HIPCHECK(c, hipMemcpy(u.b->p, u.src, u.bytes, hipMemcpyHostToDevice));
+            }
         }
         if (!G.pyrPlan.empty()) {
             rc = ensure(c, c->dPyrPlan, sizeof G.pyrLevels + G.pyrPlan.size() * sizeof(PyrStripPlan));   // level table, then one plan per strip
@@ -450,11 +498,9 @@ int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
         for (int l = 1; l < L; l++) {
             if (prof) {
                 ProfScope ps(c, KK_PYR);
-                launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
-                                  (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+                launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, pyr_tabs(c));
             } else
-                launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
-                                  (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+                launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, pyr_tabs(c));
         }
     };
     if (!G.pyrPlan.empty() && nFrames <= c->pyrStripFrames) {   // a few frames: the whole chain in one launch
@@ -468,12 +514,11 @@ int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
         launch_all(true);
         return YGZF_OK;
     }
-    const void *key[6] = {c->dGeom.p, c->dXofs.p, c->dXalpha.p, c->dYofs.p, c->dYbeta.p,
+    const void *key[6] = {c->dGeom.p, c->dXofs.p, c->dPyrCols.p, c->dPyrRows.p, c->dPyrTiles.p,
                           (const void *) (((uintptr_t) G.w << 32) | (uintptr_t) (unsigned) G.h)};
     if (!c->pyrGraph.exec || memcmp(key, c->pyrGraphKey, sizeof key) != 0) {
         pyr_chain_graph_destroy(&c->pyrGraph);
-        const hipError_t e = pyr_chain_graph_build(&c->pyrGraph, fs, dGeom, G.lv.data(), L, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
-                                                   (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+        const hipError_t e = pyr_chain_graph_build(&c->pyrGraph, fs, dGeom, G.lv.data(), L, pyr_tabs(c));
         if (e != hipSuccess) {   // no graphs on this runtime: plain launches from now on
             (void) hipGetLastError();
             c->useGraphs = false;
@@ -815,7 +860,8 @@ void ygzf_destroy(ygzf_ctx *c) {
     ygzf_ctx::Buf *bufs[] = {&c->dGeom, &c->dXofs, &c->dXalpha, &c->dYofs, &c->dYbeta, &c->dImg0, &c->dPyr, &c->dCellCnt, &c->dSlots,
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlBase, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
-                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes, &c->dResPack, &c->dFastCtr};
+                             &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes, &c->dResPack, &c->dFastCtr,
+                             &c->dPyrPlan, &c->dPyrCols, &c->dPyrRows, &c->dPyrTiles};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)

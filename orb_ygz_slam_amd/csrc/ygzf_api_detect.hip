@@ -110,8 +110,7 @@ int ygzf_extract_dso(ygzf_ctx *c, const uint8_t *img, int w, int h, int stride, 
     const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
     for (int l = 1; l < L; l++) {   // Frame ctor: ComputeImagePyramid (src/Frame.cc:807-813)
         ProfScope ps(c, KK_PYR);
-        launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, 1, (const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p,
-                          (const short *) c->dYbeta.p);
+        launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, 1, pyr_tabs(c));
     }
     c->lastFrames = 0;
     c->carryValid = false;
@@ -222,8 +221,7 @@ static int grid_extract_begin(ygzf_ctx *c, const uint8_t *img, int w, int h, int
     const LevelGeom *dGeom = (const LevelGeom *) c->dGeom.p;
     for (int l = 1; l < L; l++) {   // Frame ctor: ComputeImagePyramid (src/Frame.cc:807-813)
         ProfScope ps(c, KK_PYR);
-        launch_pyr_resize(c->stream, *fs, dGeom, G.lv[l], l, 1, (const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p,
-                          (const short *) c->dYbeta.p);
+        launch_pyr_resize(c->stream, *fs, dGeom, G.lv[l], l, 1, pyr_tabs(c));
     }
     c->lastFrames = 0;
     c->carryValid = false;

@@ -174,8 +174,7 @@ int ygzf_compute_stereo_matches(ygzf_ctx *c, const uint8_t *img_left, const uint
     const Geometry &G = c->geo;
     for (int l = 1; l < L; l++) {
         ProfScope ps(c, KK_PYR);
-        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, G.lv[l], l, 2, (const int *) c->dXofs.p, (const short *) c->dXalpha.p,
-                          (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
+        launch_pyr_resize(c->stream, fs, (const LevelGeom *) c->dGeom.p, G.lv[l], l, 2, pyr_tabs(c));
     }
     c->lastFrames = 0;
     c->carryValid = false;

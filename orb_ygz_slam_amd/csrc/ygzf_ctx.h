@@ -31,6 +31,9 @@ struct Geometry {
     std::vector<LevelGeom> lv;
     std::vector<int> xofs, yofs;
     std::vector<short> xalpha, ybeta;
+    std::vector<PyrColRec> pyrCols;      // k_pyr_resize_tiled's tables (levels >= 1, LevelGeom::pyrCol / pyrRow / pyrTile index them)
+    std::vector<PyrRowRec> pyrRows;
+    std::vector<PyrTileRec> pyrTiles;
     long long pyrBytes = 0;   // per frame, levels >= 1
     std::vector<PyrStripPlan> pyrPlan;   // k_pyr_strips: one entry per strip (empty: this geometry takes one launch per level)
     int pyrStripOffA = 0, pyrStripOffB = 0;
@@ -63,7 +66,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dStBins, dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan;
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dStBins, dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan, dPyrCols, dPyrRows, dPyrTiles;
     int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
@@ -304,6 +307,11 @@ static void drain_profile(ygzf_ctx *c) {
         c->pool.push_back(r.b);
     }
     c->recs.clear();
+}
+
+static inline ygzf::PyrTabs pyr_tabs(const ygzf_ctx *c) {
+    return ygzf::PyrTabs{(const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p,
+                         (const ygzf::PyrColRec *) c->dPyrCols.p, (const ygzf::PyrRowRec *) c->dPyrRows.p, (const ygzf::PyrTileRec *) c->dPyrTiles.p};
 }
 
 // ---- defined in ygzf_api.hip, used by the other translation units ---------------------------------------------------------------------

@@ -30,8 +30,10 @@ struct LevelGeom {
     int w, h, pitch;          // level image; pitch in bytes (64-aligned) for levels >= 1
     long long off;            // byte offset of the level inside one frame's pyramid slab (levels >= 1)
     int area2x;               // 1: previous level is exactly 2x in both axes -> 2x2 area average (cv::resize quirk)
-    int tiledOk;              // 1: every 256x32 output tile's source region fits the LDS staging area of k_pyr_resize_tiled
+    int tiledOk;              // 1: every output tile's source region fits the LDS staging area of k_pyr_resize_tiled
     int xtab, ytab;           // offsets into the resize coefficient tables
+    int pyrCol, pyrRow;       // first PyrColRec / PyrRowRec of this level
+    int pyrTile, nPyrTiles;   // this level's PyrTileRec range: one workgroup of k_pyr_resize_tiled each
     // FAST cell grid, src/ORBextractor.cc:733-745
     int nCols, nRows, wCell, hCell;
     int maxBorderX, maxBorderY;
@@ -51,6 +53,26 @@ struct LevelGeom {
     int candCap;              // nCells*slotCap
     float scale;              // mvScaleFactor[level]
     float kpSize;             // (float)(int)(PATCH_SIZE*scale)
+};
+
+// k_pyr_resize_tiled's host-built tables (cv::resize INTER_LINEAR, the same integers as xofs / xalpha / yofs / ybeta):
+// what a lane needs for the four output columns it owns, what a row needs, and the list of tiles of a level.
+struct PyrColRec {          // per group of 4 output columns, 48 bytes = three 16-byte loads
+    int sx0;                // source column of the group's first pixel
+    unsigned pad[3];
+    unsigned sel[4];        // v_perm_b32 selector of column k: (left, right) source pixel as bytes 0 and 2, relative to sx0
+    unsigned ap[4];         // alpha0 | alpha1 << 16
+};
+struct PyrRowRec {          // per output row, 16 bytes
+    unsigned r01;           // source row of the upper tap | lower tap << 16, both clamped to the source image
+    unsigned b0, b1;        // beta << 12: v_mul_hi_u32(H & ~15, beta << 12) == (beta * (H >> 4)) >> 16
+    unsigned pad;
+};
+struct PyrTileRec {         // 8 bytes
+    unsigned short x0, y0;  // first output column / row
+    unsigned short sxa;     // first staged source column (multiple of 4)
+    unsigned char nc;       // 16-byte chunks staged per source row
+    unsigned char foldLog2; // a wave's lanes cover 2^foldLog2 rows x (256 >> foldLog2) columns per pass
 };
 
 // One FAST cell as k_fast_tab wants it (host-built per (w, h) configuration, indexed [cell group * 4 + position in the 2x2 group]):

@@ -156,6 +156,14 @@ KERNEL_F64(k_mulf64, OP_MULF64) KERNEL_F64(k_addf64, OP_ADDF64) KERNEL_F64(k_fma
     }
 KERNEL_S(k_add_s1, OP_ADD_S1) KERNEL_S(k_add_s2, OP_ADD_S2) KERNEL_S(k_lerp_s1, OP_LERP_S1)
 
+// mixes of a quarter-rate-class (4-cycle) and a half-rate-class (2-cycle) instruction in ONE wave's stream: does the 2-cycle instruction keep its
+// rate between 4-cycle neighbours?  (the FAST pass 1 is 32 v_lerp_u8 + 84 v_bitop3 + 18 v_alignbyte per 4 pixels)
+#define OP_MIX11(x) asm volatile("v_lerp_u8 %0, %0, %1, %2\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x) : "v"(b), "v"(c));
+#define OP_MIX13(x) asm volatile("v_lerp_u8 %0, %0, %1, %2\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n\tv_bitop3_b32 %0, %0, %2, %1 bitop3:0x96\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0xe8" : "+v"(x) : "v"(b), "v"(c));
+#define OP_MIXPA(x) asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_add_u32 %0, %0, %1" : "+v"(x) : "v"(b), "v"(c));
+#define OP_MIXMA(x) asm volatile("v_mul_hi_u32 %0, %0, %1\n\tv_and_b32 %0, %0, %2" : "+v"(x) : "v"(b), "v"(c));
+KERNEL(k_mix11, OP_MIX11) KERNEL(k_mix13, OP_MIX13) KERNEL(k_mixpa, OP_MIXPA) KERNEL(k_mixma, OP_MIXMA)
+
 typedef void (*kern_t)(unsigned *, long long *, unsigned);
 
 int main(int argc, char **argv) {   // optional arguments: substrings of the instruction names to run
@@ -167,7 +175,7 @@ int main(int argc, char **argv) {   // optional arguments: substrings of the ins
     long long *clk;
     hipMalloc(&out, (size_t) cus * 8 * 256 * 4 + 1024);
     hipMalloc(&clk, 64);
-    struct { const char *name; kern_t k; } ks[] = {{"v_lerp_u8", k_lerp}, {"v_bitop3_b32", k_bitop3}, {"v_or3_b32", k_or3}, {"v_add_u32", k_add}, {"v_alignbyte_b32", k_align},
+    struct { const char *name; kern_t k; int mult; } ks[] = {{"lerp+bitop3 (per pair)", k_mix11, 1}, {"lerp+3 bitop3 (per 4)", k_mix13, 1}, {"perm+add (per pair)", k_mixpa, 1}, {"mul_hi+and (per pair)", k_mixma, 1}, {"v_lerp_u8", k_lerp}, {"v_bitop3_b32", k_bitop3}, {"v_or3_b32", k_or3}, {"v_add_u32", k_add}, {"v_alignbyte_b32", k_align},
                                                    {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4}, {"v_sad_u8", k_sad}, {"v_pk_min_u16", k_pkmin}, {"v_pk_add_u16", k_pkadd},
                                                    {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo}, {"v_cmp_lt_u32", k_cmp}, {"v_cndmask_b32", k_cndmask},
                                                    {"v_add_u32_dpp", k_dpp}, {"v_mbcnt_lo", k_mbcnt}, {"v_fma_f32", k_fma}, {"v_pk_fma_f32", k_pkfma},
