@@ -1298,6 +1298,33 @@ __device__ __forceinline__ void digit_bounds3(const unsigned *keys, int lo, int 
     *a1 = a[0]; *a2 = a[1]; *a3 = a[2];
 }
 
+// Candidates that follow each other in cell-major order fall into the same histogram bin / the same final node in runs, and an LDS atomic of 64 lanes
+// on one address is 64 atomics in a row (the selection pass of a 61 000-candidate level: 39 us of same-address conflicts).  Within a row of 16 lanes
+// (DPP, no LDS traffic) the lanes of a run of equal ids are combined and only the LAST lane of each run goes to LDS.
+// id >= 0; lanes without an item pass a negative id of their own.
+__device__ __forceinline__ bool row_run_last(int id) {   // is this the last lane of its run of equal ids inside its row?
+    const int nxt = __builtin_amdgcn_update_dpp(-1, id, 0x101, 0xF, 0xF, false);   // row_shl:1 -- the row's last lane keeps -1
+    return nxt != id;
+}
+template <int kCtrl>
+__device__ __forceinline__ unsigned row_run_max_step(int id, unsigned v) {
+    const int oid = __builtin_amdgcn_update_dpp(-1, id, kCtrl, 0xF, 0xF, false);
+    const unsigned ov = (unsigned) __builtin_amdgcn_update_dpp(0, (int) v, kCtrl, 0xF, 0xF, false);
+    return oid == id ? max(v, ov) : v;
+}
+__device__ __forceinline__ unsigned row_run_max(int id, unsigned v) {   // max of v over the lanes of this lane's run up to this lane (max is idempotent:
+    v = row_run_max_step<0x111>(id, v);                                 // equal ids are enough, the run need not be checked for gaps); row_shr:1, 2, 4, 8
+    v = row_run_max_step<0x112>(id, v);
+    v = row_run_max_step<0x114>(id, v);
+    return row_run_max_step<0x118>(id, v);
+}
+__device__ __forceinline__ int row_run_length(int id, int lane) {   // lanes of this lane's run up to and including this lane
+    const int prv = __builtin_amdgcn_update_dpp(-1, id, 0x111, 0xF, 0xF, false);   // row_shr:1 -- the row's first lane keeps -1
+    const unsigned long long starts = __ballot(prv != id);                          // first lanes of runs (every row's lane 0 among them)
+    const unsigned long long upTo = starts & (~0ull >> (63 - lane));
+    return lane - (63 - __builtin_clzll(upTo)) + 1;
+}
+
 struct OctShared {  // carved out of dynamic LDS
     int *cellPref;            // nCells + 1
     int *nlo[2], *ncnt[2], *ndep[2];  // node list, double buffered (cap each)
@@ -1334,7 +1361,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
                                                       int *__restrict__ lvlCandCnt, uint2 *__restrict__ procRec,
                                                       int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena,
-                                                      int regionInts, int histBins) {
+                                                      int regionInts, int histBins, int *gHist, int *gDone) {
     static_assert(!(kGlobalNodes && kHist), "the histogram plan keeps the node arrays in LDS");
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[kRadixHist];
@@ -1344,12 +1371,21 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
     __shared__ int s_head[4];
     const int tid = threadIdx.x;
     const int l = blockIdx.x + levelBase, f = blockIdx.y;
-#define OSTAMP(k) do { if (dbg && tid == 0 && f == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
+    // kHist, launches of a few frames (gridDim.z > 1): a level of one 3840x2160 frame is 60 000 candidates whose keys took ONE compute unit 95 us while
+    // 250 others had nothing to do.  The workgroups z = 1 .. gridDim.z - 1 of a (level, frame) are helpers: each computes the keys of its share of the
+    // candidates (keys and positions in the global candidate arrays as always, its bin counts into a slice of gHist), releases, bumps gDone and
+    // leaves; workgroup 0 does its own share, waits for the others, adds their counts to its own and goes on alone.  The host launches helpers only while ALL workgroups of the launch fit the device together (ygzf_api.hip), so nobody waits for
+    // a workgroup that cannot start.
+    const int parts = kHist && gHist ? (int) gridDim.z : 1, part = kHist ? (int) blockIdx.z : 0;
+#define OSTAMP(k) do { if (dbg && tid == 0 && f == 0 && part == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
     OSTAMP(0);
+    int bfsEv = 0;
+#define OBFS(nn) do { if (dbg && tid == 0 && f == 0 && part == 0 && bfsEv < 8) { dbg[16 * 8 + 16 + l * 16 + 2 * bfsEv] = (nn); dbg[16 * 8 + 16 + l * 16 + 2 * bfsEv + 1] = wall_clock64(); bfsEv++; } } while (0)
     const LevelGeom g = geom[l];
     const int nCells = g.nCols * g.nRows;
     int *lvlCnt = lvlKpCnt + f * nlevels + l;
     if (nCells <= 0 || g.nCols <= 0) {
+        if (part != 0) return;
         if (tid == 0) { *lvlCnt = 0; lvlCandCnt[f * nlevels + l] = 0; }
         for (int i = tid; i < g.kpCap; i += kOctBlock) procRec[(long long) f * kpStride + g.kpBase + i] = make_uint2(0u, kNoKeypoint);
         return;
@@ -1360,7 +1396,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
         int *p = dyn;
         S.cellPref = p;
         if (kHist) PS = dyn + regionInts;        // (the node arrays start at dyn as well: the cell prefix table is dead once the keys exist)
-        else p += nCells + 1;
+        else p += (nCells + 1 + 3) & ~3;         // (16-byte aligned node arrays: cap is a multiple of 4)
         int *candLds = p;
         if (kGlobalNodes) p = nodeArena + ((long long) blockIdx.y * nlevels + l) * (19LL * cap);
         for (int b = 0; b < 2; b++) { S.nlo[b] = p; p += cap; S.ncnt[b] = p; p += cap; S.ndep[b] = p; p += cap; }
@@ -1388,15 +1424,19 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
     bool useHist = kHist && dm >= 1;
     const int nBins = g.nIni << (2 * dm);
     const int binShift = 2 * (g.depth - dm);
+    if (part != 0 && !useHist) return;   // (no histogram for this level: workgroup 0 sorts, alone)
+    int *gh = kHist && parts > 1 ? gHist + ((long long) f * nlevels + l) * (parts - 1) * histBins : nullptr;   // one slice of histBins counts per helper
+    int *gd = kHist && parts > 1 ? gDone + (f * nlevels + l) : nullptr;
 restart:   // (kHist: a second time, on the sorting path, after the tree asked for a split below depth dm)
     if (kHist && tid == 0) s_overflow = 0;
     // ---- 1. candidate offsets per cell (cell-major order == the reference's vToDistributeKeys order) ----
     for (int i = tid; i < nCells; i += kOctBlock) S.cellPref[i] = cc[i];
     __syncthreads();
     const int M = block_scan_array(S.cellPref, nCells, s_tmp);
-    if (tid == 0) { S.cellPref[nCells] = M; lvlCandCnt[f * nlevels + l] = M; }
+    if (tid == 0) { S.cellPref[nCells] = M; if (part == 0) lvlCandCnt[f * nlevels + l] = M; }
     __syncthreads();
     if (M == 0) {
+        if (part != 0) return;
         if (tid == 0) *lvlCnt = 0;
         for (int i = tid; i < g.kpCap; i += kOctBlock) procRec[(long long) f * kpStride + g.kpBase + i] = make_uint2(0u, kNoKeypoint);
         return;
@@ -1463,7 +1503,8 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
         int steps = 0;
         while ((1 << steps) < nCells) steps++;
         constexpr int kKU = 4;
-        for (int i0 = tid; i0 < M; i0 += kKU * kOctBlock) {
+        const int shares = kHist && useHist ? parts : 1;   // (the sorting path after a restart: workgroup 0 takes everything)
+        for (int i0 = tid + part * kKU * kOctBlock; i0 < M; i0 += shares * kKU * kOctBlock) {
             int ia[kKU], a[kKU], b[kKU];
 #pragma unroll
             for (int u = 0; u < kKU; u++) { ia[u] = min(i0 + u * kOctBlock, M - 1); a[u] = 0; b[u] = nCells; }
@@ -1492,15 +1533,17 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
                     oy[u] = ci * g.hCell;
                 }
             }
+            int binOf[kKU];
 #pragma unroll
             for (int u = 0; u < kKU; u++) {
                 const int i = i0 + u * kOctBlock;
+                binOf[u] = -2 - (tid & 63);
                 if (i < M) {
                     const int x = (int) (e[u] & 255u) + ox[u], y = (int) ((e[u] >> 8) & 255u) + oy[u];
                     const unsigned key = useTab ? (xTab[x] | yTab[y]) : path_key(x, y, g);
                     if (kHist && useHist) {
                         const unsigned bin = key >> binShift;
-                        atomicAdd(&PS[bin], 1);
+                        binOf[u] = (int) bin;
                         key0[i] = bin | ((e[u] >> 16) << 16);      // bin < 65536; the score rides along for the selection pass
                     } else {
                         key0[i] = key;
@@ -1509,6 +1552,40 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
                     xy[i] = (unsigned) x | ((unsigned) y << 16);
                 }
             }
+            if (kHist && useHist) {   // (uniform per workgroup; every lane of the wave takes part in the row operations)
+#pragma unroll
+                for (int u = 0; u < kKU; u++) {
+                    const int len = row_run_length(binOf[u], tid & 63);
+                    if (binOf[u] >= 0 && row_run_last(binOf[u])) atomicAdd(&PS[binOf[u]], len);
+                }
+            }
+        }
+    }
+    if (kHist && useHist && parts > 1) {
+        // (counts in a slice of its own per helper, plain stores: 60 000 device-scope atomics on one histogram ran at 9 per nanosecond for the whole
+        // device -- every level of a 3840x2160 pair waited 95 us for them)
+        __syncthreads();
+        if (part != 0) {
+            int *mine = gh + (long long) (part - 1) * histBins;
+            for (int b = tid; b < nBins; b += kOctBlock) mine[b] = PS[b];
+        }
+        // Release / acquire by ONE thread per workgroup, the barriers carrying the other threads' accesses along: an agent-scope release is a write-back
+        // of the XCD's whole L2 -- executed by every wave of every workgroup (`__threadfence()` in all threads, the portable idiom) it made every level
+        // of a 3840x2160 pair wait 95 us for 6000 of them.
+        __syncthreads();                       // every store of this workgroup has reached the L2 (the barrier waits for vmcnt(0)) ...
+        if (part != 0) {
+            if (tid == 0) __hip_atomic_fetch_add(gd, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and leaves it with this release
+            return;
+        }
+        if (tid == 0) {
+            while (__hip_atomic_load(gd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < parts - 1) __builtin_amdgcn_s_sleep(8);
+            __hip_atomic_store(gd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
+        }
+        __syncthreads();
+        for (int b = tid; b < nBins; b += kOctBlock) {
+            int v = PS[b];
+            for (int q = 0; q < parts - 1; q++) v += gh[(long long) q * histBins + b];
+            PS[b] = v;
         }
     }
     __syncthreads();
@@ -1646,6 +1723,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
     __syncthreads();
     int n = s_head[0], cur = s_head[1];
     int nE = s_head[2];
+    OBFS(n);
     bool finish = s_head[3] == 1, toExpand = s_head[3] == 2;
     while (!finish) {
         if (!toExpand) {
@@ -1677,6 +1755,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
             cur = nxt;
             n = totK + totS;
             nE = totE;
+            OBFS(n);
             if (n >= N || n == prevSize) { finish = true; break; }
             if (n + 3 * nE <= N) continue;
         }
@@ -1699,15 +1778,32 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
                 __syncthreads();
                 unsigned *ek, *ev;
                 if (nE <= kOctBlock) {
-                    // a few hundred distinct keys (they carry the creation sequence): the position of a key is the number of smaller keys --
-                    // one thread per key counts them off broadcast LDS reads, no histogram, no scan, ONE barrier (the radix sort: three
-                    // passes of four)
-                    if (tid < nE) {
-                        const unsigned key = S.sk[0][tid];
-                        int rank = 0;
-                        for (int q = 0; q < nE; q++) rank += S.sk[0][q] < key;
+                    // a few hundred distinct keys (they carry the creation sequence): the position of a key is the number of smaller keys -- counted off
+                    // LDS reads, no histogram, no scan, ONE barrier (the radix sort: three passes of four).  T = 1 .. 16 adjacent lanes share a key, each
+                    // counting a quarter-aligned slice of the list with 16-byte reads: one thread per key reading word by word made a round of 512
+                    // expandable nodes 8192 wave-wide LDS reads -- 14 of the 22 us of a 1920x1080 level's only expand round.
+                    int tl = 0;
+                    while (tl < 4 && (nE << (tl + 1)) <= kOctBlock) tl++;
+                    const int T = 1 << tl, j = tid >> tl, sub = tid & (T - 1);
+                    const bool vec = (((unsigned) (uintptr_t) S.sk[0]) & 15u) == 0;   // (LDS offset; the host rounds the list capacity to a multiple of 4)
+                    unsigned key = 0;
+                    int rank = 0;
+                    if (j < nE) {
+                        key = S.sk[0][j];
+                        const int per = (((nE + T - 1) >> tl) + 3) & ~3;
+                        int q = sub * per;
+                        const int q1 = min(nE, q + per);
+                        if (vec)
+                            for (; q + 4 <= q1; q += 4) {
+                                const uint4 k4 = *(const uint4 *) &S.sk[0][q];
+                                rank += (int) (k4.x < key) + (int) (k4.y < key) + (int) (k4.z < key) + (int) (k4.w < key);
+                            }
+                        for (; q < q1; q++) rank += S.sk[0][q] < key;
+                    }
+                    for (int d = 1; d < T; d <<= 1) rank += __shfl_xor(rank, d);
+                    if (j < nE && sub == 0) {
                         S.sk[1][rank] = key;
-                        S.sv[1][rank] = S.sv[0][tid];
+                        S.sv[1][rank] = S.sv[0][j];
                     }
                     __syncthreads();
                     ek = S.sk[1];
@@ -1801,6 +1897,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
                 cur = nxt2;
                 n = totC + (n - nProc);
                 nE = totE2;
+                OBFS(-n);
                 if (n >= N || n == prev2) finish = true;
             }
         }
@@ -1842,9 +1939,18 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
         }
         __syncthreads();
         // the candidates once more, linearly: best (score, then smallest index) per node
-        for (int i = tid; i < M; i += kOctBlock) {
-            const unsigned w = key0[i];
-            atomicMax((unsigned *) &S.kArr[PS[w & 0xFFFFu]], ((w >> 16) << 24) | (0xFFFFFFu - (unsigned) i));
+        constexpr int kFU = 4;   // (every load of a round in flight before the first LDS operation: 60 dependent global round trips per thread were 40 us of a 3840x2160 level)
+        for (int i0 = tid; i0 < M; i0 += kFU * kOctBlock) {
+            unsigned w[kFU];
+#pragma unroll
+            for (int u = 0; u < kFU; u++) w[u] = key0[min(i0 + u * kOctBlock, M - 1)];
+#pragma unroll
+            for (int u = 0; u < kFU; u++) {
+                const int i = i0 + u * kOctBlock;
+                const int node = i < M ? PS[w[u] & 0xFFFFu] : -2 - lane;
+                const unsigned v = row_run_max(node, ((w[u] >> 16) << 24) | (0xFFFFFFu - (unsigned) i));
+                if (node >= 0 && row_run_last(node)) atomicMax((unsigned *) &S.kArr[node], v);
+            }
         }
     } else
     for (int i0 = wave * 4; i0 < n; i0 += (kOctBlock / 64) * 4) {   // sixteen lanes (a DPP row) per node: arg-max over its range (LDS / DPP only);
@@ -1895,6 +2001,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
     OSTAMP(5);
     if (dbg && tid == 0 && f == 0) { dbg[l * 8 + 6] = M; dbg[l * 8 + 7] = n; }
 #undef OSTAMP
+#undef OBFS
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2531,7 +2638,7 @@ void launch_fast_tab_persist(hipStream_t st, const FrameSet &fs, const FastCellR
 }
 
 size_t octree_lds_bytes(int maxCellsPerLevel, int cap, int ldsCand, bool globalNodes) {
-    return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + (globalNodes ? 0 : 19 * (size_t) cap) + 4 * (size_t) ldsCand);
+    return sizeof(int) * ((size_t) maxCellsPerLevel + 1 + 3 + (globalNodes ? 0 : 19 * (size_t) cap) + 4 * (size_t) ldsCand);
 }
 
 size_t octree_hist_lds_bytes(int regionInts, int histBins) { return sizeof(int) * ((size_t) regionInts + (size_t) histBins + 1); }
@@ -2549,19 +2656,19 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, int leve
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
                    uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena,
-                   int regionInts, int histBins) {
+                   int regionInts, int histBins, int helpers, int *gHist, int *gDone) {
     if (histBins > 0)
-        hipLaunchKernelGGL((k_octree<false, true>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
+        hipLaunchKernelGGL((k_octree<false, true>), dim3(nLaunchLevels, nFrames, helpers > 1 && gHist ? helpers : 1), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, 0,
-                           dbg, nullptr, regionInts, histBins);
+                           dbg, nullptr, regionInts, histBins, helpers > 1 ? gHist : nullptr, gDone);
     else if (nodeArena)
         hipLaunchKernelGGL((k_octree<true, false>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
-                           dbg, nodeArena, 0, 0);
+                           dbg, nodeArena, 0, 0, nullptr, nullptr);
     else
         hipLaunchKernelGGL((k_octree<false, false>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
-                           dbg, nodeArena, 0, 0);
+                           dbg, nodeArena, 0, 0, nullptr, nullptr);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,

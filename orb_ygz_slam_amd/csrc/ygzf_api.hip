@@ -283,7 +283,7 @@ int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
             g.kpCap = 0;
         }
         kpBase += g.kpCap;
-        G.kpCapMax = std::max(G.kpCapMax, g.kpCap);
+        G.kpCapMax = std::max(G.kpCapMax, (g.kpCap + 3) & ~3);   // (a multiple of 4: k_octree's per-node arrays stay 16-byte aligned)
     }
     G.pyrBytes = off;
     plan_pyr_strips(G, L);
@@ -403,12 +403,12 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
                 for (; l < L && (grp.n == 0 || 2 * G.lv[l].kpCap > G.lv[grp.l0].kpCap); l++, grp.n++) {
                     const LevelGeom &g = G.lv[l];
                     const int nc = g.nCols * g.nRows;
-                    grp.cap = std::max(grp.cap, g.kpCap);
+                    grp.cap = std::max(grp.cap, (g.kpCap + 3) & ~3);
                     cells = std::max(cells, nc + 1);
                     if (nc > 0)
                         tabs = std::max(tabs, nc + 1 + std::max(g.regW, g.nCols * g.wCell) + 9 + std::max(g.regH, g.nRows * g.hCell) + 9 + nc);
                 }
-                if (grp.cap < 1) grp.cap = 1;
+                if (grp.cap < 4) grp.cap = 4;
                 const size_t budget = 150 * 1024;
                 grp.histBins = binsEnv >= 4 && binsEnv <= 8192 ? binsEnv : 8192;
                 grp.regionInts = std::max(std::max(19 * grp.cap, cells), tabs);
@@ -432,11 +432,11 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
             for (int l = 0; l < L; l++) {
                 const LevelGeom &g = G.lv[l];
                 const int nc = g.nCols * g.nRows;
-                grp.cap = std::max(grp.cap, g.kpCap);
+                grp.cap = std::max(grp.cap, (g.kpCap + 3) & ~3);
                 cells = std::max(cells, nc + 1);
                 if (nc > 0) tabs = std::max(tabs, nc + 1 + std::max(g.regW, g.nCols * g.wCell) + 9 + std::max(g.regH, g.nRows * g.hCell) + 9 + nc);
             }
-            if (grp.cap < 1) grp.cap = 1;
+            if (grp.cap < 4) grp.cap = 4;
             const size_t budget = 150 * 1024;
             // bins: sixteen per node the largest level may end with (a tree of N leaves rarely splits below the depth that offers 16 N cells; if it
             // does, the level restarts on the sorting path) -- the prefix sum over 8192 bins was 3.3 of a level's 29 us, over 2048 it is 1
@@ -654,11 +654,31 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             const bool small = c->haveOctSmall && nFrames * L <= c->octSmallWgs;
             if (small) {
                 const auto &grp = c->octSmall;
+                // helper workgroups for the keys of a level (k_octree): as many as keep the WHOLE launch resident at one workgroup per compute unit
+                // (workgroup 0 of a level waits for its helpers), at most 8, and only where a level is worth the hand-over (a few microseconds)
+                int helpers = (int) forced("oct_helpers", -1);
+                if (helpers < 0) helpers = G.totalCells >= 2000 ? std::min(8, std::max(1, c->cuCount) / std::max(1, nFrames * L)) : 1;
+                helpers = std::max(1, std::min(helpers, std::min(8, std::max(1, c->cuCount / std::max(1, nFrames * L)))));
+                int *gHist = nullptr, *gDone = nullptr;
+                if (helpers > 1) {
+                    const size_t words = (size_t) nFrames * L * (helpers - 1) * grp.histBins, bytes = (words + 64) * sizeof(int) + (size_t) nFrames * L * sizeof(int);
+                    void *old = c->dOctHist.p;
+                    int rcH = ensure(c, c->dOctHist, bytes);
+                    if (rcH) return rcH;
+                    // the counters are zeroed once per layout: workgroup 0 of every (level, frame) leaves its counter at zero behind it
+                    if (old != c->dOctHist.p || c->octHistWords != words) {
+                        HIPCHECK(c, hipMemsetAsync((int *) c->dOctHist.p + words, 0, (size_t) nFrames * L * sizeof(int), so));
+                        c->octHistWords = words;
+                    }
+                    gHist = (int *) c->dOctHist.p;
+                    gDone = gHist + words;
+                }
                 launch_octree(so, dGeom, L, grp.l0, grp.n, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
                               (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                               (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
-                              (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins);
+                              (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins,
+                              helpers, gHist, gDone);
             } else if (c->octGroups.empty())
                 launch_octree(so, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
@@ -681,6 +701,12 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             for (int l = 0; l < L; l++)
                 fprintf(stderr, "[ygzf octree lvl %d, 10ns ticks] prefix %lld keys %lld sort %lld bfs %lld final %lld  M=%lld n=%lld\n", l, st[l * 8 + 1] - st[l * 8],
                         st[l * 8 + 2] - st[l * 8 + 1], st[l * 8 + 3] - st[l * 8 + 2], st[l * 8 + 4] - st[l * 8 + 3], st[l * 8 + 5] - st[l * 8 + 4], st[l * 8 + 6], st[l * 8 + 7]);
+            for (int l = 0; l < L; l++) {   // the tree passes: list size after the one-wave head, after every full pass (+) and every expand round (-), ticks since the passes began
+                const long long *ev = st + 16 * 8 + 16 + l * 16;
+                fprintf(stderr, "[ygzf octree lvl %d passes]", l);
+                for (int k = 0; k < 8 && ev[2 * k + 1]; k++) fprintf(stderr, " %+lld@%lld", ev[2 * k], ev[2 * k + 1] - st[l * 8 + 3]);
+                fprintf(stderr, "\n");
+            }
             if (!c->octGroups.empty()) {
                 fprintf(stderr, "[ygzf octree histogram plan: %zu launches;", c->octGroups.size());
                 for (const auto &grp : c->octGroups) fprintf(stderr, " levels %d-%d cap %d bins %d lds %zu;", grp.l0, grp.l0 + grp.n - 1, grp.cap, grp.histBins, grp.lds);
@@ -861,7 +887,7 @@ void ygzf_destroy(ygzf_ctx *c) {
                              &c->dK0, &c->dV0, &c->dK1, &c->dV1, &c->dXY, &c->dLvlXY, &c->dLvlScore, &c->dLvlCnt, &c->dLvlBase, &c->dLvlCand,
                              &c->dOutKp, &c->dOutDesc, &c->dOutCnt, &c->dTmpA, &c->dTmpB, &c->dTmpC, &c->dWorld, &c->dOwner, &c->dMatch,
                              &c->dNMatch, &c->dPoses, &c->dQp, &c->dProcOrder, &c->dSpill, &c->dCarryPyr, &c->dOctNodes, &c->dResPack, &c->dFastCtr,
-                             &c->dPyrPlan, &c->dPyrCols, &c->dPyrRows, &c->dPyrTiles};
+                             &c->dPyrPlan, &c->dPyrCols, &c->dPyrRows, &c->dPyrTiles, &c->dOctHist};
     for (auto *b : bufs)
         if (b->p) (void) hipFree(b->p);
     for (auto &b : c->dGen)

@@ -66,7 +66,7 @@ struct ygzf_ctx {
     };
     Buf dGeom, dXofs, dXalpha, dYofs, dYbeta, dImg0, dPyr, dCellCnt, dSlots, dK0, dV0, dK1, dV1, dXY, dLvlXY, dLvlScore,
         dLvlCnt, dLvlBase, dLvlCand, dOutKp, dOutDesc, dOutCnt, dTmpA, dTmpB, dTmpC, dWorld, dOwner, dMatch, dNMatch, dPoses, dQp,
-        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dStBins, dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan, dPyrCols, dPyrRows, dPyrTiles;
+        dGen[12], dVoc[3], dBow[3], dSia[8], dProcOrder, dF10[6], dSpill, dCarryPyr, dAl[5], dDso[8], dSt[6], dStBins, dCacheImg, dCachePyr, dDir[8], dFr[6], dSplitCnt, dSplitX, dPyrPlan, dPyrCols, dPyrRows, dPyrTiles, dOctHist;
     int vocNodes = 0, vocLevels = 0;
     int cacheSlots = 0, cacheW = 0, cacheH = 0, cachePitch = 0;
     long long cachePyrBytes = 0;
@@ -88,6 +88,7 @@ struct ygzf_ctx {
     std::vector<OctGroup> octGroups;
     OctGroup octSmall;                     // all levels in ONE histogram-plan launch: launches of a few frames (see run_extract)
     bool haveOctSmall = false;
+    size_t octHistWords = 0;   // layout dOctHist's counters were last cleared for (k_octree's helper workgroups)
     static constexpr int octSmallWgs = 128;   // launches of up to this many workgroups take it (752x480: 16 frames 0.211 against 0.221 ms, 64 frames 0.439 against 0.430)
     Buf dOctNodes;
     // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at

@@ -85,3 +85,48 @@ def test_automatic_plan_of_the_large_configs(oracle):
             res.append(ex.batch_fetch(0))
             ex.close()
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("case", [0, 1, 4, 5])
+@pytest.mark.parametrize("helpers", [2, 8])
+def test_helper_workgroups_give_the_same_tree(oracle, case, helpers):
+    """Launches of a few frames give every (level, frame) of the histogram plan helper workgroups for the keys of its candidates (k_octree, gridDim.z;
+    chosen by the library for 1920x1080 and up): forced here on small images, one and three frames per launch, twice in a row (the hand-over
+    counters must be left at zero), including the level that overflows the histogram and restarts on the sorting path -- the oracle's tree."""
+    from orb_ygz_slam_amd import Extractor
+    w, h, nl, nf, make = CASES[case]
+    img = make()
+    with _env(oct_plan="hist", oct_helpers=helpers):
+        ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+        oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
+        imgs = np.stack([img, np.ascontiguousarray(img[::-1]), img])
+        for rep in range(2):
+            ex.extract_batch_host(imgs[:1])
+            _cmp_frame(oracle, ex, oex, imgs[0], frame=0)
+            ex.extract_batch_host(imgs)
+            _cmp_frame(oracle, ex, oex, imgs[0], frame=0)
+            _cmp_frame(oracle, ex, oex, imgs[1], frame=1)
+            k0, d0 = ex.batch_fetch(0)
+            k2, d2 = ex.batch_fetch(2)
+            assert np.array_equal(k0, k2) and np.array_equal(d0, d2)
+        ex.close()
+
+
+def test_helpers_are_what_the_large_frame_takes(oracle):
+    """one 1920x1080 frame: the library's own choice (eight helpers per level) and no helpers return the same bytes"""
+    from orb_ygz_slam_amd import Extractor
+    w, h, nl, nf = 1920, 1080, 8, 4000
+    img = synth_frame(78, w, h)
+    res = []
+    for helpers in (None, 1):
+        with _env(oct_helpers=helpers):
+            ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=1)
+            ex.extract_batch_host(img[None])
+            res.append(ex.batch_fetch(0))
+            ex.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
+    ok, od = oex.extract(img)
+    for fld in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert (res[0][0][fld] == ok[fld]).all(), fld
+    assert np.array_equal(od, res[0][1])
