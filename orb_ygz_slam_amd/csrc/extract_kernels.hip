@@ -1782,8 +1782,9 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
                     // LDS reads, no histogram, no scan, ONE barrier (the radix sort: three passes of four).  T = 1 .. 16 adjacent lanes share a key, each
                     // counting a quarter-aligned slice of the list with 16-byte reads: one thread per key reading word by word made a round of 512
                     // expandable nodes 8192 wave-wide LDS reads -- 14 of the 22 us of a 1920x1080 level's only expand round.
+                    // (launches of many frames have other workgroups to fill the wait: there one thread per key issues the fewest instructions)
                     int tl = 0;
-                    while (tl < 4 && (nE << (tl + 1)) <= kOctBlock) tl++;
+                    while (gridDim.y <= 16 && tl < 4 && (nE << (tl + 1)) <= kOctBlock) tl++;
                     const int T = 1 << tl, j = tid >> tl, sub = tid & (T - 1);
                     const bool vec = (((unsigned) (uintptr_t) S.sk[0]) & 15u) == 0;   // (LDS offset; the host rounds the list capacity to a multiple of 4)
                     unsigned key = 0;

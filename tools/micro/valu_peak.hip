@@ -80,10 +80,11 @@ constexpr int kIter = 2000, kUnroll = 8, kChains = 8;   // 2000 x 8 x 8 = 128000
         unsigned a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
         unsigned b = seed * 2654435761u + threadIdx.x, c = seed ^ 0x5bd1e995u;                                   \
         unsigned long long msk = 0x5555aaaa3333ccccull * seed, sm = 0;                                           \
+        unsigned z = a0 * 23, z2 = a0 * 29, z3 = a0 * 31;                                                        \
         const long long t0 = clock64(), w0 = wall_clock64();                                                     \
         CHAIN8(OP)                                                                                               \
         const long long t1 = clock64(), w1 = wall_clock64();                                                     \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (unsigned) sm;      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (unsigned) sm ^ z ^ z2 ^ z3; \
         if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1) { clk[0] = t1 - t0; clk[1] = w1 - w0; }             \
     }
 
@@ -162,6 +163,12 @@ KERNEL_S(k_add_s1, OP_ADD_S1) KERNEL_S(k_add_s2, OP_ADD_S2) KERNEL_S(k_lerp_s1, 
 #define OP_MIX13(x) asm volatile("v_lerp_u8 %0, %0, %1, %2\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n\tv_bitop3_b32 %0, %0, %2, %1 bitop3:0x96\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0xe8" : "+v"(x) : "v"(b), "v"(c));
 #define OP_MIXPA(x) asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_add_u32 %0, %0, %1" : "+v"(x) : "v"(b), "v"(c));
 #define OP_MIXMA(x) asm volatile("v_mul_hi_u32 %0, %0, %1\n\tv_and_b32 %0, %0, %2" : "+v"(x) : "v"(b), "v"(c));
+// the same mixes with the half-rate instructions on accumulators of their own (no instruction waits for its neighbour's result)
+#define OP_MIXI11(x) asm volatile("v_lerp_u8 %0, %0, %2, %3\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96" : "+v"(x), "+v"(z) : "v"(b), "v"(c));
+#define OP_MIXI13(x) asm volatile("v_lerp_u8 %0, %0, %4, %5\n\tv_bitop3_b32 %1, %1, %4, %5 bitop3:0x96\n\tv_bitop3_b32 %2, %2, %5, %4 bitop3:0x96\n\tv_bitop3_b32 %3, %3, %4, %5 bitop3:0xe8" : "+v"(x), "+v"(z), "+v"(z2), "+v"(z3) : "v"(b), "v"(c));
+#define OP_MIXIPA(x) asm volatile("v_perm_b32 %0, %0, %2, %3\n\tv_add_u32 %1, %1, %2" : "+v"(x), "+v"(z) : "v"(b), "v"(c));
+#define OP_MIXI31(x) asm volatile("v_lerp_u8 %0, %0, %2, %3\n\tv_perm_b32 %0, %0, %2, %3\n\tv_alignbyte_b32 %0, %0, %2, 1\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96" : "+v"(x), "+v"(z) : "v"(b), "v"(c));
+KERNEL(k_mixi11, OP_MIXI11) KERNEL(k_mixi13, OP_MIXI13) KERNEL(k_mixipa, OP_MIXIPA) KERNEL(k_mixi31, OP_MIXI31)
 KERNEL(k_mix11, OP_MIX11) KERNEL(k_mix13, OP_MIX13) KERNEL(k_mixpa, OP_MIXPA) KERNEL(k_mixma, OP_MIXMA)
 
 typedef void (*kern_t)(unsigned *, long long *, unsigned);
@@ -175,7 +182,7 @@ int main(int argc, char **argv) {   // optional arguments: substrings of the ins
     long long *clk;
     hipMalloc(&out, (size_t) cus * 8 * 256 * 4 + 1024);
     hipMalloc(&clk, 64);
-    struct { const char *name; kern_t k; int mult; } ks[] = {{"lerp+bitop3 (per pair)", k_mix11, 1}, {"lerp+3 bitop3 (per 4)", k_mix13, 1}, {"perm+add (per pair)", k_mixpa, 1}, {"mul_hi+and (per pair)", k_mixma, 1}, {"v_lerp_u8", k_lerp}, {"v_bitop3_b32", k_bitop3}, {"v_or3_b32", k_or3}, {"v_add_u32", k_add}, {"v_alignbyte_b32", k_align},
+    struct { const char *name; kern_t k; int mult; } ks[] = {{"indep lerp+bitop3 (per pair)", k_mixi11, 1}, {"indep lerp+3 bitop3 (per 4)", k_mixi13, 1}, {"indep perm+add (per pair)", k_mixipa, 1}, {"indep 3 quarter + bitop3 (per 4)", k_mixi31, 1}, {"lerp+bitop3 (per pair)", k_mix11, 1}, {"lerp+3 bitop3 (per 4)", k_mix13, 1}, {"perm+add (per pair)", k_mixpa, 1}, {"mul_hi+and (per pair)", k_mixma, 1}, {"v_lerp_u8", k_lerp}, {"v_bitop3_b32", k_bitop3}, {"v_or3_b32", k_or3}, {"v_add_u32", k_add}, {"v_alignbyte_b32", k_align},
                                                    {"v_perm_b32", k_perm}, {"v_dot4_u32_u8", k_dot4}, {"v_sad_u8", k_sad}, {"v_pk_min_u16", k_pkmin}, {"v_pk_add_u16", k_pkadd},
                                                    {"v_mul_u32_u24", k_mul24}, {"v_mul_lo_u32", k_mullo}, {"v_cmp_lt_u32", k_cmp}, {"v_cndmask_b32", k_cndmask},
                                                    {"v_add_u32_dpp", k_dpp}, {"v_mbcnt_lo", k_mbcnt}, {"v_fma_f32", k_fma}, {"v_pk_fma_f32", k_pkfma},
