@@ -335,6 +335,33 @@ def test_pyramid_one_launch_and_level_by_level(oracle, monkeypatch, w, h, nl, sf
             del ex
 
 
+@pytest.mark.parametrize("sf", [1.2, 1.1, 1.27])
+def test_pyramid_tiles_of_every_fold(oracle, monkeypatch, sf):
+    """k_pyr_resize_tiled cuts a level into 256-column tiles and what is left into 128- / 64- / 32-column tiles whose waves fold 2 / 4 / 8 rows into one
+    pass (csrc/extract_kernels.hip, host tables in ygzf_api.hip): level widths with every kind of remainder -- none, 1 .. 31 columns, each binary
+    piece alone and together, just below and above a 256-column tile -- and heights that end inside a tile, inside a wave and inside a pass, one
+    frame (the graph path) and three per launch; every level byte for byte the oracle's cv::resize."""
+    from orb_ygz_slam_amd import Extractor
+    from orb_ygz_slam_amd.capi import force_env
+    monkeypatch.setenv("YGZF_FORCE", force_env(pyr_strip_frames="0"))
+    rng = np.random.default_rng(int(sf * 100))
+    level1 = [31, 32, 33, 64, 95, 128, 129, 160, 223, 224, 225, 255, 256, 257, 266, 288, 320, 383, 448, 479, 512, 522, 544, 767, 1000]
+    for i, w1 in enumerate(level1):
+        w = int(round(w1 * sf)) + 1
+        h = [64, 97, 130, 301][i % 4]
+        imgs = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+        oex = oracle.Extractor(200, sf, 3, 20, 7)
+        ex = Extractor(200, sf, 3, 20, 7, max_width=w, max_height=h, max_batch=3)
+        for batch in (imgs[:1], imgs):
+            ex.extract_batch_host(batch)
+            for f in range(len(batch)):
+                want = oex.pyramid(batch[f])
+                for l in range(3):
+                    got = ex.batch_fetch_level(f, l)
+                    assert got.shape == want[l].shape and (got == want[l]).all(), (w, h, f, l)
+        ex.close()
+
+
 def test_pyramid_contexts_of_different_sizes_on_one_device(oracle):
     """The one-launch pyramid chain asks the runtime for a large LDS allotment per workgroup (123 KB for 1920x1080, 44 KB for 320x240); the
     allotment belongs to the kernel on the device, not to a context: a context of small images prepared AFTER one of large images must not
