@@ -1380,7 +1380,13 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
 #define OSTAMP(k) do { if (dbg && tid == 0 && f == 0 && part == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
     OSTAMP(0);
     int bfsEv = 0;
+// (the tree passes' own stamps exist in the -DYGZF_PHASE_CLOCK build only: eight conditional stamps inside the pass loops cost the product build 10 % more vector
+// instructions in this kernel -- 23 k per frame -- although the branch is never taken)
+#ifndef YGZF_PHASE_CLOCK
+#define OBFS(nn) do { } while (0)
+#else
 #define OBFS(nn) do { if (dbg && tid == 0 && f == 0 && part == 0 && bfsEv < 8) { dbg[16 * 8 + 16 + l * 16 + 2 * bfsEv] = (nn); dbg[16 * 8 + 16 + l * 16 + 2 * bfsEv + 1] = wall_clock64(); bfsEv++; } } while (0)
+#endif
     const LevelGeom g = geom[l];
     const int nCells = g.nCols * g.nRows;
     int *lvlCnt = lvlKpCnt + f * nlevels + l;
@@ -1794,12 +1800,14 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
                         const int per = (((nE + T - 1) >> tl) + 3) & ~3;
                         int q = sub * per;
                         const int q1 = min(nE, q + per);
+                        // rank += (k < key) as compare + add-with-carry: two instructions per key (the compiler's select-and-add form is three)
+                        auto count = [&](unsigned k) { asm("v_cmp_lt_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(rank) : "v"(k), "v"(key) : "vcc"); };
                         if (vec)
                             for (; q + 4 <= q1; q += 4) {
                                 const uint4 k4 = *(const uint4 *) &S.sk[0][q];
-                                rank += (int) (k4.x < key) + (int) (k4.y < key) + (int) (k4.z < key) + (int) (k4.w < key);
+                                count(k4.x); count(k4.y); count(k4.z); count(k4.w);
                             }
-                        for (; q < q1; q++) rank += S.sk[0][q] < key;
+                        for (; q < q1; q++) count(S.sk[0][q]);
                     }
                     for (int d = 1; d < T; d <<= 1) rank += __shfl_xor(rank, d);
                     if (j < nE && sub == 0) {

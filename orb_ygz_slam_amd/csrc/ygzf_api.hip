@@ -701,8 +701,9 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             for (int l = 0; l < L; l++)
                 fprintf(stderr, "[ygzf octree lvl %d, 10ns ticks] prefix %lld keys %lld sort %lld bfs %lld final %lld  M=%lld n=%lld\n", l, st[l * 8 + 1] - st[l * 8],
                         st[l * 8 + 2] - st[l * 8 + 1], st[l * 8 + 3] - st[l * 8 + 2], st[l * 8 + 4] - st[l * 8 + 3], st[l * 8 + 5] - st[l * 8 + 4], st[l * 8 + 6], st[l * 8 + 7]);
-            for (int l = 0; l < L; l++) {   // the tree passes: list size after the one-wave head, after every full pass (+) and every expand round (-), ticks since the passes began
+            for (int l = 0; l < L; l++) {   // the tree passes (-DYGZF_PHASE_CLOCK builds only): list size after the one-wave head, after every full pass (+) and every expand round (-), ticks since the passes began
                 const long long *ev = st + 16 * 8 + 16 + l * 16;
+                if (!ev[1]) continue;
                 fprintf(stderr, "[ygzf octree lvl %d passes]", l);
                 for (int k = 0; k < 8 && ev[2 * k + 1]; k++) fprintf(stderr, " %+lld@%lld", ev[2 * k], ev[2 * k + 1] - st[l * 8 + 3]);
                 fprintf(stderr, "\n");

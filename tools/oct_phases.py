@@ -1,5 +1,6 @@
 """tools/oct_phases.py [workload] [frames] -- per-phase clock of k_octree for frame 0 of a batch (YGZF_DEBUG=oct timestamps, 10 ns ticks).
-workload: a key of bench.WORKLOADS (default euroc752x480_8lvl_1000feat); frames: batch size (default: the bench's sub-batch of the workload)."""
+workload: a key of bench.WORKLOADS (default euroc752x480_8lvl_1000feat); frames: batch size (default: the bench's sub-batch of the workload).
+With YGZF_LIBRARY=orb_ygz_slam_amd/lib_ab/libygzf_clk.so (python -m orb_ygz_slam_amd.build --phase-clock) every tree pass is stamped as well."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
