@@ -255,6 +255,9 @@ class Pipeline:
         self.batch = total
         self.exs = [Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=sub, device=device) for _ in range(streams)]
         self.cam = make_camera(w, h)
+        if not (match or align):           # nothing reads the carried "previous frame" (include/ygzf.h: ygzf_set_carry_previous)
+            for e in self.exs:
+                e.set_carry_previous(False)
         self.w, self.h, self.nl = w, h, nl
         p0 = self.d_frames.data_ptr()
         self.ptrs = [[p0 + ((r * streams + s) * sub) * w * h for s in range(streams)] for r in range(rounds)]
@@ -342,6 +345,8 @@ def end_to_end(pipe, min_seconds=1.2, depth=2, host_pitch=None):
     exs = list(pipe.exs[:depth])
     while len(exs) < depth:
         exs.append(Extractor(nf, sf, nl, ini, mn, max_width=w, max_height=h, max_batch=B, device=pipe.device))
+        if not (pipe.match or pipe.align):
+            exs[-1].set_carry_previous(False)
     stride = exs[0].max_keypoints(w, h)
     from orb_ygz_slam_amd.capi import host_row_pitch
     hp = host_row_pitch(w) if host_pitch is None else host_pitch      # frames laid out at the device's row pitch go up as whole frames, not row by row
@@ -359,7 +364,8 @@ def end_to_end(pipe, min_seconds=1.2, depth=2, host_pitch=None):
 
     def submit(i):
         exs[i].extract_batch_host(pins[i])
-        exs[i].match_batch_prev(pipe.cam, 15.0, True, True, True)
+        if pipe.match:
+            exs[i].match_batch_prev(pipe.cam, 15.0, True, True, True)
         if pipe.stereo:
             exs[i].stereo_batch(0.11, 47.9)                                # (its mvuRight / mvDepth rows stay on the device: 8 more bytes per keypoint)
     for i in range(depth):                                                 # warm-up

@@ -117,6 +117,11 @@ int ygzf_phase_clocks(ygzf_ctx *ctx, int kernel, unsigned long long *out16, int 
  * results (same keypoints, same bytes).  The price: the extraction is computed for every pyramid, also when no ygzf_extract_resident
  * follows, and it counts as an extraction for the batch calls' "previous frame" (ygzf_match_batch_prev / ygzf_align_batch_prev). */
 int ygzf_set_extract_ahead(ygzf_ctx *ctx, int on);
+/* The carried "previous frame" (default on).  Every batch extraction first copies the last frame of the batch before it into slot 0 of the result arrays: the
+ * Last frame of pair 0 in ygzf_match_batch_prev / ygzf_align_batch_prev (the reference: Tracking keeps mLastFrame, src/Tracking.cc:1262).  A caller that only
+ * extracts (or only pairs stereo eyes) can switch it off: one launch less per extraction, and a host-frame call's upload no longer waits behind it.  While it is
+ * off ygzf_match_batch_prev and ygzf_align_batch_prev return YGZF_ERR_STATE; switched on again, the next extraction carries the then-last frame as usual. */
+int ygzf_set_carry_previous(ygzf_ctx *ctx, int on);
 
 /* ORBextractor::GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:84-106); arrays of nlevels floats, any may be NULL. */

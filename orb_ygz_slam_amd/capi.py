@@ -160,6 +160,7 @@ def load_library(build_if_missing=True):
     L.ygzf_get_fast_plan.argtypes = [vp, vp]
     L.ygzf_set_fast_kernel.argtypes = [vp, C.c_int]
     L.ygzf_set_extract_ahead.argtypes = [vp, C.c_int]
+    L.ygzf_set_carry_previous.argtypes = [vp, C.c_int]
     L.ygzf_features_in_area.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_int, vp, vp]
     L.ygzf_sia_run.argtypes = [vp, C.POINTER(SiaFrame), C.POINTER(SiaFrame), C.POINTER(Camera), vp, C.c_int, C.c_int, C.c_int, vp,
                                C.POINTER(C.c_size_t), vp, vp]
@@ -669,6 +670,10 @@ class Extractor:
     def set_extract_ahead(self, on):
         """compute_pyramid also queues the extraction of the same image; extract_resident then only collects it (include/ygzf.h)."""
         self._ck(self.L.ygzf_set_extract_ahead(self.h, 1 if on else 0))
+
+    def set_carry_previous(self, on):
+        """off: extractions no longer carry the previous batch's last frame into slot 0 (the batch matchers then raise; include/ygzf.h)."""
+        self._ck(self.L.ygzf_set_carry_previous(self.h, 1 if on else 0))
 
     def fast_plan(self):
         p = C.c_int(0)

@@ -555,12 +555,18 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
     ygzf_kp *outKp = (ygzf_kp *) c->dOutKp.p;
     uint8_t *outDesc = (uint8_t *) c->dOutDesc.p;
     int *outCnt = (int *) c->dOutCnt.p;
-    if (!c->carryLaunched) launch_carry_slot(c->stream, outKp, outDesc, outCnt, (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
+    if (!c->carryLaunched) {
+        if (c->carryOff) c->slot0Stale = true;
+        else {
+            launch_carry_slot(c->stream, outKp, outDesc, outCnt, (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
+            c->slot0Stale = false;
+        }
+    }
     c->carryLaunched = false;
     outKp += G.kpStride;
     outDesc += (size_t) G.kpStride * 32;
     outCnt += 1;
-    if (c->alignCarry && G.pyrBytes > 0) {   // the previous batch's last pyramid is the reference of pair 0 in ygzf_align_batch_prev
+    if (c->alignCarry && !c->carryOff && G.pyrBytes > 0) {   // the previous batch's last pyramid is the reference of pair 0 in ygzf_align_batch_prev
         int rc2 = ensure(c, c->dCarryPyr, (size_t) G.pyrBytes + 256);
         if (rc2) return rc2;
         c->carryPyrValid = c->carryValid && c->lastFrames > 0 && (!pyramidReady || pyramidCarried);
@@ -982,6 +988,12 @@ int ygzf_set_fast_kernel(ygzf_ctx *c, int kernel) {
     return YGZF_OK;
 }
 
+int ygzf_set_carry_previous(ygzf_ctx *c, int on) {
+    if (!c) return YGZF_ERR_INVALID;
+    c->carryOff = !on;
+    return YGZF_OK;
+}
+
 int ygzf_set_extract_ahead(ygzf_ctx *c, int on) {
     if (!c) return YGZF_ERR_INVALID;
     HIPCHECK(c, hipSetDevice(c->device));
@@ -1089,7 +1101,7 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     // extract-ahead counts as an extraction for ygzf_align_batch_prev: the previous extraction's last pyramid (the reference image of pair 0)
     // leaves dPyr before this frame's pyramid is written over it
     bool pyramidCarried = false;
-    if (c->extractAhead && c->streamCopy && c->alignCarry && c->geo.pyrBytes > 0 && c->carryValid && c->lastFrames > 0) {
+    if (c->extractAhead && c->streamCopy && c->alignCarry && !c->carryOff && c->geo.pyrBytes > 0 && c->carryValid && c->lastFrames > 0) {
         if ((rc = ensure(c, c->dCarryPyr, (size_t) c->geo.pyrBytes + 256))) return rc;
         HIPCHECK(c, hipMemcpyAsync(c->dCarryPyr.p, (uint8_t *) c->dPyr.p + (size_t) (c->lastFrames - 1) * c->geo.pyrBytes, (size_t) c->geo.pyrBytes,
                                    hipMemcpyDeviceToDevice, c->stream));
@@ -1167,6 +1179,9 @@ int ygzf_extract_batch_device(ygzf_ctx *c, const uint8_t *d_imgs, int n_frames, 
 // while they cross the link instead of between their arrival and the pyramid (6 us of a one-frame call).  run_extract then skips its own.
 static void carry_early(ygzf_ctx *c) {
     const Geometry &G = c->geo;
+    c->carryLaunched = true;
+    if (c->carryOff) { c->slot0Stale = true; return; }
+    c->slot0Stale = false;
     launch_carry_slot(c->stream, (ygzf_kp *) c->dOutKp.p, (uint8_t *) c->dOutDesc.p, (int *) c->dOutCnt.p,
                       (c->carryValid && c->lastFrames > 0 && G.kpStride > 0) ? (long long) c->lastFrames : 0, G.kpStride);
     c->carryLaunched = true;

@@ -330,6 +330,7 @@ int ygzf_find_direct_projection_batch(ygzf_ctx *c, const ygzf_camera *cam, int c
 int ygzf_align_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, int max_level, int min_level, int n_iter) {
     if (!c || !cam) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (c->slot0Stale) return fail(c, YGZF_ERR_STATE, "the previous frame was not carried (ygzf_set_carry_previous is off)");
     const int L = c->tab.cfg.nlevels;
     if (min_level < 1 || max_level < min_level || max_level >= L)
         return fail(c, YGZF_ERR_INVALID, "level range [%d,%d] (the resident form aligns on pyramid levels >= 1, as Tracking does)", min_level, max_level);

@@ -69,6 +69,7 @@ static int plan_match_lds(ygzf_ctx *c, MatchArgs &A, int nPairs, size_t *ldsByte
 int ygzf_match_batch_prev(ygzf_ctx *c, const ygzf_camera *cam, float th, int b_mono, int check_level, int check_orientation) {
     if (!c || !cam) return fail(c, YGZF_ERR_INVALID, "null argument");
     if (c->lastFrames < 1) return fail(c, YGZF_ERR_STATE, "no extracted batch");
+    if (c->slot0Stale) return fail(c, YGZF_ERR_STATE, "the previous frame was not carried (ygzf_set_carry_previous is off)");
     HIPCHECK(c, hipSetDevice(c->device));
     const Geometry &G = c->geo;
     const int B = c->lastFrames;

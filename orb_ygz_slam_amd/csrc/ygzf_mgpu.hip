@@ -304,6 +304,8 @@ int run_job(ygzf_mgpu *m, const Job &J) {
         std::vector<const uint8_t *> ptrs((size_t) chunk);
         std::vector<int> nm(n, 0);
         auto cx = [&](int k) { return d.ctx[alternate ? (k & 1) : 0]; };
+        // only the matcher reads the carried "previous frame": extraction-only and stereo jobs leave it out (one launch less in front of every upload)
+        for (ygzf_ctx *q : d.ctx) (void) ygzf_set_carry_previous(q, J.mode == kMatch ? 1 : 0);
         const int sp = ygzf_host_row_pitch(w);   // the staging area carries the device's row pitch: a chunk goes up as whole frames, not row by row
         if (!pinned && !d.hIn[0]) {              // first pageable job of this slot: page-lock its three input staging areas (sized for the handle's maxima)
             const size_t bytes = (size_t) m->chunk * (size_t) ygzf_host_row_pitch(m->maxW) * (size_t) m->maxH;

@@ -130,6 +130,9 @@ def test_round6_entry_points_report_misuse():
     assert L.ygzf_batch_fetch_packed(a.h, host.ctypes.data_as(C.c_void_p), 1000, C.byref(ok), C.byref(od), C.byref(row), C.byref(by)) < 0
     assert b"packed results need" in L.ygzf_last_error(a.h)
     assert L.ygzf_batch_fetch_packed(a.h, host.ctypes.data_as(C.c_void_p), host.nbytes, C.byref(ok), C.byref(od), C.byref(row), C.byref(by)) == 0 and by.value > 0
+    # the carry switch: no context
+    L.ygzf_set_carry_previous.argtypes = [C.c_void_p, C.c_int]
+    assert L.ygzf_set_carry_previous(None, 0) < 0
     # the pair entry point: the same context twice, a null eye, a pitch below the width
     L.ygzf_stereo_pair_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

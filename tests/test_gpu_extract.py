@@ -438,3 +438,36 @@ def test_packed_fetch_equals_fetch_all():
             k, d = ex.batch_fetch(f)
             assert cnt[f] == len(k) and np.array_equal(kps[f, :cnt[f]], k) and np.array_equal(desc[f, :cnt[f]], d), (w, h, n, f)
     ex.close()
+
+
+def test_carry_previous_switch(oracle):
+    """ygzf_set_carry_previous (include/ygzf.h): off, a batch extraction returns the same bytes and leaves slot 0 alone -- the batch matcher then
+    refuses (there is no Last frame for pair 0, src/Tracking.cc:1262); on again, the next extraction carries the then-last frame and the matcher's
+    pair 0 is what an uninterrupted context computes."""
+    from orb_ygz_slam_amd import Extractor, make_camera
+    from orb_ygz_slam_amd.capi import YgzfError
+    w, h = 752, 480
+    imgs = np.stack([synth_frame(300 + i, w, h) for i in range(4)])
+    cam = make_camera(w, h)
+    ref = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+    ref.extract_batch_host(imgs[:2])
+    ex.extract_batch_host(imgs[:2])
+    ex.set_carry_previous(False)
+    ref.extract_batch_host(imgs[:2])
+    ex.extract_batch_host(imgs[:2])
+    for f in range(2):
+        (ka, da), (kb, db) = ref.batch_fetch(f), ex.batch_fetch(f)
+        assert np.array_equal(ka, kb) and np.array_equal(da, db)
+    with pytest.raises(YgzfError):
+        ex.match_batch_prev(cam, 15.0, True, True, True)
+    ex.set_carry_previous(True)
+    ref.extract_batch_host(imgs[2:])
+    ex.extract_batch_host(imgs[2:])
+    ref.match_batch_prev(cam, 15.0, True, True, True)
+    ex.match_batch_prev(cam, 15.0, True, True, True)
+    assert np.array_equal(ref.match_counts(), ex.match_counts()) and ref.match_counts()[0] > 50
+    for f in range(2):
+        (ma, oa), (mb, ob) = ref.match_fetch(f), ex.match_fetch(f)
+        assert np.array_equal(ma, mb) and np.array_equal(oa, ob)
+    ref.close(); ex.close()
