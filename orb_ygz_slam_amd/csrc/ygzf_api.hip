@@ -625,7 +625,9 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             const int perCu = tab ? (int) std::min<size_t>((size_t) forced("fast_persist_wgs", 8), (size_t) (160 * 1024) / std::max<size_t>(fastLds, 1)) : 0;
             const int resident = perCu * c->cuCount;
             const int persistMode = (int) forced("fast_persist", -1);   // tests: 1 always, 0 never
-            const bool persist = tab && resident > 0 && (persistMode == 1 || (persistMode != 0 && G.totalGroups >= 1000 && (long long) nFrames * G.totalGroups >= 4LL * resident));
+            // (forced or not, never for a launch of fewer than 64 cell groups: the items are dealt to the eight XCDs' workgroups, and a launch of two workgroups has none on six of them)
+            const bool persist = tab && resident > 0 && (long long) nFrames * G.totalGroups >= 64 &&
+                                 (persistMode == 1 || (persistMode != 0 && G.totalGroups >= 1000 && (long long) nFrames * G.totalGroups >= 4LL * resident));
             if (persist) {
                 int rcC = ensure(c, c->dFastCtr, kFastPersistCounterBytes);
                 if (rcC) return rcC;
@@ -777,6 +779,19 @@ int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, i
         bool pageable = true;
         if (hipPointerGetAttributes(&at, imgs) == hipSuccess) pageable = at.type != hipMemoryTypeHost && at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged;
         else (void) hipGetLastError();
+        if (!pageable && at.type == hipMemoryTypeHost && at.devicePointer && (size_t) w * h <= (size_t) forced("upload_kernel_bytes", 16u << 20)) {
+            // a page-locked frame of a Tracking-sized call: a kernel reads it over the link where it lies (ygzf_extract_batch_host_frames says why)
+            HostFrameList L;
+            L.addr[0] = (unsigned long long) (uintptr_t) at.devicePointer;
+            launch_gather_host_frames(c->stream, L, 1, (size_t) row_pitch, (uint8_t *) c->dImg0.p, (size_t) pitch, (size_t) pitch * h, w, h);
+            HIPCHECK(c, hipGetLastError());
+            fs->img0 = (const uint8_t *) c->dImg0.p;
+            fs->img0_stride = (long long) pitch * h;
+            fs->img0_pitch = pitch;
+            fs->pyr = (uint8_t *) c->dPyr.p;
+            fs->pyr_stride = c->geo.pyrBytes;
+            return YGZF_OK;
+        }
         if (pageable) {
             const size_t bytes = (size_t) w * h;
             if (bytes > c->hInBytes) {
@@ -1221,6 +1236,24 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
         // Into a tight staging buffer with the copy engine's fast paths, then ONE launch per 128 frames that lays the rows out at the context's
         // pitch.  Frames that come as runs of u back-to-back frames at one distance S (a device slot's round-robin share of a tight clip: units of u
         // frames, S = slots x u frames) go up as ONE two-dimensional copy whose "rows" are the runs; anything else as one linear copy per frame.
+        // ONE page-locked frame (a Tracking-sized call): a kernel reads it over the link where it lies.  The copy engine starts ~10 us after the copy
+        // is queued and hands over to the first kernel ~8 us after it ends; a kernel's launch and hand-over are a third of that.
+        if (n_frames <= (int) forced("upload_kernel_frames", 2) && (size_t) n_frames * w * h <= (size_t) forced("upload_kernel_bytes", 16u << 20)) {
+            HostFrameList L;
+            bool mapped = true;
+            for (int f = 0; f < n_frames && mapped; f++) {
+                hipPointerAttribute_t at;
+                memset(&at, 0, sizeof at);
+                mapped = hipPointerGetAttributes(&at, frames[f]) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+                if (!mapped) (void) hipGetLastError();
+                L.addr[f] = (unsigned long long) (uintptr_t) at.devicePointer;
+            }
+            if (mapped) {
+                launch_gather_host_frames(c->stream, L, n_frames, (size_t) row_pitch, (uint8_t *) c->dImg0.p, (size_t) pitch, (size_t) pitch * h, w, h);
+                HIPCHECK(c, hipGetLastError());
+                goto uploaded;
+            }
+        }
         const size_t frameBytes = (size_t) (h - 1) * row_pitch + w;
         const size_t tight = (size_t) h * row_pitch;
         int u = n_frames;
