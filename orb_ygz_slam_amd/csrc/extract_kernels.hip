@@ -2732,6 +2732,14 @@ __global__ __launch_bounds__(256) void k_pack_results(const unsigned *__restrict
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nKp; i += stride) dst[offKp + i] = kp[i];
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nDesc; i += stride) dst[offDesc + i] = desc[i];
 }
+__global__ __launch_bounds__(256) void k_link_copy(uint4 *__restrict__ dst, const uint4 *__restrict__ src, unsigned n16) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+void launch_link_copy(hipStream_t st, void *dst, const void *src, size_t bytes) {
+    const unsigned n16 = (unsigned) (bytes / 16);
+    if (!n16) return;
+    hipLaunchKernelGGL(k_link_copy, dim3(std::min(64u, (n16 + 255u) / 256u)), dim3(256), 0, st, (uint4 *) dst, (const uint4 *) src, n16);
+}
 void launch_pack_results(hipStream_t st, const int *cnt, const ygzf_kp *kp, const uint8_t *desc, int nFrames, int kpStride, void *dst, size_t offKp, size_t offDesc) {
     const unsigned nKp = (unsigned) ((size_t) nFrames * kpStride * sizeof(ygzf_kp) / 4), nDesc = (unsigned) ((size_t) nFrames * kpStride * 8);
     const unsigned blocks = std::min(1024u, (nDesc + 255u) / 256u + 1u);

@@ -58,6 +58,9 @@ __host__ __device__ inline int pyr_strip_lds_pitch(int w) { return ((w + 3) & ~3
 hipError_t pyr_strips_prepare(size_t ldsBytes);
 void launch_pyr_strips(hipStream_t st, const FrameSet &fs, int nlevels, const PyrStripPlan *plans, const PyrStripLevel *levels, int nStrips,
                        int offA, int offB, size_t ldsBytes, int nFrames, const int *xofs, const short *xalpha, const int *yofs, const short *ybeta);
+// dst[0 .. bytes) = src[0 .. bytes), bytes a multiple of 16, both 16-byte aligned: small blocks between the page-locked staging area (as the device addresses it) and
+// device memory -- a launch where the copy engine would start ~10 us after the copy is queued and hand over ~8 us after it ends
+void launch_link_copy(hipStream_t st, void *dst, const void *src, size_t bytes);
 void launch_carry_slot(hipStream_t st, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, long long srcSlot, int kpStride);
 void launch_pack_results(hipStream_t st, const int *cnt, const ygzf_kp *kp, const uint8_t *desc, int nFrames, int kpStride, void *dst, size_t offKp, size_t offDesc);
 void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int firstLevel, int nlevels, const unsigned *offsets, uint8_t *dst);

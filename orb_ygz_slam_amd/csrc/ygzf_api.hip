@@ -1139,6 +1139,8 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     for (int l = 1; l < L; l++) offs[l + 1] = offs[l] + (unsigned) G.lv[l].w * (unsigned) G.lv[l].h;
     const size_t total = offs[L];
     if ((rc = ensure_stage(c, total + 64)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
+    // (the levels are NOT written over the link by the packing kernel, as the small result blocks are: tight levels of odd widths are byte-granular
+    // writes, and 0.76 MB of them took longer than the copy engine's start-up saves -- ComputePyramid 94 -> 97 us, pyramid + extraction 150 -> 163)
     launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->dTmpC.p);
     HIPCHECK(c, hipGetLastError());
     // extract-ahead: FAST / octree / descriptors of this image are queued behind the pyramid now and run while the levels travel back on
@@ -1350,12 +1352,20 @@ int queue_packed_fetch(ygzf_ctx *c, void *host, size_t host_bytes, size_t *off_k
     const size_t oK = (B * sizeof(int) + 255) & ~(size_t) 255, oD = oK + ((B * ks * sizeof(ygzf_kp) + 255) & ~(size_t) 255), total = oD + B * ks * 32;
     if (total > host_bytes) return fail(c, YGZF_ERR_INVALID, "packed results need %zu bytes, %zu given", total, host_bytes);
     if (total >= (1ull << 32)) return fail(c, YGZF_ERR_UNSUPPORTED, "packed results of %zu bytes: use ygzf_batch_fetch_all", total);
-    int rc = ensure(c, c->dResPack, total + 256);
+    // page-locked memory the device can address: the gather kernel writes the block over the link itself (no copy-engine start-up / hand-over)
+    void *direct = nullptr;
+    if (forced("fetch_kernel", 1)) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer && ((uintptr_t) at.devicePointer & 3) == 0) direct = at.devicePointer;
+        else (void) hipGetLastError();
+    }
+    int rc = direct ? YGZF_OK : ensure(c, c->dResPack, total + 256);
     if (rc) return rc;
     launch_pack_results(c->stream, (const int *) c->dOutCnt.p + 1, (const ygzf_kp *) c->dOutKp.p + ks, (const uint8_t *) c->dOutDesc.p + ks * 32, (int) B, (int) ks,
-                        c->dResPack.p, oK, oD);
+                        direct ? direct : c->dResPack.p, oK, oD);
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(host, c->dResPack.p, total, hipMemcpyDeviceToHost, c->stream));
+    if (!direct) HIPCHECK(c, hipMemcpyAsync(host, c->dResPack.p, total, hipMemcpyDeviceToHost, c->stream));
     *off_kps = oK;
     *off_desc = oD;
     *row_entries = (int) ks;
@@ -1424,9 +1434,16 @@ static int fetch_frame0_packed(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap
     const size_t oK = 256, oD = oK + ((ks * sizeof(ygzf_kp) + 255) & ~(size_t) 255), total = oD + ks * 32;
     int rc = ensure_stage(c, total + 256);
     if (rc) return rc;
-    HIPCHECK(c, hipMemcpyAsync(c->hStage, (int *) c->dOutCnt.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->hStage + oK, (ygzf_kp *) c->dOutKp.p + ks, ks * sizeof(ygzf_kp), hipMemcpyDeviceToHost, c->stream));   // slot 1 = frame 0
-    HIPCHECK(c, hipMemcpyAsync(c->hStage + oD, (uint8_t *) c->dOutDesc.p + ks * 32, ks * 32, hipMemcpyDeviceToHost, c->stream));
+    if (c->hStageDev && forced("fetch_kernel", 1)) {
+        // count, keypoint row and descriptor row written into the page-locked staging area by a kernel, over the link: three copies by the copy engine
+        // start ~10 us after they are queued and the last one hands back ~8 us after it ends -- a launch does neither
+        launch_pack_results(c->stream, (const int *) c->dOutCnt.p + 1, (const ygzf_kp *) c->dOutKp.p + ks, (const uint8_t *) c->dOutDesc.p + ks * 32, 1, (int) ks, c->hStageDev, oK, oD);
+        HIPCHECK(c, hipGetLastError());
+    } else {
+        HIPCHECK(c, hipMemcpyAsync(c->hStage, (int *) c->dOutCnt.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(c->hStage + oK, (ygzf_kp *) c->dOutKp.p + ks, ks * sizeof(ygzf_kp), hipMemcpyDeviceToHost, c->stream));   // slot 1 = frame 0
+        HIPCHECK(c, hipMemcpyAsync(c->hStage + oD, (uint8_t *) c->dOutDesc.p + ks * 32, ks * 32, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     const int n = *(const int *) c->hStage;
     *n_out = n;

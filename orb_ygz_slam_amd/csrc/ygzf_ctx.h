@@ -127,6 +127,7 @@ struct ygzf_ctx {
     bool evInPending = false;
     uint8_t *hStage = nullptr;             // page-locked staging for results that go back to pageable caller memory in many small pieces
     size_t hStageBytes = 0;
+    void *hStageDev = nullptr;             // the same memory as the device addresses it (kernels write small results straight into it)
     // batch state
     int lastFrames = 0;
     FrameSet lastFs{};
@@ -207,7 +208,9 @@ static int ensure_stage(ygzf_ctx *c, size_t bytes) {
     if (c->hStage) HIPCHECK(c, hipHostFree(c->hStage));
     c->hStage = nullptr;
     c->hStageBytes = 0;
-    HIPCHECK(c, hipHostMalloc((void **) &c->hStage, bytes));
+    HIPCHECK(c, hipHostMalloc((void **) &c->hStage, bytes, hipHostMallocMapped));
+    c->hStageDev = nullptr;
+    if (hipHostGetDevicePointer(&c->hStageDev, c->hStage, 0) != hipSuccess) { (void) hipGetLastError(); c->hStageDev = nullptr; }
     c->hStageBytes = bytes;
     return YGZF_OK;
 }
@@ -231,6 +234,8 @@ struct PackedTransfer {
     // A transfer beyond kPackedMax (a KeyFrame with tens of thousands of features) does not grow the page-locked staging area: its arrays cross
     // one by one from / to the caller's own memory -- same device layout, so the kernels' pointers do not care which way the bytes came.
     bool direct() const { return inBytes + outBytes > kPackedMax; }
+    // the packed blocks cross the link by a kernel (the staging area as the device addresses it) unless YGZF_FORCE=fetch_kernel=0
+    bool link_kernel() const { return c->hStageDev != nullptr && forced("fetch_kernel", 1) != 0; }
     int upload(uint8_t **dBase) {
         int rc;
         if ((rc = ensure(c, c->dPack, inBytes + outBytes + 256))) return rc;
@@ -241,7 +246,8 @@ struct PackedTransfer {
             if ((rc = ensure_stage(c, inBytes + outBytes + 256))) return rc;
             for (const Seg &s : in)
                 if (s.bytes) memcpy(c->hStage + s.off, s.src, s.bytes);
-            if (inBytes) HIPCHECK(c, hipMemcpyAsync(c->dPack.p, c->hStage, inBytes, hipMemcpyHostToDevice, c->stream));
+            if (inBytes && link_kernel()) { ygzf::launch_link_copy(c->stream, c->dPack.p, c->hStageDev, inBytes); HIPCHECK(c, hipGetLastError()); }
+            else if (inBytes) HIPCHECK(c, hipMemcpyAsync(c->dPack.p, c->hStage, inBytes, hipMemcpyHostToDevice, c->stream));
         }
         *dBase = (uint8_t *) c->dPack.p;
         return YGZF_OK;
@@ -254,7 +260,8 @@ struct PackedTransfer {
             HIPCHECK(c, hipStreamSynchronize(c->stream));
             return YGZF_OK;
         }
-        if (outBytes) HIPCHECK(c, hipMemcpyAsync(c->hStage + inBytes, (uint8_t *) c->dPack.p + inBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
+        if (outBytes && link_kernel()) { ygzf::launch_link_copy(c->stream, (uint8_t *) c->hStageDev + inBytes, (uint8_t *) c->dPack.p + inBytes, outBytes); HIPCHECK(c, hipGetLastError()); }
+        else if (outBytes) HIPCHECK(c, hipMemcpyAsync(c->hStage + inBytes, (uint8_t *) c->dPack.p + inBytes, outBytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(c, hipStreamSynchronize(c->stream));
         for (const Seg &s : out)
             if (s.bytes && s.dst) memcpy(s.dst, c->hStage + inBytes + s.off, s.bytes);
