@@ -2412,16 +2412,37 @@ hipError_t upload_constants(const int *umax16) {
 // on the host.  The device levels have 64-byte pitches; a pitched device-to-host copy of an odd-width level is executed row by row by the
 // copy engine (1.3 ms per level), so the levels are packed here and leave in ONE linear copy.
 struct PackOffsets { unsigned v[kMaxLevels + 1]; };
-__global__ __launch_bounds__(256) void k_pack_levels(FrameSet fs, const LevelGeom *__restrict__ geom, PackOffsets off, uint8_t *__restrict__ dst, int firstLevel) {
-    const int l = blockIdx.y + firstLevel;
-    const LevelGeom g = geom[l];
-    int pitch;
-    const uint8_t *src = level_ptr(fs, g, l, 0, &pitch);
-    const unsigned n = (unsigned) g.w * (unsigned) g.h;
-    uint8_t *d = dst + off.v[l];
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const unsigned y = i / (unsigned) g.w, x = i - y * (unsigned) g.w;
-        d[i] = src[(size_t) y * pitch + x];
+// A thread produces 16 consecutive bytes of the packed stream (one aligned 16-byte store: the destination may be page-locked HOST memory, written over
+// the link, where byte stores would be a transaction each): it finds the level and the position of its first byte, then walks along the row, into the
+// next row, into the next level.
+__global__ __launch_bounds__(256) void k_pack_levels(FrameSet fs, const LevelGeom *__restrict__ geom, PackOffsets off, uint8_t *__restrict__ dst, int firstLevel, int nlevels) {
+    const unsigned total = off.v[nlevels], first = off.v[firstLevel];
+    for (unsigned o = first + 16u * (blockIdx.x * 256u + threadIdx.x); o < total; o += 16u * gridDim.x * 256u) {
+        int l = firstLevel;
+        while (l + 1 < nlevels && o >= off.v[l + 1]) l++;
+        LevelGeom g = geom[l];
+        int pitch;
+        const uint8_t *src = level_ptr(fs, g, l, 0, &pitch);
+        unsigned i = o - off.v[l], y = i / (unsigned) g.w, x = i - y * (unsigned) g.w;
+        const uint8_t *row = src + (size_t) y * pitch;
+        unsigned w4[4] = {0u, 0u, 0u, 0u};
+        const unsigned nb = min(16u, total - o);
+#pragma unroll
+        for (unsigned b = 0; b < 16; b++) {
+            if (b < nb) {
+                w4[b >> 2] |= (unsigned) row[x] << (8 * (b & 3));
+                if (++x == (unsigned) g.w) {
+                    x = 0;
+                    if (++y == (unsigned) g.h) {            // next level (never past the last one: b < nb)
+                        if (l + 1 < nlevels) { l++; g = geom[l]; src = level_ptr(fs, g, l, 0, &pitch); }
+                        y = 0;
+                    }
+                    row = src + (size_t) y * pitch;
+                }
+            }
+        }
+        if (nb == 16) *(uint4 *) (dst + o) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        else for (unsigned b = 0; b < nb; b++) dst[o + b] = (uint8_t) (w4[b >> 2] >> (8 * (b & 3)));
     }
 }
 
@@ -2429,7 +2450,9 @@ void launch_pack_levels(hipStream_t st, const FrameSet &fs, const LevelGeom *dGe
     if (firstLevel >= nlevels) return;
     PackOffsets off;
     for (int l = 0; l <= kMaxLevels; l++) off.v[l] = l <= nlevels ? offsets[l] : 0;
-    hipLaunchKernelGGL(k_pack_levels, dim3(128, nlevels - firstLevel), dim3(256), 0, st, fs, dGeom, off, dst, firstLevel);
+    const unsigned n16 = (offsets[nlevels] - offsets[firstLevel] + 15u) / 16u;
+    if (!n16) return;
+    hipLaunchKernelGGL(k_pack_levels, dim3(std::min(256u, (n16 + 255u) / 256u)), dim3(256), 0, st, fs, dGeom, off, dst, firstLevel, nlevels);
 }
 
 // rows of `w` bytes from a linear staging buffer (row pitch srcPitch) into a pitched image: the device half of an upload whose pitched

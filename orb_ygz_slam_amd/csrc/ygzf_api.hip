@@ -1139,10 +1139,13 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     for (int l = 1; l < L; l++) offs[l + 1] = offs[l] + (unsigned) G.lv[l].w * (unsigned) G.lv[l].h;
     const size_t total = offs[L];
     if ((rc = ensure_stage(c, total + 64)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
-    // (the levels are NOT written over the link by the packing kernel, as the small result blocks are: tight levels of odd widths are byte-granular
-    // writes, and 0.76 MB of them took longer than the copy engine's start-up saves -- ComputePyramid 94 -> 97 us, pyramid + extraction 150 -> 163)
-    launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->dTmpC.p);
-    HIPCHECK(c, hipGetLastError());
+    // (the page-locked staging area as the device addresses it: the packing kernel -- 16-byte stores -- writes the levels over the link itself, on the
+    // stream the copy would have taken; a byte-per-thread packing kernel doing so was slower than the copy engine: ComputePyramid 94 -> 97 us)
+    const bool linkPack = c->hStageDev != nullptr && forced("fetch_kernel", 1) != 0 && forced("pyr_link", 1) != 0;
+    if (!linkPack) {
+        launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->dTmpC.p);
+        HIPCHECK(c, hipGetLastError());
+    }
     // extract-ahead: FAST / octree / descriptors of this image are queued behind the pyramid now and run while the levels travel back on
     // the copy stream and the caller works on them (a Frame constructor clones them); ygzf_extract_resident then only collects the results.
     // (Measured alternatives: the copy on the context's own stream with an event behind it and the extraction queued after that event --
@@ -1155,7 +1158,10 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
         rd = c->streamCopy;
         ahead = true;
     }
-    if (total) HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, rd));
+    if (total && linkPack) {
+        launch_pack_levels(rd, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->hStageDev);
+        HIPCHECK(c, hipGetLastError());
+    } else if (total) HIPCHECK(c, hipMemcpyAsync(c->hStage, c->dTmpC.p, total, hipMemcpyDeviceToHost, rd));
     if (ahead && (rc = run_extract(c, fs, 1, true, pyramidCarried))) return rc;   // (queued after the copy so that the copy starts while these launches are issued)
     if (levels_out[0] != img || stride != w)
         for (int y = 0; y < h; y++) memcpy(levels_out[0] + (size_t) y * w, img + (size_t) y * stride, (size_t) w);
