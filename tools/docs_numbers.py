@@ -44,8 +44,8 @@ r="""MI355X, one GPU (round 6, `profiles/r06_bench_default.json` = one run of th
 | CPU oracle on the same host's 16 usable cores, same run, same clip and steps | %.0f | %.0f | %.0f | %.0f |
 
 `--align` (extract + match + `SparseImgAlign` of every frame): %s frames/s resident; %s on a clip cut from the reference's own `test1.png`.  One frame at a time, as a
-tracking thread calls it: extract + match of a resident frame 0.102 ms; through the class shells `SearchByProjection` 0.10 ms, `SparseImgAlign::run` 0.30 ms, pyramid +
-extraction of a new `Frame` 0.17 ms, `Tracking::SearchLocalPointsDirect` over 1000 local points 0.4 ms through the batch binding (44-79 ms one candidate per call)
+tracking thread calls it: extract + match of a resident frame 0.101 ms; through the class shells `operator()(image)` 0.12 ms, `SearchByProjection` 0.10 ms, `SparseImgAlign::run`
+0.29-0.31 ms, pyramid + extraction of a new `Frame` 0.15 ms, `Tracking::SearchLocalPointsDirect` over 1000 local points 0.4 ms through the batch binding (44-86 ms one candidate per call)
 (INTEGRATION.md).  The reference's own sources over the OpenCV stand-in, one thread: %.0f frames/s.  Several GPUs: one process per GPU
 (`bench.py --gpus N`, no collective on the data path) or `ygzf_mgpu_*` dealing frames (or frame / stereo pairs) round-robin over the devices of a node: %s frames/s from
 page-locked host frames, %s from pageable ones on one device; one 1920×1080 frame per call on one device %.2f ms, one 3840×2160 stereo pair %.2f ms.  The path is
