@@ -471,3 +471,30 @@ def test_carry_previous_switch(oracle):
         (ma, oa), (mb, ob) = ref.match_fetch(f), ex.match_fetch(f)
         assert np.array_equal(ma, mb) and np.array_equal(oa, ob)
     ref.close(); ex.close()
+
+
+def test_link_kernels_and_copy_engine_agree(oracle, monkeypatch):
+    """Small blocks of a one-frame call cross the link by kernel (a page-locked frame read where it lies, the result rows / the pyramid levels written into
+    the page-locked staging area); YGZF_FORCE=upload_kernel_frames=0,fetch_kernel=0,pyr_link=0 brings the copy engine back: same keypoints, descriptors
+    and levels either way, from pageable and from page-locked frames."""
+    import torch
+    from orb_ygz_slam_amd import Extractor
+    from orb_ygz_slam_amd.capi import force_env
+    w, h = 640, 480
+    img = synth_frame(411, w, h)
+    pinned = torch.from_numpy(img.copy()).pin_memory().numpy()
+    oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
+    want_k, want_d = oex.extract(img)
+    want_pyr = oex.pyramid(img)
+    for force in ({}, {"upload_kernel_frames": 0, "fetch_kernel": 0, "pyr_link": 0}):
+        monkeypatch.setenv("YGZF_FORCE", force_env(**force))
+        ex = Extractor(1000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=2)
+        for frame in (img, pinned):
+            k, d = ex.extract(frame)
+            assert all((k[f] == want_k[f]).all() for f in ("x", "y", "angle", "response", "octave")) and (d == want_d).all()
+            pyr = ex.compute_pyramid(frame)
+            assert all(np.array_equal(p, q) for p, q in zip(pyr, want_pyr))
+            ex.extract_batch_host(np.stack([frame, frame]))
+            kb, db = ex.batch_fetch(1)
+            assert np.array_equal(kb, k) and np.array_equal(db, d)
+        ex.close()
