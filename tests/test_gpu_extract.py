@@ -477,12 +477,19 @@ def test_link_kernels_and_copy_engine_agree(oracle, monkeypatch):
     """Small blocks of a one-frame call cross the link by kernel (a page-locked frame read where it lies, the result rows / the pyramid levels written into
     the page-locked staging area); YGZF_FORCE=upload_kernel_frames=0,fetch_kernel=0,pyr_link=0 brings the copy engine back: same keypoints, descriptors
     and levels either way, from pageable and from page-locked frames."""
-    import torch
+    import ctypes as C
     from orb_ygz_slam_amd import Extractor
-    from orb_ygz_slam_amd.capi import force_env
+    from orb_ygz_slam_amd.capi import force_env, load_library
     w, h = 640, 480
     img = synth_frame(411, w, h)
-    pinned = torch.from_numpy(img.copy()).pin_memory().numpy()
+    L = load_library()
+    L.ygzf_alloc_host.restype = C.c_void_p
+    L.ygzf_alloc_host.argtypes = [C.c_int, C.c_size_t]
+    L.ygzf_free_host.argtypes = [C.c_void_p]
+    ptr = L.ygzf_alloc_host(0, w * h)                       # page-locked, device-visible (include/ygzf.h)
+    assert ptr
+    pinned = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(h, w))
+    pinned[:] = img
     oex = oracle.Extractor(1000, 1.2, 8, 20, 7)
     want_k, want_d = oex.extract(img)
     want_pyr = oex.pyramid(img)
@@ -498,3 +505,4 @@ def test_link_kernels_and_copy_engine_agree(oracle, monkeypatch):
             kb, db = ex.batch_fetch(1)
             assert np.array_equal(kb, k) and np.array_equal(db, d)
         ex.close()
+    L.ygzf_free_host(ptr)
