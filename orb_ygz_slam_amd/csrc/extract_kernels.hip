@@ -558,7 +558,16 @@ __global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, in
                 const unsigned e0 = __builtin_amdgcn_alignbyte(d1, d0, osh), e1 = __builtin_amdgcn_alignbyte(d2, d1, osh);
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, __builtin_amdgcn_perm(e1, e0, sel[k])), __builtin_bit_cast(v2u, ap[k]), 0u, false);
+                    H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u, __builtin_amdgcn_perm(e1, e0, sel[k])), __builtin_bit_cast(v2u, ap[k]), 0u, false) & ~15u;
+            };
+            // (beta * (H >> 4)) >> 16 == v_mul_hi_u32(H & ~15, beta << 12), four pixels packed by two shifts and a byte permute: as k_pyr_resize_tiled
+            auto vout = [&](const unsigned (&H0)[4], const unsigned (&H1)[4], unsigned b01) -> unsigned {
+                const unsigned b0 = (b01 & 0xFFFFu) << 12, b1 = (b01 >> 16) << 12;
+                unsigned sum[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) sum[k] = __umulhi(H0[k], b0) + __umulhi(H1[k], b1) + 2u;
+                const unsigned t01 = (sum[0] | (sum[1] << 16)) >> 2, t23 = (sum[2] | (sum[3] << 16)) >> 2;
+                return __builtin_amdgcn_perm(t23, t01, 0x06040200u);
             };
             for (int y = ca + rp; y < cb; y += 2 * nrp) {   // two rows per turn: their LDS reads travel together
                 const int y2 = y + nrp;
@@ -569,14 +578,7 @@ __global__ __launch_bounds__(kPyrStripThreads) void k_pyr_strips(FrameSet fs, in
                 hrow((int) (rcA.x >> 16), HA1);
                 hrow((int) (rcB.x & 0xFFFFu), HB0);
                 hrow((int) (rcB.x >> 16), HB1);
-                const int a0 = (int) (short) (rcA.y & 0xFFFFu), a1 = (int) (short) (rcA.y >> 16);
-                const int c0 = (int) (short) (rcB.y & 0xFFFFu), c1 = (int) (short) (rcB.y >> 16);
-                unsigned outA = 0, outB = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    outA |= (unsigned) (((__mul24(a0, (int) (HA0[k] >> 4)) >> 16) + (__mul24(a1, (int) (HA1[k] >> 4)) >> 16) + 2) >> 2) << (8 * k);
-                    outB |= (unsigned) (((__mul24(c0, (int) (HB0[k] >> 4)) >> 16) + (__mul24(c1, (int) (HB1[k] >> 4)) >> 16) + 2) >> 2) << (8 * k);
-                }
+                const unsigned outA = vout(HA0, HA1, rcA.y), outB = vout(HB0, HB1, rcB.y);
                 *(unsigned *) (db + (y - ca) * Pd + xb) = outA;
                 if (y >= wa && y < wb) *(unsigned *) (dstf + (unsigned) y * (unsigned) pitch + xb) = outA;
                 if (two) {
