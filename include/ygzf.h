@@ -77,6 +77,9 @@ int ygzf_scale_tables_host(const ygzf_extractor_cfg *cfg, float *scale, float *i
  * at least n_strips * nlevels * 4 are needed; pass rows = NULL to ask for n_strips first: at most 64).  level_wh[2 l], level_wh[2 l + 1] = size
  * of level l.  lds_bytes = LDS per workgroup.  lds_bytes, level_wh and rows may be NULL. */
 int ygzf_pyramid_plan_host(const ygzf_extractor_cfg *cfg, int w, int h, int *n_strips, int *lds_bytes, int *level_wh, unsigned short *rows, int rows_cap);
+/* The level the strips of that plan start from: 0 = the image (the whole chain is the one launch); b > 0 (images too large for that: 3840 x 2160): levels
+ * 1 .. b come from one launch each and the strips stage level b instead of the image -- rows[..] of the levels below b are zero.  Negative: an error code. */
+int ygzf_pyramid_plan_base_host(const ygzf_extractor_cfg *cfg, int w, int h);
 
 /* ORBextractor::operator() on the image whose pyramid the context's previous call, ygzf_compute_pyramid, left on the device: FAST, octree,
  * orientation and descriptors without a second upload and a second pyramid (Frame's constructors call ComputePyramid and then the

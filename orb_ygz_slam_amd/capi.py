@@ -210,7 +210,8 @@ def host_row_pitch(w):
 
 def pyramid_plan_host(nfeatures, scale_factor, nlevels, w, h):
     """ygzf_pyramid_plan_host: how ComputePyramid of one w x h frame is launched (host arithmetic only, no device).  Returns a dict with
-    `strips` (0 = one launch per level), `lds_bytes`, `levels` = [(w, h)] and `rows`, an int array [strips, nlevels, 4] of (ca, cb, wa, wb)."""
+    `strips` (0 = one launch per level), `base` (the level the strips stage: 0 = the image), `lds_bytes`, `levels` = [(w, h)] and `rows`, an int
+    array [strips, nlevels, 4] of (ca, cb, wa, wb)."""
     L = load_library()
     cfg = ExtractorCfg(nfeatures, scale_factor, nlevels, 20, 7, 0)
     n, lds = C.c_int(0), C.c_int(0)
@@ -219,7 +220,11 @@ def pyramid_plan_host(nfeatures, scale_factor, nlevels, w, h):
     rc = L.ygzf_pyramid_plan_host(C.byref(cfg), w, h, C.byref(n), C.byref(lds), _p(wh), _p(rows), rows.size)
     if rc != 0:
         raise YgzfError("ygzf_pyramid_plan_host failed (%d)" % rc)
-    return {"strips": n.value, "lds_bytes": lds.value, "levels": [(int(wh[2 * l]), int(wh[2 * l + 1])) for l in range(nlevels)],
+    L.ygzf_pyramid_plan_base_host.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    base = L.ygzf_pyramid_plan_base_host(C.byref(cfg), w, h)
+    if base < 0:
+        raise YgzfError("ygzf_pyramid_plan_base_host failed (%d)" % base)
+    return {"strips": n.value, "base": base, "lds_bytes": lds.value, "levels": [(int(wh[2 * l]), int(wh[2 * l + 1])) for l in range(nlevels)],
             "rows": rows[:n.value * nlevels * 4].astype(np.int64).reshape(n.value, nlevels, 4)}
 
 

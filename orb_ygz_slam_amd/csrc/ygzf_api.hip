@@ -76,12 +76,11 @@ thread_local std::string g_create_err;   // last failed ygzf_create of THIS thre
 // Row ranges of k_pyr_strips (extract_kernels.hip): the last level is cut into S strips; walking up, a strip needs of level l the source
 // rows of the rows it produces of level l + 1 (yofs is monotone: first row's sy .. last row's sy + 1, clamped as the kernel clamps) and
 // owns the S-th part of every level.  S grows until the two LDS regions (even / odd levels) fit.
-static void plan_pyr_strips(Geometry &G, int L) {
-    G.pyrPlan.clear();
-    if (L < 3) return;
-    if (G.lv[0].h >= 65536) return;   // the strip plan packs row ranges into 16-bit fields: taller images keep one launch per level
-    for (int l = 1; l < L; l++)
-        if (G.lv[l].area2x || !G.lv[l].tiledOk || (G.lv[l].w + 3) / 4 > kPyrStripMaxThreads) return;
+static bool plan_pyr_strips_from(Geometry &G, int L, int base, bool only32) {
+    if (L - base < 3) return false;
+    if (G.lv[base].h >= 65536) return false;   // the strip plan packs row ranges into 16-bit fields: taller images keep one launch per level
+    for (int l = base + 1; l < L; l++)
+        if (G.lv[l].area2x || !G.lv[l].tiledOk || (G.lv[l].w + 3) / 4 > kPyrStripMaxThreads) return false;
     // 752x480, one frame: 16 strips 148 us per resident extraction, 24 146, 32 144, 48 143 (the halo rows grow with the strip count: 1.23 x
     // the pixels of the pyramid at 16); eight frames: 16 strips 218 us, 32 215
     // (more strips when the LDS regions do not fit, fewer for images whose last level has fewer than 64 rows).
@@ -89,6 +88,7 @@ static void plan_pyr_strips(Geometry &G, int L) {
     const int minS = (int) forced("pyr_strips", 0);   // at least this many strips (tests: the strip plans of large images on small ones)
     for (int S : candidates) {
         if (S < minS) continue;
+        if (only32 && S != 32) continue;
         if (G.lv[L - 1].h < 2 * S) continue;
         std::vector<PyrStripPlan> plan(S);
         size_t bytes[2] = {0, 0};
@@ -97,20 +97,20 @@ static void plan_pyr_strips(Geometry &G, int L) {
             int rows = 0, pca = 0, pcb = 0;   // the range produced of the level below the one in hand
             PyrStripPlan &p = plan[s];
             std::memset(&p, 0, sizeof p);
-            for (int l = L - 1; l >= 0; l--) {
+            for (int l = L - 1; l >= base; l--) {
                 const int hl = G.lv[l].h;
                 int wa = (int) ((long long) hl * s / S), wb = (int) ((long long) hl * (s + 1) / S), ca = wa, cb = wb;
                 if (l < L - 1) {
                     const LevelGeom &n = G.lv[l + 1];
                     const int na = std::min(std::max(G.yofs[n.ytab + pca], 0), hl - 1);
                     const int nb = std::min(std::max(G.yofs[n.ytab + pcb - 1] + 1, 0), hl - 1) + 1;
-                    if (l == 0) { ca = na; cb = nb; wa = wb = 0; }
+                    if (l == base) { ca = na; cb = nb; wa = wb = 0; }   // the base level is staged, not produced
                     else { ca = std::min(wa, na); cb = std::max(wb, nb); }
                 }
                 p.lv[l] = make_uint2((unsigned) ca | ((unsigned) cb << 16), (unsigned) wa | ((unsigned) wb << 16));
                 pca = ca; pcb = cb;
-                bytes[l & 1] = std::max(bytes[l & 1], (size_t) (cb - ca) * pyr_strip_lds_pitch(G.lv[l].w));
-                if (l >= 1) rows += cb - ca;
+                bytes[(l - base) & 1] = std::max(bytes[(l - base) & 1], (size_t) (cb - ca) * pyr_strip_lds_pitch(G.lv[l].w));
+                if (l > base) rows += cb - ca;
             }
             maxRows = std::max(maxRows, rows);
         }
@@ -119,6 +119,7 @@ static void plan_pyr_strips(Geometry &G, int L) {
         const size_t a = (bytes[0] + 16 + 15) & ~(size_t) 15, b = (bytes[1] + 16 + 15) & ~(size_t) 15;   // hrow reads up to 11 bytes past a row's pixels
         if (head + a + b > 160 * 1024) continue;
         G.pyrPlan = plan;
+        G.pyrBase = base;
         G.pyrStripOffA = (int) head;
         G.pyrStripOffB = (int) (head + a);
         G.pyrStripLds = head + a + b;
@@ -127,8 +128,25 @@ static void plan_pyr_strips(Geometry &G, int L) {
             const LevelGeom &g = G.lv[l];
             G.pyrLevels[l] = PyrStripLevel{g.w, g.h, g.pitch, g.xtab, g.ytab, 0, (long long) g.off};
         }
-        return;
+        return true;
     }
+    return false;
+}
+
+// The whole chain from the image when that fits LDS; otherwise (3840x2160: a strip of the last level would need 270 KB of level 0) the first levels
+// come from k_pyr_resize_tiled, one launch each, and the strips start from the first level whose chain fits -- a one-frame call then pays 3-4
+// launches instead of 11.  YGZF_FORCE=pyr_strip_base=s: not below level s (tests).
+static void plan_pyr_strips(Geometry &G, int L) {
+    G.pyrPlan.clear();
+    G.pyrBase = 0;
+    // (a 3840x2160 pair, same box: from level 3 with 48 strips 0.774 ms -- and two clusters of calls, 0.72 and 0.78 --, from level 4 with 32 strips 0.710,
+    // from level 5 / 6 / 9 0.76 / 0.75 / 0.75: above the image the plan of 32 strips is preferred to an earlier level with more)
+    const int first = (int) forced("pyr_strip_base", 0);
+    if (first == 0 && plan_pyr_strips_from(G, L, 0, false)) return;
+    for (int base = std::max(first, 1); base + 3 <= L; base++)
+        if (plan_pyr_strips_from(G, L, base, true)) return;
+    for (int base = std::max(first, 1); base + 3 <= L; base++)
+        if (plan_pyr_strips_from(G, L, base, false)) return;
 }
 
 int build_geometry(ygzf_ctx *c, int w, int h, Geometry &G) {
@@ -365,8 +383,18 @@ int apply_geometry(ygzf_ctx *c, int w, int h, int nFrames) {
         if (!G.pyrPlan.empty()) {
             rc = ensure(c, c->dPyrPlan, sizeof G.pyrLevels + G.pyrPlan.size() * sizeof(PyrStripPlan));   // level table, then one plan per strip
             if (rc) return rc;
-            HIPCHECK(c, hipMemcpy(c->dPyrPlan.p, G.pyrLevels, sizeof G.pyrLevels, hipMemcpyHostToDevice));
-            HIPCHECK(c, hipMemcpy((char *) c->dPyrPlan.p + sizeof G.pyrLevels, G.pyrPlan.data(), G.pyrPlan.size() * sizeof(PyrStripPlan), hipMemcpyHostToDevice));
+            {   // the kernel counts levels from the strips' base level: both tables go up shifted
+                PyrStripLevel lv[kMaxLevels];
+                std::memset(lv, 0, sizeof lv);
+                for (int l = G.pyrBase; l < L; l++) lv[l - G.pyrBase] = G.pyrLevels[l];
+                std::vector<PyrStripPlan> rel(G.pyrPlan.size());
+                for (size_t q = 0; q < rel.size(); q++) {
+                    std::memset(&rel[q], 0, sizeof rel[q]);
+                    for (int l = G.pyrBase; l < L; l++) rel[q].lv[l - G.pyrBase] = G.pyrPlan[q].lv[l];
+                }
+                HIPCHECK(c, hipMemcpy(c->dPyrPlan.p, lv, sizeof lv, hipMemcpyHostToDevice));
+                HIPCHECK(c, hipMemcpy((char *) c->dPyrPlan.p + sizeof G.pyrLevels, rel.data(), rel.size() * sizeof(PyrStripPlan), hipMemcpyHostToDevice));
+            }
             if (pyr_strips_prepare(G.pyrStripLds) != hipSuccess) {   // no such LDS allotment on this device: one launch per level
                 (void) hipGetLastError();
                 G.pyrPlan.clear();
@@ -503,9 +531,19 @@ int pyramid_chain(ygzf_ctx *c, const FrameSet &fs, int nFrames) {
                 launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, pyr_tabs(c));
         }
     };
-    if (!G.pyrPlan.empty() && nFrames <= c->pyrStripFrames) {   // a few frames: the whole chain in one launch
+    if (!G.pyrPlan.empty() && nFrames <= c->pyrStripFrames) {   // a few frames: the whole chain in one launch (large images: from the plan's base level on)
+        FrameSet fb = fs;
+        for (int l = 1; l <= G.pyrBase; l++) {
+            ProfScope ps(c, KK_PYR);
+            launch_pyr_resize(c->stream, fs, dGeom, G.lv[l], l, nFrames, pyr_tabs(c));
+        }
+        if (G.pyrBase > 0) {
+            fb.img0 = fs.pyr + G.lv[G.pyrBase].off;
+            fb.img0_stride = fs.pyr_stride;
+            fb.img0_pitch = G.lv[G.pyrBase].pitch;
+        }
         ProfScope ps(c, KK_PYR);
-        launch_pyr_strips(c->stream, fs, L, (const PyrStripPlan *) ((const char *) c->dPyrPlan.p + sizeof G.pyrLevels), (const PyrStripLevel *) c->dPyrPlan.p,
+        launch_pyr_strips(c->stream, fb, L - G.pyrBase, (const PyrStripPlan *) ((const char *) c->dPyrPlan.p + sizeof G.pyrLevels), (const PyrStripLevel *) c->dPyrPlan.p,
                           (int) G.pyrPlan.size(), G.pyrStripOffA, G.pyrStripOffB, G.pyrStripLds, nFrames,
                           (const int *) c->dXofs.p, (const short *) c->dXalpha.p, (const int *) c->dYofs.p, (const short *) c->dYbeta.p);
         return YGZF_OK;
@@ -1064,6 +1102,15 @@ int ygzf_pyramid_plan_host(const ygzf_extractor_cfg *cfg, int w, int h, int *n_s
             }
     }
     return YGZF_OK;
+}
+
+int ygzf_pyramid_plan_base_host(const ygzf_extractor_cfg *cfg, int w, int h) {
+    if (!cfg || cfg->nlevels < 1 || cfg->nlevels > kMaxLevels || cfg->nfeatures < 0 || !(cfg->scale_factor > 1.0f) || w < 1 || h < 1) return YGZF_ERR_INVALID;
+    ygzf_ctx tmp;
+    tmp.tab.init(*cfg);
+    Geometry G;
+    const int rc = build_geometry(&tmp, w, h, G);
+    return rc ? rc : G.pyrBase;
 }
 
 int ygzf_get_levels(const ygzf_ctx *c) { return c ? c->tab.cfg.nlevels : YGZF_ERR_INVALID; }

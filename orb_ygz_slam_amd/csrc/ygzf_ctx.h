@@ -37,6 +37,7 @@ struct Geometry {
     long long pyrBytes = 0;   // per frame, levels >= 1
     std::vector<PyrStripPlan> pyrPlan;   // k_pyr_strips: one entry per strip (empty: this geometry takes one launch per level)
     int pyrStripOffA = 0, pyrStripOffB = 0;
+    int pyrBase = 0;                     // the strips start from this level (0: the image; > 0: levels 1 .. pyrBase come from k_pyr_resize_tiled first)
     PyrStripLevel pyrLevels[kMaxLevels];
     size_t pyrStripLds = 0;
     int totalCells = 0, maxCellsPerLevel = 0;

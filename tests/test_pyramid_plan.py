@@ -11,7 +11,7 @@ import pytest
 from orb_ygz_slam_amd.capi import pyramid_plan_host
 
 CASES = [(752, 480, 8, 1.2), (640, 480, 8, 1.2), (1241, 376, 8, 1.2), (1920, 1080, 8, 1.2), (641, 479, 8, 1.2), (333, 517, 6, 1.25),
-         (752, 480, 12, 1.1), (752, 480, 4, 1.2), (320, 240, 8, 1.2), (200, 150, 3, 1.2), (130, 110, 8, 1.2), (4128, 2000, 6, 1.2)]
+         (752, 480, 12, 1.1), (752, 480, 4, 1.2), (320, 240, 8, 1.2), (200, 150, 3, 1.2), (130, 110, 8, 1.2), (4128, 2000, 6, 1.2), (3840, 2160, 12, 1.2), (2560, 1440, 10, 1.2)]
 
 
 def _yofs(sh, dh):
@@ -22,12 +22,13 @@ def _yofs(sh, dh):
 @pytest.mark.parametrize("w,h,nl,sf", CASES)
 def test_strips_cover_what_they_read_and_partition_what_they_write(w, h, nl, sf):
     plan = pyramid_plan_host(1000, sf, nl, w, h)
-    S, lv, rows = plan["strips"], plan["levels"], plan["rows"]
+    S, lv, rows, base = plan["strips"], plan["levels"], plan["rows"], plan["base"]
     assert lv[0] == (w, h)
     if S == 0:
         pytest.skip("this geometry takes one launch per level")
-    assert S in (8, 16, 32, 48, 64) and 0 < plan["lds_bytes"] <= 160 * 1024
-    for l in range(1, nl):
+    assert S in (8, 16, 32, 48, 64) and 0 < plan["lds_bytes"] <= 160 * 1024 and 0 <= base <= nl - 3
+    assert (rows[:, :base] == 0).all() and (rows[:, base, 2:] == 0).all()      # levels below the base are not the strips' business; the base is staged, never written
+    for l in range(base + 1, nl):
         hl, sh = lv[l][1], lv[l - 1][1]
         yofs = _yofs(sh, hl)
         written = np.zeros(hl, np.int32)
@@ -41,13 +42,15 @@ def test_strips_cover_what_they_read_and_partition_what_they_write(w, h, nl, sf)
                 s, l, ca, cb, l - 1, min(need), max(need), pa, pb)
         assert (written == 1).all(), "level %d: rows written %s times" % (l, sorted(set(written.tolist())))
     # the halo rows the strips recompute stay a modest multiple of the pyramid
-    total = sum(a * b for a, b in lv[1:])
-    produced = sum((rows[s, l, 1] - rows[s, l, 0]) * lv[l][0] for s in range(S) for l in range(1, nl))
+    total = sum(a * b for a, b in lv[base + 1:])
+    produced = sum((rows[s, l, 1] - rows[s, l, 0]) * lv[l][0] for s in range(S) for l in range(base + 1, nl))
     assert produced <= 2.5 * total
 
 
 def test_large_images_keep_one_launch_per_level():
-    assert pyramid_plan_host(8000, 1.2, 12, 3840, 2160)["strips"] == 0          # the LDS regions do not fit
+    big = pyramid_plan_host(8000, 1.2, 12, 3840, 2160)                          # the chain from the image does not fit LDS: the strips start further up
+    assert big["strips"] > 0 and 1 <= big["base"] <= 6
+    assert pyramid_plan_host(4000, 1.2, 8, 1920, 1080)["base"] == 0 and pyramid_plan_host(1000, 1.2, 8, 752, 480)["base"] == 0
     assert pyramid_plan_host(500, 2.0, 4, 640, 480)["strips"] == 0              # exact 2x levels take the area kernel
     assert pyramid_plan_host(1000, 1.2, 2, 752, 480)["strips"] == 0             # one level to produce: nothing to chain
 
@@ -81,7 +84,7 @@ def _resize_rows(src, src_row0, sw, sh, dw, dh, ya, yb):
     return (((((b0[:, None] * (H0 >> 4)) >> 16) + ((b1[:, None] * (H1 >> 4)) >> 16) + 2) >> 2)).astype(np.uint8)
 
 
-@pytest.mark.parametrize("w,h,nl,sf", [(752, 480, 8, 1.2), (641, 479, 8, 1.2), (333, 517, 6, 1.25), (200, 150, 3, 1.2)])
+@pytest.mark.parametrize("w,h,nl,sf", [(752, 480, 8, 1.2), (641, 479, 8, 1.2), (333, 517, 6, 1.25), (200, 150, 3, 1.2), (2560, 1440, 10, 1.2)])
 def test_strips_assemble_the_oracle_pyramid(oracle, w, h, nl, sf):
     """The algorithm of k_pyr_strips replayed on the CPU from the library's own plan: every strip stages its level-0 rows, produces its rows
     of every level from its OWN rows of the level below, and writes the rows it owns -- the assembled levels are the oracle's pyramid."""
@@ -89,14 +92,16 @@ def test_strips_assemble_the_oracle_pyramid(oracle, w, h, nl, sf):
     img = synth_frame(5, w, h)
     want = oracle.Extractor(500, sf, nl, 20, 7).pyramid(img)
     plan = pyramid_plan_host(500, sf, nl, w, h)
-    S, lv, rows = plan["strips"], plan["levels"], plan["rows"]
+    S, lv, rows, base = plan["strips"], plan["levels"], plan["rows"], plan["base"]
     assert S > 0
     assert (_resize_rows(img, 0, w, h, lv[1][0], lv[1][1], 0, lv[1][1]) == want[1]).all()   # the model itself against the oracle's resize
     got = [img] + [np.full((lv[l][1], lv[l][0]), 0xAA, np.uint8) for l in range(1, nl)]
+    for l in range(1, base + 1):
+        got[l] = want[l]                                                                     # (one launch each, k_pyr_resize_tiled: not the strips' business)
     for s in range(S):
-        ca, cb = rows[s, 0][:2]
-        held, held0 = img[ca:cb], ca
-        for l in range(1, nl):
+        ca, cb = rows[s, base][:2]
+        held, held0 = got[base][ca:cb], ca
+        for l in range(base + 1, nl):
             ca, cb, wa, wb = rows[s, l]
             held = _resize_rows(held, held0, lv[l - 1][0], lv[l - 1][1], lv[l][0], lv[l][1], ca, cb)
             held0 = ca
