@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
                                                       unsigned char *__restrict__ lvlKpScore, int *__restrict__ lvlKpCnt,
                                                       int *__restrict__ lvlCandCnt, uint2 *__restrict__ procRec,
                                                       int kpStride, int cap, int ldsCand, long long *dbg, int *__restrict__ nodeArena,
-                                                      int regionInts, int histBins, int *gHist, int *gDone) {
+                                                      int regionInts, int histBins, int *gHist, int *gDone, int doneTarget, int spinBudget) {
     static_assert(!(kGlobalNodes && kHist), "the histogram plan keeps the node arrays in LDS");
     extern __shared__ __attribute__((aligned(16))) int dyn[];
     __shared__ int histT[kRadixHist];
@@ -1376,7 +1376,10 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
     // kHist, launches of a few frames (gridDim.z > 1): a level of one 3840x2160 frame is 60 000 candidates whose keys took ONE compute unit 95 us while
     // 250 others had nothing to do.  The workgroups z = 1 .. gridDim.z - 1 of a (level, frame) are helpers: each computes the keys of its share of the
     // candidates (keys and positions in the global candidate arrays as always, its bin counts into a slice of gHist), releases, bumps gDone and
-    // leaves; workgroup 0 does its own share, waits for the others, adds their counts to its own and goes on alone.  The host launches helpers only while ALL workgroups of the launch fit the device together (ygzf_api.hip), so nobody waits for
+    // leaves; workgroup 0 does its own share, waits for the others, adds their counts to its own and goes on alone.  gDone only ever grows (the host
+    // passes the value this launch brings it to): should the helpers not arrive within the spin budget -- every compute unit held by waiting
+    // workgroups 0 of many contexts at once -- workgroup 0 stops waiting, computes the whole level itself and ignores the slices; helpers that come
+    // late write the same keys to the same places and bump a counter nobody reads again before the next launch.  The host launches helpers only while ALL workgroups of the launch fit the device together (ygzf_api.hip), so nobody waits for
     // a workgroup that cannot start.
     const int parts = kHist && gHist ? (int) gridDim.z : 1, part = kHist ? (int) blockIdx.z : 0;
 #define OSTAMP(k) do { if (dbg && tid == 0 && f == 0 && part == 0) dbg[l * 8 + (k)] = wall_clock64(); } while (0)
@@ -1392,8 +1395,10 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
     const LevelGeom g = geom[l];
     const int nCells = g.nCols * g.nRows;
     int *lvlCnt = lvlKpCnt + f * nlevels + l;
+    int *gd = kHist && parts > 1 ? gDone + (f * nlevels + l) : nullptr;
+    auto helper_leaves = [&]() { if (tid == 0) __hip_atomic_fetch_add(gd, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); };   // (every helper, whatever way it leaves)
     if (nCells <= 0 || g.nCols <= 0) {
-        if (part != 0) return;
+        if (part != 0) { helper_leaves(); return; }
         if (tid == 0) { *lvlCnt = 0; lvlCandCnt[f * nlevels + l] = 0; }
         for (int i = tid; i < g.kpCap; i += kOctBlock) procRec[(long long) f * kpStride + g.kpBase + i] = make_uint2(0u, kNoKeypoint);
         return;
@@ -1432,9 +1437,9 @@ __global__ __launch_bounds__(kOctBlock) __attribute__((amdgpu_waves_per_eu(kHist
     bool useHist = kHist && dm >= 1;
     const int nBins = g.nIni << (2 * dm);
     const int binShift = 2 * (g.depth - dm);
-    if (part != 0 && !useHist) return;   // (no histogram for this level: workgroup 0 sorts, alone)
+    if (part != 0 && !useHist) { helper_leaves(); return; }   // (no histogram for this level: workgroup 0 sorts, alone)
+    bool alone = false;                  // workgroup 0 gave up waiting for its helpers
     int *gh = kHist && parts > 1 ? gHist + ((long long) f * nlevels + l) * (parts - 1) * histBins : nullptr;   // one slice of histBins counts per helper
-    int *gd = kHist && parts > 1 ? gDone + (f * nlevels + l) : nullptr;
 restart:   // (kHist: a second time, on the sorting path, after the tree asked for a split below depth dm)
     if (kHist && tid == 0) s_overflow = 0;
     // ---- 1. candidate offsets per cell (cell-major order == the reference's vToDistributeKeys order) ----
@@ -1444,7 +1449,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
     if (tid == 0) { S.cellPref[nCells] = M; if (part == 0) lvlCandCnt[f * nlevels + l] = M; }
     __syncthreads();
     if (M == 0) {
-        if (part != 0) return;
+        if (part != 0) { helper_leaves(); return; }
         if (tid == 0) *lvlCnt = 0;
         for (int i = tid; i < g.kpCap; i += kOctBlock) procRec[(long long) f * kpStride + g.kpBase + i] = make_uint2(0u, kNoKeypoint);
         return;
@@ -1511,7 +1516,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
         int steps = 0;
         while ((1 << steps) < nCells) steps++;
         constexpr int kKU = 4;
-        const int shares = kHist && useHist ? parts : 1;   // (the sorting path after a restart: workgroup 0 takes everything)
+        const int shares = kHist && useHist && !alone ? parts : 1;   // (the sorting path after a restart, or no helpers in sight: workgroup 0 takes everything)
         for (int i0 = tid + part * kKU * kOctBlock; i0 < M; i0 += shares * kKU * kOctBlock) {
             int ia[kKU], a[kKU], b[kKU];
 #pragma unroll
@@ -1569,7 +1574,7 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
             }
         }
     }
-    if (kHist && useHist && parts > 1) {
+    if (kHist && useHist && parts > 1 && !alone) {
         // (counts in a slice of its own per helper, plain stores: 60 000 device-scope atomics on one histogram ran at 9 per nanosecond for the whole
         // device -- every level of a 3840x2160 pair waited 95 us for them)
         __syncthreads();
@@ -1582,14 +1587,21 @@ restart:   // (kHist: a second time, on the sorting path, after the tree asked f
         // of a 3840x2160 pair wait 95 us for 6000 of them.
         __syncthreads();                       // every store of this workgroup has reached the L2 (the barrier waits for vmcnt(0)) ...
         if (part != 0) {
-            if (tid == 0) __hip_atomic_fetch_add(gd, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... and leaves it with this release
+            helper_leaves();                   // ... and leaves it with this release
             return;
         }
         if (tid == 0) {
-            while (__hip_atomic_load(gd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < parts - 1) __builtin_amdgcn_s_sleep(8);
-            __hip_atomic_store(gd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch)
+            int spins = 0;
+            bool here;
+            while (!(here = __hip_atomic_load(gd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= doneTarget) && spins < spinBudget) { __builtin_amdgcn_s_sleep(8); spins++; }
+            s_flagA = here ? 1 : 0;
         }
         __syncthreads();
+        if (!s_flagA) {                        // (uniform) nobody came: the whole level again, alone
+            alone = true;
+            __syncthreads();
+            goto restart;
+        }
         for (int b = tid; b < nBins; b += kOctBlock) {
             int v = PS[b];
             for (int q = 0; q < parts - 1; q++) v += gh[(long long) q * histBins + b];
@@ -2692,19 +2704,19 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, int leve
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
                    uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena,
-                   int regionInts, int histBins, int helpers, int *gHist, int *gDone) {
+                   int regionInts, int histBins, int helpers, int *gHist, int *gDone, int doneTarget, int spinBudget) {
     if (histBins > 0)
         hipLaunchKernelGGL((k_octree<false, true>), dim3(nLaunchLevels, nFrames, helpers > 1 && gHist ? helpers : 1), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, 0,
-                           dbg, nullptr, regionInts, histBins, helpers > 1 ? gHist : nullptr, gDone);
+                           dbg, nullptr, regionInts, histBins, helpers > 1 ? gHist : nullptr, gDone, doneTarget, spinBudget);
     else if (nodeArena)
         hipLaunchKernelGGL((k_octree<true, false>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
-                           dbg, nodeArena, 0, 0, nullptr, nullptr);
+                           dbg, nodeArena, 0, 0, nullptr, nullptr, 0, 0);
     else
         hipLaunchKernelGGL((k_octree<false, false>), dim3(nLaunchLevels, nFrames), dim3(kOctBlock), ldsBytes, st, dGeom, nlevels, level0, cellCnt, slots, totalCells,
                            totalSlots, k0, v0, k1, v1, xy, candStride, lvlKpXY, lvlKpScore, lvlKpCnt, lvlCandCnt, procRec, kpStride, cap, ldsCand,
-                           dbg, nodeArena, 0, 0, nullptr, nullptr);
+                           dbg, nodeArena, 0, 0, nullptr, nullptr, 0, 0);
 }
 
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,

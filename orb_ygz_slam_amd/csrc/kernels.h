@@ -87,7 +87,7 @@ void launch_octree(hipStream_t st, const LevelGeom *dGeom, int nlevels, int leve
                    int totalCells, long long totalSlots, unsigned *k0, unsigned *v0, unsigned *k1, unsigned *v1, unsigned *xy,
                    long long candStride, unsigned *lvlKpXY, unsigned char *lvlKpScore, int *lvlKpCnt, int *lvlCandCnt,
                    uint2 *procRec, int kpStride, int cap, int ldsCand, size_t ldsBytes, int nFrames, long long *dbg, int *nodeArena,
-                   int regionInts, int histBins, int helpers = 1, int *gHist = nullptr, int *gDone = nullptr);
+                   int regionInts, int histBins, int helpers = 1, int *gHist = nullptr, int *gDone = nullptr, int doneTarget = 0, int spinBudget = 0);
 constexpr int kOctDbgWords = 16 * 8 + 16 + 16 * 16;   // per level: six phase stamps, M, n; then per level the workgroups that left the histogram plan; then per level up to 8 (list size, time) pairs of the tree passes
 void launch_describe(hipStream_t st, const FrameSet &fs, const LevelGeom *dGeom, int nlevels, const int *lvlKpCnt, int *lvlBase,
                      const uint2 *procRec, int kpStride, ygzf_kp *outKp, uint8_t *outDesc, int *outCnt, int outStride, int nFrames, int cvMode);

@@ -711,11 +711,13 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                     void *old = c->dOctHist.p;
                     int rcH = ensure(c, c->dOctHist, bytes);
                     if (rcH) return rcH;
-                    // the counters are zeroed once per layout: workgroup 0 of every (level, frame) leaves its counter at zero behind it
-                    if (old != c->dOctHist.p || c->octHistWords != words) {
+                    // the counters only grow -- by helpers - 1 per launch -- and are zeroed once per layout
+                    if (old != c->dOctHist.p || c->octHistWords != words || c->octDoneTarget > (1 << 30)) {
                         HIPCHECK(c, hipMemsetAsync((int *) c->dOctHist.p + words, 0, (size_t) nFrames * L * sizeof(int), so));
                         c->octHistWords = words;
+                        c->octDoneTarget = 0;
                     }
+                    c->octDoneTarget += helpers - 1;
                     gHist = (int *) c->dOctHist.p;
                     gDone = gHist + words;
                 }
@@ -724,7 +726,7 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                               (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                               (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
                               (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins,
-                              helpers, gHist, gDone);
+                              helpers, gHist, gDone, c->octDoneTarget, (int) forced("oct_helper_spin", 1 << 16));
             } else if (c->octGroups.empty())
                 launch_octree(so, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,

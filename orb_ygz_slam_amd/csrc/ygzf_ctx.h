@@ -91,7 +91,8 @@ struct ygzf_ctx {
     bool haveOctSmall = false;
     bool carryOff = false;     // ygzf_set_carry_previous(0): extractions do not carry the previous batch's last frame into slot 0 ...
     bool slot0Stale = false;   // ... and slot 0 no longer holds it: the batch matchers refuse until an extraction has carried again
-    size_t octHistWords = 0;   // layout dOctHist's counters were last cleared for (k_octree's helper workgroups)
+    size_t octHistWords = 0;
+    int octDoneTarget = 0;     // what the launches so far have brought every (level, frame) counter of dOctHist to   // layout dOctHist's counters were last cleared for (k_octree's helper workgroups)
     static constexpr int octSmallWgs = 128;   // launches of up to this many workgroups take it (752x480: 16 frames 0.211 against 0.221 ms, 64 frames 0.439 against 0.430)
     Buf dOctNodes;
     // FAST threshold plan (extract_kernels.hip, fast_cell): 0 = chosen per batch from the statistics the kernel leaves behind, 1 = one pass at

@@ -88,15 +88,16 @@ def test_automatic_plan_of_the_large_configs(oracle):
 
 
 @pytest.mark.parametrize("case", [0, 1, 4, 5])
-@pytest.mark.parametrize("helpers", [2, 8])
-def test_helper_workgroups_give_the_same_tree(oracle, case, helpers):
+@pytest.mark.parametrize("helpers,spin", [(2, None), (8, None), (8, 0)])
+def test_helper_workgroups_give_the_same_tree(oracle, case, helpers, spin):
     """Launches of a few frames give every (level, frame) of the histogram plan helper workgroups for the keys of its candidates (k_octree, gridDim.z;
     chosen by the library for 1920x1080 and up): forced here on small images, one and three frames per launch, twice in a row (the hand-over
-    counters must be left at zero), including the level that overflows the histogram and restarts on the sorting path -- the oracle's tree."""
+    counters only grow by what a launch brings), including the level that overflows the histogram and restarts on the sorting path -- the oracle's tree.
+    spin = 0: workgroup 0 gives up waiting at once (what it does when its helpers cannot start) and computes the level alone beside its late helpers."""
     from orb_ygz_slam_amd import Extractor
     w, h, nl, nf, make = CASES[case]
     img = make()
-    with _env(oct_plan="hist", oct_helpers=helpers):
+    with _env(oct_plan="hist", oct_helpers=helpers, oct_helper_spin=spin):
         ex = Extractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
         oex = oracle.Extractor(nf, 1.2, nl, 20, 7)
         imgs = np.stack([img, np.ascontiguousarray(img[::-1]), img])
