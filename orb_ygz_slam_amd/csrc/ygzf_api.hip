@@ -660,9 +660,9 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
             // waves that never leave keep the other contexts' octree / matcher workgroups (71 KB of LDS each) waiting for a CU, and at that size
             // the cell loop gains less than they lose.  Hence the rule: frames of >= 1000 cell groups.
             const size_t fastLds = tab ? fast_tab_lds_bytes(G.fastWinRows, G.fastSmapRows, G.fastQuadCap) : 0;
-            const int perCu = tab ? (int) std::min<size_t>((size_t) forced("fast_persist_wgs", 8), (size_t) (160 * 1024) / std::max<size_t>(fastLds, 1)) : 0;
+            const int perCu = tab ? (int) std::min<size_t>((size_t) c->fastPersistWgs, (size_t) (160 * 1024) / std::max<size_t>(fastLds, 1)) : 0;
             const int resident = perCu * c->cuCount;
-            const int persistMode = (int) forced("fast_persist", -1);   // tests: 1 always, 0 never
+            const int persistMode = c->fastPersistMode;   // tests: 1 always, 0 never
             // (forced or not, never for a launch of fewer than 64 cell groups: the items are dealt to the eight XCDs' workgroups, and a launch of two workgroups has none on six of them)
             const bool persist = tab && resident > 0 && (long long) nFrames * G.totalGroups >= 64 &&
                                  (persistMode == 1 || (persistMode != 0 && G.totalGroups >= 1000 && (long long) nFrames * G.totalGroups >= 4LL * resident));
@@ -702,7 +702,7 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                 const auto &grp = c->octSmall;
                 // helper workgroups for the keys of a level (k_octree): as many as keep the WHOLE launch resident at one workgroup per compute unit
                 // (workgroup 0 of a level waits for its helpers), at most 8, and only where a level is worth the hand-over (a few microseconds)
-                int helpers = (int) forced("oct_helpers", -1);
+                int helpers = c->octHelpersForced;
                 if (helpers < 0) helpers = G.totalCells >= 2000 ? std::min(8, std::max(1, c->cuCount) / std::max(1, nFrames * L)) : 1;
                 helpers = std::max(1, std::min(helpers, std::min(8, std::max(1, c->cuCount / std::max(1, nFrames * L)))));
                 int *gHist = nullptr, *gDone = nullptr;
@@ -726,7 +726,7 @@ int run_extract(ygzf_ctx *c, const FrameSet &fs, int nFrames, bool pyramidReady,
                               (unsigned *) c->dV1.p, (unsigned *) c->dXY.p, G.candStride, (unsigned *) c->dLvlXY.p,
                               (unsigned char *) c->dLvlScore.p, (int *) c->dLvlCnt.p, (int *) c->dLvlCand.p,
                               (uint2 *) c->dProcOrder.p, G.kpStride, grp.cap, 0, grp.lds, nFrames, odbg, nullptr, grp.regionInts, grp.histBins,
-                              helpers, gHist, gDone, c->octDoneTarget, (int) forced("oct_helper_spin", 1 << 16));
+                              helpers, gHist, gDone, c->octDoneTarget, c->octHelperSpin);
             } else if (c->octGroups.empty())
                 launch_octree(so, dGeom, L, 0, L, (const unsigned short *) c->dCellCnt.p, (const unsigned *) c->dSlots.p,
                               G.totalCells, G.totalSlots, (unsigned *) c->dK0.p, (unsigned *) c->dV0.p, (unsigned *) c->dK1.p,
@@ -819,7 +819,7 @@ int upload_frames(ygzf_ctx *c, const uint8_t *imgs, int nFrames, int w, int h, i
         bool pageable = true;
         if (hipPointerGetAttributes(&at, imgs) == hipSuccess) pageable = at.type != hipMemoryTypeHost && at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged;
         else (void) hipGetLastError();
-        if (!pageable && at.type == hipMemoryTypeHost && at.devicePointer && (size_t) w * h <= (size_t) forced("upload_kernel_bytes", 16u << 20)) {
+        if (!pageable && at.type == hipMemoryTypeHost && at.devicePointer && (size_t) w * h <= c->uploadKernelBytes) {
             // a page-locked frame of a Tracking-sized call: a kernel reads it over the link where it lies (ygzf_extract_batch_host_frames says why)
             HostFrameList L;
             L.addr[0] = (unsigned long long) (uintptr_t) at.devicePointer;
@@ -1190,7 +1190,7 @@ int ygzf_compute_pyramid(ygzf_ctx *c, const uint8_t *img, int w, int h, int stri
     if ((rc = ensure_stage(c, total + 64)) || (rc = ensure(c, c->dTmpC, total + 64))) return rc;
     // (the page-locked staging area as the device addresses it: the packing kernel -- 16-byte stores -- writes the levels over the link itself, on the
     // stream the copy would have taken; a byte-per-thread packing kernel doing so was slower than the copy engine: ComputePyramid 94 -> 97 us)
-    const bool linkPack = c->hStageDev != nullptr && forced("fetch_kernel", 1) != 0 && forced("pyr_link", 1) != 0;
+    const bool linkPack = c->hStageDev != nullptr && c->linkKernels && c->pyrLink;
     if (!linkPack) {
         launch_pack_levels(c->stream, fs, (const LevelGeom *) c->dGeom.p, 1, L, offs, (uint8_t *) c->dTmpC.p);
         HIPCHECK(c, hipGetLastError());
@@ -1295,7 +1295,7 @@ int ygzf_extract_batch_host_frames(ygzf_ctx *c, const uint8_t *const *frames, in
         // frames, S = slots x u frames) go up as ONE two-dimensional copy whose "rows" are the runs; anything else as one linear copy per frame.
         // ONE page-locked frame (a Tracking-sized call): a kernel reads it over the link where it lies.  The copy engine starts ~10 us after the copy
         // is queued and hands over to the first kernel ~8 us after it ends; a kernel's launch and hand-over are a third of that.
-        if (n_frames <= (int) forced("upload_kernel_frames", 2) && (size_t) n_frames * w * h <= (size_t) forced("upload_kernel_bytes", 16u << 20)) {
+        if (n_frames <= c->uploadKernelFrames && (size_t) n_frames * w * h <= c->uploadKernelBytes) {
             HostFrameList L;
             bool mapped = true;
             for (int f = 0; f < n_frames && mapped; f++) {
@@ -1409,7 +1409,7 @@ int queue_packed_fetch(ygzf_ctx *c, void *host, size_t host_bytes, size_t *off_k
     if (total >= (1ull << 32)) return fail(c, YGZF_ERR_UNSUPPORTED, "packed results of %zu bytes: use ygzf_batch_fetch_all", total);
     // page-locked memory the device can address: the gather kernel writes the block over the link itself (no copy-engine start-up / hand-over)
     void *direct = nullptr;
-    if (forced("fetch_kernel", 1)) {
+    if (c->linkKernels) {
         hipPointerAttribute_t at;
         memset(&at, 0, sizeof at);
         if (hipPointerGetAttributes(&at, host) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer && ((uintptr_t) at.devicePointer & 3) == 0) direct = at.devicePointer;
@@ -1489,7 +1489,7 @@ static int fetch_frame0_packed(ygzf_ctx *c, ygzf_kp *kps, uint8_t *desc, int cap
     const size_t oK = 256, oD = oK + ((ks * sizeof(ygzf_kp) + 255) & ~(size_t) 255), total = oD + ks * 32;
     int rc = ensure_stage(c, total + 256);
     if (rc) return rc;
-    if (c->hStageDev && forced("fetch_kernel", 1)) {
+    if (c->hStageDev && c->linkKernels) {
         // count, keypoint row and descriptor row written into the page-locked staging area by a kernel, over the link: three copies by the copy engine
         // start ~10 us after they are queued and the last one hands back ~8 us after it ends -- a launch does neither
         launch_pack_results(c->stream, (const int *) c->dOutCnt.p + 1, (const ygzf_kp *) c->dOutKp.p + ks, (const uint8_t *) c->dOutDesc.p + ks * 32, 1, (int) ks, c->hStageDev, oK, oD);

@@ -150,6 +150,12 @@ struct ygzf_ctx {
     // phase clocks of the octree, matcher and aligner kernels printed to stderr
     bool debugSync = debug_flag("sync");
     // the plans below are the library's own choice unless YGZF_FORCE pins them (tests: every plan against the oracle; ygzf_internal.h)
+    // (per-call switches, read once when the context is created like the ones below)
+    bool linkKernels = forced("fetch_kernel", 1) != 0, pyrLink = forced("pyr_link", 1) != 0;
+    int uploadKernelFrames = (int) forced("upload_kernel_frames", 2);
+    size_t uploadKernelBytes = (size_t) forced("upload_kernel_bytes", 16l << 20);
+    int octHelpersForced = (int) forced("oct_helpers", -1), octHelperSpin = (int) forced("oct_helper_spin", 1 << 16);
+    int fastPersistMode = (int) forced("fast_persist", -1), fastPersistWgs = (int) forced("fast_persist_wgs", 8);
     int matchSplit = (int) forced("match_split", 0);   // 0 automatic, 1 off, n workgroups per pair
     int matchFixedLanes = forced_is("match_lanes", "fixed");   // eight lanes per query whatever the launch
     int matchFence = (int) forced("match_fence", 0);   // 1: full fences around the matcher's hand-over
@@ -237,7 +243,7 @@ struct PackedTransfer {
     // one by one from / to the caller's own memory -- same device layout, so the kernels' pointers do not care which way the bytes came.
     bool direct() const { return inBytes + outBytes > kPackedMax; }
     // the packed blocks cross the link by a kernel (the staging area as the device addresses it) unless YGZF_FORCE=fetch_kernel=0
-    bool link_kernel() const { return c->hStageDev != nullptr && forced("fetch_kernel", 1) != 0; }
+    bool link_kernel() const { return c->hStageDev != nullptr && c->linkKernels; }
     int upload(uint8_t **dBase) {
         int rc;
         if ((rc = ensure(c, c->dPack, inBytes + outBytes + 256))) return rc;
